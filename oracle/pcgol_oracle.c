@@ -1,0 +1,790 @@
+/*
+ * pcgol_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C, single-threaded restatement of the seqsense/pcgol hot path
+ * (KD-tree nearest/range, VoxelGrid filter, point-to-point ICP gradient).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported CPU baseline.  The
+ * product (pcgol_amd/csrc, libpcgx.so) never links or calls it.
+ *
+ * Parity pinning: the reference is Go and there is no Go toolchain in the
+ * build container, so the reference itself cannot run here.  This oracle is
+ * pinned by the reference's own known-answer tables, transcribed as data in
+ * tests/golden/ref_*.json and checked by tests/test_oracle_golden.py:
+ *   pc/storage/kdtree/kdtree_test.go:35-53,62-117,124-279,281-386,955-968
+ *   pc/filter/voxelgrid/voxelgrid_test.go:18-107
+ *   pc/minmax_test.go:20-44
+ *   pc/registration/icp/{correspondence,evaluator,icp,rodrigues}_test.go
+ *   mat/mat4_test.go:120-154, mat/transform_test.go
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).
+ * All arithmetic is float32, evaluated left to right, no FMA, float64 only
+ * where the Go code converts (math.Sqrt/Sin/Cos) -- Go/amd64 semantics.
+ *
+ * Every function cites the reference file:line it follows (paths relative
+ * to the reference repository root).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_E_NO_POINT 1          /* pc/minmax.go:10-12 "no point" */
+#define ORC_E_NOT_ENOUGH_PAIRS 2  /* icp/evaluator.go:16 */
+#define ORC_E_PANIC 3             /* the Go code would panic (index out of range) */
+#define ORC_E_OOM 4
+
+/* ------------------------------------------------------------------ mat */
+
+/* mat/vec3.go:18-20 NormSq: v0*v0 + v1*v1 + v2*v2, left to right */
+static inline float normsq3(float a, float b, float c) {
+  float s = a * a;
+  s = s + b * b;
+  s = s + c * c;
+  return s;
+}
+
+/* mat/vec3.go:38-40 Sub then :18-20 NormSq  ==  (a - b).NormSq() */
+static inline float dist_sq(const float *a, const float *b) {
+  float d0 = a[0] - b[0], d1 = a[1] - b[1], d2 = a[2] - b[2];
+  return normsq3(d0, d1, d2);
+}
+
+/* mat/mat4.go:16-28 Mat4.Mul: out[4j+i] = sum_k m[4k+i]*a[4j+k], sum from 0 */
+void orc_mat4_mul(const float *m, const float *a, float *out) {
+  float tmp[16];
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      float sum = 0.0f;
+      for (int k = 0; k < 4; k++) sum += m[4 * k + i] * a[4 * j + k];
+      tmp[4 * j + i] = sum;
+    }
+  memcpy(out, tmp, sizeof tmp);
+}
+
+/* mat/mat4.go:30-36 Factor */
+static void mat4_factor(const float *m, float f, float *out) {
+  for (int i = 0; i < 16; i++) out[i] = m[i] * f;
+}
+
+/* mat/mat4.go:38-44 Add */
+static void mat4_add(const float *m, const float *a, float *out) {
+  for (int i = 0; i < 16; i++) out[i] = m[i] + a[i];
+}
+
+/* mat/mat4.go:130-137 Mat4.Transform (projective) */
+void orc_mat4_transform(const float *m, const float *a, float *out) {
+  float w = 1.0f / (m[3] * a[0] + m[7] * a[1] + m[11] * a[2] + m[15]);
+  float x = (m[0] * a[0] + m[4] * a[1] + m[8] * a[2] + m[12]) * w;
+  float y = (m[1] * a[0] + m[5] * a[1] + m[9] * a[2] + m[13]) * w;
+  float z = (m[2] * a[0] + m[6] * a[1] + m[10] * a[2] + m[14]) * w;
+  out[0] = x; out[1] = y; out[2] = z;
+}
+
+/* mat/transform.go:7-14 Translate */
+void orc_translate(float x, float y, float z, float *out) {
+  static const float I[16] = {1,0,0,0, 0,1,0,0, 0,0,1,0, 0,0,0,1};
+  memcpy(out, I, sizeof I);
+  out[12] = x; out[13] = y; out[14] = z;
+}
+
+/* mat/transform.go:25-35 Rotate */
+void orc_rotate(float x, float y, float z, float ang, float *out) {
+  float s = (float)sin((double)ang);
+  float c = (float)cos((double)ang);
+  float r[16] = {
+      c + x * x * (1 - c), x * y * (1 - c) + z * s, x * z * (1 - c) - y * s, 0,
+      y * x * (1 - c) - z * s, c + y * y * (1 - c), y * z * (1 - c) + x * s, 0,
+      z * x * (1 - c) + y * s, z * y * (1 - c) - x * s, c + z * z * (1 - c), 0,
+      0, 0, 0, 1};
+  memcpy(out, r, sizeof r);
+}
+
+/* ------------------------------------------------------------ accessor */
+
+/* pc/pointcloud.go:64-70,130-163 + pc/iterator.go:132-137: point i of an AoS
+ * cloud = three consecutive little-endian float32 at data + i*stride + off. */
+static inline void vec3_at(const uint8_t *data, int64_t stride, int64_t off,
+                           int64_t i, float *out) {
+  memcpy(out, data + i * stride + off, 12);
+}
+
+/* pc/minmax.go:9-26 MinMaxVec3 */
+int orc_minmax(const void *data, int64_t n, int32_t stride, int32_t off,
+               float *vmin, float *vmax) {
+  if (n == 0) return ORC_E_NO_POINT;
+  float mn[3], mx[3], v[3];
+  vec3_at(data, stride, off, 0, mn);
+  vec3_at(data, stride, off, 0, mx);
+  for (int64_t i = 1; i < n; i++) {
+    vec3_at(data, stride, off, i, v);
+    for (int k = 0; k < 3; k++) {
+      if (v[k] < mn[k]) mn[k] = v[k];
+      if (v[k] > mx[k]) mx[k] = v[k];
+    }
+  }
+  memcpy(vmin, mn, 12);
+  memcpy(vmax, mx, 12);
+  return ORC_OK;
+}
+
+/* -------------------------------------------------------------- kdtree */
+
+/* pc/storage/kdtree/kdtree.go:25-29 */
+typedef struct onode {
+  struct onode *children[2];
+  int64_t id;
+  int32_t dim;
+} onode;
+
+/* pc/storage/kdtree/kdtree.go:14-23 */
+typedef struct {
+  float *pts; /* own copy, xyz packed (stride 12) */
+  int64_t n;
+  onode *root;
+  onode *pool;
+  int64_t pool_used;
+  int32_t max_depth;
+  /* statistics of the last query (V(q)) */
+  int64_t stat_visits; /* nodes pushed on a traversal stack */
+  int64_t stat_dists;  /* full squared-distance evaluations */
+} okdtree;
+
+/* kdtree.go:397-413 indiceSorter: Less = strict < on coordinate `dim`.
+ * Go's sort.Sort is unstable; ties on the split axis are not pinned by any
+ * reference test.  The oracle DEFINES the canonical order: stable by
+ * (coordinate, current position in the sub-slice) -- a bottom-up merge sort. */
+static void stable_sort_ids(const float *pts, int64_t *ids, int64_t *tmp,
+                            int64_t n, int dim) {
+  if (n < 2) return;
+  /* insertion sort for short runs, then merges */
+  const int64_t RUN = 16;
+  for (int64_t s = 0; s < n; s += RUN) {
+    int64_t e = s + RUN < n ? s + RUN : n;
+    for (int64_t i = s + 1; i < e; i++) {
+      int64_t v = ids[i];
+      float kv = pts[3 * v + dim];
+      int64_t j = i;
+      while (j > s && kv < pts[3 * ids[j - 1] + dim]) {
+        ids[j] = ids[j - 1];
+        j--;
+      }
+      ids[j] = v;
+    }
+  }
+  int64_t *src = ids, *dst = tmp;
+  for (int64_t w = RUN; w < n; w *= 2) {
+    for (int64_t s = 0; s < n; s += 2 * w) {
+      int64_t m = s + w < n ? s + w : n;
+      int64_t e = s + 2 * w < n ? s + 2 * w : n;
+      int64_t a = s, b = m, o = s;
+      while (a < m && b < e) {
+        /* take right only if strictly less => stable */
+        if (pts[3 * src[b] + dim] < pts[3 * src[a] + dim]) dst[o++] = src[b++];
+        else dst[o++] = src[a++];
+      }
+      while (a < m) dst[o++] = src[a++];
+      while (b < e) dst[o++] = src[b++];
+    }
+    int64_t *t = src; src = dst; dst = t;
+  }
+  if (src != ids) memcpy(ids, src, (size_t)n * sizeof(int64_t));
+}
+
+/* kdtree.go:348-370 newNode */
+static onode *new_node(okdtree *t, int64_t *ids, int64_t *tmp, int64_t n,
+                       int depth) {
+  int dim = depth % 3;
+  stable_sort_ids(t->pts, ids, tmp, n, dim);
+  int64_t mid = n / 2;
+  onode *nd = &t->pool[t->pool_used++];
+  nd->id = ids[mid];
+  nd->dim = dim;
+  nd->children[0] = nd->children[1] = NULL;
+  if (mid > 0) nd->children[0] = new_node(t, ids, tmp, mid, depth + 1);
+  if (mid + 1 < n)
+    nd->children[1] = new_node(t, ids + mid + 1, tmp + mid + 1, n - mid - 1, depth + 1);
+  return nd;
+}
+
+/* kdtree.go:385-395 maxDepth */
+static int node_max_depth(const onode *n, int depth) {
+  if (!n) return depth;
+  int d0 = node_max_depth(n->children[0], depth + 1);
+  int d1 = node_max_depth(n->children[1], depth + 1);
+  return d0 > d1 ? d0 : d1;
+}
+
+/* kdtree.go:33-56 New.  (Go panics on an empty cloud, kdtree.go:355-356;
+ * the oracle returns NULL for n == 0.) */
+okdtree *orc_kdtree_new(const void *data, int64_t n, int32_t stride, int32_t off) {
+  if (n <= 0) return NULL;
+  okdtree *t = calloc(1, sizeof *t);
+  if (!t) return NULL;
+  t->n = n;
+  t->pts = malloc((size_t)n * 12);
+  t->pool = malloc((size_t)n * sizeof(onode));
+  int64_t *ids = malloc((size_t)n * sizeof(int64_t));
+  int64_t *tmp = malloc((size_t)n * sizeof(int64_t));
+  if (!t->pts || !t->pool || !ids || !tmp) return NULL;
+  for (int64_t i = 0; i < n; i++) {
+    vec3_at(data, stride, off, i, t->pts + 3 * i);
+    ids[i] = i;
+  }
+  t->root = new_node(t, ids, tmp, n, 0);
+  t->max_depth = node_max_depth(t->root, 0);
+  free(ids);
+  free(tmp);
+  return t;
+}
+
+void orc_kdtree_free(okdtree *t) {
+  if (!t) return;
+  free(t->pts);
+  free(t->pool);
+  free(t);
+}
+
+int32_t orc_kdtree_max_depth(const okdtree *t) { return t->max_depth; }
+int64_t orc_kdtree_len(const okdtree *t) { return t->n; }
+
+/* Pre-order dump of the tree: for node k: id, dim, index of child0/child1 in
+ * the dump (-1 = nil).  Used to compare tree shape with the reference's
+ * expected tree (kdtree_test.go:128-155) and with the product's implicit tree. */
+static int64_t dump_rec(const onode *n, int64_t *out, int64_t *k) {
+  if (!n) return -1;
+  int64_t me = (*k)++;
+  out[4 * me + 0] = n->id;
+  out[4 * me + 1] = n->dim;
+  out[4 * me + 2] = dump_rec(n->children[0], out, k);
+  out[4 * me + 3] = dump_rec(n->children[1], out, k);
+  return me;
+}
+int64_t orc_kdtree_dump(const okdtree *t, int64_t *out4) {
+  int64_t k = 0;
+  dump_rec(t->root, out4, &k);
+  return k;
+}
+
+/* In-order list of point ids (child0, node, child1) = the final state of the
+ * reference's `ids` slice after the recursive in-place sorts (kdtree.go:354-364). */
+static void inorder_rec(const onode *n, int64_t *out, int64_t *k) {
+  if (!n) return;
+  inorder_rec(n->children[0], out, k);
+  out[(*k)++] = n->id;
+  inorder_rec(n->children[1], out, k);
+}
+void orc_kdtree_inorder(const okdtree *t, int64_t *out) {
+  int64_t k = 0;
+  inorder_rec(t->root, out, &k);
+}
+
+/* kdtree.go:67-70 nodeStack (explicit array; the sync.Pool is irrelevant) */
+typedef struct {
+  okdtree *t;
+  const onode **nn;
+  int len;
+  float min_dist_sq;
+} ostack;
+
+/* kdtree.go:199-222 searchLeafNode */
+static void search_leaf_node(ostack *ns, const float *p) {
+  for (;;) {
+    const onode *parent = ns->nn[ns->len - 1];
+    const onode *c0 = parent->children[0], *c1 = parent->children[1];
+    if (!c0 && !c1) return;
+    if (!c0) { ns->nn[ns->len++] = c1; ns->t->stat_visits++; continue; }
+    if (!c1) { ns->nn[ns->len++] = c0; ns->t->stat_visits++; continue; }
+    float pivot_val = ns->t->pts[3 * parent->id + parent->dim];
+    float val = p[parent->dim];
+    if (pivot_val > val) ns->nn[ns->len++] = c0;
+    else ns->nn[ns->len++] = c1;
+    ns->t->stat_visits++;
+  }
+}
+
+typedef struct { int64_t id; float dist_sq; } oneighbor; /* storage/search.go:8-11 */
+
+/* kdtree.go:94-146 nearestImpl */
+static oneighbor nearest_impl(ostack *ns, const float *p, float max_range_sq) {
+  okdtree *t = ns->t;
+  int i = ns->len - 1;
+  oneighbor n1;
+  n1.id = ns->nn[i]->id;
+  n1.dist_sq = dist_sq(t->pts + 3 * ns->nn[i]->id, p);
+  t->stat_dists++;
+  if (n1.dist_sq > max_range_sq) {
+    n1.id = -1;
+    n1.dist_sq = max_range_sq;
+  }
+  if (n1.dist_sq < ns->min_dist_sq) return n1;
+  for (int j = i - 1; j >= 0; j--) {
+    const onode *nj = ns->nn[j];
+    const float *pivot = t->pts + 3 * nj->id;
+    float from_pivot = p[nj->dim] - pivot[nj->dim];
+    float from_pivot_sq = from_pivot * from_pivot;
+    if (from_pivot_sq > n1.dist_sq) continue;
+    float dsq_pivot = dist_sq(pivot, p);
+    t->stat_dists++;
+    if (dsq_pivot < n1.dist_sq) {
+      n1.id = nj->id;
+      n1.dist_sq = dsq_pivot;
+      if (n1.dist_sq < ns->min_dist_sq) break;
+    }
+    const onode *next;
+    if (nj->children[0] == ns->nn[j + 1]) next = nj->children[1];
+    else next = nj->children[0];
+    if (!next) continue;
+
+    const onode *buf[64];
+    ostack sub = {t, buf, 0, ns->min_dist_sq};
+    sub.nn[sub.len++] = next;
+    t->stat_visits++;
+    search_leaf_node(&sub, p);
+    oneighbor n2 = nearest_impl(&sub, p, n1.dist_sq);
+    if (n2.id >= 0) {
+      n1 = n2;
+      if (n1.dist_sq < ns->min_dist_sq) break;
+    }
+  }
+  return n1;
+}
+
+/* kdtree.go:83-92 Nearest.  root==nil cannot occur here (no DeletePoint). */
+void orc_kdtree_nearest(okdtree *t, const float *p, float max_range,
+                        float min_dist_sq, int64_t *id, float *dsq) {
+  const onode *buf[64];
+  ostack ns = {t, buf, 0, min_dist_sq};
+  t->stat_visits = 1;
+  t->stat_dists = 0;
+  ns.nn[ns.len++] = t->root;
+  search_leaf_node(&ns, p);
+  oneighbor r = nearest_impl(&ns, p, max_range * max_range);
+  *id = r.id;
+  *dsq = r.dist_sq;
+}
+
+/* Batched convenience over orc_kdtree_nearest (same per-query semantics);
+ * accumulates V(q) and distance-evaluation totals for SURVEY 8(d). */
+void orc_kdtree_nearest_batch(okdtree *t, const float *q, int64_t nq,
+                              float max_range, float min_dist_sq, int64_t *ids,
+                              float *dsq, int64_t *total_visits,
+                              int64_t *total_dists) {
+  int64_t tv = 0, td = 0;
+  for (int64_t i = 0; i < nq; i++) {
+    orc_kdtree_nearest(t, q + 3 * i, max_range, min_dist_sq, &ids[i], &dsq[i]);
+    tv += t->stat_visits;
+    td += t->stat_dists;
+  }
+  if (total_visits) *total_visits = tv;
+  if (total_dists) *total_dists = td;
+}
+
+/* Leaf reached by searchLeafNode from the root (kdtree_test.go:250-279). */
+int64_t orc_kdtree_search_leaf(okdtree *t, const float *p) {
+  const onode *buf[64];
+  ostack ns = {t, buf, 0, 0.0f};
+  ns.nn[ns.len++] = t->root;
+  search_leaf_node(&ns, p);
+  return ns.nn[ns.len - 1]->id;
+}
+
+/* Brute force, the reference's own test oracle: kdtree_test.go:955-968
+ * naiveSearch.Nearest (strict <, lowest index among minima). */
+void orc_naive_nearest(const float *pts, int64_t n, const float *p,
+                       float max_range, int64_t *id, float *dsq_out) {
+  float dsq = max_range * max_range;
+  int64_t best = -1;
+  for (int64_t i = 0; i < n; i++) {
+    float d1 = dist_sq(pts + 3 * i, p);
+    if (d1 < dsq) { best = i; dsq = d1; }
+  }
+  *id = best;
+  *dsq_out = dsq;
+}
+
+/* kdtree.go:163-197 rangeImpl */
+typedef struct { oneighbor *v; int64_t n, cap; } onlist;
+static void nl_push(onlist *l, int64_t id, float d) {
+  if (l->n == l->cap) {
+    l->cap = l->cap ? 2 * l->cap : 16;
+    l->v = realloc(l->v, (size_t)l->cap * sizeof(oneighbor));
+  }
+  l->v[l->n].id = id;
+  l->v[l->n].dist_sq = d;
+  l->n++;
+}
+static void range_impl(ostack *ns, const float *p, float max_range_sq, onlist *out) {
+  okdtree *t = ns->t;
+  int i = ns->len - 1;
+  int64_t id = ns->nn[i]->id;
+  float dsq = dist_sq(t->pts + 3 * id, p);
+  if (dsq < max_range_sq) nl_push(out, id, dsq);
+  for (int j = i - 1; j >= 0; j--) {
+    const onode *nj = ns->nn[j];
+    const float *pivot = t->pts + 3 * nj->id;
+    float from_pivot = p[nj->dim] - pivot[nj->dim];
+    float from_pivot_sq = from_pivot * from_pivot;
+    if (from_pivot_sq > max_range_sq) continue;
+    float dsq_pivot = dist_sq(pivot, p);
+    if (dsq_pivot < max_range_sq) nl_push(out, nj->id, dsq_pivot);
+    const onode *next;
+    if (nj->children[0] == ns->nn[j + 1]) next = nj->children[1];
+    else next = nj->children[0];
+    if (!next) continue;
+    const onode *buf[64];
+    ostack sub = {t, buf, 0, ns->min_dist_sq};
+    sub.nn[sub.len++] = next;
+    search_leaf_node(&sub, p);
+    range_impl(&sub, p, max_range_sq, out);
+  }
+}
+
+/* kdtree.go:148-161 Range + :415-427 neighborSorter (sort by DistSq; Go's
+ * sort is unstable, the oracle orders equal DistSq by discovery order). */
+int64_t orc_kdtree_range(okdtree *t, const float *p, float max_range,
+                         int64_t *ids, float *dsq, int64_t cap) {
+  onlist l = {0, 0, 0};
+  const onode *buf[64];
+  ostack ns = {t, buf, 0, 0.0f};
+  ns.nn[ns.len++] = t->root;
+  search_leaf_node(&ns, p);
+  range_impl(&ns, p, max_range * max_range, &l);
+  /* stable insertion sort by DistSq */
+  for (int64_t i = 1; i < l.n; i++) {
+    oneighbor v = l.v[i];
+    int64_t j = i;
+    while (j > 0 && v.dist_sq < l.v[j - 1].dist_sq) { l.v[j] = l.v[j - 1]; j--; }
+    l.v[j] = v;
+  }
+  int64_t m = l.n < cap ? l.n : cap;
+  for (int64_t i = 0; i < m; i++) { ids[i] = l.v[i].id; dsq[i] = l.v[i].dist_sq; }
+  int64_t total = l.n;
+  free(l.v);
+  return total;
+}
+
+/* ---------------------------------------------------------- voxel filter */
+
+/* pc/filter/voxelgrid/voxelgrid.go:17-21 */
+typedef struct { float sum[3]; int64_t num; int64_t index; } ovoxel;
+
+typedef struct { ovoxel *v; int64_t len; } ovoxels; /* f.voxels, :14 */
+
+/* voxelgrid.go:136-187 filterChunk.  `idx` (may be NULL) is the chunk's
+ * indice list (pc/indice.go:12-22: Vec3At(j) = ra.Vec3At(indice[j]),
+ * RawIndexAt(j) = indice[j]).  Appends records to out at *out_n. */
+static int filter_chunk(ovoxels *f, const float *vmin, const float *size,
+                        const float *leaf, const uint8_t *data, int64_t n,
+                        int32_t stride, int32_t off, const int64_t *idx,
+                        uint8_t *out, int64_t *out_n) {
+  int64_t xs = (int64_t)(size[0] / leaf[0]);
+  int64_t ys = (int64_t)(size[1] / leaf[1]);
+  int64_t zs = (int64_t)(size[2] / leaf[2]);
+  int64_t n_voxels = (xs + 1) * (ys + 1) * (zs + 1);
+  if (n_voxels < 0) return ORC_E_PANIC; /* make([]voxel, negative) panics */
+  if (f->len < n_voxels) {
+    free(f->v);
+    f->v = calloc((size_t)(n_voxels ? n_voxels : 1), sizeof(ovoxel));
+    if (!f->v) return ORC_E_OOM;
+    f->len = n_voxels;
+  } else {
+    memset(f->v, 0, (size_t)f->len * sizeof(ovoxel));
+  }
+  for (int64_t j = 0; j < n; j++) {
+    int64_t raw = idx ? idx[j] : j;
+    float pt[3], p[3];
+    vec3_at(data, stride, off, raw, pt);
+    p[0] = pt[0] - vmin[0]; p[1] = pt[1] - vmin[1]; p[2] = pt[2] - vmin[2];
+    int64_t x = (int64_t)(p[0] / leaf[0]);
+    int64_t y = (int64_t)(p[1] / leaf[1]);
+    int64_t z = (int64_t)(p[2] / leaf[2]);
+    int64_t a = x + xs * (y + ys * z);
+    if (a < 0 || a >= f->len) return ORC_E_PANIC; /* index out of range */
+    ovoxel *v = &f->v[a];
+    if (v->num == 0) v->index = raw;
+    v->num++;
+    v->sum[0] = v->sum[0] + p[0];
+    v->sum[1] = v->sum[1] + p[1];
+    v->sum[2] = v->sum[2] + p[2];
+  }
+  for (int64_t i = 0; i < f->len; i++) {
+    ovoxel *v = &f->v[i];
+    if (v->num > 0) {
+      uint8_t *dst = out + (*out_n) * stride;
+      memcpy(dst, data + v->index * stride, (size_t)stride);
+      if (v->num > 1) {
+        float inv = 1.0f / (float)v->num;
+        float c[3];
+        c[0] = v->sum[0] * inv + vmin[0];
+        c[1] = v->sum[1] * inv + vmin[1];
+        c[2] = v->sum[2] * inv + vmin[2];
+        memcpy(dst + off, c, 12);
+      }
+      (*out_n)++;
+    }
+  }
+  return ORC_OK;
+}
+
+/* voxelgrid.go:35-134 Filter.  out must hold n*stride bytes. */
+int orc_voxel_filter(const void *data_, int64_t n, int32_t stride, int32_t off,
+                     const float *leaf, const int32_t *chunk, void *out_,
+                     int64_t *out_n) {
+  const uint8_t *data = data_;
+  uint8_t *out = out_;
+  float vmin[3], vmax[3];
+  *out_n = 0;
+  int rc = orc_minmax(data, n, stride, off, vmin, vmax);
+  if (rc) return rc;
+  ovoxels f = {0, 0};
+  if ((int64_t)chunk[0] * chunk[1] * chunk[2] == 0) {
+    /* :45-47 -- sic: vMax is passed as the size */
+    rc = filter_chunk(&f, vmin, vmax, leaf, data, n, stride, off, NULL, out, out_n);
+    free(f.v);
+    return rc;
+  }
+  float size[3], cs[3];
+  for (int k = 0; k < 3; k++) {
+    size[k] = vmax[k] - vmin[k];
+    cs[k] = leaf[k] * (float)chunk[k];
+  }
+  for (int k = 0; k < 3; k++)
+    if (cs[k] > size[k] + leaf[k]) cs[k] = size[k] + leaf[k];
+  int64_t nx = (int64_t)(size[0] / cs[0]) + 1;
+  int64_t ny = (int64_t)(size[1] / cs[1]) + 1;
+  int64_t nz = (int64_t)(size[2] / cs[2]) + 1;
+  int64_t n_chunks = nx * ny * nz;
+  if (n_chunks <= 0) return ORC_E_PANIC;
+  int64_t *cnt = calloc((size_t)n_chunks + 1, sizeof(int64_t));
+  int64_t *cid_of = malloc((size_t)n * sizeof(int64_t));
+  int64_t *bucket = malloc((size_t)n * sizeof(int64_t));
+  if (!cnt || !cid_of || !bucket) return ORC_E_OOM;
+  /* :87-99 count then bucket, original order preserved inside a chunk */
+  for (int64_t i = 0; i < n; i++) {
+    float pt[3];
+    vec3_at(data, stride, off, i, pt);
+    float p0 = pt[0] - vmin[0], p1 = pt[1] - vmin[1], p2 = pt[2] - vmin[2];
+    int64_t x = (int64_t)(p0 / cs[0]), y = (int64_t)(p1 / cs[1]), z = (int64_t)(p2 / cs[2]);
+    int64_t cid = ((z * ny) + y) * nx + x;
+    if (cid < 0 || cid >= n_chunks) { rc = ORC_E_PANIC; goto done; }
+    cid_of[i] = cid;
+    cnt[cid + 1]++;
+  }
+  for (int64_t c = 0; c < n_chunks; c++) cnt[c + 1] += cnt[c];
+  {
+    int64_t *cur = malloc((size_t)n_chunks * sizeof(int64_t));
+    if (!cur) { rc = ORC_E_OOM; goto done; }
+    memcpy(cur, cnt, (size_t)n_chunks * sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++) bucket[cur[cid_of[i]]++] = i;
+    free(cur);
+  }
+  /* :102-116 per non-empty chunk in cid order */
+  for (int64_t cid = 0; cid < n_chunks; cid++) {
+    int64_t m = cnt[cid + 1] - cnt[cid];
+    if (m == 0) continue;
+    int64_t c = cid;
+    int64_t x = c % nx; c = c / nx;
+    int64_t y = c % ny;
+    int64_t z = c / ny;
+    float cp[3] = {(float)x, (float)y, (float)z};
+    float vcmin[3];
+    for (int k = 0; k < 3; k++) vcmin[k] = vmin[k] + cp[k] * cs[k];
+    rc = filter_chunk(&f, vcmin, cs, leaf, data, m, stride, off, bucket + cnt[cid], out, out_n);
+    if (rc) goto done;
+  }
+done:
+  free(f.v);
+  free(cnt);
+  free(cid_of);
+  free(bucket);
+  return rc;
+}
+
+/* ------------------------------------------------------------------- icp */
+
+/* icp/correspondence.go:22-37 NearestPointCorresponder.Pairs */
+int64_t orc_icp_pairs(okdtree *t, const float *target, int64_t nt, float max_dist,
+                      float min_dist_sq, int64_t *base_id, int64_t *target_id,
+                      float *dsq) {
+  int64_t np = 0;
+  for (int64_t i = 0; i < nt; i++) {
+    int64_t id; float d;
+    orc_kdtree_nearest(t, target + 3 * i, max_dist, min_dist_sq, &id, &d);
+    if (id < 0) continue;
+    base_id[np] = id; target_id[np] = i; dsq[np] = d;
+    np++;
+  }
+  return np;
+}
+
+/* icp/evaluator.go:25-30 Evaluated (Hessian is never written, :28) */
+typedef struct {
+  float value;
+  float gradient[6];
+  float dist_rms;
+} oevaluated;
+
+/* evaluator.go:91-189 Evaluate with the default weight (w == 1, :21-23).
+ * sums_mode 0: sequential float32 (the Go semantics);
+ * sums_mode 1: float64 accumulation of the same float32 terms (information
+ *              only: quantifies the reference's own rounding noise).
+ * raw10 (optional): the 9 sums + pair count before normalisation. */
+int orc_icp_evaluate(okdtree *t, const float *target, int64_t nt, float max_dist,
+                     float min_dist_sq, int32_t min_pairs, int32_t sums_mode,
+                     float *out_value, float *out_grad6, float *out_dist_rms,
+                     int64_t *out_npairs, double *raw10) {
+  if (min_pairs == 0) min_pairs = 6;
+  int64_t *bid = malloc((size_t)(nt ? nt : 1) * sizeof(int64_t));
+  int64_t *tid = malloc((size_t)(nt ? nt : 1) * sizeof(int64_t));
+  float *dsq = malloc((size_t)(nt ? nt : 1) * sizeof(float));
+  if (!bid || !tid || !dsq) return ORC_E_OOM;
+  int64_t np = orc_icp_pairs(t, target, nt, max_dist, min_dist_sq, bid, tid, dsq);
+  if (out_npairs) *out_npairs = np;
+  if (np < min_pairs) { free(bid); free(tid); free(dsq); return ORC_E_NOT_ENOUGH_PAIRS; }
+
+  float value = 0, sum_weight = 0, g[6] = {0, 0, 0, 0, 0, 0}, dist_rms = 0;
+  double dv = 0, dw = 0, dg[6] = {0, 0, 0, 0, 0, 0}, dr = 0;
+  for (int64_t i = 0; i < np; i++) {
+    const float *pb = t->pts + 3 * bid[i];
+    const float *pt = target + 3 * tid[i];
+    float w = 1.0f;
+    float x0 = pt[0], y0 = pt[1], z0 = pt[2];
+    float x1 = pb[0], y1 = pb[1], z1 = pb[2];
+    float tv = w * dsq[i];
+    float t0 = w * (x0 - x1), t1 = w * (y0 - y1), t2 = w * (z0 - z1);
+    float t3 = w * (z0 * y1 - y0 * z1);
+    float t4 = w * (x0 * z1 - z0 * x1);
+    float t5 = w * (y0 * x1 - x0 * y1);
+    float tr = w * normsq3(x0, y0, z0);
+    if (sums_mode == 0) {
+      value += tv; sum_weight += w;
+      g[0] += t0; g[1] += t1; g[2] += t2; g[3] += t3; g[4] += t4; g[5] += t5;
+      dist_rms += tr;
+    } else {
+      dv += tv; dw += w;
+      dg[0] += t0; dg[1] += t1; dg[2] += t2; dg[3] += t3; dg[4] += t4; dg[5] += t5;
+      dr += tr;
+    }
+  }
+  if (sums_mode != 0) {
+    value = (float)dv; sum_weight = (float)dw; dist_rms = (float)dr;
+    for (int k = 0; k < 6; k++) g[k] = (float)dg[k];
+  }
+  if (raw10) {
+    raw10[0] = sums_mode ? dv : value;
+    for (int k = 0; k < 6; k++) raw10[1 + k] = sums_mode ? dg[k] : g[k];
+    raw10[7] = sums_mode ? dr : dist_rms;
+    raw10[8] = sums_mode ? dw : sum_weight;
+    raw10[9] = (double)np;
+  }
+  free(bid); free(tid); free(dsq);
+
+  /* :156-164 */
+  float f = 1.0f;
+  if (sum_weight > 1) f = 1 / sum_weight;
+  value *= f;
+  for (int k = 0; k < 6; k++) g[k] *= 2 * f;
+  dist_rms = (float)sqrt((double)(dist_rms * f));
+  /* :170-186 rotation limiter */
+  float rot_limit = 1.0f;
+  float dist = (float)sqrt((double)value);
+  for (int k = 3; k < 6; k++) {
+    float d = g[k] * dist_rms;
+    if (d < 0) d = -d;
+    if (dist < d) {
+      float l = dist / d;
+      if (rot_limit > l) rot_limit = l;
+    }
+  }
+  for (int k = 3; k < 6; k++) g[k] *= rot_limit;
+  *out_value = value;
+  memcpy(out_grad6, g, sizeof g);
+  *out_dist_rms = dist_rms;
+  return ORC_OK;
+}
+
+/* icp/rodrigues.go:11-33 rodriguesToRotation */
+void orc_rodrigues(const float *v, float *out) {
+  float ang = (float)sqrt((double)normsq3(v[0], v[1], v[2])); /* vec3.go:22-24 */
+  float r[16] = {0, v[2], -v[1], 0, -v[2], 0, v[0], 0, v[1], -v[0], 0, 0, 0, 0, 0, 0};
+  float id[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  float f0, f1;
+  if (ang < 0.1f) {
+    f0 = 1; f1 = 0.5f;
+  } else {
+    f0 = (float)sin((double)ang) / ang;
+    f1 = (float)(1 - cos((double)ang)) / (ang * ang);
+  }
+  float a[16], rr[16], b[16], s[16];
+  mat4_factor(r, f0, a);
+  mat4_add(id, a, s);
+  orc_mat4_mul(r, r, rr);
+  mat4_factor(rr, f1, b);
+  mat4_add(s, b, out);
+}
+
+/* icp/updater.go:15-42 factory defaults + :44-71 Update.
+ * weight/threshold all-zero => defaults 0.3 / 0.01; max_iter 0 => 20.
+ * *iter is gradientDescentUpdater.i.  Returns converged flag. */
+int orc_icp_update(const float *weight_in, const float *thresh_in, int32_t max_iter,
+                   int32_t *iter, const float *grad6, float *trans /* in/out */) {
+  float weight[6], thresh[6];
+  int wz = 1, tz = 1;
+  for (int k = 0; k < 6; k++) { if (weight_in[k] != 0) wz = 0; if (thresh_in[k] != 0) tz = 0; }
+  for (int k = 0; k < 6; k++) {
+    weight[k] = wz ? 0.3f : weight_in[k];
+    thresh[k] = tz ? 0.01f : thresh_in[k];
+  }
+  if (max_iter == 0) max_iter = 20;
+  int flat = 1;
+  for (int j = 0; j < 6; j++) {
+    float g = grad6[j];
+    if (g < -thresh[j] || thresh[j] < g) { flat = 0; break; }
+  }
+  if (flat) return 1;
+  float factor_iter = -(1 - ((float)(*iter) / (float)max_iter));
+  float delta[6];
+  for (int k = 0; k < 6; k++) delta[k] = factor_iter * weight[k] * grad6[k];
+  float dt[16], drot[16], tmp[16], res[16];
+  orc_translate(delta[0], delta[1], delta[2], dt);
+  orc_rodrigues(delta + 3, drot);
+  orc_mat4_mul(drot, trans, tmp);
+  orc_mat4_mul(dt, tmp, res);
+  memcpy(trans, res, sizeof res);
+  (*iter)++;
+  return *iter >= max_iter;
+}
+
+/* icp/icp.go:23-67 Fit */
+int orc_icp_fit(okdtree *t, const float *target, int64_t nt, float max_dist,
+                float min_dist_sq, int32_t min_pairs, const float *weight6,
+                const float *thresh6, int32_t max_iter, int32_t sums_mode,
+                float *trans16, float *out_value, float *out_grad6,
+                float *out_dist_rms, int32_t *num_iteration) {
+  float *tt = malloc((size_t)(nt ? nt : 1) * 12);
+  if (!tt) return ORC_E_OOM;
+  memcpy(tt, target, (size_t)nt * 12);
+  float trans[16];
+  orc_translate(0, 0, 0, trans);
+  int32_t it = 0, niter = 0;
+  int rc = ORC_OK;
+  for (;;) {
+    float value, grad[6], rms;
+    rc = orc_icp_evaluate(t, tt, nt, max_dist, min_dist_sq, min_pairs, sums_mode,
+                          &value, grad, &rms, NULL, NULL);
+    niter++;
+    if (rc) break;
+    *out_value = value;
+    memcpy(out_grad6, grad, sizeof grad);
+    *out_dist_rms = rms;
+    int converged = orc_icp_update(weight6, thresh6, max_iter, &it, grad, trans);
+    if (converged) break;
+    for (int64_t i = 0; i < nt; i++) orc_mat4_transform(trans, target + 3 * i, tt + 3 * i);
+  }
+  memcpy(trans16, trans, sizeof trans);
+  *num_iteration = niter;
+  free(tt);
+  return rc;
+}
