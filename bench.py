@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the pcgol_amd hot path on MI355X.
+
+Metric (BASELINE.json): Mpoints/s of one ICP iteration (correspondence +
+reduction [+ re-projection + pose update]) on the 1M-point cloud, with the
+kNN queries/s (C2) and VoxelGrid Mpoints/s (C3) figures measured alongside.
+
+A "step" is ONE ICP iteration over this rank's tile of the target (1M points
+per GPU: weak scaling) against the replicated 1M-point base KD-tree:
+    partials kernel (transform + nearest + 10 partial sums)
+    -> [N > 1] RCCL all-reduce of the 10 float64 sums (torch.distributed)
+    -> update kernel (evaluate tail + gradient-descent pose update, on device)
+Every 20 steps a new Fit starts (state reset), exactly as the reference's
+MaxIteration = 20 loop (icp.go:48-65); Threshold = -1 keeps all iterations.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def morton30(pts, lo, hi):
+    """30-bit Morton code of points (host, numpy) for the spatial tiling of the global target."""
+    cells = np.clip(((pts - lo) / np.maximum(hi - lo, 1e-30) * 1024.0).astype(np.int64), 0, 1023)
+
+    def spread(v):
+        v = v & 0x3FF
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    return spread(cells[:, 0]) | (spread(cells[:, 1]) << 1) | (spread(cells[:, 2]) << 2)
+
+
+def make_tile(synth, base, rank, world, n_per_gpu):
+    """Rank's spatial tile of the global target (world x n_per_gpu points).
+    Block b of the global target = T * base[perm_b] (perm seed 5 + b: block 0 is exactly
+    config C4); the global cloud is Morton-sorted and cut into `world` contiguous ranges."""
+    pose = synth.icp_pose()
+    if world == 1:
+        perm = np.random.Generator(np.random.PCG64(5)).permutation(len(base))[:n_per_gpu]
+        return synth.transform_points(pose, base[perm])
+    blocks = []
+    for b in range(world):
+        perm = np.random.Generator(np.random.PCG64(5 + b)).permutation(len(base))[:n_per_gpu]
+        blocks.append(synth.transform_points(pose, base[perm]))
+    g = np.concatenate(blocks)
+    order = np.argsort(morton30(g, g.min(axis=0), g.max(axis=0)), kind="stable")
+    sl = order[rank * n_per_gpu:(rank + 1) * n_per_gpu]
+    return np.ascontiguousarray(g[sl])
+
+
+def load_visits():
+    p = os.path.join(ROOT, "tests", "golden", "visits.json")
+    with open(p) as f:
+        return json.load(f)
+
+
+def cpu_baseline(synth, base, target, cfg, budget_s=25.0):
+    """The CPU oracle (C restatement of the reference algorithm, 1 thread) timed on the same
+    workload: whole ICP iterations (corr + reduce + re-projection + update)."""
+    import oracle as O
+    tree = O.KDTree(base)  # build not timed (the GPU figure excludes it too)
+    trans = O.translate(0, 0, 0)
+    it = 0
+    tt = target.copy()
+    iters = 0
+    t0 = time.perf_counter()
+    while iters < cfg["max_iteration"]:
+        ev = O.icp_evaluate(tree, tt, cfg["max_dist"], cfg["min_pairs"])
+        trans, conv, it = O.icp_update(trans, ev["gradient"], it, cfg["weight"], cfg["threshold"],
+                                       cfg["max_iteration"])
+        tt = synth.transform_points(trans, target)
+        iters += 1
+        if conv or time.perf_counter() - t0 > budget_s * 0.7:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": len(target) * iters / dt / 1e6, "unit": "Mpoints/s", "cores": 1, "kind": "port",
+            "sample": "%d full ICP iterations (corr+reduce+re-projection+update) of the 1M x 1M C4 workload, "
+                      "oracle/pcgol_oracle.c, 1 thread, tree build excluded" % iters,
+            "seconds": dt}
+
+
+def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits):
+    """kNN (C2) and VoxelGrid (C3) throughput with inputs resident in HBM; reported as extras."""
+    out = {}
+    dev = "cuda"
+    c2q = synth.uniform_cloud(1_000_000, 10.0, 3)
+    dq = torch.from_numpy(c2q).to(dev)
+    ids = torch.empty(len(c2q), dtype=torch.int32, device=dev)
+    dsq = torch.empty(len(c2q), dtype=torch.float32, device=dev)
+    for presort, key in ((True, "knn_c2_presort"), (False, "knn_c2_unsorted")):
+        for _ in range(2):
+            tree.NearestBatchDev(dq.data_ptr(), len(c2q), 10.0, ids.data_ptr(), dsq.data_ptr(), presort, stream)
+        torch.cuda.synchronize()
+        L.prof_reset()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            tree.NearestBatchDev(dq.data_ptr(), len(c2q), 10.0, ids.data_ptr(), dsq.data_ptr(), presort, stream)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        kms, kn = L.prof_read(L.PROF_KNN_WALK)
+        v = visits["c2_knn"]["visits_per_query"]
+        alg = (12 + 8 + 16 * v) * len(c2q)
+        out[key] = {"mqueries_per_s": len(c2q) / dt / 1e6, "ms_per_call": dt * 1e3,
+                    "walk_kernel_ms": kms / max(kn, 1),
+                    "roofline_frac_walk_kernel": alg / (kms / max(kn, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    c3 = synth.c3_voxel()
+    dp = torch.from_numpy(c3["points"]).to(dev)
+    dout = torch.empty_like(dp)
+    vg = voxelgrid.New(c3["leaf"])
+    for _ in range(2):
+        m = vg.FilterDev(dp.data_ptr(), len(c3["points"]), 12, 0, dout.data_ptr(), stream)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m = vg.FilterDev(dp.data_ptr(), len(c3["points"]), 12, 0, dout.data_ptr(), stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    n = len(c3["points"])
+    alg = 24 * n + 24 * m
+    out["voxel_c3"] = {"mpoints_per_s": n / dt / 1e6, "ms_per_call": dt * 1e3, "out_points": int(m),
+                       "algorithmic_gbs": alg / dt / 1e9, "roofline_frac": alg / dt / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--points", type=int, default=1_000_000, help="target points per GPU (and base size)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pcgol_amd import _lib as L
+    from pcgol_amd import icp, kdtree, synth, voxelgrid
+    L.check(L.lib().pcgx_init(local_rank))
+
+    n = args.points
+    width = 10.0 * (n / 1e6) ** (1.0 / 3.0)  # keeps the C4 point density when --points is changed
+    base = synth.uniform_cloud(n, width, 2)
+    cfg = dict(max_dist=0.5, min_pairs=6, weight=np.full(6, 0.3, np.float32),
+               threshold=np.full(6, -1.0, np.float32), max_iteration=20)
+    tile = make_tile(synth, base, rank, world, n)
+    t0 = time.perf_counter()
+    tree = kdtree.New(base)
+    build_s = time.perf_counter() - t0
+
+    stream = torch.cuda.current_stream().cuda_stream
+    sums = torch.zeros(10, dtype=torch.float64, device="cuda")
+    sess = icp.IcpSession(tree, tile, cfg["max_dist"], cfg["min_pairs"], cfg["weight"], cfg["threshold"],
+                          cfg["max_iteration"], d_sums10=sums.data_ptr())
+    in_fit = [0]
+
+    def step():
+        if in_fit[0] == cfg["max_iteration"]:
+            sess.reset(stream)
+            in_fit[0] = 0
+        sess.partials(stream)
+        if world > 1:
+            dist.all_reduce(sums)  # RCCL over xGMI: 80 bytes, the path's only exchange
+        sess.update(stream)
+        in_fit[0] += 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    L.prof_enable(True)
+    L.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    walk_ms, walk_n = L.prof_read(L.PROF_ICP_WALK)
+    trans, stat, _ = sess.result(stream)
+
+    if rank == 0:
+        visits = load_visits()
+        v_icp = visits["c4_icp"]["mean_visits_per_point"]
+        alg_bytes = (12 + 16 * v_icp) * n  # 12 B target read + 16 B per node the reference walk touches
+        kernel_s = walk_ms / max(walk_n, 1) * 1e-3
+        achieved = alg_bytes / kernel_s / 1e9
+        line = {
+            "metric": "Mpoints/sec ICP iter (corr+reduce) + kNN queries/sec, 1M-pt cloud",
+            "value": world * n * args.steps / elapsed / 1e6,
+            "unit": "Mpoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C4 ICP point-to-point gradient iteration (reference has no point-to-plane): "
+                                   "%d-pt base KD-tree (replicated) x %d target pts per GPU, MaxDist 0.5, "
+                                   "20-iteration Fits, Threshold -1; one step = corr+reduce+re-projection+update"
+                                   % (n, n),
+                       "base_points": n, "target_points_per_gpu": n, "parallelism": "target tiles x%d, tree replicated" % world,
+                       "exchange": "none" if world == 1 else "all-reduce 10 x f64 per step (RCCL)"},
+            "roofline": {"bound": "hbm", "kernel": "icp_partials_kernel", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": kernel_s * 1e3, "launches": walk_n,
+                         "algorithmic_bytes_per_launch": alg_bytes, "visits_per_point": v_icp},
+            "tree_build_s": build_s,
+            "final_value": float(stat.Evaluated.Value),
+        }
+        if world == 1 and not args.no_extras:
+            line["extra"] = side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(synth, base, tile, cfg)
+            line["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        print(json.dumps(line), flush=True)
+    sess.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

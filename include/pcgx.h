@@ -1,0 +1,251 @@
+/*
+ * pcgx.h -- C ABI of libpcgx.so, the MI355X (gfx950) point-cloud hot path that
+ * plugs in behind seqsense/pcgol's Go interfaces.
+ *
+ * The reference has NO FFI of its own (pure Go); its seams are Go interfaces.
+ * Every entry point below names the reference interface / function it
+ * replaces (paths relative to the reference repository root).  A cgo shim
+ * (go/) implements those Go interfaces by calling these
+ * symbols.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *  - every function returns a pcgx_status (0 = OK); pcgx_last_error() gives
+ *    the message of the last failure on the calling thread.
+ *  - "host" pointers are ordinary process memory owned by the caller (Go
+ *    slices); the library copies in/out before returning and never retains
+ *    them (cgo pointer rules).
+ *  - "_dev" entry points take DEVICE pointers (hipMalloc / pcgx_dev_alloc /
+ *    torch tensor .data_ptr()) and a HIP stream passed as void* (NULL = the
+ *    library's own stream); they only enqueue work.
+ *  - point clouds are the reference's AoS little-endian records
+ *    (pc/pointcloud.go:64-78): record i = data + i*stride, xyz = three
+ *    consecutive float32 at byte offset xyz_off (pc/pointcloud.go:130-163).
+ *  - Mat4 is column-major float[16] (mat/mat4.go:8-10).
+ *  - ids are indices into the accessor the tree was built from
+ *    (Vec3At(id), pc/storage/search.go:8-11); -1 = not found.
+ */
+#ifndef PCGX_H
+#define PCGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCGX_API __attribute__((visibility("default")))
+
+typedef int32_t pcgx_status;
+enum {
+  PCGX_OK = 0,
+  PCGX_E_NO_POINT = 1,         /* pc/minmax.go:10-12 errors.New("no point") */
+  PCGX_E_NOT_ENOUGH_PAIRS = 2, /* icp/evaluator.go:16 ErrNotEnoughPairs */
+  PCGX_E_BAD_FIELD = 3,        /* pc/pointcloud.go:115 "invalid field name" / bad stride, offset */
+  PCGX_E_HIP = 4,              /* HIP runtime failure (no GPU, launch error, ...) */
+  PCGX_E_OOM = 5,              /* host or device allocation failed */
+  PCGX_E_INVALID = 6,          /* invalid argument (NULL handle, negative count, ...) */
+  PCGX_E_OUT_OF_RANGE = 7,     /* voxel index outside the dense grid: the Go code panics here
+                                  (pc/filter/voxelgrid/voxelgrid.go:151); we return an error */
+  PCGX_E_TOO_LARGE = 8,        /* tree larger than 2^26 points (traversal frame encoding) */
+  PCGX_E_NEED_GRADIENT = 9     /* icp/icp.go:15 ErrNeedGradient (kept for the Go shim's mapping) */
+};
+
+/* ------------------------------------------------------------ lifecycle */
+
+/* Selects HIP device `device` for this process (one process per GPU) and
+ * creates the library stream.  Idempotent. */
+PCGX_API pcgx_status pcgx_init(int32_t device);
+PCGX_API pcgx_status pcgx_shutdown(void);
+/* Copies the last error message of the calling thread; returns its length. */
+PCGX_API int32_t pcgx_last_error(char *buf, size_t cap);
+PCGX_API const char *pcgx_version(void);
+/* Block until all work enqueued on `stream` (NULL = library stream) is done. */
+PCGX_API pcgx_status pcgx_sync(void *stream);
+
+/* Optional in-library kernel timing (HIP events on the launch stream around
+ * the named kernel class).  Used by bench.py for the live roofline figure. */
+enum {
+  PCGX_PROF_ICP_WALK = 0,   /* icp_partials_kernel (transform + nearest + reduce) */
+  PCGX_PROF_KNN_WALK = 1,   /* nearest_kernel */
+  PCGX_PROF_VOXEL_ALL = 2,  /* whole voxel-filter pipeline of one call */
+  PCGX_PROF_SORT_SCATTER = 3, /* rs_scatter_kernel (radix sort passes) */
+  PCGX_PROF_KINDS = 4
+};
+PCGX_API pcgx_status pcgx_prof_enable(int32_t on);
+/* Resolves pending events; returns accumulated milliseconds and launch count
+ * of `kind` since the last pcgx_prof_reset(). */
+PCGX_API pcgx_status pcgx_prof_read(int32_t kind, double *total_ms, int64_t *launches);
+PCGX_API pcgx_status pcgx_prof_reset(void);
+
+/* Device memory helpers for hosts that have no HIP binding of their own. */
+PCGX_API pcgx_status pcgx_dev_alloc(size_t bytes, void **dptr);
+PCGX_API pcgx_status pcgx_dev_free(void *dptr);
+PCGX_API pcgx_status pcgx_dev_upload(void *dptr, const void *host, size_t bytes);
+PCGX_API pcgx_status pcgx_dev_download(void *host, const void *dptr, size_t bytes);
+
+/* --------------------------------------------------------------- KD-tree
+ * replaces pc/storage/kdtree: kdtree.New (kdtree.go:33-56, newNode :348-370),
+ * KDTree.Nearest (:83-146, searchLeafNode :199-222), MinDistSq field (:22),
+ * behind storage.Search (pc/storage/search.go:13-17).
+ */
+typedef struct pcgx_kdtree pcgx_kdtree;
+
+/* kdtree.New(ra): builds the median-split tree (dim = depth%3, upper median,
+ * ties on the split axis ordered stably by current position) and uploads it.
+ * n == 0 -> PCGX_E_NO_POINT (the Go code panics, kdtree.go:355-356). */
+PCGX_API pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t stride,
+                                       int32_t xyz_off, pcgx_kdtree **out);
+PCGX_API pcgx_status pcgx_kdtree_free(pcgx_kdtree *t);
+/* Len() of the accessor the tree indexes (pc/randomaccess.go:9). */
+PCGX_API pcgx_status pcgx_kdtree_len(const pcgx_kdtree *t, int64_t *n);
+/* node.maxDepth(0) (kdtree.go:385-395). */
+PCGX_API pcgx_status pcgx_kdtree_max_depth(const pcgx_kdtree *t, int32_t *depth);
+/* In-order point ids (child0, node, child1): the final state of the
+ * reference's in-place sorted indice slice; defines the whole tree. */
+PCGX_API pcgx_status pcgx_kdtree_inorder(const pcgx_kdtree *t, int64_t *ids /* [n] host */);
+/* Vec3At(id) for a batch of ids (pc/randomaccess.go:8). */
+PCGX_API pcgx_status pcgx_kdtree_points(const pcgx_kdtree *t, const int64_t *ids, int64_t m,
+                                        float *xyz /* [3m] host */);
+
+/* Batched KDTree.Nearest: for each query i the exact result of
+ * k.Nearest(q[i], max_range) with k.MinDistSq = min_dist_sq, i.e.
+ * {ID, DistSq} or {-1, max_range^2} (kdtree.go:84-86,100-103).
+ * q is packed xyz float32 [3*nq]. */
+PCGX_API pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const float *q, int64_t nq,
+                                               float max_range, float min_dist_sq,
+                                               int64_t *ids /* [nq] */, float *dist_sq /* [nq] */);
+
+#define PCGX_KNN_PRESORT 1u /* Morton-order the queries inside the call (results are
+                               returned in the caller's order either way) */
+/* Same, device resident: d_q packed xyz [3*nq], d_ids int32 [nq], d_dist_sq [nq]. */
+PCGX_API pcgx_status pcgx_kdtree_nearest_batch_dev(const pcgx_kdtree *t, const float *d_q,
+                                                   int64_t nq, float max_range,
+                                                   float min_dist_sq, uint32_t flags,
+                                                   int32_t *d_ids, float *d_dist_sq,
+                                                   void *stream);
+
+/* ------------------------------------------------------------- VoxelGrid
+ * replaces pc/filter/voxelgrid: voxelgrid.New(leaf, WithChunkSize(chunk))
+ * .Filter(pp) (voxelgrid.go:23-187, option.go:14-18) behind filter.Filter
+ * (pc/filter/filter.go:7-9), incl. pc.MinMaxVec3 (pc/minmax.go:9-26).
+ */
+
+/* pc.MinMaxVec3 over an AoS cloud. n == 0 -> PCGX_E_NO_POINT. */
+PCGX_API pcgx_status pcgx_minmax(const void *data, int64_t n, int32_t stride, int32_t xyz_off,
+                                 float vmin[3], float vmax[3]);
+
+/* Filter: out_data must hold n*stride bytes (worst case); *out_n = number of
+ * output records (Width of the returned cloud, Height = 1).  chunk = {0,0,0}
+ * (any product == 0) selects the non-chunked path (voxelgrid.go:45-47). */
+PCGX_API pcgx_status pcgx_voxel_filter(const void *data, int64_t n, int32_t stride,
+                                       int32_t xyz_off, const float leaf[3],
+                                       const int32_t chunk[3], void *out_data, int64_t *out_n);
+/* Device resident: d_data/d_out are device buffers (d_out >= n*stride bytes);
+ * d_out_n is a device int64.  Synchronises internally only for workspace sizing. */
+PCGX_API pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int32_t stride,
+                                           int32_t xyz_off, const float leaf[3],
+                                           const int32_t chunk[3], void *d_out,
+                                           int64_t *out_n, void *stream);
+
+/* ------------------------------------------------------------------- ICP
+ * replaces pc/registration/icp: NearestPointCorresponder.Pairs
+ * (correspondence.go:22-37), PointToPointEvaluator.Evaluate (evaluator.go:91-189,
+ * default weight w == 1), gradientDescentUpdater.Update (updater.go:44-71,
+ * rodrigues.go:11-33) and PointToPointICPGradient.Fit (icp.go:23-67).
+ */
+
+/* icp.Evaluated (evaluator.go:25-30); Hessian is never written by the
+ * reference (HasHessian() == false, :76) and is omitted. */
+typedef struct {
+  float value;
+  float gradient[6];
+  float dist_rms;
+  int64_t num_pairs;
+} pcgx_icp_evaluated;
+
+/* NearestPointCorresponder{MaxDist}, PointToPointEvaluator{MinPairs},
+ * KDTree.MinDistSq, GradientDescentUpdaterFactory{Weight,Threshold,MaxIteration}
+ * (zero values select the reference defaults 6 / 0.3 / 0.01 / 20,
+ * evaluator.go:92-95, updater.go:15-37). */
+typedef struct {
+  float max_dist;
+  float min_dist_sq;
+  int32_t min_pairs;
+  float weight[6];
+  float threshold[6];
+  int32_t max_iteration;
+} pcgx_icp_params;
+
+/* icp.Stat (stat.go:3-6) */
+typedef struct {
+  pcgx_icp_evaluated evaluated;
+  int32_t num_iteration;
+} pcgx_icp_stat;
+
+/* Pairs(): order-preserving compaction of matched targets.  Output arrays
+ * hold nt entries (worst case, correspondence.go:24). */
+PCGX_API pcgx_status pcgx_icp_pairs(const pcgx_kdtree *base, const float *target, int64_t nt,
+                                    float max_dist, float min_dist_sq, int64_t *base_id,
+                                    int64_t *target_id, float *dist_sq, int64_t *npairs);
+
+/* Evaluate(base, target): fused correspondence + reduction on the GPU.
+ * Fewer than min_pairs (0 -> 6) pairs -> PCGX_E_NOT_ENOUGH_PAIRS. */
+PCGX_API pcgx_status pcgx_icp_evaluate(const pcgx_kdtree *base, const float *target, int64_t nt,
+                                       float max_dist, float min_dist_sq, int32_t min_pairs,
+                                       pcgx_icp_evaluated *out);
+
+/* Host-only pieces (no GPU needed), exposed so a host can run the reference's
+ * loop around its own exchange step:
+ *  sums10 = {sum w*d2, G0..G5 sums, sum w*|pt|^2, sum w, pair count} (f64);
+ *  finish = evaluator.go:156-186 (normalise, sqrt, rotation limiter). */
+PCGX_API pcgx_status pcgx_icp_finish_evaluate(const double sums10[10], int32_t min_pairs,
+                                              pcgx_icp_evaluated *out);
+/* Update(trans, ev): *iter is the updater's iteration counter u.i;
+ * *converged receives the bool result (updater.go:44-71). */
+PCGX_API pcgx_status pcgx_icp_update(const pcgx_icp_params *p, int32_t *iter,
+                                     const float gradient[6], float trans16[16],
+                                     int32_t *converged);
+/* rodriguesToRotation (rodrigues.go:11-33) and Mat4 helpers used by Fit. */
+PCGX_API pcgx_status pcgx_rodrigues(const float v[3], float out16[16]);
+PCGX_API pcgx_status pcgx_mat4_mul(const float m[16], const float a[16], float out16[16]);
+PCGX_API pcgx_status pcgx_mat4_transform(const float m[16], const float *xyz, int64_t n,
+                                         float *out_xyz);
+
+/* Fit(base, target): the whole loop stays on the device (evaluate + update
+ * kernels, one download at the end).  On PCGX_E_NOT_ENOUGH_PAIRS trans16 and
+ * stat->num_iteration hold the state at failure, like icp.go:49-53. */
+PCGX_API pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target, int64_t nt,
+                                  const pcgx_icp_params *params, float trans16[16],
+                                  pcgx_icp_stat *stat);
+
+/* Device-resident ICP session: the same loop, cut at the per-iteration
+ * exchange so that N processes (one per GPU, each with a replica of the base
+ * tree and its own tile of the target) can all-reduce the 10 partial sums
+ * between `partials` and `update`.  d_sums10 is a device
+ * buffer of 10 doubles owned by the caller (e.g. a torch tensor handed to
+ * torch.distributed.all_reduce == RCCL). */
+typedef struct pcgx_icp_session pcgx_icp_session;
+PCGX_API pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const float *target,
+                                             int64_t nt, int32_t target_on_device,
+                                             const pcgx_icp_params *params, double *d_sums10,
+                                             pcgx_icp_session **out);
+PCGX_API pcgx_status pcgx_icp_session_free(pcgx_icp_session *s);
+/* Restart the loop on the same target: trans = identity, counters cleared
+ * (a new Fit, icp.go:46-47). */
+PCGX_API pcgx_status pcgx_icp_session_reset(pcgx_icp_session *s, void *stream);
+/* Enqueue transform(original target, current trans) + nearest + reduction of
+ * this rank's tile into d_sums10.  No-op once the session has converged. */
+PCGX_API pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stream);
+/* Enqueue evaluate-tail + Update from the (all-reduced) d_sums10 on the device. */
+PCGX_API pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream);
+/* Synchronise and read back trans / stat / converged flag.  Returns
+ * PCGX_E_NOT_ENOUGH_PAIRS if an iteration failed. */
+PCGX_API pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream,
+                                             float trans16[16], pcgx_icp_stat *stat,
+                                             int32_t *converged);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCGX_H */

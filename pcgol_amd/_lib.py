@@ -1,0 +1,164 @@
+"""ctypes binding of libpcgx.so (include/pcgx.h).  No CPU fallback: if the
+HIP library is missing or no GPU is present, calls fail loudly."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "libpcgx.so")
+
+PCGX_OK = 0
+PCGX_E_NO_POINT = 1
+PCGX_E_NOT_ENOUGH_PAIRS = 2
+PCGX_E_BAD_FIELD = 3
+PCGX_E_HIP = 4
+PCGX_E_OOM = 5
+PCGX_E_INVALID = 6
+PCGX_E_OUT_OF_RANGE = 7
+PCGX_E_TOO_LARGE = 8
+PCGX_E_NEED_GRADIENT = 9
+
+PCGX_KNN_PRESORT = 1
+PROF_ICP_WALK, PROF_KNN_WALK, PROF_VOXEL_ALL, PROF_SORT_SCATTER = range(4)
+
+
+def prof_enable(on=True):
+    check(lib().pcgx_prof_enable(1 if on else 0))
+
+
+def prof_reset():
+    check(lib().pcgx_prof_reset())
+
+
+def prof_read(kind):
+    """(total milliseconds, launches) of kernel class `kind` since prof_reset()."""
+    ms, n = C.c_double(), C.c_int64()
+    check(lib().pcgx_prof_read(kind, C.byref(ms), C.byref(n)))
+    return ms.value, n.value
+
+
+class PcgxError(RuntimeError):
+    def __init__(self, code, msg):
+        self.code = code
+        super().__init__("pcgx error %d: %s" % (code, msg))
+
+
+class ErrNoPoint(PcgxError):            # pc/minmax.go:11
+    pass
+
+
+class ErrNotEnoughPairs(PcgxError):     # icp/evaluator.go:16
+    pass
+
+
+class ErrNeedGradient(PcgxError):       # icp/icp.go:15
+    pass
+
+
+class ErrInvalidField(PcgxError):       # pc/pointcloud.go:115
+    pass
+
+
+_ERR = {PCGX_E_NO_POINT: ErrNoPoint, PCGX_E_NOT_ENOUGH_PAIRS: ErrNotEnoughPairs,
+        PCGX_E_NEED_GRADIENT: ErrNeedGradient, PCGX_E_BAD_FIELD: ErrInvalidField}
+
+
+class IcpEvaluated(C.Structure):
+    _fields_ = [("value", C.c_float), ("gradient", C.c_float * 6), ("dist_rms", C.c_float),
+                ("num_pairs", C.c_int64)]
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("max_dist", C.c_float), ("min_dist_sq", C.c_float), ("min_pairs", C.c_int32),
+                ("weight", C.c_float * 6), ("threshold", C.c_float * 6), ("max_iteration", C.c_int32)]
+
+
+class IcpStat(C.Structure):
+    _fields_ = [("evaluated", IcpEvaluated), ("num_iteration", C.c_int32)]
+
+
+# name -> (restype, argtypes); the complete export list of include/pcgx.h
+_vp, _i64, _i32, _u32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float, C.c_size_t
+SIGNATURES = {
+    "pcgx_init": (_i32, [_i32]),
+    "pcgx_shutdown": (_i32, []),
+    "pcgx_last_error": (_i32, [C.c_char_p, _sz]),
+    "pcgx_version": (C.c_char_p, []),
+    "pcgx_sync": (_i32, [_vp]),
+    "pcgx_prof_enable": (_i32, [_i32]),
+    "pcgx_prof_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "pcgx_prof_reset": (_i32, []),
+    "pcgx_dev_alloc": (_i32, [_sz, C.POINTER(_vp)]),
+    "pcgx_dev_free": (_i32, [_vp]),
+    "pcgx_dev_upload": (_i32, [_vp, _vp, _sz]),
+    "pcgx_dev_download": (_i32, [_vp, _vp, _sz]),
+    "pcgx_kdtree_build": (_i32, [_vp, _i64, _i32, _i32, C.POINTER(_vp)]),
+    "pcgx_kdtree_free": (_i32, [_vp]),
+    "pcgx_kdtree_len": (_i32, [_vp, C.POINTER(_i64)]),
+    "pcgx_kdtree_max_depth": (_i32, [_vp, C.POINTER(_i32)]),
+    "pcgx_kdtree_inorder": (_i32, [_vp, _vp]),
+    "pcgx_kdtree_points": (_i32, [_vp, _vp, _i64, _vp]),
+    "pcgx_kdtree_nearest_batch": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
+    "pcgx_kdtree_nearest_batch_dev": (_i32, [_vp, _vp, _i64, _f32, _f32, _u32, _vp, _vp, _vp]),
+    "pcgx_minmax": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "pcgx_voxel_filter": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "pcgx_voxel_filter_dev": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
+    "pcgx_icp_pairs": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp, C.POINTER(_i64)]),
+    "pcgx_icp_evaluate": (_i32, [_vp, _vp, _i64, _f32, _f32, _i32, C.POINTER(IcpEvaluated)]),
+    "pcgx_icp_finish_evaluate": (_i32, [_vp, _i32, C.POINTER(IcpEvaluated)]),
+    "pcgx_icp_update": (_i32, [C.POINTER(IcpParams), C.POINTER(_i32), _vp, _vp, C.POINTER(_i32)]),
+    "pcgx_rodrigues": (_i32, [_vp, _vp]),
+    "pcgx_mat4_mul": (_i32, [_vp, _vp, _vp]),
+    "pcgx_mat4_transform": (_i32, [_vp, _vp, _i64, _vp]),
+    "pcgx_icp_fit": (_i32, [_vp, _vp, _i64, C.POINTER(IcpParams), _vp, C.POINTER(IcpStat)]),
+    "pcgx_icp_session_create": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(IcpParams), _vp, C.POINTER(_vp)]),
+    "pcgx_icp_session_free": (_i32, [_vp]),
+    "pcgx_icp_session_reset": (_i32, [_vp, _vp]),
+    "pcgx_icp_session_partials": (_i32, [_vp, _vp]),
+    "pcgx_icp_session_update": (_i32, [_vp, _vp]),
+    "pcgx_icp_session_result": (_i32, [_vp, _vp, _vp, C.POINTER(IcpStat), C.POINTER(_i32)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libpcgx.so.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO):
+            raise ImportError("pcgol_amd/libpcgx.so is missing: run `python -c 'import __graft_entry__ as g; "
+                              "g.build()'` (hipcc, gfx950). There is no CPU fallback.")
+        L = C.CDLL(SO)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(1024)
+    lib().pcgx_last_error(buf, 1024)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc):
+    if rc != PCGX_OK:
+        raise _ERR.get(rc, PcgxError)(rc, last_error())
+
+
+def ptr(a):
+    """void* of a numpy array (must be C-contiguous) or a raw integer address."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    assert a.flags["C_CONTIGUOUS"]
+    return C.c_void_p(a.ctypes.data)
+
+
+def f32c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)

@@ -1,0 +1,70 @@
+"""Builds pcgol_amd/libpcgx.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+The flags matter for parity: -ffp-contract=off (the Go reference never fuses
+multiply-add on amd64), correctly rounded float32 divide/sqrt (hipcc default)
+and no fast-math, on both the host and the device side.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libpcgx.so")
+SOURCES = ["core.hip", "knn.hip", "sort.hip", "icp.hip", "voxel.hip", "kdtree_build.cpp"]
+HEADERS = ["pcgx_internal.h", "pcgx_math.h", "knn_walk.h", os.path.join("..", "..", "include", "pcgx.h")]
+ARCH = "gfx950"
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libpcgx.so can only be built with the ROCm toolchain")
+
+
+def flags():
+    return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+            "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-x", "hip"]
+
+
+def needs_build():
+    if not os.path.exists(SO):
+        return True
+    t = os.path.getmtime(SO)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return SO
+    objs = []
+    procs = []
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    for s in SOURCES:
+        o = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        objs.append(o)
+        cmd = [hipcc()] + flags() + ["-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    failed = False
+    for s, p in procs:
+        out = p.communicate()[0].decode()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("== %s ==\n%s\n" % (s, out))
+        elif verbose and out.strip():
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] + objs + ["-lpthread"]
+    subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="-f" in sys.argv, verbose=True))

@@ -1,0 +1,303 @@
+// core.hip -- context, error reporting, workspace arena, device-memory helpers
+// and the host-only math exports of the pcgx C ABI.
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "pcgx_internal.h"
+
+namespace pcgx {
+
+static thread_local std::string g_last_error;
+
+pcgx_status fail(pcgx_status code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+Context &ctx() {
+  static Context c;
+  return c;
+}
+
+static std::mutex g_init_mu;
+
+static pcgx_status init_device(int device) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  Context &c = ctx();
+  if (c.ready) {
+    if (device >= 0 && device != c.device)
+      return fail(PCGX_E_INVALID, "pcgx already initialised on device %d (one process per GPU)", c.device);
+    return PCGX_OK;
+  }
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return fail(PCGX_E_HIP, "no HIP device available (%s): libpcgx has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  if (device < 0) device = 0;
+  if (device >= count) return fail(PCGX_E_INVALID, "device %d out of range (%d devices)", device, count);
+  PCGX_HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  PCGX_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  PCGX_HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  c.device = device;
+  c.ready = true;
+  return PCGX_OK;
+}
+
+pcgx_status ensure_init() {
+  if (ctx().ready) return PCGX_OK;
+  return init_device(-1);
+}
+
+// ---- kernel timing -----------------------------------------------------------
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_pending;
+std::vector<hipEvent_t> g_prof_pool;
+double g_prof_ms[PCGX_PROF_KINDS];
+int64_t g_prof_n[PCGX_PROF_KINDS];
+std::mutex g_prof_mu;
+
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void prof_resolve() {
+  for (auto &r : g_prof_pending) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      g_prof_ms[r.kind] += ms;
+      g_prof_n[r.kind] += 1;
+    }
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  g_prof_pending.clear();
+}
+}  // namespace
+
+ProfScope::ProfScope(int kind, hipStream_t st) : kind_(kind), st_(st) {
+  if (!g_prof_on) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  a_ = prof_event();
+  b_ = prof_event();
+  if (a_) (void)hipEventRecord(a_, st_);
+}
+ProfScope::~ProfScope() {
+  if (!a_ || !b_) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  (void)hipEventRecord(b_, st_);
+  g_prof_pending.push_back(ProfRec{a_, b_, kind_});
+}
+
+// ---- arena -----------------------------------------------------------------
+static size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+pcgx_status Arena::begin(hipStream_t st) {
+  if (has_last_ && last_stream_ != st) {
+    // a different stream may still be using the previous call's temporaries
+    PCGX_HIP_TRY(hipStreamSynchronize(last_stream_));
+  }
+  last_stream_ = st;
+  has_last_ = true;
+  if (blocks_.size() > 1) {
+    size_t total = 0;
+    for (auto &b : blocks_) total += b.cap;
+    release_all();
+    total = round_up(total + total / 4, 1 << 20);
+    uint8_t *p = nullptr;
+    hipError_t e = hipMalloc((void **)&p, total);
+    if (e != hipSuccess) return fail(PCGX_E_OOM, "arena hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
+    blocks_.push_back(Block{p, total, 0});
+  }
+  for (auto &b : blocks_) b.used = 0;
+  return PCGX_OK;
+}
+
+pcgx_status Arena::alloc(size_t bytes, void **out) {
+  bytes = round_up(bytes ? bytes : 1, 256);
+  if (!blocks_.empty()) {
+    Block &b = blocks_.back();
+    if (b.used + bytes <= b.cap) {
+      *out = b.p + b.used;
+      b.used += bytes;
+      return PCGX_OK;
+    }
+  }
+  size_t cap = round_up(bytes, 1 << 20);
+  uint8_t *p = nullptr;
+  hipError_t e = hipMalloc((void **)&p, cap);
+  if (e != hipSuccess) return fail(PCGX_E_OOM, "arena hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+  blocks_.push_back(Block{p, cap, bytes});
+  *out = p;
+  return PCGX_OK;
+}
+
+void Arena::release_all() {
+  for (auto &b : blocks_) (void)hipFree(b.p);
+  blocks_.clear();
+}
+
+}  // namespace pcgx
+
+using namespace pcgx;
+
+extern "C" pcgx_status pcgx_init(int32_t device) { return init_device(device); }
+
+extern "C" pcgx_status pcgx_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_init_mu);
+  Context &c = ctx();
+  if (!c.ready) return PCGX_OK;
+  (void)hipDeviceSynchronize();
+  c.arena.release_all();
+  (void)hipStreamDestroy(c.stream);
+  c.stream = nullptr;
+  c.ready = false;
+  c.device = -1;
+  return PCGX_OK;
+}
+
+extern "C" int32_t pcgx_last_error(char *buf, size_t cap) {
+  const std::string &s = g_last_error;
+  if (buf && cap > 0) {
+    size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+    memcpy(buf, s.data(), n);
+    buf[n] = 0;
+  }
+  return (int32_t)s.size();
+}
+
+extern "C" const char *pcgx_version(void) { return "pcgx 0.1 (gfx950)"; }
+
+extern "C" pcgx_status pcgx_sync(void *stream) {
+  PCGX_TRY(ensure_init());
+  PCGX_HIP_TRY(hipStreamSynchronize(pick_stream(stream)));
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_prof_enable(int32_t on) {
+  PCGX_TRY(ensure_init());
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_prof_read(int32_t kind, double *total_ms, int64_t *launches) {
+  if (kind < 0 || kind >= PCGX_PROF_KINDS || !total_ms || !launches)
+    return fail(PCGX_E_INVALID, "pcgx_prof_read: bad argument");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  prof_resolve();
+  *total_ms = g_prof_ms[kind];
+  *launches = g_prof_n[kind];
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  prof_resolve();
+  for (int k = 0; k < PCGX_PROF_KINDS; k++) { g_prof_ms[k] = 0.0; g_prof_n[k] = 0; }
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_dev_alloc(size_t bytes, void **dptr) {
+  if (!dptr) return fail(PCGX_E_INVALID, "pcgx_dev_alloc: dptr is NULL");
+  PCGX_TRY(ensure_init());
+  hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+  if (e != hipSuccess) return fail(PCGX_E_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_dev_free(void *dptr) {
+  if (dptr) PCGX_HIP_TRY(hipFree(dptr));
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_dev_upload(void *dptr, const void *host, size_t bytes) {
+  PCGX_TRY(ensure_init());
+  if (bytes) PCGX_HIP_TRY(hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_dev_download(void *host, const void *dptr, size_t bytes) {
+  PCGX_TRY(ensure_init());
+  if (bytes) PCGX_HIP_TRY(hipMemcpy(host, dptr, bytes, hipMemcpyDeviceToHost));
+  return PCGX_OK;
+}
+
+// ---- host-only math exports (no GPU needed) ---------------------------------
+
+extern "C" pcgx_status pcgx_rodrigues(const float v[3], float out16[16]) {
+  if (!v || !out16) return fail(PCGX_E_INVALID, "pcgx_rodrigues: NULL argument");
+  Mat4 r = rodrigues_to_rotation(v[0], v[1], v[2]);
+  memcpy(out16, r.m, sizeof r.m);
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_mat4_mul(const float m[16], const float a[16], float out16[16]) {
+  if (!m || !a || !out16) return fail(PCGX_E_INVALID, "pcgx_mat4_mul: NULL argument");
+  Mat4 x, y;
+  memcpy(x.m, m, sizeof x.m);
+  memcpy(y.m, a, sizeof y.m);
+  Mat4 r = mat4_mul(x, y);
+  memcpy(out16, r.m, sizeof r.m);
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_mat4_transform(const float m[16], const float *xyz, int64_t n,
+                                           float *out_xyz) {
+  if (!m || n < 0 || (n > 0 && (!xyz || !out_xyz))) return fail(PCGX_E_INVALID, "pcgx_mat4_transform: bad argument");
+  for (int64_t i = 0; i < n; i++) {
+    float x, y, z;
+    mat4_transform(m, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], x, y, z);
+    out_xyz[3 * i] = x;
+    out_xyz[3 * i + 1] = y;
+    out_xyz[3 * i + 2] = z;
+  }
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_finish_evaluate(const double sums10[10], int32_t min_pairs,
+                                                pcgx_icp_evaluated *out) {
+  if (!sums10 || !out) return fail(PCGX_E_INVALID, "pcgx_icp_finish_evaluate: NULL argument");
+  if (min_pairs == 0) min_pairs = 6;  // evaluator.go:92-95
+  const int64_t npairs = (int64_t)sums10[S_PAIRS];
+  out->num_pairs = npairs;
+  if (npairs < min_pairs)
+    return fail(PCGX_E_NOT_ENOUGH_PAIRS, "not enough correspondence pairs (%lld < %d)", (long long)npairs, min_pairs);
+  Evaluated ev;
+  finish_evaluate(sums10, ev);
+  out->value = ev.value;
+  memcpy(out->gradient, ev.gradient, sizeof ev.gradient);
+  out->dist_rms = ev.dist_rms;
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_update(const pcgx_icp_params *p, int32_t *iter, const float gradient[6],
+                                       float trans16[16], int32_t *converged) {
+  if (!p || !iter || !gradient || !trans16 || !converged)
+    return fail(PCGX_E_INVALID, "pcgx_icp_update: NULL argument");
+  UpdaterParams u = resolve_updater(p->weight, p->threshold, p->max_iteration);
+  Mat4 t;
+  memcpy(t.m, trans16, sizeof t.m);
+  bool c = gradient_descent_update(u, *iter, gradient, t);
+  memcpy(trans16, t.m, sizeof t.m);
+  *converged = c ? 1 : 0;
+  return PCGX_OK;
+}

@@ -1,0 +1,392 @@
+// icp.hip -- point-to-point ICP (gradient) on gfx950: fused
+// transform + nearest + reduction kernel, device-side evaluate-tail/update
+// kernel, the device-resident session and the pcgx_icp_* C ABI.
+//
+// Reference: pc/registration/icp/icp.go:23-67 (Fit), correspondence.go:22-37
+// (Pairs), evaluator.go:91-189 (Evaluate), updater.go:44-71 (Update).
+#include <string.h>
+
+#include <vector>
+
+#include "knn_walk.h"
+
+namespace pcgx {
+
+// Loop state kept in device memory so that a whole Fit can be enqueued without
+// a host round trip per iteration (and captured in a hipGraph).
+struct IcpState {
+  float trans[16];        // accumulated transform (icp.go:47)
+  int32_t iter;           // gradientDescentUpdater.i (updater.go:41)
+  int32_t num_iteration;  // Stat.NumIteration (icp.go:50)
+  int32_t done;           // converged, or failed
+  int32_t status;         // PCGX_OK / PCGX_E_NOT_ENOUGH_PAIRS
+  Evaluated ev;           // Stat.Evaluated (icp.go:54)
+};
+
+struct IcpKernelParams {
+  float max_dist_sq;
+  float min_dist_sq;
+  int32_t min_pairs;
+  UpdaterParams upd;
+};
+
+constexpr int kIcpBlock = kKnnBlock;
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  return v;  // lane 0 holds the sum (fixed tree order -> deterministic)
+}
+
+// One target point per lane per grid-stride step.  Targets are stored SoA
+// (x[], y[], z[]) in Morton order of the ORIGINAL target; every iteration
+// re-projects the original by the accumulated transform (icp.go:62-64) in
+// registers, walks the tree, and accumulates the evaluator's 9 sums + the
+// pair count (evaluator.go:122-145) in float64.  Each term is formed in
+// float32 exactly as the reference forms it (w == 1).
+template <bool kMinDist>
+__global__ __launch_bounds__(kIcpBlock) void icp_partials_kernel(
+    TreeView tv, const float *__restrict__ tx, const float *__restrict__ ty,
+    const float *__restrict__ tz, int64_t nt, const IcpState *__restrict__ state,
+    IcpKernelParams kp, double *__restrict__ block_partials) {
+  extern __shared__ uint2 s_stack[];
+  __shared__ double s_red[kIcpBlock / 64][S_COUNT];
+  if (state->done) return;  // uniform
+  float m[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) m[i] = state->trans[i];
+  // Before the first update targetTransformed is a plain copy (icp.go:27-30).
+  const bool project = state->iter > 0;
+
+  double acc[S_COUNT];
+#pragma unroll
+  for (int k = 0; k < S_COUNT; k++) acc[k] = 0.0;
+
+  const int64_t step = (int64_t)gridDim.x * kIcpBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kIcpBlock + threadIdx.x; i < nt; i += step) {
+    float x0 = tx[i], y0 = ty[i], z0 = tz[i];
+    if (project) {
+      float px, py, pz;
+      mat4_transform(m, x0, y0, z0, px, py, pz);
+      x0 = px; y0 = py; z0 = pz;
+    }
+    WalkResult r = nearest_walk<kMinDist>(tv, s_stack + threadIdx.x, kIcpBlock, x0, y0, z0,
+                                          kp.max_dist_sq, kp.min_dist_sq);
+    if (r.id >= 0) {  // correspondence.go:27-29
+      const float x1 = r.bx, y1 = r.by, z1 = r.bz;
+      acc[S_VALUE] += (double)r.dist_sq;
+      acc[S_G0 + 0] += (double)(x0 - x1);
+      acc[S_G0 + 1] += (double)(y0 - y1);
+      acc[S_G0 + 2] += (double)(z0 - z1);
+      acc[S_G0 + 3] += (double)(z0 * y1 - y0 * z1);
+      acc[S_G0 + 4] += (double)(x0 * z1 - z0 * x1);
+      acc[S_G0 + 5] += (double)(y0 * x1 - x0 * y1);
+      acc[S_DIST_RMS] += (double)norm_sq3(x0, y0, z0);
+      acc[S_WEIGHT] += 1.0;
+      acc[S_PAIRS] += 1.0;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < S_COUNT; k++) {
+    double v = wave_sum_f64(acc[k]);
+    if (lane == 0) s_red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < S_COUNT) {
+    double v = 0.0;
+    for (int w = 0; w < kIcpBlock / 64; w++) v += s_red[w][threadIdx.x];
+    block_partials[(int64_t)blockIdx.x * S_COUNT + threadIdx.x] = v;
+  }
+}
+
+// Sums the per-block partials in a fixed order -> sums10 (run-to-run deterministic).
+__global__ __launch_bounds__(256) void icp_final_reduce_kernel(const double *__restrict__ block_partials,
+                                                               int nblocks,
+                                                               const IcpState *__restrict__ state,
+                                                               double *__restrict__ sums10) {
+  __shared__ double s[256];
+  if (state->done) return;
+  for (int k = 0; k < S_COUNT; k++) {
+    double v = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) v += block_partials[(int64_t)b * S_COUNT + k];
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) sums10[k] = s[0];
+    __syncthreads();
+  }
+}
+
+// Evaluate tail (evaluator.go:92-105,156-186) + Update (updater.go:44-71) +
+// the loop bookkeeping of Fit (icp.go:49-60), one thread.
+__global__ void icp_update_kernel(IcpState *__restrict__ state, const double *__restrict__ sums10,
+                                  IcpKernelParams kp) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (state->done) return;
+  state->num_iteration += 1;
+  const int64_t npairs = (int64_t)sums10[S_PAIRS];
+  if (npairs < (int64_t)kp.min_pairs) {
+    state->ev.num_pairs = npairs;
+    state->status = PCGX_E_NOT_ENOUGH_PAIRS;
+    state->done = 1;
+    return;
+  }
+  Evaluated ev;
+  finish_evaluate(sums10, ev);
+  state->ev = ev;
+  Mat4 t;
+  for (int i = 0; i < 16; i++) t.m[i] = state->trans[i];
+  int32_t it = state->iter;
+  const bool converged = gradient_descent_update(kp.upd, it, ev.gradient, t);
+  for (int i = 0; i < 16; i++) state->trans[i] = t.m[i];
+  state->iter = it;
+  if (converged) state->done = 1;
+}
+
+__global__ __launch_bounds__(256) void gather_soa_kernel(const float *__restrict__ q,
+                                                         const int32_t *__restrict__ perm, int64_t n,
+                                                         float *__restrict__ x, float *__restrict__ y,
+                                                         float *__restrict__ z) {
+  const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= n) return;
+  const int64_t i = perm ? (int64_t)perm[pos] : pos;
+  x[pos] = q[3 * i];
+  y[pos] = q[3 * i + 1];
+  z[pos] = q[3 * i + 2];
+}
+
+}  // namespace pcgx
+
+using namespace pcgx;
+
+struct pcgx_icp_session {
+  const pcgx_kdtree *base = nullptr;
+  int64_t nt = 0;
+  float *d_xyz = nullptr;  // SoA: x[nt] | y[nt] | z[nt], Morton order of the original target
+  IcpState *d_state = nullptr;
+  double *d_partials = nullptr;
+  double *d_sums = nullptr;  // caller's buffer, or own
+  bool own_sums = false;
+  int grid = 1;
+  IcpKernelParams kp;
+  int32_t max_iteration = 20;
+};
+
+static IcpKernelParams make_kernel_params(const pcgx_icp_params *p) {
+  IcpKernelParams kp;
+  kp.max_dist_sq = p->max_dist * p->max_dist;  // kdtree.go:91 via correspondence.go:26
+  kp.min_dist_sq = p->min_dist_sq;
+  kp.min_pairs = p->min_pairs == 0 ? 6 : p->min_pairs;  // evaluator.go:92-95
+  kp.upd = resolve_updater(p->weight, p->threshold, p->max_iteration);
+  return kp;
+}
+
+static int icp_grid(int64_t nt) {
+  int64_t blocks = (nt + kIcpBlock - 1) / kIcpBlock;
+  int64_t cap = (int64_t)ctx().num_cu * 4;  // 4 blocks of 256 threads per CU fit the LDS stacks
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+static pcgx_status reset_state(pcgx_icp_session *s, hipStream_t st) {
+  IcpState h;
+  memset(&h, 0, sizeof h);
+  Mat4 id = mat4_translate(0.0f, 0.0f, 0.0f);  // icp.go:47
+  memcpy(h.trans, id.m, sizeof id.m);
+  PCGX_HIP_TRY(hipMemcpyAsync(s->d_state, &h, sizeof h, hipMemcpyHostToDevice, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));  // h is a stack temporary
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_session_reset(pcgx_icp_session *s, void *stream) {
+  if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_reset: NULL session");
+  return reset_state(s, pick_stream(stream));
+}
+
+extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
+  if (!s) return PCGX_OK;
+  if (s->d_xyz) (void)hipFree(s->d_xyz);
+  if (s->d_state) (void)hipFree(s->d_state);
+  if (s->d_partials) (void)hipFree(s->d_partials);
+  if (s->own_sums && s->d_sums) (void)hipFree(s->d_sums);
+  delete s;
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const float *target,
+                                               int64_t nt, int32_t target_on_device,
+                                               const pcgx_icp_params *params, double *d_sums10,
+                                               pcgx_icp_session **out) {
+  if (!out) return fail(PCGX_E_INVALID, "pcgx_icp_session_create: out is NULL");
+  *out = nullptr;
+  if (!base || !params || nt < 0 || (nt > 0 && !target))
+    return fail(PCGX_E_INVALID, "pcgx_icp_session_create: bad argument");
+  PCGX_TRY(ensure_init());
+  hipStream_t st = ctx().stream;
+  pcgx_icp_session *s = new pcgx_icp_session();
+  s->base = base;
+  s->nt = nt;
+  s->kp = make_kernel_params(params);
+  s->max_iteration = s->kp.upd.max_iteration;
+  s->grid = icp_grid(nt);
+  pcgx_status rc = PCGX_OK;
+  auto bail = [&](pcgx_status code) {
+    pcgx_icp_session_free(s);
+    return code;
+  };
+  hipError_t e;
+  if ((e = hipMalloc((void **)&s->d_xyz, (size_t)(nt ? nt : 1) * 12)) != hipSuccess ||
+      (e = hipMalloc((void **)&s->d_state, sizeof(IcpState))) != hipSuccess ||
+      (e = hipMalloc((void **)&s->d_partials, (size_t)s->grid * S_COUNT * sizeof(double))) != hipSuccess)
+    return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
+  if (d_sums10) {
+    s->d_sums = d_sums10;
+  } else {
+    if ((e = hipMalloc((void **)&s->d_sums, S_COUNT * sizeof(double))) != hipSuccess)
+      return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
+    s->own_sums = true;
+  }
+  if ((rc = reset_state(s, st)) != PCGX_OK) return bail(rc);
+  if (nt > 0) {
+    Arena &ar = ctx().arena;
+    if ((rc = ar.begin(st)) != PCGX_OK) return bail(rc);
+    const float *d_q = target;
+    if (!target_on_device) {
+      float *stage = nullptr;
+      if ((rc = ar.alloc_n((size_t)nt * 3, &stage)) != PCGX_OK) return bail(rc);
+      if ((e = hipMemcpyAsync(stage, target, (size_t)nt * 12, hipMemcpyHostToDevice, st)) != hipSuccess)
+        return bail(fail(PCGX_E_HIP, "target upload failed: %s", hipGetErrorString(e)));
+      d_q = stage;
+    }
+    int32_t *perm = nullptr;
+    if (nt > 1) {
+      if ((rc = ar.alloc_n((size_t)nt, &perm)) != PCGX_OK) return bail(rc);
+      if ((rc = morton_order(d_q, nt, perm, st)) != PCGX_OK) return bail(rc);
+    }
+    hipLaunchKernelGGL(gather_soa_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d_q, perm, nt,
+                       s->d_xyz, s->d_xyz + nt, s->d_xyz + 2 * nt);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess)
+      return bail(fail(PCGX_E_HIP, "icp session setup failed: %s", hipGetErrorString(e)));
+  }
+  *out = s;
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stream) {
+  if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_partials: NULL session");
+  hipStream_t st = pick_stream(stream);
+  const TreeView tv = s->base->view();
+  const size_t lds = walk_stack_bytes(tv, kIcpBlock);
+  const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
+  {
+    ProfScope prof(PCGX_PROF_ICP_WALK, st);
+    if (s->kp.min_dist_sq > 0.0f)
+      hipLaunchKernelGGL(icp_partials_kernel<true>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
+                         s->d_state, s->kp, s->d_partials);
+    else
+      hipLaunchKernelGGL(icp_partials_kernel<false>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
+                         s->d_state, s->kp, s->d_partials);
+  }
+  hipLaunchKernelGGL(icp_final_reduce_kernel, dim3(1), dim3(256), 0, st, s->d_partials, s->grid, s->d_state,
+                     s->d_sums);
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream) {
+  if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_update: NULL session");
+  hipStream_t st = pick_stream(stream);
+  hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(64), 0, st, s->d_state, s->d_sums, s->kp);
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream, float trans16[16],
+                                               pcgx_icp_stat *stat, int32_t *converged) {
+  if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_result: NULL session");
+  hipStream_t st = pick_stream(stream);
+  IcpState h;
+  PCGX_HIP_TRY(hipMemcpyAsync(&h, s->d_state, sizeof h, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  if (trans16) memcpy(trans16, h.trans, sizeof h.trans);
+  if (stat) {
+    stat->evaluated.value = h.ev.value;
+    memcpy(stat->evaluated.gradient, h.ev.gradient, sizeof h.ev.gradient);
+    stat->evaluated.dist_rms = h.ev.dist_rms;
+    stat->evaluated.num_pairs = h.ev.num_pairs;
+    stat->num_iteration = h.num_iteration;
+  }
+  if (converged) *converged = (h.done && h.status == PCGX_OK) ? 1 : 0;
+  if (h.status == PCGX_E_NOT_ENOUGH_PAIRS)
+    return fail(PCGX_E_NOT_ENOUGH_PAIRS, "not enough correspondence pairs (%lld < %d) at iteration %d",
+                (long long)h.ev.num_pairs, s->kp.min_pairs, h.num_iteration);
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target, int64_t nt,
+                                    const pcgx_icp_params *params, float trans16[16],
+                                    pcgx_icp_stat *stat) {
+  if (!base || !params || !trans16) return fail(PCGX_E_INVALID, "pcgx_icp_fit: NULL argument");
+  pcgx_icp_session *s = nullptr;
+  PCGX_TRY(pcgx_icp_session_create(base, target, nt, 0, params, nullptr, &s));
+  pcgx_status rc = PCGX_OK;
+  // At most MaxIteration evaluations can happen (updater.go:69-70); once the
+  // device-side state is `done` the remaining launches return immediately.
+  for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) {
+    rc = pcgx_icp_session_partials(s, nullptr);
+    if (rc == PCGX_OK) rc = pcgx_icp_session_update(s, nullptr);
+  }
+  if (rc == PCGX_OK) rc = pcgx_icp_session_result(s, nullptr, trans16, stat, nullptr);
+  pcgx_icp_session_free(s);
+  return rc;
+}
+
+extern "C" pcgx_status pcgx_icp_evaluate(const pcgx_kdtree *base, const float *target, int64_t nt,
+                                         float max_dist, float min_dist_sq, int32_t min_pairs,
+                                         pcgx_icp_evaluated *out) {
+  if (!base || !out) return fail(PCGX_E_INVALID, "pcgx_icp_evaluate: NULL argument");
+  pcgx_icp_params p;
+  memset(&p, 0, sizeof p);
+  p.max_dist = max_dist;
+  p.min_dist_sq = min_dist_sq;
+  p.min_pairs = min_pairs;
+  pcgx_icp_session *s = nullptr;
+  PCGX_TRY(pcgx_icp_session_create(base, target, nt, 0, &p, nullptr, &s));
+  pcgx_status rc = pcgx_icp_session_partials(s, nullptr);
+  double sums[S_COUNT];
+  if (rc == PCGX_OK) {
+    hipError_t e = hipMemcpyAsync(sums, s->d_sums, sizeof sums, hipMemcpyDeviceToHost, ctx().stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx().stream);
+    if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_icp_evaluate: %s", hipGetErrorString(e));
+  }
+  pcgx_icp_session_free(s);
+  if (rc != PCGX_OK) return rc;
+  return pcgx_icp_finish_evaluate(sums, min_pairs, out);
+}
+
+extern "C" pcgx_status pcgx_icp_pairs(const pcgx_kdtree *base, const float *target, int64_t nt,
+                                      float max_dist, float min_dist_sq, int64_t *base_id,
+                                      int64_t *target_id, float *dist_sq, int64_t *npairs) {
+  if (!base || !npairs || nt < 0 || (nt > 0 && (!target || !base_id || !target_id || !dist_sq)))
+    return fail(PCGX_E_INVALID, "pcgx_icp_pairs: bad argument");
+  *npairs = 0;
+  if (nt == 0) return PCGX_OK;
+  std::vector<int64_t> ids((size_t)nt);
+  std::vector<float> dsq((size_t)nt);
+  PCGX_TRY(pcgx_kdtree_nearest_batch(base, target, nt, max_dist, min_dist_sq, ids.data(), dsq.data()));
+  int64_t m = 0;
+  for (int64_t i = 0; i < nt; i++) {  // order-preserving compaction (correspondence.go:25-36)
+    if (ids[i] < 0) continue;
+    base_id[m] = ids[i];
+    target_id[m] = i;
+    dist_sq[m] = dsq[i];
+    m++;
+  }
+  *npairs = m;
+  return PCGX_OK;
+}

@@ -1,0 +1,193 @@
+// knn.hip -- batched KDTree.Nearest on gfx950 + the pcgx_kdtree_* C ABI.
+// Reference: pc/storage/kdtree/kdtree.go (New :33-56, Nearest :83-146).
+#include <string.h>
+
+#include <vector>
+
+#include "knn_walk.h"
+
+namespace pcgx {
+
+// One query per lane.  Queries are packed xyz (AoS, 12 B): a wave reads 768
+// contiguous bytes.  `perm` (optional) maps the launch position to the query
+// index (Morton order, see morton.hip): results are written at the original
+// index so the permutation is invisible to the caller.
+template <bool kMinDist>
+__global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const float *__restrict__ q,
+                                                            const int32_t *__restrict__ perm,
+                                                            int64_t nq, float max_range_sq,
+                                                            float min_dist_sq,
+                                                            int32_t *__restrict__ out_id,
+                                                            float *__restrict__ out_dsq) {
+  extern __shared__ uint2 s_stack[];
+  const int64_t pos = (int64_t)blockIdx.x * kKnnBlock + threadIdx.x;
+  if (pos >= nq) return;
+  const int64_t i = perm ? (int64_t)perm[pos] : pos;
+  const float qx = q[3 * i + 0], qy = q[3 * i + 1], qz = q[3 * i + 2];
+  WalkResult r = nearest_walk<kMinDist>(tv, s_stack + threadIdx.x, kKnnBlock, qx, qy, qz,
+                                        max_range_sq, min_dist_sq);
+  out_id[i] = r.id;
+  out_dsq[i] = r.dist_sq;
+}
+
+pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *d_perm, int64_t nq,
+                           float max_range_sq, float min_dist_sq, int32_t *d_ids, float *d_dsq,
+                           hipStream_t st) {
+  if (nq == 0) return PCGX_OK;
+  const size_t lds = walk_stack_bytes(tv, kKnnBlock);
+  const int64_t blocks = (nq + kKnnBlock - 1) / kKnnBlock;
+  if (blocks > 0x7fffffff) return fail(PCGX_E_INVALID, "too many queries in one batch: %lld", (long long)nq);
+  ProfScope prof(PCGX_PROF_KNN_WALK, st);
+  // `x < MinDistSq` can only hold for MinDistSq > 0 (or NaN distances, which compare false).
+  if (min_dist_sq > 0.0f)
+    hipLaunchKernelGGL(nearest_kernel<true>, dim3((unsigned)blocks), dim3(kKnnBlock), lds, st, tv, d_q,
+                       d_perm, nq, max_range_sq, min_dist_sq, d_ids, d_dsq);
+  else
+    hipLaunchKernelGGL(nearest_kernel<false>, dim3((unsigned)blocks), dim3(kKnnBlock), lds, st, tv, d_q,
+                       d_perm, nq, max_range_sq, min_dist_sq, d_ids, d_dsq);
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
+}  // namespace pcgx
+
+using namespace pcgx;
+
+namespace {
+// Device staging of a host-pointer call (plain hipMalloc: these calls are
+// dominated by the PCIe copies anyway; the arena is reserved for the _dev path
+// so that nested _dev calls may reset it).
+struct HostCallBufs {
+  float *q = nullptr;
+  int32_t *ids = nullptr;
+  float *dsq = nullptr;
+  ~HostCallBufs() {
+    if (q) (void)hipFree(q);
+    if (ids) (void)hipFree(ids);
+    if (dsq) (void)hipFree(dsq);
+  }
+  pcgx_status alloc(int64_t nq) {
+    PCGX_HIP_TRY(hipMalloc((void **)&q, (size_t)nq * 12));
+    PCGX_HIP_TRY(hipMalloc((void **)&ids, (size_t)nq * 4));
+    PCGX_HIP_TRY(hipMalloc((void **)&dsq, (size_t)nq * 4));
+    return PCGX_OK;
+  }
+};
+}  // namespace
+
+// ------------------------------------------------------------------ C ABI
+
+extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t stride,
+                                         int32_t xyz_off, pcgx_kdtree **out) {
+  if (!out) return fail(PCGX_E_INVALID, "pcgx_kdtree_build: out is NULL");
+  *out = nullptr;
+  if (n < 0 || (n > 0 && !data)) return fail(PCGX_E_INVALID, "pcgx_kdtree_build: bad data/n");
+  if (n == 0) return fail(PCGX_E_NO_POINT, "pcgx_kdtree_build: empty cloud (kdtree.New panics in the reference)");
+  if (stride < 12 || xyz_off < 0 || xyz_off + 12 > stride)
+    return fail(PCGX_E_BAD_FIELD, "pcgx_kdtree_build: stride %d / xyz offset %d do not hold an xyz triple", stride, xyz_off);
+  if (n > kMaxTreePoints) return fail(PCGX_E_TOO_LARGE, "pcgx_kdtree_build: %lld points > 2^26", (long long)n);
+  PCGX_TRY(ensure_init());
+  pcgx_kdtree *t = new pcgx_kdtree();
+  t->n = n;
+  t->depth = tree_depth(n);
+  t->points.resize((size_t)n * 3);
+  const uint8_t *src = (const uint8_t *)data;
+  for (int64_t i = 0; i < n; i++) memcpy(&t->points[3 * i], src + i * (int64_t)stride + xyz_off, 12);
+  t->inorder.resize((size_t)n);
+  build_inorder(t->points.data(), n, t->inorder.data());
+  std::vector<float4> nodes((size_t)n);
+  for (int64_t i = 0; i < n; i++) {
+    int32_t id = t->inorder[i];
+    nodes[i] = make_float4(t->points[3 * (int64_t)id], t->points[3 * (int64_t)id + 1],
+                           t->points[3 * (int64_t)id + 2], __builtin_bit_cast(float, id));
+  }
+  hipError_t e = hipMalloc((void **)&t->d_nodes, (size_t)n * sizeof(float4));
+  if (e != hipSuccess) {
+    delete t;
+    return fail(PCGX_E_OOM, "hipMalloc for %lld tree nodes failed: %s", (long long)n, hipGetErrorString(e));
+  }
+  e = hipMemcpy(t->d_nodes, nodes.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    (void)hipFree(t->d_nodes);
+    delete t;
+    return fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
+  }
+  *out = t;
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_kdtree_free(pcgx_kdtree *t) {
+  if (!t) return PCGX_OK;
+  if (t->d_nodes) (void)hipFree(t->d_nodes);
+  delete t;
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_kdtree_len(const pcgx_kdtree *t, int64_t *n) {
+  if (!t || !n) return fail(PCGX_E_INVALID, "pcgx_kdtree_len: NULL argument");
+  *n = t->n;
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_kdtree_max_depth(const pcgx_kdtree *t, int32_t *depth) {
+  if (!t || !depth) return fail(PCGX_E_INVALID, "pcgx_kdtree_max_depth: NULL argument");
+  *depth = t->depth;
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_kdtree_inorder(const pcgx_kdtree *t, int64_t *ids) {
+  if (!t || !ids) return fail(PCGX_E_INVALID, "pcgx_kdtree_inorder: NULL argument");
+  for (int64_t i = 0; i < t->n; i++) ids[i] = t->inorder[i];
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_kdtree_points(const pcgx_kdtree *t, const int64_t *ids, int64_t m,
+                                          float *xyz) {
+  if (!t || (m > 0 && (!ids || !xyz))) return fail(PCGX_E_INVALID, "pcgx_kdtree_points: NULL argument");
+  for (int64_t i = 0; i < m; i++) {
+    if (ids[i] < 0 || ids[i] >= t->n) return fail(PCGX_E_INVALID, "pcgx_kdtree_points: id %lld out of range", (long long)ids[i]);
+    memcpy(xyz + 3 * i, &t->points[3 * ids[i]], 12);
+  }
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_kdtree_nearest_batch_dev(const pcgx_kdtree *t, const float *d_q,
+                                                     int64_t nq, float max_range,
+                                                     float min_dist_sq, uint32_t flags,
+                                                     int32_t *d_ids, float *d_dist_sq,
+                                                     void *stream) {
+  if (!t || nq < 0 || (nq > 0 && (!d_q || !d_ids || !d_dist_sq)))
+    return fail(PCGX_E_INVALID, "pcgx_kdtree_nearest_batch_dev: bad argument");
+  PCGX_TRY(ensure_init());
+  hipStream_t st = pick_stream(stream);
+  const float max_range_sq = max_range * max_range;  // kdtree.go:91
+  if ((flags & PCGX_KNN_PRESORT) && nq > 1) {
+    PCGX_TRY(ctx().arena.begin(st));
+    int32_t *perm = nullptr;
+    PCGX_TRY(ctx().arena.alloc_n((size_t)nq, &perm));
+    PCGX_TRY(morton_order(d_q, nq, perm, st));
+    return launch_nearest(t->view(), d_q, perm, nq, max_range_sq, min_dist_sq, d_ids, d_dist_sq, st);
+  }
+  return launch_nearest(t->view(), d_q, nullptr, nq, max_range_sq, min_dist_sq, d_ids, d_dist_sq, st);
+}
+
+extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const float *q, int64_t nq,
+                                                 float max_range, float min_dist_sq, int64_t *ids,
+                                                 float *dist_sq) {
+  if (!t || nq < 0 || (nq > 0 && (!q || !ids || !dist_sq)))
+    return fail(PCGX_E_INVALID, "pcgx_kdtree_nearest_batch: bad argument");
+  if (nq == 0) return PCGX_OK;
+  PCGX_TRY(ensure_init());
+  hipStream_t st = ctx().stream;
+  HostCallBufs b;
+  PCGX_TRY(b.alloc(nq));
+  PCGX_HIP_TRY(hipMemcpyAsync(b.q, q, (size_t)nq * 12, hipMemcpyHostToDevice, st));
+  PCGX_TRY(pcgx_kdtree_nearest_batch_dev(t, b.q, nq, max_range, min_dist_sq,
+                                         nq >= 4096 ? PCGX_KNN_PRESORT : 0u, b.ids, b.dsq, st));
+  std::vector<int32_t> h_id((size_t)nq);
+  PCGX_HIP_TRY(hipMemcpyAsync(h_id.data(), b.ids, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipMemcpyAsync(dist_sq, b.dsq, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  for (int64_t i = 0; i < nq; i++) ids[i] = h_id[i];
+  return PCGX_OK;
+}

@@ -1,0 +1,130 @@
+// pcgx_internal.h -- library-internal declarations (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pcgx.h"
+#include "pcgx_math.h"
+
+namespace pcgx {
+
+// ---- error handling --------------------------------------------------------
+pcgx_status fail(pcgx_status code, const char *fmt, ...);
+
+#define PCGX_HIP_TRY(expr)                                                             \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess)                                                             \
+      return ::pcgx::fail(e__ == hipErrorOutOfMemory ? PCGX_E_OOM : PCGX_E_HIP,        \
+                          "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),      \
+                          __FILE__, __LINE__);                                         \
+  } while (0)
+
+#define PCGX_TRY(expr)                 \
+  do {                                 \
+    pcgx_status s__ = (expr);          \
+    if (s__ != PCGX_OK) return s__;    \
+  } while (0)
+
+// ---- workspace arena -------------------------------------------------------
+// Call-scoped device temporaries are bump-allocated from a grow-only arena so
+// that steady-state calls perform no hipMalloc/hipFree.  begin() is called on
+// entry of every API function that needs temporaries; work enqueued by the
+// previous call on the same stream is ordered before the new work, so reuse
+// is safe.  If a block overflows, a new one is added and the blocks are
+// consolidated at the next begin() (hipFree synchronises the device).
+class Arena {
+ public:
+  pcgx_status begin(hipStream_t st);
+  pcgx_status alloc(size_t bytes, void **out);
+  template <class T>
+  pcgx_status alloc_n(size_t count, T **out) {
+    return alloc(count * sizeof(T), (void **)out);
+  }
+  void release_all();
+
+ private:
+  struct Block {
+    uint8_t *p;
+    size_t cap, used;
+  };
+  std::vector<Block> blocks_;
+  hipStream_t last_stream_ = nullptr;
+  bool has_last_ = false;
+};
+
+// ---- kernel timing (pcgx_prof_*) ---------------------------------------------
+struct ProfScope {
+  ProfScope(int kind, hipStream_t st);
+  ~ProfScope();
+  int kind_;
+  hipStream_t st_;
+  hipEvent_t a_ = nullptr, b_ = nullptr;
+};
+
+// ---- context ---------------------------------------------------------------
+struct Context {
+  bool ready = false;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  int num_cu = 256;
+  Arena arena;
+};
+Context &ctx();
+pcgx_status ensure_init();
+inline hipStream_t pick_stream(void *s) { return s ? (hipStream_t)s : ctx().stream; }
+
+// ---- KD-tree ---------------------------------------------------------------
+// Device layout (DESIGN.md "KD-tree"): the reference's recursively sorted
+// indice slice (kdtree.go:348-370) IS the tree: the node of range [lo,hi) is
+// element lo + (hi-lo)/2, children are [lo,mid) and [mid+1,hi), dim = depth%3.
+// nodes[i] = {x, y, z, bits(id)} of the i-th point in that in-order sequence.
+constexpr int64_t kMaxTreePoints = (int64_t)1 << 26;  // frame encoding: 26-bit node index
+
+struct TreeView {
+  const float4 *nodes;
+  int32_t n;
+  int32_t depth;  // node.maxDepth(0) = floor(log2 n) + 1
+};
+
+// kdtree_build.cpp
+void build_inorder(const float *xyz, int64_t n, int32_t *inorder_ids);
+inline int32_t tree_depth(int64_t n) {
+  int32_t d = 0;
+  while (n > 0) { d++; n >>= 1; }
+  return d;
+}
+
+// knn.hip
+constexpr int kKnnBlock = 256;  // 4 waves; LDS = (depth-1) * 256 * 8 B (38 KB at 1M points)
+inline size_t walk_stack_bytes(const TreeView &tv, int block) {
+  int levels = tv.depth > 1 ? tv.depth - 1 : 1;
+  return (size_t)levels * block * sizeof(uint2);
+}
+pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *d_perm, int64_t nq,
+                           float max_range_sq, float min_dist_sq, int32_t *d_ids, float *d_dsq,
+                           hipStream_t st);
+
+// sort.hip
+size_t radix_sort_workspace_bytes(int64_t n);
+pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, int key_bits,
+                             void *workspace, int *result, hipStream_t st);
+pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
+                          hipStream_t st);
+// perm[pos] = index of the point visited at position pos (Morton order).  Uses the arena.
+pcgx_status morton_order(const float *d_q, int64_t n, int32_t *d_perm, hipStream_t st);
+
+}  // namespace pcgx
+
+struct pcgx_kdtree {
+  int64_t n = 0;
+  int32_t depth = 0;
+  float4 *d_nodes = nullptr;       // [n] in-order nodes
+  std::vector<int32_t> inorder;    // host copy of the in-order ids
+  std::vector<float> points;       // host copy of xyz (accessor order), for Vec3At
+  pcgx::TreeView view() const { return pcgx::TreeView{d_nodes, (int32_t)n, depth}; }
+};

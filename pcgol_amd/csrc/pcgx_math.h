@@ -1,0 +1,178 @@
+// pcgx_math.h -- float32 pose arithmetic shared by host code and device kernels.
+//
+// Restates (product side; the test oracle has its own, separate restatement)
+// the O(1) per-iteration arithmetic of the reference's ICP loop exactly as Go
+// evaluates it on amd64: float32, left to right, no FMA (build with
+// -ffp-contract=off), float64 only where the Go code converts
+// (math.Sqrt/Sin/Cos).  Paths are relative to the reference repository root.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define PCGX_HD __host__ __device__ inline
+#else
+#define PCGX_HD inline
+#endif
+
+namespace pcgx {
+
+struct Mat4 {
+  float m[16];  // column-major: m[4*col + row]   (mat/mat4.go:8-10)
+};
+
+// mat/transform.go:7-14
+PCGX_HD Mat4 mat4_translate(float x, float y, float z) {
+  Mat4 r;
+  for (int i = 0; i < 16; i++) r.m[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+  r.m[12] = x;
+  r.m[13] = y;
+  r.m[14] = z;
+  return r;
+}
+
+// mat/mat4.go:16-28: out[4j+i] = sum_k m[4k+i]*a[4j+k], accumulated from 0 in k order
+PCGX_HD Mat4 mat4_mul(const Mat4 &m, const Mat4 &a) {
+  Mat4 o;
+  for (int i = 0; i < 4; i++)
+    for (int j = 0; j < 4; j++) {
+      float s = 0.0f;
+      for (int k = 0; k < 4; k++) s = s + m.m[4 * k + i] * a.m[4 * j + k];
+      o.m[4 * j + i] = s;
+    }
+  return o;
+}
+
+// mat/mat4.go:30-36 and :38-44
+PCGX_HD Mat4 mat4_factor(const Mat4 &m, float f) {
+  Mat4 o;
+  for (int i = 0; i < 16; i++) o.m[i] = m.m[i] * f;
+  return o;
+}
+PCGX_HD Mat4 mat4_add(const Mat4 &m, const Mat4 &a) {
+  Mat4 o;
+  for (int i = 0; i < 16; i++) o.m[i] = m.m[i] + a.m[i];
+  return o;
+}
+
+// mat/mat4.go:130-137 Mat4.Transform: projective, w = 1/(m3 x + m7 y + m11 z + m15)
+PCGX_HD void mat4_transform(const float *m, float x, float y, float z, float &ox, float &oy,
+                            float &oz) {
+  float w = 1.0f / (((m[3] * x + m[7] * y) + m[11] * z) + m[15]);
+  ox = (((m[0] * x + m[4] * y) + m[8] * z) + m[12]) * w;
+  oy = (((m[1] * x + m[5] * y) + m[9] * z) + m[13]) * w;
+  oz = (((m[2] * x + m[6] * y) + m[10] * z) + m[14]) * w;
+}
+
+// mat/vec3.go:18-20
+PCGX_HD float norm_sq3(float a, float b, float c) { return (a * a + b * b) + c * c; }
+
+// icp/rodrigues.go:11-33
+PCGX_HD Mat4 rodrigues_to_rotation(float v0, float v1, float v2) {
+  float ang = (float)sqrt((double)norm_sq3(v0, v1, v2));  // Vec3.Norm, mat/vec3.go:22-24
+  Mat4 r;
+  for (int i = 0; i < 16; i++) r.m[i] = 0.0f;
+  r.m[1] = v2;  r.m[2] = -v1;
+  r.m[4] = -v2; r.m[6] = v0;
+  r.m[8] = v1;  r.m[9] = -v0;
+  Mat4 id = mat4_translate(0.0f, 0.0f, 0.0f);
+  float f0, f1;
+  if (ang < 0.1f) {
+    f0 = 1.0f;
+    f1 = 0.5f;
+  } else {
+    f0 = (float)sin((double)ang) / ang;
+    f1 = (float)(1.0 - cos((double)ang)) / (ang * ang);
+  }
+  return mat4_add(mat4_add(id, mat4_factor(r, f0)), mat4_factor(mat4_mul(r, r), f1));
+}
+
+// The 10 per-iteration sums: order fixed across the library.
+enum { S_VALUE = 0, S_G0 = 1, S_DIST_RMS = 7, S_WEIGHT = 8, S_PAIRS = 9, S_COUNT = 10 };
+
+struct Evaluated {
+  float value;
+  float gradient[6];
+  float dist_rms;
+  int64_t num_pairs;
+};
+
+// icp/evaluator.go:156-186: normalise by 1/sum(w) (only if > 1), gradient by
+// 2f, DistRMS = sqrt(.), rotation limiter.  The sums arrive as float64
+// (device reduction) and are rounded to float32 first: from here on the
+// arithmetic is the reference's float32 sequence.
+PCGX_HD void finish_evaluate(const double *sums, Evaluated &ev) {
+  float value = (float)sums[S_VALUE];
+  float sum_weight = (float)sums[S_WEIGHT];
+  float dist_rms = (float)sums[S_DIST_RMS];
+  float g[6];
+  for (int i = 0; i < 6; i++) g[i] = (float)sums[S_G0 + i];
+  float f = 1.0f;
+  if (sum_weight > 1.0f) f = 1.0f / sum_weight;
+  value = value * f;
+  float f2 = 2.0f * f;
+  for (int i = 0; i < 6; i++) g[i] = g[i] * f2;
+  dist_rms = (float)sqrt((double)(dist_rms * f));
+  float rot_limit = 1.0f;
+  float dist = (float)sqrt((double)value);
+  for (int i = 3; i < 6; i++) {
+    float d = g[i] * dist_rms;
+    if (d < 0.0f) d = -d;
+    if (dist < d) {
+      float l = dist / d;
+      if (rot_limit > l) rot_limit = l;
+    }
+  }
+  for (int i = 3; i < 6; i++) g[i] = g[i] * rot_limit;
+  ev.value = value;
+  for (int i = 0; i < 6; i++) ev.gradient[i] = g[i];
+  ev.dist_rms = dist_rms;
+  ev.num_pairs = (int64_t)sums[S_PAIRS];
+}
+
+struct UpdaterParams {
+  float weight[6];
+  float threshold[6];
+  int32_t max_iteration;
+};
+
+// icp/updater.go:15-37 factory defaults: all-zero vectors / zero count select
+// 0.3 / 0.01 / 20.
+PCGX_HD UpdaterParams resolve_updater(const float *weight, const float *threshold,
+                                      int32_t max_iteration) {
+  UpdaterParams u;
+  bool wz = true, tz = true;
+  for (int i = 0; i < 6; i++) {
+    if (weight[i] != 0.0f) wz = false;
+    if (threshold[i] != 0.0f) tz = false;
+  }
+  for (int i = 0; i < 6; i++) {
+    u.weight[i] = wz ? 0.3f : weight[i];
+    u.threshold[i] = tz ? 0.01f : threshold[i];
+  }
+  u.max_iteration = max_iteration == 0 ? 20 : max_iteration;
+  return u;
+}
+
+// icp/updater.go:44-71 gradientDescentUpdater.Update.  Returns converged.
+PCGX_HD bool gradient_descent_update(const UpdaterParams &u, int32_t &iter, const float *g,
+                                     Mat4 &trans) {
+  bool flat = true;
+  for (int j = 0; j < 6; j++) {
+    if (g[j] < -u.threshold[j] || u.threshold[j] < g[j]) {
+      flat = false;
+      break;
+    }
+  }
+  if (flat) return true;
+  float factor_iter = -(1.0f - ((float)iter / (float)u.max_iteration));
+  float d[6];
+  for (int j = 0; j < 6; j++) d[j] = (factor_iter * u.weight[j]) * g[j];
+  Mat4 delta_trans = mat4_translate(d[0], d[1], d[2]);
+  Mat4 delta_rot = rodrigues_to_rotation(d[3], d[4], d[5]);
+  trans = mat4_mul(delta_trans, mat4_mul(delta_rot, trans));
+  iter = iter + 1;
+  return iter >= u.max_iteration;
+}
+
+}  // namespace pcgx

@@ -1,0 +1,384 @@
+// sort.hip -- stable LSD radix sort of (key32, value32) pairs for gfx950, and
+// the Morton ordering of query points built on it.
+//
+// Used by (a) the voxel filter: points sorted by dense voxel index keep their
+// input order inside a voxel (stability), which is what makes the sequential
+// float32 centroid sum of the reference (voxelgrid.go:157) reproducible;
+// (b) the kNN / ICP paths: queries are walked in Morton order so the lanes of
+// a wave traverse neighbouring sub-trees (results are written back in the
+// caller's order).
+//
+// One pass = histogram kernel (LDS bins) -> two tiny scan kernels -> scatter
+// kernel.  The scatter kernel ranks a 4096-element tile with wave64 ballots
+// (8 per element round: a match-any on the 8-bit digit), re-orders the tile in
+// LDS by digit and writes each digit run contiguously, so global writes are
+// coalesced runs rather than 4-byte scatters.
+#include "pcgx_internal.h"
+
+namespace pcgx {
+
+constexpr int kRsThreads = 256;
+constexpr int kRsItems = 16;
+constexpr int kRsTile = kRsThreads * kRsItems;  // 4096 elements per block
+constexpr int kRsWaves = kRsThreads / 64;
+constexpr int kRsWaveChunk = kRsTile / kRsWaves;  // 1024 contiguous elements per wave
+constexpr int kRadix = 256;
+
+__global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t *__restrict__ keys, int64_t n,
+                                                             int shift, uint32_t *__restrict__ block_hist,
+                                                             int nblocks) {
+  __shared__ uint32_t hist[kRadix];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kRsTile;
+#pragma unroll
+  for (int r = 0; r < kRsItems; r++) {
+    int64_t i = base + r * kRsThreads + threadIdx.x;
+    if (i < n) atomicAdd(&hist[(keys[i] >> shift) & (kRadix - 1)], 1u);
+  }
+  __syncthreads();
+  block_hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+// Block b turns row b (one digit, all tiles) into its exclusive prefix and
+// records the row total.
+__global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t *__restrict__ block_hist,
+                                                                  int nblocks, uint32_t *__restrict__ totals) {
+  __shared__ uint32_t wave_sum[kRsWaves];
+  __shared__ uint32_t carry_s;
+  uint32_t *row = block_hist + (int64_t)blockIdx.x * nblocks;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int start = 0; start < nblocks; start += kRsThreads) {
+    int i = start + threadIdx.x;
+    uint32_t v = i < nblocks ? row[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += wave_sum[w];
+    uint32_t carry = carry_s;
+    if (i < nblocks) row[i] = carry + wbase + inc - v;
+    __syncthreads();
+    if (threadIdx.x == kRsThreads - 1) carry_s = carry + wbase + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+__global__ __launch_bounds__(kRadix) void rs_scan_totals_kernel(const uint32_t *__restrict__ totals,
+                                                                uint32_t *__restrict__ base) {
+  __shared__ uint32_t wave_sum[kRadix / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t v = totals[threadIdx.x], inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wave_sum[wave] = inc;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int w = 0; w < wave; w++) wbase += wave_sum[w];
+  base[threadIdx.x] = wbase + inc - v;
+}
+
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n, int shift,
+    const uint32_t *__restrict__ block_hist, int nblocks, const uint32_t *__restrict__ base,
+    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+  __shared__ uint32_t cnt[kRsWaves][kRadix];
+  __shared__ uint32_t tile_pref[kRadix];
+  __shared__ uint32_t gbase[kRadix];
+  __shared__ uint32_t wave_sum[kRsWaves];
+  __shared__ uint32_t skeys[kRsTile];
+  __shared__ uint32_t svals[kRsTile];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile_base = (int64_t)blockIdx.x * kRsTile;
+  const int64_t wave_base = tile_base + (int64_t)wave * kRsWaveChunk;
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+
+#pragma unroll
+  for (int w = 0; w < kRsWaves; w++) cnt[w][threadIdx.x] = 0;
+  __syncthreads();
+
+  uint32_t key[kRsItems], val[kRsItems];
+  uint32_t rank[kRsItems];
+  volatile uint32_t *my_cnt = cnt[wave];
+#pragma unroll
+  for (int r = 0; r < kRsItems; r++) {
+    const int64_t i = wave_base + r * 64 + lane;
+    const bool valid = i < n;
+    key[r] = valid ? keys_in[i] : 0u;
+    val[r] = valid ? vals_in[i] : 0u;
+    const uint32_t d = (key[r] >> shift) & (kRadix - 1);
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    // m = lanes of this wave holding the same digit (valid lanes only)
+    uint32_t prev = 0;
+    if (valid) prev = my_cnt[d];
+    rank[r] = prev + (uint32_t)__popcll(m & lt_mask);
+    __builtin_amdgcn_wave_barrier();
+    if (valid && (m >> lane) == 1ull) my_cnt[d] = prev + (uint32_t)__popcll(m);  // highest lane of the group
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+
+  // digit t: per-wave exclusive offsets, tile total, exclusive prefix over digits
+  {
+    const int t = threadIdx.x;
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < kRsWaves; w++) {
+      uint32_t c = cnt[w][t];
+      cnt[w][t] = run;
+      run += c;
+    }
+    uint32_t inc = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t x = __shfl_up(inc, o);
+      if (lane >= o) inc += x;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += wave_sum[w];
+    const uint32_t excl = wbase + inc - run;
+    tile_pref[t] = excl;
+    gbase[t] = base[t] + block_hist[(int64_t)t * nblocks + blockIdx.x] - excl;  // dst = gbase[d] + pos
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int r = 0; r < kRsItems; r++) {
+    const int64_t i = wave_base + r * 64 + lane;
+    if (i < n) {
+      const uint32_t d = (key[r] >> shift) & (kRadix - 1);
+      const uint32_t pos = tile_pref[d] + cnt[wave][d] + rank[r];
+      skeys[pos] = key[r];
+      svals[pos] = val[r];
+    }
+  }
+  __syncthreads();
+
+  const int64_t rem = n - tile_base;
+  const int count = rem < kRsTile ? (int)rem : kRsTile;
+  for (int p = threadIdx.x; p < count; p += kRsThreads) {
+    const uint32_t k = skeys[p];
+    const uint32_t d = (k >> shift) & (kRadix - 1);
+    const uint32_t dst = gbase[d] + (uint32_t)p;
+    keys_out[dst] = k;
+    vals_out[dst] = svals[p];
+  }
+}
+
+size_t radix_sort_workspace_bytes(int64_t n) {
+  int64_t nblocks = (n + kRsTile - 1) / kRsTile;
+  return (size_t)(nblocks * kRadix + 2 * kRadix) * sizeof(uint32_t);
+}
+
+// Sorts pairs by key bits [0, key_bits).  keys[0]/vals[0] hold the input;
+// *result is the index (0/1) of the buffers holding the output.
+pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, int key_bits,
+                             void *workspace, int *result, hipStream_t st) {
+  *result = 0;
+  if (n <= 1 || key_bits <= 0) return PCGX_OK;
+  if (n > 0x7fffffffll) return fail(PCGX_E_INVALID, "radix sort: n too large");
+  const int nblocks = (int)((n + kRsTile - 1) / kRsTile);
+  uint32_t *block_hist = (uint32_t *)workspace;
+  uint32_t *totals = block_hist + (int64_t)nblocks * kRadix;
+  uint32_t *base = totals + kRadix;
+  int cur = 0;
+  for (int shift = 0; shift < key_bits; shift += 8) {
+    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(kRsThreads), 0, st, keys[cur], n, shift,
+                       block_hist, nblocks);
+    hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(kRadix), dim3(kRsThreads), 0, st, block_hist, nblocks,
+                       totals);
+    hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(kRadix), 0, st, totals, base);
+    {
+      ProfScope prof(PCGX_PROF_SORT_SCATTER, st);
+      hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(kRsThreads), 0, st, keys[cur], vals[cur], n,
+                         shift, block_hist, nblocks, base, keys[cur ^ 1], vals[cur ^ 1]);
+    }
+    cur ^= 1;
+  }
+  PCGX_HIP_TRY(hipGetLastError());
+  *result = cur;
+  return PCGX_OK;
+}
+
+// ---------------------------------------------------------------- min / max
+// pc.MinMaxVec3 (pc/minmax.go:9-26): per-axis min and max with strict
+// comparisons starting from point 0.  For equal values (only -0 vs +0 differ
+// in bits) the sequential loop keeps the FIRST occurrence, and a NaN never
+// replaces anything but a NaN at index 0 sticks: the reduction therefore
+// carries (value, index) and prefers the lower index on equality; NaNs lose
+// against everything, and point 0 is folded in last with the reference's rule.
+__device__ __forceinline__ float ld_f32_any(const uint8_t *p) {
+  float v;
+  __builtin_memcpy(&v, p, 4);  // records may be byte aligned (pc/iterator.go:71-76)
+  return v;
+}
+
+struct MinMaxAcc {
+  float mn[3], mx[3];
+  int32_t imn[3], imx[3];
+};
+
+__device__ __forceinline__ void mm_take(float &m, int32_t &im, float v, int32_t iv, bool is_min) {
+  // true if (v, iv) should replace (m, im)
+  const bool better = is_min ? (v < m) : (v > m);
+  const bool tie = (v == m) && (iv < im);
+  const bool m_nan = m != m;
+  if (better || tie || (m_nan && !(v != v))) {
+    m = v;
+    im = iv;
+  }
+}
+
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__restrict__ data, int64_t n,
+                                                             int32_t stride, int32_t off,
+                                                             MinMaxAcc *__restrict__ partials) {
+  __shared__ MinMaxAcc s_acc[4];
+  MinMaxAcc a;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  for (int k = 0; k < 3; k++) {
+    a.mn[k] = qnan; a.mx[k] = qnan;
+    a.imn[k] = 0x7fffffff; a.imx[k] = 0x7fffffff;
+  }
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const uint8_t *p = data + i * stride + off;
+    const float v[3] = {ld_f32_any(p), ld_f32_any(p + 4), ld_f32_any(p + 8)};
+    for (int k = 0; k < 3; k++) {
+      mm_take(a.mn[k], a.imn[k], v[k], (int32_t)i, true);
+      mm_take(a.mx[k], a.imx[k], v[k], (int32_t)i, false);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int k = 0; k < 3; k++) {
+      float v = __shfl_down(a.mn[k], o); int32_t iv = __shfl_down(a.imn[k], o);
+      mm_take(a.mn[k], a.imn[k], v, iv, true);
+      v = __shfl_down(a.mx[k], o); iv = __shfl_down(a.imx[k], o);
+      mm_take(a.mx[k], a.imx[k], v, iv, false);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_acc[wave] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++)
+      for (int k = 0; k < 3; k++) {
+        mm_take(a.mn[k], a.imn[k], s_acc[w].mn[k], s_acc[w].imn[k], true);
+        mm_take(a.mx[k], a.imx[k], s_acc[w].mx[k], s_acc[w].imx[k], false);
+      }
+    partials[blockIdx.x] = a;
+  }
+}
+
+// out6 = {min xyz, max xyz}
+__global__ void minmax_final_kernel(const MinMaxAcc *__restrict__ partials, int nparts,
+                                    const uint8_t *__restrict__ data, int32_t off,
+                                    float *__restrict__ out6) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  MinMaxAcc a = partials[0];
+  for (int b = 1; b < nparts; b++)
+    for (int k = 0; k < 3; k++) {
+      mm_take(a.mn[k], a.imn[k], partials[b].mn[k], partials[b].imn[k], true);
+      mm_take(a.mx[k], a.imx[k], partials[b].mx[k], partials[b].imx[k], false);
+    }
+  for (int k = 0; k < 3; k++) {
+    // min, max := Vec3At(0): a NaN there is never replaced (minmax.go:13-23)
+    const float p0 = ld_f32_any(data + off + 4 * k);
+    if (p0 != p0) { a.mn[k] = p0; a.mx[k] = p0; }
+    out6[k] = a.mn[k];
+    out6[3 + k] = a.mx[k];
+  }
+}
+
+pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
+                          hipStream_t st) {
+  if (n <= 0) return fail(PCGX_E_NO_POINT, "no point");
+  int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  MinMaxAcc *partials = nullptr;
+  PCGX_TRY(ctx().arena.alloc_n(blocks, &partials));
+  hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t *)d_data, n,
+                     stride, off, partials);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, st, partials, blocks,
+                     (const uint8_t *)d_data, off, d_out6);
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
+// ------------------------------------------------------------------ Morton
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void morton_key_kernel(const float *__restrict__ q, int64_t n,
+                                                         const float *__restrict__ mm6, int bits_per_axis,
+                                                         uint32_t *__restrict__ keys,
+                                                         uint32_t *__restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float cells = (float)(1u << bits_per_axis);
+  uint32_t c[3];
+  for (int k = 0; k < 3; k++) {
+    const float lo = mm6[k], hi = mm6[3 + k];
+    const float ext = hi - lo;
+    float f = ext > 0.0f ? (q[3 * i + k] - lo) / ext * cells : 0.0f;
+    f = f < 0.0f ? 0.0f : f;  // NaN -> 0 through the second clamp
+    uint32_t ci = (uint32_t)fminf(f, cells - 1.0f);
+    c[k] = ci;
+  }
+  keys[i] = spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
+  vals[i] = (uint32_t)i;
+}
+
+constexpr int kMortonBitsPerAxis = 8;  // 24-bit keys: 3 radix passes
+
+// perm[pos] = index of the query visited at position pos (a permutation of 0..n-1).
+pcgx_status morton_order(const float *d_q, int64_t n, int32_t *d_perm, hipStream_t st) {
+  if (n > 0x7fffffffll) return fail(PCGX_E_INVALID, "morton_order: n too large");
+  Arena &ar = ctx().arena;
+  const size_t nb = (size_t)n * 4;
+  float *mm6 = nullptr;
+  uint32_t *keys[2] = {nullptr, nullptr};
+  uint32_t *vals[2] = {(uint32_t *)d_perm, nullptr};
+  void *wsp = nullptr;
+  PCGX_TRY(ar.alloc_n(6, &mm6));
+  PCGX_TRY(ar.alloc_n((size_t)n, &keys[0]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &keys[1]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &vals[1]));
+  PCGX_TRY(ar.alloc(radix_sort_workspace_bytes(n), &wsp));
+  PCGX_TRY(launch_minmax(d_q, n, 12, 0, mm6, st));
+  hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_q, n, mm6,
+                     kMortonBitsPerAxis, keys[0], vals[0]);
+  int res = 0;
+  PCGX_TRY(radix_sort_pairs(keys, vals, n, 3 * kMortonBitsPerAxis, wsp, &res, st));
+  if (res != 0)
+    PCGX_HIP_TRY(hipMemcpyAsync(d_perm, vals[res], nb, hipMemcpyDeviceToDevice, st));
+  return PCGX_OK;
+}
+
+}  // namespace pcgx

@@ -1,0 +1,422 @@
+// voxel.hip -- VoxelGrid downsample filter on gfx950 + pcgx_minmax / pcgx_voxel_filter.
+//
+// Reference: pc/filter/voxelgrid/voxelgrid.go:35-187 (Filter / filterChunk),
+// pc/minmax.go:9-26.  The reference scatters into a dense []voxel array and
+// then scans the whole array; here the same result is produced sparsely:
+//
+//   1. min/max reduction (sort.hip)                         -> vMin, vMax
+//   2. key kernel: a = x + xs*(y + ys*z) per point, with the reference's
+//      quirks kept (non-chunked size = vMax, stride xs/ys on an
+//      (xs+1)(ys+1)(zs+1) array: voxelgrid.go:46,137-138,151); chunked mode
+//      also yields the chunk id (voxelgrid.go:76-79)
+//   3. STABLE radix sort of (key, point index) (sort.hip); chunked mode sorts
+//      by `a` and then by chunk id, giving (cid, a) order = the reference's
+//      output order (chunks ascending, cells ascending inside a chunk)
+//   4. segment kernel: one lane per occupied voxel walks its points in input
+//      order (stability!) doing the sequential float32 sum of voxelgrid.go:157,
+//      copies the first point's whole record and overwrites xyz with
+//      sum*(1/num)+origin when num > 1 (voxelgrid.go:173-184).
+//
+// Out-of-range cell indices make the Go code panic; here they raise
+// PCGX_E_OUT_OF_RANGE.
+#include <string.h>
+
+#include <vector>
+
+#include "pcgx_internal.h"
+
+namespace pcgx {
+
+struct VoxelParams {
+  float vmin[3];
+  float leaf[3];
+  int64_t xs, ys;      // strides of the dense index (voxelgrid.go:137,151)
+  int64_t n_voxels;    // (xs+1)(ys+1)(zs+1) (voxelgrid.go:138)
+  // chunked mode (voxelgrid.go:49-79)
+  int32_t chunked;
+  float cs[3];         // clamped chunk size in metres
+  int64_t nx, ny, n_chunks;
+};
+
+__device__ __forceinline__ float ld_f32(const uint8_t *p) {
+  float v;
+  __builtin_memcpy(&v, p, 4);  // records may be 1-byte aligned (pc/iterator.go:71-76)
+  return v;
+}
+
+__device__ __forceinline__ void chunk_origin(const VoxelParams &vp, uint32_t cid, float o[3]) {
+  // cid2xyz + vMin.Add(cp.ElementMul(chunkSize))  (voxelgrid.go:69-75,109-110)
+  int64_t c = cid;
+  const int64_t x = c % vp.nx;
+  c = c / vp.nx;
+  const int64_t y = c % vp.ny;
+  const int64_t z = c / vp.ny;
+  o[0] = vp.vmin[0] + (float)x * vp.cs[0];
+  o[1] = vp.vmin[1] + (float)y * vp.cs[1];
+  o[2] = vp.vmin[2] + (float)z * vp.cs[2];
+}
+
+__global__ __launch_bounds__(256) void voxel_key_kernel(const uint8_t *__restrict__ data, int64_t n,
+                                                        int32_t stride, int32_t off, VoxelParams vp,
+                                                        uint32_t *__restrict__ key_a,
+                                                        uint32_t *__restrict__ a_orig,
+                                                        uint32_t *__restrict__ key_cid,
+                                                        uint32_t *__restrict__ idx,
+                                                        int32_t *__restrict__ err) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t *rec = data + i * stride + off;
+  const float pt[3] = {ld_f32(rec), ld_f32(rec + 4), ld_f32(rec + 8)};
+  float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
+  uint32_t cid = 0;
+  if (vp.chunked) {
+    const float q0 = pt[0] - vp.vmin[0], q1 = pt[1] - vp.vmin[1], q2 = pt[2] - vp.vmin[2];
+    const int64_t cx = (int64_t)(q0 / vp.cs[0]), cy = (int64_t)(q1 / vp.cs[1]), cz = (int64_t)(q2 / vp.cs[2]);
+    const int64_t c = ((cz * vp.ny) + cy) * vp.nx + cx;
+    if (c < 0 || c >= vp.n_chunks) {  // nIndices[cid] would panic
+      atomicOr(err, 1);
+      key_a[i] = 0; idx[i] = (uint32_t)i;
+      if (key_cid) { key_cid[i] = 0; a_orig[i] = 0; }
+      return;
+    }
+    cid = (uint32_t)c;
+    chunk_origin(vp, cid, origin);
+    if (key_cid) key_cid[i] = cid;
+  }
+  const float p0 = pt[0] - origin[0], p1 = pt[1] - origin[1], p2 = pt[2] - origin[2];
+  const int64_t x = (int64_t)(p0 / vp.leaf[0]), y = (int64_t)(p1 / vp.leaf[1]), z = (int64_t)(p2 / vp.leaf[2]);
+  const int64_t a = x + vp.xs * (y + vp.ys * z);
+  uint32_t ka = 0;
+  if (a < 0 || a >= vp.n_voxels) atomicOr(err, 1);  // f.voxels[a] would panic
+  else ka = (uint32_t)a;
+  key_a[i] = ka;
+  if (a_orig) a_orig[i] = ka;
+  idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t *__restrict__ src,
+                                                         const uint32_t *__restrict__ index, int64_t n,
+                                                         uint32_t *__restrict__ dst) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) dst[j] = src[index[j]];
+}
+
+// ---- head flags + exclusive scan + per-voxel reduction ------------------------
+constexpr int kSegTile = 2048;  // elements per block (256 threads x 8)
+
+__device__ __forceinline__ bool is_head(const uint32_t *__restrict__ sa, const uint32_t *__restrict__ sc,
+                                        int64_t j) {
+  if (j == 0) return true;
+  if (sa[j] != sa[j - 1]) return true;
+  return sc && sc[j] != sc[j - 1];
+}
+
+__global__ __launch_bounds__(256) void seg_count_kernel(const uint32_t *__restrict__ sa,
+                                                        const uint32_t *__restrict__ sc, int64_t n,
+                                                        uint32_t *__restrict__ tile_count) {
+  __shared__ uint32_t ws[4];
+  const int64_t base = (int64_t)blockIdx.x * kSegTile;
+  uint32_t c = 0;
+  for (int r = 0; r < kSegTile / 256; r++) {
+    const int64_t j = base + r * 256 + threadIdx.x;
+    if (j < n && is_head(sa, sc, j)) c++;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// In-place exclusive scan of tile_count[0..ntiles) by one block; total -> *total.
+__global__ __launch_bounds__(1024) void seg_scan_kernel(uint32_t *__restrict__ tile_count, int ntiles,
+                                                        int64_t *__restrict__ total) {
+  __shared__ uint32_t ws[16];
+  __shared__ uint32_t carry_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int start = 0; start < ntiles; start += 1024) {
+    const int i = start + threadIdx.x;
+    const uint32_t v = i < ntiles ? tile_count[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) ws[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += ws[w];
+    const uint32_t carry = carry_s;
+    if (i < ntiles) tile_count[i] = carry + wbase + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + wbase + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = (int64_t)carry_s;
+}
+
+// One lane per sorted position; head lanes own a voxel.
+__global__ __launch_bounds__(256) void seg_reduce_kernel(
+    const uint8_t *__restrict__ data, int32_t stride, int32_t off, VoxelParams vp,
+    const uint32_t *__restrict__ sa, const uint32_t *__restrict__ sc, const uint32_t *__restrict__ sidx,
+    int64_t n, const uint32_t *__restrict__ tile_offset, uint8_t *__restrict__ out) {
+  __shared__ uint32_t ws[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kSegTile;
+  uint32_t running = tile_offset[blockIdx.x];
+  for (int r = 0; r < kSegTile / 256; r++) {
+    const int64_t j = base + r * 256 + threadIdx.x;
+    const bool head = j < n && is_head(sa, sc, j);
+    // exclusive rank of this head among the heads of the round
+    const uint64_t bal = __ballot(head);
+    const uint32_t below = (uint32_t)__popcll(bal & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+    if (lane == 0) ws[wave] = (uint32_t)__popcll(bal);
+    __syncthreads();
+    uint32_t wbase = 0, round_total = 0;
+    for (int w = 0; w < 4; w++) {
+      if (w < wave) wbase += ws[w];
+      round_total += ws[w];
+    }
+    if (head) {
+      const uint32_t slot = running + wbase + below;
+      const uint32_t a = sa[j];
+      const uint32_t cid = sc ? sc[j] : 0u;
+      float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
+      if (vp.chunked) chunk_origin(vp, cid, origin);
+      const uint32_t first = sidx[j];  // v.index: first point in input order (voxelgrid.go:152-155)
+      float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+      uint32_t num = 0;
+      int64_t k = j;
+      do {
+        const uint8_t *rec = data + (int64_t)sidx[k] * stride + off;
+        // p := it.Vec3().Sub(vMin); v.sum = v.sum.Add(p)   (voxelgrid.go:149,157)
+        s0 = s0 + (ld_f32(rec) - origin[0]);
+        s1 = s1 + (ld_f32(rec + 4) - origin[1]);
+        s2 = s2 + (ld_f32(rec + 8) - origin[2]);
+        num++;
+        k++;
+      } while (k < n && sa[k] == a && (!sc || sc[k] == cid));
+      const uint8_t *src = data + (int64_t)first * stride;
+      uint8_t *dst = out + (int64_t)slot * stride;
+      if (((stride | off) & 3) == 0 && ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out)) & 3) == 0) {
+        for (int b = 0; b < stride; b += 4) *(uint32_t *)(dst + b) = *(const uint32_t *)(src + b);
+      } else {
+        for (int b = 0; b < stride; b++) dst[b] = src[b];
+      }
+      if (num > 1) {  // jt.SetVec3(v.sum.Mul(1.0 / float32(n)).Add(vMin))  (voxelgrid.go:178-180)
+        const float inv = 1.0f / (float)num;
+        const float c0 = s0 * inv + origin[0], c1 = s1 * inv + origin[1], c2 = s2 * inv + origin[2];
+        __builtin_memcpy(dst + off, &c0, 4);
+        __builtin_memcpy(dst + off + 4, &c1, 4);
+        __builtin_memcpy(dst + off + 8, &c2, 4);
+      }
+    }
+    running += round_total;
+    __syncthreads();
+  }
+}
+
+static int bits_for(int64_t count) {  // bits needed for values in [0, count)
+  int b = 0;
+  while (b < 63 && ((int64_t)1 << b) < count) b++;
+  return b;
+}
+
+// Host-side grid set-up in the reference's float32 arithmetic (voxelgrid.go:45-62,137-138).
+static pcgx_status make_params(const float mm6[6], const float leaf[3], const int32_t chunk[3],
+                               VoxelParams &vp) {
+  memset(&vp, 0, sizeof vp);
+  const float *vmin = mm6, *vmax = mm6 + 3;
+  for (int k = 0; k < 3; k++) {
+    vp.vmin[k] = vmin[k];
+    vp.leaf[k] = leaf[k];
+  }
+  float size[3];
+  if ((int64_t)chunk[0] * chunk[1] * chunk[2] == 0) {
+    for (int k = 0; k < 3; k++) size[k] = vmax[k];  // sic (voxelgrid.go:46)
+    vp.chunked = 0;
+    vp.nx = vp.ny = vp.n_chunks = 1;
+  } else {
+    float ext[3];
+    for (int k = 0; k < 3; k++) {
+      ext[k] = vmax[k] - vmin[k];
+      vp.cs[k] = leaf[k] * (float)chunk[k];
+    }
+    for (int k = 0; k < 3; k++)
+      if (vp.cs[k] > ext[k] + leaf[k]) vp.cs[k] = ext[k] + leaf[k];
+    vp.chunked = 1;
+    vp.nx = (int64_t)(ext[0] / vp.cs[0]) + 1;
+    vp.ny = (int64_t)(ext[1] / vp.cs[1]) + 1;
+    const int64_t nz = (int64_t)(ext[2] / vp.cs[2]) + 1;
+    if (vp.nx <= 0 || vp.ny <= 0 || nz <= 0 || (double)vp.nx * (double)vp.ny * (double)nz >= 4294967296.0)
+      return fail(PCGX_E_OUT_OF_RANGE, "voxel filter: chunk grid %lld x %lld x %lld is not addressable",
+                  (long long)vp.nx, (long long)vp.ny, (long long)nz);
+    vp.n_chunks = vp.nx * vp.ny * nz;
+    for (int k = 0; k < 3; k++) size[k] = vp.cs[k];
+  }
+  const int64_t xs = (int64_t)(size[0] / leaf[0]), ys = (int64_t)(size[1] / leaf[1]),
+                zs = (int64_t)(size[2] / leaf[2]);
+  const double nv = ((double)xs + 1) * ((double)ys + 1) * ((double)zs + 1);
+  if (xs < 0 || ys < 0 || zs < 0 || !(nv >= 1.0) || nv >= 4294967296.0)
+    return fail(PCGX_E_OUT_OF_RANGE,
+                "voxel filter: dense grid (%lld+1)(%lld+1)(%lld+1) is empty or exceeds 2^32 cells "
+                "(the reference would panic or need >128 GiB)",
+                (long long)xs, (long long)ys, (long long)zs);
+  vp.xs = xs;
+  vp.ys = ys;
+  vp.n_voxels = (xs + 1) * (ys + 1) * (zs + 1);
+  return PCGX_OK;
+}
+
+}  // namespace pcgx
+
+using namespace pcgx;
+
+extern "C" pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int32_t stride,
+                                             int32_t xyz_off, const float leaf[3],
+                                             const int32_t chunk[3], void *d_out, int64_t *out_n,
+                                             void *stream) {
+  if (!out_n) return fail(PCGX_E_INVALID, "pcgx_voxel_filter_dev: out_n is NULL");
+  *out_n = 0;
+  if (n < 0 || !leaf || !chunk || (n > 0 && (!d_data || !d_out)))
+    return fail(PCGX_E_INVALID, "pcgx_voxel_filter_dev: bad argument");
+  if (n == 0) return fail(PCGX_E_NO_POINT, "no point");  // pc/minmax.go:10-12 via voxelgrid.go:41-44
+  if (stride < 12 || xyz_off < 0 || xyz_off + 12 > stride)
+    return fail(PCGX_E_BAD_FIELD, "pcgx_voxel_filter_dev: stride %d / xyz offset %d do not hold an xyz triple", stride, xyz_off);
+  if (n > 0x7fffffffll) return fail(PCGX_E_TOO_LARGE, "pcgx_voxel_filter_dev: more than 2^31-1 points");
+  PCGX_TRY(ensure_init());
+  hipStream_t st = pick_stream(stream);
+  Arena &ar = ctx().arena;
+  PCGX_TRY(ar.begin(st));
+  ProfScope prof(PCGX_PROF_VOXEL_ALL, st);
+
+  float *d_mm6 = nullptr;
+  PCGX_TRY(ar.alloc_n(6, &d_mm6));
+  PCGX_TRY(launch_minmax(d_data, n, stride, xyz_off, d_mm6, st));
+  float mm6[6];
+  PCGX_HIP_TRY(hipMemcpyAsync(mm6, d_mm6, sizeof mm6, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  VoxelParams vp;
+  PCGX_TRY(make_params(mm6, leaf, chunk, vp));
+
+  uint32_t *keys[2], *vals[2], *a_orig = nullptr, *cid_orig = nullptr;
+  void *ws = nullptr;
+  int32_t *d_err = nullptr;
+  int64_t *d_total = nullptr;
+  uint32_t *tile_count = nullptr;
+  const int ntiles = (int)((n + kSegTile - 1) / kSegTile);
+  const bool two_level = vp.chunked && vp.n_chunks > 1;
+  PCGX_TRY(ar.alloc_n((size_t)n, &keys[0]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &keys[1]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &vals[0]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &vals[1]));
+  if (two_level) {
+    PCGX_TRY(ar.alloc_n((size_t)n, &a_orig));
+    PCGX_TRY(ar.alloc_n((size_t)n, &cid_orig));
+  }
+  PCGX_TRY(ar.alloc(radix_sort_workspace_bytes(n), &ws));
+  PCGX_TRY(ar.alloc_n(1, &d_err));
+  PCGX_TRY(ar.alloc_n(1, &d_total));
+  PCGX_TRY(ar.alloc_n((size_t)ntiles, &tile_count));
+  PCGX_HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int32_t), st));
+
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(256), 0, st, (const uint8_t *)d_data, n, stride, xyz_off,
+                     vp, keys[0], a_orig, cid_orig, vals[0], d_err);
+  int res = 0;
+  PCGX_TRY(radix_sort_pairs(keys, vals, n, bits_for(vp.n_voxels), ws, &res, st));
+  const uint32_t *sa = keys[res], *sc = nullptr, *sidx = vals[res];
+  if (two_level) {
+    // second stable sort, by chunk id: (cid, a) order with input order kept inside a cell
+    uint32_t *k2[2] = {keys[res ^ 1], keys[res]};
+    uint32_t *v2[2] = {vals[res], vals[res ^ 1]};
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(nb), dim3(256), 0, st, cid_orig, v2[0], n, k2[0]);
+    int res2 = 0;
+    PCGX_TRY(radix_sort_pairs(k2, v2, n, bits_for(vp.n_chunks), ws, &res2, st));
+    sc = k2[res2];
+    sidx = v2[res2];
+    uint32_t *sorted_a = k2[res2 ^ 1];
+    hipLaunchKernelGGL(gather_u32_kernel, dim3(nb), dim3(256), 0, st, a_orig, sidx, n, sorted_a);
+    sa = sorted_a;
+  }
+  hipLaunchKernelGGL(seg_count_kernel, dim3(ntiles), dim3(256), 0, st, sa, sc, n, tile_count);
+  hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, st, tile_count, ntiles, d_total);
+  hipLaunchKernelGGL(seg_reduce_kernel, dim3(ntiles), dim3(256), 0, st, (const uint8_t *)d_data, stride,
+                     xyz_off, vp, sa, sc, sidx, n, tile_count, (uint8_t *)d_out);
+  PCGX_HIP_TRY(hipGetLastError());
+  int32_t h_err = 0;
+  int64_t h_total = 0;
+  PCGX_HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof h_err, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipMemcpyAsync(&h_total, d_total, sizeof h_total, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  if (h_err)
+    return fail(PCGX_E_OUT_OF_RANGE, "voxel filter: a point falls outside the dense grid (the reference panics: index out of range)");
+  *out_n = h_total;
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_minmax(const void *data, int64_t n, int32_t stride, int32_t xyz_off,
+                                   float vmin[3], float vmax[3]) {
+  if (n < 0 || !vmin || !vmax || (n > 0 && !data)) return fail(PCGX_E_INVALID, "pcgx_minmax: bad argument");
+  if (n == 0) return fail(PCGX_E_NO_POINT, "no point");
+  if (stride < 12 || xyz_off < 0 || xyz_off + 12 > stride)
+    return fail(PCGX_E_BAD_FIELD, "pcgx_minmax: stride %d / xyz offset %d do not hold an xyz triple", stride, xyz_off);
+  PCGX_TRY(ensure_init());
+  hipStream_t st = ctx().stream;
+  const void *src = data;
+  const int32_t s = stride, o = xyz_off;
+  void *d = nullptr;
+  PCGX_HIP_TRY(hipMalloc(&d, (size_t)n * s));
+  pcgx_status rc = PCGX_OK;
+  float mm6[6];
+  hipError_t e = hipMemcpyAsync(d, src, (size_t)n * s, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_minmax upload: %s", hipGetErrorString(e));
+  float *d_mm6 = nullptr;
+  if (rc == PCGX_OK) rc = ctx().arena.begin(st);
+  if (rc == PCGX_OK) rc = ctx().arena.alloc_n(6, &d_mm6);
+  if (rc == PCGX_OK) rc = launch_minmax(d, n, s, o, d_mm6, st);
+  if (rc == PCGX_OK) {
+    e = hipMemcpyAsync(mm6, d_mm6, sizeof mm6, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_minmax: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d);
+  if (rc != PCGX_OK) return rc;
+  memcpy(vmin, mm6, 12);
+  memcpy(vmax, mm6 + 3, 12);
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_voxel_filter(const void *data, int64_t n, int32_t stride, int32_t xyz_off,
+                                         const float leaf[3], const int32_t chunk[3], void *out_data,
+                                         int64_t *out_n) {
+  if (!out_n) return fail(PCGX_E_INVALID, "pcgx_voxel_filter: out_n is NULL");
+  *out_n = 0;
+  if (n < 0 || (n > 0 && (!data || !out_data))) return fail(PCGX_E_INVALID, "pcgx_voxel_filter: bad argument");
+  if (n == 0) return fail(PCGX_E_NO_POINT, "no point");
+  PCGX_TRY(ensure_init());
+  hipStream_t st = ctx().stream;
+  void *d_in = nullptr, *d_out = nullptr;
+  const size_t bytes = (size_t)n * (size_t)stride;
+  PCGX_HIP_TRY(hipMalloc(&d_in, bytes));
+  hipError_t e = hipMalloc(&d_out, bytes);
+  if (e != hipSuccess) {
+    (void)hipFree(d_in);
+    return fail(PCGX_E_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  pcgx_status rc = PCGX_OK;
+  e = hipMemcpyAsync(d_in, data, bytes, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_voxel_filter upload: %s", hipGetErrorString(e));
+  int64_t m = 0;
+  if (rc == PCGX_OK) rc = pcgx_voxel_filter_dev(d_in, n, stride, xyz_off, leaf, chunk, d_out, &m, st);
+  if (rc == PCGX_OK && m > 0) {
+    e = hipMemcpy(out_data, d_out, (size_t)m * (size_t)stride, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_voxel_filter download: %s", hipGetErrorString(e));
+  }
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  if (rc == PCGX_OK) *out_n = m;
+  return rc;
+}

@@ -1,0 +1,195 @@
+"""pc/registration/icp mirror: NearestPointCorresponder, PointToPointEvaluator,
+GradientDescentUpdaterFactory and PointToPointICPGradient.Fit on the GPU."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from . import mat
+from .kdtree import KDTree
+
+ErrNotEnoughPairs = L.ErrNotEnoughPairs  # evaluator.go:16
+ErrNeedGradient = L.ErrNeedGradient      # icp.go:15
+
+
+class PointToPointCorrespondence:  # correspondence.go:8-12
+    __slots__ = ("BaseID", "TargetID", "SquaredDistance")
+
+    def __init__(self, b, t, d):
+        self.BaseID, self.TargetID, self.SquaredDistance = int(b), int(t), np.float32(d)
+
+    def __eq__(self, o):
+        return (self.BaseID, self.TargetID, self.SquaredDistance) == (o.BaseID, o.TargetID, o.SquaredDistance)
+
+    def __repr__(self):
+        return "{%d %d %r}" % (self.BaseID, self.TargetID, float(self.SquaredDistance))
+
+
+class NearestPointCorresponder:  # correspondence.go:18-37
+    def __init__(self, MaxDist):
+        self.MaxDist = float(MaxDist)
+
+    def PairsArrays(self, base, target):
+        target = L.f32c(target).reshape(-1, 3)
+        n = len(target)
+        b = np.empty(max(n, 1), np.int64)
+        t = np.empty(max(n, 1), np.int64)
+        d = np.empty(max(n, 1), np.float32)
+        m = C.c_int64()
+        L.check(L.lib().pcgx_icp_pairs(base._h, L.ptr(target), n, self.MaxDist, base.MinDistSq, L.ptr(b),
+                                       L.ptr(t), L.ptr(d), C.byref(m)))
+        return b[: m.value], t[: m.value], d[: m.value]
+
+    def Pairs(self, base, target):
+        return [PointToPointCorrespondence(*r) for r in zip(*self.PairsArrays(base, target))]
+
+
+class Evaluated:  # evaluator.go:25-30
+    def __init__(self, ev=None):
+        self.Value = np.float32(ev.value if ev else 0)
+        self.Gradient = np.array(list(ev.gradient) if ev else [0] * 6, np.float32)
+        self.Hessian = np.zeros(36, np.float32)  # never written by the reference (:28,:76)
+        self.DistRMS = np.float32(ev.dist_rms if ev else 0)
+        self.NumPairs = int(ev.num_pairs) if ev else 0
+
+
+class PointToPointEvaluator:  # evaluator.go:69-76
+    def __init__(self, Corresponder, MinPairs=0, WeightFn=None):
+        if WeightFn is not None:
+            raise NotImplementedError("custom WeightFn closures cannot run on the device; only the "
+                                      "default weight (1) is supported (DESIGN.md, out of scope)")
+        if not isinstance(Corresponder, NearestPointCorresponder):
+            raise TypeError("the GPU evaluator fuses NearestPointCorresponder")
+        self.Corresponder = Corresponder
+        self.MinPairs = int(MinPairs)
+
+    def HasGradient(self):
+        return True
+
+    def HasHessian(self):
+        return False
+
+    def Evaluate(self, base, target):
+        if not isinstance(base, KDTree):
+            raise TypeError("base must be a pcgol_amd KDTree")
+        target = L.f32c(target).reshape(-1, 3)
+        ev = L.IcpEvaluated()
+        L.check(L.lib().pcgx_icp_evaluate(base._h, L.ptr(target), len(target), self.Corresponder.MaxDist,
+                                          base.MinDistSq, self.MinPairs, C.byref(ev)))
+        return Evaluated(ev)
+
+
+def _params(max_dist, min_dist_sq, min_pairs, weight, threshold, max_iteration):
+    p = L.IcpParams()
+    p.max_dist, p.min_dist_sq, p.min_pairs, p.max_iteration = max_dist, min_dist_sq, min_pairs, max_iteration
+    for i in range(6):
+        p.weight[i] = float(weight[i])
+        p.threshold[i] = float(threshold[i])
+    return p
+
+
+class GradientDescentUpdaterFactory:  # updater.go:18-37
+    def __init__(self, Weight=None, Threshold=None, MaxIteration=0):
+        self.Weight = np.zeros(6, np.float32) if Weight is None else np.asarray(Weight, np.float32)
+        self.Threshold = np.zeros(6, np.float32) if Threshold is None else np.asarray(Threshold, np.float32)
+        self.MaxIteration = int(MaxIteration)
+
+    def New(self):
+        return _GradientDescentUpdater(self)
+
+
+class _GradientDescentUpdater:  # updater.go:39-71
+    def __init__(self, f):
+        self.f = f
+        self.i = 0
+
+    def Update(self, trans, ev):
+        p = _params(0, 0, 0, self.f.Weight, self.f.Threshold, self.f.MaxIteration)
+        it = C.c_int32(self.i)
+        t = L.f32c(trans).copy()
+        g = L.f32c(ev.Gradient)
+        conv = C.c_int32()
+        L.check(L.lib().pcgx_icp_update(C.byref(p), C.byref(it), L.ptr(g), L.ptr(t), C.byref(conv)))
+        self.i = it.value
+        return t, bool(conv.value)
+
+
+class Stat:  # stat.go:3-6
+    def __init__(self, st=None):
+        self.Evaluated = Evaluated(st.evaluated if st else None)
+        self.NumIteration = st.num_iteration if st else 0
+
+
+class PointToPointICPGradient:  # icp.go:18-67
+    def __init__(self, Evaluator, UpdaterFactory=None):
+        self.Evaluator = Evaluator
+        self.UpdaterFactory = UpdaterFactory
+
+    def Fit(self, base, target):
+        """(trans[16], Stat).  Raises ErrNotEnoughPairs with .trans/.stat attached, like icp.go:49-53."""
+        ev = self.Evaluator
+        if not ev.HasGradient():
+            raise ErrNeedGradient(L.PCGX_E_NEED_GRADIENT, "need gradient output of Evaluator")
+        uf = self.UpdaterFactory or GradientDescentUpdaterFactory()
+        target = L.f32c(target).reshape(-1, 3)
+        p = _params(ev.Corresponder.MaxDist, base.MinDistSq, ev.MinPairs, uf.Weight, uf.Threshold, uf.MaxIteration)
+        trans = np.empty(16, np.float32)
+        st = L.IcpStat()
+        rc = L.lib().pcgx_icp_fit(base._h, L.ptr(target), len(target), C.byref(p), L.ptr(trans), C.byref(st))
+        if rc == L.PCGX_E_NOT_ENOUGH_PAIRS:
+            e = ErrNotEnoughPairs(rc, L.last_error())
+            e.trans, e.stat = trans, Stat(st)
+            raise e
+        L.check(rc)
+        return trans, Stat(st)
+
+
+class IcpSession:
+    """Device-resident Fit loop cut at the per-iteration exchange (include/pcgx.h)."""
+
+    def __init__(self, base, target, MaxDist, MinPairs=0, Weight=None, Threshold=None, MaxIteration=0,
+                 d_sums10=0, target_on_device=False, nt=None):
+        w = np.zeros(6, np.float32) if Weight is None else Weight
+        th = np.zeros(6, np.float32) if Threshold is None else Threshold
+        self.params = _params(MaxDist, base.MinDistSq, MinPairs, w, th, MaxIteration)
+        self.max_iteration = MaxIteration or 20
+        self.base = base
+        if target_on_device:
+            tptr, n = L.ptr(int(target)), int(nt)
+        else:
+            self._t = L.f32c(target).reshape(-1, 3)
+            tptr, n = L.ptr(self._t), len(self._t)
+        h = C.c_void_p()
+        L.check(L.lib().pcgx_icp_session_create(base._h, tptr, n, 1 if target_on_device else 0,
+                                                C.byref(self.params), L.ptr(int(d_sums10)) if d_sums10 else None,
+                                                C.byref(h)))
+        self._h = h
+
+    def partials(self, stream=0):
+        L.check(L.lib().pcgx_icp_session_partials(self._h, L.ptr(stream) if stream else None))
+
+    def update(self, stream=0):
+        L.check(L.lib().pcgx_icp_session_update(self._h, L.ptr(stream) if stream else None))
+
+    def reset(self, stream=0):
+        L.check(L.lib().pcgx_icp_session_reset(self._h, L.ptr(stream) if stream else None))
+
+    def result(self, stream=0):
+        trans = np.empty(16, np.float32)
+        st = L.IcpStat()
+        conv = C.c_int32()
+        rc = L.lib().pcgx_icp_session_result(self._h, L.ptr(stream) if stream else None, L.ptr(trans),
+                                             C.byref(st), C.byref(conv))
+        if rc == L.PCGX_E_NOT_ENOUGH_PAIRS:
+            e = ErrNotEnoughPairs(rc, L.last_error())
+            e.trans, e.stat = trans, Stat(st)
+            raise e
+        L.check(rc)
+        return trans, Stat(st), bool(conv.value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib().pcgx_icp_session_free(self._h)
+            self._h = None
+
+    __del__ = close

@@ -1,0 +1,73 @@
+"""Synthetic inputs of the BASELINE.json configurations.
+
+Coordinates mirror the reference's own random clouds, `rand.Float32()*width`
+(pc/storage/kdtree/kdtree_test.go:1007-1013): u = k / 2^24 with k uniform in
+[0, 2^24), x = float32(u * W).  Generator: numpy PCG64 with the stated seed."""
+import numpy as np
+
+
+def uniform_cloud(n, width, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    k = rng.integers(0, 1 << 24, size=(n, 3), dtype=np.int64)
+    u = k.astype(np.float32) / np.float32(1 << 24)
+    return np.ascontiguousarray(u * np.float32(width), dtype=np.float32)
+
+
+def c1_voxel():   # VoxelGrid 100k, leaf 0.05 (CPU reference config)
+    return dict(points=uniform_cloud(100_000, 1.6, 1), leaf=(0.05, 0.05, 0.05))
+
+
+def c2_knn(n_base=1_000_000, n_query=1_000_000):   # kNN k=1, 1M x 1M, width 10, maxRange 10
+    return dict(base=uniform_cloud(n_base, 10.0, 2), queries=uniform_cloud(n_query, 10.0, 3), max_range=10.0)
+
+
+def c3_voxel(n=10_000_000):   # VoxelGrid 10M, leaf 0.02, cube 3.0 m
+    return dict(points=uniform_cloud(n, 3.0, 4), leaf=(0.02, 0.02, 0.02))
+
+
+def icp_pose():
+    """T = Translate(.02,.01,-.015) * Rotate(0,0,1,.001) in the reference's float32 arithmetic
+    (mat/transform.go:7-14,25-35; mat/mat4.go:16-28), column-major."""
+    f = np.float32
+    ang = f(0.001)
+    s, c = f(np.sin(np.float64(ang))), f(np.cos(np.float64(ang)))
+    one_c = f(f(1) - c)
+    x, y, z = f(0), f(0), f(1)
+    r = np.array([
+        c + x * x * one_c, x * y * one_c + z * s, x * z * one_c - y * s, 0,
+        y * x * one_c - z * s, c + y * y * one_c, y * z * one_c + x * s, 0,
+        z * x * one_c + y * s, z * y * one_c - x * s, c + z * z * one_c, 0,
+        0, 0, 0, 1], dtype=np.float32)
+    t = np.eye(4, dtype=np.float32).reshape(-1)
+    t[12:15] = (f(0.02), f(0.01), f(-0.015))
+    # Mat4.Mul (t * r): out[4j+i] = sum_k t[4k+i] * r[4j+k], float32 left to right
+    out = np.zeros(16, np.float32)
+    for i in range(4):
+        for j in range(4):
+            acc = f(0)
+            for k in range(4):
+                acc = f(acc + f(t[4 * k + i] * r[4 * j + k]))
+            out[4 * j + i] = acc
+    return out
+
+
+def transform_points(m, pts):
+    """Mat4.Transform (mat/mat4.go:130-137) vectorised in float32, left to right."""
+    f = np.float32
+    x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    w = f(1) / (((m[3] * x + m[7] * y) + m[11] * z) + m[15])
+    ox = (((m[0] * x + m[4] * y) + m[8] * z) + m[12]) * w
+    oy = (((m[1] * x + m[5] * y) + m[9] * z) + m[13]) * w
+    oz = (((m[2] * x + m[6] * y) + m[10] * z) + m[14]) * w
+    return np.ascontiguousarray(np.stack([ox, oy, oz], axis=1), dtype=np.float32)
+
+
+def c4_icp(n=1_000_000, width=10.0, base_seed=2, perm_seed=5):
+    """ICP 1M x 1M: target_i = T * base[perm(i)]; MaxDist 0.5, MinPairs 6, Weight 0.3,
+    Threshold -1 (run all iterations, as icp_test.go:126), MaxIteration 20."""
+    base = uniform_cloud(n, width, base_seed)
+    perm = np.random.Generator(np.random.PCG64(perm_seed)).permutation(n)
+    target = transform_points(icp_pose(), base[perm])
+    return dict(base=base, target=target, max_dist=0.5, min_pairs=6,
+                weight=np.full(6, 0.3, np.float32), threshold=np.full(6, -1.0, np.float32),
+                max_iteration=20)

@@ -1,0 +1,50 @@
+"""pc/filter/voxelgrid mirror: voxelgrid.New(leaf, WithChunkSize(..)).Filter(pp)
+(voxelgrid.go:23-134) behind filter.Filter (pc/filter/filter.go:7-9)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .pc import PointCloud
+
+
+def WithChunkSize(s):  # option.go:14-18
+    def opt(o):
+        o.ChunkSize = [int(v) for v in s]
+    return opt
+
+
+class VoxelGrid:
+    def __init__(self, leafSize, *opts):
+        self.LeafSize = np.asarray(leafSize, np.float32).reshape(3)
+        self.ChunkSize = [0, 0, 0]
+        for o in opts:
+            o(self)
+
+    def Filter(self, pp):
+        """Returns a new PointCloud (header cloned, Width = M, Height = 1)."""
+        if not isinstance(pp, PointCloud):
+            pp = PointCloud.from_xyz(pp)
+        stride, off = pp.Stride(), pp.xyz_offset()
+        n = pp.Points
+        out = np.empty(max(n, 1) * stride, np.uint8)
+        m = C.c_int64()
+        chunk = np.asarray(self.ChunkSize, np.int32)
+        L.check(L.lib().pcgx_voxel_filter(L.ptr(pp.Data), n, stride, off, L.ptr(self.LeafSize),
+                                          L.ptr(chunk), L.ptr(out), C.byref(m)))
+        h = pp.PointCloudHeader.Clone()
+        h.Width, h.Height = m.value, 1
+        return PointCloud(h, m.value, out[: m.value * stride].copy())
+
+    def FilterDev(self, d_data, n, stride, off, d_out, stream=0):
+        """Device-resident variant (raw device addresses). Returns M."""
+        m = C.c_int64()
+        chunk = np.asarray(self.ChunkSize, np.int32)
+        L.check(L.lib().pcgx_voxel_filter_dev(L.ptr(d_data), n, stride, off, L.ptr(self.LeafSize),
+                                              L.ptr(chunk), L.ptr(d_out), C.byref(m),
+                                              L.ptr(stream) if stream else None))
+        return m.value
+
+
+def New(leafSize, *opts):
+    return VoxelGrid(leafSize, *opts)

@@ -1,0 +1,144 @@
+"""GPU parity: ICP correspondence / evaluate / update / Fit (through the C ABI)
+vs the CPU oracle and the reference's known-answer tables.
+Tolerance: transform within 1e-5 absolute (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from pcgol_amd import icp, kdtree, mat, synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+TOL = 1e-5
+
+
+def test_corresponder_golden(golden):
+    g = golden("ref_icp.json")["corresponder"]
+    t = kdtree.New(np.array(g["base"], f32))
+    pairs = icp.NearestPointCorresponder(MaxDist=g["max_dist"]).Pairs(t, np.array(g["targets"], f32))
+    assert [[p.BaseID, p.TargetID, float(p.SquaredDistance)] for p in pairs] == g["expected_pairs"]
+
+
+def test_evaluator_golden(golden):
+    g = golden("ref_icp.json")["evaluator"]
+    base = np.array(g["base"], f32)
+    delta = np.array(g["delta"], f32)
+    target = base[g["target_base_ids"]] + delta
+    t = kdtree.New(base)
+    e = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=g["max_dist"]), MinPairs=g["min_pairs"])
+    assert e.HasGradient() and not e.HasHessian()
+    ev = e.Evaluate(t, target)
+    assert ev.Value == f32(g["expected_value"])  # exact, evaluator_test.go:40-42
+    fct = f32(g["step_factor"])
+    dR = mat.RodriguesToRotation(ev.Gradient[3:] * fct)
+    assert e.Evaluate(t, mat.Transform(dR, target)).Value < ev.Value
+    assert e.Evaluate(t, target + ev.Gradient[:3] * fct).Value < ev.Value
+    oe = O.icp_evaluate(O.KDTree(base), target, g["max_dist"], g["min_pairs"])
+    assert ev.Value == oe["value"] and np.array_equal(ev.Gradient, oe["gradient"]) and ev.DistRMS == oe["dist_rms"]
+    with pytest.raises(icp.ErrNotEnoughPairs):
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=g["max_dist"]), MinPairs=4).Evaluate(t, target)
+
+
+def _delta(ops):
+    m = None
+    for op in ops:
+        f = O.translate(*op[1:]) if op[0] == "trans" else O.rotate(*op[1:])
+        m = f if m is None else O.mat4_mul(m, f)
+    return m
+
+
+def test_fit_poses_golden(golden):
+    """icp_test.go:13-98: 2 bases x 14 poses, residual <= 0.05; and the same transform as the oracle."""
+    g = golden("ref_icp.json")["fit"]
+    idx = g["indices"]
+    for name, base in g["bases"].items():
+        base = np.array(base, f32)
+        for ops in g["deltas"]:
+            target = O.mat4_transform(_delta(ops), base[idx])
+            t = kdtree.New(base, MinDistSq=g["min_dist_sq"])
+            reg = icp.PointToPointICPGradient(icp.PointToPointEvaluator(
+                icp.NearestPointCorresponder(MaxDist=g["max_dist"]), MinPairs=g["min_pairs"]))
+            trans, stat = reg.Fit(t, target)
+            moved = mat.Transform(trans, target)
+            res = np.mean(np.sum((moved - base[idx]).astype(np.float64) ** 2, axis=1))
+            assert res <= g["max_residual"], (name, ops, res)
+            o = O.icp_fit(O.KDTree(base, min_dist_sq=g["min_dist_sq"]), target, g["max_dist"], g["min_pairs"])
+            assert stat.NumIteration == o["num_iteration"]
+            assert np.max(np.abs(trans - o["trans"])) <= TOL, (name, ops)
+
+
+def test_updater_matches_oracle():
+    rng = np.random.default_rng(3)
+    for case in range(50):
+        g = (rng.random(6, dtype=f32) - f32(0.5)) * f32(10.0 if case % 2 else 0.05)
+        tr = O.mat4_mul(O.translate(*rng.random(3, dtype=f32)), O.rotate(0, 0, 1, float(rng.random())))
+        it = int(rng.integers(0, 20))
+        ev = icp.Evaluated()
+        ev.Gradient = g
+        u = icp.GradientDescentUpdaterFactory().New()
+        u.i = it
+        t1, conv = u.Update(tr, ev)
+        t2, conv2, it2 = O.icp_update(tr, g, it)
+        assert conv == conv2 and u.i == it2
+        assert np.array_equal(t1.view(np.uint32), t2.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,max_dist,min_dist_sq", [(20000, 0.5, 0.0), (20000, 0.5, 0.0004), (100000, 0.3, 0.0)])
+def test_evaluate_vs_oracle(n, max_dist, min_dist_sq):
+    c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
+    t = kdtree.New(c["base"], MinDistSq=min_dist_sq)
+    ev = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=max_dist), MinPairs=6).Evaluate(t, c["target"])
+    o = O.KDTree(c["base"], min_dist_sq=min_dist_sq)
+    oe = O.icp_evaluate(o, c["target"], max_dist, 6, sums_mode=1)  # float64 sums of the same float32 terms
+    assert ev.NumPairs == oe["npairs"]
+    # the device sums in float64 (different association): agree to float32 rounding of the results
+    assert abs(float(ev.Value) - float(oe["value"])) <= 2e-7 * max(1.0, abs(float(oe["value"])))
+    assert np.max(np.abs(ev.Gradient - oe["gradient"])) <= 1e-6
+    assert abs(float(ev.DistRMS) - float(oe["dist_rms"])) <= 1e-5
+    # pairs: identical to the oracle's
+    b, tid, d = icp.NearestPointCorresponder(MaxDist=max_dist).PairsArrays(t, c["target"])
+    ob, ot, od = O.icp_pairs(o, c["target"], max_dist)
+    assert np.array_equal(b, ob) and np.array_equal(tid, ot) and np.array_equal(d, od)
+
+
+@pytest.mark.parametrize("n", [20000, 200000])
+def test_fit_vs_oracle(n):
+    """Scaled-down C4: same density as the 1M config; transform within 1e-5 of the oracle
+    (sequential float32 sums = Go semantics) and recovers the inverse pose."""
+    c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
+    t = kdtree.New(c["base"])
+    reg = icp.PointToPointICPGradient(
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=c["min_pairs"]),
+        icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=c["threshold"], MaxIteration=c["max_iteration"]))
+    trans, stat = reg.Fit(t, c["target"])
+    o = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
+                  c["max_iteration"])
+    assert stat.NumIteration == o["num_iteration"] == 20
+    assert np.max(np.abs(trans - o["trans"])) <= TOL
+    assert np.max(np.abs(stat.Evaluated.Gradient - o["gradient"])) <= TOL
+
+
+def test_fit_not_enough_pairs():
+    base = synth.uniform_cloud(1000, 1.0, 1)
+    target = base[:50] + f32(100.0)
+    reg = icp.PointToPointICPGradient(icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=0.5)))
+    with pytest.raises(icp.ErrNotEnoughPairs) as ei:
+        reg.Fit(kdtree.New(base), target)
+    assert ei.value.stat.NumIteration == 1  # icp.go:50-53
+    assert np.array_equal(ei.value.trans, mat.Translate(0, 0, 0))
+
+
+def test_session_matches_fit():
+    c = synth.c4_icp(n=50000, width=3.7)
+    t = kdtree.New(c["base"])
+    s = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+    for _ in range(c["max_iteration"]):
+        s.partials()
+        s.update()
+    trans, stat, conv = s.result()
+    reg = icp.PointToPointICPGradient(
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=c["min_pairs"]),
+        icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=c["threshold"], MaxIteration=c["max_iteration"]))
+    trans2, stat2 = reg.Fit(t, c["target"])
+    assert conv and stat.NumIteration == stat2.NumIteration
+    assert np.array_equal(trans, trans2)  # deterministic reduction: bitwise reproducible

@@ -1,0 +1,117 @@
+"""GPU parity: pcgx KD-tree (through the C ABI) vs the CPU oracle and the
+reference's known-answer tables.  Bit-exact ids and float32 DistSq."""
+import numpy as np
+import pytest
+
+import oracle as O
+from pcgol_amd import kdtree, synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def test_tree_shape_golden(golden):
+    g = golden("ref_kdtree.json")
+    t = kdtree.New(np.array(g["test_cloud"]["points"], f32))
+    assert t.InOrder().tolist() == [5, 4, 1, 3, 2, 0, 6]  # == expected_tree in-order
+    assert t.MaxDepth() == 3
+    assert t.Len() == 7
+    assert t.Vec3At(6).tolist() == [6, 2, 1]
+    for c in g["max_depth"]["cases"]:
+        assert kdtree.New(np.array(c["points"], f32)).MaxDepth() == c["expected"]
+
+
+def test_nearest_table_golden(golden):
+    g = golden("ref_kdtree.json")
+    base = kdtree.New(np.array(g["test_cloud"]["points"], f32))
+    for md in g["nearest"]["min_dist"]:
+        t = base.With(MinDistSq=float(f32(md) * f32(md)))
+        for c in g["nearest"]["cases"]:
+            nb = t.Nearest(c["p"], c["max_range"])
+            assert nb.ID == c["id"], (md, c)
+            assert abs(float(nb.DistSq) - c["dist_sq"]) <= g["nearest"]["eps"]
+
+
+@pytest.mark.parametrize("n,ties", [(1, False), (2, False), (3, False), (6, False), (100, False),
+                                    (1000, True), (4097, False), (50000, True)])
+def test_build_matches_oracle(n, ties):
+    rng = np.random.default_rng(n)
+    if ties:  # integer grid coordinates: many equal split keys -> exercises the stable order
+        pts = rng.integers(0, 8, size=(n, 3)).astype(f32)
+    else:
+        pts = rng.random((n, 3), dtype=f32) * f32(10)
+    t = kdtree.New(pts)
+    o = O.KDTree(pts)
+    assert np.array_equal(t.InOrder(), o.inorder())
+    assert t.MaxDepth() == o.max_depth()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_nearest_equals_naive_property(golden, seed):
+    """kdtree_test.go:794-834 through the C ABI: == brute force on ID and DistSq."""
+    g = golden("ref_kdtree.json")["random_property"]
+    rng = np.random.default_rng(seed)
+    w = f32(g["width"])
+    pts = rng.random((g["n_points"], 3), dtype=f32) * w
+    t = kdtree.New(pts)
+    for _ in range(g["n_queries"]):
+        p = rng.random(3, dtype=f32) * w
+        mr = float(rng.random(dtype=f32) * w)
+        nb = t.Nearest(p, mr)
+        assert (nb.ID, nb.DistSq) == O.naive_nearest(pts, p, mr)
+
+
+@pytest.mark.parametrize("n,nq,max_range,min_dist_sq", [
+    (1, 50, 10.0, 0.0), (2, 50, 10.0, 0.0), (5, 200, 3.0, 0.0), (1000, 5000, 10.0, 0.0),
+    (20000, 20000, 0.3, 0.0), (20000, 20000, 10.0, 0.01), (20000, 20000, 0.5, 0.1),
+    (200000, 100000, 10.0, 0.0), (200000, 100000, 0.05, 0.0), (200000, 50000, 10.0, 0.001),
+])
+def test_nearest_batch_vs_oracle(n, nq, max_range, min_dist_sq):
+    base = synth.uniform_cloud(n, 10.0, 100 + n)
+    q = synth.uniform_cloud(nq, 10.0, 200 + nq)
+    t = kdtree.New(base, MinDistSq=min_dist_sq)
+    ids, dsq = t.NearestBatch(q, max_range)
+    o = O.KDTree(base, min_dist_sq=min_dist_sq)
+    oi, od = o.nearest_batch(q, max_range)
+    assert np.array_equal(ids, oi)
+    assert np.array_equal(dsq.view(np.uint32), od.view(np.uint32))
+
+
+def test_nearest_with_ties_and_duplicates():
+    """Integer lattice: exact distance ties everywhere; the id chosen depends on the
+    reference's visit order, which the device walk reproduces."""
+    rng = np.random.default_rng(7)
+    base = rng.integers(0, 6, size=(3000, 3)).astype(f32)
+    q = rng.integers(0, 12, size=(4000, 3)).astype(f32) * f32(0.5)
+    for md in (0.0, 0.3):
+        t = kdtree.New(base, MinDistSq=md)
+        ids, dsq = t.NearestBatch(q, 2.0)
+        oi, od = O.KDTree(base, min_dist_sq=md).nearest_batch(q, 2.0)
+        assert np.array_equal(ids, oi)
+        assert np.array_equal(dsq, od)
+
+
+def test_not_found_and_empty():
+    base = synth.uniform_cloud(100, 1.0, 3)
+    t = kdtree.New(base)
+    nb = t.Nearest([50, 50, 50], 0.25)
+    assert nb.ID == -1 and nb.DistSq == f32(0.25) * f32(0.25)  # kdtree.go:100-103
+    ids, dsq = t.NearestBatch(np.zeros((0, 3), f32), 1.0)
+    assert len(ids) == 0
+    from pcgol_amd import ErrNoPoint
+    with pytest.raises(ErrNoPoint):
+        kdtree.New(np.zeros((0, 3), f32))
+
+
+def test_c2_full_size_vs_oracle():
+    """BASELINE config C2: 1M base, 1M queries, maxRange 10: ids and DistSq bit-exact."""
+    c = synth.c2_knn()
+    t = kdtree.New(c["base"])
+    ids, dsq = t.NearestBatch(c["queries"], c["max_range"])
+    o = O.KDTree(c["base"])
+    assert np.array_equal(t.InOrder(), o.inorder())
+    oi, od, visits, dists = o.nearest_batch(c["queries"], c["max_range"], stats=True)
+    assert np.array_equal(ids, oi)
+    assert np.array_equal(dsq.view(np.uint32), od.view(np.uint32))
+    # V(q) is the figure the roofline's algorithmic bytes are built on
+    assert 35.0 < visits / len(ids) < 55.0
