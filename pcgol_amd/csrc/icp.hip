@@ -38,16 +38,16 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;  // lane 0 holds the sum (fixed tree order -> deterministic)
 }
 
-// One target point per lane per grid-stride step.  Targets are stored SoA
-// (x[], y[], z[]) in Morton order of the ORIGINAL target; every iteration
-// re-projects the original by the accumulated transform (icp.go:62-64) in
-// registers, walks the tree, and accumulates the evaluator's 9 sums + the
-// pair count (evaluator.go:122-145) in float64.  Each term is formed in
-// float32 exactly as the reference forms it (w == 1).
+// Each wave owns a contiguous range of targets (walk_range).  Targets are
+// stored SoA (x[], y[], z[]) in Morton order of the ORIGINAL target; every
+// iteration re-projects the original by the accumulated transform
+// (icp.go:62-64) in registers, walks the tree, and accumulates the evaluator's
+// 9 sums + the pair count (evaluator.go:122-145) in float64.  Each term is
+// formed in float32 exactly as the reference forms it (w == 1).
 template <bool kMinDist>
 __global__ __launch_bounds__(kIcpBlock) void icp_partials_kernel(
     TreeView tv, const float *__restrict__ tx, const float *__restrict__ ty,
-    const float *__restrict__ tz, int64_t nt, const IcpState *__restrict__ state,
+    const float *__restrict__ tz, int64_t nt, int64_t per_wave, const IcpState *__restrict__ state,
     IcpKernelParams kp, double *__restrict__ block_partials) {
   extern __shared__ uint2 s_stack[];
   __shared__ double s_red[kIcpBlock / 64][S_COUNT];
@@ -62,29 +62,36 @@ __global__ __launch_bounds__(kIcpBlock) void icp_partials_kernel(
 #pragma unroll
   for (int k = 0; k < S_COUNT; k++) acc[k] = 0.0;
 
-  const int64_t step = (int64_t)gridDim.x * kIcpBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kIcpBlock + threadIdx.x; i < nt; i += step) {
-    float x0 = tx[i], y0 = ty[i], z0 = tz[i];
-    if (project) {
-      float px, py, pz;
-      mat4_transform(m, x0, y0, z0, px, py, pz);
-      x0 = px; y0 = py; z0 = pz;
-    }
-    WalkResult r = nearest_walk<kMinDist>(tv, s_stack + threadIdx.x, kIcpBlock, x0, y0, z0,
-                                          kp.max_dist_sq, kp.min_dist_sq);
-    if (r.id >= 0) {  // correspondence.go:27-29
-      const float x1 = r.bx, y1 = r.by, z1 = r.bz;
-      acc[S_VALUE] += (double)r.dist_sq;
-      acc[S_G0 + 0] += (double)(x0 - x1);
-      acc[S_G0 + 1] += (double)(y0 - y1);
-      acc[S_G0 + 2] += (double)(z0 - z1);
-      acc[S_G0 + 3] += (double)(z0 * y1 - y0 * z1);
-      acc[S_G0 + 4] += (double)(x0 * z1 - z0 * x1);
-      acc[S_G0 + 5] += (double)(y0 * x1 - x0 * y1);
-      acc[S_DIST_RMS] += (double)norm_sq3(x0, y0, z0);
-      acc[S_WEIGHT] += 1.0;
-      acc[S_PAIRS] += 1.0;
-    }
+  const int64_t wave_id = (int64_t)blockIdx.x * (kIcpBlock / 64) + (threadIdx.x >> 6);
+  const int64_t q_begin = wave_id * per_wave;
+  int64_t q_end = q_begin + per_wave;
+  if (q_end > nt) q_end = nt;
+  if (q_begin < q_end) {
+    walk_range<kMinDist>(
+        tv, s_stack + threadIdx.x, kIcpBlock, q_begin, q_end, kp.max_dist_sq, kp.min_dist_sq,
+        [&](int64_t i, float &x, float &y, float &z) {
+          x = tx[i]; y = ty[i]; z = tz[i];
+          if (project) {
+            float px, py, pz;
+            mat4_transform(m, x, y, z, px, py, pz);
+            x = px; y = py; z = pz;
+          }
+        },
+        [&](int64_t, float x0, float y0, float z0, int32_t best_pos, float best_d) {
+          if (best_pos < 0) return;  // correspondence.go:27-29
+          const float4 b = tv.nodes[best_pos];
+          const float x1 = b.x, y1 = b.y, z1 = b.z;
+          acc[S_VALUE] += (double)best_d;
+          acc[S_G0 + 0] += (double)(x0 - x1);
+          acc[S_G0 + 1] += (double)(y0 - y1);
+          acc[S_G0 + 2] += (double)(z0 - z1);
+          acc[S_G0 + 3] += (double)(z0 * y1 - y0 * z1);
+          acc[S_G0 + 4] += (double)(x0 * z1 - z0 * x1);
+          acc[S_G0 + 5] += (double)(y0 * x1 - x0 * y1);
+          acc[S_DIST_RMS] += (double)norm_sq3(x0, y0, z0);
+          acc[S_WEIGHT] += 1.0;
+          acc[S_PAIRS] += 1.0;
+        });
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -172,6 +179,7 @@ struct pcgx_icp_session {
   double *d_sums = nullptr;  // caller's buffer, or own
   bool own_sums = false;
   int grid = 1;
+  int64_t per_wave = 1;
   IcpKernelParams kp;
   int32_t max_iteration = 20;
 };
@@ -185,9 +193,9 @@ static IcpKernelParams make_kernel_params(const pcgx_icp_params *p) {
   return kp;
 }
 
-static int icp_grid(int64_t nt) {
+static int icp_grid(int64_t nt, const TreeView &tv) {
   int64_t blocks = (nt + kIcpBlock - 1) / kIcpBlock;
-  int64_t cap = (int64_t)ctx().num_cu * 4;  // 4 blocks of 256 threads per CU fit the LDS stacks
+  int64_t cap = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv);
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   return (int)blocks;
@@ -233,7 +241,8 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
   s->nt = nt;
   s->kp = make_kernel_params(params);
   s->max_iteration = s->kp.upd.max_iteration;
-  s->grid = icp_grid(nt);
+  s->grid = icp_grid(nt, base->view());
+  s->per_wave = (nt + (int64_t)s->grid * (kIcpBlock / 64) - 1) / ((int64_t)s->grid * (kIcpBlock / 64));
   pcgx_status rc = PCGX_OK;
   auto bail = [&](pcgx_status code) {
     pcgx_icp_session_free(s);
@@ -287,10 +296,10 @@ extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stre
     ProfScope prof(PCGX_PROF_ICP_WALK, st);
     if (s->kp.min_dist_sq > 0.0f)
       hipLaunchKernelGGL(icp_partials_kernel<true>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                         s->d_state, s->kp, s->d_partials);
+                         s->per_wave, s->d_state, s->kp, s->d_partials);
     else
       hipLaunchKernelGGL(icp_partials_kernel<false>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                         s->d_state, s->kp, s->d_partials);
+                         s->per_wave, s->d_state, s->kp, s->d_partials);
   }
   hipLaunchKernelGGL(icp_final_reduce_kernel, dim3(1), dim3(256), 0, st, s->d_partials, s->grid, s->d_state,
                      s->d_sums);

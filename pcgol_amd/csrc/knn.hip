@@ -1,5 +1,6 @@
 // knn.hip -- batched KDTree.Nearest on gfx950 + the pcgx_kdtree_* C ABI.
 // Reference: pc/storage/kdtree/kdtree.go (New :33-56, Nearest :83-146).
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -8,26 +9,51 @@
 
 namespace pcgx {
 
-// One query per lane.  Queries are packed xyz (AoS, 12 B): a wave reads 768
-// contiguous bytes.  `perm` (optional) maps the launch position to the query
-// index (Morton order, see morton.hip): results are written at the original
-// index so the permutation is invisible to the caller.
+// Each wave owns a contiguous range of launch positions and walks it with
+// walk_range (one query per lane, finished lanes refill from the range).
+// Queries are packed xyz (AoS, 12 B).  `perm` (optional) maps the launch
+// position to the query index (Morton order, sort.hip): results are written at
+// the original index, so the permutation is invisible to the caller.
 template <bool kMinDist>
 __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const float *__restrict__ q,
                                                             const int32_t *__restrict__ perm,
-                                                            int64_t nq, float max_range_sq,
-                                                            float min_dist_sq,
+                                                            int64_t nq, int64_t per_wave,
+                                                            float max_range_sq, float min_dist_sq,
                                                             int32_t *__restrict__ out_id,
                                                             float *__restrict__ out_dsq) {
   extern __shared__ uint2 s_stack[];
-  const int64_t pos = (int64_t)blockIdx.x * kKnnBlock + threadIdx.x;
-  if (pos >= nq) return;
-  const int64_t i = perm ? (int64_t)perm[pos] : pos;
-  const float qx = q[3 * i + 0], qy = q[3 * i + 1], qz = q[3 * i + 2];
-  WalkResult r = nearest_walk<kMinDist>(tv, s_stack + threadIdx.x, kKnnBlock, qx, qy, qz,
-                                        max_range_sq, min_dist_sq);
-  out_id[i] = r.id;
-  out_dsq[i] = r.dist_sq;
+  const int64_t wave = (int64_t)blockIdx.x * (kKnnBlock / 64) + (threadIdx.x >> 6);
+  const int64_t q_begin = wave * per_wave;
+  int64_t q_end = q_begin + per_wave;
+  if (q_end > nq) q_end = nq;
+  if (q_begin >= q_end) return;
+  walk_range<kMinDist>(
+      tv, s_stack + threadIdx.x, kKnnBlock, q_begin, q_end, max_range_sq, min_dist_sq,
+      [&](int64_t pos, float &x, float &y, float &z) {
+        const int64_t i = perm ? (int64_t)perm[pos] : pos;
+        x = q[3 * i + 0];
+        y = q[3 * i + 1];
+        z = q[3 * i + 2];
+      },
+      [&](int64_t pos, float, float, float, int32_t best_pos, float best_d) {
+        const int64_t i = perm ? (int64_t)perm[pos] : pos;
+        out_id[i] = best_pos >= 0 ? __float_as_int(tv.nodes[best_pos].w) : -1;
+        out_dsq[i] = best_d;
+      });
+}
+
+// Waves resident per CU for the walk kernels: the LDS stacks of a 256-thread
+// block take (depth-1)*2 KiB, so 4 blocks (16 waves) fit at depth <= 20.
+int walk_blocks_per_cu(const TreeView &tv) {
+  const size_t lds = walk_stack_bytes(tv, kKnnBlock);
+  int b = (int)((160 * 1024) / (lds ? lds : 1));
+  if (b > 4) b = 4;
+  if (b < 1) b = 1;
+  if (const char *e = getenv("PCGX_WALK_BLOCKS_PER_CU")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 8) b = v;
+  }
+  return b;
 }
 
 pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *d_perm, int64_t nq,
@@ -35,16 +61,20 @@ pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *
                            hipStream_t st) {
   if (nq == 0) return PCGX_OK;
   const size_t lds = walk_stack_bytes(tv, kKnnBlock);
-  const int64_t blocks = (nq + kKnnBlock - 1) / kKnnBlock;
-  if (blocks > 0x7fffffff) return fail(PCGX_E_INVALID, "too many queries in one batch: %lld", (long long)nq);
+  const int waves_per_block = kKnnBlock / 64;
+  int64_t blocks = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv);
+  const int64_t max_blocks = (nq + kKnnBlock - 1) / kKnnBlock;
+  if (blocks > max_blocks) blocks = max_blocks;
+  const int64_t waves = blocks * waves_per_block;
+  const int64_t per_wave = (nq + waves - 1) / waves;
   ProfScope prof(PCGX_PROF_KNN_WALK, st);
   // `x < MinDistSq` can only hold for MinDistSq > 0 (or NaN distances, which compare false).
   if (min_dist_sq > 0.0f)
     hipLaunchKernelGGL(nearest_kernel<true>, dim3((unsigned)blocks), dim3(kKnnBlock), lds, st, tv, d_q,
-                       d_perm, nq, max_range_sq, min_dist_sq, d_ids, d_dsq);
+                       d_perm, nq, per_wave, max_range_sq, min_dist_sq, d_ids, d_dsq);
   else
     hipLaunchKernelGGL(nearest_kernel<false>, dim3((unsigned)blocks), dim3(kKnnBlock), lds, st, tv, d_q,
-                       d_perm, nq, max_range_sq, min_dist_sq, d_ids, d_dsq);
+                       d_perm, nq, per_wave, max_range_sq, min_dist_sq, d_ids, d_dsq);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }

@@ -105,6 +105,7 @@ inline size_t walk_stack_bytes(const TreeView &tv, int block) {
   int levels = tv.depth > 1 ? tv.depth - 1 : 1;
   return (size_t)levels * block * sizeof(uint2);
 }
+int walk_blocks_per_cu(const TreeView &tv);
 pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *d_perm, int64_t nq,
                            float max_range_sq, float min_dist_sq, int32_t *d_ids, float *d_dsq,
                            hipStream_t st);
