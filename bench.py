@@ -29,20 +29,6 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 
-def morton30(pts, lo, hi):
-    """30-bit Morton code of points (host, numpy) for the spatial tiling of the global target."""
-    cells = np.clip(((pts - lo) / np.maximum(hi - lo, 1e-30) * 1024.0).astype(np.int64), 0, 1023)
-
-    def spread(v):
-        v = v & 0x3FF
-        v = (v | (v << 16)) & 0x030000FF
-        v = (v | (v << 8)) & 0x0300F00F
-        v = (v | (v << 4)) & 0x030C30C3
-        v = (v | (v << 2)) & 0x09249249
-        return v
-    return spread(cells[:, 0]) | (spread(cells[:, 1]) << 1) | (spread(cells[:, 2]) << 2)
-
-
 def make_tile(synth, base, rank, world, n_per_gpu):
     """Rank's spatial tile of the global target (world x n_per_gpu points).
     Block b of the global target = T * base[perm_b] (perm seed 5 + b: block 0 is exactly
@@ -56,9 +42,8 @@ def make_tile(synth, base, rank, world, n_per_gpu):
         perm = np.random.Generator(np.random.PCG64(5 + b)).permutation(len(base))[:n_per_gpu]
         blocks.append(synth.transform_points(pose, base[perm]))
     g = np.concatenate(blocks)
-    order = np.argsort(morton30(g, g.min(axis=0), g.max(axis=0)), kind="stable")
-    sl = order[rank * n_per_gpu:(rank + 1) * n_per_gpu]
-    return np.ascontiguousarray(g[sl])
+    from pcgol_amd.distributed import spatial_tiles
+    return np.ascontiguousarray(g[spatial_tiles(g, world)[rank]])
 
 
 def load_visits():
@@ -179,19 +164,16 @@ def main():
     build_s = time.perf_counter() - t0
 
     stream = torch.cuda.current_stream().cuda_stream
-    sums = torch.zeros(10, dtype=torch.float64, device="cuda")
-    sess = icp.IcpSession(tree, tile, cfg["max_dist"], cfg["min_pairs"], cfg["weight"], cfg["threshold"],
-                          cfg["max_iteration"], d_sums10=sums.data_ptr())
+    from pcgol_amd.distributed import ShardedIcp
+    sicp = ShardedIcp(tree, tile, cfg["max_dist"], cfg["min_pairs"], cfg["weight"], cfg["threshold"],
+                      cfg["max_iteration"])
     in_fit = [0]
 
     def step():
         if in_fit[0] == cfg["max_iteration"]:
-            sess.reset(stream)
+            sicp.reset()
             in_fit[0] = 0
-        sess.partials(stream)
-        if world > 1:
-            dist.all_reduce(sums)  # RCCL over xGMI: 80 bytes, the path's only exchange
-        sess.update(stream)
+        sicp.step()  # partials kernel -> [N>1: RCCL all-reduce of 80 bytes] -> update kernel
         in_fit[0] += 1
 
     def barrier():
@@ -216,7 +198,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     walk_ms, walk_n = L.prof_read(L.PROF_ICP_WALK)
-    trans, stat, _ = sess.result(stream)
+    trans, stat, _ = sicp.result()
 
     if rank == 0:
         visits = load_visits()
@@ -251,7 +233,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(synth, base, tile, cfg)
             line["cpu_baseline"]["host_cpus"] = os.cpu_count()
         print(json.dumps(line), flush=True)
-    sess.close()
+    sicp.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

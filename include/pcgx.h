@@ -234,6 +234,13 @@ PCGX_API pcgx_status pcgx_icp_session_free(pcgx_icp_session *s);
 /* Restart the loop on the same target: trans = identity, counters cleared
  * (a new Fit, icp.go:46-47). */
 PCGX_API pcgx_status pcgx_icp_session_reset(pcgx_icp_session *s, void *stream);
+/* Overwrite the loop state's transform and updater counter (host-driven loops:
+ * evaluate this rank's partial sums at a given pose).  iter == 0 means "no
+ * re-projection yet" (the first Evaluate of Fit sees the raw target, icp.go:27-30). */
+PCGX_API pcgx_status pcgx_icp_session_set_pose(pcgx_icp_session *s, const float trans16[16],
+                                               int32_t iter, void *stream);
+/* Copy the session's d_sums10 to the host (synchronises the stream). */
+PCGX_API pcgx_status pcgx_icp_session_read_sums(pcgx_icp_session *s, double sums10[10], void *stream);
 /* Enqueue transform(original target, current trans) + nearest + reduction of
  * this rank's tile into d_sums10.  No-op once the session has converged. */
 PCGX_API pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stream);

@@ -115,6 +115,8 @@ SIGNATURES = {
     "pcgx_icp_session_create": (_i32, [_vp, _vp, _i64, _i32, C.POINTER(IcpParams), _vp, C.POINTER(_vp)]),
     "pcgx_icp_session_free": (_i32, [_vp]),
     "pcgx_icp_session_reset": (_i32, [_vp, _vp]),
+    "pcgx_icp_session_set_pose": (_i32, [_vp, _vp, _i32, _vp]),
+    "pcgx_icp_session_read_sums": (_i32, [_vp, _vp, _vp]),
     "pcgx_icp_session_partials": (_i32, [_vp, _vp]),
     "pcgx_icp_session_update": (_i32, [_vp, _vp]),
     "pcgx_icp_session_result": (_i32, [_vp, _vp, _vp, C.POINTER(IcpStat), C.POINTER(_i32)]),

@@ -216,6 +216,27 @@ extern "C" pcgx_status pcgx_icp_session_reset(pcgx_icp_session *s, void *stream)
   return reset_state(s, pick_stream(stream));
 }
 
+extern "C" pcgx_status pcgx_icp_session_set_pose(pcgx_icp_session *s, const float trans16[16],
+                                                 int32_t iter, void *stream) {
+  if (!s || !trans16 || iter < 0) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_pose: bad argument");
+  hipStream_t st = pick_stream(stream);
+  IcpState h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.trans, trans16, sizeof h.trans);
+  h.iter = iter;
+  PCGX_HIP_TRY(hipMemcpyAsync(s->d_state, &h, sizeof h, hipMemcpyHostToDevice, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_session_read_sums(pcgx_icp_session *s, double sums10[10], void *stream) {
+  if (!s || !sums10) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums: bad argument");
+  hipStream_t st = pick_stream(stream);
+  PCGX_HIP_TRY(hipMemcpyAsync(sums10, s->d_sums, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  return PCGX_OK;
+}
+
 extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   if (!s) return PCGX_OK;
   if (s->d_xyz) (void)hipFree(s->d_xyz);

@@ -213,7 +213,7 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const flo
   PCGX_TRY(b.alloc(nq));
   PCGX_HIP_TRY(hipMemcpyAsync(b.q, q, (size_t)nq * 12, hipMemcpyHostToDevice, st));
   PCGX_TRY(pcgx_kdtree_nearest_batch_dev(t, b.q, nq, max_range, min_dist_sq,
-                                         nq >= 4096 ? PCGX_KNN_PRESORT : 0u, b.ids, b.dsq, st));
+                                         0u, b.ids, b.dsq, st));
   std::vector<int32_t> h_id((size_t)nq);
   PCGX_HIP_TRY(hipMemcpyAsync(h_id.data(), b.ids, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipMemcpyAsync(dist_sq, b.dsq, (size_t)nq * 4, hipMemcpyDeviceToHost, st));

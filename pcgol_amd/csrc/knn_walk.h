@@ -42,6 +42,14 @@ __device__ __forceinline__ float sel3(int dim, float a, float b, float c) {
 
 // fetch(idx, qx, qy, qz): loads query idx.   emit(idx, qx, qy, qz, best_pos, best_d):
 // consumes the result; best_pos is the in-order node index of the match or -1.
+//
+// The step is written with selects rather than nested branches: on gfx950 a
+// divergent if/else costs scalar exec-mask bookkeeping on the CU's single
+// scalar unit, which (not memory) was what bound the first version of this
+// kernel (profiles/r01a_pmc.json: 121 SALU and 85 VALU instructions per node
+// fetch, 29 % of the lanes active per VALU instruction).
+constexpr int kRefillThreshold = 12;  // refill when this many lanes are idle (or nothing is active)
+
 template <bool kMinDist, class Fetch, class Emit>
 __device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict__ stk,
                                            const int stk_stride, const int64_t q_begin,
@@ -50,9 +58,10 @@ __device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict_
   const int lane = (int)(threadIdx.x & 63u);
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const uint32_t np1 = (uint32_t)tv.n + 1u;
-  int64_t next = q_begin;  // wave-uniform
+  const int32_t count = (int32_t)(q_end - q_begin);  // a wave's range is far below 2^31
+  int32_t next = 0;                                   // wave-uniform, relative to q_begin
   bool active = false;
-  int64_t my_q = 0;
+  int32_t my_q = 0;
   float qx = 0.0f, qy = 0.0f, qz = 0.0f, best_d = 0.0f;
   int32_t best_pos = -1;
   int32_t lo = 0, n = 0, depth = 0, sp = 0;
@@ -61,12 +70,13 @@ __device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict_
   for (;;) {
     // ---- refill idle lanes from the wave's range --------------------------------
     const uint64_t idle = __ballot(!active);
-    if (idle != 0ull) {
-      if (next < q_end) {
+    const int n_idle = __popcll(idle);
+    if (n_idle >= kRefillThreshold || n_idle == 64) {
+      if (next < count) {
         if (!active) {
-          const int64_t idx = next + (int64_t)__popcll(idle & lt_mask);
-          if (idx < q_end) {
-            fetch(idx, qx, qy, qz);
+          const int32_t idx = next + (int32_t)__popcll(idle & lt_mask);
+          if (idx < count) {
+            fetch(q_begin + idx, qx, qy, qz);
             my_q = idx;
             best_d = max_range_sq;
             best_pos = -1;
@@ -78,100 +88,75 @@ __device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict_
             active = true;
           }
         }
-        next += (int64_t)__popcll(idle);
-      }
-      if (__ballot(active) == 0ull) break;  // range exhausted and every lane done
-    }
-
-    // ---- choose the node this lane looks at in this step -------------------------
-    int32_t mid = 0;
-    bool look = false;
-    float ffp = 0.0f;
-    int32_t fdepth = 0, fn = 0;
-    bool finish = false;
-    if (active) {
-      if (desc) {
-        mid = lo + (n >> 1);
-        look = true;
-      } else if (sp == 0) {
-        finish = true;
-      } else {
-        // unwind: examine the two topmost frames at once (kdtree.go:107-115)
-        const uint2 f0 = stk[(sp - 1) * stk_stride];
-        const uint2 f1 = stk[(sp >= 2 ? sp - 2 : 0) * stk_stride];
-        const float fp0 = __uint_as_float(f0.y), fp1 = __uint_as_float(f1.y);
-        const bool pass0 = !(fp0 * fp0 > best_d);
-        const bool pass1 = sp >= 2 && !(fp1 * fp1 > best_d);
-        uint32_t fx = 0;
-        if (pass0) {
-          fx = f0.x; ffp = fp0; sp -= 1; look = true;
-        } else if (pass1) {
-          fx = f1.x; ffp = fp1; sp -= 2; look = true;
-        } else {
-          sp = sp >= 2 ? sp - 2 : 0;
-          finish = sp == 0;
-        }
-        mid = (int32_t)(fx & 0x03FFFFFFu);
-        fdepth = (int32_t)((fx >> 26) & 31u);
-        fn = (int32_t)((np1 >> fdepth) - 1u + (fx >> 31));
+        next += n_idle;
+      } else if (n_idle == 64) {
+        break;  // range exhausted and every lane done
       }
     }
 
+    // ---- unwinding lanes: look at the two topmost frames (kdtree.go:107-115) ------
+    const bool popping = active && !desc;
+    const int32_t i0 = sp >= 1 ? sp - 1 : 0, i1 = sp >= 2 ? sp - 2 : 0;
+    const uint2 f0 = stk[i0 * stk_stride];
+    const uint2 f1 = stk[i1 * stk_stride];
+    const float fp0 = __uint_as_float(f0.y), fp1 = __uint_as_float(f1.y);
+    const bool pass0 = sp >= 1 && !(fp0 * fp0 > best_d);
+    const bool pass1 = sp >= 2 && !(fp1 * fp1 > best_d);
+    const bool pfound = popping && (pass0 || pass1);
+    const uint32_t fx = pass0 ? f0.x : f1.x;
+    const float ffp = pass0 ? fp0 : fp1;
+    const int32_t sp_pop = pass0 ? sp - 1 : i1;  // pass1 -> sp-2; neither -> max(sp-2, 0)
+    sp = popping ? sp_pop : sp;
+    bool finish = popping && !pfound && sp == 0;
+    const int32_t fdepth = (int32_t)((fx >> 26) & 31u);
+    const int32_t fn = (int32_t)((np1 >> fdepth) - 1u + (fx >> 31));
+
+    // ---- the one node fetch of this step -----------------------------------------
+    const int32_t mid = desc ? lo + (n >> 1) : (int32_t)(fx & 0x03FFFFFFu);
+    const bool look = active && (desc || pfound);
     if (look) {
       const float4 nd = tv.nodes[mid];
       const float dx = nd.x - qx, dy = nd.y - qy, dz = nd.z - qz;  // pivot.Sub(p)
       const float d = (dx * dx + dy * dy) + dz * dz;                // NormSq, mat/vec3.go:18-20
-      if (desc) {
-        if (n == 1) {  // leaf: kdtree.go:95-106
-          if (!(d > best_d)) {
-            best_d = d;
-            best_pos = mid;
-          }
-          desc = false;
-          if (kMinDist && best_d < min_dist_sq) finish = true;
-        } else {  // searchLeafNode step: kdtree.go:202-221
-          const int dim = depth % 3;
-          const float pv = sel3(dim, nd.x, nd.y, nd.z);
-          const float qv = sel3(dim, qx, qy, qz);
-          const float fp = qv - pv;
-          if (!(fp * fp > best_d)) {
-            const uint32_t size_bit = (uint32_t)n - ((np1 >> depth) - 1u);
-            stk[sp * stk_stride] = make_uint2((uint32_t)mid | ((uint32_t)depth << 26) | (size_bit << 31),
-                                              __float_as_uint(fp));
-            ++sp;
-          }
-          const int32_t half = n >> 1;
-          if (n == 2 || pv > qv) {  // only child, or pivotVal > val -> child0
-            n = half;
-          } else {
-            lo = mid + 1;
-            n = n - half - 1;
-          }
-          ++depth;
-        }
-      } else {  // a frame that passed the plane test: kdtree.go:116-143
-        if (d < best_d) {
-          best_d = d;
-          best_pos = mid;
-          if (kMinDist && best_d < min_dist_sq) finish = true;
-        }
-        if (fn != 2) {  // fn == 2: single child, nextNode == nil (kdtree.go:130-132)
-          const int32_t half = fn >> 1;
-          if (ffp < 0.0f) {  // went to child0, the other side is child1
-            lo = mid + 1;
-            n = fn - half - 1;
-          } else {
-            lo = mid - half;
-            n = half;
-          }
-          depth = fdepth + 1;
-          desc = true;
-        }
+      const bool leaf = desc && n == 1;
+      const bool inner = desc && n != 1;
+      // leaf: replace unless d > best (kdtree.go:95-103); pivot: replace if d < best (:116-119)
+      const bool take = leaf ? !(d > best_d) : (!desc && d < best_d);
+      best_d = take ? d : best_d;
+      best_pos = take ? mid : best_pos;
+      if (kMinDist) finish = finish || ((leaf || take) && best_d < min_dist_sq);  // :104,120,140
+
+      // descending through an inner node: searchLeafNode step (kdtree.go:202-221)
+      const int dim = depth % 3;
+      const float pv = sel3(dim, nd.x, nd.y, nd.z);
+      const float qv = sel3(dim, qx, qy, qz);
+      const float fp = qv - pv;
+      if (inner && !(fp * fp > best_d)) {
+        const uint32_t size_bit = (uint32_t)n - ((np1 >> depth) - 1u);
+        stk[sp * stk_stride] = make_uint2((uint32_t)mid | ((uint32_t)depth << 26) | (size_bit << 31),
+                                          __float_as_uint(fp));
+        ++sp;
       }
+      const int32_t half = n >> 1;
+      const bool go_left = n == 2 || pv > qv;  // only child, or pivotVal > val -> child0
+      const int32_t d_lo = go_left ? lo : mid + 1;
+      const int32_t d_n = go_left ? half : n - half - 1;
+
+      // unwinding through a frame that passed the plane test: the other side (kdtree.go:124-137)
+      const int32_t phalf = fn >> 1;
+      const bool went_left = ffp < 0.0f;
+      const int32_t p_lo = went_left ? mid + 1 : mid - phalf;
+      const int32_t p_n = went_left ? fn - phalf - 1 : phalf;
+      const bool p_far = fn != 2;  // fn == 2: single child, nextNode == nil (:130-132)
+
+      lo = desc ? d_lo : p_lo;
+      n = desc ? d_n : p_n;
+      depth = (desc ? depth : fdepth) + 1;
+      desc = desc ? inner : p_far;
     }
 
     if (finish) {
-      emit(my_q, qx, qy, qz, best_pos, best_d);
+      emit(q_begin + my_q, qx, qy, qz, best_pos, best_d);
       active = false;
     }
   }

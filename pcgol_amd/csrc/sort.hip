@@ -289,17 +289,29 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__re
   }
 }
 
-// out6 = {min xyz, max xyz}
-__global__ void minmax_final_kernel(const MinMaxAcc *__restrict__ partials, int nparts,
-                                    const uint8_t *__restrict__ data, int32_t off,
-                                    float *__restrict__ out6) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  MinMaxAcc a = partials[0];
-  for (int b = 1; b < nparts; b++)
+// out6 = {min xyz, max xyz}; one wave folds the per-block partials.
+__global__ __launch_bounds__(64) void minmax_final_kernel(const MinMaxAcc *__restrict__ partials, int nparts,
+                                                          const uint8_t *__restrict__ data, int32_t off,
+                                                          float *__restrict__ out6) {
+  const float qnan = __uint_as_float(0x7fc00000u);
+  MinMaxAcc a;
+  for (int k = 0; k < 3; k++) {
+    a.mn[k] = qnan; a.mx[k] = qnan;
+    a.imn[k] = 0x7fffffff; a.imx[k] = 0x7fffffff;
+  }
+  for (int b = threadIdx.x; b < nparts; b += 64)
     for (int k = 0; k < 3; k++) {
       mm_take(a.mn[k], a.imn[k], partials[b].mn[k], partials[b].imn[k], true);
       mm_take(a.mx[k], a.imx[k], partials[b].mx[k], partials[b].imx[k], false);
     }
+  for (int o = 32; o > 0; o >>= 1)
+    for (int k = 0; k < 3; k++) {
+      float v = __shfl_down(a.mn[k], o); int32_t iv = __shfl_down(a.imn[k], o);
+      mm_take(a.mn[k], a.imn[k], v, iv, true);
+      v = __shfl_down(a.mx[k], o); iv = __shfl_down(a.imx[k], o);
+      mm_take(a.mx[k], a.imx[k], v, iv, false);
+    }
+  if (threadIdx.x != 0) return;
   for (int k = 0; k < 3; k++) {
     // min, max := Vec3At(0): a NaN there is never replaced (minmax.go:13-23)
     const float p0 = ld_f32_any(data + off + 4 * k);

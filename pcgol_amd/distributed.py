@@ -1,0 +1,125 @@
+"""Multi-GPU ICP: one process per GPU, target tiles sharded across ranks, base
+KD-tree replicated, ONE exchange per iteration: the all-reduce (sum) of the 10
+float64 partial sums.  torch.distributed's "nccl" backend is
+RCCL on ROCm (xGMI inside a node); "gloo" runs the same host logic on CPU.
+
+Nothing else on the path communicates: kNN batches and the voxel filter shard
+by independent tiles / chunks with no collective.
+"""
+import numpy as np
+
+from . import _lib as L
+from . import icp as _icp
+from . import mat
+
+
+def morton30(pts, lo, hi):
+    """30-bit Morton code (host, numpy) used to cut a cloud into spatial tiles."""
+    ext = np.maximum((hi - lo).astype(np.float64), 1e-30)
+    cells = np.clip(((pts.astype(np.float64) - lo) / ext * 1024.0).astype(np.int64), 0, 1023)
+
+    def spread(v):
+        v = v & 0x3FF
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    return spread(cells[:, 0]) | (spread(cells[:, 1]) << 1) | (spread(cells[:, 2]) << 2)
+
+
+def spatial_tiles(points, world):
+    """Index arrays of `world` spatial tiles: the cloud in Morton order cut into contiguous,
+    equally sized ranges.  The tiles partition the cloud (every point in exactly one tile)."""
+    points = np.asarray(points, np.float32).reshape(-1, 3)
+    order = np.argsort(morton30(points, points.min(axis=0), points.max(axis=0)), kind="stable")
+    bounds = [(len(points) * r) // world for r in range(world + 1)]
+    return [order[bounds[r]:bounds[r + 1]] for r in range(world)]
+
+
+def allreduce_sums(sums10, group=None):
+    """Sum of the 10 partial sums over all ranks.  numpy float64[10] (host, any backend that
+    supports CPU tensors) or a torch tensor (device tensors go through RCCL)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return sums10
+    if isinstance(sums10, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(sums10, dtype=np.float64).copy())
+        if dist.get_backend(group) == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, group=group)
+        return t.cpu().numpy()
+    dist.all_reduce(sums10, group=group)
+    return sums10
+
+
+def fit_sharded(partials_fn, MinPairs=0, UpdaterFactory=None, group=None):
+    """The reference's Fit loop (icp.go:46-66) with the evaluator split at the exchange:
+
+        sums   = partials_fn(trans, it)       # this rank's 10 float64 sums at the current pose
+        sums   = all-reduce(sums)             # the only collective
+        ev     = finish_evaluate(sums)        # evaluator.go:156-186, identical on every rank
+        trans  = updater.Update(trans, ev)    # updater.go:44-71, identical on every rank
+
+    `it` is the number of pose updates applied so far (0: the raw target is evaluated).
+    Returns (trans, Stat).  Raises ErrNotEnoughPairs like Fit.  Host-driven: used by the
+    backend-agnostic tests and by hosts that bring their own exchange; bench.py uses
+    ShardedIcp below, which keeps the loop on the device."""
+    uf = UpdaterFactory or _icp.GradientDescentUpdaterFactory()
+    updater = uf.New()
+    trans = mat.Translate(0, 0, 0)
+    stat = _icp.Stat()
+    while True:
+        sums = allreduce_sums(np.asarray(partials_fn(trans, updater.i), np.float64), group)
+        stat.NumIteration += 1
+        try:
+            ev = _icp.FinishEvaluate(sums, MinPairs)
+        except L.ErrNotEnoughPairs as e:
+            e.trans, e.stat = trans, stat
+            raise
+        stat.Evaluated = ev
+        trans, converged = updater.Update(trans, ev)
+        if converged:
+            return trans, stat
+
+
+class ShardedIcp:
+    """Device-resident sharded Fit: every rank holds the whole base tree and one tile of the
+    target; per iteration the partial sums are all-reduced in place on the device (RCCL) and the
+    pose update runs on every GPU redundantly, so no rank ever waits for the host."""
+
+    def __init__(self, base_tree, target_tile, MaxDist, MinPairs=0, Weight=None, Threshold=None,
+                 MaxIteration=0, group=None):
+        import torch
+        self.torch = torch
+        self.group = group
+        self.sums = torch.zeros(10, dtype=torch.float64, device="cuda")
+        self.sess = _icp.IcpSession(base_tree, target_tile, MaxDist, MinPairs, Weight, Threshold, MaxIteration,
+                                    d_sums10=self.sums.data_ptr())
+        self.max_iteration = self.sess.max_iteration
+        import torch.distributed as dist
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def step(self):
+        """One ICP iteration, enqueued on torch's current stream."""
+        st = self.torch.cuda.current_stream().cuda_stream
+        self.sess.partials(st)
+        if self.world > 1:
+            self.torch.distributed.all_reduce(self.sums, group=self.group)
+        self.sess.update(st)
+
+    def reset(self):
+        self.sess.reset(self.torch.cuda.current_stream().cuda_stream)
+
+    def fit(self):
+        self.reset()
+        for _ in range(self.max_iteration):
+            self.step()
+        return self.result()
+
+    def result(self):
+        return self.sess.result(self.torch.cuda.current_stream().cuda_stream)
+
+    def close(self):
+        self.sess.close()

@@ -114,6 +114,14 @@ class _GradientDescentUpdater:  # updater.go:39-71
         return t, bool(conv.value)
 
 
+def FinishEvaluate(sums10, MinPairs=0):
+    """evaluator.go:92-105,156-186 from the 10 (all-reduced) float64 sums."""
+    s = np.ascontiguousarray(sums10, dtype=np.float64)
+    ev = L.IcpEvaluated()
+    L.check(L.lib().pcgx_icp_finish_evaluate(L.ptr(s), int(MinPairs), C.byref(ev)))
+    return Evaluated(ev)
+
+
 class Stat:  # stat.go:3-6
     def __init__(self, st=None):
         self.Evaluated = Evaluated(st.evaluated if st else None)
@@ -170,6 +178,15 @@ class IcpSession:
 
     def update(self, stream=0):
         L.check(L.lib().pcgx_icp_session_update(self._h, L.ptr(stream) if stream else None))
+
+    def set_pose(self, trans, it, stream=0):
+        t = L.f32c(trans)
+        L.check(L.lib().pcgx_icp_session_set_pose(self._h, L.ptr(t), int(it), L.ptr(stream) if stream else None))
+
+    def read_sums(self, stream=0):
+        out = np.empty(10, np.float64)
+        L.check(L.lib().pcgx_icp_session_read_sums(self._h, L.ptr(out), L.ptr(stream) if stream else None))
+        return out
 
     def reset(self, stream=0):
         L.check(L.lib().pcgx_icp_session_reset(self._h, L.ptr(stream) if stream else None))

@@ -1,0 +1,85 @@
+"""world_size-2 test of the N > 1 path on CPU (gloo): target tiles sharded over ranks, one
+all-reduce of the 10 float64 partial sums per iteration, evaluator tail + pose update computed
+redundantly by the PRODUCT's host functions (libpcgx.so, no GPU needed).  The per-rank
+partial sums, which on a GPU box come from the HIP kernel, are supplied here by the oracle --
+the test checks the sharding + exchange + update logic, not the kernel."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case():
+    from pcgol_amd import synth
+    c = synth.c4_icp(n=6000, width=1.8)
+    return c
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from pcgol_amd import icp, mat
+        from pcgol_amd.distributed import fit_sharded, spatial_tiles
+        c = _case()
+        tile = c["target"][spatial_tiles(c["target"], world)[rank]]
+        tree = O.KDTree(c["base"])  # replicated base
+
+        def partials(trans, it):
+            tt = tile if it == 0 else mat.Transform(trans, tile)
+            try:
+                return O.icp_evaluate(tree, tt, c["max_dist"], 1, sums_mode=1)["raw10"]
+            except O.OracleError:  # this tile alone has no pairs: contributes zeros
+                return np.zeros(10)
+
+        uf = icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=c["threshold"],
+                                               MaxIteration=c["max_iteration"])
+        trans, stat = fit_sharded(partials, MinPairs=c["min_pairs"], UpdaterFactory=uf)
+        q.put((rank, trans, stat.NumIteration, float(stat.Evaluated.Value)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_fit_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # every rank ends with the same pose (the update is computed redundantly from identical sums)
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2] == 20
+    sys.path.insert(0, ROOT)
+    import oracle as O
+    c = _case()
+    tree = O.KDTree(c["base"])
+    o64 = O.icp_fit(tree, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
+                    c["max_iteration"], sums_mode=1)
+    o32 = O.icp_fit(tree, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
+                    c["max_iteration"], sums_mode=0)
+    assert np.max(np.abs(res[0][1] - o64["trans"])) <= 1e-6   # same float64-summed algorithm, different association
+    assert np.max(np.abs(res[0][1] - o32["trans"])) <= 1e-5   # the reference's sequential float32 sums
