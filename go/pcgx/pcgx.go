@@ -1,0 +1,275 @@
+// Package pcgx binds libpcgx.so (include/pcgx.h), the MI355X hot path, behind
+// seqsense/pcgol's interfaces: storage.Search, filter.Filter, icp.Evaluator.
+//
+// NOT compiled in the build image (no Go toolchain there); see go/README.md.
+package pcgx
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -lpcgx
+#include <stdlib.h>
+#include "pcgx.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"fmt"
+	"runtime"
+	"unsafe"
+
+	"github.com/seqsense/pcgol/mat"
+	"github.com/seqsense/pcgol/pc"
+	"github.com/seqsense/pcgol/pc/filter"
+	"github.com/seqsense/pcgol/pc/registration/icp"
+	"github.com/seqsense/pcgol/pc/storage"
+)
+
+// ErrOutOfRange is returned where the pure-Go filter would panic with
+// "index out of range" (pc/filter/voxelgrid/voxelgrid.go:151).
+var ErrOutOfRange = errors.New("pcgx: point outside the dense voxel grid")
+
+func lastError() string {
+	buf := make([]byte, 512)
+	C.pcgx_last_error((*C.char)(unsafe.Pointer(&buf[0])), C.size_t(len(buf)))
+	for i, b := range buf {
+		if b == 0 {
+			return string(buf[:i])
+		}
+	}
+	return string(buf)
+}
+
+// status maps pcgx_status onto the reference's sentinel errors so that
+// errors.Is keeps working for callers.
+func status(rc C.pcgx_status) error {
+	switch rc {
+	case C.PCGX_OK:
+		return nil
+	case C.PCGX_E_NO_POINT:
+		return errors.New("no point") // pc/minmax.go:11
+	case C.PCGX_E_NOT_ENOUGH_PAIRS:
+		return icp.ErrNotEnoughPairs // icp/evaluator.go:16
+	case C.PCGX_E_NEED_GRADIENT:
+		return icp.ErrNeedGradient // icp/icp.go:15
+	case C.PCGX_E_BAD_FIELD:
+		return errors.New("invalid field name") // pc/pointcloud.go:115
+	case C.PCGX_E_OUT_OF_RANGE:
+		return ErrOutOfRange
+	default:
+		return fmt.Errorf("pcgx: %s (status %d)", lastError(), int(rc))
+	}
+}
+
+// Init selects the GPU of this process (one process per GPU).
+func Init(device int) error { return status(C.pcgx_init(C.int32_t(device))) }
+
+// xyzLayout finds stride and xyz byte offset of a cloud exactly as
+// PointCloud.Vec3Iterator does (pc/pointcloud.go:130-150).
+func xyzLayout(pp *pc.PointCloud) (stride, off int, err error) {
+	state, start := 0, 0
+	for i, name := range pp.Fields {
+		switch {
+		case name == "xyz":
+			return pp.Stride(), off, nil
+		case name == "x" && state == 0:
+			state, start = 1, off
+		case name == "y" && state == 1:
+			state = 2
+		case name == "z" && state == 2:
+			return pp.Stride(), start, nil
+		default:
+			state = 0
+		}
+		off += pp.Size[i] * pp.Count[i]
+	}
+	return 0, 0, errors.New("invalid field name")
+}
+
+// ---------------------------------------------------------------- KD-tree
+
+// KDTree implements storage.Search on the GPU (replaces kdtree.New /
+// KDTree.Nearest, pc/storage/kdtree/kdtree.go:33-56,83-146).
+type KDTree struct {
+	pc.Vec3RandomAccessor
+	h *C.pcgx_kdtree
+	// MinDistSq > 0 selects the reference's approximate search (kdtree.go:20-22).
+	MinDistSq float32
+}
+
+var _ storage.Search = (*KDTree)(nil)
+
+// New builds the tree from any Vec3RandomAccessor (packed copy, one upload).
+func New(ra pc.Vec3RandomAccessor) (*KDTree, error) {
+	n := ra.Len()
+	xyz := make([]float32, 3*n)
+	for i := 0; i < n; i++ {
+		v := ra.Vec3At(i)
+		copy(xyz[3*i:], v[:])
+	}
+	var data unsafe.Pointer
+	if n > 0 {
+		data = unsafe.Pointer(&xyz[0])
+	}
+	k := &KDTree{Vec3RandomAccessor: ra}
+	if err := status(C.pcgx_kdtree_build(data, C.int64_t(n), 12, 0, &k.h)); err != nil {
+		return nil, err
+	}
+	runtime.SetFinalizer(k, func(k *KDTree) { k.Close() })
+	return k, nil
+}
+
+// Close releases the device tree.
+func (k *KDTree) Close() {
+	if k.h != nil {
+		C.pcgx_kdtree_free(k.h)
+		k.h = nil
+	}
+}
+
+// NearestBatch is the batched seam: result i equals k.Nearest(q[i], maxRange).
+func (k *KDTree) NearestBatch(q []mat.Vec3, maxRange float32) ([]storage.Neighbor, error) {
+	n := len(q)
+	out := make([]storage.Neighbor, n)
+	if n == 0 {
+		return out, nil
+	}
+	ids := make([]int64, n)
+	dsq := make([]float32, n)
+	rc := C.pcgx_kdtree_nearest_batch(k.h, (*C.float)(unsafe.Pointer(&q[0])), C.int64_t(n),
+		C.float(maxRange), C.float(k.MinDistSq), (*C.int64_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&dsq[0])))
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	for i := range out {
+		out[i] = storage.Neighbor{ID: int(ids[i]), DistSq: dsq[i]}
+	}
+	return out, nil
+}
+
+// Nearest keeps storage.Search working for single points (one tiny batch).
+func (k *KDTree) Nearest(p mat.Vec3, maxRange float32) storage.Neighbor {
+	r, err := k.NearestBatch([]mat.Vec3{p}, maxRange)
+	if err != nil {
+		panic(err)
+	}
+	return r[0]
+}
+
+// Range is not on the GPU path yet (SURVEY.md 8(f) N2).
+func (k *KDTree) Range(p mat.Vec3, maxRange float32) []storage.Neighbor {
+	panic("pcgx: KDTree.Range is not implemented on the GPU path (use pc/storage/kdtree)")
+}
+
+// -------------------------------------------------------------- VoxelGrid
+
+type voxelGrid struct {
+	leaf  mat.Vec3
+	chunk [3]int
+}
+
+// NewVoxelGrid replaces voxelgrid.New(leaf, WithChunkSize(chunk))
+// (pc/filter/voxelgrid/voxelgrid.go:23-33); chunk {0,0,0} = non-chunked.
+func NewVoxelGrid(leaf mat.Vec3, chunk [3]int) filter.Filter {
+	return &voxelGrid{leaf: leaf, chunk: chunk}
+}
+
+func (f *voxelGrid) Filter(pp *pc.PointCloud) (*pc.PointCloud, error) {
+	stride, off, err := xyzLayout(pp)
+	if err != nil {
+		return nil, err
+	}
+	n := pp.Points
+	if n == 0 {
+		return nil, errors.New("no point")
+	}
+	out := make([]byte, n*stride)
+	leaf := [3]C.float{C.float(f.leaf[0]), C.float(f.leaf[1]), C.float(f.leaf[2])}
+	chunk := [3]C.int32_t{C.int32_t(f.chunk[0]), C.int32_t(f.chunk[1]), C.int32_t(f.chunk[2])}
+	var m C.int64_t
+	rc := C.pcgx_voxel_filter(unsafe.Pointer(&pp.Data[0]), C.int64_t(n), C.int32_t(stride), C.int32_t(off),
+		&leaf[0], &chunk[0], unsafe.Pointer(&out[0]), &m)
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	newPc := &pc.PointCloud{PointCloudHeader: pp.Clone(), Points: int(m), Data: out[:int(m)*stride]}
+	newPc.Width, newPc.Height = int(m), 1
+	return newPc, nil
+}
+
+// -------------------------------------------------------------------- ICP
+
+// Evaluator implements icp.Evaluator with the fused GPU correspondence +
+// reduction (replaces PointToPointEvaluator + NearestPointCorresponder,
+// evaluator.go:91-189, correspondence.go:22-37; default weight only).
+type Evaluator struct {
+	MaxDist  float32
+	MinPairs int
+}
+
+var _ icp.Evaluator = (*Evaluator)(nil)
+
+func (Evaluator) HasGradient() bool { return true }
+func (Evaluator) HasHessian() bool  { return false }
+
+func packVec3(ra pc.Vec3RandomAccessor) []float32 {
+	if s, ok := ra.(pc.Vec3Slice); ok && len(s) > 0 {
+		return unsafe.Slice((*float32)(unsafe.Pointer(&s[0])), 3*len(s))
+	}
+	out := make([]float32, 3*ra.Len())
+	for i := 0; i < ra.Len(); i++ {
+		v := ra.Vec3At(i)
+		copy(out[3*i:], v[:])
+	}
+	return out
+}
+
+func (e *Evaluator) Evaluate(base storage.Search, target pc.Vec3RandomAccessor) (*icp.Evaluated, error) {
+	k, ok := base.(*KDTree)
+	if !ok {
+		return nil, errors.New("pcgx: base must be a *pcgx.KDTree")
+	}
+	t := packVec3(target)
+	var tp *C.float
+	if len(t) > 0 {
+		tp = (*C.float)(unsafe.Pointer(&t[0]))
+	}
+	var ev C.pcgx_icp_evaluated
+	rc := C.pcgx_icp_evaluate(k.h, tp, C.int64_t(target.Len()), C.float(e.MaxDist), C.float(k.MinDistSq),
+		C.int32_t(e.MinPairs), &ev)
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	out := &icp.Evaluated{Value: float32(ev.value), DistRMS: float32(ev.dist_rms)}
+	for i := 0; i < 6; i++ {
+		out.Gradient[i] = float32(ev.gradient[i])
+	}
+	return out, nil
+}
+
+// Fit runs the whole PointToPointICPGradient.Fit loop on the device
+// (icp.go:23-67) with a GradientDescentUpdaterFactory's parameters.
+func Fit(base *KDTree, target pc.Vec3RandomAccessor, e *Evaluator, u *icp.GradientDescentUpdaterFactory) (mat.Mat4, icp.Stat, error) {
+	var p C.pcgx_icp_params
+	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(base.MinDistSq), C.int32_t(e.MinPairs)
+	if u != nil {
+		for i := 0; i < 6; i++ {
+			p.weight[i], p.threshold[i] = C.float(u.Weight[i]), C.float(u.Threshold[i])
+		}
+		p.max_iteration = C.int32_t(u.MaxIteration)
+	}
+	t := packVec3(target)
+	var tp *C.float
+	if len(t) > 0 {
+		tp = (*C.float)(unsafe.Pointer(&t[0]))
+	}
+	var trans mat.Mat4
+	var st C.pcgx_icp_stat
+	rc := C.pcgx_icp_fit(base.h, tp, C.int64_t(target.Len()), &p, (*C.float)(unsafe.Pointer(&trans[0])), &st)
+	stat := icp.Stat{NumIteration: int(st.num_iteration)}
+	stat.Value, stat.DistRMS = float32(st.evaluated.value), float32(st.evaluated.dist_rms)
+	for i := 0; i < 6; i++ {
+		stat.Gradient[i] = float32(st.evaluated.gradient[i])
+	}
+	return trans, stat, status(rc)
+}

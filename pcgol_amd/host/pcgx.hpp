@@ -1,0 +1,122 @@
+// pcgx.hpp -- header-only C++ mirror of the reference's Go interfaces on the
+// hot path, over the C ABI (include/pcgx.h).  The reference is compiled code
+// (Go) whose toolchain is absent from the build image, so the host side above
+// the C ABI is mirrored in C++ (and in Python, pcgol_amd/*.py, for the tests):
+// same names, argument meaning and error behaviour.
+//
+//   pcgx::KDTree            <- pc/storage/kdtree.KDTree      (storage.Search)
+//   pcgx::VoxelGrid         <- pc/filter/voxelgrid.New(...)  (filter.Filter)
+//   pcgx::PointToPointICP   <- icp.PointToPointICPGradient{Evaluator, UpdaterFactory}
+#pragma once
+#include <array>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pcgx.h"
+
+namespace pcgx {
+
+struct Error : std::runtime_error {
+  pcgx_status code;
+  Error(pcgx_status c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+struct ErrNoPoint : Error { using Error::Error; };          // pc/minmax.go:11
+struct ErrNotEnoughPairs : Error { using Error::Error; };   // icp/evaluator.go:16
+
+inline void check(pcgx_status rc) {
+  if (rc == PCGX_OK) return;
+  char buf[512];
+  pcgx_last_error(buf, sizeof buf);
+  if (rc == PCGX_E_NO_POINT) throw ErrNoPoint(rc, buf);
+  if (rc == PCGX_E_NOT_ENOUGH_PAIRS) throw ErrNotEnoughPairs(rc, buf);
+  throw Error(rc, buf);
+}
+
+using Vec3 = std::array<float, 3>;   // mat.Vec3
+using Mat4 = std::array<float, 16>;  // mat.Mat4, column-major
+
+struct Neighbor {  // pc/storage/search.go:8-11
+  int64_t ID;
+  float DistSq;
+};
+
+// pc.PointCloud's layout contract (pc/pointcloud.go:64-78): AoS records.
+struct CloudView {
+  const void *data;
+  int64_t points;
+  int32_t stride, xyz_offset;
+};
+
+class KDTree {  // pc/storage/kdtree/kdtree.go:14-23
+ public:
+  float MinDistSq = 0.0f;
+  explicit KDTree(const CloudView &c) { check(pcgx_kdtree_build(c.data, c.points, c.stride, c.xyz_offset, &h_)); }
+  explicit KDTree(const std::vector<Vec3> &pts)
+      : KDTree(CloudView{pts.data(), (int64_t)pts.size(), 12, 0}) {}
+  ~KDTree() { pcgx_kdtree_free(h_); }
+  KDTree(const KDTree &) = delete;
+  KDTree &operator=(const KDTree &) = delete;
+  int64_t Len() const { int64_t n; check(pcgx_kdtree_len(h_, &n)); return n; }
+  Vec3 Vec3At(int64_t i) const { Vec3 v; check(pcgx_kdtree_points(h_, &i, 1, v.data())); return v; }
+  Neighbor Nearest(const Vec3 &p, float maxRange) const { return NearestBatch({p}, maxRange)[0]; }
+  std::vector<Neighbor> NearestBatch(const std::vector<Vec3> &q, float maxRange) const {
+    std::vector<int64_t> ids(q.size());
+    std::vector<float> d(q.size());
+    check(pcgx_kdtree_nearest_batch(h_, q.empty() ? nullptr : q[0].data(), (int64_t)q.size(), maxRange, MinDistSq,
+                                    ids.data(), d.data()));
+    std::vector<Neighbor> out(q.size());
+    for (size_t i = 0; i < q.size(); i++) out[i] = Neighbor{ids[i], d[i]};
+    return out;
+  }
+  const pcgx_kdtree *handle() const { return h_; }
+
+ private:
+  pcgx_kdtree *h_ = nullptr;
+};
+
+class VoxelGrid {  // pc/filter/voxelgrid/voxelgrid.go:23-33 + option.go:14-18
+ public:
+  Vec3 LeafSize;
+  std::array<int32_t, 3> ChunkSize{0, 0, 0};
+  explicit VoxelGrid(Vec3 leaf) : LeafSize(leaf) {}
+  VoxelGrid &WithChunkSize(std::array<int32_t, 3> s) { ChunkSize = s; return *this; }
+  // Filter: returns the output records (Width = size()/stride, Height = 1).
+  std::vector<uint8_t> Filter(const CloudView &c) const {
+    std::vector<uint8_t> out((size_t)c.points * c.stride);
+    int64_t m = 0;
+    check(pcgx_voxel_filter(c.data, c.points, c.stride, c.xyz_offset, LeafSize.data(), ChunkSize.data(), out.data(), &m));
+    out.resize((size_t)m * c.stride);
+    return out;
+  }
+};
+
+struct Stat {  // icp/stat.go:3-6
+  pcgx_icp_evaluated Evaluated;
+  int NumIteration;
+};
+
+class PointToPointICP {  // icp.go:18-67 with evaluator.go:69-73 and updater.go:18-22 options
+ public:
+  float MaxDist = 0.0f;
+  int MinPairs = 0;
+  std::array<float, 6> Weight{}, Threshold{};
+  int MaxIteration = 0;
+  std::pair<Mat4, Stat> Fit(const KDTree &base, const std::vector<Vec3> &target) const {
+    pcgx_icp_params p{};
+    p.max_dist = MaxDist;
+    p.min_dist_sq = base.MinDistSq;
+    p.min_pairs = MinPairs;
+    std::memcpy(p.weight, Weight.data(), sizeof p.weight);
+    std::memcpy(p.threshold, Threshold.data(), sizeof p.threshold);
+    p.max_iteration = MaxIteration;
+    Mat4 t;
+    pcgx_icp_stat st{};
+    check(pcgx_icp_fit(base.handle(), target.empty() ? nullptr : target[0].data(), (int64_t)target.size(), &p,
+                       t.data(), &st));
+    return {t, Stat{st.evaluated, st.num_iteration}};
+  }
+};
+
+}  // namespace pcgx
