@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
 int walk_blocks_per_cu(const TreeView &tv) {
   const size_t lds = walk_stack_bytes(tv, kKnnBlock);
   int b = (int)((160 * 1024) / (lds ? lds : 1));
-  if (b > 4) b = 4;
+  if (b > 8) b = 8;
   if (b < 1) b = 1;
   if (const char *e = getenv("PCGX_WALK_BLOCKS_PER_CU")) {
     int v = atoi(e);

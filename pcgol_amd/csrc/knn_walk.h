@@ -67,11 +67,19 @@ __device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict_
   int32_t lo = 0, n = 0, depth = 0, sp = 0;
   bool desc = false;
 
+  bool pending = false;  // finished, result not yet emitted
+
   for (;;) {
-    // ---- refill idle lanes from the wave's range --------------------------------
+    // ---- emit finished lanes and refill them from the wave's range ---------------
+    // Both are divergent sections, so they run only once enough lanes are waiting
+    // (or nothing is left to step): a lane that finished just idles until then.
     const uint64_t idle = __ballot(!active);
     const int n_idle = __popcll(idle);
     if (n_idle >= kRefillThreshold || n_idle == 64) {
+      if (pending) {
+        emit(q_begin + my_q, qx, qy, qz, best_pos, best_d);
+        pending = false;
+      }
       if (next < count) {
         if (!active) {
           const int32_t idx = next + (int32_t)__popcll(idle & lt_mask);
@@ -90,7 +98,7 @@ __device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict_
         }
         next += n_idle;
       } else if (n_idle == 64) {
-        break;  // range exhausted and every lane done
+        break;  // range exhausted, every lane done and emitted
       }
     }
 
@@ -156,8 +164,8 @@ __device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict_
     }
 
     if (finish) {
-      emit(q_begin + my_q, qx, qy, qz, best_pos, best_d);
       active = false;
+      pending = true;
     }
   }
 }
