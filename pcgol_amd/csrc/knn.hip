@@ -105,6 +105,21 @@ struct HostCallBufs {
 };
 }  // namespace
 
+// In-order sequence -> BFS slots: the node of range [lo, lo+cnt) is element lo + cnt/2
+// (kdtree.go:355-364); children 2b (left, cnt/2 points) and 2b+1 (right).
+static void fill_bfs(const pcgx_kdtree &t, std::vector<float4> &nodes, size_t b, int64_t lo, int64_t cnt) {
+  while (cnt > 0) {
+    const int64_t half = cnt / 2, mid = lo + half;
+    const int32_t id = t.inorder[mid];
+    nodes[b] = make_float4(t.points[3 * (int64_t)id], t.points[3 * (int64_t)id + 1],
+                           t.points[3 * (int64_t)id + 2], __builtin_bit_cast(float, id));
+    if (half > 0) fill_bfs(t, nodes, 2 * b, lo, half);
+    lo = mid + 1;  // iterate into the right child
+    cnt = cnt - half - 1;
+    b = 2 * b + 1;
+  }
+}
+
 // ------------------------------------------------------------------ C ABI
 
 extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t stride,
@@ -125,18 +140,15 @@ extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t st
   for (int64_t i = 0; i < n; i++) memcpy(&t->points[3 * i], src + i * (int64_t)stride + xyz_off, 12);
   t->inorder.resize((size_t)n);
   build_inorder(t->points.data(), n, t->inorder.data());
-  std::vector<float4> nodes((size_t)n);
-  for (int64_t i = 0; i < n; i++) {
-    int32_t id = t->inorder[i];
-    nodes[i] = make_float4(t->points[3 * (int64_t)id], t->points[3 * (int64_t)id + 1],
-                           t->points[3 * (int64_t)id + 2], __builtin_bit_cast(float, id));
-  }
-  hipError_t e = hipMalloc((void **)&t->d_nodes, (size_t)n * sizeof(float4));
+  const size_t slots = (size_t)1 << t->depth;
+  std::vector<float4> nodes(slots, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+  fill_bfs(*t, nodes, 1, 0, n);
+  hipError_t e = hipMalloc((void **)&t->d_nodes, slots * sizeof(float4));
   if (e != hipSuccess) {
     delete t;
     return fail(PCGX_E_OOM, "hipMalloc for %lld tree nodes failed: %s", (long long)n, hipGetErrorString(e));
   }
-  e = hipMemcpy(t->d_nodes, nodes.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice);
+  e = hipMemcpy(t->d_nodes, nodes.data(), slots * sizeof(float4), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
     (void)hipFree(t->d_nodes);
     delete t;

@@ -14,12 +14,13 @@
 // Visit order, comparisons and float32 expression order are those of the
 // reference, so ids agree even on exact distance ties and for MinDistSq > 0.
 //
-// Tree encoding: see pcgx_internal.h (implicit in-order layout).  Subtree
-// sizes at depth d are smin(d) or smin(d)+1 with smin(d) = ((N+1) >> d) - 1.
+// Tree encoding: see pcgx_internal.h (implicit tree in BFS order: node b has
+// children 2b / 2b+1, depth = floor(log2 b)).  Subtree sizes at depth d are
+// smin(d) or smin(d)+1 with smin(d) = ((N+1) >> d) - 1.
 //
 // Traversal stack: one 8-byte frame per pending ancestor, in LDS, laid out
 // [level][thread] so that a wave's accesses are conflict-free:
-//   .x = node index (26 bits) | depth (5 bits) << 26 | size bit << 31
+//   .x = BFS node index (27 bits) | size bit << 31
 //   .y = bits of fp = q[dim] - pivot[dim]   (sign = which side was taken,
 //        fp*fp = the plane test; both bit-identical to recomputing them)
 // A frame whose plane test already fails when it would be pushed can never
@@ -64,9 +65,9 @@ __device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict_
   int32_t my_q = 0;
   float qx = 0.0f, qy = 0.0f, qz = 0.0f, best_d = 0.0f;
   int32_t best_pos = -1;
-  int32_t lo = 0, n = 0, depth = 0, sp = 0;
+  uint32_t b = 1;  // BFS index of the node the lane is at
+  int32_t n = 0, sp = 0;
   bool desc = false;
-
   bool pending = false;  // finished, result not yet emitted
 
   for (;;) {
@@ -88,9 +89,8 @@ __device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict_
             my_q = idx;
             best_d = max_range_sq;
             best_pos = -1;
-            lo = 0;
+            b = 1u;
             n = tv.n;
-            depth = 0;
             sp = 0;
             desc = true;
             active = true;
@@ -116,14 +116,15 @@ __device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict_
     const int32_t sp_pop = pass0 ? sp - 1 : i1;  // pass1 -> sp-2; neither -> max(sp-2, 0)
     sp = popping ? sp_pop : sp;
     bool finish = popping && !pfound && sp == 0;
-    const int32_t fdepth = (int32_t)((fx >> 26) & 31u);
+    const uint32_t fb = fx & 0x07FFFFFFu;
+    const int32_t fdepth = 31 - __clz((int)(fb | 1u));
     const int32_t fn = (int32_t)((np1 >> fdepth) - 1u + (fx >> 31));
 
     // ---- the one node fetch of this step -----------------------------------------
-    const int32_t mid = desc ? lo + (n >> 1) : (int32_t)(fx & 0x03FFFFFFu);
+    const uint32_t at = desc ? b : fb;
     const bool look = active && (desc || pfound);
     if (look) {
-      const float4 nd = tv.nodes[mid];
+      const float4 nd = tv.nodes[at];
       const float dx = nd.x - qx, dy = nd.y - qy, dz = nd.z - qz;  // pivot.Sub(p)
       const float d = (dx * dx + dy * dy) + dz * dz;                // NormSq, mat/vec3.go:18-20
       const bool leaf = desc && n == 1;
@@ -131,35 +132,34 @@ __device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict_
       // leaf: replace unless d > best (kdtree.go:95-103); pivot: replace if d < best (:116-119)
       const bool take = leaf ? !(d > best_d) : (!desc && d < best_d);
       best_d = take ? d : best_d;
-      best_pos = take ? mid : best_pos;
+      best_pos = take ? (int32_t)at : best_pos;
       if (kMinDist) finish = finish || ((leaf || take) && best_d < min_dist_sq);  // :104,120,140
 
       // descending through an inner node: searchLeafNode step (kdtree.go:202-221)
+      const int32_t depth = 31 - __clz((int)b);
       const int dim = depth % 3;
       const float pv = sel3(dim, nd.x, nd.y, nd.z);
       const float qv = sel3(dim, qx, qy, qz);
       const float fp = qv - pv;
       if (inner && !(fp * fp > best_d)) {
         const uint32_t size_bit = (uint32_t)n - ((np1 >> depth) - 1u);
-        stk[sp * stk_stride] = make_uint2((uint32_t)mid | ((uint32_t)depth << 26) | (size_bit << 31),
-                                          __float_as_uint(fp));
+        stk[sp * stk_stride] = make_uint2(b | (size_bit << 31), __float_as_uint(fp));
         ++sp;
       }
       const int32_t half = n >> 1;
       const bool go_left = n == 2 || pv > qv;  // only child, or pivotVal > val -> child0
-      const int32_t d_lo = go_left ? lo : mid + 1;
+      const uint32_t d_b = 2u * b + (go_left ? 0u : 1u);
       const int32_t d_n = go_left ? half : n - half - 1;
 
       // unwinding through a frame that passed the plane test: the other side (kdtree.go:124-137)
       const int32_t phalf = fn >> 1;
       const bool went_left = ffp < 0.0f;
-      const int32_t p_lo = went_left ? mid + 1 : mid - phalf;
+      const uint32_t p_b = 2u * fb + (went_left ? 1u : 0u);
       const int32_t p_n = went_left ? fn - phalf - 1 : phalf;
       const bool p_far = fn != 2;  // fn == 2: single child, nextNode == nil (:130-132)
 
-      lo = desc ? d_lo : p_lo;
+      b = desc ? d_b : p_b;
       n = desc ? d_n : p_n;
-      depth = (desc ? depth : fdepth) + 1;
       desc = desc ? inner : p_far;
     }
 

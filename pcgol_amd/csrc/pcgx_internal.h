@@ -80,14 +80,20 @@ pcgx_status ensure_init();
 inline hipStream_t pick_stream(void *s) { return s ? (hipStream_t)s : ctx().stream; }
 
 // ---- KD-tree ---------------------------------------------------------------
-// Device layout (DESIGN.md "KD-tree"): the reference's recursively sorted
-// indice slice (kdtree.go:348-370) IS the tree: the node of range [lo,hi) is
-// element lo + (hi-lo)/2, children are [lo,mid) and [mid+1,hi), dim = depth%3.
-// nodes[i] = {x, y, z, bits(id)} of the i-th point in that in-order sequence.
-constexpr int64_t kMaxTreePoints = (int64_t)1 << 26;  // frame encoding: 26-bit node index
+// The reference's recursively sorted indice slice (kdtree.go:348-370), read left
+// to right, is the in-order traversal of its tree and defines it completely: the
+// node of range [lo,hi) is element lo + (hi-lo)/2, its children are [lo,mid) and
+// [mid+1,hi), dim = depth%3.  Because the split is always at len/2 the SHAPE
+// depends on N only, so no child pointers are stored.  Device layout (DESIGN.md
+// "KD-tree"): BFS / Eytzinger order, nodes[b] = {x, y, z, bits(id)} with the root
+// at b = 1 and the children of b at 2b and 2b+1 (slots of absent nodes are
+// unused); depth(b) = floor(log2 b).  Ancestors of a node are plain shifts of
+// its index, which is what lets a whole root-to-leaf path be fetched in
+// parallel (speculative descent, knn_walk.h).
+constexpr int64_t kMaxTreePoints = (int64_t)1 << 26;  // BFS index < 2^27 (frame encoding)
 
 struct TreeView {
-  const float4 *nodes;
+  const float4 *nodes;  // [2^depth] BFS slots, index 0 unused
   int32_t n;
   int32_t depth;  // node.maxDepth(0) = floor(log2 n) + 1
 };
@@ -125,7 +131,7 @@ pcgx_status morton_order(const float *d_q, int64_t n, int32_t *d_perm, hipStream
 struct pcgx_kdtree {
   int64_t n = 0;
   int32_t depth = 0;
-  float4 *d_nodes = nullptr;       // [n] in-order nodes
+  float4 *d_nodes = nullptr;       // [2^depth] BFS-ordered nodes
   std::vector<int32_t> inorder;    // host copy of the in-order ids
   std::vector<float> points;       // host copy of xyz (accessor order), for Vec3At
   pcgx::TreeView view() const { return pcgx::TreeView{d_nodes, (int32_t)n, depth}; }
