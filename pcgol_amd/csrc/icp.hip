@@ -49,8 +49,9 @@ __global__ __launch_bounds__(kIcpBlock) void icp_partials_kernel(
     TreeView tv, const float *__restrict__ tx, const float *__restrict__ ty,
     const float *__restrict__ tz, int64_t nt, int64_t per_wave, const IcpState *__restrict__ state,
     IcpKernelParams kp, double *__restrict__ block_partials) {
-  extern __shared__ uint2 s_stack[];
-  __shared__ double s_red[kIcpBlock / 64][S_COUNT];
+  extern __shared__ uint32_t s_stack[];
+  uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kIcpBlock +
+                    (threadIdx.x >> 6) * (kWalkQueueBytesPerWave / 4);
   if (state->done) return;  // uniform
   float m[16];
 #pragma unroll
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kIcpBlock) void icp_partials_kernel(
   if (q_end > nt) q_end = nt;
   if (q_begin < q_end) {
     walk_range<kMinDist>(
-        tv, s_stack + threadIdx.x, kIcpBlock, q_begin, q_end, kp.max_dist_sq, kp.min_dist_sq,
+        tv, s_stack + threadIdx.x, kIcpBlock, queue, q_begin, q_end, kp.max_dist_sq, kp.min_dist_sq,
         [&](int64_t i, float &x, float &y, float &z) {
           x = tx[i]; y = ty[i]; z = tz[i];
           if (project) {
@@ -77,10 +78,9 @@ __global__ __launch_bounds__(kIcpBlock) void icp_partials_kernel(
             x = px; y = py; z = pz;
           }
         },
-        [&](int64_t, float x0, float y0, float z0, int32_t best_pos, float best_d) {
-          if (best_pos < 0) return;  // correspondence.go:27-29
-          const float4 b = tv.nodes[best_pos];
-          const float x1 = b.x, y1 = b.y, z1 = b.z;
+        [&](int64_t, float x0, float y0, float z0, const float4 &bp, float best_d) {
+          if (__float_as_int(bp.w) < 0) return;  // correspondence.go:27-29
+          const float x1 = bp.x, y1 = bp.y, z1 = bp.z;
           acc[S_VALUE] += (double)best_d;
           acc[S_G0 + 0] += (double)(x0 - x1);
           acc[S_G0 + 1] += (double)(y0 - y1);
@@ -94,6 +94,8 @@ __global__ __launch_bounds__(kIcpBlock) void icp_partials_kernel(
         });
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();  // every wave is done with its stack / queue: reuse the LDS for the block sum
+  double(*s_red)[S_COUNT] = reinterpret_cast<double(*)[S_COUNT]>(s_stack);
 #pragma unroll
   for (int k = 0; k < S_COUNT; k++) {
     double v = wave_sum_f64(acc[k]);
@@ -311,7 +313,7 @@ extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stre
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_partials: NULL session");
   hipStream_t st = pick_stream(stream);
   const TreeView tv = s->base->view();
-  const size_t lds = walk_stack_bytes(tv, kIcpBlock);
+  const size_t lds = walk_lds_bytes(tv, kIcpBlock);
   const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
   {
     ProfScope prof(PCGX_PROF_ICP_WALK, st);

@@ -21,31 +21,58 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
                                                             float max_range_sq, float min_dist_sq,
                                                             int32_t *__restrict__ out_id,
                                                             float *__restrict__ out_dsq) {
-  extern __shared__ uint2 s_stack[];
+  extern __shared__ uint32_t s_stack[];
+  uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kKnnBlock +
+                    (threadIdx.x >> 6) * (kWalkQueueBytesPerWave / 4);
   const int64_t wave = (int64_t)blockIdx.x * (kKnnBlock / 64) + (threadIdx.x >> 6);
   const int64_t q_begin = wave * per_wave;
   int64_t q_end = q_begin + per_wave;
   if (q_end > nq) q_end = nq;
   if (q_begin >= q_end) return;
   walk_range<kMinDist>(
-      tv, s_stack + threadIdx.x, kKnnBlock, q_begin, q_end, max_range_sq, min_dist_sq,
+      tv, s_stack + threadIdx.x, kKnnBlock, queue, q_begin, q_end, max_range_sq, min_dist_sq,
       [&](int64_t pos, float &x, float &y, float &z) {
         const int64_t i = perm ? (int64_t)perm[pos] : pos;
         x = q[3 * i + 0];
         y = q[3 * i + 1];
         z = q[3 * i + 2];
       },
-      [&](int64_t pos, float, float, float, int32_t best_pos, float best_d) {
+      [&](int64_t pos, float, float, float, const float4 &best, float best_d) {
         const int64_t i = perm ? (int64_t)perm[pos] : pos;
-        out_id[i] = best_pos >= 0 ? __float_as_int(tv.nodes[best_pos].w) : -1;
+        out_id[i] = __float_as_int(best.w);
         out_dsq[i] = best_d;
       });
 }
 
-// Waves resident per CU for the walk kernels: the LDS stacks of a 256-thread
-// block take (depth-1)*2 KiB, so 4 blocks (16 waves) fit at depth <= 20.
+// Leaf directory: one thread per grid cell descends from the root with the cell's centre
+// (the reference's searchLeafNode rule, kdtree.go:202-221) and records the leaf reached.
+__global__ __launch_bounds__(256) void dir_build_kernel(TreeView tv, uint32_t *__restrict__ dir) {
+  const int g = tv.dir_bits;
+  const uint32_t cells = 1u << (3 * g);
+  const uint32_t cell = blockIdx.x * 256u + threadIdx.x;
+  if (cell >= cells) return;
+  const uint32_t mask = (1u << g) - 1u;
+  const uint32_t c[3] = {cell & mask, (cell >> g) & mask, cell >> (2 * g)};
+  float p[3];
+  for (int k = 0; k < 3; k++)
+    p[k] = tv.dir_scale[k] > 0.0f ? tv.dir_lo[k] + ((float)c[k] + 0.5f) / tv.dir_scale[k] : tv.dir_lo[k];
+  uint32_t b = 1u, n = (uint32_t)tv.n;
+  int depth = 0;
+  while (n > 1u) {
+    const int dim = depth % 3;
+    const float pv = node_comp(tv.nodes, b, dim);
+    const bool left = n == 2u || pv > p[dim];
+    const uint32_t half = n >> 1;
+    n = left ? half : n - half - 1u;
+    b = 2u * b + (left ? 0u : 1u);
+    depth++;
+  }
+  dir[cell] = b;
+}
+
+// Blocks resident per CU for the walk kernels, limited by their LDS (walk_lds_bytes).
 int walk_blocks_per_cu(const TreeView &tv) {
-  const size_t lds = walk_stack_bytes(tv, kKnnBlock);
+  const size_t lds = walk_lds_bytes(tv, kKnnBlock);
   int b = (int)((160 * 1024) / (lds ? lds : 1));
   if (b > 8) b = 8;
   if (b < 1) b = 1;
@@ -60,7 +87,7 @@ pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *
                            float max_range_sq, float min_dist_sq, int32_t *d_ids, float *d_dsq,
                            hipStream_t st) {
   if (nq == 0) return PCGX_OK;
-  const size_t lds = walk_stack_bytes(tv, kKnnBlock);
+  const size_t lds = walk_lds_bytes(tv, kKnnBlock);
   const int waves_per_block = kKnnBlock / 64;
   int64_t blocks = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv);
   const int64_t max_blocks = (nq + kKnnBlock - 1) / kKnnBlock;
@@ -154,6 +181,42 @@ extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t st
     delete t;
     return fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
   }
+  // leaf directory: ~2 cells per point, at most 2^27 cells
+  {
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) lo[k] = hi[k] = t->points[k];
+    for (int64_t i = 1; i < n; i++)
+      for (int k = 0; k < 3; k++) {
+        const float v = t->points[3 * i + k];
+        if (v < lo[k]) lo[k] = v;
+        if (v > hi[k]) hi[k] = v;
+      }
+    int g = 0;
+    while (g < 9 && ((int64_t)1 << (3 * g)) < 2 * n) g++;
+    t->dir_bits = g;
+    for (int k = 0; k < 3; k++) {
+      const float ext = hi[k] - lo[k];
+      t->dir_lo[k] = lo[k];
+      t->dir_scale[k] = (ext > 0.0f && ext == ext && ext < 3.0e38f) ? (float)(1 << g) / ext : 0.0f;
+      if (!(lo[k] == lo[k])) { t->dir_lo[k] = 0.0f; t->dir_scale[k] = 0.0f; }  // NaN coordinates
+    }
+    const size_t cells = (size_t)1 << (3 * g);
+    e = hipMalloc((void **)&t->d_dir, cells * sizeof(uint32_t));
+    if (e != hipSuccess) {
+      (void)hipFree(t->d_nodes);
+      delete t;
+      return fail(PCGX_E_OOM, "hipMalloc for the leaf directory (%zu cells) failed: %s", cells, hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(dir_build_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx().stream,
+                       t->view(), t->d_dir);
+    e = hipStreamSynchronize(ctx().stream);
+    if (e != hipSuccess) {
+      (void)hipFree(t->d_nodes);
+      (void)hipFree(t->d_dir);
+      delete t;
+      return fail(PCGX_E_HIP, "leaf directory build failed: %s", hipGetErrorString(e));
+    }
+  }
   *out = t;
   return PCGX_OK;
 }
@@ -161,6 +224,7 @@ extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t st
 extern "C" pcgx_status pcgx_kdtree_free(pcgx_kdtree *t) {
   if (!t) return PCGX_OK;
   if (t->d_nodes) (void)hipFree(t->d_nodes);
+  if (t->d_dir) (void)hipFree(t->d_dir);
   delete t;
   return PCGX_OK;
 }

@@ -1,5 +1,6 @@
 // knn_walk.h -- device-side restatement of KDTree.Nearest, one query per lane,
-// organised as a wave-persistent state machine.
+// organised as a wave-persistent state machine with a speculative, parallel
+// first descent.
 //
 // Reference: pc/storage/kdtree/kdtree.go:83-146 (Nearest / nearestImpl) and
 // :199-222 (searchLeafNode).  The reference recursion
@@ -14,24 +15,57 @@
 // Visit order, comparisons and float32 expression order are those of the
 // reference, so ids agree even on exact distance ties and for MinDistSq > 0.
 //
-// Tree encoding: see pcgx_internal.h (implicit tree in BFS order: node b has
+// Tree encoding: pcgx_internal.h (implicit tree in BFS order: node b has
 // children 2b / 2b+1, depth = floor(log2 b)).  Subtree sizes at depth d are
 // smin(d) or smin(d)+1 with smin(d) = ((N+1) >> d) - 1.
 //
-// Traversal stack: one 8-byte frame per pending ancestor, in LDS, laid out
-// [level][thread] so that a wave's accesses are conflict-free:
-//   .x = BFS node index (27 bits) | size bit << 31
-//   .y = bits of fp = q[dim] - pivot[dim]   (sign = which side was taken,
-//        fp*fp = the plane test; both bit-identical to recomputing them)
-// A frame whose plane test already fails when it would be pushed can never
-// pass later (the best only shrinks), so it is not pushed at all.
+// ---- 1. speculative first descent (prepare_query) -----------------------------
+// The first root-to-leaf descent is a chain of ~log2(N) DEPENDENT node fetches
+// in the reference.  Here a grid directory (TreeView::dir, built with the tree)
+// predicts the leaf a query will reach; in BFS order the ancestors of that leaf
+// are plain shifts of its index, so the split values of the WHOLE predicted path
+// (and the leaf itself) are fetched in parallel -- one memory round trip.  The
+// prediction is then VERIFIED level by level with the reference's own
+// comparison (pivotVal > val -> child0, kdtree.go:216): up to the first level m
+// where the real descent leaves the predicted path everything is exactly what
+// the reference computes; from m on the lane continues with ordinary dependent
+// steps.  A wrong prediction therefore costs time, never correctness.
 //
-// Execution shape (DESIGN.md "walk kernel"): a wave owns a contiguous range of
-// (Morton-ordered) queries.  Every loop iteration performs ONE step for every
-// lane -- at most one 16-byte node fetch, shared by both modes (descending /
-// unwinding) -- and lanes whose query has finished pull the next query of the
-// range at once, so lanes stay busy until the range is exhausted.  Which lane
-// gets which query is a deterministic function of the input (no atomics).
+// Frames of this first descent are not materialised: the path is one word
+// (path_b, BFS index of the deepest verified node), `pend` has bit j set when
+// the ancestor at level j still has to be examined when the walk unwinds to it,
+// `szmask` bit j is its subtree-size bit.  When the walk pops such a level it
+// re-fetches the ancestor, recomputes fp (bit-identical) and applies the plane
+// test, as the reference does.
+//
+// Pruning bound.  A level is recorded in `pend` (a frame pushed, a popped frame
+// followed) only if its plane test can still pass: fp*fp <= bound, where
+//   * bound = the running best, as in the reference, and additionally
+//   * with MinDistSq == 0 (kExact): bound = min(best, ub), ub = the distance to
+//     the predicted leaf's point.  ub >= d*, the final nearest distance; every
+//     subtree holding a point at distance d* has fp*fp <= d* <= bound for the
+//     planes of all its ancestors, so it is visited when the reference visits
+//     it and in the same relative order, and candidates farther than d* never
+//     decide the outcome (a leaf at d* replaces, a pivot at d* replaces only a
+//     strictly larger best -- the same in both walks).  The returned {id, dist}
+//     hence equals the reference's, exact ties included.
+//   * with MinDistSq > 0 (approximate, visit-order dependent search) only the
+//     running best is used; the first-descent levels are filtered with the best
+//     right after the verified leaf, which is when the reference tests them.
+//
+// ---- 2. wave-persistent stepping (walk_range) ---------------------------------
+// A wave owns a contiguous range of queries.  64 queries at a time are prepared
+// by all lanes together (full lane efficiency) into an LDS queue; every loop
+// iteration then performs ONE step for every lane -- at most one 16-byte node
+// fetch, shared by all modes -- and lanes whose query has finished take the
+// next prepared query from the queue.  Explicit frames exist only below the
+// verified path: one 32-bit word per pending ancestor, in LDS laid out
+// [level][thread] (conflict-free):
+//   BFS node index (27 bits) | went-to-child0 bit << 27 | size bit << 31
+// Popping a frame re-fetches its node and recomputes fp = q[dim] - pivot[dim]
+// (bit-identical to the value at push time) for the plane test, exactly like a
+// level of the first descent; a frame is pushed only if that test can still pass.
+// Which lane gets which query is a deterministic function of the input.
 #pragma once
 #include "pcgx_internal.h"
 
@@ -41,122 +75,271 @@ __device__ __forceinline__ float sel3(int dim, float a, float b, float c) {
   return dim == 0 ? a : (dim == 1 ? b : c);
 }
 
-// fetch(idx, qx, qy, qz): loads query idx.   emit(idx, qx, qy, qz, best_pos, best_d):
-// consumes the result; best_pos is the in-order node index of the match or -1.
-//
-// The step is written with selects rather than nested branches: on gfx950 a
-// divergent if/else costs scalar exec-mask bookkeeping on the CU's single
-// scalar unit, which (not memory) was what bound the first version of this
-// kernel (profiles/r01a_pmc.json: 121 SALU and 85 VALU instructions per node
-// fetch, 29 % of the lanes active per VALU instruction).
-constexpr int kRefillThreshold = 12;  // refill when this many lanes are idle (or nothing is active)
+constexpr int kRefillThreshold = 8;  // emit + refill once this many lanes wait (or nothing is active)
+constexpr int kMaxLevels = 26;       // inner levels on a root-to-leaf path (N <= 2^26)
 
+// State a prepared query starts the stepping loop with (= one LDS queue entry).
+struct Prepared {
+  float qx, qy, qz;
+  float best_d;       // running best (kdtree.go neighbor1.DistSq)
+  float bound_d;      // pruning bound: min(best, ub) in exact mode, = best otherwise
+  float4 best;        // record of the current best {x, y, z, bits(id)}, id < 0 = none
+  uint32_t path_b;    // deepest verified node of the first descent
+  uint32_t n;         // subtree size at path_b if the lane must descend from it, 0 = leaf done,
+                      // 0x80000000 = query finished inside prepare
+  uint32_t pend;      // first-descent levels still to examine
+  uint32_t szmask;    // their subtree-size bits
+};
+
+// One float of node b; 32-bit byte offset (tree < 2^27 slots x 16 B) so the load uses
+// scalar-base + 32-bit-offset addressing instead of a 64-bit address per lane.
+__device__ __forceinline__ float node_comp(const float4 *nodes, uint32_t b, int dim) {
+  const uint32_t off = (b << 4) + 4u * (uint32_t)dim;
+  return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(nodes) + off);
+}
+__device__ __forceinline__ float4 node_at(const float4 *nodes, uint32_t b) {
+  const uint32_t off = b << 4;
+  return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + off);
+}
+
+constexpr int kChunk = 9;  // levels fetched per round (a multiple of 3: the split axis is static)
+
+template <bool kExact>
+__device__ __forceinline__ Prepared prepare_query(const TreeView &tv, float qx, float qy, float qz,
+                                                  float max_range_sq, float min_dist_sq) {
+  Prepared p;
+  p.qx = qx; p.qy = qy; p.qz = qz;
+  p.best_d = max_range_sq;
+  p.best = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+  const uint32_t np1 = (uint32_t)tv.n + 1u;
+  // --- predicted leaf from the grid directory
+  const int g = tv.dir_bits;
+  const float cmax = (float)((1 << g) - 1);
+  const float fx = fminf(fmaxf((qx - tv.dir_lo[0]) * tv.dir_scale[0], 0.0f), cmax);
+  const float fy = fminf(fmaxf((qy - tv.dir_lo[1]) * tv.dir_scale[1], 0.0f), cmax);
+  const float fz = fminf(fmaxf((qz - tv.dir_lo[2]) * tv.dir_scale[2], 0.0f), cmax);
+  const uint32_t cell = (uint32_t)fx | ((uint32_t)fy << g) | ((uint32_t)fz << (2 * g));
+  const uint32_t bl = tv.dir[cell];
+  const int L = 31 - __clz((int)bl);  // depth of the predicted leaf = inner levels above it
+
+  // --- the predicted leaf: its distance is an upper bound of the nearest distance
+  const float4 leaf = node_at(tv.nodes, bl);
+  const float ldx = leaf.x - qx, ldy = leaf.y - qy, ldz = leaf.z - qz;
+  const float d_leaf = (ldx * ldx + ldy * ldy) + ldz * ldz;
+  // Bound for recording a level in `pend`: the best while the reference descends
+  // (= maxRange^2), tightened by ub in exact mode (header, "Pruning bound").
+  const float bound0 = kExact ? fminf(max_range_sq, d_leaf) : max_range_sq;
+
+  // --- fetch the predicted path kChunk levels at a time (independent loads) and verify it with
+  //     the reference's own comparison (kdtree.go:202-221)
+  uint32_t n = (uint32_t)tv.n;  // subtree size at the current level
+  uint32_t n_m = n;             // ... at the first mismatch
+  int m = L;                    // first level where the prediction fails (L: verified to the leaf)
+  uint32_t szmask = 0, pend = 0;
+#pragma unroll 1
+  for (int base = 0; base < kMaxLevels + 1; base += kChunk) {
+    if (__ballot(m == L && base < L) == 0ull) break;
+    float pv[kChunk];
+#pragma unroll
+    for (int k = 0; k < kChunk; k++) {
+      const int j = base + k;
+      pv[k] = 0.0f;
+      if (j < L && m == L) pv[k] = node_comp(tv.nodes, bl >> (L - j), k % 3);
+    }
+#pragma unroll
+    for (int k = 0; k < kChunk; k++) {
+      const int j = base + k;
+      if (j < L && m == L) {
+        const float qv = (k % 3 == 0) ? qx : ((k % 3 == 1) ? qy : qz);
+        const bool pred_left = ((bl >> (L - j - 1)) & 1u) == 0u;
+        const bool real_left = n == 2u || pv[k] > qv;
+        if (pred_left != real_left) {
+          m = j;
+          n_m = n;
+        } else {
+          const float fp = qv - pv[k];
+          if (!(fp * fp > bound0)) pend |= 1u << j;
+          szmask |= (n - ((np1 >> j) - 1u)) << j;
+          const uint32_t half = n >> 1;
+          n = pred_left ? half : n - half - 1u;
+        }
+      }
+    }
+  }
+  const bool verified = m == L;
+
+  // --- the leaf (kdtree.go:95-106), only if the real descent arrives there
+  bool finished = false;
+  if (verified) {
+    if (!(d_leaf > p.best_d)) {
+      p.best_d = d_leaf;
+      p.best = leaf;
+    }
+    if (!kExact && p.best_d < min_dist_sq) finished = true;
+  }
+  p.bound_d = kExact ? fminf(p.best_d, d_leaf) : p.best_d;
+  p.path_b = bl >> (L - m);
+  p.n = finished ? 0x80000000u : (verified ? 0u : n_m);
+  p.pend = pend;
+  p.szmask = szmask;
+  return p;
+}
+
+constexpr int kQueueWords = 12;  // LDS queue entry words (SoA [word][slot], 64 slots per wave)
+
+// fetch(idx, qx, qy, qz): loads query idx.   emit(idx, qx, qy, qz, best, best_d): consumes the
+// result; best = {x, y, z, bits(id)} of the matched base point, id < 0 = no match.
+// `queue`: this wave's LDS queue, kQueueWords * 64 words.
 template <bool kMinDist, class Fetch, class Emit>
-__device__ __forceinline__ void walk_range(const TreeView tv, uint2 *__restrict__ stk,
-                                           const int stk_stride, const int64_t q_begin,
-                                           const int64_t q_end, const float max_range_sq,
-                                           const float min_dist_sq, Fetch &&fetch, Emit &&emit) {
+__device__ __forceinline__ void walk_range(const TreeView tv, uint32_t *__restrict__ stk,
+                                           const int stk_stride, uint32_t *__restrict__ queue,
+                                           const int64_t q_begin, const int64_t q_end,
+                                           const float max_range_sq, const float min_dist_sq,
+                                           Fetch &&fetch, Emit &&emit) {
+  constexpr bool kExact = !kMinDist;
   const int lane = (int)(threadIdx.x & 63u);
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const uint32_t np1 = (uint32_t)tv.n + 1u;
   const int32_t count = (int32_t)(q_end - q_begin);  // a wave's range is far below 2^31
-  int32_t next = 0;                                   // wave-uniform, relative to q_begin
-  bool active = false;
+  int32_t next_prep = 0;                        // wave-uniform: first query not yet prepared
+  int32_t q_head = 0, q_count = 0, q_base = 0;  // wave-uniform: LDS queue state
+
+  bool active = false, pending = false, desc = false;
   int32_t my_q = 0;
-  float qx = 0.0f, qy = 0.0f, qz = 0.0f, best_d = 0.0f;
-  int32_t best_pos = -1;
-  uint32_t b = 1;  // BFS index of the node the lane is at
+  float qx = 0.0f, qy = 0.0f, qz = 0.0f, best_d = 0.0f, bound_d = 0.0f;
+  float4 best = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+  uint32_t b = 1, path_b = 1, pend = 0, szmask = 0;
   int32_t n = 0, sp = 0;
-  bool desc = false;
-  bool pending = false;  // finished, result not yet emitted
 
   for (;;) {
-    // ---- emit finished lanes and refill them from the wave's range ---------------
-    // Both are divergent sections, so they run only once enough lanes are waiting
-    // (or nothing is left to step): a lane that finished just idles until then.
+    // ---- emit finished lanes, prepare more queries, refill ------------------------
+    // Divergent sections, so they run only once enough lanes are waiting (or nothing
+    // is left to step): a lane that finished idles until then.
     const uint64_t idle = __ballot(!active);
     const int n_idle = __popcll(idle);
     if (n_idle >= kRefillThreshold || n_idle == 64) {
       if (pending) {
-        emit(q_begin + my_q, qx, qy, qz, best_pos, best_d);
+        emit(q_begin + my_q, qx, qy, qz, best, best_d);
         pending = false;
       }
-      if (next < count) {
-        if (!active) {
-          const int32_t idx = next + (int32_t)__popcll(idle & lt_mask);
-          if (idx < count) {
-            fetch(q_begin + idx, qx, qy, qz);
-            my_q = idx;
-            best_d = max_range_sq;
-            best_pos = -1;
-            b = 1u;
-            n = tv.n;
-            sp = 0;
-            desc = true;
+      if (q_head == q_count && next_prep < count) {
+        // queue empty: all 64 lanes prepare one query each, whatever they are walking
+        const int32_t idx = next_prep + lane;
+        if (idx < count) {
+          float x, y, z;
+          fetch(q_begin + idx, x, y, z);
+          const Prepared p = prepare_query<kExact>(tv, x, y, z, max_range_sq, min_dist_sq);
+          queue[0 * 64 + lane] = __float_as_uint(p.qx);
+          queue[1 * 64 + lane] = __float_as_uint(p.qy);
+          queue[2 * 64 + lane] = __float_as_uint(p.qz);
+          // best_d is implied: bound_d if a best exists (then best_d == bound_d), else maxRange^2
+          queue[3 * 64 + lane] = __float_as_uint(p.bound_d);
+          queue[4 * 64 + lane] = p.path_b;
+          queue[5 * 64 + lane] = p.n;
+          queue[6 * 64 + lane] = p.pend;
+          queue[7 * 64 + lane] = p.szmask;
+          queue[8 * 64 + lane] = __float_as_uint(p.best.x);
+          queue[9 * 64 + lane] = __float_as_uint(p.best.y);
+          queue[10 * 64 + lane] = __float_as_uint(p.best.z);
+          queue[11 * 64 + lane] = __float_as_uint(p.best.w);
+        }
+        q_base = next_prep;
+        q_count = count - next_prep < 64 ? count - next_prep : 64;
+        q_head = 0;
+        next_prep += q_count;
+      }
+      if (!active) {
+        const int32_t slot = q_head + (int32_t)__popcll(idle & lt_mask);
+        if (slot < q_count) {
+          qx = __uint_as_float(queue[0 * 64 + slot]);
+          qy = __uint_as_float(queue[1 * 64 + slot]);
+          qz = __uint_as_float(queue[2 * 64 + slot]);
+          bound_d = __uint_as_float(queue[3 * 64 + slot]);
+          path_b = queue[4 * 64 + slot];
+          const uint32_t nn = queue[5 * 64 + slot];
+          pend = queue[6 * 64 + slot];
+          szmask = queue[7 * 64 + slot];
+          best.x = __uint_as_float(queue[8 * 64 + slot]);
+          best.y = __uint_as_float(queue[9 * 64 + slot]);
+          best.z = __uint_as_float(queue[10 * 64 + slot]);
+          best.w = __uint_as_float(queue[11 * 64 + slot]);
+          best_d = __float_as_int(best.w) >= 0 ? bound_d : max_range_sq;
+          my_q = q_base + slot;
+          sp = 0;
+          if (nn & 0x80000000u) {  // MinDistSq cut at the first leaf: nothing left to walk
+            pending = true;
+          } else {
+            n = (int32_t)nn;
+            b = path_b;
+            desc = nn != 0u;
             active = true;
           }
         }
-        next += n_idle;
-      } else if (n_idle == 64) {
+      }
+      q_head = q_head + n_idle < q_count ? q_head + n_idle : q_count;
+      if (q_head == q_count && next_prep >= count && __ballot(active) == 0ull) {
+        if (pending) emit(q_begin + my_q, qx, qy, qz, best, best_d);
         break;  // range exhausted, every lane done and emitted
       }
     }
 
-    // ---- unwinding lanes: look at the two topmost frames (kdtree.go:107-115) ------
+    // ---- unwinding lanes: the topmost explicit frame, else the deepest pending level of the
+    //      first descent (kdtree.go:107-110); its plane test follows the node fetch
     const bool popping = active && !desc;
-    const int32_t i0 = sp >= 1 ? sp - 1 : 0, i1 = sp >= 2 ? sp - 2 : 0;
-    const uint2 f0 = stk[i0 * stk_stride];
-    const uint2 f1 = stk[i1 * stk_stride];
-    const float fp0 = __uint_as_float(f0.y), fp1 = __uint_as_float(f1.y);
-    const bool pass0 = sp >= 1 && !(fp0 * fp0 > best_d);
-    const bool pass1 = sp >= 2 && !(fp1 * fp1 > best_d);
-    const bool pfound = popping && (pass0 || pass1);
-    const uint32_t fx = pass0 ? f0.x : f1.x;
-    const float ffp = pass0 ? fp0 : fp1;
-    const int32_t sp_pop = pass0 ? sp - 1 : i1;  // pass1 -> sp-2; neither -> max(sp-2, 0)
-    sp = popping ? sp_pop : sp;
-    bool finish = popping && !pfound && sp == 0;
-    const uint32_t fb = fx & 0x07FFFFFFu;
-    const int32_t fdepth = 31 - __clz((int)(fb | 1u));
-    const int32_t fn = (int32_t)((np1 >> fdepth) - 1u + (fx >> 31));
+    const bool has_exp = sp > 0;
+    const uint32_t fw = stk[(has_exp ? sp - 1 : 0) * stk_stride];
+    const bool implicit = popping && !has_exp && pend != 0u;
+    bool finish = popping && !has_exp && pend == 0u;
+    sp = (popping && has_exp) ? sp - 1 : sp;
+    const int m = 31 - __clz((int)path_b);
+    const int j = 31 - __clz((int)(pend | 1u));
+    pend = implicit ? (pend & ~(1u << j)) : pend;
+    const uint32_t fb = has_exp ? (fw & 0x07FFFFFFu) : (path_b >> (m - j));
+    const bool went_left = has_exp ? ((fw >> 27) & 1u) != 0u : ((path_b >> (m - j - 1)) & 1u) == 0u;
+    const uint32_t fbit = has_exp ? (fw >> 31) : ((szmask >> j) & 1u);
 
     // ---- the one node fetch of this step -----------------------------------------
     const uint32_t at = desc ? b : fb;
-    const bool look = active && (desc || pfound);
+    const bool look = active && (desc || has_exp || implicit);
     if (look) {
-      const float4 nd = tv.nodes[at];
+      const float4 nd = node_at(tv.nodes, at);
       const float dx = nd.x - qx, dy = nd.y - qy, dz = nd.z - qz;  // pivot.Sub(p)
       const float d = (dx * dx + dy * dy) + dz * dz;                // NormSq, mat/vec3.go:18-20
       const bool leaf = desc && n == 1;
       const bool inner = desc && n != 1;
-      // leaf: replace unless d > best (kdtree.go:95-103); pivot: replace if d < best (:116-119)
-      const bool take = leaf ? !(d > best_d) : (!desc && d < best_d);
-      best_d = take ? d : best_d;
-      best_pos = take ? (int32_t)at : best_pos;
-      if (kMinDist) finish = finish || ((leaf || take) && best_d < min_dist_sq);  // :104,120,140
-
-      // descending through an inner node: searchLeafNode step (kdtree.go:202-221)
-      const int32_t depth = 31 - __clz((int)b);
+      const int32_t depth = 31 - __clz((int)at);
       const int dim = depth % 3;
       const float pv = sel3(dim, nd.x, nd.y, nd.z);
       const float qv = sel3(dim, qx, qy, qz);
       const float fp = qv - pv;
-      if (inner && !(fp * fp > best_d)) {
-        const uint32_t size_bit = (uint32_t)n - ((np1 >> depth) - 1u);
-        stk[sp * stk_stride] = make_uint2(b | (size_bit << 31), __float_as_uint(fp));
-        ++sp;
-      }
+      const bool plane_ok = !(fp * fp > bound_d);  // kdtree.go:111-115
+      // leaf: replace unless d > best (kdtree.go:95-103); pivot: replace if d < best (:116-119)
+      const bool take = leaf ? !(d > best_d) : (!desc && plane_ok && d < best_d);
+      best_d = take ? d : best_d;
+      bound_d = fminf(bound_d, best_d);
+      best.x = take ? nd.x : best.x;
+      best.y = take ? nd.y : best.y;
+      best.z = take ? nd.z : best.z;
+      best.w = take ? nd.w : best.w;
+      if (kMinDist) finish = finish || ((leaf || take) && best_d < min_dist_sq);  // :104,120,140
+
+      // descending through an inner node: searchLeafNode step (kdtree.go:202-221)
       const int32_t half = n >> 1;
       const bool go_left = n == 2 || pv > qv;  // only child, or pivotVal > val -> child0
+      if (inner && plane_ok) {
+        const uint32_t size_bit = (uint32_t)n - ((np1 >> depth) - 1u);
+        stk[sp * stk_stride] = b | (go_left ? (1u << 27) : 0u) | (size_bit << 31);
+        ++sp;
+      }
       const uint32_t d_b = 2u * b + (go_left ? 0u : 1u);
       const int32_t d_n = go_left ? half : n - half - 1;
 
-      // unwinding through a frame that passed the plane test: the other side (kdtree.go:124-137)
+      // unwinding through a node that passed the plane test: the other side (kdtree.go:124-137)
+      const int32_t fn = (int32_t)((np1 >> depth) - 1u + fbit);
       const int32_t phalf = fn >> 1;
-      const bool went_left = ffp < 0.0f;
       const uint32_t p_b = 2u * fb + (went_left ? 1u : 0u);
       const int32_t p_n = went_left ? fn - phalf - 1 : phalf;
-      const bool p_far = fn != 2;  // fn == 2: single child, nextNode == nil (:130-132)
+      const bool p_far = plane_ok && fn != 2;  // fn == 2: single child, nextNode == nil (:130-132)
 
       b = desc ? d_b : p_b;
       n = desc ? d_n : p_n;

@@ -96,6 +96,13 @@ struct TreeView {
   const float4 *nodes;  // [2^depth] BFS slots, index 0 unused
   int32_t n;
   int32_t depth;  // node.maxDepth(0) = floor(log2 n) + 1
+  // Leaf directory: a 2^g x 2^g x 2^g grid over the base cloud's bounding box; dir[cell] is
+  // the BFS index of the leaf the descent of the cell's centre reaches.  Used ONLY as a
+  // prediction of a query's descent path (verified against the real comparisons).
+  const uint32_t *dir;
+  int32_t dir_bits;  // g
+  float dir_lo[3];
+  float dir_scale[3];  // cells per metre (0 for a degenerate axis)
 };
 
 // kdtree_build.cpp
@@ -107,10 +114,16 @@ inline int32_t tree_depth(int64_t n) {
 }
 
 // knn.hip
-constexpr int kKnnBlock = 256;  // 4 waves; LDS = (depth-1) * 256 * 8 B (38 KB at 1M points)
+constexpr int kKnnBlock = 256;  // 4 waves
+constexpr int kWalkQueueBytesPerWave = 12 * 64 * 4;  // knn_walk.h kQueueWords
+// Dynamic LDS of a walk kernel block: frame stacks [(depth-1)][block] x 4 B (19 KB at 1M
+// points) followed by one prepared-query queue per wave (3 KB each).
 inline size_t walk_stack_bytes(const TreeView &tv, int block) {
   int levels = tv.depth > 1 ? tv.depth - 1 : 1;
-  return (size_t)levels * block * sizeof(uint2);
+  return (size_t)levels * block * sizeof(uint32_t);
+}
+inline size_t walk_lds_bytes(const TreeView &tv, int block) {
+  return walk_stack_bytes(tv, block) + (size_t)(block / 64) * kWalkQueueBytesPerWave;
 }
 int walk_blocks_per_cu(const TreeView &tv);
 pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *d_perm, int64_t nq,
@@ -132,7 +145,19 @@ struct pcgx_kdtree {
   int64_t n = 0;
   int32_t depth = 0;
   float4 *d_nodes = nullptr;       // [2^depth] BFS-ordered nodes
+  uint32_t *d_dir = nullptr;       // [8^dir_bits] leaf directory
+  int32_t dir_bits = 0;
+  float dir_lo[3] = {0, 0, 0}, dir_scale[3] = {0, 0, 0};
   std::vector<int32_t> inorder;    // host copy of the in-order ids
   std::vector<float> points;       // host copy of xyz (accessor order), for Vec3At
-  pcgx::TreeView view() const { return pcgx::TreeView{d_nodes, (int32_t)n, depth}; }
+  pcgx::TreeView view() const {
+    pcgx::TreeView v;
+    v.nodes = d_nodes;
+    v.n = (int32_t)n;
+    v.depth = depth;
+    v.dir = d_dir;
+    v.dir_bits = dir_bits;
+    for (int k = 0; k < 3; k++) { v.dir_lo[k] = dir_lo[k]; v.dir_scale[k] = dir_scale[k]; }
+    return v;
+  }
 };
