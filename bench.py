@@ -220,7 +220,7 @@ def main():
                                    % (n, n),
                        "base_points": n, "target_points_per_gpu": n, "parallelism": "target tiles x%d, tree replicated" % world,
                        "exchange": "none" if world == 1 else "all-reduce 10 x f64 per step (RCCL)"},
-            "roofline": {"bound": "hbm", "kernel": "icp_partials_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "icp_corr_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel_ms": kernel_s * 1e3, "launches": walk_n,
                          "algorithmic_bytes_per_launch": alg_bytes, "visits_per_point": v_icp},

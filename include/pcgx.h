@@ -66,7 +66,7 @@ PCGX_API pcgx_status pcgx_sync(void *stream);
 /* Optional in-library kernel timing (HIP events on the launch stream around
  * the named kernel class).  Used by bench.py for the live roofline figure. */
 enum {
-  PCGX_PROF_ICP_WALK = 0,   /* icp_partials_kernel (transform + nearest + reduce) */
+  PCGX_PROF_ICP_WALK = 0,   /* icp_corr_kernel (re-projection + nearest for every target) */
   PCGX_PROF_KNN_WALK = 1,   /* nearest_kernel */
   PCGX_PROF_VOXEL_ALL = 2,  /* whole voxel-filter pipeline of one call */
   PCGX_PROF_SORT_SCATTER = 3, /* rs_scatter_kernel (radix sort passes) */

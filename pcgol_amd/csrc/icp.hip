@@ -38,64 +38,87 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;  // lane 0 holds the sum (fixed tree order -> deterministic)
 }
 
-// Each wave owns a contiguous range of targets (walk_range).  Targets are
-// stored SoA (x[], y[], z[]) in Morton order of the ORIGINAL target; every
-// iteration re-projects the original by the accumulated transform
-// (icp.go:62-64) in registers, walks the tree, and accumulates the evaluator's
-// 9 sums + the pair count (evaluator.go:122-145) in float64.  Each term is
-// formed in float32 exactly as the reference forms it (w == 1).
+// Correspondence (correspondence.go:22-37 for every target at once).  Targets are stored
+// SoA (x[], y[], z[]) in Morton order of the ORIGINAL target; every iteration re-projects
+// the original by the accumulated transform (icp.go:62-64) in registers and walks the tree
+// (walk_queries).  Output per target: match = {base x, y, z, DistSq}, DistSq < 0 = no pair.
 template <bool kMinDist>
-__global__ __launch_bounds__(kIcpBlock) void icp_partials_kernel(
+__global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     TreeView tv, const float *__restrict__ tx, const float *__restrict__ ty,
-    const float *__restrict__ tz, int64_t nt, int64_t per_wave, const IcpState *__restrict__ state,
-    IcpKernelParams kp, double *__restrict__ block_partials) {
+    const float *__restrict__ tz, int64_t nt, const IcpState *__restrict__ state,
+    IcpKernelParams kp, float4 *__restrict__ match) {
   extern __shared__ uint32_t s_stack[];
+  __shared__ uint32_t s_next_chunk;
+  if (state->done) return;  // uniform
+  uint32_t chunk_begin, chunk_end;
+  block_chunk_range(nt, blockIdx.x, gridDim.x, chunk_begin, chunk_end);
+  if (threadIdx.x == 0) s_next_chunk = chunk_begin;
+  __syncthreads();
   uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kIcpBlock +
                     (threadIdx.x >> 6) * (kWalkQueueBytesPerWave / 4);
-  if (state->done) return;  // uniform
   float m[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) m[i] = state->trans[i];
   // Before the first update targetTransformed is a plain copy (icp.go:27-30).
   const bool project = state->iter > 0;
+  walk_queries<kMinDist>(
+      tv, s_stack + threadIdx.x, kIcpBlock, queue, nt, &s_next_chunk, chunk_end, kp.max_dist_sq, kp.min_dist_sq,
+      [&](int64_t i, float &x, float &y, float &z) {
+        x = tx[i]; y = ty[i]; z = tz[i];
+        if (project) {
+          float px, py, pz;
+          mat4_transform(m, x, y, z, px, py, pz);
+          x = px; y = py; z = pz;
+        }
+      },
+      [&](int64_t i, const float4 &bp, float best_d) {
+        match[i] = make_float4(bp.x, bp.y, bp.z, __float_as_int(bp.w) >= 0 ? best_d : -1.0f);
+      });
+}
 
+// Reduction (evaluator.go:122-145): streams targets and matches in a fixed assignment and
+// accumulates the evaluator's 9 sums + the pair count in float64, each term formed in float32
+// exactly as the reference forms it (w == 1).  Fixed order everywhere -> bitwise reproducible,
+// whatever the scheduling of the correspondence kernel was.
+__global__ __launch_bounds__(256) void icp_terms_kernel(const float *__restrict__ tx,
+                                                        const float *__restrict__ ty,
+                                                        const float *__restrict__ tz, int64_t nt,
+                                                        const IcpState *__restrict__ state,
+                                                        const float4 *__restrict__ match,
+                                                        double *__restrict__ block_partials) {
+  __shared__ double s_red[4][S_COUNT];
+  if (state->done) return;  // uniform
+  float m[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) m[i] = state->trans[i];
+  const bool project = state->iter > 0;
   double acc[S_COUNT];
 #pragma unroll
   for (int k = 0; k < S_COUNT; k++) acc[k] = 0.0;
-
-  const int64_t wave_id = (int64_t)blockIdx.x * (kIcpBlock / 64) + (threadIdx.x >> 6);
-  const int64_t q_begin = wave_id * per_wave;
-  int64_t q_end = q_begin + per_wave;
-  if (q_end > nt) q_end = nt;
-  if (q_begin < q_end) {
-    walk_range<kMinDist>(
-        tv, s_stack + threadIdx.x, kIcpBlock, queue, q_begin, q_end, kp.max_dist_sq, kp.min_dist_sq,
-        [&](int64_t i, float &x, float &y, float &z) {
-          x = tx[i]; y = ty[i]; z = tz[i];
-          if (project) {
-            float px, py, pz;
-            mat4_transform(m, x, y, z, px, py, pz);
-            x = px; y = py; z = pz;
-          }
-        },
-        [&](int64_t, float x0, float y0, float z0, const float4 &bp, float best_d) {
-          if (__float_as_int(bp.w) < 0) return;  // correspondence.go:27-29
-          const float x1 = bp.x, y1 = bp.y, z1 = bp.z;
-          acc[S_VALUE] += (double)best_d;
-          acc[S_G0 + 0] += (double)(x0 - x1);
-          acc[S_G0 + 1] += (double)(y0 - y1);
-          acc[S_G0 + 2] += (double)(z0 - z1);
-          acc[S_G0 + 3] += (double)(z0 * y1 - y0 * z1);
-          acc[S_G0 + 4] += (double)(x0 * z1 - z0 * x1);
-          acc[S_G0 + 5] += (double)(y0 * x1 - x0 * y1);
-          acc[S_DIST_RMS] += (double)norm_sq3(x0, y0, z0);
-          acc[S_WEIGHT] += 1.0;
-          acc[S_PAIRS] += 1.0;
-        });
+  const int64_t step = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nt; i += step) {
+    float x0 = tx[i], y0 = ty[i], z0 = tz[i];
+    if (project) {
+      float px, py, pz;
+      mat4_transform(m, x0, y0, z0, px, py, pz);
+      x0 = px; y0 = py; z0 = pz;
+    }
+    const float4 bp = match[i];
+    if (bp.w >= 0.0f) {  // correspondence.go:27-29
+      const float x1 = bp.x, y1 = bp.y, z1 = bp.z;
+      acc[S_VALUE] += (double)bp.w;
+      acc[S_G0 + 0] += (double)(x0 - x1);
+      acc[S_G0 + 1] += (double)(y0 - y1);
+      acc[S_G0 + 2] += (double)(z0 - z1);
+      acc[S_G0 + 3] += (double)(z0 * y1 - y0 * z1);
+      acc[S_G0 + 4] += (double)(x0 * z1 - z0 * x1);
+      acc[S_G0 + 5] += (double)(y0 * x1 - x0 * y1);
+      acc[S_DIST_RMS] += (double)norm_sq3(x0, y0, z0);
+      acc[S_WEIGHT] += 1.0;
+      acc[S_PAIRS] += 1.0;
+    }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();  // every wave is done with its stack / queue: reuse the LDS for the block sum
-  double(*s_red)[S_COUNT] = reinterpret_cast<double(*)[S_COUNT]>(s_stack);
 #pragma unroll
   for (int k = 0; k < S_COUNT; k++) {
     double v = wave_sum_f64(acc[k]);
@@ -104,7 +127,7 @@ __global__ __launch_bounds__(kIcpBlock) void icp_partials_kernel(
   __syncthreads();
   if (threadIdx.x < S_COUNT) {
     double v = 0.0;
-    for (int w = 0; w < kIcpBlock / 64; w++) v += s_red[w][threadIdx.x];
+    for (int w = 0; w < 4; w++) v += s_red[w][threadIdx.x];
     block_partials[(int64_t)blockIdx.x * S_COUNT + threadIdx.x] = v;
   }
 }
@@ -178,10 +201,11 @@ struct pcgx_icp_session {
   float *d_xyz = nullptr;  // SoA: x[nt] | y[nt] | z[nt], Morton order of the original target
   IcpState *d_state = nullptr;
   double *d_partials = nullptr;
+  float4 *d_match = nullptr;       // [nt] matched base point + DistSq per target
+  int terms_grid = 1;
   double *d_sums = nullptr;  // caller's buffer, or own
   bool own_sums = false;
   int grid = 1;
-  int64_t per_wave = 1;
   IcpKernelParams kp;
   int32_t max_iteration = 20;
 };
@@ -199,6 +223,7 @@ static int icp_grid(int64_t nt, const TreeView &tv) {
   int64_t blocks = (nt + kIcpBlock - 1) / kIcpBlock;
   int64_t cap = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv);
   if (blocks > cap) blocks = cap;
+  if (blocks >= 8) blocks &= ~(int64_t)7;  // multiple of 8: see block_chunk_range
   if (blocks < 1) blocks = 1;
   return (int)blocks;
 }
@@ -244,6 +269,7 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   if (s->d_xyz) (void)hipFree(s->d_xyz);
   if (s->d_state) (void)hipFree(s->d_state);
   if (s->d_partials) (void)hipFree(s->d_partials);
+  if (s->d_match) (void)hipFree(s->d_match);
   if (s->own_sums && s->d_sums) (void)hipFree(s->d_sums);
   delete s;
   return PCGX_OK;
@@ -265,7 +291,11 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
   s->kp = make_kernel_params(params);
   s->max_iteration = s->kp.upd.max_iteration;
   s->grid = icp_grid(nt, base->view());
-  s->per_wave = (nt + (int64_t)s->grid * (kIcpBlock / 64) - 1) / ((int64_t)s->grid * (kIcpBlock / 64));
+  {
+    int64_t tb = (nt + 256 * 4 - 1) / (256 * 4);  // ~4 targets per thread
+    if (tb > 2048) tb = 2048;
+    s->terms_grid = tb < 1 ? 1 : (int)tb;
+  }
   pcgx_status rc = PCGX_OK;
   auto bail = [&](pcgx_status code) {
     pcgx_icp_session_free(s);
@@ -274,7 +304,8 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
   hipError_t e;
   if ((e = hipMalloc((void **)&s->d_xyz, (size_t)(nt ? nt : 1) * 12)) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_state, sizeof(IcpState))) != hipSuccess ||
-      (e = hipMalloc((void **)&s->d_partials, (size_t)s->grid * S_COUNT * sizeof(double))) != hipSuccess)
+      (e = hipMalloc((void **)&s->d_partials, (size_t)s->terms_grid * S_COUNT * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void **)&s->d_match, (size_t)(nt ? nt : 1) * sizeof(float4))) != hipSuccess)
     return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
   if (d_sums10) {
     s->d_sums = d_sums10;
@@ -318,14 +349,16 @@ extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stre
   {
     ProfScope prof(PCGX_PROF_ICP_WALK, st);
     if (s->kp.min_dist_sq > 0.0f)
-      hipLaunchKernelGGL(icp_partials_kernel<true>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                         s->per_wave, s->d_state, s->kp, s->d_partials);
+      hipLaunchKernelGGL(icp_corr_kernel<true>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
+                         s->d_state, s->kp, s->d_match);
     else
-      hipLaunchKernelGGL(icp_partials_kernel<false>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                         s->per_wave, s->d_state, s->kp, s->d_partials);
+      hipLaunchKernelGGL(icp_corr_kernel<false>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
+                         s->d_state, s->kp, s->d_match);
   }
-  hipLaunchKernelGGL(icp_final_reduce_kernel, dim3(1), dim3(256), 0, st, s->d_partials, s->grid, s->d_state,
-                     s->d_sums);
+  hipLaunchKernelGGL(icp_terms_kernel, dim3(s->terms_grid), dim3(256), 0, st, x, y, z, s->nt, s->d_state,
+                     s->d_match, s->d_partials);
+  hipLaunchKernelGGL(icp_final_reduce_kernel, dim3(1), dim3(256), 0, st, s->d_partials, s->terms_grid,
+                     s->d_state, s->d_sums);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }

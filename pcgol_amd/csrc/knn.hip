@@ -9,35 +9,33 @@
 
 namespace pcgx {
 
-// Each wave owns a contiguous range of launch positions and walks it with
-// walk_range (one query per lane, finished lanes refill from the range).
-// Queries are packed xyz (AoS, 12 B).  `perm` (optional) maps the launch
-// position to the query index (Morton order, sort.hip): results are written at
-// the original index, so the permutation is invisible to the caller.
+// Waves pull chunks of 64 launch positions (walk_queries) until the batch is done.
+// Queries are packed xyz (AoS, 12 B).  `perm` (optional) maps the launch position to
+// the query index (Morton order, sort.hip): results are written at the original
+// index, so the permutation is invisible to the caller.
 template <bool kMinDist>
 __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const float *__restrict__ q,
                                                             const int32_t *__restrict__ perm,
-                                                            int64_t nq, int64_t per_wave,
-                                                            float max_range_sq, float min_dist_sq,
+                                                            int64_t nq, float max_range_sq, float min_dist_sq,
                                                             int32_t *__restrict__ out_id,
                                                             float *__restrict__ out_dsq) {
   extern __shared__ uint32_t s_stack[];
+  __shared__ uint32_t s_next_chunk;
   uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kKnnBlock +
                     (threadIdx.x >> 6) * (kWalkQueueBytesPerWave / 4);
-  const int64_t wave = (int64_t)blockIdx.x * (kKnnBlock / 64) + (threadIdx.x >> 6);
-  const int64_t q_begin = wave * per_wave;
-  int64_t q_end = q_begin + per_wave;
-  if (q_end > nq) q_end = nq;
-  if (q_begin >= q_end) return;
-  walk_range<kMinDist>(
-      tv, s_stack + threadIdx.x, kKnnBlock, queue, q_begin, q_end, max_range_sq, min_dist_sq,
+  uint32_t chunk_begin, chunk_end;
+  block_chunk_range(nq, blockIdx.x, gridDim.x, chunk_begin, chunk_end);
+  if (threadIdx.x == 0) s_next_chunk = chunk_begin;
+  __syncthreads();
+  walk_queries<kMinDist>(
+      tv, s_stack + threadIdx.x, kKnnBlock, queue, nq, &s_next_chunk, chunk_end, max_range_sq, min_dist_sq,
       [&](int64_t pos, float &x, float &y, float &z) {
         const int64_t i = perm ? (int64_t)perm[pos] : pos;
         x = q[3 * i + 0];
         y = q[3 * i + 1];
         z = q[3 * i + 2];
       },
-      [&](int64_t pos, float, float, float, const float4 &best, float best_d) {
+      [&](int64_t pos, const float4 &best, float best_d) {
         const int64_t i = perm ? (int64_t)perm[pos] : pos;
         out_id[i] = __float_as_int(best.w);
         out_dsq[i] = best_d;
@@ -88,20 +86,18 @@ pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *
                            hipStream_t st) {
   if (nq == 0) return PCGX_OK;
   const size_t lds = walk_lds_bytes(tv, kKnnBlock);
-  const int waves_per_block = kKnnBlock / 64;
   int64_t blocks = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv);
   const int64_t max_blocks = (nq + kKnnBlock - 1) / kKnnBlock;
   if (blocks > max_blocks) blocks = max_blocks;
-  const int64_t waves = blocks * waves_per_block;
-  const int64_t per_wave = (nq + waves - 1) / waves;
+  if (blocks >= 8) blocks &= ~(int64_t)7;  // multiple of 8: see block_chunk_range
   ProfScope prof(PCGX_PROF_KNN_WALK, st);
   // `x < MinDistSq` can only hold for MinDistSq > 0 (or NaN distances, which compare false).
   if (min_dist_sq > 0.0f)
     hipLaunchKernelGGL(nearest_kernel<true>, dim3((unsigned)blocks), dim3(kKnnBlock), lds, st, tv, d_q,
-                       d_perm, nq, per_wave, max_range_sq, min_dist_sq, d_ids, d_dsq);
+                       d_perm, nq, max_range_sq, min_dist_sq, d_ids, d_dsq);
   else
     hipLaunchKernelGGL(nearest_kernel<false>, dim3((unsigned)blocks), dim3(kKnnBlock), lds, st, tv, d_q,
-                       d_perm, nq, per_wave, max_range_sq, min_dist_sq, d_ids, d_dsq);
+                       d_perm, nq, max_range_sq, min_dist_sq, d_ids, d_dsq);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }

@@ -9,11 +9,11 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 BENCH="python3 bench.py --steps 40 --warmup 20 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/bench_trace.log 2>&1
 for PASS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU" \
             "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum"; do
   NAME=$(echo $PASS | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --kernel-trace --pmc $PASS --output-format csv -d $OUT/pmc_$NAME -- $BENCH --no-extras > $OUT/pmc_$NAME.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $PASS --output-format csv -d $OUT/pmc_$NAME -- $BENCH --no-extras > $OUT/pmc_$NAME.log 2>&1
 done
 python3 profiles/summarize.py $OUT $TAG
