@@ -246,6 +246,8 @@ PCGX_API pcgx_status pcgx_icp_session_read_sums(pcgx_icp_session *s, double sums
 PCGX_API pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stream);
 /* Enqueue evaluate-tail + Update from the (all-reduced) d_sums10 on the device. */
 PCGX_API pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream);
+/* partials + update back to back, for a single GPU (no exchange in between): fewer launches. */
+PCGX_API pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream);
 /* Synchronise and read back trans / stat / converged flag.  Returns
  * PCGX_E_NOT_ENOUGH_PAIRS if an iteration failed. */
 PCGX_API pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream,

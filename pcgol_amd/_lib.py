@@ -119,6 +119,7 @@ SIGNATURES = {
     "pcgx_icp_session_read_sums": (_i32, [_vp, _vp, _vp]),
     "pcgx_icp_session_partials": (_i32, [_vp, _vp]),
     "pcgx_icp_session_update": (_i32, [_vp, _vp]),
+    "pcgx_icp_session_step": (_i32, [_vp, _vp]),
     "pcgx_icp_session_result": (_i32, [_vp, _vp, _vp, C.POINTER(IcpStat), C.POINTER(_i32)]),
 }
 

@@ -38,15 +38,37 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;  // lane 0 holds the sum (fixed tree order -> deterministic)
 }
 
-// Correspondence (correspondence.go:22-37 for every target at once).  Targets are stored
-// SoA (x[], y[], z[]) in Morton order of the ORIGINAL target; every iteration re-projects
-// the original by the accumulated transform (icp.go:62-64) in registers and walks the tree
-// (walk_queries).  Output per target: match = {base x, y, z, DistSq}, DistSq < 0 = no pair.
+__device__ __forceinline__ void accumulate_terms(double *acc, float x0, float y0, float z0, const float4 &bp) {
+  // evaluator.go:132-144 with w == 1; every term is formed in float32 as the reference forms it
+  const float x1 = bp.x, y1 = bp.y, z1 = bp.z;
+  acc[S_VALUE] += (double)bp.w;
+  acc[S_G0 + 0] += (double)(x0 - x1);
+  acc[S_G0 + 1] += (double)(y0 - y1);
+  acc[S_G0 + 2] += (double)(z0 - z1);
+  acc[S_G0 + 3] += (double)(z0 * y1 - y0 * z1);
+  acc[S_G0 + 4] += (double)(x0 * z1 - z0 * x1);
+  acc[S_G0 + 5] += (double)(y0 * x1 - x0 * y1);
+  acc[S_DIST_RMS] += (double)norm_sq3(x0, y0, z0);
+  acc[S_WEIGHT] += 1.0;
+  acc[S_PAIRS] += 1.0;
+}
+
+// One ICP iteration's correspondence + reduction for a tile of targets.
+//
+// Phase 1, correspondence (correspondence.go:22-37 for every target at once): targets are
+// stored SoA (x[], y[], z[]) in Morton order of the ORIGINAL target; every iteration
+// re-projects the original by the accumulated transform (icp.go:62-64) in registers and walks
+// the tree (walk_queries).  Result per target: match = {base x, y, z, DistSq}, DistSq < 0 = no
+// pair.  Phase 2, reduction (evaluator.go:122-145): after a workgroup barrier the workgroup
+// streams the targets of ITS OWN (static) chunk range again in a fixed thread assignment and
+// accumulates the evaluator's 9 sums + the pair count in float64.  The order of every addition
+// is fixed by the launch geometry alone, so the sums are bitwise reproducible although the
+// walk hands queries to lanes dynamically.
 template <bool kMinDist>
 __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     TreeView tv, const float *__restrict__ tx, const float *__restrict__ ty,
     const float *__restrict__ tz, int64_t nt, const IcpState *__restrict__ state,
-    IcpKernelParams kp, float4 *__restrict__ match) {
+    IcpKernelParams kp, float4 *__restrict__ match, double *__restrict__ block_partials) {
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
   if (state->done) return;  // uniform
@@ -61,64 +83,40 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
   for (int i = 0; i < 16; i++) m[i] = state->trans[i];
   // Before the first update targetTransformed is a plain copy (icp.go:27-30).
   const bool project = state->iter > 0;
+  auto load_target = [&](int64_t i, float &x, float &y, float &z) {
+    x = tx[i]; y = ty[i]; z = tz[i];
+    if (project) {
+      float px, py, pz;
+      mat4_transform(m, x, y, z, px, py, pz);
+      x = px; y = py; z = pz;
+    }
+  };
   walk_queries<kMinDist>(
       tv, s_stack + threadIdx.x, kIcpBlock, queue, nt, &s_next_chunk, chunk_end, kp.max_dist_sq, kp.min_dist_sq,
-      [&](int64_t i, float &x, float &y, float &z) {
-        x = tx[i]; y = ty[i]; z = tz[i];
-        if (project) {
-          float px, py, pz;
-          mat4_transform(m, x, y, z, px, py, pz);
-          x = px; y = py; z = pz;
-        }
-      },
+      load_target,
       [&](int64_t i, const float4 &bp, float best_d) {
         match[i] = make_float4(bp.x, bp.y, bp.z, __float_as_int(bp.w) >= 0 ? best_d : -1.0f);
       });
-}
 
-// Reduction (evaluator.go:122-145): streams targets and matches in a fixed assignment and
-// accumulates the evaluator's 9 sums + the pair count in float64, each term formed in float32
-// exactly as the reference forms it (w == 1).  Fixed order everywhere -> bitwise reproducible,
-// whatever the scheduling of the correspondence kernel was.
-__global__ __launch_bounds__(256) void icp_terms_kernel(const float *__restrict__ tx,
-                                                        const float *__restrict__ ty,
-                                                        const float *__restrict__ tz, int64_t nt,
-                                                        const IcpState *__restrict__ state,
-                                                        const float4 *__restrict__ match,
-                                                        double *__restrict__ block_partials) {
-  __shared__ double s_red[4][S_COUNT];
-  if (state->done) return;  // uniform
-  float m[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) m[i] = state->trans[i];
-  const bool project = state->iter > 0;
+  // ---- phase 2: this workgroup's range, fixed order
+  __threadfence_block();
+  __syncthreads();  // all match[] of the range are written; stacks / queues are free for reuse
   double acc[S_COUNT];
 #pragma unroll
   for (int k = 0; k < S_COUNT; k++) acc[k] = 0.0;
-  const int64_t step = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nt; i += step) {
-    float x0 = tx[i], y0 = ty[i], z0 = tz[i];
-    if (project) {
-      float px, py, pz;
-      mat4_transform(m, x0, y0, z0, px, py, pz);
-      x0 = px; y0 = py; z0 = pz;
-    }
+  const int64_t r_begin = (int64_t)chunk_begin * 64;
+  int64_t r_end = (int64_t)chunk_end * 64;
+  if (r_end > nt) r_end = nt;
+  for (int64_t i = r_begin + threadIdx.x; i < r_end; i += kIcpBlock) {
     const float4 bp = match[i];
     if (bp.w >= 0.0f) {  // correspondence.go:27-29
-      const float x1 = bp.x, y1 = bp.y, z1 = bp.z;
-      acc[S_VALUE] += (double)bp.w;
-      acc[S_G0 + 0] += (double)(x0 - x1);
-      acc[S_G0 + 1] += (double)(y0 - y1);
-      acc[S_G0 + 2] += (double)(z0 - z1);
-      acc[S_G0 + 3] += (double)(z0 * y1 - y0 * z1);
-      acc[S_G0 + 4] += (double)(x0 * z1 - z0 * x1);
-      acc[S_G0 + 5] += (double)(y0 * x1 - x0 * y1);
-      acc[S_DIST_RMS] += (double)norm_sq3(x0, y0, z0);
-      acc[S_WEIGHT] += 1.0;
-      acc[S_PAIRS] += 1.0;
+      float x0, y0, z0;
+      load_target(i, x0, y0, z0);
+      accumulate_terms(acc, x0, y0, z0, bp);
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double(*s_red)[S_COUNT] = reinterpret_cast<double(*)[S_COUNT]>(s_stack);
 #pragma unroll
   for (int k = 0; k < S_COUNT; k++) {
     double v = wave_sum_f64(acc[k]);
@@ -127,38 +125,15 @@ __global__ __launch_bounds__(256) void icp_terms_kernel(const float *__restrict_
   __syncthreads();
   if (threadIdx.x < S_COUNT) {
     double v = 0.0;
-    for (int w = 0; w < 4; w++) v += s_red[w][threadIdx.x];
+    for (int w = 0; w < kIcpBlock / 64; w++) v += s_red[w][threadIdx.x];
     block_partials[(int64_t)blockIdx.x * S_COUNT + threadIdx.x] = v;
   }
 }
 
-// Sums the per-block partials in a fixed order -> sums10 (run-to-run deterministic).
-__global__ __launch_bounds__(256) void icp_final_reduce_kernel(const double *__restrict__ block_partials,
-                                                               int nblocks,
-                                                               const IcpState *__restrict__ state,
-                                                               double *__restrict__ sums10) {
-  __shared__ double s[256];
-  if (state->done) return;
-  for (int k = 0; k < S_COUNT; k++) {
-    double v = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += 256) v += block_partials[(int64_t)b * S_COUNT + k];
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) sums10[k] = s[0];
-    __syncthreads();
-  }
-}
-
-// Evaluate tail (evaluator.go:92-105,156-186) + Update (updater.go:44-71) +
-// the loop bookkeeping of Fit (icp.go:49-60), one thread.
-__global__ void icp_update_kernel(IcpState *__restrict__ state, const double *__restrict__ sums10,
-                                  IcpKernelParams kp) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  if (state->done) return;
+// Evaluate tail (evaluator.go:92-105,156-186) + Update (updater.go:44-71) + the loop
+// bookkeeping of Fit (icp.go:49-60); one thread.
+__device__ __forceinline__ void icp_update_step(IcpState *__restrict__ state, const double *__restrict__ sums10,
+                                                const IcpKernelParams &kp) {
   state->num_iteration += 1;
   const int64_t npairs = (int64_t)sums10[S_PAIRS];
   if (npairs < (int64_t)kp.min_pairs) {
@@ -177,6 +152,37 @@ __global__ void icp_update_kernel(IcpState *__restrict__ state, const double *__
   for (int i = 0; i < 16; i++) state->trans[i] = t.m[i];
   state->iter = it;
   if (converged) state->done = 1;
+}
+
+// Sums the per-workgroup partials in a fixed order -> sums10: wave k owns component k.
+// With kFuseUpdate (single GPU: no exchange between reduce and update) thread 0 then runs
+// the evaluate tail + pose update in the same launch.
+template <bool kFuseUpdate>
+__global__ __launch_bounds__(64 * S_COUNT) void icp_final_reduce_kernel(const double *__restrict__ block_partials,
+                                                                       int nblocks, IcpState *__restrict__ state,
+                                                                       double *__restrict__ sums10,
+                                                                       IcpKernelParams kp) {
+  __shared__ double s_sums[S_COUNT];
+  if (state->done) return;
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double v = 0.0;
+  for (int b = lane; b < nblocks; b += 64) v += block_partials[(int64_t)b * S_COUNT + k];
+  v = wave_sum_f64(v);
+  if (lane == 0) {
+    sums10[k] = v;
+    s_sums[k] = v;
+  }
+  if (kFuseUpdate) {
+    __syncthreads();
+    if (threadIdx.x == 0) icp_update_step(state, s_sums, kp);
+  }
+}
+
+__global__ void icp_update_kernel(IcpState *__restrict__ state, const double *__restrict__ sums10,
+                                  IcpKernelParams kp) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (state->done) return;
+  icp_update_step(state, sums10, kp);
 }
 
 __global__ __launch_bounds__(256) void gather_soa_kernel(const float *__restrict__ q,
@@ -202,7 +208,6 @@ struct pcgx_icp_session {
   IcpState *d_state = nullptr;
   double *d_partials = nullptr;
   float4 *d_match = nullptr;       // [nt] matched base point + DistSq per target
-  int terms_grid = 1;
   double *d_sums = nullptr;  // caller's buffer, or own
   bool own_sums = false;
   int grid = 1;
@@ -291,11 +296,6 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
   s->kp = make_kernel_params(params);
   s->max_iteration = s->kp.upd.max_iteration;
   s->grid = icp_grid(nt, base->view());
-  {
-    int64_t tb = (nt + 256 * 4 - 1) / (256 * 4);  // ~4 targets per thread
-    if (tb > 2048) tb = 2048;
-    s->terms_grid = tb < 1 ? 1 : (int)tb;
-  }
   pcgx_status rc = PCGX_OK;
   auto bail = [&](pcgx_status code) {
     pcgx_icp_session_free(s);
@@ -304,7 +304,7 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
   hipError_t e;
   if ((e = hipMalloc((void **)&s->d_xyz, (size_t)(nt ? nt : 1) * 12)) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_state, sizeof(IcpState))) != hipSuccess ||
-      (e = hipMalloc((void **)&s->d_partials, (size_t)s->terms_grid * S_COUNT * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void **)&s->d_partials, (size_t)s->grid * S_COUNT * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_match, (size_t)(nt ? nt : 1) * sizeof(float4))) != hipSuccess)
     return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
   if (d_sums10) {
@@ -340,25 +340,26 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
   return PCGX_OK;
 }
 
-extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stream) {
-  if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_partials: NULL session");
-  hipStream_t st = pick_stream(stream);
+static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   const TreeView tv = s->base->view();
   const size_t lds = walk_lds_bytes(tv, kIcpBlock);
   const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
-  {
-    ProfScope prof(PCGX_PROF_ICP_WALK, st);
-    if (s->kp.min_dist_sq > 0.0f)
-      hipLaunchKernelGGL(icp_corr_kernel<true>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                         s->d_state, s->kp, s->d_match);
-    else
-      hipLaunchKernelGGL(icp_corr_kernel<false>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                         s->d_state, s->kp, s->d_match);
-  }
-  hipLaunchKernelGGL(icp_terms_kernel, dim3(s->terms_grid), dim3(256), 0, st, x, y, z, s->nt, s->d_state,
-                     s->d_match, s->d_partials);
-  hipLaunchKernelGGL(icp_final_reduce_kernel, dim3(1), dim3(256), 0, st, s->d_partials, s->terms_grid,
-                     s->d_state, s->d_sums);
+  ProfScope prof(PCGX_PROF_ICP_WALK, st);
+  if (s->kp.min_dist_sq > 0.0f)
+    hipLaunchKernelGGL(icp_corr_kernel<true>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
+                       s->d_state, s->kp, s->d_match, s->d_partials);
+  else
+    hipLaunchKernelGGL(icp_corr_kernel<false>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
+                       s->d_state, s->kp, s->d_match, s->d_partials);
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stream) {
+  if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_partials: NULL session");
+  hipStream_t st = pick_stream(stream);
+  PCGX_TRY(enqueue_corr(s, st));
+  hipLaunchKernelGGL(icp_final_reduce_kernel<false>, dim3(1), dim3(64 * S_COUNT), 0, st, s->d_partials, s->grid,
+                     s->d_state, s->d_sums, s->kp);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }
@@ -367,6 +368,17 @@ extern "C" pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_update: NULL session");
   hipStream_t st = pick_stream(stream);
   hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(64), 0, st, s->d_state, s->d_sums, s->kp);
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
+// partials + update with no exchange in between (single GPU): two launches per iteration.
+extern "C" pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream) {
+  if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_step: NULL session");
+  hipStream_t st = pick_stream(stream);
+  PCGX_TRY(enqueue_corr(s, st));
+  hipLaunchKernelGGL(icp_final_reduce_kernel<true>, dim3(1), dim3(64 * S_COUNT), 0, st, s->d_partials, s->grid,
+                     s->d_state, s->d_sums, s->kp);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }
@@ -402,10 +414,7 @@ extern "C" pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target
   pcgx_status rc = PCGX_OK;
   // At most MaxIteration evaluations can happen (updater.go:69-70); once the
   // device-side state is `done` the remaining launches return immediately.
-  for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) {
-    rc = pcgx_icp_session_partials(s, nullptr);
-    if (rc == PCGX_OK) rc = pcgx_icp_session_update(s, nullptr);
-  }
+  for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) rc = pcgx_icp_session_step(s, nullptr);
   if (rc == PCGX_OK) rc = pcgx_icp_session_result(s, nullptr, trans16, stat, nullptr);
   pcgx_icp_session_free(s);
   return rc;

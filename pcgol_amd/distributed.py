@@ -104,9 +104,11 @@ class ShardedIcp:
     def step(self):
         """One ICP iteration, enqueued on torch's current stream."""
         st = self.torch.cuda.current_stream().cuda_stream
+        if self.world == 1:
+            self.sess.step(st)  # reduce + update fused: no exchange needed
+            return
         self.sess.partials(st)
-        if self.world > 1:
-            self.torch.distributed.all_reduce(self.sums, group=self.group)
+        self.torch.distributed.all_reduce(self.sums, group=self.group)
         self.sess.update(st)
 
     def reset(self):

@@ -179,6 +179,9 @@ class IcpSession:
     def update(self, stream=0):
         L.check(L.lib().pcgx_icp_session_update(self._h, L.ptr(stream) if stream else None))
 
+    def step(self, stream=0):
+        L.check(L.lib().pcgx_icp_session_step(self._h, L.ptr(stream) if stream else None))
+
     def set_pose(self, trans, it, stream=0):
         t = L.f32c(trans)
         L.check(L.lib().pcgx_icp_session_set_pose(self._h, L.ptr(t), int(it), L.ptr(stream) if stream else None))
