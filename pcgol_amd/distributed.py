@@ -90,7 +90,7 @@ class ShardedIcp:
     pose update runs on every GPU redundantly, so no rank ever waits for the host."""
 
     def __init__(self, base_tree, target_tile, MaxDist, MinPairs=0, Weight=None, Threshold=None,
-                 MaxIteration=0, group=None):
+                 MaxIteration=0, group=None, force_exchange=False):
         import torch
         self.torch = torch
         self.group = group
@@ -100,11 +100,13 @@ class ShardedIcp:
         self.max_iteration = self.sess.max_iteration
         import torch.distributed as dist
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # force_exchange: take the partials -> all-reduce -> update path even with one rank (tests)
+        self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
 
     def step(self):
         """One ICP iteration, enqueued on torch's current stream."""
         st = self.torch.cuda.current_stream().cuda_stream
-        if self.world == 1:
+        if not self.exchange:
             self.sess.step(st)  # reduce + update fused: no exchange needed
             return
         self.sess.partials(st)

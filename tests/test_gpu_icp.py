@@ -142,3 +142,31 @@ def test_session_matches_fit():
     trans2, stat2 = reg.Fit(t, c["target"])
     assert conv and stat.NumIteration == stat2.NumIteration
     assert np.array_equal(trans, trans2)  # deterministic reduction: bitwise reproducible
+
+
+def test_sharded_icp_rccl_single_rank():
+    """The N > 1 code path (partials -> RCCL all-reduce on the device -> update) on one GPU:
+    a 1-rank nccl group; must equal the fused single-GPU loop bit for bit."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from pcgol_amd.distributed import ShardedIcp
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        c = synth.c4_icp(n=50000, width=3.7)
+        t = kdtree.New(c["base"])
+        args = (t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+        a = ShardedIcp(*args, force_exchange=True)
+        assert a.exchange
+        ta, sa, ca = a.fit()
+        b = ShardedIcp(*args)
+        tb, sb, cb = b.fit()
+        torch.cuda.synchronize()
+        assert ca and cb and sa.NumIteration == sb.NumIteration == 20
+        assert np.array_equal(ta, tb)
+        a.close()
+        b.close()
+    finally:
+        dist.destroy_process_group()
