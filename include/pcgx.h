@@ -142,7 +142,8 @@ PCGX_API pcgx_status pcgx_voxel_filter(const void *data, int64_t n, int32_t stri
                                        int32_t xyz_off, const float leaf[3],
                                        const int32_t chunk[3], void *out_data, int64_t *out_n);
 /* Device resident: d_data/d_out are device buffers (d_out >= n*stride bytes);
- * d_out_n is a device int64.  Synchronises internally only for workspace sizing. */
+ * *out_n is known when the call returns (it synchronises internally for the grid set-up and
+ * the count), but the kernels that fill d_out may still be running on `stream`. */
 PCGX_API pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int32_t stride,
                                            int32_t xyz_off, const float leaf[3],
                                            const int32_t chunk[3], void *d_out,

@@ -412,7 +412,9 @@ extern "C" pcgx_status pcgx_voxel_filter(const void *data, int64_t n, int32_t st
   int64_t m = 0;
   if (rc == PCGX_OK) rc = pcgx_voxel_filter_dev(d_in, n, stride, xyz_off, leaf, chunk, d_out, &m, st);
   if (rc == PCGX_OK && m > 0) {
-    e = hipMemcpy(out_data, d_out, (size_t)m * (size_t)stride, hipMemcpyDeviceToHost);
+    // same stream as the filter (the library stream is non-blocking w.r.t. the null stream)
+    e = hipMemcpyAsync(out_data, d_out, (size_t)m * (size_t)stride, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_voxel_filter download: %s", hipGetErrorString(e));
   }
   (void)hipFree(d_in);
