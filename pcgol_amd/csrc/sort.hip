@@ -259,13 +259,24 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__re
     a.mn[k] = qnan; a.mx[k] = qnan;
     a.imn[k] = 0x7fffffff; a.imx[k] = 0x7fffffff;
   }
+  // four independent loads in flight per thread; indices still increase per thread
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
-    const uint8_t *p = data + i * stride + off;
-    const float v[3] = {ld_f32_any(p), ld_f32_any(p + 4), ld_f32_any(p + 8)};
-    for (int k = 0; k < 3; k++) {
-      mm_take(a.mn[k], a.imn[k], v[k], (int32_t)i, true);
-      mm_take(a.mx[k], a.imx[k], v[k], (int32_t)i, false);
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * step) {
+    float v[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t i = i0 + u * step;
+      const uint8_t *p = data + (i < n ? i : i0) * stride + off;
+      v[u][0] = ld_f32_any(p); v[u][1] = ld_f32_any(p + 4); v[u][2] = ld_f32_any(p + 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t i = i0 + u * step;
+      if (i < n)
+        for (int k = 0; k < 3; k++) {
+          mm_take(a.mn[k], a.imn[k], v[u][k], (int32_t)i, true);
+          mm_take(a.mx[k], a.imx[k], v[u][k], (int32_t)i, false);
+        }
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -289,17 +300,18 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__re
   }
 }
 
-// out6 = {min xyz, max xyz}; one wave folds the per-block partials.
-__global__ __launch_bounds__(64) void minmax_final_kernel(const MinMaxAcc *__restrict__ partials, int nparts,
-                                                          const uint8_t *__restrict__ data, int32_t off,
-                                                          float *__restrict__ out6) {
+// out6 = {min xyz, max xyz}; one block folds the per-block partials.
+__global__ __launch_bounds__(256) void minmax_final_kernel(const MinMaxAcc *__restrict__ partials, int nparts,
+                                                           const uint8_t *__restrict__ data, int32_t off,
+                                                           float *__restrict__ out6) {
+  __shared__ MinMaxAcc s_acc[4];
   const float qnan = __uint_as_float(0x7fc00000u);
   MinMaxAcc a;
   for (int k = 0; k < 3; k++) {
     a.mn[k] = qnan; a.mx[k] = qnan;
     a.imn[k] = 0x7fffffff; a.imx[k] = 0x7fffffff;
   }
-  for (int b = threadIdx.x; b < nparts; b += 64)
+  for (int b = threadIdx.x; b < nparts; b += 256)
     for (int k = 0; k < 3; k++) {
       mm_take(a.mn[k], a.imn[k], partials[b].mn[k], partials[b].imn[k], true);
       mm_take(a.mx[k], a.imx[k], partials[b].mx[k], partials[b].imx[k], false);
@@ -311,7 +323,14 @@ __global__ __launch_bounds__(64) void minmax_final_kernel(const MinMaxAcc *__res
       v = __shfl_down(a.mx[k], o); iv = __shfl_down(a.imx[k], o);
       mm_take(a.mx[k], a.imx[k], v, iv, false);
     }
+  if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = a;
+  __syncthreads();
   if (threadIdx.x != 0) return;
+  for (int w = 1; w < 4; w++)
+    for (int k = 0; k < 3; k++) {
+      mm_take(a.mn[k], a.imn[k], s_acc[w].mn[k], s_acc[w].imn[k], true);
+      mm_take(a.mx[k], a.imx[k], s_acc[w].mx[k], s_acc[w].imx[k], false);
+    }
   for (int k = 0; k < 3; k++) {
     // min, max := Vec3At(0): a NaN there is never replaced (minmax.go:13-23)
     const float p0 = ld_f32_any(data + off + 4 * k);
@@ -331,7 +350,7 @@ pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t
   PCGX_TRY(ctx().arena.alloc_n(blocks, &partials));
   hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t *)d_data, n,
                      stride, off, partials);
-  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(64), 0, st, partials, blocks,
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, st, partials, blocks,
                      (const uint8_t *)d_data, off, d_out6);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
