@@ -72,12 +72,15 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
   if (state->done) return;  // uniform
+  uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kIcpBlock +
+                    (threadIdx.x >> 6) * (kWalkQueueBytesPerWave / 4);
+  float *top = reinterpret_cast<float *>(s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kIcpBlock +
+                                         (kIcpBlock / 64) * (kWalkQueueBytesPerWave / 4));
+  load_top_levels(tv, top);
   uint32_t chunk_begin, chunk_end;
   block_chunk_range(nt, blockIdx.x, gridDim.x, chunk_begin, chunk_end);
   if (threadIdx.x == 0) s_next_chunk = chunk_begin;
   __syncthreads();
-  uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kIcpBlock +
-                    (threadIdx.x >> 6) * (kWalkQueueBytesPerWave / 4);
   float m[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) m[i] = state->trans[i];
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     }
   };
   walk_queries<kMinDist>(
-      tv, s_stack + threadIdx.x, kIcpBlock, queue, nt, &s_next_chunk, chunk_end, kp.max_dist_sq, kp.min_dist_sq,
+      tv, s_stack + threadIdx.x, kIcpBlock, queue, top, nt, &s_next_chunk, chunk_end, kp.max_dist_sq, kp.min_dist_sq,
       load_target,
       [&](int64_t i, const float4 &bp, float best_d) {
         match[i] = make_float4(bp.x, bp.y, bp.z, __float_as_int(bp.w) >= 0 ? best_d : -1.0f);
@@ -226,7 +229,7 @@ static IcpKernelParams make_kernel_params(const pcgx_icp_params *p) {
 
 static int icp_grid(int64_t nt, const TreeView &tv) {
   int64_t blocks = (nt + kIcpBlock - 1) / kIcpBlock;
-  int64_t cap = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv);
+  int64_t cap = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv) * walk_oversubscribe();
   if (blocks > cap) blocks = cap;
   if (blocks >= 8) blocks &= ~(int64_t)7;  // multiple of 8: see block_chunk_range
   if (blocks < 1) blocks = 1;

@@ -23,12 +23,15 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
   __shared__ uint32_t s_next_chunk;
   uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kKnnBlock +
                     (threadIdx.x >> 6) * (kWalkQueueBytesPerWave / 4);
+  float *top = reinterpret_cast<float *>(s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kKnnBlock +
+                                         (kKnnBlock / 64) * (kWalkQueueBytesPerWave / 4));
+  load_top_levels(tv, top);
   uint32_t chunk_begin, chunk_end;
   block_chunk_range(nq, blockIdx.x, gridDim.x, chunk_begin, chunk_end);
   if (threadIdx.x == 0) s_next_chunk = chunk_begin;
   __syncthreads();
   walk_queries<kMinDist>(
-      tv, s_stack + threadIdx.x, kKnnBlock, queue, nq, &s_next_chunk, chunk_end, max_range_sq, min_dist_sq,
+      tv, s_stack + threadIdx.x, kKnnBlock, queue, top, nq, &s_next_chunk, chunk_end, max_range_sq, min_dist_sq,
       [&](int64_t pos, float &x, float &y, float &z) {
         const int64_t i = perm ? (int64_t)perm[pos] : pos;
         x = q[3 * i + 0];
@@ -68,12 +71,43 @@ __global__ __launch_bounds__(256) void dir_build_kernel(TreeView tv, uint32_t *_
   dir[cell] = b;
 }
 
+// Idle lanes a wave tolerates before it runs the (divergent) emit + refill section.
+int walk_refill_threshold() {
+  static int v = -1;
+  if (v < 0) {
+    v = 8;
+    if (const char *e = getenv("PCGX_WALK_REFILL")) {
+      const int t = atoi(e);
+      if (t >= 1 && t <= 64) v = t;
+    }
+  }
+  return v;
+}
+
+// Grid oversubscription of the walk kernels: workgroups launched per resident slot.  Ranges are
+// static per workgroup, so launching more workgroups than fit lets the dispatcher even out the
+// differences between ranges.
+int walk_oversubscribe() {
+  static int v = -1;
+  if (v < 0) {
+    v = 1;
+    if (const char *e = getenv("PCGX_WALK_OVERSUB")) {
+      const int t = atoi(e);
+      if (t >= 1 && t <= 16) v = t;
+    }
+  }
+  return v;
+}
+
+static int g_walk_resident = 4;
+
 // Blocks resident per CU for the walk kernels, limited by their LDS (walk_lds_bytes).
 int walk_blocks_per_cu(const TreeView &tv) {
   const size_t lds = walk_lds_bytes(tv, kKnnBlock);
   int b = (int)((160 * 1024) / (lds ? lds : 1));
   if (b > 8) b = 8;
   if (b < 1) b = 1;
+  g_walk_resident = b;
   if (const char *e = getenv("PCGX_WALK_BLOCKS_PER_CU")) {
     int v = atoi(e);
     if (v >= 1 && v <= 8) b = v;
@@ -86,7 +120,7 @@ pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *
                            hipStream_t st) {
   if (nq == 0) return PCGX_OK;
   const size_t lds = walk_lds_bytes(tv, kKnnBlock);
-  int64_t blocks = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv);
+  int64_t blocks = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv) * walk_oversubscribe();
   const int64_t max_blocks = (nq + kKnnBlock - 1) / kKnnBlock;
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks >= 8) blocks &= ~(int64_t)7;  // multiple of 8: see block_chunk_range
@@ -189,6 +223,10 @@ extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t st
       }
     int g = 0;
     while (g < 9 && ((int64_t)1 << (3 * g)) < 2 * n) g++;
+    if (const char *e = getenv("PCGX_DIR_BITS")) {  // tuning knob: cells per axis = 2^g
+      const int v = atoi(e);
+      if (v >= 0 && v <= 9) g = v;
+    }
     t->dir_bits = g;
     for (int k = 0; k < 3; k++) {
       const float ext = hi[k] - lo[k];

@@ -24,7 +24,8 @@
 // in the reference.  Here a grid directory (TreeView::dir, built with the tree)
 // predicts the leaf a query will reach; in BFS order the ancestors of that leaf
 // are plain shifts of its index, so the split values of the WHOLE predicted path
-// (and the leaf itself) are fetched in parallel -- one memory round trip.  The
+// (and the leaf itself) are fetched in parallel -- one memory round trip; the
+// split values of the top 11 levels come from an LDS copy per workgroup.  The
 // prediction is then VERIFIED level by level with the reference's own
 // comparison (pivotVal > val -> child0, kdtree.go:216): up to the first level m
 // where the real descent leaves the predicted path everything is exactly what
@@ -85,7 +86,6 @@ __device__ __forceinline__ float sel3(int dim, float a, float b, float c) {
   return dim == 0 ? a : (dim == 1 ? b : c);
 }
 
-constexpr int kRefillThreshold = 8;  // emit + refill once this many lanes wait (or nothing is active)
 constexpr int kMaxLevels = 26;       // inner levels on a root-to-leaf path (N <= 2^26)
 
 // State a prepared query starts the stepping loop with (= one LDS queue entry).
@@ -112,11 +112,23 @@ __device__ __forceinline__ float4 node_at(const float4 *nodes, uint32_t b) {
   return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + off);
 }
 
-constexpr int kChunk = 9;  // levels fetched per round (a multiple of 3: the split axis is static)
+constexpr int kTopLevels = 11;                 // split values of levels 0..10 (BFS 1..2047) live in LDS
+constexpr int kTopEntries = 1 << kTopLevels;   // 2048 floats = 8 KB per workgroup
+constexpr int kDeepLevels = kMaxLevels - kTopLevels;
+
+// Fills the workgroup's LDS copy of the top split values (call before walk_queries, then sync).
+__device__ __forceinline__ void load_top_levels(const TreeView &tv, float *__restrict__ top) {
+  const uint32_t slots = 1u << tv.depth;  // BFS slots that exist
+  for (uint32_t b = threadIdx.x; b < (uint32_t)kTopEntries; b += blockDim.x) {
+    float v = 0.0f;
+    if (b >= 1u && b < slots) v = node_comp(tv.nodes, b, (31 - __clz((int)b)) % 3);
+    top[b] = v;
+  }
+}
 
 template <bool kExact>
-__device__ __forceinline__ Prepared prepare_query(const TreeView &tv, float qx, float qy, float qz,
-                                                  float max_range_sq, float min_dist_sq) {
+__device__ __forceinline__ Prepared prepare_query(const TreeView &tv, const float *__restrict__ top, float qx,
+                                                  float qy, float qz, float max_range_sq, float min_dist_sq) {
   Prepared p;
   p.qx = qx; p.qy = qy; p.qz = qz;
   p.best_d = max_range_sq;
@@ -132,49 +144,66 @@ __device__ __forceinline__ Prepared prepare_query(const TreeView &tv, float qx, 
   const uint32_t bl = tv.dir[cell];
   const int L = 31 - __clz((int)bl);  // depth of the predicted leaf = inner levels above it
 
-  // --- the predicted leaf: its distance is an upper bound of the nearest distance
+  // --- ONE round of independent fetches: the predicted leaf and the split values of the
+  //     predicted path below the LDS-resident top levels
   const float4 leaf = node_at(tv.nodes, bl);
-  const float ldx = leaf.x - qx, ldy = leaf.y - qy, ldz = leaf.z - qz;
-  const float d_leaf = (ldx * ldx + ldy * ldy) + ldz * ldz;
-  // Bound for recording a level in `pend`: the best while the reference descends
-  // (= maxRange^2), tightened by ub in exact mode (header, "Pruning bound").
-  const float bound0 = kExact ? fminf(max_range_sq, d_leaf) : max_range_sq;
+  float pv_deep[kDeepLevels];
+#pragma unroll
+  for (int k = 0; k < kDeepLevels; k++) {
+    const int j = kTopLevels + k;
+    pv_deep[k] = 0.0f;
+    if (j < L) pv_deep[k] = node_comp(tv.nodes, bl >> (L - j), j % 3);
+  }
 
-  // --- fetch the predicted path kChunk levels at a time (independent loads) and verify it with
-  //     the reference's own comparison (kdtree.go:202-221)
+  // --- verify the predicted path with the reference's own comparison (kdtree.go:202-221);
+  //     the LDS levels are checked while the fetches above are in flight
   uint32_t n = (uint32_t)tv.n;  // subtree size at the current level
   uint32_t n_m = n;             // ... at the first mismatch
   int m = L;                    // first level where the prediction fails (L: verified to the leaf)
-  uint32_t szmask = 0, pend = 0;
-#pragma unroll 1
-  for (int base = 0; base < kMaxLevels + 1; base += kChunk) {
-    if (__ballot(m == L && base < L) == 0ull) break;
-    float pv[kChunk];
-#pragma unroll
-    for (int k = 0; k < kChunk; k++) {
-      const int j = base + k;
-      pv[k] = 0.0f;
-      if (j < L && m == L) pv[k] = node_comp(tv.nodes, bl >> (L - j), k % 3);
-    }
-#pragma unroll
-    for (int k = 0; k < kChunk; k++) {
-      const int j = base + k;
-      if (j < L && m == L) {
-        const float qv = (k % 3 == 0) ? qx : ((k % 3 == 1) ? qy : qz);
-        const bool pred_left = ((bl >> (L - j - 1)) & 1u) == 0u;
-        const bool real_left = n == 2u || pv[k] > qv;
-        if (pred_left != real_left) {
-          m = j;
-          n_m = n;
-        } else {
-          const float fp = qv - pv[k];
-          if (!(fp * fp > bound0)) pend |= 1u << j;
-          szmask |= (n - ((np1 >> j) - 1u)) << j;
-          const uint32_t half = n >> 1;
-          n = pred_left ? half : n - half - 1u;
-        }
+  uint32_t szmask = 0;
+  uint32_t near = 0;            // levels whose plane is within maxRange (candidates for `pend`)
+  float fp2[1];                 // (placeholder to keep the two loops symmetrical)
+  (void)fp2;
+  // level j: returns false once the prediction has failed
+  auto check_level = [&](int j, float pv, float bound) {
+    if (j < L && m == L) {
+      const float qv = (j % 3 == 0) ? qx : ((j % 3 == 1) ? qy : qz);
+      const bool pred_left = ((bl >> (L - j - 1)) & 1u) == 0u;
+      const bool real_left = n == 2u || pv > qv;
+      if (pred_left != real_left) {
+        m = j;
+        n_m = n;
+      } else {
+        const float fp = qv - pv;
+        if (!(fp * fp > bound)) near |= 1u << j;
+        szmask |= (n - ((np1 >> j) - 1u)) << j;
+        const uint32_t half = n >> 1;
+        n = pred_left ? half : n - half - 1u;
       }
     }
+  };
+  // Bound for recording a level in `pend`: the best while the reference descends (= maxRange^2);
+  // tightened below by ub in exact mode (header, "Pruning bound").  The top levels are checked
+  // against maxRange^2 first and re-filtered once the leaf distance has arrived.
+  float top_fp2[kTopLevels];
+#pragma unroll
+  for (int j = 0; j < kTopLevels; j++) {
+    float pv = 0.0f;
+    if (j < L) pv = top[bl >> (L - j)];
+    const float qv = (j % 3 == 0) ? qx : ((j % 3 == 1) ? qy : qz);
+    const float fp = qv - pv;
+    top_fp2[j] = fp * fp;
+    check_level(j, pv, max_range_sq);
+  }
+  const float ldx = leaf.x - qx, ldy = leaf.y - qy, ldz = leaf.z - qz;
+  const float d_leaf = (ldx * ldx + ldy * ldy) + ldz * ldz;
+  const float bound0 = kExact ? fminf(max_range_sq, d_leaf) : max_range_sq;
+#pragma unroll
+  for (int k = 0; k < kDeepLevels; k++) check_level(kTopLevels + k, pv_deep[k], bound0);
+  if (kExact) {  // re-filter the top levels with the tighter bound
+#pragma unroll
+    for (int j = 0; j < kTopLevels; j++)
+      if (top_fp2[j] > bound0) near &= ~(1u << j);
   }
   const bool verified = m == L;
 
@@ -190,7 +219,7 @@ __device__ __forceinline__ Prepared prepare_query(const TreeView &tv, float qx, 
   p.bound_d = kExact ? fminf(p.best_d, d_leaf) : p.best_d;
   p.path_b = bl >> (L - m);
   p.n = finished ? 0x80000000u : (verified ? 0u : n_m);
-  p.pend = pend;
+  p.pend = near & ((m >= 32) ? 0xFFFFFFFFu : ((1u << m) - 1u));  // only levels above the mismatch
   p.szmask = szmask;
   return p;
 }
@@ -210,12 +239,14 @@ __device__ __forceinline__ void block_chunk_range(int64_t nq, uint32_t bid, uint
 
 // fetch(idx, qx, qy, qz): loads query idx.   emit(idx, best, best_d): consumes the result;
 // best = {x, y, z, bits(id)} of the matched base point, id < 0 = no match.
-// `queue`: this wave's LDS queue (kQueueWords * 64 words); `next_chunk`: the workgroup's LDS
-// chunk counter, initialised to the first chunk of its range [.., chunk_end).
+// `queue`: this wave's LDS queue (kQueueWords * 64 words); `top`: the workgroup's LDS copy of the
+// top split values (load_top_levels); `next_chunk`: the workgroup's LDS chunk counter,
+// initialised to the first chunk of its range [.., chunk_end).
 template <bool kMinDist, class Fetch, class Emit>
 __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__restrict__ stk,
                                              const int stk_stride, uint32_t *__restrict__ queue,
-                                             const int64_t nq, uint32_t *__restrict__ next_chunk,
+                                             const float *__restrict__ top, const int64_t nq,
+                                             uint32_t *__restrict__ next_chunk,
                                              const uint32_t chunk_end,
                                              const float max_range_sq, const float min_dist_sq,
                                              Fetch &&fetch, Emit &&emit) {
@@ -240,7 +271,7 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
     // is left to step): a lane that finished idles until then.
     const uint64_t idle = __ballot(!active);
     const int n_idle = __popcll(idle);
-    if (n_idle >= kRefillThreshold || n_idle == 64) {
+    if (n_idle >= tv.refill_threshold || n_idle == 64) {
       if (pending) {
         emit(my_q, best, best_d);
         pending = false;
@@ -263,7 +294,7 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
         if (lane < q_count) {
           float x, y, z;
           fetch(idx, x, y, z);
-          const Prepared p = prepare_query<kExact>(tv, x, y, z, max_range_sq, min_dist_sq);
+          const Prepared p = prepare_query<kExact>(tv, top, x, y, z, max_range_sq, min_dist_sq);
           queue[0 * 64 + lane] = __float_as_uint(p.qx);
           queue[1 * 64 + lane] = __float_as_uint(p.qy);
           queue[2 * 64 + lane] = __float_as_uint(p.qz);

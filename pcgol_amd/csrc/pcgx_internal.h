@@ -103,6 +103,7 @@ struct TreeView {
   int32_t dir_bits;  // g
   float dir_lo[3];
   float dir_scale[3];  // cells per metre (0 for a degenerate axis)
+  int32_t refill_threshold;  // walk kernels: emit + refill once this many lanes of a wave wait
 };
 
 // kdtree_build.cpp
@@ -117,15 +118,18 @@ inline int32_t tree_depth(int64_t n) {
 constexpr int kKnnBlock = 256;  // 4 waves
 constexpr int kWalkQueueBytesPerWave = 12 * 64 * 4;  // knn_walk.h kQueueWords
 // Dynamic LDS of a walk kernel block: frame stacks [(depth-1)][block] x 4 B (19 KB at 1M
-// points) followed by one prepared-query queue per wave (3 KB each).
+// points), one prepared-query queue per wave (3 KB each), the top split values (8 KB).
 inline size_t walk_stack_bytes(const TreeView &tv, int block) {
   int levels = tv.depth > 1 ? tv.depth - 1 : 1;
   return (size_t)levels * block * sizeof(uint32_t);
 }
+constexpr int kWalkTopBytes = 2048 * 4;  // knn_walk.h kTopEntries floats
 inline size_t walk_lds_bytes(const TreeView &tv, int block) {
-  return walk_stack_bytes(tv, block) + (size_t)(block / 64) * kWalkQueueBytesPerWave;
+  return walk_stack_bytes(tv, block) + (size_t)(block / 64) * kWalkQueueBytesPerWave + kWalkTopBytes;
 }
 int walk_blocks_per_cu(const TreeView &tv);
+int walk_refill_threshold();
+int walk_oversubscribe();
 pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *d_perm, int64_t nq,
                            float max_range_sq, float min_dist_sq, int32_t *d_ids, float *d_dsq,
                            hipStream_t st);
@@ -158,6 +162,7 @@ struct pcgx_kdtree {
     v.dir = d_dir;
     v.dir_bits = dir_bits;
     for (int k = 0; k < 3; k++) { v.dir_lo[k] = dir_lo[k]; v.dir_scale[k] = dir_scale[k]; }
+    v.refill_threshold = pcgx::walk_refill_threshold();
     return v;
   }
 };

@@ -151,9 +151,13 @@ def test_sharded_icp_rccl_single_rank():
     import torch
     import torch.distributed as dist
     from pcgol_amd.distributed import ShardedIcp
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29531")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
     try:
         c = synth.c4_icp(n=50000, width=3.7)
         t = kdtree.New(c["base"])
