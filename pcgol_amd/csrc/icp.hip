@@ -332,7 +332,7 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
     int32_t *perm = nullptr;
     if (nt > 1) {
       if ((rc = ar.alloc_n((size_t)nt, &perm)) != PCGX_OK) return bail(rc);
-      if ((rc = morton_order(d_q, nt, perm, st)) != PCGX_OK) return bail(rc);
+      if ((rc = morton_order(d_q, nt, base->bbox_lo, base->bbox_hi, perm, st)) != PCGX_OK) return bail(rc);
     }
     hipLaunchKernelGGL(gather_soa_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d_q, perm, nt,
                        s->d_xyz, s->d_xyz + nt, s->d_xyz + 2 * nt);

@@ -221,6 +221,7 @@ extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t st
         if (v < lo[k]) lo[k] = v;
         if (v > hi[k]) hi[k] = v;
       }
+    for (int k = 0; k < 3; k++) { t->bbox_lo[k] = lo[k]; t->bbox_hi[k] = hi[k]; }
     int g = 0;
     while (g < 9 && ((int64_t)1 << (3 * g)) < 2 * n) g++;
     if (const char *e = getenv("PCGX_DIR_BITS")) {  // tuning knob: cells per axis = 2^g
@@ -305,7 +306,7 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch_dev(const pcgx_kdtree *t, const
     PCGX_TRY(ctx().arena.begin(st));
     int32_t *perm = nullptr;
     PCGX_TRY(ctx().arena.alloc_n((size_t)nq, &perm));
-    PCGX_TRY(morton_order(d_q, nq, perm, st));
+    PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, perm, st));
     return launch_nearest(t->view(), d_q, perm, nq, max_range_sq, min_dist_sq, d_ids, d_dist_sq, st);
   }
   return launch_nearest(t->view(), d_q, nullptr, nq, max_range_sq, min_dist_sq, d_ids, d_dist_sq, st);

@@ -140,8 +140,10 @@ pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, in
                              void *workspace, int *result, hipStream_t st);
 pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
                           hipStream_t st);
-// perm[pos] = index of the point visited at position pos (Morton order).  Uses the arena.
-pcgx_status morton_order(const float *d_q, int64_t n, int32_t *d_perm, hipStream_t st);
+// perm[pos] = index of the point visited at position pos (coarse Morton order over the box
+// [lo, hi]).  Uses the arena.
+pcgx_status morton_order(const float *d_q, int64_t n, const float lo[3], const float hi[3], int32_t *d_perm,
+                         hipStream_t st);
 
 }  // namespace pcgx
 
@@ -152,6 +154,7 @@ struct pcgx_kdtree {
   uint32_t *d_dir = nullptr;       // [8^dir_bits] leaf directory
   int32_t dir_bits = 0;
   float dir_lo[3] = {0, 0, 0}, dir_scale[3] = {0, 0, 0};
+  float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // of the base cloud
   std::vector<int32_t> inorder;    // host copy of the in-order ids
   std::vector<float> points;       // host copy of xyz (accessor order), for Vec3At
   pcgx::TreeView view() const {

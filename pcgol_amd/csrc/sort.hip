@@ -366,49 +366,59 @@ __device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 10 bits -> every t
   return v;
 }
 
-__global__ __launch_bounds__(256) void morton_key_kernel(const float *__restrict__ q, int64_t n,
-                                                         const float *__restrict__ mm6, int bits_per_axis,
+struct MortonBox {
+  float lo[3];
+  float scale[3];  // cells per metre at `bits` bits per axis
+  int bits;
+};
+
+__global__ __launch_bounds__(256) void morton_key_kernel(const float *__restrict__ q, int64_t n, MortonBox box,
                                                          uint32_t *__restrict__ keys,
                                                          uint32_t *__restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float cells = (float)(1u << bits_per_axis);
+  const float cmax = (float)((1u << box.bits) - 1u);
   uint32_t c[3];
   for (int k = 0; k < 3; k++) {
-    const float lo = mm6[k], hi = mm6[3 + k];
-    const float ext = hi - lo;
-    float f = ext > 0.0f ? (q[3 * i + k] - lo) / ext * cells : 0.0f;
-    f = f < 0.0f ? 0.0f : f;  // NaN -> 0 through the second clamp
-    uint32_t ci = (uint32_t)fminf(f, cells - 1.0f);
-    c[k] = ci;
+    float f = (q[3 * i + k] - box.lo[k]) * box.scale[k];
+    f = fminf(fmaxf(f, 0.0f), cmax);  // points outside the box clamp to its faces; NaN -> 0
+    c[k] = (uint32_t)f;
   }
   keys[i] = spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
   vals[i] = (uint32_t)i;
 }
 
-constexpr int kMortonBitsPerAxis = 8;  // 24-bit keys: 3 radix passes
+// Queries only need to be ordered coarsely (lanes of a wave should walk neighbouring sub-trees):
+// 16-bit keys (2 radix passes) over the bounding box of the base cloud, which the tree already
+// knows -- no min/max pass over the queries.  Axis bits 6/5/5 (x gets the spare bit).
+constexpr int kMortonBitsPerAxis = 5;
 
 // perm[pos] = index of the query visited at position pos (a permutation of 0..n-1).
-pcgx_status morton_order(const float *d_q, int64_t n, int32_t *d_perm, hipStream_t st) {
+// lo/hi: box the keys are taken over (the base cloud's bounding box).
+pcgx_status morton_order(const float *d_q, int64_t n, const float lo[3], const float hi[3], int32_t *d_perm,
+                         hipStream_t st) {
   if (n > 0x7fffffffll) return fail(PCGX_E_INVALID, "morton_order: n too large");
   Arena &ar = ctx().arena;
   const size_t nb = (size_t)n * 4;
-  float *mm6 = nullptr;
   uint32_t *keys[2] = {nullptr, nullptr};
   uint32_t *vals[2] = {(uint32_t *)d_perm, nullptr};
   void *wsp = nullptr;
-  PCGX_TRY(ar.alloc_n(6, &mm6));
   PCGX_TRY(ar.alloc_n((size_t)n, &keys[0]));
   PCGX_TRY(ar.alloc_n((size_t)n, &keys[1]));
   PCGX_TRY(ar.alloc_n((size_t)n, &vals[1]));
   PCGX_TRY(ar.alloc(radix_sort_workspace_bytes(n), &wsp));
-  PCGX_TRY(launch_minmax(d_q, n, 12, 0, mm6, st));
-  hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_q, n, mm6,
-                     kMortonBitsPerAxis, keys[0], vals[0]);
+  MortonBox box;
+  box.bits = kMortonBitsPerAxis;
+  for (int k = 0; k < 3; k++) {
+    const float ext = hi[k] - lo[k];
+    box.lo[k] = lo[k] == lo[k] ? lo[k] : 0.0f;
+    box.scale[k] = (ext > 0.0f && ext < 3.0e38f) ? (float)(1u << box.bits) / ext : 0.0f;
+  }
+  hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_q, n, box, keys[0],
+                     vals[0]);
   int res = 0;
-  PCGX_TRY(radix_sort_pairs(keys, vals, n, 3 * kMortonBitsPerAxis, wsp, &res, st));
-  if (res != 0)
-    PCGX_HIP_TRY(hipMemcpyAsync(d_perm, vals[res], nb, hipMemcpyDeviceToDevice, st));
+  PCGX_TRY(radix_sort_pairs(keys, vals, n, 3 * kMortonBitsPerAxis + 1, wsp, &res, st));
+  if (res != 0) PCGX_HIP_TRY(hipMemcpyAsync(d_perm, vals[res], nb, hipMemcpyDeviceToDevice, st));
   return PCGX_OK;
 }
 

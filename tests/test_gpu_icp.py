@@ -152,6 +152,8 @@ def test_sharded_icp_rccl_single_rank():
     import torch.distributed as dist
     from pcgol_amd.distributed import ShardedIcp
     import socket
+    assert torch.cuda.is_available()
+    torch.cuda.set_device(0)  # the CUDA/HIP runtime must be up before ProcessGroupNCCL counts devices
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
