@@ -133,6 +133,14 @@ def lib():
         if not os.path.exists(SO):
             raise ImportError("pcgol_amd/libpcgx.so is missing: run `python -c 'import __graft_entry__ as g; "
                               "g.build()'` (hipcc, gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own HIP runtime (same soname as /opt/rocm's).  One process
+        # must use ONE runtime: when torch is installed, load it first so that libpcgx.so binds to
+        # the runtime torch (and RCCL) will use; loading libpcgx first was seen to make a later
+        # ProcessGroupNCCL report "no GPUs found".  Without torch the system runtime is used.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(SO)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
