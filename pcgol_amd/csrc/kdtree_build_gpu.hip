@@ -1,0 +1,159 @@
+// kdtree_build_gpu.hip -- device-side construction of the reference's KD-tree order.
+//
+// Reference: pc/storage/kdtree/kdtree.go:348-370 (newNode): at depth d the sub-slice of a
+// node is sorted ascending by coordinate d%3 (Less = strict <, :407-409), the element at
+// len/2 becomes the node and the halves recurse.  After the recursion the slice, read left
+// to right, is the in-order traversal of the tree (pcgx_internal.h).  Ties on the split
+// coordinate keep their current relative order (this library's definition, see
+// kdtree_build.cpp; Go's sort is unstable there).
+//
+// Level-synchronous form of the same recursion: before level d the array is cut into
+// "units" -- the sub-slices of the depth-d nodes, and single elements already fixed as the
+// node of a shallower level.  Level d is ONE stable sort of the whole array by the pair
+//     (unit start position, coordinate d%3 of the element)
+// which sorts every depth-d sub-slice by its coordinate, leaves every fixed element where
+// it is, and keeps ties in their current order.  The pair is sorted as two stable LSD radix
+// sorts (coordinate first, unit second) with the hand-written radix sort of sort.hip;
+// floats are mapped to order-preserving integers with -0.0 folded onto +0.0 (they compare
+// equal under <).  NaN coordinates have no consistent order under <; clouds containing
+// NaNs are built on the host instead.
+#include "pcgx_internal.h"
+
+namespace pcgx {
+
+// Start position of the unit that holds position p before level `depth` is sorted:
+// walk the implicit tree (node of [lo, lo+n) sits at lo + n/2).  If p is the node of a
+// level shallower than `depth` the unit is that single position.
+__device__ __forceinline__ uint32_t unit_start(uint32_t p, uint32_t n_total, int depth, bool &fixed) {
+  uint32_t lo = 0, n = n_total;
+  fixed = false;
+  for (int d = 0; d < depth; d++) {
+    const uint32_t half = n >> 1, mid = lo + half;
+    if (p == mid) {
+      fixed = true;
+      return p;
+    }
+    if (p < mid) {
+      n = half;
+    } else {
+      lo = mid + 1;
+      n = n - half - 1;
+    }
+  }
+  return lo;
+}
+
+__device__ __forceinline__ uint32_t ordered_bits(float v) {
+  v = v == 0.0f ? 0.0f : v;  // -0.0 and +0.0 are equal under <
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// keys[p] = ordered coordinate of the element at position p (0 for fixed elements), vals[p] = p
+__global__ __launch_bounds__(256) void kb_coord_key_kernel(const float *__restrict__ xyz,
+                                                           const uint32_t *__restrict__ order, uint32_t n,
+                                                           int depth, uint32_t *__restrict__ keys,
+                                                           uint32_t *__restrict__ vals) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= n) return;
+  bool fixed;
+  (void)unit_start(p, n, depth, fixed);
+  keys[p] = fixed ? 0u : ordered_bits(xyz[3 * (size_t)order[p] + depth % 3]);
+  vals[p] = p;
+}
+
+// keys[j] = unit start of the ORIGINAL position vals[j] (the element sorted to slot j)
+__global__ __launch_bounds__(256) void kb_unit_key_kernel(const uint32_t *__restrict__ vals, uint32_t n, int depth,
+                                                          uint32_t *__restrict__ keys) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= n) return;
+  bool fixed;
+  keys[j] = unit_start(vals[j], n, depth, fixed);
+}
+
+__global__ __launch_bounds__(256) void kb_permute_kernel(const uint32_t *__restrict__ order,
+                                                         const uint32_t *__restrict__ vals, uint32_t n,
+                                                         uint32_t *__restrict__ order_out) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j < n) order_out[j] = order[vals[j]];
+}
+
+__global__ __launch_bounds__(256) void kb_iota_kernel(uint32_t *__restrict__ a, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) a[i] = i;
+}
+
+// nodes[b] = {x, y, z, bits(id)} of the point at the in-order position of BFS slot b
+__global__ __launch_bounds__(256) void kb_fill_bfs_kernel(const float *__restrict__ xyz,
+                                                          const uint32_t *__restrict__ order, uint32_t n_total,
+                                                          uint32_t slots, float4 *__restrict__ nodes) {
+  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  if (b >= slots) return;
+  float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (b >= 1u) {
+    const int depth = 31 - __clz((int)b);
+    uint32_t lo = 0, n = n_total;
+    bool exists = true;
+    for (int d = depth - 1; d >= 0 && exists; d--) {  // follow b's bits from the root
+      const uint32_t half = n >> 1;
+      if ((b >> d) & 1u) {
+        lo = lo + half + 1;
+        n = n - half - 1;
+      } else {
+        n = half;
+      }
+      exists = n > 0u && n <= n_total;
+    }
+    if (exists && n > 0u) {
+      const uint32_t id = order[lo + (n >> 1)];
+      out = make_float4(xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2], __uint_as_float(id));
+    }
+  }
+  nodes[b] = out;
+}
+
+// d_xyz: packed xyz of the base cloud on the device; d_order (out): in-order point ids;
+// d_nodes (out): BFS slots.  Uses the arena (caller has begun it).
+pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint32_t *d_order, float4 *d_nodes,
+                              hipStream_t st) {
+  Arena &ar = ctx().arena;
+  const uint32_t un = (uint32_t)n;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *order_tmp = nullptr;
+  void *ws = nullptr;
+  PCGX_TRY(ar.alloc_n((size_t)n, &keys[0]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &keys[1]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &vals[0]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &vals[1]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &order_tmp));
+  PCGX_TRY(ar.alloc(radix_sort_workspace_bytes(n), &ws));
+  int pos_bits = 0;
+  while (pos_bits < 31 && ((int64_t)1 << pos_bits) < n) pos_bits++;
+  uint32_t *cur = d_order, *nxt = order_tmp;
+  hipLaunchKernelGGL(kb_iota_kernel, dim3(nb), dim3(256), 0, st, cur, un);
+  // levels 0 .. depth-2 have sub-slices longer than one element
+  for (int d = 0; d + 1 < depth; d++) {
+    hipLaunchKernelGGL(kb_coord_key_kernel, dim3(nb), dim3(256), 0, st, d_xyz, cur, un, d, keys[0], vals[0]);
+    int r1 = 0;
+    PCGX_TRY(radix_sort_pairs(keys, vals, n, 32, ws, &r1, st));
+    // second (stable) sort by unit start; its input values are vals[r1]
+    uint32_t *k2[2] = {keys[r1 ^ 1], keys[r1]};
+    uint32_t *v2[2] = {vals[r1], vals[r1 ^ 1]};
+    hipLaunchKernelGGL(kb_unit_key_kernel, dim3(nb), dim3(256), 0, st, v2[0], un, d, k2[0]);
+    int r2 = 0;
+    PCGX_TRY(radix_sort_pairs(k2, v2, n, pos_bits, ws, &r2, st));
+    hipLaunchKernelGGL(kb_permute_kernel, dim3(nb), dim3(256), 0, st, cur, v2[r2], un, nxt);
+    uint32_t *t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  if (cur != d_order)
+    PCGX_HIP_TRY(hipMemcpyAsync(d_order, cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+  const uint32_t slots = 1u << depth;
+  hipLaunchKernelGGL(kb_fill_bfs_kernel, dim3((slots + 255) / 256), dim3(256), 0, st, d_xyz, d_order, un, slots,
+                     d_nodes);
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
+}  // namespace pcgx

@@ -196,20 +196,54 @@ extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t st
   const uint8_t *src = (const uint8_t *)data;
   for (int64_t i = 0; i < n; i++) memcpy(&t->points[3 * i], src + i * (int64_t)stride + xyz_off, 12);
   t->inorder.resize((size_t)n);
-  build_inorder(t->points.data(), n, t->inorder.data());
   const size_t slots = (size_t)1 << t->depth;
-  std::vector<float4> nodes(slots, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-  fill_bfs(*t, nodes, 1, 0, n);
   hipError_t e = hipMalloc((void **)&t->d_nodes, slots * sizeof(float4));
   if (e != hipSuccess) {
     delete t;
     return fail(PCGX_E_OOM, "hipMalloc for %lld tree nodes failed: %s", (long long)n, hipGetErrorString(e));
   }
-  e = hipMemcpy(t->d_nodes, nodes.data(), slots * sizeof(float4), hipMemcpyHostToDevice);
-  if (e != hipSuccess) {
-    (void)hipFree(t->d_nodes);
-    delete t;
-    return fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
+  // Build on the device for large clouds; NaN coordinates (no consistent order under <) and
+  // small clouds take the host build.  PCGX_BUILD=host|gpu forces one (tests).
+  bool has_nan = false;
+  for (size_t i = 0; i < (size_t)n * 3 && !has_nan; i++) has_nan = t->points[i] != t->points[i];
+  bool on_gpu = n >= 32768 && !has_nan;
+  if (const char *f = getenv("PCGX_BUILD")) {
+    if (!strcmp(f, "host")) on_gpu = false;
+    if (!strcmp(f, "gpu") && !has_nan && n >= 2) on_gpu = true;
+  }
+  if (on_gpu) {
+    hipStream_t st = ctx().stream;
+    Arena &ar = ctx().arena;
+    pcgx_status rc = ar.begin(st);
+    float *d_xyz = nullptr;
+    uint32_t *d_order = nullptr;
+    if (rc == PCGX_OK) rc = ar.alloc_n((size_t)n * 3, &d_xyz);
+    if (rc == PCGX_OK) rc = ar.alloc_n((size_t)n, &d_order);
+    if (rc == PCGX_OK) {
+      e = hipMemcpyAsync(d_xyz, t->points.data(), (size_t)n * 12, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) rc = fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
+    }
+    if (rc == PCGX_OK) rc = build_tree_device(d_xyz, n, t->depth, d_order, t->d_nodes, st);
+    if (rc == PCGX_OK) {
+      e = hipMemcpyAsync(t->inorder.data(), d_order, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) rc = fail(PCGX_E_HIP, "tree build failed: %s", hipGetErrorString(e));
+    }
+    if (rc != PCGX_OK) {
+      (void)hipFree(t->d_nodes);
+      delete t;
+      return rc;
+    }
+  } else {
+    build_inorder(t->points.data(), n, t->inorder.data());
+    std::vector<float4> nodes(slots, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    fill_bfs(*t, nodes, 1, 0, n);
+    e = hipMemcpy(t->d_nodes, nodes.data(), slots * sizeof(float4), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(t->d_nodes);
+      delete t;
+      return fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
+    }
   }
   // leaf directory: ~2 cells per point, at most 2^27 cells
   {

@@ -114,6 +114,10 @@ inline int32_t tree_depth(int64_t n) {
   return d;
 }
 
+// kdtree_build_gpu.hip: in-order ids (d_order) and BFS slots (d_nodes) from packed device xyz
+pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint32_t *d_order, float4 *d_nodes,
+                              hipStream_t st);
+
 // knn.hip
 constexpr int kKnnBlock = 256;  // 4 waves
 constexpr int kWalkQueueBytesPerWave = 12 * 64 * 4;  // knn_walk.h kQueueWords
