@@ -163,7 +163,8 @@ def main():
     tree = kdtree.New(base)
     build_s = time.perf_counter() - t0
 
-    stream = torch.cuda.current_stream().cuda_stream
+    side_stream = torch.cuda.Stream()  # a real (non-zero) stream handle for the side benchmarks
+    stream = side_stream.cuda_stream
     from pcgol_amd.distributed import ShardedIcp
     sicp = ShardedIcp(tree, tile, cfg["max_dist"], cfg["min_pairs"], cfg["weight"], cfg["threshold"],
                       cfg["max_iteration"])

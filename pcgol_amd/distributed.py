@@ -94,7 +94,13 @@ class ShardedIcp:
         import torch
         self.torch = torch
         self.group = group
+        # A stream of our own: the kernels are launched on it through the C ABI and the
+        # all-reduce is issued while it is torch's current stream, so RCCL orders itself after
+        # the partial sums and the update kernel after RCCL.  (torch's default stream has
+        # handle 0, which the C ABI reads as "use the library's stream": never use it here.)
+        self.stream = torch.cuda.Stream()
         self.sums = torch.zeros(10, dtype=torch.float64, device="cuda")
+        torch.cuda.current_stream().synchronize()
         self.sess = _icp.IcpSession(base_tree, target_tile, MaxDist, MinPairs, Weight, Threshold, MaxIteration,
                                     d_sums10=self.sums.data_ptr())
         self.max_iteration = self.sess.max_iteration
@@ -104,17 +110,18 @@ class ShardedIcp:
         self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
 
     def step(self):
-        """One ICP iteration, enqueued on torch's current stream."""
-        st = self.torch.cuda.current_stream().cuda_stream
+        """One ICP iteration, enqueued on self.stream."""
+        st = self.stream.cuda_stream
         if not self.exchange:
             self.sess.step(st)  # reduce + update fused: no exchange needed
             return
-        self.sess.partials(st)
-        self.torch.distributed.all_reduce(self.sums, group=self.group)
-        self.sess.update(st)
+        with self.torch.cuda.stream(self.stream):
+            self.sess.partials(st)
+            self.torch.distributed.all_reduce(self.sums, group=self.group)
+            self.sess.update(st)
 
     def reset(self):
-        self.sess.reset(self.torch.cuda.current_stream().cuda_stream)
+        self.sess.reset(self.stream.cuda_stream)
 
     def fit(self):
         self.reset()
@@ -123,7 +130,7 @@ class ShardedIcp:
         return self.result()
 
     def result(self):
-        return self.sess.result(self.torch.cuda.current_stream().cuda_stream)
+        return self.sess.result(self.stream.cuda_stream)
 
     def close(self):
         self.sess.close()
