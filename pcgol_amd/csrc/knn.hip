@@ -13,12 +13,13 @@ namespace pcgx {
 // Queries are packed xyz (AoS, 12 B).  `perm` (optional) maps the launch position to
 // the query index (Morton order, sort.hip): results are written at the original
 // index, so the permutation is invisible to the caller.
-template <bool kMinDist>
+template <bool kMinDist, bool kStats = false>
 __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const float *__restrict__ q,
                                                             const int32_t *__restrict__ perm,
                                                             int64_t nq, float max_range_sq, float min_dist_sq,
                                                             int32_t *__restrict__ out_id,
-                                                            float *__restrict__ out_dsq) {
+                                                            float *__restrict__ out_dsq,
+                                                            unsigned long long *__restrict__ stats = nullptr) {
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
   uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kKnnBlock +
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
   block_chunk_range(nq, blockIdx.x, gridDim.x, chunk_begin, chunk_end);
   if (threadIdx.x == 0) s_next_chunk = chunk_begin;
   __syncthreads();
-  walk_queries<kMinDist>(
+  walk_queries<kMinDist, kStats>(
       tv, s_stack + threadIdx.x, kKnnBlock, queue, top, nq, &s_next_chunk, chunk_end, max_range_sq, min_dist_sq,
       [&](int64_t pos, float &x, float &y, float &z) {
         const int64_t i = perm ? (int64_t)perm[pos] : pos;
@@ -42,7 +43,8 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
         const int64_t i = perm ? (int64_t)perm[pos] : pos;
         out_id[i] = __float_as_int(best.w);
         out_dsq[i] = best_d;
-      });
+      },
+      stats);
 }
 
 // Leaf directory: one thread per grid cell descends from the root with the cell's centre
@@ -364,5 +366,38 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const flo
   PCGX_HIP_TRY(hipMemcpyAsync(dist_sq, b.dsq, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
   for (int64_t i = 0; i < nq; i++) ids[i] = h_id[i];
+  return PCGX_OK;
+}
+
+// Debug / profiling aid: runs the instrumented exact-mode walk over device queries and returns
+// its 8 counters (knn_walk.h).  Not part of the drop-in surface.
+extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
+                                             int32_t presort, uint64_t stats8[8]) {
+  if (!t || !d_q || !stats8 || nq <= 0) return fail(PCGX_E_INVALID, "pcgx_debug_walk_stats: bad argument");
+  PCGX_TRY(ensure_init());
+  hipStream_t st = ctx().stream;
+  Arena &ar = ctx().arena;
+  PCGX_TRY(ar.begin(st));
+  unsigned long long *d_stats = nullptr;
+  int32_t *d_ids = nullptr, *perm = nullptr;
+  float *d_dsq = nullptr;
+  PCGX_TRY(ar.alloc_n(8, &d_stats));
+  PCGX_TRY(ar.alloc_n((size_t)nq, &d_ids));
+  PCGX_TRY(ar.alloc_n((size_t)nq, &d_dsq));
+  if (presort) {
+    PCGX_TRY(ar.alloc_n((size_t)nq, &perm));
+    PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, perm, st));
+  }
+  PCGX_HIP_TRY(hipMemsetAsync(d_stats, 0, 8 * sizeof(unsigned long long), st));
+  const TreeView tv = t->view();
+  int64_t blocks = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv);
+  const int64_t max_blocks = (nq + kKnnBlock - 1) / kKnnBlock;
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks >= 8) blocks &= ~(int64_t)7;
+  hipLaunchKernelGGL((nearest_kernel<false, true>), dim3((unsigned)blocks), dim3(kKnnBlock), walk_lds_bytes(tv, kKnnBlock),
+                     st, tv, d_q, perm, nq, max_range * max_range, 0.0f, d_ids, d_dsq, d_stats);
+  PCGX_HIP_TRY(hipGetLastError());
+  PCGX_HIP_TRY(hipMemcpyAsync(stats8, d_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
   return PCGX_OK;
 }

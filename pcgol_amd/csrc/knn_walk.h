@@ -242,15 +242,22 @@ __device__ __forceinline__ void block_chunk_range(int64_t nq, uint32_t bid, uint
 // `queue`: this wave's LDS queue (kQueueWords * 64 words); `top`: the workgroup's LDS copy of the
 // top split values (load_top_levels); `next_chunk`: the workgroup's LDS chunk counter,
 // initialised to the first chunk of its range [.., chunk_end).
-template <bool kMinDist, class Fetch, class Emit>
+// Optional instrumentation (kStats): per-wave counts accumulated into stats[] with atomics:
+// [0] loop iterations, [1] active lanes summed over iterations, [2] node fetches (lanes),
+// [3] emit/refill sections run, [4] chunks prepared, [5] queries that verified down to the leaf,
+// [6] first-descent levels recorded in pend, [7] queries.
+template <bool kMinDist, bool kStats = false, class Fetch, class Emit>
 __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__restrict__ stk,
                                              const int stk_stride, uint32_t *__restrict__ queue,
                                              const float *__restrict__ top, const int64_t nq,
                                              uint32_t *__restrict__ next_chunk,
                                              const uint32_t chunk_end,
                                              const float max_range_sq, const float min_dist_sq,
-                                             Fetch &&fetch, Emit &&emit) {
+                                             Fetch &&fetch, Emit &&emit,
+                                             unsigned long long *__restrict__ stats = nullptr) {
   constexpr bool kExact = !kMinDist;
+  unsigned long long st_iter = 0, st_active = 0, st_look = 0, st_refill = 0, st_prep = 0, st_verified = 0,
+                     st_pend = 0, st_queries = 0;
   const int lane = (int)(threadIdx.x & 63u);
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const uint32_t np1 = (uint32_t)tv.n + 1u;
@@ -271,7 +278,12 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
     // is left to step): a lane that finished idles until then.
     const uint64_t idle = __ballot(!active);
     const int n_idle = __popcll(idle);
+    if (kStats) {
+      st_iter += 1;
+      st_active += (unsigned long long)(64 - n_idle);
+    }
     if (n_idle >= tv.refill_threshold || n_idle == 64) {
+      if (kStats) st_refill += 1;
       if (pending) {
         emit(my_q, best, best_d);
         pending = false;
@@ -290,11 +302,17 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
           q_count = left >= 64 ? 64 : (int32_t)left;
         }
         exhausted = c + 1u >= chunk_end;
+        if (kStats) st_prep += 1;
         const int64_t idx = q_base + lane;
         if (lane < q_count) {
           float x, y, z;
           fetch(idx, x, y, z);
           const Prepared p = prepare_query<kExact>(tv, top, x, y, z, max_range_sq, min_dist_sq);
+          if (kStats) {
+            st_queries += 1;
+            st_verified += p.n == 0u;
+            st_pend += (unsigned long long)__popc(p.pend);
+          }
           queue[0 * 64 + lane] = __float_as_uint(p.qx);
           queue[1 * 64 + lane] = __float_as_uint(p.qy);
           queue[2 * 64 + lane] = __float_as_uint(p.qz);
@@ -363,6 +381,7 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
     // ---- the one node fetch of this step -----------------------------------------
     const uint32_t at = desc ? b : fb;
     const bool look = active && (desc || has_exp || implicit);
+    if (kStats) st_look += look;
     if (look) {
       const float4 nd = node_at(tv.nodes, at);
       const float dx = nd.x - qx, dy = nd.y - qy, dz = nd.z - qz;  // pivot.Sub(p)
@@ -411,6 +430,25 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
     if (finish) {
       active = false;
       pending = true;
+    }
+  }
+  if (kStats && stats) {
+    // per-lane counters: sum over the wave; wave-uniform ones are taken from lane 0
+    for (int o = 32; o > 0; o >>= 1) {
+      st_look += __shfl_down(st_look, o);
+      st_verified += __shfl_down(st_verified, o);
+      st_pend += __shfl_down(st_pend, o);
+      st_queries += __shfl_down(st_queries, o);
+    }
+    if (lane == 0) {
+      atomicAdd(stats + 0, st_iter);
+      atomicAdd(stats + 1, st_active);
+      atomicAdd(stats + 2, st_look);
+      atomicAdd(stats + 3, st_refill);
+      atomicAdd(stats + 4, st_prep);
+      atomicAdd(stats + 5, st_verified);
+      atomicAdd(stats + 6, st_pend);
+      atomicAdd(stats + 7, st_queries);
     }
   }
 }

@@ -1,0 +1,21 @@
+"""Counters of the instrumented walk: python tools/walk_stats.py {c2|c4} [presort]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from pcgol_amd import synth, kdtree, _lib as L
+which = sys.argv[1] if len(sys.argv) > 1 else "c4"
+presort = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+L.check(L.lib().pcgx_init(0))
+if which == "c2":
+    c = synth.c2_knn(); base, q, mr = c["base"], c["queries"], 10.0
+else:
+    c = synth.c4_icp(); base, q, mr = c["base"], c["target"], 0.5
+t = kdtree.New(base)
+dq = torch.from_numpy(q).cuda()
+st = np.zeros(8, np.uint64)
+L.check(L.lib().pcgx_debug_walk_stats(t._h, L.ptr(dq.data_ptr()), len(q), mr, presort, L.ptr(st)))
+it, act, look, refill, prep, ver, pend, nq = [int(x) for x in st]
+print("%s presort=%d: queries %d, iterations(wave) %d = %.3f/query, active lane-steps %.2f/query (util %.1f%%), "
+      "node fetches %.2f/query, refill sections %d, chunks %d, verified %.1f%%, pend levels %.2f/query" %
+      (which, presort, nq, it, it / nq, act / nq, 100.0 * act / (64.0 * it), look / nq, refill, prep,
+       100.0 * ver / nq, pend / nq))
