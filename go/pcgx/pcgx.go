@@ -156,9 +156,49 @@ func (k *KDTree) Nearest(p mat.Vec3, maxRange float32) storage.Neighbor {
 	return r[0]
 }
 
-// Range is not on the GPU path yet (SURVEY.md 8(f) N2).
+// RangeBatch: neighbours with DistSq < maxRange^2 of every query, each list sorted by DistSq
+// (KDTree.Range, kdtree.go:148-161).  out[i] belongs to q[i].
+func (k *KDTree) RangeBatch(q []mat.Vec3, maxRange float32) ([][]storage.Neighbor, error) {
+	n := len(q)
+	out := make([][]storage.Neighbor, n)
+	if n == 0 {
+		return out, nil
+	}
+	counts := make([]int64, n)
+	qp := (*C.float)(unsafe.Pointer(&q[0]))
+	if err := status(C.pcgx_kdtree_range_count(k.h, qp, C.int64_t(n), C.float(maxRange),
+		(*C.int64_t)(unsafe.Pointer(&counts[0])))); err != nil {
+		return nil, err
+	}
+	offs := make([]int64, n+1)
+	for i, c := range counts {
+		offs[i+1] = offs[i] + c
+	}
+	total := offs[n]
+	ids := make([]int64, total+1)
+	dsq := make([]float32, total+1)
+	if err := status(C.pcgx_kdtree_range_fill(k.h, qp, C.int64_t(n), C.float(maxRange),
+		(*C.int64_t)(unsafe.Pointer(&offs[0])), (*C.int64_t)(unsafe.Pointer(&ids[0])),
+		(*C.float)(unsafe.Pointer(&dsq[0])))); err != nil {
+		return nil, err
+	}
+	for i := range out {
+		nb := make([]storage.Neighbor, counts[i])
+		for j := range nb {
+			nb[j] = storage.Neighbor{ID: int(ids[offs[i]+int64(j)]), DistSq: dsq[offs[i]+int64(j)]}
+		}
+		out[i] = nb
+	}
+	return out, nil
+}
+
+// Range keeps storage.Search working for single points.
 func (k *KDTree) Range(p mat.Vec3, maxRange float32) []storage.Neighbor {
-	panic("pcgx: KDTree.Range is not implemented on the GPU path (use pc/storage/kdtree)")
+	r, err := k.RangeBatch([]mat.Vec3{p}, maxRange)
+	if err != nil {
+		panic(err)
+	}
+	return r[0]
 }
 
 // -------------------------------------------------------------- VoxelGrid

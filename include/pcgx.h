@@ -123,6 +123,18 @@ PCGX_API pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const float
                                                float max_range, float min_dist_sq,
                                                int64_t *ids /* [nq] */, float *dist_sq /* [nq] */);
 
+/* Batched KDTree.Range (kdtree.go:148-197): all points with DistSq < max_range^2, per query
+ * sorted by DistSq (ties: discovery order of the reference walk; Go's sort leaves them
+ * unspecified).  The result length is data dependent, hence two calls:
+ *   count: counts[i] = number of neighbours of q[i];
+ *   fill:  offsets[0..nq] = exclusive prefix sum of the counts (offsets[nq] = total); query i's
+ *          neighbours are written to ids / dist_sq [offsets[i], offsets[i+1]). */
+PCGX_API pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float *q, int64_t nq,
+                                             float max_range, int64_t *counts /* [nq] */);
+PCGX_API pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float *q, int64_t nq,
+                                            float max_range, const int64_t *offsets /* [nq+1] */,
+                                            int64_t *ids, float *dist_sq);
+
 #define PCGX_KNN_PRESORT 1u /* Morton-order the queries inside the call (results are
                                returned in the caller's order either way) */
 /* Same, device resident: d_q packed xyz [3*nq], d_ids int32 [nq], d_dist_sq [nq]. */

@@ -101,6 +101,8 @@ SIGNATURES = {
     "pcgx_kdtree_inorder": (_i32, [_vp, _vp]),
     "pcgx_kdtree_points": (_i32, [_vp, _vp, _i64, _vp]),
     "pcgx_kdtree_nearest_batch": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp, _vp]),
+    "pcgx_kdtree_range_count": (_i32, [_vp, _vp, _i64, _f32, _vp]),
+    "pcgx_kdtree_range_fill": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "pcgx_kdtree_nearest_batch_dev": (_i32, [_vp, _vp, _i64, _f32, _f32, _u32, _vp, _vp, _vp]),
     "pcgx_minmax": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "pcgx_voxel_filter": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i64)]),

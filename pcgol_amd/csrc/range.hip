@@ -1,0 +1,222 @@
+// range.hip -- batched KDTree.Range (radius search) on gfx950.
+//
+// Reference: pc/storage/kdtree/kdtree.go:148-197 (Range / rangeImpl) + :415-427
+// (neighborSorter).  rangeImpl is the same in-order walk as nearestImpl with a FIXED bound:
+//   leaf:   append if dsq < maxRange^2                                   (:166-169)
+//   unwind: skip the pivot and the far side if fp*fp > maxRange^2        (:173-177)
+//           append the pivot if dsq < maxRange^2                         (:178-181)
+//           recurse into the other child                                 (:182-195)
+// then the neighbours are sorted by DistSq (:159).  Go's sort is unstable, so the order of
+// equal DistSq is unspecified in the reference; here (and in the oracle) ties keep the
+// discovery order of the walk.
+//
+// Two entry points because the result length is data dependent: pcgx_kdtree_range_count
+// (walk, count) and pcgx_kdtree_range_fill (walk again, write at the caller's offsets, then
+// one stable sort of the whole batch by (query, DistSq) with the radix sort of sort.hip).
+// One query per lane; 4-byte frames [level][thread] in LDS as in knn_walk.h.
+#include <string.h>
+
+#include <vector>
+
+#include "knn_walk.h"
+
+namespace pcgx {
+
+constexpr int kRangeBlock = 256;
+
+// kFill == false: counts[i] = number of neighbours.  kFill == true: neighbours of query i are
+// written from offsets[i] in discovery order: {point id, DistSq bits, query index}.
+template <bool kFill>
+__global__ __launch_bounds__(kRangeBlock) void range_kernel(TreeView tv, const float *__restrict__ q, int64_t nq,
+                                                            float bound, int64_t *__restrict__ counts,
+                                                            const int64_t *__restrict__ offsets, int64_t total,
+                                                            int32_t *__restrict__ out_id,
+                                                            uint32_t *__restrict__ out_key,
+                                                            uint32_t *__restrict__ out_query) {
+  extern __shared__ uint32_t s_stack[];
+  const int64_t i = (int64_t)blockIdx.x * kRangeBlock + threadIdx.x;
+  if (i >= nq) return;
+  uint32_t *stk = s_stack + threadIdx.x;
+  const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
+  const uint32_t np1 = (uint32_t)tv.n + 1u;
+  int64_t found = 0;
+  // never write outside the slice the caller's offsets give this query (they may be wrong)
+  const int64_t out0 = kFill ? offsets[i] : 0;
+  const int64_t cap = kFill ? offsets[i + 1] - out0 : 0;
+  const bool slice_ok = kFill && out0 >= 0 && cap >= 0 && out0 + cap <= total;
+  uint32_t b = 1;
+  int32_t n = tv.n, sp = 0;
+  bool desc = true;
+  // every iteration fetches one node; a walk touches a node at most twice
+  for (int64_t guard = 2 * (int64_t)tv.n + 2; guard > 0; --guard) {
+    uint32_t at = b, fw = 0;
+    if (!desc) {
+      if (sp == 0) break;
+      fw = stk[(--sp) * kRangeBlock];
+      at = fw & 0x07FFFFFFu;
+    }
+    const float4 nd = node_at(tv.nodes, at);
+    const float dx = nd.x - qx, dy = nd.y - qy, dz = nd.z - qz;
+    const float d = (dx * dx + dy * dy) + dz * dz;
+    const int32_t depth = 31 - __clz((int)at);
+    const int dim = depth % 3;
+    const float pv = sel3(dim, nd.x, nd.y, nd.z), qv = sel3(dim, qx, qy, qz);
+    const float fp = qv - pv;
+    const bool plane_ok = !(fp * fp > bound);
+    bool hit;
+    if (desc) {
+      if (n == 1) {  // leaf
+        hit = d < bound;
+        desc = false;
+      } else {  // searchLeafNode step (kdtree.go:202-221); a frame that cannot pass is not pushed
+        hit = false;
+        const int32_t half = n >> 1;
+        const bool go_left = n == 2 || pv > qv;
+        if (plane_ok) {
+          const uint32_t size_bit = (uint32_t)n - ((np1 >> depth) - 1u);
+          stk[(sp++) * kRangeBlock] = b | (go_left ? (1u << 27) : 0u) | (size_bit << 31);
+        }
+        b = 2u * b + (go_left ? 0u : 1u);
+        n = go_left ? half : n - half - 1;
+      }
+    } else {  // a popped frame always passes its plane test (the bound is fixed)
+      hit = d < bound;
+      const int32_t fn = (int32_t)((np1 >> depth) - 1u + (fw >> 31));
+      if (fn != 2) {  // the other child (kdtree.go:182-195)
+        const bool went_left = ((fw >> 27) & 1u) != 0u;
+        const int32_t half = fn >> 1;
+        b = 2u * at + (went_left ? 1u : 0u);
+        n = went_left ? fn - half - 1 : half;
+        desc = true;
+      }
+    }
+    if (hit) {
+      if (kFill && slice_ok && found < cap) {
+        out_id[out0 + found] = __float_as_int(nd.w);
+        out_key[out0 + found] = __float_as_uint(d);  // d >= 0: the bit pattern orders like the value
+        out_query[out0 + found] = (uint32_t)i;
+      }
+      ++found;
+    }
+  }
+  if (!kFill) counts[i] = found;
+}
+
+__global__ __launch_bounds__(256) void range_iota_kernel(uint32_t *__restrict__ a, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) a[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void range_gather_u32_kernel(const uint32_t *__restrict__ src,
+                                                               const uint32_t *__restrict__ index, int64_t n,
+                                                               uint32_t *__restrict__ dst) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) dst[j] = src[index[j]];
+}
+
+}  // namespace pcgx
+
+using namespace pcgx;
+
+namespace {
+struct DevMem {  // host-pointer call staging (plain hipMalloc; these calls are PCIe bound anyway)
+  void *p = nullptr;
+  ~DevMem() { if (p) (void)hipFree(p); }
+  pcgx_status alloc(size_t bytes) {
+    PCGX_HIP_TRY(hipMalloc(&p, bytes ? bytes : 1));
+    return PCGX_OK;
+  }
+};
+}  // namespace
+
+extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float *q, int64_t nq, float max_range,
+                                               int64_t *counts) {
+  if (!t || nq < 0 || (nq > 0 && (!q || !counts))) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_count: bad argument");
+  if (nq == 0) return PCGX_OK;
+  PCGX_TRY(ensure_init());
+  hipStream_t st = ctx().stream;
+  DevMem dq, dc;
+  PCGX_TRY(dq.alloc((size_t)nq * 12));
+  PCGX_TRY(dc.alloc((size_t)nq * 8));
+  PCGX_HIP_TRY(hipMemcpyAsync(dq.p, q, (size_t)nq * 12, hipMemcpyHostToDevice, st));
+  const TreeView tv = t->view();
+  const size_t lds = walk_stack_bytes(tv, kRangeBlock);
+  hipLaunchKernelGGL(range_kernel<false>, dim3((unsigned)((nq + kRangeBlock - 1) / kRangeBlock)), dim3(kRangeBlock), lds,
+                     st, tv, (const float *)dq.p, nq, max_range * max_range, (int64_t *)dc.p, nullptr, 0, nullptr, nullptr,
+                     nullptr);
+  PCGX_HIP_TRY(hipGetLastError());
+  PCGX_HIP_TRY(hipMemcpyAsync(counts, dc.p, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float *q, int64_t nq, float max_range,
+                                              const int64_t *offsets, int64_t *ids, float *dist_sq) {
+  if (!t || nq < 0 || (nq > 0 && (!q || !offsets))) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: bad argument");
+  if (nq == 0) return PCGX_OK;
+  const int64_t total = offsets[nq];
+  if (total < 0 || offsets[0] != 0) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: offsets must start at 0");
+  if (total == 0) return PCGX_OK;
+  if (!ids || !dist_sq) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: NULL output");
+  if (total > 0x7fffffffll) return fail(PCGX_E_TOO_LARGE, "pcgx_kdtree_range_fill: more than 2^31-1 neighbours in one batch");
+  PCGX_TRY(ensure_init());
+  hipStream_t st = ctx().stream;
+  Arena &ar = ctx().arena;
+  PCGX_TRY(ar.begin(st));
+  float *d_q = nullptr;
+  int64_t *d_off = nullptr;
+  int32_t *d_id = nullptr;
+  uint32_t *keys[2] = {nullptr, nullptr}, *vals[2] = {nullptr, nullptr}, *d_query = nullptr, *d_key = nullptr,
+           *d_out_id = nullptr, *d_out_key = nullptr;
+  void *ws = nullptr;
+  PCGX_TRY(ar.alloc_n((size_t)nq * 3, &d_q));
+  PCGX_TRY(ar.alloc_n((size_t)nq + 1, &d_off));
+  PCGX_TRY(ar.alloc_n((size_t)total, &d_id));
+  PCGX_TRY(ar.alloc_n((size_t)total, &d_key));
+  PCGX_TRY(ar.alloc_n((size_t)total, &d_query));
+  PCGX_TRY(ar.alloc_n((size_t)total, &keys[0]));
+  PCGX_TRY(ar.alloc_n((size_t)total, &keys[1]));
+  PCGX_TRY(ar.alloc_n((size_t)total, &vals[0]));
+  PCGX_TRY(ar.alloc_n((size_t)total, &vals[1]));
+  PCGX_TRY(ar.alloc_n((size_t)total, &d_out_id));
+  PCGX_TRY(ar.alloc_n((size_t)total, &d_out_key));
+  PCGX_TRY(ar.alloc(radix_sort_workspace_bytes(total), &ws));
+  PCGX_HIP_TRY(hipMemcpyAsync(d_q, q, (size_t)nq * 12, hipMemcpyHostToDevice, st));
+  PCGX_HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, st));
+  // Poison the ids so that offsets inconsistent with the counts are caught below.
+  PCGX_HIP_TRY(hipMemsetAsync(d_id, 0xFF, (size_t)total * 4, st));
+  PCGX_HIP_TRY(hipMemsetAsync(d_key, 0, (size_t)total * 4, st));
+  PCGX_HIP_TRY(hipMemsetAsync(d_query, 0, (size_t)total * 4, st));
+  const TreeView tv = t->view();
+  const size_t lds = walk_stack_bytes(tv, kRangeBlock);
+  hipLaunchKernelGGL(range_kernel<true>, dim3((unsigned)((nq + kRangeBlock - 1) / kRangeBlock)), dim3(kRangeBlock), lds,
+                     st, tv, d_q, nq, max_range * max_range, nullptr, d_off, total, d_id, d_key, d_query);
+  const unsigned tb = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(range_iota_kernel, dim3(tb), dim3(256), 0, st, vals[0], total);
+  PCGX_HIP_TRY(hipMemcpyAsync(keys[0], d_key, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
+  // stable sort by DistSq, then stable by query: (query, DistSq) order, ties in discovery order
+  int r1 = 0;
+  PCGX_TRY(radix_sort_pairs(keys, vals, total, 32, ws, &r1, st));
+  uint32_t *k2[2] = {keys[r1 ^ 1], keys[r1]};
+  uint32_t *v2[2] = {vals[r1], vals[r1 ^ 1]};
+  hipLaunchKernelGGL(range_gather_u32_kernel, dim3(tb), dim3(256), 0, st, d_query, v2[0], total, k2[0]);
+  int qbits = 0;
+  while (qbits < 32 && ((int64_t)1 << qbits) < nq) qbits++;
+  int r2 = 0;
+  PCGX_TRY(radix_sort_pairs(k2, v2, total, qbits, ws, &r2, st));
+  const uint32_t *perm = v2[r2];  // final slot -> position in discovery order
+  hipLaunchKernelGGL(range_gather_u32_kernel, dim3(tb), dim3(256), 0, st, (const uint32_t *)d_id, perm, total,
+                     d_out_id);
+  hipLaunchKernelGGL(range_gather_u32_kernel, dim3(tb), dim3(256), 0, st, d_key, perm, total, d_out_key);
+  PCGX_HIP_TRY(hipGetLastError());
+  std::vector<int32_t> h_id((size_t)total);
+  PCGX_HIP_TRY(hipMemcpyAsync(h_id.data(), d_out_id, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipMemcpyAsync(dist_sq, d_out_key, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  for (int64_t j = 0; j < total; j++) {
+    if (h_id[j] < 0)
+      return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: offsets do not match the neighbour counts");
+    ids[j] = h_id[j];
+  }
+  return PCGX_OK;
+}

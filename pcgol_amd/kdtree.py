@@ -89,6 +89,26 @@ class KDTree:
                                                   L.ptr(ids), L.ptr(dsq)))
         return ids, dsq
 
+    def Range(self, p, maxRange):
+        """KDTree.Range (kdtree.go:148-161): [Neighbor] with DistSq < maxRange^2 sorted by DistSq."""
+        offs, ids, dsq = self.RangeBatch(np.asarray(p, np.float32).reshape(1, 3), maxRange)
+        return [Neighbor(i, d) for i, d in zip(ids, dsq)]
+
+    def RangeBatch(self, q, maxRange):
+        """Range for every row of q -> (offsets int64[n+1], ids int64[total], distSq float32[total]);
+        query i owns [offsets[i], offsets[i+1])."""
+        q = L.f32c(q).reshape(-1, 3)
+        n = len(q)
+        counts = np.zeros(n, np.int64)
+        L.check(L.lib().pcgx_kdtree_range_count(self._h, L.ptr(q), n, maxRange, L.ptr(counts)))
+        offs = np.zeros(n + 1, np.int64)
+        np.cumsum(counts, out=offs[1:])
+        total = int(offs[-1])
+        ids = np.empty(total, np.int64)
+        dsq = np.empty(total, np.float32)
+        L.check(L.lib().pcgx_kdtree_range_fill(self._h, L.ptr(q), n, maxRange, L.ptr(offs), L.ptr(ids), L.ptr(dsq)))
+        return offs, ids, dsq
+
     def NearestBatchDev(self, d_q, nq, maxRange, d_ids, d_dsq, presort=True, stream=0):
         """Device-resident variant: raw device addresses (e.g. torch .data_ptr())."""
         L.check(L.lib().pcgx_kdtree_nearest_batch_dev(

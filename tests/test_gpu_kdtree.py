@@ -115,3 +115,56 @@ def test_c2_full_size_vs_oracle():
     assert np.array_equal(dsq.view(np.uint32), od.view(np.uint32))
     # V(q) is the figure the roofline's algorithmic bytes are built on
     assert 35.0 < visits / len(ids) < 55.0
+
+
+def test_range_table_golden(golden):
+    """kdtree_test.go:281-386 through the C ABI."""
+    g = golden("ref_kdtree.json")["range"]
+    t = kdtree.New(np.array(g["points"], f32))
+    for c in g["cases"]:
+        nb = t.Range(c["p"], c["max_range"])
+        assert [n.ID for n in nb] == [x[0] for x in c["neighbors"]]
+        for n, x in zip(nb, c["neighbors"]):
+            assert abs(float(n.DistSq) - x[1]) <= g["eps"]
+
+
+@pytest.mark.parametrize("n,nq,max_range", [(100, 100, 3.0), (5000, 2000, 1.0), (200000, 20000, 0.2),
+                                            (3000, 500, 20.0)])
+def test_range_batch_vs_oracle(n, nq, max_range):
+    """kdtree_test.go:887-924 at scale: same set, sorted by DistSq; ties in the walk's discovery
+    order (the oracle's order), so the arrays are identical."""
+    base = synth.uniform_cloud(n, 10.0, 300 + n)
+    q = synth.uniform_cloud(nq, 10.0, 400 + nq)
+    if n == 3000:  # lattice: many exact distance ties
+        base = np.random.default_rng(1).integers(0, 8, size=(n, 3)).astype(f32)
+        q = np.random.default_rng(2).integers(0, 16, size=(nq, 3)).astype(f32) * f32(0.5)
+        max_range = 1.6
+    t = kdtree.New(base)
+    offs, ids, dsq = t.RangeBatch(q, max_range)
+    o = O.KDTree(base)
+    assert offs[0] == 0 and offs[-1] == len(ids)
+    for i in range(0, nq, max(1, nq // 300)):
+        oi, od = o.range(q[i], max_range)
+        s, e = offs[i], offs[i + 1]
+        assert np.array_equal(ids[s:e], oi), i
+        assert np.array_equal(dsq[s:e], od), i
+    # every count agrees with brute force on a sample
+    for i in range(0, nq, max(1, nq // 50)):
+        d = base - q[i]
+        dn = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        assert offs[i + 1] - offs[i] == int(np.sum(dn < f32(max_range) * f32(max_range)))
+
+
+def test_range_fill_rejects_wrong_offsets():
+    import ctypes as C
+    from pcgol_amd import _lib as L
+    base = synth.uniform_cloud(2000, 1.0, 8)
+    q = synth.uniform_cloud(50, 1.0, 9)
+    t = kdtree.New(base)
+    offs, ids, dsq = t.RangeBatch(q, 0.2)
+    bad = offs.copy()
+    bad[1:] += 3  # claims more neighbours than exist
+    ids2 = np.empty(int(bad[-1]), np.int64)
+    dsq2 = np.empty(int(bad[-1]), np.float32)
+    rc = L.lib().pcgx_kdtree_range_fill(t._h, L.ptr(q), len(q), 0.2, L.ptr(bad), L.ptr(ids2), L.ptr(dsq2))
+    assert rc == L.PCGX_E_INVALID
