@@ -370,10 +370,10 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const flo
 }
 
 // Debug / profiling aid: runs the instrumented exact-mode walk over device queries and returns
-// its 8 counters (knn_walk.h).  Not part of the drop-in surface.
+// its 16 counters (knn_walk.h).  Not part of the drop-in surface.
 extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
-                                             int32_t presort, uint64_t stats8[8]) {
-  if (!t || !d_q || !stats8 || nq <= 0) return fail(PCGX_E_INVALID, "pcgx_debug_walk_stats: bad argument");
+                                             int32_t presort, uint64_t stats16[16]) {
+  if (!t || !d_q || !stats16 || nq <= 0) return fail(PCGX_E_INVALID, "pcgx_debug_walk_stats: bad argument");
   PCGX_TRY(ensure_init());
   hipStream_t st = ctx().stream;
   Arena &ar = ctx().arena;
@@ -381,14 +381,14 @@ extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *
   unsigned long long *d_stats = nullptr;
   int32_t *d_ids = nullptr, *perm = nullptr;
   float *d_dsq = nullptr;
-  PCGX_TRY(ar.alloc_n(8, &d_stats));
+  PCGX_TRY(ar.alloc_n(16, &d_stats));
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_ids));
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_dsq));
   if (presort) {
     PCGX_TRY(ar.alloc_n((size_t)nq, &perm));
     PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, perm, st));
   }
-  PCGX_HIP_TRY(hipMemsetAsync(d_stats, 0, 8 * sizeof(unsigned long long), st));
+  PCGX_HIP_TRY(hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), st));
   const TreeView tv = t->view();
   int64_t blocks = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv);
   const int64_t max_blocks = (nq + kKnnBlock - 1) / kKnnBlock;
@@ -397,7 +397,7 @@ extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *
   hipLaunchKernelGGL((nearest_kernel<false, true>), dim3((unsigned)blocks), dim3(kKnnBlock), walk_lds_bytes(tv, kKnnBlock),
                      st, tv, d_q, perm, nq, max_range * max_range, 0.0f, d_ids, d_dsq, d_stats);
   PCGX_HIP_TRY(hipGetLastError());
-  PCGX_HIP_TRY(hipMemcpyAsync(stats8, d_stats, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipMemcpyAsync(stats16, d_stats, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
   return PCGX_OK;
 }

@@ -245,7 +245,9 @@ __device__ __forceinline__ void block_chunk_range(int64_t nq, uint32_t bid, uint
 // Optional instrumentation (kStats): per-wave counts accumulated into stats[] with atomics:
 // [0] loop iterations, [1] active lanes summed over iterations, [2] node fetches (lanes),
 // [3] emit/refill sections run, [4] chunks prepared, [5] queries that verified down to the leaf,
-// [6] first-descent levels recorded in pend, [7] queries.
+// [6] first-descent levels recorded in pend, [7] queries, [8] fetches while descending,
+// [9] explicit-frame pops, [10] of those passing the plane test, [11] first-descent pops,
+// [12] of those passing, [13] leaves evaluated in the loop.
 template <bool kMinDist, bool kStats = false, class Fetch, class Emit>
 __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__restrict__ stk,
                                              const int stk_stride, uint32_t *__restrict__ queue,
@@ -257,7 +259,8 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
                                              unsigned long long *__restrict__ stats = nullptr) {
   constexpr bool kExact = !kMinDist;
   unsigned long long st_iter = 0, st_active = 0, st_look = 0, st_refill = 0, st_prep = 0, st_verified = 0,
-                     st_pend = 0, st_queries = 0;
+                     st_pend = 0, st_queries = 0, st_desc = 0, st_epop = 0, st_epass = 0, st_ipop = 0, st_ipass = 0,
+                     st_leaf = 0;
   const int lane = (int)(threadIdx.x & 63u);
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const uint32_t np1 = (uint32_t)tv.n + 1u;
@@ -394,6 +397,14 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
       const float qv = sel3(dim, qx, qy, qz);
       const float fp = qv - pv;
       const bool plane_ok = !(fp * fp > bound_d);  // kdtree.go:111-115
+      if (kStats) {
+        st_desc += desc;
+        st_leaf += leaf;
+        st_epop += !desc && has_exp;
+        st_epass += !desc && has_exp && plane_ok;
+        st_ipop += !desc && !has_exp;
+        st_ipass += !desc && !has_exp && plane_ok;
+      }
       // leaf: replace unless d > best (kdtree.go:95-103); pivot: replace if d < best (:116-119)
       const bool take = leaf ? !(d > best_d) : (!desc && plane_ok && d < best_d);
       best_d = take ? d : best_d;
@@ -439,6 +450,12 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
       st_verified += __shfl_down(st_verified, o);
       st_pend += __shfl_down(st_pend, o);
       st_queries += __shfl_down(st_queries, o);
+      st_desc += __shfl_down(st_desc, o);
+      st_epop += __shfl_down(st_epop, o);
+      st_epass += __shfl_down(st_epass, o);
+      st_ipop += __shfl_down(st_ipop, o);
+      st_ipass += __shfl_down(st_ipass, o);
+      st_leaf += __shfl_down(st_leaf, o);
     }
     if (lane == 0) {
       atomicAdd(stats + 0, st_iter);
@@ -449,6 +466,12 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
       atomicAdd(stats + 5, st_verified);
       atomicAdd(stats + 6, st_pend);
       atomicAdd(stats + 7, st_queries);
+      atomicAdd(stats + 8, st_desc);
+      atomicAdd(stats + 9, st_epop);
+      atomicAdd(stats + 10, st_epass);
+      atomicAdd(stats + 11, st_ipop);
+      atomicAdd(stats + 12, st_ipass);
+      atomicAdd(stats + 13, st_leaf);
     }
   }
 }

@@ -1,0 +1,70 @@
+"""GPU robustness: degenerate inputs must neither hang nor fault, and must not disturb the
+well-formed queries of the same batch."""
+import numpy as np
+import pytest
+
+import oracle as O
+from pcgol_amd import PcgxError, kdtree, synth, voxelgrid
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def test_all_points_identical():
+    """Every plane test passes (fp == 0): the walk visits the whole tree, like the reference."""
+    base = np.tile(np.array([[1.5, -2.0, 0.25]], f32), (777, 1))
+    q = np.array([[1.5, -2.0, 0.25], [1.0, 1.0, 1.0], [1.5, -2.0, 0.2500001]], f32)
+    for md in (0.0, 0.01):
+        t = kdtree.New(base, MinDistSq=md)
+        ids, dsq = t.NearestBatch(q, 10.0)
+        oi, od = O.KDTree(base, min_dist_sq=md).nearest_batch(q, 10.0)
+        assert np.array_equal(ids, oi) and np.array_equal(dsq, od)
+    offs, rid, rd = kdtree.New(base).RangeBatch(q[:1], 0.5)
+    assert offs[-1] == 777 and np.all(rd == 0)
+
+
+def test_non_finite_queries_do_not_disturb_others():
+    base = synth.uniform_cloud(50000, 10.0, 21)
+    q = synth.uniform_cloud(4096, 10.0, 22)
+    bad = q.copy()
+    bad[::7, 0] = np.nan
+    bad[3::11, 1] = np.inf
+    bad[5::13] = (-np.inf, np.nan, 1e38)
+    good_rows = np.isfinite(bad).all(axis=1)
+    t = kdtree.New(base)
+    ids, dsq = t.NearestBatch(bad, 3.0)           # must return (no hang / fault)
+    oi, od = O.KDTree(base).nearest_batch(q, 3.0)
+    assert np.array_equal(ids[good_rows], oi[good_rows])
+    assert np.array_equal(dsq[good_rows], od[good_rows])
+    assert np.all((ids >= -1) & (ids < len(base)))
+
+
+def test_far_outside_queries_and_tiny_trees():
+    base = synth.uniform_cloud(3, 1.0, 5)
+    q = np.array([[1e6, -1e6, 3.0], [0.5, 0.5, 0.5], [-5.0, 0.1, 0.2]], f32)
+    for n in (1, 2, 3):
+        t = kdtree.New(base[:n])
+        ids, dsq = t.NearestBatch(q, 1e7)
+        oi, od = O.KDTree(base[:n]).nearest_batch(q, 1e7)
+        assert np.array_equal(ids, oi) and np.array_equal(dsq, od)
+
+
+def test_degenerate_axis_cloud():
+    """A planar cloud (z constant): the directory has a zero-extent axis."""
+    base = synth.uniform_cloud(20000, 5.0, 31)
+    base[:, 2] = f32(0.75)
+    q = synth.uniform_cloud(5000, 5.0, 32)
+    t = kdtree.New(base)
+    ids, dsq = t.NearestBatch(q, 10.0)
+    oi, od = O.KDTree(base).nearest_batch(q, 10.0)
+    assert np.array_equal(ids, oi) and np.array_equal(dsq, od)
+
+
+def test_voxel_bad_leaf_sizes():
+    pts = synth.uniform_cloud(1000, 1.0, 3)
+    for leaf in ((0.0, 0.1, 0.1), (-0.1, 0.1, 0.1), (np.nan, 0.1, 0.1), (1e-12, 1e-12, 1e-12)):
+        with pytest.raises(PcgxError):
+            voxelgrid.New(leaf).Filter(pts)
+    out = voxelgrid.New((10.0, 10.0, 10.0)).Filter(pts)   # one voxel
+    assert out.Points == 1
+    assert np.array_equal(out.Data, O.voxel_filter(pts, len(pts), 12, 0, (10.0, 10.0, 10.0)))

@@ -12,10 +12,12 @@ else:
     c = synth.c4_icp(); base, q, mr = c["base"], c["target"], 0.5
 t = kdtree.New(base)
 dq = torch.from_numpy(q).cuda()
-st = np.zeros(8, np.uint64)
+st = np.zeros(16, np.uint64)
 L.check(L.lib().pcgx_debug_walk_stats(t._h, L.ptr(dq.data_ptr()), len(q), mr, presort, L.ptr(st)))
-it, act, look, refill, prep, ver, pend, nq = [int(x) for x in st]
+it, act, look, refill, prep, ver, pend, nq, desc, epop, epass, ipop, ipass, leaf = [int(x) for x in st[:14]]
 print("%s presort=%d: queries %d, iterations(wave) %d = %.3f/query, active lane-steps %.2f/query (util %.1f%%), "
       "node fetches %.2f/query, refill sections %d, chunks %d, verified %.1f%%, pend levels %.2f/query" %
       (which, presort, nq, it, it / nq, act / nq, 100.0 * act / (64.0 * it), look / nq, refill, prep,
        100.0 * ver / nq, pend / nq))
+print("  per query: descending fetches %.2f (leaves %.2f), explicit pops %.2f (passing %.2f), first-descent pops %.2f (passing %.2f)"
+      % (desc / nq, leaf / nq, epop / nq, epass / nq, ipop / nq, ipass / nq))
