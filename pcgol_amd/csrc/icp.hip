@@ -94,9 +94,22 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
       x = px; y = py; z = pz;
     }
   };
+  // From the second iteration of a Fit on, match[i] still holds the base point matched in the
+  // previous iteration: its distance to the re-projected target bounds the new nearest distance
+  // from above and seeds the walk's pruning bound (knn_walk.h, "Pruning bound"; exact mode only).
+  // A session's match[] starts out invalid (w = NaN) and only ever holds points of its tree.
+  auto load_query = [&](int64_t i, float &x, float &y, float &z, float &ub) {
+    load_target(i, x, y, z);
+    ub = __builtin_inff();
+    if (!kMinDist && project) {
+      const float4 pm = match[i];
+      const float dx = pm.x - x, dy = pm.y - y, dz = pm.z - z;
+      if (pm.w >= 0.0f) ub = (dx * dx + dy * dy) + dz * dz;
+    }
+  };
   walk_queries<kMinDist>(
       tv, s_stack + threadIdx.x, kIcpBlock, queue, top, nt, &s_next_chunk, chunk_end, kp.max_dist_sq, kp.min_dist_sq,
-      load_target,
+      load_query,
       [&](int64_t i, const float4 &bp, float best_d) {
         match[i] = make_float4(bp.x, bp.y, bp.z, __float_as_int(bp.w) >= 0 ? best_d : -1.0f);
       });
@@ -318,6 +331,9 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
     s->own_sums = true;
   }
   if ((rc = reset_state(s, st)) != PCGX_OK) return bail(rc);
+  // no previous match yet: w = NaN (icp_corr_kernel takes pruning hints from match[] only when w >= 0)
+  if ((e = hipMemsetAsync(s->d_match, 0xFF, (size_t)(nt ? nt : 1) * sizeof(float4), st)) != hipSuccess)
+    return bail(fail(PCGX_E_HIP, "icp session: hipMemsetAsync failed: %s", hipGetErrorString(e)));
   if (nt > 0) {
     Arena &ar = ctx().arena;
     if ((rc = ar.begin(st)) != PCGX_OK) return bail(rc);

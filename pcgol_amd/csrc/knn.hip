@@ -33,11 +33,12 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
   __syncthreads();
   walk_queries<kMinDist, kStats>(
       tv, s_stack + threadIdx.x, kKnnBlock, queue, top, nq, &s_next_chunk, chunk_end, max_range_sq, min_dist_sq,
-      [&](int64_t pos, float &x, float &y, float &z) {
+      [&](int64_t pos, float &x, float &y, float &z, float &ub) {
         const int64_t i = perm ? (int64_t)perm[pos] : pos;
         x = q[3 * i + 0];
         y = q[3 * i + 1];
         z = q[3 * i + 2];
+        ub = __builtin_inff();
       },
       [&](int64_t pos, const float4 &best, float best_d) {
         const int64_t i = perm ? (int64_t)perm[pos] : pos;

@@ -43,7 +43,9 @@
 // followed) only if its plane test can still pass: fp*fp <= bound, where
 //   * bound = the running best, as in the reference, and additionally
 //   * with MinDistSq == 0 (kExact): bound = min(best, ub), ub = the distance to
-//     the predicted leaf's point.  ub >= d*, the final nearest distance; every
+//     some point OF THE TREE: the predicted leaf's point, and optionally a caller's
+//     hint (the ICP loop passes the distance to the point matched in the previous
+//     iteration).  ub >= d*, the final nearest distance; every
 //     subtree holding a point at distance d* has fp*fp <= d* <= bound for the
 //     planes of all its ancestors, so it is visited when the reference visits
 //     it and in the same relative order, and candidates farther than d* never
@@ -128,7 +130,8 @@ __device__ __forceinline__ void load_top_levels(const TreeView &tv, float *__res
 
 template <bool kExact>
 __device__ __forceinline__ Prepared prepare_query(const TreeView &tv, const float *__restrict__ top, float qx,
-                                                  float qy, float qz, float max_range_sq, float min_dist_sq) {
+                                                  float qy, float qz, float max_range_sq, float min_dist_sq,
+                                                  float ub_hint) {
   Prepared p;
   p.qx = qx; p.qy = qy; p.qz = qz;
   p.best_d = max_range_sq;
@@ -197,7 +200,9 @@ __device__ __forceinline__ Prepared prepare_query(const TreeView &tv, const floa
   }
   const float ldx = leaf.x - qx, ldy = leaf.y - qy, ldz = leaf.z - qz;
   const float d_leaf = (ldx * ldx + ldy * ldy) + ldz * ldz;
-  const float bound0 = kExact ? fminf(max_range_sq, d_leaf) : max_range_sq;
+  // fminf drops a NaN operand: a NaN hint or leaf distance simply does not tighten the bound
+  const float ub = fminf(d_leaf, ub_hint);
+  const float bound0 = kExact ? fminf(max_range_sq, ub) : max_range_sq;
 #pragma unroll
   for (int k = 0; k < kDeepLevels; k++) check_level(kTopLevels + k, pv_deep[k], bound0);
   if (kExact) {  // re-filter the top levels with the tighter bound
@@ -216,7 +221,7 @@ __device__ __forceinline__ Prepared prepare_query(const TreeView &tv, const floa
     }
     if (!kExact && p.best_d < min_dist_sq) finished = true;
   }
-  p.bound_d = kExact ? fminf(p.best_d, d_leaf) : p.best_d;
+  p.bound_d = kExact ? fminf(p.best_d, ub) : p.best_d;
   p.path_b = bl >> (L - m);
   p.n = finished ? 0x80000000u : (verified ? 0u : n_m);
   p.pend = near & ((m >= 32) ? 0xFFFFFFFFu : ((1u << m) - 1u));  // only levels above the mismatch
@@ -237,7 +242,9 @@ __device__ __forceinline__ void block_chunk_range(int64_t nq, uint32_t bid, uint
   end = (uint32_t)(n_chunks * (slot + 1) / nblocks);
 }
 
-// fetch(idx, qx, qy, qz): loads query idx.   emit(idx, best, best_d): consumes the result;
+// fetch(idx, qx, qy, qz, ub): loads query idx; ub = squared distance (the walk's own float32
+// expression) from the query to ANY point stored in the tree, or +inf: a pruning hint used in
+// exact mode only (header, "Pruning bound").   emit(idx, best, best_d): consumes the result;
 // best = {x, y, z, bits(id)} of the matched base point, id < 0 = no match.
 // `queue`: this wave's LDS queue (kQueueWords * 64 words); `top`: the workgroup's LDS copy of the
 // top split values (load_top_levels); `next_chunk`: the workgroup's LDS chunk counter,
@@ -308,9 +315,9 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
         if (kStats) st_prep += 1;
         const int64_t idx = q_base + lane;
         if (lane < q_count) {
-          float x, y, z;
-          fetch(idx, x, y, z);
-          const Prepared p = prepare_query<kExact>(tv, top, x, y, z, max_range_sq, min_dist_sq);
+          float x, y, z, ub_hint;
+          fetch(idx, x, y, z, ub_hint);
+          const Prepared p = prepare_query<kExact>(tv, top, x, y, z, max_range_sq, min_dist_sq, ub_hint);
           if (kStats) {
             st_queries += 1;
             st_verified += p.n == 0u;
@@ -319,7 +326,8 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
           queue[0 * 64 + lane] = __float_as_uint(p.qx);
           queue[1 * 64 + lane] = __float_as_uint(p.qy);
           queue[2 * 64 + lane] = __float_as_uint(p.qz);
-          // best_d is implied: bound_d if a best exists (then best_d == bound_d), else maxRange^2
+          // best_d is implied: the distance to `best` if there is one (recomputed bit-identically
+          // when the entry is taken), else maxRange^2
           queue[3 * 64 + lane] = __float_as_uint(p.bound_d);
           queue[4 * 64 + lane] = p.path_b;
           queue[5 * 64 + lane] = p.n;
@@ -346,7 +354,8 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
           best.y = __uint_as_float(queue[9 * 64 + slot]);
           best.z = __uint_as_float(queue[10 * 64 + slot]);
           best.w = __uint_as_float(queue[11 * 64 + slot]);
-          best_d = __float_as_int(best.w) >= 0 ? bound_d : max_range_sq;
+          const float bx = best.x - qx, by = best.y - qy, bz = best.z - qz;
+          best_d = __float_as_int(best.w) >= 0 ? (bx * bx + by * by) + bz * bz : max_range_sq;
           my_q = q_base + slot;
           sp = 0;
           if (nn & 0x80000000u) {  // MinDistSq cut at the first leaf: nothing left to walk
