@@ -84,7 +84,7 @@ PCGX_API pcgx_status pcgx_prof_reset(void);
  * fetches while descending, explicit pops, passing, first-descent pops, passing, leaves, -, -}. */
 typedef struct pcgx_kdtree pcgx_kdtree;
 PCGX_API pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
-                                           int32_t presort, uint64_t stats16[16]);
+                                           int32_t presort, const float *d_hint_xyz, uint64_t stats16[16]);
 
 /* Device memory helpers for hosts that have no HIP binding of their own. */
 PCGX_API pcgx_status pcgx_dev_alloc(size_t bytes, void **dptr);

@@ -19,7 +19,8 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
                                                             int64_t nq, float max_range_sq, float min_dist_sq,
                                                             int32_t *__restrict__ out_id,
                                                             float *__restrict__ out_dsq,
-                                                            unsigned long long *__restrict__ stats = nullptr) {
+                                                            unsigned long long *__restrict__ stats = nullptr,
+                                                            const float *__restrict__ hint = nullptr) {
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
   uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kKnnBlock +
@@ -39,6 +40,10 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
         y = q[3 * i + 1];
         z = q[3 * i + 2];
         ub = __builtin_inff();
+        if (kStats && hint) {  // instrumented runs only: a tree point per query (see pcgx_debug_walk_stats)
+          const float dx = hint[3 * i + 0] - x, dy = hint[3 * i + 1] - y, dz = hint[3 * i + 2] - z;
+          ub = (dx * dx + dy * dy) + dz * dz;
+        }
       },
       [&](int64_t pos, const float4 &best, float best_d) {
         const int64_t i = perm ? (int64_t)perm[pos] : pos;
@@ -371,9 +376,11 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const flo
 }
 
 // Debug / profiling aid: runs the instrumented exact-mode walk over device queries and returns
-// its 16 counters (knn_walk.h).  Not part of the drop-in surface.
+// its 16 counters (knn_walk.h).  d_hint_xyz (optional): per query the packed xyz of ANY point of
+// the tree, used as the pruning hint the ICP loop takes from its previous iteration.  Not part of
+// the drop-in surface.
 extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
-                                             int32_t presort, uint64_t stats16[16]) {
+                                             int32_t presort, const float *d_hint_xyz, uint64_t stats16[16]) {
   if (!t || !d_q || !stats16 || nq <= 0) return fail(PCGX_E_INVALID, "pcgx_debug_walk_stats: bad argument");
   PCGX_TRY(ensure_init());
   hipStream_t st = ctx().stream;
@@ -396,7 +403,7 @@ extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks >= 8) blocks &= ~(int64_t)7;
   hipLaunchKernelGGL((nearest_kernel<false, true>), dim3((unsigned)blocks), dim3(kKnnBlock), walk_lds_bytes(tv, kKnnBlock),
-                     st, tv, d_q, perm, nq, max_range * max_range, 0.0f, d_ids, d_dsq, d_stats);
+                     st, tv, d_q, perm, nq, max_range * max_range, 0.0f, d_ids, d_dsq, d_stats, d_hint_xyz);
   PCGX_HIP_TRY(hipGetLastError());
   PCGX_HIP_TRY(hipMemcpyAsync(stats16, d_stats, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));

@@ -32,12 +32,17 @@
 // the reference computes; from m on the lane continues with ordinary dependent
 // steps.  A wrong prediction therefore costs time, never correctness.
 //
+// The verification is branch-free: one bit per level for "the real descent goes
+// to child1" (pivotVal > val is false) is compared with the path bits of the
+// predicted leaf; the first differing level is m.  Subtree sizes are never
+// tracked: the size of BFS node b is a closed form of b (node_size below), needed
+// only to recognise leaves (size 1) and single-child nodes (size 2).
+//
 // Frames of this first descent are not materialised: the path is one word
-// (path_b, BFS index of the deepest verified node), `pend` has bit j set when
-// the ancestor at level j still has to be examined when the walk unwinds to it,
-// `szmask` bit j is its subtree-size bit.  When the walk pops such a level it
-// re-fetches the ancestor, recomputes fp (bit-identical) and applies the plane
-// test, as the reference does.
+// (path_b, BFS index of the deepest verified node) and `pend` has bit j set when
+// the ancestor at level j still has to be examined when the walk unwinds to it.
+// When the walk pops such a level it re-fetches the ancestor, recomputes fp
+// (bit-identical) and applies the plane test, as the reference does.
 //
 // Pruning bound.  A level is recorded in `pend` (a frame pushed, a popped frame
 // followed) only if its plane test can still pass: fp*fp <= bound, where
@@ -72,8 +77,9 @@
 // fetch, shared by all modes -- and lanes whose query has finished take the
 // next prepared query from the queue.  Explicit frames exist only below the
 // verified path: one 32-bit word per pending ancestor, in LDS laid out
-// [level][thread] (conflict-free):
-//   BFS node index (27 bits) | went-to-child0 bit << 27 | size bit << 31
+// [level][thread] (conflict-free): the BFS index c of the CHILD the descent
+// took (the ancestor is c >> 1, the other side c ^ 1) -- the same word a level
+// of the first descent yields as a shift of path_b.
 // Popping a frame re-fetches its node and recomputes fp = q[dim] - pivot[dim]
 // (bit-identical to the value at push time) for the plane test, exactly like a
 // level of the first descent; a frame is pushed only if that test can still pass.
@@ -90,18 +96,29 @@ __device__ __forceinline__ float sel3(int dim, float a, float b, float c) {
 
 constexpr int kMaxLevels = 26;       // inner levels on a root-to-leaf path (N <= 2^26)
 
+// Size of the subtree of BFS node b at depth `depth` in a tree of m1 - 1 points.  With
+// m = size + 1 the reference's split (kdtree.go:357-369: len/2 left of the median, the rest
+// right) reads m_child0 = ceil(m / 2), m_child1 = floor(m / 2); after `depth` halvings the
+// 2^depth parts differ by at most one and the larger ones are those whose bit-reversed path is
+// below the remainder.  Nodes that do not exist give 0 or 0xFFFFFFFF.
+__device__ __forceinline__ uint32_t node_size(uint32_t b, int depth, uint32_t m1) {
+  const uint32_t rev = __brev(b) >> ((32 - depth) & 31);  // path bits, the root's choice lowest
+  const uint32_t rem = m1 & ((1u << depth) - 1u);
+  return (m1 >> depth) - 1u + (rev < rem ? 1u : 0u);
+}
+
 // State a prepared query starts the stepping loop with (= one LDS queue entry).
 struct Prepared {
   float qx, qy, qz;
   float best_d;       // running best (kdtree.go neighbor1.DistSq)
   float bound_d;      // pruning bound: min(best, ub) in exact mode, = best otherwise
   float4 best;        // record of the current best {x, y, z, bits(id)}, id < 0 = none
-  uint32_t path_b;    // deepest verified node of the first descent
-  uint32_t n;         // subtree size at path_b if the lane must descend from it, 0 = leaf done,
-                      // 0x80000000 = query finished inside prepare
+  uint32_t path_b;    // deepest verified node of the first descent, plus the flags below
   uint32_t pend;      // first-descent levels still to examine
-  uint32_t szmask;    // their subtree-size bits
 };
+constexpr uint32_t kPathFinished = 0x80000000u;  // query finished inside prepare (MinDistSq cut)
+constexpr uint32_t kPathDescend = 0x40000000u;   // prediction failed at path_b: descend from there
+constexpr uint32_t kPathMask = 0x07FFFFFFu;
 
 // One float of node b; 32-bit byte offset (tree < 2^27 slots x 16 B) so the load uses
 // scalar-base + 32-bit-offset addressing instead of a 64-bit address per lane.
@@ -116,7 +133,8 @@ __device__ __forceinline__ float4 node_at(const float4 *nodes, uint32_t b) {
 
 constexpr int kTopLevels = 11;                 // split values of levels 0..10 (BFS 1..2047) live in LDS
 constexpr int kTopEntries = 1 << kTopLevels;   // 2048 floats = 8 KB per workgroup
-constexpr int kDeepLevels = kMaxLevels - kTopLevels;
+constexpr int kDeepGroup = 5;                  // deeper levels are fetched in groups of this many
+static_assert((kMaxLevels - kTopLevels) % kDeepGroup == 0, "deep levels must split into whole groups");
 
 // Fills the workgroup's LDS copy of the top split values (call before walk_queries, then sync).
 __device__ __forceinline__ void load_top_levels(const TreeView &tv, float *__restrict__ top) {
@@ -136,7 +154,7 @@ __device__ __forceinline__ Prepared prepare_query(const TreeView &tv, const floa
   p.qx = qx; p.qy = qy; p.qz = qz;
   p.best_d = max_range_sq;
   p.best = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-  const uint32_t np1 = (uint32_t)tv.n + 1u;
+  const uint32_t m1 = (uint32_t)tv.n + 1u;
   // --- predicted leaf from the grid directory
   const int g = tv.dir_bits;
   const float cmax = (float)((1 << g) - 1);
@@ -146,71 +164,57 @@ __device__ __forceinline__ Prepared prepare_query(const TreeView &tv, const floa
   const uint32_t cell = (uint32_t)fx | ((uint32_t)fy << g) | ((uint32_t)fz << (2 * g));
   const uint32_t bl = tv.dir[cell];
   const int L = 31 - __clz((int)bl);  // depth of the predicted leaf = inner levels above it
+  // The predicted path extended to kMaxLevels: its ancestor at level j is ext >> (kMaxLevels - j)
+  // for every j; for j >= L that is a slot without a node (those levels are masked off below).
+  // Bit (kMaxLevels - 1 - j) of ext says whether the predicted path takes child1 at level j; the
+  // per-level masks below use the same (root-highest) bit order.
+  const uint32_t ext = bl << (kMaxLevels - L);
 
   // --- ONE round of independent fetches: the predicted leaf and the split values of the
-  //     predicted path below the LDS-resident top levels
+  //     predicted path (top levels from LDS; deeper ones from memory in groups of kDeepGroup
+  //     levels, a group is skipped when the tree ends above it; slots exist for j < 2^depth)
   const float4 leaf = node_at(tv.nodes, bl);
-  float pv_deep[kDeepLevels];
+  float pv[kMaxLevels];
 #pragma unroll
-  for (int k = 0; k < kDeepLevels; k++) {
-    const int j = kTopLevels + k;
-    pv_deep[k] = 0.0f;
-    if (j < L) pv_deep[k] = node_comp(tv.nodes, bl >> (L - j), j % 3);
-  }
-
-  // --- verify the predicted path with the reference's own comparison (kdtree.go:202-221);
-  //     the LDS levels are checked while the fetches above are in flight
-  uint32_t n = (uint32_t)tv.n;  // subtree size at the current level
-  uint32_t n_m = n;             // ... at the first mismatch
-  int m = L;                    // first level where the prediction fails (L: verified to the leaf)
-  uint32_t szmask = 0;
-  uint32_t near = 0;            // levels whose plane is within maxRange (candidates for `pend`)
-  float fp2[1];                 // (placeholder to keep the two loops symmetrical)
-  (void)fp2;
-  // level j: returns false once the prediction has failed
-  auto check_level = [&](int j, float pv, float bound) {
-    if (j < L && m == L) {
-      const float qv = (j % 3 == 0) ? qx : ((j % 3 == 1) ? qy : qz);
-      const bool pred_left = ((bl >> (L - j - 1)) & 1u) == 0u;
-      const bool real_left = n == 2u || pv > qv;
-      if (pred_left != real_left) {
-        m = j;
-        n_m = n;
-      } else {
-        const float fp = qv - pv;
-        if (!(fp * fp > bound)) near |= 1u << j;
-        szmask |= (n - ((np1 >> j) - 1u)) << j;
-        const uint32_t half = n >> 1;
-        n = pred_left ? half : n - half - 1u;
+  for (int j = 0; j < kTopLevels; j++) pv[j] = top[ext >> (kMaxLevels - j)];
+#pragma unroll
+  for (int g0 = kTopLevels; g0 < kMaxLevels; g0 += kDeepGroup) {
+    if (g0 < tv.depth) {  // wave-uniform
+#pragma unroll
+      for (int j = g0; j < g0 + kDeepGroup; j++) {
+        // the last group may reach past the slots of a tree whose depth is not a group boundary
+        const uint32_t idx = ext >> (kMaxLevels - j);
+        pv[j] = node_comp(tv.nodes, idx & ((1u << tv.depth) - 1u), j % 3);
       }
-    }
-  };
-  // Bound for recording a level in `pend`: the best while the reference descends (= maxRange^2);
-  // tightened below by ub in exact mode (header, "Pruning bound").  The top levels are checked
-  // against maxRange^2 first and re-filtered once the leaf distance has arrived.
-  float top_fp2[kTopLevels];
+    } else {
 #pragma unroll
-  for (int j = 0; j < kTopLevels; j++) {
-    float pv = 0.0f;
-    if (j < L) pv = top[bl >> (L - j)];
-    const float qv = (j % 3 == 0) ? qx : ((j % 3 == 1) ? qy : qz);
-    const float fp = qv - pv;
-    top_fp2[j] = fp * fp;
-    check_level(j, pv, max_range_sq);
+      for (int j = g0; j < g0 + kDeepGroup; j++) pv[j] = 0.0f;
+    }
   }
   const float ldx = leaf.x - qx, ldy = leaf.y - qy, ldz = leaf.z - qz;
   const float d_leaf = (ldx * ldx + ldy * ldy) + ldz * ldz;
-  // fminf drops a NaN operand: a NaN hint or leaf distance simply does not tighten the bound
+  // Bound for recording a level in `pend`: the best while the reference descends (= maxRange^2),
+  // tightened by ub in exact mode (header, "Pruning bound").  fminf drops a NaN operand: a NaN
+  // hint or leaf distance simply does not tighten the bound.
   const float ub = fminf(d_leaf, ub_hint);
   const float bound0 = kExact ? fminf(max_range_sq, ub) : max_range_sq;
+
+  // --- per level: does the real descent go to child1 (kdtree.go:216: pivotVal > val -> child0),
+  //     and can the level's plane test still pass.  One bit per level, shifted in root first.
+  uint32_t right = 0, near = 0;
 #pragma unroll
-  for (int k = 0; k < kDeepLevels; k++) check_level(kTopLevels + k, pv_deep[k], bound0);
-  if (kExact) {  // re-filter the top levels with the tighter bound
-#pragma unroll
-    for (int j = 0; j < kTopLevels; j++)
-      if (top_fp2[j] > bound0) near &= ~(1u << j);
+  for (int j = 0; j < kMaxLevels; j++) {
+    const float qv = (j % 3 == 0) ? qx : ((j % 3 == 1) ? qy : qz);
+    right = right + right + ((pv[j] > qv) ? 0u : 1u);
+    const float fp = qv - pv[j];
+    near = near + near + ((fp * fp > bound0) ? 0u : 1u);
   }
-  const bool verified = m == L;
+  const uint32_t valid = ((1u << L) - 1u) << (kMaxLevels - L);  // levels above the predicted leaf
+  // only child (kdtree.go:208-211): a node of size 2 sends every query to child0
+  if (L > 0 && node_size(bl >> 1, L - 1, m1) == 2u) right &= ~(1u << (kMaxLevels - L));
+  const uint32_t wrong = (right ^ ext) & valid;
+  const bool verified = wrong == 0u;
+  const int m = verified ? L : __clz((int)wrong) - (32 - kMaxLevels);  // first level where the prediction fails
 
   // --- the leaf (kdtree.go:95-106), only if the real descent arrives there
   bool finished = false;
@@ -222,14 +226,14 @@ __device__ __forceinline__ Prepared prepare_query(const TreeView &tv, const floa
     if (!kExact && p.best_d < min_dist_sq) finished = true;
   }
   p.bound_d = kExact ? fminf(p.best_d, ub) : p.best_d;
-  p.path_b = bl >> (L - m);
-  p.n = finished ? 0x80000000u : (verified ? 0u : n_m);
-  p.pend = near & ((m >= 32) ? 0xFFFFFFFFu : ((1u << m) - 1u));  // only levels above the mismatch
-  p.szmask = szmask;
+  p.path_b = (bl >> (L - m)) | (finished ? kPathFinished : 0u) | (verified ? 0u : kPathDescend);
+  // only levels above the mismatch; stored with bit j = level j
+  p.pend = (near >> (kMaxLevels - m)) == 0u ? 0u : __brev(near >> (kMaxLevels - m)) >> ((32 - m) & 31);
   return p;
 }
 
-constexpr int kQueueWords = 12;  // LDS queue entry words (SoA [word][slot], 64 slots per wave)
+constexpr int kQueueWords = 10;  // LDS queue entry words (SoA [word][slot], 64 slots per wave)
+static_assert(kQueueWords * 64 * 4 == kWalkQueueBytesPerWave, "pcgx_internal.h kWalkQueueBytesPerWave");
 
 // Chunk range [begin, end) of workgroup `bid` out of `nblocks` (a multiple of 8, or < 8):
 // workgroups with equal bid % 8 get adjacent ranges.
@@ -259,8 +263,7 @@ template <bool kMinDist, bool kStats = false, class Fetch, class Emit>
 __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__restrict__ stk,
                                              const int stk_stride, uint32_t *__restrict__ queue,
                                              const float *__restrict__ top, const int64_t nq,
-                                             uint32_t *__restrict__ next_chunk,
-                                             const uint32_t chunk_end,
+                                             uint32_t *__restrict__ next_chunk, const uint32_t chunk_end,
                                              const float max_range_sq, const float min_dist_sq,
                                              Fetch &&fetch, Emit &&emit,
                                              unsigned long long *__restrict__ stats = nullptr) {
@@ -270,7 +273,7 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
                      st_leaf = 0;
   const int lane = (int)(threadIdx.x & 63u);
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  const uint32_t np1 = (uint32_t)tv.n + 1u;
+  const uint32_t m1 = (uint32_t)tv.n + 1u;
   bool exhausted = false;           // wave-uniform: the workgroup's range is used up
   int32_t q_head = 0, q_count = 0;  // wave-uniform: LDS queue state
   int64_t q_base = 0;               // wave-uniform: first query of the queued chunk
@@ -279,8 +282,8 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
   int64_t my_q = 0;
   float qx = 0.0f, qy = 0.0f, qz = 0.0f, best_d = 0.0f, bound_d = 0.0f;
   float4 best = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-  uint32_t b = 1, path_b = 1, pend = 0, szmask = 0;
-  int32_t n = 0, sp = 0;
+  uint32_t b = 1, path_b = 1, pend = 0;
+  int32_t sp = 0;
 
   for (;;) {
     // ---- emit finished lanes, prepare more queries, refill ------------------------
@@ -320,7 +323,7 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
           const Prepared p = prepare_query<kExact>(tv, top, x, y, z, max_range_sq, min_dist_sq, ub_hint);
           if (kStats) {
             st_queries += 1;
-            st_verified += p.n == 0u;
+            st_verified += (p.path_b & kPathDescend) == 0u;
             st_pend += (unsigned long long)__popc(p.pend);
           }
           queue[0 * 64 + lane] = __float_as_uint(p.qx);
@@ -330,13 +333,11 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
           // when the entry is taken), else maxRange^2
           queue[3 * 64 + lane] = __float_as_uint(p.bound_d);
           queue[4 * 64 + lane] = p.path_b;
-          queue[5 * 64 + lane] = p.n;
-          queue[6 * 64 + lane] = p.pend;
-          queue[7 * 64 + lane] = p.szmask;
-          queue[8 * 64 + lane] = __float_as_uint(p.best.x);
-          queue[9 * 64 + lane] = __float_as_uint(p.best.y);
-          queue[10 * 64 + lane] = __float_as_uint(p.best.z);
-          queue[11 * 64 + lane] = __float_as_uint(p.best.w);
+          queue[5 * 64 + lane] = p.pend;
+          queue[6 * 64 + lane] = __float_as_uint(p.best.x);
+          queue[7 * 64 + lane] = __float_as_uint(p.best.y);
+          queue[8 * 64 + lane] = __float_as_uint(p.best.z);
+          queue[9 * 64 + lane] = __float_as_uint(p.best.w);
         }
       }
       if (!active) {
@@ -346,24 +347,22 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
           qy = __uint_as_float(queue[1 * 64 + slot]);
           qz = __uint_as_float(queue[2 * 64 + slot]);
           bound_d = __uint_as_float(queue[3 * 64 + slot]);
-          path_b = queue[4 * 64 + slot];
-          const uint32_t nn = queue[5 * 64 + slot];
-          pend = queue[6 * 64 + slot];
-          szmask = queue[7 * 64 + slot];
-          best.x = __uint_as_float(queue[8 * 64 + slot]);
-          best.y = __uint_as_float(queue[9 * 64 + slot]);
-          best.z = __uint_as_float(queue[10 * 64 + slot]);
-          best.w = __uint_as_float(queue[11 * 64 + slot]);
+          const uint32_t pw = queue[4 * 64 + slot];
+          pend = queue[5 * 64 + slot];
+          best.x = __uint_as_float(queue[6 * 64 + slot]);
+          best.y = __uint_as_float(queue[7 * 64 + slot]);
+          best.z = __uint_as_float(queue[8 * 64 + slot]);
+          best.w = __uint_as_float(queue[9 * 64 + slot]);
           const float bx = best.x - qx, by = best.y - qy, bz = best.z - qz;
           best_d = __float_as_int(best.w) >= 0 ? (bx * bx + by * by) + bz * bz : max_range_sq;
           my_q = q_base + slot;
           sp = 0;
-          if (nn & 0x80000000u) {  // MinDistSq cut at the first leaf: nothing left to walk
+          path_b = pw & kPathMask;
+          if (pw & kPathFinished) {  // MinDistSq cut at the first leaf: nothing left to walk
             pending = true;
           } else {
-            n = (int32_t)nn;
             b = path_b;
-            desc = nn != 0u;
+            desc = (pw & kPathDescend) != 0u;
             active = true;
           }
         }
@@ -376,7 +375,8 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
     }
 
     // ---- unwinding lanes: the topmost explicit frame, else the deepest pending level of the
-    //      first descent (kdtree.go:107-110); its plane test follows the node fetch
+    //      first descent (kdtree.go:107-110); either way the frame is the child c the descent
+    //      took below the ancestor c >> 1.  Its plane test follows the node fetch.
     const bool popping = active && !desc;
     const bool has_exp = sp > 0;
     const uint32_t fw = stk[(has_exp ? sp - 1 : 0) * stk_stride];
@@ -386,26 +386,28 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
     const int m = 31 - __clz((int)path_b);
     const int j = 31 - __clz((int)(pend | 1u));
     pend = implicit ? (pend & ~(1u << j)) : pend;
-    const uint32_t fb = has_exp ? (fw & 0x07FFFFFFu) : (path_b >> (m - j));
-    const bool went_left = has_exp ? ((fw >> 27) & 1u) != 0u : ((path_b >> (m - j - 1)) & 1u) == 0u;
-    const uint32_t fbit = has_exp ? (fw >> 31) : ((szmask >> j) & 1u);
+    const uint32_t c = has_exp ? fw : (path_b >> ((m - j - 1) & 31));
 
     // ---- the one node fetch of this step -----------------------------------------
-    const uint32_t at = desc ? b : fb;
+    const uint32_t at = desc ? b : (c >> 1);
     const bool look = active && (desc || has_exp || implicit);
     if (kStats) st_look += look;
     if (look) {
       const float4 nd = node_at(tv.nodes, at);
       const float dx = nd.x - qx, dy = nd.y - qy, dz = nd.z - qz;  // pivot.Sub(p)
-      const float d = (dx * dx + dy * dy) + dz * dz;                // NormSq, mat/vec3.go:18-20
-      const bool leaf = desc && n == 1;
-      const bool inner = desc && n != 1;
+      const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+      const float d = (xx + yy) + zz;                                // NormSq, mat/vec3.go:18-20
       const int32_t depth = 31 - __clz((int)at);
+      const uint32_t n = node_size(at, depth, m1);
+      const bool leaf = desc && n == 1u;
+      const bool inner = desc && n != 1u;
       const int dim = depth % 3;
-      const float pv = sel3(dim, nd.x, nd.y, nd.z);
-      const float qv = sel3(dim, qx, qy, qz);
-      const float fp = qv - pv;
-      const bool plane_ok = !(fp * fp > bound_d);  // kdtree.go:111-115
+      // fp = q[dim] - pivot[dim] = -(pivot[dim] - q[dim]) exactly, so fp * fp is the square already
+      // formed for the distance, and pivotVal > val <=> pivot[dim] - q[dim] > 0 (float32
+      // denormals are on for this code object: the difference is zero only for equal operands)
+      const float fp2 = sel3(dim, xx, yy, zz);
+      const float sd = sel3(dim, dx, dy, dz);
+      const bool plane_ok = !(fp2 > bound_d);  // kdtree.go:111-115
       if (kStats) {
         st_desc += desc;
         st_leaf += leaf;
@@ -425,26 +427,16 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
       if (kMinDist) finish = finish || ((leaf || take) && best_d < min_dist_sq);  // :104,120,140
 
       // descending through an inner node: searchLeafNode step (kdtree.go:202-221)
-      const int32_t half = n >> 1;
-      const bool go_left = n == 2 || pv > qv;  // only child, or pivotVal > val -> child0
+      const bool go_left = n == 2u || sd > 0.0f;  // only child, or pivotVal > val -> child0
+      const uint32_t child = 2u * at + (go_left ? 0u : 1u);
       if (inner && plane_ok) {
-        const uint32_t size_bit = (uint32_t)n - ((np1 >> depth) - 1u);
-        stk[sp * stk_stride] = b | (go_left ? (1u << 27) : 0u) | (size_bit << 31);
+        stk[sp * stk_stride] = child;
         ++sp;
       }
-      const uint32_t d_b = 2u * b + (go_left ? 0u : 1u);
-      const int32_t d_n = go_left ? half : n - half - 1;
-
-      // unwinding through a node that passed the plane test: the other side (kdtree.go:124-137)
-      const int32_t fn = (int32_t)((np1 >> depth) - 1u + fbit);
-      const int32_t phalf = fn >> 1;
-      const uint32_t p_b = 2u * fb + (went_left ? 1u : 0u);
-      const int32_t p_n = went_left ? fn - phalf - 1 : phalf;
-      const bool p_far = plane_ok && fn != 2;  // fn == 2: single child, nextNode == nil (:130-132)
-
-      b = desc ? d_b : p_b;
-      n = desc ? d_n : p_n;
-      desc = desc ? inner : p_far;
+      // unwinding through a node that passed the plane test: the other side (kdtree.go:124-137);
+      // n == 2: single child, nextNode == nil (:130-132)
+      b = desc ? child : (c ^ 1u);
+      desc = desc ? inner : (plane_ok && n != 2u);
     }
 
     if (finish) {

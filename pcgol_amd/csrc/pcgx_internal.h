@@ -120,9 +120,9 @@ pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint
 
 // knn.hip
 constexpr int kKnnBlock = 256;  // 4 waves
-constexpr int kWalkQueueBytesPerWave = 12 * 64 * 4;  // knn_walk.h kQueueWords
+constexpr int kWalkQueueBytesPerWave = 10 * 64 * 4;  // knn_walk.h kQueueWords
 // Dynamic LDS of a walk kernel block: frame stacks [(depth-1)][block] x 4 B (19 KB at 1M
-// points), one prepared-query queue per wave (3 KB each), the top split values (8 KB).
+// points), one prepared-query queue per wave (2.5 KB each), the top split values (8 KB).
 inline size_t walk_stack_bytes(const TreeView &tv, int block) {
   int levels = tv.depth > 1 ? tv.depth - 1 : 1;
   return (size_t)levels * block * sizeof(uint32_t);

@@ -208,7 +208,7 @@ class IcpSession:
         return trans, Stat(st), bool(conv.value)
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and L is not None:  # L is None during interpreter shutdown
             L.lib().pcgx_icp_session_free(self._h)
             self._h = None
 

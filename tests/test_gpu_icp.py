@@ -176,3 +176,57 @@ def test_sharded_icp_rccl_single_rank():
         b.close()
     finally:
         dist.destroy_process_group()
+
+
+def _cold_sums(t, target, c, trans, it):
+    """Sums of one evaluation at a given pose from a FRESH session: its match[] is invalid,
+    so the walk runs without the previous-match pruning hint."""
+    s = icp.IcpSession(t, target, c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+    s.set_pose(trans, it)
+    s.partials()
+    out = s.read_sums()
+    s.close()
+    return out
+
+
+def test_hinted_walk_equals_cold_walk_every_iteration():
+    """Iterations >= 1 seed the walk's pruning bound with the previous iteration's match
+    (icp.hip load_query): the 10 sums must equal, bit for bit, those of a walk without hints."""
+    c = synth.c4_icp(n=30000, width=3.1)
+    t = kdtree.New(c["base"])
+    s = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+    for it in range(8):
+        trans, _, _ = s.result()
+        s.partials()
+        hinted = s.read_sums()
+        cold = _cold_sums(t, c["target"], c, trans, it)
+        assert hinted[9] > 0
+        assert np.array_equal(hinted.view(np.uint64), cold.view(np.uint64)), it
+        s.update()
+
+
+def test_hinted_walk_exact_ties():
+    """Lattice base, targets on cell centres (8 equidistant base points each), pose held at the
+    identity with iter = 1 so that hints are taken from a previous launch and every target still
+    ties exactly.  Sums and pair lists must equal the cold walk's and the oracle's."""
+    g = np.arange(20, dtype=np.float32) * f32(0.25)
+    base = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    rng = np.random.default_rng(5)
+    target = (base[rng.choice(len(base), 3000, replace=False)] + f32(0.125)).astype(np.float32)
+    c = dict(max_dist=0.5, min_pairs=6, weight=None, threshold=None, max_iteration=20)
+    t = kdtree.New(base)
+    ident = mat.Translate(0, 0, 0)
+    s = icp.IcpSession(t, target, c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+    s.partials()                     # iteration 0: fills match[]
+    first = s.read_sums()
+    s.set_pose(ident, 1)             # iter > 0: the next launch takes hints from match[]
+    s.partials()
+    hinted = s.read_sums()
+    cold = _cold_sums(t, target, c, ident, 1)
+    assert np.array_equal(hinted.view(np.uint64), cold.view(np.uint64))
+    assert np.array_equal(hinted.view(np.uint64), first.view(np.uint64))  # identity re-projection is exact
+    o = O.icp_evaluate(O.KDTree(base), target, 0.5, 6, sums_mode=1)
+    assert int(hinted[9]) == o["npairs"] == len(target)
+    ev = icp.FinishEvaluate(hinted, MinPairs=6)
+    assert abs(float(ev.Value) - float(o["value"])) <= 2e-7 * max(1.0, abs(float(o["value"])))
+    assert np.max(np.abs(ev.Gradient - o["gradient"])) <= 1e-6
