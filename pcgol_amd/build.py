@@ -26,7 +26,8 @@ def hipcc():
 
 def flags():
     return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-            "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-x", "hip"]
+            "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-x", "hip"] + \
+        os.environ.get("PCGX_EXTRA_CFLAGS", "").split()  # experiments only (e.g. -DPCGX_WALK_TOP_LEVELS=6)
 
 
 def needs_build():

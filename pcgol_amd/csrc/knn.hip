@@ -3,6 +3,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "knn_walk.h"
@@ -376,12 +378,12 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const flo
 }
 
 // Debug / profiling aid: runs the instrumented exact-mode walk over device queries and returns
-// its 16 counters (knn_walk.h).  d_hint_xyz (optional): per query the packed xyz of ANY point of
+// its 24 counters (knn_walk.h).  d_hint_xyz (optional): per query the packed xyz of ANY point of
 // the tree, used as the pruning hint the ICP loop takes from its previous iteration.  Not part of
 // the drop-in surface.
 extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
-                                             int32_t presort, const float *d_hint_xyz, uint64_t stats16[16]) {
-  if (!t || !d_q || !stats16 || nq <= 0) return fail(PCGX_E_INVALID, "pcgx_debug_walk_stats: bad argument");
+                                             int32_t presort, const float *d_hint_xyz, uint64_t stats24[24]) {
+  if (!t || !d_q || !stats24 || nq <= 0) return fail(PCGX_E_INVALID, "pcgx_debug_walk_stats: bad argument");
   PCGX_TRY(ensure_init());
   hipStream_t st = ctx().stream;
   Arena &ar = ctx().arena;
@@ -389,23 +391,51 @@ extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *
   unsigned long long *d_stats = nullptr;
   int32_t *d_ids = nullptr, *perm = nullptr;
   float *d_dsq = nullptr;
-  PCGX_TRY(ar.alloc_n(16, &d_stats));
+  PCGX_TRY(ar.alloc_n((size_t)24 * 4 * ((size_t)ctx().num_cu * 8 + 8), &d_stats));
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_ids));
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_dsq));
   if (presort) {
     PCGX_TRY(ar.alloc_n((size_t)nq, &perm));
     PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, perm, st));
   }
-  PCGX_HIP_TRY(hipMemsetAsync(d_stats, 0, 16 * sizeof(unsigned long long), st));
+  PCGX_HIP_TRY(hipMemsetAsync(d_stats, 0, 24 * sizeof(unsigned long long), st));
   const TreeView tv = t->view();
   int64_t blocks = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv);
   const int64_t max_blocks = (nq + kKnnBlock - 1) / kKnnBlock;
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks >= 8) blocks &= ~(int64_t)7;
-  hipLaunchKernelGGL((nearest_kernel<false, true>), dim3((unsigned)blocks), dim3(kKnnBlock), walk_lds_bytes(tv, kKnnBlock),
-                     st, tv, d_q, perm, nq, max_range * max_range, 0.0f, d_ids, d_dsq, d_stats, d_hint_xyz);
+  hipEvent_t ev0, ev1;
+  PCGX_HIP_TRY(hipEventCreate(&ev0));
+  PCGX_HIP_TRY(hipEventCreate(&ev1));
+  for (int rep = 0; rep < 2; rep++) {  // the first launch warms caches and TLBs: its timings are discarded
+    PCGX_HIP_TRY(hipMemsetAsync(d_stats, 0, (size_t)blocks * (kKnnBlock / 64) * 24 * sizeof(unsigned long long), st));
+    PCGX_HIP_TRY(hipEventRecord(ev0, st));
+    hipLaunchKernelGGL((nearest_kernel<false, true>), dim3((unsigned)blocks), dim3(kKnnBlock),
+                       walk_lds_bytes(tv, kKnnBlock), st, tv, d_q, perm, nq, max_range * max_range, 0.0f, d_ids,
+                       d_dsq, d_stats, d_hint_xyz);
+    PCGX_HIP_TRY(hipEventRecord(ev1, st));
+  }
   PCGX_HIP_TRY(hipGetLastError());
-  PCGX_HIP_TRY(hipMemcpyAsync(stats16, d_stats, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  std::vector<uint64_t> rows((size_t)blocks * (kKnnBlock / 64) * 24);
+  PCGX_HIP_TRY(hipMemcpyAsync(rows.data(), d_stats, rows.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
+  if (const char *dump = getenv("PCGX_DEBUG_WALK_ROWS")) {  // raw per-wave rows (uint64[waves][24]) for tools/
+    if (FILE *f = fopen(dump, "wb")) {
+      fwrite(rows.data(), sizeof(uint64_t), rows.size(), f);
+      fclose(f);
+    }
+  }
+  for (int k = 0; k < 24; k++) stats24[k] = 0;
+  for (size_t w = 0; w < rows.size() / 24; w++)
+    for (int k = 0; k < 24; k++) {
+      const uint64_t v = rows[w * 24 + k];
+      if (k == 15 || k == 18) stats24[k] = v > stats24[k] ? v : stats24[k];
+      else stats24[k] += v;
+    }
+  float ms = 0.0f;
+  PCGX_HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+  stats24[20] = (uint64_t)(ms * 1.0e6f);  // instrumented kernel, nanoseconds
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
   return PCGX_OK;
 }

@@ -131,7 +131,7 @@ __device__ __forceinline__ float4 node_at(const float4 *nodes, uint32_t b) {
   return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + off);
 }
 
-constexpr int kTopLevels = 11;                 // split values of levels 0..10 (BFS 1..2047) live in LDS
+constexpr int kTopLevels = kWalkTopLevels;     // split values of levels 0..10 (BFS 1..2047) live in LDS
 constexpr int kTopEntries = 1 << kTopLevels;   // 2048 floats = 8 KB per workgroup
 constexpr int kDeepGroup = 5;                  // deeper levels are fetched in groups of this many
 static_assert((kMaxLevels - kTopLevels) % kDeepGroup == 0, "deep levels must split into whole groups");
@@ -253,12 +253,15 @@ __device__ __forceinline__ void block_chunk_range(int64_t nq, uint32_t bid, uint
 // `queue`: this wave's LDS queue (kQueueWords * 64 words); `top`: the workgroup's LDS copy of the
 // top split values (load_top_levels); `next_chunk`: the workgroup's LDS chunk counter,
 // initialised to the first chunk of its range [.., chunk_end).
-// Optional instrumentation (kStats): per-wave counts accumulated into stats[] with atomics:
+// Optional instrumentation (kStats): per-wave counts, one row of 24 words per wave in stats[]
+// (summed by the host, [15] and [18] maximised):
 // [0] loop iterations, [1] active lanes summed over iterations, [2] node fetches (lanes),
 // [3] emit/refill sections run, [4] chunks prepared, [5] queries that verified down to the leaf,
 // [6] first-descent levels recorded in pend, [7] queries, [8] fetches while descending,
 // [9] explicit-frame pops, [10] of those passing the plane test, [11] first-descent pops,
-// [12] of those passing, [13] leaves evaluated in the loop.
+// [12] of those passing, [13] leaves evaluated in the loop, [14] iterations after the wave's last
+// query was handed out, [15] most iterations of any wave, [16] / [17] 100 MHz ticks summed over
+// waves before / after that hand-out, [18] longest wave (ticks), [19] waves.
 template <bool kMinDist, bool kStats = false, class Fetch, class Emit>
 __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__restrict__ stk,
                                              const int stk_stride, uint32_t *__restrict__ queue,
@@ -270,7 +273,7 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
   constexpr bool kExact = !kMinDist;
   unsigned long long st_iter = 0, st_active = 0, st_look = 0, st_refill = 0, st_prep = 0, st_verified = 0,
                      st_pend = 0, st_queries = 0, st_desc = 0, st_epop = 0, st_epass = 0, st_ipop = 0, st_ipass = 0,
-                     st_leaf = 0;
+                     st_leaf = 0, st_tail = 0;
   const int lane = (int)(threadIdx.x & 63u);
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const uint32_t m1 = (uint32_t)tv.n + 1u;
@@ -285,6 +288,8 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
   uint32_t b = 1, path_b = 1, pend = 0;
   int32_t sp = 0;
 
+  const unsigned long long t_start = kStats ? wall_clock64() : 0ull;
+  unsigned long long t_dry = 0ull;  // when the wave's last query was handed out
   for (;;) {
     // ---- emit finished lanes, prepare more queries, refill ------------------------
     // Divergent sections, so they run only once enough lanes are waiting (or nothing
@@ -294,6 +299,10 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
     if (kStats) {
       st_iter += 1;
       st_active += (unsigned long long)(64 - n_idle);
+      if (exhausted && q_head == q_count) {
+        st_tail += 1;
+        if (t_dry == 0ull) t_dry = wall_clock64();
+      }
     }
     if (n_idle >= tv.refill_threshold || n_idle == 64) {
       if (kStats) st_refill += 1;
@@ -444,6 +453,11 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
       pending = true;
     }
   }
+  unsigned long long t_end = 0ull;
+  if (kStats) {  // read the clock before the contended atomics below; the asm keeps it there
+    t_end = wall_clock64();
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(t_end)::"memory");
+  }
   if (kStats && stats) {
     // per-lane counters: sum over the wave; wave-uniform ones are taken from lane 0
     for (int o = 32; o > 0; o >>= 1) {
@@ -458,21 +472,15 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
       st_ipass += __shfl_down(st_ipass, o);
       st_leaf += __shfl_down(st_leaf, o);
     }
-    if (lane == 0) {
-      atomicAdd(stats + 0, st_iter);
-      atomicAdd(stats + 1, st_active);
-      atomicAdd(stats + 2, st_look);
-      atomicAdd(stats + 3, st_refill);
-      atomicAdd(stats + 4, st_prep);
-      atomicAdd(stats + 5, st_verified);
-      atomicAdd(stats + 6, st_pend);
-      atomicAdd(stats + 7, st_queries);
-      atomicAdd(stats + 8, st_desc);
-      atomicAdd(stats + 9, st_epop);
-      atomicAdd(stats + 10, st_epass);
-      atomicAdd(stats + 11, st_ipop);
-      atomicAdd(stats + 12, st_ipass);
-      atomicAdd(stats + 13, st_leaf);
+    if (lane == 0) {  // one row of 24 counters per wave: the host adds them up (no contended atomics)
+      unsigned long long *row =
+          stats + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 24;
+      if (t_dry == 0ull) t_dry = t_end;
+      row[0] = st_iter; row[1] = st_active; row[2] = st_look; row[3] = st_refill; row[4] = st_prep;
+      row[5] = st_verified; row[6] = st_pend; row[7] = st_queries; row[8] = st_desc; row[9] = st_epop;
+      row[10] = st_epass; row[11] = st_ipop; row[12] = st_ipass; row[13] = st_leaf; row[14] = st_tail;
+      row[15] = st_iter; row[16] = t_dry - t_start; row[17] = t_end - t_dry; row[18] = t_end - t_start;
+      row[19] = 1ull;
     }
   }
 }

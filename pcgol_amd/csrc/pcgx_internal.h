@@ -127,7 +127,11 @@ inline size_t walk_stack_bytes(const TreeView &tv, int block) {
   int levels = tv.depth > 1 ? tv.depth - 1 : 1;
   return (size_t)levels * block * sizeof(uint32_t);
 }
-constexpr int kWalkTopBytes = 2048 * 4;  // knn_walk.h kTopEntries floats
+#ifndef PCGX_WALK_TOP_LEVELS
+#define PCGX_WALK_TOP_LEVELS 11
+#endif
+constexpr int kWalkTopLevels = PCGX_WALK_TOP_LEVELS;  // levels whose split values a walk block keeps in LDS
+constexpr int kWalkTopBytes = (1 << kWalkTopLevels) * 4;
 inline size_t walk_lds_bytes(const TreeView &tv, int block) {
   return walk_stack_bytes(tv, block) + (size_t)(block / 64) * kWalkQueueBytesPerWave + kWalkTopBytes;
 }

@@ -28,12 +28,26 @@ if which == "c4h":
     hint_ptr = L.ptr(hint.data_ptr())
     q = synth.transform_points(poses[k], q)
 dq = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)).cuda()
-st = np.zeros(16, np.uint64)
+st = np.zeros(24, np.uint64)
 L.check(L.lib().pcgx_debug_walk_stats(t._h, L.ptr(dq.data_ptr()), len(q), mr, presort, hint_ptr, L.ptr(st)))
 it, act, look, refill, prep, ver, pend, nq, desc, epop, epass, ipop, ipass, leaf = [int(x) for x in st[:14]]
+tail, itmax = int(st[14]), int(st[15])
 print("%s presort=%d: queries %d, iterations(wave) %d = %.3f/query, active lane-steps %.2f/query (util %.1f%%), "
       "node fetches %.2f/query, refill sections %d, chunks %d, verified %.1f%%, pend levels %.2f/query" %
       (which, presort, nq, it, it / nq, act / nq, 100.0 * act / (64.0 * it), look / nq, refill, prep,
        100.0 * ver / nq, pend / nq))
 print("  per query: descending fetches %.2f (leaves %.2f), explicit pops %.2f (passing %.2f), first-descent pops %.2f (passing %.2f)"
       % (desc / nq, leaf / nq, epop / nq, epass / nq, ipop / nq, ipass / nq))
+print("  iterations after a wave's last hand-out %.1f%% of all, most iterations of one wave %d" % (100.0 * tail / it, itmax))
+w = max(int(st[19]), 1)
+print("  instrumented kernel %.1f us; per wave: %.0f ticks until the last hand-out, %.0f after it; longest wave %d ticks"
+      % (int(st[20]) / 1e3, int(st[16]) / w, int(st[17]) / w, int(st[18])))
+if os.environ.get("PCGX_DEBUG_WALK_ROWS"):
+    r = np.fromfile(os.environ["PCGX_DEBUG_WALK_ROWS"], np.uint64).reshape(-1, 24).astype(np.float64)
+    dur, it_w, dry = r[:, 18] / 100.0, r[:, 0], r[:, 16] / 100.0
+    pct = lambda a: " ".join("%.1f" % x for x in np.percentile(a, [0, 10, 50, 90, 99, 100]))
+    print("  per wave (min p10 p50 p90 p99 max): duration us %s | until last hand-out us %s | iterations %s | queries %s"
+          % (pct(dur), pct(dry), pct(it_w), pct(r[:, 7])))
+    blk = dur.reshape(-1, 4).max(axis=1)
+    print("  per block duration us: %s; per XCD (block %% 8) mean of block durations: %s"
+          % (pct(blk), " ".join("%.1f" % blk[i::8].mean() for i in range(8))))
