@@ -83,10 +83,12 @@ PCGX_API pcgx_status pcgx_prof_reset(void);
  * sections, chunks prepared, queries verified to the leaf, first-descent levels kept, queries,
  * fetches while descending, explicit pops, passing, first-descent pops, passing, leaves,
  * iterations after the last hand-out, most iterations of a wave, 100 MHz ticks summed over waves
- * before / after the last hand-out, longest wave in ticks, -...}. */
+ * before / after the last hand-out, longest wave in ticks, waves, kernel ns, queries finished
+ * inside the preparation, lane-steps / iterations of its descent loop, ticks per phase (6), -, -}. */
 typedef struct pcgx_kdtree pcgx_kdtree;
 PCGX_API pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
-                                           int32_t presort, const float *d_hint_xyz, uint64_t stats24[24]);
+                                           int32_t presort, const float *d_hint_xyz, uint32_t *d_leaf_io,
+                                           uint64_t stats32[32]);
 
 /* Device memory helpers for hosts that have no HIP binding of their own. */
 PCGX_API pcgx_status pcgx_dev_alloc(size_t bytes, void **dptr);

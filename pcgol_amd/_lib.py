@@ -89,7 +89,7 @@ SIGNATURES = {
     "pcgx_prof_enable": (_i32, [_i32]),
     "pcgx_prof_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "pcgx_prof_reset": (_i32, []),
-    "pcgx_debug_walk_stats": (_i32, [_vp, _vp, _i64, _f32, _i32, _vp, _vp]),
+    "pcgx_debug_walk_stats": (_i32, [_vp, _vp, _i64, _f32, _i32, _vp, _vp, _vp]),
     "pcgx_dev_alloc": (_i32, [_sz, C.POINTER(_vp)]),
     "pcgx_dev_free": (_i32, [_vp]),
     "pcgx_dev_upload": (_i32, [_vp, _vp, _sz]),

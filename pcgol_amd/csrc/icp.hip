@@ -68,7 +68,8 @@ template <bool kMinDist>
 __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     TreeView tv, const float *__restrict__ tx, const float *__restrict__ ty,
     const float *__restrict__ tz, int64_t nt, const IcpState *__restrict__ state,
-    IcpKernelParams kp, float4 *__restrict__ match, double *__restrict__ block_partials) {
+    IcpKernelParams kp, float4 *__restrict__ match, uint32_t *__restrict__ first_leaf,
+    double *__restrict__ block_partials) {
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
   if (state->done) return;  // uniform
@@ -98,21 +99,34 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
   // previous iteration: its distance to the re-projected target bounds the new nearest distance
   // from above and seeds the walk's pruning bound (knn_walk.h, "Pruning bound"; exact mode only).
   // A session's match[] starts out invalid (w = NaN) and only ever holds points of its tree.
-  auto load_query = [&](int64_t i, float &x, float &y, float &z, float &ub) {
-    load_target(i, x, y, z);
-    ub = __builtin_inff();
-    if (!kMinDist && project) {
-      const float4 pm = match[i];
-      const float dx = pm.x - x, dy = pm.y - y, dz = pm.z - z;
-      if (pm.w >= 0.0f) ub = (dx * dx + dy * dy) + dz * dz;
+  // Likewise first_leaf[i] holds the leaf the target's first descent ended in last time (0: none):
+  // the re-projected target has hardly moved, so it predicts this iteration's descent far better
+  // than the grid directory does (the prediction is verified either way).
+  auto load_query = [&](int64_t i, float &x, float &y, float &z, float &ub, uint32_t &pred) {
+    // every load is issued before the first use: one memory round trip per chunk
+    const float x0 = tx[i], y0 = ty[i], z0 = tz[i];
+    float4 pm = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    pred = 0u;
+    if (project) {  // uniform
+      pred = first_leaf[i];
+      if (!kMinDist) pm = match[i];
     }
+    x = x0; y = y0; z = z0;
+    if (project) mat4_transform(m, x0, y0, z0, x, y, z);
+    // The distance is used arithmetically whatever w says, so the compiler cannot split the
+    // 16-byte load into "w first, xyz if valid" (two dependent round trips).  dm + 0 is dm
+    // exactly; an invalid record gives +inf or NaN, neither tightens the bound.
+    const float dx = pm.x - x, dy = pm.y - y, dz = pm.z - z;
+    const float dm = (dx * dx + dy * dy) + dz * dz;
+    ub = dm + (pm.w >= 0.0f ? 0.0f : __builtin_inff());
   };
   walk_queries<kMinDist>(
-      tv, s_stack + threadIdx.x, kIcpBlock, queue, top, nt, &s_next_chunk, chunk_end, kp.max_dist_sq, kp.min_dist_sq,
-      load_query,
+      tv, s_stack + threadIdx.x, kIcpBlock, queue, top, nt, &s_next_chunk, chunk_end, (int64_t)chunk_begin * 64,
+      kp.max_dist_sq, kp.min_dist_sq, load_query,
       [&](int64_t i, const float4 &bp, float best_d) {
         match[i] = make_float4(bp.x, bp.y, bp.z, __float_as_int(bp.w) >= 0 ? best_d : -1.0f);
-      });
+      },
+      [&](int64_t i, uint32_t leaf) { first_leaf[i] = leaf; });
 
   // ---- phase 2: this workgroup's range, fixed order
   __threadfence_block();
@@ -224,6 +238,7 @@ struct pcgx_icp_session {
   IcpState *d_state = nullptr;
   double *d_partials = nullptr;
   float4 *d_match = nullptr;       // [nt] matched base point + DistSq per target
+  uint32_t *d_first_leaf = nullptr;  // [nt] leaf the target's first descent ended in (0: unknown)
   double *d_sums = nullptr;  // caller's buffer, or own
   bool own_sums = false;
   int grid = 1;
@@ -291,6 +306,7 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   if (s->d_state) (void)hipFree(s->d_state);
   if (s->d_partials) (void)hipFree(s->d_partials);
   if (s->d_match) (void)hipFree(s->d_match);
+  if (s->d_first_leaf) (void)hipFree(s->d_first_leaf);
   if (s->own_sums && s->d_sums) (void)hipFree(s->d_sums);
   delete s;
   return PCGX_OK;
@@ -321,7 +337,8 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
   if ((e = hipMalloc((void **)&s->d_xyz, (size_t)(nt ? nt : 1) * 12)) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_state, sizeof(IcpState))) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_partials, (size_t)s->grid * S_COUNT * sizeof(double))) != hipSuccess ||
-      (e = hipMalloc((void **)&s->d_match, (size_t)(nt ? nt : 1) * sizeof(float4))) != hipSuccess)
+      (e = hipMalloc((void **)&s->d_match, (size_t)(nt ? nt : 1) * sizeof(float4))) != hipSuccess ||
+      (e = hipMalloc((void **)&s->d_first_leaf, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess)
     return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
   if (d_sums10) {
     s->d_sums = d_sums10;
@@ -332,7 +349,8 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
   }
   if ((rc = reset_state(s, st)) != PCGX_OK) return bail(rc);
   // no previous match yet: w = NaN (icp_corr_kernel takes pruning hints from match[] only when w >= 0)
-  if ((e = hipMemsetAsync(s->d_match, 0xFF, (size_t)(nt ? nt : 1) * sizeof(float4), st)) != hipSuccess)
+  if ((e = hipMemsetAsync(s->d_match, 0xFF, (size_t)(nt ? nt : 1) * sizeof(float4), st)) != hipSuccess ||
+      (e = hipMemsetAsync(s->d_first_leaf, 0, (size_t)(nt ? nt : 1) * sizeof(uint32_t), st)) != hipSuccess)
     return bail(fail(PCGX_E_HIP, "icp session: hipMemsetAsync failed: %s", hipGetErrorString(e)));
   if (nt > 0) {
     Arena &ar = ctx().arena;
@@ -366,10 +384,10 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   ProfScope prof(PCGX_PROF_ICP_WALK, st);
   if (s->kp.min_dist_sq > 0.0f)
     hipLaunchKernelGGL(icp_corr_kernel<true>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                       s->d_state, s->kp, s->d_match, s->d_partials);
+                       s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials);
   else
     hipLaunchKernelGGL(icp_corr_kernel<false>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                       s->d_state, s->kp, s->d_match, s->d_partials);
+                       s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials);
   return PCGX_OK;
 }
 

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
                                                             int32_t *__restrict__ out_id,
                                                             float *__restrict__ out_dsq,
                                                             unsigned long long *__restrict__ stats = nullptr,
-                                                            const float *__restrict__ hint = nullptr) {
+                                                            const float *__restrict__ hint = nullptr,
+                                                            uint32_t *__restrict__ leaf_io = nullptr) {
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
   uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kKnnBlock +
@@ -35,8 +36,10 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
   if (threadIdx.x == 0) s_next_chunk = chunk_begin;
   __syncthreads();
   walk_queries<kMinDist, kStats>(
-      tv, s_stack + threadIdx.x, kKnnBlock, queue, top, nq, &s_next_chunk, chunk_end, max_range_sq, min_dist_sq,
-      [&](int64_t pos, float &x, float &y, float &z, float &ub) {
+      tv, s_stack + threadIdx.x, kKnnBlock, queue, top, nq, &s_next_chunk, chunk_end, (int64_t)chunk_begin * 64,
+      max_range_sq, min_dist_sq,
+      [&](int64_t pos, float &x, float &y, float &z, float &ub, uint32_t &pred) {
+        pred = (kStats && leaf_io) ? leaf_io[perm ? (int64_t)perm[pos] : pos] : 0u;
         const int64_t i = perm ? (int64_t)perm[pos] : pos;
         x = q[3 * i + 0];
         y = q[3 * i + 1];
@@ -51,6 +54,9 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
         const int64_t i = perm ? (int64_t)perm[pos] : pos;
         out_id[i] = __float_as_int(best.w);
         out_dsq[i] = best_d;
+      },
+      [&](int64_t pos, uint32_t leaf) {
+        if (kStats && leaf_io) leaf_io[perm ? (int64_t)perm[pos] : pos] = leaf;
       },
       stats);
 }
@@ -85,8 +91,35 @@ __global__ __launch_bounds__(256) void dir_build_kernel(TreeView tv, uint32_t *_
 int walk_refill_threshold() {
   static int v = -1;
   if (v < 0) {
-    v = 8;
+    v = 16;
     if (const char *e = getenv("PCGX_WALK_REFILL")) {
+      const int t = atoi(e);
+      if (t >= 1 && t <= 64) v = t;
+    }
+  }
+  return v;
+}
+
+// Levels the preparation of a chunk follows the real descent below a wrong prediction, all such
+// lanes in lockstep, before it leaves the rest to the stepping loop (knn_walk.h).
+int walk_tight_levels() {
+  static int v = -1;
+  if (v < 0) {
+    v = 0;
+    if (const char *e = getenv("PCGX_WALK_TIGHT")) {
+      const int t = atoi(e);
+      if (t >= 0 && t <= 32) v = t;
+    }
+  }
+  return v;
+}
+
+// Chunks a wave may prepare in one refill section while its queue cannot serve every waiting lane.
+int walk_chunks_per_refill() {
+  static int v = -1;
+  if (v < 0) {
+    v = 1;
+    if (const char *e = getenv("PCGX_WALK_CHUNKS_PER_REFILL")) {
       const int t = atoi(e);
       if (t >= 1 && t <= 64) v = t;
     }
@@ -378,12 +411,14 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const flo
 }
 
 // Debug / profiling aid: runs the instrumented exact-mode walk over device queries and returns
-// its 24 counters (knn_walk.h).  d_hint_xyz (optional): per query the packed xyz of ANY point of
-// the tree, used as the pruning hint the ICP loop takes from its previous iteration.  Not part of
-// the drop-in surface.
+// its 32 counters (knn_walk.h).  d_hint_xyz (optional): per query the packed xyz of ANY point of
+// the tree, used as the pruning hint the ICP loop takes from its previous iteration; d_leaf_io
+// (optional, uint32 per query, 0 = none): predicted first-descent leaves in, the real ones out,
+// as the ICP loop carries them from one iteration to the next.  Not part of the drop-in surface.
 extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
-                                             int32_t presort, const float *d_hint_xyz, uint64_t stats24[24]) {
-  if (!t || !d_q || !stats24 || nq <= 0) return fail(PCGX_E_INVALID, "pcgx_debug_walk_stats: bad argument");
+                                             int32_t presort, const float *d_hint_xyz, uint32_t *d_leaf_io,
+                                             uint64_t stats32[32]) {
+  if (!t || !d_q || !stats32 || nq <= 0) return fail(PCGX_E_INVALID, "pcgx_debug_walk_stats: bad argument");
   PCGX_TRY(ensure_init());
   hipStream_t st = ctx().stream;
   Arena &ar = ctx().arena;
@@ -391,14 +426,13 @@ extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *
   unsigned long long *d_stats = nullptr;
   int32_t *d_ids = nullptr, *perm = nullptr;
   float *d_dsq = nullptr;
-  PCGX_TRY(ar.alloc_n((size_t)24 * 4 * ((size_t)ctx().num_cu * 8 + 8), &d_stats));
+  PCGX_TRY(ar.alloc_n((size_t)kStatWords * 4 * ((size_t)ctx().num_cu * 8 + 8), &d_stats));
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_ids));
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_dsq));
   if (presort) {
     PCGX_TRY(ar.alloc_n((size_t)nq, &perm));
     PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, perm, st));
   }
-  PCGX_HIP_TRY(hipMemsetAsync(d_stats, 0, 24 * sizeof(unsigned long long), st));
   const TreeView tv = t->view();
   int64_t blocks = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv);
   const int64_t max_blocks = (nq + kKnnBlock - 1) / kKnnBlock;
@@ -408,15 +442,15 @@ extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *
   PCGX_HIP_TRY(hipEventCreate(&ev0));
   PCGX_HIP_TRY(hipEventCreate(&ev1));
   for (int rep = 0; rep < 2; rep++) {  // the first launch warms caches and TLBs: its timings are discarded
-    PCGX_HIP_TRY(hipMemsetAsync(d_stats, 0, (size_t)blocks * (kKnnBlock / 64) * 24 * sizeof(unsigned long long), st));
+    PCGX_HIP_TRY(hipMemsetAsync(d_stats, 0, (size_t)blocks * (kKnnBlock / 64) * kStatWords * sizeof(unsigned long long), st));
     PCGX_HIP_TRY(hipEventRecord(ev0, st));
     hipLaunchKernelGGL((nearest_kernel<false, true>), dim3((unsigned)blocks), dim3(kKnnBlock),
                        walk_lds_bytes(tv, kKnnBlock), st, tv, d_q, perm, nq, max_range * max_range, 0.0f, d_ids,
-                       d_dsq, d_stats, d_hint_xyz);
+                       d_dsq, d_stats, d_hint_xyz, d_leaf_io);
     PCGX_HIP_TRY(hipEventRecord(ev1, st));
   }
   PCGX_HIP_TRY(hipGetLastError());
-  std::vector<uint64_t> rows((size_t)blocks * (kKnnBlock / 64) * 24);
+  std::vector<uint64_t> rows((size_t)blocks * (kKnnBlock / 64) * kStatWords);
   PCGX_HIP_TRY(hipMemcpyAsync(rows.data(), d_stats, rows.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
   if (const char *dump = getenv("PCGX_DEBUG_WALK_ROWS")) {  // raw per-wave rows (uint64[waves][24]) for tools/
@@ -425,16 +459,16 @@ extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *
       fclose(f);
     }
   }
-  for (int k = 0; k < 24; k++) stats24[k] = 0;
-  for (size_t w = 0; w < rows.size() / 24; w++)
-    for (int k = 0; k < 24; k++) {
-      const uint64_t v = rows[w * 24 + k];
-      if (k == 15 || k == 18) stats24[k] = v > stats24[k] ? v : stats24[k];
-      else stats24[k] += v;
+  for (int k = 0; k < kStatWords; k++) stats32[k] = 0;
+  for (size_t w = 0; w < rows.size() / kStatWords; w++)
+    for (int k = 0; k < kStatWords; k++) {
+      const uint64_t v = rows[w * kStatWords + k];
+      if (k == 15 || k == 18) stats32[k] = v > stats32[k] ? v : stats32[k];
+      else stats32[k] += v;
     }
   float ms = 0.0f;
   PCGX_HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-  stats24[20] = (uint64_t)(ms * 1.0e6f);  // instrumented kernel, nanoseconds
+  stats32[20] = (uint64_t)(ms * 1.0e6f);  // instrumented kernel, nanoseconds
   (void)hipEventDestroy(ev0);
   (void)hipEventDestroy(ev1);
   return PCGX_OK;

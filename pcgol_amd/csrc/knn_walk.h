@@ -107,17 +107,20 @@ __device__ __forceinline__ uint32_t node_size(uint32_t b, int depth, uint32_t m1
   return (m1 >> depth) - 1u + (rev < rem ? 1u : 0u);
 }
 
-// State a prepared query starts the stepping loop with (= one LDS queue entry).
+// Result of the per-lane part of a chunk's preparation (prepare_query).
 struct Prepared {
-  float qx, qy, qz;
-  float best_d;       // running best (kdtree.go neighbor1.DistSq)
-  float bound_d;      // pruning bound: min(best, ub) in exact mode, = best otherwise
-  float4 best;        // record of the current best {x, y, z, bits(id)}, id < 0 = none
-  uint32_t path_b;    // deepest verified node of the first descent, plus the flags below
-  uint32_t pend;      // first-descent levels still to examine
+  float bound0;       // bound for recording first-descent levels (maxRange^2, ub folded in when exact)
+  float ub;           // min(distance to the predicted leaf's point, caller's hint): >= d*
+  float4 leaf;        // the predicted leaf's record
+  float d_leaf;       // its distance
+  uint32_t path_b;    // deepest node of the predicted path the real descent is known to reach
+  int32_t depth;      // its depth
+  uint32_t pend;      // levels above it whose plane test can still pass (bit j = level j)
+  bool verified;      // path_b is the predicted leaf: the prediction was right
 };
-constexpr uint32_t kPathFinished = 0x80000000u;  // query finished inside prepare (MinDistSq cut)
-constexpr uint32_t kPathDescend = 0x40000000u;   // prediction failed at path_b: descend from there
+// Queue entry word 4: BFS index of the deepest verified node | flags
+constexpr uint32_t kPathDescend = 0x40000000u;    // the first descent is not finished: descend from path_b
+constexpr uint32_t kPathLeafTaken = 0x20000000u;  // path_b is the first leaf and it is the running best
 constexpr uint32_t kPathMask = 0x07FFFFFFu;
 
 // One float of node b; 32-bit byte offset (tree < 2^27 slots x 16 B) so the load uses
@@ -146,23 +149,24 @@ __device__ __forceinline__ void load_top_levels(const TreeView &tv, float *__res
   }
 }
 
+// Per-lane part of the preparation: predicted leaf (the caller's `pred` if it has one, else the
+// grid directory), one round of fetches for the predicted path, verification.
 template <bool kExact>
 __device__ __forceinline__ Prepared prepare_query(const TreeView &tv, const float *__restrict__ top, float qx,
-                                                  float qy, float qz, float max_range_sq, float min_dist_sq,
-                                                  float ub_hint) {
+                                                  float qy, float qz, float max_range_sq, float ub_hint,
+                                                  uint32_t pred) {
   Prepared p;
-  p.qx = qx; p.qy = qy; p.qz = qz;
-  p.best_d = max_range_sq;
-  p.best = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
   const uint32_t m1 = (uint32_t)tv.n + 1u;
-  // --- predicted leaf from the grid directory
-  const int g = tv.dir_bits;
-  const float cmax = (float)((1 << g) - 1);
-  const float fx = fminf(fmaxf((qx - tv.dir_lo[0]) * tv.dir_scale[0], 0.0f), cmax);
-  const float fy = fminf(fmaxf((qy - tv.dir_lo[1]) * tv.dir_scale[1], 0.0f), cmax);
-  const float fz = fminf(fmaxf((qz - tv.dir_lo[2]) * tv.dir_scale[2], 0.0f), cmax);
-  const uint32_t cell = (uint32_t)fx | ((uint32_t)fy << g) | ((uint32_t)fz << (2 * g));
-  const uint32_t bl = tv.dir[cell];
+  uint32_t bl = pred;
+  if (pred == 0u || pred >= (1u << tv.depth)) {  // no (usable) prediction from the caller: grid directory
+    const int g = tv.dir_bits;
+    const float cmax = (float)((1 << g) - 1);
+    const float fx = fminf(fmaxf((qx - tv.dir_lo[0]) * tv.dir_scale[0], 0.0f), cmax);
+    const float fy = fminf(fmaxf((qy - tv.dir_lo[1]) * tv.dir_scale[1], 0.0f), cmax);
+    const float fz = fminf(fmaxf((qz - tv.dir_lo[2]) * tv.dir_scale[2], 0.0f), cmax);
+    const uint32_t cell = (uint32_t)fx | ((uint32_t)fy << g) | ((uint32_t)fz << (2 * g));
+    bl = tv.dir[cell];
+  }
   const int L = 31 - __clz((int)bl);  // depth of the predicted leaf = inner levels above it
   // The predicted path extended to kMaxLevels: its ancestor at level j is ext >> (kMaxLevels - j)
   // for every j; for j >= L that is a slot without a node (those levels are masked off below).
@@ -196,8 +200,8 @@ __device__ __forceinline__ Prepared prepare_query(const TreeView &tv, const floa
   // Bound for recording a level in `pend`: the best while the reference descends (= maxRange^2),
   // tightened by ub in exact mode (header, "Pruning bound").  fminf drops a NaN operand: a NaN
   // hint or leaf distance simply does not tighten the bound.
-  const float ub = fminf(d_leaf, ub_hint);
-  const float bound0 = kExact ? fminf(max_range_sq, ub) : max_range_sq;
+  const float ub = kExact ? fminf(d_leaf, ub_hint) : __builtin_inff();
+  const float bound0 = fminf(max_range_sq, ub);
 
   // --- per level: does the real descent go to child1 (kdtree.go:216: pivotVal > val -> child0),
   //     and can the level's plane test still pass.  One bit per level, shifted in root first.
@@ -216,24 +220,22 @@ __device__ __forceinline__ Prepared prepare_query(const TreeView &tv, const floa
   const bool verified = wrong == 0u;
   const int m = verified ? L : __clz((int)wrong) - (32 - kMaxLevels);  // first level where the prediction fails
 
-  // --- the leaf (kdtree.go:95-106), only if the real descent arrives there
-  bool finished = false;
-  if (verified) {
-    if (!(d_leaf > p.best_d)) {
-      p.best_d = d_leaf;
-      p.best = leaf;
-    }
-    if (!kExact && p.best_d < min_dist_sq) finished = true;
-  }
-  p.bound_d = kExact ? fminf(p.best_d, ub) : p.best_d;
-  p.path_b = (bl >> (L - m)) | (finished ? kPathFinished : 0u) | (verified ? 0u : kPathDescend);
+  p.bound0 = bound0;
+  p.ub = ub;
+  p.leaf = leaf;
+  p.d_leaf = d_leaf;
+  p.path_b = bl >> (L - m);
+  p.depth = m;
   // only levels above the mismatch; stored with bit j = level j
-  p.pend = (near >> (kMaxLevels - m)) == 0u ? 0u : __brev(near >> (kMaxLevels - m)) >> ((32 - m) & 31);
+  p.pend = __brev(near >> (kMaxLevels - m)) >> ((32 - m) & 31);
+  p.verified = verified;
   return p;
 }
 
-constexpr int kQueueWords = 10;  // LDS queue entry words (SoA [word][slot], 64 slots per wave)
-static_assert(kQueueWords * 64 * 4 == kWalkQueueBytesPerWave, "pcgx_internal.h kWalkQueueBytesPerWave");
+constexpr int kStatWords = 32;    // instrumentation: counters per wave
+constexpr int kQueueWords = 7;    // LDS queue entry words (SoA [word][slot])
+constexpr int kQueueSlots = 128;  // ring of prepared queries per wave: < 64 left over + <= 64 new
+static_assert(kQueueWords * kQueueSlots * 4 == kWalkQueueBytesPerWave, "pcgx_internal.h kWalkQueueBytesPerWave");
 
 // Chunk range [begin, end) of workgroup `bid` out of `nblocks` (a multiple of 8, or < 8):
 // workgroups with equal bid % 8 get adjacent ranges.
@@ -246,40 +248,54 @@ __device__ __forceinline__ void block_chunk_range(int64_t nq, uint32_t bid, uint
   end = (uint32_t)(n_chunks * (slot + 1) / nblocks);
 }
 
-// fetch(idx, qx, qy, qz, ub): loads query idx; ub = squared distance (the walk's own float32
+// fetch(idx, qx, qy, qz, ub, pred): loads query idx.  ub = squared distance (the walk's own float32
 // expression) from the query to ANY point stored in the tree, or +inf: a pruning hint used in
-// exact mode only (header, "Pruning bound").   emit(idx, best, best_d): consumes the result;
-// best = {x, y, z, bits(id)} of the matched base point, id < 0 = no match.
-// `queue`: this wave's LDS queue (kQueueWords * 64 words); `top`: the workgroup's LDS copy of the
-// top split values (load_top_levels); `next_chunk`: the workgroup's LDS chunk counter,
-// initialised to the first chunk of its range [.., chunk_end).
-// Optional instrumentation (kStats): per-wave counts, one row of 24 words per wave in stats[]
+// exact mode only (header, "Pruning bound").  pred = BFS index of the LEAF the caller expects the
+// query's first descent to end in, or 0 (then the grid directory predicts it).
+// emit(idx, best, best_d): consumes the result; best = {x, y, z, bits(id)} of the matched base
+// point, id < 0 = no match.   note_leaf(idx, leaf): the leaf the first descent really ended in, or
+// 0 if the preparation did not get that far (a caller may feed it back as `pred` next time).
+// `queue`: this wave's LDS queue (kQueueWords * kQueueSlots words); `top`: the workgroup's LDS copy
+// of the top split values (load_top_levels); `next_chunk`: the workgroup's LDS chunk counter,
+// initialised to the first chunk of its range [range_first / 64, chunk_end).
+// Optional instrumentation (kStats): per-wave counts, one row of kStatWords words per wave in stats[]
 // (summed by the host, [15] and [18] maximised):
 // [0] loop iterations, [1] active lanes summed over iterations, [2] node fetches (lanes),
-// [3] emit/refill sections run, [4] chunks prepared, [5] queries that verified down to the leaf,
+// [3] emit/refill sections run, [4] chunks prepared, [5] queries whose prediction verified,
 // [6] first-descent levels recorded in pend, [7] queries, [8] fetches while descending,
 // [9] explicit-frame pops, [10] of those passing the plane test, [11] first-descent pops,
 // [12] of those passing, [13] leaves evaluated in the loop, [14] iterations after the wave's last
-// query was handed out, [15] most iterations of any wave, [16] / [17] 100 MHz ticks summed over
-// waves before / after that hand-out, [18] longest wave (ticks), [19] waves.
-template <bool kMinDist, bool kStats = false, class Fetch, class Emit>
+// query was handed out, [15] most iterations of any wave, [16] / [17] 100 MHz ticks before / after
+// that hand-out, [18] longest wave (ticks), [19] waves, [20] (host) kernel ns, [21] queries finished
+// inside the preparation, [22] lane-steps of the preparation's descent loop, [23] its iterations,
+// [24..29] ticks in: query fetch, path fetch + verification, descent loop, first leaf + emit +
+// enqueue, taking queued queries, stepping.
+template <bool kMinDist, bool kStats = false, class Fetch, class Emit, class NoteLeaf>
 __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__restrict__ stk,
                                              const int stk_stride, uint32_t *__restrict__ queue,
                                              const float *__restrict__ top, const int64_t nq,
                                              uint32_t *__restrict__ next_chunk, const uint32_t chunk_end,
-                                             const float max_range_sq, const float min_dist_sq,
-                                             Fetch &&fetch, Emit &&emit,
-                                             unsigned long long *__restrict__ stats = nullptr) {
+                                             const int64_t range_first, const float max_range_sq,
+                                             const float min_dist_sq, Fetch &&fetch, Emit &&emit,
+                                             NoteLeaf &&note_leaf, unsigned long long *__restrict__ stats = nullptr) {
   constexpr bool kExact = !kMinDist;
   unsigned long long st_iter = 0, st_active = 0, st_look = 0, st_refill = 0, st_prep = 0, st_verified = 0,
                      st_pend = 0, st_queries = 0, st_desc = 0, st_epop = 0, st_epass = 0, st_ipop = 0, st_ipass = 0,
-                     st_leaf = 0, st_tail = 0;
+                     st_leaf = 0, st_tail = 0, st_early = 0, st_tsteps = 0, st_titer = 0;
+  unsigned long long tk_fetch = 0, tk_path = 0, tk_tight = 0, tk_finish = 0, tk_take = 0, tk_step = 0, tk_mark = 0;
+  auto lap = [&](unsigned long long &acc) {  // kStats: time since the previous lap goes to acc
+    if (kStats) {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const unsigned long long now = wall_clock64();
+      acc += now - tk_mark;
+      tk_mark = now;
+    }
+  };
   const int lane = (int)(threadIdx.x & 63u);
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   const uint32_t m1 = (uint32_t)tv.n + 1u;
-  bool exhausted = false;           // wave-uniform: the workgroup's range is used up
-  int32_t q_head = 0, q_count = 0;  // wave-uniform: LDS queue state
-  int64_t q_base = 0;               // wave-uniform: first query of the queued chunk
+  bool exhausted = false;            // wave-uniform: the workgroup's range is used up
+  uint32_t q_head = 0, q_tail = 0;   // wave-uniform: LDS ring [q_head, q_tail), slot = index % kQueueSlots
 
   bool active = false, pending = false, desc = false;
   int64_t my_q = 0;
@@ -289,6 +305,7 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
   int32_t sp = 0;
 
   const unsigned long long t_start = kStats ? wall_clock64() : 0ull;
+  tk_mark = t_start;
   unsigned long long t_dry = 0ull;  // when the wave's last query was handed out
   for (;;) {
     // ---- emit finished lanes, prepare more queries, refill ------------------------
@@ -299,90 +316,149 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
     if (kStats) {
       st_iter += 1;
       st_active += (unsigned long long)(64 - n_idle);
-      if (exhausted && q_head == q_count) {
+      if (exhausted && q_head == q_tail) {
         st_tail += 1;
         if (t_dry == 0ull) t_dry = wall_clock64();
       }
     }
+    lap(tk_step);
     if (n_idle >= tv.refill_threshold || n_idle == 64) {
       if (kStats) st_refill += 1;
       if (pending) {
         emit(my_q, best, best_d);
         pending = false;
       }
-      if (q_head == q_count && !exhausted) {
-        // queue empty: take the next chunk; all 64 lanes prepare one query each, whatever
-        // they are walking
+      // ---- prepare chunks while the queue cannot serve every waiting lane (at most
+      //      chunks_per_refill in a row).  All 64 lanes prepare one query each, whatever they are
+      //      walking (full lane efficiency).
+      for (int k = 0; k < tv.chunks_per_refill && (int)(q_tail - q_head) < n_idle && !exhausted; k++) {
         uint32_t c = 0;
         if (lane == 0) c = atomicAdd(next_chunk, 1u);  // LDS atomic
         c = __builtin_amdgcn_readfirstlane(c);
-        q_head = 0;
-        q_count = 0;
+        int32_t cnt = 0;
+        const int64_t c_base = (int64_t)c * 64;
         if (c < chunk_end) {
-          q_base = (int64_t)c * 64;
-          const int64_t left = nq - q_base;
-          q_count = left >= 64 ? 64 : (int32_t)left;
+          const int64_t left = nq - c_base;
+          cnt = left >= 64 ? 64 : (int32_t)left;
         }
         exhausted = c + 1u >= chunk_end;
         if (kStats) st_prep += 1;
-        const int64_t idx = q_base + lane;
-        if (lane < q_count) {
-          float x, y, z, ub_hint;
-          fetch(idx, x, y, z, ub_hint);
-          const Prepared p = prepare_query<kExact>(tv, top, x, y, z, max_range_sq, min_dist_sq, ub_hint);
+        const int64_t idx = c_base + lane;
+        const bool valid = lane < cnt;
+        float x = 0.0f, y = 0.0f, z = 0.0f, ub_hint = __builtin_inff();
+        uint32_t pred = 0;
+        Prepared p = {};
+        bool unresolved = false;
+        if (valid) fetch(idx, x, y, z, ub_hint, pred);
+        lap(tk_fetch);
+        if (valid) {
+          p = prepare_query<kExact>(tv, top, x, y, z, max_range_sq, ub_hint, pred);
+          unresolved = !p.verified;
           if (kStats) {
             st_queries += 1;
-            st_verified += (p.path_b & kPathDescend) == 0u;
-            st_pend += (unsigned long long)__popc(p.pend);
+            st_verified += p.verified;
           }
-          queue[0 * 64 + lane] = __float_as_uint(p.qx);
-          queue[1 * 64 + lane] = __float_as_uint(p.qy);
-          queue[2 * 64 + lane] = __float_as_uint(p.qz);
-          // best_d is implied: the distance to `best` if there is one (recomputed bit-identically
-          // when the entry is taken), else maxRange^2
-          queue[3 * 64 + lane] = __float_as_uint(p.bound_d);
-          queue[4 * 64 + lane] = p.path_b;
-          queue[5 * 64 + lane] = p.pend;
-          queue[6 * 64 + lane] = __float_as_uint(p.best.x);
-          queue[7 * 64 + lane] = __float_as_uint(p.best.y);
-          queue[8 * 64 + lane] = __float_as_uint(p.best.z);
-          queue[9 * 64 + lane] = __float_as_uint(p.best.w);
         }
+        // ---- wrong prediction: the real descent continues below the mismatch with the
+        //      reference's steps (kdtree.go:202-221), all such lanes of the chunk in lockstep and
+        //      for a bounded number of levels; whoever is still not at a leaf finishes the
+        //      descent in the stepping loop.
+        lap(tk_path);
+        uint32_t tb = p.path_b, tpend = p.pend;
+        int32_t td = p.depth;
+        bool at_leaf = valid && p.verified;
+        for (int it = 0; it < tv.tight_levels && __ballot(unresolved) != 0ull; it++) {
+          if (kStats) {
+            st_titer += 1;
+            st_tsteps += unresolved;
+          }
+          if (unresolved) {
+            const uint32_t n = node_size(tb, td, m1);
+            if (n == 1u) {
+              unresolved = false;
+              at_leaf = true;
+            } else {
+              const int dim = td % 3;
+              const float pvv = node_comp(tv.nodes, tb, dim);
+              const float qv = sel3(dim, x, y, z);
+              const float fp = qv - pvv;
+              if (!(fp * fp > p.bound0)) tpend |= 1u << td;
+              tb = 2u * tb + ((n == 2u || pvv > qv) ? 0u : 1u);
+              ++td;
+            }
+          }
+        }
+        if (valid && unresolved && node_size(tb, td, m1) == 1u) {  // reached a leaf on the last allowed step
+          unresolved = false;
+          at_leaf = true;
+        }
+        lap(tk_tight);
+        // ---- the first leaf (kdtree.go:95-106)
+        float4 lf = p.leaf;
+        float d_lf = p.d_leaf;
+        if (at_leaf && !p.verified) {
+          lf = node_at(tv.nodes, tb);
+          const float ldx = lf.x - x, ldy = lf.y - y, ldz = lf.z - z;
+          d_lf = (ldx * ldx + ldy * ldy) + ldz * ldz;
+        }
+        const bool leaf_taken = at_leaf && !(d_lf > max_range_sq);
+        const float bd = leaf_taken ? d_lf : max_range_sq;  // the running best after the first leaf
+        if (valid) note_leaf(idx, at_leaf ? tb : 0u);
+        if (kStats && valid) st_pend += (unsigned long long)__popc(tpend);
+        // finished already: nothing left to unwind (or the MinDistSq cut, kdtree.go:104)
+        const bool done = at_leaf && (tpend == 0u || (kMinDist && bd < min_dist_sq));
+        if (valid && done) {
+          if (kStats) st_early += 1;
+          float4 r = lf;
+          if (!leaf_taken) r = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+          emit(idx, r, bd);
+        }
+        const bool enq = valid && !done;
+        const uint64_t enq_mask = __ballot(enq);
+        if (enq) {
+          const uint32_t slot = (q_tail + (uint32_t)__popcll(enq_mask & lt_mask)) % kQueueSlots;
+          queue[0 * kQueueSlots + slot] = __float_as_uint(x);
+          queue[1 * kQueueSlots + slot] = __float_as_uint(y);
+          queue[2 * kQueueSlots + slot] = __float_as_uint(z);
+          queue[3 * kQueueSlots + slot] = __float_as_uint(kExact ? fminf(bd, p.ub) : bd);  // bound_d
+          queue[4 * kQueueSlots + slot] = tb | (at_leaf ? 0u : kPathDescend) | (leaf_taken ? kPathLeafTaken : 0u);
+          queue[5 * kQueueSlots + slot] = tpend;
+          queue[6 * kQueueSlots + slot] = (uint32_t)(idx - range_first);
+        }
+        q_tail += (uint32_t)__popcll(enq_mask);
+        lap(tk_finish);
       }
+      // ---- waiting lanes take queued queries
+      const int32_t avail = (int32_t)(q_tail - q_head);
       if (!active) {
-        const int32_t slot = q_head + (int32_t)__popcll(idle & lt_mask);
-        if (slot < q_count) {
-          qx = __uint_as_float(queue[0 * 64 + slot]);
-          qy = __uint_as_float(queue[1 * 64 + slot]);
-          qz = __uint_as_float(queue[2 * 64 + slot]);
-          bound_d = __uint_as_float(queue[3 * 64 + slot]);
-          const uint32_t pw = queue[4 * 64 + slot];
-          pend = queue[5 * 64 + slot];
-          best.x = __uint_as_float(queue[6 * 64 + slot]);
-          best.y = __uint_as_float(queue[7 * 64 + slot]);
-          best.z = __uint_as_float(queue[8 * 64 + slot]);
-          best.w = __uint_as_float(queue[9 * 64 + slot]);
-          const float bx = best.x - qx, by = best.y - qy, bz = best.z - qz;
-          best_d = __float_as_int(best.w) >= 0 ? (bx * bx + by * by) + bz * bz : max_range_sq;
-          my_q = q_base + slot;
-          sp = 0;
+        const int32_t r = (int32_t)__popcll(idle & lt_mask);
+        if (r < avail) {
+          const uint32_t slot = (q_head + (uint32_t)r) % kQueueSlots;
+          qx = __uint_as_float(queue[0 * kQueueSlots + slot]);
+          qy = __uint_as_float(queue[1 * kQueueSlots + slot]);
+          qz = __uint_as_float(queue[2 * kQueueSlots + slot]);
+          bound_d = __uint_as_float(queue[3 * kQueueSlots + slot]);
+          const uint32_t pw = queue[4 * kQueueSlots + slot];
+          pend = queue[5 * kQueueSlots + slot];
+          my_q = range_first + (int64_t)queue[6 * kQueueSlots + slot];
           path_b = pw & kPathMask;
-          if (pw & kPathFinished) {  // MinDistSq cut at the first leaf: nothing left to walk
-            pending = true;
-          } else {
-            b = path_b;
-            desc = (pw & kPathDescend) != 0u;
-            active = true;
+          best = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+          best_d = max_range_sq;
+          if (pw & kPathLeafTaken) {  // the running best is the first leaf: its record and distance again
+            best = node_at(tv.nodes, path_b);
+            const float bx = best.x - qx, by = best.y - qy, bz = best.z - qz;
+            best_d = (bx * bx + by * by) + bz * bz;
           }
+          sp = 0;
+          b = path_b;
+          desc = (pw & kPathDescend) != 0u;
+          active = true;
         }
       }
-      q_head = q_head + n_idle < q_count ? q_head + n_idle : q_count;
-      if (q_head == q_count && exhausted && __ballot(active) == 0ull) {
-        if (pending) emit(my_q, best, best_d);
-        break;  // batch exhausted, every lane done and emitted
-      }
+      q_head += (uint32_t)(n_idle < avail ? n_idle : avail);
+      lap(tk_take);
+      if (q_head == q_tail && exhausted && __ballot(active) == 0ull) break;  // all done and emitted
     }
-
     // ---- unwinding lanes: the topmost explicit frame, else the deepest pending level of the
     //      first descent (kdtree.go:107-110); either way the frame is the child c the descent
     //      took below the ancestor c >> 1.  Its plane test follows the node fetch.
@@ -471,16 +547,20 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
       st_ipop += __shfl_down(st_ipop, o);
       st_ipass += __shfl_down(st_ipass, o);
       st_leaf += __shfl_down(st_leaf, o);
+      st_early += __shfl_down(st_early, o);
+      st_tsteps += __shfl_down(st_tsteps, o);
     }
     if (lane == 0) {  // one row of 24 counters per wave: the host adds them up (no contended atomics)
       unsigned long long *row =
-          stats + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 24;
+          stats + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kStatWords;
       if (t_dry == 0ull) t_dry = t_end;
       row[0] = st_iter; row[1] = st_active; row[2] = st_look; row[3] = st_refill; row[4] = st_prep;
       row[5] = st_verified; row[6] = st_pend; row[7] = st_queries; row[8] = st_desc; row[9] = st_epop;
       row[10] = st_epass; row[11] = st_ipop; row[12] = st_ipass; row[13] = st_leaf; row[14] = st_tail;
       row[15] = st_iter; row[16] = t_dry - t_start; row[17] = t_end - t_dry; row[18] = t_end - t_start;
-      row[19] = 1ull;
+      row[19] = 1ull; row[21] = st_early; row[22] = st_tsteps; row[23] = st_titer;
+      row[24] = tk_fetch; row[25] = tk_path; row[26] = tk_tight; row[27] = tk_finish; row[28] = tk_take;
+      row[29] = tk_step;
     }
   }
 }

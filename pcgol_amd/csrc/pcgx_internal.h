@@ -104,6 +104,8 @@ struct TreeView {
   float dir_lo[3];
   float dir_scale[3];  // cells per metre (0 for a degenerate axis)
   int32_t refill_threshold;  // walk kernels: emit + refill once this many lanes of a wave wait
+  int32_t tight_levels;      // walk kernels: levels a chunk preparation descends below a wrong prediction
+  int32_t chunks_per_refill; // walk kernels: chunks a wave may prepare in one refill section
 };
 
 // kdtree_build.cpp
@@ -120,15 +122,15 @@ pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint
 
 // knn.hip
 constexpr int kKnnBlock = 256;  // 4 waves
-constexpr int kWalkQueueBytesPerWave = 10 * 64 * 4;  // knn_walk.h kQueueWords
+constexpr int kWalkQueueBytesPerWave = 7 * 128 * 4;  // knn_walk.h kQueueWords x kQueueSlots
 // Dynamic LDS of a walk kernel block: frame stacks [(depth-1)][block] x 4 B (19 KB at 1M
-// points), one prepared-query queue per wave (2.5 KB each), the top split values (8 KB).
+// points), one prepared-query queue per wave (3.5 KB each), the top split values (8 KB).
 inline size_t walk_stack_bytes(const TreeView &tv, int block) {
   int levels = tv.depth > 1 ? tv.depth - 1 : 1;
   return (size_t)levels * block * sizeof(uint32_t);
 }
 #ifndef PCGX_WALK_TOP_LEVELS
-#define PCGX_WALK_TOP_LEVELS 11
+#define PCGX_WALK_TOP_LEVELS 6
 #endif
 constexpr int kWalkTopLevels = PCGX_WALK_TOP_LEVELS;  // levels whose split values a walk block keeps in LDS
 constexpr int kWalkTopBytes = (1 << kWalkTopLevels) * 4;
@@ -137,6 +139,8 @@ inline size_t walk_lds_bytes(const TreeView &tv, int block) {
 }
 int walk_blocks_per_cu(const TreeView &tv);
 int walk_refill_threshold();
+int walk_tight_levels();
+int walk_chunks_per_refill();
 int walk_oversubscribe();
 pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *d_perm, int64_t nq,
                            float max_range_sq, float min_dist_sq, int32_t *d_ids, float *d_dsq,
@@ -174,6 +178,8 @@ struct pcgx_kdtree {
     v.dir_bits = dir_bits;
     for (int k = 0; k < 3; k++) { v.dir_lo[k] = dir_lo[k]; v.dir_scale[k] = dir_scale[k]; }
     v.refill_threshold = pcgx::walk_refill_threshold();
+    v.tight_levels = pcgx::walk_tight_levels();
+    v.chunks_per_refill = pcgx::walk_chunks_per_refill();
     return v;
   }
 };

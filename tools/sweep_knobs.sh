@@ -1,8 +1,8 @@
 #!/bin/bash
-# Sweep the walk kernel's launch knobs on the ICP step (run on the GPU box): one bench line per setting.
+# Sweep walk-kernel knobs on the ICP step and the C2 kNN batch (run on the GPU box).
 out=gpurun_out/sweep.log
 : > $out
-for b in 2 3 4; do for r in 4 8 16 24; do
-  echo "blocks=$b refill=$r" >> $out
-  PCGX_WALK_BLOCKS_PER_CU=$b PCGX_WALK_REFILL=$r timeout 120 python bench.py --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['kernel_ms'])" >> $out
-done; done
+for t in 0 2 8; do for c in 1 2 4; do for r in 8 24; do
+  echo -n "tight=$t chunks=$c refill=$r : " >> $out
+  PCGX_WALK_TIGHT=$t PCGX_WALK_CHUNKS_PER_REFILL=$c PCGX_WALK_REFILL=$r timeout 120 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), round(d['roofline']['kernel_ms'],4), 'knn', round(d['extra']['knn_c2_presort']['walk_kernel_ms'],4))" >> $out
+done; done; done
