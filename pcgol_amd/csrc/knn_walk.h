@@ -322,7 +322,13 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
       }
     }
     lap(tk_step);
-    if (n_idle >= tv.refill_threshold || n_idle == 64) {
+    if (exhausted && q_head == q_tail) {
+      // nothing left to hand out: finished lanes keep their result until the wave is done
+      if (n_idle == 64) {
+        if (pending) emit(my_q, best, best_d);
+        break;
+      }
+    } else if (n_idle >= tv.refill_threshold) {
       if (kStats) st_refill += 1;
       if (pending) {
         emit(my_q, best, best_d);
@@ -457,7 +463,6 @@ __device__ __forceinline__ void walk_queries(const TreeView tv, uint32_t *__rest
       }
       q_head += (uint32_t)(n_idle < avail ? n_idle : avail);
       lap(tk_take);
-      if (q_head == q_tail && exhausted && __ballot(active) == 0ull) break;  // all done and emitted
     }
     // ---- unwinding lanes: the topmost explicit frame, else the deepest pending level of the
     //      first descent (kdtree.go:107-110); either way the frame is the child c the descent
