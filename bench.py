@@ -52,6 +52,28 @@ def load_visits():
         return json.load(f)
 
 
+def load_traffic(kernel="icp_corr_kernel"):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/rNN*_pmc.json,
+    written by profiles/collect.sh: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this
+    same bench command).  rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE tallies 128-byte
+    requests at 64 bytes, so it is doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
+    PMC collection cannot run inside the timed process, hence the committed summary."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc.json")))
+    for p in reversed(files):
+        try:
+            with open(p) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for name, c in d.items():
+            if kernel in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                fetch = c["FETCH_SIZE"]["mean_per_dispatch"] * 1024.0 * 2.0
+                write = c["WRITE_SIZE"]["mean_per_dispatch"] * 1024.0
+                return fetch + write, os.path.basename(p)
+    return None, None
+
+
 def cpu_baseline(synth, base, target, cfg, budget_s=25.0):
     """The CPU oracle (C restatement of the reference algorithm, 1 thread) timed on the same
     workload: whole ICP iterations (corr + reduce + re-projection + update)."""
@@ -207,6 +229,7 @@ def main():
         alg_bytes = (12 + 16 * v_icp) * n  # 12 B target read + 16 B per node the reference walk touches
         kernel_s = walk_ms / max(walk_n, 1) * 1e-3
         achieved = alg_bytes / kernel_s / 1e9
+        traffic, traffic_src = load_traffic() if n == 1_000_000 else (None, None)
         line = {
             "metric": "Mpoints/sec ICP iter (corr+reduce) + kNN queries/sec, 1M-pt cloud",
             "value": world * n * args.steps / elapsed / 1e6,
@@ -223,7 +246,7 @@ def main():
                        "exchange": "none" if world == 1 else "all-reduce 10 x f64 per step (RCCL)"},
             "roofline": {"bound": "hbm", "kernel": "icp_corr_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": kernel_s * 1e3, "launches": walk_n,
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_s * 1e3, "launches": walk_n,
                          "algorithmic_bytes_per_launch": alg_bytes, "visits_per_point": v_icp},
             "tree_build_s": build_s,
             "final_value": float(stat.Evaluated.Value),
