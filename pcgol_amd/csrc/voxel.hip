@@ -158,50 +158,104 @@ __global__ __launch_bounds__(1024) void seg_scan_kernel(uint32_t *__restrict__ t
 }
 
 // One lane per sorted position; head lanes own a voxel.
+//
+// Phase A: every lane gathers the points of its 8 sorted positions (8 independent random
+// 12-byte reads in flight per lane: the gather is latency bound, so memory-level parallelism
+// is what counts) and parks p = pt - origin in LDS together with a head flag.
+// Phase B: head lanes run the reference's sequential float32 sum (voxelgrid.go:157) over
+// their segment out of LDS; only a segment that runs past the tile's end continues with
+// global gathers (at most one per tile).
 __global__ __launch_bounds__(256) void seg_reduce_kernel(
     const uint8_t *__restrict__ data, int32_t stride, int32_t off, VoxelParams vp,
     const uint32_t *__restrict__ sa, const uint32_t *__restrict__ sc, const uint32_t *__restrict__ sidx,
     int64_t n, const uint32_t *__restrict__ tile_offset, uint8_t *__restrict__ out) {
-  __shared__ uint32_t ws[4];
+  constexpr int kRounds = kSegTile / 256;
+  __shared__ float sp[3][kSegTile];
+  __shared__ uint8_t shead[kSegTile];
+  __shared__ uint32_t ws[kRounds][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t base = (int64_t)blockIdx.x * kSegTile;
+  const int64_t rem = n - base;
+  const int count = rem < kSegTile ? (int)rem : kSegTile;
+
+  uint32_t idx[kRounds];
+  float v[kRounds][3];
+  bool head[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; r++) {
+    const int l = r * 256 + threadIdx.x;
+    idx[r] = l < count ? sidx[base + l] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < kRounds; r++) {
+    const uint8_t *rec = data + (int64_t)idx[r] * stride + off;
+    v[r][0] = ld_f32(rec);
+    v[r][1] = ld_f32(rec + 4);
+    v[r][2] = ld_f32(rec + 8);
+  }
+#pragma unroll
+  for (int r = 0; r < kRounds; r++) {
+    const int l = r * 256 + threadIdx.x;
+    head[r] = l < count && is_head(sa, sc, base + l);
+    float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
+    if (vp.chunked && l < count) chunk_origin(vp, sc ? sc[base + l] : 0u, origin);
+    // p := it.Vec3().Sub(vMin)   (voxelgrid.go:149)
+    sp[0][l] = v[r][0] - origin[0];
+    sp[1][l] = v[r][1] - origin[1];
+    sp[2][l] = v[r][2] - origin[2];
+    shead[l] = head[r] ? 1 : 0;
+    const uint64_t bal = __ballot(head[r]);
+    if (lane == 0) ws[r][wave] = (uint32_t)__popcll(bal);
+  }
+  __syncthreads();
+
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   uint32_t running = tile_offset[blockIdx.x];
-  for (int r = 0; r < kSegTile / 256; r++) {
-    const int64_t j = base + r * 256 + threadIdx.x;
-    const bool head = j < n && is_head(sa, sc, j);
-    // exclusive rank of this head among the heads of the round
-    const uint64_t bal = __ballot(head);
-    const uint32_t below = (uint32_t)__popcll(bal & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
-    if (lane == 0) ws[wave] = (uint32_t)__popcll(bal);
-    __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kRounds; r++) {
     uint32_t wbase = 0, round_total = 0;
+#pragma unroll
     for (int w = 0; w < 4; w++) {
-      if (w < wave) wbase += ws[w];
-      round_total += ws[w];
+      const uint32_t c = ws[r][w];
+      if (w < wave) wbase += c;
+      round_total += c;
     }
-    if (head) {
-      const uint32_t slot = running + wbase + below;
-      const uint32_t a = sa[j];
+    const uint64_t bal = __ballot(head[r]);
+    if (head[r]) {
+      int l = r * 256 + threadIdx.x;
+      const int64_t j = base + l;
+      const uint32_t slot = running + wbase + (uint32_t)__popcll(bal & lt_mask);
       const uint32_t cid = sc ? sc[j] : 0u;
       float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
       if (vp.chunked) chunk_origin(vp, cid, origin);
-      const uint32_t first = sidx[j];  // v.index: first point in input order (voxelgrid.go:152-155)
       float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
       uint32_t num = 0;
-      int64_t k = j;
-      do {
-        const uint8_t *rec = data + (int64_t)sidx[k] * stride + off;
-        // p := it.Vec3().Sub(vMin); v.sum = v.sum.Add(p)   (voxelgrid.go:149,157)
-        s0 = s0 + (ld_f32(rec) - origin[0]);
-        s1 = s1 + (ld_f32(rec + 4) - origin[1]);
-        s2 = s2 + (ld_f32(rec + 8) - origin[2]);
+      do {  // v.sum = v.sum.Add(p)   (voxelgrid.go:157), points in input order (stable sort)
+        s0 = s0 + sp[0][l];
+        s1 = s1 + sp[1][l];
+        s2 = s2 + sp[2][l];
         num++;
-        k++;
-      } while (k < n && sa[k] == a && (!sc || sc[k] == cid));
-      const uint8_t *src = data + (int64_t)first * stride;
+        l++;
+      } while (l < count && !shead[l]);
+      if (l == kSegTile) {  // the segment may continue in the next tile
+        for (int64_t k = base + kSegTile; k < n && !is_head(sa, sc, k); k++) {
+          const uint8_t *rec = data + (int64_t)sidx[k] * stride + off;
+          s0 = s0 + (ld_f32(rec) - origin[0]);
+          s1 = s1 + (ld_f32(rec + 4) - origin[1]);
+          s2 = s2 + (ld_f32(rec + 8) - origin[2]);
+          num++;
+        }
+      }
+      // v.index: first point in input order (voxelgrid.go:152-155); its whole record is copied
+      const uint8_t *src = data + (int64_t)idx[r] * stride;
       uint8_t *dst = out + (int64_t)slot * stride;
       if (((stride | off) & 3) == 0 && ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out)) & 3) == 0) {
-        for (int b = 0; b < stride; b += 4) *(uint32_t *)(dst + b) = *(const uint32_t *)(src + b);
+        if (stride == 12) {
+          float *d = (float *)dst;
+          d[0] = v[r][0]; d[1] = v[r][1]; d[2] = v[r][2];
+        } else {
+          for (int b = 0; b < stride; b += 4) *(uint32_t *)(dst + b) = *(const uint32_t *)(src + b);
+        }
       } else {
         for (int b = 0; b < stride; b++) dst[b] = src[b];
       }
@@ -214,7 +268,6 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(
       }
     }
     running += round_total;
-    __syncthreads();
   }
 }
 
