@@ -124,6 +124,35 @@ def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits):
         out[key] = {"mqueries_per_s": len(c2q) / dt / 1e6, "ms_per_call": dt * 1e3,
                     "walk_kernel_ms": kms / max(kn, 1),
                     "roofline_frac_walk_kernel": alg / (kms / max(kn, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # Point-to-plane / Gauss-Newton extension (BASELINE.json config "ICP point-to-plane, 1M source vs
+    # 1M target, 20 iters"; the reference has no such evaluator: no reference parity).
+    # One step = correspondence + 30-sum reduction (6x6 normal equations) + Gauss-Newton update.
+    from pcgol_amd.distributed import ShardedIcp
+    cp = synth.c4_plane(1_000_000)
+    ptree = kdtree.New(cp["base"])
+    picp = ShardedIcp(ptree, cp["target"], cp["max_dist"], cp["min_pairs"], None, cp["threshold"],
+                      cp["max_iteration"], BaseNormals=cp["normals"])
+    for _ in range(20):
+        picp.step()
+    torch.cuda.synchronize()
+    L.prof_reset()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        picp.reset()
+        for _ in range(cp["max_iteration"]):
+            picp.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (reps * cp["max_iteration"])
+    kms, kn = L.prof_read(L.PROF_ICP_WALK)
+    ptrans, pstat, _ = picp.result()
+    inv = np.linalg.inv(synth.icp_pose().astype(np.float64).reshape(4, 4).T).T.reshape(-1)
+    out["icp_plane_c4"] = {"mpoints_per_s": len(cp["target"]) / dt / 1e6, "ms_per_step": dt * 1e3,
+                           "corr_kernel_ms": kms / max(kn, 1), "final_value": float(pstat.Evaluated.Value),
+                           "pose_error_max": float(np.max(np.abs(ptrans.astype(np.float64) - inv))),
+                           "exchange_doubles": 30, "parity": "none in the reference (extension)"}
+    picp.close()
+    del ptree
     c3 = synth.c3_voxel()
     dp = torch.from_numpy(c3["points"]).to(dev)
     dout = torch.empty_like(dp)

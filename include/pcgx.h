@@ -48,7 +48,8 @@ enum {
   PCGX_E_OUT_OF_RANGE = 7,     /* voxel index outside the dense grid: the Go code panics here
                                   (pc/filter/voxelgrid/voxelgrid.go:151); we return an error */
   PCGX_E_TOO_LARGE = 8,        /* tree larger than 2^26 points (traversal frame encoding) */
-  PCGX_E_NEED_GRADIENT = 9     /* icp/icp.go:15 ErrNeedGradient (kept for the Go shim's mapping) */
+  PCGX_E_NEED_GRADIENT = 9,    /* icp/icp.go:15 ErrNeedGradient (kept for the Go shim's mapping) */
+  PCGX_E_SINGULAR = 10         /* point-to-plane extension: 6x6 normal equations not positive definite */
 };
 
 /* ------------------------------------------------------------ lifecycle */
@@ -278,6 +279,42 @@ PCGX_API pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream);
 PCGX_API pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream,
                                              float trans16[16], pcgx_icp_stat *stat,
                                              int32_t *converged);
+
+/* ------------------------------------------- point-to-plane ICP (extension)
+ * NOT in the reference: pcgol declares only the slots -- Evaluated.Hessian mat.Mat6
+ * (evaluator.go:28), Evaluator.HasHessian (evaluator.go:35,76), mat.Mat6 (mat/mat6.go:3),
+ * UpdaterGradient (updater.go:11-13).  This fills them: an evaluator whose residual is the
+ * point-to-plane distance r = n . (pt - pb) with the 6x6 Gauss-Newton normal equations
+ * (J = {n, pt x n}, parameters {t, w} ordered like Evaluated.Gradient), and a Gauss-Newton
+ * updater with the reference updater's flat test, pose composition
+ * trans = Translate(d0..2) * (Rodrigues(d3..5) * trans) and iteration cap.
+ * No reference parity exists; tests check against the CPU oracle's float64 restatement.
+ *
+ * base_normals: packed xyz float32 per base point, in the tree's id order (unit length).
+ * A plane session is a pcgx_icp_session whose exchange vector has 30 doubles:
+ *   {sum r^2, sum J r [6], upper triangle of sum J J^T row-major [21], sum w, pair count}.
+ * partials / update / step / result / reset / set_pose / free are the session calls above;
+ * params->weight is unused, params->threshold / max_iteration / min_pairs / max_dist as above. */
+PCGX_API pcgx_status pcgx_icp_plane_session_create(const pcgx_kdtree *base, const float *base_normals,
+                                                   const float *target, int64_t nt, int32_t on_device,
+                                                   const pcgx_icp_params *params, float damping,
+                                                   double *d_sums30, pcgx_icp_session **out);
+/* 10 or 30: length of the session's exchange vector. */
+PCGX_API pcgx_status pcgx_icp_session_sums_count(const pcgx_icp_session *s, int32_t *count);
+PCGX_API pcgx_status pcgx_icp_session_read_sums_n(pcgx_icp_session *s, double *sums, int32_t cap, void *stream);
+/* Evaluated.Hessian of the last evaluation (2/sum(w) * sum J J^T, symmetric 6x6). */
+PCGX_API pcgx_status pcgx_icp_session_hessian(pcgx_icp_session *s, void *stream, float hessian36[36]);
+/* Whole Fit on the device; hessian36 may be NULL.  PCGX_E_SINGULAR if the normal equations
+ * are not positive definite (e.g. all normals parallel). */
+PCGX_API pcgx_status pcgx_icp_plane_fit(const pcgx_kdtree *base, const float *base_normals, const float *target,
+                                        int64_t nt, const pcgx_icp_params *params, float damping,
+                                        float trans16[16], pcgx_icp_stat *stat, float hessian36[36]);
+/* Host-only pieces for a host-driven exchange loop. */
+PCGX_API pcgx_status pcgx_icp_plane_finish_evaluate(const double sums30[30], int32_t min_pairs,
+                                                    pcgx_icp_evaluated *out, float hessian36[36]);
+PCGX_API pcgx_status pcgx_icp_gauss_newton_update(const pcgx_icp_params *p, float damping, int32_t *iter,
+                                                  const float gradient[6], const float hessian36[36],
+                                                  float trans16[16], int32_t *converged);
 
 #ifdef __cplusplus
 }

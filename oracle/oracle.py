@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 
-ORC_OK, ORC_E_NO_POINT, ORC_E_NOT_ENOUGH_PAIRS, ORC_E_PANIC, ORC_E_OOM = range(5)
+ORC_OK, ORC_E_NO_POINT, ORC_E_NOT_ENOUGH_PAIRS, ORC_E_PANIC, ORC_E_OOM, ORC_E_SINGULAR = range(6)
 
 
 class OracleError(RuntimeError):
@@ -20,13 +20,13 @@ class OracleError(RuntimeError):
         self.code = code
         super().__init__({1: "no point", 2: "not enough correspondence pairs",
                           3: "reference would panic (index out of range)",
-                          4: "out of memory"}.get(code, "oracle error %d" % code))
+                          4: "out of memory", 5: "normal equations not positive definite"}.get(code, "oracle error %d" % code))
 
 
 def build(force=False):
     """Compile liboracle.so with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "pcgol_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("pcgol_oracle.c", "plane_oracle.c", "Makefile")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
                               stdout=subprocess.DEVNULL)
     return _SO
@@ -69,6 +69,14 @@ def lib():
         L.orc_icp_update.argtypes = [vp, vp, i32, vp, vp, vp]
         L.orc_icp_fit.restype = i32
         L.orc_icp_fit.argtypes = [vp, vp, i64, f32, f32, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp]
+        L.orc_plane_sums.restype = i32
+        L.orc_plane_sums.argtypes = [vp, vp, vp, i64, f32, vp]
+        L.orc_plane_finish.restype = i32
+        L.orc_plane_finish.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.orc_gauss_newton_update.restype = i32
+        L.orc_gauss_newton_update.argtypes = [vp, f32, i32, vp, vp, vp, vp]
+        L.orc_plane_fit.restype = i32
+        L.orc_plane_fit.argtypes = [vp, vp, vp, i64, f32, i32, vp, f32, i32, vp, vp, vp, vp, vp]
         L.orc_mat4_mul.argtypes = [vp, vp, vp]
         L.orc_mat4_transform.argtypes = [vp, vp, vp]
         L.orc_translate.argtypes = [f32, f32, f32, vp]
@@ -277,3 +285,58 @@ def icp_fit(tree, target, max_dist, min_pairs=0, weight=None, threshold=None, ma
         raise e
     return dict(trans=tr, value=np.float32(v.value), gradient=g, dist_rms=np.float32(r.value),
                 num_iteration=nit.value)
+
+
+# ------------------------------------------- point-to-plane extension (parity unpinned)
+
+def plane_sums(tree, normals, target, max_dist):
+    """The 30 float64 sums of one point-to-plane evaluation (oracle/plane_oracle.c)."""
+    normals = _f32(normals).reshape(-1, 3)
+    target = _f32(target).reshape(-1, 3)
+    assert len(normals) == tree.n
+    out = np.zeros(30, np.float64)
+    lib().orc_plane_sums(tree.h, _p(normals), _p(target), len(target), max_dist, _p(out))
+    return out
+
+
+def plane_finish(sums30, min_pairs=0):
+    sums30 = np.ascontiguousarray(sums30, np.float64)
+    v = C.c_float(0)
+    g = np.empty(6, np.float32)
+    h = np.empty(36, np.float32)
+    npairs = C.c_int64(0)
+    rc = lib().orc_plane_finish(_p(sums30), min_pairs, C.byref(v), _p(g), _p(h), C.byref(npairs))
+    if rc:
+        raise OracleError(rc)
+    return dict(value=np.float32(v.value), gradient=g, hessian=h, npairs=npairs.value)
+
+
+def gauss_newton_update(trans, grad6, hess36, it, threshold=None, damping=0.0, max_iter=0):
+    """Returns (trans', converged, it'); raises OracleError(ORC_E_SINGULAR)."""
+    th = _f32(threshold if threshold is not None else np.zeros(6))
+    tr = _f32(trans).copy()
+    g, h = _f32(grad6), _f32(hess36)
+    i = C.c_int32(it)
+    rc = lib().orc_gauss_newton_update(_p(th), damping, max_iter, C.byref(i), _p(g), _p(h), _p(tr))
+    if rc < 0:
+        raise OracleError(ORC_E_SINGULAR)
+    return tr, bool(rc), i.value
+
+
+def plane_fit(tree, normals, target, max_dist, min_pairs=0, threshold=None, damping=0.0, max_iter=0):
+    normals = _f32(normals).reshape(-1, 3)
+    target = _f32(target).reshape(-1, 3)
+    th = _f32(threshold if threshold is not None else np.zeros(6))
+    tr = np.empty(16, np.float32)
+    v = C.c_float(0)
+    g = np.zeros(6, np.float32)
+    h = np.zeros(36, np.float32)
+    nit = C.c_int32(0)
+    rc = lib().orc_plane_fit(tree.h, _p(normals), _p(target), len(target), max_dist, min_pairs, _p(th), damping,
+                             max_iter, _p(tr), C.byref(v), _p(g), _p(h), C.byref(nit))
+    if rc:
+        e = OracleError(rc)
+        e.trans = tr
+        e.num_iteration = nit.value
+        raise e
+    return dict(trans=tr, value=np.float32(v.value), gradient=g, hessian=h, num_iteration=nit.value)

@@ -247,6 +247,8 @@ void orc_kdtree_free(okdtree *t) {
 }
 
 int32_t orc_kdtree_max_depth(const okdtree *t) { return t->max_depth; }
+/* Vec3At(id) of the accessor the tree indexes (pc/randomaccess.go:8) */
+const float *orc_kdtree_point(const okdtree *t, int64_t id) { return t->pts + 3 * id; }
 int64_t orc_kdtree_len(const okdtree *t) { return t->n; }
 
 /* Pre-order dump of the tree: for node k: id, dim, index of child0/child1 in

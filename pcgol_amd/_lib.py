@@ -18,6 +18,7 @@ PCGX_E_INVALID = 6
 PCGX_E_OUT_OF_RANGE = 7
 PCGX_E_TOO_LARGE = 8
 PCGX_E_NEED_GRADIENT = 9
+PCGX_E_SINGULAR = 10
 
 PCGX_KNN_PRESORT = 1
 PROF_ICP_WALK, PROF_KNN_WALK, PROF_VOXEL_ALL, PROF_SORT_SCATTER = range(4)
@@ -60,8 +61,13 @@ class ErrInvalidField(PcgxError):       # pc/pointcloud.go:115
     pass
 
 
+class ErrSingular(PcgxError):           # point-to-plane extension: normal equations not positive definite
+    pass
+
+
 _ERR = {PCGX_E_NO_POINT: ErrNoPoint, PCGX_E_NOT_ENOUGH_PAIRS: ErrNotEnoughPairs,
-        PCGX_E_NEED_GRADIENT: ErrNeedGradient, PCGX_E_BAD_FIELD: ErrInvalidField}
+        PCGX_E_NEED_GRADIENT: ErrNeedGradient, PCGX_E_BAD_FIELD: ErrInvalidField,
+        PCGX_E_SINGULAR: ErrSingular}
 
 
 class IcpEvaluated(C.Structure):
@@ -124,6 +130,15 @@ SIGNATURES = {
     "pcgx_icp_session_update": (_i32, [_vp, _vp]),
     "pcgx_icp_session_step": (_i32, [_vp, _vp]),
     "pcgx_icp_session_result": (_i32, [_vp, _vp, _vp, C.POINTER(IcpStat), C.POINTER(_i32)]),
+    "pcgx_icp_plane_session_create": (_i32, [_vp, _vp, _vp, _i64, _i32, C.POINTER(IcpParams), _f32, _vp,
+                                             C.POINTER(_vp)]),
+    "pcgx_icp_session_sums_count": (_i32, [_vp, C.POINTER(_i32)]),
+    "pcgx_icp_session_read_sums_n": (_i32, [_vp, _vp, _i32, _vp]),
+    "pcgx_icp_session_hessian": (_i32, [_vp, _vp, _vp]),
+    "pcgx_icp_plane_fit": (_i32, [_vp, _vp, _vp, _i64, C.POINTER(IcpParams), _f32, _vp, C.POINTER(IcpStat), _vp]),
+    "pcgx_icp_plane_finish_evaluate": (_i32, [_vp, _i32, C.POINTER(IcpEvaluated), _vp]),
+    "pcgx_icp_gauss_newton_update": (_i32, [C.POINTER(IcpParams), _f32, C.POINTER(_i32), _vp, _vp, _vp,
+                                            C.POINTER(_i32)]),
 }
 
 _lib = None

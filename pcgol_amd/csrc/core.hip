@@ -289,6 +289,42 @@ extern "C" pcgx_status pcgx_icp_finish_evaluate(const double sums10[10], int32_t
   return PCGX_OK;
 }
 
+extern "C" pcgx_status pcgx_icp_plane_finish_evaluate(const double sums30[30], int32_t min_pairs,
+                                                      pcgx_icp_evaluated *out, float hessian36[36]) {
+  if (!sums30 || !out || !hessian36) return fail(PCGX_E_INVALID, "pcgx_icp_plane_finish_evaluate: NULL argument");
+  if (min_pairs == 0) min_pairs = 6;
+  const int64_t npairs = (int64_t)sums30[P_PAIRS];
+  out->num_pairs = npairs;
+  if (npairs < min_pairs)
+    return fail(PCGX_E_NOT_ENOUGH_PAIRS, "not enough correspondence pairs (%lld < %d)", (long long)npairs, min_pairs);
+  EvaluatedPlane ev;
+  finish_evaluate_plane(sums30, ev);
+  out->value = ev.value;
+  memcpy(out->gradient, ev.gradient, sizeof ev.gradient);
+  out->dist_rms = 0.0f;
+  memcpy(hessian36, ev.hessian, sizeof ev.hessian);
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_gauss_newton_update(const pcgx_icp_params *p, float damping, int32_t *iter,
+                                                    const float gradient[6], const float hessian36[36],
+                                                    float trans16[16], int32_t *converged) {
+  if (!p || !iter || !gradient || !hessian36 || !trans16 || !converged)
+    return fail(PCGX_E_INVALID, "pcgx_icp_gauss_newton_update: NULL argument");
+  GaussNewtonParams u = resolve_gauss_newton(p->threshold, damping, p->max_iteration);
+  EvaluatedPlane ev;
+  memset(&ev, 0, sizeof ev);
+  memcpy(ev.gradient, gradient, sizeof ev.gradient);
+  memcpy(ev.hessian, hessian36, sizeof ev.hessian);
+  Mat4 t;
+  memcpy(t.m, trans16, sizeof t.m);
+  const int rc = gauss_newton_update(u, *iter, ev, t);
+  if (rc < 0) return fail(PCGX_E_SINGULAR, "normal equations are not positive definite");
+  memcpy(trans16, t.m, sizeof t.m);
+  *converged = rc;
+  return PCGX_OK;
+}
+
 extern "C" pcgx_status pcgx_icp_update(const pcgx_icp_params *p, int32_t *iter, const float gradient[6],
                                        float trans16[16], int32_t *converged) {
   if (!p || !iter || !gradient || !trans16 || !converged)

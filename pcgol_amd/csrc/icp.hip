@@ -4,6 +4,11 @@
 //
 // Reference: pc/registration/icp/icp.go:23-67 (Fit), correspondence.go:22-37
 // (Pairs), evaluator.go:91-189 (Evaluate), updater.go:44-71 (Update).
+//
+// kPlane variants: the point-to-plane / Gauss-Newton extension (6x6 normal equations,
+// SURVEY 8(f) N5; pcgx_math.h).  Same correspondence phase; the reduction accumulates the
+// 30 sums {r^2, J r, upper triangle of J J^T, w, pairs} instead of the reference's 10.
+// The reference has no such evaluator (only the Hessian slot): no reference parity.
 #include <string.h>
 
 #include <vector>
@@ -21,6 +26,7 @@ struct IcpState {
   int32_t done;           // converged, or failed
   int32_t status;         // PCGX_OK / PCGX_E_NOT_ENOUGH_PAIRS
   Evaluated ev;           // Stat.Evaluated (icp.go:54)
+  float hessian[36];      // plane sessions: Evaluated.Hessian (evaluator.go:28), else unused
 };
 
 struct IcpKernelParams {
@@ -28,6 +34,7 @@ struct IcpKernelParams {
   float min_dist_sq;
   int32_t min_pairs;
   UpdaterParams upd;
+  GaussNewtonParams gn;  // plane sessions
 };
 
 constexpr int kIcpBlock = kKnnBlock;
@@ -53,6 +60,25 @@ __device__ __forceinline__ void accumulate_terms(double *acc, float x0, float y0
   acc[S_PAIRS] += 1.0;
 }
 
+__device__ __forceinline__ void accumulate_plane_terms(double *acc, float x0, float y0, float z0, const float4 &bp,
+                                                       const float4 &nrm) {
+  float J[6], r;
+  plane_terms(x0, y0, z0, bp.x, bp.y, bp.z, nrm.x, nrm.y, nrm.z, J, r);
+  acc[P_VALUE] += (double)(r * r);
+#pragma unroll
+  for (int a = 0; a < 6; a++) acc[P_G0 + a] += (double)(J[a] * r);
+  int k = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = a; b < 6; b++) {
+      acc[P_H0 + k] += (double)(J[a] * J[b]);
+      k++;
+    }
+  acc[P_WEIGHT] += 1.0;
+  acc[P_PAIRS] += 1.0;
+}
+
 // One ICP iteration's correspondence + reduction for a tile of targets.
 //
 // Phase 1, correspondence (correspondence.go:22-37 for every target at once): targets are
@@ -64,12 +90,16 @@ __device__ __forceinline__ void accumulate_terms(double *acc, float x0, float y0
 // accumulates the evaluator's 9 sums + the pair count in float64.  The order of every addition
 // is fixed by the launch geometry alone, so the sums are bitwise reproducible although the
 // walk hands queries to lanes dynamically.
-template <bool kMinDist>
+// kPlane: match_id[i] additionally records the matched base id; the reduction gathers that
+// point's normal (normals[id], float4 per base point in id order) and accumulates the 30 sums.
+template <bool kMinDist, bool kPlane>
 __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     TreeView tv, const float *__restrict__ tx, const float *__restrict__ ty,
     const float *__restrict__ tz, int64_t nt, const IcpState *__restrict__ state,
     IcpKernelParams kp, float4 *__restrict__ match, uint32_t *__restrict__ first_leaf,
-    double *__restrict__ block_partials) {
+    double *__restrict__ block_partials, uint32_t *__restrict__ match_id,
+    const float4 *__restrict__ normals) {
+  constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
   if (state->done) return;  // uniform
@@ -125,15 +155,16 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
       kp.max_dist_sq, kp.min_dist_sq, load_query,
       [&](int64_t i, const float4 &bp, float best_d) {
         match[i] = make_float4(bp.x, bp.y, bp.z, __float_as_int(bp.w) >= 0 ? best_d : -1.0f);
+        if (kPlane) match_id[i] = __float_as_uint(bp.w);
       },
       [&](int64_t i, uint32_t leaf) { first_leaf[i] = leaf; });
 
   // ---- phase 2: this workgroup's range, fixed order
   __threadfence_block();
   __syncthreads();  // all match[] of the range are written; stacks / queues are free for reuse
-  double acc[S_COUNT];
+  double acc[NS];
 #pragma unroll
-  for (int k = 0; k < S_COUNT; k++) acc[k] = 0.0;
+  for (int k = 0; k < NS; k++) acc[k] = 0.0;
   const int64_t r_begin = (int64_t)chunk_begin * 64;
   int64_t r_end = (int64_t)chunk_end * 64;
   if (r_end > nt) r_end = nt;
@@ -142,21 +173,26 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     if (bp.w >= 0.0f) {  // correspondence.go:27-29
       float x0, y0, z0;
       load_target(i, x0, y0, z0);
-      accumulate_terms(acc, x0, y0, z0, bp);
+      if (kPlane) {
+        const float4 nrm = normals[match_id[i]];
+        accumulate_plane_terms(acc, x0, y0, z0, bp, nrm);
+      } else {
+        accumulate_terms(acc, x0, y0, z0, bp);
+      }
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double(*s_red)[S_COUNT] = reinterpret_cast<double(*)[S_COUNT]>(s_stack);
+  double(*s_red)[NS] = reinterpret_cast<double(*)[NS]>(s_stack);
 #pragma unroll
-  for (int k = 0; k < S_COUNT; k++) {
+  for (int k = 0; k < NS; k++) {
     double v = wave_sum_f64(acc[k]);
     if (lane == 0) s_red[wave][k] = v;
   }
   __syncthreads();
-  if (threadIdx.x < S_COUNT) {
+  if (threadIdx.x < NS) {
     double v = 0.0;
     for (int w = 0; w < kIcpBlock / 64; w++) v += s_red[w][threadIdx.x];
-    block_partials[(int64_t)blockIdx.x * S_COUNT + threadIdx.x] = v;
+    block_partials[(int64_t)blockIdx.x * NS + threadIdx.x] = v;
   }
 }
 
@@ -184,35 +220,83 @@ __device__ __forceinline__ void icp_update_step(IcpState *__restrict__ state, co
   if (converged) state->done = 1;
 }
 
-// Sums the per-workgroup partials in a fixed order -> sums10: wave k owns component k.
-// With kFuseUpdate (single GPU: no exchange between reduce and update) thread 0 then runs
-// the evaluate tail + pose update in the same launch.
-template <bool kFuseUpdate>
-__global__ __launch_bounds__(64 * S_COUNT) void icp_final_reduce_kernel(const double *__restrict__ block_partials,
-                                                                       int nblocks, IcpState *__restrict__ state,
-                                                                       double *__restrict__ sums10,
-                                                                       IcpKernelParams kp) {
-  __shared__ double s_sums[S_COUNT];
+// Plane sessions: evaluate tail (finish_evaluate_plane) + Gauss-Newton update; one thread.
+__device__ __forceinline__ void icp_plane_update_step(IcpState *__restrict__ state, const double *__restrict__ sums30,
+                                                      const IcpKernelParams &kp) {
+  state->num_iteration += 1;
+  const int64_t npairs = (int64_t)sums30[P_PAIRS];
+  if (npairs < (int64_t)kp.min_pairs) {
+    state->ev.num_pairs = npairs;
+    state->status = PCGX_E_NOT_ENOUGH_PAIRS;
+    state->done = 1;
+    return;
+  }
+  EvaluatedPlane ev;
+  finish_evaluate_plane(sums30, ev);
+  state->ev.value = ev.value;
+  for (int i = 0; i < 6; i++) state->ev.gradient[i] = ev.gradient[i];
+  state->ev.dist_rms = 0.0f;
+  state->ev.num_pairs = ev.num_pairs;
+  for (int i = 0; i < 36; i++) state->hessian[i] = ev.hessian[i];
+  Mat4 t;
+  for (int i = 0; i < 16; i++) t.m[i] = state->trans[i];
+  int32_t it = state->iter;
+  const int rc = gauss_newton_update(kp.gn, it, ev, t);
+  if (rc < 0) {
+    state->status = PCGX_E_SINGULAR;
+    state->done = 1;
+    return;
+  }
+  for (int i = 0; i < 16; i++) state->trans[i] = t.m[i];
+  state->iter = it;
+  if (rc > 0) state->done = 1;
+}
+
+// Sums the per-workgroup partials in a fixed order -> sums: wave w owns components w, w + waves, ...
+// (launched with one wave per component for the reference's 10 sums).  With kFuseUpdate (single
+// GPU: no exchange between reduce and update) thread 0 then runs the evaluate tail + pose update
+// in the same launch.
+template <bool kFuseUpdate, bool kPlane>
+__global__ __launch_bounds__(1024) void icp_final_reduce_kernel(const double *__restrict__ block_partials,
+                                                                int nblocks, IcpState *__restrict__ state,
+                                                                double *__restrict__ sums,
+                                                                IcpKernelParams kp) {
+  constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
+  __shared__ double s_sums[NS];
   if (state->done) return;
-  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double v = 0.0;
-  for (int b = lane; b < nblocks; b += 64) v += block_partials[(int64_t)b * S_COUNT + k];
-  v = wave_sum_f64(v);
-  if (lane == 0) {
-    sums10[k] = v;
-    s_sums[k] = v;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, waves = blockDim.x >> 6;
+  for (int k = wave; k < NS; k += waves) {
+    double v = 0.0;
+    for (int b = lane; b < nblocks; b += 64) v += block_partials[(int64_t)b * NS + k];
+    v = wave_sum_f64(v);
+    if (lane == 0) {
+      sums[k] = v;
+      s_sums[k] = v;
+    }
   }
   if (kFuseUpdate) {
     __syncthreads();
-    if (threadIdx.x == 0) icp_update_step(state, s_sums, kp);
+    if (threadIdx.x == 0) {
+      if (kPlane) icp_plane_update_step(state, s_sums, kp);
+      else icp_update_step(state, s_sums, kp);
+    }
   }
 }
 
-__global__ void icp_update_kernel(IcpState *__restrict__ state, const double *__restrict__ sums10,
+template <bool kPlane>
+__global__ void icp_update_kernel(IcpState *__restrict__ state, const double *__restrict__ sums,
                                   IcpKernelParams kp) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   if (state->done) return;
-  icp_update_step(state, sums10, kp);
+  if (kPlane) icp_plane_update_step(state, sums, kp);
+  else icp_update_step(state, sums, kp);
+}
+
+// normals (packed xyz, base id order) -> float4 per base point
+__global__ __launch_bounds__(256) void pack_normals_kernel(const float *__restrict__ n3, int64_t n,
+                                                           float4 *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = make_float4(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2], 0.0f);
 }
 
 __global__ __launch_bounds__(256) void gather_soa_kernel(const float *__restrict__ q,
@@ -241,6 +325,10 @@ struct pcgx_icp_session {
   uint32_t *d_first_leaf = nullptr;  // [nt] leaf the target's first descent ended in (0: unknown)
   double *d_sums = nullptr;  // caller's buffer, or own
   bool own_sums = false;
+  bool plane = false;              // point-to-plane / Gauss-Newton session (30 sums)
+  uint32_t *d_match_id = nullptr;  // plane: [nt] matched base id
+  float4 *d_normals = nullptr;     // plane: [base n] unit normals in base id order
+  int n_sums() const { return plane ? (int)P_COUNT : (int)S_COUNT; }
   int grid = 1;
   IcpKernelParams kp;
   int32_t max_iteration = 20;
@@ -248,10 +336,12 @@ struct pcgx_icp_session {
 
 static IcpKernelParams make_kernel_params(const pcgx_icp_params *p) {
   IcpKernelParams kp;
+  memset(&kp, 0, sizeof kp);
   kp.max_dist_sq = p->max_dist * p->max_dist;  // kdtree.go:91 via correspondence.go:26
   kp.min_dist_sq = p->min_dist_sq;
   kp.min_pairs = p->min_pairs == 0 ? 6 : p->min_pairs;  // evaluator.go:92-95
   kp.upd = resolve_updater(p->weight, p->threshold, p->max_iteration);
+  kp.gn = resolve_gauss_newton(p->threshold, 0.0f, p->max_iteration);
   return kp;
 }
 
@@ -294,8 +384,23 @@ extern "C" pcgx_status pcgx_icp_session_set_pose(pcgx_icp_session *s, const floa
 
 extern "C" pcgx_status pcgx_icp_session_read_sums(pcgx_icp_session *s, double sums10[10], void *stream) {
   if (!s || !sums10) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums: bad argument");
+  if (s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums: plane session (30 sums): use pcgx_icp_session_read_sums_n");
   hipStream_t st = pick_stream(stream);
   PCGX_HIP_TRY(hipMemcpyAsync(sums10, s->d_sums, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_session_sums_count(const pcgx_icp_session *s, int32_t *count) {
+  if (!s || !count) return fail(PCGX_E_INVALID, "pcgx_icp_session_sums_count: bad argument");
+  *count = s->n_sums();
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_session_read_sums_n(pcgx_icp_session *s, double *sums, int32_t cap, void *stream) {
+  if (!s || !sums || cap < s->n_sums()) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums_n: bad argument");
+  hipStream_t st = pick_stream(stream);
+  PCGX_HIP_TRY(hipMemcpyAsync(sums, s->d_sums, (size_t)s->n_sums() * sizeof(double), hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
   return PCGX_OK;
 }
@@ -307,15 +412,19 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   if (s->d_partials) (void)hipFree(s->d_partials);
   if (s->d_match) (void)hipFree(s->d_match);
   if (s->d_first_leaf) (void)hipFree(s->d_first_leaf);
+  if (s->d_match_id) (void)hipFree(s->d_match_id);
+  if (s->d_normals) (void)hipFree(s->d_normals);
   if (s->own_sums && s->d_sums) (void)hipFree(s->d_sums);
   delete s;
   return PCGX_OK;
 }
 
-extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const float *target,
-                                               int64_t nt, int32_t target_on_device,
-                                               const pcgx_icp_params *params, double *d_sums10,
-                                               pcgx_icp_session **out) {
+// normals == nullptr: the reference's point-to-point session; else a plane session (normals:
+// packed xyz per base point in id order, host or device memory like the target).
+static pcgx_status session_create(const pcgx_kdtree *base, const float *normals, float damping,
+                                  const float *target, int64_t nt, int32_t target_on_device,
+                                  const pcgx_icp_params *params, double *d_sums,
+                                  pcgx_icp_session **out) {
   if (!out) return fail(PCGX_E_INVALID, "pcgx_icp_session_create: out is NULL");
   *out = nullptr;
   if (!base || !params || nt < 0 || (nt > 0 && !target))
@@ -325,7 +434,9 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
   pcgx_icp_session *s = new pcgx_icp_session();
   s->base = base;
   s->nt = nt;
+  s->plane = normals != nullptr;
   s->kp = make_kernel_params(params);
+  s->kp.gn.damping = damping;
   s->max_iteration = s->kp.upd.max_iteration;
   s->grid = icp_grid(nt, base->view());
   pcgx_status rc = PCGX_OK;
@@ -336,16 +447,36 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
   hipError_t e;
   if ((e = hipMalloc((void **)&s->d_xyz, (size_t)(nt ? nt : 1) * 12)) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_state, sizeof(IcpState))) != hipSuccess ||
-      (e = hipMalloc((void **)&s->d_partials, (size_t)s->grid * S_COUNT * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void **)&s->d_partials, (size_t)s->grid * s->n_sums() * sizeof(double))) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_match, (size_t)(nt ? nt : 1) * sizeof(float4))) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_first_leaf, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess)
     return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
-  if (d_sums10) {
-    s->d_sums = d_sums10;
+  if (d_sums) {
+    s->d_sums = d_sums;
   } else {
-    if ((e = hipMalloc((void **)&s->d_sums, S_COUNT * sizeof(double))) != hipSuccess)
+    if ((e = hipMalloc((void **)&s->d_sums, (size_t)s->n_sums() * sizeof(double))) != hipSuccess)
       return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
     s->own_sums = true;
+  }
+  if (s->plane) {
+    const int64_t nb = base->n;
+    if ((e = hipMalloc((void **)&s->d_match_id, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
+        (e = hipMalloc((void **)&s->d_normals, (size_t)nb * sizeof(float4))) != hipSuccess)
+      return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
+    Arena &ar = ctx().arena;
+    if ((rc = ar.begin(st)) != PCGX_OK) return bail(rc);
+    const float *d_n3 = normals;
+    if (!target_on_device) {
+      float *stage = nullptr;
+      if ((rc = ar.alloc_n((size_t)nb * 3, &stage)) != PCGX_OK) return bail(rc);
+      if ((e = hipMemcpyAsync(stage, normals, (size_t)nb * 12, hipMemcpyHostToDevice, st)) != hipSuccess)
+        return bail(fail(PCGX_E_HIP, "normals upload failed: %s", hipGetErrorString(e)));
+      d_n3 = stage;
+    }
+    hipLaunchKernelGGL(pack_normals_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, d_n3, nb,
+                       s->d_normals);
+    if ((e = hipStreamSynchronize(st)) != hipSuccess)
+      return bail(fail(PCGX_E_HIP, "icp session setup failed: %s", hipGetErrorString(e)));
   }
   if ((rc = reset_state(s, st)) != PCGX_OK) return bail(rc);
   // no previous match yet: w = NaN (icp_corr_kernel takes pruning hints from match[] only when w >= 0)
@@ -377,17 +508,41 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
   return PCGX_OK;
 }
 
+extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const float *target,
+                                               int64_t nt, int32_t target_on_device,
+                                               const pcgx_icp_params *params, double *d_sums10,
+                                               pcgx_icp_session **out) {
+  return session_create(base, nullptr, 0.0f, target, nt, target_on_device, params, d_sums10, out);
+}
+
+extern "C" pcgx_status pcgx_icp_plane_session_create(const pcgx_kdtree *base, const float *base_normals,
+                                                     const float *target, int64_t nt, int32_t on_device,
+                                                     const pcgx_icp_params *params, float damping,
+                                                     double *d_sums30, pcgx_icp_session **out) {
+  if (!base_normals) return fail(PCGX_E_INVALID, "pcgx_icp_plane_session_create: base_normals is NULL");
+  if (params && params->min_dist_sq > 0.0f)
+    return fail(PCGX_E_INVALID, "pcgx_icp_plane_session_create: MinDistSq > 0 (approximate search) is not offered here");
+  if (!(damping >= 0.0f)) return fail(PCGX_E_INVALID, "pcgx_icp_plane_session_create: damping must be >= 0");
+  return session_create(base, base_normals, damping, target, nt, on_device, params, d_sums30, out);
+}
+
 static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   const TreeView tv = s->base->view();
   const size_t lds = walk_lds_bytes(tv, kIcpBlock);
   const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
   ProfScope prof(PCGX_PROF_ICP_WALK, st);
-  if (s->kp.min_dist_sq > 0.0f)
-    hipLaunchKernelGGL(icp_corr_kernel<true>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                       s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials);
+  if (s->plane)
+    hipLaunchKernelGGL((icp_corr_kernel<false, true>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
+                       s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, s->d_match_id,
+                       (const float4 *)s->d_normals);
+  else if (s->kp.min_dist_sq > 0.0f)
+    hipLaunchKernelGGL((icp_corr_kernel<true, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
+                       s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, (uint32_t *)nullptr,
+                       (const float4 *)nullptr);
   else
-    hipLaunchKernelGGL(icp_corr_kernel<false>, dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                       s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials);
+    hipLaunchKernelGGL((icp_corr_kernel<false, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
+                       s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, (uint32_t *)nullptr,
+                       (const float4 *)nullptr);
   return PCGX_OK;
 }
 
@@ -395,8 +550,12 @@ extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stre
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_partials: NULL session");
   hipStream_t st = pick_stream(stream);
   PCGX_TRY(enqueue_corr(s, st));
-  hipLaunchKernelGGL(icp_final_reduce_kernel<false>, dim3(1), dim3(64 * S_COUNT), 0, st, s->d_partials, s->grid,
-                     s->d_state, s->d_sums, s->kp);
+  if (s->plane)
+    hipLaunchKernelGGL((icp_final_reduce_kernel<false, true>), dim3(1), dim3(1024), 0, st, s->d_partials, s->grid,
+                       s->d_state, s->d_sums, s->kp);
+  else
+    hipLaunchKernelGGL((icp_final_reduce_kernel<false, false>), dim3(1), dim3(64 * S_COUNT), 0, st, s->d_partials,
+                       s->grid, s->d_state, s->d_sums, s->kp);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }
@@ -404,7 +563,10 @@ extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stre
 extern "C" pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream) {
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_update: NULL session");
   hipStream_t st = pick_stream(stream);
-  hipLaunchKernelGGL(icp_update_kernel, dim3(1), dim3(64), 0, st, s->d_state, s->d_sums, s->kp);
+  if (s->plane)
+    hipLaunchKernelGGL(icp_update_kernel<true>, dim3(1), dim3(64), 0, st, s->d_state, s->d_sums, s->kp);
+  else
+    hipLaunchKernelGGL(icp_update_kernel<false>, dim3(1), dim3(64), 0, st, s->d_state, s->d_sums, s->kp);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }
@@ -414,8 +576,12 @@ extern "C" pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream) 
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_step: NULL session");
   hipStream_t st = pick_stream(stream);
   PCGX_TRY(enqueue_corr(s, st));
-  hipLaunchKernelGGL(icp_final_reduce_kernel<true>, dim3(1), dim3(64 * S_COUNT), 0, st, s->d_partials, s->grid,
-                     s->d_state, s->d_sums, s->kp);
+  if (s->plane)
+    hipLaunchKernelGGL((icp_final_reduce_kernel<true, true>), dim3(1), dim3(1024), 0, st, s->d_partials, s->grid,
+                       s->d_state, s->d_sums, s->kp);
+  else
+    hipLaunchKernelGGL((icp_final_reduce_kernel<true, false>), dim3(1), dim3(64 * S_COUNT), 0, st, s->d_partials,
+                       s->grid, s->d_state, s->d_sums, s->kp);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }
@@ -439,7 +605,34 @@ extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream
   if (h.status == PCGX_E_NOT_ENOUGH_PAIRS)
     return fail(PCGX_E_NOT_ENOUGH_PAIRS, "not enough correspondence pairs (%lld < %d) at iteration %d",
                 (long long)h.ev.num_pairs, s->kp.min_pairs, h.num_iteration);
+  if (h.status == PCGX_E_SINGULAR)
+    return fail(PCGX_E_SINGULAR, "normal equations are not positive definite at iteration %d", h.num_iteration);
   return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_session_hessian(pcgx_icp_session *s, void *stream, float hessian36[36]) {
+  if (!s || !hessian36) return fail(PCGX_E_INVALID, "pcgx_icp_session_hessian: bad argument");
+  if (!s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_hessian: not a plane session (HasHessian() == false)");
+  hipStream_t st = pick_stream(stream);
+  IcpState h;
+  PCGX_HIP_TRY(hipMemcpyAsync(&h, s->d_state, sizeof h, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  memcpy(hessian36, h.hessian, sizeof h.hessian);
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_icp_plane_fit(const pcgx_kdtree *base, const float *base_normals, const float *target,
+                                          int64_t nt, const pcgx_icp_params *params, float damping,
+                                          float trans16[16], pcgx_icp_stat *stat, float hessian36[36]) {
+  if (!base || !params || !trans16) return fail(PCGX_E_INVALID, "pcgx_icp_plane_fit: NULL argument");
+  pcgx_icp_session *s = nullptr;
+  PCGX_TRY(pcgx_icp_plane_session_create(base, base_normals, target, nt, 0, params, damping, nullptr, &s));
+  pcgx_status rc = PCGX_OK;
+  for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) rc = pcgx_icp_session_step(s, nullptr);
+  if (rc == PCGX_OK) rc = pcgx_icp_session_result(s, nullptr, trans16, stat, nullptr);
+  if (rc == PCGX_OK && hessian36) rc = pcgx_icp_session_hessian(s, nullptr, hessian36);
+  pcgx_icp_session_free(s);
+  return rc;
 }
 
 extern "C" pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target, int64_t nt,

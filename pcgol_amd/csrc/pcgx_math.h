@@ -175,4 +175,130 @@ PCGX_HD bool gradient_descent_update(const UpdaterParams &u, int32_t &iter, cons
   return iter >= u.max_iteration;
 }
 
+// ---------------------------------------------------------------------------
+// Point-to-plane / Gauss-Newton extension.  NOT in the reference:
+// pcgol only declares the slots (Evaluated.Hessian mat.Mat6, Evaluator.HasHessian,
+// icp/evaluator.go:28,35,76; mat/mat6.go:3).  Conventions follow the reference's
+// point-to-point evaluator so the two are interchangeable behind icp.Evaluator:
+// the pose increment is applied on the left, p' = p + t + w x p (updater.go:65-68),
+// parameters ordered {t0,t1,t2,w0,w1,w2} like Evaluated.Gradient (evaluator.go:135-142).
+//   residual  r = n . (pt - pb)            (n: unit normal of the matched base point)
+//   Jacobian  J = {n, pt x n}
+//   30 sums   {sum r^2, sum J r [6], sum J J^T upper triangle row-major [21], sum w, pairs}
+enum { P_VALUE = 0, P_G0 = 1, P_H0 = 7, P_WEIGHT = 28, P_PAIRS = 29, P_COUNT = 30 };
+
+struct EvaluatedPlane {
+  float value;         // mean squared point-to-plane distance
+  float gradient[6];   // d value / d params = 2/sum(w) * sum J r
+  float hessian[36];   // Gauss-Newton Hessian 2/sum(w) * sum J J^T, symmetric (Mat6 slot)
+  int64_t num_pairs;
+};
+
+// One pair's terms, every product formed in float32 in this fixed expression order
+// (the oracle restates the same sequence); the caller accumulates them in float64.
+PCGX_HD void plane_terms(float x0, float y0, float z0, float x1, float y1, float z1, float nx, float ny,
+                         float nz, float J[6], float &r) {
+  const float dx = x0 - x1, dy = y0 - y1, dz = z0 - z1;
+  r = (nx * dx + ny * dy) + nz * dz;
+  J[0] = nx;
+  J[1] = ny;
+  J[2] = nz;
+  J[3] = y0 * nz - z0 * ny;
+  J[4] = z0 * nx - x0 * nz;
+  J[5] = x0 * ny - y0 * nx;
+}
+
+// Normalisation with the reference's convention (evaluator.go:156-163): f = 1/sum(w) only if > 1.
+PCGX_HD void finish_evaluate_plane(const double *sums, EvaluatedPlane &ev) {
+  const double sw = sums[P_WEIGHT];
+  const double f = sw > 1.0 ? 1.0 / sw : 1.0;
+  ev.value = (float)(sums[P_VALUE] * f);
+  for (int i = 0; i < 6; i++) ev.gradient[i] = (float)(sums[P_G0 + i] * (2.0 * f));
+  int k = 0;
+  for (int a = 0; a < 6; a++)
+    for (int b = a; b < 6; b++) {
+      const float h = (float)(sums[P_H0 + k] * (2.0 * f));
+      ev.hessian[6 * a + b] = h;
+      ev.hessian[6 * b + a] = h;
+      k++;
+    }
+  ev.num_pairs = (int64_t)sums[P_PAIRS];
+}
+
+struct GaussNewtonParams {
+  float threshold[6];   // flat test on the gradient, as updater.go:45-54 (all-zero -> 0.01)
+  float damping;        // Levenberg-Marquardt: H + damping * diag(H)
+  int32_t max_iteration;  // 0 -> 20 (updater.go:33)
+};
+
+PCGX_HD GaussNewtonParams resolve_gauss_newton(const float *threshold, float damping, int32_t max_iteration) {
+  GaussNewtonParams u;
+  bool tz = true;
+  for (int i = 0; i < 6; i++)
+    if (threshold[i] != 0.0f) tz = false;
+  for (int i = 0; i < 6; i++) u.threshold[i] = tz ? 0.01f : threshold[i];
+  u.damping = damping;
+  u.max_iteration = max_iteration == 0 ? 20 : max_iteration;
+  return u;
+}
+
+// Solves (H + damping diag H) d = -g by Cholesky in float64.  false: not positive definite.
+PCGX_HD bool gauss_newton_solve(const float *h36, const float *g6, float damping, float d6[6]) {
+  double a[6][6], y[6];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) a[i][j] = (double)h36[6 * i + j];
+  double tr = 0.0;
+  for (int i = 0; i < 6; i++) {
+    a[i][i] = a[i][i] + (double)damping * a[i][i];
+    tr += a[i][i];
+  }
+  if (!(tr > 0.0)) return false;
+  const double tiny = tr * 1e-12;
+  for (int j = 0; j < 6; j++) {  // a = L L^T, L stored in the lower triangle
+    double s = a[j][j];
+    for (int k = 0; k < j; k++) s -= a[j][k] * a[j][k];
+    if (!(s > tiny)) return false;
+    const double l = sqrt(s);
+    a[j][j] = l;
+    for (int i = j + 1; i < 6; i++) {
+      double t = a[i][j];
+      for (int k = 0; k < j; k++) t -= a[i][k] * a[j][k];
+      a[i][j] = t / l;
+    }
+  }
+  for (int i = 0; i < 6; i++) {  // L y = -g
+    double t = -(double)g6[i];
+    for (int k = 0; k < i; k++) t -= a[i][k] * y[k];
+    y[i] = t / a[i][i];
+  }
+  for (int i = 5; i >= 0; i--) {  // L^T d = y
+    double t = y[i];
+    for (int k = i + 1; k < 6; k++) t -= a[k][i] * y[k];
+    y[i] = t / a[i][i];
+  }
+  for (int i = 0; i < 6; i++) d6[i] = (float)y[i];
+  return true;
+}
+
+// Gauss-Newton counterpart of gradientDescentUpdater.Update: same flat test, same pose
+// composition trans = Translate(d0..2) * (Rodrigues(d3..5) * trans), same iteration cap.
+// Returns 1 converged, 0 continue, -1 singular normal equations (trans unchanged).
+PCGX_HD int gauss_newton_update(const GaussNewtonParams &u, int32_t &iter, const EvaluatedPlane &ev, Mat4 &trans) {
+  bool flat = true;
+  for (int j = 0; j < 6; j++) {
+    if (ev.gradient[j] < -u.threshold[j] || u.threshold[j] < ev.gradient[j]) {
+      flat = false;
+      break;
+    }
+  }
+  if (flat) return 1;
+  float d[6];
+  if (!gauss_newton_solve(ev.hessian, ev.gradient, u.damping, d)) return -1;
+  Mat4 delta_trans = mat4_translate(d[0], d[1], d[2]);
+  Mat4 delta_rot = rodrigues_to_rotation(d[3], d[4], d[5]);
+  trans = mat4_mul(delta_trans, mat4_mul(delta_rot, trans));
+  iter = iter + 1;
+  return iter >= u.max_iteration ? 1 : 0;
+}
+
 }  // namespace pcgx

@@ -90,7 +90,9 @@ class ShardedIcp:
     pose update runs on every GPU redundantly, so no rank ever waits for the host."""
 
     def __init__(self, base_tree, target_tile, MaxDist, MinPairs=0, Weight=None, Threshold=None,
-                 MaxIteration=0, group=None, force_exchange=False):
+                 MaxIteration=0, group=None, force_exchange=False, BaseNormals=None, Damping=0.0):
+        """BaseNormals: point-to-plane / Gauss-Newton extension; the exchange is then the all-reduce
+        of 30 doubles (sum r^2, J^T r, upper triangle of J^T J, sum w, pairs) instead of 10."""
         import torch
         self.torch = torch
         self.group = group
@@ -99,10 +101,10 @@ class ShardedIcp:
         # the partial sums and the update kernel after RCCL.  (torch's default stream has
         # handle 0, which the C ABI reads as "use the library's stream": never use it here.)
         self.stream = torch.cuda.Stream()
-        self.sums = torch.zeros(10, dtype=torch.float64, device="cuda")
+        self.sums = torch.zeros(30 if BaseNormals is not None else 10, dtype=torch.float64, device="cuda")
         torch.cuda.current_stream().synchronize()
         self.sess = _icp.IcpSession(base_tree, target_tile, MaxDist, MinPairs, Weight, Threshold, MaxIteration,
-                                    d_sums10=self.sums.data_ptr())
+                                    d_sums10=self.sums.data_ptr(), BaseNormals=BaseNormals, Damping=Damping)
         self.max_iteration = self.sess.max_iteration
         import torch.distributed as dist
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1

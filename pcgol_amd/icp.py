@@ -10,6 +10,7 @@ from .kdtree import KDTree
 
 ErrNotEnoughPairs = L.ErrNotEnoughPairs  # evaluator.go:16
 ErrNeedGradient = L.ErrNeedGradient      # icp.go:15
+ErrSingular = L.ErrSingular              # point-to-plane extension
 
 
 class PointToPointCorrespondence:  # correspondence.go:8-12
@@ -156,21 +157,37 @@ class IcpSession:
     """Device-resident Fit loop cut at the per-iteration exchange (include/pcgx.h)."""
 
     def __init__(self, base, target, MaxDist, MinPairs=0, Weight=None, Threshold=None, MaxIteration=0,
-                 d_sums10=0, target_on_device=False, nt=None):
+                 d_sums10=0, target_on_device=False, nt=None, BaseNormals=None, Damping=0.0):
+        """BaseNormals (unit normals per base point, id order; a device address when
+        target_on_device) selects the point-to-plane / Gauss-Newton extension: the exchange
+        vector then has 30 doubles (d_sums10 must point to 30)."""
         w = np.zeros(6, np.float32) if Weight is None else Weight
         th = np.zeros(6, np.float32) if Threshold is None else Threshold
         self.params = _params(MaxDist, base.MinDistSq, MinPairs, w, th, MaxIteration)
         self.max_iteration = MaxIteration or 20
         self.base = base
+        self.plane = BaseNormals is not None
+        self.n_sums = 30 if self.plane else 10
         if target_on_device:
             tptr, n = L.ptr(int(target)), int(nt)
         else:
             self._t = L.f32c(target).reshape(-1, 3)
             tptr, n = L.ptr(self._t), len(self._t)
         h = C.c_void_p()
-        L.check(L.lib().pcgx_icp_session_create(base._h, tptr, n, 1 if target_on_device else 0,
-                                                C.byref(self.params), L.ptr(int(d_sums10)) if d_sums10 else None,
-                                                C.byref(h)))
+        sums = L.ptr(int(d_sums10)) if d_sums10 else None
+        if self.plane:
+            if target_on_device:
+                nptr = L.ptr(int(BaseNormals))
+            else:
+                self._n = L.f32c(BaseNormals).reshape(-1, 3)
+                if len(self._n) != base.Len():
+                    raise ValueError("BaseNormals must hold one normal per base point")
+                nptr = L.ptr(self._n)
+            L.check(L.lib().pcgx_icp_plane_session_create(base._h, nptr, tptr, n, 1 if target_on_device else 0,
+                                                          C.byref(self.params), float(Damping), sums, C.byref(h)))
+        else:
+            L.check(L.lib().pcgx_icp_session_create(base._h, tptr, n, 1 if target_on_device else 0,
+                                                    C.byref(self.params), sums, C.byref(h)))
         self._h = h
 
     def partials(self, stream=0):
@@ -187,8 +204,14 @@ class IcpSession:
         L.check(L.lib().pcgx_icp_session_set_pose(self._h, L.ptr(t), int(it), L.ptr(stream) if stream else None))
 
     def read_sums(self, stream=0):
-        out = np.empty(10, np.float64)
-        L.check(L.lib().pcgx_icp_session_read_sums(self._h, L.ptr(out), L.ptr(stream) if stream else None))
+        out = np.empty(self.n_sums, np.float64)
+        L.check(L.lib().pcgx_icp_session_read_sums_n(self._h, L.ptr(out), self.n_sums,
+                                                     L.ptr(stream) if stream else None))
+        return out
+
+    def hessian(self, stream=0):
+        out = np.empty(36, np.float32)
+        L.check(L.lib().pcgx_icp_session_hessian(self._h, L.ptr(stream) if stream else None, L.ptr(out)))
         return out
 
     def reset(self, stream=0):
@@ -205,7 +228,10 @@ class IcpSession:
             e.trans, e.stat = trans, Stat(st)
             raise e
         L.check(rc)
-        return trans, Stat(st), bool(conv.value)
+        stat = Stat(st)
+        if self.plane:
+            stat.Evaluated.Hessian = self.hessian(stream)
+        return trans, stat, bool(conv.value)
 
     def close(self):
         if getattr(self, "_h", None) and L is not None:  # L is None during interpreter shutdown
@@ -213,3 +239,110 @@ class IcpSession:
             self._h = None
 
     __del__ = close
+
+
+# ---------------------------------------------------------------------------
+# Point-to-plane / Gauss-Newton extension (include/pcgx.h "point-to-plane ICP (extension)").
+# NOT in the reference: it fills the reference's unused slots Evaluated.Hessian / HasHessian()
+# (evaluator.go:28,35,76) behind the same Evaluator / Updater / Fit shapes.
+
+class PointToPlaneEvaluator:
+    """Evaluator whose residual is the distance to the matched base point's tangent plane.
+    BaseNormals: (n, 3) unit normals, one per base point in the tree's id order."""
+
+    def __init__(self, Corresponder, BaseNormals, MinPairs=0):
+        if not isinstance(Corresponder, NearestPointCorresponder):
+            raise TypeError("the GPU evaluator fuses NearestPointCorresponder")
+        self.Corresponder = Corresponder
+        self.BaseNormals = L.f32c(BaseNormals).reshape(-1, 3)
+        self.MinPairs = int(MinPairs)
+
+    def HasGradient(self):
+        return True
+
+    def HasHessian(self):
+        return True
+
+    def Sums(self, base, target):
+        """The 30 float64 sums of one evaluation (what N ranks all-reduce)."""
+        s = IcpSession(base, target, self.Corresponder.MaxDist, self.MinPairs, BaseNormals=self.BaseNormals)
+        try:
+            s.partials()
+            return s.read_sums()
+        finally:
+            s.close()
+
+    def Evaluate(self, base, target):
+        return FinishEvaluatePlane(self.Sums(base, target), self.MinPairs)
+
+
+def FinishEvaluatePlane(sums30, MinPairs=0):
+    s = np.ascontiguousarray(sums30, dtype=np.float64)
+    ev = L.IcpEvaluated()
+    h = np.empty(36, np.float32)
+    L.check(L.lib().pcgx_icp_plane_finish_evaluate(L.ptr(s), int(MinPairs), C.byref(ev), L.ptr(h)))
+    out = Evaluated(ev)
+    out.Hessian = h
+    return out
+
+
+class GaussNewtonUpdaterFactory:
+    """Threshold / MaxIteration as GradientDescentUpdaterFactory (zero -> 0.01 / 20); Damping is the
+    Levenberg-Marquardt factor on diag(H)."""
+
+    def __init__(self, Threshold=None, MaxIteration=0, Damping=0.0):
+        self.Weight = np.zeros(6, np.float32)
+        self.Threshold = np.zeros(6, np.float32) if Threshold is None else np.asarray(Threshold, np.float32)
+        self.MaxIteration = int(MaxIteration)
+        self.Damping = float(Damping)
+
+    def New(self):
+        return _GaussNewtonUpdater(self)
+
+
+class _GaussNewtonUpdater:
+    def __init__(self, f):
+        self.f = f
+        self.i = 0
+
+    def Update(self, trans, ev):
+        p = _params(0, 0, 0, self.f.Weight, self.f.Threshold, self.f.MaxIteration)
+        it = C.c_int32(self.i)
+        t = L.f32c(trans).copy()
+        g, h = L.f32c(ev.Gradient), L.f32c(ev.Hessian)
+        conv = C.c_int32()
+        L.check(L.lib().pcgx_icp_gauss_newton_update(C.byref(p), self.f.Damping, C.byref(it), L.ptr(g), L.ptr(h),
+                                                     L.ptr(t), C.byref(conv)))
+        self.i = it.value
+        return t, bool(conv.value)
+
+
+class PointToPlaneICP:
+    """Fit loop of icp.go:23-67 with PointToPlaneEvaluator + GaussNewtonUpdaterFactory, on the device."""
+
+    def __init__(self, Evaluator, UpdaterFactory=None):
+        if not isinstance(Evaluator, PointToPlaneEvaluator):
+            raise TypeError("PointToPlaneICP needs a PointToPlaneEvaluator")
+        self.Evaluator = Evaluator
+        self.UpdaterFactory = UpdaterFactory
+
+    def Fit(self, base, target):
+        ev = self.Evaluator
+        uf = self.UpdaterFactory or GaussNewtonUpdaterFactory()
+        target = L.f32c(target).reshape(-1, 3)
+        if len(ev.BaseNormals) != base.Len():
+            raise ValueError("BaseNormals must hold one normal per base point")
+        p = _params(ev.Corresponder.MaxDist, 0.0, ev.MinPairs, uf.Weight, uf.Threshold, uf.MaxIteration)
+        trans = np.empty(16, np.float32)
+        st = L.IcpStat()
+        h = np.zeros(36, np.float32)
+        rc = L.lib().pcgx_icp_plane_fit(base._h, L.ptr(ev.BaseNormals), L.ptr(target), len(target), C.byref(p),
+                                        uf.Damping, L.ptr(trans), C.byref(st), L.ptr(h))
+        if rc == L.PCGX_E_NOT_ENOUGH_PAIRS:
+            e = ErrNotEnoughPairs(rc, L.last_error())
+            e.trans, e.stat = trans, Stat(st)
+            raise e
+        L.check(rc)
+        stat = Stat(st)
+        stat.Evaluated.Hessian = h
+        return trans, stat

@@ -71,3 +71,34 @@ def c4_icp(n=1_000_000, width=10.0, base_seed=2, perm_seed=5):
     return dict(base=base, target=target, max_dist=0.5, min_pairs=6,
                 weight=np.full(6, 0.3, np.float32), threshold=np.full(6, -1.0, np.float32),
                 max_iteration=20)
+
+
+def surface_cloud(n, width, seed):
+    """Points on the smooth surface z = h(x, y) over [0, width)^2 with their analytic unit
+    normals (input of the point-to-plane extension; the uniform cube has no surface).
+    h = 0.5 sin(0.7 x) cos(0.5 y) + 0.3 sin(1.3 y): curved in both directions, so the
+    point-to-plane normal equations constrain all six pose parameters."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    k = rng.integers(0, 1 << 24, size=(n, 2), dtype=np.int64)
+    xy = (k.astype(np.float64) / float(1 << 24)) * float(width)
+    x, y = xy[:, 0], xy[:, 1]
+    z = 0.5 * np.sin(0.7 * x) * np.cos(0.5 * y) + 0.3 * np.sin(1.3 * y)
+    hx = 0.35 * np.cos(0.7 * x) * np.cos(0.5 * y)
+    hy = -0.25 * np.sin(0.7 * x) * np.sin(0.5 * y) + 0.39 * np.cos(1.3 * y)
+    nrm = np.stack([-hx, -hy, np.ones_like(x)], axis=1)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    pts = np.stack([x, y, z], axis=1)
+    return (np.ascontiguousarray(pts, dtype=np.float32), np.ascontiguousarray(nrm, dtype=np.float32))
+
+
+def c4_plane(n=1_000_000, width=None, base_seed=6, perm_seed=7):
+    """Point-to-plane variant of C4 (BASELINE.json "ICP point-to-plane, 1M source vs 1M target,
+    20 iters"): base = n surface points with normals, target_i = T * base[perm(i)], T = icp_pose();
+    MaxDist 0.5, MinPairs 6, Threshold -1 (all iterations), MaxIteration 20."""
+    if width is None:
+        width = 30.0 * (n / 1e6) ** 0.5  # ~1100 points per square metre at any n
+    base, normals = surface_cloud(n, width, base_seed)
+    perm = np.random.Generator(np.random.PCG64(perm_seed)).permutation(n)
+    target = transform_points(icp_pose(), base[perm])
+    return dict(base=base, normals=normals, target=target, max_dist=0.5, min_pairs=6,
+                threshold=np.full(6, -1.0, np.float32), max_iteration=20, damping=0.0)

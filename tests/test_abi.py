@@ -82,3 +82,49 @@ def test_finish_evaluate_and_update_match_oracle():
         if conv:
             break
     assert u.i == 20  # default MaxIteration (updater.go:31-33)
+
+
+def test_plane_finish_and_gauss_newton_match_oracle():
+    """Point-to-plane extension (no reference parity): the product's host pieces (pcgx_math.h)
+    against the oracle's independent restatement (oracle/plane_oracle.c), no GPU needed."""
+    from pcgol_amd import synth
+    c = synth.c4_plane(3000)
+    t = O.KDTree(c["base"])
+    sums = O.plane_sums(t, c["normals"], c["target"], c["max_dist"])
+    oe = O.plane_finish(sums, 6)
+    ev = icp.FinishEvaluatePlane(sums, 6)
+    assert ev.Value == oe["value"] and ev.NumPairs == oe["npairs"]
+    assert np.array_equal(ev.Gradient, oe["gradient"]) and np.array_equal(ev.Hessian, oe["hessian"])
+    with pytest.raises(icp.ErrNotEnoughPairs):
+        icp.FinishEvaluatePlane(sums, 3001)
+    th = np.full(6, -1, np.float32)
+    u = icp.GaussNewtonUpdaterFactory(Threshold=th, MaxIteration=4, Damping=0.01).New()
+    tr, otr, it = mat.Translate(0, 0, 0), O.translate(0, 0, 0), 0
+    for k in range(4):
+        tr, conv = u.Update(tr, ev)
+        otr, oconv, it = O.gauss_newton_update(otr, oe["gradient"], oe["hessian"], it, th, 0.01, 4)
+        assert conv == oconv == (k == 3) and u.i == it
+        assert np.max(np.abs(tr - otr)) <= 1e-7
+    # flat test first (updater.go:45-54): a gradient inside the default thresholds converges at once
+    small = icp.Evaluated()
+    small.Gradient = np.full(6, 0.001, np.float32)
+    small.Hessian = np.eye(6, dtype=np.float32).reshape(-1)
+    assert icp.GaussNewtonUpdaterFactory().New().Update(mat.Translate(0, 0, 0), small)[1] is True
+    # singular normal equations are an error, not a silent step
+    bad = icp.Evaluated()
+    bad.Gradient = np.ones(6, np.float32)
+    bad.Hessian = np.zeros(36, np.float32)
+    with pytest.raises(icp.ErrSingular):
+        icp.GaussNewtonUpdaterFactory().New().Update(mat.Translate(0, 0, 0), bad)
+    with pytest.raises(O.OracleError):
+        O.gauss_newton_update(O.translate(0, 0, 0), bad.Gradient, bad.Hessian, 0)
+
+
+def test_oracle_plane_fit_recovers_pose():
+    """Sanity of the extension's oracle itself against synthetic ground truth."""
+    from pcgol_amd import synth
+    c = synth.c4_plane(4000)
+    o = O.plane_fit(O.KDTree(c["base"]), c["normals"], c["target"], c["max_dist"], 6, c["threshold"], 0.0, 8)
+    inv = np.linalg.inv(synth.icp_pose().astype(np.float64).reshape(4, 4).T).T.reshape(-1)
+    assert o["num_iteration"] == 8
+    assert np.max(np.abs(o["trans"].astype(np.float64) - inv)) < 5e-4
