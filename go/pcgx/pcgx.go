@@ -313,3 +313,98 @@ func Fit(base *KDTree, target pc.Vec3RandomAccessor, e *Evaluator, u *icp.Gradie
 	}
 	return trans, stat, status(rc)
 }
+
+// ------------------------------------------ point-to-plane ICP (extension)
+
+// ErrSingular: the 6x6 normal equations are not positive definite.
+var ErrSingular = errors.New("pcgx: normal equations are not positive definite")
+
+// PlaneEvaluator fills the slots the reference leaves empty (Evaluated.Hessian,
+// HasHessian(), evaluator.go:28,35,76): point-to-plane residual r = n.(pt-pb),
+// J = {n, pt x n}, Hessian = 2/sum(w) * sum J J^T.  BaseNormals holds one unit
+// normal per base point in the tree's id order.  No counterpart in the reference.
+type PlaneEvaluator struct {
+	MaxDist     float32
+	MinPairs    int
+	BaseNormals []mat.Vec3
+}
+
+var _ icp.Evaluator = (*PlaneEvaluator)(nil)
+
+func (PlaneEvaluator) HasGradient() bool { return true }
+func (PlaneEvaluator) HasHessian() bool  { return true }
+
+// Evaluate runs one fused correspondence + 30-sum reduction on the device.
+func (e *PlaneEvaluator) Evaluate(base storage.Search, target pc.Vec3RandomAccessor) (*icp.Evaluated, error) {
+	k, ok := base.(*KDTree)
+	if !ok {
+		return nil, errors.New("pcgx: base must be a *pcgx.KDTree")
+	}
+	if len(e.BaseNormals) != k.Len() || len(e.BaseNormals) == 0 {
+		return nil, errors.New("pcgx: one normal per base point is required")
+	}
+	t := packVec3(target)
+	var tp *C.float
+	if len(t) > 0 {
+		tp = (*C.float)(unsafe.Pointer(&t[0]))
+	}
+	var p C.pcgx_icp_params
+	p.max_dist, p.min_pairs = C.float(e.MaxDist), C.int32_t(e.MinPairs)
+	var s *C.pcgx_icp_session
+	rc := C.pcgx_icp_plane_session_create(k.h, (*C.float)(unsafe.Pointer(&e.BaseNormals[0])), tp,
+		C.int64_t(target.Len()), 0, &p, 0, nil, &s)
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	defer C.pcgx_icp_session_free(s)
+	if err := status(C.pcgx_icp_session_partials(s, nil)); err != nil {
+		return nil, err
+	}
+	var sums [30]C.double
+	if err := status(C.pcgx_icp_session_read_sums_n(s, &sums[0], 30, nil)); err != nil {
+		return nil, err
+	}
+	var ev C.pcgx_icp_evaluated
+	out := &icp.Evaluated{}
+	rc = C.pcgx_icp_plane_finish_evaluate(&sums[0], C.int32_t(e.MinPairs), &ev, (*C.float)(unsafe.Pointer(&out.Hessian[0])))
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	out.Value = float32(ev.value)
+	for i := 0; i < 6; i++ {
+		out.Gradient[i] = float32(ev.gradient[i])
+	}
+	return out, nil
+}
+
+// FitPlane runs the whole loop (icp.go:23-67 shape) with the point-to-plane
+// evaluator and a Gauss-Newton updater on the device.
+func FitPlane(base *KDTree, target pc.Vec3RandomAccessor, e *PlaneEvaluator, threshold mat.Vec6, maxIteration int, damping float32) (mat.Mat4, icp.Stat, error) {
+	var p C.pcgx_icp_params
+	p.max_dist, p.min_pairs, p.max_iteration = C.float(e.MaxDist), C.int32_t(e.MinPairs), C.int32_t(maxIteration)
+	for i := 0; i < 6; i++ {
+		p.threshold[i] = C.float(threshold[i])
+	}
+	t := packVec3(target)
+	var tp *C.float
+	if len(t) > 0 {
+		tp = (*C.float)(unsafe.Pointer(&t[0]))
+	}
+	var trans mat.Mat4
+	var st C.pcgx_icp_stat
+	stat := icp.Stat{}
+	if len(e.BaseNormals) != base.Len() || len(e.BaseNormals) == 0 {
+		return trans, stat, errors.New("pcgx: one normal per base point is required")
+	}
+	rc := C.pcgx_icp_plane_fit(base.h, (*C.float)(unsafe.Pointer(&e.BaseNormals[0])), tp, C.int64_t(target.Len()), &p,
+		C.float(damping), (*C.float)(unsafe.Pointer(&trans[0])), &st, (*C.float)(unsafe.Pointer(&stat.Hessian[0])))
+	stat.NumIteration = int(st.num_iteration)
+	stat.Value = float32(st.evaluated.value)
+	for i := 0; i < 6; i++ {
+		stat.Gradient[i] = float32(st.evaluated.gradient[i])
+	}
+	if rc == C.PCGX_E_SINGULAR {
+		return trans, stat, ErrSingular
+	}
+	return trans, stat, status(rc)
+}

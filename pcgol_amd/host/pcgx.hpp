@@ -7,6 +7,8 @@
 //   pcgx::KDTree            <- pc/storage/kdtree.KDTree      (storage.Search)
 //   pcgx::VoxelGrid         <- pc/filter/voxelgrid.New(...)  (filter.Filter)
 //   pcgx::PointToPointICP   <- icp.PointToPointICPGradient{Evaluator, UpdaterFactory}
+//   pcgx::PointToPlaneICP   <- (extension, no counterpart in the reference) the same Fit shape with
+//                              the point-to-plane evaluator / Gauss-Newton updater, HasHessian() == true
 #pragma once
 #include <array>
 #include <cstring>
@@ -24,6 +26,7 @@ struct Error : std::runtime_error {
 };
 struct ErrNoPoint : Error { using Error::Error; };          // pc/minmax.go:11
 struct ErrNotEnoughPairs : Error { using Error::Error; };   // icp/evaluator.go:16
+struct ErrSingular : Error { using Error::Error; };         // point-to-plane extension
 
 inline void check(pcgx_status rc) {
   if (rc == PCGX_OK) return;
@@ -31,6 +34,7 @@ inline void check(pcgx_status rc) {
   pcgx_last_error(buf, sizeof buf);
   if (rc == PCGX_E_NO_POINT) throw ErrNoPoint(rc, buf);
   if (rc == PCGX_E_NOT_ENOUGH_PAIRS) throw ErrNotEnoughPairs(rc, buf);
+  if (rc == PCGX_E_SINGULAR) throw ErrSingular(rc, buf);
   throw Error(rc, buf);
 }
 
@@ -70,6 +74,19 @@ class KDTree {  // pc/storage/kdtree/kdtree.go:14-23
     for (size_t i = 0; i < q.size(); i++) out[i] = Neighbor{ids[i], d[i]};
     return out;
   }
+  // KDTree.Range (kdtree.go:148-197): neighbours with DistSq < maxRange^2, sorted by DistSq.
+  std::vector<Neighbor> Range(const Vec3 &p, float maxRange) const {
+    int64_t cnt = 0;
+    check(pcgx_kdtree_range_count(h_, p.data(), 1, maxRange, &cnt));
+    const int64_t offs[2] = {0, cnt};
+    std::vector<int64_t> ids((size_t)cnt);
+    std::vector<float> d((size_t)cnt);
+    check(pcgx_kdtree_range_fill(h_, p.data(), 1, maxRange, offs, ids.data(), d.data()));
+    std::vector<Neighbor> out((size_t)cnt);
+    for (int64_t i = 0; i < cnt; i++) out[(size_t)i] = Neighbor{ids[(size_t)i], d[(size_t)i]};
+    return out;
+  }
+  int32_t MaxDepth() const { int32_t d; check(pcgx_kdtree_max_depth(h_, &d)); return d; }
   const pcgx_kdtree *handle() const { return h_; }
 
  private:
@@ -116,6 +133,43 @@ class PointToPointICP {  // icp.go:18-67 with evaluator.go:69-73 and updater.go:
     check(pcgx_icp_fit(base.handle(), target.empty() ? nullptr : target[0].data(), (int64_t)target.size(), &p,
                        t.data(), &st));
     return {t, Stat{st.evaluated, st.num_iteration}};
+  }
+};
+
+// Extension (no counterpart in the reference; include/pcgx.h "point-to-plane ICP (extension)"):
+// the Fit loop with the point-to-plane evaluator (fills Evaluated.Hessian) and a Gauss-Newton updater.
+struct PlaneStat {
+  pcgx_icp_evaluated Evaluated;
+  std::array<float, 36> Hessian;  // Evaluated.Hessian (mat.Mat6)
+  int NumIteration;
+};
+
+class PointToPlaneICP {
+ public:
+  float MaxDist = 0.0f;
+  int MinPairs = 0;
+  std::array<float, 6> Threshold{};
+  int MaxIteration = 0;
+  float Damping = 0.0f;
+  bool HasGradient() const { return true; }
+  bool HasHessian() const { return true; }
+  // baseNormals: one unit normal per base point, in the tree's id order.
+  std::pair<Mat4, PlaneStat> Fit(const KDTree &base, const std::vector<Vec3> &baseNormals,
+                                 const std::vector<Vec3> &target) const {
+    if ((int64_t)baseNormals.size() != base.Len()) throw Error(PCGX_E_INVALID, "one normal per base point is required");
+    pcgx_icp_params p{};
+    p.max_dist = MaxDist;
+    p.min_pairs = MinPairs;
+    std::memcpy(p.threshold, Threshold.data(), sizeof p.threshold);
+    p.max_iteration = MaxIteration;
+    Mat4 t;
+    PlaneStat ps{};
+    pcgx_icp_stat st{};
+    check(pcgx_icp_plane_fit(base.handle(), baseNormals[0].data(), target.empty() ? nullptr : target[0].data(),
+                             (int64_t)target.size(), &p, Damping, t.data(), &st, ps.Hessian.data()));
+    ps.Evaluated = st.evaluated;
+    ps.NumIteration = st.num_iteration;
+    return {t, ps};
   }
 };
 

@@ -1,0 +1,107 @@
+// Drives the C++ host mirror (pcgol_amd/host/pcgx.hpp) over the C ABI and prints results in a
+// line format tests/test_cpp_host.py compares with the reference's known-answer tables
+// (tests/golden/ref_*.json).  Input: a text file written by the test
+//   P n            followed by n lines "x y z"        base cloud
+//   Q m max_range  followed by m lines "x y z"        Nearest queries
+//   R m            followed by m lines "x y z range"  Range queries
+//   V n stride     followed by n lines "x y z label"  voxel cloud (stride 16: x y z label)
+//   L lx ly lz cx cy cz                               leaf + chunk, runs the filter
+#include <cinttypes>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <sstream>
+
+#include "../../pcgol_amd/host/pcgx.hpp"
+
+int main(int argc, char **argv) {
+  if (argc < 2) return 2;
+  try {
+    pcgx::check(pcgx_init(0));
+    std::ifstream in(argv[1]);
+    std::string tag;
+    std::vector<pcgx::Vec3> base;
+    std::vector<uint8_t> vox;
+    int64_t vox_n = 0;
+    std::unique_ptr<pcgx::KDTree> tree;
+    while (in >> tag) {
+      if (tag == "P") {
+        size_t n; in >> n;
+        base.resize(n);
+        for (auto &p : base) in >> p[0] >> p[1] >> p[2];
+        tree.reset(new pcgx::KDTree(base));
+        std::printf("tree len %" PRId64 " depth %d\n", tree->Len(), tree->MaxDepth());
+      } else if (tag == "M") {
+        float md; in >> md;
+        tree->MinDistSq = md * md;
+      } else if (tag == "Q") {
+        size_t m; float mr; in >> m >> mr;
+        std::vector<pcgx::Vec3> q(m);
+        for (auto &p : q) in >> p[0] >> p[1] >> p[2];
+        for (const auto &nb : tree->NearestBatch(q, mr)) std::printf("nearest %" PRId64 " %.9g\n", nb.ID, nb.DistSq);
+      } else if (tag == "R") {
+        size_t m; in >> m;
+        for (size_t i = 0; i < m; i++) {
+          pcgx::Vec3 p; float r; in >> p[0] >> p[1] >> p[2] >> r;
+          std::printf("range");
+          for (const auto &nb : tree->Range(p, r)) std::printf(" %" PRId64 ":%.9g", nb.ID, nb.DistSq);
+          std::printf("\n");
+        }
+      } else if (tag == "V") {
+        in >> vox_n;
+        vox.resize((size_t)vox_n * 16);
+        for (int64_t i = 0; i < vox_n; i++) {
+          float xyz[3]; uint32_t label;
+          in >> xyz[0] >> xyz[1] >> xyz[2] >> label;
+          std::memcpy(&vox[(size_t)i * 16], xyz, 12);
+          std::memcpy(&vox[(size_t)i * 16 + 12], &label, 4);
+        }
+      } else if (tag == "L") {
+        pcgx::Vec3 leaf; std::array<int32_t, 3> chunk;
+        in >> leaf[0] >> leaf[1] >> leaf[2] >> chunk[0] >> chunk[1] >> chunk[2];
+        pcgx::VoxelGrid vg(leaf);
+        vg.WithChunkSize(chunk);
+        auto out = vg.Filter(pcgx::CloudView{vox.data(), vox_n, 16, 0});
+        std::printf("voxel");
+        for (size_t i = 0; i < out.size() / 16; i++) {
+          float xyz[3]; uint32_t label;
+          std::memcpy(xyz, &out[i * 16], 12);
+          std::memcpy(&label, &out[i * 16 + 12], 4);
+          std::printf(" %.9g,%.9g,%.9g,%u", xyz[0], xyz[1], xyz[2], label);
+        }
+        std::printf("\n");
+      } else if (tag == "I") {  // ICP: target = base + (dx,dy,dz); point-to-point Fit with MinPairs / MaxDist
+        float dx, dy, dz, maxd; int minp;
+        in >> dx >> dy >> dz >> maxd >> minp;
+        std::vector<pcgx::Vec3> target(base);
+        for (auto &p : target) { p[0] += dx; p[1] += dy; p[2] += dz; }
+        pcgx::PointToPointICP reg;
+        reg.MaxDist = maxd;
+        reg.MinPairs = minp;
+        auto r = reg.Fit(*tree, target);
+        std::printf("icp iters %d value %.9g trans", r.second.NumIteration, r.second.Evaluated.value);
+        for (float v : r.first) std::printf(" %.9g", v);
+        std::printf("\n");
+        try {
+          reg.MinPairs = (int)base.size() + 1;
+          reg.Fit(*tree, target);
+          std::printf("icp_minpairs no-error\n");
+        } catch (const pcgx::ErrNotEnoughPairs &) {
+          std::printf("icp_minpairs ErrNotEnoughPairs\n");
+        }
+      }
+    }
+    try {
+      pcgx::KDTree empty(std::vector<pcgx::Vec3>{});
+      std::printf("empty no-error\n");
+    } catch (const pcgx::ErrNoPoint &) {
+      std::printf("empty ErrNoPoint\n");
+    }
+  } catch (const std::exception &e) {
+    std::printf("EXCEPTION %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -1,0 +1,90 @@
+"""The C++ host mirror (pcgol_amd/host/pcgx.hpp) over the C ABI: compiled with g++ everywhere
+(CPU check: it builds and links against libpcgx.so), run on the GPU box against the
+reference's known-answer tables (tests/golden/ref_*.json)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "host_mirror.cpp")
+
+
+def _build(tmpdir):
+    from pcgol_amd import build as B
+    B.build()
+    exe = os.path.join(str(tmpdir), "host_mirror")
+    libdir = os.path.join(ROOT, "pcgol_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", exe, SRC, "-L" + libdir, "-lpcgx",
+                           "-Wl,-rpath," + libdir])
+    return exe
+
+
+def test_cpp_host_mirror_compiles_and_links(tmp_path):
+    exe = _build(tmp_path)
+    assert os.path.getsize(exe) > 0
+    out = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libpcgx.so" in out and "not found" not in out.split("libpcgx.so")[1].split("\n")[0]
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_known_answers(tmp_path, golden):
+    exe = _build(tmp_path)
+    kd = golden("ref_kdtree.json")
+    vx = golden("ref_voxelgrid.json")
+    lines = []
+    pts = kd["test_cloud"]["points"]
+    lines.append("P %d" % len(pts))
+    lines += ["%r %r %r" % tuple(map(float, p)) for p in pts]
+    ncases = kd["nearest"]["cases"]
+    for md in kd["nearest"]["min_dist"]:
+        lines.append("M %r" % md)
+        for c in ncases:  # max_range differs per case: one batch each
+            lines.append("Q 1 %r" % c["max_range"])
+            lines.append("%r %r %r" % tuple(map(float, c["p"])))
+    lines.append("M 0")
+    lines.append("I 0.01 -0.02 0.015 2.0 3")
+    rp = kd["range"]["points"]
+    lines.append("P %d" % len(rp))
+    lines += ["%r %r %r" % tuple(map(float, p)) for p in rp]
+    lines.append("R %d" % len(kd["range"]["cases"]))
+    lines += ["%r %r %r %r" % (*map(float, c["p"]), c["max_range"]) for c in kd["range"]["cases"]]
+    lines.append("V %d" % len(vx["cloud"]["xyz"]))
+    lines += ["%r %r %r %d" % (*map(float, p), l) for p, l in zip(vx["cloud"]["xyz"], vx["cloud"]["label"])]
+    for c in vx["cases"]:
+        lines.append("L %r %r %r %d %d %d" % (*vx["leaf"], *c["chunk"]))
+    inp = tmp_path / "in.txt"
+    inp.write_text("\n".join(lines) + "\n")
+    r = subprocess.run([exe, str(inp)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.strip().split("\n")
+    assert out[0] == "tree len 7 depth %d" % kd["max_depth"]["cases"][-1]["expected"]
+    near = [l.split() for l in out if l.startswith("nearest")]
+    assert len(near) == 2 * len(ncases)
+    eps = kd["nearest"]["eps"]
+    for k, l in enumerate(near):
+        c = ncases[k % len(ncases)]
+        assert int(l[1]) == c["id"] and abs(float(l[2]) - c["dist_sq"]) <= eps, (k, l, c)
+    rng = [l for l in out if l.startswith("range")]
+    for l, c in zip(rng, kd["range"]["cases"]):
+        got = [(int(t.split(":")[0]), float(t.split(":")[1])) for t in l.split()[1:]]
+        assert [g[0] for g in got] == [nb[0] for nb in c["neighbors"]]
+        assert all(abs(g[1] - nb[1]) <= kd["range"]["eps"] for g, nb in zip(got, c["neighbors"]))
+    vox = [l for l in out if l.startswith("voxel")]
+    for l, c in zip(vox, vx["cases"]):
+        recs = [t.split(",") for t in l.split()[1:]]
+        assert [int(r[3]) for r in recs] == c["expected_labels"], c["name"]
+        got = np.array([[float(v) for v in r[:3]] for r in recs], np.float32)
+        assert np.array_equal(got, np.array(c["expected"], np.float32)), c["name"]
+    icp = [l for l in out if l.startswith("icp ")][0].split()
+    # same Fit through the Python mirror (same C ABI): identical transform
+    from pcgol_amd import icp as picp, kdtree
+    base = np.array(pts, np.float32)
+    target = base + np.array([0.01, -0.02, 0.015], np.float32)
+    tr, st = picp.PointToPointICPGradient(picp.PointToPointEvaluator(picp.NearestPointCorresponder(2.0), 3)).Fit(
+        kdtree.New(base), target)
+    assert int(icp[2]) == st.NumIteration
+    assert np.array_equal(np.array([float(v) for v in icp[6:22]], np.float32), tr)
+    assert "icp_minpairs ErrNotEnoughPairs" in out and "empty ErrNoPoint" in out
