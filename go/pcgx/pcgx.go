@@ -127,6 +127,16 @@ func (k *KDTree) Close() {
 	}
 }
 
+// DeletePoint removes a point from the tree (KDTree.DeletePoint, kdtree.go:322-332).
+func (k *KDTree) DeletePoint(pID int) error {
+	id := C.int64_t(pID)
+	rc := C.pcgx_kdtree_delete_points(k.h, &id, 1)
+	if rc == C.PCGX_E_OUT_OF_RANGE {
+		return fmt.Errorf("%d does not correspond to any point in the tree", pID) // kdtree.go:324
+	}
+	return status(rc)
+}
+
 // NearestBatch is the batched seam: result i equals k.Nearest(q[i], maxRange).
 func (k *KDTree) NearestBatch(q []mat.Vec3, maxRange float32) ([]storage.Neighbor, error) {
 	n := len(q)

@@ -121,6 +121,20 @@ PCGX_API pcgx_status pcgx_kdtree_inorder(const pcgx_kdtree *t, int64_t *ids /* [
 PCGX_API pcgx_status pcgx_kdtree_points(const pcgx_kdtree *t, const int64_t *ids, int64_t m,
                                         float *xyz /* [3m] host */);
 
+/* KDTree.DeletePoint (kdtree.go:322-332) for a batch of ids.  An id outside [0, Len()) is
+ * PCGX_E_OUT_OF_RANGE (the reference's "does not correspond to any point in the tree",
+ * :323-325) and deletes nothing; deleting a point twice is a no-op (kdtree_test.go:576-650).
+ * Len() / Vec3At() keep describing the accessor (all points), as in the reference.
+ * The implicit device layout cannot express the reference's patched tree (findMinimum /
+ * deleteNodeImpl, :224-320): the next query rebuilds the canonical tree over the remaining
+ * points (their ids unchanged).  Results equal the reference's -- the nearest / in-range points
+ * among the remaining ones, ID and DistSq exact -- except where the reference's answer depends on
+ * its tree shape: exact-distance ties and MinDistSq > 0.  max_depth / inorder then describe the
+ * rebuilt tree; open ICP sessions keep the tree they were created on. */
+PCGX_API pcgx_status pcgx_kdtree_delete_points(pcgx_kdtree *t, const int64_t *ids, int64_t m);
+/* Points still in the tree (Len() minus deleted). */
+PCGX_API pcgx_status pcgx_kdtree_live_count(const pcgx_kdtree *t, int64_t *n_live);
+
 /* Batched KDTree.Nearest: for each query i the exact result of
  * k.Nearest(q[i], max_range) with k.MinDistSq = min_dist_sq, i.e.
  * {ID, DistSq} or {-1, max_range^2} (kdtree.go:84-86,100-103).

@@ -56,6 +56,10 @@ def lib():
         L.orc_naive_nearest.argtypes = [vp, i64, vp, f32, vp, vp]
         L.orc_kdtree_range.restype = i64
         L.orc_kdtree_range.argtypes = [vp, vp, f32, vp, vp, i64]
+        L.orc_kdtree_find_minimum.restype = i64
+        L.orc_kdtree_find_minimum.argtypes = [vp, i32]
+        L.orc_kdtree_delete_point.restype = i32
+        L.orc_kdtree_delete_point.argtypes = [vp, i64]
         L.orc_minmax.restype = i32
         L.orc_minmax.argtypes = [vp, i64, i32, i32, vp, vp]
         L.orc_voxel_filter.restype = i32
@@ -204,6 +208,27 @@ class KDTree:
         if stats:
             return ids, dsq, tv.value, td.value
         return ids, dsq
+
+    def find_minimum(self, dim):
+        """findMinimumImpl from the root (kdtree.go:224-262); ValueError for dim > 2."""
+        r = lib().orc_kdtree_find_minimum(self.h, dim)
+        if r == -2:
+            raise ValueError("dim should be <3")
+        return r
+
+    def delete_point(self, pid):
+        """KDTree.DeletePoint (kdtree.go:322-332); IndexError for an id outside [0, Len())."""
+        if lib().orc_kdtree_delete_point(self.h, pid):
+            raise IndexError("%d does not correspond to any point in the tree" % pid)
+
+    def tree(self):
+        """Nested [id, dim, child0, child1] form of the current tree (None = nil)."""
+        d = self.dump()
+        def rec(k):
+            if k < 0:
+                return None
+            return [int(d[k][0]), int(d[k][1]), rec(int(d[k][2])), rec(int(d[k][3]))]
+        return rec(0) if len(d) else None
 
     def search_leaf(self, p):
         p = _f32(p)

@@ -282,6 +282,61 @@ void orc_kdtree_inorder(const okdtree *t, int64_t *out) {
   inorder_rec(t->root, out, &k);
 }
 
+/* kdtree.go:224-262 findMinimumImpl: id of the point with the smallest coordinate `dim` in the
+ * subtree (-1 for an empty subtree); ties keep the earlier candidate in the order
+ * node, child0's minimum, child1's minimum (strict <, :234-241). */
+static int64_t find_minimum_impl(const okdtree *t, const onode *n, int dim) {
+  if (!n) return -1;
+  if (n->dim == dim) {
+    if (!n->children[0]) return n->id;
+    return find_minimum_impl(t, n->children[0], dim);
+  }
+  int64_t min0 = find_minimum_impl(t, n->children[0], dim);
+  int64_t min1 = find_minimum_impl(t, n->children[1], dim);
+  int64_t min = n->id;
+  if (min0 != -1 && t->pts[3 * min0 + dim] < t->pts[3 * min + dim]) min = min0;
+  if (min1 != -1 && t->pts[3 * min1 + dim] < t->pts[3 * min + dim]) min = min1;
+  return min;
+}
+/* dim > 2 is an error in the reference (:225-227): -2 here */
+int64_t orc_kdtree_find_minimum(const okdtree *t, int32_t dim) {
+  if (dim > 2 || dim < 0) return -2;
+  return find_minimum_impl(t, t->root, dim);
+}
+
+/* kdtree.go:264-320 deleteNodeImpl */
+static onode *delete_node_impl(okdtree *t, onode *n, int64_t pid) {
+  if (!n) return NULL;
+  if (pid == n->id) {
+    if (n->children[1]) {
+      int64_t m = find_minimum_impl(t, n->children[1], n->dim);
+      onode *child = delete_node_impl(t, n->children[1], m);
+      n->id = m;
+      n->children[1] = child;
+    } else if (n->children[0]) {
+      int64_t m = find_minimum_impl(t, n->children[0], n->dim);
+      onode *child = delete_node_impl(t, n->children[0], m);
+      n->id = m;
+      n->children[0] = NULL;
+      n->children[1] = child;
+    } else {
+      return NULL;
+    }
+    return n;
+  }
+  const float *at = t->pts + 3 * n->id, *p = t->pts + 3 * pid;
+  if (p[n->dim] <= at[n->dim]) n->children[0] = delete_node_impl(t, n->children[0], pid);
+  if (p[n->dim] >= at[n->dim]) n->children[1] = delete_node_impl(t, n->children[1], pid);
+  return n;
+}
+/* kdtree.go:322-332 DeletePoint: range error for pID outside [0, Len()); deleting a point that
+ * is no longer in the tree leaves it unchanged */
+int orc_kdtree_delete_point(okdtree *t, int64_t pid) {
+  if (pid < 0 || pid > t->n - 1) return ORC_E_PANIC + 100; /* "does not correspond to any point" */
+  t->root = delete_node_impl(t, t->root, pid);
+  return ORC_OK;
+}
+
 /* kdtree.go:67-70 nodeStack (explicit array; the sync.Pool is irrelevant) */
 typedef struct {
   okdtree *t;
@@ -353,10 +408,15 @@ static oneighbor nearest_impl(ostack *ns, const float *p, float max_range_sq) {
   return n1;
 }
 
-/* kdtree.go:83-92 Nearest.  root==nil cannot occur here (no DeletePoint). */
+/* kdtree.go:83-92 Nearest; root == nil (everything deleted) -> {-1, maxRange^2} (:84-86) */
 void orc_kdtree_nearest(okdtree *t, const float *p, float max_range,
                         float min_dist_sq, int64_t *id, float *dsq) {
   const onode *buf[64];
+  if (!t->root) {
+    *id = -1;
+    *dsq = max_range * max_range;
+    return;
+  }
   ostack ns = {t, buf, 0, min_dist_sq};
   t->stat_visits = 1;
   t->stat_dists = 0;
@@ -450,6 +510,7 @@ int64_t orc_kdtree_range(okdtree *t, const float *p, float max_range,
   onlist l = {0, 0, 0};
   const onode *buf[64];
   ostack ns = {t, buf, 0, 0.0f};
+  if (!t->root) return 0; /* kdtree.go:150-152 */
   ns.nn[ns.len++] = t->root;
   search_leaf_node(&ns, p);
   range_impl(&ns, p, max_range * max_range, &l);

@@ -431,6 +431,11 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
     return fail(PCGX_E_INVALID, "pcgx_icp_session_create: bad argument");
   PCGX_TRY(ensure_init());
   hipStream_t st = ctx().stream;
+  const int64_t n_base_ids = base->n;  // normals are indexed by the original ids
+  bool empty = false;
+  PCGX_TRY(resolve_tree(base, &base, &empty));  // after DeletePoint: the tree over the remaining points
+  if (empty)  // no node left: Pairs() finds nothing (correspondence.go:27-29 with kdtree.go:84-86)
+    return fail(PCGX_E_NOT_ENOUGH_PAIRS, "not enough correspondence pairs (every base point was deleted)");
   pcgx_icp_session *s = new pcgx_icp_session();
   s->base = base;
   s->nt = nt;
@@ -459,7 +464,7 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
     s->own_sums = true;
   }
   if (s->plane) {
-    const int64_t nb = base->n;
+    const int64_t nb = n_base_ids;
     if ((e = hipMalloc((void **)&s->d_match_id, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
         (e = hipMalloc((void **)&s->d_normals, (size_t)nb * sizeof(float4))) != hipSuccess)
       return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));

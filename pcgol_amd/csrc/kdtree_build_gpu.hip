@@ -86,7 +86,8 @@ __global__ __launch_bounds__(256) void kb_iota_kernel(uint32_t *__restrict__ a, 
 // nodes[b] = {x, y, z, bits(id)} of the point at the in-order position of BFS slot b
 __global__ __launch_bounds__(256) void kb_fill_bfs_kernel(const float *__restrict__ xyz,
                                                           const uint32_t *__restrict__ order, uint32_t n_total,
-                                                          uint32_t slots, float4 *__restrict__ nodes) {
+                                                          uint32_t slots, const int32_t *__restrict__ labels,
+                                                          float4 *__restrict__ nodes) {
   const uint32_t b = blockIdx.x * 256u + threadIdx.x;
   if (b >= slots) return;
   float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -106,7 +107,10 @@ __global__ __launch_bounds__(256) void kb_fill_bfs_kernel(const float *__restric
     }
     if (exists && n > 0u) {
       const uint32_t id = order[lo + (n >> 1)];
-      out = make_float4(xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2], __uint_as_float(id));
+      // labels: the id a node reports (trees rebuilt over the points left after DeletePoint keep
+      // the ids of the original accessor)
+      const uint32_t label = labels ? (uint32_t)labels[id] : id;
+      out = make_float4(xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2], __uint_as_float(label));
     }
   }
   nodes[b] = out;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void kb_fill_bfs_kernel(const float *__restric
 // d_xyz: packed xyz of the base cloud on the device; d_order (out): in-order point ids;
 // d_nodes (out): BFS slots.  Uses the arena (caller has begun it).
 pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint32_t *d_order, float4 *d_nodes,
-                              hipStream_t st) {
+                              const int32_t *d_labels, hipStream_t st) {
   Arena &ar = ctx().arena;
   const uint32_t un = (uint32_t)n;
   const unsigned nb = (unsigned)((n + 255) / 256);
@@ -151,7 +155,7 @@ pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint
     PCGX_HIP_TRY(hipMemcpyAsync(d_order, cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   const uint32_t slots = 1u << depth;
   hipLaunchKernelGGL(kb_fill_bfs_kernel, dim3((slots + 255) / 256), dim3(256), 0, st, d_xyz, d_order, un, slots,
-                     d_nodes);
+                     d_labels, d_nodes);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }

@@ -63,6 +63,16 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
 
 // Leaf directory: one thread per grid cell descends from the root with the cell's centre
 // (the reference's searchLeafNode rule, kdtree.go:202-221) and records the leaf reached.
+// Nearest on a tree without nodes (root == nil, kdtree.go:84-86): {-1, maxRange^2} for every query
+__global__ __launch_bounds__(256) void nearest_empty_kernel(int64_t nq, float max_range_sq, int32_t *__restrict__ ids,
+                                                            float *__restrict__ dsq) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nq) {
+    ids[i] = -1;
+    dsq[i] = max_range_sq;
+  }
+}
+
 __global__ __launch_bounds__(256) void dir_build_kernel(TreeView tv, uint32_t *__restrict__ dir) {
   const int g = tv.dir_bits;
   const uint32_t cells = 1u << (3 * g);
@@ -207,13 +217,15 @@ struct HostCallBufs {
 
 // In-order sequence -> BFS slots: the node of range [lo, lo+cnt) is element lo + cnt/2
 // (kdtree.go:355-364); children 2b (left, cnt/2 points) and 2b+1 (right).
-static void fill_bfs(const pcgx_kdtree &t, std::vector<float4> &nodes, size_t b, int64_t lo, int64_t cnt) {
+static void fill_bfs(const pcgx_kdtree &t, const int32_t *labels, std::vector<float4> &nodes, size_t b, int64_t lo,
+                     int64_t cnt) {
   while (cnt > 0) {
     const int64_t half = cnt / 2, mid = lo + half;
     const int32_t id = t.inorder[mid];
+    const int32_t label = labels ? labels[id] : id;
     nodes[b] = make_float4(t.points[3 * (int64_t)id], t.points[3 * (int64_t)id + 1],
-                           t.points[3 * (int64_t)id + 2], __builtin_bit_cast(float, id));
-    if (half > 0) fill_bfs(t, nodes, 2 * b, lo, half);
+                           t.points[3 * (int64_t)id + 2], __builtin_bit_cast(float, label));
+    if (half > 0) fill_bfs(t, labels, nodes, 2 * b, lo, half);
     lo = mid + 1;  // iterate into the right child
     cnt = cnt - half - 1;
     b = 2 * b + 1;
@@ -222,8 +234,9 @@ static void fill_bfs(const pcgx_kdtree &t, std::vector<float4> &nodes, size_t b,
 
 // ------------------------------------------------------------------ C ABI
 
-extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t stride,
-                                         int32_t xyz_off, pcgx_kdtree **out) {
+// labels (optional, host, [n]): the id each point's node reports (default: its index).
+static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32_t xyz_off, const int32_t *labels,
+                              pcgx_kdtree **out) {
   if (!out) return fail(PCGX_E_INVALID, "pcgx_kdtree_build: out is NULL");
   *out = nullptr;
   if (n < 0 || (n > 0 && !data)) return fail(PCGX_E_INVALID, "pcgx_kdtree_build: bad data/n");
@@ -260,13 +273,17 @@ extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t st
     pcgx_status rc = ar.begin(st);
     float *d_xyz = nullptr;
     uint32_t *d_order = nullptr;
+    int32_t *d_labels = nullptr;
     if (rc == PCGX_OK) rc = ar.alloc_n((size_t)n * 3, &d_xyz);
     if (rc == PCGX_OK) rc = ar.alloc_n((size_t)n, &d_order);
+    if (rc == PCGX_OK && labels) rc = ar.alloc_n((size_t)n, &d_labels);
     if (rc == PCGX_OK) {
       e = hipMemcpyAsync(d_xyz, t->points.data(), (size_t)n * 12, hipMemcpyHostToDevice, st);
+      if (e == hipSuccess && labels)
+        e = hipMemcpyAsync(d_labels, labels, (size_t)n * 4, hipMemcpyHostToDevice, st);
       if (e != hipSuccess) rc = fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
     }
-    if (rc == PCGX_OK) rc = build_tree_device(d_xyz, n, t->depth, d_order, t->d_nodes, st);
+    if (rc == PCGX_OK) rc = build_tree_device(d_xyz, n, t->depth, d_order, t->d_nodes, d_labels, st);
     if (rc == PCGX_OK) {
       e = hipMemcpyAsync(t->inorder.data(), d_order, (size_t)n * 4, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -280,7 +297,7 @@ extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t st
   } else {
     build_inorder(t->points.data(), n, t->inorder.data());
     std::vector<float4> nodes(slots, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-    fill_bfs(*t, nodes, 1, 0, n);
+    fill_bfs(*t, labels, nodes, 1, 0, n);
     e = hipMemcpy(t->d_nodes, nodes.data(), slots * sizeof(float4), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
       (void)hipFree(t->d_nodes);
@@ -333,11 +350,74 @@ extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t st
   return PCGX_OK;
 }
 
+extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t stride,
+                                         int32_t xyz_off, pcgx_kdtree **out) {
+  return build_tree(data, n, stride, xyz_off, nullptr, out);
+}
+
 extern "C" pcgx_status pcgx_kdtree_free(pcgx_kdtree *t) {
   if (!t) return PCGX_OK;
+  if (t->live) pcgx_kdtree_free(t->live);
+  for (pcgx_kdtree *r : t->retired) pcgx_kdtree_free(r);
   if (t->d_nodes) (void)hipFree(t->d_nodes);
   if (t->d_dir) (void)hipFree(t->d_dir);
   delete t;
+  return PCGX_OK;
+}
+
+// KDTree.DeletePoint (kdtree.go:322-332) for a batch of ids.  An id outside [0, Len()) is the
+// reference's error (:323-325) and nothing is deleted; deleting a point twice is a no-op, as in the
+// reference (kdtree_test.go "TwiceTheSamePoint").  The tree over the remaining points is rebuilt
+// lazily by the next query (resolve_tree).
+extern "C" pcgx_status pcgx_kdtree_delete_points(pcgx_kdtree *t, const int64_t *ids, int64_t m) {
+  if (!t || m < 0 || (m > 0 && !ids)) return fail(PCGX_E_INVALID, "pcgx_kdtree_delete_points: bad argument");
+  for (int64_t i = 0; i < m; i++)
+    if (ids[i] < 0 || ids[i] > t->n - 1)
+      return fail(PCGX_E_OUT_OF_RANGE, "%lld does not correspond to any point in the tree", (long long)ids[i]);
+  std::lock_guard<std::mutex> lock(t->mu);
+  if (t->deleted.empty()) t->deleted.assign((size_t)t->n, 0);
+  for (int64_t i = 0; i < m; i++) {
+    if (t->deleted[(size_t)ids[i]]) continue;
+    t->deleted[(size_t)ids[i]] = 1;
+    t->n_deleted++;
+    t->dirty = true;
+  }
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_kdtree_live_count(const pcgx_kdtree *t, int64_t *n_live) {
+  if (!t || !n_live) return fail(PCGX_E_INVALID, "pcgx_kdtree_live_count: NULL argument");
+  *n_live = t->n - t->n_deleted;
+  return PCGX_OK;
+}
+
+pcgx_status resolve_tree(const pcgx_kdtree *tc, const pcgx_kdtree **active, bool *empty) {
+  *empty = false;
+  *active = tc;
+  if (!tc || tc->n_deleted == 0) return PCGX_OK;
+  pcgx_kdtree *t = const_cast<pcgx_kdtree *>(tc);  // deletion state is the handle's own, guarded by mu
+  std::lock_guard<std::mutex> lock(t->mu);
+  if (t->dirty) {
+    const int64_t n_live = t->n - t->n_deleted;
+    pcgx_kdtree *nt = nullptr;
+    if (n_live > 0) {
+      std::vector<float> xyz((size_t)n_live * 3);
+      std::vector<int32_t> labels((size_t)n_live);
+      int64_t k = 0;
+      for (int64_t i = 0; i < t->n; i++) {
+        if (t->deleted[(size_t)i]) continue;
+        memcpy(&xyz[3 * (size_t)k], &t->points[3 * (size_t)i], 12);
+        labels[(size_t)k++] = (int32_t)i;
+      }
+      PCGX_TRY(build_tree(xyz.data(), n_live, 12, 0, labels.data(), &nt));
+      for (auto &id : nt->inorder) id = labels[(size_t)id];  // in-order sequence in original ids
+    }
+    if (t->live) t->retired.push_back(t->live);
+    t->live = nt;
+    t->dirty = false;
+  }
+  *active = t->live;
+  *empty = t->live == nullptr;
   return PCGX_OK;
 }
 
@@ -349,13 +429,20 @@ extern "C" pcgx_status pcgx_kdtree_len(const pcgx_kdtree *t, int64_t *n) {
 
 extern "C" pcgx_status pcgx_kdtree_max_depth(const pcgx_kdtree *t, int32_t *depth) {
   if (!t || !depth) return fail(PCGX_E_INVALID, "pcgx_kdtree_max_depth: NULL argument");
-  *depth = t->depth;
+  const pcgx_kdtree *a = nullptr;
+  bool empty = false;
+  PCGX_TRY(resolve_tree(t, &a, &empty));
+  *depth = empty ? 0 : a->depth;
   return PCGX_OK;
 }
 
 extern "C" pcgx_status pcgx_kdtree_inorder(const pcgx_kdtree *t, int64_t *ids) {
   if (!t || !ids) return fail(PCGX_E_INVALID, "pcgx_kdtree_inorder: NULL argument");
-  for (int64_t i = 0; i < t->n; i++) ids[i] = t->inorder[i];
+  const pcgx_kdtree *a = nullptr;
+  bool empty = false;
+  PCGX_TRY(resolve_tree(t, &a, &empty));  // after DeletePoint: the remaining (live_count) ids
+  if (empty) return PCGX_OK;
+  for (int64_t i = 0; i < a->n; i++) ids[i] = a->inorder[i];
   return PCGX_OK;
 }
 
@@ -379,6 +466,15 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch_dev(const pcgx_kdtree *t, const
   PCGX_TRY(ensure_init());
   hipStream_t st = pick_stream(stream);
   const float max_range_sq = max_range * max_range;  // kdtree.go:91
+  bool empty = false;
+  PCGX_TRY(resolve_tree(t, &t, &empty));  // after DeletePoint: the tree over the remaining points
+  if (empty) {
+    if (nq > 0)
+      hipLaunchKernelGGL(nearest_empty_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, nq, max_range_sq,
+                         d_ids, d_dist_sq);
+    PCGX_HIP_TRY(hipGetLastError());
+    return PCGX_OK;
+  }
   if ((flags & PCGX_KNN_PRESORT) && nq > 1) {
     PCGX_TRY(ctx().arena.begin(st));
     int32_t *perm = nullptr;

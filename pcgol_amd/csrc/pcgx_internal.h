@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -118,7 +119,13 @@ inline int32_t tree_depth(int64_t n) {
 
 // kdtree_build_gpu.hip: in-order ids (d_order) and BFS slots (d_nodes) from packed device xyz
 pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint32_t *d_order, float4 *d_nodes,
-                              hipStream_t st);
+                              const int32_t *d_labels, hipStream_t st);
+
+}  // namespace pcgx
+// knn.hip: the tree queries run on: `t` itself, or the tree over the points left after DeletePoint
+// (rebuilt here if deletions happened since).  *empty: every point was deleted (root == nil).
+pcgx_status resolve_tree(const pcgx_kdtree *t, const pcgx_kdtree **active, bool *empty);
+namespace pcgx {
 
 // knn.hip
 constexpr int kKnnBlock = 256;  // 4 waves
@@ -169,6 +176,16 @@ struct pcgx_kdtree {
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // of the base cloud
   std::vector<int32_t> inorder;    // host copy of the in-order ids
   std::vector<float> points;       // host copy of xyz (accessor order), for Vec3At
+  // KDTree.DeletePoint (kdtree.go:322-332).  The implicit layout cannot express the reference's
+  // patched tree, so deletions are recorded here and the next query rebuilds a tree over the
+  // remaining points whose nodes keep the ORIGINAL ids (`live`; nullptr while nothing is left).
+  // Trees replaced by a later rebuild are retired, not freed: sessions may still reference them.
+  std::vector<uint8_t> deleted;    // [n] once the first point was deleted
+  int64_t n_deleted = 0;
+  bool dirty = false;              // deletions since `live` was built
+  pcgx_kdtree *live = nullptr;
+  std::vector<pcgx_kdtree *> retired;
+  std::mutex mu;
   pcgx::TreeView view() const {
     pcgx::TreeView v;
     v.nodes = d_nodes;

@@ -134,6 +134,12 @@ extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float
   if (!t || nq < 0 || (nq > 0 && (!q || !counts))) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_count: bad argument");
   if (nq == 0) return PCGX_OK;
   PCGX_TRY(ensure_init());
+  bool empty = false;
+  PCGX_TRY(resolve_tree(t, &t, &empty));  // after DeletePoint: the tree over the remaining points
+  if (empty) {  // root == nil (kdtree.go:150-152)
+    for (int64_t i = 0; i < nq; i++) counts[i] = 0;
+    return PCGX_OK;
+  }
   hipStream_t st = ctx().stream;
   DevMem dq, dc;
   PCGX_TRY(dq.alloc((size_t)nq * 12));
@@ -160,6 +166,9 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
   if (!ids || !dist_sq) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: NULL output");
   if (total > 0x7fffffffll) return fail(PCGX_E_TOO_LARGE, "pcgx_kdtree_range_fill: more than 2^31-1 neighbours in one batch");
   PCGX_TRY(ensure_init());
+  bool empty = false;
+  PCGX_TRY(resolve_tree(t, &t, &empty));
+  if (empty) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: offsets do not match the neighbour counts");
   hipStream_t st = ctx().stream;
   Arena &ar = ctx().arena;
   PCGX_TRY(ar.begin(st));

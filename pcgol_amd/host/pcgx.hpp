@@ -86,6 +86,16 @@ class KDTree {  // pc/storage/kdtree/kdtree.go:14-23
     for (int64_t i = 0; i < cnt; i++) out[(size_t)i] = Neighbor{ids[(size_t)i], d[(size_t)i]};
     return out;
   }
+  // KDTree.DeletePoint (kdtree.go:322-332); std::out_of_range for an id outside [0, Len()).
+  void DeletePoint(int64_t pID) {
+    pcgx_status rc = pcgx_kdtree_delete_points(h_, &pID, 1);
+    if (rc == PCGX_E_OUT_OF_RANGE) {
+      char buf[256];
+      pcgx_last_error(buf, sizeof buf);
+      throw std::out_of_range(buf);
+    }
+    check(rc);
+  }
   int32_t MaxDepth() const { int32_t d; check(pcgx_kdtree_max_depth(h_, &d)); return d; }
   const pcgx_kdtree *handle() const { return h_; }
 

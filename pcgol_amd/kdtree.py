@@ -71,9 +71,27 @@ class KDTree:
         return d.value
 
     def InOrder(self):
-        out = np.empty(self.Len(), np.int64)
+        out = np.empty(self.LiveCount(), np.int64)
         L.check(L.lib().pcgx_kdtree_inorder(self._h, L.ptr(out)))
         return out
+
+    # -- KDTree.DeletePoint (kdtree.go:322-332)
+    def DeletePoint(self, pID):
+        """Removes point pID from the tree (the accessor, Len() and Vec3At() keep it).  An id
+        outside [0, Len()) raises IndexError with the reference's message (kdtree.go:323-325)."""
+        self.DeletePoints([pID])
+
+    def DeletePoints(self, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.int64).reshape(-1)
+        rc = L.lib().pcgx_kdtree_delete_points(self._h, L.ptr(ids), len(ids))
+        if rc == L.PCGX_E_OUT_OF_RANGE:
+            raise IndexError(L.last_error())
+        L.check(rc)
+
+    def LiveCount(self):
+        n = C.c_int64()
+        L.check(L.lib().pcgx_kdtree_live_count(self._h, C.byref(n)))
+        return n.value
 
     # -- storage.Search
     def Nearest(self, p, maxRange):

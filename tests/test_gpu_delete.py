@@ -1,0 +1,100 @@
+"""GPU parity of KDTree.DeletePoint (kdtree.go:322-332) through the C ABI.
+
+The oracle restates the reference's deleteNodeImpl / findMinimumImpl (pinned by the reference's
+exact trees after deletion, tests/test_oracle_golden.py); the device rebuilds the canonical tree
+over the remaining points instead of patching it, so the comparison is on what Nearest / Range
+return -- ID and DistSq exact -- on inputs without exact-distance ties (the reference's own
+property test compares the same way, kdtree_test.go:864-885)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from pcgol_amd import icp, kdtree, synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def test_delete_tables_nearest(golden):
+    """After every step of every known-answer deletion sequence (kdtree_test.go:413-729) the device
+    answers all Nearest / Range queries like the oracle's patched tree."""
+    g = golden("ref_kdtree.json")
+    pts = np.array(g["test_cloud"]["points"], f32)
+    queries = np.array([c["p"] for c in g["nearest"]["cases"]] + pts.tolist(), f32) + f32(0.013)
+    for name, steps in g["delete_point"]["sequences"].items():
+        t, o = kdtree.New(pts), O.KDTree(pts)
+        for st in steps:
+            if st["has_error"]:
+                with pytest.raises(IndexError):
+                    t.DeletePoint(st["pid"])
+                with pytest.raises(IndexError):
+                    o.delete_point(st["pid"])
+            else:
+                t.DeletePoint(st["pid"])
+                o.delete_point(st["pid"])
+            ids, dsq = t.NearestBatch(queries, 10.0)
+            oi, od = o.nearest_batch(queries, 10.0)
+            assert np.array_equal(ids, oi) and np.array_equal(dsq, od), (name, st["pid"])
+            assert t.Len() == len(pts)  # the accessor is unchanged
+            for q in queries[:4]:
+                r = t.Range(q, 2.5)
+                ri, rd = o.range(q, 2.5)
+                assert sorted((n.ID, float(n.DistSq)) for n in r) == sorted(zip(ri.tolist(), rd.tolist()))
+
+
+def test_delete_all_points_on_a_line(golden):
+    """kdtree_test.go:731-751, then root == nil: {-1, maxRange^2} (kdtree.go:84-86)."""
+    g = golden("ref_kdtree.json")["delete_on_line"]
+    pts = np.array(g["points"], f32)
+    t = kdtree.New(pts)
+    for i in range(len(pts)):
+        t.DeletePoint(i)
+        assert t.Nearest(pts[i], g["max_range"]).ID < 0
+    assert t.LiveCount() == 0 and t.MaxDepth() == 0 and len(t.InOrder()) == 0
+    n = t.Nearest(pts[0], 100.0)
+    assert n.ID == -1 and n.DistSq == f32(100.0) * f32(100.0)
+    assert t.Range(pts[0], 100.0) == []
+    with pytest.raises(icp.ErrNotEnoughPairs):
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(10.0), MinPairs=1).Evaluate(t, pts)
+
+
+@pytest.mark.parametrize("n,seed", [(100, 0), (100, 1), (60000, 2)])
+def test_delete_third_then_nearest_equals_oracle_and_naive(n, seed):
+    """kdtree_test.go:864-885 (delete a third, then Nearest == brute force), also at a size that
+    takes the device build, with deletions in two batches (two rebuilds)."""
+    rng = np.random.default_rng(seed)
+    w = f32(10.0)
+    pts = synth.uniform_cloud(n, float(w), 40 + seed)
+    t, o = kdtree.New(pts), O.KDTree(pts)
+    gone = rng.permutation(n)[: n // 3]
+    q = synth.uniform_cloud(2000, float(w), 50 + seed)
+    for part in (gone[: len(gone) // 2], gone[len(gone) // 2:]):
+        t.DeletePoints(part)
+        for i in part:
+            o.delete_point(int(i))
+        ids, dsq = t.NearestBatch(q, 3.0)
+        oi, od = o.nearest_batch(q, 3.0)
+        assert np.array_equal(dsq, od)
+        assert np.array_equal(ids, oi)
+    assert t.LiveCount() == n - len(gone)
+    assert not np.isin(ids, gone).any()
+    keep = np.setdiff1d(np.arange(n), gone)
+    for k in range(50):  # brute force over the remaining points
+        i, d = O.naive_nearest(pts[keep], q[k], 3.0)
+        assert ids[k] == (keep[i] if i >= 0 else -1) and dsq[k] == d
+    assert sorted(t.InOrder().tolist()) == keep.tolist()
+
+
+def test_delete_then_icp_uses_remaining_points():
+    c = synth.c4_icp(n=20000, width=2.7)
+    t, o = kdtree.New(c["base"]), O.KDTree(c["base"])
+    gone = np.arange(0, 20000, 3)
+    t.DeletePoints(gone)
+    for i in gone:
+        o.delete_point(int(i))
+    e = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=6)
+    ev = e.Evaluate(t, c["target"])
+    oe = O.icp_evaluate(o, c["target"], c["max_dist"], 6, sums_mode=1)
+    assert ev.NumPairs == oe["npairs"]
+    assert abs(float(ev.Value) - float(oe["value"])) <= 1e-6 * float(oe["value"])
+    assert np.allclose(ev.Gradient, oe["gradient"], rtol=1e-5, atol=1e-8)

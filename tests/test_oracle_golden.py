@@ -89,6 +89,70 @@ def test_kdtree_range_equals_naive():
         assert sorted(zip(dsq.tolist(), ids.tolist())) == sorted(zip(dn[sel].tolist(), sel.tolist()))
 
 
+def test_kdtree_find_minimum_table(golden):
+    """kdtree_test.go:388-411 + :836-862 (vs brute force on random clouds)."""
+    g = golden("ref_kdtree.json")
+    t = O.KDTree(np.array(g["test_cloud"]["points"], f32))
+    for c in g["find_minimum"]["cases"]:
+        if c.get("error"):
+            with pytest.raises(ValueError):
+                t.find_minimum(c["dim"])
+        else:
+            assert t.find_minimum(c["dim"]) == c["id"]
+    rng = np.random.default_rng(11)
+    for _ in range(100):
+        pts = rng.random((100, 3), dtype=f32) * f32(10)
+        tr = O.KDTree(pts)
+        for dim in range(3):
+            assert tr.find_minimum(dim) == int(np.argmin(pts[:, dim]))  # first strict minimum
+
+
+def test_kdtree_delete_point_tables(golden):
+    """kdtree_test.go:413-729: exact trees after each deletion of every named sequence."""
+    g = golden("ref_kdtree.json")
+    pts = np.array(g["test_cloud"]["points"], f32)
+    for name, steps in g["delete_point"]["sequences"].items():
+        t = O.KDTree(pts)
+        for st in steps:
+            if st["has_error"]:
+                with pytest.raises(IndexError):
+                    t.delete_point(st["pid"])
+            else:
+                t.delete_point(st["pid"])
+            assert t.tree() == st["tree"], (name, st["pid"])
+
+
+def test_kdtree_delete_on_line_and_everything(golden):
+    """kdtree_test.go:731-751, and root == nil after the last deletion (kdtree.go:84-86,150-152)."""
+    g = golden("ref_kdtree.json")["delete_on_line"]
+    pts = np.array(g["points"], f32)
+    t = O.KDTree(pts)
+    for i in range(len(pts)):
+        t.delete_point(i)
+        assert t.nearest(pts[i], g["max_range"])[0] < 0
+    assert t.tree() is None
+    assert t.nearest(pts[0], 100.0) == (-1, f32(100.0) * f32(100.0))
+    assert len(t.range(pts[0], 100.0)[0]) == 0
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_kdtree_delete_then_nearest_equals_naive(seed):
+    """kdtree_test.go:864-885: delete a third of the points, then ID and DistSq must == brute
+    force over the remaining points."""
+    rng = np.random.default_rng(100 + seed)
+    pts = rng.random((100, 3), dtype=f32) * f32(10)
+    t = O.KDTree(pts)
+    gone = rng.permutation(33)
+    for i in gone:
+        t.delete_point(int(i))
+    keep = np.setdiff1d(np.arange(100), gone)
+    for _ in range(100):
+        p = rng.random(3, dtype=f32) * f32(10)
+        mr = float(rng.random(dtype=f32) * f32(10))
+        i, d = O.naive_nearest(pts[keep], p, mr)
+        assert t.nearest(p, mr) == ((int(keep[i]) if i >= 0 else -1), d)
+
+
 def _voxel_cloud(g):
     c = g["cloud"]
     rec = np.zeros((len(c["xyz"]), 4), np.float32)
