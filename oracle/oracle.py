@@ -25,7 +25,7 @@ class OracleError(RuntimeError):
 
 def build(force=False):
     """Compile liboracle.so with gcc (oracle/Makefile)."""
-    srcs = [os.path.join(_HERE, f) for f in ("pcgol_oracle.c", "plane_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pcgol_oracle.c", "plane_oracle.c", "segment_oracle.c", "Makefile")]
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
                               stdout=subprocess.DEVNULL)
@@ -81,6 +81,24 @@ def lib():
         L.orc_gauss_newton_update.argtypes = [vp, f32, i32, vp, vp, vp, vp]
         L.orc_plane_fit.restype = i32
         L.orc_plane_fit.argtypes = [vp, vp, vp, i64, f32, i32, vp, f32, i32, vp, vp, vp, vp, vp]
+        L.orc_grid_new.restype = vp
+        L.orc_grid_new.argtypes = [f32, vp, vp]
+        L.orc_grid_free.argtypes = [vp]
+        L.orc_grid_addr.restype = i32
+        L.orc_grid_addr.argtypes = [vp, vp, vp]
+        L.orc_grid_add.restype = i32
+        L.orc_grid_add.argtypes = [vp, vp, i64]
+        L.orc_grid_add_by_addr.argtypes = [vp, i64, i64]
+        L.orc_grid_get.restype = i64
+        L.orc_grid_get.argtypes = [vp, vp, vp, i64]
+        L.orc_grid_get_by_addr.restype = i64
+        L.orc_grid_get_by_addr.argtypes = [vp, i64, vp, i64]
+        L.orc_grid_indice.restype = i64
+        L.orc_grid_indice.argtypes = [vp, vp]
+        L.orc_grid_segment.restype = i64
+        L.orc_grid_segment.argtypes = [vp, vp, vp]
+        L.orc_region_growing_segment.restype = i64
+        L.orc_region_growing_segment.argtypes = [vp, vp, vp, f32, vp]
         L.orc_mat4_mul.argtypes = [vp, vp, vp]
         L.orc_mat4_transform.argtypes = [vp, vp, vp]
         L.orc_translate.argtypes = [f32, f32, f32, vp]
@@ -365,3 +383,67 @@ def plane_fit(tree, normals, target, max_dist, min_pairs=0, threshold=None, damp
         e.num_iteration = nit.value
         raise e
     return dict(trans=tr, value=np.float32(v.value), gradient=g, hessian=h, num_iteration=nit.value)
+
+
+# ------------------------------------ bucket voxel grid / flood fill / region growing
+
+class BucketGrid:
+    """pc/storage/voxelgrid.VoxelGrid + pc/segmentation/voxelgrid.Segment (oracle/segment_oracle.c)."""
+
+    def __init__(self, resolution, size, origin):
+        self.size = np.ascontiguousarray(size, dtype=np.int64)
+        self.origin = _f32(origin)
+        self.h = lib().orc_grid_new(resolution, _p(self.size), _p(self.origin))
+        self.n = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_grid_free(self.h)
+            self.h = None
+
+    def add(self, p, index):
+        p = _f32(p)
+        ok = bool(lib().orc_grid_add(self.h, _p(p), index))
+        self.n += ok
+        return ok
+
+    def add_all(self, pts):
+        for i, p in enumerate(_f32(pts).reshape(-1, 3)):
+            self.add(p, i)
+
+    def addr(self, p):
+        p = _f32(p)
+        a = C.c_int64(0)
+        ok = lib().orc_grid_addr(self.h, _p(p), C.byref(a))
+        return (a.value, True) if ok else (0, False)
+
+    def add_by_addr(self, a, index):
+        lib().orc_grid_add_by_addr(self.h, a, index)
+        self.n += 1
+
+    def get(self, p):
+        p = _f32(p)
+        out = np.empty(max(self.n, 1), np.int64)
+        k = lib().orc_grid_get(self.h, _p(p), _p(out), len(out))
+        return None if k < 0 else out[:k].copy()
+
+    def indice(self):
+        out = np.empty(max(self.n, 1), np.int64)
+        k = lib().orc_grid_indice(self.h, _p(out))
+        return out[:k].copy()
+
+    def segment(self, p):
+        p = _f32(p)
+        out = np.empty(max(self.n, 1), np.int64)
+        k = lib().orc_grid_segment(self.h, _p(p), _p(out))
+        return out[:k].copy()
+
+
+def region_growing_segment(tree, labels, p, max_range):
+    """regiongrowing.Segment (regiongrowing.go:23-56): ids in the reference's BFS order."""
+    labels = np.ascontiguousarray(labels, dtype=np.uint32)
+    assert len(labels) == tree.n
+    p = _f32(p)
+    out = np.empty(max(tree.n, 1), np.int64)
+    k = lib().orc_region_growing_segment(tree.h, _p(labels), _p(p), max_range, _p(out))
+    return out[:k].copy()

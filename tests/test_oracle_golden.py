@@ -280,3 +280,49 @@ def test_rodrigues_sweep(golden):
                 vn = vec * f32(f32(1.0) / norm)
                 e = O.rotate(float(vn[0]), float(vn[1]), float(vn[2]), float(norm))
                 assert np.all(np.abs(r - e) <= g["eps"]), (vec, r, e)
+
+
+# ------------------------------------------------ bucket grid / flood fill / region growing
+
+def test_bucket_grid_table(golden):
+    """pc/storage/voxelgrid/voxelgrid_test.go:10-87: Add and AddByAddr."""
+    g = golden("ref_segment.json")["bucket_grid"]
+    pts = np.array(g["points"], f32)
+    for mode in ("add", "add_by_addr"):
+        v = O.BucketGrid(g["resolution"], g["size"], g["origin"])
+        for i, p in enumerate(pts):
+            if mode == "add":
+                assert v.add(p, i) == g["add_ok"][i]
+            else:
+                a, ok = v.addr(p)
+                assert ok == g["add_ok"][i]
+                if ok:
+                    v.add_by_addr(a, i)
+        for p, exp in zip(pts, g["get"]):
+            got = v.get(p)
+            assert (got is None) if exp is None else (got.tolist() == exp)
+        assert v.indice().tolist() == [1, 2, 3]
+
+
+def test_flood_fill_table(golden):
+    """pc/segmentation/voxelgrid/voxelgrid_test.go:11-40."""
+    g = golden("ref_segment.json")["flood_fill"]
+    v = O.BucketGrid(g["resolution"], g["size"], np.array(g["origin"], f32))
+    v.add_all(np.array(g["points"], f32))
+    assert sorted(v.segment(g["seed_point"]).tolist()) == g["expected_sorted"]
+    assert v.segment([0.3, 0.3, 0.3]).tolist() == []   # empty seed voxel: nothing (voxelgrid.go:57-60)
+    assert v.segment([9, 9, 9]).tolist() == []         # seed outside the grid (:41-44)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_region_growing_table(golden, seed):
+    """pc/segmentation/regiongrowing/regiongrowing_test.go:15-175."""
+    from segment_scene import region_growing_scene
+    g = golden("ref_segment.json")["region_growing"]
+    pts, labels, ids = region_growing_scene(g, seed)
+    t = O.KDTree(pts)
+    for c in g["cases"]:
+        exp = sorted(sum((ids[o] for o in c["objects"]), []))
+        got = O.region_growing_segment(t, labels, c["p"], c["max_range"])
+        assert sorted(got.tolist()) == exp, c["name"]
+    assert O.region_growing_segment(t, labels, [50, 50, 50], 0.1).tolist() == []
