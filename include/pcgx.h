@@ -294,6 +294,56 @@ PCGX_API pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream,
                                              float trans16[16], pcgx_icp_stat *stat,
                                              int32_t *converged);
 
+/* ------------------------------------------------ bucket voxel grid + segmentation
+ * replaces pc/storage/voxelgrid.VoxelGrid (voxelgrid.go:7-122: dense [][]int buckets addressed by
+ * int(pos*resolutionInv + 0.5)), pc/segmentation/voxelgrid.VoxelGrid.Segment (26-neighbour flood
+ * fill, segmentation/voxelgrid/voxelgrid.go:39-73) and pc/segmentation/regiongrowing
+ * .RegionGrowing.Segment (regiongrowing.go:23-56).  The device computes the buckets with one
+ * stable sort and the connected components of the whole grid / cloud with a union-find; a seed
+ * query is then a lookup.  Result ORDER differs from the reference's BFS discovery order (its
+ * tests sort before comparing): ascending voxel address with insertion order inside a voxel,
+ * resp. ascending point id. */
+typedef struct pcgx_bucket_grid pcgx_bucket_grid;
+/* New(resolution, size, origin) followed by Add(point i, i) for every record of the cloud
+ * (voxelgrid.go:15-23,37-45); points outside the grid are not added. */
+PCGX_API pcgx_status pcgx_bucket_grid_build(const void *data, int64_t n, int32_t stride, int32_t xyz_off,
+                                            float resolution, const int64_t size[3], const float origin[3],
+                                            pcgx_bucket_grid **out);
+PCGX_API pcgx_status pcgx_bucket_grid_free(pcgx_bucket_grid *g);
+/* Len() (voxelgrid.go:110-112), points accepted by Add, occupied voxels; any pointer may be NULL */
+PCGX_API pcgx_status pcgx_bucket_grid_counts(const pcgx_bucket_grid *g, int64_t *len, int64_t *n_added,
+                                             int64_t *n_occupied);
+/* Addr(p) (voxelgrid.go:64-79): *ok = 0 outside the grid */
+PCGX_API pcgx_status pcgx_bucket_grid_addr(const pcgx_bucket_grid *g, const float p[3], int64_t *addr, int32_t *ok);
+/* voxel address of every offered point, -1 where Add returned false */
+PCGX_API pcgx_status pcgx_bucket_grid_point_addrs(const pcgx_bucket_grid *g, int64_t *addrs /* [n] */);
+/* GetByAddr / Get (voxelgrid.go:52-62): *count = bucket length (Get: -1 = nil, p outside the grid);
+ * the first min(count, cap) ids are written in insertion order.  An address outside
+ * [0, Len()) is PCGX_E_OUT_OF_RANGE (the reference panics). */
+PCGX_API pcgx_status pcgx_bucket_grid_get_by_addr(const pcgx_bucket_grid *g, int64_t addr, int64_t *out, int64_t cap,
+                                                  int64_t *count);
+PCGX_API pcgx_status pcgx_bucket_grid_get(const pcgx_bucket_grid *g, const float p[3], int64_t *out, int64_t cap,
+                                          int64_t *count);
+/* Indice() (voxelgrid.go:114-120): out holds n_added ids */
+PCGX_API pcgx_status pcgx_bucket_grid_indice(const pcgx_bucket_grid *g, int64_t *out);
+/* Segment(p) for every seed at once: point_comp[i] = smallest voxel address of the 26-connected
+ * set of occupied voxels point i's voxel belongs to, -1 for points outside the grid. */
+PCGX_API pcgx_status pcgx_bucket_grid_components(pcgx_bucket_grid *g, int64_t *point_comp /* [n] */);
+/* Segment(p) (segmentation/voxelgrid/voxelgrid.go:39-73): *count = result length, the first
+ * min(count, cap) ids are written; empty when p is outside the grid or its voxel is empty. */
+PCGX_API pcgx_status pcgx_bucket_grid_segment(pcgx_bucket_grid *g, const float p[3], int64_t *out, int64_t cap,
+                                              int64_t *count);
+
+/* RegionGrowing (regiongrowing.go:18-56).  labels = the property accessor (Uint32At(id), id in
+ * [0, Len())).  _components answers every seed at once for one max_range: comp[i] = smallest id of
+ * the points reachable from i through steps with DistSq < max_range^2 between points of i's
+ * property value.  _segment is Segment(p, maxRange) given those components. */
+PCGX_API pcgx_status pcgx_region_growing_components(const pcgx_kdtree *t, const uint32_t *labels, float max_range,
+                                                    int64_t *comp /* [Len()] */);
+PCGX_API pcgx_status pcgx_region_growing_segment(const pcgx_kdtree *t, const uint32_t *labels, const int64_t *comp,
+                                                 const float p[3], float max_range, int64_t *out, int64_t cap,
+                                                 int64_t *count);
+
 /* ------------------------------------------- point-to-plane ICP (extension)
  * NOT in the reference: pcgol declares only the slots -- Evaluated.Hessian mat.Mat6
  * (evaluator.go:28), Evaluator.HasHessian (evaluator.go:35,76), mat.Mat6 (mat/mat6.go:3),

@@ -132,6 +132,18 @@ SIGNATURES = {
     "pcgx_icp_session_update": (_i32, [_vp, _vp]),
     "pcgx_icp_session_step": (_i32, [_vp, _vp]),
     "pcgx_icp_session_result": (_i32, [_vp, _vp, _vp, C.POINTER(IcpStat), C.POINTER(_i32)]),
+    "pcgx_bucket_grid_build": (_i32, [_vp, _i64, _i32, _i32, _f32, _vp, _vp, C.POINTER(_vp)]),
+    "pcgx_bucket_grid_free": (_i32, [_vp]),
+    "pcgx_bucket_grid_counts": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "pcgx_bucket_grid_addr": (_i32, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i32)]),
+    "pcgx_bucket_grid_point_addrs": (_i32, [_vp, _vp]),
+    "pcgx_bucket_grid_get_by_addr": (_i32, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "pcgx_bucket_grid_get": (_i32, [_vp, _vp, _vp, _i64, C.POINTER(_i64)]),
+    "pcgx_bucket_grid_indice": (_i32, [_vp, _vp]),
+    "pcgx_bucket_grid_components": (_i32, [_vp, _vp]),
+    "pcgx_bucket_grid_segment": (_i32, [_vp, _vp, _vp, _i64, C.POINTER(_i64)]),
+    "pcgx_region_growing_components": (_i32, [_vp, _vp, _f32, _vp]),
+    "pcgx_region_growing_segment": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, C.POINTER(_i64)]),
     "pcgx_icp_plane_session_create": (_i32, [_vp, _vp, _vp, _i64, _i32, C.POINTER(IcpParams), _f32, _vp,
                                              C.POINTER(_vp)]),
     "pcgx_icp_session_sums_count": (_i32, [_vp, C.POINTER(_i32)]),

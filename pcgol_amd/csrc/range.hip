@@ -18,11 +18,11 @@
 
 #include <vector>
 
-#include "knn_walk.h"
+#include "range_walk.h"
 
 namespace pcgx {
 
-constexpr int kRangeBlock = 256;
+constexpr int kRangeBlock = kRangeWalkBlock;
 
 // kFill == false: counts[i] = number of neighbours.  kFill == true: neighbours of query i are
 // written from offsets[i] in discovery order: {point id, DistSq bits, query index}.
@@ -36,69 +36,20 @@ __global__ __launch_bounds__(kRangeBlock) void range_kernel(TreeView tv, const f
   extern __shared__ uint32_t s_stack[];
   const int64_t i = (int64_t)blockIdx.x * kRangeBlock + threadIdx.x;
   if (i >= nq) return;
-  uint32_t *stk = s_stack + threadIdx.x;
   const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
-  const uint32_t np1 = (uint32_t)tv.n + 1u;
   int64_t found = 0;
   // never write outside the slice the caller's offsets give this query (they may be wrong)
   const int64_t out0 = kFill ? offsets[i] : 0;
   const int64_t cap = kFill ? offsets[i + 1] - out0 : 0;
   const bool slice_ok = kFill && out0 >= 0 && cap >= 0 && out0 + cap <= total;
-  uint32_t b = 1;
-  int32_t n = tv.n, sp = 0;
-  bool desc = true;
-  // every iteration fetches one node; a walk touches a node at most twice
-  for (int64_t guard = 2 * (int64_t)tv.n + 2; guard > 0; --guard) {
-    uint32_t at = b, fw = 0;
-    if (!desc) {
-      if (sp == 0) break;
-      fw = stk[(--sp) * kRangeBlock];
-      at = fw & 0x07FFFFFFu;
+  range_walk(tv, s_stack + threadIdx.x, kRangeBlock, qx, qy, qz, bound, [&](int32_t id, float d) {
+    if (kFill && slice_ok && found < cap) {
+      out_id[out0 + found] = id;
+      out_key[out0 + found] = __float_as_uint(d);  // d >= 0: the bit pattern orders like the value
+      out_query[out0 + found] = (uint32_t)i;
     }
-    const float4 nd = node_at(tv.nodes, at);
-    const float dx = nd.x - qx, dy = nd.y - qy, dz = nd.z - qz;
-    const float d = (dx * dx + dy * dy) + dz * dz;
-    const int32_t depth = 31 - __clz((int)at);
-    const int dim = depth % 3;
-    const float pv = sel3(dim, nd.x, nd.y, nd.z), qv = sel3(dim, qx, qy, qz);
-    const float fp = qv - pv;
-    const bool plane_ok = !(fp * fp > bound);
-    bool hit;
-    if (desc) {
-      if (n == 1) {  // leaf
-        hit = d < bound;
-        desc = false;
-      } else {  // searchLeafNode step (kdtree.go:202-221); a frame that cannot pass is not pushed
-        hit = false;
-        const int32_t half = n >> 1;
-        const bool go_left = n == 2 || pv > qv;
-        if (plane_ok) {
-          const uint32_t size_bit = (uint32_t)n - ((np1 >> depth) - 1u);
-          stk[(sp++) * kRangeBlock] = b | (go_left ? (1u << 27) : 0u) | (size_bit << 31);
-        }
-        b = 2u * b + (go_left ? 0u : 1u);
-        n = go_left ? half : n - half - 1;
-      }
-    } else {  // a popped frame always passes its plane test (the bound is fixed)
-      hit = d < bound;
-      const int32_t fn = (int32_t)((np1 >> depth) - 1u + (fw >> 31));
-      if (fn != 2) {  // the other child (kdtree.go:182-195)
-        const bool went_left = ((fw >> 27) & 1u) != 0u;
-        const int32_t half = fn >> 1;
-        b = 2u * at + (went_left ? 1u : 0u);
-        n = went_left ? fn - half - 1 : half;
-        desc = true;
-      }
-    }
-    if (hit) {
-      if (kFill && slice_ok && found < cap) {
-        out_id[out0 + found] = __float_as_int(nd.w);
-        out_key[out0 + found] = __float_as_uint(d);  // d >= 0: the bit pattern orders like the value
-        out_query[out0 + found] = (uint32_t)i;
-      }
-      ++found;
-    }
-  }
+    ++found;
+  });
   if (!kFill) counts[i] = found;
 }
 
