@@ -13,6 +13,8 @@
 // (8 per element round: a match-any on the 8-bit digit), re-orders the tile in
 // LDS by digit and writes each digit run contiguously, so global writes are
 // coalesced runs rather than 4-byte scatters.
+#include <string.h>
+
 #include "pcgx_internal.h"
 
 namespace pcgx {
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(kRadix) void rs_scan_totals_kernel(const uint32_t *
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n, int shift,
     const uint32_t *__restrict__ block_hist, int nblocks, const uint32_t *__restrict__ base,
-    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int xcd_remap) {
   __shared__ uint32_t cnt[kRsWaves][kRadix];
   __shared__ uint32_t tile_pref[kRadix];
   __shared__ uint32_t gbase[kRadix];
@@ -101,7 +103,13 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
   __shared__ uint32_t svals[kRsTile];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t tile_base = (int64_t)blockIdx.x * kRsTile;
+  // XCD-contiguous placement: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), so
+  // XCD x takes the tiles [x * per, (x + 1) * per).  Consecutive tiles then write adjacent pieces
+  // of every digit's output run through the SAME L2, where partial lines merge before they leave.
+  const int per = (int)(gridDim.x >> 3);
+  const int tile = xcd_remap ? (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  if (tile >= nblocks) return;
+  const int64_t tile_base = (int64_t)tile * kRsTile;
   const int64_t wave_base = tile_base + (int64_t)wave * kRsWaveChunk;
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
     for (int w = 0; w < wave; w++) wbase += wave_sum[w];
     const uint32_t excl = wbase + inc - run;
     tile_pref[t] = excl;
-    gbase[t] = base[t] + block_hist[(int64_t)t * nblocks + blockIdx.x] - excl;  // dst = gbase[d] + pos
+    gbase[t] = base[t] + block_hist[(int64_t)t * nblocks + tile] - excl;  // dst = gbase[d] + pos
   }
   __syncthreads();
 
@@ -185,8 +193,23 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
   }
 }
 
+// Measured and rejected: a single-kernel pass with decoupled look-back
+// ("onesweep": global digit histograms up front, per-(tile, digit) status words walked back with
+// agent-scope loads).  Correct, but 105 us per 10M-pair pass against 91 us for the four launches
+// here: the pass is bound by the VALU work of the ballot ranking, and every look-back hop is a
+// cross-XCD round trip (the per-XCD L2s are not coherent), so the chain costs more than the
+// second read of the keys it saves; at 1M pairs (tree build, Morton presort) it was no faster either.
+
+static bool sort_xcd_remap() {
+  static const int v = [] {
+    const char *e = getenv("PCGX_SORT_XCD");
+    return (e && !strcmp(e, "0")) ? 0 : 1;
+  }();
+  return v != 0;
+}
+
 size_t radix_sort_workspace_bytes(int64_t n) {
-  int64_t nblocks = (n + kRsTile - 1) / kRsTile;
+  const int64_t nblocks = (n + kRsTile - 1) / kRsTile;
   return (size_t)(nblocks * kRadix + 2 * kRadix) * sizeof(uint32_t);
 }
 
@@ -210,8 +233,10 @@ pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, in
     hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(kRadix), 0, st, totals, base);
     {
       ProfScope prof(PCGX_PROF_SORT_SCATTER, st);
-      hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(kRsThreads), 0, st, keys[cur], vals[cur], n,
-                         shift, block_hist, nblocks, base, keys[cur ^ 1], vals[cur ^ 1]);
+      const int remap = sort_xcd_remap() && nblocks >= 64;
+      const int grid = remap ? 8 * ((nblocks + 7) / 8) : nblocks;
+      hipLaunchKernelGGL(rs_scatter_kernel, dim3(grid), dim3(kRsThreads), 0, st, keys[cur], vals[cur], n,
+                         shift, block_hist, nblocks, base, keys[cur ^ 1], vals[cur ^ 1], remap);
     }
     cur ^= 1;
   }
