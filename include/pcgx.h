@@ -49,7 +49,11 @@ enum {
                                   (pc/filter/voxelgrid/voxelgrid.go:151); we return an error */
   PCGX_E_TOO_LARGE = 8,        /* tree larger than 2^26 points (traversal frame encoding) */
   PCGX_E_NEED_GRADIENT = 9,    /* icp/icp.go:15 ErrNeedGradient (kept for the Go shim's mapping) */
-  PCGX_E_SINGULAR = 10         /* point-to-plane extension: 6x6 normal equations not positive definite */
+  PCGX_E_SINGULAR = 10,        /* point-to-plane extension: 6x6 normal equations not positive definite */
+  PCGX_E_SYNTAX = 11,          /* PCD: strconv.ErrSyntax / ErrRange from a header or ascii token (pc/io.go) */
+  PCGX_E_EOF = 12,             /* PCD: io.EOF / io.ErrUnexpectedEOF */
+  PCGX_E_CORRUPT = 13,         /* PCD: lzf.ErrDataCorruption / lzf.ErrInsufficientBuffer */
+  PCGX_E_BAD_HEADER = 14       /* PCD: the errors.New cases of pc/io.go:55,119,125-133,202 */
 };
 
 /* ------------------------------------------------------------ lifecycle */
@@ -343,6 +347,39 @@ PCGX_API pcgx_status pcgx_region_growing_components(const pcgx_kdtree *t, const 
 PCGX_API pcgx_status pcgx_region_growing_segment(const pcgx_kdtree *t, const uint32_t *labels, const int64_t *comp,
                                                  const float p[3], float max_range, int64_t *out, int64_t cap,
                                                  int64_t *count);
+
+/* ---------------------------------------------------------------- PCD files
+ * replaces pc.UnmarshalHeader / pc.Unmarshal / pc.Marshal (pc/io.go:24-45,47-230,232-285) with a
+ * device-resident output: the records of an ascii / binary / binary_compressed file land in HBM
+ * (one upload; compressed files: LZF decode on the host, the SoA -> AoS de-interleave on the
+ * device) ready for the *_dev entry points.  The reference's de-interleave quirk is kept (COUNT > 1
+ * fields of compressed files: only element 0 is filled, io.go:217-226). */
+#define PCGX_PCD_MAX_FIELDS 64
+enum { PCGX_PCD_ASCII = 0, PCGX_PCD_BINARY = 1, PCGX_PCD_BINARY_COMPRESSED = 2 }; /* pc.Format, io.go:16-22 */
+typedef struct {            /* pc.PointCloudHeader (pc/pointcloud.go:9-18) + what Unmarshal derives */
+  float version;
+  int32_t n_fields;
+  char fields[PCGX_PCD_MAX_FIELDS][32]; /* NUL-terminated names */
+  int32_t size[PCGX_PCD_MAX_FIELDS];
+  char type[PCGX_PCD_MAX_FIELDS];       /* 'F', 'U', 'I' */
+  int32_t count[PCGX_PCD_MAX_FIELDS];
+  int64_t width, height;
+  int32_t n_viewpoint;
+  float viewpoint[16];
+  int64_t points;                       /* POINTS */
+  int32_t format;                       /* PCGX_PCD_* */
+  int64_t stride;                       /* sum size*count (pointcloud.go:64-70) */
+  int64_t data_offset;                  /* byte offset of the payload in the file */
+} pcgx_pcd_header;
+PCGX_API pcgx_status pcgx_pcd_unmarshal_header(const void *file, size_t len, pcgx_pcd_header *h);
+/* out_data: host buffer of h->points * h->stride bytes */
+PCGX_API pcgx_status pcgx_pcd_unmarshal(const void *file, size_t len, const pcgx_pcd_header *h, void *out_data);
+/* d_out: DEVICE buffer of h->points * h->stride bytes; returns when the records are in HBM */
+PCGX_API pcgx_status pcgx_pcd_unmarshal_dev(const void *file, size_t len, const pcgx_pcd_header *h, void *d_out,
+                                            void *stream);
+/* Marshal (always "DATA binary"): *out_len = file size; out == NULL only sizes */
+PCGX_API pcgx_status pcgx_pcd_marshal(const pcgx_pcd_header *h, const void *data, void *out, size_t cap,
+                                      size_t *out_len);
 
 /* ------------------------------------------- point-to-plane ICP (extension)
  * NOT in the reference: pcgol declares only the slots -- Evaluated.Hessian mat.Mat6

@@ -19,6 +19,11 @@ PCGX_E_OUT_OF_RANGE = 7
 PCGX_E_TOO_LARGE = 8
 PCGX_E_NEED_GRADIENT = 9
 PCGX_E_SINGULAR = 10
+PCGX_E_SYNTAX = 11
+PCGX_E_EOF = 12
+PCGX_E_CORRUPT = 13
+PCGX_E_BAD_HEADER = 14
+PCGX_PCD_MAX_FIELDS = 64
 
 PCGX_KNN_PRESORT = 1
 PROF_ICP_WALK, PROF_KNN_WALK, PROF_VOXEL_ALL, PROF_SORT_SCATTER = range(4)
@@ -61,13 +66,30 @@ class ErrInvalidField(PcgxError):       # pc/pointcloud.go:115
     pass
 
 
+class ErrSyntax(PcgxError):             # strconv.ErrSyntax (pc/io.go header / ascii tokens)
+    pass
+
+
+class ErrEOF(PcgxError):                # io.EOF / io.ErrUnexpectedEOF
+    pass
+
+
+class ErrDataCorruption(PcgxError):     # lzf.ErrDataCorruption
+    pass
+
+
+class ErrBadHeader(PcgxError):          # the errors.New cases of pc/io.go
+    pass
+
+
 class ErrSingular(PcgxError):           # point-to-plane extension: normal equations not positive definite
     pass
 
 
 _ERR = {PCGX_E_NO_POINT: ErrNoPoint, PCGX_E_NOT_ENOUGH_PAIRS: ErrNotEnoughPairs,
         PCGX_E_NEED_GRADIENT: ErrNeedGradient, PCGX_E_BAD_FIELD: ErrInvalidField,
-        PCGX_E_SINGULAR: ErrSingular}
+        PCGX_E_SINGULAR: ErrSingular, PCGX_E_SYNTAX: ErrSyntax, PCGX_E_EOF: ErrEOF,
+        PCGX_E_CORRUPT: ErrDataCorruption, PCGX_E_BAD_HEADER: ErrBadHeader}
 
 
 class IcpEvaluated(C.Structure):
@@ -78,6 +100,14 @@ class IcpEvaluated(C.Structure):
 class IcpParams(C.Structure):
     _fields_ = [("max_dist", C.c_float), ("min_dist_sq", C.c_float), ("min_pairs", C.c_int32),
                 ("weight", C.c_float * 6), ("threshold", C.c_float * 6), ("max_iteration", C.c_int32)]
+
+
+class PcdHeader(C.Structure):  # pcgx_pcd_header
+    _fields_ = [("version", C.c_float), ("n_fields", C.c_int32), ("fields", (C.c_char * 32) * 64),
+                ("size", C.c_int32 * 64), ("type", C.c_char * 64), ("count", C.c_int32 * 64),
+                ("width", C.c_int64), ("height", C.c_int64), ("n_viewpoint", C.c_int32),
+                ("viewpoint", C.c_float * 16), ("points", C.c_int64), ("format", C.c_int32),
+                ("stride", C.c_int64), ("data_offset", C.c_int64)]
 
 
 class IcpStat(C.Structure):
@@ -144,6 +174,10 @@ SIGNATURES = {
     "pcgx_bucket_grid_segment": (_i32, [_vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     "pcgx_region_growing_components": (_i32, [_vp, _vp, _f32, _vp]),
     "pcgx_region_growing_segment": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, C.POINTER(_i64)]),
+    "pcgx_pcd_unmarshal_header": (_i32, [_vp, _sz, C.POINTER(PcdHeader)]),
+    "pcgx_pcd_unmarshal": (_i32, [_vp, _sz, C.POINTER(PcdHeader), _vp]),
+    "pcgx_pcd_unmarshal_dev": (_i32, [_vp, _sz, C.POINTER(PcdHeader), _vp, _vp]),
+    "pcgx_pcd_marshal": (_i32, [C.POINTER(PcdHeader), _vp, _vp, _sz, C.POINTER(_sz)]),
     "pcgx_icp_plane_session_create": (_i32, [_vp, _vp, _vp, _i64, _i32, C.POINTER(IcpParams), _f32, _vp,
                                              C.POINTER(_vp)]),
     "pcgx_icp_session_sums_count": (_i32, [_vp, C.POINTER(_i32)]),
