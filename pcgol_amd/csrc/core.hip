@@ -167,6 +167,7 @@ extern "C" pcgx_status pcgx_shutdown(void) {
   if (!c.ready) return PCGX_OK;
   (void)hipDeviceSynchronize();
   c.arena.release_all();
+  c.host_arena.release_all();
   (void)hipStreamDestroy(c.stream);
   c.stream = nullptr;
   c.ready = false;

@@ -194,22 +194,18 @@ pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *
 using namespace pcgx;
 
 namespace {
-// Device staging of a host-pointer call (plain hipMalloc: these calls are
-// dominated by the PCIe copies anyway; the arena is reserved for the _dev path
-// so that nested _dev calls may reset it).
+// Device staging of a host-pointer call: bump-allocated from the grow-only host arena (no
+// hipMalloc / hipFree in steady state; hipFree alone costs more than the PCIe copies of a 1M batch).
 struct HostCallBufs {
   float *q = nullptr;
   int32_t *ids = nullptr;
   float *dsq = nullptr;
-  ~HostCallBufs() {
-    if (q) (void)hipFree(q);
-    if (ids) (void)hipFree(ids);
-    if (dsq) (void)hipFree(dsq);
-  }
-  pcgx_status alloc(int64_t nq) {
-    PCGX_HIP_TRY(hipMalloc((void **)&q, (size_t)nq * 12));
-    PCGX_HIP_TRY(hipMalloc((void **)&ids, (size_t)nq * 4));
-    PCGX_HIP_TRY(hipMalloc((void **)&dsq, (size_t)nq * 4));
+  pcgx_status alloc(int64_t nq, hipStream_t st) {
+    Arena &ar = ctx().host_arena;
+    PCGX_TRY(ar.begin(st));
+    PCGX_TRY(ar.alloc_n((size_t)nq * 3, &q));
+    PCGX_TRY(ar.alloc_n((size_t)nq, &ids));
+    PCGX_TRY(ar.alloc_n((size_t)nq, &dsq));
     return PCGX_OK;
   }
 };
@@ -494,7 +490,7 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const flo
   PCGX_TRY(ensure_init());
   hipStream_t st = ctx().stream;
   HostCallBufs b;
-  PCGX_TRY(b.alloc(nq));
+  PCGX_TRY(b.alloc(nq, st));
   PCGX_HIP_TRY(hipMemcpyAsync(b.q, q, (size_t)nq * 12, hipMemcpyHostToDevice, st));
   PCGX_TRY(pcgx_kdtree_nearest_batch_dev(t, b.q, nq, max_range, min_dist_sq,
                                          0u, b.ids, b.dsq, st));

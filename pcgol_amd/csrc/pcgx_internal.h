@@ -74,7 +74,9 @@ struct Context {
   int device = -1;
   hipStream_t stream = nullptr;
   int num_cu = 256;
-  Arena arena;
+  Arena arena;       // temporaries of the device-resident (_dev) entry points
+  Arena host_arena;  // device staging of the host-pointer entry points (they call the _dev ones,
+                     // which restart `arena`; separate so the staging survives that)
 };
 Context &ctx();
 pcgx_status ensure_init();

@@ -69,16 +69,6 @@ __global__ __launch_bounds__(256) void range_gather_u32_kernel(const uint32_t *_
 
 using namespace pcgx;
 
-namespace {
-struct DevMem {  // host-pointer call staging (plain hipMalloc; these calls are PCIe bound anyway)
-  void *p = nullptr;
-  ~DevMem() { if (p) (void)hipFree(p); }
-  pcgx_status alloc(size_t bytes) {
-    PCGX_HIP_TRY(hipMalloc(&p, bytes ? bytes : 1));
-    return PCGX_OK;
-  }
-};
-}  // namespace
 
 extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float *q, int64_t nq, float max_range,
                                                int64_t *counts) {
@@ -92,17 +82,19 @@ extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float
     return PCGX_OK;
   }
   hipStream_t st = ctx().stream;
-  DevMem dq, dc;
-  PCGX_TRY(dq.alloc((size_t)nq * 12));
-  PCGX_TRY(dc.alloc((size_t)nq * 8));
-  PCGX_HIP_TRY(hipMemcpyAsync(dq.p, q, (size_t)nq * 12, hipMemcpyHostToDevice, st));
+  float *d_q = nullptr;
+  int64_t *d_c = nullptr;
+  PCGX_TRY(ctx().host_arena.begin(st));
+  PCGX_TRY(ctx().host_arena.alloc_n((size_t)nq * 3, &d_q));
+  PCGX_TRY(ctx().host_arena.alloc_n((size_t)nq, &d_c));
+  PCGX_HIP_TRY(hipMemcpyAsync(d_q, q, (size_t)nq * 12, hipMemcpyHostToDevice, st));
   const TreeView tv = t->view();
   const size_t lds = walk_stack_bytes(tv, kRangeBlock);
   hipLaunchKernelGGL(range_kernel<false>, dim3((unsigned)((nq + kRangeBlock - 1) / kRangeBlock)), dim3(kRangeBlock), lds,
-                     st, tv, (const float *)dq.p, nq, max_range * max_range, (int64_t *)dc.p, nullptr, 0, nullptr, nullptr,
+                     st, tv, (const float *)d_q, nq, max_range * max_range, d_c, nullptr, 0, nullptr, nullptr,
                      nullptr);
   PCGX_HIP_TRY(hipGetLastError());
-  PCGX_HIP_TRY(hipMemcpyAsync(counts, dc.p, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipMemcpyAsync(counts, d_c, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
   return PCGX_OK;
 }

@@ -420,8 +420,9 @@ extern "C" pcgx_status pcgx_minmax(const void *data, int64_t n, int32_t stride, 
   hipStream_t st = ctx().stream;
   const void *src = data;
   const int32_t s = stride, o = xyz_off;
-  void *d = nullptr;
-  PCGX_HIP_TRY(hipMalloc(&d, (size_t)n * s));
+  uint8_t *d = nullptr;
+  PCGX_TRY(ctx().host_arena.begin(st));
+  PCGX_TRY(ctx().host_arena.alloc_n((size_t)n * s, &d));
   pcgx_status rc = PCGX_OK;
   float mm6[6];
   hipError_t e = hipMemcpyAsync(d, src, (size_t)n * s, hipMemcpyHostToDevice, st);
@@ -435,7 +436,6 @@ extern "C" pcgx_status pcgx_minmax(const void *data, int64_t n, int32_t stride, 
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_minmax: %s", hipGetErrorString(e));
   }
-  (void)hipFree(d);
   if (rc != PCGX_OK) return rc;
   memcpy(vmin, mm6, 12);
   memcpy(vmax, mm6 + 3, 12);
@@ -451,16 +451,13 @@ extern "C" pcgx_status pcgx_voxel_filter(const void *data, int64_t n, int32_t st
   if (n == 0) return fail(PCGX_E_NO_POINT, "no point");
   PCGX_TRY(ensure_init());
   hipStream_t st = ctx().stream;
-  void *d_in = nullptr, *d_out = nullptr;
+  uint8_t *d_in = nullptr, *d_out = nullptr;
   const size_t bytes = (size_t)n * (size_t)stride;
-  PCGX_HIP_TRY(hipMalloc(&d_in, bytes));
-  hipError_t e = hipMalloc(&d_out, bytes);
-  if (e != hipSuccess) {
-    (void)hipFree(d_in);
-    return fail(PCGX_E_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
-  }
+  PCGX_TRY(ctx().host_arena.begin(st));
+  PCGX_TRY(ctx().host_arena.alloc_n(bytes, &d_in));
+  PCGX_TRY(ctx().host_arena.alloc_n(bytes, &d_out));
   pcgx_status rc = PCGX_OK;
-  e = hipMemcpyAsync(d_in, data, bytes, hipMemcpyHostToDevice, st);
+  hipError_t e = hipMemcpyAsync(d_in, data, bytes, hipMemcpyHostToDevice, st);
   if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_voxel_filter upload: %s", hipGetErrorString(e));
   int64_t m = 0;
   if (rc == PCGX_OK) rc = pcgx_voxel_filter_dev(d_in, n, stride, xyz_off, leaf, chunk, d_out, &m, st);
@@ -470,8 +467,6 @@ extern "C" pcgx_status pcgx_voxel_filter(const void *data, int64_t n, int32_t st
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_voxel_filter download: %s", hipGetErrorString(e));
   }
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
   if (rc == PCGX_OK) *out_n = m;
   return rc;
 }

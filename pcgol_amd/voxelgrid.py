@@ -18,6 +18,7 @@ class VoxelGrid:
     def __init__(self, leafSize, *opts):
         self.LeafSize = np.asarray(leafSize, np.float32).reshape(3)
         self.ChunkSize = [0, 0, 0]
+        self._scratch = np.empty(0, np.uint8)  # worst-case output buffer, kept like the reference's f.voxels
         for o in opts:
             o(self)
 
@@ -27,7 +28,9 @@ class VoxelGrid:
             pp = PointCloud.from_xyz(pp)
         stride, off = pp.Stride(), pp.xyz_offset()
         n = pp.Points
-        out = np.empty(max(n, 1) * stride, np.uint8)
+        if len(self._scratch) < max(n, 1) * stride:
+            self._scratch = np.empty(max(n, 1) * stride, np.uint8)
+        out = self._scratch
         m = C.c_int64()
         chunk = np.asarray(self.ChunkSize, np.int32)
         L.check(L.lib().pcgx_voxel_filter(L.ptr(pp.Data), n, stride, off, L.ptr(self.LeafSize),
