@@ -67,14 +67,19 @@ def fit_sharded(partials_fn, MinPairs=0, UpdaterFactory=None, group=None):
     backend-agnostic tests and by hosts that bring their own exchange; bench.py uses
     ShardedIcp below, which keeps the loop on the device."""
     uf = UpdaterFactory or _icp.GradientDescentUpdaterFactory()
+    # point-to-plane extension: 30 sums (J^T J upper triangle, J^T r, ...) and a Gauss-Newton update
+    plane = isinstance(uf, _icp.GaussNewtonUpdaterFactory)
+    finish = _icp.FinishEvaluatePlane if plane else _icp.FinishEvaluate
     updater = uf.New()
     trans = mat.Translate(0, 0, 0)
     stat = _icp.Stat()
     while True:
         sums = allreduce_sums(np.asarray(partials_fn(trans, updater.i), np.float64), group)
+        if len(sums) != (30 if plane else 10):
+            raise ValueError("partials_fn must return %d sums" % (30 if plane else 10))
         stat.NumIteration += 1
         try:
-            ev = _icp.FinishEvaluate(sums, MinPairs)
+            ev = finish(sums, MinPairs)
         except L.ErrNotEnoughPairs as e:
             e.trans, e.stat = trans, stat
             raise

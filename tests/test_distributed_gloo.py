@@ -83,3 +83,54 @@ def test_sharded_fit_world2_gloo():
                     c["max_iteration"], sums_mode=0)
     assert np.max(np.abs(res[0][1] - o64["trans"])) <= 1e-6   # same float64-summed algorithm, different association
     assert np.max(np.abs(res[0][1] - o32["trans"])) <= 1e-5   # the reference's sequential float32 sums
+
+
+def _plane_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from pcgol_amd import icp, mat, synth
+        from pcgol_amd.distributed import fit_sharded, spatial_tiles
+        c = synth.c4_plane(5000)
+        tile = c["target"][spatial_tiles(c["target"], world)[rank]]
+        tree = O.KDTree(c["base"])
+
+        def partials(trans, it):
+            tt = tile if it == 0 else mat.Transform(trans, tile)
+            return O.plane_sums(tree, c["normals"], tt, c["max_dist"])
+
+        uf = icp.GaussNewtonUpdaterFactory(Threshold=c["threshold"], MaxIteration=6)
+        trans, stat = fit_sharded(partials, MinPairs=c["min_pairs"], UpdaterFactory=uf)
+        q.put((rank, trans, stat.NumIteration, stat.Evaluated.Hessian.copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_plane_fit_world2_gloo():
+    """The 30-double exchange of the point-to-plane extension (6x6 normal equations): tiles on two
+    ranks, all-reduce, redundant Gauss-Newton update == the single-process oracle Fit."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plane_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(res[0][1], res[1][1]) and res[0][2] == res[1][2] == 6
+    assert np.array_equal(res[0][3], res[1][3])
+    sys.path.insert(0, ROOT)
+    import oracle as O
+    from pcgol_amd import synth
+    c = synth.c4_plane(5000)
+    o = O.plane_fit(O.KDTree(c["base"]), c["normals"], c["target"], c["max_dist"], c["min_pairs"], c["threshold"], 0.0, 6)
+    assert np.max(np.abs(res[0][1] - o["trans"])) <= 1e-6
+    inv = np.linalg.inv(synth.icp_pose().astype(np.float64).reshape(4, 4).T).T.reshape(-1)
+    assert np.max(np.abs(res[0][1].astype(np.float64) - inv)) <= 5e-4
