@@ -68,3 +68,47 @@ def test_voxel_bad_leaf_sizes():
     out = voxelgrid.New((10.0, 10.0, 10.0)).Filter(pts)   # one voxel
     assert out.Points == 1
     assert np.array_equal(out.Data, O.voxel_filter(pts, len(pts), 12, 0, (10.0, 10.0, 10.0)))
+
+
+def test_edge_cases_of_the_next_rows():
+    """Empty / degenerate inputs of the rows built after the hot path (N2-N5)."""
+    import ctypes as C
+    from pcgol_amd import icp, pc, segmentation
+    from pcgol_amd import _lib as L
+    one = np.array([[1.0, 2.0, 3.0]], f32)
+    # bucket grid: nothing added, a grid with an empty axis, one point
+    v = segmentation.SegmentationVoxelGrid(0.5, [4, 4, 4], [0, 0, 0])
+    assert v.Indice().tolist() == [] and v.Segment([1, 1, 1]).tolist() == [] and v.Get([1, 1, 1]).tolist() == []
+    assert v.Get([9, 9, 9]) is None and v.Len() == 64
+    z = segmentation.SegmentationVoxelGrid(0.5, [4, 0, 4], [0, 0, 0])
+    assert z.AddAll(one).tolist() == [False] and z.Len() == 0
+    # int(pos / 0.5 + 0.5): 1.4 and 1.26 round to cell 3, 0.1 to cell 0, 1.9 falls outside (cell 4)
+    assert v.AddAll(np.array([[1.4, 1.4, 1.4], [0.1, 0.1, 0.1], [1.26, 1.4, 1.4], [1.9, 1.4, 1.4]], f32)).tolist() == \
+        [True, True, True, False]
+    assert v.Get([1.4, 1.4, 1.4]).tolist() == [0, 2] and v.Segment([1.5, 1.5, 1.5]).tolist() == [0, 2]
+    assert v.Get([1.9, 1.4, 1.4]) is None
+    a3 = v.Addr([1.4, 1.4, 1.4])[0]
+    assert a3 == 3 + (3 + 3 * 4) * 4 and v.Components().tolist() == [a3, 0, a3, -1]
+    with pytest.raises(L.PcgxError):
+        v.GetByAddr(64)
+    # region growing on a single point / a seed with no neighbour
+    t = kdtree.New(one)
+    rg = segmentation.RegionGrowing(t, [7])
+    assert rg.Segment(one[0], 0.5).tolist() == [0] and rg.Segment([9, 9, 9], 0.5).tolist() == []
+    # plane ICP: empty target -> not enough pairs; normals of the wrong length -> error
+    with pytest.raises(icp.ErrNotEnoughPairs):
+        icp.PointToPlaneICP(icp.PointToPlaneEvaluator(icp.NearestPointCorresponder(1.0), np.array([[0, 0, 1]], f32))
+                            ).Fit(t, np.zeros((0, 3), f32))
+    with pytest.raises(ValueError):
+        icp.PointToPlaneICP(icp.PointToPlaneEvaluator(icp.NearestPointCorresponder(1.0), np.zeros((2, 3), f32))
+                            ).Fit(t, one)
+    # PCD with zero points, straight to the device
+    buf = b"VERSION 0.7\nFIELDS x y z\nSIZE 4 4 4\nTYPE F F F\nCOUNT 1 1 1\nWIDTH 0\nHEIGHT 1\nPOINTS 0\nDATA binary\n"
+    hd, n, stride, _ = pc.UnmarshalDev(buf)
+    assert (n, stride, hd.Fields) == (0, 12, ["x", "y", "z"]) and pc.Unmarshal(buf).Points == 0
+    # DeletePoint on a one-point tree, then everything is "not found"
+    t.DeletePoint(0)
+    assert t.Nearest(one[0], 5.0).ID == -1 and t.LiveCount() == 0
+    t.DeletePoint(0)  # twice: no-op
+    with pytest.raises(IndexError):
+        t.DeletePoint(1)
