@@ -10,7 +10,7 @@
 // Level-synchronous form of the same recursion: before level d the array is cut into
 // "units" -- the sub-slices of the depth-d nodes, and single elements already fixed as the
 // node of a shallower level.  Level d is ONE stable sort of the whole array by the pair
-//     (unit start position, coordinate d%3 of the element)
+//     (rank of the unit in array order, coordinate d%3 of the element)
 // which sorts every depth-d sub-slice by its coordinate, leaves every fixed element where
 // it is, and keeps ties in their current order.  The pair is sorted as two stable LSD radix
 // sorts (coordinate first, unit second) with the hand-written radix sort of sort.hip;
@@ -21,26 +21,31 @@
 
 namespace pcgx {
 
-// Start position of the unit that holds position p before level `depth` is sorted:
-// walk the implicit tree (node of [lo, lo+n) sits at lo + n/2).  If p is the node of a
-// level shallower than `depth` the unit is that single position.
-__device__ __forceinline__ uint32_t unit_start(uint32_t p, uint32_t n_total, int depth, bool &fixed) {
-  uint32_t lo = 0, n = n_total;
+// Rank (in array order) of the unit that holds position p before level `depth` is sorted: walk
+// the implicit tree (node of [lo, lo+n) sits at lo + n/2).  A subtree with r more levels to split
+// holds 2^r sub-slices and 2^r - 1 fixed nodes, so the rank needs only depth + 1 bits -- the
+// second radix sort of a level takes ceil((depth + 1) / 8) passes instead of ceil(log2 N / 8).
+// (Sub-slices that are empty still count: ranks only have to be monotonic.)  If p is the node of
+// a level shallower than `depth` the unit is that single position (fixed = true).
+__device__ __forceinline__ uint32_t unit_rank(uint32_t p, uint32_t n_total, int depth, bool &fixed) {
+  uint32_t lo = 0, n = n_total, rank = 0;
   fixed = false;
   for (int d = 0; d < depth; d++) {
     const uint32_t half = n >> 1, mid = lo + half;
-    if (p == mid) {
+    const uint32_t left_units = (2u << (depth - d - 1)) - 1u;  // units of a child subtree
+    if (p == mid && n > 0u) {
       fixed = true;
-      return p;
+      return rank + left_units;
     }
     if (p < mid) {
       n = half;
     } else {
+      rank += left_units + 1u;
       lo = mid + 1;
       n = n - half - 1;
     }
   }
-  return lo;
+  return rank;
 }
 
 __device__ __forceinline__ uint32_t ordered_bits(float v) {
@@ -57,18 +62,18 @@ __global__ __launch_bounds__(256) void kb_coord_key_kernel(const float *__restri
   const uint32_t p = blockIdx.x * 256u + threadIdx.x;
   if (p >= n) return;
   bool fixed;
-  (void)unit_start(p, n, depth, fixed);
+  (void)unit_rank(p, n, depth, fixed);
   keys[p] = fixed ? 0u : ordered_bits(xyz[3 * (size_t)order[p] + depth % 3]);
   vals[p] = p;
 }
 
-// keys[j] = unit start of the ORIGINAL position vals[j] (the element sorted to slot j)
+// keys[j] = unit rank of the ORIGINAL position vals[j] (the element sorted to slot j)
 __global__ __launch_bounds__(256) void kb_unit_key_kernel(const uint32_t *__restrict__ vals, uint32_t n, int depth,
                                                           uint32_t *__restrict__ keys) {
   const uint32_t j = blockIdx.x * 256u + threadIdx.x;
   if (j >= n) return;
   bool fixed;
-  keys[j] = unit_start(vals[j], n, depth, fixed);
+  keys[j] = unit_rank(vals[j], n, depth, fixed);
 }
 
 __global__ __launch_bounds__(256) void kb_permute_kernel(const uint32_t *__restrict__ order,
@@ -131,8 +136,6 @@ pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint
   PCGX_TRY(ar.alloc_n((size_t)n, &vals[1]));
   PCGX_TRY(ar.alloc_n((size_t)n, &order_tmp));
   PCGX_TRY(ar.alloc(radix_sort_workspace_bytes(n), &ws));
-  int pos_bits = 0;
-  while (pos_bits < 31 && ((int64_t)1 << pos_bits) < n) pos_bits++;
   uint32_t *cur = d_order, *nxt = order_tmp;
   hipLaunchKernelGGL(kb_iota_kernel, dim3(nb), dim3(256), 0, st, cur, un);
   // levels 0 .. depth-2 have sub-slices longer than one element
@@ -145,7 +148,8 @@ pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint
     uint32_t *v2[2] = {vals[r1], vals[r1 ^ 1]};
     hipLaunchKernelGGL(kb_unit_key_kernel, dim3(nb), dim3(256), 0, st, v2[0], un, d, k2[0]);
     int r2 = 0;
-    PCGX_TRY(radix_sort_pairs(k2, v2, n, pos_bits, ws, &r2, st));
+    // unit ranks at level d: d + 1 bits (level 0 is one unit: nothing to regroup)
+    if (d > 0) PCGX_TRY(radix_sort_pairs(k2, v2, n, d + 1, ws, &r2, st));
     hipLaunchKernelGGL(kb_permute_kernel, dim3(nb), dim3(256), 0, st, cur, v2[r2], un, nxt);
     uint32_t *t = cur;
     cur = nxt;

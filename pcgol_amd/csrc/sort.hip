@@ -8,8 +8,8 @@
 // a wave traverse neighbouring sub-trees (results are written back in the
 // caller's order).
 //
-// One pass = histogram kernel (LDS bins) -> two tiny scan kernels -> scatter
-// kernel.  The scatter kernel ranks a 4096-element tile with wave64 ballots
+// One pass = histogram kernel (LDS bins) -> scan kernel (per digit over the tiles) -> scatter
+// kernel (which also scans the 256 digit totals).  The scatter kernel ranks a 4096-element tile with wave64 ballots
 // (8 per element round: a match-any on the 8-bit digit), re-orders the tile in
 // LDS by digit and writes each digit run contiguously, so global writes are
 // coalesced runs rather than 4-byte scatters.
@@ -74,31 +74,15 @@ __global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t *__re
   if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
-__global__ __launch_bounds__(kRadix) void rs_scan_totals_kernel(const uint32_t *__restrict__ totals,
-                                                                uint32_t *__restrict__ base) {
-  __shared__ uint32_t wave_sum[kRadix / 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t v = totals[threadIdx.x], inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t t = __shfl_up(inc, o);
-    if (lane >= o) inc += t;
-  }
-  if (lane == 63) wave_sum[wave] = inc;
-  __syncthreads();
-  uint32_t wbase = 0;
-  for (int w = 0; w < wave; w++) wbase += wave_sum[w];
-  base[threadIdx.x] = wbase + inc - v;
-}
-
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n, int shift,
-    const uint32_t *__restrict__ block_hist, int nblocks, const uint32_t *__restrict__ base,
+    const uint32_t *__restrict__ block_hist, int nblocks, const uint32_t *__restrict__ totals,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int xcd_remap) {
   __shared__ uint32_t cnt[kRsWaves][kRadix];
   __shared__ uint32_t tile_pref[kRadix];
   __shared__ uint32_t gbase[kRadix];
   __shared__ uint32_t wave_sum[kRsWaves];
+  __shared__ uint32_t gwave_sum[kRsWaves];
   __shared__ uint32_t skeys[kRsTile];
   __shared__ uint32_t svals[kRsTile];
 
@@ -144,7 +128,9 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
   }
   __syncthreads();
 
-  // digit t: per-wave exclusive offsets, tile total, exclusive prefix over digits
+  // digit t: per-wave exclusive offsets, tile total, exclusive prefix over digits; the global
+  // start of digit t (exclusive prefix of the digit totals) is scanned here too, by every
+  // workgroup for itself: 256 values, cheaper than a launch of its own
   {
     const int t = threadIdx.x;
     uint32_t run = 0;
@@ -154,19 +140,29 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
       cnt[w][t] = run;
       run += c;
     }
-    uint32_t inc = run;
+    const uint32_t tot = totals[t];
+    uint32_t inc = run, ginc = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      uint32_t x = __shfl_up(inc, o);
-      if (lane >= o) inc += x;
+      uint32_t x = __shfl_up(inc, o), g = __shfl_up(ginc, o);
+      if (lane >= o) {
+        inc += x;
+        ginc += g;
+      }
     }
-    if (lane == 63) wave_sum[wave] = inc;
+    if (lane == 63) {
+      wave_sum[wave] = inc;
+      gwave_sum[wave] = ginc;
+    }
     __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wave; w++) wbase += wave_sum[w];
+    uint32_t wbase = 0, gwbase = 0;
+    for (int w = 0; w < wave; w++) {
+      wbase += wave_sum[w];
+      gwbase += gwave_sum[w];
+    }
     const uint32_t excl = wbase + inc - run;
     tile_pref[t] = excl;
-    gbase[t] = base[t] + block_hist[(int64_t)t * nblocks + tile] - excl;  // dst = gbase[d] + pos
+    gbase[t] = (gwbase + ginc - tot) + block_hist[(int64_t)t * nblocks + tile] - excl;  // dst = gbase[d] + pos
   }
   __syncthreads();
 
@@ -223,20 +219,18 @@ pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, in
   const int nblocks = (int)((n + kRsTile - 1) / kRsTile);
   uint32_t *block_hist = (uint32_t *)workspace;
   uint32_t *totals = block_hist + (int64_t)nblocks * kRadix;
-  uint32_t *base = totals + kRadix;
   int cur = 0;
   for (int shift = 0; shift < key_bits; shift += 8) {
     hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(kRsThreads), 0, st, keys[cur], n, shift,
                        block_hist, nblocks);
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(kRadix), dim3(kRsThreads), 0, st, block_hist, nblocks,
                        totals);
-    hipLaunchKernelGGL(rs_scan_totals_kernel, dim3(1), dim3(kRadix), 0, st, totals, base);
     {
       ProfScope prof(PCGX_PROF_SORT_SCATTER, st);
       const int remap = sort_xcd_remap() && nblocks >= 64;
       const int grid = remap ? 8 * ((nblocks + 7) / 8) : nblocks;
       hipLaunchKernelGGL(rs_scatter_kernel, dim3(grid), dim3(kRsThreads), 0, st, keys[cur], vals[cur], n,
-                         shift, block_hist, nblocks, base, keys[cur ^ 1], vals[cur ^ 1], remap);
+                         shift, block_hist, nblocks, totals, keys[cur ^ 1], vals[cur ^ 1], remap);
     }
     cur ^= 1;
   }
