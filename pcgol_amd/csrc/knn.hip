@@ -246,7 +246,27 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
   t->depth = tree_depth(n);
   t->points.resize((size_t)n * 3);
   const uint8_t *src = (const uint8_t *)data;
-  for (int64_t i = 0; i < n; i++) memcpy(&t->points[3 * i], src + i * (int64_t)stride + xyz_off, 12);
+  if (stride == 12) memcpy(t->points.data(), src, (size_t)n * 12);
+  else
+    for (int64_t i = 0; i < n; i++) memcpy(&t->points[3 * i], src + i * (int64_t)stride + xyz_off, 12);
+  // one pass: bounding box (first point, then strict < / >, so NaNs never replace a bound) and NaN scan
+  float blo[3], bhi[3];
+  bool has_nan = false;
+  {
+    const float *pp = t->points.data();
+    float l0 = pp[0], l1 = pp[1], l2 = pp[2], h0 = l0, h1 = l1, h2 = l2;
+    int nan_count = 0;
+    for (int64_t i = 0; i < n; i++) {
+      const float x = pp[3 * i], y = pp[3 * i + 1], z = pp[3 * i + 2];
+      l0 = x < l0 ? x : l0; h0 = x > h0 ? x : h0;
+      l1 = y < l1 ? y : l1; h1 = y > h1 ? y : h1;
+      l2 = z < l2 ? z : l2; h2 = z > h2 ? z : h2;
+      nan_count += (x != x) | (y != y) | (z != z);
+    }
+    blo[0] = l0; blo[1] = l1; blo[2] = l2;
+    bhi[0] = h0; bhi[1] = h1; bhi[2] = h2;
+    has_nan = nan_count != 0;
+  }
   t->inorder.resize((size_t)n);
   const size_t slots = (size_t)1 << t->depth;
   hipError_t e = hipMalloc((void **)&t->d_nodes, slots * sizeof(float4));
@@ -256,8 +276,6 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
   }
   // Build on the device for large clouds; NaN coordinates (no consistent order under <) and
   // small clouds take the host build.  PCGX_BUILD=host|gpu forces one (tests).
-  bool has_nan = false;
-  for (size_t i = 0; i < (size_t)n * 3 && !has_nan; i++) has_nan = t->points[i] != t->points[i];
   bool on_gpu = n >= 32768 && !has_nan;
   if (const char *f = getenv("PCGX_BUILD")) {
     if (!strcmp(f, "host")) on_gpu = false;
@@ -303,14 +321,7 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
   }
   // leaf directory: ~2 cells per point, at most 2^27 cells
   {
-    float lo[3], hi[3];
-    for (int k = 0; k < 3; k++) lo[k] = hi[k] = t->points[k];
-    for (int64_t i = 1; i < n; i++)
-      for (int k = 0; k < 3; k++) {
-        const float v = t->points[3 * i + k];
-        if (v < lo[k]) lo[k] = v;
-        if (v > hi[k]) hi[k] = v;
-      }
+    const float *lo = blo, *hi = bhi;
     for (int k = 0; k < 3; k++) { t->bbox_lo[k] = lo[k]; t->bbox_hi[k] = hi[k]; }
     int g = 0;
     while (g < 9 && ((int64_t)1 << (3 * g)) < 2 * n) g++;
