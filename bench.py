@@ -196,9 +196,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (no CPU fallback)")
+    # Rehearsal of the N > 1 path on a one-GPU box: PCGX_BENCH_REHEARSE=1 puts every rank on
+    # cuda:0 and exchanges through gloo (RCCL refuses two ranks on one device).  Never used by the
+    # driver; the numbers of such a run are not comparable (ranks share the GPU).
+    rehearse = os.environ.get("PCGX_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from pcgol_amd import _lib as L
     from pcgol_amd import icp, kdtree, synth, voxelgrid
@@ -272,7 +281,8 @@ def main():
                                    "20-iteration Fits, Threshold -1; one step = corr+reduce+re-projection+update"
                                    % (n, n),
                        "base_points": n, "target_points_per_gpu": n, "parallelism": "target tiles x%d, tree replicated" % world,
-                       "exchange": "none" if world == 1 else "all-reduce 10 x f64 per step (RCCL)"},
+                       "exchange": "none" if world == 1 else "all-reduce 10 x f64 per step (%s)"
+                                   % ("gloo: REHEARSAL on one GPU, not a measurement" if rehearse else "RCCL")},
             "roofline": {"bound": "hbm", "kernel": "icp_corr_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_s * 1e3, "launches": walk_n,
