@@ -418,3 +418,111 @@ func FitPlane(base *KDTree, target pc.Vec3RandomAccessor, e *PlaneEvaluator, thr
 	}
 	return trans, stat, status(rc)
 }
+
+// ------------------------------------------------- bucket grid, segmentation
+
+// BucketGrid is pc/storage/voxelgrid.VoxelGrid filled with Add(point i, i) for
+// a whole cloud (voxelgrid.go:15-23,37-45), with pc/segmentation/voxelgrid's
+// Segment (voxelgrid.go:39-73) answered from the connected components the
+// device computes for the whole grid.
+type BucketGrid struct {
+	h *C.pcgx_bucket_grid
+}
+
+// NewBucketGrid builds the grid over every point of ra.
+func NewBucketGrid(resolution float32, size [3]int, origin mat.Vec3, ra pc.Vec3RandomAccessor) (*BucketGrid, error) {
+	xyz := packVec3(ra)
+	var data unsafe.Pointer
+	if len(xyz) > 0 {
+		data = unsafe.Pointer(&xyz[0])
+	}
+	sz := [3]C.int64_t{C.int64_t(size[0]), C.int64_t(size[1]), C.int64_t(size[2])}
+	g := &BucketGrid{}
+	rc := C.pcgx_bucket_grid_build(data, C.int64_t(ra.Len()), 12, 0, C.float(resolution), &sz[0],
+		(*C.float)(unsafe.Pointer(&origin[0])), &g.h)
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	runtime.SetFinalizer(g, func(g *BucketGrid) { g.Close() })
+	return g, nil
+}
+
+// Close releases the grid.
+func (g *BucketGrid) Close() {
+	if g.h != nil {
+		C.pcgx_bucket_grid_free(g.h)
+		g.h = nil
+	}
+}
+
+func idsToInt(ids []int64) []int {
+	out := make([]int, len(ids))
+	for i, v := range ids {
+		out[i] = int(v)
+	}
+	return out
+}
+
+// Get returns the ids of p's voxel, nil when p is outside the grid (voxelgrid.go:52-58).
+func (g *BucketGrid) Get(p mat.Vec3) []int {
+	var cnt C.int64_t
+	if C.pcgx_bucket_grid_get(g.h, (*C.float)(unsafe.Pointer(&p[0])), nil, 0, &cnt) != C.PCGX_OK || cnt < 0 {
+		return nil
+	}
+	ids := make([]int64, int(cnt)+1)
+	C.pcgx_bucket_grid_get(g.h, (*C.float)(unsafe.Pointer(&p[0])), (*C.int64_t)(unsafe.Pointer(&ids[0])), cnt, &cnt)
+	return idsToInt(ids[:int(cnt)])
+}
+
+// Segment is segmentation/voxelgrid.VoxelGrid.Segment (ids ascending by voxel, not in BFS order).
+func (g *BucketGrid) Segment(p mat.Vec3) []int {
+	var cnt C.int64_t
+	if C.pcgx_bucket_grid_segment(g.h, (*C.float)(unsafe.Pointer(&p[0])), nil, 0, &cnt) != C.PCGX_OK || cnt <= 0 {
+		return nil
+	}
+	ids := make([]int64, int(cnt))
+	C.pcgx_bucket_grid_segment(g.h, (*C.float)(unsafe.Pointer(&p[0])), (*C.int64_t)(unsafe.Pointer(&ids[0])), cnt, &cnt)
+	return idsToInt(ids[:int(cnt)])
+}
+
+// RegionGrowing is pc/segmentation/regiongrowing.RegionGrowing (regiongrowing.go:13-56) with the
+// regions of the whole cloud labelled on the device once per maxRange.
+type RegionGrowing struct {
+	search   *KDTree
+	labels   []uint32
+	comp     []int64
+	maxRange float32
+}
+
+// NewRegionGrowing mirrors regiongrowing.New(search, propertyIter).
+func NewRegionGrowing(search *KDTree, propertyIter pc.Uint32RandomAccessor) *RegionGrowing {
+	labels := make([]uint32, search.Len())
+	for i := range labels {
+		labels[i] = propertyIter.Uint32At(i)
+	}
+	return &RegionGrowing{search: search, labels: labels}
+}
+
+// Segment mirrors RegionGrowing.Segment (ids ascending, not in BFS order).
+func (r *RegionGrowing) Segment(p mat.Vec3, maxRange float32) []int {
+	n := len(r.labels)
+	if n == 0 {
+		return []int{}
+	}
+	if r.comp == nil || r.maxRange != maxRange {
+		comp := make([]int64, n)
+		if C.pcgx_region_growing_components(r.search.h, (*C.uint32_t)(unsafe.Pointer(&r.labels[0])), C.float(maxRange),
+			(*C.int64_t)(unsafe.Pointer(&comp[0]))) != C.PCGX_OK {
+			return []int{}
+		}
+		r.comp, r.maxRange = comp, maxRange
+	}
+	ids := make([]int64, n)
+	var cnt C.int64_t
+	if C.pcgx_region_growing_segment(r.search.h, (*C.uint32_t)(unsafe.Pointer(&r.labels[0])),
+		(*C.int64_t)(unsafe.Pointer(&r.comp[0])), (*C.float)(unsafe.Pointer(&p[0])), C.float(maxRange),
+		(*C.int64_t)(unsafe.Pointer(&ids[0])), C.int64_t(n), &cnt) != C.PCGX_OK {
+		return []int{}
+	}
+	return idsToInt(ids[:int(cnt)])
+}

@@ -7,6 +7,8 @@
 //   pcgx::KDTree            <- pc/storage/kdtree.KDTree      (storage.Search)
 //   pcgx::VoxelGrid         <- pc/filter/voxelgrid.New(...)  (filter.Filter)
 //   pcgx::PointToPointICP   <- icp.PointToPointICPGradient{Evaluator, UpdaterFactory}
+//   pcgx::BucketVoxelGrid   <- pc/storage/voxelgrid.VoxelGrid + pc/segmentation/voxelgrid (Segment)
+//   pcgx::RegionGrowing     <- pc/segmentation/regiongrowing.RegionGrowing
 //   pcgx::PointToPlaneICP   <- (extension, no counterpart in the reference) the same Fit shape with
 //                              the point-to-plane evaluator / Gauss-Newton updater, HasHessian() == true
 #pragma once
@@ -117,6 +119,65 @@ class VoxelGrid {  // pc/filter/voxelgrid/voxelgrid.go:23-33 + option.go:14-18
     out.resize((size_t)m * c.stride);
     return out;
   }
+};
+
+// pc/storage/voxelgrid.VoxelGrid (voxelgrid.go:7-122) filled with Add(point i, i) for a whole
+// cloud, plus pc/segmentation/voxelgrid's Segment (voxelgrid.go:39-73).
+class BucketVoxelGrid {
+ public:
+  BucketVoxelGrid(float resolution, std::array<int64_t, 3> size, Vec3 origin, const CloudView &c) {
+    check(pcgx_bucket_grid_build(c.data, c.points, c.stride, c.xyz_offset, resolution, size.data(), origin.data(), &h_));
+  }
+  ~BucketVoxelGrid() { pcgx_bucket_grid_free(h_); }
+  BucketVoxelGrid(const BucketVoxelGrid &) = delete;
+  BucketVoxelGrid &operator=(const BucketVoxelGrid &) = delete;
+  int64_t Len() const { int64_t n; check(pcgx_bucket_grid_counts(h_, &n, nullptr, nullptr)); return n; }
+  // Get(p): false = nil (p outside the grid), else the ids of p's voxel in insertion order
+  bool Get(const Vec3 &p, std::vector<int64_t> *ids) const {
+    int64_t cnt = 0;
+    check(pcgx_bucket_grid_get(h_, p.data(), nullptr, 0, &cnt));
+    if (cnt < 0) return false;
+    ids->resize((size_t)cnt);
+    if (cnt > 0) check(pcgx_bucket_grid_get(h_, p.data(), ids->data(), cnt, &cnt));
+    return true;
+  }
+  std::vector<int64_t> Segment(const Vec3 &p) {
+    int64_t cnt = 0;
+    check(pcgx_bucket_grid_segment(h_, p.data(), nullptr, 0, &cnt));
+    std::vector<int64_t> out((size_t)cnt);
+    if (cnt > 0) check(pcgx_bucket_grid_segment(h_, p.data(), out.data(), cnt, &cnt));
+    return out;
+  }
+
+ private:
+  pcgx_bucket_grid *h_ = nullptr;
+};
+
+// pc/segmentation/regiongrowing.RegionGrowing (regiongrowing.go:13-56): New(search, propertyIter)
+class RegionGrowing {
+ public:
+  RegionGrowing(const KDTree &search, std::vector<uint32_t> property) : t_(search), labels_(std::move(property)) {
+    if ((int64_t)labels_.size() != t_.Len()) throw Error(PCGX_E_INVALID, "one property value per point is required");
+  }
+  std::vector<int64_t> Segment(const Vec3 &p, float maxRange) {
+    if (comp_.empty() || maxRange != range_) {  // components of the whole cloud, once per maxRange
+      comp_.resize(labels_.size());
+      check(pcgx_region_growing_components(t_.handle(), labels_.data(), maxRange, comp_.data()));
+      range_ = maxRange;
+    }
+    std::vector<int64_t> out(labels_.size());
+    int64_t cnt = 0;
+    check(pcgx_region_growing_segment(t_.handle(), labels_.data(), comp_.data(), p.data(), maxRange, out.data(),
+                                      (int64_t)out.size(), &cnt));
+    out.resize((size_t)cnt);
+    return out;
+  }
+
+ private:
+  const KDTree &t_;
+  std::vector<uint32_t> labels_;
+  std::vector<int64_t> comp_;
+  float range_ = 0.0f;
 };
 
 struct Stat {  // icp/stat.go:3-6

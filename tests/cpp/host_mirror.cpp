@@ -72,6 +72,26 @@ int main(int argc, char **argv) {
           std::printf(" %.9g,%.9g,%.9g,%u", xyz[0], xyz[1], xyz[2], label);
         }
         std::printf("\n");
+      } else if (tag == "G") {  // bucket grid over the current base cloud: resolution, size, origin, then seed
+        float res; std::array<int64_t, 3> size; pcgx::Vec3 origin, seed;
+        in >> res >> size[0] >> size[1] >> size[2] >> origin[0] >> origin[1] >> origin[2] >> seed[0] >> seed[1] >> seed[2];
+        pcgx::BucketVoxelGrid g(res, size, origin, pcgx::CloudView{base.data(), (int64_t)base.size(), 12, 0});
+        auto seg = g.Segment(seed);
+        std::printf("segment");
+        for (int64_t id : seg) std::printf(" %" PRId64, id);
+        std::printf("\n");
+        std::vector<int64_t> ids;
+        std::printf("get %d", g.Get(seed, &ids) ? (int)ids.size() : -1);
+        std::printf(" len %" PRId64 "\n", g.Len());
+      } else if (tag == "W") {  // region growing: labels = (id % modulo), seed, maxRange
+        uint32_t mod; pcgx::Vec3 seed; float mr;
+        in >> mod >> seed[0] >> seed[1] >> seed[2] >> mr;
+        std::vector<uint32_t> lab(base.size());
+        for (size_t i = 0; i < lab.size(); i++) lab[i] = (uint32_t)(i % mod);
+        pcgx::RegionGrowing rg(*tree, lab);
+        std::printf("region");
+        for (int64_t id : rg.Segment(seed, mr)) std::printf(" %" PRId64, id);
+        std::printf("\n");
       } else if (tag == "I") {  // ICP: target = base + (dx,dy,dz); point-to-point Fit with MinPairs / MaxDist
         float dx, dy, dz, maxd; int minp;
         in >> dx >> dy >> dz >> maxd >> minp;

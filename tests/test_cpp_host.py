@@ -51,6 +51,12 @@ def test_cpp_host_mirror_known_answers(tmp_path, golden):
     lines += ["%r %r %r" % tuple(map(float, p)) for p in rp]
     lines.append("R %d" % len(kd["range"]["cases"]))
     lines += ["%r %r %r %r" % (*map(float, c["p"]), c["max_range"]) for c in kd["range"]["cases"]]
+    sg = golden("ref_segment.json")["flood_fill"]
+    lines.append("P %d" % len(sg["points"]))
+    lines += ["%r %r %r" % tuple(map(float, p)) for p in sg["points"]]
+    o = float(np.float32(sg["origin"][0]))
+    lines.append("G %r %d %d %d %r %r %r %r %r %r" % (sg["resolution"], *sg["size"], o, o, o, *sg["seed_point"]))
+    lines.append("W 1 0.5 0.5 0.5 0.051")
     lines.append("V %d" % len(vx["cloud"]["xyz"]))
     lines += ["%r %r %r %d" % (*map(float, p), l) for p, l in zip(vx["cloud"]["xyz"], vx["cloud"]["label"])]
     for c in vx["cases"]:
@@ -78,6 +84,16 @@ def test_cpp_host_mirror_known_answers(tmp_path, golden):
         assert [int(r[3]) for r in recs] == c["expected_labels"], c["name"]
         got = np.array([[float(v) for v in r[:3]] for r in recs], np.float32)
         assert np.array_equal(got, np.array(c["expected"], np.float32)), c["name"]
+    seg = [l for l in out if l.startswith("segment")][0].split()[1:]
+    assert sorted(int(v) for v in seg) == sg["expected_sorted"]
+    import oracle as O
+    spts = np.array(sg["points"], np.float32)
+    og = O.BucketGrid(sg["resolution"], sg["size"], np.array(sg["origin"], np.float32))
+    og.add_all(spts)
+    assert [l for l in out if l.startswith("get ")][0] == "get %d len %d" % (len(og.get(sg["seed_point"])), 64 ** 3)
+    # region growing through the C++ mirror == the oracle's BFS (one property value, maxRange 0.051)
+    exp = sorted(O.region_growing_segment(O.KDTree(spts), np.zeros(len(spts), np.uint32), [0.5, 0.5, 0.5], 0.051).tolist())
+    assert [int(v) for v in [l for l in out if l.startswith("region")][0].split()[1:]] == exp and len(exp) >= 3
     icp = [l for l in out if l.startswith("icp ")][0].split()
     # same Fit through the Python mirror (same C ABI): identical transform
     from pcgol_amd import icp as picp, kdtree
