@@ -25,7 +25,7 @@
 // predicts the leaf a query will reach; in BFS order the ancestors of that leaf
 // are plain shifts of its index, so the split values of the WHOLE predicted path
 // (and the leaf itself) are fetched in parallel -- one memory round trip; the
-// split values of the top 11 levels come from an LDS copy per workgroup.  The
+// split values of the top kWalkTopLevels (6) levels come from an LDS copy per workgroup.  The
 // prediction is then VERIFIED level by level with the reference's own
 // comparison (pivotVal > val -> child0, kdtree.go:216): up to the first level m
 // where the real descent leaves the predicted path everything is exactly what
@@ -134,8 +134,8 @@ __device__ __forceinline__ float4 node_at(const float4 *nodes, uint32_t b) {
   return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(nodes) + off);
 }
 
-constexpr int kTopLevels = kWalkTopLevels;     // split values of levels 0..10 (BFS 1..2047) live in LDS
-constexpr int kTopEntries = 1 << kTopLevels;   // 2048 floats = 8 KB per workgroup
+constexpr int kTopLevels = kWalkTopLevels;     // split values of levels 0..kTopLevels-1 live in LDS
+constexpr int kTopEntries = 1 << kTopLevels;   // 64 floats = 256 B per workgroup at the default 6 levels
 constexpr int kDeepGroup = 5;                  // deeper levels are fetched in groups of this many
 static_assert((kMaxLevels - kTopLevels) % kDeepGroup == 0, "deep levels must split into whole groups");
 

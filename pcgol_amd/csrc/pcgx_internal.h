@@ -133,7 +133,7 @@ namespace pcgx {
 constexpr int kKnnBlock = 256;  // 4 waves
 constexpr int kWalkQueueBytesPerWave = 7 * 128 * 4;  // knn_walk.h kQueueWords x kQueueSlots
 // Dynamic LDS of a walk kernel block: frame stacks [(depth-1)][block] x 4 B (19 KB at 1M
-// points), one prepared-query queue per wave (3.5 KB each), the top split values (8 KB).
+// points), one prepared-query queue per wave (3.5 KB each), the top split values (256 B).
 inline size_t walk_stack_bytes(const TreeView &tv, int block) {
   int levels = tv.depth > 1 ? tv.depth - 1 : 1;
   return (size_t)levels * block * sizeof(uint32_t);
