@@ -531,8 +531,22 @@ extern "C" pcgx_status pcgx_icp_plane_session_create(const pcgx_kdtree *base, co
   return session_create(base, base_normals, damping, target, nt, on_device, params, d_sums30, out);
 }
 
+// Walk knobs of the ICP kernel (the hinted walk of iterations >= 1 profits from resolving wrong
+// leaf predictions in lockstep during the chunk preparation; the cold C2 walk does not):
+// PCGX_ICP_TIGHT (default 32: the whole descent), PCGX_ICP_CHUNKS (default 2 chunks per refill section).
+static int icp_knob(const char *name, int def, int lo, int hi) {
+  if (const char *e = getenv(name)) {
+    const int v = atoi(e);
+    if (v >= lo && v <= hi) return v;
+  }
+  return def;
+}
+
 static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
-  const TreeView tv = s->base->view();
+  static const int tight = icp_knob("PCGX_ICP_TIGHT", 32, 0, 32), chunks = icp_knob("PCGX_ICP_CHUNKS", 2, 1, 64);
+  TreeView tv = s->base->view();
+  tv.tight_levels = tight;
+  tv.chunks_per_refill = chunks;
   const size_t lds = walk_lds_bytes(tv, kIcpBlock);
   const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
   ProfScope prof(PCGX_PROF_ICP_WALK, st);

@@ -130,7 +130,7 @@ pcgx_status resolve_tree(const pcgx_kdtree *t, const pcgx_kdtree **active, bool 
 namespace pcgx {
 
 // knn.hip
-constexpr int kKnnBlock = 256;  // 4 waves
+constexpr int kKnnBlock = 512;  // 8 waves (2 workgroups per CU; 256 x 4 and 1024 x 1 measured slower)
 constexpr int kWalkQueueBytesPerWave = 7 * 128 * 4;  // knn_walk.h kQueueWords x kQueueSlots
 // Dynamic LDS of a walk kernel block: frame stacks [(depth-1)][block] x 4 B (19 KB at 1M
 // points), one prepared-query queue per wave (3.5 KB each), the top split values (256 B).
