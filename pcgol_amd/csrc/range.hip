@@ -23,19 +23,24 @@
 namespace pcgx {
 
 constexpr int kRangeBlock = kRangeWalkBlock;
+constexpr int64_t kRangePresortMin = 16384;  // batches from this size on are walked in Morton order
 
 // kFill == false: counts[i] = number of neighbours.  kFill == true: neighbours of query i are
 // written from offsets[i] in discovery order: {point id, DistSq bits, query index}.
 template <bool kFill>
-__global__ __launch_bounds__(kRangeBlock) void range_kernel(TreeView tv, const float *__restrict__ q, int64_t nq,
+__global__ __launch_bounds__(kRangeBlock) void range_kernel(TreeView tv, const float *__restrict__ q,
+                                                            const int32_t *__restrict__ perm, int64_t nq,
                                                             float bound, int64_t *__restrict__ counts,
                                                             const int64_t *__restrict__ offsets, int64_t total,
                                                             int32_t *__restrict__ out_id,
                                                             uint32_t *__restrict__ out_key,
                                                             uint32_t *__restrict__ out_query) {
   extern __shared__ uint32_t s_stack[];
-  const int64_t i = (int64_t)blockIdx.x * kRangeBlock + threadIdx.x;
-  if (i >= nq) return;
+  const int64_t pos = (int64_t)blockIdx.x * kRangeBlock + threadIdx.x;
+  if (pos >= nq) return;
+  // perm (optional): launch position -> query index (Morton order: the lanes of a wave walk
+  // neighbouring sub-trees); everything is written at the query's own index
+  const int64_t i = perm ? (int64_t)perm[pos] : pos;
   const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
   int64_t found = 0;
   // never write outside the slice the caller's offsets give this query (they may be wrong)
@@ -90,9 +95,15 @@ extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float
   PCGX_HIP_TRY(hipMemcpyAsync(d_q, q, (size_t)nq * 12, hipMemcpyHostToDevice, st));
   const TreeView tv = t->view();
   const size_t lds = walk_stack_bytes(tv, kRangeBlock);
+  int32_t *perm = nullptr;
+  if (nq >= kRangePresortMin) {
+    PCGX_TRY(ctx().arena.begin(st));
+    PCGX_TRY(ctx().arena.alloc_n((size_t)nq, &perm));
+    PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, perm, st));
+  }
   hipLaunchKernelGGL(range_kernel<false>, dim3((unsigned)((nq + kRangeBlock - 1) / kRangeBlock)), dim3(kRangeBlock), lds,
-                     st, tv, (const float *)d_q, nq, max_range * max_range, d_c, nullptr, 0, nullptr, nullptr,
-                     nullptr);
+                     st, tv, (const float *)d_q, (const int32_t *)perm, nq, max_range * max_range, d_c, nullptr, 0,
+                     nullptr, nullptr, nullptr);
   PCGX_HIP_TRY(hipGetLastError());
   PCGX_HIP_TRY(hipMemcpyAsync(counts, d_c, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
@@ -141,8 +152,14 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
   PCGX_HIP_TRY(hipMemsetAsync(d_query, 0, (size_t)total * 4, st));
   const TreeView tv = t->view();
   const size_t lds = walk_stack_bytes(tv, kRangeBlock);
+  int32_t *qperm = nullptr;
+  if (nq >= kRangePresortMin) {
+    PCGX_TRY(ar.alloc_n((size_t)nq, &qperm));
+    PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, qperm, st));
+  }
   hipLaunchKernelGGL(range_kernel<true>, dim3((unsigned)((nq + kRangeBlock - 1) / kRangeBlock)), dim3(kRangeBlock), lds,
-                     st, tv, d_q, nq, max_range * max_range, nullptr, d_off, total, d_id, d_key, d_query);
+                     st, tv, d_q, (const int32_t *)qperm, nq, max_range * max_range, nullptr, d_off, total, d_id, d_key,
+                     d_query);
   const unsigned tb = (unsigned)((total + 255) / 256);
   hipLaunchKernelGGL(range_iota_kernel, dim3(tb), dim3(256), 0, st, vals[0], total);
   PCGX_HIP_TRY(hipMemcpyAsync(keys[0], d_key, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
