@@ -2,7 +2,9 @@
 through the C ABI next to the CPU oracle (C restatement of the reference, 1 thread) on a bounded
 sample of the same workload.  Host-pointer entry points: the times INCLUDE the PCIe copies and the
 host-side marshalling (the device-resident numbers of the headline path are bench.py's).
-    python tools/bench_rows.py > profiles/rNN_rows.json"""
+    python tests/perf_rows.py > profiles/rNN_rows.json
+(lives under tests/ because it times and checks against the oracle, which only tests/, smoke() and
+bench.py's cpu_baseline leg may load; not collected by pytest)"""
 import json
 import os
 import sys
