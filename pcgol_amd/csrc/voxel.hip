@@ -19,6 +19,7 @@
 //
 // Out-of-range cell indices make the Go code panic; here they raise
 // PCGX_E_OUT_OF_RANGE.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -36,6 +37,8 @@ struct VoxelParams {
   int32_t chunked;
   float cs[3];         // clamped chunk size in metres
   int64_t nx, ny, n_chunks;
+  // chunked mode with (chunk id, cell) fitting 32 bits: ONE sort key = cid << key_shift | cell
+  int32_t combined, key_shift;
 };
 
 __device__ __forceinline__ float ld_f32(const uint8_t *p) {
@@ -89,9 +92,15 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(const uint8_t *__restric
   uint32_t ka = 0;
   if (a < 0 || a >= vp.n_voxels) atomicOr(err, 1);  // f.voxels[a] would panic
   else ka = (uint32_t)a;
-  key_a[i] = ka;
+  key_a[i] = vp.combined ? ((cid << vp.key_shift) | ka) : ka;
   if (a_orig) a_orig[i] = ka;
   idx[i] = (uint32_t)i;
+}
+
+// chunk id of sorted position j: its own array (two sorts), or the high bits of the combined key
+__device__ __forceinline__ uint32_t sorted_cid(const VoxelParams &vp, const uint32_t *__restrict__ sa,
+                                               const uint32_t *__restrict__ sc, int64_t j) {
+  return sc ? sc[j] : (vp.combined ? sa[j] >> vp.key_shift : 0u);
 }
 
 __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t *__restrict__ src,
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(
     const int l = r * 256 + threadIdx.x;
     head[r] = l < count && is_head(sa, sc, base + l);
     float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
-    if (vp.chunked && l < count) chunk_origin(vp, sc ? sc[base + l] : 0u, origin);
+    if (vp.chunked && l < count) chunk_origin(vp, sorted_cid(vp, sa, sc, base + l), origin);
     // p := it.Vec3().Sub(vMin)   (voxelgrid.go:149)
     sp[0][l] = v[r][0] - origin[0];
     sp[1][l] = v[r][1] - origin[1];
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(
       int l = r * 256 + threadIdx.x;
       const int64_t j = base + l;
       const uint32_t slot = running + wbase + (uint32_t)__popcll(bal & lt_mask);
-      const uint32_t cid = sc ? sc[j] : 0u;
+      const uint32_t cid = sorted_cid(vp, sa, sc, j);
       float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
       if (vp.chunked) chunk_origin(vp, cid, origin);
       float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
@@ -360,7 +369,17 @@ extern "C" pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int3
   int64_t *d_total = nullptr;
   uint32_t *tile_count = nullptr;
   const int ntiles = (int)((n + kSegTile - 1) / kSegTile);
-  const bool two_level = vp.chunked && vp.n_chunks > 1;
+  bool two_level = vp.chunked && vp.n_chunks > 1;
+  int key_bits = bits_for(vp.n_voxels);
+  const char *force_two = getenv("PCGX_VOXEL_TWO_SORTS");  // tests: keep the two-sort path covered
+  if (two_level && key_bits + bits_for(vp.n_chunks) <= 32 && !(force_two && force_two[0] == '1')) {
+    // (chunk id, cell) in one 32-bit key: one stable sort gives the reference's output order
+    // (chunks ascending, cells ascending inside a chunk) without the second sort and its gathers
+    vp.combined = 1;
+    vp.key_shift = key_bits;
+    key_bits += bits_for(vp.n_chunks);
+    two_level = false;
+  }
   PCGX_TRY(ar.alloc_n((size_t)n, &keys[0]));
   PCGX_TRY(ar.alloc_n((size_t)n, &keys[1]));
   PCGX_TRY(ar.alloc_n((size_t)n, &vals[0]));
@@ -379,7 +398,7 @@ extern "C" pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int3
   hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(256), 0, st, (const uint8_t *)d_data, n, stride, xyz_off,
                      vp, keys[0], a_orig, cid_orig, vals[0], d_err);
   int res = 0;
-  PCGX_TRY(radix_sort_pairs(keys, vals, n, bits_for(vp.n_voxels), ws, &res, st));
+  PCGX_TRY(radix_sort_pairs(keys, vals, n, key_bits, ws, &res, st));
   const uint32_t *sa = keys[res], *sc = nullptr, *sidx = vals[res];
   if (two_level) {
     // second stable sort, by chunk id: (cid, a) order with input order kept inside a cell

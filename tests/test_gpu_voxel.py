@@ -156,3 +156,16 @@ def test_c3_scale_properties():
     exp = O.voxel_filter(sub, len(sub), 12, 0, c["leaf"])
     got = voxelgrid.New(c["leaf"]).Filter(sub)
     assert np.array_equal(got.Data, exp)
+
+
+def test_chunked_two_sort_path_still_matches(monkeypatch):
+    """Chunked mode normally sorts ONE combined (chunk id, cell) key; grids whose two indices do not
+    fit 32 bits fall back to two stable sorts.  Force that path and compare both with the oracle."""
+    pts = synth.uniform_cloud(60000, 3.0, 77) - f32(0.7)
+    leaf, chunk = (0.05, 0.04, 0.06), (7, 5, 9)
+    exp = O.voxel_filter(pts, len(pts), 12, 0, leaf, chunk)
+    got = voxelgrid.New(leaf, voxelgrid.WithChunkSize(chunk)).Filter(pts)
+    assert np.array_equal(got.Data, exp)
+    monkeypatch.setenv("PCGX_VOXEL_TWO_SORTS", "1")
+    got2 = voxelgrid.New(leaf, voxelgrid.WithChunkSize(chunk)).Filter(pts)
+    assert np.array_equal(got2.Data, exp)
