@@ -268,16 +268,43 @@ __device__ __forceinline__ void mm_take(float &m, int32_t &im, float v, int32_t 
   }
 }
 
-__global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__restrict__ data, int64_t n,
-                                                             int32_t stride, int32_t off,
-                                                             MinMaxAcc *__restrict__ partials) {
+// wave shuffle -> LDS -> one partial per workgroup
+__device__ __forceinline__ void minmax_block_fold(MinMaxAcc &a, MinMaxAcc *__restrict__ partials) {
   __shared__ MinMaxAcc s_acc[4];
-  MinMaxAcc a;
+  for (int o = 32; o > 0; o >>= 1) {
+    for (int k = 0; k < 3; k++) {
+      float v = __shfl_down(a.mn[k], o); int32_t iv = __shfl_down(a.imn[k], o);
+      mm_take(a.mn[k], a.imn[k], v, iv, true);
+      v = __shfl_down(a.mx[k], o); iv = __shfl_down(a.imx[k], o);
+      mm_take(a.mx[k], a.imx[k], v, iv, false);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_acc[wave] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++)
+      for (int k = 0; k < 3; k++) {
+        mm_take(a.mn[k], a.imn[k], s_acc[w].mn[k], s_acc[w].imn[k], true);
+        mm_take(a.mx[k], a.imx[k], s_acc[w].mx[k], s_acc[w].imx[k], false);
+      }
+    partials[blockIdx.x] = a;
+  }
+}
+
+__device__ __forceinline__ void minmax_init(MinMaxAcc &a) {
   const float qnan = __uint_as_float(0x7fc00000u);
   for (int k = 0; k < 3; k++) {
     a.mn[k] = qnan; a.mx[k] = qnan;
     a.imn[k] = 0x7fffffff; a.imx[k] = 0x7fffffff;
   }
+}
+
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__restrict__ data, int64_t n,
+                                                             int32_t stride, int32_t off,
+                                                             MinMaxAcc *__restrict__ partials) {
+  MinMaxAcc a;
+  minmax_init(a);
   // four independent loads in flight per thread; indices still increase per thread
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * step) {
@@ -298,25 +325,49 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__re
         }
     }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    for (int k = 0; k < 3; k++) {
-      float v = __shfl_down(a.mn[k], o); int32_t iv = __shfl_down(a.imn[k], o);
-      mm_take(a.mn[k], a.imn[k], v, iv, true);
-      v = __shfl_down(a.mx[k], o); iv = __shfl_down(a.imx[k], o);
-      mm_take(a.mx[k], a.imx[k], v, iv, false);
+  minmax_block_fold(a, partials);
+}
+
+// Packed xyz clouds (stride 12, offset 0, 16-byte aligned base): a thread takes 4 consecutive
+// points = three 16-byte loads, two such groups in flight.  Same (value, index) rule, so the
+// same result as the general kernel.
+__global__ __launch_bounds__(256) void minmax_partial_packed_kernel(const float4 *__restrict__ data, int64_t n,
+                                                                    MinMaxAcc *__restrict__ partials) {
+  MinMaxAcc a;
+  minmax_init(a);
+  const int64_t groups = n >> 2;  // whole groups of 4 points; the tail is handled by one thread below
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < groups; g0 += 2 * step) {
+    float4 r[2][3];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int64_t g = g0 + u * step < groups ? g0 + u * step : g0;
+      r[u][0] = data[3 * g]; r[u][1] = data[3 * g + 1]; r[u][2] = data[3 * g + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int64_t g = g0 + u * step;
+      if (g < groups) {
+        const float f[12] = {r[u][0].x, r[u][0].y, r[u][0].z, r[u][0].w, r[u][1].x, r[u][1].y,
+                             r[u][1].z, r[u][1].w, r[u][2].x, r[u][2].y, r[u][2].z, r[u][2].w};
+#pragma unroll
+        for (int p = 0; p < 4; p++)
+          for (int k = 0; k < 3; k++) {
+            mm_take(a.mn[k], a.imn[k], f[3 * p + k], (int32_t)(4 * g + p), true);
+            mm_take(a.mx[k], a.imx[k], f[3 * p + k], (int32_t)(4 * g + p), false);
+          }
+      }
     }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) s_acc[wave] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; w++)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // up to 3 points behind the last whole group
+    const float *f = reinterpret_cast<const float *>(data);
+    for (int64_t i = groups << 2; i < n; i++)
       for (int k = 0; k < 3; k++) {
-        mm_take(a.mn[k], a.imn[k], s_acc[w].mn[k], s_acc[w].imn[k], true);
-        mm_take(a.mx[k], a.imx[k], s_acc[w].mx[k], s_acc[w].imx[k], false);
+        mm_take(a.mn[k], a.imn[k], f[3 * i + k], (int32_t)i, true);
+        mm_take(a.mx[k], a.imx[k], f[3 * i + k], (int32_t)i, false);
       }
-    partials[blockIdx.x] = a;
   }
+  minmax_block_fold(a, partials);
 }
 
 // out6 = {min xyz, max xyz}; one block folds the per-block partials.
@@ -367,8 +418,12 @@ pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t
   if (blocks < 1) blocks = 1;
   MinMaxAcc *partials = nullptr;
   PCGX_TRY(ctx().arena.alloc_n(blocks, &partials));
-  hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t *)d_data, n,
-                     stride, off, partials);
+  if (stride == 12 && off == 0 && (reinterpret_cast<uintptr_t>(d_data) & 15) == 0)
+    hipLaunchKernelGGL(minmax_partial_packed_kernel, dim3(blocks), dim3(256), 0, st, (const float4 *)d_data, n,
+                       partials);
+  else
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t *)d_data, n,
+                       stride, off, partials);
   hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, st, partials, blocks,
                      (const uint8_t *)d_data, off, d_out6);
   PCGX_HIP_TRY(hipGetLastError());
