@@ -407,6 +407,7 @@ extern "C" pcgx_status pcgx_icp_session_read_sums_n(pcgx_icp_session *s, double 
 
 extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   if (!s) return PCGX_OK;
+  if (s->base) const_cast<pcgx_kdtree *>(s->base)->sessions.fetch_sub(1);
   if (s->d_xyz) (void)hipFree(s->d_xyz);
   if (s->d_state) (void)hipFree(s->d_state);
   if (s->d_partials) (void)hipFree(s->d_partials);
@@ -438,6 +439,7 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
     return fail(PCGX_E_NOT_ENOUGH_PAIRS, "not enough correspondence pairs (every base point was deleted)");
   pcgx_icp_session *s = new pcgx_icp_session();
   s->base = base;
+  const_cast<pcgx_kdtree *>(base)->sessions.fetch_add(1);  // keeps a rebuilt tree alive (resolve_tree)
   s->nt = nt;
   s->plane = normals != nullptr;
   s->kp = make_kernel_params(params);

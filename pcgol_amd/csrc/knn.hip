@@ -419,7 +419,14 @@ pcgx_status resolve_tree(const pcgx_kdtree *tc, const pcgx_kdtree **active, bool
       PCGX_TRY(build_tree(xyz.data(), n_live, 12, 0, labels.data(), &nt));
       for (auto &id : nt->inorder) id = labels[(size_t)id];  // in-order sequence in original ids
     }
+    // drop the replaced tree and earlier retired ones unless a session still walks them
     if (t->live) t->retired.push_back(t->live);
+    std::vector<pcgx_kdtree *> keep;
+    for (pcgx_kdtree *r : t->retired) {
+      if (r->sessions.load() == 0) pcgx_kdtree_free(r);
+      else keep.push_back(r);
+    }
+    t->retired.swap(keep);
     t->live = nt;
     t->dirty = false;
   }

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -181,12 +182,14 @@ struct pcgx_kdtree {
   // KDTree.DeletePoint (kdtree.go:322-332).  The implicit layout cannot express the reference's
   // patched tree, so deletions are recorded here and the next query rebuilds a tree over the
   // remaining points whose nodes keep the ORIGINAL ids (`live`; nullptr while nothing is left).
-  // Trees replaced by a later rebuild are retired, not freed: sessions may still reference them.
+  // A tree replaced by a later rebuild is freed at once unless ICP sessions still run on it
+  // (`sessions`); those are retired and freed by a later rebuild or with the handle.
   std::vector<uint8_t> deleted;    // [n] once the first point was deleted
   int64_t n_deleted = 0;
   bool dirty = false;              // deletions since `live` was built
   pcgx_kdtree *live = nullptr;
   std::vector<pcgx_kdtree *> retired;
+  std::atomic<int> sessions{0};    // open pcgx_icp_session objects that walk THIS tree object
   std::mutex mu;
   pcgx::TreeView view() const {
     pcgx::TreeView v;

@@ -98,3 +98,31 @@ def test_delete_then_icp_uses_remaining_points():
     assert ev.NumPairs == oe["npairs"]
     assert abs(float(ev.Value) - float(oe["value"])) <= 1e-6 * float(oe["value"])
     assert np.allclose(ev.Gradient, oe["gradient"], rtol=1e-5, atol=1e-8)
+
+
+def test_many_delete_query_cycles_with_an_open_session():
+    """Every cycle rebuilds the tree of the remaining points; replaced trees are freed unless an ICP
+    session still walks them (it keeps answering on the tree it was created on)."""
+    n = 40000
+    pts = synth.uniform_cloud(n, 5.0, 91)
+    q = synth.uniform_cloud(500, 5.0, 92)
+    t, o = kdtree.New(pts), O.KDTree(pts)
+    t.DeletePoints(np.arange(0, 100))
+    for i in range(100):
+        o.delete_point(i)
+    sess = icp.IcpSession(t, q, 1.0, 6)  # on the tree without points 0..99
+    sess.partials()
+    sums_before = sess.read_sums()
+    rng = np.random.default_rng(5)
+    for cycle in range(25):
+        gone = rng.choice(n, 200, replace=False)
+        t.DeletePoints(gone)
+        for i in gone:
+            o.delete_point(int(i))
+        ids, dsq = t.NearestBatch(q, 1.0)
+        oi, od = o.nearest_batch(q, 1.0)
+        assert np.array_equal(ids, oi) and np.array_equal(dsq, od), cycle
+    sess.set_pose(np.eye(4, dtype=f32).reshape(-1), 0)
+    sess.partials()
+    assert np.array_equal(sess.read_sums(), sums_before)  # the session's tree is untouched
+    sess.close()
