@@ -22,6 +22,11 @@ pcgx_status fail(pcgx_status code, const char *fmt, ...) {
   return code;
 }
 
+std::recursive_mutex &api_mutex() {
+  static std::recursive_mutex m;
+  return m;
+}
+
 Context &ctx() {
   static Context c;
   return c;
@@ -162,6 +167,7 @@ using namespace pcgx;
 extern "C" pcgx_status pcgx_init(int32_t device) { return init_device(device); }
 
 extern "C" pcgx_status pcgx_shutdown(void) {
+  PCGX_API_LOCK();
   std::lock_guard<std::mutex> lk(g_init_mu);
   Context &c = ctx();
   if (!c.ready) return PCGX_OK;
@@ -188,12 +194,14 @@ extern "C" int32_t pcgx_last_error(char *buf, size_t cap) {
 extern "C" const char *pcgx_version(void) { return "pcgx 0.1 (gfx950)"; }
 
 extern "C" pcgx_status pcgx_sync(void *stream) {
+  PCGX_API_LOCK();
   PCGX_TRY(ensure_init());
   PCGX_HIP_TRY(hipStreamSynchronize(pick_stream(stream)));
   return PCGX_OK;
 }
 
 extern "C" pcgx_status pcgx_prof_enable(int32_t on) {
+  PCGX_API_LOCK();
   PCGX_TRY(ensure_init());
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
@@ -201,6 +209,7 @@ extern "C" pcgx_status pcgx_prof_enable(int32_t on) {
 }
 
 extern "C" pcgx_status pcgx_prof_read(int32_t kind, double *total_ms, int64_t *launches) {
+  PCGX_API_LOCK();
   if (kind < 0 || kind >= PCGX_PROF_KINDS || !total_ms || !launches)
     return fail(PCGX_E_INVALID, "pcgx_prof_read: bad argument");
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -211,6 +220,7 @@ extern "C" pcgx_status pcgx_prof_read(int32_t kind, double *total_ms, int64_t *l
 }
 
 extern "C" pcgx_status pcgx_prof_reset(void) {
+  PCGX_API_LOCK();
   std::lock_guard<std::mutex> lk(g_prof_mu);
   prof_resolve();
   for (int k = 0; k < PCGX_PROF_KINDS; k++) { g_prof_ms[k] = 0.0; g_prof_n[k] = 0; }
@@ -218,6 +228,7 @@ extern "C" pcgx_status pcgx_prof_reset(void) {
 }
 
 extern "C" pcgx_status pcgx_dev_alloc(size_t bytes, void **dptr) {
+  PCGX_API_LOCK();
   if (!dptr) return fail(PCGX_E_INVALID, "pcgx_dev_alloc: dptr is NULL");
   PCGX_TRY(ensure_init());
   hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
@@ -226,17 +237,20 @@ extern "C" pcgx_status pcgx_dev_alloc(size_t bytes, void **dptr) {
 }
 
 extern "C" pcgx_status pcgx_dev_free(void *dptr) {
+  PCGX_API_LOCK();
   if (dptr) PCGX_HIP_TRY(hipFree(dptr));
   return PCGX_OK;
 }
 
 extern "C" pcgx_status pcgx_dev_upload(void *dptr, const void *host, size_t bytes) {
+  PCGX_API_LOCK();
   PCGX_TRY(ensure_init());
   if (bytes) PCGX_HIP_TRY(hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
   return PCGX_OK;
 }
 
 extern "C" pcgx_status pcgx_dev_download(void *host, const void *dptr, size_t bytes) {
+  PCGX_API_LOCK();
   PCGX_TRY(ensure_init());
   if (bytes) PCGX_HIP_TRY(hipMemcpy(host, dptr, bytes, hipMemcpyDeviceToHost));
   return PCGX_OK;
@@ -245,6 +259,7 @@ extern "C" pcgx_status pcgx_dev_download(void *host, const void *dptr, size_t by
 // ---- host-only math exports (no GPU needed) ---------------------------------
 
 extern "C" pcgx_status pcgx_rodrigues(const float v[3], float out16[16]) {
+  PCGX_API_LOCK();
   if (!v || !out16) return fail(PCGX_E_INVALID, "pcgx_rodrigues: NULL argument");
   Mat4 r = rodrigues_to_rotation(v[0], v[1], v[2]);
   memcpy(out16, r.m, sizeof r.m);
@@ -252,6 +267,7 @@ extern "C" pcgx_status pcgx_rodrigues(const float v[3], float out16[16]) {
 }
 
 extern "C" pcgx_status pcgx_mat4_mul(const float m[16], const float a[16], float out16[16]) {
+  PCGX_API_LOCK();
   if (!m || !a || !out16) return fail(PCGX_E_INVALID, "pcgx_mat4_mul: NULL argument");
   Mat4 x, y;
   memcpy(x.m, m, sizeof x.m);
@@ -263,6 +279,7 @@ extern "C" pcgx_status pcgx_mat4_mul(const float m[16], const float a[16], float
 
 extern "C" pcgx_status pcgx_mat4_transform(const float m[16], const float *xyz, int64_t n,
                                            float *out_xyz) {
+  PCGX_API_LOCK();
   if (!m || n < 0 || (n > 0 && (!xyz || !out_xyz))) return fail(PCGX_E_INVALID, "pcgx_mat4_transform: bad argument");
   for (int64_t i = 0; i < n; i++) {
     float x, y, z;
@@ -276,6 +293,7 @@ extern "C" pcgx_status pcgx_mat4_transform(const float m[16], const float *xyz, 
 
 extern "C" pcgx_status pcgx_icp_finish_evaluate(const double sums10[10], int32_t min_pairs,
                                                 pcgx_icp_evaluated *out) {
+  PCGX_API_LOCK();
   if (!sums10 || !out) return fail(PCGX_E_INVALID, "pcgx_icp_finish_evaluate: NULL argument");
   if (min_pairs == 0) min_pairs = 6;  // evaluator.go:92-95
   const int64_t npairs = (int64_t)sums10[S_PAIRS];
@@ -292,6 +310,7 @@ extern "C" pcgx_status pcgx_icp_finish_evaluate(const double sums10[10], int32_t
 
 extern "C" pcgx_status pcgx_icp_plane_finish_evaluate(const double sums30[30], int32_t min_pairs,
                                                       pcgx_icp_evaluated *out, float hessian36[36]) {
+  PCGX_API_LOCK();
   if (!sums30 || !out || !hessian36) return fail(PCGX_E_INVALID, "pcgx_icp_plane_finish_evaluate: NULL argument");
   if (min_pairs == 0) min_pairs = 6;
   const int64_t npairs = (int64_t)sums30[P_PAIRS];
@@ -310,6 +329,7 @@ extern "C" pcgx_status pcgx_icp_plane_finish_evaluate(const double sums30[30], i
 extern "C" pcgx_status pcgx_icp_gauss_newton_update(const pcgx_icp_params *p, float damping, int32_t *iter,
                                                     const float gradient[6], const float hessian36[36],
                                                     float trans16[16], int32_t *converged) {
+  PCGX_API_LOCK();
   if (!p || !iter || !gradient || !hessian36 || !trans16 || !converged)
     return fail(PCGX_E_INVALID, "pcgx_icp_gauss_newton_update: NULL argument");
   GaussNewtonParams u = resolve_gauss_newton(p->threshold, damping, p->max_iteration);
@@ -328,6 +348,7 @@ extern "C" pcgx_status pcgx_icp_gauss_newton_update(const pcgx_icp_params *p, fl
 
 extern "C" pcgx_status pcgx_icp_update(const pcgx_icp_params *p, int32_t *iter, const float gradient[6],
                                        float trans16[16], int32_t *converged) {
+  PCGX_API_LOCK();
   if (!p || !iter || !gradient || !trans16 || !converged)
     return fail(PCGX_E_INVALID, "pcgx_icp_update: NULL argument");
   UpdaterParams u = resolve_updater(p->weight, p->threshold, p->max_iteration);

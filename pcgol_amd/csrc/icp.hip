@@ -365,12 +365,14 @@ static pcgx_status reset_state(pcgx_icp_session *s, hipStream_t st) {
 }
 
 extern "C" pcgx_status pcgx_icp_session_reset(pcgx_icp_session *s, void *stream) {
+  PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_reset: NULL session");
   return reset_state(s, pick_stream(stream));
 }
 
 extern "C" pcgx_status pcgx_icp_session_set_pose(pcgx_icp_session *s, const float trans16[16],
                                                  int32_t iter, void *stream) {
+  PCGX_API_LOCK();
   if (!s || !trans16 || iter < 0) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_pose: bad argument");
   hipStream_t st = pick_stream(stream);
   IcpState h;
@@ -383,6 +385,7 @@ extern "C" pcgx_status pcgx_icp_session_set_pose(pcgx_icp_session *s, const floa
 }
 
 extern "C" pcgx_status pcgx_icp_session_read_sums(pcgx_icp_session *s, double sums10[10], void *stream) {
+  PCGX_API_LOCK();
   if (!s || !sums10) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums: bad argument");
   if (s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums: plane session (30 sums): use pcgx_icp_session_read_sums_n");
   hipStream_t st = pick_stream(stream);
@@ -392,12 +395,14 @@ extern "C" pcgx_status pcgx_icp_session_read_sums(pcgx_icp_session *s, double su
 }
 
 extern "C" pcgx_status pcgx_icp_session_sums_count(const pcgx_icp_session *s, int32_t *count) {
+  PCGX_API_LOCK();
   if (!s || !count) return fail(PCGX_E_INVALID, "pcgx_icp_session_sums_count: bad argument");
   *count = s->n_sums();
   return PCGX_OK;
 }
 
 extern "C" pcgx_status pcgx_icp_session_read_sums_n(pcgx_icp_session *s, double *sums, int32_t cap, void *stream) {
+  PCGX_API_LOCK();
   if (!s || !sums || cap < s->n_sums()) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums_n: bad argument");
   hipStream_t st = pick_stream(stream);
   PCGX_HIP_TRY(hipMemcpyAsync(sums, s->d_sums, (size_t)s->n_sums() * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -406,6 +411,7 @@ extern "C" pcgx_status pcgx_icp_session_read_sums_n(pcgx_icp_session *s, double 
 }
 
 extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
+  PCGX_API_LOCK();
   if (!s) return PCGX_OK;
   if (s->base) const_cast<pcgx_kdtree *>(s->base)->sessions.fetch_sub(1);
   if (s->d_xyz) (void)hipFree(s->d_xyz);
@@ -519,6 +525,7 @@ extern "C" pcgx_status pcgx_icp_session_create(const pcgx_kdtree *base, const fl
                                                int64_t nt, int32_t target_on_device,
                                                const pcgx_icp_params *params, double *d_sums10,
                                                pcgx_icp_session **out) {
+  PCGX_API_LOCK();
   return session_create(base, nullptr, 0.0f, target, nt, target_on_device, params, d_sums10, out);
 }
 
@@ -526,6 +533,7 @@ extern "C" pcgx_status pcgx_icp_plane_session_create(const pcgx_kdtree *base, co
                                                      const float *target, int64_t nt, int32_t on_device,
                                                      const pcgx_icp_params *params, float damping,
                                                      double *d_sums30, pcgx_icp_session **out) {
+  PCGX_API_LOCK();
   if (!base_normals) return fail(PCGX_E_INVALID, "pcgx_icp_plane_session_create: base_normals is NULL");
   if (params && params->min_dist_sq > 0.0f)
     return fail(PCGX_E_INVALID, "pcgx_icp_plane_session_create: MinDistSq > 0 (approximate search) is not offered here");
@@ -568,6 +576,7 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
 }
 
 extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stream) {
+  PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_partials: NULL session");
   hipStream_t st = pick_stream(stream);
   PCGX_TRY(enqueue_corr(s, st));
@@ -582,6 +591,7 @@ extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stre
 }
 
 extern "C" pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream) {
+  PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_update: NULL session");
   hipStream_t st = pick_stream(stream);
   if (s->plane)
@@ -594,6 +604,7 @@ extern "C" pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream
 
 // partials + update with no exchange in between (single GPU): two launches per iteration.
 extern "C" pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream) {
+  PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_step: NULL session");
   hipStream_t st = pick_stream(stream);
   PCGX_TRY(enqueue_corr(s, st));
@@ -609,6 +620,7 @@ extern "C" pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream) 
 
 extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream, float trans16[16],
                                                pcgx_icp_stat *stat, int32_t *converged) {
+  PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_result: NULL session");
   hipStream_t st = pick_stream(stream);
   IcpState h;
@@ -632,6 +644,7 @@ extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream
 }
 
 extern "C" pcgx_status pcgx_icp_session_hessian(pcgx_icp_session *s, void *stream, float hessian36[36]) {
+  PCGX_API_LOCK();
   if (!s || !hessian36) return fail(PCGX_E_INVALID, "pcgx_icp_session_hessian: bad argument");
   if (!s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_hessian: not a plane session (HasHessian() == false)");
   hipStream_t st = pick_stream(stream);
@@ -645,6 +658,7 @@ extern "C" pcgx_status pcgx_icp_session_hessian(pcgx_icp_session *s, void *strea
 extern "C" pcgx_status pcgx_icp_plane_fit(const pcgx_kdtree *base, const float *base_normals, const float *target,
                                           int64_t nt, const pcgx_icp_params *params, float damping,
                                           float trans16[16], pcgx_icp_stat *stat, float hessian36[36]) {
+  PCGX_API_LOCK();
   if (!base || !params || !trans16) return fail(PCGX_E_INVALID, "pcgx_icp_plane_fit: NULL argument");
   pcgx_icp_session *s = nullptr;
   PCGX_TRY(pcgx_icp_plane_session_create(base, base_normals, target, nt, 0, params, damping, nullptr, &s));
@@ -659,6 +673,7 @@ extern "C" pcgx_status pcgx_icp_plane_fit(const pcgx_kdtree *base, const float *
 extern "C" pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target, int64_t nt,
                                     const pcgx_icp_params *params, float trans16[16],
                                     pcgx_icp_stat *stat) {
+  PCGX_API_LOCK();
   if (!base || !params || !trans16) return fail(PCGX_E_INVALID, "pcgx_icp_fit: NULL argument");
   pcgx_icp_session *s = nullptr;
   PCGX_TRY(pcgx_icp_session_create(base, target, nt, 0, params, nullptr, &s));
@@ -674,6 +689,7 @@ extern "C" pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target
 extern "C" pcgx_status pcgx_icp_evaluate(const pcgx_kdtree *base, const float *target, int64_t nt,
                                          float max_dist, float min_dist_sq, int32_t min_pairs,
                                          pcgx_icp_evaluated *out) {
+  PCGX_API_LOCK();
   if (!base || !out) return fail(PCGX_E_INVALID, "pcgx_icp_evaluate: NULL argument");
   pcgx_icp_params p;
   memset(&p, 0, sizeof p);
@@ -697,6 +713,7 @@ extern "C" pcgx_status pcgx_icp_evaluate(const pcgx_kdtree *base, const float *t
 extern "C" pcgx_status pcgx_icp_pairs(const pcgx_kdtree *base, const float *target, int64_t nt,
                                       float max_dist, float min_dist_sq, int64_t *base_id,
                                       int64_t *target_id, float *dist_sq, int64_t *npairs) {
+  PCGX_API_LOCK();
   if (!base || !npairs || nt < 0 || (nt > 0 && (!target || !base_id || !target_id || !dist_sq)))
     return fail(PCGX_E_INVALID, "pcgx_icp_pairs: bad argument");
   *npairs = 0;

@@ -359,10 +359,12 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
 
 extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t stride,
                                          int32_t xyz_off, pcgx_kdtree **out) {
+  PCGX_API_LOCK();
   return build_tree(data, n, stride, xyz_off, nullptr, out);
 }
 
 extern "C" pcgx_status pcgx_kdtree_free(pcgx_kdtree *t) {
+  PCGX_API_LOCK();
   if (!t) return PCGX_OK;
   if (t->live) pcgx_kdtree_free(t->live);
   for (pcgx_kdtree *r : t->retired) pcgx_kdtree_free(r);
@@ -377,6 +379,7 @@ extern "C" pcgx_status pcgx_kdtree_free(pcgx_kdtree *t) {
 // reference (kdtree_test.go "TwiceTheSamePoint").  The tree over the remaining points is rebuilt
 // lazily by the next query (resolve_tree).
 extern "C" pcgx_status pcgx_kdtree_delete_points(pcgx_kdtree *t, const int64_t *ids, int64_t m) {
+  PCGX_API_LOCK();
   if (!t || m < 0 || (m > 0 && !ids)) return fail(PCGX_E_INVALID, "pcgx_kdtree_delete_points: bad argument");
   for (int64_t i = 0; i < m; i++)
     if (ids[i] < 0 || ids[i] > t->n - 1)
@@ -393,6 +396,7 @@ extern "C" pcgx_status pcgx_kdtree_delete_points(pcgx_kdtree *t, const int64_t *
 }
 
 extern "C" pcgx_status pcgx_kdtree_live_count(const pcgx_kdtree *t, int64_t *n_live) {
+  PCGX_API_LOCK();
   if (!t || !n_live) return fail(PCGX_E_INVALID, "pcgx_kdtree_live_count: NULL argument");
   *n_live = t->n - t->n_deleted;
   return PCGX_OK;
@@ -436,12 +440,14 @@ pcgx_status resolve_tree(const pcgx_kdtree *tc, const pcgx_kdtree **active, bool
 }
 
 extern "C" pcgx_status pcgx_kdtree_len(const pcgx_kdtree *t, int64_t *n) {
+  PCGX_API_LOCK();
   if (!t || !n) return fail(PCGX_E_INVALID, "pcgx_kdtree_len: NULL argument");
   *n = t->n;
   return PCGX_OK;
 }
 
 extern "C" pcgx_status pcgx_kdtree_max_depth(const pcgx_kdtree *t, int32_t *depth) {
+  PCGX_API_LOCK();
   if (!t || !depth) return fail(PCGX_E_INVALID, "pcgx_kdtree_max_depth: NULL argument");
   const pcgx_kdtree *a = nullptr;
   bool empty = false;
@@ -451,6 +457,7 @@ extern "C" pcgx_status pcgx_kdtree_max_depth(const pcgx_kdtree *t, int32_t *dept
 }
 
 extern "C" pcgx_status pcgx_kdtree_inorder(const pcgx_kdtree *t, int64_t *ids) {
+  PCGX_API_LOCK();
   if (!t || !ids) return fail(PCGX_E_INVALID, "pcgx_kdtree_inorder: NULL argument");
   const pcgx_kdtree *a = nullptr;
   bool empty = false;
@@ -462,6 +469,7 @@ extern "C" pcgx_status pcgx_kdtree_inorder(const pcgx_kdtree *t, int64_t *ids) {
 
 extern "C" pcgx_status pcgx_kdtree_points(const pcgx_kdtree *t, const int64_t *ids, int64_t m,
                                           float *xyz) {
+  PCGX_API_LOCK();
   if (!t || (m > 0 && (!ids || !xyz))) return fail(PCGX_E_INVALID, "pcgx_kdtree_points: NULL argument");
   for (int64_t i = 0; i < m; i++) {
     if (ids[i] < 0 || ids[i] >= t->n) return fail(PCGX_E_INVALID, "pcgx_kdtree_points: id %lld out of range", (long long)ids[i]);
@@ -475,6 +483,7 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch_dev(const pcgx_kdtree *t, const
                                                      float min_dist_sq, uint32_t flags,
                                                      int32_t *d_ids, float *d_dist_sq,
                                                      void *stream) {
+  PCGX_API_LOCK();
   if (!t || nq < 0 || (nq > 0 && (!d_q || !d_ids || !d_dist_sq)))
     return fail(PCGX_E_INVALID, "pcgx_kdtree_nearest_batch_dev: bad argument");
   PCGX_TRY(ensure_init());
@@ -502,6 +511,7 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch_dev(const pcgx_kdtree *t, const
 extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const float *q, int64_t nq,
                                                  float max_range, float min_dist_sq, int64_t *ids,
                                                  float *dist_sq) {
+  PCGX_API_LOCK();
   if (!t || nq < 0 || (nq > 0 && (!q || !ids || !dist_sq)))
     return fail(PCGX_E_INVALID, "pcgx_kdtree_nearest_batch: bad argument");
   if (nq == 0) return PCGX_OK;
@@ -530,6 +540,7 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const flo
 extern "C" pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
                                              int32_t presort, const float *d_hint_xyz, uint32_t *d_leaf_io,
                                              uint64_t stats32[32]) {
+  PCGX_API_LOCK();
   if (!t || !d_q || !stats32 || nq <= 0) return fail(PCGX_E_INVALID, "pcgx_debug_walk_stats: bad argument");
   PCGX_TRY(ensure_init());
   hipStream_t st = ctx().stream;

@@ -225,6 +225,7 @@ static pcgx_status parse_ascii(const uint8_t *file, size_t len, const pcgx_pcd_h
 using namespace pcgx;
 
 extern "C" pcgx_status pcgx_pcd_unmarshal_header(const void *file, size_t len, pcgx_pcd_header *h) {
+  PCGX_API_LOCK();
   if (!h || (len > 0 && !file)) return fail(PCGX_E_INVALID, "pcgx_pcd_unmarshal_header: NULL argument");
   memset(h, 0, sizeof *h);
   const uint8_t *buf = (const uint8_t *)file;
@@ -302,6 +303,7 @@ extern "C" pcgx_status pcgx_pcd_unmarshal_header(const void *file, size_t len, p
 }
 
 extern "C" pcgx_status pcgx_pcd_unmarshal(const void *file, size_t len, const pcgx_pcd_header *h, void *out_data) {
+  PCGX_API_LOCK();
   if (!h || (len > 0 && !file)) return fail(PCGX_E_INVALID, "pcgx_pcd_unmarshal: NULL argument");
   const int64_t total = h->points * h->stride;
   if (total > 0 && !out_data) return fail(PCGX_E_INVALID, "pcgx_pcd_unmarshal: out_data is NULL");
@@ -327,6 +329,7 @@ extern "C" pcgx_status pcgx_pcd_unmarshal(const void *file, size_t len, const pc
 
 extern "C" pcgx_status pcgx_pcd_unmarshal_dev(const void *file, size_t len, const pcgx_pcd_header *h, void *d_out,
                                               void *stream) {
+  PCGX_API_LOCK();
   if (!h || (len > 0 && !file)) return fail(PCGX_E_INVALID, "pcgx_pcd_unmarshal_dev: NULL argument");
   const int64_t total = h->points * h->stride;
   if (total > 0 && !d_out) return fail(PCGX_E_INVALID, "pcgx_pcd_unmarshal_dev: d_out is NULL");
@@ -367,6 +370,7 @@ extern "C" pcgx_status pcgx_pcd_unmarshal_dev(const void *file, size_t len, cons
 
 extern "C" pcgx_status pcgx_pcd_marshal(const pcgx_pcd_header *h, const void *data, void *out, size_t cap,
                                         size_t *out_len) {
+  PCGX_API_LOCK();
   if (!h || !out_len) return fail(PCGX_E_INVALID, "pcgx_pcd_marshal: NULL argument");
   const int64_t total = h->points * h->stride;
   if (total > 0 && !data) return fail(PCGX_E_INVALID, "pcgx_pcd_marshal: data is NULL");

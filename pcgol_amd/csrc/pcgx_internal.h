@@ -81,6 +81,11 @@ struct Context {
 };
 Context &ctx();
 pcgx_status ensure_init();
+// One lock around every entry point that touches the context (arenas, library stream, handles'
+// lazily rebuilt trees): callers such as a Go program may enter from several OS threads at once.
+// Recursive: the host-pointer entry points call the device-resident ones.
+std::recursive_mutex &api_mutex();
+#define PCGX_API_LOCK() std::lock_guard<std::recursive_mutex> pcgx_api_lock__(::pcgx::api_mutex())
 inline hipStream_t pick_stream(void *s) { return s ? (hipStream_t)s : ctx().stream; }
 
 // ---- KD-tree ---------------------------------------------------------------

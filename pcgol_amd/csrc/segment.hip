@@ -286,6 +286,7 @@ static int bits_for_count(int64_t count) {
 extern "C" pcgx_status pcgx_bucket_grid_build(const void *data, int64_t n, int32_t stride, int32_t xyz_off,
                                               float resolution, const int64_t size[3], const float origin[3],
                                               pcgx_bucket_grid **out) {
+  PCGX_API_LOCK();
   if (!out) return fail(PCGX_E_INVALID, "pcgx_bucket_grid_build: out is NULL");
   *out = nullptr;
   if (n < 0 || !size || !origin || (n > 0 && !data)) return fail(PCGX_E_INVALID, "pcgx_bucket_grid_build: bad argument");
@@ -368,6 +369,7 @@ extern "C" pcgx_status pcgx_bucket_grid_build(const void *data, int64_t n, int32
 }
 
 extern "C" pcgx_status pcgx_bucket_grid_free(pcgx_bucket_grid *g) {
+  PCGX_API_LOCK();
   delete g;
   return PCGX_OK;
 }
@@ -375,6 +377,7 @@ extern "C" pcgx_status pcgx_bucket_grid_free(pcgx_bucket_grid *g) {
 // {Len() = voxels of the grid (voxelgrid.go:110-112), points accepted by Add, occupied voxels}
 extern "C" pcgx_status pcgx_bucket_grid_counts(const pcgx_bucket_grid *g, int64_t *len, int64_t *n_added,
                                                int64_t *n_occupied) {
+  PCGX_API_LOCK();
   if (!g) return fail(PCGX_E_INVALID, "pcgx_bucket_grid_counts: NULL grid");
   if (len) *len = g->gp.len;
   if (n_added) *n_added = g->n_in;
@@ -397,6 +400,7 @@ static bool grid_addr_host(const GridParams &gp, const float p[3], int64_t *addr
 }
 
 extern "C" pcgx_status pcgx_bucket_grid_addr(const pcgx_bucket_grid *g, const float p[3], int64_t *addr, int32_t *ok) {
+  PCGX_API_LOCK();
   if (!g || !p || !addr || !ok) return fail(PCGX_E_INVALID, "pcgx_bucket_grid_addr: NULL argument");
   int64_t xyz[3];
   *addr = 0;
@@ -406,6 +410,7 @@ extern "C" pcgx_status pcgx_bucket_grid_addr(const pcgx_bucket_grid *g, const fl
 
 // addr of every offered point, -1 where Add returned false (voxelgrid.go:37-41)
 extern "C" pcgx_status pcgx_bucket_grid_point_addrs(const pcgx_bucket_grid *g, int64_t *addrs) {
+  PCGX_API_LOCK();
   if (!g || (g->n > 0 && !addrs)) return fail(PCGX_E_INVALID, "pcgx_bucket_grid_point_addrs: NULL argument");
   for (int64_t i = 0; i < g->n; i++)
     addrs[i] = g->point_key[(size_t)i] == (uint32_t)g->gp.len ? -1 : (int64_t)g->point_key[(size_t)i];
@@ -421,6 +426,7 @@ static int64_t find_cell(const pcgx_bucket_grid *g, int64_t addr) {
 // GetByAddr (voxelgrid.go:60-62): *count = bucket length; the first min(count, cap) ids are written
 extern "C" pcgx_status pcgx_bucket_grid_get_by_addr(const pcgx_bucket_grid *g, int64_t addr, int64_t *out, int64_t cap,
                                                     int64_t *count) {
+  PCGX_API_LOCK();
   if (!g || !count || cap < 0 || (cap > 0 && !out)) return fail(PCGX_E_INVALID, "pcgx_bucket_grid_get_by_addr: bad argument");
   if (addr < 0 || addr >= g->gp.len)
     return fail(PCGX_E_OUT_OF_RANGE, "voxel address %lld outside the grid (the reference panics: index out of range)", (long long)addr);
@@ -436,6 +442,7 @@ extern "C" pcgx_status pcgx_bucket_grid_get_by_addr(const pcgx_bucket_grid *g, i
 // Get (voxelgrid.go:52-58): *count = -1 for nil (p outside the grid)
 extern "C" pcgx_status pcgx_bucket_grid_get(const pcgx_bucket_grid *g, const float p[3], int64_t *out, int64_t cap,
                                             int64_t *count) {
+  PCGX_API_LOCK();
   if (!g || !p || !count) return fail(PCGX_E_INVALID, "pcgx_bucket_grid_get: NULL argument");
   int64_t addr, xyz[3];
   if (!grid_addr_host(g->gp, p, &addr, xyz)) {
@@ -447,6 +454,7 @@ extern "C" pcgx_status pcgx_bucket_grid_get(const pcgx_bucket_grid *g, const flo
 
 // Indice (voxelgrid.go:114-120): all ids, voxels ascending, insertion order inside a voxel
 extern "C" pcgx_status pcgx_bucket_grid_indice(const pcgx_bucket_grid *g, int64_t *out) {
+  PCGX_API_LOCK();
   if (!g || (g->n_in > 0 && !out)) return fail(PCGX_E_INVALID, "pcgx_bucket_grid_indice: NULL argument");
   for (int64_t k = 0; k < g->n_in; k++) out[k] = g->idx_sorted[(size_t)k];
   return PCGX_OK;
@@ -485,6 +493,7 @@ static pcgx_status ensure_components(pcgx_bucket_grid *g) {
 // set of occupied voxels its voxel belongs to; -1 for points outside the grid.  Segment(p) for
 // every seed at once.
 extern "C" pcgx_status pcgx_bucket_grid_components(pcgx_bucket_grid *g, int64_t *point_comp) {
+  PCGX_API_LOCK();
   if (!g || (g->n > 0 && !point_comp)) return fail(PCGX_E_INVALID, "pcgx_bucket_grid_components: NULL argument");
   PCGX_TRY(ensure_components(g));
   for (int64_t i = 0; i < g->n; i++) point_comp[i] = -1;
@@ -498,6 +507,7 @@ extern "C" pcgx_status pcgx_bucket_grid_components(pcgx_bucket_grid *g, int64_t 
 // voxel is empty.  *count = result length; the first min(count, cap) ids are written.
 extern "C" pcgx_status pcgx_bucket_grid_segment(pcgx_bucket_grid *g, const float p[3], int64_t *out, int64_t cap,
                                                 int64_t *count) {
+  PCGX_API_LOCK();
   if (!g || !p || !count || cap < 0 || (cap > 0 && !out)) return fail(PCGX_E_INVALID, "pcgx_bucket_grid_segment: bad argument");
   *count = 0;
   int64_t addr, xyz[3];
@@ -523,6 +533,7 @@ extern "C" pcgx_status pcgx_bucket_grid_segment(pcgx_bucket_grid *g, const float
 // i's property value.  labels: Uint32At(id) for id in [0, Len()).
 extern "C" pcgx_status pcgx_region_growing_components(const pcgx_kdtree *t, const uint32_t *labels, float max_range,
                                                       int64_t *comp) {
+  PCGX_API_LOCK();
   if (!t || !labels || !comp) return fail(PCGX_E_INVALID, "pcgx_region_growing_components: NULL argument");
   PCGX_TRY(ensure_init());
   const int64_t n = t->n;  // ids of the accessor, also after DeletePoint
@@ -562,6 +573,7 @@ extern "C" pcgx_status pcgx_region_growing_components(const pcgx_kdtree *t, cons
 extern "C" pcgx_status pcgx_region_growing_segment(const pcgx_kdtree *t, const uint32_t *labels, const int64_t *comp,
                                                    const float p[3], float max_range, int64_t *out, int64_t cap,
                                                    int64_t *count) {
+  PCGX_API_LOCK();
   if (!t || !labels || !comp || !p || !count || cap < 0 || (cap > 0 && !out))
     return fail(PCGX_E_INVALID, "pcgx_region_growing_segment: bad argument");
   *count = 0;
