@@ -112,3 +112,28 @@ def test_edge_cases_of_the_next_rows():
     t.DeletePoint(0)  # twice: no-op
     with pytest.raises(IndexError):
         t.DeletePoint(1)
+
+
+def test_concurrent_callers_are_serialised():
+    """Several host threads (as goroutines would) issue batches on one tree at once."""
+    import threading
+    base = synth.uniform_cloud(50000, 5.0, 31)
+    t = kdtree.New(base)
+    qs = [synth.uniform_cloud(4000, 5.0, 40 + k) for k in range(6)]
+    exp = [O.KDTree(base).nearest_batch(q, 1.0) for q in qs[:2]]
+    out = [None] * len(qs)
+
+    def work(k):
+        for _ in range(5):
+            out[k] = t.NearestBatch(qs[k], 1.0)
+            voxelgrid.New((0.2, 0.2, 0.2)).Filter(qs[k])
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(qs))]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for k in range(2):
+        assert np.array_equal(out[k][0], exp[k][0]) and np.array_equal(out[k][1], exp[k][1])
+    single = [t.NearestBatch(q, 1.0) for q in qs]
+    for k in range(len(qs)):
+        assert np.array_equal(out[k][0], single[k][0]) and np.array_equal(out[k][1], single[k][1])
