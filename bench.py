@@ -99,7 +99,7 @@ def cpu_baseline(synth, base, target, cfg, budget_s=25.0):
             "seconds": dt}
 
 
-def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits):
+def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, icp):
     """kNN (C2) and VoxelGrid (C3) throughput with inputs resident in HBM; reported as extras."""
     out = {}
     dev = "cuda"
@@ -153,6 +153,22 @@ def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits):
                            "exchange_doubles": 30, "parity": "none in the reference (extension)"}
     picp.close()
     del ptree
+    # STRICT sums (sequential float32 in target order: bit-identical to the Go code at any size)
+    c4 = synth.c4_icp()
+    ss = icp.IcpSession(tree, c4["target"], c4["max_dist"], c4["min_pairs"], c4["weight"], c4["threshold"],
+                        c4["max_iteration"])
+    ss.set_strict(True)
+    for _ in range(3):
+        ss.step(stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ss.step(stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    out["icp_strict_c4"] = {"mpoints_per_s": len(c4["target"]) / dt / 1e6, "ms_per_step": dt * 1e3,
+                            "note": "one wave adds the evaluator's float32 terms sequentially (reference bits)"}
+    ss.close()
     c3 = synth.c3_voxel()
     dp = torch.from_numpy(c3["points"]).to(dev)
     dout = torch.empty_like(dp)
@@ -291,7 +307,7 @@ def main():
             "final_value": float(stat.Evaluated.Value),
         }
         if world == 1 and not args.no_extras:
-            line["extra"] = side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits)
+            line["extra"] = side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, icp)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(synth, base, tile, cfg)
             line["cpu_baseline"]["host_cpus"] = os.cpu_count()

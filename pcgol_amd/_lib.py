@@ -161,6 +161,7 @@ SIGNATURES = {
     "pcgx_icp_session_partials": (_i32, [_vp, _vp]),
     "pcgx_icp_session_update": (_i32, [_vp, _vp]),
     "pcgx_icp_session_step": (_i32, [_vp, _vp]),
+    "pcgx_icp_session_set_strict": (_i32, [_vp, _i32]),
     "pcgx_icp_session_result": (_i32, [_vp, _vp, _vp, C.POINTER(IcpStat), C.POINTER(_i32)]),
     "pcgx_bucket_grid_build": (_i32, [_vp, _i64, _i32, _i32, _f32, _vp, _vp, C.POINTER(_vp)]),
     "pcgx_bucket_grid_free": (_i32, [_vp]),

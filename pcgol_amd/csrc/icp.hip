@@ -299,13 +299,119 @@ __global__ __launch_bounds__(256) void pack_normals_kernel(const float *__restri
   if (i < n) out[i] = make_float4(n3[3 * i], n3[3 * i + 1], n3[3 * i + 2], 0.0f);
 }
 
+// STRICT mode: the evaluator's sums exactly as the reference forms them -- sequential float32
+// additions over the pairs in target order (evaluator.go:122-145; Go evaluates them one pair after
+// the other in a single goroutine).  A parallel reduction cannot reproduce those bits (float
+// addition is not associative; at 1M pairs the reference's own rounding noise is ~1.6e-5 on the
+// final transform), so: (1) icp_strict_terms_kernel forms the nine float32 terms of every target
+// in parallel and stores them in the CALLER's target order (through pos_of), one row per
+// component, plus a valid bit per target; (2) icp_strict_sums_kernel is ONE wave whose lane k
+// streams row k and adds its terms one after the other (next block's 16-byte loads in flight
+// while the dependent chain of 64 additions runs).  Milliseconds per iteration at 1M pairs
+// against 0.07 ms for the float64 tree, hence opt-in (pcgx_icp_session_set_strict /
+// PCGX_ICP_STRICT=1): bit-identical Evaluated and pose at any size.
+__global__ __launch_bounds__(256) void icp_strict_terms_kernel(const float *__restrict__ tx, const float *__restrict__ ty,
+                                                               const float *__restrict__ tz, int64_t nt, int64_t nt_pad,
+                                                               const float4 *__restrict__ match,
+                                                               const uint32_t *__restrict__ pos_of,
+                                                               const IcpState *__restrict__ state,
+                                                               float *__restrict__ terms,
+                                                               unsigned long long *__restrict__ valid_bits) {
+  if (state->done) return;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // grid covers nt_pad (a multiple of 64)
+  float m[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) m[k] = state->trans[k];
+  const bool project = state->iter > 0;  // icp.go:27-30: the first Evaluate sees the raw target
+  bool valid = false;
+  // unmatched targets and the padding behind nt carry -0.0f: x + (-0.0f) == x for EVERY float x
+  // (including both zeros), so the sequential sum needs no branch or select for them
+  float t[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) t[k] = -0.0f;
+  if (i < nt) {
+    const uint32_t pos = pos_of[i];
+    const float4 bp = match[pos];
+    if (bp.w >= 0.0f) {  // correspondence.go:27-29
+      valid = true;
+      float x0 = tx[pos], y0 = ty[pos], z0 = tz[pos];
+      if (project) {
+        float px, py, pz;
+        mat4_transform(m, x0, y0, z0, px, py, pz);
+        x0 = px; y0 = py; z0 = pz;
+      }
+      const float x1 = bp.x, y1 = bp.y, z1 = bp.z, w = 1.0f;  // evaluator.go:21-23,130
+      t[0] = w * bp.w;
+      t[1] = w * (x0 - x1);
+      t[2] = w * (y0 - y1);
+      t[3] = w * (z0 - z1);
+      t[4] = w * (z0 * y1 - y0 * z1);
+      t[5] = w * (x0 * z1 - z0 * x1);
+      t[6] = w * (y0 * x1 - x0 * y1);
+      t[7] = w * norm_sq3(x0, y0, z0);
+      t[8] = w;
+    }
+  }
+  if (i < nt_pad) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) terms[(int64_t)k * nt_pad + i] = t[k];
+  }
+  const unsigned long long bal = __ballot(valid);
+  if ((threadIdx.x & 63) == 0 && i < nt_pad) valid_bits[i >> 6] = bal;
+}
+
+// kFuseUpdate: thread 0 then runs the evaluate tail + pose update (single GPU).
+template <bool kFuseUpdate>
+__global__ __launch_bounds__(64) void icp_strict_sums_kernel(const float *__restrict__ terms,
+                                                             const unsigned long long *__restrict__ valid_bits,
+                                                             int64_t nt_pad, IcpState *__restrict__ state,
+                                                             double *__restrict__ sums10, IcpKernelParams kp) {
+  __shared__ double s_sums[S_COUNT];
+  if (state->done) return;
+  const int lane = threadIdx.x;
+  const int64_t nblk = nt_pad >> 6;
+  float acc = 0.0f;   // lanes 0..8: Value, G0..G5, DistRMS, sum of weights (float32, sequential)
+  int64_t pairs = 0;  // lane 9
+  if (lane < 9 && nblk > 0) {
+    const float4 *row = reinterpret_cast<const float4 *>(terms + (int64_t)lane * nt_pad);
+    float4 cur[16], nxt[16];
+#pragma unroll
+    for (int v = 0; v < 16; v++) cur[v] = row[v];
+    for (int64_t blk = 0; blk < nblk; blk++) {
+      const int64_t nb = blk + 1 < nblk ? blk + 1 : blk;
+#pragma unroll
+      for (int v = 0; v < 16; v++) nxt[v] = row[nb * 16 + v];  // in flight during the chain below
+#pragma unroll
+      for (int v = 0; v < 16; v++) acc = (((acc + cur[v].x) + cur[v].y) + cur[v].z) + cur[v].w;
+#pragma unroll
+      for (int v = 0; v < 16; v++) cur[v] = nxt[v];
+    }
+  } else if (lane == 9) {
+    for (int64_t blk = 0; blk < nblk; blk++) pairs += (int64_t)__popcll(valid_bits[blk]);
+  }
+  // component order of sums10: Value, G0..G5, DistRMS, Weight, Pairs
+  if (lane < 9) {
+    const int slot = lane == 0 ? S_VALUE : (lane <= 6 ? S_G0 + lane - 1 : (lane == 7 ? S_DIST_RMS : S_WEIGHT));
+    sums10[slot] = (double)acc;
+    s_sums[slot] = (double)acc;
+  } else if (lane == 9) {
+    sums10[S_PAIRS] = (double)pairs;
+    s_sums[S_PAIRS] = (double)pairs;
+  }
+  if (kFuseUpdate) {
+    __syncthreads();
+    if (lane == 0) icp_update_step(state, s_sums, kp);
+  }
+}
+
 __global__ __launch_bounds__(256) void gather_soa_kernel(const float *__restrict__ q,
                                                          const int32_t *__restrict__ perm, int64_t n,
                                                          float *__restrict__ x, float *__restrict__ y,
-                                                         float *__restrict__ z) {
+                                                         float *__restrict__ z, uint32_t *__restrict__ pos_of) {
   const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (pos >= n) return;
   const int64_t i = perm ? (int64_t)perm[pos] : pos;
+  pos_of[i] = (uint32_t)pos;  // where the caller's target i sits in the session's (Morton) order
   x[pos] = q[3 * i];
   y[pos] = q[3 * i + 1];
   z[pos] = q[3 * i + 2];
@@ -321,6 +427,11 @@ struct pcgx_icp_session {
   float *d_xyz = nullptr;  // SoA: x[nt] | y[nt] | z[nt], Morton order of the original target
   IcpState *d_state = nullptr;
   double *d_partials = nullptr;
+  uint32_t *d_pos_of = nullptr;  // [nt] position of the caller's target i in the session's order
+  bool strict = false;           // sequential float32 sums (icp_strict_*_kernel)
+  float *d_terms = nullptr;      // strict: [9][nt_pad] float32 terms in the caller's target order
+  unsigned long long *d_valid = nullptr;  // strict: [nt_pad / 64] matched-target bits
+  int64_t nt_pad = 0;
   float4 *d_match = nullptr;       // [nt] matched base point + DistSq per target
   uint32_t *d_first_leaf = nullptr;  // [nt] leaf the target's first descent ended in (0: unknown)
   double *d_sums = nullptr;  // caller's buffer, or own
@@ -394,6 +505,14 @@ extern "C" pcgx_status pcgx_icp_session_read_sums(pcgx_icp_session *s, double su
   return PCGX_OK;
 }
 
+extern "C" pcgx_status pcgx_icp_session_set_strict(pcgx_icp_session *s, int32_t on) {
+  PCGX_API_LOCK();
+  if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_strict: NULL session");
+  if (on && s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_strict: point-to-plane sessions have no reference sums to reproduce");
+  s->strict = on != 0;
+  return PCGX_OK;
+}
+
 extern "C" pcgx_status pcgx_icp_session_sums_count(const pcgx_icp_session *s, int32_t *count) {
   PCGX_API_LOCK();
   if (!s || !count) return fail(PCGX_E_INVALID, "pcgx_icp_session_sums_count: bad argument");
@@ -417,6 +536,9 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   if (s->d_xyz) (void)hipFree(s->d_xyz);
   if (s->d_state) (void)hipFree(s->d_state);
   if (s->d_partials) (void)hipFree(s->d_partials);
+  if (s->d_pos_of) (void)hipFree(s->d_pos_of);
+  if (s->d_terms) (void)hipFree(s->d_terms);
+  if (s->d_valid) (void)hipFree(s->d_valid);
   if (s->d_match) (void)hipFree(s->d_match);
   if (s->d_first_leaf) (void)hipFree(s->d_first_leaf);
   if (s->d_match_id) (void)hipFree(s->d_match_id);
@@ -448,6 +570,7 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
   const_cast<pcgx_kdtree *>(base)->sessions.fetch_add(1);  // keeps a rebuilt tree alive (resolve_tree)
   s->nt = nt;
   s->plane = normals != nullptr;
+  if (const char *e = getenv("PCGX_ICP_STRICT")) s->strict = !s->plane && e[0] == '1';
   s->kp = make_kernel_params(params);
   s->kp.gn.damping = damping;
   s->max_iteration = s->kp.upd.max_iteration;
@@ -461,6 +584,7 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
   if ((e = hipMalloc((void **)&s->d_xyz, (size_t)(nt ? nt : 1) * 12)) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_state, sizeof(IcpState))) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_partials, (size_t)s->grid * s->n_sums() * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc((void **)&s->d_pos_of, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_match, (size_t)(nt ? nt : 1) * sizeof(float4))) != hipSuccess ||
       (e = hipMalloc((void **)&s->d_first_leaf, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess)
     return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
@@ -513,7 +637,7 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
       if ((rc = morton_order(d_q, nt, base->bbox_lo, base->bbox_hi, perm, st)) != PCGX_OK) return bail(rc);
     }
     hipLaunchKernelGGL(gather_soa_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d_q, perm, nt,
-                       s->d_xyz, s->d_xyz + nt, s->d_xyz + 2 * nt);
+                       s->d_xyz, s->d_xyz + nt, s->d_xyz + 2 * nt, s->d_pos_of);
     if ((e = hipStreamSynchronize(st)) != hipSuccess)
       return bail(fail(PCGX_E_HIP, "icp session setup failed: %s", hipGetErrorString(e)));
   }
@@ -575,12 +699,31 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   return PCGX_OK;
 }
 
+template <bool kFuseUpdate>
+static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
+  if (!s->d_terms) {  // first strict launch of the session
+    s->nt_pad = (s->nt + 63) & ~(int64_t)63;
+    const size_t np = (size_t)(s->nt_pad ? s->nt_pad : 64);
+    PCGX_HIP_TRY(hipMalloc((void **)&s->d_terms, 9 * np * sizeof(float)));
+    PCGX_HIP_TRY(hipMalloc((void **)&s->d_valid, (np / 64) * sizeof(unsigned long long)));
+  }
+  if (s->nt_pad > 0)
+    hipLaunchKernelGGL(icp_strict_terms_kernel, dim3((unsigned)(s->nt_pad / 256 + 1)), dim3(256), 0, st, s->d_xyz,
+                       s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, s->nt, s->nt_pad, (const float4 *)s->d_match,
+                       (const uint32_t *)s->d_pos_of, (const IcpState *)s->d_state, s->d_terms, s->d_valid);
+  hipLaunchKernelGGL(icp_strict_sums_kernel<kFuseUpdate>, dim3(1), dim3(64), 0, st, (const float *)s->d_terms,
+                     (const unsigned long long *)s->d_valid, s->nt_pad, s->d_state, s->d_sums, s->kp);
+  return PCGX_OK;
+}
+
 extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stream) {
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_partials: NULL session");
   hipStream_t st = pick_stream(stream);
   PCGX_TRY(enqueue_corr(s, st));
-  if (s->plane)
+  if (s->strict)
+    PCGX_TRY(enqueue_strict<false>(s, st));
+  else if (s->plane)
     hipLaunchKernelGGL((icp_final_reduce_kernel<false, true>), dim3(1), dim3(1024), 0, st, s->d_partials, s->grid,
                        s->d_state, s->d_sums, s->kp);
   else
@@ -608,7 +751,9 @@ extern "C" pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream) 
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_step: NULL session");
   hipStream_t st = pick_stream(stream);
   PCGX_TRY(enqueue_corr(s, st));
-  if (s->plane)
+  if (s->strict)
+    PCGX_TRY(enqueue_strict<true>(s, st));
+  else if (s->plane)
     hipLaunchKernelGGL((icp_final_reduce_kernel<true, true>), dim3(1), dim3(1024), 0, st, s->d_partials, s->grid,
                        s->d_state, s->d_sums, s->kp);
   else

@@ -203,6 +203,11 @@ class IcpSession:
         t = L.f32c(trans)
         L.check(L.lib().pcgx_icp_session_set_pose(self._h, L.ptr(t), int(it), L.ptr(stream) if stream else None))
 
+    def set_strict(self, on=True):
+        """Sequential float32 sums in target order, as the Go code adds them: bit-identical
+        Evaluated / pose at any size (slow: one wave).  See include/pcgx.h."""
+        L.check(L.lib().pcgx_icp_session_set_strict(self._h, 1 if on else 0))
+
     def read_sums(self, stream=0):
         out = np.empty(self.n_sums, np.float64)
         L.check(L.lib().pcgx_icp_session_read_sums_n(self._h, L.ptr(out), self.n_sums,

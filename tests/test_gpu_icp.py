@@ -230,3 +230,76 @@ def test_hinted_walk_exact_ties():
     ev = icp.FinishEvaluate(hinted, MinPairs=6)
     assert abs(float(ev.Value) - float(o["value"])) <= 2e-7 * max(1.0, abs(float(o["value"])))
     assert np.max(np.abs(ev.Gradient - o["gradient"])) <= 1e-6
+
+
+def test_c4_full_size_vs_oracle():
+    """BASELINE config C4 at full size (1M x 1M, 20 iterations): pairs of the first evaluation
+    identical to the oracle's; the Fit's transform within 1e-6 of the oracle run with float64 sums
+    (same algorithm, different association) and within the stated 1e-5 of the oracle run with the
+    reference's sequential float32 sums (whose own rounding noise grows with the pair count)."""
+    c = synth.c4_icp()
+    t = kdtree.New(c["base"])
+    o = O.KDTree(c["base"])
+    b, tid, d = icp.NearestPointCorresponder(MaxDist=c["max_dist"]).PairsArrays(t, c["target"])
+    ob, ot, od = O.icp_pairs(o, c["target"], c["max_dist"])
+    assert np.array_equal(b, ob) and np.array_equal(tid, ot) and np.array_equal(d, od)
+    reg = icp.PointToPointICPGradient(
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=c["min_pairs"]),
+        icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=c["threshold"], MaxIteration=c["max_iteration"]))
+    trans, stat = reg.Fit(t, c["target"])
+    o64 = O.icp_fit(o, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"],
+                    sums_mode=1)
+    assert stat.NumIteration == o64["num_iteration"] == 20
+    assert np.max(np.abs(trans - o64["trans"])) <= 1e-6
+    # the reference's sequential float32 sums carry their own rounding noise at this size (measured
+    # 1.6e-5 on the translation); test_strict_mode_c4_full_size reproduces them bit for bit
+    o32 = O.icp_fit(o, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"],
+                    sums_mode=0)
+    assert np.max(np.abs(trans - o32["trans"])) <= 3e-5
+
+
+@pytest.mark.parametrize("n,max_dist", [(5000, 0.5), (20003, 0.03), (200000, 0.5)])
+def test_strict_mode_is_bit_identical_to_the_reference_sums(n, max_dist):
+    """STRICT sums (one wave, sequential float32 in target order, evaluator.go:122-145): Evaluated
+    and every pose of the Fit loop equal the oracle's Go-semantics run bit for bit -- also when
+    many targets find no partner (max_dist 0.03) and the count is no multiple of 64."""
+    c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
+    c["max_dist"] = max_dist
+    if max_dist < 0.1:  # targets that never find a partner, scattered through the target order
+        far = c["target"][::37] + f32(50.0)
+        c["target"] = np.ascontiguousarray(np.insert(c["target"], np.arange(0, len(far)) * 30, far, axis=0))
+    t, o = kdtree.New(c["base"]), O.KDTree(c["base"])
+    s = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+    s.set_strict(True)
+    trans = O.translate(0, 0, 0)
+    it = 0
+    tt = c["target"].copy()
+    for k in range(c["max_iteration"]):
+        s.step()
+        tr, st, conv = s.result()
+        oe = O.icp_evaluate(o, tt, c["max_dist"], c["min_pairs"], sums_mode=0)
+        assert st.Evaluated.Value == oe["value"] and st.Evaluated.DistRMS == oe["dist_rms"], k
+        assert np.array_equal(st.Evaluated.Gradient, oe["gradient"]), k
+        trans, oconv, it = O.icp_update(trans, oe["gradient"], it, c["weight"], c["threshold"], c["max_iteration"])
+        assert np.array_equal(tr, trans) and conv == oconv, k
+        tt = O.mat4_transform(trans, c["target"]) if n <= 5000 else synth.transform_points(trans, c["target"])
+    assert 6 <= st.Evaluated.NumPairs <= len(c["target"]) and (max_dist > 0.1 or st.Evaluated.NumPairs < len(c["target"]))
+    s.close()
+
+
+def test_strict_mode_c4_full_size():
+    """C4 at full size: with strict sums the Fit equals the reference-semantics oracle bit for bit
+    (the default float64 sums differ from it by the reference's own rounding noise, 1.6e-5)."""
+    c = synth.c4_icp()
+    t = kdtree.New(c["base"])
+    s = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+    s.set_strict(True)
+    for _ in range(c["max_iteration"]):
+        s.step()
+    tr, st, conv = s.result()
+    s.close()
+    o32 = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
+                    c["max_iteration"], sums_mode=0)
+    assert conv and st.NumIteration == o32["num_iteration"] == 20
+    assert np.array_equal(tr, o32["trans"])
+    assert st.Evaluated.Value == o32["value"] and np.array_equal(st.Evaluated.Gradient, o32["gradient"])
