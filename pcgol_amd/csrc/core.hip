@@ -27,6 +27,66 @@ std::recursive_mutex &api_mutex() {
   return m;
 }
 
+namespace {
+struct CachedBlock {
+  void *p;
+  size_t cap;
+};
+std::vector<CachedBlock> &cache_free_list() {
+  static std::vector<CachedBlock> v;
+  return v;
+}
+std::vector<CachedBlock> &cache_live_list() {
+  static std::vector<CachedBlock> v;
+  return v;
+}
+constexpr size_t kCacheLimitBytes = (size_t)2 << 30;
+}  // namespace
+
+// callers hold the API lock
+hipError_t dev_cache_alloc(void **ptr, size_t bytes) {
+  bytes = bytes ? bytes : 1;
+  auto &fl = cache_free_list();
+  size_t best = fl.size();
+  for (size_t i = 0; i < fl.size(); i++)
+    if (fl[i].cap >= bytes && fl[i].cap <= 2 * bytes + 4096 && (best == fl.size() || fl[i].cap < fl[best].cap)) best = i;
+  if (best != fl.size()) {
+    *ptr = fl[best].p;
+    cache_live_list().push_back(fl[best]);
+    fl.erase(fl.begin() + (long)best);
+    return hipSuccess;
+  }
+  const size_t cap = (bytes + 255) & ~(size_t)255;
+  hipError_t e = hipMalloc(ptr, cap);
+  if (e != hipSuccess) {  // make room and try once more
+    dev_cache_release_all();
+    e = hipMalloc(ptr, cap);
+  }
+  if (e == hipSuccess) cache_live_list().push_back(CachedBlock{*ptr, cap});
+  return e;
+}
+
+void dev_cache_free(void *ptr) {
+  if (!ptr) return;
+  auto &ll = cache_live_list();
+  for (size_t i = 0; i < ll.size(); i++)
+    if (ll[i].p == ptr) {
+      auto &fl = cache_free_list();
+      size_t held = 0;
+      for (auto &b : fl) held += b.cap;
+      if (held + ll[i].cap <= kCacheLimitBytes) fl.push_back(ll[i]);
+      else (void)hipFree(ptr);
+      ll.erase(ll.begin() + (long)i);
+      return;
+    }
+  (void)hipFree(ptr);  // not one of ours
+}
+
+void dev_cache_release_all() {
+  for (auto &b : cache_free_list()) (void)hipFree(b.p);
+  cache_free_list().clear();
+}
+
 Context &ctx() {
   static Context c;
   return c;
@@ -174,6 +234,7 @@ extern "C" pcgx_status pcgx_shutdown(void) {
   (void)hipDeviceSynchronize();
   c.arena.release_all();
   c.host_arena.release_all();
+  dev_cache_release_all();
   (void)hipStreamDestroy(c.stream);
   c.stream = nullptr;
   c.ready = false;

@@ -533,17 +533,20 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   PCGX_API_LOCK();
   if (!s) return PCGX_OK;
   if (s->base) const_cast<pcgx_kdtree *>(s->base)->sessions.fetch_sub(1);
-  if (s->d_xyz) (void)hipFree(s->d_xyz);
-  if (s->d_state) (void)hipFree(s->d_state);
-  if (s->d_partials) (void)hipFree(s->d_partials);
-  if (s->d_pos_of) (void)hipFree(s->d_pos_of);
-  if (s->d_terms) (void)hipFree(s->d_terms);
-  if (s->d_valid) (void)hipFree(s->d_valid);
-  if (s->d_match) (void)hipFree(s->d_match);
-  if (s->d_first_leaf) (void)hipFree(s->d_first_leaf);
-  if (s->d_match_id) (void)hipFree(s->d_match_id);
-  if (s->d_normals) (void)hipFree(s->d_normals);
-  if (s->own_sums && s->d_sums) (void)hipFree(s->d_sums);
+  // the buffers go back to the block cache and may be handed out again at once: work the caller
+  // enqueued on its own streams must have finished with them (hipFree synchronised, too)
+  (void)hipDeviceSynchronize();
+  dev_cache_free(s->d_xyz);
+  dev_cache_free(s->d_state);
+  dev_cache_free(s->d_partials);
+  dev_cache_free(s->d_pos_of);
+  dev_cache_free(s->d_terms);
+  dev_cache_free(s->d_valid);
+  dev_cache_free(s->d_match);
+  dev_cache_free(s->d_first_leaf);
+  dev_cache_free(s->d_match_id);
+  dev_cache_free(s->d_normals);
+  if (s->own_sums) dev_cache_free(s->d_sums);
   delete s;
   return PCGX_OK;
 }
@@ -581,24 +584,24 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
     return code;
   };
   hipError_t e;
-  if ((e = hipMalloc((void **)&s->d_xyz, (size_t)(nt ? nt : 1) * 12)) != hipSuccess ||
-      (e = hipMalloc((void **)&s->d_state, sizeof(IcpState))) != hipSuccess ||
-      (e = hipMalloc((void **)&s->d_partials, (size_t)s->grid * s->n_sums() * sizeof(double))) != hipSuccess ||
-      (e = hipMalloc((void **)&s->d_pos_of, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
-      (e = hipMalloc((void **)&s->d_match, (size_t)(nt ? nt : 1) * sizeof(float4))) != hipSuccess ||
-      (e = hipMalloc((void **)&s->d_first_leaf, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess)
+  if ((e = dev_cache_alloc((void **)&s->d_xyz, (size_t)(nt ? nt : 1) * 12)) != hipSuccess ||
+      (e = dev_cache_alloc((void **)&s->d_state, sizeof(IcpState))) != hipSuccess ||
+      (e = dev_cache_alloc((void **)&s->d_partials, (size_t)s->grid * s->n_sums() * sizeof(double))) != hipSuccess ||
+      (e = dev_cache_alloc((void **)&s->d_pos_of, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
+      (e = dev_cache_alloc((void **)&s->d_match, (size_t)(nt ? nt : 1) * sizeof(float4))) != hipSuccess ||
+      (e = dev_cache_alloc((void **)&s->d_first_leaf, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess)
     return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
   if (d_sums) {
     s->d_sums = d_sums;
   } else {
-    if ((e = hipMalloc((void **)&s->d_sums, (size_t)s->n_sums() * sizeof(double))) != hipSuccess)
+    if ((e = dev_cache_alloc((void **)&s->d_sums, (size_t)s->n_sums() * sizeof(double))) != hipSuccess)
       return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
     s->own_sums = true;
   }
   if (s->plane) {
     const int64_t nb = n_base_ids;
-    if ((e = hipMalloc((void **)&s->d_match_id, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
-        (e = hipMalloc((void **)&s->d_normals, (size_t)nb * sizeof(float4))) != hipSuccess)
+    if ((e = dev_cache_alloc((void **)&s->d_match_id, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
+        (e = dev_cache_alloc((void **)&s->d_normals, (size_t)nb * sizeof(float4))) != hipSuccess)
       return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
     Arena &ar = ctx().arena;
     if ((rc = ar.begin(st)) != PCGX_OK) return bail(rc);
@@ -704,8 +707,8 @@ static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
   if (!s->d_terms) {  // first strict launch of the session
     s->nt_pad = (s->nt + 63) & ~(int64_t)63;
     const size_t np = (size_t)(s->nt_pad ? s->nt_pad : 64);
-    PCGX_HIP_TRY(hipMalloc((void **)&s->d_terms, 9 * np * sizeof(float)));
-    PCGX_HIP_TRY(hipMalloc((void **)&s->d_valid, (np / 64) * sizeof(unsigned long long)));
+    PCGX_HIP_TRY(dev_cache_alloc((void **)&s->d_terms, 9 * np * sizeof(float)));
+    PCGX_HIP_TRY(dev_cache_alloc((void **)&s->d_valid, (np / 64) * sizeof(unsigned long long)));
   }
   if (s->nt_pad > 0)
     hipLaunchKernelGGL(icp_strict_terms_kernel, dim3((unsigned)(s->nt_pad / 256 + 1)), dim3(256), 0, st, s->d_xyz,

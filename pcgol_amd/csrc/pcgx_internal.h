@@ -60,6 +60,16 @@ class Arena {
   bool has_last_ = false;
 };
 
+// ---- cached device blocks -----------------------------------------------------
+// Short-lived objects with device state (ICP sessions: the reference's own Fit loop calls
+// Evaluate once per iteration, i.e. one session per iteration through the Go shim) take their
+// buffers from a small cache of blocks instead of hipMalloc / hipFree, which cost more than the
+// whole evaluation at 1M points.  A freed block is kept for reuse (first fit among blocks at most
+// twice the requested size); the cache holds at most 2 GiB, anything beyond is hipFree'd.
+hipError_t dev_cache_alloc(void **ptr, size_t bytes);
+void dev_cache_free(void *ptr);
+void dev_cache_release_all();
+
 // ---- kernel timing (pcgx_prof_*) ---------------------------------------------
 struct ProfScope {
   ProfScope(int kind, hipStream_t st);
