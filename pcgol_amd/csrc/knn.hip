@@ -269,7 +269,7 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
   }
   t->inorder.resize((size_t)n);
   const size_t slots = (size_t)1 << t->depth;
-  hipError_t e = hipMalloc((void **)&t->d_nodes, slots * sizeof(float4));
+  hipError_t e = dev_cache_alloc((void **)&t->d_nodes, slots * sizeof(float4));
   if (e != hipSuccess) {
     delete t;
     return fail(PCGX_E_OOM, "hipMalloc for %lld tree nodes failed: %s", (long long)n, hipGetErrorString(e));
@@ -304,7 +304,7 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
       if (e != hipSuccess) rc = fail(PCGX_E_HIP, "tree build failed: %s", hipGetErrorString(e));
     }
     if (rc != PCGX_OK) {
-      (void)hipFree(t->d_nodes);
+      dev_cache_free(t->d_nodes);
       delete t;
       return rc;
     }
@@ -314,7 +314,7 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
     fill_bfs(*t, labels, nodes, 1, 0, n);
     e = hipMemcpy(t->d_nodes, nodes.data(), slots * sizeof(float4), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
-      (void)hipFree(t->d_nodes);
+      dev_cache_free(t->d_nodes);
       delete t;
       return fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
     }
@@ -337,9 +337,9 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
       if (!(lo[k] == lo[k])) { t->dir_lo[k] = 0.0f; t->dir_scale[k] = 0.0f; }  // NaN coordinates
     }
     const size_t cells = (size_t)1 << (3 * g);
-    e = hipMalloc((void **)&t->d_dir, cells * sizeof(uint32_t));
+    e = dev_cache_alloc((void **)&t->d_dir, cells * sizeof(uint32_t));
     if (e != hipSuccess) {
-      (void)hipFree(t->d_nodes);
+      dev_cache_free(t->d_nodes);
       delete t;
       return fail(PCGX_E_OOM, "hipMalloc for the leaf directory (%zu cells) failed: %s", cells, hipGetErrorString(e));
     }
@@ -347,8 +347,8 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
                        t->view(), t->d_dir);
     e = hipStreamSynchronize(ctx().stream);
     if (e != hipSuccess) {
-      (void)hipFree(t->d_nodes);
-      (void)hipFree(t->d_dir);
+      dev_cache_free(t->d_nodes);
+      dev_cache_free(t->d_dir);
       delete t;
       return fail(PCGX_E_HIP, "leaf directory build failed: %s", hipGetErrorString(e));
     }
@@ -368,8 +368,8 @@ extern "C" pcgx_status pcgx_kdtree_free(pcgx_kdtree *t) {
   if (!t) return PCGX_OK;
   if (t->live) pcgx_kdtree_free(t->live);
   for (pcgx_kdtree *r : t->retired) pcgx_kdtree_free(r);
-  if (t->d_nodes) (void)hipFree(t->d_nodes);
-  if (t->d_dir) (void)hipFree(t->d_dir);
+  if (t->d_nodes) dev_cache_free(t->d_nodes);
+  if (t->d_dir) dev_cache_free(t->d_dir);
   delete t;
   return PCGX_OK;
 }
