@@ -474,14 +474,14 @@ func (g *BucketGrid) Get(p mat.Vec3) []int {
 	return idsToInt(ids[:int(cnt)])
 }
 
-// Segment is segmentation/voxelgrid.VoxelGrid.Segment (ids ascending by voxel, not in BFS order).
+// Segment is segmentation/voxelgrid.VoxelGrid.Segment, ids in the reference's own order.
 func (g *BucketGrid) Segment(p mat.Vec3) []int {
 	var cnt C.int64_t
-	if C.pcgx_bucket_grid_segment(g.h, (*C.float)(unsafe.Pointer(&p[0])), nil, 0, &cnt) != C.PCGX_OK || cnt <= 0 {
+	if C.pcgx_bucket_grid_segment_bfs(g.h, (*C.float)(unsafe.Pointer(&p[0])), nil, 0, &cnt) != C.PCGX_OK || cnt <= 0 {
 		return nil
 	}
 	ids := make([]int64, int(cnt))
-	C.pcgx_bucket_grid_segment(g.h, (*C.float)(unsafe.Pointer(&p[0])), (*C.int64_t)(unsafe.Pointer(&ids[0])), cnt, &cnt)
+	C.pcgx_bucket_grid_segment_bfs(g.h, (*C.float)(unsafe.Pointer(&p[0])), (*C.int64_t)(unsafe.Pointer(&ids[0])), cnt, &cnt)
 	return idsToInt(ids[:int(cnt)])
 }
 
@@ -503,8 +503,25 @@ func NewRegionGrowing(search *KDTree, propertyIter pc.Uint32RandomAccessor) *Reg
 	return &RegionGrowing{search: search, labels: labels}
 }
 
-// Segment mirrors RegionGrowing.Segment (ids ascending, not in BFS order).
+// Segment mirrors RegionGrowing.Segment, ids in the reference's own order.
 func (r *RegionGrowing) Segment(p mat.Vec3, maxRange float32) []int {
+	n := len(r.labels)
+	if n == 0 {
+		return []int{}
+	}
+	ids := make([]int64, n)
+	var cnt C.int64_t
+	if C.pcgx_region_growing_segment_bfs(r.search.h, (*C.uint32_t)(unsafe.Pointer(&r.labels[0])),
+		(*C.float)(unsafe.Pointer(&p[0])), C.float(maxRange), (*C.int64_t)(unsafe.Pointer(&ids[0])), C.int64_t(n),
+		&cnt) != C.PCGX_OK {
+		return []int{}
+	}
+	return idsToInt(ids[:int(cnt)])
+}
+
+// SegmentByID returns the same set in ascending id order from region labels of the whole cloud
+// (computed once per maxRange): the fast path for many seeds.
+func (r *RegionGrowing) SegmentByID(p mat.Vec3, maxRange float32) []int {
 	n := len(r.labels)
 	if n == 0 {
 		return []int{}

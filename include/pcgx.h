@@ -313,9 +313,9 @@ PCGX_API pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream,
  * fill, segmentation/voxelgrid/voxelgrid.go:39-73) and pc/segmentation/regiongrowing
  * .RegionGrowing.Segment (regiongrowing.go:23-56).  The device computes the buckets with one
  * stable sort and the connected components of the whole grid / cloud with a union-find; a seed
- * query is then a lookup.  Result ORDER differs from the reference's BFS discovery order (its
- * tests sort before comparing): ascending voxel address with insertion order inside a voxel,
- * resp. ascending point id. */
+ * query is then a lookup (ids ascending by voxel address / point id).  The *_bfs variants return
+ * the same set in the reference's own discovery order (its FIFO search replayed over the
+ * device-built buckets / device Range batches); the reference's tests sort before comparing. */
 typedef struct pcgx_bucket_grid pcgx_bucket_grid;
 /* New(resolution, size, origin) followed by Add(point i, i) for every record of the cloud
  * (voxelgrid.go:15-23,37-45); points outside the grid are not added. */
@@ -347,6 +347,11 @@ PCGX_API pcgx_status pcgx_bucket_grid_components(pcgx_bucket_grid *g, int64_t *p
 PCGX_API pcgx_status pcgx_bucket_grid_segment(pcgx_bucket_grid *g, const float p[3], int64_t *out, int64_t cap,
                                               int64_t *count);
 
+/* Segment(p) with the ids in the reference's own (FIFO flood-fill) order: the Go algorithm run on the
+ * host over the device-built buckets.  Same set as pcgx_bucket_grid_segment. */
+PCGX_API pcgx_status pcgx_bucket_grid_segment_bfs(pcgx_bucket_grid *g, const float p[3], int64_t *out, int64_t cap,
+                                                  int64_t *count);
+
 /* RegionGrowing (regiongrowing.go:18-56).  labels = the property accessor (Uint32At(id), id in
  * [0, Len())).  _components answers every seed at once for one max_range: comp[i] = smallest id of
  * the points reachable from i through steps with DistSq < max_range^2 between points of i's
@@ -356,6 +361,12 @@ PCGX_API pcgx_status pcgx_region_growing_components(const pcgx_kdtree *t, const 
 PCGX_API pcgx_status pcgx_region_growing_segment(const pcgx_kdtree *t, const uint32_t *labels, const int64_t *comp,
                                                  const float p[3], float max_range, int64_t *out, int64_t cap,
                                                  int64_t *count);
+
+/* Segment(p, maxRange) with the ids in the reference's own (FIFO) order: the Range() calls of one
+ * BFS level are one device batch, the queue logic runs on the host as in regiongrowing.go:33-54.
+ * Same set as pcgx_region_growing_segment; needs no components. */
+PCGX_API pcgx_status pcgx_region_growing_segment_bfs(const pcgx_kdtree *t, const uint32_t *labels, const float p[3],
+                                                     float max_range, int64_t *out, int64_t cap, int64_t *count);
 
 /* ---------------------------------------------------------------- PCD files
  * replaces pc.UnmarshalHeader / pc.Unmarshal / pc.Marshal (pc/io.go:24-45,47-230,232-285) with a

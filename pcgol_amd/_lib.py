@@ -173,12 +173,14 @@ SIGNATURES = {
     "pcgx_bucket_grid_indice": (_i32, [_vp, _vp]),
     "pcgx_bucket_grid_components": (_i32, [_vp, _vp]),
     "pcgx_bucket_grid_segment": (_i32, [_vp, _vp, _vp, _i64, C.POINTER(_i64)]),
+    "pcgx_bucket_grid_segment_bfs": (_i32, [_vp, _vp, _vp, _i64, C.POINTER(_i64)]),
     "pcgx_region_growing_components": (_i32, [_vp, _vp, _f32, _vp]),
     "pcgx_region_growing_segment": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, C.POINTER(_i64)]),
     "pcgx_pcd_unmarshal_header": (_i32, [_vp, _sz, C.POINTER(PcdHeader)]),
     "pcgx_pcd_unmarshal": (_i32, [_vp, _sz, C.POINTER(PcdHeader), _vp]),
     "pcgx_pcd_unmarshal_dev": (_i32, [_vp, _sz, C.POINTER(PcdHeader), _vp, _vp]),
     "pcgx_pcd_marshal": (_i32, [C.POINTER(PcdHeader), _vp, _vp, _sz, C.POINTER(_sz)]),
+    "pcgx_region_growing_segment_bfs": (_i32, [_vp, _vp, _vp, _f32, _vp, _i64, C.POINTER(_i64)]),
     "pcgx_icp_plane_session_create": (_i32, [_vp, _vp, _vp, _i64, _i32, C.POINTER(IcpParams), _f32, _vp,
                                              C.POINTER(_vp)]),
     "pcgx_icp_session_sums_count": (_i32, [_vp, C.POINTER(_i32)]),

@@ -20,6 +20,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <deque>
+#include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "range_walk.h"
@@ -255,6 +258,7 @@ struct pcgx_bucket_grid {
   GridParams gp;
   // host copies of the CSR buckets (downloaded once): occupied voxels ascending
   std::vector<uint32_t> cell_addr, cell_start, idx_sorted, point_key;
+  std::vector<int32_t> cell_of_addr;  // lazily (segment_bfs, grids up to 2^27 voxels): address -> voxel, -1 empty
   std::vector<uint32_t> cell_comp;  // lazily: smallest voxel address of each voxel's component
   bool have_comp = false;
   int64_t n_in = 0;
@@ -528,6 +532,70 @@ extern "C" pcgx_status pcgx_bucket_grid_segment(pcgx_bucket_grid *g, const float
   return PCGX_OK;
 }
 
+// The same Segment(p) in the reference's own order: its FIFO flood fill (voxelgrid.go:39-73, cursor
+// order x, y, z in {-1, 0, 1}, :13-25) run on the host over the device-built sparse buckets, so the
+// ids come out exactly as the Go code appends them.  Costs 26 voxel look-ups per voxel of the
+// component (dense address -> voxel map up to 2^27 voxels, hashing beyond); use
+// pcgx_bucket_grid_segment / _components when the order does not matter.
+extern "C" pcgx_status pcgx_bucket_grid_segment_bfs(pcgx_bucket_grid *g, const float p[3], int64_t *out, int64_t cap,
+                                                    int64_t *count) {
+  PCGX_API_LOCK();
+  if (!g || !p || !count || cap < 0 || (cap > 0 && !out)) return fail(PCGX_E_INVALID, "pcgx_bucket_grid_segment_bfs: bad argument");
+  *count = 0;
+  int64_t addr0, pos[3];
+  if (!grid_addr_host(g->gp, p, &addr0, pos)) return PCGX_OK;  // PosInt failed (voxelgrid.go:41-44)
+  const GridParams &gp = g->gp;
+  const bool dense = gp.len <= ((int64_t)1 << 27);
+  if (dense && g->cell_of_addr.empty() && gp.len > 0) {
+    g->cell_of_addr.assign((size_t)gp.len, -1);
+    for (size_t c = 0; c < g->cell_addr.size(); c++) g->cell_of_addr[g->cell_addr[c]] = (int32_t)c;
+  }
+  std::vector<uint8_t> searched_dense;
+  std::unordered_set<int64_t> searched_sparse;
+  if (dense) searched_dense.assign((size_t)gp.len, 0);
+  auto test_and_set = [&](int64_t a) {  // returns true if already searched
+    if (dense) {
+      const bool was = searched_dense[(size_t)a] != 0;
+      searched_dense[(size_t)a] = 1;
+      return was;
+    }
+    return !searched_sparse.insert(a).second;
+  };
+  auto is_searched = [&](int64_t a) { return dense ? searched_dense[(size_t)a] != 0 : searched_sparse.count(a) != 0; };
+  auto addr_of = [&](const int64_t v[3], int64_t *a) {  // AddrByPosInt (voxelgrid.go:81-92)
+    if (v[0] < 0 || v[1] < 0 || v[2] < 0 || v[0] >= gp.size[0] || v[1] >= gp.size[1] || v[2] >= gp.size[2]) return false;
+    *a = v[0] + (v[1] + v[2] * gp.size[1]) * gp.size[0];
+    return true;
+  };
+  struct P3 { int64_t v[3]; };
+  std::deque<P3> next;
+  next.push_back(P3{{pos[0], pos[1], pos[2]}});
+  int64_t k = 0;
+  while (!next.empty()) {
+    const P3 cur = next.front();
+    next.pop_front();
+    int64_t a;
+    if (!addr_of(cur.v, &a) || test_and_set(a)) continue;
+    const int64_t c = dense ? g->cell_of_addr[(size_t)a] : find_cell(g, a);
+    if (c < 0) continue;  // empty voxel: not expanded (voxelgrid.go:57-60)
+    for (uint32_t e = g->cell_start[(size_t)c]; e < g->cell_start[(size_t)c + 1]; e++) {
+      if (k < cap) out[k] = g->idx_sorted[e];
+      k++;
+    }
+    for (int dx = -1; dx <= 1; dx++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dz = -1; dz <= 1; dz++) {
+          if (dx == 0 && dy == 0 && dz == 0) continue;
+          const int64_t n[3] = {cur.v[0] + dx, cur.v[1] + dy, cur.v[2] + dz};
+          int64_t a2;
+          if (!addr_of(n, &a2) || is_searched(a2)) continue;
+          next.push_back(P3{{n[0], n[1], n[2]}});
+        }
+  }
+  *count = k;
+  return PCGX_OK;
+}
+
 // Region-growing components (regiongrowing.go:23-56 for every seed at once): comp[i] = smallest id
 // of the set of points reachable from i through steps shorter than max_range between points of
 // i's property value.  labels: Uint32At(id) for id in [0, Len()).
@@ -595,6 +663,65 @@ extern "C" pcgx_status pcgx_region_growing_segment(const pcgx_kdtree *t, const u
     if (labels[i] != target || !std::binary_search(roots.begin(), roots.end(), comp[i])) continue;
     if (k < cap) out[k] = i;
     k++;
+  }
+  *count = k;
+  return PCGX_OK;
+}
+
+// RegionGrowing.Segment(p, maxRange) with the ids in the reference's own order: its FIFO search
+// (regiongrowing.go:23-56) level by level -- the Range() calls of one BFS level are ONE batch on
+// the device (each list sorted by DistSq like KDTree.Range), the queue bookkeeping (toVisit, append
+// order) runs on the host exactly as the Go code does it.  Same set as pcgx_region_growing_segment.
+extern "C" pcgx_status pcgx_region_growing_segment_bfs(const pcgx_kdtree *t, const uint32_t *labels, const float p[3],
+                                                       float max_range, int64_t *out, int64_t cap, int64_t *count) {
+  PCGX_API_LOCK();
+  if (!t || !labels || !p || !count || cap < 0 || (cap > 0 && !out))
+    return fail(PCGX_E_INVALID, "pcgx_region_growing_segment_bfs: bad argument");
+  *count = 0;
+  auto range_batch = [&](const std::vector<float> &q, std::vector<int64_t> &offs, std::vector<int64_t> &ids) -> pcgx_status {
+    const int64_t nq = (int64_t)q.size() / 3;
+    std::vector<int64_t> counts((size_t)nq);
+    PCGX_TRY(pcgx_kdtree_range_count(t, q.data(), nq, max_range, counts.data()));
+    offs.assign((size_t)nq + 1, 0);
+    for (int64_t i = 0; i < nq; i++) offs[(size_t)i + 1] = offs[(size_t)i] + counts[(size_t)i];
+    ids.assign((size_t)offs[(size_t)nq], 0);
+    std::vector<float> dsq((size_t)offs[(size_t)nq]);
+    if (offs[(size_t)nq] > 0)
+      PCGX_TRY(pcgx_kdtree_range_fill(t, q.data(), nq, max_range, offs.data(), ids.data(), dsq.data()));
+    return PCGX_OK;
+  };
+  std::vector<float> q(p, p + 3);
+  std::vector<int64_t> offs, ids;
+  PCGX_TRY(range_batch(q, offs, ids));
+  if (ids.empty()) return PCGX_OK;  // regiongrowing.go:27-29
+  const uint32_t target = labels[ids[0]];  // :31
+  std::vector<uint8_t> to_visit((size_t)t->n, 0);
+  std::vector<int64_t> frontier(ids.begin(), ids.end());  // `next`, in append order
+  for (int64_t id : frontier) to_visit[(size_t)id] = 1;
+  int64_t k = 0;
+  while (!frontier.empty()) {
+    // the ids of this level that are kept (:41-45), in queue order; their Range() lists in one batch
+    std::vector<int64_t> kept;
+    for (int64_t id : frontier)
+      if (labels[id] == target) kept.push_back(id);
+    q.resize(kept.size() * 3);
+    for (size_t j = 0; j < kept.size(); j++) memcpy(&q[3 * j], &t->points[3 * (size_t)kept[j]], 12);  // Vec3At(id), :46
+    std::vector<int64_t> next;
+    if (!kept.empty()) {
+      PCGX_TRY(range_batch(q, offs, ids));
+      for (size_t j = 0; j < kept.size(); j++) {
+        if (k < cap) out[k] = kept[j];
+        k++;
+        for (int64_t e = offs[j]; e < offs[j + 1]; e++) {
+          const int64_t nb = ids[(size_t)e];
+          if (!to_visit[(size_t)nb]) {  // :48-51
+            to_visit[(size_t)nb] = 1;
+            next.push_back(nb);
+          }
+        }
+      }
+    }
+    frontier.swap(next);
   }
   *count = k;
   return PCGX_OK;

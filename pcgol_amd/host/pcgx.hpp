@@ -141,11 +141,12 @@ class BucketVoxelGrid {
     if (cnt > 0) check(pcgx_bucket_grid_get(h_, p.data(), ids->data(), cnt, &cnt));
     return true;
   }
+  // Segment(p) in the reference's order (voxelgrid.go:39-73)
   std::vector<int64_t> Segment(const Vec3 &p) {
     int64_t cnt = 0;
-    check(pcgx_bucket_grid_segment(h_, p.data(), nullptr, 0, &cnt));
+    check(pcgx_bucket_grid_segment_bfs(h_, p.data(), nullptr, 0, &cnt));
     std::vector<int64_t> out((size_t)cnt);
-    if (cnt > 0) check(pcgx_bucket_grid_segment(h_, p.data(), out.data(), cnt, &cnt));
+    if (cnt > 0) check(pcgx_bucket_grid_segment_bfs(h_, p.data(), out.data(), cnt, &cnt));
     return out;
   }
 
@@ -159,8 +160,18 @@ class RegionGrowing {
   RegionGrowing(const KDTree &search, std::vector<uint32_t> property) : t_(search), labels_(std::move(property)) {
     if ((int64_t)labels_.size() != t_.Len()) throw Error(PCGX_E_INVALID, "one property value per point is required");
   }
+  // Segment(p, maxRange) in the reference's order (regiongrowing.go:23-56)
   std::vector<int64_t> Segment(const Vec3 &p, float maxRange) {
-    if (comp_.empty() || maxRange != range_) {  // components of the whole cloud, once per maxRange
+    std::vector<int64_t> out(labels_.size());
+    int64_t cnt = 0;
+    check(pcgx_region_growing_segment_bfs(t_.handle(), labels_.data(), p.data(), maxRange, out.data(),
+                                          (int64_t)out.size(), &cnt));
+    out.resize((size_t)cnt);
+    return out;
+  }
+  // the same set for many seeds: regions of the whole cloud labelled once per maxRange, ascending id
+  std::vector<int64_t> SegmentById(const Vec3 &p, float maxRange) {
+    if (comp_.empty() || maxRange != range_) {
       comp_.resize(labels_.size());
       check(pcgx_region_growing_components(t_.handle(), labels_.data(), maxRange, comp_.data()));
       range_ = maxRange;

@@ -109,12 +109,16 @@ class SegmentationVoxelGrid(StorageVoxelGrid):
         L.check(L.lib().pcgx_bucket_grid_components(self._h, L.ptr(out) if self._n else None))
         return out
 
-    def Segment(self, p):  # segmentation/voxelgrid/voxelgrid.go:39-73
+    def Segment(self, p, order="bfs"):
+        """segmentation/voxelgrid/voxelgrid.go:39-73.  order="bfs": ids exactly as the reference
+        appends them (its FIFO flood fill, run over the device-built buckets); order="address":
+        the same set from the device's component labels, ascending voxel address (fast path)."""
+        fn = L.lib().pcgx_bucket_grid_segment_bfs if order == "bfs" else L.lib().pcgx_bucket_grid_segment
         p = L.f32c(p)
         cnt = C.c_int64()
-        L.check(L.lib().pcgx_bucket_grid_segment(self._h, L.ptr(p), None, 0, C.byref(cnt)))
+        L.check(fn(self._h, L.ptr(p), None, 0, C.byref(cnt)))
         out = np.empty(max(cnt.value, 1), np.int64)
-        L.check(L.lib().pcgx_bucket_grid_segment(self._h, L.ptr(p), L.ptr(out), len(out), C.byref(cnt)))
+        L.check(fn(self._h, L.ptr(p), L.ptr(out), len(out), C.byref(cnt)))
         return out[: cnt.value]
 
 
@@ -141,11 +145,19 @@ class RegionGrowing:
             self._comp[key] = out
         return self._comp[key]
 
-    def Segment(self, p, maxRange):
-        comp = self.Components(maxRange)
+    def Segment(self, p, maxRange, order="bfs"):
+        """regiongrowing.go:23-56.  order="bfs": ids exactly as the reference appends them (its FIFO
+        search, one device Range batch per BFS level); order="id": the same set from the device's
+        region labels (Components), ascending id (fast path for many seeds)."""
         p = L.f32c(p)
         out = np.empty(max(len(self.labels), 1), np.int64)
         cnt = C.c_int64()
+        if order == "bfs":
+            L.check(L.lib().pcgx_region_growing_segment_bfs(self.search._h, L.ptr(self.labels), L.ptr(p),
+                                                            float(np.float32(maxRange)), L.ptr(out), len(out),
+                                                            C.byref(cnt)))
+            return out[: cnt.value].copy()
+        comp = self.Components(maxRange)
         L.check(L.lib().pcgx_region_growing_segment(self.search._h, L.ptr(self.labels), L.ptr(comp), L.ptr(p),
                                                     float(np.float32(maxRange)), L.ptr(out), len(out), C.byref(cnt)))
         return out[: cnt.value].copy()

@@ -22,6 +22,13 @@ def _build(tmpdir):
     return exe
 
 
+def O_segment_order(sg):
+    import oracle as O
+    og = O.BucketGrid(sg["resolution"], sg["size"], np.array(sg["origin"], np.float32))
+    og.add_all(np.array(sg["points"], np.float32))
+    return og.segment(sg["seed_point"]).tolist()
+
+
 def test_cpp_host_mirror_compiles_and_links(tmp_path):
     exe = _build(tmp_path)
     assert os.path.getsize(exe) > 0
@@ -86,13 +93,15 @@ def test_cpp_host_mirror_known_answers(tmp_path, golden):
         assert np.array_equal(got, np.array(c["expected"], np.float32)), c["name"]
     seg = [l for l in out if l.startswith("segment")][0].split()[1:]
     assert sorted(int(v) for v in seg) == sg["expected_sorted"]
+    assert [int(v) for v in seg] == O_segment_order(sg)
     import oracle as O
     spts = np.array(sg["points"], np.float32)
     og = O.BucketGrid(sg["resolution"], sg["size"], np.array(sg["origin"], np.float32))
     og.add_all(spts)
     assert [l for l in out if l.startswith("get ")][0] == "get %d len %d" % (len(og.get(sg["seed_point"])), 64 ** 3)
     # region growing through the C++ mirror == the oracle's BFS (one property value, maxRange 0.051)
-    exp = sorted(O.region_growing_segment(O.KDTree(spts), np.zeros(len(spts), np.uint32), [0.5, 0.5, 0.5], 0.051).tolist())
+    # (the mirror's Segment returns the reference's own BFS order)
+    exp = O.region_growing_segment(O.KDTree(spts), np.zeros(len(spts), np.uint32), [0.5, 0.5, 0.5], 0.051).tolist()
     assert [int(v) for v in [l for l in out if l.startswith("region")][0].split()[1:]] == exp and len(exp) >= 3
     icp = [l for l in out if l.startswith("icp ")][0].split()
     # same Fit through the Python mirror (same C ABI): identical transform

@@ -86,6 +86,7 @@ def test_edge_cases_of_the_next_rows():
     assert v.AddAll(np.array([[1.4, 1.4, 1.4], [0.1, 0.1, 0.1], [1.26, 1.4, 1.4], [1.9, 1.4, 1.4]], f32)).tolist() == \
         [True, True, True, False]
     assert v.Get([1.4, 1.4, 1.4]).tolist() == [0, 2] and v.Segment([1.5, 1.5, 1.5]).tolist() == [0, 2]
+    assert v.Segment([1.5, 1.5, 1.5], order="address").tolist() == [0, 2]
     assert v.Get([1.9, 1.4, 1.4]) is None
     a3 = v.Addr([1.4, 1.4, 1.4])[0]
     assert a3 == 3 + (3 + 3 * 4) * 4 and v.Components().tolist() == [a3, 0, a3, -1]
@@ -95,6 +96,7 @@ def test_edge_cases_of_the_next_rows():
     t = kdtree.New(one)
     rg = segmentation.RegionGrowing(t, [7])
     assert rg.Segment(one[0], 0.5).tolist() == [0] and rg.Segment([9, 9, 9], 0.5).tolist() == []
+    assert rg.Segment(one[0], 0.5, order="id").tolist() == [0]
     # plane ICP: empty target -> not enough pairs; normals of the wrong length -> error
     with pytest.raises(icp.ErrNotEnoughPairs):
         icp.PointToPlaneICP(icp.PointToPlaneEvaluator(icp.NearestPointCorresponder(1.0), np.array([[0, 0, 1]], f32))

@@ -32,7 +32,12 @@ def test_flood_fill_table(golden):
     v = segmentation.SegmentationVoxelGrid(g["resolution"], g["size"], np.array(g["origin"], f32))
     v.AddAll(np.array(g["points"], f32))
     assert sorted(v.Segment(g["seed_point"]).tolist()) == g["expected_sorted"]
+    assert sorted(v.Segment(g["seed_point"], order="address").tolist()) == g["expected_sorted"]
+    o = O.BucketGrid(g["resolution"], g["size"], np.array(g["origin"], f32))
+    o.add_all(np.array(g["points"], f32))
+    assert v.Segment(g["seed_point"]).tolist() == o.segment(g["seed_point"]).tolist()  # the reference's order
     assert v.Segment([0.3, 0.3, 0.3]).tolist() == [] and v.Segment([9, 9, 9]).tolist() == []
+    assert v.Segment([0.3, 0.3, 0.3], order="address").tolist() == []
 
 
 @pytest.mark.parametrize("n,res,seed", [(3000, 0.25, 0), (200_000, 0.08, 1)])
@@ -65,8 +70,10 @@ def test_bucket_grid_and_flood_fill_vs_oracle(n, res, seed):
         if comp[i] in seen:
             continue
         seen.add(int(comp[i]))
-        exp = np.sort(o.segment(pts[i]))
-        assert np.array_equal(np.sort(v.Segment(pts[i])), exp)
+        exact = o.segment(pts[i])
+        assert np.array_equal(v.Segment(pts[i]), exact)  # id for id in the reference's BFS order
+        exp = np.sort(exact)
+        assert np.array_equal(np.sort(v.Segment(pts[i], order="address")), exp)
         assert np.array_equal(np.nonzero(comp == comp[i])[0], exp)
         assert comp[i] == addrs[exp].min()  # canonical id: smallest voxel address of the component
 
@@ -80,10 +87,12 @@ def test_region_growing_table(golden, seed):
     ot = O.KDTree(pts)
     for c in g["cases"]:
         exp = sorted(sum((ids[o] for o in c["objects"]), []))
-        got = rg.Segment(c["p"], c["max_range"])
+        got = rg.Segment(c["p"], c["max_range"], order="id")
         assert got.tolist() == exp, c["name"]  # ascending id
-        assert sorted(O.region_growing_segment(ot, labels, c["p"], c["max_range"]).tolist()) == exp
-    assert rg.Segment([50, 50, 50], 0.1).tolist() == []
+        oseg = O.region_growing_segment(ot, labels, c["p"], c["max_range"])
+        assert sorted(oseg.tolist()) == exp
+        assert rg.Segment(c["p"], c["max_range"]).tolist() == oseg.tolist(), c["name"]  # the reference's order
+    assert rg.Segment([50, 50, 50], 0.1).tolist() == [] and rg.Segment([50, 50, 50], 0.1, order="id").tolist() == []
 
 
 def test_region_growing_vs_oracle_random():
@@ -99,8 +108,10 @@ def test_region_growing_vs_oracle_random():
         assert np.all(comp <= np.arange(n)) and np.array_equal(labels[comp], labels)
         for k in range(25):
             p = pts[rng.integers(n)] + f32(0.01)
-            exp = np.sort(O.region_growing_segment(ot, labels, p, mr))
-            assert np.array_equal(rg.Segment(p, mr), exp), (mr, k)
+            exact = O.region_growing_segment(ot, labels, p, mr)
+            assert np.array_equal(rg.Segment(p, mr, order="id"), np.sort(exact)), (mr, k)
+            if k < 8:
+                assert np.array_equal(rg.Segment(p, mr), exact), (mr, k)  # id for id, BFS order
     # after DeletePoint the regions are those of the remaining points
     gone = rng.choice(n, n // 4, replace=False)
     t.DeletePoints(gone)
@@ -109,5 +120,7 @@ def test_region_growing_vs_oracle_random():
     rg2 = segmentation.RegionGrowing(t, labels)
     for k in range(10):
         p = pts[rng.integers(n)] + f32(0.01)
-        exp = np.sort(O.region_growing_segment(ot, labels, p, 0.2))
-        assert np.array_equal(rg2.Segment(p, 0.2), exp)
+        exact = O.region_growing_segment(ot, labels, p, 0.2)
+        assert np.array_equal(rg2.Segment(p, 0.2, order="id"), np.sort(exact))
+        if k < 3:
+            assert np.array_equal(rg2.Segment(p, 0.2), exact)
