@@ -374,17 +374,23 @@ __global__ __launch_bounds__(64) void icp_strict_sums_kernel(const float *__rest
   int64_t pairs = 0;  // lane 9
   if (lane < 9 && nblk > 0) {
     const float4 *row = reinterpret_cast<const float4 *>(terms + (int64_t)lane * nt_pad);
-    float4 cur[16], nxt[16];
+    // two register buffers used alternately: while one block's 64 additions run (a dependent
+    // chain), the 16 loads of the block after the next are already in flight
+    float4 a[16], b[16];
 #pragma unroll
-    for (int v = 0; v < 16; v++) cur[v] = row[v];
-    for (int64_t blk = 0; blk < nblk; blk++) {
-      const int64_t nb = blk + 1 < nblk ? blk + 1 : blk;
+    for (int v = 0; v < 16; v++) a[v] = row[v];
+    for (int64_t blk = 0; blk < nblk; blk += 2) {
+      const int64_t b1 = blk + 1 < nblk ? blk + 1 : blk, b2 = blk + 2 < nblk ? blk + 2 : blk;
 #pragma unroll
-      for (int v = 0; v < 16; v++) nxt[v] = row[nb * 16 + v];  // in flight during the chain below
+      for (int v = 0; v < 16; v++) b[v] = row[b1 * 16 + v];
 #pragma unroll
-      for (int v = 0; v < 16; v++) acc = (((acc + cur[v].x) + cur[v].y) + cur[v].z) + cur[v].w;
+      for (int v = 0; v < 16; v++) acc = (((acc + a[v].x) + a[v].y) + a[v].z) + a[v].w;
 #pragma unroll
-      for (int v = 0; v < 16; v++) cur[v] = nxt[v];
+      for (int v = 0; v < 16; v++) a[v] = row[b2 * 16 + v];
+      if (blk + 1 < nblk) {
+#pragma unroll
+        for (int v = 0; v < 16; v++) acc = (((acc + b[v].x) + b[v].y) + b[v].z) + b[v].w;
+      }
     }
   } else if (lane == 9) {
     for (int64_t blk = 0; blk < nblk; blk++) pairs += (int64_t)__popcll(valid_bits[blk]);
