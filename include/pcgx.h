@@ -296,7 +296,7 @@ PCGX_API pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream);
  * terms: more accurate than the reference, equal to it only up to ITS rounding noise (sequential
  * float32 additions, evaluator.go:122-145; ~1.6e-5 on the final transform at 1M pairs).  With
  * strict on, one wave adds the terms sequentially in float32 in target order instead: Evaluated
- * and the resulting pose are then bit-identical to the Go code's at any size, at ~4 ms per
+ * and the resulting pose are then bit-identical to the Go code's at any size, at ~7 ms per
  * iteration and 1M pairs instead of 0.07 ms.  Single-GPU sessions only (a sharded sum has no
  * sequential order).  Environment PCGX_ICP_STRICT=1 turns it on for every new session
  * (pcgx_icp_fit / pcgx_icp_evaluate included). */
