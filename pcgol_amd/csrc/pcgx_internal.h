@@ -6,14 +6,36 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pcgx.h"
 #include "pcgx_math.h"
 
 namespace pcgx {
+
+// std::vector whose resize() leaves new elements uninitialised (buffers that are overwritten at
+// once: zero-filling 12 MB first costs as much as the copy that follows)
+template <class T>
+struct DefaultInitAlloc : std::allocator<T> {
+  template <class U>
+  struct rebind {
+    using other = DefaultInitAlloc<U>;
+  };
+  template <class U>
+  void construct(U *p) noexcept {
+    ::new ((void *)p) U;
+  }
+  template <class U, class... A>
+  void construct(U *p, A &&...a) {
+    ::new ((void *)p) U(std::forward<A>(a)...);
+  }
+};
+template <class T>
+using RawVector = std::vector<T, DefaultInitAlloc<T>>;
 
 // ---- error handling --------------------------------------------------------
 pcgx_status fail(pcgx_status code, const char *fmt, ...);
@@ -192,8 +214,8 @@ struct pcgx_kdtree {
   int32_t dir_bits = 0;
   float dir_lo[3] = {0, 0, 0}, dir_scale[3] = {0, 0, 0};
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // of the base cloud
-  std::vector<int32_t> inorder;    // host copy of the in-order ids
-  std::vector<float> points;       // host copy of xyz (accessor order), for Vec3At
+  pcgx::RawVector<int32_t> inorder;  // host copy of the in-order ids
+  pcgx::RawVector<float> points;   // host copy of xyz (accessor order), for Vec3At
   // KDTree.DeletePoint (kdtree.go:322-332).  The implicit layout cannot express the reference's
   // patched tree, so deletions are recorded here and the next query rebuilds a tree over the
   // remaining points whose nodes keep the ORIGINAL ids (`live`; nullptr while nothing is left).
