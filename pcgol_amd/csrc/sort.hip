@@ -19,16 +19,22 @@
 
 namespace pcgx {
 
-constexpr int kRsThreads = 256;
-constexpr int kRsItems = 16;
-constexpr int kRsTile = kRsThreads * kRsItems;  // 4096 elements per block
+constexpr int kRsThreads = 256;  // fixed: thread t owns digit t in the histogram / prefix steps
 constexpr int kRsWaves = kRsThreads / 64;
-constexpr int kRsWaveChunk = kRsTile / kRsWaves;  // 1024 contiguous elements per wave
 constexpr int kRadix = 256;
+static_assert(kRsThreads == kRadix, "one thread per digit");
+// Elements per thread: 16 (4096-element tiles: long output runs per digit) for large inputs, 8
+// (2048-element tiles: twice as many workgroups, each half as long) when 4096-element tiles would
+// not even give every CU two workgroups -- a pass over 1M pairs is bound by the serial time of one
+// workgroup (load, 16 ranking rounds, re-order, write), not by bandwidth.
+constexpr int64_t kRsSmallInput = (int64_t)1 << 22;
+inline int rs_items(int64_t n) { return n <= kRsSmallInput ? 8 : 16; }  // 4 measured no better at 1M
 
+template <int kRsItems>
 __global__ __launch_bounds__(kRsThreads) void rs_hist_kernel(const uint32_t *__restrict__ keys, int64_t n,
                                                              int shift, uint32_t *__restrict__ block_hist,
                                                              int nblocks) {
+  constexpr int kRsTile = kRsThreads * kRsItems;
   __shared__ uint32_t hist[kRadix];
   hist[threadIdx.x] = 0;
   __syncthreads();
@@ -74,10 +80,13 @@ __global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t *__re
   if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
+template <int kRsItems>
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, int64_t n, int shift,
     const uint32_t *__restrict__ block_hist, int nblocks, const uint32_t *__restrict__ totals,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int xcd_remap) {
+  constexpr int kRsTile = kRsThreads * kRsItems;
+  constexpr int kRsWaveChunk = kRsTile / kRsWaves;  // contiguous elements per wave
   __shared__ uint32_t cnt[kRsWaves][kRadix];
   __shared__ uint32_t tile_pref[kRadix];
   __shared__ uint32_t gbase[kRadix];
@@ -205,7 +214,8 @@ static bool sort_xcd_remap() {
 }
 
 size_t radix_sort_workspace_bytes(int64_t n) {
-  const int64_t nblocks = (n + kRsTile - 1) / kRsTile;
+  const int64_t tile = (int64_t)kRsThreads * rs_items(n);
+  const int64_t nblocks = (n + tile - 1) / tile;
   return (size_t)(nblocks * kRadix + 2 * kRadix) * sizeof(uint32_t);
 }
 
@@ -216,21 +226,31 @@ pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, in
   *result = 0;
   if (n <= 1 || key_bits <= 0) return PCGX_OK;
   if (n > 0x7fffffffll) return fail(PCGX_E_INVALID, "radix sort: n too large");
-  const int nblocks = (int)((n + kRsTile - 1) / kRsTile);
+  const int items = rs_items(n);
+  const int64_t tile = (int64_t)kRsThreads * items;
+  const int nblocks = (int)((n + tile - 1) / tile);
   uint32_t *block_hist = (uint32_t *)workspace;
   uint32_t *totals = block_hist + (int64_t)nblocks * kRadix;
   int cur = 0;
   for (int shift = 0; shift < key_bits; shift += 8) {
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(kRsThreads), 0, st, keys[cur], n, shift,
-                       block_hist, nblocks);
+    if (items == 8)
+      hipLaunchKernelGGL(rs_hist_kernel<8>, dim3(nblocks), dim3(kRsThreads), 0, st, keys[cur], n, shift, block_hist,
+                         nblocks);
+    else
+      hipLaunchKernelGGL(rs_hist_kernel<16>, dim3(nblocks), dim3(kRsThreads), 0, st, keys[cur], n, shift, block_hist,
+                         nblocks);
     hipLaunchKernelGGL(rs_scan_rows_kernel, dim3(kRadix), dim3(kRsThreads), 0, st, block_hist, nblocks,
                        totals);
     {
       ProfScope prof(PCGX_PROF_SORT_SCATTER, st);
       const int remap = sort_xcd_remap() && nblocks >= 64;
       const int grid = remap ? 8 * ((nblocks + 7) / 8) : nblocks;
-      hipLaunchKernelGGL(rs_scatter_kernel, dim3(grid), dim3(kRsThreads), 0, st, keys[cur], vals[cur], n,
-                         shift, block_hist, nblocks, totals, keys[cur ^ 1], vals[cur ^ 1], remap);
+      if (items == 8)
+        hipLaunchKernelGGL(rs_scatter_kernel<8>, dim3(grid), dim3(kRsThreads), 0, st, keys[cur], vals[cur], n, shift,
+                           block_hist, nblocks, totals, keys[cur ^ 1], vals[cur ^ 1], remap);
+      else
+        hipLaunchKernelGGL(rs_scatter_kernel<16>, dim3(grid), dim3(kRsThreads), 0, st, keys[cur], vals[cur], n, shift,
+                           block_hist, nblocks, totals, keys[cur ^ 1], vals[cur ^ 1], remap);
     }
     cur ^= 1;
   }
