@@ -308,6 +308,8 @@ def main():
         }
         if world == 1 and not args.no_extras:
             line["extra"] = side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, icp)
+            # the second half of BASELINE.json's metric ("+ kNN queries/sec, 1M-pt cloud", config C2)
+            line["knn_queries_per_s"] = line["extra"]["knn_c2_presort"]["mqueries_per_s"] * 1e6
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(synth, base, tile, cfg)
             line["cpu_baseline"]["host_cpus"] = os.cpu_count()
