@@ -119,22 +119,29 @@ PCGX_API pcgx_status pcgx_kdtree_len(const pcgx_kdtree *t, int64_t *n);
 /* node.maxDepth(0) (kdtree.go:385-395). */
 PCGX_API pcgx_status pcgx_kdtree_max_depth(const pcgx_kdtree *t, int32_t *depth);
 /* In-order point ids (child0, node, child1): the final state of the
- * reference's in-place sorted indice slice; defines the whole tree. */
+ * reference's in-place sorted indice slice; defines the whole tree.  After DeletePoint: the
+ * remaining ids (live_count of them) in the in-order sequence of the canonical tree over them. */
 PCGX_API pcgx_status pcgx_kdtree_inorder(const pcgx_kdtree *t, int64_t *ids /* [n] host */);
 /* Vec3At(id) for a batch of ids (pc/randomaccess.go:8). */
 PCGX_API pcgx_status pcgx_kdtree_points(const pcgx_kdtree *t, const int64_t *ids, int64_t m,
                                         float *xyz /* [3m] host */);
 
+/* The tree as the reference holds it (kdtree.go:25-29), pre-order: node k = {id, dim, index of
+ * child0, index of child1} in the dump (-1 = nil); after DeletePoint the patched tree.  *n_nodes =
+ * nodes in the tree, the first min(n_nodes, cap_nodes) quadruples are written. */
+PCGX_API pcgx_status pcgx_kdtree_dump(const pcgx_kdtree *t, int64_t *out4, int64_t cap_nodes, int64_t *n_nodes);
+
 /* KDTree.DeletePoint (kdtree.go:322-332) for a batch of ids.  An id outside [0, Len()) is
  * PCGX_E_OUT_OF_RANGE (the reference's "does not correspond to any point in the tree",
  * :323-325) and deletes nothing; deleting a point twice is a no-op (kdtree_test.go:576-650).
  * Len() / Vec3At() keep describing the accessor (all points), as in the reference.
- * The implicit device layout cannot express the reference's patched tree (findMinimum /
- * deleteNodeImpl, :224-320): the next query rebuilds the canonical tree over the remaining
- * points (their ids unchanged).  Results equal the reference's -- the nearest / in-range points
- * among the remaining ones, ID and DistSq exact -- except where the reference's answer depends on
- * its tree shape: exact-distance ties and MinDistSq > 0.  max_depth / inorder then describe the
- * rebuilt tree; open ICP sessions keep the tree they were created on. */
+ * The handle then keeps the reference's own patched tree (findMinimumImpl / deleteNodeImpl,
+ * :224-320, applied in call order on a host mirror) and Nearest / Range walk an explicit device
+ * copy of it in the reference's visit order: ids and DistSq as the Go code returns them, exact ties
+ * and MinDistSq > 0 included (slower than the implicit tree: no speculative descent).  max_depth
+ * and pcgx_kdtree_dump describe the patched tree.  ICP sessions and region growing on such a handle
+ * use a canonical tree rebuilt over the remaining points (same pairs except on exact-distance
+ * ties); open sessions keep the tree they were created on. */
 PCGX_API pcgx_status pcgx_kdtree_delete_points(pcgx_kdtree *t, const int64_t *ids, int64_t m);
 /* Points still in the tree (Len() minus deleted). */
 PCGX_API pcgx_status pcgx_kdtree_live_count(const pcgx_kdtree *t, int64_t *n_live);

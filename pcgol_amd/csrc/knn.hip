@@ -368,6 +368,7 @@ extern "C" pcgx_status pcgx_kdtree_free(pcgx_kdtree *t) {
   if (!t) return PCGX_OK;
   if (t->live) pcgx_kdtree_free(t->live);
   for (pcgx_kdtree *r : t->retired) pcgx_kdtree_free(r);
+  xtree_free(t);
   if (t->d_nodes) dev_cache_free(t->d_nodes);
   if (t->d_dir) dev_cache_free(t->d_dir);
   delete t;
@@ -387,6 +388,7 @@ extern "C" pcgx_status pcgx_kdtree_delete_points(pcgx_kdtree *t, const int64_t *
   std::lock_guard<std::mutex> lock(t->mu);
   if (t->deleted.empty()) t->deleted.assign((size_t)t->n, 0);
   for (int64_t i = 0; i < m; i++) {
+    xtree_delete(t, ids[i]);  // the reference's patching, in call order (a repeated id finds nothing)
     if (t->deleted[(size_t)ids[i]]) continue;
     t->deleted[(size_t)ids[i]] = 1;
     t->n_deleted++;
@@ -449,10 +451,13 @@ extern "C" pcgx_status pcgx_kdtree_len(const pcgx_kdtree *t, int64_t *n) {
 extern "C" pcgx_status pcgx_kdtree_max_depth(const pcgx_kdtree *t, int32_t *depth) {
   PCGX_API_LOCK();
   if (!t || !depth) return fail(PCGX_E_INVALID, "pcgx_kdtree_max_depth: NULL argument");
-  const pcgx_kdtree *a = nullptr;
-  bool empty = false;
-  PCGX_TRY(resolve_tree(t, &a, &empty));
-  *depth = empty ? 0 : a->depth;
+  if (t->n_deleted > 0) {  // the reference's patched tree (knn_explicit.hip)
+    pcgx_kdtree *m = const_cast<pcgx_kdtree *>(t);
+    std::lock_guard<std::mutex> lock(m->mu);
+    *depth = xtree_max_depth(t);
+    return PCGX_OK;
+  }
+  *depth = t->depth;
   return PCGX_OK;
 }
 
@@ -489,6 +494,17 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch_dev(const pcgx_kdtree *t, const
   PCGX_TRY(ensure_init());
   hipStream_t st = pick_stream(stream);
   const float max_range_sq = max_range * max_range;  // kdtree.go:91
+  if (t->n_deleted > 0) {
+    // a handle that has seen DeletePoint: the reference's patched tree, walked in its visit order
+    // (exact ties and MinDistSq > 0 as the Go code answers them; knn_explicit.hip)
+    PCGX_TRY(ctx().arena.begin(st));
+    int32_t *perm = nullptr;
+    if ((flags & PCGX_KNN_PRESORT) && nq > 1) {
+      PCGX_TRY(ctx().arena.alloc_n((size_t)nq, &perm));
+      PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, perm, st));
+    }
+    return xtree_launch_nearest(t, d_q, perm, nq, max_range_sq, min_dist_sq, d_ids, d_dist_sq, st);
+  }
   bool empty = false;
   PCGX_TRY(resolve_tree(t, &t, &empty));  // after DeletePoint: the tree over the remaining points
   if (empty) {

@@ -165,6 +165,15 @@ pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint
 // knn.hip: the tree queries run on: `t` itself, or the tree over the points left after DeletePoint
 // (rebuilt here if deletions happened since).  *empty: every point was deleted (root == nil).
 pcgx_status resolve_tree(const pcgx_kdtree *t, const pcgx_kdtree **active, bool *empty);
+// knn_explicit.hip: the reference's patched tree of a handle that has seen DeletePoint
+void xtree_delete(pcgx_kdtree *t, int64_t pid);  // caller holds t->mu
+void xtree_free(pcgx_kdtree *t);
+int xtree_max_depth(const pcgx_kdtree *t);  // caller holds t->mu
+pcgx_status xtree_launch_nearest(const pcgx_kdtree *t, const float *d_q, const int32_t *d_perm, int64_t nq,
+                                 float max_range_sq, float min_dist_sq, int32_t *d_ids, float *d_dsq, hipStream_t st);
+pcgx_status xtree_launch_range(const pcgx_kdtree *t, bool fill, const float *d_q, const int32_t *d_perm, int64_t nq,
+                               float bound, int64_t *d_counts, const int64_t *d_offsets, int64_t total, int32_t *d_id,
+                               uint32_t *d_key, uint32_t *d_query, hipStream_t st);
 namespace pcgx {
 
 // knn.hip
@@ -221,6 +230,17 @@ struct pcgx_kdtree {
   // remaining points whose nodes keep the ORIGINAL ids (`live`; nullptr while nothing is left).
   // A tree replaced by a later rebuild is freed at once unless ICP sessions still run on it
   // (`sessions`); those are retired and freed by a later rebuild or with the handle.
+  // ... and, for Nearest / Range, the reference's own patched tree (knn_explicit.hip): host mirror
+  // {id, child0, child1, dim} with node index = in-order position, patched by deleteNodeImpl's
+  // rules, plus its explicit device copy.
+  struct XNode {
+    int32_t id, c0, c1, dim;
+  };
+  std::vector<XNode> xnodes;
+  int32_t xroot = -1;
+  bool x_init = false, x_dirty = false;
+  float4 *d_xpts = nullptr;
+  void *d_xlinks = nullptr;
   std::vector<uint8_t> deleted;    // [n] once the first point was deleted
   int64_t n_deleted = 0;
   bool dirty = false;              // deletions since `live` was built

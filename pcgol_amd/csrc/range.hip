@@ -81,12 +81,10 @@ extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float
   if (!t || nq < 0 || (nq > 0 && (!q || !counts))) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_count: bad argument");
   if (nq == 0) return PCGX_OK;
   PCGX_TRY(ensure_init());
+  const pcgx_kdtree *outer = t;  // a handle with deletions walks the reference's patched tree (knn_explicit.hip)
+  const bool patched = outer->n_deleted > 0;
   bool empty = false;
-  PCGX_TRY(resolve_tree(t, &t, &empty));  // after DeletePoint: the tree over the remaining points
-  if (empty) {  // root == nil (kdtree.go:150-152)
-    for (int64_t i = 0; i < nq; i++) counts[i] = 0;
-    return PCGX_OK;
-  }
+  if (!patched) PCGX_TRY(resolve_tree(t, &t, &empty));
   hipStream_t st = ctx().stream;
   float *d_q = nullptr;
   int64_t *d_c = nullptr;
@@ -102,9 +100,13 @@ extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float
     PCGX_TRY(ctx().arena.alloc_n((size_t)nq, &perm));
     PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, perm, st));
   }
-  hipLaunchKernelGGL(range_kernel<false>, dim3((unsigned)((nq + kRangeBlock - 1) / kRangeBlock)), dim3(kRangeBlock), lds,
-                     st, tv, (const float *)d_q, (const int32_t *)perm, nq, max_range * max_range, d_c, nullptr, 0,
-                     nullptr, nullptr, nullptr);
+  if (patched)
+    PCGX_TRY(xtree_launch_range(outer, false, d_q, perm, nq, max_range * max_range, d_c, nullptr, 0, nullptr, nullptr,
+                                nullptr, st));
+  else
+    hipLaunchKernelGGL(range_kernel<false>, dim3((unsigned)((nq + kRangeBlock - 1) / kRangeBlock)), dim3(kRangeBlock),
+                       lds, st, tv, (const float *)d_q, (const int32_t *)perm, nq, max_range * max_range, d_c, nullptr, 0,
+                       nullptr, nullptr, nullptr);
   PCGX_HIP_TRY(hipGetLastError());
   PCGX_HIP_TRY(hipMemcpyAsync(counts, d_c, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
@@ -122,9 +124,10 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
   if (!ids || !dist_sq) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: NULL output");
   if (total > 0x7fffffffll) return fail(PCGX_E_TOO_LARGE, "pcgx_kdtree_range_fill: more than 2^31-1 neighbours in one batch");
   PCGX_TRY(ensure_init());
+  const pcgx_kdtree *outer = t;
+  const bool patched = outer->n_deleted > 0;
   bool empty = false;
-  PCGX_TRY(resolve_tree(t, &t, &empty));
-  if (empty) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: offsets do not match the neighbour counts");
+  if (!patched) PCGX_TRY(resolve_tree(t, &t, &empty));
   hipStream_t st = ctx().stream;
   Arena &ar = ctx().arena;
   PCGX_TRY(ar.begin(st));
@@ -159,9 +162,13 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
     PCGX_TRY(ar.alloc_n((size_t)nq, &qperm));
     PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, qperm, st));
   }
-  hipLaunchKernelGGL(range_kernel<true>, dim3((unsigned)((nq + kRangeBlock - 1) / kRangeBlock)), dim3(kRangeBlock), lds,
-                     st, tv, d_q, (const int32_t *)qperm, nq, max_range * max_range, nullptr, d_off, total, d_id, d_key,
-                     d_query);
+  if (patched)
+    PCGX_TRY(xtree_launch_range(outer, true, d_q, qperm, nq, max_range * max_range, nullptr, d_off, total, d_id, d_key,
+                                d_query, st));
+  else
+    hipLaunchKernelGGL(range_kernel<true>, dim3((unsigned)((nq + kRangeBlock - 1) / kRangeBlock)), dim3(kRangeBlock),
+                       lds, st, tv, d_q, (const int32_t *)qperm, nq, max_range * max_range, nullptr, d_off, total, d_id,
+                       d_key, d_query);
   const unsigned tb = (unsigned)((total + 255) / 256);
   hipLaunchKernelGGL(range_iota_kernel, dim3(tb), dim3(256), 0, st, vals[0], total);
   PCGX_HIP_TRY(hipMemcpyAsync(keys[0], d_key, (size_t)total * 4, hipMemcpyDeviceToDevice, st));

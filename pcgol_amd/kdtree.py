@@ -70,6 +70,18 @@ class KDTree:
         L.check(L.lib().pcgx_kdtree_max_depth(self._h, C.byref(d)))
         return d.value
 
+    def Tree(self):
+        """The tree as the reference holds it, nested [id, dim, child0, child1] (None = nil); after
+        DeletePoint the patched tree (kdtree.go:264-320)."""
+        n = C.c_int64()
+        L.check(L.lib().pcgx_kdtree_dump(self._h, None, 0, C.byref(n)))
+        d = np.empty((max(n.value, 1), 4), np.int64)
+        L.check(L.lib().pcgx_kdtree_dump(self._h, L.ptr(d), n.value, C.byref(n)))
+
+        def rec(k):
+            return None if k < 0 else [int(d[k][0]), int(d[k][1]), rec(int(d[k][2])), rec(int(d[k][3]))]
+        return rec(0) if n.value else None
+
     def InOrder(self):
         out = np.empty(self.LiveCount(), np.int64)
         L.check(L.lib().pcgx_kdtree_inorder(self._h, L.ptr(out)))

@@ -1,10 +1,11 @@
 """GPU parity of KDTree.DeletePoint (kdtree.go:322-332) through the C ABI.
 
 The oracle restates the reference's deleteNodeImpl / findMinimumImpl (pinned by the reference's
-exact trees after deletion, tests/test_oracle_golden.py); the device rebuilds the canonical tree
-over the remaining points instead of patching it, so the comparison is on what Nearest / Range
-return -- ID and DistSq exact -- on inputs without exact-distance ties (the reference's own
-property test compares the same way, kdtree_test.go:864-885)."""
+exact trees after deletion, tests/test_oracle_golden.py).  The product keeps the same patched tree
+(csrc/knn_explicit.hip): its dump must equal the reference's expected trees node for node, and
+Nearest / Range on it return ID and DistSq exactly as the oracle's patched tree does -- on lattice
+clouds full of exact-distance ties and with MinDistSq > 0 too, where the answer depends on the
+tree's shape."""
 import numpy as np
 import pytest
 
@@ -40,6 +41,77 @@ def test_delete_tables_nearest(golden):
                 r = t.Range(q, 2.5)
                 ri, rd = o.range(q, 2.5)
                 assert sorted((n.ID, float(n.DistSq)) for n in r) == sorted(zip(ri.tolist(), rd.tolist()))
+
+
+def test_delete_tables_tree_equals_the_reference_trees(golden):
+    """kdtree_test.go:413-729: after every DeletePoint the PRODUCT's tree is the expected tree."""
+    g = golden("ref_kdtree.json")
+    pts = np.array(g["test_cloud"]["points"], f32)
+    assert kdtree.New(pts).Tree() == g["expected_tree"]["root"]
+    for name, steps in g["delete_point"]["sequences"].items():
+        t, o = kdtree.New(pts), O.KDTree(pts)
+        for st in steps:
+            try:
+                t.DeletePoint(st["pid"])
+                assert not st["has_error"], name
+                o.delete_point(st["pid"])
+            except IndexError:
+                assert st["has_error"], name
+            assert t.Tree() == st["tree"], (name, st["pid"])
+            assert t.MaxDepth() == o.max_depth()
+
+
+def _lattice(side, seed):
+    g = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(f32)
+    return g[np.random.default_rng(seed).permutation(len(g))]
+
+
+@pytest.mark.parametrize("min_dist_sq", [0.0, 0.3, 1.5])
+def test_delete_on_a_lattice_ties_and_min_dist(min_dist_sq):
+    """Every query has several points at exactly the same distance and MinDistSq cuts the search
+    short: which id comes back depends on the patched tree's shape.  Must equal the oracle's."""
+    pts = _lattice(12, 3)
+    n = len(pts)
+    t = kdtree.New(pts).With(MinDistSq=min_dist_sq) if min_dist_sq else kdtree.New(pts)
+    o = O.KDTree(pts, min_dist_sq)
+    rng = np.random.default_rng(8)
+    q = np.concatenate([rng.integers(0, 23, (3000, 3)).astype(f32) * f32(0.5),      # lattice + half points
+                        rng.uniform(-1, 12, (1000, 3)).astype(f32)])
+    gone = rng.permutation(n)[: n // 2]
+    for part in np.array_split(gone, 4):
+        t.DeletePoints(part)
+        for i in part:
+            o.delete_point(int(i))
+        assert t.Tree() == o.tree()
+        ids, dsq = t.NearestBatch(q, 2.0)
+        oi, od = o.nearest_batch(q, 2.0)
+        assert np.array_equal(dsq, od)
+        assert np.array_equal(ids, oi)
+        for k in range(0, 40):
+            r = t.Range(q[k], 1.5)
+            ri, rd = o.range(q[k], 1.5)
+            assert sorted((x.ID, float(x.DistSq)) for x in r) == sorted(zip(ri.tolist(), rd.tolist()))
+        offs, rid, rdsq = t.RangeBatch(q[:500], 1.5)
+        assert np.diff(offs).tolist() == [len(o.range(qq, 1.5)[0]) for qq in q[:500]]
+
+
+def test_delete_presorted_device_queries_use_the_patched_tree():
+    """nq large enough for the Morton presort of the device entry point."""
+    import torch
+    pts = _lattice(16, 4)
+    t, o = kdtree.New(pts), O.KDTree(pts)
+    gone = np.arange(0, len(pts), 3)
+    t.DeletePoints(gone)
+    for i in gone:
+        o.delete_point(int(i))
+    q = (np.random.default_rng(2).integers(0, 31, (1 << 16, 3)).astype(f32) * f32(0.5))
+    dq = torch.from_numpy(q).cuda()
+    ids = torch.empty(len(q), dtype=torch.int32, device="cuda")
+    dsq = torch.empty(len(q), dtype=torch.float32, device="cuda")
+    t.NearestBatchDev(dq.data_ptr(), len(q), 3.0, ids.data_ptr(), dsq.data_ptr(), presort=True)
+    torch.cuda.synchronize()
+    oi, od = o.nearest_batch(q, 3.0)
+    assert np.array_equal(ids.cpu().numpy(), oi) and np.array_equal(dsq.cpu().numpy(), od)
 
 
 def test_delete_all_points_on_a_line(golden):
