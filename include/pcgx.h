@@ -139,9 +139,10 @@ PCGX_API pcgx_status pcgx_kdtree_dump(const pcgx_kdtree *t, int64_t *out4, int64
  * :224-320, applied in call order on a host mirror) and Nearest / Range walk an explicit device
  * copy of it in the reference's visit order: ids and DistSq as the Go code returns them, exact ties
  * and MinDistSq > 0 included (slower than the implicit tree: no speculative descent).  max_depth
- * and pcgx_kdtree_dump describe the patched tree.  ICP sessions and region growing on such a handle
- * use a canonical tree rebuilt over the remaining points (same pairs except on exact-distance
- * ties); open sessions keep the tree they were created on. */
+ * and pcgx_kdtree_dump describe the patched tree.  ICP sessions created on such a handle walk the
+ * patched tree as well (and see later deletions); a session created before the first deletion keeps
+ * the tree it was created on.  Region growing uses a canonical tree rebuilt over the remaining points
+ * (Range hits are a set: same components). */
 PCGX_API pcgx_status pcgx_kdtree_delete_points(pcgx_kdtree *t, const int64_t *ids, int64_t m);
 /* Points still in the tree (Len() minus deleted). */
 PCGX_API pcgx_status pcgx_kdtree_live_count(const pcgx_kdtree *t, int64_t *n_live);

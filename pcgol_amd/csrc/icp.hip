@@ -13,7 +13,7 @@
 
 #include <vector>
 
-#include "knn_walk.h"
+#include "knn_xwalk.h"
 
 namespace pcgx {
 
@@ -79,6 +79,56 @@ __device__ __forceinline__ void accumulate_plane_terms(double *acc, float x0, fl
   acc[P_PAIRS] += 1.0;
 }
 
+// Phase 2 of the correspondence kernels (evaluator.go:122-145): the workgroup streams the targets of
+// its own chunk range in a fixed thread assignment and accumulates the evaluator's sums in float64;
+// s_scratch: >= (kIcpBlock / 64) * NS doubles of LDS no longer in use.
+template <bool kPlane>
+__device__ __forceinline__ void reduce_block_range(uint32_t *s_scratch, const float *__restrict__ tx,
+                                                   const float *__restrict__ ty, const float *__restrict__ tz,
+                                                   int64_t nt, uint32_t chunk_begin, uint32_t chunk_end, bool project,
+                                                   const float (&m)[16], const float4 *__restrict__ match,
+                                                   const uint32_t *__restrict__ match_id,
+                                                   const float4 *__restrict__ normals,
+                                                   double *__restrict__ block_partials) {
+  constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
+  double acc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) acc[k] = 0.0;
+  const int64_t r_begin = (int64_t)chunk_begin * 64;
+  int64_t r_end = (int64_t)chunk_end * 64;
+  if (r_end > nt) r_end = nt;
+  for (int64_t i = r_begin + threadIdx.x; i < r_end; i += kIcpBlock) {
+    const float4 bp = match[i];
+    if (bp.w >= 0.0f) {  // correspondence.go:27-29
+      float x0 = tx[i], y0 = ty[i], z0 = tz[i];
+      if (project) {  // icp.go:62-64
+        float px, py, pz;
+        mat4_transform(m, x0, y0, z0, px, py, pz);
+        x0 = px; y0 = py; z0 = pz;
+      }
+      if (kPlane) {
+        const float4 nrm = normals[match_id[i]];
+        accumulate_plane_terms(acc, x0, y0, z0, bp, nrm);
+      } else {
+        accumulate_terms(acc, x0, y0, z0, bp);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double(*s_red)[NS] = reinterpret_cast<double(*)[NS]>(s_scratch);
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    double v = wave_sum_f64(acc[k]);
+    if (lane == 0) s_red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    double v = 0.0;
+    for (int w = 0; w < kIcpBlock / 64; w++) v += s_red[w][threadIdx.x];
+    block_partials[(int64_t)blockIdx.x * NS + threadIdx.x] = v;
+  }
+}
+
 // One ICP iteration's correspondence + reduction for a tile of targets.
 //
 // Phase 1, correspondence (correspondence.go:22-37 for every target at once): targets are
@@ -117,14 +167,6 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
   for (int i = 0; i < 16; i++) m[i] = state->trans[i];
   // Before the first update targetTransformed is a plain copy (icp.go:27-30).
   const bool project = state->iter > 0;
-  auto load_target = [&](int64_t i, float &x, float &y, float &z) {
-    x = tx[i]; y = ty[i]; z = tz[i];
-    if (project) {
-      float px, py, pz;
-      mat4_transform(m, x, y, z, px, py, pz);
-      x = px; y = py; z = pz;
-    }
-  };
   // From the second iteration of a Fit on, match[i] still holds the base point matched in the
   // previous iteration: its distance to the re-projected target bounds the new nearest distance
   // from above and seeds the walk's pruning bound (knn_walk.h, "Pruning bound"; exact mode only).
@@ -162,38 +204,63 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
   // ---- phase 2: this workgroup's range, fixed order
   __threadfence_block();
   __syncthreads();  // all match[] of the range are written; stacks / queues are free for reuse
-  double acc[NS];
+  reduce_block_range<kPlane>(s_stack, tx, ty, tz, nt, chunk_begin, chunk_end, project, m, match, match_id, normals,
+                             block_partials);
+}
+
+// The same iteration on a base handle that has seen DeletePoint: correspondence by the reference's
+// own walk of its patched tree (knn_xwalk.h; one target per lane, static assignment, no hints from
+// the previous iteration -- the tree may have changed in between), then the same phase 2.
+template <bool kMinDist, bool kPlane>
+__global__ __launch_bounds__(kIcpBlock) void icp_corr_xkernel(
+    XTreeView xv, const float *__restrict__ tx, const float *__restrict__ ty, const float *__restrict__ tz,
+    int64_t nt, const IcpState *__restrict__ state, IcpKernelParams kp, float4 *__restrict__ match,
+    double *__restrict__ block_partials, uint32_t *__restrict__ match_id, const float4 *__restrict__ normals,
+    int64_t guard) {
+  extern __shared__ uint32_t s_stack[];
+  if (state->done) return;  // uniform
+  uint32_t chunk_begin, chunk_end;
+  block_chunk_range(nt, blockIdx.x, gridDim.x, chunk_begin, chunk_end);
+  float m[16];
 #pragma unroll
-  for (int k = 0; k < NS; k++) acc[k] = 0.0;
+  for (int i = 0; i < 16; i++) m[i] = state->trans[i];
+  const bool project = state->iter > 0;
   const int64_t r_begin = (int64_t)chunk_begin * 64;
   int64_t r_end = (int64_t)chunk_end * 64;
   if (r_end > nt) r_end = nt;
   for (int64_t i = r_begin + threadIdx.x; i < r_end; i += kIcpBlock) {
-    const float4 bp = match[i];
-    if (bp.w >= 0.0f) {  // correspondence.go:27-29
-      float x0, y0, z0;
-      load_target(i, x0, y0, z0);
-      if (kPlane) {
-        const float4 nrm = normals[match_id[i]];
-        accumulate_plane_terms(acc, x0, y0, z0, bp, nrm);
-      } else {
-        accumulate_terms(acc, x0, y0, z0, bp);
-      }
+    float qx = tx[i], qy = ty[i], qz = tz[i];
+    if (project) {
+      float px, py, pz;
+      mat4_transform(m, qx, qy, qz, px, py, pz);
+      qx = px; qy = py; qz = pz;
     }
+    float4 best = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+    float best_d = kp.max_dist_sq;
+    xwalk(
+        xv, s_stack + threadIdx.x, kIcpBlock, qx, qy, qz, guard, [&]() { return best_d; },
+        [&](const float4 &nd, float d) {  // kdtree.go:95-106
+          if (!(d > best_d)) {
+            best = nd;
+            best_d = d;
+          }
+          return !(kMinDist && best_d < kp.min_dist_sq);
+        },
+        [&](const float4 &nd, float d) {  // kdtree.go:116-123
+          if (d < best_d) {
+            best = nd;
+            best_d = d;
+            if (kMinDist && best_d < kp.min_dist_sq) return false;
+          }
+          return true;
+        });
+    match[i] = make_float4(best.x, best.y, best.z, __float_as_int(best.w) >= 0 ? best_d : -1.0f);
+    if (kPlane) match_id[i] = __float_as_uint(best.w);
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double(*s_red)[NS] = reinterpret_cast<double(*)[NS]>(s_stack);
-#pragma unroll
-  for (int k = 0; k < NS; k++) {
-    double v = wave_sum_f64(acc[k]);
-    if (lane == 0) s_red[wave][k] = v;
-  }
+  __threadfence_block();
   __syncthreads();
-  if (threadIdx.x < NS) {
-    double v = 0.0;
-    for (int w = 0; w < kIcpBlock / 64; w++) v += s_red[w][threadIdx.x];
-    block_partials[(int64_t)blockIdx.x * NS + threadIdx.x] = v;
-  }
+  reduce_block_range<kPlane>(s_stack, tx, ty, tz, nt, chunk_begin, chunk_end, project, m, match, match_id, normals,
+                             block_partials);
 }
 
 // Evaluate tail (evaluator.go:92-105,156-186) + Update (updater.go:44-71) + the loop
@@ -429,6 +496,7 @@ using namespace pcgx;
 
 struct pcgx_icp_session {
   const pcgx_kdtree *base = nullptr;
+  bool patched = false;  // base had deletions at creation: walk its patched explicit tree (icp_corr_xkernel)
   int64_t nt = 0;
   float *d_xyz = nullptr;  // SoA: x[nt] | y[nt] | z[nt], Morton order of the original target
   IcpState *d_state = nullptr;
@@ -570,13 +638,15 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
   PCGX_TRY(ensure_init());
   hipStream_t st = ctx().stream;
   const int64_t n_base_ids = base->n;  // normals are indexed by the original ids
-  bool empty = false;
-  PCGX_TRY(resolve_tree(base, &base, &empty));  // after DeletePoint: the tree over the remaining points
-  if (empty)  // no node left: Pairs() finds nothing (correspondence.go:27-29 with kdtree.go:84-86)
+  // after DeletePoint the handle holds the reference's patched tree: the session walks that one
+  // (knn_explicit.hip); no node left: Pairs() finds nothing (correspondence.go:27-29, kdtree.go:84-86)
+  const bool patched = base->n_deleted > 0;
+  if (patched && base->n_deleted >= base->n)
     return fail(PCGX_E_NOT_ENOUGH_PAIRS, "not enough correspondence pairs (every base point was deleted)");
   pcgx_icp_session *s = new pcgx_icp_session();
   s->base = base;
-  const_cast<pcgx_kdtree *>(base)->sessions.fetch_add(1);  // keeps a rebuilt tree alive (resolve_tree)
+  s->patched = patched;
+  const_cast<pcgx_kdtree *>(base)->sessions.fetch_add(1);
   s->nt = nt;
   s->plane = normals != nullptr;
   if (const char *e = getenv("PCGX_ICP_STRICT")) s->strict = !s->plane && e[0] == '1';
@@ -685,8 +755,29 @@ static int icp_knob(const char *name, int def, int lo, int hi) {
   return def;
 }
 
+static pcgx_status enqueue_corr_patched(pcgx_icp_session *s, hipStream_t st) {
+  XTreeView xv;
+  PCGX_TRY(xtree_view(s->base, &xv, st));
+  const size_t lds = (size_t)(xv.depth > 1 ? xv.depth : 2) * kIcpBlock * sizeof(uint32_t);
+  const int64_t guard = 4 * s->base->n + 8;
+  const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
+  ProfScope prof(PCGX_PROF_ICP_WALK, st);
+  if (s->plane)
+    hipLaunchKernelGGL((icp_corr_xkernel<false, true>), dim3(s->grid), dim3(kIcpBlock), lds, st, xv, x, y, z, s->nt,
+                       s->d_state, s->kp, s->d_match, s->d_partials, s->d_match_id, (const float4 *)s->d_normals, guard);
+  else if (s->kp.min_dist_sq > 0.0f)
+    hipLaunchKernelGGL((icp_corr_xkernel<true, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, xv, x, y, z, s->nt,
+                       s->d_state, s->kp, s->d_match, s->d_partials, (uint32_t *)nullptr, (const float4 *)nullptr, guard);
+  else
+    hipLaunchKernelGGL((icp_corr_xkernel<false, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, xv, x, y, z, s->nt,
+                       s->d_state, s->kp, s->d_match, s->d_partials, (uint32_t *)nullptr, (const float4 *)nullptr, guard);
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
 static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   static const int tight = icp_knob("PCGX_ICP_TIGHT", 32, 0, 32), chunks = icp_knob("PCGX_ICP_CHUNKS", 2, 1, 64);
+  if (s->patched) return enqueue_corr_patched(s, st);
   TreeView tv = s->base->view();
   tv.tight_levels = tight;
   tv.chunks_per_refill = chunks;

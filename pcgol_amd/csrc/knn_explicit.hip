@@ -18,65 +18,9 @@
 
 #include <vector>
 
-#include "knn_walk.h"
+#include "knn_xwalk.h"
 
 namespace pcgx {
-
-struct XTreeView {
-  const float4 *pts;   // [n] {x, y, z, bits(id)} of node k
-  const int4 *links;   // [n] {child0, child1, dim, -}; -1 = nil
-  int32_t root;        // -1: empty tree
-  int32_t depth;       // frames a walk may need
-};
-
-constexpr int kXBlock = 256;
-
-// frame word: node index (27 bits) | side taken << 27
-// visit: called for every leaf / pivot the reference evaluates, in its order; returns false to stop
-// (MinDistSq cut).  bound(): current pruning bound (best.d for Nearest, maxRange^2 for Range).
-template <class Bound, class Leaf, class Pivot>
-__device__ __forceinline__ void xwalk(const XTreeView &xv, uint32_t *__restrict__ stk, const int stk_stride,
-                                      const float qx, const float qy, const float qz, int64_t guard, Bound &&bound,
-                                      Leaf &&on_leaf, Pivot &&on_pivot) {
-  if (xv.root < 0) return;
-  int32_t cur = xv.root, sp = 0;
-  bool desc = true;
-  for (; guard > 0; --guard) {
-    if (desc) {
-      // searchLeafNode step (kdtree.go:202-221)
-      const int4 lk = xv.links[cur];
-      const float4 nd = xv.pts[cur];
-      if (lk.x < 0 && lk.y < 0) {  // no children: the leaf of this descent
-        const float dx = nd.x - qx, dy = nd.y - qy, dz = nd.z - qz;
-        if (!on_leaf(__float_as_int(nd.w), (dx * dx + dy * dy) + dz * dz)) return;
-        desc = false;
-        continue;
-      }
-      int side;
-      if (lk.x < 0) side = 1;        // only child1
-      else if (lk.y < 0) side = 0;   // only child0
-      else side = sel3(lk.z, nd.x, nd.y, nd.z) > sel3(lk.z, qx, qy, qz) ? 0 : 1;  // pivotVal > val -> child0
-      stk[(sp++) * stk_stride] = (uint32_t)cur | ((uint32_t)side << 27);
-      cur = side ? lk.y : lk.x;
-    } else {
-      if (sp == 0) return;
-      const uint32_t fw = stk[(--sp) * stk_stride];
-      const int32_t n = (int32_t)(fw & 0x07FFFFFFu);
-      const int side = (int)(fw >> 27);
-      const int4 lk = xv.links[n];
-      const float4 nd = xv.pts[n];
-      const float fp = sel3(lk.z, qx, qy, qz) - sel3(lk.z, nd.x, nd.y, nd.z);  // p[dim] - pivot[dim]
-      if (fp * fp > bound()) continue;  // kdtree.go:111-115 / :173-177
-      const float dx = nd.x - qx, dy = nd.y - qy, dz = nd.z - qz;
-      if (!on_pivot(__float_as_int(nd.w), (dx * dx + dy * dy) + dz * dz)) return;
-      const int32_t other = side ? lk.x : lk.y;  // the child that is not on the stack (:124-132)
-      if (other >= 0) {
-        cur = other;
-        desc = true;
-      }
-    }
-  }
-}
 
 template <bool kMinDist>
 __global__ __launch_bounds__(kXBlock) void xnearest_kernel(XTreeView xv, const float *__restrict__ q,
@@ -93,16 +37,16 @@ __global__ __launch_bounds__(kXBlock) void xnearest_kernel(XTreeView xv, const f
   float best_d = max_range_sq;  // root == nil or nothing in range: {-1, maxRange^2} (kdtree.go:84-86,100-103)
   xwalk(
       xv, s_stack + threadIdx.x, kXBlock, qx, qy, qz, guard, [&]() { return best_d; },
-      [&](int32_t id, float d) {  // leaf: replaces unless d > best (kdtree.go:95-103,138-139)
+      [&](const float4 &nd, float d) {  // leaf: replaces unless d > best (kdtree.go:95-103,138-139)
         if (!(d > best_d)) {
-          best_id = id;
+          best_id = __float_as_int(nd.w);
           best_d = d;
         }
         return !(kMinDist && best_d < min_dist_sq);  // :104-106 (checked on DistSq alone), :140-142
       },
-      [&](int32_t id, float d) {  // pivot: strict < (kdtree.go:116-123)
+      [&](const float4 &nd, float d) {  // pivot: strict < (kdtree.go:116-123)
         if (d < best_d) {
-          best_id = id;
+          best_id = __float_as_int(nd.w);
           best_d = d;
           if (kMinDist && best_d < min_dist_sq) return false;
         }
@@ -129,10 +73,10 @@ __global__ __launch_bounds__(kXBlock) void xrange_kernel(XTreeView xv, const flo
   const int64_t out0 = kFill ? offsets[i] : 0;
   const int64_t cap = kFill ? offsets[i + 1] - out0 : 0;
   const bool slice_ok = kFill && out0 >= 0 && cap >= 0 && out0 + cap <= total;
-  auto hit = [&](int32_t id, float d) {
+  auto hit = [&](const float4 &nd, float d) {
     if (d < bound) {  // kdtree.go:166-169,178-181
       if (kFill && slice_ok && found < cap) {
-        out_id[out0 + found] = id;
+        out_id[out0 + found] = __float_as_int(nd.w);
         out_key[out0 + found] = __float_as_uint(d);
         out_query[out0 + found] = (uint32_t)i;
       }
@@ -274,8 +218,9 @@ void xtree_free(pcgx_kdtree *t) {
   t->d_xlinks = nullptr;
 }
 
+namespace pcgx {
 // Device copy of the patched tree (uploaded again after further deletions).
-static pcgx_status xtree_view(const pcgx_kdtree *tc, XTreeView *xv, hipStream_t st) {
+pcgx_status xtree_view(const pcgx_kdtree *tc, XTreeView *xv, hipStream_t st) {
   pcgx_kdtree *t = const_cast<pcgx_kdtree *>(tc);
   std::lock_guard<std::mutex> lock(t->mu);
   if (!t->x_init) return fail(PCGX_E_INVALID, "explicit tree requested for a handle without deletions");
@@ -306,6 +251,7 @@ static pcgx_status xtree_view(const pcgx_kdtree *tc, XTreeView *xv, hipStream_t 
   xv->depth = t->depth;
   return PCGX_OK;
 }
+}  // namespace pcgx
 
 pcgx_status xtree_launch_nearest(const pcgx_kdtree *t, const float *d_q, const int32_t *d_perm, int64_t nq,
                                  float max_range_sq, float min_dist_sq, int32_t *d_ids, float *d_dsq, hipStream_t st) {

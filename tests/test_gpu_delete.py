@@ -157,6 +157,57 @@ def test_delete_third_then_nearest_equals_oracle_and_naive(n, seed):
     assert sorted(t.InOrder().tolist()) == keep.tolist()
 
 
+@pytest.mark.parametrize("min_dist_sq", [0.0, 0.6])
+def test_delete_then_icp_pairs_on_a_lattice_equal_the_reference_walk(min_dist_sq):
+    """Targets on lattice and half-lattice positions: most have several base points at exactly the
+    same distance, so the pair the Corresponder reports depends on the patched tree's shape and the
+    walk's visit order (correspondence.go:22-37 over kdtree.go:83-146).  Ids and DistSq must be the
+    oracle's, pair for pair; so must the float64 sums of one Evaluate and a whole strict Fit."""
+    pts = _lattice(14, 6)
+    n = len(pts)
+    t = kdtree.New(pts).With(MinDistSq=min_dist_sq) if min_dist_sq else kdtree.New(pts)
+    o = O.KDTree(pts, min_dist_sq)
+    gone = np.random.default_rng(12).permutation(n)[: n // 3]
+    t.DeletePoints(gone)
+    for i in gone:
+        o.delete_point(int(i))
+    rng = np.random.default_rng(13)
+    target = rng.integers(0, 27, (20000, 3)).astype(f32) * f32(0.5)
+    b, ti, d = icp.NearestPointCorresponder(MaxDist=1.6).PairsArrays(t, target)
+    ob, ot, od = O.icp_pairs(o, target, 1.6)
+    assert np.array_equal(ti, ot) and np.array_equal(b, ob) and np.array_equal(d, od)
+    assert not np.isin(b, gone).any()
+    e = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=1.6), MinPairs=6)
+    ev = e.Evaluate(t, target)
+    oe = O.icp_evaluate(o, target, 1.6, 6, sums_mode=1)
+    assert ev.NumPairs == oe["npairs"]
+    assert abs(float(ev.Value) - float(oe["value"])) <= 1e-6 * float(oe["value"])
+    assert np.allclose(ev.Gradient, oe["gradient"], rtol=1e-5, atol=1e-6)
+
+
+def test_delete_then_strict_fit_is_the_reference_fit_bit_for_bit():
+    """A whole Fit (icp.go:24-72) on a handle with deletions, strict sums: the pose after every
+    iteration depends on every pair, so equality of the final transform pins the patched walk."""
+    c = synth.c4_icp(n=8000, width=1.9)
+    t, o = kdtree.New(c["base"]), O.KDTree(c["base"])
+    gone = np.arange(0, 8000, 4)
+    t.DeletePoints(gone)
+    for i in gone:
+        o.delete_point(int(i))
+    sess = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
+                          c["max_iteration"])
+    sess.set_strict(True)
+    for _ in range(c["max_iteration"]):
+        sess.step()
+    trans, stat, conv = sess.result()
+    sess.close()
+    of = O.icp_fit(o, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
+                   c["max_iteration"], sums_mode=0)
+    assert stat.NumIteration == of["num_iteration"]
+    assert np.array_equal(trans, of["trans"])
+    assert stat.Evaluated.Value == of["value"] and np.array_equal(stat.Evaluated.Gradient, of["gradient"])
+
+
 def test_delete_then_icp_uses_remaining_points():
     c = synth.c4_icp(n=20000, width=2.7)
     t, o = kdtree.New(c["base"]), O.KDTree(c["base"])
@@ -173,8 +224,9 @@ def test_delete_then_icp_uses_remaining_points():
 
 
 def test_many_delete_query_cycles_with_an_open_session():
-    """Every cycle rebuilds the tree of the remaining points; replaced trees are freed unless an ICP
-    session still walks them (it keeps answering on the tree it was created on)."""
+    """Every cycle patches the tree further and uploads it again; a session created on a handle that
+    already had deletions walks the handle's current patched tree, like an Evaluate call on the
+    reference's KDTree would."""
     n = 40000
     pts = synth.uniform_cloud(n, 5.0, 91)
     q = synth.uniform_cloud(500, 5.0, 92)
@@ -182,9 +234,11 @@ def test_many_delete_query_cycles_with_an_open_session():
     t.DeletePoints(np.arange(0, 100))
     for i in range(100):
         o.delete_point(i)
-    sess = icp.IcpSession(t, q, 1.0, 6)  # on the tree without points 0..99
+    early = icp.IcpSession(kdtree.New(pts), q, 1.0, 6)  # a handle without deletions: the implicit tree
+    sess = icp.IcpSession(t, q, 1.0, 6)  # on the patched tree without points 0..99
     sess.partials()
     sums_before = sess.read_sums()
+    assert np.allclose(sums_before, O.icp_evaluate(o, q, 1.0, 6, sums_mode=1)["raw10"], rtol=1e-12, atol=0)
     rng = np.random.default_rng(5)
     for cycle in range(25):
         gone = rng.choice(n, 200, replace=False)
@@ -196,5 +250,11 @@ def test_many_delete_query_cycles_with_an_open_session():
         assert np.array_equal(ids, oi) and np.array_equal(dsq, od), cycle
     sess.set_pose(np.eye(4, dtype=f32).reshape(-1), 0)
     sess.partials()
-    assert np.array_equal(sess.read_sums(), sums_before)  # the session's tree is untouched
+    now = sess.read_sums()
+    want = O.icp_evaluate(o, q, 1.0, 6, sums_mode=1)["raw10"]
+    assert now[9] == want[9] and not np.array_equal(now, sums_before)  # it saw the later deletions
+    assert np.allclose(now, want, rtol=1e-12, atol=0)
+    early.partials()
+    assert early.read_sums()[9] == 500
+    early.close()
     sess.close()
