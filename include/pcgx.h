@@ -95,6 +95,12 @@ PCGX_API pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_
                                            int32_t presort, const float *d_hint_xyz, uint32_t *d_leaf_io,
                                            uint64_t stats32[32]);
 
+/* Tuning aid (not part of the drop-in surface): out = {queries of the batch the grid pass leaves to
+ * the tree walk, grid cells, 1000 x mean number of other points in a point's cell, grid in use, -,
+ * queries per reason 1..7 (csrc/knn_grid.h)}. */
+PCGX_API pcgx_status pcgx_debug_grid_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
+                                           int64_t out[12]);
+
 /* Device memory helpers for hosts that have no HIP binding of their own. */
 PCGX_API pcgx_status pcgx_dev_alloc(size_t bytes, void **dptr);
 PCGX_API pcgx_status pcgx_dev_free(void *dptr);

@@ -136,6 +136,7 @@ SIGNATURES = {
     "pcgx_kdtree_max_depth": (_i32, [_vp, C.POINTER(_i32)]),
     "pcgx_kdtree_inorder": (_i32, [_vp, _vp]),
     "pcgx_kdtree_points": (_i32, [_vp, _vp, _i64, _vp]),
+    "pcgx_debug_grid_stats": (_i32, [_vp, _vp, _i64, C.c_float, C.POINTER(_i64)]),
     "pcgx_kdtree_dump": (_i32, [_vp, _vp, _i64, C.POINTER(_i64)]),
     "pcgx_kdtree_delete_points": (_i32, [_vp, _vp, _i64]),
     "pcgx_kdtree_live_count": (_i32, [_vp, C.POINTER(_i64)]),

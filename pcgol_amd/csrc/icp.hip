@@ -13,6 +13,7 @@
 
 #include <vector>
 
+#include "knn_grid.h"
 #include "knn_xwalk.h"
 
 namespace pcgx {
@@ -82,14 +83,17 @@ __device__ __forceinline__ void accumulate_plane_terms(double *acc, float x0, fl
 // Phase 2 of the correspondence kernels (evaluator.go:122-145): the workgroup streams the targets of
 // its own chunk range in a fixed thread assignment and accumulates the evaluator's sums in float64;
 // s_scratch: >= (kIcpBlock / 64) * NS doubles of LDS no longer in use.
-template <bool kPlane>
+template <bool kPlane, bool kFlagged = false>
 __device__ __forceinline__ void reduce_block_range(uint32_t *s_scratch, const float *__restrict__ tx,
                                                    const float *__restrict__ ty, const float *__restrict__ tz,
                                                    int64_t nt, uint32_t chunk_begin, uint32_t chunk_end, bool project,
                                                    const float (&m)[16], const float4 *__restrict__ match,
                                                    const uint32_t *__restrict__ match_id,
                                                    const float4 *__restrict__ normals,
-                                                   double *__restrict__ block_partials) {
+                                                   double *__restrict__ block_partials,
+                                                   uint32_t *__restrict__ flags = nullptr, double extra = 0.0) {
+  // extra: added to component threadIdx.x of the row (threads < NS)
+  // kFlagged: only the targets whose flags[] word has bit 31 set (cleared here)
   constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
   double acc[NS];
 #pragma unroll
@@ -98,6 +102,11 @@ __device__ __forceinline__ void reduce_block_range(uint32_t *s_scratch, const fl
   int64_t r_end = (int64_t)chunk_end * 64;
   if (r_end > nt) r_end = nt;
   for (int64_t i = r_begin + threadIdx.x; i < r_end; i += kIcpBlock) {
+    if (kFlagged) {
+      const uint32_t f = flags[i];
+      if (!(f >> 31)) continue;
+      flags[i] = f & 0x7fffffffu;
+    }
     const float4 bp = match[i];
     if (bp.w >= 0.0f) {  // correspondence.go:27-29
       float x0 = tx[i], y0 = ty[i], z0 = tz[i];
@@ -125,7 +134,7 @@ __device__ __forceinline__ void reduce_block_range(uint32_t *s_scratch, const fl
   if (threadIdx.x < NS) {
     double v = 0.0;
     for (int w = 0; w < kIcpBlock / 64; w++) v += s_red[w][threadIdx.x];
-    block_partials[(int64_t)blockIdx.x * NS + threadIdx.x] = v;
+    block_partials[(int64_t)blockIdx.x * NS + threadIdx.x] = v + extra;
   }
 }
 
@@ -142,14 +151,20 @@ __device__ __forceinline__ void reduce_block_range(uint32_t *s_scratch, const fl
 // walk hands queries to lanes dynamically.
 // kPlane: match_id[i] additionally records the matched base id; the reduction gathers that
 // point's normal (normals[id], float4 per base point in id order) and accumulates the 30 sums.
-template <bool kMinDist, bool kPlane>
+// kGrid (exact mode only): icp_grid_kernel ran before and answered every target the uniform grid
+// could certify (knn_grid.h); only the rest (walk_list, this workgroup's segment, walk_count[slot]
+// entries) is walked here.
+constexpr int kIcpGridBlock = 256;
+
+template <bool kMinDist, bool kPlane, bool kGrid>
 __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     TreeView tv, const float *__restrict__ tx, const float *__restrict__ ty,
     const float *__restrict__ tz, int64_t nt, const IcpState *__restrict__ state,
     IcpKernelParams kp, float4 *__restrict__ match, uint32_t *__restrict__ first_leaf,
     double *__restrict__ block_partials, uint32_t *__restrict__ match_id,
-    const float4 *__restrict__ normals) {
-  constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
+    const float4 *__restrict__ normals, uint32_t *__restrict__ walk_list, uint32_t *__restrict__ walk_count,
+    int32_t n_grid_rows) {
+  static_assert(!(kGrid && kMinDist), "the grid answers exact-mode queries only");
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
   if (state->done) return;  // uniform
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     float4 pm = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
     pred = 0u;
     if (project) {  // uniform
-      pred = first_leaf[i];
+      pred = first_leaf[i] & 0x7fffffffu;
       if (!kMinDist) pm = match[i];
     }
     x = x0; y = y0; z = z0;
@@ -192,20 +207,130 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     const float dm = (dx * dx + dy * dy) + dz * dz;
     ub = dm + (pm.w >= 0.0f ? 0.0f : __builtin_inff());
   };
-  walk_queries<kMinDist>(
-      tv, s_stack + threadIdx.x, kIcpBlock, queue, top, nt, &s_next_chunk, chunk_end, (int64_t)chunk_begin * 64,
-      kp.max_dist_sq, kp.min_dist_sq, load_query,
-      [&](int64_t i, const float4 &bp, float best_d) {
-        match[i] = make_float4(bp.x, bp.y, bp.z, __float_as_int(bp.w) >= 0 ? best_d : -1.0f);
-        if (kPlane) match_id[i] = __float_as_uint(bp.w);
-      },
-      [&](int64_t i, uint32_t leaf) { first_leaf[i] = leaf; });
+  auto emit = [&](int64_t i, const float4 &bp, float best_d) {
+    match[i] = make_float4(bp.x, bp.y, bp.z, __float_as_int(bp.w) >= 0 ? best_d : -1.0f);
+    if (kPlane) match_id[i] = __float_as_uint(bp.w);
+  };
+  if (kGrid) {
+    // icp_grid_kernel answered what the grid could certify and summed those terms; this workgroup
+    // walks what was left in its segment of walk_list (usually nothing) and sums the terms of
+    // exactly those targets (flag in first_leaf[], bit 31) in the fixed order of its range
+    constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
+    const int64_t r_begin = (int64_t)chunk_begin * 64;
+    const uint32_t slot = block_slot(blockIdx.x, gridDim.x);
+    const uint32_t left = walk_count[slot];  // uniform
+    // this workgroup's share of icp_grid_kernel's rows, folded into its own row (fixed order)
+    double grid_part = 0.0;
+    if (threadIdx.x < NS) {
+      const int64_t g0 = (int64_t)n_grid_rows * blockIdx.x / gridDim.x, g1 = (int64_t)n_grid_rows * (blockIdx.x + 1) / gridDim.x;
+      for (int64_t r = g0; r < g1; r++) grid_part += block_partials[((int64_t)gridDim.x + r) * NS + threadIdx.x];
+    }
+    if (left == 0) {
+      if (threadIdx.x < NS) block_partials[(int64_t)blockIdx.x * NS + threadIdx.x] = grid_part;
+      return;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      walk_count[slot] = 0;  // for the next iteration's grid pass
+      s_next_chunk = 0;
+    }
+    __syncthreads();
+    walk_queries<kMinDist>(
+        tv, s_stack + threadIdx.x, kIcpBlock, queue, top, (int64_t)left, &s_next_chunk, (left + 63u) / 64u, 0,
+        kp.max_dist_sq, kp.min_dist_sq,
+        [&](int64_t j, float &x, float &y, float &z, float &ub, uint32_t &pred) {
+          load_query(r_begin + walk_list[r_begin + j], x, y, z, ub, pred);
+          pred &= 0x7fffffffu;
+        },
+        [&](int64_t j, const float4 &bp, float best_d) { emit(r_begin + walk_list[r_begin + j], bp, best_d); },
+        [&](int64_t j, uint32_t leaf) { first_leaf[r_begin + walk_list[r_begin + j]] = leaf | 0x80000000u; });
+    __threadfence_block();
+    __syncthreads();
+    reduce_block_range<kPlane, true>(s_stack, tx, ty, tz, nt, chunk_begin, chunk_end, project, m, match, match_id,
+                                     normals, block_partials, first_leaf, grid_part);
+    return;
+  } else {
+    walk_queries<kMinDist>(
+        tv, s_stack + threadIdx.x, kIcpBlock, queue, top, nt, &s_next_chunk, chunk_end, (int64_t)chunk_begin * 64,
+        kp.max_dist_sq, kp.min_dist_sq, load_query, emit, [&](int64_t i, uint32_t leaf) { first_leaf[i] = leaf; });
+  }
 
   // ---- phase 2: this workgroup's range, fixed order
   __threadfence_block();
   __syncthreads();  // all match[] of the range are written; stacks / queues are free for reuse
   reduce_block_range<kPlane>(s_stack, tx, ty, tz, nt, chunk_begin, chunk_end, project, m, match, match_id, normals,
                              block_partials);
+}
+
+// Grid pass of an iteration (exact mode): one target per lane asks the uniform grid (knn_grid.h)
+// with the distance to its previous match as bound.  Certified answers go to match[] (the same
+// record the walk writes) and, in the lanes' fixed order, into this workgroup's row of partial sums
+// (rows n_corr_blocks .. of block_partials).  The others are flagged in first_leaf[] (bit 31) and
+// queued in the walk_list segment of the icp_corr_kernel workgroup (n_corr_blocks of them) that owns
+// the target; that kernel walks them and adds their terms to ITS row.
+template <bool kPlane>
+__global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
+    GridView grid, const float *__restrict__ tx, const float *__restrict__ ty, const float *__restrict__ tz, int64_t nt,
+    const IcpState *__restrict__ state, IcpKernelParams kp, float4 *__restrict__ match,
+    uint32_t *__restrict__ match_id, const float4 *__restrict__ normals, uint32_t *__restrict__ first_leaf,
+    uint32_t *__restrict__ walk_list, uint32_t *__restrict__ walk_count, uint32_t n_corr_blocks,
+    double *__restrict__ block_partials) {
+  constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
+  __shared__ float s_terms[NS][kIcpGridBlock];
+  if (state->done) return;  // uniform
+  const int64_t i = (int64_t)blockIdx.x * kIcpGridBlock + threadIdx.x;
+  double acc[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++) acc[k] = 0.0;
+  if (i < nt) {
+    const bool project = state->iter > 0;  // icp.go:27-30
+    float x = tx[i], y = ty[i], z = tz[i];
+    float ub = __builtin_inff();
+    if (project) {
+      const float4 pm = match[i];  // previous iteration's pair (w = NaN before the first one)
+      const float *m = state->trans;
+      float px, py, pz;
+      mat4_transform(m, x, y, z, px, py, pz);
+      x = px; y = py; z = pz;
+      const float dx = pm.x - x, dy = pm.y - y, dz = pm.z - z;
+      const float dm = (dx * dx + dy * dy) + dz * dz;
+      if (pm.w >= 0.0f && dm == dm) ub = dm;
+    }
+    float4 best = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+    float best_d = kp.max_dist_sq;
+    const GridVerdict v = grid_nearest(grid, x, y, z, kp.max_dist_sq, ub, best, best_d);
+    if (v == GRID_WALK) {
+      uint32_t begin;
+      const uint32_t slot = slot_of_query(nt, i, n_corr_blocks, begin);
+      const int64_t r_begin = (int64_t)begin * 64;
+      walk_list[r_begin + atomicAdd(&walk_count[slot], 1u)] = (uint32_t)(i - r_begin);
+      first_leaf[i] = 0x80000000u;  // "walked this iteration" (icp_corr_kernel adds its terms)
+    } else {
+      const bool found = __float_as_int(best.w) >= 0;
+      const float4 bp = make_float4(best.x, best.y, best.z, found ? best_d : -1.0f);
+      match[i] = bp;
+      if (kPlane) match_id[i] = __float_as_uint(best.w);
+      if (found) {  // correspondence.go:27-29
+        if (kPlane) accumulate_plane_terms(acc, x, y, z, bp, normals[__float_as_uint(best.w)]);
+        else accumulate_terms(acc, x, y, z, bp);
+      }
+    }
+  }
+  // every lane holds the float32 terms of (at most) one pair: through LDS, component k is added
+  // up by kSub lanes over contiguous runs of targets, then across those lanes -- a fixed order
+  constexpr int kSub = kPlane ? 8 : 16, kRun = kIcpGridBlock / kSub;
+  static_assert(NS * kSub <= kIcpGridBlock, "one lane per (component, run)");
+#pragma unroll
+  for (int k = 0; k < NS; k++) s_terms[k][threadIdx.x] = (float)acc[k];  // exact: acc[k] is one float32 term or 0
+  __syncthreads();
+  if (threadIdx.x < NS * kSub) {
+    const int k = threadIdx.x / kSub, j = threadIdx.x % kSub;
+    double v = 0.0;
+    for (int u = 0; u < kRun; u++) v += (double)s_terms[k][j * kRun + u];
+#pragma unroll
+    for (int o = kSub / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kSub);
+    if (j == 0) block_partials[((int64_t)n_corr_blocks + blockIdx.x) * NS + k] = v;
+  }
 }
 
 // The same iteration on a base handle that has seen DeletePoint: correspondence by the reference's
@@ -508,6 +633,8 @@ struct pcgx_icp_session {
   int64_t nt_pad = 0;
   float4 *d_match = nullptr;       // [nt] matched base point + DistSq per target
   uint32_t *d_first_leaf = nullptr;  // [nt] leaf the target's first descent ended in (0: unknown)
+  uint32_t *d_walk_list = nullptr;   // [nt] per workgroup segment: targets the grid pass left to the walk
+  uint32_t *d_walk_count = nullptr;  // [grid] entries in each segment (zero between iterations)
   double *d_sums = nullptr;  // caller's buffer, or own
   bool own_sums = false;
   bool plane = false;              // point-to-plane / Gauss-Newton session (30 sums)
@@ -618,6 +745,8 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   dev_cache_free(s->d_valid);
   dev_cache_free(s->d_match);
   dev_cache_free(s->d_first_leaf);
+  dev_cache_free(s->d_walk_list);
+  dev_cache_free(s->d_walk_count);
   dev_cache_free(s->d_match_id);
   dev_cache_free(s->d_normals);
   if (s->own_sums) dev_cache_free(s->d_sums);
@@ -662,10 +791,13 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
   hipError_t e;
   if ((e = dev_cache_alloc((void **)&s->d_xyz, (size_t)(nt ? nt : 1) * 12)) != hipSuccess ||
       (e = dev_cache_alloc((void **)&s->d_state, sizeof(IcpState))) != hipSuccess ||
-      (e = dev_cache_alloc((void **)&s->d_partials, (size_t)s->grid * s->n_sums() * sizeof(double))) != hipSuccess ||
+      (e = dev_cache_alloc((void **)&s->d_partials,
+                           ((size_t)s->grid + (size_t)(nt / kIcpGridBlock) + 1) * s->n_sums() * sizeof(double))) != hipSuccess ||
       (e = dev_cache_alloc((void **)&s->d_pos_of, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
       (e = dev_cache_alloc((void **)&s->d_match, (size_t)(nt ? nt : 1) * sizeof(float4))) != hipSuccess ||
-      (e = dev_cache_alloc((void **)&s->d_first_leaf, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess)
+      (e = dev_cache_alloc((void **)&s->d_first_leaf, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
+      (e = dev_cache_alloc((void **)&s->d_walk_list, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
+      (e = dev_cache_alloc((void **)&s->d_walk_count, (size_t)s->grid * sizeof(uint32_t))) != hipSuccess)
     return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
   if (d_sums) {
     s->d_sums = d_sums;
@@ -697,7 +829,8 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
   if ((rc = reset_state(s, st)) != PCGX_OK) return bail(rc);
   // no previous match yet: w = NaN (icp_corr_kernel takes pruning hints from match[] only when w >= 0)
   if ((e = hipMemsetAsync(s->d_match, 0xFF, (size_t)(nt ? nt : 1) * sizeof(float4), st)) != hipSuccess ||
-      (e = hipMemsetAsync(s->d_first_leaf, 0, (size_t)(nt ? nt : 1) * sizeof(uint32_t), st)) != hipSuccess)
+      (e = hipMemsetAsync(s->d_first_leaf, 0, (size_t)(nt ? nt : 1) * sizeof(uint32_t), st)) != hipSuccess ||
+      (e = hipMemsetAsync(s->d_walk_count, 0, (size_t)s->grid * sizeof(uint32_t), st)) != hipSuccess)
     return bail(fail(PCGX_E_HIP, "icp session: hipMemsetAsync failed: %s", hipGetErrorString(e)));
   if (nt > 0) {
     Arena &ar = ctx().arena;
@@ -784,18 +917,33 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   const size_t lds = walk_lds_bytes(tv, kIcpBlock);
   const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
   ProfScope prof(PCGX_PROF_ICP_WALK, st);
-  if (s->plane)
-    hipLaunchKernelGGL((icp_corr_kernel<false, true>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                       s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, s->d_match_id,
-                       (const float4 *)s->d_normals);
-  else if (s->kp.min_dist_sq > 0.0f)
-    hipLaunchKernelGGL((icp_corr_kernel<true, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                       s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, (uint32_t *)nullptr,
-                       (const float4 *)nullptr);
-  else
-    hipLaunchKernelGGL((icp_corr_kernel<false, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,
-                       s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, (uint32_t *)nullptr,
-                       (const float4 *)nullptr);
+  const bool grid = grid_enabled(s->base) && !(s->kp.min_dist_sq > 0.0f) && s->nt > 0;
+  if (grid) {
+    const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
+    if (s->plane)
+      hipLaunchKernelGGL(icp_grid_kernel<true>, dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
+                         s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
+                         s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
+    else
+      hipLaunchKernelGGL(icp_grid_kernel<false>, dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
+                         s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
+                         s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
+  }
+#define PCGX_LAUNCH_CORR(MD, PL, GR)                                                                                  \
+  hipLaunchKernelGGL((icp_corr_kernel<MD, PL, GR>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,     \
+                     s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, s->d_match_id,                   \
+                     (const float4 *)s->d_normals, s->d_walk_list, s->d_walk_count,                                  \
+                     (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock))
+  if (s->plane) {
+    if (grid) PCGX_LAUNCH_CORR(false, true, true);
+    else PCGX_LAUNCH_CORR(false, true, false);
+  } else if (s->kp.min_dist_sq > 0.0f) {
+    PCGX_LAUNCH_CORR(true, false, false);
+  } else {
+    if (grid) PCGX_LAUNCH_CORR(false, false, true);
+    else PCGX_LAUNCH_CORR(false, false, false);
+  }
+#undef PCGX_LAUNCH_CORR
   return PCGX_OK;
 }
 

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "knn_grid.h"
 #include "knn_walk.h"
 
 namespace pcgx {
@@ -23,9 +24,14 @@ __global__ __launch_bounds__(kKnnBlock) void nearest_kernel(TreeView tv, const f
                                                             float *__restrict__ out_dsq,
                                                             unsigned long long *__restrict__ stats = nullptr,
                                                             const float *__restrict__ hint = nullptr,
-                                                            uint32_t *__restrict__ leaf_io = nullptr) {
+                                                            uint32_t *__restrict__ leaf_io = nullptr,
+                                                            const uint32_t *__restrict__ nq_dev = nullptr) {
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
+  if (nq_dev) {  // the queries perm[0 .. *nq_dev): what the grid pass left for the walk (knn_grid.hip)
+    nq = (int64_t)*nq_dev;
+    if (nq == 0) return;  // uniform
+  }
   uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kKnnBlock +
                     (threadIdx.x >> 6) * (kWalkQueueBytesPerWave / 4);
   float *top = reinterpret_cast<float *>(s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kKnnBlock +
@@ -189,6 +195,23 @@ pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *
   return PCGX_OK;
 }
 
+pcgx_status launch_nearest_listed(const TreeView &tv, const float *d_q, const int32_t *d_list,
+                                  const uint32_t *d_count, int64_t nq_max, float max_range_sq, int32_t *d_ids,
+                                  float *d_dsq, hipStream_t st) {
+  if (nq_max == 0) return PCGX_OK;
+  const size_t lds = walk_lds_bytes(tv, kKnnBlock);
+  int64_t blocks = (int64_t)ctx().num_cu * walk_blocks_per_cu(tv) * walk_oversubscribe();
+  const int64_t max_blocks = (nq_max + kKnnBlock - 1) / kKnnBlock;
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks >= 8) blocks &= ~(int64_t)7;
+  ProfScope prof(PCGX_PROF_KNN_WALK, st);
+  hipLaunchKernelGGL(nearest_kernel<false>, dim3((unsigned)blocks), dim3(kKnnBlock), lds, st, tv, d_q, d_list, nq_max,
+                     max_range_sq, 0.0f, d_ids, d_dsq, (unsigned long long *)nullptr, (const float *)nullptr,
+                     (uint32_t *)nullptr, d_count);
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
 }  // namespace pcgx
 
 using namespace pcgx;
@@ -266,6 +289,7 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
     blo[0] = l0; blo[1] = l1; blo[2] = l2;
     bhi[0] = h0; bhi[1] = h1; bhi[2] = h2;
     has_nan = nan_count != 0;
+    for (int k = 0; k < 3; k++) { t->bbox_lo[k] = blo[k]; t->bbox_hi[k] = bhi[k]; }
   }
   t->inorder.resize((size_t)n);
   const size_t slots = (size_t)1 << t->depth;
@@ -298,12 +322,14 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
       if (e != hipSuccess) rc = fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
     }
     if (rc == PCGX_OK) rc = build_tree_device(d_xyz, n, t->depth, d_order, t->d_nodes, d_labels, st);
+    if (rc == PCGX_OK) rc = grid_build(t, d_xyz, d_labels, st);  // has_nan is false here
     if (rc == PCGX_OK) {
       e = hipMemcpyAsync(t->inorder.data(), d_order, (size_t)n * 4, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
       if (e != hipSuccess) rc = fail(PCGX_E_HIP, "tree build failed: %s", hipGetErrorString(e));
     }
     if (rc != PCGX_OK) {
+      grid_free(t);
       dev_cache_free(t->d_nodes);
       delete t;
       return rc;
@@ -317,6 +343,28 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
       dev_cache_free(t->d_nodes);
       delete t;
       return fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
+    }
+    if (!has_nan) {  // the grid of the certified fast path (knn_grid.h)
+      hipStream_t st = ctx().stream;
+      Arena &ar = ctx().arena;
+      pcgx_status rc = ar.begin(st);
+      float *d_xyz = nullptr;
+      int32_t *d_labels = nullptr;
+      if (rc == PCGX_OK) rc = ar.alloc_n((size_t)n * 3, &d_xyz);
+      if (rc == PCGX_OK && labels) rc = ar.alloc_n((size_t)n, &d_labels);
+      if (rc == PCGX_OK) {
+        e = hipMemcpyAsync(d_xyz, t->points.data(), (size_t)n * 12, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && labels) e = hipMemcpyAsync(d_labels, labels, (size_t)n * 4, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) rc = fail(PCGX_E_HIP, "grid upload failed: %s", hipGetErrorString(e));
+      }
+      if (rc == PCGX_OK) rc = grid_build(t, d_xyz, d_labels, st);
+      if (rc == PCGX_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(PCGX_E_HIP, "grid build failed");
+      if (rc != PCGX_OK) {
+        grid_free(t);
+        dev_cache_free(t->d_nodes);
+        delete t;
+        return rc;
+      }
     }
   }
   // leaf directory: ~2 cells per point, at most 2^27 cells
@@ -369,6 +417,7 @@ extern "C" pcgx_status pcgx_kdtree_free(pcgx_kdtree *t) {
   if (t->live) pcgx_kdtree_free(t->live);
   for (pcgx_kdtree *r : t->retired) pcgx_kdtree_free(r);
   xtree_free(t);
+  grid_free(t);
   if (t->d_nodes) dev_cache_free(t->d_nodes);
   if (t->d_dir) dev_cache_free(t->d_dir);
   delete t;
@@ -514,14 +563,17 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch_dev(const pcgx_kdtree *t, const
     PCGX_HIP_TRY(hipGetLastError());
     return PCGX_OK;
   }
+  PCGX_TRY(ctx().arena.begin(st));
+  int32_t *perm = nullptr;
   if ((flags & PCGX_KNN_PRESORT) && nq > 1) {
-    PCGX_TRY(ctx().arena.begin(st));
-    int32_t *perm = nullptr;
     PCGX_TRY(ctx().arena.alloc_n((size_t)nq, &perm));
     PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, perm, st));
-    return launch_nearest(t->view(), d_q, perm, nq, max_range_sq, min_dist_sq, d_ids, d_dist_sq, st);
   }
-  return launch_nearest(t->view(), d_q, nullptr, nq, max_range_sq, min_dist_sq, d_ids, d_dist_sq, st);
+  // exact mode: answers the uniform grid can certify come from there, the rest from the walk
+  // (knn_grid.h); MinDistSq > 0 depends on the visit order: walk only
+  if (!(min_dist_sq > 0.0f) && grid_enabled(t))
+    return grid_launch_nearest(t, d_q, perm, nq, max_range_sq, d_ids, d_dist_sq, st);
+  return launch_nearest(t->view(), d_q, perm, nq, max_range_sq, min_dist_sq, d_ids, d_dist_sq, st);
 }
 
 extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const float *q, int64_t nq,

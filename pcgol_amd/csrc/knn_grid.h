@@ -1,0 +1,301 @@
+// knn_grid.h -- certified nearest neighbour on a uniform grid (fast path of KDTree.Nearest).
+//
+// Reference: pc/storage/kdtree/kdtree.go:83-146.  Nearest is an EXACT search: its pruning
+// (`fromPivotSq > best -> skip`, :111-115) never discards a point whose float32 DistSq is below the
+// best one (float subtraction, multiplication and addition of non-negative terms are monotonic, so a
+// point beyond a splitting plane has a computed DistSq >= the computed plane distance).  It therefore
+// returns the point with the smallest computed DistSq -- and WHICH of several points with exactly
+// the same DistSq only when there is such a tie, or when DistSq == maxRange^2 exactly (the leaf and
+// pivot rules differ there, :100-103 vs :117).  Any other exact search that evaluates DistSq with the
+// same expression returns the same {ID, DistSq}.
+//
+// So every tree also gets a uniform grid over its bounding box (~2 points per cell, points stored
+// in cell order).  A query scans the cells that can hold a point within its current bound (the
+// nearest point of its own cell, or the hint the ICP loop carries over), keeps the minimum and
+// whether it is tied, and accepts the result only when the scanned cells provably hold EVERY point
+// at or below that minimum (grid_cover: monotonic float binning, no tolerances).  Everything else --
+// ties, DistSq == maxRange^2, a search region beyond 3 x 3 x 5 cells, non-finite queries,
+// MinDistSq > 0 (approximate search, depends on the visit order) -- goes to the tree walk
+// (knn_walk.h), which reproduces the reference's visit order.  Results are the walk's, bit for bit; the grid only removes
+// the dependent-load chains of the descent for the queries where the answer does not depend on them.
+#pragma once
+#include "pcgx_internal.h"
+
+namespace pcgx {
+
+__device__ __forceinline__ int grid_cell(float v, float lo, float inv_h, int n) {
+  // monotonic in v (float subtraction, multiplication by a positive number, clamping and truncation
+  // all are): v <= w implies grid_cell(v) <= grid_cell(w).  Everything below rests on that alone.
+  float f = (v - lo) * inv_h;
+  f = fminf(fmaxf(f, 0.0f), (float)(n - 1));  // NaN -> 0
+  return (int)f;
+}
+
+struct GridBox {
+  int x0, x1, y0, y1, z0, z1;  // inclusive cell ranges
+};
+
+// Cells that hold every point whose computed DistSq to q is <= lim.  Such a point has
+// |p.x - q.x| <= sqrt(lim) (1 + 2e-7) (DistSq >= fl(dx^2), dx = fl(p.x - q.x)); rad below is larger,
+// fl(q.x + rad) >= p.x and fl(q.x - rad) <= p.x by monotonic rounding, and grid_cell is monotonic.
+__device__ __forceinline__ GridBox grid_cover(const GridView &g, float qx, float qy, float qz, float lim) {
+  const float rad = sqrtf(lim) * 1.0001f;
+  GridBox c;
+  c.x0 = grid_cell(qx - rad, g.lo[0], g.inv_h, g.nx);
+  c.x1 = grid_cell(qx + rad, g.lo[0], g.inv_h, g.nx);
+  c.y0 = grid_cell(qy - rad, g.lo[1], g.inv_h, g.ny);
+  c.y1 = grid_cell(qy + rad, g.lo[1], g.inv_h, g.ny);
+  c.z0 = grid_cell(qz - rad, g.lo[2], g.inv_h, g.nz);
+  c.z1 = grid_cell(qz + rad, g.lo[2], g.inv_h, g.nz);
+  return c;
+}
+
+struct GridBest {
+  float4 p;  // {x, y, z, bits(id)}; id < 0: none seen
+  float d;   // +inf: none seen
+  bool tie;  // a second point at exactly d
+};
+
+__device__ __forceinline__ void grid_take(GridBest &b, const float4 &p, float qx, float qy, float qz, bool valid) {
+  const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+  const float d = (dx * dx + dy * dy) + dz * dz;  // the reference's expression (mat/vec3.go:18-20,38-40)
+  if (valid) {
+    if (d < b.d) {
+      b.p = p;
+      b.d = d;
+      b.tie = false;
+    } else if (d == b.d) {
+      b.tie = true;
+    }
+  }
+}
+
+// start[row + cx - 1 .. row + cx + 2]: the bounds of the three cells cx - 1 .. cx + 1 of a row in one
+// 16-byte load (4-byte aligned; start[] is padded by one element on either side)
+struct __attribute__((packed, aligned(4))) GridQuad {
+  uint32_t v[4];
+};
+__device__ __forceinline__ uint32_t grid_quad_at(const GridQuad &q, int k) {  // k in 0..3
+  return k == 0 ? q.v[0] : (k == 1 ? q.v[1] : (k == 2 ? q.v[2] : q.v[3]));
+}
+
+// The points of up to N segments [seg_s[j], seg_e[j]) of pts[] as ONE sequence, four loads in flight.
+template <int N>
+__device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint32_t (&seg_s)[N],
+                                                   const uint32_t (&seg_e)[N], float qx, float qy, float qz,
+                                                   GridBest &best) {
+  // flat position f lives in segment j iff first[j] <= f < first[j + 1]; its point is pts[f + shift[j]]
+  uint32_t first[N], shift[N];
+  uint32_t total = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    first[j] = total;
+    shift[j] = seg_s[j] - total;
+    total += seg_e[j] - seg_s[j];
+  }
+  for (uint32_t f0 = 0; f0 < total; f0 += 4) {
+    float4 p[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      ok[u] = f0 + u < total;
+      const uint32_t f = ok[u] ? f0 + u : f0;
+      uint32_t sh = shift[0];
+#pragma unroll
+      for (int j = 1; j < N; j++) sh = f >= first[j] ? shift[j] : sh;
+      p[u] = g.pts[f + sh];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) grid_take(best, p[u], qx, qy, qz, ok[u]);
+  }
+}
+
+enum GridVerdict { GRID_FOUND = 0, GRID_NONE = 1, GRID_WALK = 2 };
+
+// Nearest of an exact-mode query (MinDistSq == 0) if the grid can certify it.  ub: squared distance
+// (the same float32 expression) from q to ANY point of the tree, +inf if unknown.  GRID_FOUND: best /
+// best_d are the reference's answer; GRID_NONE: {-1, maxRange^2} is (kdtree.go:100-103); GRID_WALK:
+// ask the tree walk.
+//
+// With a useful bound (the ICP loop's hint) the cells covering it are scanned at once.  Without one,
+// the 2 x 2 x 2 cells nearest to the query come first (the nearest point is among them most of the
+// time), then whatever else of the 3 x 3 x 3 block the distance found there still covers; a
+// region reaching beyond that block (sparse spots) is scanned cell row by cell row up to 5 x 5 x 5.
+__device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const float qx, const float qy, const float qz,
+                                                    const float max_range_sq, const float ub, float4 &best,
+                                                    float &best_d, int *why = nullptr) {
+  // why (tuning aid): 1 non-finite query, 2 nothing in the 27 cells, 3 beyond 5 x 5 x 5 cells, 4 DistSq ==
+  // maxRange^2, 5 tie, 6 bound not met, 7 took the row-by-row scan (not a walk)
+#define PCGX_GRID_WHY(code) do { if (why) *why = (code); } while (0)
+  // non-finite queries: NaN distances follow the walk's comparisons, not an ordering
+  if (!(fabsf(qx) < 3.0e38f && fabsf(qy) < 3.0e38f && fabsf(qz) < 3.0e38f)) {
+    PCGX_GRID_WHY(1);
+    return GRID_WALK;
+  }
+  // the answer is a point with DistSq <= bound (ub is attained by a real point)
+  const float bound = fminf(ub, max_range_sq);
+  const int cx = grid_cell(qx, g.lo[0], g.inv_h, g.nx), cy = grid_cell(qy, g.lo[1], g.inv_h, g.ny),
+            cz = grid_cell(qz, g.lo[2], g.inv_h, g.nz);
+  GridBest b;
+  b.p = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+  b.d = __builtin_inff();
+  b.tie = false;
+  GridBox box;  // cells that hold every point with DistSq <= min(b.d, bound) once `covered`
+  bool covered = false, wide = false;
+  if (bound < 3.0e38f) {
+    box = grid_cover(g, qx, qy, qz, bound);
+    covered = box.x1 - box.x0 < 3 && box.y1 - box.y0 < 3 && box.z1 - box.z0 < 3;
+  }
+  if (covered) {
+    // ---- hinted: up to 3 x 3 rows of up to 3 cells, all bounds fetched at once; mostly 2 x 2 rows
+    //      or fewer, which take the cheaper 4-segment scan
+    if (box.y1 - box.y0 < 2 && box.z1 - box.z0 < 2) {  // (a branch of its own for a single row of cells: slower)
+      uint32_t seg_s[4], seg_e[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int y = box.y0 + j % 2, z = box.z0 + j / 2;
+        const bool on = y <= box.y1 && z <= box.z1;
+        const uint32_t row = (uint32_t)((z * g.ny + y) * g.nx);
+        seg_s[j] = on ? g.start[row + (uint32_t)box.x0] : 0u;
+        seg_e[j] = on ? g.start[row + (uint32_t)box.x1 + 1u] : 0u;
+      }
+      grid_scan_segments<4>(g, seg_s, seg_e, qx, qy, qz, b);
+    } else {
+      uint32_t seg_s[9], seg_e[9];
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        const int y = box.y0 + j % 3, z = box.z0 + j / 3;
+        const bool on = y <= box.y1 && z <= box.z1;
+        const uint32_t row = (uint32_t)((z * g.ny + y) * g.nx);
+        seg_s[j] = on ? g.start[row + (uint32_t)box.x0] : 0u;
+        seg_e[j] = on ? g.start[row + (uint32_t)box.x1 + 1u] : 0u;
+      }
+      grid_scan_segments<9>(g, seg_s, seg_e, qx, qy, qz, b);
+    }
+  } else {
+    // ---- cold: the octant of the 3 x 3 x 3 block the query sits in, 2 x 2 x 2 cells (fewer at the
+    //      grid's border).  Rows (cy, cz), (cy + sy, cz), (cy, cz + sz), (cy + sy, cz + sz).
+    const int bx0 = max(cx - 1, 0), bx1 = min(cx + 1, g.nx - 1), by0 = max(cy - 1, 0), by1 = min(cy + 1, g.ny - 1),
+              bz0 = max(cz - 1, 0), bz1 = min(cz + 1, g.nz - 1);
+    const float ux = (qx - g.lo[0]) * g.inv_h - (float)cx, uy = (qy - g.lo[1]) * g.inv_h - (float)cy,
+                uz = (qz - g.lo[2]) * g.inv_h - (float)cz;
+    const int sx = ux < 0.5f ? -1 : 1, sy = uy < 0.5f ? -1 : 1, sz = uz < 0.5f ? -1 : 1;  // any choice is valid
+    const int ox0 = max(min(cx, cx + sx), bx0), ox1 = min(max(cx, cx + sx), bx1);
+    const bool y_on = cy + sy >= by0 && cy + sy <= by1, z_on = cz + sz >= bz0 && cz + sz <= bz1;
+    const int oy0 = y_on ? min(cy, cy + sy) : cy, oy1 = y_on ? max(cy, cy + sy) : cy;
+    const int oz0 = z_on ? min(cz, cz + sz) : cz, oz1 = z_on ? max(cz, cz + sz) : cz;
+    auto load_quad = [&](int y, int z, bool on) {
+      GridQuad r;
+      if (on) r = *reinterpret_cast<const GridQuad *>(g.start + ((z * g.ny + y) * g.nx + cx - 1));
+      else r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
+      return r;
+    };
+    // cells [xa, xb] (within cx - 1 .. cx + 1) of a row
+    auto range = [&](const GridQuad &r, int xa, int xb, bool on, uint32_t &s2, uint32_t &e2) {
+      on = on && xa <= xb;
+      s2 = on ? grid_quad_at(r, xa - (cx - 1)) : 0u;
+      e2 = on ? grid_quad_at(r, xb + 1 - (cx - 1)) : 0u;
+    };
+    const GridQuad r00 = load_quad(cy, cz, true), r10 = load_quad(cy + sy, cz, y_on),
+                   r01 = load_quad(cy, cz + sz, z_on), r11 = load_quad(cy + sy, cz + sz, y_on && z_on);
+    {
+      uint32_t seg_s[4], seg_e[4];
+      range(r00, ox0, ox1, true, seg_s[0], seg_e[0]);
+      range(r10, ox0, ox1, y_on, seg_s[1], seg_e[1]);
+      range(r01, ox0, ox1, z_on, seg_s[2], seg_e[2]);
+      range(r11, ox0, ox1, y_on && z_on, seg_s[3], seg_e[3]);
+      grid_scan_segments<4>(g, seg_s, seg_e, qx, qy, qz, b);
+    }
+    const float lim = fminf(b.d, bound);
+    bool guess = true;  // nothing found and no bound: the whole block, checked afterwards
+    box.x0 = bx0; box.x1 = bx1; box.y0 = by0; box.y1 = by1; box.z0 = bz0; box.z1 = bz1;
+    if (lim < 3.0e38f) {
+      const GridBox need = grid_cover(g, qx, qy, qz, lim);
+      // a far point in a thinly filled octant may cover more than the block: the rest of the block
+      // most likely holds a nearer one, so that stays a guess as well
+      if (need.x0 >= bx0 && need.x1 <= bx1 && need.y0 >= by0 && need.y1 <= by1 && need.z0 >= bz0 && need.z1 <= bz1) {
+        box = need;
+        guess = false;
+      }
+    }
+    const bool more = box.x0 < ox0 || box.x1 > ox1 || box.y0 < oy0 || box.y1 > oy1 || box.z0 < oz0 || box.z1 > oz1;
+    if (more) {
+      // the cells of `box` outside the octant: the far cell in x of the octant's rows, and the five
+      // rows on the far side in y or z
+      const int fy = cy - sy, fz = cz - sz;  // far rows (may lie outside the grid or the box)
+      auto in_box = [&](int y, int z) { return y >= box.y0 && y <= box.y1 && z >= box.z0 && z <= box.z1; };
+      const bool f0 = in_box(fy, cz - 1), f1 = in_box(fy, cz), f2 = in_box(fy, cz + 1), f3 = in_box(cy, fz),
+                 f4 = in_box(cy + sy, fz);
+      const GridQuad q0 = load_quad(fy, cz - 1, f0), q1 = load_quad(fy, cz, f1), q2 = load_quad(fy, cz + 1, f2),
+                     q3 = load_quad(cy, fz, f3), q4 = load_quad(cy + sy, fz, f4);
+      int xa = box.x0, xb = box.x1;  // what is left of the octant's rows: beyond [ox0, ox1]
+      if (sx < 0) xa = max(xa, ox1 + 1);
+      else xb = min(xb, ox0 - 1);
+      uint32_t seg_s[9], seg_e[9];
+      range(r00, xa, xb, in_box(cy, cz), seg_s[0], seg_e[0]);
+      range(r10, xa, xb, y_on && in_box(cy + sy, cz), seg_s[1], seg_e[1]);
+      range(r01, xa, xb, z_on && in_box(cy, cz + sz), seg_s[2], seg_e[2]);
+      range(r11, xa, xb, y_on && z_on && in_box(cy + sy, cz + sz), seg_s[3], seg_e[3]);
+      range(q0, box.x0, box.x1, f0, seg_s[4], seg_e[4]);
+      range(q1, box.x0, box.x1, f1, seg_s[5], seg_e[5]);
+      range(q2, box.x0, box.x1, f2, seg_s[6], seg_e[6]);
+      range(q3, box.x0, box.x1, f3, seg_s[7], seg_e[7]);
+      range(q4, box.x0, box.x1, f4, seg_s[8], seg_e[8]);
+      grid_scan_segments<9>(g, seg_s, seg_e, qx, qy, qz, b);
+    }
+    if (guess) {  // the block was a guess: it must cover what was found in it
+      if (!(b.d < 3.0e38f)) {
+        PCGX_GRID_WHY(2);
+        return GRID_WALK;
+      }
+      box = grid_cover(g, qx, qy, qz, fminf(b.d, bound));
+      wide = box.x0 < bx0 || box.x1 > bx1 || box.y0 < by0 || box.y1 > by1 || box.z0 < bz0 || box.z1 > bz1;
+    }
+    if (wide) {
+      // ---- sparse spot: `box` (the cover of the best distance so far) reaches beyond the block.
+      //      Scan all of it afresh, row by row; give up beyond 5 x 5 x 5 cells.
+      if (box.x0 < cx - 2 || box.x1 > cx + 2 || box.y0 < cy - 2 || box.y1 > cy + 2 || box.z0 < cz - 2 ||
+          box.z1 > cz + 2) {
+        PCGX_GRID_WHY(3);
+        return GRID_WALK;
+      }
+      PCGX_GRID_WHY(7);
+      b.p = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+      b.d = __builtin_inff();
+      b.tie = false;
+      for (int z = box.z0; z <= box.z1; z++)
+        for (int y = box.y0; y <= box.y1; y++) {
+          const int row = (z * g.ny + y) * g.nx;
+          const uint32_t s = g.start[row + box.x0], e = g.start[row + box.x1 + 1];
+          for (uint32_t k = s; k < e; k++) grid_take(b, g.pts[k], qx, qy, qz, true);
+        }
+    }
+  }
+  // every point with DistSq <= min(b.d, bound) was looked at
+  if (b.d <= bound) {  // so b.d is the minimum over the whole tree
+    if (b.d == max_range_sq) {  // a leaf is accepted there, a pivot is not (:100-103, :117)
+      PCGX_GRID_WHY(4);
+      return GRID_WALK;
+    }
+    if (b.tie) {  // the winner depends on the visit order
+      PCGX_GRID_WHY(5);
+      return GRID_WALK;
+    }
+    best = b.p;
+    best_d = b.d;
+    return GRID_FOUND;
+  }
+  if (bound == max_range_sq) return GRID_NONE;  // nothing within maxRange^2
+  PCGX_GRID_WHY(6);
+  return GRID_WALK;  // ub promised a point the scan did not see: cannot happen, let the walk answer
+#undef PCGX_GRID_WHY
+}
+
+// knn_grid.hip
+pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labels, hipStream_t st);
+void grid_free(pcgx_kdtree *t);
+bool grid_enabled(const pcgx_kdtree *t);
+pcgx_status grid_launch_nearest(const pcgx_kdtree *t, const float *d_q, const int32_t *d_perm, int64_t nq,
+                                float max_range_sq, int32_t *d_ids, float *d_dsq, hipStream_t st);
+
+}  // namespace pcgx

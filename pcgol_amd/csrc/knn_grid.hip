@@ -1,0 +1,259 @@
+// knn_grid.hip -- build of the uniform grid and the certified-nearest kernel (see knn_grid.h).
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "knn_grid.h"
+
+namespace pcgx {
+
+constexpr int kGridBlock = 256;
+
+__global__ __launch_bounds__(256) void grid_key_points_kernel(const float *__restrict__ xyz, int64_t n, GridView g,
+                                                              uint32_t *__restrict__ keys,
+                                                              uint32_t *__restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int cx = grid_cell(xyz[3 * i], g.lo[0], g.inv_h, g.nx), cy = grid_cell(xyz[3 * i + 1], g.lo[1], g.inv_h, g.ny),
+            cz = grid_cell(xyz[3 * i + 2], g.lo[2], g.inv_h, g.nz);
+  keys[i] = (uint32_t)((cz * g.ny + cy) * g.nx + cx);
+  vals[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void grid_gather_kernel(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
+                                                          const int32_t *__restrict__ labels, int64_t n,
+                                                          float4 *__restrict__ pts) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t i = order[j];
+  const int32_t id = labels ? labels[i] : (int32_t)i;
+  pts[j] = make_float4(xyz[3 * (int64_t)i], xyz[3 * (int64_t)i + 1], xyz[3 * (int64_t)i + 2], __int_as_float(id));
+}
+
+// start[c] = first position whose key is >= c (c = cells: n); sum of squared populations for the
+// occupancy check
+__global__ __launch_bounds__(256) void grid_start_kernel(const uint32_t *__restrict__ sorted_keys, int64_t n,
+                                                         uint32_t cells, uint32_t *__restrict__ start,
+                                                         unsigned long long *__restrict__ crowd) {
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c > cells) return;
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (sorted_keys[mid] < c) lo = mid + 1;
+    else hi = mid;
+  }
+  start[c] = (uint32_t)lo;
+  if (c == 0) start[-1] = 0u;                  // padding read (never used) by the 16-byte row loads
+  if (c == cells) start[cells + 1] = (uint32_t)n;
+  if (c < cells) {
+    int64_t lo2 = lo, hi2 = n;
+    while (lo2 < hi2) {
+      const int64_t mid = (lo2 + hi2) >> 1;
+      if (sorted_keys[mid] <= c) lo2 = mid + 1;
+      else hi2 = mid;
+    }
+    const unsigned long long cnt = (unsigned long long)(lo2 - lo);
+    if (cnt > 1) atomicAdd(crowd, cnt * cnt - cnt);  // ordered pairs sharing a cell
+  }
+}
+
+// One query per lane.  Certified answers are written; the rest is appended to walk_list (query
+// indices) for the tree walk.
+template <bool kWhy>
+__global__ __launch_bounds__(kGridBlock) void grid_nearest_kernel(GridView g, const float *__restrict__ q,
+                                                                  const int32_t *__restrict__ perm, int64_t nq,
+                                                                  float max_range_sq, int32_t *__restrict__ out_id,
+                                                                  float *__restrict__ out_dsq,
+                                                                  int32_t *__restrict__ walk_list,
+                                                                  uint32_t *__restrict__ walk_count,
+                                                                  uint32_t *__restrict__ why_counts = nullptr) {
+  const int64_t pos = (int64_t)blockIdx.x * kGridBlock + threadIdx.x;
+  if (pos >= nq) return;
+  const int64_t i = perm ? (int64_t)perm[pos] : pos;
+  const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
+  float4 best;
+  float best_d;
+  int why = 0;
+  const GridVerdict v = grid_nearest(g, qx, qy, qz, max_range_sq, __builtin_inff(), best, best_d, kWhy ? &why : nullptr);
+  if (kWhy && why) atomicAdd(&why_counts[why], 1u);
+  if (v == GRID_FOUND) {
+    out_id[i] = __float_as_int(best.w);
+    out_dsq[i] = best_d;
+  } else if (v == GRID_NONE) {
+    out_id[i] = -1;
+    out_dsq[i] = max_range_sq;
+  } else {
+    walk_list[atomicAdd(walk_count, 1u)] = (int32_t)i;
+  }
+}
+
+void grid_free(pcgx_kdtree *t) {
+  dev_cache_free(t->d_gpts);
+  dev_cache_free(t->d_gstart);
+  t->d_gpts = nullptr;
+  t->d_gstart = nullptr;
+  t->grid_ok = false;
+}
+
+static int grid_mode() {  // PCGX_GRID=0: tree walk only; =2: grid even for crowded cells (tests)
+  const char *e = getenv("PCGX_GRID");
+  return e ? atoi(e) : 1;
+}
+
+bool grid_enabled(const pcgx_kdtree *t) { return t->grid_ok && grid_mode() != 0; }
+
+// d_xyz: packed device xyz in accessor order; d_labels: optional ids the points report.  Finite
+// coordinates only (the caller checks).  Leaves t->grid_ok false when a grid would not pay.
+pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labels, hipStream_t st) {
+  t->grid_ok = false;
+  const int64_t n = t->n;
+  if (n < 64 || grid_mode() == 0) return PCGX_OK;
+  float ext[3];
+  int dims = 0;
+  double vol = 1.0;
+  for (int k = 0; k < 3; k++) {
+    ext[k] = t->bbox_hi[k] - t->bbox_lo[k];
+    if (!(ext[k] >= 0.0f) || !(ext[k] < 1.0e30f)) return PCGX_OK;
+    if (ext[k] > 0.0f) {
+      dims++;
+      vol *= (double)ext[k];
+    }
+  }
+  if (dims == 0) return PCGX_OK;  // all points identical
+  // ~2 points per cell of the occupied volume; a thin axis gets one layer of cells
+  double h = pow(vol / ((double)n / 2.0), 1.0 / dims);
+  GridView g;
+  memset(&g, 0, sizeof g);
+  int64_t cells = 0;
+  for (int tries = 0; tries < 64; tries++) {
+    g.h = (float)h;
+    g.inv_h = 1.0f / g.h;
+    if (!(g.h > 0.0f) || !(g.inv_h < 1.0e30f)) return PCGX_OK;
+    int64_t d[3];
+    bool ok = true;
+    for (int k = 0; k < 3; k++) {
+      d[k] = (int64_t)((double)ext[k] * (double)g.inv_h) + 1;
+      ok = ok && d[k] < (1 << 20);
+    }
+    cells = ok ? d[0] * d[1] * d[2] : 0;
+    if (ok && cells <= 4 * n + 4096) {
+      g.nx = (int32_t)d[0];
+      g.ny = (int32_t)d[1];
+      g.nz = (int32_t)d[2];
+      break;
+    }
+    cells = 0;
+    h *= 1.26;
+  }
+  if (cells == 0) return PCGX_OK;
+  for (int k = 0; k < 3; k++) g.lo[k] = t->bbox_lo[k];
+  Arena &ar = ctx().arena;  // the caller has begun it
+  uint32_t *keys[2], *vals[2];
+  void *ws = nullptr;
+  unsigned long long *d_crowd = nullptr;
+  PCGX_TRY(ar.alloc_n((size_t)n, &keys[0]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &keys[1]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &vals[0]));
+  PCGX_TRY(ar.alloc_n((size_t)n, &vals[1]));
+  PCGX_TRY(ar.alloc_n(1, &d_crowd));
+  {
+    uint8_t *w = nullptr;
+    PCGX_TRY(ar.alloc_n(radix_sort_workspace_bytes(n), &w));
+    ws = w;
+  }
+  hipError_t e = dev_cache_alloc((void **)&t->d_gpts, (size_t)n * sizeof(float4));
+  if (e == hipSuccess) e = dev_cache_alloc((void **)&t->d_gstart, (size_t)(cells + 3) * sizeof(uint32_t));  // one pad element either side (GridQuad)
+  if (e != hipSuccess) {
+    grid_free(t);
+    return fail(PCGX_E_OOM, "grid allocation failed: %s", hipGetErrorString(e));
+  }
+  g.pts = t->d_gpts;
+  g.start = t->d_gstart + 1;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  PCGX_HIP_TRY(hipMemsetAsync(d_crowd, 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(grid_key_points_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n, g, keys[0], vals[0]);
+  int key_bits = 1;
+  while (((int64_t)1 << key_bits) < cells) key_bits++;
+  int res = 0;
+  PCGX_TRY(radix_sort_pairs(keys, vals, n, key_bits, ws, &res, st));
+  hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, (const uint32_t *)vals[res], d_labels, n,
+                     t->d_gpts);
+  hipLaunchKernelGGL(grid_start_kernel, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, st,
+                     (const uint32_t *)keys[res], n, (uint32_t)cells, t->d_gstart + 1, d_crowd);
+  unsigned long long crowd = 0;
+  PCGX_HIP_TRY(hipMemcpyAsync(&crowd, d_crowd, sizeof crowd, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  t->grid = g;
+  // mean number of OTHER points in a point's cell: ~2 for a volume filled evenly; clouds that
+  // crowd a few cells (surfaces in a large box, clusters) are better served by the tree
+  t->grid_crowding = (double)crowd / (double)n;
+  t->grid_ok = t->grid_crowding <= 12.0 || grid_mode() == 2;
+  if (!t->grid_ok) {
+    dev_cache_free(t->d_gpts);
+    dev_cache_free(t->d_gstart);
+    t->d_gpts = nullptr;
+    t->d_gstart = nullptr;
+  }
+  return PCGX_OK;
+}
+
+// Exact-mode Nearest (MinDistSq == 0) of a batch: certified answers from the grid, the rest by the
+// tree walk over the list the grid kernel leaves (its length stays on the device).
+pcgx_status grid_launch_nearest(const pcgx_kdtree *t, const float *d_q, const int32_t *d_perm, int64_t nq,
+                                float max_range_sq, int32_t *d_ids, float *d_dsq, hipStream_t st) {
+  if (nq == 0) return PCGX_OK;
+  Arena &ar = ctx().arena;  // begun by the caller
+  int32_t *d_list = nullptr;
+  uint32_t *d_count = nullptr;
+  PCGX_TRY(ar.alloc_n((size_t)nq, &d_list));
+  PCGX_TRY(ar.alloc_n(1, &d_count));
+  PCGX_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), st));
+  {
+    ProfScope prof(PCGX_PROF_KNN_WALK, st);
+    hipLaunchKernelGGL(grid_nearest_kernel<false>, dim3((unsigned)((nq + kGridBlock - 1) / kGridBlock)),
+                       dim3(kGridBlock), 0, st, t->grid, d_q, d_perm, nq, max_range_sq, d_ids, d_dsq, d_list, d_count,
+                       (uint32_t *)nullptr);
+  }
+  PCGX_HIP_TRY(hipGetLastError());
+  return launch_nearest_listed(t->view(), d_q, d_list, d_count, nq, max_range_sq, d_ids, d_dsq, st);
+}
+
+}  // namespace pcgx
+
+// Debug / tuning aid (not part of the drop-in surface): how many of the queries the grid pass leaves
+// to the tree walk, and the tree's grid parameters.  out[0] = queries left to the walk, out[1] =
+// cells, out[2] = crowding * 1000, out[3] = grid enabled, out[4 + k] = queries with reason k (knn_grid.h,
+// grid_nearest `why`; k = 1..7).
+extern "C" pcgx_status pcgx_debug_grid_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
+                                             int64_t out[12]) {
+  PCGX_API_LOCK();
+  if (!t || !out || nq < 0 || (nq > 0 && !d_q)) return pcgx::fail(PCGX_E_INVALID, "pcgx_debug_grid_stats: bad argument");
+  PCGX_TRY(pcgx::ensure_init());
+  for (int k = 0; k < 12; k++) out[k] = 0;
+  out[2] = (int64_t)(t->grid_crowding * 1000.0);
+  out[3] = pcgx::grid_enabled(t) ? 1 : 0;
+  if (!out[3]) return PCGX_OK;
+  out[1] = (int64_t)t->grid.nx * t->grid.ny * t->grid.nz;
+  if (nq == 0) return PCGX_OK;
+  hipStream_t st = pcgx::ctx().stream;
+  pcgx::Arena &ar = pcgx::ctx().arena;
+  PCGX_TRY(ar.begin(st));
+  int32_t *d_list = nullptr, *d_ids = nullptr;
+  float *d_dsq = nullptr;
+  uint32_t *d_count = nullptr;  // [0] walk count, [8 + k] reasons
+  PCGX_TRY(ar.alloc_n((size_t)nq, &d_list));
+  PCGX_TRY(ar.alloc_n((size_t)nq, &d_ids));
+  PCGX_TRY(ar.alloc_n((size_t)nq, &d_dsq));
+  PCGX_TRY(ar.alloc_n(16, &d_count));
+  PCGX_HIP_TRY(hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(pcgx::grid_nearest_kernel<true>, dim3((unsigned)((nq + pcgx::kGridBlock - 1) / pcgx::kGridBlock)),
+                     dim3(pcgx::kGridBlock), 0, st, t->grid, d_q, (const int32_t *)nullptr, nq, max_range * max_range,
+                     d_ids, d_dsq, d_list, d_count, d_count + 8);
+  uint32_t c[16];
+  PCGX_HIP_TRY(hipMemcpyAsync(c, d_count, sizeof c, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  out[0] = (int64_t)c[0];
+  for (int k = 1; k < 8; k++) out[4 + k] = (int64_t)c[8 + k];
+  return PCGX_OK;
+}

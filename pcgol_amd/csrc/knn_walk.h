@@ -239,13 +239,23 @@ static_assert(kQueueWords * kQueueSlots * 4 == kWalkQueueBytesPerWave, "pcgx_int
 
 // Chunk range [begin, end) of workgroup `bid` out of `nblocks` (a multiple of 8, or < 8):
 // workgroups with equal bid % 8 get adjacent ranges.
+__device__ __forceinline__ uint32_t block_slot(uint32_t bid, uint32_t nblocks) {
+  return (nblocks & 7u) == 0u ? (bid & 7u) * (nblocks >> 3) + (bid >> 3) : bid;
+}
 __device__ __forceinline__ void block_chunk_range(int64_t nq, uint32_t bid, uint32_t nblocks,
                                                   uint32_t &begin, uint32_t &end) {
   const uint64_t n_chunks = (uint64_t)((nq + 63) / 64);
-  uint32_t slot = bid;
-  if ((nblocks & 7u) == 0u) slot = (bid & 7u) * (nblocks >> 3) + (bid >> 3);
+  const uint32_t slot = block_slot(bid, nblocks);
   begin = (uint32_t)(n_chunks * slot / nblocks);
   end = (uint32_t)(n_chunks * (slot + 1) / nblocks);
+}
+// the slot whose chunk range holds query i, and that range's first chunk
+__device__ __forceinline__ uint32_t slot_of_query(int64_t nq, int64_t i, uint32_t nblocks, uint32_t &begin) {
+  const uint64_t n_chunks = (uint64_t)((nq + 63) / 64);
+  const uint64_t c = (uint64_t)i / 64;
+  const uint32_t slot = (uint32_t)(((c + 1) * nblocks - 1) / n_chunks);
+  begin = (uint32_t)(n_chunks * slot / nblocks);
+  return slot;
 }
 
 // fetch(idx, qx, qy, qz, ub, pred): loads query idx.  ub = squared distance (the walk's own float32

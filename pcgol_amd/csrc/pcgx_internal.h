@@ -149,6 +149,15 @@ struct TreeView {
   int32_t chunks_per_refill; // walk kernels: chunks a wave may prepare in one refill section
 };
 
+// knn_grid.h: uniform grid over the base cloud (certified fast path of Nearest)
+struct GridView {
+  const float4 *pts;      // [n] {x, y, z, bits(id)} in cell order
+  const uint32_t *start;  // [cells + 1] first point of each cell, cell = (z * ny + y) * nx + x
+  float lo[3];
+  float h, inv_h;  // cell edge
+  int32_t nx, ny, nz;
+};
+
 // kdtree_build.cpp
 void build_inorder(const float *xyz, int64_t n, int32_t *inorder_ids);
 inline int32_t tree_depth(int64_t n) {
@@ -201,6 +210,10 @@ int walk_oversubscribe();
 pcgx_status launch_nearest(const TreeView &tv, const float *d_q, const int32_t *d_perm, int64_t nq,
                            float max_range_sq, float min_dist_sq, int32_t *d_ids, float *d_dsq,
                            hipStream_t st);
+// exact-mode walk of the queries d_list[0 .. *d_count) (a device-side count <= nq_max)
+pcgx_status launch_nearest_listed(const TreeView &tv, const float *d_q, const int32_t *d_list,
+                                  const uint32_t *d_count, int64_t nq_max, float max_range_sq, int32_t *d_ids,
+                                  float *d_dsq, hipStream_t st);
 
 // sort.hip
 size_t radix_sort_workspace_bytes(int64_t n);
@@ -241,6 +254,12 @@ struct pcgx_kdtree {
   bool x_init = false, x_dirty = false;
   float4 *d_xpts = nullptr;
   void *d_xlinks = nullptr;
+  // uniform grid of the certified-nearest fast path (knn_grid.h); grid_ok false: tree walk only
+  float4 *d_gpts = nullptr;
+  uint32_t *d_gstart = nullptr;
+  pcgx::GridView grid;
+  bool grid_ok = false;
+  double grid_crowding = 0.0;  // mean number of other points in a point's cell
   std::vector<uint8_t> deleted;    // [n] once the first point was deleted
   int64_t n_deleted = 0;
   bool dirty = false;              // deletions since `live` was built
