@@ -16,6 +16,7 @@ MaxIteration = 20 loop (icp.go:48-65); Threshold = -1 keeps all iterations.
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -119,11 +120,21 @@ def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, ic
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         kms, kn = L.prof_read(L.PROF_KNN_WALK)
+        gms, gn = L.prof_read(L.PROF_KNN_GRID)
         v = visits["c2_knn"]["visits_per_query"]
-        alg = (12 + 8 + 16 * v) * len(c2q)
+        ref = (12 + 8 + 16 * v) * len(c2q)  # bytes the reference's walk touches
         out[key] = {"mqueries_per_s": len(c2q) / dt / 1e6, "ms_per_call": dt * 1e3,
-                    "walk_kernel_ms": kms / max(kn, 1),
-                    "roofline_frac_walk_kernel": alg / (kms / max(kn, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    "walk_kernel_ms": kms / max(kn, 1)}
+        if gn > 0:
+            st = (C.c_int64 * 14)()
+            L.check(L.lib().pcgx_debug_grid_stats(tree._h, L.ptr(dq.data_ptr()), len(c2q), 10.0, st))
+            alg = (12 + 8 + 16 * st[12] / len(c2q) + 4 * st[13] / len(c2q)) * len(c2q)
+            out[key].update({"grid_kernel_ms": gms / gn, "queries_left_to_walk": st[0],
+                             "point_records_per_query": st[12] / len(c2q), "bound_words_per_query": st[13] / len(c2q),
+                             "roofline_frac_grid_kernel": alg / (gms / gn * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "reference_walk_frac_of_peak": ref / ((gms / gn + kms / max(kn, 1)) * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        else:
+            out[key]["roofline_frac_walk_kernel"] = ref / (kms / max(kn, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS
     # Point-to-plane / Gauss-Newton extension (BASELINE.json config "ICP point-to-plane, 1M source vs
     # 1M target, 20 iters"; the reference has no such evaluator: no reference parity).
     # One step = correspondence + 30-sum reduction (6x6 normal equations) + Gauss-Newton update.
@@ -275,15 +286,41 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     walk_ms, walk_n = L.prof_read(L.PROF_ICP_WALK)
+    grid_ms, grid_n = L.prof_read(L.PROF_ICP_GRID)
     trans, stat, _ = sicp.result()
+
+    # What the grid pass reads per iteration (an untimed Fit, one instrumented launch before each
+    # step): point records and cell-bound words, targets left to the tree walk.
+    grid_pts = grid_words = grid_walked = 0
+    if grid_n > 0:
+        sicp.reset()
+        for _ in range(cfg["max_iteration"]):
+            g = sicp.sess.grid_stats(sicp.stream.cuda_stream)
+            grid_walked += g[1]
+            grid_pts += g[2]
+            grid_words += g[3]
+            sicp.step()
+        torch.cuda.synchronize()
 
     if rank == 0:
         visits = load_visits()
         v_icp = visits["c4_icp"]["mean_visits_per_point"]
-        alg_bytes = (12 + 16 * v_icp) * n  # 12 B target read + 16 B per node the reference walk touches
-        kernel_s = walk_ms / max(walk_n, 1) * 1e-3
+        ref_bytes = (12 + 16 * v_icp) * n  # 12 B target read + 16 B per node the REFERENCE walk touches
+        if grid_n > 0:
+            # the dominant kernel is the grid pass; its algorithmic bytes in SURVEY 8(d)'s form, for
+            # the records IT touches: 12 B target + 16 B previous pair read (iterations >= 1) + 16 B
+            # pair written + 16 B per point record + 4 B per cell-bound word, averaged over a Fit
+            its = cfg["max_iteration"]
+            v_pts, v_words = grid_pts / (its * n), grid_words / (its * n)
+            alg_bytes = (12 + 16 * (its - 1) / its + 16 + 16 * v_pts + 4 * v_words) * n
+            kernel, kernel_s, launches = "icp_grid_kernel", grid_ms / max(grid_n, 1) * 1e-3, grid_n
+        else:
+            v_pts = v_words = None
+            alg_bytes = ref_bytes
+            kernel, kernel_s, launches = "icp_corr_kernel", walk_ms / max(walk_n, 1) * 1e-3, walk_n
         achieved = alg_bytes / kernel_s / 1e9
-        traffic, traffic_src = load_traffic() if n == 1_000_000 else (None, None)
+        traffic, traffic_src = load_traffic(kernel) if n == 1_000_000 else (None, None)
+        corr_s = walk_ms / max(walk_n, 1) * 1e-3 if grid_n == 0 else None  # with the grid pass: see profiles/
         line = {
             "metric": "Mpoints/sec ICP iter (corr+reduce) + kNN queries/sec, 1M-pt cloud",
             "value": world * n * args.steps / elapsed / 1e6,
@@ -299,10 +336,19 @@ def main():
                        "base_points": n, "target_points_per_gpu": n, "parallelism": "target tiles x%d, tree replicated" % world,
                        "exchange": "none" if world == 1 else "all-reduce 10 x f64 per step (%s)"
                                    % ("gloo: REHEARSAL on one GPU, not a measurement" if rehearse else "RCCL")},
-            "roofline": {"bound": "hbm", "kernel": "icp_corr_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_s * 1e3, "launches": walk_n,
-                         "algorithmic_bytes_per_launch": alg_bytes, "visits_per_point": v_icp},
+                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": kernel_s * 1e3, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "point_records_per_target": v_pts, "bound_words_per_target": v_words,
+                         "targets_left_to_walk_per_fit": grid_walked if grid_n > 0 else None,
+                         "corr_kernel_ms": corr_s * 1e3 if corr_s is not None else None,
+                         # the same launch priced as SURVEY 8(d) prices the reference's walk (12 + 16 V B per
+                         # target, V = nodes the reference touches): above 1 means the grid answers with
+                         # fewer bytes than that walk would stream
+                         "reference_walk": {"visits_per_point": v_icp, "bytes_per_launch": ref_bytes,
+                                            "rate_gbs": ref_bytes / kernel_s / 1e9,
+                                            "frac_of_peak": ref_bytes / kernel_s / 1e9 / HBM_PEAK_GBS}},
             "tree_build_s": build_s,
             "final_value": float(stat.Evaluated.Value),
         }

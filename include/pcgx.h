@@ -71,11 +71,14 @@ PCGX_API pcgx_status pcgx_sync(void *stream);
 /* Optional in-library kernel timing (HIP events on the launch stream around
  * the named kernel class).  Used by bench.py for the live roofline figure. */
 enum {
-  PCGX_PROF_ICP_WALK = 0,   /* icp_corr_kernel (re-projection + nearest for every target) */
+  PCGX_PROF_ICP_WALK = 0,   /* icp_corr_kernel (tree walk of the targets the grid pass left + reduce;
+                               every target when the base tree has no grid) */
   PCGX_PROF_KNN_WALK = 1,   /* nearest_kernel */
   PCGX_PROF_VOXEL_ALL = 2,  /* whole voxel-filter pipeline of one call */
   PCGX_PROF_SORT_SCATTER = 3, /* rs_scatter_kernel (radix sort passes) */
-  PCGX_PROF_KINDS = 4
+  PCGX_PROF_ICP_GRID = 4,   /* icp_grid_kernel (re-projection + certified nearest + sums) */
+  PCGX_PROF_KNN_GRID = 5,   /* grid_nearest_kernel */
+  PCGX_PROF_KINDS = 6
 };
 PCGX_API pcgx_status pcgx_prof_enable(int32_t on);
 /* Resolves pending events; returns accumulated milliseconds and launch count
@@ -97,9 +100,14 @@ PCGX_API pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_
 
 /* Tuning aid (not part of the drop-in surface): out = {queries of the batch the grid pass leaves to
  * the tree walk, grid cells, 1000 x mean number of other points in a point's cell, grid in use, -,
- * queries per reason 1..7 (csrc/knn_grid.h)}. */
+ * queries per reason 1..7 (csrc/knn_grid.h), point records read, cell-bound words read}. */
 PCGX_API pcgx_status pcgx_debug_grid_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
-                                           int64_t out[12]);
+                                           int64_t out[14]);
+
+/* Measurement aid: what the grid pass of the session's NEXT iteration would read, without changing
+ * the session: out = {targets, targets left to the walk, point records read, cell-bound words read}. */
+typedef struct pcgx_icp_session pcgx_icp_session;
+PCGX_API pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream, int64_t out[4]);
 
 /* Device memory helpers for hosts that have no HIP binding of their own. */
 PCGX_API pcgx_status pcgx_dev_alloc(size_t bytes, void **dptr);

@@ -26,7 +26,7 @@ PCGX_E_BAD_HEADER = 14
 PCGX_PCD_MAX_FIELDS = 64
 
 PCGX_KNN_PRESORT = 1
-PROF_ICP_WALK, PROF_KNN_WALK, PROF_VOXEL_ALL, PROF_SORT_SCATTER = range(4)
+PROF_ICP_WALK, PROF_KNN_WALK, PROF_VOXEL_ALL, PROF_SORT_SCATTER, PROF_ICP_GRID, PROF_KNN_GRID = range(6)
 
 
 def prof_enable(on=True):
@@ -136,6 +136,7 @@ SIGNATURES = {
     "pcgx_kdtree_max_depth": (_i32, [_vp, C.POINTER(_i32)]),
     "pcgx_kdtree_inorder": (_i32, [_vp, _vp]),
     "pcgx_kdtree_points": (_i32, [_vp, _vp, _i64, _vp]),
+    "pcgx_debug_icp_grid_stats": (_i32, [_vp, _vp, C.POINTER(_i64)]),
     "pcgx_debug_grid_stats": (_i32, [_vp, _vp, _i64, C.c_float, C.POINTER(_i64)]),
     "pcgx_kdtree_dump": (_i32, [_vp, _vp, _i64, C.POINTER(_i64)]),
     "pcgx_kdtree_delete_points": (_i32, [_vp, _vp, _i64]),

@@ -159,7 +159,7 @@ void prof_resolve() {
 }  // namespace
 
 ProfScope::ProfScope(int kind, hipStream_t st) : kind_(kind), st_(st) {
-  if (!g_prof_on) return;
+  if (!g_prof_on || kind < 0) return;  // kind < 0: not timed
   std::lock_guard<std::mutex> lk(g_prof_mu);
   a_ = prof_event();
   b_ = prof_event();

@@ -268,13 +268,15 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
 // (rows n_corr_blocks .. of block_partials).  The others are flagged in first_leaf[] (bit 31) and
 // queued in the walk_list segment of the icp_corr_kernel workgroup (n_corr_blocks of them) that owns
 // the target; that kernel walks them and adds their terms to ITS row.
-template <bool kPlane>
+// kTrace (measurement aid): nothing is stored; trace[0..2] += targets left to the walk, point
+// records read, cell-bound words read.
+template <bool kPlane, bool kTrace = false>
 __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
     GridView grid, const float *__restrict__ tx, const float *__restrict__ ty, const float *__restrict__ tz, int64_t nt,
     const IcpState *__restrict__ state, IcpKernelParams kp, float4 *__restrict__ match,
     uint32_t *__restrict__ match_id, const float4 *__restrict__ normals, uint32_t *__restrict__ first_leaf,
     uint32_t *__restrict__ walk_list, uint32_t *__restrict__ walk_count, uint32_t n_corr_blocks,
-    double *__restrict__ block_partials) {
+    double *__restrict__ block_partials, unsigned long long *__restrict__ trace = nullptr) {
   constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
   __shared__ float s_terms[NS][kIcpGridBlock];
   if (state->done) return;  // uniform
@@ -298,8 +300,13 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
     }
     float4 best = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
     float best_d = kp.max_dist_sq;
-    const GridVerdict v = grid_nearest(grid, x, y, z, kp.max_dist_sq, ub, best, best_d);
-    if (v == GRID_WALK) {
+    GridTrace tr;
+    const GridVerdict v = grid_nearest(grid, x, y, z, kp.max_dist_sq, ub, best, best_d, kTrace ? &tr : nullptr);
+    if (kTrace) {
+      if (v == GRID_WALK) atomicAdd(&trace[0], 1ull);
+      atomicAdd(&trace[1], (unsigned long long)tr.points);
+      atomicAdd(&trace[2], (unsigned long long)tr.words);
+    } else if (v == GRID_WALK) {
       uint32_t begin;
       const uint32_t slot = slot_of_query(nt, i, n_corr_blocks, begin);
       const int64_t r_begin = (int64_t)begin * 64;
@@ -316,8 +323,9 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
       }
     }
   }
+  if (kTrace) return;  // uniform
   // every lane holds the float32 terms of (at most) one pair: through LDS, component k is added
-  // up by kSub lanes over contiguous runs of targets, then across those lanes -- a fixed order
+  // up by kSub lanes, each over every kSub-th target, then across those lanes -- a fixed order
   constexpr int kSub = kPlane ? 8 : 16, kRun = kIcpGridBlock / kSub;
   static_assert(NS * kSub <= kIcpGridBlock, "one lane per (component, run)");
 #pragma unroll
@@ -326,7 +334,7 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
   if (threadIdx.x < NS * kSub) {
     const int k = threadIdx.x / kSub, j = threadIdx.x % kSub;
     double v = 0.0;
-    for (int u = 0; u < kRun; u++) v += (double)s_terms[k][j * kRun + u];
+    for (int u = 0; u < kRun; u++) v += (double)s_terms[k][u * kSub + j];  // lanes j side by side: no bank conflicts
 #pragma unroll
     for (int o = kSub / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kSub);
     if (j == 0) block_partials[((int64_t)n_corr_blocks + blockIdx.x) * NS + k] = v;
@@ -916,9 +924,9 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   tv.chunks_per_refill = chunks;
   const size_t lds = walk_lds_bytes(tv, kIcpBlock);
   const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
-  ProfScope prof(PCGX_PROF_ICP_WALK, st);
   const bool grid = grid_enabled(s->base) && !(s->kp.min_dist_sq > 0.0f) && s->nt > 0;
   if (grid) {
+    ProfScope prof_grid(PCGX_PROF_ICP_GRID, st);
     const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
     if (s->plane)
       hipLaunchKernelGGL(icp_grid_kernel<true>, dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
@@ -929,6 +937,9 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
                          s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
                          s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
   }
+  // timed (pcgx_prof_enable) when it is the kernel that does the work: with the grid pass before it
+  // it walks next to nothing, and a second pair of events per step costs more than it
+  ProfScope prof(grid ? -1 : PCGX_PROF_ICP_WALK, st);
 #define PCGX_LAUNCH_CORR(MD, PL, GR)                                                                                  \
   hipLaunchKernelGGL((icp_corr_kernel<MD, PL, GR>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,     \
                      s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, s->d_match_id,                   \
@@ -1123,5 +1134,32 @@ extern "C" pcgx_status pcgx_icp_pairs(const pcgx_kdtree *base, const float *targ
     m++;
   }
   *npairs = m;
+  return PCGX_OK;
+}
+
+// Measurement aid: see include/pcgx.h.
+extern "C" pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream, int64_t out[4]) {
+  PCGX_API_LOCK();
+  if (!s || !out) return fail(PCGX_E_INVALID, "pcgx_debug_icp_grid_stats: NULL argument");
+  out[0] = s->nt;
+  out[1] = out[2] = out[3] = 0;
+  if (s->patched || !grid_enabled(s->base) || s->kp.min_dist_sq > 0.0f || s->nt == 0) return PCGX_OK;
+  hipStream_t st = pick_stream(stream);
+  unsigned long long *d_trace = nullptr;
+  PCGX_HIP_TRY(dev_cache_alloc((void **)&d_trace, 4 * sizeof(unsigned long long)));
+  PCGX_HIP_TRY(hipMemsetAsync(d_trace, 0, 4 * sizeof(unsigned long long), st));
+  const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
+  const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
+  hipLaunchKernelGGL((icp_grid_kernel<false, true>), dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
+                     s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
+                     s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials, d_trace);
+  unsigned long long h[4];
+  hipError_t e = hipMemcpyAsync(h, d_trace, sizeof h, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  dev_cache_free(d_trace);
+  if (e != hipSuccess) return fail(PCGX_E_HIP, "pcgx_debug_icp_grid_stats: %s", hipGetErrorString(e));
+  out[1] = (int64_t)h[0];
+  out[2] = (int64_t)h[1];
+  out[3] = (int64_t)h[2];
   return PCGX_OK;
 }

@@ -79,11 +79,23 @@ __device__ __forceinline__ uint32_t grid_quad_at(const GridQuad &q, int k) {  //
   return k == 0 ? q.v[0] : (k == 1 ? q.v[1] : (k == 2 ? q.v[2] : q.v[3]));
 }
 
+enum GridVerdict { GRID_FOUND = 0, GRID_NONE = 1, GRID_WALK = 2 };
+
+// Tuning / measurement aid (nullptr in the product kernels, where it compiles away): why a query
+// was left to the walk and what the scan read.  why: 1 non-finite query, 2 nothing in the 27 cells, 3
+// beyond 5 x 5 x 5 cells, 4 DistSq == maxRange^2, 5 tie, 6 bound not met, 7 took the row-by-row scan
+// (not a walk).
+struct GridTrace {
+  int why = 0;
+  uint32_t points = 0;  // float4 point records read
+  uint32_t words = 0;   // uint32 cell bounds read
+};
+
 // The points of up to N segments [seg_s[j], seg_e[j]) of pts[] as ONE sequence, four loads in flight.
 template <int N>
 __device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint32_t (&seg_s)[N],
                                                    const uint32_t (&seg_e)[N], float qx, float qy, float qz,
-                                                   GridBest &best) {
+                                                   GridBest &best, GridTrace *tr = nullptr) {
   // flat position f lives in segment j iff first[j] <= f < first[j + 1]; its point is pts[f + shift[j]]
   uint32_t first[N], shift[N];
   uint32_t total = 0;
@@ -92,7 +104,9 @@ __device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint
     first[j] = total;
     shift[j] = seg_s[j] - total;
     total += seg_e[j] - seg_s[j];
+    if (tr && seg_e[j] != seg_s[j]) tr->words += 2;  // (a row without cells to scan costs no useful word)
   }
+  if (tr) tr->points += total;
   for (uint32_t f0 = 0; f0 < total; f0 += 4) {
     float4 p[4];
     bool ok[4];
@@ -110,7 +124,6 @@ __device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint
   }
 }
 
-enum GridVerdict { GRID_FOUND = 0, GRID_NONE = 1, GRID_WALK = 2 };
 
 // Nearest of an exact-mode query (MinDistSq == 0) if the grid can certify it.  ub: squared distance
 // (the same float32 expression) from q to ANY point of the tree, +inf if unknown.  GRID_FOUND: best /
@@ -123,10 +136,8 @@ enum GridVerdict { GRID_FOUND = 0, GRID_NONE = 1, GRID_WALK = 2 };
 // region reaching beyond that block (sparse spots) is scanned cell row by cell row up to 5 x 5 x 5.
 __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const float qx, const float qy, const float qz,
                                                     const float max_range_sq, const float ub, float4 &best,
-                                                    float &best_d, int *why = nullptr) {
-  // why (tuning aid): 1 non-finite query, 2 nothing in the 27 cells, 3 beyond 5 x 5 x 5 cells, 4 DistSq ==
-  // maxRange^2, 5 tie, 6 bound not met, 7 took the row-by-row scan (not a walk)
-#define PCGX_GRID_WHY(code) do { if (why) *why = (code); } while (0)
+                                                    float &best_d, GridTrace *tr = nullptr) {
+#define PCGX_GRID_WHY(code) do { if (tr) tr->why = (code); } while (0)
   // non-finite queries: NaN distances follow the walk's comparisons, not an ordering
   if (!(fabsf(qx) < 3.0e38f && fabsf(qy) < 3.0e38f && fabsf(qz) < 3.0e38f)) {
     PCGX_GRID_WHY(1);
@@ -159,7 +170,7 @@ __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const flo
         seg_s[j] = on ? g.start[row + (uint32_t)box.x0] : 0u;
         seg_e[j] = on ? g.start[row + (uint32_t)box.x1 + 1u] : 0u;
       }
-      grid_scan_segments<4>(g, seg_s, seg_e, qx, qy, qz, b);
+      grid_scan_segments<4>(g, seg_s, seg_e, qx, qy, qz, b, tr);
     } else {
       uint32_t seg_s[9], seg_e[9];
 #pragma unroll
@@ -170,7 +181,7 @@ __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const flo
         seg_s[j] = on ? g.start[row + (uint32_t)box.x0] : 0u;
         seg_e[j] = on ? g.start[row + (uint32_t)box.x1 + 1u] : 0u;
       }
-      grid_scan_segments<9>(g, seg_s, seg_e, qx, qy, qz, b);
+      grid_scan_segments<9>(g, seg_s, seg_e, qx, qy, qz, b, tr);
     }
   } else {
     // ---- cold: the octant of the 3 x 3 x 3 block the query sits in, 2 x 2 x 2 cells (fewer at the
@@ -204,7 +215,7 @@ __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const flo
       range(r10, ox0, ox1, y_on, seg_s[1], seg_e[1]);
       range(r01, ox0, ox1, z_on, seg_s[2], seg_e[2]);
       range(r11, ox0, ox1, y_on && z_on, seg_s[3], seg_e[3]);
-      grid_scan_segments<4>(g, seg_s, seg_e, qx, qy, qz, b);
+      grid_scan_segments<4>(g, seg_s, seg_e, qx, qy, qz, b, tr);
     }
     const float lim = fminf(b.d, bound);
     bool guess = true;  // nothing found and no bound: the whole block, checked afterwards
@@ -241,7 +252,7 @@ __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const flo
       range(q2, box.x0, box.x1, f2, seg_s[6], seg_e[6]);
       range(q3, box.x0, box.x1, f3, seg_s[7], seg_e[7]);
       range(q4, box.x0, box.x1, f4, seg_s[8], seg_e[8]);
-      grid_scan_segments<9>(g, seg_s, seg_e, qx, qy, qz, b);
+      grid_scan_segments<9>(g, seg_s, seg_e, qx, qy, qz, b, tr);
     }
     if (guess) {  // the block was a guess: it must cover what was found in it
       if (!(b.d < 3.0e38f)) {
@@ -268,6 +279,10 @@ __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const flo
           const int row = (z * g.ny + y) * g.nx;
           const uint32_t s = g.start[row + box.x0], e = g.start[row + box.x1 + 1];
           for (uint32_t k = s; k < e; k++) grid_take(b, g.pts[k], qx, qy, qz, true);
+          if (tr) {
+            tr->points += e - s;
+            tr->words += 2;
+          }
         }
     }
   }

@@ -74,9 +74,13 @@ __global__ __launch_bounds__(kGridBlock) void grid_nearest_kernel(GridView g, co
   const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
   float4 best;
   float best_d;
-  int why = 0;
-  const GridVerdict v = grid_nearest(g, qx, qy, qz, max_range_sq, __builtin_inff(), best, best_d, kWhy ? &why : nullptr);
-  if (kWhy && why) atomicAdd(&why_counts[why], 1u);
+  GridTrace tr;
+  const GridVerdict v = grid_nearest(g, qx, qy, qz, max_range_sq, __builtin_inff(), best, best_d, kWhy ? &tr : nullptr);
+  if (kWhy) {  // why_counts: [1..7] reasons, [8] / [9] point records / bound words read (64-bit, two words each)
+    if (tr.why) atomicAdd(&why_counts[tr.why], 1u);
+    atomicAdd(reinterpret_cast<unsigned long long *>(why_counts + 8), (unsigned long long)tr.points);
+    atomicAdd(reinterpret_cast<unsigned long long *>(why_counts + 10), (unsigned long long)tr.words);
+  }
   if (v == GRID_FOUND) {
     out_id[i] = __float_as_int(best.w);
     out_dsq[i] = best_d;
@@ -122,7 +126,12 @@ pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labe
   }
   if (dims == 0) return PCGX_OK;  // all points identical
   // ~2 points per cell of the occupied volume; a thin axis gets one layer of cells
-  double h = pow(vol / ((double)n / 2.0), 1.0 / dims);
+  double occ = 2.0;  // PCGX_GRID_OCC: tuning knob, points per cell
+  if (const char *e = getenv("PCGX_GRID_OCC")) {
+    const double v = atof(e);
+    if (v >= 0.25 && v <= 16.0) occ = v;
+  }
+  double h = pow(vol / ((double)n / occ), 1.0 / dims);
   GridView g;
   memset(&g, 0, sizeof g);
   int64_t cells = 0;
@@ -137,7 +146,7 @@ pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labe
       ok = ok && d[k] < (1 << 20);
     }
     cells = ok ? d[0] * d[1] * d[2] : 0;
-    if (ok && cells <= 4 * n + 4096) {
+    if (ok && cells <= 8 * n + 4096) {
       g.nx = (int32_t)d[0];
       g.ny = (int32_t)d[1];
       g.nz = (int32_t)d[2];
@@ -210,7 +219,7 @@ pcgx_status grid_launch_nearest(const pcgx_kdtree *t, const float *d_q, const in
   PCGX_TRY(ar.alloc_n(1, &d_count));
   PCGX_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), st));
   {
-    ProfScope prof(PCGX_PROF_KNN_WALK, st);
+    ProfScope prof(PCGX_PROF_KNN_GRID, st);
     hipLaunchKernelGGL(grid_nearest_kernel<false>, dim3((unsigned)((nq + kGridBlock - 1) / kGridBlock)),
                        dim3(kGridBlock), 0, st, t->grid, d_q, d_perm, nq, max_range_sq, d_ids, d_dsq, d_list, d_count,
                        (uint32_t *)nullptr);
@@ -224,13 +233,13 @@ pcgx_status grid_launch_nearest(const pcgx_kdtree *t, const float *d_q, const in
 // Debug / tuning aid (not part of the drop-in surface): how many of the queries the grid pass leaves
 // to the tree walk, and the tree's grid parameters.  out[0] = queries left to the walk, out[1] =
 // cells, out[2] = crowding * 1000, out[3] = grid enabled, out[4 + k] = queries with reason k (knn_grid.h,
-// grid_nearest `why`; k = 1..7).
+// GridTrace::why; k = 1..7), out[12] / out[13] = point records / cell-bound words the pass read.
 extern "C" pcgx_status pcgx_debug_grid_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
-                                             int64_t out[12]) {
+                                             int64_t out[14]) {
   PCGX_API_LOCK();
   if (!t || !out || nq < 0 || (nq > 0 && !d_q)) return pcgx::fail(PCGX_E_INVALID, "pcgx_debug_grid_stats: bad argument");
   PCGX_TRY(pcgx::ensure_init());
-  for (int k = 0; k < 12; k++) out[k] = 0;
+  for (int k = 0; k < 14; k++) out[k] = 0;
   out[2] = (int64_t)(t->grid_crowding * 1000.0);
   out[3] = pcgx::grid_enabled(t) ? 1 : 0;
   if (!out[3]) return PCGX_OK;
@@ -241,19 +250,21 @@ extern "C" pcgx_status pcgx_debug_grid_stats(const pcgx_kdtree *t, const float *
   PCGX_TRY(ar.begin(st));
   int32_t *d_list = nullptr, *d_ids = nullptr;
   float *d_dsq = nullptr;
-  uint32_t *d_count = nullptr;  // [0] walk count, [8 + k] reasons
+  uint32_t *d_count = nullptr;  // [0] walk count, [8 + k] reasons, [16..19] 64-bit totals
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_list));
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_ids));
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_dsq));
-  PCGX_TRY(ar.alloc_n(16, &d_count));
-  PCGX_HIP_TRY(hipMemsetAsync(d_count, 0, 16 * sizeof(uint32_t), st));
+  PCGX_TRY(ar.alloc_n(24, &d_count));
+  PCGX_HIP_TRY(hipMemsetAsync(d_count, 0, 24 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(pcgx::grid_nearest_kernel<true>, dim3((unsigned)((nq + pcgx::kGridBlock - 1) / pcgx::kGridBlock)),
                      dim3(pcgx::kGridBlock), 0, st, t->grid, d_q, (const int32_t *)nullptr, nq, max_range * max_range,
                      d_ids, d_dsq, d_list, d_count, d_count + 8);
-  uint32_t c[16];
+  uint32_t c[24];
   PCGX_HIP_TRY(hipMemcpyAsync(c, d_count, sizeof c, hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
   out[0] = (int64_t)c[0];
   for (int k = 1; k < 8; k++) out[4 + k] = (int64_t)c[8 + k];
+  out[12] = (int64_t)(((uint64_t)c[17] << 32) | c[16]);
+  out[13] = (int64_t)(((uint64_t)c[19] << 32) | c[18]);
   return PCGX_OK;
 }

@@ -190,6 +190,13 @@ class IcpSession:
                                                     C.byref(self.params), sums, C.byref(h)))
         self._h = h
 
+    def grid_stats(self, stream=0):
+        """Measurement aid: (targets, targets left to the walk, point records, cell-bound words) the
+        grid pass of the NEXT iteration would read; zeros when the base tree has no grid."""
+        out = (C.c_int64 * 4)()
+        L.check(L.lib().pcgx_debug_icp_grid_stats(self._h, L.ptr(stream) if stream else None, out))
+        return tuple(out)
+
     def partials(self, stream=0):
         L.check(L.lib().pcgx_icp_session_partials(self._h, L.ptr(stream) if stream else None))
 

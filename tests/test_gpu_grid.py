@@ -1,0 +1,174 @@
+"""The certified grid fast path of KDTree.Nearest (csrc/knn_grid.h) against the oracle's walk.
+
+The grid may only answer what does not depend on the reference's visit order; ties, DistSq ==
+maxRange^2, sparse spots and non-finite queries must reach the tree walk.  Every case compares ID and
+DistSq bit for bit with oracle/pcgol_oracle.c (kdtree.go:83-146) and with the walk-only library path
+(PCGX_GRID=0)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from pcgol_amd import _lib as L
+from pcgol_amd import icp, kdtree, synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _grid_stats(t, q, max_range):
+    import torch
+    dq = torch.from_numpy(np.ascontiguousarray(q, f32)).cuda()
+    out = (C.c_int64 * 14)()
+    L.check(L.lib().pcgx_debug_grid_stats(t._h, L.ptr(dq.data_ptr()), len(q), max_range, out))
+    return list(out)
+
+
+def _check(pts, q, max_range, expect_grid=True):
+    t, o = kdtree.New(pts), O.KDTree(pts)
+    ids, dsq = t.NearestBatch(q, max_range)
+    oi, od = o.nearest_batch(q, max_range)
+    assert np.array_equal(dsq, od, equal_nan=True)
+    assert np.array_equal(ids, oi)
+    st = _grid_stats(t, q, max_range)
+    assert st[3] == (1 if expect_grid else 0)
+    return t, st
+
+
+@pytest.mark.parametrize("n,width,seed", [(64, 1.0, 0), (1000, 3.0, 1), (40000, 10.0, 2), (200000, 25.0, 3)])
+def test_uniform_clouds_queries_inside_and_outside(n, width, seed):
+    pts = synth.uniform_cloud(n, width, 10 + seed)
+    rng = np.random.default_rng(seed)
+    q = np.concatenate([synth.uniform_cloud(20000, width, 20 + seed),
+                        rng.uniform(-0.5 * width, 1.5 * width, (5000, 3)).astype(f32),   # around the box
+                        rng.uniform(-50 * width, 50 * width, (200, 3)).astype(f32),      # far away
+                        pts[:500]])                                                         # on base points
+    for max_range in (width * 10, width * 0.05):
+        t, st = _check(pts, q, max_range)
+        assert st[0] < len(q)  # the grid answered something
+
+
+def test_max_range_boundaries():
+    """DistSq == maxRange^2 is accepted for a leaf and not for a pivot (kdtree.go:100-103 vs :117): the
+    grid must hand those to the walk; just below / above it answers itself."""
+    pts = synth.uniform_cloud(5000, 4.0, 5)
+    o = O.KDTree(pts)
+    q = synth.uniform_cloud(3000, 4.0, 6)
+    _, d0 = o.nearest_batch(q, 100.0)
+    t = kdtree.New(pts)
+    for k in range(0, 3000, 7):
+        r = f32(np.sqrt(np.float64(d0[k])))
+        for mr in (r, np.nextafter(r, f32(0)), np.nextafter(r, f32(10))):
+            got = t.Nearest(q[k], float(mr))
+            oi, od = o.nearest_batch(q[k:k + 1], float(mr))
+            assert got.ID == oi[0] and f32(got.DistSq) == od[0], (k, mr)
+
+
+def test_lattice_every_query_tied_goes_to_the_walk():
+    g = np.stack(np.meshgrid(*[np.arange(16)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(f32)
+    pts = g[np.random.default_rng(0).permutation(len(g))]
+    q = (np.random.default_rng(1).integers(0, 31, (20000, 3)).astype(f32) * f32(0.5))
+    t, st = _check(pts, q, 3.0)
+    assert st[4 + 5] > 1000  # reason 5: ties
+
+
+def test_duplicate_points_and_clusters():
+    rng = np.random.default_rng(3)
+    base = synth.uniform_cloud(3000, 5.0, 7)
+    pts = np.concatenate([base, base[:1000], base[:300]])          # exact duplicates
+    centres = rng.uniform(0, 5, (20, 3)).astype(f32)
+    clusters = (centres[rng.integers(0, 20, 20000)] + rng.normal(0, 0.01, (20000, 3))).astype(f32)
+    pts = np.concatenate([pts, clusters])[rng.permutation(24300)]
+    q = np.concatenate([synth.uniform_cloud(10000, 5.0, 8), clusters[:5000] + f32(0.003)])
+    t, o = kdtree.New(pts), O.KDTree(pts)
+    ids, dsq = t.NearestBatch(q, 1.0)
+    oi, od = o.nearest_batch(q, 1.0)
+    assert np.array_equal(dsq, od) and np.array_equal(ids, oi)
+
+
+@pytest.mark.parametrize("shape", ["plane", "line", "slab"])
+def test_degenerate_extents(shape):
+    rng = np.random.default_rng(4)
+    pts = synth.uniform_cloud(20000, 8.0, 9)
+    if shape == "plane":
+        pts[:, 2] = f32(1.25)
+    elif shape == "line":
+        pts[:, 1] = f32(-3.0)
+        pts[:, 2] = f32(0.5)
+    else:
+        pts[:, 0] = (pts[:, 0] * f32(0.001)).astype(f32)
+    q = (pts[rng.integers(0, len(pts), 8000)] + rng.normal(0, 0.05, (8000, 3))).astype(f32)
+    t, o = kdtree.New(pts), O.KDTree(pts)
+    ids, dsq = t.NearestBatch(q, 2.0)
+    oi, od = o.nearest_batch(q, 2.0)
+    assert np.array_equal(dsq, od) and np.array_equal(ids, oi)
+
+
+def test_surface_cloud_forced_grid_and_default(monkeypatch):
+    """Surfaces in a box crowd few cells: the grid is switched off by default (crowding), forced on
+    with PCGX_GRID=2; both give the oracle's answers."""
+    pts = np.ascontiguousarray(synth.surface_cloud(60000, 10.0, 11)[0], f32)
+    q = (pts[::3] + f32(0.004)).astype(f32)
+    o = O.KDTree(pts)
+    oi, od = o.nearest_batch(q, 1.0)
+    for mode in (None, "2", "0"):
+        if mode is None:
+            monkeypatch.delenv("PCGX_GRID", raising=False)
+        else:
+            monkeypatch.setenv("PCGX_GRID", mode)
+        t = kdtree.New(pts)
+        ids, dsq = t.NearestBatch(q, 1.0)
+        assert np.array_equal(dsq, od) and np.array_equal(ids, oi), mode
+
+
+def test_non_finite_queries_reach_the_walk():
+    pts = synth.uniform_cloud(5000, 2.0, 12)
+    q = synth.uniform_cloud(200, 2.0, 13)
+    q[3, 0] = np.nan
+    q[7, 1] = np.inf
+    q[11, 2] = -np.inf
+    q[13] = np.nan
+    _check(pts, q, 5.0)
+
+
+def test_grid_and_walk_only_agree_at_c2_size(monkeypatch):
+    pts = synth.uniform_cloud(1_000_000, 10.0, 2)
+    q = synth.uniform_cloud(300_000, 10.0, 3)
+    t = kdtree.New(pts)
+    a = t.NearestBatch(q, 10.0)
+    st = _grid_stats(t, q, 10.0)
+    assert st[3] == 1 and st[0] < 100  # nearly everything certified
+    monkeypatch.setenv("PCGX_GRID", "0")
+    b = t.NearestBatch(q, 10.0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    o = O.KDTree(pts)
+    oi, od = o.nearest_batch(q[:20000], 10.0)
+    assert np.array_equal(a[0][:20000], oi) and np.array_equal(a[1][:20000], od)
+
+
+def test_icp_pairs_grid_vs_walk_vs_oracle(monkeypatch):
+    """Iteration 0 (no hint) and a later iteration (hint = previous match) of a session: pairs from
+    the grid pass equal the walk-only pairs and the oracle's."""
+    c = synth.c4_icp(n=50000, width=3.7)
+    t, o = kdtree.New(c["base"]), O.KDTree(c["base"])
+    ob, ot, od = O.icp_pairs(o, c["target"], c["max_dist"])
+    corr = icp.NearestPointCorresponder(MaxDist=c["max_dist"])
+    b, ti, d = corr.PairsArrays(t, c["target"])
+    assert np.array_equal(b, ob) and np.array_equal(ti, ot) and np.array_equal(d, od)
+
+    def fit():
+        s = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], 8)
+        for _ in range(8):
+            s.step()
+        r = s.result()
+        sums = s.read_sums()
+        s.close()
+        return r, sums
+    (tr1, st1, _), s1 = fit()
+    monkeypatch.setenv("PCGX_GRID", "0")
+    (tr0, st0, _), s0 = fit()
+    # the float64 sums are added in a different (fixed) order: equal to ~1e-15, poses to a float32 ulp or two
+    assert s1[9] == s0[9] and np.allclose(s1, s0, rtol=1e-12, atol=1e-12)
+    assert np.max(np.abs(tr1 - tr0)) <= 1e-6

@@ -13,9 +13,9 @@ t = kdtree.New(pts)
 dq = torch.from_numpy(q).cuda()
 ids = torch.empty(n, dtype=torch.int32, device="cuda")
 dsq = torch.empty(n, dtype=torch.float32, device="cuda")
-out = (C.c_int64 * 12)()
+out = (C.c_int64 * 14)()
 L.check(L.lib().pcgx_debug_grid_stats(t._h, L.ptr(dq.data_ptr()), n, mr, out))
-print("grid stats: walk", out[0], "cells", out[1], "crowding", out[2] / 1000, "enabled", out[3], "why[1..7]", list(out)[5:12], flush=True)
+print("grid stats: walk", out[0], "cells", out[1], "crowding", out[2] / 1000, "enabled", out[3], "why[1..7]", list(out)[5:12], "points/query", out[12] / n, "words/query", out[13] / n, flush=True)
 
 def bench(label, presort, reps=10):
     for _ in range(2):
