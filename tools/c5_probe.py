@@ -67,9 +67,13 @@ for rep in range(2):
         sicp.step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    ms, k = L.prof_read(L.PROF_ICP_WALK)
-    print("fit %d: 20 iterations %.2f ms (%.1f Mpoints/s), corr kernel %.3f ms" %
-          (rep, dt * 1e3, nt * 20 / dt / 1e6, ms / max(k, 1)), flush=True)
+    ms, k = L.prof_read(L.PROF_ICP_GRID)
+    which = "grid kernel"
+    if k == 0:  # base tree without a grid: the walk kernel does the work
+        ms, k = L.prof_read(L.PROF_ICP_WALK)
+        which = "corr kernel"
+    print("fit %d: 20 iterations %.2f ms (%.1f Mpoints/s), %s %.3f ms" %
+          (rep, dt * 1e3, nt * 20 / dt / 1e6, which, ms / max(k, 1)), flush=True)
 trans, stat, _ = sicp.result()
 err = np.abs(np.asarray(trans, np.float64).reshape(4, 4) - np.linalg.inv(synth.icp_pose().astype(np.float64).reshape(4, 4).T).T)
 print("final Value %.3e, |trans - inverse pose|max %.2e" % (float(stat.Evaluated.Value), float(err.max())))
