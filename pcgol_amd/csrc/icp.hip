@@ -278,7 +278,7 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
     uint32_t *__restrict__ walk_list, uint32_t *__restrict__ walk_count, uint32_t n_corr_blocks,
     double *__restrict__ block_partials, unsigned long long *__restrict__ trace = nullptr) {
   constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
-  __shared__ float s_terms[NS][kIcpGridBlock];
+  __shared__ float s_terms[NS][kIcpGridBlock + 16];  // + 16: the kSub-lane groups of one wave land on different banks
   if (state->done) return;  // uniform
   const int64_t i = (int64_t)blockIdx.x * kIcpGridBlock + threadIdx.x;
   double acc[NS];
