@@ -80,6 +80,8 @@ enum {
   PCGX_PROF_KNN_GRID = 5,   /* grid_nearest_kernel */
   PCGX_PROF_KINDS = 6
 };
+/* on: 0 = off, 1 = every launch, n > 1 = every n-th launch of each kind (a pair of events around a
+ * 30 us kernel costs several us of stream time: sampling keeps the timed run close to the untimed one). */
 PCGX_API pcgx_status pcgx_prof_enable(int32_t on);
 /* Resolves pending events; returns accumulated milliseconds and launch count
  * of `kind` since the last pcgx_prof_reset(). */

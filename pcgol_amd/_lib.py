@@ -30,7 +30,8 @@ PROF_ICP_WALK, PROF_KNN_WALK, PROF_VOXEL_ALL, PROF_SORT_SCATTER, PROF_ICP_GRID, 
 
 
 def prof_enable(on=True):
-    check(lib().pcgx_prof_enable(1 if on else 0))
+    """True / 1: time every launch; n > 1: every n-th launch of each kind; False / 0: off."""
+    check(lib().pcgx_prof_enable(int(on)))
 
 
 def prof_reset():

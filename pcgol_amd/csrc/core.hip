@@ -128,6 +128,8 @@ pcgx_status ensure_init() {
 namespace {
 struct ProfRec { hipEvent_t a, b; int kind; };
 bool g_prof_on = false;
+int g_prof_stride = 1;                 // time every n-th scope of a kind
+int64_t g_prof_seen[PCGX_PROF_KINDS];  // scopes opened per kind
 std::vector<ProfRec> g_prof_pending;
 std::vector<hipEvent_t> g_prof_pool;
 double g_prof_ms[PCGX_PROF_KINDS];
@@ -161,6 +163,7 @@ void prof_resolve() {
 ProfScope::ProfScope(int kind, hipStream_t st) : kind_(kind), st_(st) {
   if (!g_prof_on || kind < 0) return;  // kind < 0: not timed
   std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (g_prof_seen[kind]++ % g_prof_stride != 0) return;
   a_ = prof_event();
   b_ = prof_event();
   if (a_) (void)hipEventRecord(a_, st_);
@@ -266,6 +269,8 @@ extern "C" pcgx_status pcgx_prof_enable(int32_t on) {
   PCGX_TRY(ensure_init());
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;
+  g_prof_stride = on > 1 ? on : 1;
+  for (int k = 0; k < PCGX_PROF_KINDS; k++) g_prof_seen[k] = 0;
   return PCGX_OK;
 }
 
