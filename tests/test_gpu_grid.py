@@ -172,3 +172,41 @@ def test_icp_pairs_grid_vs_walk_vs_oracle(monkeypatch):
     # the float64 sums are added in a different (fixed) order: equal to ~1e-15, poses to a float32 ulp or two
     assert s1[9] == s0[9] and np.allclose(s1, s0, rtol=1e-12, atol=1e-12)
     assert np.max(np.abs(tr1 - tr0)) <= 1e-6
+
+
+def test_random_clouds_grid_equals_walk_equals_oracle(monkeypatch):
+    """Randomly drawn shapes -- anisotropic boxes, large offsets, mixtures of uniform / clustered /
+    planar parts, queries near and far, small and large maxRange: the default path (grid where it is
+    built) must equal the walk-only path bit for bit, and both the oracle on a sample."""
+    rng = np.random.default_rng(2026)
+    used = 0
+    for case in range(40):
+        n = int(rng.choice([300, 2000, 20000, 60000]))
+        ext = rng.choice([0.05, 1.0, 7.0, 300.0], 3).astype(np.float64)
+        off = rng.choice([0.0, -3.0, 1.0e3, -2.5e4], 3)
+        parts = []
+        kind = rng.integers(0, 4)
+        u = rng.random((n, 3))
+        if kind == 1:   # clusters
+            c = rng.random((8, 3))
+            u = c[rng.integers(0, 8, n)] + rng.normal(0, 0.01, (n, 3))
+        elif kind == 2:  # half on a plane
+            u[: n // 2, int(rng.integers(0, 3))] = 0.5
+        elif kind == 3:  # density gradient
+            u[:, 0] = u[:, 0] ** 3
+        pts = (u * ext + off).astype(f32)
+        nq = 6000
+        q = np.concatenate([
+            (pts[rng.integers(0, n, nq // 2)] + rng.normal(0, 0.02, (nq // 2, 3)) * ext).astype(f32),
+            (rng.random((nq // 2, 3)) * 1.4 * ext - 0.2 * ext + off).astype(f32)])
+        max_range = float(rng.choice([0.01, 0.2, 5.0]) * ext.max())
+        monkeypatch.delenv("PCGX_GRID", raising=False)
+        t = kdtree.New(pts)
+        a = t.NearestBatch(q, max_range)
+        used += _grid_stats(t, q, max_range)[3]
+        monkeypatch.setenv("PCGX_GRID", "0")
+        b = t.NearestBatch(q, max_range)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), case
+        oi, od = O.KDTree(pts).nearest_batch(q[::6], max_range)
+        assert np.array_equal(a[0][::6], oi) and np.array_equal(a[1][::6], od), case
+    assert used >= 10  # the grid was in use for a good part of the cases
