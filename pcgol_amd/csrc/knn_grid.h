@@ -11,13 +11,14 @@
 //
 // So every tree also gets a uniform grid over its bounding box (~2 points per cell, points stored
 // in cell order).  A query scans the cells that can hold a point within its current bound (the
-// nearest point of its own cell, or the hint the ICP loop carries over), keeps the minimum and
-// whether it is tied, and accepts the result only when the scanned cells provably hold EVERY point
-// at or below that minimum (grid_cover: monotonic float binning, no tolerances).  Everything else --
-// ties, DistSq == maxRange^2, a search region beyond 3 x 3 x 5 cells, non-finite queries,
-// MinDistSq > 0 (approximate search, depends on the visit order) -- goes to the tree walk
-// (knn_walk.h), which reproduces the reference's visit order.  Results are the walk's, bit for bit; the grid only removes
-// the dependent-load chains of the descent for the queries where the answer does not depend on them.
+// nearest point found in the cells around it, or the hint the ICP loop carries over), keeps the
+// minimum and whether it is tied, and accepts the result only when the scanned cells provably hold
+// EVERY point at or below that minimum (grid_cover: monotonic float binning, no tolerances).
+// Everything else -- ties, DistSq == maxRange^2, a search region beyond 5 x 5 x 5 cells, non-finite
+// queries, MinDistSq > 0 (approximate search, depends on the visit order) -- goes to the tree walk
+// (knn_walk.h), which reproduces the reference's visit order.  Results are the walk's, bit for bit;
+// the grid only removes the dependent-load chains of the descent for the queries where the answer
+// does not depend on them.
 #pragma once
 #include "pcgx_internal.h"
 
@@ -124,7 +125,6 @@ __device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint
   }
 }
 
-
 // Nearest of an exact-mode query (MinDistSq == 0) if the grid can certify it.  ub: squared distance
 // (the same float32 expression) from q to ANY point of the tree, +inf if unknown.  GRID_FOUND: best /
 // best_d are the reference's answer; GRID_NONE: {-1, maxRange^2} is (kdtree.go:100-103); GRID_WALK:
@@ -139,8 +139,8 @@ __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const flo
                                                     float &best_d, GridTrace *tr = nullptr) {
 #define PCGX_GRID_WHY(code) do { if (tr) tr->why = (code); } while (0)
   // non-finite queries: NaN distances follow the walk's comparisons, not an ordering
-  if (!(fabsf(qx) < 3.0e38f && fabsf(qy) < 3.0e38f && fabsf(qz) < 3.0e38f)) {
-    PCGX_GRID_WHY(1);
+  if (!(fabsf(qx) < 3.0e38f && fabsf(qy) < 3.0e38f && fabsf(qz) < 3.0e38f) || max_range_sq != max_range_sq) {
+    PCGX_GRID_WHY(1);  // (a NaN maxRange^2 compares false with everything: the walk's rules decide)
     return GRID_WALK;
   }
   // the answer is a point with DistSq <= bound (ub is attained by a real point)

@@ -210,3 +210,15 @@ def test_random_clouds_grid_equals_walk_equals_oracle(monkeypatch):
         oi, od = O.KDTree(pts).nearest_batch(q[::6], max_range)
         assert np.array_equal(a[0][::6], oi) and np.array_equal(a[1][::6], od), case
     assert used >= 10  # the grid was in use for a good part of the cases
+
+
+@pytest.mark.parametrize("max_range", [float("nan"), float("inf"), -0.3, 0.0, 1.0e20, 1.0e-30])
+def test_odd_max_range_values(max_range):
+    """maxRange only enters as maxRange * maxRange (kdtree.go:91): NaN compares false with everything,
+    +inf / 1e20 square to +inf, 0 and 1e-30 leave nothing in range except exact hits."""
+    pts = synth.uniform_cloud(4000, 2.0, 21)
+    q = np.concatenate([synth.uniform_cloud(1500, 2.0, 22), pts[:200]])
+    t, o = kdtree.New(pts), O.KDTree(pts)
+    ids, dsq = t.NearestBatch(q, max_range)
+    oi, od = o.nearest_batch(q, max_range)
+    assert np.array_equal(ids, oi) and np.array_equal(dsq, od, equal_nan=True)
