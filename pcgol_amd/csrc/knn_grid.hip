@@ -126,37 +126,11 @@ pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labe
   }
   if (dims == 0) return PCGX_OK;  // all points identical
   // ~2 points per cell of the occupied volume; a thin axis gets one layer of cells
-  double occ = 2.0;  // PCGX_GRID_OCC: tuning knob, points per cell
+  double occ = 2.0;  // PCGX_GRID_OCC: tuning knob, points per cell of the bounding box's volume
   if (const char *e = getenv("PCGX_GRID_OCC")) {
     const double v = atof(e);
     if (v >= 0.25 && v <= 16.0) occ = v;
   }
-  double h = pow(vol / ((double)n / occ), 1.0 / dims);
-  GridView g;
-  memset(&g, 0, sizeof g);
-  int64_t cells = 0;
-  for (int tries = 0; tries < 64; tries++) {
-    g.h = (float)h;
-    g.inv_h = 1.0f / g.h;
-    if (!(g.h > 0.0f) || !(g.inv_h < 1.0e30f)) return PCGX_OK;
-    int64_t d[3];
-    bool ok = true;
-    for (int k = 0; k < 3; k++) {
-      d[k] = (int64_t)((double)ext[k] * (double)g.inv_h) + 1;
-      ok = ok && d[k] < (1 << 20);
-    }
-    cells = ok ? d[0] * d[1] * d[2] : 0;
-    if (ok && cells <= 8 * n + 4096) {
-      g.nx = (int32_t)d[0];
-      g.ny = (int32_t)d[1];
-      g.nz = (int32_t)d[2];
-      break;
-    }
-    cells = 0;
-    h *= 1.26;
-  }
-  if (cells == 0) return PCGX_OK;
-  for (int k = 0; k < 3; k++) g.lo[k] = t->bbox_lo[k];
   Arena &ar = ctx().arena;  // the caller has begun it
   uint32_t *keys[2], *vals[2];
   void *ws = nullptr;
@@ -171,33 +145,82 @@ pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labe
     PCGX_TRY(ar.alloc_n(radix_sort_workspace_bytes(n), &w));
     ws = w;
   }
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  GridView g;
+  int res = 0;
+  double crowding = 0.0;
+  // A cloud that fills its box evenly has ~occ other points in a point's cell.  Surfaces and other
+  // thin shapes crowd the few cells they pass through: the cells are then made smaller (a surface's
+  // crowding goes with h^2) until a point has ~3 neighbours in its cell, within 32 cells per point.
+  for (int attempt = 0; attempt < 3; attempt++) {
+    double h = pow(vol / ((double)n / occ), 1.0 / dims);
+    memset(&g, 0, sizeof g);
+    int64_t cells = 0;
+    for (int tries = 0; tries < 64; tries++) {
+      g.h = (float)h;
+      g.inv_h = 1.0f / g.h;
+      if (!(g.h > 0.0f) || !(g.inv_h < 1.0e30f)) break;
+      int64_t d[3];
+      bool ok = true;
+      for (int k = 0; k < 3; k++) {
+        d[k] = (int64_t)((double)ext[k] * (double)g.inv_h) + 1;
+        ok = ok && d[k] < (1 << 20);
+      }
+      cells = ok ? d[0] * d[1] * d[2] : 0;
+      if (ok && cells <= 32 * n + 4096 && cells <= ((int64_t)1 << 28)) {
+        g.nx = (int32_t)d[0];
+        g.ny = (int32_t)d[1];
+        g.nz = (int32_t)d[2];
+        break;
+      }
+      cells = 0;
+      h *= 1.26;
+    }
+    if (cells == 0) {
+      grid_free(t);
+      return PCGX_OK;
+    }
+    for (int k = 0; k < 3; k++) g.lo[k] = t->bbox_lo[k];
+    dev_cache_free(t->d_gstart);
+    t->d_gstart = nullptr;
+    // pad elements: one in front, one behind (GridQuad)
+    hipError_t e = dev_cache_alloc((void **)&t->d_gstart, (size_t)(cells + 3) * sizeof(uint32_t));
+    if (e != hipSuccess) {
+      grid_free(t);
+      return fail(PCGX_E_OOM, "grid allocation failed: %s", hipGetErrorString(e));
+    }
+    g.start = t->d_gstart + 1;
+    PCGX_HIP_TRY(hipMemsetAsync(d_crowd, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(grid_key_points_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n, g, keys[0], vals[0]);
+    int key_bits = 1;
+    while (((int64_t)1 << key_bits) < cells) key_bits++;
+    PCGX_TRY(radix_sort_pairs(keys, vals, n, key_bits, ws, &res, st));
+    hipLaunchKernelGGL(grid_start_kernel, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, st,
+                       (const uint32_t *)keys[res], n, (uint32_t)cells, t->d_gstart + 1, d_crowd);
+    unsigned long long crowd = 0;
+    PCGX_HIP_TRY(hipMemcpyAsync(&crowd, d_crowd, sizeof crowd, hipMemcpyDeviceToHost, st));
+    PCGX_HIP_TRY(hipStreamSynchronize(st));
+    // mean number of OTHER points in a point's cell
+    crowding = (double)crowd / (double)n;
+    double finer = occ * pow(3.0 / crowding, 1.5);
+    const double occ_min = occ * (double)cells / (30.0 * (double)n);  // stays under 32 cells per point
+    if (finer < occ_min) finer = occ_min;
+    if (crowding <= 4.0 || attempt == 2 || finer > 0.7 * occ) break;
+    occ = finer;
+  }
   hipError_t e = dev_cache_alloc((void **)&t->d_gpts, (size_t)n * sizeof(float4));
-  if (e == hipSuccess) e = dev_cache_alloc((void **)&t->d_gstart, (size_t)(cells + 3) * sizeof(uint32_t));  // one pad element either side (GridQuad)
   if (e != hipSuccess) {
     grid_free(t);
     return fail(PCGX_E_OOM, "grid allocation failed: %s", hipGetErrorString(e));
   }
   g.pts = t->d_gpts;
-  g.start = t->d_gstart + 1;
-  const unsigned nb = (unsigned)((n + 255) / 256);
-  PCGX_HIP_TRY(hipMemsetAsync(d_crowd, 0, sizeof(unsigned long long), st));
-  hipLaunchKernelGGL(grid_key_points_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n, g, keys[0], vals[0]);
-  int key_bits = 1;
-  while (((int64_t)1 << key_bits) < cells) key_bits++;
-  int res = 0;
-  PCGX_TRY(radix_sort_pairs(keys, vals, n, key_bits, ws, &res, st));
   hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, (const uint32_t *)vals[res], d_labels, n,
                      t->d_gpts);
-  hipLaunchKernelGGL(grid_start_kernel, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, st,
-                     (const uint32_t *)keys[res], n, (uint32_t)cells, t->d_gstart + 1, d_crowd);
-  unsigned long long crowd = 0;
-  PCGX_HIP_TRY(hipMemcpyAsync(&crowd, d_crowd, sizeof crowd, hipMemcpyDeviceToHost, st));
-  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));  // vals[] live in the arena
   t->grid = g;
-  // mean number of OTHER points in a point's cell: ~2 for a volume filled evenly; clouds that
-  // crowd a few cells (surfaces in a large box, clusters) are better served by the tree
-  t->grid_crowding = (double)crowd / (double)n;
-  t->grid_ok = t->grid_crowding <= 12.0 || grid_mode() == 2;
+  // clouds that still crowd their cells (tight clusters) are better served by the tree
+  t->grid_crowding = crowding;
+  t->grid_ok = crowding <= 12.0 || grid_mode() == 2;
   if (!t->grid_ok) {
     dev_cache_free(t->d_gpts);
     dev_cache_free(t->d_gstart);

@@ -7,8 +7,12 @@ from pcgol_amd import kdtree, synth, _lib as L
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 w = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 mr = float(sys.argv[3]) if len(sys.argv) > 3 else 10.0
-pts = synth.uniform_cloud(n, w, 2)
-q = synth.uniform_cloud(n, w, 3)
+if os.environ.get("PROBE_SURFACE"):  # points on a curved surface, queries 2 cm off it
+    pts = synth.surface_cloud(n, w, 2)[0]
+    q = (synth.surface_cloud(n, w, 3)[0] + np.float32(0.02)).astype(np.float32)
+else:
+    pts = synth.uniform_cloud(n, w, 2)
+    q = synth.uniform_cloud(n, w, 3)
 t = kdtree.New(pts)
 dq = torch.from_numpy(q).cuda()
 ids = torch.empty(n, dtype=torch.int32, device="cuda")
