@@ -107,8 +107,9 @@ def test_degenerate_extents(shape):
 
 
 def test_surface_cloud_forced_grid_and_default(monkeypatch):
-    """Surfaces in a box crowd few cells: the grid is switched off by default (crowding), forced on
-    with PCGX_GRID=2; both give the oracle's answers."""
+    """Surfaces in a box crowd the few cells they pass through: the build refines the cells until a
+    point has ~3 neighbours in its own (so the grid stays in use); default, forced (PCGX_GRID=2) and
+    walk-only runs all give the oracle's answers."""
     pts = np.ascontiguousarray(synth.surface_cloud(60000, 10.0, 11)[0], f32)
     q = (pts[::3] + f32(0.004)).astype(f32)
     o = O.KDTree(pts)
@@ -121,6 +122,9 @@ def test_surface_cloud_forced_grid_and_default(monkeypatch):
         t = kdtree.New(pts)
         ids, dsq = t.NearestBatch(q, 1.0)
         assert np.array_equal(dsq, od) and np.array_equal(ids, oi), mode
+        if mode is None:
+            st = _grid_stats(t, q, 1.0)
+            assert st[3] == 1 and st[2] <= 6000 and st[1] > 4 * len(pts)  # in use, crowding <= 6, refined cells
 
 
 def test_non_finite_queries_reach_the_walk():
