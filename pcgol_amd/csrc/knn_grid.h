@@ -14,7 +14,7 @@
 // nearest point found in the cells around it, or the hint the ICP loop carries over), keeps the
 // minimum and whether it is tied, and accepts the result only when the scanned cells provably hold
 // EVERY point at or below that minimum (grid_cover: monotonic float binning, no tolerances).
-// Everything else -- ties, DistSq == maxRange^2, a search region beyond 5 x 5 x 5 cells, non-finite
+// Everything else -- ties, DistSq == maxRange^2, a search region beyond 9 x 9 x 9 cells, non-finite
 // queries, MinDistSq > 0 (approximate search, depends on the visit order) -- goes to the tree walk
 // (knn_walk.h), which reproduces the reference's visit order.  Results are the walk's, bit for bit;
 // the grid only removes the dependent-load chains of the descent for the queries where the answer
@@ -51,6 +51,8 @@ __device__ __forceinline__ GridBox grid_cover(const GridView &g, float qx, float
   return c;
 }
 
+constexpr int kGridWide = 4;  // a search region may reach this many cells from the query's own one (9 x 9 x 9)
+
 struct GridBest {
   float4 p;  // {x, y, z, bits(id)}; id < 0: none seen
   float d;   // +inf: none seen
@@ -83,8 +85,8 @@ __device__ __forceinline__ uint32_t grid_quad_at(const GridQuad &q, int k) {  //
 enum GridVerdict { GRID_FOUND = 0, GRID_NONE = 1, GRID_WALK = 2 };
 
 // Tuning / measurement aid (nullptr in the product kernels, where it compiles away): why a query
-// was left to the walk and what the scan read.  why: 1 non-finite query, 2 nothing in the 27 cells, 3
-// beyond 5 x 5 x 5 cells, 4 DistSq == maxRange^2, 5 tie, 6 bound not met, 7 took the row-by-row scan
+// was left to the walk and what the scan read.  why: 1 non-finite query, 2 nothing in the 125 cells, 3
+// beyond 9 x 9 x 9 cells, 4 DistSq == maxRange^2, 5 tie, 6 bound not met, 7 took the slab-by-slab scan
 // (not a walk).
 struct GridTrace {
   int why = 0;
@@ -133,7 +135,8 @@ __device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint
 // With a useful bound (the ICP loop's hint) the cells covering it are scanned at once.  Without one,
 // the 2 x 2 x 2 cells nearest to the query come first (the nearest point is among them most of the
 // time), then whatever else of the 3 x 3 x 3 block the distance found there still covers; a
-// region reaching beyond that block (sparse spots) is scanned cell row by cell row up to 5 x 5 x 5.
+// region reaching beyond that block (sparse spots, queries off a thin cloud) is scanned slab by slab
+// up to 9 x 9 x 9 cells.
 __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const float qx, const float qy, const float qz,
                                                     const float max_range_sq, const float ub, float4 &best,
                                                     float &best_d, GridTrace *tr = nullptr) {
@@ -254,19 +257,23 @@ __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const flo
       range(q4, box.x0, box.x1, f4, seg_s[8], seg_e[8]);
       grid_scan_segments<9>(g, seg_s, seg_e, qx, qy, qz, b, tr);
     }
+    bool guess5 = false;  // nothing in the 27 cells: the 125 around the query, checked afterwards
     if (guess) {  // the block was a guess: it must cover what was found in it
-      if (!(b.d < 3.0e38f)) {
-        PCGX_GRID_WHY(2);
-        return GRID_WALK;
+      if (b.d < 3.0e38f) {
+        box = grid_cover(g, qx, qy, qz, fminf(b.d, bound));
+        wide = box.x0 < bx0 || box.x1 > bx1 || box.y0 < by0 || box.y1 > by1 || box.z0 < bz0 || box.z1 > bz1;
+      } else {
+        box.x0 = max(cx - 2, 0); box.x1 = min(cx + 2, g.nx - 1);
+        box.y0 = max(cy - 2, 0); box.y1 = min(cy + 2, g.ny - 1);
+        box.z0 = max(cz - 2, 0); box.z1 = min(cz + 2, g.nz - 1);
+        wide = guess5 = true;
       }
-      box = grid_cover(g, qx, qy, qz, fminf(b.d, bound));
-      wide = box.x0 < bx0 || box.x1 > bx1 || box.y0 < by0 || box.y1 > by1 || box.z0 < bz0 || box.z1 > bz1;
     }
     if (wide) {
       // ---- sparse spot: `box` (the cover of the best distance so far) reaches beyond the block.
-      //      Scan all of it afresh, row by row; give up beyond 5 x 5 x 5 cells.
-      if (box.x0 < cx - 2 || box.x1 > cx + 2 || box.y0 < cy - 2 || box.y1 > cy + 2 || box.z0 < cz - 2 ||
-          box.z1 > cz + 2) {
+      //      Scan all of it afresh, slab by slab; give up beyond 9 x 9 x 9 cells (kGridWide).
+      if (box.x0 < cx - kGridWide || box.x1 > cx + kGridWide || box.y0 < cy - kGridWide || box.y1 > cy + kGridWide ||
+          box.z0 < cz - kGridWide || box.z1 > cz + kGridWide) {
         PCGX_GRID_WHY(3);
         return GRID_WALK;
       }
@@ -275,15 +282,30 @@ __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const flo
       b.d = __builtin_inff();
       b.tie = false;
       for (int z = box.z0; z <= box.z1; z++)
-        for (int y = box.y0; y <= box.y1; y++) {
-          const int row = (z * g.ny + y) * g.nx;
-          const uint32_t s = g.start[row + box.x0], e = g.start[row + box.x1 + 1];
-          for (uint32_t k = s; k < e; k++) grid_take(b, g.pts[k], qx, qy, qz, true);
-          if (tr) {
-            tr->points += e - s;
-            tr->words += 2;
+        for (int y0 = box.y0; y0 <= box.y1; y0 += 5) {  // up to 5 rows at a time: bounds in one round, points in one sequence
+          uint32_t seg_s[5], seg_e[5];
+#pragma unroll
+          for (int j = 0; j < 5; j++) {
+            const int y = y0 + j;
+            const bool on = y <= box.y1;
+            const int row = (z * g.ny + y) * g.nx;
+            seg_s[j] = on ? g.start[row + box.x0] : 0u;
+            seg_e[j] = on ? g.start[row + box.x1 + 1] : 0u;
           }
+          grid_scan_segments<5>(g, seg_s, seg_e, qx, qy, qz, b, tr);
         }
+      if (guess5) {  // the 125 cells must cover what was found in them
+        if (!(b.d < 3.0e38f)) {
+          PCGX_GRID_WHY(2);
+          return GRID_WALK;
+        }
+        const GridBox need = grid_cover(g, qx, qy, qz, fminf(b.d, bound));
+        if (need.x0 < box.x0 || need.x1 > box.x1 || need.y0 < box.y0 || need.y1 > box.y1 || need.z0 < box.z0 ||
+            need.z1 > box.z1) {
+          PCGX_GRID_WHY(3);
+          return GRID_WALK;
+        }
+      }
     }
   }
   // every point with DistSq <= min(b.d, bound) was looked at
