@@ -674,13 +674,20 @@ static int icp_grid(int64_t nt, const TreeView &tv) {
   return (int)blocks;
 }
 
-static pcgx_status reset_state(pcgx_icp_session *s, hipStream_t st) {
+// Loop state of a fresh Fit (icp.go:47): identity transform, counters zero.  On the device, in
+// stream order: a reset between two Fits costs a launch, not a host synchronisation.
+__global__ void icp_reset_kernel(IcpState *__restrict__ state) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
   IcpState h;
   memset(&h, 0, sizeof h);
-  Mat4 id = mat4_translate(0.0f, 0.0f, 0.0f);  // icp.go:47
-  memcpy(h.trans, id.m, sizeof id.m);
-  PCGX_HIP_TRY(hipMemcpyAsync(s->d_state, &h, sizeof h, hipMemcpyHostToDevice, st));
-  PCGX_HIP_TRY(hipStreamSynchronize(st));  // h is a stack temporary
+  const Mat4 id = mat4_translate(0.0f, 0.0f, 0.0f);
+  for (int i = 0; i < 16; i++) h.trans[i] = id.m[i];
+  *state = h;
+}
+
+static pcgx_status reset_state(pcgx_icp_session *s, hipStream_t st) {
+  hipLaunchKernelGGL(icp_reset_kernel, dim3(1), dim3(64), 0, st, s->d_state);
+  PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }
 
