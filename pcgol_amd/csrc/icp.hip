@@ -168,6 +168,36 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
   if (state->done) return;  // uniform
+  // grid mode: what this workgroup has to do is known before any of the walk's set-up -- usually
+  // nothing but folding its share of icp_grid_kernel's rows
+  constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
+  uint32_t slot = 0, left = 0;
+  double grid_part = 0.0;
+  if (kGrid) {
+    slot = block_slot(blockIdx.x, gridDim.x);
+    left = walk_count[slot];  // uniform
+    // this workgroup's share of icp_grid_kernel's rows, folded into its own row in a fixed order:
+    // kFold lanes per component take every kFold-th row each (their loads in flight together: one
+    // lane per component would wait for 8 dependent round trips), then fold across the lanes
+    constexpr int kFold = kPlane ? 16 : 32;
+    static_assert(NS * kFold <= kIcpBlock, "one lane per (component, residue)");
+    __shared__ double s_fold[NS];
+    if (threadIdx.x < NS * kFold) {
+      const int k = threadIdx.x / kFold, j = threadIdx.x % kFold;
+      const int64_t g0 = (int64_t)n_grid_rows * blockIdx.x / gridDim.x, g1 = (int64_t)n_grid_rows * (blockIdx.x + 1) / gridDim.x;
+      double v = 0.0;
+      for (int64_t r = g0 + j; r < g1; r += kFold) v += block_partials[((int64_t)gridDim.x + r) * NS + k];
+#pragma unroll
+      for (int o = kFold / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kFold);
+      if (j == 0) s_fold[k] = v;
+    }
+    __syncthreads();
+    grid_part = threadIdx.x < NS ? s_fold[threadIdx.x] : 0.0;
+    if (left == 0) {
+      if (threadIdx.x < NS) block_partials[(int64_t)blockIdx.x * NS + threadIdx.x] = grid_part;
+      return;
+    }
+  }
   uint32_t *queue = s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kIcpBlock +
                     (threadIdx.x >> 6) * (kWalkQueueBytesPerWave / 4);
   float *top = reinterpret_cast<float *>(s_stack + (size_t)(tv.depth > 1 ? tv.depth - 1 : 1) * kIcpBlock +
@@ -215,20 +245,7 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     // icp_grid_kernel answered what the grid could certify and summed those terms; this workgroup
     // walks what was left in its segment of walk_list (usually nothing) and sums the terms of
     // exactly those targets (flag in first_leaf[], bit 31) in the fixed order of its range
-    constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
     const int64_t r_begin = (int64_t)chunk_begin * 64;
-    const uint32_t slot = block_slot(blockIdx.x, gridDim.x);
-    const uint32_t left = walk_count[slot];  // uniform
-    // this workgroup's share of icp_grid_kernel's rows, folded into its own row (fixed order)
-    double grid_part = 0.0;
-    if (threadIdx.x < NS) {
-      const int64_t g0 = (int64_t)n_grid_rows * blockIdx.x / gridDim.x, g1 = (int64_t)n_grid_rows * (blockIdx.x + 1) / gridDim.x;
-      for (int64_t r = g0; r < g1; r++) grid_part += block_partials[((int64_t)gridDim.x + r) * NS + threadIdx.x];
-    }
-    if (left == 0) {
-      if (threadIdx.x < NS) block_partials[(int64_t)blockIdx.x * NS + threadIdx.x] = grid_part;
-      return;
-    }
     __syncthreads();
     if (threadIdx.x == 0) {
       walk_count[slot] = 0;  // for the next iteration's grid pass
