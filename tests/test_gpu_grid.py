@@ -226,3 +226,51 @@ def test_odd_max_range_values(max_range):
     ids, dsq = t.NearestBatch(q, max_range)
     oi, od = o.nearest_batch(q, max_range)
     assert np.array_equal(ids, oi) and np.array_equal(dsq, od, equal_nan=True)
+
+
+def test_icp_strict_fit_grid_equals_walk_on_random_setups(monkeypatch):
+    """Whole strict Fits (sequential float32 sums: every pair of every iteration matters bit for bit)
+    with and without the grid pass, on setups that exercise its branches: small and large MaxDist
+    (many targets without a partner), partial overlap, outliers far from the base cloud, a lattice
+    part (ties -> walk), few iterations and many."""
+    rng = np.random.default_rng(77)
+    for case in range(10):
+        n = int(rng.choice([3000, 20000, 60000]))
+        width = float(rng.choice([2.0, 6.0]))
+        base = synth.uniform_cloud(n, width, 100 + case)
+        if case % 3 == 2:  # a lattice corner: exact ties
+            g = np.stack(np.meshgrid(*[np.arange(8)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(f32) * f32(0.05)
+            base = np.concatenate([base, g])
+        pose = synth.icp_pose()
+        tgt = synth.transform_points(pose, base[rng.permutation(len(base))[: n // 2]])
+        extra = [tgt]
+        if case % 2 == 0:  # outliers and a part that overlaps nothing
+            extra.append((rng.random((500, 3)) * 3 * width - width).astype(f32))
+            extra.append((rng.random((500, 3)) * 0.3 + width * 1.5).astype(f32))
+        tgt = np.concatenate(extra).astype(f32)
+        max_dist = float(rng.choice([0.03, 0.2, 1.0]))
+        iters = int(rng.choice([3, 12]))
+        w = np.full(6, 0.3, f32)
+        th = np.full(6, -1.0, f32)
+
+        def fit():
+            t = kdtree.New(base)
+            s = icp.IcpSession(t, tgt, max_dist, 6, w, th, iters)
+            s.set_strict(True)
+            try:
+                for _ in range(iters):
+                    s.step()
+                tr, st, conv = s.result()
+                out = (tr.copy(), st.NumIteration, float(st.Evaluated.Value), st.Evaluated.NumPairs)
+            except icp.ErrNotEnoughPairs as e:
+                out = ("not enough pairs", e.stat.NumIteration if hasattr(e, "stat") else None)
+            s.close()
+            return out
+        monkeypatch.delenv("PCGX_GRID", raising=False)
+        a = fit()
+        monkeypatch.setenv("PCGX_GRID", "0")
+        b = fit()
+        if isinstance(a[0], str) or isinstance(b[0], str):
+            assert a == b, case
+        else:
+            assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (case, a[1:], b[1:])
