@@ -322,7 +322,9 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
       if (e != hipSuccess) rc = fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
     }
     if (rc == PCGX_OK) rc = build_tree_device(d_xyz, n, t->depth, d_order, t->d_nodes, d_labels, st);
-    if (rc == PCGX_OK) rc = grid_build(t, d_xyz, d_labels, st);  // has_nan is false here
+    // (has_nan is false here.  A tree rebuilt over the points left after DeletePoint -- labels -- only
+    // serves region growing's Range walks: no grid for it)
+    if (rc == PCGX_OK && !labels) rc = grid_build(t, d_xyz, d_labels, st);
     if (rc == PCGX_OK) {
       e = hipMemcpyAsync(t->inorder.data(), d_order, (size_t)n * 4, hipMemcpyDeviceToHost, st);
       if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -344,7 +346,7 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
       delete t;
       return fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
     }
-    if (!has_nan) {  // the grid of the certified fast path (knn_grid.h)
+    if (!has_nan && !labels) {  // the grid of the certified fast path (knn_grid.h)
       hipStream_t st = ctx().stream;
       Arena &ar = ctx().arena;
       pcgx_status rc = ar.begin(st);
