@@ -185,9 +185,10 @@ pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labe
     t->d_gstart = nullptr;
     // pad elements: one in front, one behind (GridQuad)
     hipError_t e = dev_cache_alloc((void **)&t->d_gstart, (size_t)(cells + 3) * sizeof(uint32_t));
-    if (e != hipSuccess) {
+    if (e != hipSuccess) {  // the grid is an accelerator, not a requirement: the tree is walked instead
+      (void)hipGetLastError();
       grid_free(t);
-      return fail(PCGX_E_OOM, "grid allocation failed: %s", hipGetErrorString(e));
+      return PCGX_OK;
     }
     g.start = t->d_gstart + 1;
     PCGX_HIP_TRY(hipMemsetAsync(d_crowd, 0, sizeof(unsigned long long), st));
@@ -210,8 +211,9 @@ pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labe
   }
   hipError_t e = dev_cache_alloc((void **)&t->d_gpts, (size_t)n * sizeof(float4));
   if (e != hipSuccess) {
+    (void)hipGetLastError();
     grid_free(t);
-    return fail(PCGX_E_OOM, "grid allocation failed: %s", hipGetErrorString(e));
+    return PCGX_OK;
   }
   g.pts = t->d_gpts;
   hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, (const uint32_t *)vals[res], d_labels, n,
