@@ -111,6 +111,18 @@ PCGX_API pcgx_status pcgx_debug_grid_stats(const pcgx_kdtree *t, const float *d_
 typedef struct pcgx_icp_session pcgx_icp_session;
 PCGX_API pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream, int64_t out[4]);
 
+/* Measurement aid: counters of the strict sums (set_strict 1) since the last call: out = {runs
+ * applied, runs whose record did not cover the state, tiles recomputed exactly, leaves of those added
+ * term by term, tile records that did not cover the state, -...}. */
+PCGX_API pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *stream, int64_t out[16]);
+
+/* The strict-sum pipeline in plain host loops (no GPU): *out = the sequential float32 sum
+ * 0 + t0 + t1 + ... computed the way the strict kernels compute it; stats as in csrc/strict_sum.h
+ * (ss_host_model).  For tests of the arithmetic.  mode bit 0: general leaf form only; bit 1: no
+ * error-prefix refinement. */
+PCGX_API pcgx_status pcgx_debug_strict_sum_host(const float *terms, int64_t n, int32_t mode, float *out,
+                                                int64_t stats[8]);
+
 /* Device memory helpers for hosts that have no HIP binding of their own. */
 PCGX_API pcgx_status pcgx_dev_alloc(size_t bytes, void **dptr);
 PCGX_API pcgx_status pcgx_dev_free(void *dptr);
@@ -319,11 +331,15 @@ PCGX_API pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream);
 /* STRICT sums.  By default the evaluator's sums are float64 reductions of the reference's float32
  * terms: more accurate than the reference, equal to it only up to ITS rounding noise (sequential
  * float32 additions, evaluator.go:122-145; ~1.6e-5 on the final transform at 1M pairs).  With
- * strict on, one wave adds the terms sequentially in float32 in target order instead: Evaluated
- * and the resulting pose are then bit-identical to the Go code's at any size, at ~7 ms per
- * iteration and 1M pairs instead of 0.07 ms.  Single-GPU sessions only (a sharded sum has no
- * sequential order).  Environment PCGX_ICP_STRICT=1 turns it on for every new session
- * (pcgx_icp_fit / pcgx_icp_evaluate included). */
+ * strict on, the sums are the reference's: float32 additions in target order, every rounding
+ * included, so Evaluated and the resulting pose are bit-identical to the Go code's at any size.
+ * on = 1: evaluated by the whole GPU (csrc/strict_sum.h: the additions of a stretch act on the
+ *         state as a translation of its mantissa that is proven per rounding class, stretches are
+ *         composed, one wave applies them; exact by construction);
+ * on = 2: one wave adds the terms one after the other (~7 ms per 1M pairs; kept as a cross-check);
+ * on = 0: the float64 reduction.
+ * Single-GPU sessions only (a sharded sum has no sequential order).  Environment PCGX_ICP_STRICT=1
+ * (or 2) turns it on for every new session (pcgx_icp_fit / pcgx_icp_evaluate included). */
 PCGX_API pcgx_status pcgx_icp_session_set_strict(pcgx_icp_session *s, int32_t on);
 /* Synchronise and read back trans / stat / converged flag.  Returns
  * PCGX_E_NOT_ENOUGH_PAIRS if an iteration failed. */

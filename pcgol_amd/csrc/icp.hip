@@ -18,18 +18,6 @@
 
 namespace pcgx {
 
-// Loop state kept in device memory so that a whole Fit can be enqueued without
-// a host round trip per iteration (and captured in a hipGraph).
-struct IcpState {
-  float trans[16];        // accumulated transform (icp.go:47)
-  int32_t iter;           // gradientDescentUpdater.i (updater.go:41)
-  int32_t num_iteration;  // Stat.NumIteration (icp.go:50)
-  int32_t done;           // converged, or failed
-  int32_t status;         // PCGX_OK / PCGX_E_NOT_ENOUGH_PAIRS
-  Evaluated ev;           // Stat.Evaluated (icp.go:54)
-  float hessian[36];      // plane sessions: Evaluated.Hessian (evaluator.go:28), else unused
-};
-
 struct IcpKernelParams {
   float max_dist_sq;
   float min_dist_sq;
@@ -652,8 +640,9 @@ struct pcgx_icp_session {
   IcpState *d_state = nullptr;
   double *d_partials = nullptr;
   uint32_t *d_pos_of = nullptr;  // [nt] position of the caller's target i in the session's order
-  bool strict = false;           // sequential float32 sums (icp_strict_*_kernel)
-  float *d_terms = nullptr;      // strict: [9][nt_pad] float32 terms in the caller's target order
+  int strict = 0;                // sequential float32 sums: 1 = in parallel (strict.hip), 2 = one wave (icp_strict_sums_kernel)
+  pcgx::StrictBuffers *strict_buf = nullptr;  // strict 1
+  float *d_terms = nullptr;      // strict 2: [9][nt_pad] float32 terms in the caller's target order
   unsigned long long *d_valid = nullptr;  // strict: [nt_pad / 64] matched-target bits
   int64_t nt_pad = 0;
   float4 *d_match = nullptr;       // [nt] matched base point + DistSq per target
@@ -742,7 +731,8 @@ extern "C" pcgx_status pcgx_icp_session_set_strict(pcgx_icp_session *s, int32_t 
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_strict: NULL session");
   if (on && s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_strict: point-to-plane sessions have no reference sums to reproduce");
-  s->strict = on != 0;
+  if (on < 0 || on > 2) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_strict: mode must be 0, 1 or 2");
+  s->strict = on;
   return PCGX_OK;
 }
 
@@ -775,6 +765,7 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   dev_cache_free(s->d_pos_of);
   dev_cache_free(s->d_terms);
   dev_cache_free(s->d_valid);
+  strict_destroy(s->strict_buf);
   dev_cache_free(s->d_match);
   dev_cache_free(s->d_first_leaf);
   dev_cache_free(s->d_walk_list);
@@ -810,7 +801,7 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
   const_cast<pcgx_kdtree *>(base)->sessions.fetch_add(1);
   s->nt = nt;
   s->plane = normals != nullptr;
-  if (const char *e = getenv("PCGX_ICP_STRICT")) s->strict = !s->plane && e[0] == '1';
+  if (const char *e = getenv("PCGX_ICP_STRICT")) s->strict = s->plane ? 0 : (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0));
   s->kp = make_kernel_params(params);
   s->kp.gn.damping = damping;
   s->max_iteration = s->kp.upd.max_iteration;
@@ -984,6 +975,14 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
 
 template <bool kFuseUpdate>
 static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
+  if (s->strict == 1) {  // the whole GPU: strict.hip
+    if (!s->strict_buf) PCGX_TRY(strict_create(s->nt, &s->strict_buf, st));
+    PCGX_TRY(strict_enqueue(s->strict_buf, s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, (const float4 *)s->d_match,
+                            (const uint32_t *)s->d_pos_of, (const IcpState *)s->d_state, s->d_sums, st));
+    if (kFuseUpdate) hipLaunchKernelGGL(icp_update_kernel<false>, dim3(1), dim3(64), 0, st, s->d_state, s->d_sums, s->kp);
+    return PCGX_OK;
+  }
+  // strict 2: the plain dependent chain, one wave (kept as the on-device cross-check of strict 1)
   if (!s->d_terms) {  // first strict launch of the session
     s->nt_pad = (s->nt + 63) & ~(int64_t)63;
     const size_t np = (size_t)(s->nt_pad ? s->nt_pad : 64);
@@ -996,6 +995,18 @@ static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
                        (const uint32_t *)s->d_pos_of, (const IcpState *)s->d_state, s->d_terms, s->d_valid);
   hipLaunchKernelGGL(icp_strict_sums_kernel<kFuseUpdate>, dim3(1), dim3(64), 0, st, (const float *)s->d_terms,
                      (const unsigned long long *)s->d_valid, s->nt_pad, s->d_state, s->d_sums, s->kp);
+  return PCGX_OK;
+}
+
+// Measurement aid: counters of the strict chain since the last call (see include/pcgx.h).
+extern "C" pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *stream, int64_t out[16]) {
+  PCGX_API_LOCK();
+  if (!s || !out) return fail(PCGX_E_INVALID, "pcgx_debug_icp_strict_stats: NULL argument");
+  for (int k = 0; k < 16; k++) out[k] = 0;
+  if (!s->strict_buf) return PCGX_OK;
+  unsigned long long h[16];
+  PCGX_TRY(strict_read_debug(s->strict_buf, h, pick_stream(stream)));
+  for (int k = 0; k < 16; k++) out[k] = (int64_t)h[k];
   return PCGX_OK;
 }
 

@@ -226,6 +226,28 @@ pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t
 pcgx_status morton_order(const float *d_q, int64_t n, const float lo[3], const float hi[3], int32_t *d_perm,
                          hipStream_t st);
 
+
+// icp.hip / strict.hip
+// Loop state kept in device memory so that a whole Fit can be enqueued without
+// a host round trip per iteration (and captured in a hipGraph).
+struct IcpState {
+  float trans[16];        // accumulated transform (icp.go:47)
+  int32_t iter;           // gradientDescentUpdater.i (updater.go:41)
+  int32_t num_iteration;  // Stat.NumIteration (icp.go:50)
+  int32_t done;           // converged, or failed
+  int32_t status;         // PCGX_OK / PCGX_E_NOT_ENOUGH_PAIRS
+  Evaluated ev;           // Stat.Evaluated (icp.go:54)
+  float hessian[36];      // plane sessions: Evaluated.Hessian (evaluator.go:28), else unused
+};
+
+
+// strict.hip: the evaluator's sequential float32 sums (evaluator.go:122-145), bit for bit, in parallel
+struct StrictBuffers;
+pcgx_status strict_create(int64_t nt, StrictBuffers **out, hipStream_t st);
+void strict_destroy(StrictBuffers *b);
+pcgx_status strict_enqueue(StrictBuffers *b, const float *tx, const float *ty, const float *tz, const float4 *match,
+                           const uint32_t *pos_of, const IcpState *state, double *sums10, hipStream_t st);
+pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[16], hipStream_t st);
 }  // namespace pcgx
 
 struct pcgx_kdtree {

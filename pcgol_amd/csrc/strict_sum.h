@@ -1,0 +1,480 @@
+// strict_sum.h -- the reference's SEQUENTIAL float32 sums, evaluated exactly and in parallel.
+//
+// Reference: pc/registration/icp/evaluator.go:122-145 adds the evaluator's nine float32 terms of
+// one pair after the other, in target order, in a single goroutine:  s <- fl32(s + t_i).  Float
+// addition is not associative, so a tree reduction does not give those bits (at 1M pairs the
+// reference's own rounding noise is 1.6e-5 on the final pose).  This file holds the arithmetic that
+// lets thousands of waves reproduce that chain bit for bit; it is compiled for the device (the
+// strict_* kernels, strict.hip) and for the host (ss_host_model below: the same arithmetic in plain
+// loops, run by the CPU tests against a sequential float32 loop).
+//
+// Idea.  Inside one binade the float32 grid is uniform: for a state s = m * ulp and any term t,
+// fl32(s + t) = (m + RN(t / ulp)) * ulp with round-half-even on the integer m, whatever m is, as
+// long as the result stays in the binade.  So the effect of a whole run of additions on a state is
+// a TRANSLATION of its mantissa integer that depends only on the parity class of m (ties) -- and it
+// can be obtained by simply running the hardware's float adds from one representative state per
+// class.  Two adjacent binades ("window" e: exponent fields e-1 and e, states counted in units of
+// the lower binade's ulp, n in [2^23, 2^25), even above 2^24) work the same way with four classes
+// (n mod 4), provided a translated state lands on the same side of 2^24 as the representative does
+// at every step.  A Summary records, per class, the translation and the interval of inputs for
+// which that proviso holds; summaries compose associatively (compose()), so leaves (kLeaf terms per
+// lane) fold into tiles (one wave), tiles into runs, and a single wave applies the run summaries
+// one after the other to the exact state.  Where the interval check fails -- a state that lands
+// within a few ulps of a binade boundary differently from its representative -- the tile is
+// recomputed exactly from the known state (resolve: leaf by leaf, a leaf whose own summary does not
+// cover the state is simply added term by term).
+// Every accepted step is proven equal to the sequential result, so the sum is bit-identical by
+// construction; how often the slow path runs only affects speed.
+//
+// The representatives come from a GUESS of the state at every leaf: the float64 prefix sum of the
+// terms (strict_terms_kernel) plus the float64 prefix of the ROUNDING ERRORS the chain makes when
+// started from that first guess (strict_err_kernel: error of a leaf = (end - start) - sum of its
+// terms; translation invariance makes that error exact whenever the guess is in the right class
+// interval).  With both, a guess is typically within a few ulps of the true state.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#if defined(__HIPCC__)
+#define SS_HD __host__ __device__ __forceinline__
+#else
+#define SS_HD inline
+#endif
+
+namespace pcgx {
+namespace ss {
+
+constexpr int kLeaf = 32;              // terms per lane
+constexpr int kLanes = 64;             // leaves per tile (one wave)
+constexpr int kTile = kLeaf * kLanes;  // 2048 terms
+constexpr int kBinTiles = 64;          // tiles per level-1 bin of the prefix sums
+
+constexpr int32_t N23 = 1 << 23, N24 = 1 << 24, N25 = 1 << 25;
+constexpr int32_t kBig = 1 << 29;    // bound sentinels: lo = -kBig "any", lo = +kBig "none"
+constexpr int32_t kClamp = 1 << 28;  // translations are clamped here (far outside any window)
+
+SS_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+SS_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+SS_HD int32_t imin(int32_t a, int32_t b) { return a < b ? a : b; }
+SS_HD int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
+SS_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+SS_HD uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+SS_HD int32_t iclamp(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// For inputs n = r (mod 4) with lo[r] <= n <= hi[r]:  n_out = n + c[r].
+struct Summary {
+  int32_t c[4], lo[4], hi[4];
+};
+
+// key = (sign << 8) | e, e = exponent field of the window's UPPER binade (2..254); -1: no summary.
+// Point record: the guess chains of the tile joined up exactly (every leaf's guess equals the end of
+// the chain before it), so for the ONE input state `in` the result is `out` -- plain float adds, no
+// class argument needed.  It catches what the class intervals must exclude: sums whose every step
+// is exact (all-ones weights) land exactly on binade boundaries, and their guesses are exact.
+struct TileRec {
+  int32_t key;
+  uint32_t in, out;
+  int32_t cons;  // point record valid
+  Summary s;
+};
+static_assert(sizeof(TileRec) == 64, "one 64-byte record");
+
+SS_HD Summary summary_identity() {
+  Summary S;
+  for (int r = 0; r < 4; r++) {
+    S.c[r] = 0;
+    S.lo[r] = -kBig;
+    S.hi[r] = kBig;
+  }
+  return S;
+}
+
+// X first, then Y
+SS_HD Summary compose(const Summary &X, const Summary &Y) {
+  Summary Z;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int q = (r + X.c[r]) & 3;
+    const int32_t yc = q == 0 ? Y.c[0] : (q == 1 ? Y.c[1] : (q == 2 ? Y.c[2] : Y.c[3]));
+    const int32_t yl = q == 0 ? Y.lo[0] : (q == 1 ? Y.lo[1] : (q == 2 ? Y.lo[2] : Y.lo[3]));
+    const int32_t yh = q == 0 ? Y.hi[0] : (q == 1 ? Y.hi[1] : (q == 2 ? Y.hi[2] : Y.hi[3]));
+    Z.c[r] = iclamp(X.c[r] + yc, -kClamp, kClamp);
+    Z.lo[r] = imax(X.lo[r], iclamp(yl - X.c[r], -kBig, kBig));
+    Z.hi[r] = imin(X.hi[r], iclamp(yh - X.c[r], -kBig, kBig));
+  }
+  return Z;
+}
+
+// state (float bits) -> units of the lower binade's ulp inside window `key`; -1: not in the window
+SS_HD int32_t state_to_n(uint32_t bits, int32_t key) {
+  if (key < 0) return -1;
+  const int32_t sg = (int32_t)(bits >> 31), E = (int32_t)((bits >> 23) & 0xff), e = key & 0xff;
+  if (sg != (key >> 8)) return -1;
+  const int32_t mant = (int32_t)((bits & 0x7fffffu) | 0x800000u);
+  if (E == e - 1) return mant;
+  if (E == e) return mant << 1;
+  return -1;
+}
+
+SS_HD uint32_t n_to_state(int32_t n, int32_t key) {
+  const uint32_t sg = (uint32_t)(key >> 8) << 31;
+  const uint32_t e = (uint32_t)(key & 0xff);
+  if (n < N24) return sg | ((e - 1u) << 23) | ((uint32_t)n & 0x7fffffu);
+  return sg | (e << 23) | (((uint32_t)n >> 1) & 0x7fffffu);
+}
+
+// the exact effect of the summarised additions on `bits`, if the summary covers that state
+SS_HD bool apply(uint32_t &bits, int32_t key, const Summary &S) {
+  int32_t n = state_to_n(bits, key);
+  if (n < 0) return false;
+  const int r = n & 3;
+  const int32_t lo = r == 0 ? S.lo[0] : (r == 1 ? S.lo[1] : (r == 2 ? S.lo[2] : S.lo[3]));
+  const int32_t hi = r == 0 ? S.hi[0] : (r == 1 ? S.hi[1] : (r == 2 ? S.hi[2] : S.hi[3]));
+  const int32_t c = r == 0 ? S.c[0] : (r == 1 ? S.c[1] : (r == 2 ? S.c[2] : S.c[3]));
+  if (n < lo || n > hi) return false;
+  bits = n_to_state(n + c, key);
+  return true;
+}
+
+// ---- leaf: pass 1, the guess chain ------------------------------------------------------------
+struct ChainRange {
+  uint32_t mn, mx;  // smallest / largest magnitude bits over the kLeaf + 1 states
+  uint32_t sg_or, sg_and;
+  uint32_t end;
+};
+
+SS_HD ChainRange guess_chain(const float *t, uint32_t g0) {
+  ChainRange R;
+  R.mn = R.mx = g0 & 0x7fffffffu;
+  R.sg_or = R.sg_and = g0 >> 31;
+  float s = u2f(g0);
+#pragma unroll
+  for (int j = 0; j < kLeaf; j++) {
+    s = s + t[j];
+    const uint32_t b = f2u(s), m = b & 0x7fffffffu;
+    R.mn = umin(R.mn, m);
+    R.mx = umax(R.mx, m);
+    R.sg_or |= b >> 31;
+    R.sg_and &= b >> 31;
+  }
+  R.end = f2u(s);
+  return R;
+}
+
+// window of a range of magnitudes [mn, mx] with one sign: the two binades that hold it, the level
+// between them as near (in log) to `ref` as possible; -1 if no window holds the range
+SS_HD int32_t choose_window(uint32_t mn, uint32_t mx, uint32_t sign, uint32_t ref_mag) {
+  const int32_t Emin = (int32_t)(mn >> 23), Emax = (int32_t)(mx >> 23);
+  if (Emin < 1 || Emax > 254) return -1;  // zero / subnormal / inf / nan
+  int32_t e;
+  if (Emax - Emin >= 2) return -1;
+  if (Emax == Emin + 1) {
+    e = Emax;
+  } else {
+    e = (ref_mag & 0x7fffffu) >= 0x3504F3u ? Emin + 1 : Emin;  // mantissa >= sqrt(2): level above
+    if (e < 2) e = Emin + 1;
+    if (e > 254) e = Emin;
+  }
+  if (e < 2 || e > 254) return -1;
+  return (int32_t)(sign << 8) | e;
+}
+
+// ---- leaf: pass 2, the class summaries ---------------------------------------------------------
+// General form: up to four class representatives next to the guess, each run through the leaf with
+// real float adds; per class the translation and the interval of inputs that land on the same side
+// of the level 2^24 (and inside the window) as the representative at every step.
+SS_HD void class_chain(const float *t, uint32_t rep, int32_t key, int32_t &c, int32_t &lo, int32_t &hi) {
+  const uint32_t sign = (uint32_t)(key >> 8), e = (uint32_t)(key & 0xff);
+  const uint32_t Lbits = e << 23, firstLow = (e - 1u) << 23, lastUp = Lbits | 0x7fffffu;
+  float s = u2f(rep);
+  uint32_t maxB = 0u, minA = 0xffffffffu, mnAll = 0xffffffffu, mxAll = 0u, sg_bad = 0u;
+#pragma unroll
+  for (int j = 0; j < kLeaf; j++) {
+    s = s + t[j];
+    const uint32_t b = f2u(s), m = b & 0x7fffffffu;
+    sg_bad |= (b >> 31) ^ sign;
+    const bool above = m >= Lbits;
+    maxB = above ? maxB : umax(maxB, m);
+    minA = above ? umin(minA, m) : minA;
+    mnAll = umin(mnAll, m);
+    mxAll = umax(mxAll, m);
+  }
+  const uint32_t r0 = rep & 0x7fffffffu;
+  auto to_n = [&](uint32_t m) -> int32_t {
+    const int32_t mant = (int32_t)((m & 0x7fffffu) | 0x800000u);
+    return m >= Lbits ? mant << 1 : mant;
+  };
+  // the representative's own landings must respect their sides (then each of its steps rounds on
+  // the grid of the side it lands on, and so does every translated copy within [lo, hi])
+  const bool ok = !sg_bad && mnAll >= firstLow + 1u && mxAll <= lastUp && (minA == 0xffffffffu || minA >= Lbits + 1u);
+  if (!ok || r0 < firstLow || r0 > lastUp || ((rep >> 31) != sign)) {
+    c = 0;
+    lo = kBig;
+    hi = -kBig;
+    return;
+  }
+  const int32_t n0 = to_n(r0);
+  int32_t dlo = (N23 + 1) - to_n(mnAll), dhi = (N25 - 2) - to_n(mxAll);
+  if (maxB != 0u) dhi = imin(dhi, (N24 - 1) - to_n(maxB));
+  if (minA != 0xffffffffu) dlo = imax(dlo, (N24 + 2) - to_n(minA));
+  // (the input state itself is an exact float of the window: where it lies does not matter, the
+  // grid a step rounds on depends on where the step LANDS)
+  c = to_n(f2u(s) & 0x7fffffffu) - n0;
+  lo = n0 + dlo;
+  hi = n0 + dhi;
+}
+
+SS_HD Summary leaf_summary_general(const float *t, uint32_t guess, int32_t key) {
+  Summary S;
+  const uint32_t e = (uint32_t)(key & 0xff);
+  const uint32_t E = (guess >> 23) & 0xffu;
+  if (E == e - 1u) {  // lower binade: n = mantissa, classes by its two low bits
+#pragma unroll
+    for (int r = 0; r < 4; r++) class_chain(t, (guess & ~3u) | (uint32_t)r, key, S.c[r], S.lo[r], S.hi[r]);
+  } else {  // upper binade (or outside: class_chain rejects): n = 2 * mantissa, classes 0 and 2
+    class_chain(t, guess & ~1u, key, S.c[0], S.lo[0], S.hi[0]);
+    class_chain(t, guess | 1u, key, S.c[2], S.lo[2], S.hi[2]);
+    S.c[1] = S.c[3] = 0;
+    S.lo[1] = S.lo[3] = kBig;
+    S.hi[1] = S.hi[3] = -kBig;
+  }
+  return S;
+}
+
+// Fast form for a leaf whose guess chain stays in ONE binade E of the window: two representatives
+// (mantissa even / odd), tracked in bit space (inside a binade the bit pattern IS the mantissa
+// integer and its order).
+SS_HD void binade_chain(const float *t, uint32_t rep, uint32_t &end, uint32_t &mn, uint32_t &mx, uint32_t &sg_bad) {
+  float s = u2f(rep);
+  mn = 0xffffffffu;
+  mx = 0u;
+  sg_bad = 0u;
+  const uint32_t sign = rep >> 31;
+#pragma unroll
+  for (int j = 0; j < kLeaf; j++) {
+    s = s + t[j];
+    const uint32_t b = f2u(s), m = b & 0x7fffffffu;
+    sg_bad |= (b >> 31) ^ sign;
+    mn = umin(mn, m);
+    mx = umax(mx, m);
+  }
+  end = f2u(s) & 0x7fffffffu;
+}
+
+SS_HD Summary leaf_summary_binade(const float *t, uint32_t guess, int32_t key) {
+  Summary S;
+  const uint32_t e = (uint32_t)(key & 0xff), sign = (uint32_t)(key >> 8);
+  const uint32_t E = (guess >> 23) & 0xffu;
+  const bool upper = E == e;
+  const uint32_t first = E << 23, last = first | 0x7fffffu;
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const uint32_t rep = p ? (guess | 1u) : (guess & ~1u);
+    uint32_t end, mn, mx, bad;
+    binade_chain(t, rep, end, mn, mx, bad);
+    const uint32_t r0 = rep & 0x7fffffffu;
+    int32_t c, lo, hi;
+    if (bad || (rep >> 31) != sign || (E != e && E != e - 1u) || mn < first + 1u || mx > last) {
+      c = 0;
+      lo = kBig;
+      hi = -kBig;
+    } else {
+      const int32_t f = upper ? 2 : 1;
+      const int32_t mant0 = (int32_t)((r0 & 0x7fffffu) | 0x800000u);
+      const int32_t n0 = mant0 * f;
+      const int32_t dlo = (int32_t)(first + 1u) - (int32_t)mn;
+      const int32_t dhi = (int32_t)last - (int32_t)mx;
+      c = ((int32_t)end - (int32_t)r0) * f;
+      lo = n0 + dlo * f;
+      hi = n0 + dhi * f;
+    }
+    if (upper) {  // n = 2 * mantissa: mantissa parity p <-> n = 2p (mod 4)
+      S.c[2 * p] = c;
+      S.lo[2 * p] = lo;
+      S.hi[2 * p] = hi;
+      S.c[2 * p + 1] = 0;
+      S.lo[2 * p + 1] = kBig;
+      S.hi[2 * p + 1] = -kBig;
+    } else {  // n = mantissa: parity p <-> classes p and p + 2
+      S.c[p] = S.c[p + 2] = c;
+      S.lo[p] = S.lo[p + 2] = lo;
+      S.hi[p] = S.hi[p + 2] = hi;
+    }
+  }
+  return S;
+}
+
+// ---- host model ---------------------------------------------------------------------------------
+// The whole pipeline in plain loops (what the strict_* kernels do wave-parallel), for the CPU
+// tests.  terms[n] -> the sequential float32 sum of 0.0f + t0 + t1 + ... ; stats: [0] tiles,
+// [1] tiles without a record, [2] runs applied, [3] runs that failed, [4] tiles resolved exactly,
+// [5] leaves added serially, [6] leaves in the general (crossing) form, [7] tile records that failed.
+// mode bit 0: never use the in-binade fast form; bit 1: no error-prefix refinement of the guesses.
+inline float ss_host_model(const float *terms_in, int64_t n, int64_t stats[8], int mode) {
+  for (int k = 0; k < 8; k++) stats[k] = 0;
+  const int64_t ntiles = n > 0 ? (n + kTile - 1) / kTile : 1;
+  const int64_t npad = ntiles * kTile;
+  float *terms = new float[(size_t)npad];
+  for (int64_t i = 0; i < npad; i++) terms[i] = i < n ? terms_in[i] : -0.0f;
+  double *tile_sum = new double[(size_t)ntiles], *tile_err = new double[(size_t)ntiles];
+  TileRec *recs = new TileRec[(size_t)ntiles];
+  stats[0] = ntiles;
+  // strict_terms_kernel: float64 sums per tile
+  for (int64_t k = 0; k < ntiles; k++) {
+    double v = 0.0;
+    for (int i = 0; i < kTile; i++) v += (double)terms[k * kTile + i];
+    tile_sum[k] = v;
+  }
+  // strict_err_kernel: rounding error of every tile's chains when started from the float64 prefix
+  {
+    double P0 = 0.0;
+    for (int64_t k = 0; k < ntiles; k++) {
+      double pre = 0.0, err = 0.0;
+      for (int l = 0; l < kLanes; l++) {
+        const float *t = terms + k * kTile + l * kLeaf;
+        double lsum = 0.0;
+        for (int j = 0; j < kLeaf; j++) lsum += (double)t[j];
+        const float g = (float)(P0 + pre);
+        float s = g;
+        for (int j = 0; j < kLeaf; j++) s = s + t[j];
+        err += ((double)s - (double)g) - lsum;
+        pre += lsum;
+      }
+      tile_err[k] = (mode & 2) ? 0.0 : err;
+      P0 += tile_sum[k];
+    }
+  }
+  // strict_sum_kernel: one record per tile
+  {
+    double P0 = 0.0, E0 = 0.0;
+    for (int64_t k = 0; k < ntiles; k++) {
+      uint32_t guess[kLanes];
+      ChainRange cr[kLanes];
+      double pre = 0.0;
+      uint32_t mn = 0xffffffffu, mx = 0u, sg_or = 0u, sg_and = 1u;
+      for (int l = 0; l < kLanes; l++) {
+        const float *t = terms + k * kTile + l * kLeaf;
+        guess[l] = f2u((float)(P0 + E0 + pre));
+        cr[l] = guess_chain(t, guess[l]);
+        mn = umin(mn, cr[l].mn);
+        mx = umax(mx, cr[l].mx);
+        sg_or |= cr[l].sg_or;
+        sg_and &= cr[l].sg_and;
+        for (int j = 0; j < kLeaf; j++) pre += (double)t[j];
+      }
+      TileRec T;
+      memset(&T, 0, sizeof T);
+      T.key = sg_or == sg_and ? choose_window(mn, mx, sg_or, guess[0] & 0x7fffffffu) : -1;
+      T.in = guess[0];
+      T.out = cr[kLanes - 1].end;
+      T.cons = 1;
+      for (int l = 0; l + 1 < kLanes; l++) T.cons &= guess[l + 1] == cr[l].end;
+      if (T.key >= 0) {
+        Summary acc = summary_identity();
+        for (int l = 0; l < kLanes; l++) {
+          const float *t = terms + k * kTile + l * kLeaf;
+          const bool one_binade = (cr[l].mn >> 23) == (cr[l].mx >> 23);
+          Summary S;
+          if (one_binade && !(mode & 1)) {
+            S = leaf_summary_binade(t, guess[l], T.key);
+          } else {
+            S = leaf_summary_general(t, guess[l], T.key);
+            stats[6]++;
+          }
+          acc = compose(acc, S);
+        }
+        T.s = acc;
+      } else {
+        stats[1]++;
+      }
+      recs[k] = T;
+      P0 += tile_sum[k];
+      E0 += tile_err[k];
+    }
+  }
+  // strict_chain_kernel: runs of equal windows, applied in order; exact recomputation on failure
+  uint32_t s = f2u(0.0f);
+  auto resolve_tile = [&](int64_t k) {  // = resolve_generic of strict.hip
+    const float *tt = terms + k * kTile;
+    double lsum[kLanes], pre[kLanes], err[kLanes];
+    uint32_t g[kLanes];
+    {
+      double p = 0.0;
+      for (int l = 0; l < kLanes; l++) {
+        double v = 0.0;
+        for (int j = 0; j < kLeaf; j++) v += (double)tt[l * kLeaf + j];
+        lsum[l] = v;
+        pre[l] = p;
+        p += v;
+      }
+    }
+    const double s0 = (double)u2f(s);
+    for (int l = 0; l < kLanes; l++) {  // first guesses, and the rounding error each leaf makes from there
+      g[l] = l == 0 ? s : f2u((float)(s0 + pre[l]));
+      const ChainRange c = guess_chain(tt + l * kLeaf, g[l]);
+      err[l] = ((double)u2f(c.end) - (double)u2f(g[l])) - lsum[l];
+    }
+    {
+      double e = 0.0;
+      for (int l = 0; l < kLanes; l++) {
+        if (l > 0) g[l] = f2u((float)(s0 + pre[l] + e));
+        e += err[l];
+      }
+    }
+    for (int l = 0; l < kLanes; l++) {  // every leaf: a summary in a window of its own, else the adds themselves
+      const float *t = tt + l * kLeaf;
+      const ChainRange c = guess_chain(t, g[l]);
+      const int32_t key = c.sg_or == c.sg_and ? choose_window(c.mn, c.mx, c.sg_or, g[l] & 0x7fffffffu) : -1;
+      bool done = false;
+      if (key >= 0) {
+        const Summary S = (c.mn >> 23) == (c.mx >> 23) && !(mode & 1) ? leaf_summary_binade(t, g[l], key)
+                                                                     : leaf_summary_general(t, g[l], key);
+        done = apply(s, key, S);
+      }
+      if (!done) {
+        float x = u2f(s);
+        for (int j = 0; j < kLeaf; j++) x = x + t[j];
+        s = f2u(x);
+        stats[5]++;
+      }
+    }
+    stats[4]++;
+  };
+  int64_t k = 0;
+  while (k < ntiles) {
+    int64_t k1 = k + 1;
+    TileRec R = recs[k];
+    while (R.key >= 0 && k1 < ntiles && recs[k1].key == R.key && (k1 % 64) != 0) {  // runs end at wave boundaries
+      R.s = compose(R.s, recs[k1].s);
+      R.cons = R.cons && recs[k1].cons && R.out == recs[k1].in;
+      R.out = recs[k1].out;
+      k1++;
+    }
+    if ((R.key >= 0 && apply(s, R.key, R.s))) {
+      stats[2]++;
+    } else if (R.cons && R.in == s) {
+      s = R.out;
+      stats[2]++;
+    } else {
+      if (R.key >= 0) stats[3]++;
+      for (int64_t q = k; q < k1; q++) {
+        if (recs[q].key >= 0 && apply(s, recs[q].key, recs[q].s)) continue;
+        if (recs[q].cons && recs[q].in == s) {
+          s = recs[q].out;
+          continue;
+        }
+        if (recs[q].key >= 0) stats[7]++;
+        resolve_tile(q);
+      }
+    }
+    k = k1;
+  }
+  delete[] terms;
+  delete[] tile_sum;
+  delete[] tile_err;
+  delete[] recs;
+  return u2f(s);
+}
+
+}  // namespace ss
+}  // namespace pcgx

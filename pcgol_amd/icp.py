@@ -212,8 +212,16 @@ class IcpSession:
 
     def set_strict(self, on=True):
         """Sequential float32 sums in target order, as the Go code adds them: bit-identical
-        Evaluated / pose at any size (slow: one wave).  See include/pcgx.h."""
-        L.check(L.lib().pcgx_icp_session_set_strict(self._h, 1 if on else 0))
+        Evaluated / pose at any size.  True / 1: evaluated in parallel by the whole GPU
+        (csrc/strict_sum.h); 2: one wave adding term after term (cross-check).  See include/pcgx.h."""
+        L.check(L.lib().pcgx_icp_session_set_strict(self._h, int(on)))
+
+    def strict_stats(self, stream=0):
+        """Measurement aid: counters of the parallel strict sums since the last call
+        (runs applied, runs failed, tiles recomputed, leaves added serially, tile records failed)."""
+        out = np.zeros(16, np.int64)
+        L.check(L.lib().pcgx_debug_icp_strict_stats(self._h, L.ptr(stream) if stream else None, L.ptr(out)))
+        return out
 
     def read_sums(self, stream=0):
         out = np.empty(self.n_sums, np.float64)

@@ -1,0 +1,47 @@
+"""GPU probe: parallel strict sums (set_strict 1) against the one-wave chain (set_strict 2) on C4,
+iteration by iteration, then timings.  Usage: python tools/strict_probe.py [n]"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from pcgol_amd import _lib as L, icp, kdtree, synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
+t = kdtree.New(c["base"])
+
+
+def session(mode):
+    s = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+    s.set_strict(mode)
+    return s
+
+
+a, b = session(1), session(2)
+bad = 0
+for k in range(c["max_iteration"]):
+    a.step()
+    b.step()
+    sa, sb = a.read_sums(), b.read_sums()
+    st = a.strict_stats()
+    ok = np.array_equal(sa.view(np.uint64), sb.view(np.uint64))
+    bad += not ok
+    print("iter %2d %s runs %d runfail %d resolved %d serial leaves %d recfail %d" % (k, "OK " if ok else "MISMATCH", st[0], st[1], st[2], st[3], st[4]))
+    if not ok:
+        print("   parallel", sa)
+        print("   serial  ", sb)
+ta, _, _ = a.result()
+tb, _, _ = b.result()
+print("final pose equal:", np.array_equal(ta, tb), "mismatching iterations:", bad)
+for mode, s in ((1, a), (2, b), (0, session(0))):
+    for rep in range(2):
+        L.check(L.lib().pcgx_icp_session_reset(s._h, None))
+        L.check(L.lib().pcgx_sync(None))
+        t0 = time.perf_counter()
+        for k in range(c["max_iteration"]):
+            s.step()
+        L.check(L.lib().pcgx_sync(None))
+        dt = (time.perf_counter() - t0) / c["max_iteration"]
+    print("strict %d: %.1f us per iteration, %.2f Gpoints/s" % (mode, dt * 1e6, n / dt / 1e9))
