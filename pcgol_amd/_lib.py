@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "libpcgx.so")
+SO = os.environ.get("PCGX_LIB") or os.path.join(HERE, "libpcgx.so")  # PCGX_LIB: experiments with another build
 
 PCGX_OK = 0
 PCGX_E_NO_POINT = 1

@@ -976,9 +976,11 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
 template <bool kFuseUpdate>
 static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
   if (s->strict == 1) {  // the whole GPU: strict.hip
-    if (!s->strict_buf) PCGX_TRY(strict_create(s->nt, &s->strict_buf, st));
-    PCGX_TRY(strict_enqueue(s->strict_buf, s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, (const float4 *)s->d_match,
-                            (const uint32_t *)s->d_pos_of, (const IcpState *)s->d_state, s->d_sums, st));
+    if (!s->strict_buf)
+      PCGX_TRY(strict_create(s->nt, s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, (const uint32_t *)s->d_pos_of,
+                             &s->strict_buf, st));
+    PCGX_TRY(strict_enqueue(s->strict_buf, (const float4 *)s->d_match, (const uint32_t *)s->d_pos_of,
+                            (const IcpState *)s->d_state, s->d_sums, st));
     if (kFuseUpdate) hipLaunchKernelGGL(icp_update_kernel<false>, dim3(1), dim3(64), 0, st, s->d_state, s->d_sums, s->kp);
     return PCGX_OK;
   }
@@ -999,14 +1001,14 @@ static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
 }
 
 // Measurement aid: counters of the strict chain since the last call (see include/pcgx.h).
-extern "C" pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *stream, int64_t out[16]) {
+extern "C" pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *stream, int64_t out[48]) {
   PCGX_API_LOCK();
   if (!s || !out) return fail(PCGX_E_INVALID, "pcgx_debug_icp_strict_stats: NULL argument");
-  for (int k = 0; k < 16; k++) out[k] = 0;
+  for (int k = 0; k < 48; k++) out[k] = 0;
   if (!s->strict_buf) return PCGX_OK;
-  unsigned long long h[16];
+  unsigned long long h[48];
   PCGX_TRY(strict_read_debug(s->strict_buf, h, pick_stream(stream)));
-  for (int k = 0; k < 16; k++) out[k] = (int64_t)h[k];
+  for (int k = 0; k < 48; k++) out[k] = (int64_t)h[k];
   return PCGX_OK;
 }
 

@@ -243,11 +243,12 @@ struct IcpState {
 
 // strict.hip: the evaluator's sequential float32 sums (evaluator.go:122-145), bit for bit, in parallel
 struct StrictBuffers;
-pcgx_status strict_create(int64_t nt, StrictBuffers **out, hipStream_t st);
+pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const float *tz, const uint32_t *pos_of,
+                          StrictBuffers **out, hipStream_t st);
 void strict_destroy(StrictBuffers *b);
-pcgx_status strict_enqueue(StrictBuffers *b, const float *tx, const float *ty, const float *tz, const float4 *match,
-                           const uint32_t *pos_of, const IcpState *state, double *sums10, hipStream_t st);
-pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[16], hipStream_t st);
+pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, const IcpState *state,
+                           double *sums10, hipStream_t st);
+pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[48], hipStream_t st);
 }  // namespace pcgx
 
 struct pcgx_kdtree {

@@ -59,15 +59,46 @@ __device__ __forceinline__ Summary shfl_summary(const Summary &S, int src) {
 }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+struct LeafAux {  // per leaf of a tile with a level crossing: compositions of leaves 0..l and l..63
+  Summary pre, suf;
+};
+
 struct StrictWork {
-  float *terms;                 // [9][nt_pad]
+  float *terms;                 // [9][ntiles][kLeaf / 4][64 lanes][4]: lane l of a tile holds its leaf's terms 4 by 4
+  const float *xyz_caller;      // [nt][3] the targets in the caller's order
   double *tile_sum, *tile_err;  // [9][ntiles]
   double *bin_sum, *bin_err;    // [9][nbins] level-1 sums of kBinTiles tiles (atomics; zeroed by the chain kernel)
   TileRec *recs;                // [9][ntiles]
+  LeafAux *aux;                 // [naux][64]
+  unsigned int *aux_count;      // slots handed out this iteration (zeroed by the chain kernel)
   unsigned long long *pairs;    // matched targets of this iteration (atomic; zeroed by the chain kernel)
-  unsigned long long *dbg;      // [16] counters (measurement aid), may be null
+  unsigned long long *dbg;      // [16] counters (measurement aid)
   int64_t nt, nt_pad, ntiles, nbins;
+  int32_t naux;
+  int32_t selfcheck;  // debugging: every step of the chain walk is re-derived term by term and compared (dbg[12..15])
 };
+
+// where term i (caller's order) of a row lives: leaves are interleaved 4 floats at a time so that the
+// 64 lanes of a wave read their leaves with fully coalesced 16-byte loads
+__device__ __forceinline__ int64_t term_index(int64_t i) {
+  const int64_t tile = i / kTile;
+  const int w = (int)(i % kTile), l = w / kLeaf, j = w % kLeaf;
+  return ((tile * (kLeaf / 4) + j / 4) * kLanes + l) * 4 + (j & 3);
+}
+__device__ __forceinline__ void load_leaf(const float *__restrict__ row, int64_t tile, int lane, float *t) {
+  const float4 *q = reinterpret_cast<const float4 *>(row) + tile * (kLeaf / 4) * kLanes + lane;
+#pragma unroll
+  for (int v = 0; v < kLeaf / 4; v++) {
+    const float4 a = q[v * kLanes];
+    t[4 * v] = a.x; t[4 * v + 1] = a.y; t[4 * v + 2] = a.z; t[4 * v + 3] = a.w;
+  }
+}
+__device__ __forceinline__ double leaf_sum_f64(const float *t) {
+  double v = 0.0;
+#pragma unroll
+  for (int j = 0; j < kLeaf; j++) v += (double)t[j];
+  return v;
+}
 
 // float64 prefix of `tile` from the level-1 bins and the tile sums inside its bin; every lane gets it
 __device__ __forceinline__ double tile_prefix(const double *__restrict__ tile_v, const double *__restrict__ bin_v,
@@ -81,15 +112,16 @@ __device__ __forceinline__ double tile_prefix(const double *__restrict__ tile_v,
 }
 
 // ---- terms ---------------------------------------------------------------------------------------
-// One workgroup per tile of 2048 targets in the caller's order (pos_of: where the session keeps
-// target i).  Unmatched targets and the padding behind nt carry -0.0f: x + (-0.0f) == x for every x.
-__global__ __launch_bounds__(1024) void strict_terms_kernel(const float *__restrict__ tx, const float *__restrict__ ty,
-                                                            const float *__restrict__ tz,
-                                                            const float4 *__restrict__ match,
-                                                            const uint32_t *__restrict__ pos_of,
-                                                            const IcpState *__restrict__ state, StrictWork W) {
-  __shared__ double s_part[16][kStrictRows];
-  __shared__ int s_pairs[16];
+// One workgroup per tile of 2048 targets in the caller's order: the target itself is read in that
+// order (xyz_caller) and re-projected here exactly as the correspondence kernels do, only its pair
+// is a gather (pos_of: where the session keeps target i).  Unmatched targets and the padding behind
+// nt carry -0.0f: x + (-0.0f) == x for every x.
+constexpr int kTermsBlock = 256, kTermsPer = kTile / kTermsBlock;
+__global__ __launch_bounds__(kTermsBlock) void strict_terms_kernel(const float4 *__restrict__ match,
+                                                                   const uint32_t *__restrict__ pos_of,
+                                                                   const IcpState *__restrict__ state, StrictWork W) {
+  __shared__ double s_part[kTermsBlock / 64][kStrictRows];
+  __shared__ int s_pairs[kTermsBlock / 64];
   if (state->done) return;
   float m[16];
 #pragma unroll
@@ -100,38 +132,50 @@ __global__ __launch_bounds__(1024) void strict_terms_kernel(const float *__restr
 #pragma unroll
   for (int k = 0; k < kStrictRows; k++) acc[k] = 0.0;
   int npairs = 0;
+  // the eight gathers of a thread are issued together
+  float4 bp[kTermsPer];
+  float tx[kTermsPer], ty[kTermsPer], tz[kTermsPer];
 #pragma unroll
-  for (int h = 0; h < kTile / 1024; h++) {
-    const int64_t i = tile * kTile + h * 1024 + threadIdx.x;
+  for (int h = 0; h < kTermsPer; h++) {
+    const int64_t i = tile * kTile + h * kTermsBlock + threadIdx.x;
+    bp[h] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    tx[h] = ty[h] = tz[h] = 0.0f;
+    if (i < W.nt) {
+      bp[h] = match[pos_of[i]];
+      tx[h] = W.xyz_caller[3 * i];
+      ty[h] = W.xyz_caller[3 * i + 1];
+      tz[h] = W.xyz_caller[3 * i + 2];
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < kTermsPer; h++) {
+    const int64_t i = tile * kTile + h * kTermsBlock + threadIdx.x;
     float t[kStrictRows];
 #pragma unroll
     for (int k = 0; k < kStrictRows; k++) t[k] = -0.0f;
-    if (i < W.nt) {
-      const uint32_t pos = pos_of[i];
-      const float4 bp = match[pos];
-      if (bp.w >= 0.0f) {  // correspondence.go:27-29
-        npairs++;
-        float x0 = tx[pos], y0 = ty[pos], z0 = tz[pos];
-        if (project) {
-          float px, py, pz;
-          mat4_transform(m, x0, y0, z0, px, py, pz);
-          x0 = px; y0 = py; z0 = pz;
-        }
-        const float x1 = bp.x, y1 = bp.y, z1 = bp.z, w = 1.0f;  // evaluator.go:21-23,130
-        t[0] = w * bp.w;
-        t[1] = w * (x0 - x1);
-        t[2] = w * (y0 - y1);
-        t[3] = w * (z0 - z1);
-        t[4] = w * (z0 * y1 - y0 * z1);
-        t[5] = w * (x0 * z1 - z0 * x1);
-        t[6] = w * (y0 * x1 - x0 * y1);
-        t[7] = w * norm_sq3(x0, y0, z0);
-        t[8] = w;
+    if (bp[h].w >= 0.0f) {  // correspondence.go:27-29
+      npairs++;
+      float x0 = tx[h], y0 = ty[h], z0 = tz[h];
+      if (project) {
+        float px, py, pz;
+        mat4_transform(m, x0, y0, z0, px, py, pz);
+        x0 = px; y0 = py; z0 = pz;
       }
+      const float x1 = bp[h].x, y1 = bp[h].y, z1 = bp[h].z, w = 1.0f;  // evaluator.go:21-23,130
+      t[0] = w * bp[h].w;
+      t[1] = w * (x0 - x1);
+      t[2] = w * (y0 - y1);
+      t[3] = w * (z0 - z1);
+      t[4] = w * (z0 * y1 - y0 * z1);
+      t[5] = w * (x0 * z1 - z0 * x1);
+      t[6] = w * (y0 * x1 - x0 * y1);
+      t[7] = w * norm_sq3(x0, y0, z0);
+      t[8] = w;
     }
+    const int64_t at = term_index(i);
 #pragma unroll
     for (int k = 0; k < kStrictRows; k++) {
-      W.terms[(int64_t)k * W.nt_pad + i] = t[k];
+      W.terms[(int64_t)k * W.nt_pad + at] = t[k];
       acc[k] += (double)t[k];
     }
   }
@@ -150,32 +194,30 @@ __global__ __launch_bounds__(1024) void strict_terms_kernel(const float *__restr
   __syncthreads();
   if (threadIdx.x < kStrictRows) {
     double v = 0.0;
-    for (int w = 0; w < 16; w++) v += s_part[w][threadIdx.x];
+    for (int w = 0; w < kTermsBlock / 64; w++) v += s_part[w][threadIdx.x];
     W.tile_sum[threadIdx.x * W.ntiles + tile] = v;
-    atomicAdd(&W.bin_sum[threadIdx.x * W.nbins + tile / kBinTiles], v);
+    unsafeAtomicAdd(&W.bin_sum[threadIdx.x * W.nbins + tile / kBinTiles], v);  // global_atomic_add_f64, no CAS loop
   } else if (threadIdx.x == 64) {
     int p = 0;
-    for (int w = 0; w < 16; w++) p += s_pairs[w];
+    for (int w = 0; w < kTermsBlock / 64; w++) p += s_pairs[w];
     if (p) atomicAdd(W.pairs, (unsigned long long)p);
   }
 }
 
-// ---- error pass ------------------------------------------------------------------------------------
-__device__ __forceinline__ void load_leaf(const float *__restrict__ p, float *t) {
-  const float4 *q = reinterpret_cast<const float4 *>(p);
-#pragma unroll
-  for (int v = 0; v < kLeaf / 4; v++) {
-    const float4 a = q[v];
-    t[4 * v] = a.x; t[4 * v + 1] = a.y; t[4 * v + 2] = a.z; t[4 * v + 3] = a.w;
-  }
-}
-__device__ __forceinline__ double leaf_sum_f64(const float *t) {
-  double v = 0.0;
-#pragma unroll
-  for (int j = 0; j < kLeaf; j++) v += (double)t[j];
-  return v;
+// the targets in the caller's order, from the session's Morton-ordered SoA copy (once per session)
+__global__ __launch_bounds__(256) void strict_xyz_caller_kernel(const float *__restrict__ tx, const float *__restrict__ ty,
+                                                                const float *__restrict__ tz,
+                                                                const uint32_t *__restrict__ pos_of, int64_t nt,
+                                                                float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nt) return;
+  const uint32_t pos = pos_of[i];
+  out[3 * i] = tx[pos];
+  out[3 * i + 1] = ty[pos];
+  out[3 * i + 2] = tz[pos];
 }
 
+// ---- error pass ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void strict_err_kernel(const IcpState *__restrict__ state, StrictWork W) {
   if (state->done) return;
   const int lane = threadIdx.x & 63;
@@ -184,7 +226,7 @@ __global__ __launch_bounds__(256) void strict_err_kernel(const IcpState *__restr
   const int row = (int)(w / W.ntiles);
   const int64_t tile = w % W.ntiles;
   float t[kLeaf];
-  load_leaf(W.terms + (int64_t)row * W.nt_pad + tile * kTile + lane * kLeaf, t);
+  load_leaf(W.terms + (int64_t)row * W.nt_pad, tile, lane, t);
   const double P0 = tile_prefix(W.tile_sum, W.bin_sum, W.ntiles, W.nbins, row, tile, lane);
   const double lsum = leaf_sum_f64(t);
   const double pre = wave_excl_scan_f64(lsum, lane);
@@ -196,26 +238,53 @@ __global__ __launch_bounds__(256) void strict_err_kernel(const IcpState *__restr
   const double err = wave_allsum_f64(((double)s - (double)g) - lsum);
   if (lane == 0) {
     W.tile_err[row * W.ntiles + tile] = err;
-    atomicAdd(&W.bin_err[row * W.nbins + tile / kBinTiles], err);
+    unsafeAtomicAdd(&W.bin_err[row * W.nbins + tile / kBinTiles], err);
   }
 }
 
 // ---- summaries ---------------------------------------------------------------------------------------
 // leaf guesses of a tile whose first state is (about) base: float64 prefix of the leaf sums, then one
 // refinement with the prefix of the rounding errors the chains make from those guesses
-__device__ __forceinline__ void tile_guesses(const float *t, double base, bool exact_first, uint32_t first, int lane,
-                                             uint32_t &g, ChainRange &cr) {
+__device__ __forceinline__ void tile_guesses(const float *t, double base, int lane, uint32_t &g, ChainRange &cr) {
   const double lsum = leaf_sum_f64(t);
   const double pre = wave_excl_scan_f64(lsum, lane);
-  g = (exact_first && lane == 0) ? first : f2u((float)(base + pre));
+  g = f2u((float)(base + pre));
   cr = guess_chain(t, g);
   const double err = ((double)u2f(cr.end) - (double)u2f(g)) - lsum;
   const double epre = wave_excl_scan_f64(err, lane);
-  const uint32_t g2 = (exact_first && lane == 0) ? first : f2u((float)(base + pre + epre));
+  const uint32_t g2 = f2u((float)(base + pre + epre));
   if (__ballot(g2 != g) != 0ull) {  // uniform
     g = g2;
     cr = guess_chain(t, g);
   }
+}
+
+// the 32 additions of leaf l, one after the other, on the state every lane holds
+__device__ __forceinline__ uint32_t serial_leaf(uint32_t s, const float *t, int l) {
+  float x = u2f(s);
+#pragma unroll
+  for (int j = 0; j < kLeaf; j++) x = x + u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(t[j]), l));
+  return f2u(x);
+}
+
+// all 2048 additions of a tile, one after the other: the terms go to LDS in their order and every
+// lane runs the same chain over them (broadcast reads; the loads run ahead of the dependent adds)
+__device__ __forceinline__ uint32_t serial_tile(uint32_t s, const float *t, int lane, float *lds /* [kTile] of this wave */) {
+  float4 *w4 = reinterpret_cast<float4 *>(lds) + lane * (kLeaf / 4);
+#pragma unroll
+  for (int v = 0; v < kLeaf / 4; v++) w4[v] = make_float4(t[4 * v], t[4 * v + 1], t[4 * v + 2], t[4 * v + 3]);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
+  const float4 *r4 = reinterpret_cast<const float4 *>(lds);
+  float x = u2f(s);
+  for (int k = 0; k < kTile / 4; k += 8) {
+    float4 a[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] = r4[k + u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) x = (((x + a[u].x) + a[u].y) + a[u].z) + a[u].w;
+  }
+  return f2u(x);
 }
 
 __global__ __launch_bounds__(256) void strict_sum_kernel(const IcpState *__restrict__ state, StrictWork W) {
@@ -225,13 +294,28 @@ __global__ __launch_bounds__(256) void strict_sum_kernel(const IcpState *__restr
   if (w >= kStrictRows * W.ntiles) return;  // whole wave
   const int row = (int)(w / W.ntiles);
   const int64_t tile = w % W.ntiles;
+  __shared__ float s_tile[4][kTile];
   float t[kLeaf];
-  load_leaf(W.terms + (int64_t)row * W.nt_pad + tile * kTile + lane * kLeaf, t);
+  load_leaf(W.terms + (int64_t)row * W.nt_pad, tile, lane, t);
+  TileRec T;
+  T.s = summary_identity();
+  if (tile == 0) {
+    // the first tile starts from the one state known in advance (0.0f, evaluator.go:122) and runs
+    // through a new binade every few terms: its additions are simply carried out, here, off the
+    // chain kernel's critical path -> point record
+    const uint32_t s = serial_tile(f2u(0.0f), t, lane, s_tile[threadIdx.x >> 6]);
+    T.key = -1;
+    T.in = f2u(0.0f);
+    T.out = s;
+    T.cons = 1;
+    if (lane == 0) W.recs[row * W.ntiles] = T;
+    return;
+  }
   const double P0 = tile_prefix(W.tile_sum, W.bin_sum, W.ntiles, W.nbins, row, tile, lane);
   const double E0 = tile_prefix(W.tile_err, W.bin_err, W.ntiles, W.nbins, row, tile, lane);
   uint32_t g;
   ChainRange cr;
-  tile_guesses(t, P0 + E0, false, 0u, lane, g, cr);
+  tile_guesses(t, P0 + E0, lane, g, cr);
   // window of the tile
   const uint32_t mn = wave_all_umin(cr.mn), mx = wave_all_umax(cr.mx);
   const bool one_sign = __ballot(cr.sg_or != cr.sg_and) == 0ull &&
@@ -241,99 +325,185 @@ __global__ __launch_bounds__(256) void strict_sum_kernel(const IcpState *__restr
   // point record: the guess chains join up exactly
   const uint32_t g_next = (uint32_t)__shfl_down((int)g, 1);
   const bool cons = __ballot(lane < 63 && g_next != cr.end) == 0ull;
-  const uint32_t out = (uint32_t)__shfl((int)cr.end, 63);
-  TileRec T;
   T.key = key;
   T.in = g_first;
-  T.out = out;
+  T.out = (uint32_t)__shfl((int)cr.end, 63);
   T.cons = cons ? 1 : 0;
-  T.s = summary_identity();
   if (key >= 0) {  // uniform
     const bool one_binade = (cr.mn >> 23) == (cr.mx >> 23);
     Summary S;
     if (__ballot(!one_binade) != 0ull) {  // uniform: some leaf crosses the level
       if (one_binade) S = leaf_summary_binade(t, g, key);
       else S = leaf_summary_general(t, g, key);
+      // this is where a record is most likely not to cover the true state (a landing next to the
+      // level): keep the compositions of leaves 0..l and l..63, so that the chain kernel finds the
+      // leaf in one parallel step and carries on behind it
+      Summary P = S, Q = S;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const Summary X = shfl_summary(P, lane - o);
+        if (lane >= o) P = compose(X, P);
+        const Summary Y = shfl_summary(Q, lane + o);
+        if (lane + o < 64) Q = compose(Q, Y);
+      }
+      T.s = shfl_summary(P, 63);
+      unsigned slot = 0xffffffffu;
+      if (lane == 0) slot = atomicAdd(W.aux_count, 1u);
+      slot = (unsigned)rfl((int)slot);
+      if (slot < (unsigned)W.naux) {
+        LeafAux *a = W.aux + (size_t)slot * kLanes + lane;
+        a->pre = P;
+        a->suf = Q;
+        T.cons |= (int32_t)(slot + 1u) << 8;
+      }
     } else {
       S = leaf_summary_binade(t, g, key);
-    }
-    // ordered reduction over the 64 leaves
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const Summary Y = shfl_summary(S, lane + o);
-      if ((lane & (2 * o - 1)) == 0) S = compose(S, Y);
+      for (int o = 1; o < 64; o <<= 1) {  // ordered reduction over the 64 leaves
+        const Summary Y = shfl_summary(S, lane + o);
+        if ((lane & (2 * o - 1)) == 0) S = compose(S, Y);
+      }
+      T.s = S;
     }
-    T.s = S;
   }
   if (lane == 0) W.recs[row * W.ntiles + tile] = T;
 }
 
 // ---- chain -----------------------------------------------------------------------------------------
-// Exact recomputation of one tile from the known state: leaf guesses from the state itself, every
-// leaf summarised in a window of its own, then leaf after leaf: its summary if it covers the
-// state, the 32 additions themselves if not.
-__device__ __noinline__ uint32_t resolve_generic(uint32_t s, const float *__restrict__ tt, int lane,
-                                                 unsigned long long *dbg) {
-  float t[kLeaf];
-  load_leaf(tt + lane * kLeaf, t);
-  uint32_t g;
-  ChainRange cr;
-  tile_guesses(t, (double)u2f(s), true, s, lane, g, cr);
-  const int32_t key = cr.sg_or == cr.sg_and ? choose_window(cr.mn, cr.mx, cr.sg_or, g & 0x7fffffffu) : -1;
-  Summary S = summary_identity();
-  if (key >= 0) {
-    if ((cr.mn >> 23) == (cr.mx >> 23)) S = leaf_summary_binade(t, g, key);
-    else S = leaf_summary_general(t, g, key);
+__device__ __forceinline__ bool apply_point(uint32_t &s, const TileRec &R) {
+  if ((R.cons & 1) && R.in == s) {
+    s = R.out;
+    return true;
   }
+  return false;
+}
+
+// One tile, exactly, from the known state s (every lane holds it; returns it in every lane).
+// With aux (a tile with a level crossing whose record did not cover s): the first leaf whose prefix
+// composition fails is found by all lanes at once, that leaf is added term by term, and the suffix
+// composition behind it finishes the tile.  Without: the 2048 additions, one after the other.
+__device__ __forceinline__ uint32_t resolve_tile(uint32_t s, const float *__restrict__ row_terms, int64_t tile, int32_t key,
+                                             const LeafAux *__restrict__ aux, int lane, unsigned long long *dbg,
+                                             float *lds) {
+  const long long t_begin = wall_clock64();
+  float t[kLeaf];
+  load_leaf(row_terms, tile, lane, t);
   int serial = 0;
-  for (int l = 0; l < kLanes; l++) {
-    const int32_t k = __builtin_amdgcn_readlane(key, l);
-    bool done = false;
-    const int32_t n = state_to_n(s, k);
-    if (n >= 0) {
-      const int r = n & 3;
-      int32_t c, lo, hi;
-      if (r == 0) { c = __builtin_amdgcn_readlane(S.c[0], l); lo = __builtin_amdgcn_readlane(S.lo[0], l); hi = __builtin_amdgcn_readlane(S.hi[0], l); }
-      else if (r == 1) { c = __builtin_amdgcn_readlane(S.c[1], l); lo = __builtin_amdgcn_readlane(S.lo[1], l); hi = __builtin_amdgcn_readlane(S.hi[1], l); }
-      else if (r == 2) { c = __builtin_amdgcn_readlane(S.c[2], l); lo = __builtin_amdgcn_readlane(S.lo[2], l); hi = __builtin_amdgcn_readlane(S.hi[2], l); }
-      else { c = __builtin_amdgcn_readlane(S.c[3], l); lo = __builtin_amdgcn_readlane(S.lo[3], l); hi = __builtin_amdgcn_readlane(S.hi[3], l); }
-      if (n >= lo && n <= hi) {
-        s = n_to_state(n + c, k);
-        done = true;
+  int l = 0;
+  if (aux) {
+    const LeafAux A = aux[lane];
+    uint32_t mine = s;
+    const bool ok = apply(mine, key, A.pre);
+    const unsigned long long bad = __ballot(!ok);
+    l = bad ? __builtin_ctzll(bad) : kLanes;  // leaves 0 .. l-1 are covered
+    if (l > 0) s = (uint32_t)__builtin_amdgcn_readlane((int)mine, l - 1);
+    while (l < kLanes) {
+      s = serial_leaf(s, t, l);
+      serial++;
+      l++;
+      if (l == kLanes) break;
+      uint32_t rest = s;
+      const bool ok2 = apply(rest, key, A.suf);  // lane l: leaves l..63
+      const int okl = __builtin_amdgcn_readlane(ok2 ? 1 : 0, l);
+      if (okl) {
+        s = (uint32_t)__builtin_amdgcn_readlane((int)rest, l);
+        break;
       }
     }
-    if (!done) {
-      float x = u2f(s);
-#pragma unroll
-      for (int j = 0; j < kLeaf; j++) x = x + u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(t[j]), l));
-      s = f2u(x);
-      serial++;
-    }
+  } else {
+    s = serial_tile(s, t, lane, lds);
+    serial = kLanes;
   }
-  if (dbg && lane == 0) {
+  if (lane == 0) {
     atomicAdd(&dbg[2], 1ull);
     atomicAdd(&dbg[3], (unsigned long long)serial);
+    if (!aux) atomicAdd(&dbg[5], 1ull);
+    atomicAdd(&dbg[aux ? 10 : 11], (unsigned long long)(wall_clock64() - t_begin));
   }
   return s;
 }
 
-struct RunRec {
-  TileRec r;
-  int32_t begin, end;  // tiles [begin, end)
-};
+// debugging aid (W.selfcheck): the state after tiles [a, b) from `before`, term by term; mismatches
+// against what the walk produced are counted per path in dbg[12 + path]
+__device__ __forceinline__ void selfcheck(const StrictWork &W, const float *row_terms, uint32_t before, uint32_t after,
+                                          int64_t a, int64_t b, int path, int lane, float *lds) {
+  if (!W.selfcheck) return;
+  uint32_t x = before;
+  for (int64_t k = a; k < b; k++) {
+    float t[kLeaf];
+    load_leaf(row_terms, k, lane, t);
+    x = serial_tile(x, t, lane, lds);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (x != after && lane == 0) {
+    const unsigned long long k = atomicAdd(&W.dbg[12 + path], 1ull);
+    if (0) {  // details of the first few: dbg[16 + 4k ..] = {a | b << 32, before | after << 32, expected, blockIdx}
+      W.dbg[16 + 4 * k] = (unsigned long long)a | ((unsigned long long)b << 32);
+      W.dbg[17 + 4 * k] = (unsigned long long)before | ((unsigned long long)after << 32);
+      W.dbg[18 + 4 * k] = x;
+      W.dbg[19 + 4 * k] = blockIdx.x;
+    }
+  }
+}
 
 constexpr int kChainBlock = 512;
 
+// a record every lane of the walking wave reads from the same LDS address, as scalars
+__device__ __forceinline__ TileRec load_rec_uniform(const TileRec *p) {
+  const int32_t *w = reinterpret_cast<const int32_t *>(p);
+  int32_t v[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) v[k] = rfl(w[k]);
+  TileRec R;
+  R.key = v[0];
+  R.in = (uint32_t)v[1];
+  R.out = (uint32_t)v[2];
+  R.cons = v[3];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    R.s.c[r] = v[4 + r];
+    R.s.lo[r] = v[8 + r];
+    R.s.hi[r] = v[12 + r];
+  }
+  return R;
+}
+
+__device__ __forceinline__ TileRec shfl_rec(const TileRec &R, int src) {
+  TileRec X;
+  X.key = __shfl(R.key, src);
+  X.in = (uint32_t)__shfl((int)R.in, src);
+  X.out = (uint32_t)__shfl((int)R.out, src);
+  X.cons = __shfl(R.cons, src);
+  X.s = shfl_summary(R.s, src);
+  return X;
+}
+// X (earlier tiles) then Y, same window
+__device__ __forceinline__ TileRec compose_rec(const TileRec &X, const TileRec &Y) {
+  TileRec Z;
+  Z.key = Y.key;
+  Z.s = compose(X.s, Y.s);
+  Z.cons = ((X.cons & 1) && (Y.cons & 1) && X.out == Y.in) ? 1 : 0;
+  Z.in = X.in;
+  Z.out = Y.out;
+  return Z;
+}
+
 __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const IcpState *__restrict__ state, StrictWork W,
                                                                   double *__restrict__ sums10) {
-  __shared__ TileRec s_run[kChainBlock];
-  __shared__ int32_t s_begin[kChainBlock], s_end[kChainBlock];
+  __shared__ TileRec s_rec[kChainBlock];  // the tiles' own records
+  __shared__ TileRec s_pre[kChainBlock];  // composition from the tile's run head to the tile
+  __shared__ TileRec s_suf[kChainBlock];  // composition from the tile to its run's tail
+  __shared__ int16_t s_tail[kChainBlock];  // per wave: the tails of its runs, in order
+  __shared__ int16_t s_head[kChainBlock];
   __shared__ int32_t s_count[kChainBlock / 64];
+  __shared__ float s_tile[kTile];
   if (state->done) return;
   const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *row_terms = W.terms + (int64_t)row * W.nt_pad;
   uint32_t s = f2u(0.0f);  // walker state (wave 0), evaluator.go:122: the sums start at zero
   for (int64_t chunk = 0; chunk < W.ntiles; chunk += kChainBlock) {
-    // ---- runs of equal windows: segmented inclusive scan inside each wave
+    // ---- runs of equal windows: segmented scans inside each wave, forwards and backwards
+    const long long t_a = wall_clock64();
     const int64_t tile = chunk + threadIdx.x;
     const bool valid = tile < W.ntiles;
     TileRec R;
@@ -345,67 +515,122 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const IcpStat
       R.cons = 0;
       R.s = summary_identity();
     }
-    const int32_t key_prev = __shfl_up(R.key, 1);
+    s_rec[threadIdx.x] = R;
+    const int32_t key_prev = __shfl_up(R.key, 1), key_next = __shfl_down(R.key, 1);
     const bool head = lane == 0 || R.key < 0 || R.key != key_prev;
-    int32_t begin = (int32_t)tile;
-    int flag = head ? 1 : 0;
+    const bool tail = lane == 63 || R.key < 0 || R.key != key_next;
+    TileRec P = R, Q = R;
+    int fp = head ? 1 : 0, fq = tail ? 1 : 0, hd = lane;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-      const Summary X = shfl_summary(R.s, lane - o);
-      const uint32_t xin = (uint32_t)__shfl_up((int)R.in, o), xout = (uint32_t)__shfl_up((int)R.out, o);
-      const int xcons = __shfl_up(R.cons, o), xbegin = __shfl_up(begin, o), xflag = __shfl_up(flag, o);
-      if (lane >= o && !flag) {
-        R.s = compose(X, R.s);
-        R.cons = xcons && R.cons && xout == R.in;
-        R.in = xin;
-        begin = xbegin;
-        flag = xflag;
+      const TileRec X = shfl_rec(P, lane - o);
+      const int xf = __shfl_up(fp, o), xh = __shfl_up(hd, o);
+      if (lane >= o && !fp) {
+        P = compose_rec(X, P);
+        fp = xf;
+        hd = xh;
+      }
+      const TileRec Y = shfl_rec(Q, lane + o);
+      const int yf = __shfl_down(fq, o);
+      if (lane + o < 64 && !fq) {
+        Q = compose_rec(Q, Y);
+        fq = yf;
       }
     }
-    const int head_next = __shfl_down(head ? 1 : 0, 1);
-    const bool tail = valid && (lane == 63 || tile + 1 >= W.ntiles || head_next);
-    const unsigned long long tails = __ballot(tail);
-    if (tail) {
+    s_pre[threadIdx.x] = P;
+    s_suf[threadIdx.x] = Q;
+    const unsigned long long tails = __ballot(tail && valid);
+    if (tail && valid) {
       const int idx = wave * 64 + __popcll(tails & ((1ull << lane) - 1ull));
-      s_run[idx] = R;
-      s_begin[idx] = begin;
-      s_end[idx] = (int32_t)tile + 1;
+      s_tail[idx] = (int16_t)threadIdx.x;
+      s_head[idx] = (int16_t)(wave * 64 + hd);
     }
     if (lane == 0) s_count[wave] = __popcll(tails);
     __syncthreads();
     // ---- the walk: one wave, every lane with the same state
     if (wave == 0) {
+      const long long t_b = wall_clock64();
       unsigned long long n_run = 0, n_runfail = 0, n_recfail = 0;
       for (int w = 0; w < kChainBlock / 64; w++) {
         const int cnt = s_count[w];
         for (int i = 0; i < cnt; i++) {
-          const TileRec &Q = s_run[w * 64 + i];
+          const int e = s_tail[w * 64 + i], h = s_head[w * 64 + i];
           n_run++;
-          if (Q.key >= 0 && apply(s, Q.key, Q.s)) continue;
-          if (Q.cons && Q.in == s) {
-            s = Q.out;
-            continue;
+          {
+            const TileRec Qr = load_rec_uniform(&s_pre[e]);  // the whole run
+            const uint32_t s_in = s;
+            if ((Qr.key >= 0 && apply(s, Qr.key, Qr.s)) || apply_point(s, Qr)) {
+              selfcheck(W, row_terms, s_in, s, chunk + h, chunk + e + 1, 0, lane, s_tile);
+              if (W.selfcheck) {  // the same run composed tile after tile from the tiles' own records
+                TileRec acc = load_rec_uniform(&s_rec[h]);
+                for (int q = h + 1; q <= e; q++) acc = compose_rec(acc, load_rec_uniform(&s_rec[q]));
+                uint32_t y = s_in;
+                const bool okc = acc.key >= 0 && apply(y, acc.key, acc.s);
+                bool same = acc.key == Qr.key && acc.in == Qr.in && acc.out == Qr.out && (acc.cons & 1) == (Qr.cons & 1);
+                for (int r = 0; r < 4; r++) same = same && acc.s.c[r] == Qr.s.c[r] && acc.s.lo[r] == Qr.s.lo[r] && acc.s.hi[r] == Qr.s.hi[r];
+                if (lane == 0) {
+                  if (!same) atomicAdd(&W.dbg[6], 1ull);          // the wave scan disagrees with the serial composition
+                  if (okc && y != s) {
+                    const unsigned long long k = atomicAdd(&W.dbg[7], 1ull);  // and gives another result
+                    if (k < 2) {
+                      uint32_t z = s_in;
+                      const int32_t nn = state_to_n(s_in, Qr.key);
+                      const bool okq = apply(z, Qr.key, Qr.s);
+                      unsigned long long *d = W.dbg + 16 + 16 * k;
+                      d[0] = s_in; d[1] = s; d[2] = y; d[3] = (unsigned long long)(uint32_t)Qr.key; d[4] = (unsigned long long)(uint32_t)nn;
+                      d[5] = (uint32_t)Qr.s.c[nn & 3]; d[6] = (uint32_t)Qr.s.lo[nn & 3]; d[7] = (uint32_t)Qr.s.hi[nn & 3];
+                      d[8] = (uint32_t)acc.s.c[nn & 3]; d[9] = okq; d[10] = z; d[11] = Qr.in; d[12] = Qr.out; d[13] = Qr.cons;
+                    }
+                  }
+                }
+              }
+              continue;
+            }
           }
           n_runfail++;
-          const int32_t b = s_begin[w * 64 + i], e = s_end[w * 64 + i];
-          for (int32_t q = b; q < e; q++) {
-            if (e - b > 1) {  // a run of several tiles: their own records first
-              const TileRec T = W.recs[row * W.ntiles + q];
-              if (T.key >= 0 && apply(s, T.key, T.s)) continue;
-              if (T.cons && T.in == s) {
-                s = T.out;
-                continue;
-              }
+          // which tile?  lane j tries the composition h .. h + j
+          int f = h;
+          if (e > h) {
+            uint32_t mine = s;
+            bool ok = false;
+            if (h + lane <= e) {
+              const TileRec Pj = s_pre[h + lane];
+              ok = Pj.key >= 0 && apply(mine, Pj.key, Pj.s);
             }
-            n_recfail++;
-            s = (uint32_t)rfl((int)resolve_generic(s, W.terms + (int64_t)row * W.nt_pad + (int64_t)q * kTile, lane, W.dbg));
+            const unsigned long long good = __ballot(ok);
+            const int ngood = __builtin_ctzll(~good);  // tiles h .. h + ngood - 1 are covered
+            const uint32_t s_in = s;
+            if (ngood > 0) s = (uint32_t)__builtin_amdgcn_readlane((int)mine, ngood - 1);
+            f = h + ngood;
+            selfcheck(W, row_terms, s_in, s, chunk + h, chunk + f, 1, lane, s_tile);
+          }
+          while (f <= e) {
+            const TileRec T = load_rec_uniform(&s_rec[f]);
+            const uint32_t s_in = s;
+            if (!(f > h && ((T.key >= 0 && apply(s, T.key, T.s)) || apply_point(s, T)))) {
+              n_recfail++;
+              const int slot = (T.cons >> 8) - 1;
+              s = (uint32_t)rfl((int)resolve_tile(s, row_terms, chunk + f, T.key,
+                                                  slot >= 0 ? W.aux + (size_t)slot * kLanes : nullptr, lane, W.dbg, s_tile));
+            }
+            selfcheck(W, row_terms, s_in, s, chunk + f, chunk + f + 1, 2, lane, s_tile);
+            f++;
+            if (f > e) break;
+            const TileRec Sf = load_rec_uniform(&s_suf[f]);  // the rest of the run in one step
+            const uint32_t s_in2 = s;
+            if ((Sf.key >= 0 && apply(s, Sf.key, Sf.s)) || apply_point(s, Sf)) {
+              selfcheck(W, row_terms, s_in2, s, chunk + f, chunk + e + 1, 3, lane, s_tile);
+              break;
+            }
           }
         }
       }
-      if (W.dbg && lane == 0) {
+      if (lane == 0) {
         atomicAdd(&W.dbg[0], n_run);
         atomicAdd(&W.dbg[1], n_runfail);
         atomicAdd(&W.dbg[4], n_recfail);
+        atomicAdd(&W.dbg[8], (unsigned long long)(t_b - t_a));
+        atomicAdd(&W.dbg[9], (unsigned long long)(wall_clock64() - t_b));
       }
     }
     __syncthreads();
@@ -417,6 +642,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const IcpStat
     if (row == 0) {
       sums10[S_PAIRS] = (double)*W.pairs;
       *W.pairs = 0ull;
+      *W.aux_count = 0u;
     }
   }
   for (int64_t b = threadIdx.x; b < W.nbins; b += kChainBlock) {
@@ -431,19 +657,24 @@ struct StrictBuffers {
   void *block = nullptr;
 };
 
-pcgx_status strict_create(int64_t nt, StrictBuffers **out, hipStream_t st) {
+pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const float *tz, const uint32_t *pos_of,
+                          StrictBuffers **out, hipStream_t st) {
   StrictBuffers *b = new StrictBuffers();
   StrictWork &W = b->w;
   W.nt = nt;
   W.ntiles = nt > 0 ? (nt + kTile - 1) / kTile : 1;
   W.nt_pad = W.ntiles * kTile;
   W.nbins = (W.ntiles + kBinTiles - 1) / kBinTiles;
+  W.selfcheck = getenv("PCGX_STRICT_SELFCHECK") ? 1 : 0;
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t sz_terms = up((size_t)kStrictRows * W.nt_pad * sizeof(float));
   const size_t sz_tile = up((size_t)kStrictRows * W.ntiles * sizeof(double));
   const size_t sz_bin = up((size_t)kStrictRows * W.nbins * sizeof(double));
   const size_t sz_rec = up((size_t)kStrictRows * W.ntiles * sizeof(TileRec));
-  const size_t total = sz_terms + 2 * sz_tile + 2 * sz_bin + sz_rec + 256 + 256;
+  W.naux = (int32_t)(kStrictRows * W.ntiles / 4 + 64);
+  const size_t sz_aux = up((size_t)W.naux * kLanes * sizeof(LeafAux));
+  const size_t sz_xyz = up((size_t)(nt ? nt : 1) * 12);
+  const size_t total = sz_terms + 2 * sz_tile + 2 * sz_bin + sz_rec + sz_aux + sz_xyz + 256 + 512;
   hipError_t e = dev_cache_alloc(&b->block, total);
   if (e != hipSuccess) {
     delete b;
@@ -456,11 +687,19 @@ pcgx_status strict_create(int64_t nt, StrictBuffers **out, hipStream_t st) {
   W.bin_sum = (double *)p; p += sz_bin;
   W.bin_err = (double *)p; p += sz_bin;
   W.recs = (TileRec *)p; p += sz_rec;
-  W.pairs = (unsigned long long *)p; p += 256;
+  W.aux = (LeafAux *)p; p += sz_aux;
+  W.xyz_caller = (const float *)p; p += sz_xyz;
+  W.pairs = (unsigned long long *)p;
+  W.aux_count = (unsigned int *)(p + 8); p += 256;
   W.dbg = (unsigned long long *)p;
   // bins, pair counter and debug counters start at zero (the chain kernel re-zeroes what it consumed)
   e = hipMemsetAsync(W.bin_sum, 0, 2 * sz_bin, st);
-  if (e == hipSuccess) e = hipMemsetAsync(W.pairs, 0, 512, st);
+  if (e == hipSuccess) e = hipMemsetAsync(W.pairs, 0, 768, st);
+  if (e == hipSuccess && nt > 0) {
+    hipLaunchKernelGGL(strict_xyz_caller_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, tx, ty, tz, pos_of, nt,
+                       const_cast<float *>(W.xyz_caller));
+    e = hipGetLastError();
+  }
   if (e != hipSuccess) {
     dev_cache_free(b->block);
     delete b;
@@ -476,11 +715,11 @@ void strict_destroy(StrictBuffers *b) {
   delete b;
 }
 
-pcgx_status strict_enqueue(StrictBuffers *b, const float *tx, const float *ty, const float *tz, const float4 *match,
-                           const uint32_t *pos_of, const IcpState *state, double *sums10, hipStream_t st) {
+pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, const IcpState *state,
+                           double *sums10, hipStream_t st) {
   const StrictWork &W = b->w;
   const unsigned waves = (unsigned)(kStrictRows * W.ntiles);
-  hipLaunchKernelGGL(strict_terms_kernel, dim3((unsigned)W.ntiles), dim3(1024), 0, st, tx, ty, tz, match, pos_of, state, W);
+  hipLaunchKernelGGL(strict_terms_kernel, dim3((unsigned)W.ntiles), dim3(kTermsBlock), 0, st, match, pos_of, state, W);
   hipLaunchKernelGGL(strict_err_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, state, W);
   hipLaunchKernelGGL(strict_sum_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, state, W);
   hipLaunchKernelGGL(strict_chain_kernel, dim3(kStrictRows), dim3(kChainBlock), 0, st, state, W, sums10);
@@ -488,10 +727,10 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float *tx, const float *ty, c
   return PCGX_OK;
 }
 
-pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[16], hipStream_t st) {
-  PCGX_HIP_TRY(hipMemcpyAsync(out, b->w.dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[48], hipStream_t st) {
+  PCGX_HIP_TRY(hipMemcpyAsync(out, b->w.dbg, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
-  PCGX_HIP_TRY(hipMemsetAsync(b->w.dbg, 0, 16 * sizeof(unsigned long long), st));
+  PCGX_HIP_TRY(hipMemsetAsync(b->w.dbg, 0, 48 * sizeof(unsigned long long), st));
   return PCGX_OK;
 }
 

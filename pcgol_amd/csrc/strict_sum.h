@@ -89,18 +89,25 @@ SS_HD Summary summary_identity() {
   return S;
 }
 
+// v[r] for r in 0..3 with the four values already in registers (two selects, no memory indexing)
+SS_HD int32_t pick4(int r, int32_t v0, int32_t v1, int32_t v2, int32_t v3) {
+  const int32_t a = (r & 1) ? v1 : v0, b = (r & 1) ? v3 : v2;
+  return (r & 2) ? b : a;
+}
+
 // X first, then Y
 SS_HD Summary compose(const Summary &X, const Summary &Y) {
   Summary Z;
+  const int32_t yc0 = Y.c[0], yc1 = Y.c[1], yc2 = Y.c[2], yc3 = Y.c[3];
+  const int32_t yl0 = Y.lo[0], yl1 = Y.lo[1], yl2 = Y.lo[2], yl3 = Y.lo[3];
+  const int32_t yh0 = Y.hi[0], yh1 = Y.hi[1], yh2 = Y.hi[2], yh3 = Y.hi[3];
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    const int q = (r + X.c[r]) & 3;
-    const int32_t yc = q == 0 ? Y.c[0] : (q == 1 ? Y.c[1] : (q == 2 ? Y.c[2] : Y.c[3]));
-    const int32_t yl = q == 0 ? Y.lo[0] : (q == 1 ? Y.lo[1] : (q == 2 ? Y.lo[2] : Y.lo[3]));
-    const int32_t yh = q == 0 ? Y.hi[0] : (q == 1 ? Y.hi[1] : (q == 2 ? Y.hi[2] : Y.hi[3]));
-    Z.c[r] = iclamp(X.c[r] + yc, -kClamp, kClamp);
-    Z.lo[r] = imax(X.lo[r], iclamp(yl - X.c[r], -kBig, kBig));
-    Z.hi[r] = imin(X.hi[r], iclamp(yh - X.c[r], -kBig, kBig));
+    const int32_t xc = X.c[r];
+    const int q = (r + xc) & 3;
+    Z.c[r] = iclamp(xc + pick4(q, yc0, yc1, yc2, yc3), -kClamp, kClamp);
+    Z.lo[r] = imax(X.lo[r], iclamp(pick4(q, yl0, yl1, yl2, yl3) - xc, -kBig, kBig));
+    Z.hi[r] = imin(X.hi[r], iclamp(pick4(q, yh0, yh1, yh2, yh3) - xc, -kBig, kBig));
   }
   return Z;
 }
@@ -125,12 +132,13 @@ SS_HD uint32_t n_to_state(int32_t n, int32_t key) {
 
 // the exact effect of the summarised additions on `bits`, if the summary covers that state
 SS_HD bool apply(uint32_t &bits, int32_t key, const Summary &S) {
-  int32_t n = state_to_n(bits, key);
+  const int32_t c0 = S.c[0], c1 = S.c[1], c2 = S.c[2], c3 = S.c[3];
+  const int32_t l0 = S.lo[0], l1 = S.lo[1], l2 = S.lo[2], l3 = S.lo[3];
+  const int32_t h0 = S.hi[0], h1 = S.hi[1], h2 = S.hi[2], h3 = S.hi[3];
+  const int32_t n = state_to_n(bits, key);
   if (n < 0) return false;
   const int r = n & 3;
-  const int32_t lo = r == 0 ? S.lo[0] : (r == 1 ? S.lo[1] : (r == 2 ? S.lo[2] : S.lo[3]));
-  const int32_t hi = r == 0 ? S.hi[0] : (r == 1 ? S.hi[1] : (r == 2 ? S.hi[2] : S.hi[3]));
-  const int32_t c = r == 0 ? S.c[0] : (r == 1 ? S.c[1] : (r == 2 ? S.c[2] : S.c[3]));
+  const int32_t lo = pick4(r, l0, l1, l2, l3), hi = pick4(r, h0, h1, h2, h3), c = pick4(r, c0, c1, c2, c3);
   if (n < lo || n > hi) return false;
   bits = n_to_state(n + c, key);
   return true;
