@@ -18,14 +18,6 @@
 
 namespace pcgx {
 
-struct IcpKernelParams {
-  float max_dist_sq;
-  float min_dist_sq;
-  int32_t min_pairs;
-  UpdaterParams upd;
-  GaussNewtonParams gn;  // plane sessions
-};
-
 constexpr int kIcpBlock = kKnnBlock;
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -399,30 +391,6 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_xkernel(
   __syncthreads();
   reduce_block_range<kPlane>(s_stack, tx, ty, tz, nt, chunk_begin, chunk_end, project, m, match, match_id, normals,
                              block_partials);
-}
-
-// Evaluate tail (evaluator.go:92-105,156-186) + Update (updater.go:44-71) + the loop
-// bookkeeping of Fit (icp.go:49-60); one thread.
-__device__ __forceinline__ void icp_update_step(IcpState *__restrict__ state, const double *__restrict__ sums10,
-                                                const IcpKernelParams &kp) {
-  state->num_iteration += 1;
-  const int64_t npairs = (int64_t)sums10[S_PAIRS];
-  if (npairs < (int64_t)kp.min_pairs) {
-    state->ev.num_pairs = npairs;
-    state->status = PCGX_E_NOT_ENOUGH_PAIRS;
-    state->done = 1;
-    return;
-  }
-  Evaluated ev;
-  finish_evaluate(sums10, ev);
-  state->ev = ev;
-  Mat4 t;
-  for (int i = 0; i < 16; i++) t.m[i] = state->trans[i];
-  int32_t it = state->iter;
-  const bool converged = gradient_descent_update(kp.upd, it, ev.gradient, t);
-  for (int i = 0; i < 16; i++) state->trans[i] = t.m[i];
-  state->iter = it;
-  if (converged) state->done = 1;
 }
 
 // Plane sessions: evaluate tail (finish_evaluate_plane) + Gauss-Newton update; one thread.
@@ -979,9 +947,8 @@ static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
     if (!s->strict_buf)
       PCGX_TRY(strict_create(s->nt, s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, (const uint32_t *)s->d_pos_of,
                              &s->strict_buf, st));
-    PCGX_TRY(strict_enqueue(s->strict_buf, (const float4 *)s->d_match, (const uint32_t *)s->d_pos_of,
-                            (const IcpState *)s->d_state, s->d_sums, st));
-    if (kFuseUpdate) hipLaunchKernelGGL(icp_update_kernel<false>, dim3(1), dim3(64), 0, st, s->d_state, s->d_sums, s->kp);
+    PCGX_TRY(strict_enqueue(s->strict_buf, (const float4 *)s->d_match, (const uint32_t *)s->d_pos_of, s->d_state,
+                            s->d_sums, s->kp, kFuseUpdate, st));
     return PCGX_OK;
   }
   // strict 2: the plain dependent chain, one wave (kept as the on-device cross-check of strict 1)

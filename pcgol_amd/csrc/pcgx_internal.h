@@ -241,13 +241,49 @@ struct IcpState {
 };
 
 
+struct IcpKernelParams {
+  float max_dist_sq;
+  float min_dist_sq;
+  int32_t min_pairs;
+  UpdaterParams upd;
+  GaussNewtonParams gn;  // plane sessions
+};
+
+
+#if defined(__HIPCC__)
+// Evaluate tail (evaluator.go:92-105,156-186) + Update (updater.go:44-71) + the loop
+// bookkeeping of Fit (icp.go:49-60); one thread.
+__device__ __forceinline__ void icp_update_step(IcpState *__restrict__ state, const double *__restrict__ sums10,
+                                                const IcpKernelParams &kp) {
+  state->num_iteration += 1;
+  const int64_t npairs = (int64_t)sums10[S_PAIRS];
+  if (npairs < (int64_t)kp.min_pairs) {
+    state->ev.num_pairs = npairs;
+    state->status = PCGX_E_NOT_ENOUGH_PAIRS;
+    state->done = 1;
+    return;
+  }
+  Evaluated ev;
+  finish_evaluate(sums10, ev);
+  state->ev = ev;
+  Mat4 t;
+  for (int i = 0; i < 16; i++) t.m[i] = state->trans[i];
+  int32_t it = state->iter;
+  const bool converged = gradient_descent_update(kp.upd, it, ev.gradient, t);
+  for (int i = 0; i < 16; i++) state->trans[i] = t.m[i];
+  state->iter = it;
+  if (converged) state->done = 1;
+}
+
+#endif
+
 // strict.hip: the evaluator's sequential float32 sums (evaluator.go:122-145), bit for bit, in parallel
 struct StrictBuffers;
 pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const float *tz, const uint32_t *pos_of,
                           StrictBuffers **out, hipStream_t st);
 void strict_destroy(StrictBuffers *b);
-pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, const IcpState *state,
-                           double *sums10, hipStream_t st);
+pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
+                           double *sums10, const IcpKernelParams &kp, bool fuse_update, hipStream_t st);
 pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[48], hipStream_t st);
 }  // namespace pcgx
 

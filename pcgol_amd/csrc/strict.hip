@@ -5,9 +5,8 @@
 // Per iteration, after the correspondence kernels left match[] (icp.hip):
 //   strict_terms_kernel  one thread per target in the CALLER's order: the nine float32 terms
 //                        (rows of terms[]), float64 tile sums, level-1 bins (atomics), pair count
-//   strict_err_kernel    one wave per (row, tile): rounding error the chain makes in this tile when
-//                        started from the float64 prefix  -> tile_err, bins
-//   strict_sum_kernel    one wave per (row, tile): guesses from prefix + error prefix, class
+//   strict_sum_kernel    one wave per (row, tile): leaf guesses from the float64 prefix (refined once
+//                        inside the tile by the rounding errors the chains make from them), class
 //                        summaries of the 64 leaves, composed -> one 64-byte record per tile
 //   strict_chain_kernel  one workgroup per row: records of equal windows merged into runs
 //                        (segmented wave scan), one wave applies them in order to the exact state;
@@ -66,11 +65,12 @@ struct LeafAux {  // per leaf of a tile with a level crossing: compositions of l
 struct StrictWork {
   float *terms;                 // [9][ntiles][kLeaf / 4][64 lanes][4]: lane l of a tile holds its leaf's terms 4 by 4
   const float *xyz_caller;      // [nt][3] the targets in the caller's order
-  double *tile_sum, *tile_err;  // [9][ntiles]
-  double *bin_sum, *bin_err;    // [9][nbins] level-1 sums of kBinTiles tiles (atomics; zeroed by the chain kernel)
+  double *tile_sum;             // [9][ntiles] float64 sums of the tiles' terms
+  double *bin_sum;              // [9][nbins] level-1 sums of kBinTiles tiles (atomics; zeroed by the chain kernel)
   TileRec *recs;                // [9][ntiles]
   LeafAux *aux;                 // [naux][64]
   unsigned int *aux_count;      // slots handed out this iteration (zeroed by the chain kernel)
+  unsigned int *done_rows;      // rows of the chain kernel that have finished (ticket of the fused update)
   unsigned long long *pairs;    // matched targets of this iteration (atomic; zeroed by the chain kernel)
   unsigned long long *dbg;      // [16] counters (measurement aid)
   int64_t nt, nt_pad, ntiles, nbins;
@@ -78,13 +78,9 @@ struct StrictWork {
   int32_t selfcheck;  // debugging: every step of the chain walk is re-derived term by term and compared (dbg[12..15])
 };
 
-// where term i (caller's order) of a row lives: leaves are interleaved 4 floats at a time so that the
-// 64 lanes of a wave read their leaves with fully coalesced 16-byte loads
-__device__ __forceinline__ int64_t term_index(int64_t i) {
-  const int64_t tile = i / kTile;
-  const int w = (int)(i % kTile), l = w / kLeaf, j = w % kLeaf;
-  return ((tile * (kLeaf / 4) + j / 4) * kLanes + l) * 4 + (j & 3);
-}
+// term i (caller's order) of a row lives at ((tile * 8 + j / 4) * 64 + l) * 4 + j % 4 with tile = i /
+// 2048, l = i % 2048 / 32, j = i % 32: leaves are interleaved 4 floats at a time so that the 64 lanes
+// of a wave read (and the terms kernel writes) them with fully coalesced 16-byte accesses
 __device__ __forceinline__ void load_leaf(const float *__restrict__ row, int64_t tile, int lane, float *t) {
   const float4 *q = reinterpret_cast<const float4 *>(row) + tile * (kLeaf / 4) * kLanes + lane;
 #pragma unroll
@@ -116,7 +112,10 @@ __device__ __forceinline__ double tile_prefix(const double *__restrict__ tile_v,
 // order (xyz_caller) and re-projected here exactly as the correspondence kernels do, only its pair
 // is a gather (pos_of: where the session keeps target i).  Unmatched targets and the padding behind
 // nt carry -0.0f: x + (-0.0f) == x for every x.
-constexpr int kTermsBlock = 256, kTermsPer = kTile / kTermsBlock;
+constexpr int kTermsBlock = 256;
+// One workgroup per tile; a thread forms the terms of two QUADS (4 consecutive targets of one leaf):
+// its eight gathers are issued together and each row's four terms leave as one 16-byte store, lanes
+// side by side (the interleaved layout of terms[]).
 __global__ __launch_bounds__(kTermsBlock) void strict_terms_kernel(const float4 *__restrict__ match,
                                                                    const uint32_t *__restrict__ pos_of,
                                                                    const IcpState *__restrict__ state, StrictWork W) {
@@ -132,51 +131,60 @@ __global__ __launch_bounds__(kTermsBlock) void strict_terms_kernel(const float4 
 #pragma unroll
   for (int k = 0; k < kStrictRows; k++) acc[k] = 0.0;
   int npairs = 0;
-  // the eight gathers of a thread are issued together
-  float4 bp[kTermsPer];
-  float tx[kTermsPer], ty[kTermsPer], tz[kTermsPer];
+  constexpr int kQuads = kTile / 4 / kTermsBlock;  // 2
+  float4 bp[kQuads][4];
+  float tx[kQuads][4], ty[kQuads][4], tz[kQuads][4];
 #pragma unroll
-  for (int h = 0; h < kTermsPer; h++) {
-    const int64_t i = tile * kTile + h * kTermsBlock + threadIdx.x;
-    bp[h] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-    tx[h] = ty[h] = tz[h] = 0.0f;
-    if (i < W.nt) {
-      bp[h] = match[pos_of[i]];
-      tx[h] = W.xyz_caller[3 * i];
-      ty[h] = W.xyz_caller[3 * i + 1];
-      tz[h] = W.xyz_caller[3 * i + 2];
+  for (int h = 0; h < kQuads; h++) {
+    const int q = h * kTermsBlock + threadIdx.x, l = q & (kLanes - 1), v = q / kLanes;
+    const int64_t i0 = tile * kTile + l * kLeaf + 4 * v;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int64_t i = i0 + c;
+      bp[h][c] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+      tx[h][c] = ty[h][c] = tz[h][c] = 0.0f;
+      if (i < W.nt) {
+        bp[h][c] = match[pos_of[i]];
+        tx[h][c] = W.xyz_caller[3 * i];
+        ty[h][c] = W.xyz_caller[3 * i + 1];
+        tz[h][c] = W.xyz_caller[3 * i + 2];
+      }
     }
   }
 #pragma unroll
-  for (int h = 0; h < kTermsPer; h++) {
-    const int64_t i = tile * kTile + h * kTermsBlock + threadIdx.x;
-    float t[kStrictRows];
+  for (int h = 0; h < kQuads; h++) {
+    const int q = h * kTermsBlock + threadIdx.x, l = q & (kLanes - 1), v = q / kLanes;
+    float t[kStrictRows][4];
 #pragma unroll
-    for (int k = 0; k < kStrictRows; k++) t[k] = -0.0f;
-    if (bp[h].w >= 0.0f) {  // correspondence.go:27-29
-      npairs++;
-      float x0 = tx[h], y0 = ty[h], z0 = tz[h];
-      if (project) {
-        float px, py, pz;
-        mat4_transform(m, x0, y0, z0, px, py, pz);
-        x0 = px; y0 = py; z0 = pz;
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int k = 0; k < kStrictRows; k++) t[k][c] = -0.0f;
+      const float4 b = bp[h][c];
+      if (b.w >= 0.0f) {  // correspondence.go:27-29
+        npairs++;
+        float x0 = tx[h][c], y0 = ty[h][c], z0 = tz[h][c];
+        if (project) {
+          float px, py, pz;
+          mat4_transform(m, x0, y0, z0, px, py, pz);
+          x0 = px; y0 = py; z0 = pz;
+        }
+        const float x1 = b.x, y1 = b.y, z1 = b.z, w = 1.0f;  // evaluator.go:21-23,130
+        t[0][c] = w * b.w;
+        t[1][c] = w * (x0 - x1);
+        t[2][c] = w * (y0 - y1);
+        t[3][c] = w * (z0 - z1);
+        t[4][c] = w * (z0 * y1 - y0 * z1);
+        t[5][c] = w * (x0 * z1 - z0 * x1);
+        t[6][c] = w * (y0 * x1 - x0 * y1);
+        t[7][c] = w * norm_sq3(x0, y0, z0);
+        t[8][c] = w;
       }
-      const float x1 = bp[h].x, y1 = bp[h].y, z1 = bp[h].z, w = 1.0f;  // evaluator.go:21-23,130
-      t[0] = w * bp[h].w;
-      t[1] = w * (x0 - x1);
-      t[2] = w * (y0 - y1);
-      t[3] = w * (z0 - z1);
-      t[4] = w * (z0 * y1 - y0 * z1);
-      t[5] = w * (x0 * z1 - z0 * x1);
-      t[6] = w * (y0 * x1 - x0 * y1);
-      t[7] = w * norm_sq3(x0, y0, z0);
-      t[8] = w;
     }
-    const int64_t at = term_index(i);
+    float4 *out = reinterpret_cast<float4 *>(W.terms) + (tile * (kLeaf / 4) + v) * kLanes + l;
 #pragma unroll
     for (int k = 0; k < kStrictRows; k++) {
-      W.terms[(int64_t)k * W.nt_pad + at] = t[k];
-      acc[k] += (double)t[k];
+      out[(int64_t)k * (W.nt_pad / 4)] = make_float4(t[k][0], t[k][1], t[k][2], t[k][3]);
+      acc[k] += (((double)t[k][0] + (double)t[k][1]) + (double)t[k][2]) + (double)t[k][3];
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -215,31 +223,6 @@ __global__ __launch_bounds__(256) void strict_xyz_caller_kernel(const float *__r
   out[3 * i] = tx[pos];
   out[3 * i + 1] = ty[pos];
   out[3 * i + 2] = tz[pos];
-}
-
-// ---- error pass ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void strict_err_kernel(const IcpState *__restrict__ state, StrictWork W) {
-  if (state->done) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= kStrictRows * W.ntiles) return;  // whole wave
-  const int row = (int)(w / W.ntiles);
-  const int64_t tile = w % W.ntiles;
-  float t[kLeaf];
-  load_leaf(W.terms + (int64_t)row * W.nt_pad, tile, lane, t);
-  const double P0 = tile_prefix(W.tile_sum, W.bin_sum, W.ntiles, W.nbins, row, tile, lane);
-  const double lsum = leaf_sum_f64(t);
-  const double pre = wave_excl_scan_f64(lsum, lane);
-  const float g = (float)(P0 + pre);
-  float s = g;
-#pragma unroll
-  for (int j = 0; j < kLeaf; j++) s = s + t[j];
-  // rounding error of this leaf's 32 additions (exact: the differences are exact in float64)
-  const double err = wave_allsum_f64(((double)s - (double)g) - lsum);
-  if (lane == 0) {
-    W.tile_err[row * W.ntiles + tile] = err;
-    unsafeAtomicAdd(&W.bin_err[row * W.nbins + tile / kBinTiles], err);
-  }
 }
 
 // ---- summaries ---------------------------------------------------------------------------------------
@@ -312,10 +295,9 @@ __global__ __launch_bounds__(256) void strict_sum_kernel(const IcpState *__restr
     return;
   }
   const double P0 = tile_prefix(W.tile_sum, W.bin_sum, W.ntiles, W.nbins, row, tile, lane);
-  const double E0 = tile_prefix(W.tile_err, W.bin_err, W.ntiles, W.nbins, row, tile, lane);
   uint32_t g;
   ChainRange cr;
-  tile_guesses(t, P0 + E0, lane, g, cr);
+  tile_guesses(t, P0, lane, g, cr);
   // window of the tile
   const uint32_t mn = wave_all_umin(cr.mn), mx = wave_all_umax(cr.mx);
   const bool one_sign = __ballot(cr.sg_or != cr.sg_and) == 0ull &&
@@ -488,11 +470,11 @@ __device__ __forceinline__ TileRec compose_rec(const TileRec &X, const TileRec &
   return Z;
 }
 
-__global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const IcpState *__restrict__ state, StrictWork W,
-                                                                  double *__restrict__ sums10) {
+__global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(IcpState *__restrict__ state, StrictWork W,
+                                                                  double *__restrict__ sums10, IcpKernelParams kp,
+                                                                  int fuse_update) {
   __shared__ TileRec s_rec[kChainBlock];  // the tiles' own records
   __shared__ TileRec s_pre[kChainBlock];  // composition from the tile's run head to the tile
-  __shared__ TileRec s_suf[kChainBlock];  // composition from the tile to its run's tail
   __shared__ int16_t s_tail[kChainBlock];  // per wave: the tails of its runs, in order
   __shared__ int16_t s_head[kChainBlock];
   __shared__ int32_t s_count[kChainBlock / 64];
@@ -519,31 +501,24 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const IcpStat
     const int32_t key_prev = __shfl_up(R.key, 1), key_next = __shfl_down(R.key, 1);
     const bool head = lane == 0 || R.key < 0 || R.key != key_prev;
     const bool tail = lane == 63 || R.key < 0 || R.key != key_next;
-    TileRec P = R, Q = R;
-    int fp = head ? 1 : 0, fq = tail ? 1 : 0, hd = lane;
+    TileRec P = R;
+    int fp = head ? 1 : 0;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const TileRec X = shfl_rec(P, lane - o);
-      const int xf = __shfl_up(fp, o), xh = __shfl_up(hd, o);
+      const int xf = __shfl_up(fp, o);
       if (lane >= o && !fp) {
         P = compose_rec(X, P);
         fp = xf;
-        hd = xh;
-      }
-      const TileRec Y = shfl_rec(Q, lane + o);
-      const int yf = __shfl_down(fq, o);
-      if (lane + o < 64 && !fq) {
-        Q = compose_rec(Q, Y);
-        fq = yf;
       }
     }
     s_pre[threadIdx.x] = P;
-    s_suf[threadIdx.x] = Q;
     const unsigned long long tails = __ballot(tail && valid);
     if (tail && valid) {
-      const int idx = wave * 64 + __popcll(tails & ((1ull << lane) - 1ull));
+      const unsigned long long below = tails & ((1ull << lane) - 1ull);  // the run starts behind the tail before this one
+      const int idx = wave * 64 + __popcll(below);
       s_tail[idx] = (int16_t)threadIdx.x;
-      s_head[idx] = (int16_t)(wave * 64 + hd);
+      s_head[idx] = (int16_t)(wave * 64 + (below ? 64 - __builtin_clzll(below) : 0));
     }
     if (lane == 0) s_count[wave] = __popcll(tails);
     __syncthreads();
@@ -616,7 +591,22 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const IcpStat
             selfcheck(W, row_terms, s_in, s, chunk + f, chunk + f + 1, 2, lane, s_tile);
             f++;
             if (f > e) break;
-            const TileRec Sf = load_rec_uniform(&s_suf[f]);  // the rest of the run in one step
+            // the rest of the run in one step: tiles f .. e composed on the spot (ordered tree over the lanes)
+            TileRec Sf;
+            {
+              TileRec Y = s_rec[f + lane <= e ? f + lane : e];
+              if (f + lane > e) {
+                Y.key = -3;  // identity
+                Y.s = summary_identity();
+              }
+#pragma unroll
+              for (int o = 1; o < 64; o <<= 1) {
+                const TileRec Z = shfl_rec(Y, lane + o);
+                if ((lane & (2 * o - 1)) == 0 && Z.key != -3) Y = Y.key == -3 ? Z : compose_rec(Y, Z);
+              }
+              Sf = shfl_rec(Y, 0);
+              Sf.key = rfl(Sf.key);
+            }
             const uint32_t s_in2 = s;
             if ((Sf.key >= 0 && apply(s, Sf.key, Sf.s)) || apply_point(s, Sf)) {
               selfcheck(W, row_terms, s_in2, s, chunk + f, chunk + e + 1, 3, lane, s_tile);
@@ -635,19 +625,26 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const IcpStat
     }
     __syncthreads();
   }
+  for (int64_t b = threadIdx.x; b < W.nbins; b += kChainBlock) W.bin_sum[row * W.nbins + b] = 0.0;
   // component order of sums10: Value, G0..G5, DistRMS, Weight, Pairs
   if (threadIdx.x == 0) {
     const int slot = row == 0 ? S_VALUE : (row <= 6 ? S_G0 + row - 1 : (row == 7 ? S_DIST_RMS : S_WEIGHT));
-    sums10[slot] = (double)u2f(s);
-    if (row == 0) {
-      sums10[S_PAIRS] = (double)*W.pairs;
+    __hip_atomic_store(&sums10[slot], (double)u2f(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the row that finishes last has all nine sums: evaluate tail + pose update (evaluator.go:156-186,
+    // updater.go:44-71) in the same launch
+    __threadfence();
+    const unsigned ticket = atomicAdd(W.done_rows, 1u);
+    if (ticket == (unsigned)kStrictRows - 1u) {
+      __threadfence();
+      double sums[S_COUNT];
+      for (int k = 0; k < S_COUNT; k++) sums[k] = __hip_atomic_load(&sums10[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sums[S_PAIRS] = (double)__hip_atomic_load(W.pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sums10[S_PAIRS] = sums[S_PAIRS];
       *W.pairs = 0ull;
       *W.aux_count = 0u;
+      *W.done_rows = 0u;
+      if (fuse_update) icp_update_step(state, sums, kp);
     }
-  }
-  for (int64_t b = threadIdx.x; b < W.nbins; b += kChainBlock) {
-    W.bin_sum[row * W.nbins + b] = 0.0;
-    W.bin_err[row * W.nbins + b] = 0.0;
   }
 }
 
@@ -674,7 +671,7 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   W.naux = (int32_t)(kStrictRows * W.ntiles / 4 + 64);
   const size_t sz_aux = up((size_t)W.naux * kLanes * sizeof(LeafAux));
   const size_t sz_xyz = up((size_t)(nt ? nt : 1) * 12);
-  const size_t total = sz_terms + 2 * sz_tile + 2 * sz_bin + sz_rec + sz_aux + sz_xyz + 256 + 512;
+  const size_t total = sz_terms + sz_tile + sz_bin + sz_rec + sz_aux + sz_xyz + 256 + 512;
   hipError_t e = dev_cache_alloc(&b->block, total);
   if (e != hipSuccess) {
     delete b;
@@ -683,17 +680,16 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   uint8_t *p = (uint8_t *)b->block;
   W.terms = (float *)p; p += sz_terms;
   W.tile_sum = (double *)p; p += sz_tile;
-  W.tile_err = (double *)p; p += sz_tile;
   W.bin_sum = (double *)p; p += sz_bin;
-  W.bin_err = (double *)p; p += sz_bin;
   W.recs = (TileRec *)p; p += sz_rec;
   W.aux = (LeafAux *)p; p += sz_aux;
   W.xyz_caller = (const float *)p; p += sz_xyz;
   W.pairs = (unsigned long long *)p;
-  W.aux_count = (unsigned int *)(p + 8); p += 256;
+  W.aux_count = (unsigned int *)(p + 8);
+  W.done_rows = (unsigned int *)(p + 12); p += 256;
   W.dbg = (unsigned long long *)p;
   // bins, pair counter and debug counters start at zero (the chain kernel re-zeroes what it consumed)
-  e = hipMemsetAsync(W.bin_sum, 0, 2 * sz_bin, st);
+  e = hipMemsetAsync(W.bin_sum, 0, sz_bin, st);
   if (e == hipSuccess) e = hipMemsetAsync(W.pairs, 0, 768, st);
   if (e == hipSuccess && nt > 0) {
     hipLaunchKernelGGL(strict_xyz_caller_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, tx, ty, tz, pos_of, nt,
@@ -715,14 +711,13 @@ void strict_destroy(StrictBuffers *b) {
   delete b;
 }
 
-pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, const IcpState *state,
-                           double *sums10, hipStream_t st) {
+pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
+                           double *sums10, const IcpKernelParams &kp, bool fuse_update, hipStream_t st) {
   const StrictWork &W = b->w;
   const unsigned waves = (unsigned)(kStrictRows * W.ntiles);
-  hipLaunchKernelGGL(strict_terms_kernel, dim3((unsigned)W.ntiles), dim3(kTermsBlock), 0, st, match, pos_of, state, W);
-  hipLaunchKernelGGL(strict_err_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, state, W);
-  hipLaunchKernelGGL(strict_sum_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, state, W);
-  hipLaunchKernelGGL(strict_chain_kernel, dim3(kStrictRows), dim3(kChainBlock), 0, st, state, W, sums10);
+  hipLaunchKernelGGL(strict_terms_kernel, dim3((unsigned)W.ntiles), dim3(kTermsBlock), 0, st, match, pos_of, (const IcpState *)state, W);
+  hipLaunchKernelGGL(strict_sum_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, (const IcpState *)state, W);
+  hipLaunchKernelGGL(strict_chain_kernel, dim3(kStrictRows), dim3(kChainBlock), 0, st, state, W, sums10, kp, fuse_update ? 1 : 0);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }

@@ -27,10 +27,13 @@
 // construction; how often the slow path runs only affects speed.
 //
 // The representatives come from a GUESS of the state at every leaf: the float64 prefix sum of the
-// terms (strict_terms_kernel) plus the float64 prefix of the ROUNDING ERRORS the chain makes when
-// started from that first guess (strict_err_kernel: error of a leaf = (end - start) - sum of its
-// terms; translation invariance makes that error exact whenever the guess is in the right class
-// interval).  With both, a guess is typically within a few ulps of the true state.
+// terms (tile sums from strict_terms_kernel, leaf sums inside the tile), refined once inside the tile
+// by the prefix of the ROUNDING ERRORS the chains make when started from those first guesses (error
+// of a leaf = (end - start) - sum of its terms; translation invariance makes it the true error
+// whenever the guess is in the right class interval).  A guess is typically within tens of ulps of
+// the true state -- close enough everywhere except next to a level crossing, which is what the
+// exact recomputation is for.  (A whole-row error prefix was tried as a kernel of its own: it cost
+// 18 us per iteration at 1M pairs and removed only a third of the recomputations.)
 #pragma once
 #include <stdint.h>
 #include <string.h>
@@ -317,14 +320,14 @@ SS_HD Summary leaf_summary_binade(const float *t, uint32_t guess, int32_t key) {
 // tests.  terms[n] -> the sequential float32 sum of 0.0f + t0 + t1 + ... ; stats: [0] tiles,
 // [1] tiles without a record, [2] runs applied, [3] runs that failed, [4] tiles resolved exactly,
 // [5] leaves added serially, [6] leaves in the general (crossing) form, [7] tile records that failed.
-// mode bit 0: never use the in-binade fast form; bit 1: no error-prefix refinement of the guesses.
+// mode bit 0: never use the in-binade fast form; bit 1: no refinement of the guesses inside a tile.
 inline float ss_host_model(const float *terms_in, int64_t n, int64_t stats[8], int mode) {
   for (int k = 0; k < 8; k++) stats[k] = 0;
   const int64_t ntiles = n > 0 ? (n + kTile - 1) / kTile : 1;
   const int64_t npad = ntiles * kTile;
   float *terms = new float[(size_t)npad];
   for (int64_t i = 0; i < npad; i++) terms[i] = i < n ? terms_in[i] : -0.0f;
-  double *tile_sum = new double[(size_t)ntiles], *tile_err = new double[(size_t)ntiles];
+  double *tile_sum = new double[(size_t)ntiles];
   TileRec *recs = new TileRec[(size_t)ntiles];
   stats[0] = ntiles;
   // strict_terms_kernel: float64 sums per tile
@@ -333,45 +336,66 @@ inline float ss_host_model(const float *terms_in, int64_t n, int64_t stats[8], i
     for (int i = 0; i < kTile; i++) v += (double)terms[k * kTile + i];
     tile_sum[k] = v;
   }
-  // strict_err_kernel: rounding error of every tile's chains when started from the float64 prefix
+  // leaf guesses of a tile whose first state is about `base` (tile_guesses of strict.hip)
+  auto tile_guesses = [&](const float *tt, double base, uint32_t *guess, ChainRange *cr) {
+    double lsum[kLanes], pre[kLanes], err[kLanes];
+    double p = 0.0;
+    for (int l = 0; l < kLanes; l++) {
+      double v = 0.0;
+      for (int j = 0; j < kLeaf; j++) v += (double)tt[l * kLeaf + j];
+      lsum[l] = v;
+      pre[l] = p;
+      p += v;
+    }
+    bool changed = false;
+    for (int l = 0; l < kLanes; l++) {
+      guess[l] = f2u((float)(base + pre[l]));
+      cr[l] = guess_chain(tt + l * kLeaf, guess[l]);
+      err[l] = ((double)u2f(cr[l].end) - (double)u2f(guess[l])) - lsum[l];
+    }
+    if (mode & 2) return;
+    double e = 0.0;
+    uint32_t g2[kLanes];
+    for (int l = 0; l < kLanes; l++) {
+      g2[l] = f2u((float)(base + pre[l] + e));
+      changed = changed || g2[l] != guess[l];
+      e += err[l];
+    }
+    if (changed)
+      for (int l = 0; l < kLanes; l++) {
+        guess[l] = g2[l];
+        cr[l] = guess_chain(tt + l * kLeaf, guess[l]);
+      }
+  };
+  // strict_sum_kernel: one record per tile
   {
     double P0 = 0.0;
     for (int64_t k = 0; k < ntiles; k++) {
-      double pre = 0.0, err = 0.0;
-      for (int l = 0; l < kLanes; l++) {
-        const float *t = terms + k * kTile + l * kLeaf;
-        double lsum = 0.0;
-        for (int j = 0; j < kLeaf; j++) lsum += (double)t[j];
-        const float g = (float)(P0 + pre);
-        float s = g;
-        for (int j = 0; j < kLeaf; j++) s = s + t[j];
-        err += ((double)s - (double)g) - lsum;
-        pre += lsum;
+      const float *tt = terms + k * kTile;
+      TileRec T;
+      memset(&T, 0, sizeof T);
+      if (k == 0) {  // the first tile starts from 0.0f: its additions are simply carried out -> point record
+        float x = 0.0f;
+        for (int i = 0; i < kTile; i++) x = x + tt[i];
+        T.key = -1;
+        T.in = f2u(0.0f);
+        T.out = f2u(x);
+        T.cons = 1;
+        stats[1]++;
+        recs[k] = T;
+        P0 += tile_sum[k];
+        continue;
       }
-      tile_err[k] = (mode & 2) ? 0.0 : err;
-      P0 += tile_sum[k];
-    }
-  }
-  // strict_sum_kernel: one record per tile
-  {
-    double P0 = 0.0, E0 = 0.0;
-    for (int64_t k = 0; k < ntiles; k++) {
       uint32_t guess[kLanes];
       ChainRange cr[kLanes];
-      double pre = 0.0;
+      tile_guesses(tt, P0, guess, cr);
       uint32_t mn = 0xffffffffu, mx = 0u, sg_or = 0u, sg_and = 1u;
       for (int l = 0; l < kLanes; l++) {
-        const float *t = terms + k * kTile + l * kLeaf;
-        guess[l] = f2u((float)(P0 + E0 + pre));
-        cr[l] = guess_chain(t, guess[l]);
         mn = umin(mn, cr[l].mn);
         mx = umax(mx, cr[l].mx);
         sg_or |= cr[l].sg_or;
         sg_and &= cr[l].sg_and;
-        for (int j = 0; j < kLeaf; j++) pre += (double)t[j];
       }
-      TileRec T;
-      memset(&T, 0, sizeof T);
       T.key = sg_or == sg_and ? choose_window(mn, mx, sg_or, guess[0] & 0x7fffffffu) : -1;
       T.in = guess[0];
       T.out = cr[kLanes - 1].end;
@@ -380,7 +404,7 @@ inline float ss_host_model(const float *terms_in, int64_t n, int64_t stats[8], i
       if (T.key >= 0) {
         Summary acc = summary_identity();
         for (int l = 0; l < kLanes; l++) {
-          const float *t = terms + k * kTile + l * kLeaf;
+          const float *t = tt + l * kLeaf;
           const bool one_binade = (cr[l].mn >> 23) == (cr[l].mx >> 23);
           Summary S;
           if (one_binade && !(mode & 1)) {
@@ -397,56 +421,38 @@ inline float ss_host_model(const float *terms_in, int64_t n, int64_t stats[8], i
       }
       recs[k] = T;
       P0 += tile_sum[k];
-      E0 += tile_err[k];
     }
   }
   // strict_chain_kernel: runs of equal windows, applied in order; exact recomputation on failure
   uint32_t s = f2u(0.0f);
-  auto resolve_tile = [&](int64_t k) {  // = resolve_generic of strict.hip
+  auto resolve_tile = [&](int64_t k) {  // resolve_tile of strict.hip
     const float *tt = terms + k * kTile;
-    double lsum[kLanes], pre[kLanes], err[kLanes];
-    uint32_t g[kLanes];
-    {
-      double p = 0.0;
+    stats[4]++;
+    const int32_t key = recs[k].key;
+    if (key >= 0) {
+      // what the summary kernel keeps for a tile with a level crossing: the leaves' summaries (there as
+      // compositions 0..l and l..63); a leaf whose summary does not cover the state is added term by term
+      uint32_t guess[kLanes];
+      ChainRange cr[kLanes];
+      double P0 = 0.0;
+      for (int64_t q = 0; q < k; q++) P0 += tile_sum[q];
+      tile_guesses(tt, P0, guess, cr);
       for (int l = 0; l < kLanes; l++) {
-        double v = 0.0;
-        for (int j = 0; j < kLeaf; j++) v += (double)tt[l * kLeaf + j];
-        lsum[l] = v;
-        pre[l] = p;
-        p += v;
-      }
-    }
-    const double s0 = (double)u2f(s);
-    for (int l = 0; l < kLanes; l++) {  // first guesses, and the rounding error each leaf makes from there
-      g[l] = l == 0 ? s : f2u((float)(s0 + pre[l]));
-      const ChainRange c = guess_chain(tt + l * kLeaf, g[l]);
-      err[l] = ((double)u2f(c.end) - (double)u2f(g[l])) - lsum[l];
-    }
-    {
-      double e = 0.0;
-      for (int l = 0; l < kLanes; l++) {
-        if (l > 0) g[l] = f2u((float)(s0 + pre[l] + e));
-        e += err[l];
-      }
-    }
-    for (int l = 0; l < kLanes; l++) {  // every leaf: a summary in a window of its own, else the adds themselves
-      const float *t = tt + l * kLeaf;
-      const ChainRange c = guess_chain(t, g[l]);
-      const int32_t key = c.sg_or == c.sg_and ? choose_window(c.mn, c.mx, c.sg_or, g[l] & 0x7fffffffu) : -1;
-      bool done = false;
-      if (key >= 0) {
-        const Summary S = (c.mn >> 23) == (c.mx >> 23) && !(mode & 1) ? leaf_summary_binade(t, g[l], key)
-                                                                     : leaf_summary_general(t, g[l], key);
-        done = apply(s, key, S);
-      }
-      if (!done) {
+        const float *t = tt + l * kLeaf;
+        const Summary S = (cr[l].mn >> 23) == (cr[l].mx >> 23) && !(mode & 1) ? leaf_summary_binade(t, guess[l], key)
+                                                                             : leaf_summary_general(t, guess[l], key);
+        if (apply(s, key, S)) continue;
         float x = u2f(s);
         for (int j = 0; j < kLeaf; j++) x = x + t[j];
         s = f2u(x);
         stats[5]++;
       }
+      return;
     }
-    stats[4]++;
+    float x = u2f(s);
+    for (int i = 0; i < kTile; i++) x = x + tt[i];
+    s = f2u(x);
+    stats[5] += kLanes;
   };
   int64_t k = 0;
   while (k < ntiles) {
@@ -479,7 +485,6 @@ inline float ss_host_model(const float *terms_in, int64_t n, int64_t stats[8], i
   }
   delete[] terms;
   delete[] tile_sum;
-  delete[] tile_err;
   delete[] recs;
   return u2f(s);
 }

@@ -260,9 +260,10 @@ def test_c4_full_size_vs_oracle():
 
 @pytest.mark.parametrize("n,max_dist", [(5000, 0.5), (20003, 0.03), (200000, 0.5)])
 def test_strict_mode_is_bit_identical_to_the_reference_sums(n, max_dist):
-    """STRICT sums (one wave, sequential float32 in target order, evaluator.go:122-145): Evaluated
-    and every pose of the Fit loop equal the oracle's Go-semantics run bit for bit -- also when
-    many targets find no partner (max_dist 0.03) and the count is no multiple of 64."""
+    """STRICT sums (sequential float32 in target order, evaluator.go:122-145, evaluated in parallel:
+    csrc/strict_sum.h): Evaluated and every pose of the Fit loop equal the oracle's Go-semantics
+    run bit for bit -- also when many targets find no partner (max_dist 0.03) and the count is no
+    multiple of the tile size."""
     c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
     c["max_dist"] = max_dist
     if max_dist < 0.1:  # targets that never find a partner, scattered through the target order
@@ -303,3 +304,55 @@ def test_strict_mode_c4_full_size():
     assert conv and st.NumIteration == o32["num_iteration"] == 20
     assert np.array_equal(tr, o32["trans"])
     assert st.Evaluated.Value == o32["value"] and np.array_equal(st.Evaluated.Gradient, o32["gradient"])
+
+
+@pytest.mark.parametrize("n,max_dist", [(3, 0.5), (2048, 0.5), (70001, 0.5), (300000, 0.04)])
+def test_strict_parallel_equals_the_one_wave_chain(n, max_dist, monkeypatch):
+    """The parallel evaluation of the sequential float32 sums (set_strict 1: class summaries,
+    composition, exact recomputation where a record does not cover the state) against the plain
+    dependent chain on the device (set_strict 2), sum by sum, over a whole Fit.  With
+    PCGX_STRICT_SELFCHECK every step of the chain walk is re-derived term by term inside the
+    kernel: none may differ."""
+    monkeypatch.setenv("PCGX_STRICT_SELFCHECK", "1")
+    c = synth.c4_icp(n=max(n, 64), width=10.0 * (max(n, 64) / 1e6) ** (1 / 3))
+    target = c["target"][:n] if n < 64 else c["target"]
+    if max_dist < 0.1:
+        far = target[::11] + f32(50.0)
+        target = np.ascontiguousarray(np.insert(target, np.arange(0, len(far)) * 9, far, axis=0))
+    t = kdtree.New(c["base"])
+    a = icp.IcpSession(t, target, max_dist, 1, c["weight"], c["threshold"], c["max_iteration"])
+    b = icp.IcpSession(t, target, max_dist, 1, c["weight"], c["threshold"], c["max_iteration"])
+    a.set_strict(1)
+    b.set_strict(2)
+    for k in range(c["max_iteration"]):
+        a.step()
+        b.step()
+        sa, sb = a.read_sums(), b.read_sums()
+        assert np.array_equal(sa.view(np.uint64), sb.view(np.uint64)), (k, sa, sb)
+        st = a.strict_stats()
+        assert not st[12:16].any() and st[6] == 0 and st[7] == 0, (k, st[:16])
+    ta, sta, _ = a.result()
+    tb, stb, _ = b.result()
+    assert np.array_equal(ta, tb) and sta.Evaluated.NumPairs == stb.Evaluated.NumPairs
+    a.close()
+    b.close()
+
+
+def test_strict_sums_on_structured_terms():
+    """Targets on a lattice that coincide with base points: every term is exact (zeros, ones), sums
+    land exactly on binade boundaries -- the point records' case -- and a second cloud shifted by
+    a power of two makes every addition of the translation gradient a tie."""
+    g = np.arange(0, 40, dtype=np.float32) * f32(0.25)
+    base = np.ascontiguousarray(np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3))
+    t = kdtree.New(base)
+    o = O.KDTree(base)
+    for shift in (0.0, 0.0625):
+        target = np.ascontiguousarray(base[::-1] + f32(shift))
+        s = icp.IcpSession(t, target, 0.5, 6, np.full(6, 0.3, np.float32), np.full(6, -1.0, np.float32), 5)
+        s.set_strict(1)
+        s.step()
+        _, st, _ = s.result()
+        oe = O.icp_evaluate(o, target, 0.5, 6, sums_mode=0)
+        assert st.Evaluated.Value == oe["value"] and st.Evaluated.DistRMS == oe["dist_rms"]
+        assert np.array_equal(st.Evaluated.Gradient, oe["gradient"])
+        s.close()
