@@ -102,3 +102,74 @@ def c4_plane(n=1_000_000, width=None, base_seed=6, perm_seed=7):
     target = transform_points(icp_pose(), base[perm])
     return dict(base=base, normals=normals, target=target, max_dist=0.5, min_pairs=6,
                 threshold=np.full(6, -1.0, np.float32), max_iteration=20, damping=0.0)
+
+
+def spatial_cell(points, world, lo, hi):
+    """Which of `world` spatial tiles of the box [lo, hi) each point falls in -- decided point by
+    point, nothing sorted, so a rank finds its own tile without looking at anybody else's.  The box is
+    cut along x, then y, then z, then x again ... by successive halving while the factor 2 divides
+    `world` (8 tiles = the octants), and into equal slabs along the next axis for what is left (an
+    odd factor).  Uniform clouds give equally filled tiles up to sampling noise."""
+    points = np.asarray(points, np.float32).reshape(-1, 3)
+    cell = np.zeros(len(points), np.int64)
+    stride = 1
+    rest = int(world)
+    axis = 0
+    u = (points.astype(np.float64) - np.asarray(lo, np.float64)) / (np.asarray(hi, np.float64) - np.asarray(lo, np.float64))
+    while rest > 1:
+        k = 2 if rest % 2 == 0 else rest
+        c = np.clip((u[:, axis % 3] * k).astype(np.int64), 0, k - 1)
+        if axis >= 3:   # this axis was cut before: cut each of its parts again
+            prev = 2 ** (axis // 3)
+            c = np.clip((u[:, axis % 3] * prev * k).astype(np.int64), 0, prev * k - 1) % k
+        cell += stride * c
+        stride *= k
+        rest //= k
+        axis += 1
+    return cell
+
+
+def icp_tile(base, rank, world, n_per_gpu, width, perm_seed=5, order_seed=17):
+    """Rank's spatial tile of the global target of a `world`-GPU ICP job: the global target is
+    `world` blocks T * base[perm_b][:n_per_gpu] (perm seed perm_seed + b; block 0 alone is config C4),
+    i.e. world * n_per_gpu points in the base's box; the rank keeps the points of ITS cell
+    (spatial_cell) in a seeded random order.  world == 1: exactly c4_icp's target."""
+    pose = icp_pose()
+    if world == 1:
+        perm = np.random.Generator(np.random.PCG64(perm_seed)).permutation(len(base))[:n_per_gpu]
+        return transform_points(pose, base[perm])
+    parts = []
+    for b in range(world):
+        perm = np.random.Generator(np.random.PCG64(perm_seed + b)).permutation(len(base))[:n_per_gpu]
+        t = transform_points(pose, base[perm])
+        parts.append(t[spatial_cell(t, world, (0, 0, 0), (width,) * 3) == rank])
+    t = np.concatenate(parts)
+    order = np.random.Generator(np.random.PCG64(order_seed + rank)).permutation(len(t))
+    return np.ascontiguousarray(t[order])
+
+
+def c5_tile(base, rank, world=8, width=40.0, order_seed=23, chunk=8_000_000):
+    """Config C5 (ICP on a 64M-point cloud tiled over 8 GPUs), the share of one rank: the global
+    target is T * base (every base point once); the rank keeps the points of its spatial cell
+    (world = 8: an octant of the cube), in a seeded random order -- a pass over the base in chunks,
+    no global permutation or sort.  ~len(base) / world points."""
+    pose = icp_pose()
+    parts = []
+    for s in range(0, len(base), chunk):
+        t = transform_points(pose, base[s:s + chunk])
+        parts.append(t[spatial_cell(t, world, (0, 0, 0), (width,) * 3) == rank])
+    t = np.concatenate(parts)
+    order = np.random.Generator(np.random.PCG64(order_seed + rank)).permutation(len(t))
+    return np.ascontiguousarray(t[order])
+
+
+def uniform_cloud_chunked(n, width, seed, chunk=8_000_000):
+    """uniform_cloud for sizes where its int64 temporaries would be large (same distribution; the
+    stream differs from uniform_cloud's because numbers are drawn chunk by chunk)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = np.empty((n, 3), np.float32)
+    for s in range(0, n, chunk):
+        m = min(chunk, n - s)
+        k = rng.integers(0, 1 << 24, size=(m, 3), dtype=np.int32)
+        out[s:s + m] = (k.astype(np.float32) / np.float32(1 << 24)) * np.float32(width)
+    return out

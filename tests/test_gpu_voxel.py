@@ -158,6 +158,23 @@ def test_c3_scale_properties():
     assert np.array_equal(got.Data, exp)
 
 
+@pytest.mark.parametrize("chunk", [None, (64, 64, 64)])
+def test_c3_full_size_against_the_oracle(chunk):
+    """BASELINE config C3 (10M points, leaf 0.02, cube 3 m) at FULL size, byte for byte against the
+    oracle's dense-array restatement (voxelgrid.go:35-187; its 151^3 x 32 B array is 110 MB), in the
+    plain mode and with WithChunkSize{64,64,64}."""
+    c = synth.c3_voxel()
+    pts = c["points"]
+    if chunk is None:
+        exp = O.voxel_filter(pts, len(pts), 12, 0, c["leaf"])
+        got = voxelgrid.New(c["leaf"]).Filter(pts)
+    else:
+        exp = O.voxel_filter(pts, len(pts), 12, 0, c["leaf"], chunk)
+        got = voxelgrid.New(c["leaf"], voxelgrid.WithChunkSize(chunk)).Filter(pts)
+    assert got.Data.shape == exp.shape and 3_000_000 < len(exp) // 12 < 3_400_000
+    assert np.array_equal(got.Data, exp)
+
+
 def test_chunked_two_sort_path_still_matches(monkeypatch):
     """Chunked mode normally sorts ONE combined (chunk id, cell) key; grids whose two indices do not
     fit 32 bits fall back to two stable sorts.  Force that path and compare both with the oracle."""
