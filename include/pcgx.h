@@ -53,7 +53,8 @@ enum {
   PCGX_E_SYNTAX = 11,          /* PCD: strconv.ErrSyntax / ErrRange from a header or ascii token (pc/io.go) */
   PCGX_E_EOF = 12,             /* PCD: io.EOF / io.ErrUnexpectedEOF */
   PCGX_E_CORRUPT = 13,         /* PCD: lzf.ErrDataCorruption / lzf.ErrInsufficientBuffer */
-  PCGX_E_BAD_HEADER = 14       /* PCD: the errors.New cases of pc/io.go:55,119,125-133,202 */
+  PCGX_E_BAD_HEADER = 14,      /* PCD: the errors.New cases of pc/io.go:55,119,125-133,202 */
+  PCGX_E_RCCL = 15             /* the exchange of the sharded ICP path failed (RCCL missing / error, callback error) */
 };
 
 /* ------------------------------------------------------------ lifecycle */
@@ -328,6 +329,33 @@ PCGX_API pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stream
 PCGX_API pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream);
 /* partials + update back to back, for a single GPU (no exchange in between): fewer launches. */
 PCGX_API pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream);
+
+/* ---- the exchange of the sharded path -------------------------------------------
+ * One process per GPU; every rank holds a replica of the base tree and one spatial tile of the
+ * target.  A communicator is made from an id that rank 0 generates (pcgx_comm_unique_id) and the
+ * host hands to every rank over any channel it has (a file, a socket, MPI, torch's store);
+ * pcgx_comm_init is collective.  RCCL (xGMI inside a node) is bound at run time: a process that
+ * never shards needs none.  pcgx_comm_init_callback is the same exchange through a host function
+ * that sums `count` float64 in place over the ranks (the sums then make a round trip through host
+ * memory): for hosts with a transport of their own, and for tests that run several ranks on one GPU.
+ * pcgx_icp_session_step_sharded = partials -> all-reduce (sum) of the session's 10 (plane: 30)
+ * float64 sums -> update on every rank; pcgx_icp_fit_sharded is the whole Fit (icp.go:23-67) on this
+ * rank's tile: every rank returns the same transform.  Strict sums are not offered here: a sum
+ * spread over ranks has no sequential order to reproduce. */
+typedef struct pcgx_comm pcgx_comm;
+typedef struct { char internal[128]; } pcgx_comm_id;   /* == ncclUniqueId */
+typedef int32_t (*pcgx_allreduce_fn)(double *host_buf, int32_t count, void *user);
+PCGX_API pcgx_status pcgx_comm_unique_id(pcgx_comm_id *id);
+PCGX_API pcgx_status pcgx_comm_init(int32_t rank, int32_t world, const pcgx_comm_id *id, pcgx_comm **out);
+PCGX_API pcgx_status pcgx_comm_init_callback(int32_t rank, int32_t world, pcgx_allreduce_fn fn, void *user,
+                                             pcgx_comm **out);
+PCGX_API pcgx_status pcgx_comm_free(pcgx_comm *c);
+PCGX_API pcgx_status pcgx_comm_rank(const pcgx_comm *c, int32_t *rank, int32_t *world);
+PCGX_API pcgx_status pcgx_comm_allreduce_f64(pcgx_comm *c, double *d_buf, int32_t count, void *stream);
+PCGX_API pcgx_status pcgx_icp_session_step_sharded(pcgx_icp_session *s, pcgx_comm *c, void *stream);
+PCGX_API pcgx_status pcgx_icp_fit_sharded(const pcgx_kdtree *base, const float *tile, int64_t nt,
+                                          const pcgx_icp_params *params, pcgx_comm *c, float trans16[16],
+                                          pcgx_icp_stat *stat);
 /* STRICT sums.  By default the evaluator's sums are float64 reductions of the reference's float32
  * terms: more accurate than the reference, equal to it only up to ITS rounding noise (sequential
  * float32 additions, evaluator.go:122-145; ~1.6e-5 on the final transform at 1M pairs).  With

@@ -166,6 +166,14 @@ SIGNATURES = {
     "pcgx_icp_session_update": (_i32, [_vp, _vp]),
     "pcgx_icp_session_step": (_i32, [_vp, _vp]),
     "pcgx_icp_session_set_strict": (_i32, [_vp, _i32]),
+    "pcgx_comm_unique_id": (_i32, [_vp]),
+    "pcgx_comm_init": (_i32, [_i32, _i32, _vp, C.POINTER(_vp)]),
+    "pcgx_comm_init_callback": (_i32, [_i32, _i32, _vp, _vp, C.POINTER(_vp)]),
+    "pcgx_comm_free": (_i32, [_vp]),
+    "pcgx_comm_rank": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "pcgx_comm_allreduce_f64": (_i32, [_vp, _vp, _i32, _vp]),
+    "pcgx_icp_session_step_sharded": (_i32, [_vp, _vp, _vp]),
+    "pcgx_icp_fit_sharded": (_i32, [_vp, _vp, _i64, C.POINTER(IcpParams), _vp, _vp, C.POINTER(IcpStat)]),
     "pcgx_debug_icp_strict_stats": (_i32, [_vp, _vp, _vp]),
     "pcgx_debug_strict_sum_host": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "pcgx_icp_session_result": (_i32, [_vp, _vp, _vp, C.POINTER(IcpStat), C.POINTER(_i32)]),

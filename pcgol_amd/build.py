@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libpcgx.so")
-SOURCES = ["core.hip", "knn.hip", "knn_explicit.hip", "knn_grid.hip", "sort.hip", "icp.hip", "strict.hip", "voxel.hip", "range.hip", "segment.hip", "pcd.hip", "kdtree_build_gpu.hip", "kdtree_build.cpp"]
+SOURCES = ["core.hip", "knn.hip", "knn_explicit.hip", "knn_grid.hip", "sort.hip", "icp.hip", "strict.hip", "comm.hip", "voxel.hip", "range.hip", "segment.hip", "pcd.hip", "kdtree_build_gpu.hip", "kdtree_build.cpp"]
 HEADERS = ["pcgx_internal.h", "pcgx_math.h", "knn_walk.h", "knn_xwalk.h", "knn_grid.h", "range_walk.h", "strict_sum.h", os.path.join("..", "..", "include", "pcgx.h")]
 ARCH = "gfx950"
 
@@ -62,8 +62,8 @@ def build(force=False, verbose=False):
             print(out)
     if failed:
         raise RuntimeError("hipcc failed")
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] + objs + ["-lpthread"]
-    subprocess.check_call(cmd)
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] + objs + ["-lpthread", "-ldl"]
+    subprocess.check_call(cmd)  # (-ldl is part of libc on this image; RCCL is bound at run time, csrc/comm.hip)
     return SO
 
 

@@ -1026,6 +1026,35 @@ extern "C" pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream) 
   return PCGX_OK;
 }
 
+extern "C" pcgx_status pcgx_icp_session_step_sharded(pcgx_icp_session *s, pcgx_comm *c, void *stream) {
+  PCGX_API_LOCK();
+  if (!s || !c) return fail(PCGX_E_INVALID, "pcgx_icp_session_step_sharded: NULL argument");
+  int32_t rank = 0, world = 1;
+  PCGX_TRY(pcgx_comm_rank(c, &rank, &world));
+  if (world == 1) return pcgx_icp_session_step(s, stream);
+  if (s->strict) return fail(PCGX_E_INVALID, "strict sums are not offered on a sharded target (no sequential order)");
+  PCGX_TRY(pcgx_icp_session_partials(s, stream));
+  PCGX_TRY(pcgx_comm_allreduce_f64(c, s->d_sums, s->n_sums(), stream));
+  return pcgx_icp_session_update(s, stream);
+}
+
+extern "C" pcgx_status pcgx_icp_fit_sharded(const pcgx_kdtree *base, const float *tile, int64_t nt,
+                                            const pcgx_icp_params *params, pcgx_comm *c, float trans16[16],
+                                            pcgx_icp_stat *stat) {
+  PCGX_API_LOCK();
+  if (!base || !params || !trans16 || !c) return fail(PCGX_E_INVALID, "pcgx_icp_fit_sharded: NULL argument");
+  pcgx_icp_session *s = nullptr;
+  PCGX_TRY(pcgx_icp_session_create(base, tile, nt, 0, params, nullptr, &s));
+  s->strict = 0;
+  pcgx_status rc = PCGX_OK;
+  // every rank enqueues MaxIteration steps: the loop state is the same on all of them (same sums),
+  // so they stop together, and a step after `done` is a no-op on the device
+  for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) rc = pcgx_icp_session_step_sharded(s, c, nullptr);
+  if (rc == PCGX_OK) rc = pcgx_icp_session_result(s, nullptr, trans16, stat, nullptr);
+  pcgx_icp_session_free(s);
+  return rc;
+}
+
 extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream, float trans16[16],
                                                pcgx_icp_stat *stat, int32_t *converged) {
   PCGX_API_LOCK();

@@ -89,18 +89,89 @@ def fit_sharded(partials_fn, MinPairs=0, UpdaterFactory=None, group=None):
             return trans, stat
 
 
+class Comm:
+    """The exchange of the sharded path behind the C ABI (include/pcgx.h, csrc/comm.hip).
+
+    Comm.rccl(rank, world, store): RCCL communicator; the ncclUniqueId travels from rank 0 to the
+    others through `store` (anything with set(key, bytes) / get(key) -> bytes, e.g.
+    torch.distributed.TCPStore).  Comm.callback(rank, world, fn): the exchange through a host
+    function fn(numpy float64 array) that sums the array over the ranks in place (e.g. gloo)."""
+
+    def __init__(self, handle, keep=None):
+        self._h = handle
+        self._keep = keep
+
+    @classmethod
+    def rccl(cls, rank, world, store, key="pcgx_comm_id"):
+        import ctypes as C
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            L.check(L.lib().pcgx_comm_unique_id(buf))
+            store.set(key, buf.raw)
+        else:
+            raw = bytes(store.get(key))
+            assert len(raw) == 128
+            buf = C.create_string_buffer(raw, 128)
+        h = C.c_void_p()
+        L.check(L.lib().pcgx_comm_init(rank, world, buf, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def callback(cls, rank, world, fn):
+        import ctypes as C
+        proto = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_void_p)
+
+        def tramp(ptr, count, _user):
+            try:
+                fn(np.ctypeslib.as_array(ptr, shape=(count,)))
+                return 0
+            except Exception:   # the C side turns this into PCGX_E_RCCL
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = proto(tramp)
+        h = C.c_void_p()
+        L.check(L.lib().pcgx_comm_init_callback(rank, world, C.cast(cb, C.c_void_p), None, C.byref(h)))
+        return cls(h, keep=cb)
+
+    @classmethod
+    def gloo(cls, group=None):
+        """Callback communicator over an initialised torch.distributed group (CPU tensors: gloo)."""
+        import torch
+        import torch.distributed as dist
+
+        def fn(a):
+            t = torch.from_numpy(a)
+            dist.all_reduce(t, group=group)
+        return cls.callback(dist.get_rank(group), dist.get_world_size(group), fn)
+
+    def close(self):
+        if self._h:
+            L.check(L.lib().pcgx_comm_free(self._h))
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ShardedIcp:
     """Device-resident sharded Fit: every rank holds the whole base tree and one tile of the
     target; per iteration the partial sums are all-reduced in place on the device (RCCL) and the
     pose update runs on every GPU redundantly, so no rank ever waits for the host."""
 
     def __init__(self, base_tree, target_tile, MaxDist, MinPairs=0, Weight=None, Threshold=None,
-                 MaxIteration=0, group=None, force_exchange=False, BaseNormals=None, Damping=0.0):
+                 MaxIteration=0, group=None, force_exchange=False, BaseNormals=None, Damping=0.0, comm=None):
         """BaseNormals: point-to-plane / Gauss-Newton extension; the exchange is then the all-reduce
-        of 30 doubles (sum r^2, J^T r, upper triangle of J^T J, sum w, pairs) instead of 10."""
+        of 30 doubles (sum r^2, J^T r, upper triangle of J^T J, sum w, pairs) instead of 10.
+        comm: a Comm -- the exchange then runs inside libpcgx.so (pcgx_icp_session_step_sharded: what
+        a Go host calls); without it the all-reduce is torch.distributed's on the sums tensor."""
         import torch
         self.torch = torch
         self.group = group
+        self.comm = comm
         # A stream of our own: the kernels are launched on it through the C ABI and the
         # all-reduce is issued while it is torch's current stream, so RCCL orders itself after
         # the partial sums and the update kernel after RCCL.  (torch's default stream has
@@ -119,6 +190,9 @@ class ShardedIcp:
     def step(self):
         """One ICP iteration, enqueued on self.stream."""
         st = self.stream.cuda_stream
+        if self.comm is not None:
+            L.check(L.lib().pcgx_icp_session_step_sharded(self.sess._h, self.comm._h, L.ptr(st)))
+            return
         if not self.exchange:
             self.sess.step(st)  # reduce + update fused: no exchange needed
             return

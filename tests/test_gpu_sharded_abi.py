@@ -1,0 +1,118 @@
+"""The sharded ICP path through the C ABI's own exchange (pcgx_comm_*, pcgx_icp_session_step_sharded,
+pcgx_icp_fit_sharded): what a Go host drives.
+
+* two PROCESSES on the one GPU of the test box, each with a replica of the base tree and its spatial
+  tile of the target, exchanging through the callback communicator (gloo underneath: RCCL refuses two
+  ranks on one device) -- the result must equal the single-GPU Fit on the whole target up to the
+  summation order of the float64 partial sums;
+* the RCCL communicator with one rank (id generation, ncclCommInitRank, destroy; a 1-rank all-reduce
+  is the identity)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case():
+    from pcgol_amd import synth
+    return synth.c4_icp(n=120_000, width=10.0 * 0.12 ** (1 / 3))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        from pcgol_amd import _lib as L
+        from pcgol_amd import icp, kdtree, synth
+        from pcgol_amd.distributed import Comm, ShardedIcp
+        c = _case()
+        width = 10.0 * 0.12 ** (1 / 3)
+        cell = synth.spatial_cell(c["target"], world, (0, 0, 0), (width,) * 3)
+        tile = np.ascontiguousarray(c["target"][cell == rank])
+        tree = kdtree.New(c["base"])
+        comm = Comm.gloo()
+        # (1) the whole Fit in one call
+        params = icp._params(c["max_dist"], 0.0, c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+        trans = np.empty(16, np.float32)
+        st = L.IcpStat()
+        L.check(L.lib().pcgx_icp_fit_sharded(tree._h, L.ptr(tile), len(tile), C.byref(params), comm._h, L.ptr(trans),
+                                             C.byref(st)))
+        # (2) step by step through ShardedIcp(comm=...)
+        s = ShardedIcp(tree, tile, c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"], comm=comm)
+        t2, st2, _ = s.fit()
+        s.close()
+        comm.close()
+        q.put((rank, len(tile), trans, int(st.num_iteration), t2, int(st2.NumIteration)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_through_the_abi_exchange():
+    import torch.multiprocessing as mp
+    from pcgol_amd import icp, kdtree
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    c = _case()
+    assert sum(r[1] for r in res) == len(c["target"])
+    # every rank ends with the same transform, by both routes
+    for r in res[1:]:
+        assert np.array_equal(r[2], res[0][2]) and np.array_equal(r[4], res[0][4])
+    assert np.array_equal(res[0][2], res[0][4]) and res[0][3] == res[0][5] == 20
+    # and it is the single-GPU Fit on the whole target (float64 sums in another order: ~1e-7)
+    reg = icp.PointToPointICPGradient(
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=c["min_pairs"]),
+        icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=c["threshold"], MaxIteration=c["max_iteration"]))
+    trans1, stat1 = reg.Fit(kdtree.New(c["base"]), c["target"])
+    assert np.max(np.abs(trans1 - res[0][2])) <= 1e-6
+
+
+def test_rccl_communicator_one_rank():
+    import ctypes as C
+    from pcgol_amd import _lib as L
+    from pcgol_amd import icp, kdtree
+    from pcgol_amd.distributed import Comm, ShardedIcp
+
+    class Store(dict):
+        def set(self, k, v):
+            self[k] = v
+
+    comm = Comm.rccl(0, 1, Store())
+    c = _case()
+    tree = kdtree.New(c["base"])
+    s = ShardedIcp(tree, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"],
+                   comm=comm)
+    t1, st1, _ = s.fit()
+    s.close()
+    s0 = icp.IcpSession(tree, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+    for _ in range(c["max_iteration"]):
+        s0.step()
+    t0, st0, _ = s0.result()
+    s0.close()
+    comm.close()
+    assert np.array_equal(t0, t1) and st0.NumIteration == st1.NumIteration
