@@ -715,9 +715,18 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
                            double *sums10, const IcpKernelParams &kp, bool fuse_update, hipStream_t st) {
   const StrictWork &W = b->w;
   const unsigned waves = (unsigned)(kStrictRows * W.ntiles);
-  hipLaunchKernelGGL(strict_terms_kernel, dim3((unsigned)W.ntiles), dim3(kTermsBlock), 0, st, match, pos_of, (const IcpState *)state, W);
-  hipLaunchKernelGGL(strict_sum_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, (const IcpState *)state, W);
-  hipLaunchKernelGGL(strict_chain_kernel, dim3(kStrictRows), dim3(kChainBlock), 0, st, state, W, sums10, kp, fuse_update ? 1 : 0);
+  {
+    ProfScope prof(PCGX_PROF_STRICT_TERMS, st);
+    hipLaunchKernelGGL(strict_terms_kernel, dim3((unsigned)W.ntiles), dim3(kTermsBlock), 0, st, match, pos_of, (const IcpState *)state, W);
+  }
+  {
+    ProfScope prof(PCGX_PROF_STRICT_SUM, st);
+    hipLaunchKernelGGL(strict_sum_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, (const IcpState *)state, W);
+  }
+  {
+    ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
+    hipLaunchKernelGGL(strict_chain_kernel, dim3(kStrictRows), dim3(kChainBlock), 0, st, state, W, sums10, kp, fuse_update ? 1 : 0);
+  }
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }
