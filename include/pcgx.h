@@ -68,6 +68,16 @@ PCGX_API int32_t pcgx_last_error(char *buf, size_t cap);
 PCGX_API const char *pcgx_version(void);
 /* Block until all work enqueued on `stream` (NULL = library stream) is done. */
 PCGX_API pcgx_status pcgx_sync(void *stream);
+/* Threading.  Handles are immutable after build (DeletePoint excepted, as in the reference,
+ * kdtree.go:322-332).  The blocking host-pointer entry points -- pcgx_kdtree_build, _nearest_batch,
+ * _range_count / _range_fill, pcgx_voxel_filter, pcgx_minmax, pcgx_icp_fit / _evaluate / _pairs --
+ * may be called from any number of threads at once: each call works on a stream and workspace of
+ * its own (a pool of 4; a fifth caller waits) and they overlap on the GPU.  Entry points with a
+ * `stream` argument (the `_dev` calls, ICP sessions) and everything else run one caller at a time
+ * in the library's context, so that work given to the NULL stream stays ordered.
+ * Measurement aid: out = {largest number of pooled calls in flight at once, pooled calls} since the
+ * last reset. */
+PCGX_API pcgx_status pcgx_debug_call_stats(int64_t out[2], int32_t reset);
 
 /* Optional in-library kernel timing (HIP events on the launch stream around
  * the named kernel class).  Used by bench.py for the live roofline figure. */

@@ -3,6 +3,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <vector>
 
@@ -22,11 +23,6 @@ pcgx_status fail(pcgx_status code, const char *fmt, ...) {
   return code;
 }
 
-std::recursive_mutex &api_mutex() {
-  static std::recursive_mutex m;
-  return m;
-}
-
 namespace {
 struct CachedBlock {
   void *p;
@@ -41,10 +37,17 @@ std::vector<CachedBlock> &cache_live_list() {
   return v;
 }
 constexpr size_t kCacheLimitBytes = (size_t)2 << 30;
+std::mutex g_cache_mu;
+void cache_release_all_locked() {
+  for (auto &b : cache_free_list()) (void)hipFree(b.p);
+  cache_free_list().clear();
+}
 }  // namespace
 
-// callers hold the API lock
+void dev_cache_quiesce() { (void)hipDeviceSynchronize(); }
+
 hipError_t dev_cache_alloc(void **ptr, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_cache_mu);
   bytes = bytes ? bytes : 1;
   auto &fl = cache_free_list();
   size_t best = fl.size();
@@ -59,7 +62,7 @@ hipError_t dev_cache_alloc(void **ptr, size_t bytes) {
   const size_t cap = (bytes + 255) & ~(size_t)255;
   hipError_t e = hipMalloc(ptr, cap);
   if (e != hipSuccess) {  // make room and try once more
-    dev_cache_release_all();
+    cache_release_all_locked();
     e = hipMalloc(ptr, cap);
   }
   if (e == hipSuccess) cache_live_list().push_back(CachedBlock{*ptr, cap});
@@ -68,6 +71,7 @@ hipError_t dev_cache_alloc(void **ptr, size_t bytes) {
 
 void dev_cache_free(void *ptr) {
   if (!ptr) return;
+  std::lock_guard<std::mutex> lk(g_cache_mu);
   auto &ll = cache_live_list();
   for (size_t i = 0; i < ll.size(); i++)
     if (ll[i].p == ptr) {
@@ -83,20 +87,75 @@ void dev_cache_free(void *ptr) {
 }
 
 void dev_cache_release_all() {
-  for (auto &b : cache_free_list()) (void)hipFree(b.p);
-  cache_free_list().clear();
+  std::lock_guard<std::mutex> lk(g_cache_mu);
+  cache_release_all_locked();
 }
 
-Context &ctx() {
-  static Context c;
-  return c;
+// ---- call contexts -----------------------------------------------------------
+namespace {
+constexpr int kPoolSlots = 4;
+struct Global {
+  Context slots[1 + kPoolSlots];  // [0]: the library's context; [1..]: the pool
+  bool busy[1 + kPoolSlots] = {};
+  std::mutex mu;                 // busy[]
+  std::condition_variable cv;
+  std::recursive_mutex lib_mu;   // context 0, one caller at a time
+  std::mutex init_mu;
+  int in_pool = 0, peak_in_pool = 0;
+  long long pooled_calls = 0;
+};
+Global &glob() {
+  static Global g;
+  return g;
+}
+thread_local Context *tl_ctx = nullptr;
+thread_local int tl_depth = 0;
+}  // namespace
+
+Context &ctx() { return tl_ctx ? *tl_ctx : glob().slots[0]; }
+
+CallScope::CallScope(bool pooled) {
+  Global &g = glob();
+  if (tl_depth++ > 0) return;  // nested: the outer call's context
+  if (pooled) {
+    std::unique_lock<std::mutex> lk(g.mu);
+    for (;;) {
+      for (int k = 1; k <= kPoolSlots && slot_ < 0; k++)
+        if (!g.busy[k]) slot_ = k;
+      if (slot_ >= 0) break;
+      g.cv.wait(lk);
+    }
+    g.busy[slot_] = true;
+    g.pooled_calls++;
+    if (++g.in_pool > g.peak_in_pool) g.peak_in_pool = g.in_pool;
+  } else {
+    g.lib_mu.lock();
+    slot_ = 0;
+  }
+  tl_ctx = &g.slots[slot_];
+  if (g.slots[0].ready) (void)hipSetDevice(g.slots[0].device);
 }
 
-static std::mutex g_init_mu;
+CallScope::~CallScope() {
+  if (--tl_depth > 0) return;
+  Global &g = glob();
+  tl_ctx = nullptr;
+  if (slot_ == 0) {
+    g.lib_mu.unlock();
+  } else if (slot_ > 0) {
+    {
+      std::lock_guard<std::mutex> lk(g.mu);
+      g.busy[slot_] = false;
+      g.in_pool--;
+    }
+    g.cv.notify_one();
+  }
+}
 
 static pcgx_status init_device(int device) {
-  std::lock_guard<std::mutex> lk(g_init_mu);
-  Context &c = ctx();
+  Global &g = glob();
+  std::lock_guard<std::mutex> lk(g.init_mu);
+  Context &c = g.slots[0];
   if (c.ready) {
     if (device >= 0 && device != c.device)
       return fail(PCGX_E_INVALID, "pcgx already initialised on device %d (one process per GPU)", c.device);
@@ -112,15 +171,21 @@ static pcgx_status init_device(int device) {
   PCGX_HIP_TRY(hipSetDevice(device));
   hipDeviceProp_t prop;
   PCGX_HIP_TRY(hipGetDeviceProperties(&prop, device));
-  c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  PCGX_HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-  c.device = device;
-  c.ready = true;
+  for (int k = 0; k <= kPoolSlots; k++) {
+    Context &s = g.slots[k];
+    s.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    PCGX_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    s.device = device;
+  }
+  for (int k = kPoolSlots; k >= 0; k--) g.slots[k].ready = true;
   return PCGX_OK;
 }
 
 pcgx_status ensure_init() {
-  if (ctx().ready) return PCGX_OK;
+  if (glob().slots[0].ready) {
+    (void)hipSetDevice(glob().slots[0].device);  // this thread may not have been bound yet (first call of its scope)
+    return PCGX_OK;
+  }
   return init_device(-1);
 }
 
@@ -231,17 +296,33 @@ extern "C" pcgx_status pcgx_init(int32_t device) { return init_device(device); }
 
 extern "C" pcgx_status pcgx_shutdown(void) {
   PCGX_API_LOCK();
-  std::lock_guard<std::mutex> lk(g_init_mu);
-  Context &c = ctx();
-  if (!c.ready) return PCGX_OK;
+  Global &g = glob();
+  std::lock_guard<std::mutex> lk(g.init_mu);
+  if (!g.slots[0].ready) return PCGX_OK;
   (void)hipDeviceSynchronize();
-  c.arena.release_all();
-  c.host_arena.release_all();
+  for (int k = 0; k <= kPoolSlots; k++) {
+    Context &c = g.slots[k];
+    c.arena.release_all();
+    c.host_arena.release_all();
+    (void)hipStreamDestroy(c.stream);
+    c.stream = nullptr;
+    c.ready = false;
+    c.device = -1;
+  }
   dev_cache_release_all();
-  (void)hipStreamDestroy(c.stream);
-  c.stream = nullptr;
-  c.ready = false;
-  c.device = -1;
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_debug_call_stats(int64_t out[2], int32_t reset) {
+  if (!out) return fail(PCGX_E_INVALID, "pcgx_debug_call_stats: NULL argument");
+  Global &g = glob();
+  std::lock_guard<std::mutex> lk(g.mu);
+  out[0] = g.peak_in_pool;
+  out[1] = g.pooled_calls;
+  if (reset) {
+    g.peak_in_pool = g.in_pool;
+    g.pooled_calls = 0;
+  }
   return PCGX_OK;
 }
 

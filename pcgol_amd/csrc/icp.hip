@@ -901,6 +901,9 @@ static pcgx_status enqueue_corr_patched(pcgx_icp_session *s, hipStream_t st) {
 
 static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   static const int tight = icp_knob("PCGX_ICP_TIGHT", 32, 0, 32), chunks = icp_knob("PCGX_ICP_CHUNKS", 2, 1, 64);
+  // a deletion made after the session was created: from now on the reference's patched tree is walked
+  // (the same handle's Nearest / Range already do), without hints from earlier iterations
+  if (!s->patched && s->base->n_deleted > 0) s->patched = true;
   if (s->patched) return enqueue_corr_patched(s, st);
   TreeView tv = s->base->view();
   tv.tight_levels = tight;
@@ -1095,7 +1098,7 @@ extern "C" pcgx_status pcgx_icp_session_hessian(pcgx_icp_session *s, void *strea
 extern "C" pcgx_status pcgx_icp_plane_fit(const pcgx_kdtree *base, const float *base_normals, const float *target,
                                           int64_t nt, const pcgx_icp_params *params, float damping,
                                           float trans16[16], pcgx_icp_stat *stat, float hessian36[36]) {
-  PCGX_API_LOCK();
+  PCGX_API_CALL();
   if (!base || !params || !trans16) return fail(PCGX_E_INVALID, "pcgx_icp_plane_fit: NULL argument");
   pcgx_icp_session *s = nullptr;
   PCGX_TRY(pcgx_icp_plane_session_create(base, base_normals, target, nt, 0, params, damping, nullptr, &s));
@@ -1110,8 +1113,16 @@ extern "C" pcgx_status pcgx_icp_plane_fit(const pcgx_kdtree *base, const float *
 extern "C" pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target, int64_t nt,
                                     const pcgx_icp_params *params, float trans16[16],
                                     pcgx_icp_stat *stat) {
-  PCGX_API_LOCK();
+  PCGX_API_CALL();
   if (!base || !params || !trans16) return fail(PCGX_E_INVALID, "pcgx_icp_fit: NULL argument");
+  {  // what Fit returns when its first Evaluate fails (icp.go:47-53): identity, NumIteration 1
+    const Mat4 id = mat4_translate(0.0f, 0.0f, 0.0f);
+    memcpy(trans16, id.m, sizeof id.m);
+    if (stat) {
+      memset(stat, 0, sizeof *stat);
+      stat->num_iteration = 1;
+    }
+  }
   pcgx_icp_session *s = nullptr;
   PCGX_TRY(pcgx_icp_session_create(base, target, nt, 0, params, nullptr, &s));
   pcgx_status rc = PCGX_OK;
@@ -1126,7 +1137,7 @@ extern "C" pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target
 extern "C" pcgx_status pcgx_icp_evaluate(const pcgx_kdtree *base, const float *target, int64_t nt,
                                          float max_dist, float min_dist_sq, int32_t min_pairs,
                                          pcgx_icp_evaluated *out) {
-  PCGX_API_LOCK();
+  PCGX_API_CALL();
   if (!base || !out) return fail(PCGX_E_INVALID, "pcgx_icp_evaluate: NULL argument");
   pcgx_icp_params p;
   memset(&p, 0, sizeof p);
@@ -1150,7 +1161,7 @@ extern "C" pcgx_status pcgx_icp_evaluate(const pcgx_kdtree *base, const float *t
 extern "C" pcgx_status pcgx_icp_pairs(const pcgx_kdtree *base, const float *target, int64_t nt,
                                       float max_dist, float min_dist_sq, int64_t *base_id,
                                       int64_t *target_id, float *dist_sq, int64_t *npairs) {
-  PCGX_API_LOCK();
+  PCGX_API_CALL();
   if (!base || !npairs || nt < 0 || (nt > 0 && (!target || !base_id || !target_id || !dist_sq)))
     return fail(PCGX_E_INVALID, "pcgx_icp_pairs: bad argument");
   *npairs = 0;

@@ -389,6 +389,7 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
     const size_t cells = (size_t)1 << (3 * g);
     e = dev_cache_alloc((void **)&t->d_dir, cells * sizeof(uint32_t));
     if (e != hipSuccess) {
+      grid_free(t);
       dev_cache_free(t->d_nodes);
       delete t;
       return fail(PCGX_E_OOM, "hipMalloc for the leaf directory (%zu cells) failed: %s", cells, hipGetErrorString(e));
@@ -397,6 +398,7 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
                        t->view(), t->d_dir);
     e = hipStreamSynchronize(ctx().stream);
     if (e != hipSuccess) {
+      grid_free(t);
       dev_cache_free(t->d_nodes);
       dev_cache_free(t->d_dir);
       delete t;
@@ -409,13 +411,16 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
 
 extern "C" pcgx_status pcgx_kdtree_build(const void *data, int64_t n, int32_t stride,
                                          int32_t xyz_off, pcgx_kdtree **out) {
-  PCGX_API_LOCK();
+  PCGX_API_CALL();
   return build_tree(data, n, stride, xyz_off, nullptr, out);
 }
 
 extern "C" pcgx_status pcgx_kdtree_free(pcgx_kdtree *t) {
   PCGX_API_LOCK();
   if (!t) return PCGX_OK;
+  // the buffers go back to the block cache and may be handed out again at once: kernels a caller
+  // enqueued on a stream of its own (NearestBatchDev, ICP steps) must be done with them
+  dev_cache_quiesce();
   if (t->live) pcgx_kdtree_free(t->live);
   for (pcgx_kdtree *r : t->retired) pcgx_kdtree_free(r);
   xtree_free(t);
@@ -581,7 +586,7 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch_dev(const pcgx_kdtree *t, const
 extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const float *q, int64_t nq,
                                                  float max_range, float min_dist_sq, int64_t *ids,
                                                  float *dist_sq) {
-  PCGX_API_LOCK();
+  PCGX_API_CALL();
   if (!t || nq < 0 || (nq > 0 && (!q || !ids || !dist_sq)))
     return fail(PCGX_E_INVALID, "pcgx_kdtree_nearest_batch: bad argument");
   if (nq == 0) return PCGX_OK;

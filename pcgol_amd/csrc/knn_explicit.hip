@@ -12,8 +12,10 @@
 // the reference's nodes {id, dim, child0, child1}, patched exactly as deleteNodeImpl does it, an
 // explicit device copy of it (32 B per node), and Nearest / Range walk THAT tree with the
 // reference's visit order (one query per lane, explicit frames in LDS; no speculation -- this is the
-// exact path for mutated trees, the fast path is the implicit tree).  ICP sessions and region
-// growing on such a handle use the rebuilt canonical tree of resolve_tree (knn.hip).
+// exact path for mutated trees, the fast path is the implicit tree).  ICP sessions on such a handle
+// walk this patched tree too (icp_corr_xkernel, icp.hip; also when the deletion comes after the
+// session was created); region growing uses the rebuilt canonical tree of resolve_tree (knn.hip):
+// Range hits are a set, whatever the tree's shape.
 #include <string.h>
 
 #include <vector>
@@ -232,6 +234,8 @@ pcgx_status xtree_view(const pcgx_kdtree *tc, XTreeView *xv, hipStream_t st) {
     t->x_dirty = true;
   }
   if (t->x_dirty) {
+    // uploaded in place: walks other streams still run on the previous copy must have finished
+    dev_cache_quiesce();
     std::vector<float4> pts(n);
     std::vector<int4> links(n);
     for (size_t k = 0; k < n; k++) {

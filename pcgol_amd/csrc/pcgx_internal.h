@@ -102,6 +102,15 @@ struct ProfScope {
 };
 
 // ---- context ---------------------------------------------------------------
+// One process drives one GPU.  Work is enqueued from CALL CONTEXTS: a stream plus the two workspace
+// arenas.  Context 0 is the library's own: every entry point that takes a `stream` argument (the
+// device-resident `_dev` calls, ICP sessions) runs in it, one caller at a time, so that work given
+// to the NULL stream stays ordered whatever OS thread a goroutine happens to be on.  The blocking
+// host-pointer entry points (Nearest / Range batches, VoxelGrid.Filter, MinMax, tree build, Fit,
+// Evaluate, Pairs -- the seams the reference's own interfaces map to, which it allows to be called
+// from several goroutines at once, kdtree.go:44-50,72-81) take a context from a small pool instead:
+// handles are immutable after build, so these calls overlap on the GPU, each on its own stream with
+// its own workspace, and synchronise only their own stream before they return.
 struct Context {
   bool ready = false;
   int device = -1;
@@ -111,14 +120,22 @@ struct Context {
   Arena host_arena;  // device staging of the host-pointer entry points (they call the _dev ones,
                      // which restart `arena`; separate so the staging survives that)
 };
-Context &ctx();
+Context &ctx();  // the calling thread's current context (the library's outside any call)
 pcgx_status ensure_init();
-// One lock around every entry point that touches the context (arenas, library stream, handles'
-// lazily rebuilt trees): callers such as a Go program may enter from several OS threads at once.
-// Recursive: the host-pointer entry points call the device-resident ones.
-std::recursive_mutex &api_mutex();
-#define PCGX_API_LOCK() std::lock_guard<std::recursive_mutex> pcgx_api_lock__(::pcgx::api_mutex())
+// Scope of one ABI call: binds the thread to a context (pooled: any free one of the pool, waiting for
+// one if all are busy; else the library's, exclusively) and to the library's device -- HIP's current
+// device is per thread, a caller may come from any OS thread.  Nested calls keep the outer context.
+struct CallScope {
+  explicit CallScope(bool pooled);
+  ~CallScope();
+  int slot_ = -1;
+};
+#define PCGX_API_LOCK() ::pcgx::CallScope pcgx_call_scope__(false)
+#define PCGX_API_CALL() ::pcgx::CallScope pcgx_call_scope__(true)
 inline hipStream_t pick_stream(void *s) { return s ? (hipStream_t)s : ctx().stream; }
+// Buffers go back to the block cache and may be handed out again at once: whatever any stream still
+// has in flight on them must be done first (hipFree used to synchronise implicitly).
+void dev_cache_quiesce();
 
 // ---- KD-tree ---------------------------------------------------------------
 // The reference's recursively sorted indice slice (kdtree.go:348-370), read left

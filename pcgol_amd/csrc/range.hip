@@ -77,7 +77,7 @@ using namespace pcgx;
 
 extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float *q, int64_t nq, float max_range,
                                                int64_t *counts) {
-  PCGX_API_LOCK();
+  PCGX_API_CALL();
   if (!t || nq < 0 || (nq > 0 && (!q || !counts))) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_count: bad argument");
   if (nq == 0) return PCGX_OK;
   PCGX_TRY(ensure_init());
@@ -115,7 +115,7 @@ extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float
 
 extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float *q, int64_t nq, float max_range,
                                               const int64_t *offsets, int64_t *ids, float *dist_sq) {
-  PCGX_API_LOCK();
+  PCGX_API_CALL();
   if (!t || nq < 0 || (nq > 0 && (!q || !offsets))) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: bad argument");
   if (nq == 0) return PCGX_OK;
   const int64_t total = offsets[nq];

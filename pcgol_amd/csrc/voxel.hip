@@ -432,7 +432,7 @@ extern "C" pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int3
 
 extern "C" pcgx_status pcgx_minmax(const void *data, int64_t n, int32_t stride, int32_t xyz_off,
                                    float vmin[3], float vmax[3]) {
-  PCGX_API_LOCK();
+  PCGX_API_CALL();
   if (n < 0 || !vmin || !vmax || (n > 0 && !data)) return fail(PCGX_E_INVALID, "pcgx_minmax: bad argument");
   if (n == 0) return fail(PCGX_E_NO_POINT, "no point");
   if (stride < 12 || xyz_off < 0 || xyz_off + 12 > stride)
@@ -466,7 +466,7 @@ extern "C" pcgx_status pcgx_minmax(const void *data, int64_t n, int32_t stride, 
 extern "C" pcgx_status pcgx_voxel_filter(const void *data, int64_t n, int32_t stride, int32_t xyz_off,
                                          const float leaf[3], const int32_t chunk[3], void *out_data,
                                          int64_t *out_n) {
-  PCGX_API_LOCK();
+  PCGX_API_CALL();
   if (!out_n) return fail(PCGX_E_INVALID, "pcgx_voxel_filter: out_n is NULL");
   *out_n = 0;
   if (n < 0 || (n > 0 && (!data || !out_data))) return fail(PCGX_E_INVALID, "pcgx_voxel_filter: bad argument");

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from pcgol_amd import PcgxError, kdtree, synth, voxelgrid
+from pcgol_amd import PcgxError, icp, kdtree, synth, voxelgrid
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -116,26 +116,71 @@ def test_edge_cases_of_the_next_rows():
         t.DeletePoint(1)
 
 
-def test_concurrent_callers_are_serialised():
-    """Several host threads (as goroutines would) issue batches on one tree at once."""
+def test_concurrent_callers_overlap_and_match_the_oracle():
+    """Several host threads (as goroutines would, kdtree.go:44-50,72-81) issue batches on one tree at
+    once: the blocking batch calls run on streams of their own (csrc/core.hip: call contexts), so at
+    least two are in flight together, and every result is what a lone call -- and the oracle -- gives."""
     import threading
-    base = synth.uniform_cloud(50000, 5.0, 31)
+    from pcgol_amd import _lib as L
+    base = synth.uniform_cloud(200000, 5.0, 31)
     t = kdtree.New(base)
-    qs = [synth.uniform_cloud(4000, 5.0, 40 + k) for k in range(6)]
-    exp = [O.KDTree(base).nearest_batch(q, 1.0) for q in qs[:2]]
+    o = O.KDTree(base)
+    qs = [synth.uniform_cloud(300000, 5.0, 40 + k) for k in range(6)]
+    exp = [o.nearest_batch(q[:20000], 1.0) for q in qs[:2]]
+    vexp = [O.voxel_filter(q, len(q), 12, 0, (0.2, 0.2, 0.2)) for q in qs[:2]]
     out = [None] * len(qs)
+    vout = [None] * len(qs)
+    st = np.zeros(2, np.int64)
+    L.check(L.lib().pcgx_debug_call_stats(L.ptr(st), 1))
+    go = threading.Barrier(len(qs))
 
     def work(k):
-        for _ in range(5):
+        go.wait()
+        for _ in range(6):
             out[k] = t.NearestBatch(qs[k], 1.0)
-            voxelgrid.New((0.2, 0.2, 0.2)).Filter(qs[k])
+            vout[k] = voxelgrid.New((0.2, 0.2, 0.2)).Filter(qs[k]).Data
+            t.RangeBatch(qs[k][:2000], 0.1)
     th = [threading.Thread(target=work, args=(k,)) for k in range(len(qs))]
     for x in th:
         x.start()
     for x in th:
         x.join()
+    L.check(L.lib().pcgx_debug_call_stats(L.ptr(st), 0))
+    assert st[0] >= 2 and st[1] >= 6 * 6 * 3, st      # calls did overlap
     for k in range(2):
-        assert np.array_equal(out[k][0], exp[k][0]) and np.array_equal(out[k][1], exp[k][1])
+        assert np.array_equal(out[k][0][:20000], exp[k][0]) and np.array_equal(out[k][1][:20000], exp[k][1])
+        assert np.array_equal(vout[k], vexp[k])
     single = [t.NearestBatch(q, 1.0) for q in qs]
     for k in range(len(qs)):
         assert np.array_equal(out[k][0], single[k][0]) and np.array_equal(out[k][1], single[k][1])
+        assert np.array_equal(vout[k], voxelgrid.New((0.2, 0.2, 0.2)).Filter(qs[k]).Data)
+
+
+def test_concurrent_fits_and_session_calls():
+    """Whole Fits from several threads at once (pooled contexts) next to a session driven through the
+    library's own context: same transforms as one after the other."""
+    import threading
+    c = synth.c4_icp(n=60000, width=3.9)
+    t = kdtree.New(c["base"])
+    reg = icp.PointToPointICPGradient(
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=c["min_pairs"]),
+        icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=c["threshold"], MaxIteration=c["max_iteration"]))
+    ref, _ = reg.Fit(t, c["target"])
+    res = [None] * 4
+
+    def work(k):
+        if k == 0:
+            s = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+            for _ in range(c["max_iteration"]):
+                s.step()
+            res[k] = s.result()[0]
+            s.close()
+        else:
+            res[k] = reg.Fit(t, c["target"])[0]
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    for k in range(4):
+        assert np.array_equal(res[k], ref), k
