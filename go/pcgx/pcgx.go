@@ -57,6 +57,8 @@ func status(rc C.pcgx_status) error {
 	case C.PCGX_E_OUT_OF_RANGE:
 		return ErrOutOfRange
 	default:
+		// callers hold the OS thread (runtime.LockOSThread) from the cgo call to here: the C side
+		// keeps the message per thread
 		return fmt.Errorf("pcgx: %s (status %d)", lastError(), int(rc))
 	}
 }
@@ -101,6 +103,8 @@ var _ storage.Search = (*KDTree)(nil)
 
 // New builds the tree from any Vec3RandomAccessor (packed copy, one upload).
 func New(ra pc.Vec3RandomAccessor) (*KDTree, error) {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
 	n := ra.Len()
 	xyz := make([]float32, 3*n)
 	for i := 0; i < n; i++ {
@@ -121,6 +125,10 @@ func New(ra pc.Vec3RandomAccessor) (*KDTree, error) {
 
 // Close releases the device tree.
 func (k *KDTree) Close() {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(k) // the finalizer must not free the handle while a call is in flight
+	runtime.SetFinalizer(k, nil)
 	if k.h != nil {
 		C.pcgx_kdtree_free(k.h)
 		k.h = nil
@@ -129,6 +137,9 @@ func (k *KDTree) Close() {
 
 // DeletePoint removes a point from the tree (KDTree.DeletePoint, kdtree.go:322-332).
 func (k *KDTree) DeletePoint(pID int) error {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(k) // the finalizer must not free the handle while a call is in flight
 	id := C.int64_t(pID)
 	rc := C.pcgx_kdtree_delete_points(k.h, &id, 1)
 	if rc == C.PCGX_E_OUT_OF_RANGE {
@@ -139,6 +150,9 @@ func (k *KDTree) DeletePoint(pID int) error {
 
 // NearestBatch is the batched seam: result i equals k.Nearest(q[i], maxRange).
 func (k *KDTree) NearestBatch(q []mat.Vec3, maxRange float32) ([]storage.Neighbor, error) {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(k) // the finalizer must not free the handle while a call is in flight
 	n := len(q)
 	out := make([]storage.Neighbor, n)
 	if n == 0 {
@@ -169,6 +183,9 @@ func (k *KDTree) Nearest(p mat.Vec3, maxRange float32) storage.Neighbor {
 // RangeBatch: neighbours with DistSq < maxRange^2 of every query, each list sorted by DistSq
 // (KDTree.Range, kdtree.go:148-161).  out[i] belongs to q[i].
 func (k *KDTree) RangeBatch(q []mat.Vec3, maxRange float32) ([][]storage.Neighbor, error) {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(k) // the finalizer must not free the handle while a call is in flight
 	n := len(q)
 	out := make([][]storage.Neighbor, n)
 	if n == 0 {
@@ -225,6 +242,9 @@ func NewVoxelGrid(leaf mat.Vec3, chunk [3]int) filter.Filter {
 }
 
 func (f *voxelGrid) Filter(pp *pc.PointCloud) (*pc.PointCloud, error) {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(f) // the finalizer must not free the handle while a call is in flight
 	stride, off, err := xyzLayout(pp)
 	if err != nil {
 		return nil, err
@@ -275,6 +295,9 @@ func packVec3(ra pc.Vec3RandomAccessor) []float32 {
 }
 
 func (e *Evaluator) Evaluate(base storage.Search, target pc.Vec3RandomAccessor) (*icp.Evaluated, error) {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(e) // the finalizer must not free the handle while a call is in flight
 	k, ok := base.(*KDTree)
 	if !ok {
 		return nil, errors.New("pcgx: base must be a *pcgx.KDTree")
@@ -300,6 +323,9 @@ func (e *Evaluator) Evaluate(base storage.Search, target pc.Vec3RandomAccessor) 
 // Fit runs the whole PointToPointICPGradient.Fit loop on the device
 // (icp.go:23-67) with a GradientDescentUpdaterFactory's parameters.
 func Fit(base *KDTree, target pc.Vec3RandomAccessor, e *Evaluator, u *icp.GradientDescentUpdaterFactory) (mat.Mat4, icp.Stat, error) {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(base)
 	var p C.pcgx_icp_params
 	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(base.MinDistSq), C.int32_t(e.MinPairs)
 	if u != nil {
@@ -346,6 +372,9 @@ func (PlaneEvaluator) HasHessian() bool  { return true }
 
 // Evaluate runs one fused correspondence + 30-sum reduction on the device.
 func (e *PlaneEvaluator) Evaluate(base storage.Search, target pc.Vec3RandomAccessor) (*icp.Evaluated, error) {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(e) // the finalizer must not free the handle while a call is in flight
 	k, ok := base.(*KDTree)
 	if !ok {
 		return nil, errors.New("pcgx: base must be a *pcgx.KDTree")
@@ -390,6 +419,9 @@ func (e *PlaneEvaluator) Evaluate(base storage.Search, target pc.Vec3RandomAcces
 // FitPlane runs the whole loop (icp.go:23-67 shape) with the point-to-plane
 // evaluator and a Gauss-Newton updater on the device.
 func FitPlane(base *KDTree, target pc.Vec3RandomAccessor, e *PlaneEvaluator, threshold mat.Vec6, maxIteration int, damping float32) (mat.Mat4, icp.Stat, error) {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(base)
 	var p C.pcgx_icp_params
 	p.max_dist, p.min_pairs, p.max_iteration = C.float(e.MaxDist), C.int32_t(e.MinPairs), C.int32_t(maxIteration)
 	for i := 0; i < 6; i++ {
@@ -431,6 +463,8 @@ type BucketGrid struct {
 
 // NewBucketGrid builds the grid over every point of ra.
 func NewBucketGrid(resolution float32, size [3]int, origin mat.Vec3, ra pc.Vec3RandomAccessor) (*BucketGrid, error) {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
 	xyz := packVec3(ra)
 	var data unsafe.Pointer
 	if len(xyz) > 0 {
@@ -449,6 +483,9 @@ func NewBucketGrid(resolution float32, size [3]int, origin mat.Vec3, ra pc.Vec3R
 
 // Close releases the grid.
 func (g *BucketGrid) Close() {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(g) // the finalizer must not free the handle while a call is in flight
 	if g.h != nil {
 		C.pcgx_bucket_grid_free(g.h)
 		g.h = nil
@@ -465,6 +502,9 @@ func idsToInt(ids []int64) []int {
 
 // Get returns the ids of p's voxel, nil when p is outside the grid (voxelgrid.go:52-58).
 func (g *BucketGrid) Get(p mat.Vec3) []int {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(g) // the finalizer must not free the handle while a call is in flight
 	var cnt C.int64_t
 	if C.pcgx_bucket_grid_get(g.h, (*C.float)(unsafe.Pointer(&p[0])), nil, 0, &cnt) != C.PCGX_OK || cnt < 0 {
 		return nil
@@ -476,6 +516,9 @@ func (g *BucketGrid) Get(p mat.Vec3) []int {
 
 // Segment is segmentation/voxelgrid.VoxelGrid.Segment, ids in the reference's own order.
 func (g *BucketGrid) Segment(p mat.Vec3) []int {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(g) // the finalizer must not free the handle while a call is in flight
 	var cnt C.int64_t
 	if C.pcgx_bucket_grid_segment_bfs(g.h, (*C.float)(unsafe.Pointer(&p[0])), nil, 0, &cnt) != C.PCGX_OK || cnt <= 0 {
 		return nil
@@ -505,6 +548,9 @@ func NewRegionGrowing(search *KDTree, propertyIter pc.Uint32RandomAccessor) *Reg
 
 // Segment mirrors RegionGrowing.Segment, ids in the reference's own order.
 func (r *RegionGrowing) Segment(p mat.Vec3, maxRange float32) []int {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(r) // the finalizer must not free the handle while a call is in flight
 	n := len(r.labels)
 	if n == 0 {
 		return []int{}
@@ -522,6 +568,9 @@ func (r *RegionGrowing) Segment(p mat.Vec3, maxRange float32) []int {
 // SegmentByID returns the same set in ascending id order from region labels of the whole cloud
 // (computed once per maxRange): the fast path for many seeds.
 func (r *RegionGrowing) SegmentByID(p mat.Vec3, maxRange float32) []int {
+	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(r) // the finalizer must not free the handle while a call is in flight
 	n := len(r.labels)
 	if n == 0 {
 		return []int{}
@@ -542,4 +591,121 @@ func (r *RegionGrowing) SegmentByID(p mat.Vec3, maxRange float32) []int {
 		return []int{}
 	}
 	return idsToInt(ids[:int(cnt)])
+}
+
+
+// ------------------------------------------ strict sums and the sharded Fit
+
+// FitStrict is Fit with the evaluator's sums formed exactly as the Go code forms them
+// (sequential float32 additions in target order, evaluator.go:122-145): the returned transform and
+// Stat are bit-identical to PointToPointICPGradient.Fit on the CPU at any size.  The sums are
+// evaluated by the whole GPU (csrc/strict_sum.h), about 6x the time of the float64 reduction.
+func FitStrict(base *KDTree, target pc.Vec3RandomAccessor, e *Evaluator, u *icp.GradientDescentUpdaterFactory) (mat.Mat4, icp.Stat, error) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(base)
+	var p C.pcgx_icp_params
+	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(base.MinDistSq), C.int32_t(e.MinPairs)
+	maxIter := 20
+	if u != nil {
+		for i := 0; i < 6; i++ {
+			p.weight[i], p.threshold[i] = C.float(u.Weight[i]), C.float(u.Threshold[i])
+		}
+		p.max_iteration = C.int32_t(u.MaxIteration)
+		if u.MaxIteration > 0 {
+			maxIter = u.MaxIteration
+		}
+	}
+	t := packVec3(target)
+	var tp *C.float
+	if len(t) > 0 {
+		tp = (*C.float)(unsafe.Pointer(&t[0]))
+	}
+	var trans mat.Mat4
+	var st C.pcgx_icp_stat
+	var s *C.pcgx_icp_session
+	if err := status(C.pcgx_icp_session_create(base.h, tp, C.int64_t(target.Len()), 0, &p, nil, &s)); err != nil {
+		return trans, icp.Stat{NumIteration: 1}, err
+	}
+	defer C.pcgx_icp_session_free(s)
+	if err := status(C.pcgx_icp_session_set_strict(s, 1)); err != nil {
+		return trans, icp.Stat{}, err
+	}
+	for i := 0; i < maxIter; i++ {
+		if err := status(C.pcgx_icp_session_step(s, nil)); err != nil {
+			return trans, icp.Stat{}, err
+		}
+	}
+	rc := C.pcgx_icp_session_result(s, nil, (*C.float)(unsafe.Pointer(&trans[0])), &st, nil)
+	stat := icp.Stat{NumIteration: int(st.num_iteration)}
+	stat.Value, stat.DistRMS = float32(st.evaluated.value), float32(st.evaluated.dist_rms)
+	for i := 0; i < 6; i++ {
+		stat.Gradient[i] = float32(st.evaluated.gradient[i])
+	}
+	return trans, stat, status(rc)
+}
+
+// Comm is the exchange of the sharded Fit: one process per GPU, every rank with a replica of the
+// base tree and one spatial tile of the target; per iteration the ten float64 partial sums are
+// all-reduced over the ranks (RCCL over xGMI, bound by libpcgx.so at run time).
+type Comm struct{ h *C.pcgx_comm }
+
+// CommID is generated by rank 0 (NewCommID) and handed to every rank by any channel the host has.
+type CommID [128]byte
+
+func NewCommID() (CommID, error) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var id CommID
+	err := status(C.pcgx_comm_unique_id((*C.pcgx_comm_id)(unsafe.Pointer(&id[0]))))
+	return id, err
+}
+
+// NewComm is collective: every rank calls it with the same id.
+func NewComm(rank, world int, id CommID) (*Comm, error) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	c := &Comm{}
+	if err := status(C.pcgx_comm_init(C.int32_t(rank), C.int32_t(world), (*C.pcgx_comm_id)(unsafe.Pointer(&id[0])), &c.h)); err != nil {
+		return nil, err
+	}
+	return c, nil
+}
+
+func (c *Comm) Close() {
+	if c.h != nil {
+		C.pcgx_comm_free(c.h)
+		c.h = nil
+	}
+}
+
+// FitSharded runs Fit on this rank's tile of the target; every rank returns the same transform.
+// The sums are float64 reductions (a sum spread over ranks has no sequential order to reproduce).
+func FitSharded(base *KDTree, tile pc.Vec3RandomAccessor, e *Evaluator, u *icp.GradientDescentUpdaterFactory, c *Comm) (mat.Mat4, icp.Stat, error) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(base)
+	defer runtime.KeepAlive(c)
+	var p C.pcgx_icp_params
+	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(base.MinDistSq), C.int32_t(e.MinPairs)
+	if u != nil {
+		for i := 0; i < 6; i++ {
+			p.weight[i], p.threshold[i] = C.float(u.Weight[i]), C.float(u.Threshold[i])
+		}
+		p.max_iteration = C.int32_t(u.MaxIteration)
+	}
+	t := packVec3(tile)
+	var tp *C.float
+	if len(t) > 0 {
+		tp = (*C.float)(unsafe.Pointer(&t[0]))
+	}
+	var trans mat.Mat4
+	var st C.pcgx_icp_stat
+	rc := C.pcgx_icp_fit_sharded(base.h, tp, C.int64_t(tile.Len()), &p, c.h, (*C.float)(unsafe.Pointer(&trans[0])), &st)
+	stat := icp.Stat{NumIteration: int(st.num_iteration)}
+	stat.Value, stat.DistRMS = float32(st.evaluated.value), float32(st.evaluated.dist_rms)
+	for i := 0; i < 6; i++ {
+		stat.Gradient[i] = float32(st.evaluated.gradient[i])
+	}
+	return trans, stat, status(rc)
 }

@@ -13,6 +13,7 @@
 // filled (from the first 1/COUNT of the field's block) and the other elements stay zero.
 #include <errno.h>
 #include <stdlib.h>
+#include <limits.h>
 #include <string.h>
 
 #include <string>
@@ -161,6 +162,22 @@ static PcdLayout make_layout(const pcgx_pcd_header *h) {
   return lay;
 }
 
+// POINTS x stride, and every field block's end, without int64 wrap-around: a header is untrusted
+// input, and every bounds check below is made in terms of these products.
+static pcgx_status payload_bytes(const pcgx_pcd_header *h, int64_t *total) {
+  if (h->n_fields < 0 || h->n_fields > PCGX_PCD_MAX_FIELDS || h->points < 0 || h->stride < 0)
+    return fail(PCGX_E_BAD_HEADER, "bad header (fields / POINTS / stride out of range)");
+  int64_t stride = 0;
+  for (int i = 0; i < h->n_fields; i++) {
+    if (h->size[i] < 0 || h->count[i] < 0) return fail(PCGX_E_BAD_HEADER, "negative SIZE / COUNT");
+    stride += (int64_t)h->size[i] * h->count[i];
+  }
+  if (stride != h->stride) return fail(PCGX_E_BAD_HEADER, "stride does not match SIZE x COUNT");
+  if (__builtin_mul_overflow(h->points, h->stride, total) || *total > ((int64_t)1 << 60))
+    return fail(PCGX_E_BAD_HEADER, "POINTS x stride overflows");
+  return PCGX_OK;
+}
+
 // Payload of a binary_compressed file, LZF-decoded (field-major blocks).
 static pcgx_status decode_compressed(const uint8_t *file, size_t len, const pcgx_pcd_header *h,
                                      std::vector<uint8_t> *dec) {
@@ -179,17 +196,24 @@ static pcgx_status decode_compressed(const uint8_t *file, size_t len, const pcgx
   PCGX_TRY(lzf_decompress(file + pos, (size_t)ncomp, dec->data(), dec->size(), &got));
   if (got != (size_t)nunc) return fail(PCGX_E_BAD_HEADER, "wrong uncompressed size");  // io.go:201-203
   // the reference would panic on a stream shorter than the header promises: an error here
+  {
+    int64_t t0;
+    PCGX_TRY(payload_bytes(h, &t0));  // from here on size x count x POINTS cannot wrap (each <= POINTS x stride)
+  }
   const PcdLayout lay = make_layout(h);
   for (int i = 0; i < lay.n_fields; i++)
     if (h->points > 0 && lay.head[i] + (h->points - 1) * (int64_t)lay.size[i] + lay.size[i] > (int64_t)nunc)
       return fail(PCGX_E_OUT_OF_RANGE, "binary_compressed payload shorter than POINTS x fields (the reference panics)");
-  if ((int64_t)nunc < h->points * h->stride && h->points > 0)
+  int64_t total;
+  PCGX_TRY(payload_bytes(h, &total));
+  if ((int64_t)nunc < total && h->points > 0)
     return fail(PCGX_E_OUT_OF_RANGE, "binary_compressed payload shorter than POINTS x stride (the reference panics)");
   return PCGX_OK;
 }
 
 static pcgx_status parse_ascii(const uint8_t *file, size_t len, const pcgx_pcd_header *h, uint8_t *out) {
-  const int64_t total = h->points * h->stride;
+  int64_t total;
+  PCGX_TRY(payload_bytes(h, &total));
   memset(out, 0, (size_t)total);
   size_t pos = (size_t)h->data_offset;
   int64_t data_off = 0;
@@ -256,6 +280,7 @@ extern "C" pcgx_status pcgx_pcd_unmarshal_header(const void *file, size_t len, p
       for (size_t i = 0; i < nv; i++) {
         int64_t v;
         PCGX_TRY(go_atoi(a[i + 1], &v));
+        if (v > INT32_MAX || v < INT32_MIN) return fail(PCGX_E_BAD_HEADER, "SIZE does not fit 32 bits");
         h->size[i] = (int32_t)v;
       }
     } else if (k == "TYPE") {
@@ -266,6 +291,7 @@ extern "C" pcgx_status pcgx_pcd_unmarshal_header(const void *file, size_t len, p
       for (size_t i = 0; i < nv; i++) {
         int64_t v;
         PCGX_TRY(go_atoi(a[i + 1], &v));
+        if (v > INT32_MAX || v < INT32_MIN) return fail(PCGX_E_BAD_HEADER, "COUNT does not fit 32 bits");
         h->count[i] = (int32_t)v;
       }
     } else if (k == "WIDTH") {
@@ -294,18 +320,20 @@ extern "C" pcgx_status pcgx_pcd_unmarshal_header(const void *file, size_t len, p
   int64_t stride = 0;
   for (int i = 0; i < n_fields; i++) {
     if (h->size[i] < 0 || h->count[i] < 0) return fail(PCGX_E_BAD_HEADER, "negative SIZE / COUNT");
-    stride += (int64_t)h->size[i] * h->count[i];  // pointcloud.go:64-70
+    stride += (int64_t)h->size[i] * h->count[i];  // pointcloud.go:64-70 (<= 64 x 2^62: no overflow)
   }
   if (h->points < 0) return fail(PCGX_E_BAD_HEADER, "negative POINTS (the reference panics in make)");
   h->stride = stride;
   h->data_offset = (int64_t)pos;
-  return PCGX_OK;
+  int64_t total;
+  return payload_bytes(h, &total);  // POINTS x stride must be a size a buffer can have
 }
 
 extern "C" pcgx_status pcgx_pcd_unmarshal(const void *file, size_t len, const pcgx_pcd_header *h, void *out_data) {
   PCGX_API_LOCK();
   if (!h || (len > 0 && !file)) return fail(PCGX_E_INVALID, "pcgx_pcd_unmarshal: NULL argument");
-  const int64_t total = h->points * h->stride;
+  int64_t total;
+  PCGX_TRY(payload_bytes(h, &total));
   if (total > 0 && !out_data) return fail(PCGX_E_INVALID, "pcgx_pcd_unmarshal: out_data is NULL");
   if (h->data_offset < 0 || (size_t)h->data_offset > len) return fail(PCGX_E_INVALID, "pcgx_pcd_unmarshal: bad header");
   const uint8_t *buf = (const uint8_t *)file;
@@ -331,7 +359,8 @@ extern "C" pcgx_status pcgx_pcd_unmarshal_dev(const void *file, size_t len, cons
                                               void *stream) {
   PCGX_API_LOCK();
   if (!h || (len > 0 && !file)) return fail(PCGX_E_INVALID, "pcgx_pcd_unmarshal_dev: NULL argument");
-  const int64_t total = h->points * h->stride;
+  int64_t total;
+  PCGX_TRY(payload_bytes(h, &total));
   if (total > 0 && !d_out) return fail(PCGX_E_INVALID, "pcgx_pcd_unmarshal_dev: d_out is NULL");
   if (h->data_offset < 0 || (size_t)h->data_offset > len) return fail(PCGX_E_INVALID, "pcgx_pcd_unmarshal_dev: bad header");
   if (total == 0) return PCGX_OK;

@@ -67,6 +67,37 @@ def test_header_errors():
             P.unmarshal(txt)
 
 
+def test_untrusted_header_cannot_wrap_the_size_arithmetic():
+    """POINTS x stride and the field-block ends are computed without int64 wrap-around: a header whose
+    products overflow is refused before any buffer is sized or any loop runs (POINTS =
+    2^62 + 1 with a 4-byte field wrapped `total` to 4 and passed the 'payload shorter than' checks)."""
+    import ctypes as C
+    base = b"VERSION 0.7\nFIELDS x\nSIZE 4\nTYPE F\nCOUNT 1\nWIDTH 1\nHEIGHT 1\nPOINTS %d\nDATA %s\n"
+    for fmt in (b"binary", b"binary_compressed", b"ascii"):
+        for points in ((1 << 62) + 1, (1 << 63) - 1, 1 << 61):
+            buf = base % (points, fmt) + struct.pack("<ii", 4, 4) + b"\x00" * 16
+            h = L.PcdHeader()
+            rc = L.lib().pcgx_pcd_unmarshal_header(L.ptr(np.frombuffer(buf, np.uint8).copy()), len(buf), C.byref(h))
+            assert rc == L.PCGX_E_BAD_HEADER, (fmt, points, rc)
+    # SIZE / COUNT beyond 32 bits are refused instead of truncated
+    for line in (b"SIZE 4294967300", b"COUNT 4294967297"):
+        txt = b"VERSION 0.7\nFIELDS x\n" + (line if line.startswith(b"SIZE") else b"SIZE 4") + b"\nTYPE F\n" + \
+              (line if line.startswith(b"COUNT") else b"COUNT 1") + b"\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary\n"
+        h = L.PcdHeader()
+        rc = L.lib().pcgx_pcd_unmarshal_header(L.ptr(np.frombuffer(txt, np.uint8).copy()), len(txt), C.byref(h))
+        assert rc == L.PCGX_E_BAD_HEADER, (line, rc)
+    # a hand-made header struct (the C ABI takes it from the caller) with wrapping products
+    h = L.PcdHeader()
+    ok = b"VERSION 0.7\nFIELDS x\nSIZE 4\nTYPE F\nCOUNT 1\nWIDTH 1\nHEIGHT 1\nPOINTS 1\nDATA binary\n" + b"\x00" * 4
+    assert L.lib().pcgx_pcd_unmarshal_header(L.ptr(np.frombuffer(ok, np.uint8).copy()), len(ok), C.byref(h)) == 0
+    h.points = (1 << 62) + 1
+    out = np.zeros(64, np.uint8)
+    assert L.lib().pcgx_pcd_unmarshal(L.ptr(np.frombuffer(ok, np.uint8).copy()), len(ok), C.byref(h), L.ptr(out)) == L.PCGX_E_BAD_HEADER
+    h.points = 1
+    h.stride = 8   # does not match SIZE x COUNT
+    assert L.lib().pcgx_pcd_unmarshal(L.ptr(np.frombuffer(ok, np.uint8).copy()), len(ok), C.byref(h), L.ptr(out)) == L.PCGX_E_BAD_HEADER
+
+
 def test_marshal_fixtures(golden):
     """pc/io_test.go:252-345: Marshal -> Unmarshal / UnmarshalHeader round trip, default viewpoint."""
     for c in golden("ref_pcd.json")["marshal"]["cases"]:
