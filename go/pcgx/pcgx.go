@@ -15,6 +15,7 @@ import "C"
 import (
 	"errors"
 	"fmt"
+	"math"
 	"runtime"
 	"unsafe"
 
@@ -275,6 +276,51 @@ func (f *voxelGrid) Filter(pp *pc.PointCloud) (*pc.PointCloud, error) {
 type Evaluator struct {
 	MaxDist  float32
 	MinPairs int
+	// Weight replaces PointToPointEvaluator.WeightFn (evaluator.go:72): the reference accepts any Go
+	// closure, the device one of the built-in forms below.  Weight.Func() is the matching closure
+	// for the CPU evaluator, so both compute the same float32 weights.  Zero value: w = 1.
+	Weight WeightFn
+}
+
+// WeightFn kinds (include/pcgx.h PCGX_WEIGHT_*).
+const (
+	WeightOne      = 0 // DefaultEvaluateWeightFn
+	WeightConstant = 1 // a
+	WeightInverse  = 2 // 1 / (a + d)
+	WeightHuber    = 3 // d <= a ? 1 : sqrt(a / d)
+	WeightTukey    = 4 // d < a ? (1 - d/a)^2 : 0
+)
+
+type WeightFn struct {
+	Kind int
+	A    float32
+}
+
+// Func is the closure icp.PointToPointEvaluator{WeightFn: ...} takes for the same weights on the CPU.
+func (w WeightFn) Func() icp.EvaluateWeightFn {
+	a := w.A
+	switch w.Kind {
+	case WeightConstant:
+		return func(float32) float32 { return a }
+	case WeightInverse:
+		return func(d float32) float32 { return 1 / (a + d) }
+	case WeightHuber:
+		return func(d float32) float32 {
+			if d <= a {
+				return 1
+			}
+			return float32(math.Sqrt(float64(a / d)))
+		}
+	case WeightTukey:
+		return func(d float32) float32 {
+			if !(d < a) {
+				return 0
+			}
+			u := 1 - d/a
+			return u * u
+		}
+	}
+	return icp.DefaultEvaluateWeightFn
 }
 
 var _ icp.Evaluator = (*Evaluator)(nil)
@@ -308,8 +354,11 @@ func (e *Evaluator) Evaluate(base storage.Search, target pc.Vec3RandomAccessor) 
 		tp = (*C.float)(unsafe.Pointer(&t[0]))
 	}
 	var ev C.pcgx_icp_evaluated
-	rc := C.pcgx_icp_evaluate(k.h, tp, C.int64_t(target.Len()), C.float(e.MaxDist), C.float(k.MinDistSq),
-		C.int32_t(e.MinPairs), &ev)
+	var p C.pcgx_icp_params
+	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(k.MinDistSq), C.int32_t(e.MinPairs)
+	p.weight_fn, p.weight_fn_param = C.int32_t(e.Weight.Kind), C.float(e.Weight.A)
+	rc := C.pcgx_icp_evaluate_params(k.h, tp, C.int64_t(target.Len()), &p, &ev)
+	runtime.KeepAlive(k)
 	if err := status(rc); err != nil {
 		return nil, err
 	}
@@ -328,6 +377,7 @@ func Fit(base *KDTree, target pc.Vec3RandomAccessor, e *Evaluator, u *icp.Gradie
 	defer runtime.KeepAlive(base)
 	var p C.pcgx_icp_params
 	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(base.MinDistSq), C.int32_t(e.MinPairs)
+	p.weight_fn, p.weight_fn_param = C.int32_t(e.Weight.Kind), C.float(e.Weight.A)
 	if u != nil {
 		for i := 0; i < 6; i++ {
 			p.weight[i], p.threshold[i] = C.float(u.Weight[i]), C.float(u.Threshold[i])
@@ -606,6 +656,7 @@ func FitStrict(base *KDTree, target pc.Vec3RandomAccessor, e *Evaluator, u *icp.
 	defer runtime.KeepAlive(base)
 	var p C.pcgx_icp_params
 	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(base.MinDistSq), C.int32_t(e.MinPairs)
+	p.weight_fn, p.weight_fn_param = C.int32_t(e.Weight.Kind), C.float(e.Weight.A)
 	maxIter := 20
 	if u != nil {
 		for i := 0; i < 6; i++ {
@@ -688,6 +739,7 @@ func FitSharded(base *KDTree, tile pc.Vec3RandomAccessor, e *Evaluator, u *icp.G
 	defer runtime.KeepAlive(c)
 	var p C.pcgx_icp_params
 	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(base.MinDistSq), C.int32_t(e.MinPairs)
+	p.weight_fn, p.weight_fn_param = C.int32_t(e.Weight.Kind), C.float(e.Weight.A)
 	if u != nil {
 		for i := 0; i < 6; i++ {
 			p.weight[i], p.threshold[i] = C.float(u.Weight[i]), C.float(u.Threshold[i])

@@ -269,7 +269,23 @@ typedef struct {
   float weight[6];
   float threshold[6];
   int32_t max_iteration;
+  /* PointToPointEvaluator.WeightFn (evaluator.go:19-23,72,110-113,130): the reference takes any Go
+   * closure w = WeightFn(distSq); arbitrary host code cannot run on the device, so the weight is
+   * one of the built-in forms below, each evaluated in float32 exactly as the Go expression next to
+   * it (the Go shim hands out the matching closure, go/pcgx: WeightFn.Func()).  0 = the reference's
+   * default.  Not offered for the point-to-plane extension. */
+  int32_t weight_fn;
+  float weight_fn_param; /* a */
 } pcgx_icp_params;
+
+enum {
+  PCGX_WEIGHT_ONE = 0,      /* DefaultEvaluateWeightFn: return 1 */
+  PCGX_WEIGHT_CONSTANT = 1, /* return a */
+  PCGX_WEIGHT_INVERSE = 2,  /* return 1 / (a + d)                                   (Cauchy-like) */
+  PCGX_WEIGHT_HUBER = 3,    /* if d <= a { return 1 }; return float32(math.Sqrt(float64(a / d)))   (k^2 = a) */
+  PCGX_WEIGHT_TUKEY = 4,    /* if !(d < a) { return 0 }; u := 1 - d/a; return u * u               (c^2 = a) */
+  PCGX_WEIGHT_KINDS = 5
+};
 
 /* icp.Stat (stat.go:3-6) */
 typedef struct {
@@ -305,6 +321,11 @@ PCGX_API pcgx_status pcgx_rodrigues(const float v[3], float out16[16]);
 PCGX_API pcgx_status pcgx_mat4_mul(const float m[16], const float a[16], float out16[16]);
 PCGX_API pcgx_status pcgx_mat4_transform(const float m[16], const float *xyz, int64_t n,
                                          float *out_xyz);
+
+/* Evaluate with every parameter of pcgx_icp_params that concerns it (max_dist, min_dist_sq, min_pairs,
+ * weight_fn, weight_fn_param). */
+PCGX_API pcgx_status pcgx_icp_evaluate_params(const pcgx_kdtree *base, const float *target, int64_t nt,
+                                              const pcgx_icp_params *params, pcgx_icp_evaluated *out);
 
 /* Fit(base, target): the whole loop stays on the device (evaluate + update
  * kernels, one download at the end).  On PCGX_E_NOT_ENOUGH_PAIRS trans16 and

@@ -64,6 +64,7 @@ def lib():
         L.orc_minmax.argtypes = [vp, i64, i32, i32, vp, vp]
         L.orc_voxel_filter.restype = i32
         L.orc_voxel_filter.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp]
+        L.orc_set_weight_fn.argtypes = [i32, f32]
         L.orc_icp_pairs.restype = i64
         L.orc_icp_pairs.argtypes = [vp, vp, i64, f32, f32, vp, vp, vp]
         L.orc_icp_evaluate.restype = i32
@@ -270,6 +271,12 @@ def naive_nearest(pts, p, max_range):
 
 
 # ------------------------------------------------------------------ icp
+
+def set_weight_fn(kind=0, a=0.0):
+    """PointToPointEvaluator.WeightFn for the evaluate / fit calls that follow (0: the default, w = 1;
+    1 constant a; 2 1/(a+d); 3 Huber k^2 = a; 4 Tukey c^2 = a -- include/pcgx.h PCGX_WEIGHT_*)."""
+    lib().orc_set_weight_fn(int(kind), float(a))
+
 
 def icp_pairs(tree, target, max_dist):
     target = _f32(target).reshape(-1, 3)

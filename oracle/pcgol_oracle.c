@@ -689,7 +689,24 @@ typedef struct {
   float dist_rms;
 } oevaluated;
 
-/* evaluator.go:91-189 Evaluate with the default weight (w == 1, :21-23).
+/* PointToPointEvaluator.WeightFn (evaluator.go:19-23,110-113,130): the closures the GPU build offers
+ * as built-ins (include/pcgx.h PCGX_WEIGHT_*), written as a Go author would write them in float32.
+ * Test infrastructure sets the one in use with orc_set_weight_fn; 0 = DefaultEvaluateWeightFn. */
+static int g_weight_kind = 0;
+static float g_weight_a = 0.0f;
+void orc_set_weight_fn(int32_t kind, float a) { g_weight_kind = kind; g_weight_a = a; }
+static float weight_fn(float d) {
+  const float a = g_weight_a;
+  switch (g_weight_kind) {
+    case 1: return a;
+    case 2: return 1.0f / (a + d);
+    case 3: { if (d <= a) return 1.0f; float q = a / d; return (float)sqrt((double)q); }
+    case 4: { if (!(d < a)) return 0.0f; float u = 1.0f - d / a; return u * u; }
+    default: return 1.0f;
+  }
+}
+
+/* evaluator.go:91-189 Evaluate (w = WeightFn(d^2), default 1, :21-23,130).
  * sums_mode 0: sequential float32 (the Go semantics);
  * sums_mode 1: float64 accumulation of the same float32 terms (information
  *              only: quantifies the reference's own rounding noise).
@@ -712,7 +729,7 @@ int orc_icp_evaluate(okdtree *t, const float *target, int64_t nt, float max_dist
   for (int64_t i = 0; i < np; i++) {
     const float *pb = t->pts + 3 * bid[i];
     const float *pt = target + 3 * tid[i];
-    float w = 1.0f;
+    float w = weight_fn(dsq[i]);
     float x0 = pt[0], y0 = pt[1], z0 = pt[2];
     float x1 = pb[0], y1 = pb[1], z1 = pb[2];
     float tv = w * dsq[i];

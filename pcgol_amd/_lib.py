@@ -23,6 +23,8 @@ PCGX_E_SYNTAX = 11
 PCGX_E_EOF = 12
 PCGX_E_CORRUPT = 13
 PCGX_E_BAD_HEADER = 14
+PCGX_E_RCCL = 15
+PCGX_WEIGHT_ONE, PCGX_WEIGHT_CONSTANT, PCGX_WEIGHT_INVERSE, PCGX_WEIGHT_HUBER, PCGX_WEIGHT_TUKEY = range(5)
 PCGX_PCD_MAX_FIELDS = 64
 
 PCGX_KNN_PRESORT = 1
@@ -101,7 +103,8 @@ class IcpEvaluated(C.Structure):
 
 class IcpParams(C.Structure):
     _fields_ = [("max_dist", C.c_float), ("min_dist_sq", C.c_float), ("min_pairs", C.c_int32),
-                ("weight", C.c_float * 6), ("threshold", C.c_float * 6), ("max_iteration", C.c_int32)]
+                ("weight", C.c_float * 6), ("threshold", C.c_float * 6), ("max_iteration", C.c_int32),
+                ("weight_fn", C.c_int32), ("weight_fn_param", C.c_float)]
 
 
 class PcdHeader(C.Structure):  # pcgx_pcd_header
@@ -152,6 +155,7 @@ SIGNATURES = {
     "pcgx_voxel_filter_dev": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
     "pcgx_icp_pairs": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp, C.POINTER(_i64)]),
     "pcgx_icp_evaluate": (_i32, [_vp, _vp, _i64, _f32, _f32, _i32, C.POINTER(IcpEvaluated)]),
+    "pcgx_icp_evaluate_params": (_i32, [_vp, _vp, _i64, C.POINTER(IcpParams), C.POINTER(IcpEvaluated)]),
     "pcgx_icp_finish_evaluate": (_i32, [_vp, _i32, C.POINTER(IcpEvaluated)]),
     "pcgx_icp_update": (_i32, [C.POINTER(IcpParams), C.POINTER(_i32), _vp, _vp, C.POINTER(_i32)]),
     "pcgx_rodrigues": (_i32, [_vp, _vp]),

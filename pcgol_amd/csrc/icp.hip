@@ -26,18 +26,20 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return v;  // lane 0 holds the sum (fixed tree order -> deterministic)
 }
 
-__device__ __forceinline__ void accumulate_terms(double *acc, float x0, float y0, float z0, const float4 &bp) {
-  // evaluator.go:132-144 with w == 1; every term is formed in float32 as the reference forms it
+__device__ __forceinline__ void accumulate_terms(double *acc, float x0, float y0, float z0, const float4 &bp,
+                                                 const IcpKernelParams &kp) {
+  // evaluator.go:130-144; every term is formed in float32 as the reference forms it (w = 1: exact)
   const float x1 = bp.x, y1 = bp.y, z1 = bp.z;
-  acc[S_VALUE] += (double)bp.w;
-  acc[S_G0 + 0] += (double)(x0 - x1);
-  acc[S_G0 + 1] += (double)(y0 - y1);
-  acc[S_G0 + 2] += (double)(z0 - z1);
-  acc[S_G0 + 3] += (double)(z0 * y1 - y0 * z1);
-  acc[S_G0 + 4] += (double)(x0 * z1 - z0 * x1);
-  acc[S_G0 + 5] += (double)(y0 * x1 - x0 * y1);
-  acc[S_DIST_RMS] += (double)norm_sq3(x0, y0, z0);
-  acc[S_WEIGHT] += 1.0;
+  const float w = eval_weight_fn(kp.weight_fn, kp.weight_a, bp.w);
+  acc[S_VALUE] += (double)(w * bp.w);
+  acc[S_G0 + 0] += (double)(w * (x0 - x1));
+  acc[S_G0 + 1] += (double)(w * (y0 - y1));
+  acc[S_G0 + 2] += (double)(w * (z0 - z1));
+  acc[S_G0 + 3] += (double)(w * (z0 * y1 - y0 * z1));
+  acc[S_G0 + 4] += (double)(w * (x0 * z1 - z0 * x1));
+  acc[S_G0 + 5] += (double)(w * (y0 * x1 - x0 * y1));
+  acc[S_DIST_RMS] += (double)(w * norm_sq3(x0, y0, z0));
+  acc[S_WEIGHT] += (double)w;
   acc[S_PAIRS] += 1.0;
 }
 
@@ -69,7 +71,7 @@ __device__ __forceinline__ void reduce_block_range(uint32_t *s_scratch, const fl
                                                    int64_t nt, uint32_t chunk_begin, uint32_t chunk_end, bool project,
                                                    const float (&m)[16], const float4 *__restrict__ match,
                                                    const uint32_t *__restrict__ match_id,
-                                                   const float4 *__restrict__ normals,
+                                                   const float4 *__restrict__ normals, const IcpKernelParams &kp,
                                                    double *__restrict__ block_partials,
                                                    uint32_t *__restrict__ flags = nullptr, double extra = 0.0) {
   // extra: added to component threadIdx.x of the row (threads < NS)
@@ -99,7 +101,7 @@ __device__ __forceinline__ void reduce_block_range(uint32_t *s_scratch, const fl
         const float4 nrm = normals[match_id[i]];
         accumulate_plane_terms(acc, x0, y0, z0, bp, nrm);
       } else {
-        accumulate_terms(acc, x0, y0, z0, bp);
+        accumulate_terms(acc, x0, y0, z0, bp, kp);
       }
     }
   }
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     __threadfence_block();
     __syncthreads();
     reduce_block_range<kPlane, true>(s_stack, tx, ty, tz, nt, chunk_begin, chunk_end, project, m, match, match_id,
-                                     normals, block_partials, first_leaf, grid_part);
+                                     normals, kp, block_partials, first_leaf, grid_part);
     return;
   } else {
     walk_queries<kMinDist>(
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
   __threadfence_block();
   __syncthreads();  // all match[] of the range are written; stacks / queues are free for reuse
   reduce_block_range<kPlane>(s_stack, tx, ty, tz, nt, chunk_begin, chunk_end, project, m, match, match_id, normals,
-                             block_partials);
+                             kp, block_partials);
 }
 
 // Grid pass of an iteration (exact mode): one target per lane asks the uniform grid (knn_grid.h)
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
       if (kPlane) match_id[i] = __float_as_uint(best.w);
       if (found) {  // correspondence.go:27-29
         if (kPlane) accumulate_plane_terms(acc, x, y, z, bp, normals[__float_as_uint(best.w)]);
-        else accumulate_terms(acc, x, y, z, bp);
+        else accumulate_terms(acc, x, y, z, bp, kp);
       }
     }
   }
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_xkernel(
   __threadfence_block();
   __syncthreads();
   reduce_block_range<kPlane>(s_stack, tx, ty, tz, nt, chunk_begin, chunk_end, project, m, match, match_id, normals,
-                             block_partials);
+                             kp, block_partials);
 }
 
 // Plane sessions: evaluate tail (finish_evaluate_plane) + Gauss-Newton update; one thread.
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(256) void icp_strict_terms_kernel(const float *__re
                                                                const float *__restrict__ tz, int64_t nt, int64_t nt_pad,
                                                                const float4 *__restrict__ match,
                                                                const uint32_t *__restrict__ pos_of,
-                                                               const IcpState *__restrict__ state,
+                                                               const IcpState *__restrict__ state, IcpKernelParams kp,
                                                                float *__restrict__ terms,
                                                                unsigned long long *__restrict__ valid_bits) {
   if (state->done) return;
@@ -513,7 +515,8 @@ __global__ __launch_bounds__(256) void icp_strict_terms_kernel(const float *__re
         mat4_transform(m, x0, y0, z0, px, py, pz);
         x0 = px; y0 = py; z0 = pz;
       }
-      const float x1 = bp.x, y1 = bp.y, z1 = bp.z, w = 1.0f;  // evaluator.go:21-23,130
+      const float x1 = bp.x, y1 = bp.y, z1 = bp.z;
+      const float w = eval_weight_fn(kp.weight_fn, kp.weight_a, bp.w);  // evaluator.go:130
       t[0] = w * bp.w;
       t[1] = w * (x0 - x1);
       t[2] = w * (y0 - y1);
@@ -636,6 +639,8 @@ static IcpKernelParams make_kernel_params(const pcgx_icp_params *p) {
   kp.min_pairs = p->min_pairs == 0 ? 6 : p->min_pairs;  // evaluator.go:92-95
   kp.upd = resolve_updater(p->weight, p->threshold, p->max_iteration);
   kp.gn = resolve_gauss_newton(p->threshold, 0.0f, p->max_iteration);
+  kp.weight_fn = p->weight_fn;
+  kp.weight_a = p->weight_fn_param;
   return kp;
 }
 
@@ -755,6 +760,11 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
   *out = nullptr;
   if (!base || !params || nt < 0 || (nt > 0 && !target))
     return fail(PCGX_E_INVALID, "pcgx_icp_session_create: bad argument");
+  if (params->weight_fn < 0 || params->weight_fn >= PCGX_WEIGHT_KINDS)
+    return fail(PCGX_E_INVALID, "pcgx_icp_session_create: weight_fn %d is none of the built-in forms (a custom Go closure "
+                                "cannot run on the device)", params->weight_fn);
+  if (normals && params->weight_fn != PCGX_WEIGHT_ONE)
+    return fail(PCGX_E_INVALID, "the point-to-plane extension takes the default weight only");
   PCGX_TRY(ensure_init());
   hipStream_t st = ctx().stream;
   const int64_t n_base_ids = base->n;  // normals are indexed by the original ids
@@ -964,7 +974,7 @@ static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
   if (s->nt_pad > 0)
     hipLaunchKernelGGL(icp_strict_terms_kernel, dim3((unsigned)(s->nt_pad / 256 + 1)), dim3(256), 0, st, s->d_xyz,
                        s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, s->nt, s->nt_pad, (const float4 *)s->d_match,
-                       (const uint32_t *)s->d_pos_of, (const IcpState *)s->d_state, s->d_terms, s->d_valid);
+                       (const uint32_t *)s->d_pos_of, (const IcpState *)s->d_state, s->kp, s->d_terms, s->d_valid);
   hipLaunchKernelGGL(icp_strict_sums_kernel<kFuseUpdate>, dim3(1), dim3(64), 0, st, (const float *)s->d_terms,
                      (const unsigned long long *)s->d_valid, s->nt_pad, s->d_state, s->d_sums, s->kp);
   return PCGX_OK;
@@ -1134,18 +1144,12 @@ extern "C" pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target
   return rc;
 }
 
-extern "C" pcgx_status pcgx_icp_evaluate(const pcgx_kdtree *base, const float *target, int64_t nt,
-                                         float max_dist, float min_dist_sq, int32_t min_pairs,
-                                         pcgx_icp_evaluated *out) {
+extern "C" pcgx_status pcgx_icp_evaluate_params(const pcgx_kdtree *base, const float *target, int64_t nt,
+                                                const pcgx_icp_params *params, pcgx_icp_evaluated *out) {
   PCGX_API_CALL();
-  if (!base || !out) return fail(PCGX_E_INVALID, "pcgx_icp_evaluate: NULL argument");
-  pcgx_icp_params p;
-  memset(&p, 0, sizeof p);
-  p.max_dist = max_dist;
-  p.min_dist_sq = min_dist_sq;
-  p.min_pairs = min_pairs;
+  if (!base || !out || !params) return fail(PCGX_E_INVALID, "pcgx_icp_evaluate: NULL argument");
   pcgx_icp_session *s = nullptr;
-  PCGX_TRY(pcgx_icp_session_create(base, target, nt, 0, &p, nullptr, &s));
+  PCGX_TRY(pcgx_icp_session_create(base, target, nt, 0, params, nullptr, &s));
   pcgx_status rc = pcgx_icp_session_partials(s, nullptr);
   double sums[S_COUNT];
   if (rc == PCGX_OK) {
@@ -1155,7 +1159,18 @@ extern "C" pcgx_status pcgx_icp_evaluate(const pcgx_kdtree *base, const float *t
   }
   pcgx_icp_session_free(s);
   if (rc != PCGX_OK) return rc;
-  return pcgx_icp_finish_evaluate(sums, min_pairs, out);
+  return pcgx_icp_finish_evaluate(sums, params->min_pairs, out);
+}
+
+extern "C" pcgx_status pcgx_icp_evaluate(const pcgx_kdtree *base, const float *target, int64_t nt,
+                                         float max_dist, float min_dist_sq, int32_t min_pairs,
+                                         pcgx_icp_evaluated *out) {
+  pcgx_icp_params p;
+  memset(&p, 0, sizeof p);
+  p.max_dist = max_dist;
+  p.min_dist_sq = min_dist_sq;
+  p.min_pairs = min_pairs;
+  return pcgx_icp_evaluate_params(base, target, nt, &p, out);
 }
 
 extern "C" pcgx_status pcgx_icp_pairs(const pcgx_kdtree *base, const float *target, int64_t nt,

@@ -264,6 +264,8 @@ struct IcpKernelParams {
   int32_t min_pairs;
   UpdaterParams upd;
   GaussNewtonParams gn;  // plane sessions
+  int32_t weight_fn;     // PCGX_WEIGHT_* (evaluator.go:130)
+  float weight_a;
 };
 
 

@@ -130,6 +130,26 @@ PCGX_HD void finish_evaluate(const double *sums, Evaluated &ev) {
   ev.num_pairs = (int64_t)sums[S_PAIRS];
 }
 
+// PointToPointEvaluator.WeightFn built-ins (include/pcgx.h PCGX_WEIGHT_*): float32, the Go
+// expression's order of operations, math.Sqrt in float64 where Go would call it.
+PCGX_HD float eval_weight_fn(int32_t kind, float a, float d) {
+  switch (kind) {
+    case 1: return a;
+    case 2: return 1.0f / (a + d);
+    case 3: {
+      if (d <= a) return 1.0f;
+      const float q = a / d;
+      return (float)sqrt((double)q);
+    }
+    case 4: {
+      if (!(d < a)) return 0.0f;
+      const float u = 1.0f - d / a;
+      return u * u;
+    }
+    default: return 1.0f;  // DefaultEvaluateWeightFn (evaluator.go:21-23)
+  }
+}
+
 struct UpdaterParams {
   float weight[6];
   float threshold[6];

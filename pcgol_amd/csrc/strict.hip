@@ -75,6 +75,8 @@ struct StrictWork {
   unsigned long long *dbg;      // [16] counters (measurement aid)
   int64_t nt, nt_pad, ntiles, nbins;
   int32_t naux;
+  int32_t weight_fn;  // evaluator.go:130 (PCGX_WEIGHT_*)
+  float weight_a;
   int32_t selfcheck;  // debugging: every step of the chain walk is re-derived term by term and compared (dbg[12..15])
 };
 
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(kTermsBlock) void strict_terms_kernel(const float4 
           mat4_transform(m, x0, y0, z0, px, py, pz);
           x0 = px; y0 = py; z0 = pz;
         }
-        const float x1 = b.x, y1 = b.y, z1 = b.z, w = 1.0f;  // evaluator.go:21-23,130
+        const float x1 = b.x, y1 = b.y, z1 = b.z;
+        const float w = eval_weight_fn(W.weight_fn, W.weight_a, b.w);  // evaluator.go:130
         t[0][c] = w * b.w;
         t[1][c] = w * (x0 - x1);
         t[2][c] = w * (y0 - y1);
@@ -713,6 +716,8 @@ void strict_destroy(StrictBuffers *b) {
 
 pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
                            double *sums10, const IcpKernelParams &kp, bool fuse_update, hipStream_t st) {
+  b->w.weight_fn = kp.weight_fn;
+  b->w.weight_a = kp.weight_a;
   const StrictWork &W = b->w;
   const unsigned waves = (unsigned)(kStrictRows * W.ntiles);
   {

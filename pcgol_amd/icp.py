@@ -54,15 +54,57 @@ class Evaluated:  # evaluator.go:25-30
         self.NumPairs = int(ev.num_pairs) if ev else 0
 
 
+class WeightFn:
+    """PointToPointEvaluator.WeightFn (evaluator.go:19-23): the reference takes any closure of the
+    squared distance; the device evaluates one of these built-in forms, each in float32 exactly as
+    the Go expression reads (include/pcgx.h PCGX_WEIGHT_*).  Calling the object evaluates the same
+    expression on the host (numpy float32)."""
+
+    def __init__(self, kind, a=0.0):
+        self.kind, self.a = int(kind), np.float32(a)
+
+    def __call__(self, d):
+        f, a, d = np.float32, self.a, np.float32(d)
+        if self.kind == L.PCGX_WEIGHT_CONSTANT:
+            return a
+        if self.kind == L.PCGX_WEIGHT_INVERSE:
+            return f(f(1) / f(a + d))
+        if self.kind == L.PCGX_WEIGHT_HUBER:
+            return f(1) if d <= a else f(np.sqrt(np.float64(f(a / d))))
+        if self.kind == L.PCGX_WEIGHT_TUKEY:
+            if not d < a:
+                return f(0)
+            u = f(f(1) - f(d / a))
+            return f(u * u)
+        return f(1)
+
+
+def WeightConstant(a):
+    return WeightFn(L.PCGX_WEIGHT_CONSTANT, a)
+
+
+def WeightInverse(a):
+    return WeightFn(L.PCGX_WEIGHT_INVERSE, a)
+
+
+def WeightHuber(k_sq):
+    return WeightFn(L.PCGX_WEIGHT_HUBER, k_sq)
+
+
+def WeightTukey(c_sq):
+    return WeightFn(L.PCGX_WEIGHT_TUKEY, c_sq)
+
+
 class PointToPointEvaluator:  # evaluator.go:69-76
     def __init__(self, Corresponder, MinPairs=0, WeightFn=None):
-        if WeightFn is not None:
-            raise NotImplementedError("custom WeightFn closures cannot run on the device; only the "
-                                      "default weight (1) is supported (DESIGN.md, out of scope)")
+        if WeightFn is not None and not isinstance(WeightFn, globals()["WeightFn"]):
+            raise NotImplementedError("a custom WeightFn closure cannot run on the device: use one of the built-in "
+                                      "forms (icp.WeightConstant / WeightInverse / WeightHuber / WeightTukey)")
         if not isinstance(Corresponder, NearestPointCorresponder):
             raise TypeError("the GPU evaluator fuses NearestPointCorresponder")
         self.Corresponder = Corresponder
         self.MinPairs = int(MinPairs)
+        self.WeightFn = WeightFn
 
     def HasGradient(self):
         return True
@@ -75,14 +117,16 @@ class PointToPointEvaluator:  # evaluator.go:69-76
             raise TypeError("base must be a pcgol_amd KDTree")
         target = L.f32c(target).reshape(-1, 3)
         ev = L.IcpEvaluated()
-        L.check(L.lib().pcgx_icp_evaluate(base._h, L.ptr(target), len(target), self.Corresponder.MaxDist,
-                                          base.MinDistSq, self.MinPairs, C.byref(ev)))
+        p = _params(self.Corresponder.MaxDist, base.MinDistSq, self.MinPairs, np.zeros(6), np.zeros(6), 0, self.WeightFn)
+        L.check(L.lib().pcgx_icp_evaluate_params(base._h, L.ptr(target), len(target), C.byref(p), C.byref(ev)))
         return Evaluated(ev)
 
 
-def _params(max_dist, min_dist_sq, min_pairs, weight, threshold, max_iteration):
+def _params(max_dist, min_dist_sq, min_pairs, weight, threshold, max_iteration, weight_fn=None):
     p = L.IcpParams()
     p.max_dist, p.min_dist_sq, p.min_pairs, p.max_iteration = max_dist, min_dist_sq, min_pairs, max_iteration
+    if weight_fn is not None:
+        p.weight_fn, p.weight_fn_param = weight_fn.kind, float(weight_fn.a)
     for i in range(6):
         p.weight[i] = float(weight[i])
         p.threshold[i] = float(threshold[i])
@@ -141,7 +185,8 @@ class PointToPointICPGradient:  # icp.go:18-67
             raise ErrNeedGradient(L.PCGX_E_NEED_GRADIENT, "need gradient output of Evaluator")
         uf = self.UpdaterFactory or GradientDescentUpdaterFactory()
         target = L.f32c(target).reshape(-1, 3)
-        p = _params(ev.Corresponder.MaxDist, base.MinDistSq, ev.MinPairs, uf.Weight, uf.Threshold, uf.MaxIteration)
+        p = _params(ev.Corresponder.MaxDist, base.MinDistSq, ev.MinPairs, uf.Weight, uf.Threshold, uf.MaxIteration,
+                    ev.WeightFn)
         trans = np.empty(16, np.float32)
         st = L.IcpStat()
         rc = L.lib().pcgx_icp_fit(base._h, L.ptr(target), len(target), C.byref(p), L.ptr(trans), C.byref(st))
@@ -157,13 +202,13 @@ class IcpSession:
     """Device-resident Fit loop cut at the per-iteration exchange (include/pcgx.h)."""
 
     def __init__(self, base, target, MaxDist, MinPairs=0, Weight=None, Threshold=None, MaxIteration=0,
-                 d_sums10=0, target_on_device=False, nt=None, BaseNormals=None, Damping=0.0):
+                 d_sums10=0, target_on_device=False, nt=None, BaseNormals=None, Damping=0.0, WeightFn=None):
         """BaseNormals (unit normals per base point, id order; a device address when
         target_on_device) selects the point-to-plane / Gauss-Newton extension: the exchange
         vector then has 30 doubles (d_sums10 must point to 30)."""
         w = np.zeros(6, np.float32) if Weight is None else Weight
         th = np.zeros(6, np.float32) if Threshold is None else Threshold
-        self.params = _params(MaxDist, base.MinDistSq, MinPairs, w, th, MaxIteration)
+        self.params = _params(MaxDist, base.MinDistSq, MinPairs, w, th, MaxIteration, WeightFn)
         self.max_iteration = MaxIteration or 20
         self.base = base
         self.plane = BaseNormals is not None

@@ -356,3 +356,40 @@ def test_strict_sums_on_structured_terms():
         assert st.Evaluated.Value == oe["value"] and st.Evaluated.DistRMS == oe["dist_rms"]
         assert np.array_equal(st.Evaluated.Gradient, oe["gradient"])
         s.close()
+
+
+@pytest.mark.parametrize("wf", [icp.WeightConstant(0.25), icp.WeightInverse(0.01), icp.WeightHuber(0.0009),
+                                icp.WeightTukey(0.004)], ids=["constant", "inverse", "huber", "tukey"])
+def test_builtin_weight_fns_match_the_oracle(wf):
+    """PointToPointEvaluator.WeightFn (evaluator.go:19-23,130): the built-in forms weigh every term
+    in float32 exactly as the Go closure would.  Strict sums: Evaluated and the whole Fit equal the
+    oracle bit for bit; the float64 reduction agrees with the oracle's float64 sums to rounding."""
+    n = 40000
+    c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
+    t, o = kdtree.New(c["base"]), O.KDTree(c["base"])
+    O.set_weight_fn(wf.kind, wf.a)
+    try:
+        ev = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=6, WeightFn=wf)
+        got = ev.Evaluate(t, c["target"])
+        exp = O.icp_evaluate(o, c["target"], c["max_dist"], 6, sums_mode=1)
+        assert abs(got.Value - exp["value"]) <= 1e-6 * abs(exp["value"]) + 1e-12
+        assert np.allclose(got.Gradient, exp["gradient"], rtol=2e-6, atol=1e-9)
+        s = icp.IcpSession(t, c["target"], c["max_dist"], 6, c["weight"], c["threshold"], c["max_iteration"], WeightFn=wf)
+        s.set_strict(1)
+        for _ in range(c["max_iteration"]):
+            s.step()
+        tr, st, conv = s.result()
+        s.close()
+        o32 = O.icp_fit(o, c["target"], c["max_dist"], 6, c["weight"], c["threshold"], c["max_iteration"], sums_mode=0)
+        assert np.array_equal(tr, o32["trans"]) and st.Evaluated.Value == o32["value"]
+        assert np.array_equal(st.Evaluated.Gradient, o32["gradient"]) and st.Evaluated.DistRMS == o32["dist_rms"]
+        # the weights differ from 1 on this data (the test would pass trivially otherwise)
+        w = np.array([wf(d) for d in np.linspace(1e-5, 0.01, 50, dtype=np.float32)])
+        assert np.any(w != 1.0)
+    finally:
+        O.set_weight_fn(0, 0.0)
+
+
+def test_custom_weight_closure_is_refused():
+    with pytest.raises(NotImplementedError):
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=1.0), WeightFn=lambda d: 1.0)
