@@ -175,6 +175,37 @@ def test_c3_full_size_against_the_oracle(chunk):
     assert np.array_equal(got.Data, exp)
 
 
+def test_voxel_filter_more_shapes_vs_oracle():
+    """Larger clouds than the table above, against the oracle's bytes: plain and chunked, a record
+    with extra fields around xyz (the first point's whole record is carried over), ~400 points per
+    voxel (long sequential sums) and a cloud squeezed into a thin slab (most of the key range empty)."""
+    import ctypes as C
+    from pcgol_amd import _lib as L
+    rng = np.random.Generator(np.random.PCG64(3))
+    cases = []
+    pts = synth.uniform_cloud(400_000, 3.0, 5)
+    cases.append((pts, 12, 0, (0.02, 0.02, 0.02), (0, 0, 0)))
+    cases.append((pts, 12, 0, (0.03, 0.02, 0.025), (16, 8, 32)))
+    rec = np.zeros((len(pts), 5), np.float32)        # label | x y z | intensity
+    rec[:, 1:4] = pts
+    rec[:, 0] = np.arange(len(pts))
+    rec[:, 4] = rng.random(len(pts))
+    cases.append((np.ascontiguousarray(rec), 20, 4, (0.02, 0.02, 0.02), (0, 0, 0)))
+    cases.append((pts, 12, 0, (0.3, 0.3, 0.3), (0, 0, 0)))
+    slab = pts.copy()
+    slab[:, 2] = slab[:, 2] * f32(0.001)
+    cases.append((np.ascontiguousarray(slab), 12, 0, (0.004, 0.004, 0.004), (0, 0, 0)))
+    for data, stride, off, leaf, chunk in cases:
+        n = len(data)
+        exp = O.voxel_filter(data, n, stride, off, leaf, chunk)
+        out = np.empty(n * stride, np.uint8)
+        m = C.c_int64()
+        leafv, chunkv = np.asarray(leaf, f32), np.asarray(chunk, np.int32)   # kept alive across the call
+        L.check(L.lib().pcgx_voxel_filter(L.ptr(data), n, stride, off, L.ptr(leafv), L.ptr(chunkv), L.ptr(out),
+                                          C.byref(m)))
+        assert m.value * stride == len(exp) and np.array_equal(out[: len(exp)], exp), (stride, leaf, chunk)
+
+
 def test_chunked_two_sort_path_still_matches(monkeypatch):
     """Chunked mode normally sorts ONE combined (chunk id, cell) key; grids whose two indices do not
     fit 32 bits fall back to two stable sorts.  Force that path and compare both with the oracle."""
