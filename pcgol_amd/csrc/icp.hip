@@ -138,7 +138,7 @@ __device__ __forceinline__ void reduce_block_range(uint32_t *s_scratch, const fl
 // entries) is walked here.
 constexpr int kIcpGridBlock = 256;
 
-template <bool kMinDist, bool kPlane, bool kGrid>
+template <bool kMinDist, bool kPlane, bool kGrid, bool kSums = true>
 __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     TreeView tv, const float *__restrict__ tx, const float *__restrict__ ty,
     const float *__restrict__ tz, int64_t nt, const IcpState *__restrict__ state,
@@ -155,7 +155,11 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
   constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
   uint32_t slot = 0, left = 0;
   double grid_part = 0.0;
-  if (kGrid) {
+  if (kGrid && !kSums) {
+    slot = block_slot(blockIdx.x, gridDim.x);
+    left = walk_count[slot];  // uniform
+    if (left == 0) return;
+  } else if (kGrid) {
     slot = block_slot(blockIdx.x, gridDim.x);
     left = walk_count[slot];  // uniform
     // this workgroup's share of icp_grid_kernel's rows, folded into its own row in a fixed order:
@@ -242,7 +246,8 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
           pred &= 0x7fffffffu;
         },
         [&](int64_t j, const float4 &bp, float best_d) { emit(r_begin + walk_list[r_begin + j], bp, best_d); },
-        [&](int64_t j, uint32_t leaf) { first_leaf[r_begin + walk_list[r_begin + j]] = leaf | 0x80000000u; });
+        [&](int64_t j, uint32_t leaf) { first_leaf[r_begin + walk_list[r_begin + j]] = kSums ? (leaf | 0x80000000u) : leaf; });
+    if (!kSums) return;
     __threadfence_block();
     __syncthreads();
     reduce_block_range<kPlane, true>(s_stack, tx, ty, tz, nt, chunk_begin, chunk_end, project, m, match, match_id,
@@ -254,6 +259,7 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
         kp.max_dist_sq, kp.min_dist_sq, load_query, emit, [&](int64_t i, uint32_t leaf) { first_leaf[i] = leaf; });
   }
 
+  if (!kSums) return;
   // ---- phase 2: this workgroup's range, fixed order
   __threadfence_block();
   __syncthreads();  // all match[] of the range are written; stacks / queues are free for reuse
@@ -269,7 +275,9 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
 // the target; that kernel walks them and adds their terms to ITS row.
 // kTrace (measurement aid): nothing is stored; trace[0..2] += targets left to the walk, point
 // records read, cell-bound words read.
-template <bool kPlane, bool kTrace = false>
+// kSums false (strict sessions: the sums are formed by strict.hip from match[]): the terms, their LDS
+// reduction and the walk flags are left out.
+template <bool kPlane, bool kTrace = false, bool kSums = true>
 __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
     GridView grid, const float *__restrict__ tx, const float *__restrict__ ty, const float *__restrict__ tz, int64_t nt,
     const IcpState *__restrict__ state, IcpKernelParams kp, float4 *__restrict__ match,
@@ -310,19 +318,19 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
       const uint32_t slot = slot_of_query(nt, i, n_corr_blocks, begin);
       const int64_t r_begin = (int64_t)begin * 64;
       walk_list[r_begin + atomicAdd(&walk_count[slot], 1u)] = (uint32_t)(i - r_begin);
-      first_leaf[i] = 0x80000000u;  // "walked this iteration" (icp_corr_kernel adds its terms)
+      first_leaf[i] = kSums ? 0x80000000u : 0u;  // "walked this iteration" (icp_corr_kernel adds its terms)
     } else {
       const bool found = __float_as_int(best.w) >= 0;
       const float4 bp = make_float4(best.x, best.y, best.z, found ? best_d : -1.0f);
       match[i] = bp;
       if (kPlane) match_id[i] = __float_as_uint(best.w);
-      if (found) {  // correspondence.go:27-29
+      if (found && kSums) {  // correspondence.go:27-29
         if (kPlane) accumulate_plane_terms(acc, x, y, z, bp, normals[__float_as_uint(best.w)]);
         else accumulate_terms(acc, x, y, z, bp, kp);
       }
     }
   }
-  if (kTrace) return;  // uniform
+  if (kTrace || !kSums) return;  // uniform
   // every lane holds the float32 terms of (at most) one pair: through LDS, component k is added
   // up by kSub lanes, each over every kSub-th target, then across those lanes -- a fixed order
   constexpr int kSub = kPlane ? 8 : 16, kRun = kIcpGridBlock / kSub;
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
 // The same iteration on a base handle that has seen DeletePoint: correspondence by the reference's
 // own walk of its patched tree (knn_xwalk.h; one target per lane, static assignment, no hints from
 // the previous iteration -- the tree may have changed in between), then the same phase 2.
-template <bool kMinDist, bool kPlane>
+template <bool kMinDist, bool kPlane, bool kSums = true>
 __global__ __launch_bounds__(kIcpBlock) void icp_corr_xkernel(
     XTreeView xv, const float *__restrict__ tx, const float *__restrict__ ty, const float *__restrict__ tz,
     int64_t nt, const IcpState *__restrict__ state, IcpKernelParams kp, float4 *__restrict__ match,
@@ -389,6 +397,7 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_xkernel(
     match[i] = make_float4(best.x, best.y, best.z, __float_as_int(best.w) >= 0 ? best_d : -1.0f);
     if (kPlane) match_id[i] = __float_as_uint(best.w);
   }
+  if (!kSums) return;
   __threadfence_block();
   __syncthreads();
   reduce_block_range<kPlane>(s_stack, tx, ty, tz, nt, chunk_begin, chunk_end, project, m, match, match_id, normals,
@@ -899,8 +908,14 @@ static pcgx_status enqueue_corr_patched(pcgx_icp_session *s, hipStream_t st) {
   if (s->plane)
     hipLaunchKernelGGL((icp_corr_xkernel<false, true>), dim3(s->grid), dim3(kIcpBlock), lds, st, xv, x, y, z, s->nt,
                        s->d_state, s->kp, s->d_match, s->d_partials, s->d_match_id, (const float4 *)s->d_normals, guard);
+  else if (s->kp.min_dist_sq > 0.0f && s->strict)
+    hipLaunchKernelGGL((icp_corr_xkernel<true, false, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, xv, x, y, z, s->nt,
+                       s->d_state, s->kp, s->d_match, s->d_partials, (uint32_t *)nullptr, (const float4 *)nullptr, guard);
   else if (s->kp.min_dist_sq > 0.0f)
     hipLaunchKernelGGL((icp_corr_xkernel<true, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, xv, x, y, z, s->nt,
+                       s->d_state, s->kp, s->d_match, s->d_partials, (uint32_t *)nullptr, (const float4 *)nullptr, guard);
+  else if (s->strict)
+    hipLaunchKernelGGL((icp_corr_xkernel<false, false, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, xv, x, y, z, s->nt,
                        s->d_state, s->kp, s->d_match, s->d_partials, (uint32_t *)nullptr, (const float4 *)nullptr, guard);
   else
     hipLaunchKernelGGL((icp_corr_xkernel<false, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, xv, x, y, z, s->nt,
@@ -928,6 +943,10 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
       hipLaunchKernelGGL(icp_grid_kernel<true>, dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
                          s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
                          s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
+    else if (s->strict)
+      hipLaunchKernelGGL((icp_grid_kernel<false, false, false>), dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z,
+                         s->nt, s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals,
+                         s->d_first_leaf, s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
     else
       hipLaunchKernelGGL(icp_grid_kernel<false>, dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
                          s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
@@ -937,10 +956,18 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   // it walks next to nothing, and a second pair of events per step costs more than it
   ProfScope prof(grid ? -1 : PCGX_PROF_ICP_WALK, st);
 #define PCGX_LAUNCH_CORR(MD, PL, GR)                                                                                  \
+  do {                                                                                                                \
+  if (s->strict && !PL)                                                                                               \
+    hipLaunchKernelGGL((icp_corr_kernel<MD, false, GR, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, \
+                       s->nt, s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, s->d_match_id,           \
+                       (const float4 *)s->d_normals, s->d_walk_list, s->d_walk_count,                                 \
+                       (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock));                                       \
+  else                                                                                                                \
   hipLaunchKernelGGL((icp_corr_kernel<MD, PL, GR>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,     \
                      s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, s->d_match_id,                   \
                      (const float4 *)s->d_normals, s->d_walk_list, s->d_walk_count,                                  \
-                     (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock))
+                     (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock));                                         \
+  } while (0)
   if (s->plane) {
     if (grid) PCGX_LAUNCH_CORR(false, true, true);
     else PCGX_LAUNCH_CORR(false, true, false);
