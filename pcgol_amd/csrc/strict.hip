@@ -435,21 +435,16 @@ constexpr int kChainBlock = 512;
 
 // a record every lane of the walking wave reads from the same LDS address, as scalars
 __device__ __forceinline__ TileRec load_rec_uniform(const TileRec *p) {
-  const int32_t *w = reinterpret_cast<const int32_t *>(p);
-  int32_t v[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) v[k] = rfl(w[k]);
+  const int4 *w4 = reinterpret_cast<const int4 *>(p);
+  const int4 a = w4[0], b = w4[1], c = w4[2], d = w4[3];  // four 16-byte LDS reads in flight, one wait
   TileRec R;
-  R.key = v[0];
-  R.in = (uint32_t)v[1];
-  R.out = (uint32_t)v[2];
-  R.cons = v[3];
-#pragma unroll
-  for (int r = 0; r < 4; r++) {
-    R.s.c[r] = v[4 + r];
-    R.s.lo[r] = v[8 + r];
-    R.s.hi[r] = v[12 + r];
-  }
+  R.key = rfl(a.x);
+  R.in = (uint32_t)rfl(a.y);
+  R.out = (uint32_t)rfl(a.z);
+  R.cons = rfl(a.w);
+  R.s.c[0] = rfl(b.x); R.s.c[1] = rfl(b.y); R.s.c[2] = rfl(b.z); R.s.c[3] = rfl(b.w);
+  R.s.lo[0] = rfl(c.x); R.s.lo[1] = rfl(c.y); R.s.lo[2] = rfl(c.z); R.s.lo[3] = rfl(c.w);
+  R.s.hi[0] = rfl(d.x); R.s.hi[1] = rfl(d.y); R.s.hi[2] = rfl(d.z); R.s.hi[3] = rfl(d.w);
   return R;
 }
 
@@ -478,6 +473,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(IcpState *__r
                                                                   int fuse_update) {
   __shared__ TileRec s_rec[kChainBlock];  // the tiles' own records
   __shared__ TileRec s_pre[kChainBlock];  // composition from the tile's run head to the tile
+  __shared__ TileRec s_suf[kChainBlock];  // composition from the tile to its run's tail
   __shared__ int16_t s_tail[kChainBlock];  // per wave: the tails of its runs, in order
   __shared__ int16_t s_head[kChainBlock];
   __shared__ int32_t s_count[kChainBlock / 64];
@@ -504,8 +500,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(IcpState *__r
     const int32_t key_prev = __shfl_up(R.key, 1), key_next = __shfl_down(R.key, 1);
     const bool head = lane == 0 || R.key < 0 || R.key != key_prev;
     const bool tail = lane == 63 || R.key < 0 || R.key != key_next;
-    TileRec P = R;
-    int fp = head ? 1 : 0;
+    TileRec P = R, Q = R;
+    int fp = head ? 1 : 0, fq = tail ? 1 : 0;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const TileRec X = shfl_rec(P, lane - o);
@@ -514,8 +510,15 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(IcpState *__r
         P = compose_rec(X, P);
         fp = xf;
       }
+      const TileRec Y = shfl_rec(Q, lane + o);
+      const int yf = __shfl_down(fq, o);
+      if (lane + o < 64 && !fq) {
+        Q = compose_rec(Q, Y);
+        fq = yf;
+      }
     }
     s_pre[threadIdx.x] = P;
+    s_suf[threadIdx.x] = Q;
     const unsigned long long tails = __ballot(tail && valid);
     if (tail && valid) {
       const unsigned long long below = tails & ((1ull << lane) - 1ull);  // the run starts behind the tail before this one
@@ -594,22 +597,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(IcpState *__r
             selfcheck(W, row_terms, s_in, s, chunk + f, chunk + f + 1, 2, lane, s_tile);
             f++;
             if (f > e) break;
-            // the rest of the run in one step: tiles f .. e composed on the spot (ordered tree over the lanes)
-            TileRec Sf;
-            {
-              TileRec Y = s_rec[f + lane <= e ? f + lane : e];
-              if (f + lane > e) {
-                Y.key = -3;  // identity
-                Y.s = summary_identity();
-              }
-#pragma unroll
-              for (int o = 1; o < 64; o <<= 1) {
-                const TileRec Z = shfl_rec(Y, lane + o);
-                if ((lane & (2 * o - 1)) == 0 && Z.key != -3) Y = Y.key == -3 ? Z : compose_rec(Y, Z);
-              }
-              Sf = shfl_rec(Y, 0);
-              Sf.key = rfl(Sf.key);
-            }
+            const TileRec Sf = load_rec_uniform(&s_suf[f]);  // the rest of the run in one step
             const uint32_t s_in2 = s;
             if ((Sf.key >= 0 && apply(s, Sf.key, Sf.s)) || apply_point(s, Sf)) {
               selfcheck(W, row_terms, s_in2, s, chunk + f, chunk + e + 1, 3, lane, s_tile);
