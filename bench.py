@@ -47,10 +47,11 @@ def load_visits():
 def load_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/rNN*_pmc.json,
     written by profiles/collect.sh: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this
-    same bench command).  rocprofv3 reports both in KiB; FETCH_SIZE is doubled for the kernels the
-    summary marks as wide streaming readers only (gfx950 tallies their 128-byte requests at 64 bytes,
-    MI355X_MICROARCH.md; profiles/fetch_probe.json has the check on a streaming copy and on a 16-byte
-    gather), WRITE_SIZE is exact.  PMC collection cannot run inside the timed process, hence the
+    same bench command).  rocprofv3 reports both in KiB; FETCH_SIZE is doubled for wide streaming reads
+    only (gfx950 tallies their 128-byte requests at 64 bytes, MI355X_MICROARCH.md); a random gather is
+    reported at the sector bytes it costs (profiles/rNN_fetch_probe.json: the check on a streaming
+    copy, a 16-byte and a 4-byte gather), so gather kernels take the counter as it is plus half of
+    their known coalesced reads (summarize.py); WRITE_SIZE is exact.  PMC collection cannot run inside the timed process, hence the
     committed summary."""
     import glob
     for p in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc.json")))):
@@ -62,7 +63,7 @@ def load_traffic(kernel):
         for name, c in d.items():
             if kernel in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 scale = float(c.get("fetch_scale", 2.0))
-                fetch = c["FETCH_SIZE"]["mean_per_dispatch"] * 1024.0 * scale
+                fetch = c["FETCH_SIZE"]["mean_per_dispatch"] * 1024.0 * scale + float(c.get("fetch_add_bytes", 0.0))
                 write = c["WRITE_SIZE"]["mean_per_dispatch"] * 1024.0
                 return fetch + write, os.path.basename(p)
     return None, None
