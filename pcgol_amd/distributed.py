@@ -172,6 +172,9 @@ class ShardedIcp:
         self.torch = torch
         self.group = group
         self.comm = comm
+        # the library works on ONE device per process: bind it to torch's current one (fails loudly if it
+        # was initialised on another)
+        L.check(L.lib().pcgx_init(torch.cuda.current_device()))
         # A stream of our own: the kernels are launched on it through the C ABI and the
         # all-reduce is issued while it is torch's current stream, so RCCL orders itself after
         # the partial sums and the update kernel after RCCL.  (torch's default stream has

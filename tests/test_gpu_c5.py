@@ -101,3 +101,25 @@ def test_c5_partial_sums_reproducible_over_a_fit(c5):
     assert runs[0][0][0][9] > 0.99 * len(tile)   # pairs
     inv = np.linalg.inv(synth.icp_pose().astype(np.float64).reshape(4, 4).T).T.reshape(-1)
     assert np.max(np.abs(runs[0][1].astype(np.float64) - inv)) < 0.02
+
+
+def test_c5_strict_sums_on_the_tile(c5, monkeypatch):
+    """The parallel strict sums over 8M targets (3907 tiles per sum: eight chunks of the chain kernel,
+    62 level-1 bins) against the one-wave chain, three iterations, with the in-kernel self-check."""
+    monkeypatch.setenv("PCGX_STRICT_SELFCHECK", "1")
+    base, tile, tree = c5
+    cfg = dict(MaxDist=0.5, MinPairs=6, Weight=np.full(6, 0.3, np.float32), Threshold=np.full(6, -1.0, np.float32),
+               MaxIteration=20)
+    a = icp.IcpSession(tree, tile, **cfg)
+    b = icp.IcpSession(tree, tile, **cfg)
+    a.set_strict(1)
+    b.set_strict(2)
+    for k in range(3):
+        a.step()
+        b.step()
+        sa, sb = a.read_sums(), b.read_sums()
+        assert np.array_equal(sa.view(np.uint64), sb.view(np.uint64)), (k, sa, sb)
+        st = a.strict_stats()
+        assert not st[12:16].any() and st[6] == 0 and st[7] == 0, (k, st[:16])
+    a.close()
+    b.close()
