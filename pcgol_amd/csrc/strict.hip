@@ -256,7 +256,8 @@ __device__ __forceinline__ uint32_t serial_leaf(uint32_t s, const float *t, int 
 }
 
 // all 2048 additions of a tile, one after the other: the terms go to LDS in their order and every
-// lane runs the same chain over them (broadcast reads; the loads run ahead of the dependent adds)
+// lane runs the same chain over them (broadcast reads; the next 32 terms are read while the 32
+// additions on the current ones run)
 __device__ __forceinline__ uint32_t serial_tile(uint32_t s, const float *t, int lane, float *lds /* [kTile] of this wave */) {
   float4 *w4 = reinterpret_cast<float4 *>(lds) + lane * (kLeaf / 4);
 #pragma unroll
@@ -265,22 +266,37 @@ __device__ __forceinline__ uint32_t serial_tile(uint32_t s, const float *t, int 
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
   const float4 *r4 = reinterpret_cast<const float4 *>(lds);
   float x = u2f(s);
-  for (int k = 0; k < kTile / 4; k += 8) {
-    float4 a[8];
+  float4 a[8], b[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) a[u] = r4[k + u];
+  for (int u = 0; u < 8; u++) a[u] = r4[u];
+  for (int k = 0; k < kTile / 4; k += 16) {
+#pragma unroll
+    for (int u = 0; u < 8; u++) b[u] = r4[k + 8 + u];
 #pragma unroll
     for (int u = 0; u < 8; u++) x = (((x + a[u].x) + a[u].y) + a[u].z) + a[u].w;
+    const int kn = k + 16 < kTile / 4 ? k + 16 : 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] = r4[kn + u];
+#pragma unroll
+    for (int u = 0; u < 8; u++) x = (((x + b[u].x) + b[u].y) + b[u].z) + b[u].w;
   }
+  __builtin_amdgcn_wave_barrier();
   return f2u(x);
 }
+
+// tiles at the start of every sum that are added up term by term in the summary kernel (by the wave
+// of tile 0, one after the other, beside the other waves' work).  A sum starts at 0.0f and runs
+// through a new binade every few terms, so no window holds its first tile.  More than one such tile
+// was measured (4: the summary kernel's slowest wave then outlasts the rest of it, 151.9 vs 147.7 us
+// per iteration at C4; the tiles where a sum hovers around zero are not the first ones)
+constexpr int kExactTiles = 1;
 
 __global__ __launch_bounds__(256) void strict_sum_kernel(const IcpState *__restrict__ state, StrictWork W) {
   if (state->done) return;
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= kStrictRows * W.ntiles) return;  // whole wave
-  // the nine first tiles take longest (their 2048 additions are carried out): they go first
+  // the nine waves of the first tiles take longest (they carry out kExactTiles x 2048 additions): they go first
   int row;
   int64_t tile;
   if (w < kStrictRows) {
@@ -295,16 +311,21 @@ __global__ __launch_bounds__(256) void strict_sum_kernel(const IcpState *__restr
   load_leaf(W.terms + (int64_t)row * W.nt_pad, tile, lane, t);
   TileRec T;
   T.s = summary_identity();
-  if (tile == 0) {
-    // the first tile starts from the one state known in advance (0.0f, evaluator.go:122) and runs
-    // through a new binade every few terms: its additions are simply carried out, here, off the
-    // chain kernel's critical path -> point record
-    const uint32_t s = serial_tile(f2u(0.0f), t, lane, s_tile[threadIdx.x >> 6]);
-    T.key = -1;
-    T.in = f2u(0.0f);
-    T.out = s;
-    T.cons = 1;
-    if (lane == 0) W.recs[row * W.ntiles] = T;
+  if (tile < kExactTiles) {
+    if (tile != 0) return;  // done by the wave of tile 0
+    // from the one state known in advance (0.0f, evaluator.go:122) the additions are simply carried
+    // out, here, off the chain kernel's critical path -> point records
+    uint32_t state = f2u(0.0f);
+    for (int64_t k = 0; k < kExactTiles && k < W.ntiles; k++) {
+      if (k > 0) load_leaf(W.terms + (int64_t)row * W.nt_pad, k, lane, t);
+      const uint32_t next = serial_tile(state, t, lane, s_tile[threadIdx.x >> 6]);
+      T.key = -1;
+      T.in = state;
+      T.out = next;
+      T.cons = 1;
+      if (lane == 0) W.recs[row * W.ntiles + k] = T;
+      state = next;
+    }
     return;
   }
   const double P0 = tile_prefix(W.tile_sum, W.bin_sum, W.ntiles, W.nbins, row, tile, lane);
@@ -622,6 +643,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(IcpState *__r
         atomicAdd(&W.dbg[4], n_recfail);
         atomicAdd(&W.dbg[8], (unsigned long long)(t_b - t_a));
         atomicAdd(&W.dbg[9], (unsigned long long)(wall_clock64() - t_b));
+        atomicMax(&W.dbg[14 + 32], (unsigned long long)(wall_clock64() - t_b));   // slowest row of the launch
       }
     }
     __syncthreads();

@@ -374,12 +374,15 @@ inline float ss_host_model(const float *terms_in, int64_t n, int64_t stats[8], i
       const float *tt = terms + k * kTile;
       TileRec T;
       memset(&T, 0, sizeof T);
-      if (k == 0) {  // the first tile starts from 0.0f: its additions are simply carried out -> point record
-        float x = 0.0f;
+      if (k < 1) {  // the first tiles (kExactTiles of strict.hip): added up from 0.0f -> point records
+        static thread_local float carry;
+        if (k == 0) carry = 0.0f;
+        float x = carry;
         for (int i = 0; i < kTile; i++) x = x + tt[i];
         T.key = -1;
-        T.in = f2u(0.0f);
+        T.in = f2u(carry);
         T.out = f2u(x);
+        carry = x;
         T.cons = 1;
         stats[1]++;
         recs[k] = T;

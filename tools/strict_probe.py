@@ -29,7 +29,7 @@ for k in range(c["max_iteration"]):
     ok = np.array_equal(sa.view(np.uint64), sb.view(np.uint64))
     bad += not ok
     print("iter %2d %s runs %d runfail %d resolved %d (no aux %d) serial leaves %d recfail %d | us/row: phaseA %.1f walk %.1f (resolve aux %.1f serial %.1f)" % (
-        k, "OK " if ok else "MISMATCH", st[0], st[1], st[2], st[5], st[3], st[4], st[8] / 900.0, st[9] / 900.0, st[10] / 900.0, st[11] / 900.0), "selfcheck bad: run %d prefix %d tile %d suffix %d; scan != serial composition %d, other result %d" % (tuple(st[12:16]) + (st[6], st[7])))
+        k, "OK " if ok else "MISMATCH", st[0], st[1], st[2], st[5], st[3], st[4], st[8] / 900.0, st[9] / 900.0, st[10] / 900.0, st[11] / 900.0), "slowest row walk %.1f us" % (st[46] / 100.0), "selfcheck bad: run %d prefix %d tile %d suffix %d; scan != serial composition %d, other result %d" % (tuple(st[12:16]) + (st[6], st[7])))
     for q in range(2):
         d = st[16 + 16 * q: 32 + 16 * q]
         if d[0] or d[1]:
