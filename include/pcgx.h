@@ -115,15 +115,17 @@ PCGX_API pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_
                                            uint64_t stats32[32]);
 
 /* Tuning aid (not part of the drop-in surface): out = {queries of the batch the grid pass leaves to
- * the tree walk, grid cells, 1000 x mean number of other points in a point's cell, grid in use, -,
+ * the tree walk, grid cells, 1000 x mean number of other points in a point's cell, grid in use,
+ * lane-slots the scan loops ran (64 per round of 4 records per wave, idle lanes included),
  * queries per reason 1..7 (csrc/knn_grid.h), point records read, cell-bound words read}. */
 PCGX_API pcgx_status pcgx_debug_grid_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
                                            int64_t out[14]);
 
 /* Measurement aid: what the grid pass of the session's NEXT iteration would read, without changing
- * the session: out = {targets, targets left to the walk, point records read, cell-bound words read}. */
+ * the session: out = {targets, targets left to the walk, point records read, cell-bound words read,
+ * lane-slots its scan loops run (64 per round of 4 records per wave, idle lanes included)}. */
 typedef struct pcgx_icp_session pcgx_icp_session;
-PCGX_API pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream, int64_t out[4]);
+PCGX_API pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream, int64_t out[5]);
 
 /* Measurement aid: counters of the strict sums (set_strict 1) since the last call: out = {runs
  * applied, runs whose record did not cover the state, tiles recomputed exactly, leaves of those added

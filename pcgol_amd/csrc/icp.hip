@@ -313,6 +313,9 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
       if (v == GRID_WALK) atomicAdd(&trace[0], 1ull);
       atomicAdd(&trace[1], (unsigned long long)tr.points);
       atomicAdd(&trace[2], (unsigned long long)tr.words);
+      if (tr.wave_slots) atomicAdd(&trace[3], (unsigned long long)tr.wave_slots);
+      atomicAdd(&trace[4 + (tr.rounds4 < 0 ? 0 : min(tr.rounds4 + 1, 15))], 1ull);
+      atomicAdd(&trace[20 + (tr.rounds9 < 0 ? 0 : min(tr.rounds9 + 1, 15))], 1ull);
     } else if (v == GRID_WALK) {
       uint32_t begin;
       const uint32_t slot = slot_of_query(nt, i, n_corr_blocks, begin);
@@ -1224,22 +1227,22 @@ extern "C" pcgx_status pcgx_icp_pairs(const pcgx_kdtree *base, const float *targ
 }
 
 // Measurement aid: see include/pcgx.h.
-extern "C" pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream, int64_t out[4]) {
+extern "C" pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream, int64_t out[5]) {
   PCGX_API_LOCK();
   if (!s || !out) return fail(PCGX_E_INVALID, "pcgx_debug_icp_grid_stats: NULL argument");
   out[0] = s->nt;
-  out[1] = out[2] = out[3] = 0;
+  out[1] = out[2] = out[3] = out[4] = 0;
   if (s->patched || !grid_enabled(s->base) || s->kp.min_dist_sq > 0.0f || s->nt == 0) return PCGX_OK;
   hipStream_t st = pick_stream(stream);
   unsigned long long *d_trace = nullptr;
-  PCGX_HIP_TRY(dev_cache_alloc((void **)&d_trace, 4 * sizeof(unsigned long long)));
-  PCGX_HIP_TRY(hipMemsetAsync(d_trace, 0, 4 * sizeof(unsigned long long), st));
+  PCGX_HIP_TRY(dev_cache_alloc((void **)&d_trace, 36 * sizeof(unsigned long long)));
+  PCGX_HIP_TRY(hipMemsetAsync(d_trace, 0, 36 * sizeof(unsigned long long), st));
   const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
   const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
   hipLaunchKernelGGL((icp_grid_kernel<false, true>), dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
                      s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
                      s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials, d_trace);
-  unsigned long long h[4];
+  unsigned long long h[36];
   hipError_t e = hipMemcpyAsync(h, d_trace, sizeof h, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   dev_cache_free(d_trace);
@@ -1247,5 +1250,12 @@ extern "C" pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stre
   out[1] = (int64_t)h[0];
   out[2] = (int64_t)h[1];
   out[3] = (int64_t)h[2];
+  out[4] = (int64_t)h[3];
+  if (getenv("PCGX_GRID_TRACE_PRINT"))
+    for (int b = 0; b < 2; b++) {
+      fprintf(stderr, "%d-segment scan per target: none %.4f, rounds of 4:", b ? 9 : 4, (double)h[4 + 16 * b] / (double)s->nt);
+      for (int k = 1; k < 16; k++) fprintf(stderr, " %d:%.4f", k - 1, (double)h[4 + 16 * b + k] / (double)s->nt);
+      fprintf(stderr, "\n");
+    }
   return PCGX_OK;
 }

@@ -62,15 +62,14 @@ struct GridBest {
 __device__ __forceinline__ void grid_take(GridBest &b, const float4 &p, float qx, float qy, float qz, bool valid) {
   const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
   const float d = (dx * dx + dy * dy) + dz * dz;  // the reference's expression (mat/vec3.go:18-20,38-40)
-  if (valid) {
-    if (d < b.d) {
-      b.p = p;
-      b.d = d;
-      b.tie = false;
-    } else if (d == b.d) {
-      b.tie = true;
-    }
-  }
+  // selects, not branches: the lanes of a wave rarely agree on which of them improves
+  const bool lt = valid & (d < b.d), eq = valid & (d == b.d);
+  b.p.x = lt ? p.x : b.p.x;
+  b.p.y = lt ? p.y : b.p.y;
+  b.p.z = lt ? p.z : b.p.z;
+  b.p.w = lt ? p.w : b.p.w;
+  b.d = lt ? d : b.d;
+  b.tie = (b.tie & !lt) | eq;
 }
 
 // start[row + cx - 1 .. row + cx + 2]: the bounds of the three cells cx - 1 .. cx + 1 of a row in one
@@ -92,6 +91,9 @@ struct GridTrace {
   int why = 0;
   uint32_t points = 0;  // float4 point records read
   uint32_t words = 0;   // uint32 cell bounds read
+  uint32_t wave_slots = 0;  // in the first active lane of a scan: 64 x the rounds of the scan loop x 4 (what the wave pays for)
+  int rounds9 = -1, rounds4 = -1;  // rounds of 4 of this lane's (last) 9- / 4-segment scan (-1: none)
+  uint32_t slots_n[3] = {0, 0, 0}, points_n[3] = {0, 0, 0};  // the same / the records, per kind of scan (4, 9, 5 segments)
 };
 
 // The points of up to N segments [seg_s[j], seg_e[j]) of pts[] as ONE sequence, four loads in flight.
@@ -109,7 +111,24 @@ __device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint
     total += seg_e[j] - seg_s[j];
     if (tr && seg_e[j] != seg_s[j]) tr->words += 2;  // (a row without cells to scan costs no useful word)
   }
-  if (tr) tr->points += total;
+  if (tr) {
+    tr->points += total;
+    unsigned long long act = __ballot(1);
+    const int first_lane = __ffsll(act) - 1;
+    uint32_t mx = 0;
+    while (act) {
+      const int l = __ffsll(act) - 1;
+      mx = max(mx, (uint32_t)__builtin_amdgcn_readlane((int)((total + 3) / 4 * 4), l));
+      act &= act - 1;
+    }
+    if ((int)(threadIdx.x & 63) == first_lane) {
+      tr->wave_slots += 64 * mx;
+      tr->slots_n[N == 4 ? 0 : (N == 9 ? 1 : 2)] += 64 * mx;
+    }
+    tr->points_n[N == 4 ? 0 : (N == 9 ? 1 : 2)] += total;
+    if (N == 9) tr->rounds9 = (int)((total + 3) / 4);
+    if (N == 4) tr->rounds4 = (int)((total + 3) / 4);
+  }
   for (uint32_t f0 = 0; f0 < total; f0 += 4) {
     float4 p[4];
     bool ok[4];
@@ -137,25 +156,42 @@ __device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint
 // time), then whatever else of the 3 x 3 x 3 block the distance found there still covers; a
 // region reaching beyond that block (sparse spots, queries off a thin cloud) is scanned slab by slab
 // up to 9 x 9 x 9 cells.
-__device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const float qx, const float qy, const float qz,
-                                                    const float max_range_sq, const float ub, float4 &best,
-                                                    float &best_d, GridTrace *tr = nullptr) {
+//
+// In three steps, so that a kernel may hand the second scan of its few queries that need one to
+// lanes of their own (grid_nearest_kernel): grid_nearest_begin (hinted scan, or the octant and the
+// segments of what else must be read), the scan of GridSearch::seg_s/seg_e when `more`, and
+// grid_nearest_end (the rest: guesses checked, sparse spots, the verdict).
+struct GridSearch {
+  GridBest b;
+  GridBox box;    // cells that hold every point with DistSq <= min(b.d, bound) once the scans are done
+  float bound;    // the answer is a point with DistSq <= bound (ub is attained by a real point)
+  bool early;     // verdict known in grid_nearest_begin (GRID_WALK)
+  bool cold;      // no useful hint: octant first
+  bool guess;     // the block was a guess: grid_nearest_end checks that it covers what was found in it
+  bool more;      // seg_s / seg_e hold cells still to be scanned
+  uint32_t seg_s[9], seg_e[9];
+};
+
 #define PCGX_GRID_WHY(code) do { if (tr) tr->why = (code); } while (0)
+
+__device__ __forceinline__ void grid_nearest_begin(const GridView &g, const float qx, const float qy, const float qz,
+                                                   const float max_range_sq, const float ub, GridSearch &S,
+                                                   GridTrace *tr = nullptr) {
+  S.early = S.cold = S.guess = S.more = false;
+  S.b.p = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+  S.b.d = __builtin_inff();
+  S.b.tie = false;
+  S.bound = fminf(ub, max_range_sq);
   // non-finite queries: NaN distances follow the walk's comparisons, not an ordering
   if (!(fabsf(qx) < 3.0e38f && fabsf(qy) < 3.0e38f && fabsf(qz) < 3.0e38f) || max_range_sq != max_range_sq) {
     PCGX_GRID_WHY(1);  // (a NaN maxRange^2 compares false with everything: the walk's rules decide)
-    return GRID_WALK;
+    S.early = true;
+    return;
   }
-  // the answer is a point with DistSq <= bound (ub is attained by a real point)
-  const float bound = fminf(ub, max_range_sq);
-  const int cx = grid_cell(qx, g.lo[0], g.inv_h, g.nx), cy = grid_cell(qy, g.lo[1], g.inv_h, g.ny),
-            cz = grid_cell(qz, g.lo[2], g.inv_h, g.nz);
-  GridBest b;
-  b.p = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-  b.d = __builtin_inff();
-  b.tie = false;
-  GridBox box;  // cells that hold every point with DistSq <= min(b.d, bound) once `covered`
-  bool covered = false, wide = false;
+  const float bound = S.bound;
+  GridBest &b = S.b;
+  GridBox &box = S.box;
+  bool covered = false;
   if (bound < 3.0e38f) {
     box = grid_cover(g, qx, qy, qz, bound);
     covered = box.x1 - box.x0 < 3 && box.y1 - box.y0 < 3 && box.z1 - box.z0 < 3;
@@ -186,79 +222,96 @@ __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const flo
       }
       grid_scan_segments<9>(g, seg_s, seg_e, qx, qy, qz, b, tr);
     }
-  } else {
-    // ---- cold: the octant of the 3 x 3 x 3 block the query sits in, 2 x 2 x 2 cells (fewer at the
-    //      grid's border).  Rows (cy, cz), (cy + sy, cz), (cy, cz + sz), (cy + sy, cz + sz).
+    return;
+  }
+  // ---- cold: the octant of the 3 x 3 x 3 block the query sits in, 2 x 2 x 2 cells (fewer at the
+  //      grid's border).  Rows (cy, cz), (cy + sy, cz), (cy, cz + sz), (cy + sy, cz + sz).
+  S.cold = true;
+  const int cx = grid_cell(qx, g.lo[0], g.inv_h, g.nx), cy = grid_cell(qy, g.lo[1], g.inv_h, g.ny),
+            cz = grid_cell(qz, g.lo[2], g.inv_h, g.nz);
+  const int bx0 = max(cx - 1, 0), bx1 = min(cx + 1, g.nx - 1), by0 = max(cy - 1, 0), by1 = min(cy + 1, g.ny - 1),
+            bz0 = max(cz - 1, 0), bz1 = min(cz + 1, g.nz - 1);
+  const float ux = (qx - g.lo[0]) * g.inv_h - (float)cx, uy = (qy - g.lo[1]) * g.inv_h - (float)cy,
+              uz = (qz - g.lo[2]) * g.inv_h - (float)cz;
+  const int sx = ux < 0.5f ? -1 : 1, sy = uy < 0.5f ? -1 : 1, sz = uz < 0.5f ? -1 : 1;  // any choice is valid
+  const int ox0 = max(min(cx, cx + sx), bx0), ox1 = min(max(cx, cx + sx), bx1);
+  const bool y_on = cy + sy >= by0 && cy + sy <= by1, z_on = cz + sz >= bz0 && cz + sz <= bz1;
+  const int oy0 = y_on ? min(cy, cy + sy) : cy, oy1 = y_on ? max(cy, cy + sy) : cy;
+  const int oz0 = z_on ? min(cz, cz + sz) : cz, oz1 = z_on ? max(cz, cz + sz) : cz;
+  auto load_quad = [&](int y, int z, bool on) {
+    GridQuad r;
+    if (on) r = *reinterpret_cast<const GridQuad *>(g.start + ((z * g.ny + y) * g.nx + cx - 1));
+    else r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
+    return r;
+  };
+  // cells [xa, xb] (within cx - 1 .. cx + 1) of a row
+  auto range = [&](const GridQuad &r, int xa, int xb, bool on, uint32_t &s2, uint32_t &e2) {
+    on = on && xa <= xb;
+    s2 = on ? grid_quad_at(r, xa - (cx - 1)) : 0u;
+    e2 = on ? grid_quad_at(r, xb + 1 - (cx - 1)) : 0u;
+  };
+  const GridQuad r00 = load_quad(cy, cz, true), r10 = load_quad(cy + sy, cz, y_on),
+                 r01 = load_quad(cy, cz + sz, z_on), r11 = load_quad(cy + sy, cz + sz, y_on && z_on);
+  {
+    uint32_t seg_s[4], seg_e[4];
+    range(r00, ox0, ox1, true, seg_s[0], seg_e[0]);
+    range(r10, ox0, ox1, y_on, seg_s[1], seg_e[1]);
+    range(r01, ox0, ox1, z_on, seg_s[2], seg_e[2]);
+    range(r11, ox0, ox1, y_on && z_on, seg_s[3], seg_e[3]);
+    grid_scan_segments<4>(g, seg_s, seg_e, qx, qy, qz, b, tr);
+  }
+  const float lim = fminf(b.d, bound);
+  S.guess = true;  // nothing found and no bound: the whole block, checked afterwards
+  box.x0 = bx0; box.x1 = bx1; box.y0 = by0; box.y1 = by1; box.z0 = bz0; box.z1 = bz1;
+  if (lim < 3.0e38f) {
+    const GridBox need = grid_cover(g, qx, qy, qz, lim);
+    // a far point in a thinly filled octant may cover more than the block: the rest of the block
+    // most likely holds a nearer one, so that stays a guess as well
+    if (need.x0 >= bx0 && need.x1 <= bx1 && need.y0 >= by0 && need.y1 <= by1 && need.z0 >= bz0 && need.z1 <= bz1) {
+      box = need;
+      S.guess = false;
+    }
+  }
+  S.more = box.x0 < ox0 || box.x1 > ox1 || box.y0 < oy0 || box.y1 > oy1 || box.z0 < oz0 || box.z1 > oz1;
+  if (S.more) {
+    // the cells of `box` outside the octant: the far cell in x of the octant's rows, and the five
+    // rows on the far side in y or z
+    const int fy = cy - sy, fz = cz - sz;  // far rows (may lie outside the grid or the box)
+    auto in_box = [&](int y, int z) { return y >= box.y0 && y <= box.y1 && z >= box.z0 && z <= box.z1; };
+    const bool f0 = in_box(fy, cz - 1), f1 = in_box(fy, cz), f2 = in_box(fy, cz + 1), f3 = in_box(cy, fz),
+               f4 = in_box(cy + sy, fz);
+    const GridQuad q0 = load_quad(fy, cz - 1, f0), q1 = load_quad(fy, cz, f1), q2 = load_quad(fy, cz + 1, f2),
+                   q3 = load_quad(cy, fz, f3), q4 = load_quad(cy + sy, fz, f4);
+    int xa = box.x0, xb = box.x1;  // what is left of the octant's rows: beyond [ox0, ox1]
+    if (sx < 0) xa = max(xa, ox1 + 1);
+    else xb = min(xb, ox0 - 1);
+    range(r00, xa, xb, in_box(cy, cz), S.seg_s[0], S.seg_e[0]);
+    range(r10, xa, xb, y_on && in_box(cy + sy, cz), S.seg_s[1], S.seg_e[1]);
+    range(r01, xa, xb, z_on && in_box(cy, cz + sz), S.seg_s[2], S.seg_e[2]);
+    range(r11, xa, xb, y_on && z_on && in_box(cy + sy, cz + sz), S.seg_s[3], S.seg_e[3]);
+    range(q0, box.x0, box.x1, f0, S.seg_s[4], S.seg_e[4]);
+    range(q1, box.x0, box.x1, f1, S.seg_s[5], S.seg_e[5]);
+    range(q2, box.x0, box.x1, f2, S.seg_s[6], S.seg_e[6]);
+    range(q3, box.x0, box.x1, f3, S.seg_s[7], S.seg_e[7]);
+    range(q4, box.x0, box.x1, f4, S.seg_s[8], S.seg_e[8]);
+  }
+}
+
+__device__ __forceinline__ GridVerdict grid_nearest_end(const GridView &g, const float qx, const float qy, const float qz,
+                                                        const float max_range_sq, GridSearch &S, float4 &best,
+                                                        float &best_d, GridTrace *tr = nullptr) {
+  if (S.early) return GRID_WALK;
+  GridBest &b = S.b;
+  GridBox &box = S.box;
+  const float bound = S.bound;
+  if (S.cold) {
+    const int cx = grid_cell(qx, g.lo[0], g.inv_h, g.nx), cy = grid_cell(qy, g.lo[1], g.inv_h, g.ny),
+              cz = grid_cell(qz, g.lo[2], g.inv_h, g.nz);
     const int bx0 = max(cx - 1, 0), bx1 = min(cx + 1, g.nx - 1), by0 = max(cy - 1, 0), by1 = min(cy + 1, g.ny - 1),
               bz0 = max(cz - 1, 0), bz1 = min(cz + 1, g.nz - 1);
-    const float ux = (qx - g.lo[0]) * g.inv_h - (float)cx, uy = (qy - g.lo[1]) * g.inv_h - (float)cy,
-                uz = (qz - g.lo[2]) * g.inv_h - (float)cz;
-    const int sx = ux < 0.5f ? -1 : 1, sy = uy < 0.5f ? -1 : 1, sz = uz < 0.5f ? -1 : 1;  // any choice is valid
-    const int ox0 = max(min(cx, cx + sx), bx0), ox1 = min(max(cx, cx + sx), bx1);
-    const bool y_on = cy + sy >= by0 && cy + sy <= by1, z_on = cz + sz >= bz0 && cz + sz <= bz1;
-    const int oy0 = y_on ? min(cy, cy + sy) : cy, oy1 = y_on ? max(cy, cy + sy) : cy;
-    const int oz0 = z_on ? min(cz, cz + sz) : cz, oz1 = z_on ? max(cz, cz + sz) : cz;
-    auto load_quad = [&](int y, int z, bool on) {
-      GridQuad r;
-      if (on) r = *reinterpret_cast<const GridQuad *>(g.start + ((z * g.ny + y) * g.nx + cx - 1));
-      else r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0u;
-      return r;
-    };
-    // cells [xa, xb] (within cx - 1 .. cx + 1) of a row
-    auto range = [&](const GridQuad &r, int xa, int xb, bool on, uint32_t &s2, uint32_t &e2) {
-      on = on && xa <= xb;
-      s2 = on ? grid_quad_at(r, xa - (cx - 1)) : 0u;
-      e2 = on ? grid_quad_at(r, xb + 1 - (cx - 1)) : 0u;
-    };
-    const GridQuad r00 = load_quad(cy, cz, true), r10 = load_quad(cy + sy, cz, y_on),
-                   r01 = load_quad(cy, cz + sz, z_on), r11 = load_quad(cy + sy, cz + sz, y_on && z_on);
-    {
-      uint32_t seg_s[4], seg_e[4];
-      range(r00, ox0, ox1, true, seg_s[0], seg_e[0]);
-      range(r10, ox0, ox1, y_on, seg_s[1], seg_e[1]);
-      range(r01, ox0, ox1, z_on, seg_s[2], seg_e[2]);
-      range(r11, ox0, ox1, y_on && z_on, seg_s[3], seg_e[3]);
-      grid_scan_segments<4>(g, seg_s, seg_e, qx, qy, qz, b, tr);
-    }
-    const float lim = fminf(b.d, bound);
-    bool guess = true;  // nothing found and no bound: the whole block, checked afterwards
-    box.x0 = bx0; box.x1 = bx1; box.y0 = by0; box.y1 = by1; box.z0 = bz0; box.z1 = bz1;
-    if (lim < 3.0e38f) {
-      const GridBox need = grid_cover(g, qx, qy, qz, lim);
-      // a far point in a thinly filled octant may cover more than the block: the rest of the block
-      // most likely holds a nearer one, so that stays a guess as well
-      if (need.x0 >= bx0 && need.x1 <= bx1 && need.y0 >= by0 && need.y1 <= by1 && need.z0 >= bz0 && need.z1 <= bz1) {
-        box = need;
-        guess = false;
-      }
-    }
-    const bool more = box.x0 < ox0 || box.x1 > ox1 || box.y0 < oy0 || box.y1 > oy1 || box.z0 < oz0 || box.z1 > oz1;
-    if (more) {
-      // the cells of `box` outside the octant: the far cell in x of the octant's rows, and the five
-      // rows on the far side in y or z
-      const int fy = cy - sy, fz = cz - sz;  // far rows (may lie outside the grid or the box)
-      auto in_box = [&](int y, int z) { return y >= box.y0 && y <= box.y1 && z >= box.z0 && z <= box.z1; };
-      const bool f0 = in_box(fy, cz - 1), f1 = in_box(fy, cz), f2 = in_box(fy, cz + 1), f3 = in_box(cy, fz),
-                 f4 = in_box(cy + sy, fz);
-      const GridQuad q0 = load_quad(fy, cz - 1, f0), q1 = load_quad(fy, cz, f1), q2 = load_quad(fy, cz + 1, f2),
-                     q3 = load_quad(cy, fz, f3), q4 = load_quad(cy + sy, fz, f4);
-      int xa = box.x0, xb = box.x1;  // what is left of the octant's rows: beyond [ox0, ox1]
-      if (sx < 0) xa = max(xa, ox1 + 1);
-      else xb = min(xb, ox0 - 1);
-      uint32_t seg_s[9], seg_e[9];
-      range(r00, xa, xb, in_box(cy, cz), seg_s[0], seg_e[0]);
-      range(r10, xa, xb, y_on && in_box(cy + sy, cz), seg_s[1], seg_e[1]);
-      range(r01, xa, xb, z_on && in_box(cy, cz + sz), seg_s[2], seg_e[2]);
-      range(r11, xa, xb, y_on && z_on && in_box(cy + sy, cz + sz), seg_s[3], seg_e[3]);
-      range(q0, box.x0, box.x1, f0, seg_s[4], seg_e[4]);
-      range(q1, box.x0, box.x1, f1, seg_s[5], seg_e[5]);
-      range(q2, box.x0, box.x1, f2, seg_s[6], seg_e[6]);
-      range(q3, box.x0, box.x1, f3, seg_s[7], seg_e[7]);
-      range(q4, box.x0, box.x1, f4, seg_s[8], seg_e[8]);
-      grid_scan_segments<9>(g, seg_s, seg_e, qx, qy, qz, b, tr);
-    }
+    bool wide = false;
     bool guess5 = false;  // nothing in the 27 cells: the 125 around the query, checked afterwards
-    if (guess) {  // the block was a guess: it must cover what was found in it
+    if (S.guess) {  // the block was a guess: it must cover what was found in it
       if (b.d < 3.0e38f) {
         box = grid_cover(g, qx, qy, qz, fminf(b.d, bound));
         wide = box.x0 < bx0 || box.x1 > bx1 || box.y0 < by0 || box.y1 > by1 || box.z0 < bz0 || box.z1 > bz1;
@@ -325,7 +378,16 @@ __device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const flo
   if (bound == max_range_sq) return GRID_NONE;  // nothing within maxRange^2
   PCGX_GRID_WHY(6);
   return GRID_WALK;  // ub promised a point the scan did not see: cannot happen, let the walk answer
+}
 #undef PCGX_GRID_WHY
+
+__device__ __forceinline__ GridVerdict grid_nearest(const GridView &g, const float qx, const float qy, const float qz,
+                                                    const float max_range_sq, const float ub, float4 &best,
+                                                    float &best_d, GridTrace *tr = nullptr) {
+  GridSearch S;
+  grid_nearest_begin(g, qx, qy, qz, max_range_sq, ub, S, tr);
+  if (S.more) grid_scan_segments<9>(g, S.seg_s, S.seg_e, qx, qy, qz, S.b, tr);
+  return grid_nearest_end(g, qx, qy, qz, max_range_sq, S, best, best_d, tr);
 }
 
 // knn_grid.hip

@@ -80,6 +80,12 @@ __global__ __launch_bounds__(kGridBlock) void grid_nearest_kernel(GridView g, co
     if (tr.why) atomicAdd(&why_counts[tr.why], 1u);
     atomicAdd(reinterpret_cast<unsigned long long *>(why_counts + 8), (unsigned long long)tr.points);
     atomicAdd(reinterpret_cast<unsigned long long *>(why_counts + 10), (unsigned long long)tr.words);
+    if (tr.wave_slots) atomicAdd(reinterpret_cast<unsigned long long *>(why_counts + 12), (unsigned long long)tr.wave_slots);
+    atomicAdd(&why_counts[32 + (tr.rounds9 < 0 ? 0 : min(tr.rounds9 + 1, 15))], 1u);
+    for (int k = 0; k < 3; k++) {
+      if (tr.slots_n[k]) atomicAdd(reinterpret_cast<unsigned long long *>(why_counts + 14 + 2 * k), (unsigned long long)tr.slots_n[k]);
+      if (tr.points_n[k]) atomicAdd(reinterpret_cast<unsigned long long *>(why_counts + 20 + 2 * k), (unsigned long long)tr.points_n[k]);
+    }
   }
   if (v == GRID_FOUND) {
     out_id[i] = __float_as_int(best.w);
@@ -279,17 +285,28 @@ extern "C" pcgx_status pcgx_debug_grid_stats(const pcgx_kdtree *t, const float *
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_list));
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_ids));
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_dsq));
-  PCGX_TRY(ar.alloc_n(24, &d_count));
-  PCGX_HIP_TRY(hipMemsetAsync(d_count, 0, 24 * sizeof(uint32_t), st));
+  PCGX_TRY(ar.alloc_n(64, &d_count));
+  PCGX_HIP_TRY(hipMemsetAsync(d_count, 0, 64 * sizeof(uint32_t), st));
   hipLaunchKernelGGL(pcgx::grid_nearest_kernel<true>, dim3((unsigned)((nq + pcgx::kGridBlock - 1) / pcgx::kGridBlock)),
                      dim3(pcgx::kGridBlock), 0, st, t->grid, d_q, (const int32_t *)nullptr, nq, max_range * max_range,
                      d_ids, d_dsq, d_list, d_count, d_count + 8);
-  uint32_t c[24];
+  uint32_t c[64];
   PCGX_HIP_TRY(hipMemcpyAsync(c, d_count, sizeof c, hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
+  if (getenv("PCGX_GRID_TRACE_PRINT")) {
+    fprintf(stderr, "9-segment scan per query: none %.4f, rounds of 4:", c[40] / (double)nq);
+    for (int k = 1; k < 16; k++) fprintf(stderr, " %d:%.4f", k - 1, c[40 + k] / (double)nq);
+    fprintf(stderr, "\n");
+  }
+  if (getenv("PCGX_GRID_TRACE_PRINT"))
+    for (int k = 0; k < 3; k++)
+      fprintf(stderr, "scan kind %d (%d segments): records/query %.2f lane-slots/query %.2f\n", k, k == 0 ? 4 : (k == 1 ? 9 : 5),
+              (double)(((uint64_t)c[29 + 2 * k] << 32) | c[28 + 2 * k]) / (double)nq,
+              (double)(((uint64_t)c[23 + 2 * k] << 32) | c[22 + 2 * k]) / (double)nq);
   out[0] = (int64_t)c[0];
   for (int k = 1; k < 8; k++) out[4 + k] = (int64_t)c[8 + k];
   out[12] = (int64_t)(((uint64_t)c[17] << 32) | c[16]);
   out[13] = (int64_t)(((uint64_t)c[19] << 32) | c[18]);
+  out[4] = (int64_t)(((uint64_t)c[21] << 32) | c[20]);  // lane-slots the scan loops ran (64 per round of 4 records, idle lanes included)
   return PCGX_OK;
 }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kTermsBlock) void strict_terms_kernel(const float4 
   float tx[kQuads][4], ty[kQuads][4], tz[kQuads][4];
 #pragma unroll
   for (int h = 0; h < kQuads; h++) {
-    const int q = h * kTermsBlock + threadIdx.x, l = q & (kLanes - 1), v = q / kLanes;
+    const int q = h * kTermsBlock + threadIdx.x, l = q / (kLeaf / 4), v = q % (kLeaf / 4);  // consecutive threads, consecutive targets
     const int64_t i0 = tile * kTile + l * kLeaf + 4 * v;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kTermsBlock) void strict_terms_kernel(const float4 
   }
 #pragma unroll
   for (int h = 0; h < kQuads; h++) {
-    const int q = h * kTermsBlock + threadIdx.x, l = q & (kLanes - 1), v = q / kLanes;
+    const int q = h * kTermsBlock + threadIdx.x, l = q / (kLeaf / 4), v = q % (kLeaf / 4);  // consecutive threads, consecutive targets
     float t[kStrictRows][4];
 #pragma unroll
     for (int c = 0; c < 4; c++) {

@@ -236,9 +236,10 @@ class IcpSession:
         self._h = h
 
     def grid_stats(self, stream=0):
-        """Measurement aid: (targets, targets left to the walk, point records, cell-bound words) the
-        grid pass of the NEXT iteration would read; zeros when the base tree has no grid."""
-        out = (C.c_int64 * 4)()
+        """Measurement aid: (targets, targets left to the walk, point records, cell-bound words,
+        lane-slots of the scan loops) the grid pass of the NEXT iteration would read; zeros when the
+        base tree has no grid."""
+        out = (C.c_int64 * 5)()
         L.check(L.lib().pcgx_debug_icp_grid_stats(self._h, L.ptr(stream) if stream else None, out))
         return tuple(out)
 
