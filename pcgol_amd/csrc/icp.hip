@@ -287,7 +287,11 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
   constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
   __shared__ float s_terms[NS][kIcpGridBlock + 16];  // + 16: the kSub-lane groups of one wave land on different banks
   if (state->done) return;  // uniform
-  const int64_t i = (int64_t)blockIdx.x * kIcpGridBlock + threadIdx.x;
+  // targets are stored in cell order: an XCD takes a contiguous eighth of them (pcgx_internal.h, xcd_tile)
+  const uint32_t n_tiles = (uint32_t)((nt + kIcpGridBlock - 1) / kIcpGridBlock);
+  const uint32_t tile = xcd_tile(blockIdx.x, n_tiles);
+  if (tile >= n_tiles) return;  // uniform
+  const int64_t i = (int64_t)tile * kIcpGridBlock + threadIdx.x;
   double acc[NS];
 #pragma unroll
   for (int k = 0; k < NS; k++) acc[k] = 0.0;
@@ -347,7 +351,7 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
     for (int u = 0; u < kRun; u++) v += (double)s_terms[k][u * kSub + j];  // lanes j side by side: no bank conflicts
 #pragma unroll
     for (int o = kSub / 2; o > 0; o >>= 1) v += __shfl_down(v, o, kSub);
-    if (j == 0) block_partials[((int64_t)n_corr_blocks + blockIdx.x) * NS + k] = v;
+    if (j == 0) block_partials[((int64_t)n_corr_blocks + tile) * NS + k] = v;
   }
 }
 
@@ -943,15 +947,15 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
     ProfScope prof_grid(PCGX_PROF_ICP_GRID, st);
     const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
     if (s->plane)
-      hipLaunchKernelGGL(icp_grid_kernel<true>, dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
+      hipLaunchKernelGGL(icp_grid_kernel<true>, dim3(xcd_grid(gb)), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
                          s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
                          s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
     else if (s->strict)
-      hipLaunchKernelGGL((icp_grid_kernel<false, false, false>), dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z,
+      hipLaunchKernelGGL((icp_grid_kernel<false, false, false>), dim3(xcd_grid(gb)), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z,
                          s->nt, s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals,
                          s->d_first_leaf, s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
     else
-      hipLaunchKernelGGL(icp_grid_kernel<false>, dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
+      hipLaunchKernelGGL(icp_grid_kernel<false>, dim3(xcd_grid(gb)), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
                          s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
                          s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
   }
@@ -1239,7 +1243,7 @@ extern "C" pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stre
   PCGX_HIP_TRY(hipMemsetAsync(d_trace, 0, 36 * sizeof(unsigned long long), st));
   const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
   const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
-  hipLaunchKernelGGL((icp_grid_kernel<false, true>), dim3(gb), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
+  hipLaunchKernelGGL((icp_grid_kernel<false, true>), dim3(xcd_grid(gb)), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
                      s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
                      s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials, d_trace);
   unsigned long long h[36];

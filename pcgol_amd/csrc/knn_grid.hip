@@ -68,7 +68,10 @@ __global__ __launch_bounds__(kGridBlock) void grid_nearest_kernel(GridView g, co
                                                                   int32_t *__restrict__ walk_list,
                                                                   uint32_t *__restrict__ walk_count,
                                                                   uint32_t *__restrict__ why_counts = nullptr) {
-  const int64_t pos = (int64_t)blockIdx.x * kGridBlock + threadIdx.x;
+  // with `perm` the launch positions are in Morton order: an XCD takes a contiguous eighth of them
+  // (pcgx_internal.h, xcd_tile); harmless without
+  const uint32_t n_tiles = (uint32_t)((nq + kGridBlock - 1) / kGridBlock);
+  const int64_t pos = (int64_t)xcd_tile(blockIdx.x, n_tiles) * kGridBlock + threadIdx.x;
   if (pos >= nq) return;
   const int64_t i = perm ? (int64_t)perm[pos] : pos;
   const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
@@ -251,7 +254,7 @@ pcgx_status grid_launch_nearest(const pcgx_kdtree *t, const float *d_q, const in
   PCGX_HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(uint32_t), st));
   {
     ProfScope prof(PCGX_PROF_KNN_GRID, st);
-    hipLaunchKernelGGL(grid_nearest_kernel<false>, dim3((unsigned)((nq + kGridBlock - 1) / kGridBlock)),
+    hipLaunchKernelGGL(grid_nearest_kernel<false>, dim3(xcd_grid((unsigned)((nq + kGridBlock - 1) / kGridBlock))),
                        dim3(kGridBlock), 0, st, t->grid, d_q, d_perm, nq, max_range_sq, d_ids, d_dsq, d_list, d_count,
                        (uint32_t *)nullptr);
   }
@@ -287,7 +290,7 @@ extern "C" pcgx_status pcgx_debug_grid_stats(const pcgx_kdtree *t, const float *
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_dsq));
   PCGX_TRY(ar.alloc_n(64, &d_count));
   PCGX_HIP_TRY(hipMemsetAsync(d_count, 0, 64 * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(pcgx::grid_nearest_kernel<true>, dim3((unsigned)((nq + pcgx::kGridBlock - 1) / pcgx::kGridBlock)),
+  hipLaunchKernelGGL(pcgx::grid_nearest_kernel<true>, dim3(pcgx::xcd_grid((unsigned)((nq + pcgx::kGridBlock - 1) / pcgx::kGridBlock))),
                      dim3(pcgx::kGridBlock), 0, st, t->grid, d_q, (const int32_t *)nullptr, nq, max_range * max_range,
                      d_ids, d_dsq, d_list, d_count, d_count + 8);
   uint32_t c[64];

@@ -175,6 +175,19 @@ struct GridView {
   int32_t nx, ny, nz;
 };
 
+// XCD-contiguous placement of the tiles of a launch whose neighbouring tiles read neighbouring data:
+// workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8), each with an L2 of its own, so
+// workgroup b takes tile (b % 8) * per + b / 8 and an XCD works through one contiguous eighth of the
+// tiles -- its L2 then holds an eighth of what the launch reads instead of all of it.  Launch
+// xcd_grid(ntiles) workgroups; tiles >= ntiles have nothing to do.
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t block, uint32_t ntiles) {
+  const uint32_t per = (ntiles + 7u) / 8u;
+  return (block & 7u) * per + (block >> 3);
+}
+#endif
+inline unsigned xcd_grid(unsigned ntiles) { return 8u * ((ntiles + 7u) / 8u); }
+
 // kdtree_build.cpp
 void build_inorder(const float *xyz, int64_t n, int32_t *inorder_ids);
 inline int32_t tree_depth(int64_t n) {

@@ -4,7 +4,7 @@ TAG=$1; PMC=$2; shift; shift
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc -- python3 "$@" > $OUT/run.log 2>&1
+timeout -k 10 90 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc -- python3 "$@" > $OUT/run.log 2>&1
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 from collections import defaultdict
