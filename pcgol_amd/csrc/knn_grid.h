@@ -9,7 +9,7 @@
 // pivot rules differ there, :100-103 vs :117).  Any other exact search that evaluates DistSq with the
 // same expression returns the same {ID, DistSq}.
 //
-// So every tree also gets a uniform grid over its bounding box (~2 points per cell, points stored
+// So every tree also gets a uniform grid over its bounding box (~1.5 points per cell, points stored
 // in cell order).  A query scans the cells that can hold a point within its current bound (the
 // nearest point found in the cells around it, or the hint the ICP loop carries over), keeps the
 // minimum and whether it is tied, and accepts the result only when the scanned cells provably hold
