@@ -268,6 +268,39 @@ func (f *voxelGrid) Filter(pp *pc.PointCloud) (*pc.PointCloud, error) {
 	return newPc, nil
 }
 
+// FilterSharded is this rank's share of Filter(pp) over the ranks of c (SURVEY 8(e)): every rank
+// passes the same cloud; the ranks' results, rank 0's first, are Filter's output record for record.
+// Collective.
+func FilterSharded(f filter.Filter, pp *pc.PointCloud, c *Comm) (*pc.PointCloud, error) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(c)
+	vg, ok := f.(*voxelGrid)
+	if !ok {
+		return nil, errors.New("pcgx: FilterSharded needs a filter made by NewVoxelGrid")
+	}
+	stride, off, err := xyzLayout(pp)
+	if err != nil {
+		return nil, err
+	}
+	n := pp.Points
+	if n == 0 {
+		return nil, errors.New("no point")
+	}
+	out := make([]byte, n*stride)
+	leaf := [3]C.float{C.float(vg.leaf[0]), C.float(vg.leaf[1]), C.float(vg.leaf[2])}
+	chunk := [3]C.int32_t{C.int32_t(vg.chunk[0]), C.int32_t(vg.chunk[1]), C.int32_t(vg.chunk[2])}
+	var m C.int64_t
+	rc := C.pcgx_voxel_filter_sharded(c.h, unsafe.Pointer(&pp.Data[0]), C.int64_t(n), C.int32_t(stride), C.int32_t(off),
+		&leaf[0], &chunk[0], unsafe.Pointer(&out[0]), &m)
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	part := &pc.PointCloud{PointCloudHeader: pp.Clone(), Points: int(m), Data: out[:int(m)*stride]}
+	part.Width, part.Height = int(m), 1
+	return part, nil
+}
+
 // -------------------------------------------------------------------- ICP
 
 // Evaluator implements icp.Evaluator with the fused GPU correspondence +

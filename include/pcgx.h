@@ -392,6 +392,23 @@ PCGX_API pcgx_status pcgx_icp_session_step_sharded(pcgx_icp_session *s, pcgx_com
 PCGX_API pcgx_status pcgx_icp_fit_sharded(const pcgx_kdtree *base, const float *tile, int64_t nt,
                                           const pcgx_icp_params *params, pcgx_comm *c, float trans16[16],
                                           pcgx_icp_stat *stat);
+/* The voxel filter over several GPUs (second half).  Every rank holds the same cloud
+ * in device memory.  Each runs the min/max pass (pc/minmax.go:9-26) over its n / world slice; the six
+ * floats are exchanged through `c` (one all-reduce of 7 x world float64) and folded in rank order with
+ * the reference's comparisons.  Each rank then keeps the points whose place in the reference's output
+ * order -- chunk id, then cell (voxelgrid.go:49-116,137-151) -- lies in its contiguous share of that
+ * key range and filters them: *out_n records in d_out (>= n * stride bytes).  The ranks' outputs,
+ * rank 0's first, ARE the output of pcgx_voxel_filter_dev on one GPU, byte for byte; putting them
+ * together is the caller's (a variable-length gather, or one copy per rank into the host cloud).
+ * Collective: every rank of `c` must call it with the same cloud and options.  Errors as
+ * pcgx_voxel_filter_dev on every rank alike. */
+PCGX_API pcgx_status pcgx_voxel_filter_sharded_dev(pcgx_comm *c, const void *d_data, int64_t n, int32_t stride,
+                                                   int32_t xyz_off, const float leaf[3], const int32_t chunk[3],
+                                                   void *d_out, int64_t *out_n, void *stream);
+/* The same with host buffers (upload, this rank's share, download of its *out_n records). */
+PCGX_API pcgx_status pcgx_voxel_filter_sharded(pcgx_comm *c, const void *data, int64_t n, int32_t stride,
+                                               int32_t xyz_off, const float leaf[3], const int32_t chunk[3],
+                                               void *out_data, int64_t *out_n);
 /* STRICT sums.  By default the evaluator's sums are float64 reductions of the reference's float32
  * terms: more accurate than the reference, equal to it only up to ITS rounding noise (sequential
  * float32 additions, evaluator.go:122-145; ~1.6e-5 on the final transform at 1M pairs).  With

@@ -153,6 +153,8 @@ SIGNATURES = {
     "pcgx_minmax": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "pcgx_voxel_filter": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i64)]),
     "pcgx_voxel_filter_dev": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
+    "pcgx_voxel_filter_sharded_dev": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i64), _vp]),
+    "pcgx_voxel_filter_sharded": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, C.POINTER(_i64)]),
     "pcgx_icp_pairs": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp, _vp, _vp, C.POINTER(_i64)]),
     "pcgx_icp_evaluate": (_i32, [_vp, _vp, _i64, _f32, _f32, _i32, C.POINTER(IcpEvaluated)]),
     "pcgx_icp_evaluate_params": (_i32, [_vp, _vp, _i64, C.POINTER(IcpParams), C.POINTER(IcpEvaluated)]),

@@ -22,6 +22,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <utility>
 #include <vector>
 
 #include "pcgx_internal.h"
@@ -280,6 +281,71 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(
   }
 }
 
+// ---- sharded filter: a rank keeps the points of ITS share of the output order -------------------
+// primary[i] in [lo, hi): the (key, index) pairs of those points, input order kept (the sort's
+// stability is what orders a voxel's points).  The two-sort mode's cell / chunk arrays stay as they
+// are: they are looked up by point index.
+constexpr int kMineTile = 2048;  // 256 threads x 8 rounds
+
+__global__ __launch_bounds__(256) void vx_mine_count_kernel(const uint32_t *__restrict__ primary, int64_t n, uint32_t lo,
+                                                            uint32_t hi, uint32_t *__restrict__ tile_count) {
+  __shared__ uint32_t ws[4];
+  const int64_t base = (int64_t)blockIdx.x * kMineTile;
+  uint32_t c = 0;
+  for (int r = 0; r < kMineTile / 256; r++) {
+    const int64_t j = base + r * 256 + threadIdx.x;
+    if (j < n) {
+      const uint32_t k = primary[j];
+      c += (k >= lo && k < hi) ? 1u : 0u;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(256) void vx_mine_compact_kernel(
+    const uint32_t *__restrict__ primary, int64_t n, uint32_t lo, uint32_t hi, const uint32_t *__restrict__ tile_start,
+    const uint32_t *__restrict__ key_in, const uint32_t *__restrict__ idx_in, uint32_t *__restrict__ key_out,
+    uint32_t *__restrict__ idx_out) {
+  constexpr int kRounds = kMineTile / 256;
+  __shared__ uint32_t cnt[kRounds][4];
+  const int64_t base = (int64_t)blockIdx.x * kMineTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  uint32_t below[kRounds];
+  bool mine[kRounds];
+#pragma unroll
+  for (int r = 0; r < kRounds; r++) {  // element base + r * 256 + t: rounds, then waves, then lanes = input order
+    const int64_t j = base + r * 256 + threadIdx.x;
+    mine[r] = false;
+    if (j < n) {
+      const uint32_t k = primary[j];
+      mine[r] = k >= lo && k < hi;
+    }
+    const uint64_t m = __ballot(mine[r]);
+    below[r] = (uint32_t)__popcll(m & lt_mask);
+    if (lane == 0) cnt[r][wave] = (uint32_t)__popcll(m);
+  }
+  __syncthreads();
+  uint32_t run = tile_start[blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < kRounds; r++) {
+    uint32_t before = run;
+    for (int w = 0; w < 4; w++) {
+      if (w < wave) before += cnt[r][w];
+      run += cnt[r][w];
+    }
+    if (mine[r]) {
+      const int64_t j = base + r * 256 + threadIdx.x;
+      const uint32_t dst = before + below[r];
+      key_out[dst] = key_in[j];
+      idx_out[dst] = idx_in[j];
+    }
+  }
+}
+
 static int bits_for(int64_t count) {  // bits needed for values in [0, count)
   int b = 0;
   while (b < 63 && ((int64_t)1 << b) < count) b++;
@@ -336,11 +402,15 @@ static pcgx_status make_params(const float mm6[6], const float leaf[3], const in
 
 using namespace pcgx;
 
-extern "C" pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int32_t stride,
-                                             int32_t xyz_off, const float leaf[3],
-                                             const int32_t chunk[3], void *d_out, int64_t *out_n,
-                                             void *stream) {
-  PCGX_API_LOCK();
+// comm == nullptr: the whole filter.  Otherwise this rank's share (second half): every
+// rank holds the same cloud; the min/max pass (pc/minmax.go:9-26 via voxelgrid.go:41-44) runs over the
+// rank's slice of it and the six floats are exchanged; each rank then keeps the points whose place in
+// the reference's output order (chunk id, cell: voxelgrid.go:49-116) falls into its contiguous share
+// of that key range, and filters those.  The ranks' outputs one after the other are the reference's
+// output, byte for byte.
+static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_t n, int32_t stride, int32_t xyz_off,
+                                     const float leaf[3], const int32_t chunk[3], void *d_out, int64_t *out_n,
+                                     void *stream) {
   if (!out_n) return fail(PCGX_E_INVALID, "pcgx_voxel_filter_dev: out_n is NULL");
   *out_n = 0;
   if (n < 0 || !leaf || !chunk || (n > 0 && (!d_data || !d_out)))
@@ -355,12 +425,60 @@ extern "C" pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int3
   PCGX_TRY(ar.begin(st));
   ProfScope prof(PCGX_PROF_VOXEL_ALL, st);
 
+  int32_t rank = 0, world = 1;
+  if (comm) PCGX_TRY(pcgx_comm_rank(comm, &rank, &world));
   float *d_mm6 = nullptr;
   PCGX_TRY(ar.alloc_n(6, &d_mm6));
-  PCGX_TRY(launch_minmax(d_data, n, stride, xyz_off, d_mm6, st));
   float mm6[6];
-  PCGX_HIP_TRY(hipMemcpyAsync(mm6, d_mm6, sizeof mm6, hipMemcpyDeviceToHost, st));
-  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  if (world == 1) {
+    PCGX_TRY(launch_minmax(d_data, n, stride, xyz_off, d_mm6, st));
+    PCGX_HIP_TRY(hipMemcpyAsync(mm6, d_mm6, sizeof mm6, hipMemcpyDeviceToHost, st));
+    PCGX_HIP_TRY(hipStreamSynchronize(st));
+  } else {
+    // the slice's six floats travel as their bit patterns in slot `rank` of a vector of zeros: the
+    // sum every rank receives holds all of them exactly (an all-gather out of the one collective the
+    // communicator has); folded in rank order with the reference's comparisons (`<`, `>`: of equal
+    // values -- +0 and -0 -- the earlier one stays, as in the sequential loop)
+    const int64_t s0 = n * rank / world, s1 = n * (rank + 1) / world;
+    const int per = 7;
+    std::vector<double> slots((size_t)per * world, 0.0);
+    if (s1 > s0) {
+      PCGX_TRY(launch_minmax((const uint8_t *)d_data + s0 * stride, s1 - s0, stride, xyz_off, d_mm6, st));
+      PCGX_HIP_TRY(hipMemcpyAsync(mm6, d_mm6, sizeof mm6, hipMemcpyDeviceToHost, st));
+      PCGX_HIP_TRY(hipStreamSynchronize(st));
+      slots[(size_t)per * rank] = 1.0;
+      for (int k = 0; k < 6; k++) {
+        uint32_t bits;
+        memcpy(&bits, &mm6[k], 4);
+        slots[(size_t)per * rank + 1 + k] = (double)bits;
+      }
+    }
+    double *d_slots = nullptr;
+    PCGX_TRY(ar.alloc_n(slots.size(), &d_slots));
+    PCGX_HIP_TRY(hipMemcpyAsync(d_slots, slots.data(), slots.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    PCGX_TRY(pcgx_comm_allreduce_f64(comm, d_slots, (int32_t)slots.size(), st));
+    PCGX_HIP_TRY(hipMemcpyAsync(slots.data(), d_slots, slots.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    PCGX_HIP_TRY(hipStreamSynchronize(st));
+    bool have = false;
+    for (int r = 0; r < world; r++) {
+      if (slots[(size_t)per * r] != 1.0) continue;
+      float v[6];
+      for (int k = 0; k < 6; k++) {
+        const uint32_t bits = (uint32_t)slots[(size_t)per * r + 1 + k];
+        memcpy(&v[k], &bits, 4);
+      }
+      if (!have) {
+        memcpy(mm6, v, sizeof mm6);
+        have = true;
+        continue;
+      }
+      for (int k = 0; k < 3; k++) {
+        if (v[k] < mm6[k]) mm6[k] = v[k];
+        if (v[3 + k] > mm6[3 + k]) mm6[3 + k] = v[3 + k];
+      }
+    }
+    if (!have) return fail(PCGX_E_RCCL, "sharded voxel filter: no rank reported a slice");
+  }
   VoxelParams vp;
   PCGX_TRY(make_params(mm6, leaf, chunk, vp));
 
@@ -369,7 +487,7 @@ extern "C" pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int3
   int32_t *d_err = nullptr;
   int64_t *d_total = nullptr;
   uint32_t *tile_count = nullptr;
-  const int ntiles = (int)((n + kSegTile - 1) / kSegTile);
+  int ntiles = (int)((n + kSegTile - 1) / kSegTile);
   bool two_level = vp.chunked && vp.n_chunks > 1;
   int key_bits = bits_for(vp.n_voxels);
   const char *force_two = getenv("PCGX_VOXEL_TWO_SORTS");  // tests: keep the two-sort path covered
@@ -395,9 +513,38 @@ extern "C" pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int3
   PCGX_TRY(ar.alloc_n((size_t)ntiles, &tile_count));
   PCGX_HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int32_t), st));
 
-  const unsigned nb = (unsigned)((n + 255) / 256);
+  unsigned nb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(256), 0, st, (const uint8_t *)d_data, n, stride, xyz_off,
                      vp, keys[0], a_orig, cid_orig, vals[0], d_err);
+  if (world > 1) {
+    // this rank's share of the output order: by chunk id (two sorts), else by the one key
+    const uint32_t *primary = two_level ? cid_orig : keys[0];
+    const uint64_t span = two_level ? (uint64_t)vp.n_chunks
+                                    : (vp.combined ? ((uint64_t)vp.n_chunks << vp.key_shift) : (uint64_t)vp.n_voxels);
+    const uint64_t lo = span * (uint64_t)rank / (uint64_t)world, hi = span * (uint64_t)(rank + 1) / (uint64_t)world;
+    const int mtiles = (int)((n + kMineTile - 1) / kMineTile);
+    uint32_t *mine_count = nullptr;
+    PCGX_TRY(ar.alloc_n((size_t)mtiles, &mine_count));
+    hipLaunchKernelGGL(vx_mine_count_kernel, dim3(mtiles), dim3(256), 0, st, primary, n, (uint32_t)lo,
+                       (uint32_t)(hi > 0xffffffffull ? 0xffffffffull : hi), mine_count);
+    hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, st, mine_count, mtiles, d_total);
+    hipLaunchKernelGGL(vx_mine_compact_kernel, dim3(mtiles), dim3(256), 0, st, primary, n, (uint32_t)lo,
+                       (uint32_t)(hi > 0xffffffffull ? 0xffffffffull : hi), (const uint32_t *)mine_count,
+                       (const uint32_t *)keys[0], (const uint32_t *)vals[0], keys[1], vals[1]);
+    int32_t h_err0 = 0;
+    int64_t h_mine = 0;
+    PCGX_HIP_TRY(hipMemcpyAsync(&h_err0, d_err, sizeof h_err0, hipMemcpyDeviceToHost, st));
+    PCGX_HIP_TRY(hipMemcpyAsync(&h_mine, d_total, sizeof h_mine, hipMemcpyDeviceToHost, st));
+    PCGX_HIP_TRY(hipStreamSynchronize(st));
+    if (h_err0)  // every rank sees every point: they all fail alike
+      return fail(PCGX_E_OUT_OF_RANGE, "voxel filter: a point falls outside the dense grid (the reference panics: index out of range)");
+    if (h_mine == 0) return PCGX_OK;  // nothing of the cloud falls into this rank's share
+    std::swap(keys[0], keys[1]);
+    std::swap(vals[0], vals[1]);
+    n = h_mine;
+    ntiles = (int)((n + kSegTile - 1) / kSegTile);
+    nb = (unsigned)((n + 255) / 256);
+  }
   int res = 0;
   PCGX_TRY(radix_sort_pairs(keys, vals, n, key_bits, ws, &res, st));
   const uint32_t *sa = keys[res], *sc = nullptr, *sidx = vals[res];
@@ -428,6 +575,22 @@ extern "C" pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int3
     return fail(PCGX_E_OUT_OF_RANGE, "voxel filter: a point falls outside the dense grid (the reference panics: index out of range)");
   *out_n = h_total;
   return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_voxel_filter_dev(const void *d_data, int64_t n, int32_t stride,
+                                             int32_t xyz_off, const float leaf[3],
+                                             const int32_t chunk[3], void *d_out, int64_t *out_n,
+                                             void *stream) {
+  PCGX_API_LOCK();
+  return voxel_filter_core(nullptr, d_data, n, stride, xyz_off, leaf, chunk, d_out, out_n, stream);
+}
+
+extern "C" pcgx_status pcgx_voxel_filter_sharded_dev(pcgx_comm *comm, const void *d_data, int64_t n, int32_t stride,
+                                                     int32_t xyz_off, const float leaf[3], const int32_t chunk[3],
+                                                     void *d_out, int64_t *out_n, void *stream) {
+  PCGX_API_LOCK();
+  if (!comm) return fail(PCGX_E_INVALID, "pcgx_voxel_filter_sharded_dev: comm is NULL");
+  return voxel_filter_core(comm, d_data, n, stride, xyz_off, leaf, chunk, d_out, out_n, stream);
 }
 
 extern "C" pcgx_status pcgx_minmax(const void *data, int64_t n, int32_t stride, int32_t xyz_off,
@@ -463,10 +626,9 @@ extern "C" pcgx_status pcgx_minmax(const void *data, int64_t n, int32_t stride, 
   return PCGX_OK;
 }
 
-extern "C" pcgx_status pcgx_voxel_filter(const void *data, int64_t n, int32_t stride, int32_t xyz_off,
-                                         const float leaf[3], const int32_t chunk[3], void *out_data,
-                                         int64_t *out_n) {
-  PCGX_API_CALL();
+// host buffers in and out around the device filter (comm: this rank's share, or nullptr)
+static pcgx_status voxel_filter_host(pcgx_comm *comm, const void *data, int64_t n, int32_t stride, int32_t xyz_off,
+                                     const float leaf[3], const int32_t chunk[3], void *out_data, int64_t *out_n) {
   if (!out_n) return fail(PCGX_E_INVALID, "pcgx_voxel_filter: out_n is NULL");
   *out_n = 0;
   if (n < 0 || (n > 0 && (!data || !out_data))) return fail(PCGX_E_INVALID, "pcgx_voxel_filter: bad argument");
@@ -482,7 +644,7 @@ extern "C" pcgx_status pcgx_voxel_filter(const void *data, int64_t n, int32_t st
   hipError_t e = hipMemcpyAsync(d_in, data, bytes, hipMemcpyHostToDevice, st);
   if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_voxel_filter upload: %s", hipGetErrorString(e));
   int64_t m = 0;
-  if (rc == PCGX_OK) rc = pcgx_voxel_filter_dev(d_in, n, stride, xyz_off, leaf, chunk, d_out, &m, st);
+  if (rc == PCGX_OK) rc = voxel_filter_core(comm, d_in, n, stride, xyz_off, leaf, chunk, d_out, &m, st);
   if (rc == PCGX_OK && m > 0) {
     // same stream as the filter (the library stream is non-blocking w.r.t. the null stream)
     e = hipMemcpyAsync(out_data, d_out, (size_t)m * (size_t)stride, hipMemcpyDeviceToHost, st);
@@ -491,4 +653,19 @@ extern "C" pcgx_status pcgx_voxel_filter(const void *data, int64_t n, int32_t st
   }
   if (rc == PCGX_OK) *out_n = m;
   return rc;
+}
+
+extern "C" pcgx_status pcgx_voxel_filter(const void *data, int64_t n, int32_t stride, int32_t xyz_off,
+                                         const float leaf[3], const int32_t chunk[3], void *out_data,
+                                         int64_t *out_n) {
+  PCGX_API_CALL();
+  return voxel_filter_host(nullptr, data, n, stride, xyz_off, leaf, chunk, out_data, out_n);
+}
+
+extern "C" pcgx_status pcgx_voxel_filter_sharded(pcgx_comm *comm, const void *data, int64_t n, int32_t stride,
+                                                 int32_t xyz_off, const float leaf[3], const int32_t chunk[3],
+                                                 void *out_data, int64_t *out_n) {
+  PCGX_API_LOCK();  // the exchange inside is collective: one such call at a time per process
+  if (!comm) return fail(PCGX_E_INVALID, "pcgx_voxel_filter_sharded: comm is NULL");
+  return voxel_filter_host(comm, data, n, stride, xyz_off, leaf, chunk, out_data, out_n);
 }

@@ -39,6 +39,22 @@ class VoxelGrid:
         h.Width, h.Height = m.value, 1
         return PointCloud(h, m.value, out[: m.value * stride].copy())
 
+    def FilterShard(self, pp, comm):
+        """This rank's share of Filter(pp) over the ranks of `comm` (collective; every rank passes the
+        same cloud): a PointCloud with the records of its contiguous part of the output."""
+        if not isinstance(pp, PointCloud):
+            pp = PointCloud.from_xyz(pp)
+        stride, off = pp.Stride(), pp.xyz_offset()
+        n = pp.Points
+        out = np.empty(max(n, 1) * stride, np.uint8)
+        m = C.c_int64()
+        chunk = np.asarray(self.ChunkSize, np.int32)
+        L.check(L.lib().pcgx_voxel_filter_sharded(comm._h, L.ptr(pp.Data), n, stride, off, L.ptr(self.LeafSize),
+                                                  L.ptr(chunk), L.ptr(out), C.byref(m)))
+        h = pp.PointCloudHeader.Clone()
+        h.Width, h.Height = m.value, 1
+        return PointCloud(h, m.value, out[: m.value * stride].copy())
+
     def FilterDev(self, d_data, n, stride, off, d_out, stream=0):
         """Device-resident variant (raw device addresses). Returns M."""
         m = C.c_int64()
@@ -46,6 +62,19 @@ class VoxelGrid:
         L.check(L.lib().pcgx_voxel_filter_dev(L.ptr(d_data), n, stride, off, L.ptr(self.LeafSize),
                                               L.ptr(chunk), L.ptr(d_out), C.byref(m),
                                               L.ptr(stream) if stream else None))
+        return m.value
+
+
+    def FilterShardDev(self, comm, d_data, n, stride, off, d_out, stream=0):
+        """This rank's share of the filter over the ranks of `comm` (pcgol_amd.distributed.Comm): every
+        rank passes the same device-resident cloud and gets the records of its contiguous part of the
+        reference's output order; rank 0's, rank 1's, ... one after the other are Filter's output.
+        Collective.  Returns this rank's M."""
+        m = C.c_int64()
+        chunk = np.asarray(self.ChunkSize, np.int32)
+        L.check(L.lib().pcgx_voxel_filter_sharded_dev(comm._h, L.ptr(d_data), n, stride, off, L.ptr(self.LeafSize),
+                                                      L.ptr(chunk), L.ptr(d_out), C.byref(m),
+                                                      L.ptr(stream) if stream else None))
         return m.value
 
 
