@@ -341,9 +341,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # HIP events around every 3rd launch of the timed kernels only (3 is coprime to the 20 iterations
+    # HIP events around every 7th launch of the timed kernels only (7 is coprime to the 20 iterations
     # of a Fit, so every iteration index is sampled): a pair of events costs ~5 us of stream time
-    L.prof_enable(3)
+    L.prof_enable(7)
     L.prof_reset()
     # the driver's K may cover less than a millisecond of GPU work: repeat the K steps until >= 50 ms
     # have been timed and report per step (the JSON's `steps` stays the driver's K)
