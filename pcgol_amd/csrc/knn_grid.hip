@@ -10,14 +10,12 @@ namespace pcgx {
 constexpr int kGridBlock = 256;
 
 __global__ __launch_bounds__(256) void grid_key_points_kernel(const float *__restrict__ xyz, int64_t n, GridView g,
-                                                              uint32_t *__restrict__ keys,
-                                                              uint32_t *__restrict__ vals) {
+                                                              uint32_t *__restrict__ keys) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int cx = grid_cell(xyz[3 * i], g.lo[0], g.inv_h, g.nx), cy = grid_cell(xyz[3 * i + 1], g.lo[1], g.inv_h, g.ny),
             cz = grid_cell(xyz[3 * i + 2], g.lo[2], g.inv_h, g.nz);
   keys[i] = (uint32_t)((cz * g.ny + cy) * g.nx + cx);
-  vals[i] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(256) void grid_gather_kernel(const float *__restrict__ xyz, const uint32_t *__restrict__ order,
@@ -204,10 +202,10 @@ pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labe
     }
     g.start = t->d_gstart + 1;
     PCGX_HIP_TRY(hipMemsetAsync(d_crowd, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(grid_key_points_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n, g, keys[0], vals[0]);
+    hipLaunchKernelGGL(grid_key_points_kernel, dim3(nb), dim3(256), 0, st, d_xyz, n, g, keys[0]);
     int key_bits = 1;
     while (((int64_t)1 << key_bits) < cells) key_bits++;
-    PCGX_TRY(radix_sort_pairs(keys, vals, n, key_bits, ws, &res, st));
+    PCGX_TRY(radix_sort_pairs(keys, vals, n, key_bits, ws, &res, st, true));
     hipLaunchKernelGGL(grid_start_kernel, dim3((unsigned)((cells + 1 + 255) / 256)), dim3(256), 0, st,
                        (const uint32_t *)keys[res], n, (uint32_t)cells, t->d_gstart + 1, d_crowd);
     unsigned long long crowd = 0;

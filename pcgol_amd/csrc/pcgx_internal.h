@@ -247,8 +247,10 @@ pcgx_status launch_nearest_listed(const TreeView &tv, const float *d_q, const in
 
 // sort.hip
 size_t radix_sort_workspace_bytes(int64_t n);
+// iota_vals: the values are the positions 0 .. n-1 and vals[0] need not be filled (the first pass
+// takes a position for its value: a 4n-byte write and read less)
 pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, int key_bits,
-                             void *workspace, int *result, hipStream_t st);
+                             void *workspace, int *result, hipStream_t st, bool iota_vals = false);
 pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
                           hipStream_t st);
 // perm[pos] = index of the point visited at position pos (coarse Morton order over the box

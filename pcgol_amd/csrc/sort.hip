@@ -118,7 +118,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
     const int64_t i = wave_base + r * 64 + lane;
     const bool valid = i < n;
     key[r] = valid ? keys_in[i] : 0u;
-    val[r] = valid ? vals_in[i] : 0u;
+    val[r] = valid ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;  // no value array: the element's position
     const uint32_t d = (key[r] >> shift) & (kRadix - 1);
     uint64_t m = __ballot(valid);
 #pragma unroll
@@ -222,7 +222,7 @@ size_t radix_sort_workspace_bytes(int64_t n) {
 // Sorts pairs by key bits [0, key_bits).  keys[0]/vals[0] hold the input;
 // *result is the index (0/1) of the buffers holding the output.
 pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, int key_bits,
-                             void *workspace, int *result, hipStream_t st) {
+                             void *workspace, int *result, hipStream_t st, bool iota_vals) {
   *result = 0;
   if (n <= 1 || key_bits <= 0) return PCGX_OK;
   if (n > 0x7fffffffll) return fail(PCGX_E_INVALID, "radix sort: n too large");
@@ -245,11 +245,13 @@ pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, in
       ProfScope prof(PCGX_PROF_SORT_SCATTER, st);
       const int remap = sort_xcd_remap() && nblocks >= 64;
       const int grid = remap ? 8 * ((nblocks + 7) / 8) : nblocks;
+      // iota_vals: the values are the positions 0 .. n-1, never stored before the first pass
+      const uint32_t *vin = (iota_vals && shift == 0) ? nullptr : vals[cur];
       if (items == 8)
-        hipLaunchKernelGGL(rs_scatter_kernel<8>, dim3(grid), dim3(kRsThreads), 0, st, keys[cur], vals[cur], n, shift,
+        hipLaunchKernelGGL(rs_scatter_kernel<8>, dim3(grid), dim3(kRsThreads), 0, st, keys[cur], vin, n, shift,
                            block_hist, nblocks, totals, keys[cur ^ 1], vals[cur ^ 1], remap);
       else
-        hipLaunchKernelGGL(rs_scatter_kernel<16>, dim3(grid), dim3(kRsThreads), 0, st, keys[cur], vals[cur], n, shift,
+        hipLaunchKernelGGL(rs_scatter_kernel<16>, dim3(grid), dim3(kRsThreads), 0, st, keys[cur], vin, n, shift,
                            block_hist, nblocks, totals, keys[cur ^ 1], vals[cur ^ 1], remap);
     }
     cur ^= 1;
@@ -467,8 +469,7 @@ struct MortonBox {
 };
 
 __global__ __launch_bounds__(256) void morton_key_kernel(const float *__restrict__ q, int64_t n, MortonBox box,
-                                                         uint32_t *__restrict__ keys,
-                                                         uint32_t *__restrict__ vals) {
+                                                         uint32_t *__restrict__ keys) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float cmax = (float)((1u << box.bits) - 1u);
@@ -479,7 +480,6 @@ __global__ __launch_bounds__(256) void morton_key_kernel(const float *__restrict
     c[k] = (uint32_t)f;
   }
   keys[i] = spread3(c[0]) | (spread3(c[1]) << 1) | (spread3(c[2]) << 2);
-  vals[i] = (uint32_t)i;
 }
 
 // Queries only need to be ordered coarsely (lanes of a wave should walk neighbouring sub-trees):
@@ -508,10 +508,9 @@ pcgx_status morton_order(const float *d_q, int64_t n, const float lo[3], const f
     box.lo[k] = lo[k] == lo[k] ? lo[k] : 0.0f;
     box.scale[k] = (ext > 0.0f && ext < 3.0e38f) ? (float)(1u << box.bits) / ext : 0.0f;
   }
-  hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_q, n, box, keys[0],
-                     vals[0]);
+  hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_q, n, box, keys[0]);
   int res = 0;
-  PCGX_TRY(radix_sort_pairs(keys, vals, n, 3 * kMortonBitsPerAxis + 1, wsp, &res, st));
+  PCGX_TRY(radix_sort_pairs(keys, vals, n, 3 * kMortonBitsPerAxis + 1, wsp, &res, st, true));
   if (res != 0) PCGX_HIP_TRY(hipMemcpyAsync(d_perm, vals[res], nb, hipMemcpyDeviceToDevice, st));
   return PCGX_OK;
 }

@@ -79,7 +79,8 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(const uint8_t *__restric
     const int64_t c = ((cz * vp.ny) + cy) * vp.nx + cx;
     if (c < 0 || c >= vp.n_chunks) {  // nIndices[cid] would panic
       atomicOr(err, 1);
-      key_a[i] = 0; idx[i] = (uint32_t)i;
+      key_a[i] = 0;
+      if (idx) idx[i] = (uint32_t)i;
       if (key_cid) { key_cid[i] = 0; a_orig[i] = 0; }
       return;
     }
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(const uint8_t *__restric
   else ka = (uint32_t)a;
   key_a[i] = vp.combined ? ((cid << vp.key_shift) | ka) : ka;
   if (a_orig) a_orig[i] = ka;
-  idx[i] = (uint32_t)i;
+  if (idx) idx[i] = (uint32_t)i;  // (nullptr: the sort takes positions for values)
 }
 
 // chunk id of sorted position j: its own array (two sorts), or the high bits of the combined key
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(256) void vx_mine_compact_kernel(
       const int64_t j = base + r * 256 + threadIdx.x;
       const uint32_t dst = before + below[r];
       key_out[dst] = key_in[j];
-      idx_out[dst] = idx_in[j];
+      idx_out[dst] = idx_in ? idx_in[j] : (uint32_t)j;
     }
   }
 }
@@ -515,7 +516,8 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
 
   unsigned nb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(256), 0, st, (const uint8_t *)d_data, n, stride, xyz_off,
-                     vp, keys[0], a_orig, cid_orig, vals[0], d_err);
+                     vp, keys[0], a_orig, cid_orig, (uint32_t *)nullptr, d_err);
+  bool iota = true;  // the values of the sort are the points' indices 0 .. n-1
   if (world > 1) {
     // this rank's share of the output order: by chunk id (two sorts), else by the one key
     const uint32_t *primary = two_level ? cid_orig : keys[0];
@@ -530,7 +532,8 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, st, mine_count, mtiles, d_total);
     hipLaunchKernelGGL(vx_mine_compact_kernel, dim3(mtiles), dim3(256), 0, st, primary, n, (uint32_t)lo,
                        (uint32_t)(hi > 0xffffffffull ? 0xffffffffull : hi), (const uint32_t *)mine_count,
-                       (const uint32_t *)keys[0], (const uint32_t *)vals[0], keys[1], vals[1]);
+                       (const uint32_t *)keys[0], (const uint32_t *)nullptr, keys[1], vals[1]);
+    iota = false;
     int32_t h_err0 = 0;
     int64_t h_mine = 0;
     PCGX_HIP_TRY(hipMemcpyAsync(&h_err0, d_err, sizeof h_err0, hipMemcpyDeviceToHost, st));
@@ -546,7 +549,7 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
     nb = (unsigned)((n + 255) / 256);
   }
   int res = 0;
-  PCGX_TRY(radix_sort_pairs(keys, vals, n, key_bits, ws, &res, st));
+  PCGX_TRY(radix_sort_pairs(keys, vals, n, key_bits, ws, &res, st, iota));
   const uint32_t *sa = keys[res], *sc = nullptr, *sidx = vals[res];
   if (two_level) {
     // second stable sort, by chunk id: (cid, a) order with input order kept inside a cell
