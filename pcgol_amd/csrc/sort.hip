@@ -221,10 +221,21 @@ size_t radix_sort_workspace_bytes(int64_t n) {
 
 // Sorts pairs by key bits [0, key_bits).  keys[0]/vals[0] hold the input;
 // *result is the index (0/1) of the buffers holding the output.
+__global__ __launch_bounds__(256) void rs_iota_kernel(uint32_t *__restrict__ v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v[i] = (uint32_t)i;
+}
+
 pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, int key_bits,
                              void *workspace, int *result, hipStream_t st, bool iota_vals) {
   *result = 0;
-  if (n <= 1 || key_bits <= 0) return PCGX_OK;
+  if (n <= 1 || key_bits <= 0) {  // nothing to sort: the values as they are -- or as they would have been
+    if (iota_vals && n > 0) {
+      hipLaunchKernelGGL(rs_iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vals[0], n);
+      PCGX_HIP_TRY(hipGetLastError());
+    }
+    return PCGX_OK;
+  }
   if (n > 0x7fffffffll) return fail(PCGX_E_INVALID, "radix sort: n too large");
   const int items = rs_items(n);
   const int64_t tile = (int64_t)kRsThreads * items;

@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(
 // are: they are looked up by point index.
 constexpr int kMineTile = 2048;  // 256 threads x 8 rounds
 
-__global__ __launch_bounds__(256) void vx_mine_count_kernel(const uint32_t *__restrict__ primary, int64_t n, uint32_t lo,
-                                                            uint32_t hi, uint32_t *__restrict__ tile_count) {
+__global__ __launch_bounds__(256) void vx_mine_count_kernel(const uint32_t *__restrict__ primary, int64_t n, uint64_t lo,
+                                                            uint64_t hi, uint32_t *__restrict__ tile_count) {
   __shared__ uint32_t ws[4];
   const int64_t base = (int64_t)blockIdx.x * kMineTile;
   uint32_t c = 0;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void vx_mine_count_kernel(const uint32_t *__re
 }
 
 __global__ __launch_bounds__(256) void vx_mine_compact_kernel(
-    const uint32_t *__restrict__ primary, int64_t n, uint32_t lo, uint32_t hi, const uint32_t *__restrict__ tile_start,
+    const uint32_t *__restrict__ primary, int64_t n, uint64_t lo, uint64_t hi, const uint32_t *__restrict__ tile_start,
     const uint32_t *__restrict__ key_in, const uint32_t *__restrict__ idx_in, uint32_t *__restrict__ key_out,
     uint32_t *__restrict__ idx_out) {
   constexpr int kRounds = kMineTile / 256;
@@ -527,11 +527,10 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
     const int mtiles = (int)((n + kMineTile - 1) / kMineTile);
     uint32_t *mine_count = nullptr;
     PCGX_TRY(ar.alloc_n((size_t)mtiles, &mine_count));
-    hipLaunchKernelGGL(vx_mine_count_kernel, dim3(mtiles), dim3(256), 0, st, primary, n, (uint32_t)lo,
-                       (uint32_t)(hi > 0xffffffffull ? 0xffffffffull : hi), mine_count);
+    hipLaunchKernelGGL(vx_mine_count_kernel, dim3(mtiles), dim3(256), 0, st, primary, n, lo, hi, mine_count);
     hipLaunchKernelGGL(seg_scan_kernel, dim3(1), dim3(1024), 0, st, mine_count, mtiles, d_total);
-    hipLaunchKernelGGL(vx_mine_compact_kernel, dim3(mtiles), dim3(256), 0, st, primary, n, (uint32_t)lo,
-                       (uint32_t)(hi > 0xffffffffull ? 0xffffffffull : hi), (const uint32_t *)mine_count,
+    hipLaunchKernelGGL(vx_mine_compact_kernel, dim3(mtiles), dim3(256), 0, st, primary, n, lo, hi,
+                       (const uint32_t *)mine_count,
                        (const uint32_t *)keys[0], (const uint32_t *)nullptr, keys[1], vals[1]);
     iota = false;
     int32_t h_err0 = 0;
