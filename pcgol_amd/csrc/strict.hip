@@ -258,30 +258,45 @@ __device__ __forceinline__ uint32_t serial_leaf(uint32_t s, const float *t, int 
 // all 2048 additions of a tile, one after the other: the terms go to LDS in their order and every
 // lane runs the same chain over them (broadcast reads; the next 32 terms are read while the 32
 // additions on the current ones run)
-__device__ __forceinline__ uint32_t serial_tile(uint32_t s, const float *t, int lane, float *lds /* [kTile] of this wave */) {
+// a tile's terms in their order in LDS (every lane its leaf)
+__device__ __forceinline__ void stage_tile(const float *t, int lane, float *lds /* [kTile] of this wave */) {
   float4 *w4 = reinterpret_cast<float4 *>(lds) + lane * (kLeaf / 4);
 #pragma unroll
   for (int v = 0; v < kLeaf / 4; v++) w4[v] = make_float4(t[4 * v], t[4 * v + 1], t[4 * v + 2], t[4 * v + 3]);
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
-  const float4 *r4 = reinterpret_cast<const float4 *>(lds);
+}
+
+// the additions of staged terms [first, first + count) (multiples of 64), one after the other: every
+// lane runs the same chain (broadcast reads; the next 32 terms are read while the 32 additions on
+// the current ones run)
+__device__ __forceinline__ uint32_t serial_span(uint32_t s, const float *lds, int first, int count) {
+  const float4 *r4 = reinterpret_cast<const float4 *>(lds) + first / 4;
+  const int n4 = count / 4;
   float x = u2f(s);
   float4 a[8], b[8];
 #pragma unroll
   for (int u = 0; u < 8; u++) a[u] = r4[u];
-  for (int k = 0; k < kTile / 4; k += 16) {
+  for (int k = 0; k < n4; k += 16) {
 #pragma unroll
     for (int u = 0; u < 8; u++) b[u] = r4[k + 8 + u];
 #pragma unroll
     for (int u = 0; u < 8; u++) x = (((x + a[u].x) + a[u].y) + a[u].z) + a[u].w;
-    const int kn = k + 16 < kTile / 4 ? k + 16 : 0;
+    const int kn = k + 16 < n4 ? k + 16 : 0;
 #pragma unroll
     for (int u = 0; u < 8; u++) a[u] = r4[kn + u];
 #pragma unroll
     for (int u = 0; u < 8; u++) x = (((x + b[u].x) + b[u].y) + b[u].z) + b[u].w;
   }
-  __builtin_amdgcn_wave_barrier();
   return f2u(x);
+}
+
+// all 2048 additions of a tile
+__device__ __forceinline__ uint32_t serial_tile(uint32_t s, const float *t, int lane, float *lds /* [kTile] of this wave */) {
+  stage_tile(t, lane, lds);
+  const uint32_t r = serial_span(s, lds, 0, kTile);
+  __builtin_amdgcn_wave_barrier();
+  return r;
 }
 
 // tiles at the start of every sum that are added up term by term in the summary kernel (by the wave
@@ -381,6 +396,46 @@ __global__ __launch_bounds__(256) void strict_sum_kernel(const IcpState *__restr
       }
       T.s = S;
     }
+  } else {
+    // no window holds the tile (its sum changes sign, or runs through three binades: sums that hover
+    // around zero): four records of 16 leaves each, a window of its own for each that has one --
+    // the chain kernel then carries out 512 additions per quarter without one instead of 2048
+    const unsigned long long mixed = __ballot(cr.sg_or != cr.sg_and), neg = __ballot(cr.sg_or != 0u);
+    const int q = lane >> 4;
+    const uint32_t qmixed = (uint32_t)(mixed >> (16 * q)) & 0xffffu, qneg = (uint32_t)(neg >> (16 * q)) & 0xffffu;
+    uint32_t mnq = cr.mn, mxq = cr.mx;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      mnq = umin(mnq, (uint32_t)__shfl_xor((int)mnq, o));
+      mxq = umax(mxq, (uint32_t)__shfl_xor((int)mxq, o));
+    }
+    const uint32_t gq = (uint32_t)__shfl((int)g, q * 16);
+    int32_t kq = -1;
+    if (qmixed == 0u && (qneg == 0u || qneg == 0xffffu)) kq = choose_window(mnq, mxq, qneg ? 1u : 0u, gq & 0x7fffffffu);
+    Summary S = summary_identity();
+    if (kq >= 0) {
+      if ((cr.mn >> 23) == (cr.mx >> 23)) S = leaf_summary_binade(t, g, kq);
+      else S = leaf_summary_general(t, g, kq);
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {  // ordered composition over the 16 leaves of a quarter
+      const Summary Y = shfl_summary(S, lane + o);
+      if ((lane & (2 * o - 1)) == 0) S = compose(S, Y);
+    }
+    unsigned slot = 0xffffffffu;
+    if (lane == 0) slot = atomicAdd(W.aux_count, 1u);
+    slot = (unsigned)rfl((int)slot);
+    if (slot < (unsigned)W.naux) {
+      if ((lane & 15) == 0) {
+        TileRec Q;
+        Q.key = kq;
+        Q.in = Q.out = 0u;
+        Q.cons = 0;
+        Q.s = S;
+        reinterpret_cast<TileRec *>(W.aux + (size_t)slot * kLanes)[q] = Q;
+      }
+      T.cons |= (int32_t)(slot + 1u) << 8;
+    }
   }
   if (lane == 0) W.recs[row * W.ntiles + tile] = T;
 }
@@ -406,7 +461,26 @@ __device__ __forceinline__ uint32_t resolve_tile(uint32_t s, const float *__rest
   load_leaf(row_terms, tile, lane, t);
   int serial = 0;
   int l = 0;
-  if (aux) {
+  if (aux && key < 0) {
+    // a tile without a window: its four quarter records (strict_sum_kernel), 64 words, one per lane
+    const int32_t w = reinterpret_cast<const int32_t *>(aux)[lane];
+    stage_tile(t, lane, lds);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int32_t kq = __builtin_amdgcn_readlane(w, 16 * q);
+      Summary S;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        S.c[k] = __builtin_amdgcn_readlane(w, 16 * q + 4 + k);
+        S.lo[k] = __builtin_amdgcn_readlane(w, 16 * q + 8 + k);
+        S.hi[k] = __builtin_amdgcn_readlane(w, 16 * q + 12 + k);
+      }
+      if (kq >= 0 && apply(s, kq, S)) continue;
+      s = serial_span(s, lds, q * (kTile / 4), kTile / 4);
+      serial += kLanes / 4;
+    }
+    __builtin_amdgcn_wave_barrier();
+  } else if (aux) {
     const LeafAux A = aux[lane];
     uint32_t mine = s;
     const bool ok = apply(mine, key, A.pre);
