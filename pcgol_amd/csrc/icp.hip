@@ -145,7 +145,7 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     IcpKernelParams kp, float4 *__restrict__ match, uint32_t *__restrict__ first_leaf,
     double *__restrict__ block_partials, uint32_t *__restrict__ match_id,
     const float4 *__restrict__ normals, uint32_t *__restrict__ walk_list, uint32_t *__restrict__ walk_count,
-    int32_t n_grid_rows) {
+    int32_t n_grid_rows, const uint32_t *__restrict__ orig_of = nullptr, float4 *__restrict__ match_caller = nullptr) {
   static_assert(!(kGrid && kMinDist), "the grid answers exact-mode queries only");
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
@@ -224,7 +224,9 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     ub = dm + (pm.w >= 0.0f ? 0.0f : __builtin_inff());
   };
   auto emit = [&](int64_t i, const float4 &bp, float best_d) {
-    match[i] = make_float4(bp.x, bp.y, bp.z, __float_as_int(bp.w) >= 0 ? best_d : -1.0f);
+    const float4 rec = make_float4(bp.x, bp.y, bp.z, __float_as_int(bp.w) >= 0 ? best_d : -1.0f);
+    match[i] = rec;
+    if (match_caller) match_caller[orig_of[i]] = rec;  // strict sums: see icp_grid_kernel
     if (kPlane) match_id[i] = __float_as_uint(bp.w);
   };
   if (kGrid) {
@@ -283,7 +285,8 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
     const IcpState *__restrict__ state, IcpKernelParams kp, float4 *__restrict__ match,
     uint32_t *__restrict__ match_id, const float4 *__restrict__ normals, uint32_t *__restrict__ first_leaf,
     uint32_t *__restrict__ walk_list, uint32_t *__restrict__ walk_count, uint32_t n_corr_blocks,
-    double *__restrict__ block_partials, unsigned long long *__restrict__ trace = nullptr) {
+    double *__restrict__ block_partials, unsigned long long *__restrict__ trace = nullptr,
+    const uint32_t *__restrict__ orig_of = nullptr, float4 *__restrict__ match_caller = nullptr) {
   constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
   __shared__ float s_terms[NS][kIcpGridBlock + 16];  // + 16: the kSub-lane groups of one wave land on different banks
   if (state->done) return;  // uniform
@@ -330,6 +333,9 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
       const bool found = __float_as_int(best.w) >= 0;
       const float4 bp = make_float4(best.x, best.y, best.z, found ? best_d : -1.0f);
       match[i] = bp;
+      // strict sums add the pairs' terms in the CALLER's target order: the pair goes there as well (a
+      // 16-byte scatter here, +6 us at C4, instead of a gather through pos_of in the terms kernel, 10 us)
+      if (!kSums && match_caller) match_caller[orig_of[i]] = bp;
       if (kPlane) match_id[i] = __float_as_uint(best.w);
       if (found && kSums) {  // correspondence.go:27-29
         if (kPlane) accumulate_plane_terms(acc, x, y, z, bp, normals[__float_as_uint(best.w)]);
@@ -602,6 +608,12 @@ __global__ __launch_bounds__(64) void icp_strict_sums_kernel(const float *__rest
   }
 }
 
+__global__ __launch_bounds__(256) void invert_positions_kernel(const uint32_t *__restrict__ pos_of, int64_t n,
+                                                               uint32_t *__restrict__ orig_of) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) orig_of[pos_of[i]] = (uint32_t)i;
+}
+
 __global__ __launch_bounds__(256) void gather_soa_kernel(const float *__restrict__ q,
                                                          const int32_t *__restrict__ perm, int64_t n,
                                                          float *__restrict__ x, float *__restrict__ y,
@@ -627,6 +639,9 @@ struct pcgx_icp_session {
   IcpState *d_state = nullptr;
   double *d_partials = nullptr;
   uint32_t *d_pos_of = nullptr;  // [nt] position of the caller's target i in the session's order
+  uint32_t *d_orig_of = nullptr;      // strict sums: [nt] the caller's index of the target at a position
+  float4 *d_match_caller = nullptr;   // strict sums: match[] in the caller's target order
+  bool caller_order_fresh = false;    // the last correspondence pass wrote d_match_caller as well
   int strict = 0;                // sequential float32 sums: 1 = in parallel (strict.hip), 2 = one wave (icp_strict_sums_kernel)
   pcgx::StrictBuffers *strict_buf = nullptr;  // strict 1
   float *d_terms = nullptr;      // strict 2: [9][nt_pad] float32 terms in the caller's target order
@@ -752,6 +767,8 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   dev_cache_free(s->d_state);
   dev_cache_free(s->d_partials);
   dev_cache_free(s->d_pos_of);
+  dev_cache_free(s->d_orig_of);
+  dev_cache_free(s->d_match_caller);
   dev_cache_free(s->d_terms);
   dev_cache_free(s->d_valid);
   strict_destroy(s->strict_buf);
@@ -936,7 +953,26 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   // a deletion made after the session was created: from now on the reference's patched tree is walked
   // (the same handle's Nearest / Range already do), without hints from earlier iterations
   if (!s->patched && s->base->n_deleted > 0) s->patched = true;
+  s->caller_order_fresh = false;
   if (s->patched) return enqueue_corr_patched(s, st);
+  if (s->strict == 1 && !s->plane && s->nt > 0) {
+    // the strict sums run in the caller's target order: the kernels below also leave every pair there
+    if (!s->d_match_caller) {
+      hipError_t e = dev_cache_alloc((void **)&s->d_orig_of, (size_t)s->nt * sizeof(uint32_t));
+      if (e == hipSuccess) e = dev_cache_alloc((void **)&s->d_match_caller, (size_t)s->nt * sizeof(float4));
+      if (e != hipSuccess) {  // not required: strict.hip then gathers through pos_of
+        (void)hipGetLastError();
+        dev_cache_free(s->d_orig_of);
+        dev_cache_free(s->d_match_caller);
+        s->d_orig_of = nullptr;
+        s->d_match_caller = nullptr;
+      } else {
+        hipLaunchKernelGGL(invert_positions_kernel, dim3((unsigned)((s->nt + 255) / 256)), dim3(256), 0, st,
+                           (const uint32_t *)s->d_pos_of, s->nt, s->d_orig_of);
+      }
+    }
+    s->caller_order_fresh = s->d_match_caller != nullptr;
+  }
   TreeView tv = s->base->view();
   tv.tight_levels = tight;
   tv.chunks_per_refill = chunks;
@@ -953,7 +989,9 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
     else if (s->strict)
       hipLaunchKernelGGL((icp_grid_kernel<false, false, false>), dim3(xcd_grid(gb)), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z,
                          s->nt, s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals,
-                         s->d_first_leaf, s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
+                         s->d_first_leaf, s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials,
+                         (unsigned long long *)nullptr, (const uint32_t *)(s->caller_order_fresh ? s->d_orig_of : nullptr),
+                         s->caller_order_fresh ? s->d_match_caller : nullptr);
     else
       hipLaunchKernelGGL(icp_grid_kernel<false>, dim3(xcd_grid(gb)), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
                          s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
@@ -968,7 +1006,9 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
     hipLaunchKernelGGL((icp_corr_kernel<MD, false, GR, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, \
                        s->nt, s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, s->d_match_id,           \
                        (const float4 *)s->d_normals, s->d_walk_list, s->d_walk_count,                                 \
-                       (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock));                                       \
+                       (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock),                                        \
+                       (const uint32_t *)(s->caller_order_fresh ? s->d_orig_of : nullptr),                            \
+                       s->caller_order_fresh ? s->d_match_caller : nullptr);                                          \
   else                                                                                                                \
   hipLaunchKernelGGL((icp_corr_kernel<MD, PL, GR>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,     \
                      s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, s->d_match_id,                   \
@@ -994,8 +1034,12 @@ static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
     if (!s->strict_buf)
       PCGX_TRY(strict_create(s->nt, s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, (const uint32_t *)s->d_pos_of,
                              &s->strict_buf, st));
-    PCGX_TRY(strict_enqueue(s->strict_buf, (const float4 *)s->d_match, (const uint32_t *)s->d_pos_of, s->d_state,
-                            s->d_sums, s->kp, kFuseUpdate, st));
+    if (s->caller_order_fresh)  // pairs already in the caller's order: no gather through pos_of
+      PCGX_TRY(strict_enqueue(s->strict_buf, (const float4 *)s->d_match_caller, (const uint32_t *)nullptr, s->d_state,
+                              s->d_sums, s->kp, kFuseUpdate, st));
+    else
+      PCGX_TRY(strict_enqueue(s->strict_buf, (const float4 *)s->d_match, (const uint32_t *)s->d_pos_of, s->d_state,
+                              s->d_sums, s->kp, kFuseUpdate, st));
     return PCGX_OK;
   }
   // strict 2: the plain dependent chain, one wave (kept as the on-device cross-check of strict 1)

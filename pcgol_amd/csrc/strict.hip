@@ -146,7 +146,7 @@ __global__ __launch_bounds__(kTermsBlock) void strict_terms_kernel(const float4 
       bp[h][c] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
       tx[h][c] = ty[h][c] = tz[h][c] = 0.0f;
       if (i < W.nt) {
-        bp[h][c] = match[pos_of[i]];
+        bp[h][c] = pos_of ? match[pos_of[i]] : match[i];  // (nullptr: match[] is in the caller's order already)
         tx[h][c] = W.xyz_caller[3 * i];
         ty[h][c] = W.xyz_caller[3 * i + 1];
         tz[h][c] = W.xyz_caller[3 * i + 2];

@@ -258,12 +258,15 @@ def test_c4_full_size_vs_oracle():
     assert np.max(np.abs(trans - o32["trans"])) <= 3e-5
 
 
-@pytest.mark.parametrize("n,max_dist", [(5000, 0.5), (20003, 0.03), (200000, 0.5)])
-def test_strict_mode_is_bit_identical_to_the_reference_sums(n, max_dist):
+@pytest.mark.parametrize("n,max_dist,grid", [(5000, 0.5, "1"), (20003, 0.03, "1"), (200000, 0.5, "1"), (20003, 0.03, "0")],
+                         ids=["5000", "20003-no-partner", "200000", "20003-walk-only"])
+def test_strict_mode_is_bit_identical_to_the_reference_sums(n, max_dist, grid, monkeypatch):
     """STRICT sums (sequential float32 in target order, evaluator.go:122-145, evaluated in parallel:
     csrc/strict_sum.h): Evaluated and every pose of the Fit loop equal the oracle's Go-semantics
     run bit for bit -- also when many targets find no partner (max_dist 0.03) and the count is no
-    multiple of the tile size."""
+    multiple of the tile size; and when every pair comes from the tree walk (PCGX_GRID=0: the pairs
+    reach the caller-order copy the sums read through the walk kernel's stores)."""
+    monkeypatch.setenv("PCGX_GRID", grid)
     c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
     c["max_dist"] = max_dist
     if max_dist < 0.1:  # targets that never find a partner, scattered through the target order
