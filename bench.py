@@ -278,8 +278,9 @@ def main():
     # Rehearsal of the N > 1 path on a one-GPU box: PCGX_BENCH_REHEARSE=1 puts every rank on cuda:0
     # and exchanges through the callback communicator over gloo (RCCL refuses two ranks on one
     # device).  Never used by the driver; such numbers are not comparable (ranks share the GPU).
+    # =2: every rank on cuda:0 but RCCL is tried first -- it refuses, which exercises the fall-back below.
     rehearse = os.environ.get("PCGX_BENCH_REHEARSE") == "1"
-    if rehearse:
+    if os.environ.get("PCGX_BENCH_REHEARSE") in ("1", "2"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -307,6 +308,7 @@ def main():
                           cfg["max_iteration"])
     sess.set_strict(1 if strict else 0)
     comm = None
+    exchange_fallback = None
     if world > 1:
         if rehearse:
             comm = Comm.gloo()
@@ -319,7 +321,21 @@ def main():
                     t = torch.zeros(128, dtype=torch.uint8)
                     dist.broadcast(t, 0)
                     return bytes(t.tolist())
-            comm = Comm.rccl(rank, world, BroadcastStore())
+            # RCCL inside the library; should its set-up fail on any rank (missing library, IPC refused),
+            # every rank takes the host callback over gloo instead and the line says so
+            rccl_error = None
+            try:
+                comm = Comm.rccl(rank, world, BroadcastStore())
+            except Exception as e:  # noqa: BLE001
+                rccl_error = str(e)
+            ok = torch.tensor([0 if rccl_error else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm = Comm.gloo()
+                exchange_fallback = "host callback over gloo (RCCL set-up failed on a rank%s)" % (
+                    ": " + rccl_error[:120] if rccl_error else "")
     in_fit = [0]
 
     def step():
@@ -460,7 +476,7 @@ def main():
                        "parallelism": "spatial target tiles x%d (synth.spatial_cell), tree replicated" % world,
                        "exchange": "none" if world == 1 else "all-reduce 10 x f64 per step (%s)"
                                    % ("callback over gloo: REHEARSAL on one GPU, not a measurement" if rehearse
-                                      else "RCCL inside libpcgx.so")},
+                                      else (exchange_fallback or "RCCL inside libpcgx.so"))},
             "roofline": roof,
             "tree_build_s": build_s,
             "final_value": float(stat.Evaluated.Value),

@@ -55,3 +55,17 @@ def test_bench_starts_its_own_ranks():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4", "--points", "100000"]
     _check(_run(cmd, env))
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bench_falls_back_when_rccl_refuses():
+    """Two ranks on one device: RCCL's set-up fails (duplicate GPU) on the ranks; all of them must then
+    agree on the host callback over gloo, finish, and say so in the line."""
+    env = dict(os.environ, PCGX_BENCH_REHEARSE="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4", "--points", "100000"]
+    d = _run(cmd, env)
+    assert d["n_gpus"] == 2 and "RCCL set-up failed" in d["config"]["exchange"]
+    assert d["final_value"] == d["final_value"] and d["final_value"] < 1e-3
