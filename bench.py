@@ -60,7 +60,7 @@ def load_traffic(kernel):
                 d = json.load(f)
         except (OSError, ValueError):
             continue
-        for name, c in d.items():
+        for name, c in sorted(d.items(), key=lambda kv: -len(kv[0])):  # the most specific entry first
             if kernel in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 scale = float(c.get("fetch_scale", 2.0))
                 fetch = c["FETCH_SIZE"]["mean_per_dispatch"] * 1024.0 * scale + float(c.get("fetch_add_bytes", 0.0))
@@ -179,7 +179,9 @@ def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, ic
                     "walk_kernel_ms": kms / max(kn, 1)}
         if gn > 0:
             kernel_s = gms / gn * 1e-3
-            traffic, src = load_traffic("grid_nearest_kernel")
+            traffic, src = load_traffic("grid_nearest_kernel<false> [queries in %s order]" % ("Morton" if presort else "caller"))
+            if traffic is None:
+                traffic, src = load_traffic("grid_nearest_kernel")
             out[key].update({"grid_kernel_ms": gms / gn,
                              "frac_survey_8d": ref / kernel_s / 1e9 / HBM_PEAK_GBS,  # > 1 possible: the grid reads less than the reference's walk
                              "frac_compulsory": (20 * len(c2q) + 16 * tree.Len()) / kernel_s / 1e9 / HBM_PEAK_GBS,

@@ -13,14 +13,13 @@ from collections import defaultdict
 # element (the sector it costs; 49 G elements/s = 3.1 TB/s of sectors), a random 16-byte row at 64-128
 # bytes.  So: streaming kernels x 2; kernels whose loads are mostly scattered gathers x 1, plus half
 # of their (known) coalesced reads, which the counter under-reports like any streaming read.
-GATHER_KERNELS = ("icp_grid_kernel", "grid_nearest_kernel", "seg_reduce_kernel", "strict_terms_kernel", "icp_corr_kernel",
+GATHER_KERNELS = ("icp_grid_kernel", "grid_nearest_kernel", "seg_reduce_kernel", "icp_corr_kernel",
                   "nearest_kernel", "range_kernel")
 # coalesced bytes the gather kernels read per launch at the bench's sizes (1M targets / queries, 10M voxel points)
 STREAMED = {"icp_grid_kernel<false": (12 + 16 * 19 / 20) * 1e6,          # target xyz + previous pair (19 of 20 iterations)
             "icp_grid_kernel<true": (12 + 16 * 19 / 20 + 4) * 1e6,       # + matched id
             "grid_nearest_kernel": (12 + 4) * 1e6,                        # query + its position in the batch
-            "seg_reduce_kernel": 8 * 10e6,                                # sorted key + sorted index
-            "strict_terms_kernel": (4 + 12) * 1e6}                        # pos_of + target xyz in the caller's order
+            "seg_reduce_kernel": 8 * 10e6}                                # sorted key + sorted index
 # one VoxelGrid C3 call (plain mode, 22-bit key: three radix passes) in kernel launches
 VOXEL_CALL = {"minmax_partial_packed_kernel": 1, "minmax_final_kernel": 1, "voxel_key_kernel": 1,
               "rs_hist_kernel<16>": 3, "rs_scan_rows_kernel": 3, "rs_scatter_kernel<16>": 3,
@@ -34,14 +33,31 @@ def short(name):
     return n.strip()
 
 
+# kernels that bench.py launches first on one kind of input, then as often on another: counters per half
+HALVES = {"grid_nearest_kernel<false>": ("queries in Morton order", "queries in caller order")}
+
+
 def read_pmc(pattern):
     pmc = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for p in glob.glob(pattern, recursive=True):
-        for r in csv.DictReader(open(p)):
+        rows = list(csv.DictReader(open(p)))
+        order = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> values in launch order
+        for r in rows:
             k = short(r.get("Kernel_Name", "?"))
+            v = float(r.get("Counter_Value", 0) or 0)
             a = pmc[k][r.get("Counter_Name")]
-            a[0] += float(r.get("Counter_Value", 0) or 0)
+            a[0] += v
             a[1] += 1
+            if k in HALVES:
+                order[k][r.get("Counter_Name")].append((int(r.get("Dispatch_Id", 0) or 0), v))
+        for k, cs in order.items():
+            for c, vals in cs.items():
+                vals.sort()
+                h = len(vals) // 2
+                for part, name in ((vals[:h], HALVES[k][0]), (vals[h:], HALVES[k][1])):
+                    a = pmc["%s [%s]" % (k, name)][c]
+                    a[0] += sum(v for _, v in part)
+                    a[1] += len(part)
     return pmc
 
 
