@@ -36,7 +36,13 @@ __global__ __launch_bounds__(kRangeBlock) void range_kernel(TreeView tv, const f
                                                             uint32_t *__restrict__ out_key,
                                                             uint32_t *__restrict__ out_query) {
   extern __shared__ uint32_t s_stack[];
-  const int64_t pos = (int64_t)blockIdx.x * kRangeBlock + threadIdx.x;
+  // launch positions are in Morton order when `perm` is given: an XCD takes a contiguous eighth of
+  // them, so its L2 holds that region's part of the tree (pcgx_internal.h, xcd_tile).  (Two queries
+  // per lane with their walks interleaved -- two node fetches in flight -- measured 1.4x SLOWER at
+  // 200k queries: half as many waves, each with twice the instructions; the walk is bound by how
+  // fast one wave issues its dependent instructions, and there are too few waves as it is.)
+  const uint32_t n_tiles = (uint32_t)((nq + kRangeBlock - 1) / kRangeBlock);
+  const int64_t pos = (int64_t)xcd_tile(blockIdx.x, n_tiles) * kRangeBlock + threadIdx.x;
   if (pos >= nq) return;
   // perm (optional): launch position -> query index (Morton order: the lanes of a wave walk
   // neighbouring sub-trees); everything is written at the query's own index
@@ -104,7 +110,7 @@ extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float
     PCGX_TRY(xtree_launch_range(outer, false, d_q, perm, nq, max_range * max_range, d_c, nullptr, 0, nullptr, nullptr,
                                 nullptr, st));
   else
-    hipLaunchKernelGGL(range_kernel<false>, dim3((unsigned)((nq + kRangeBlock - 1) / kRangeBlock)), dim3(kRangeBlock),
+    hipLaunchKernelGGL(range_kernel<false>, dim3(xcd_grid((unsigned)((nq + kRangeBlock - 1) / kRangeBlock))), dim3(kRangeBlock),
                        lds, st, tv, (const float *)d_q, (const int32_t *)perm, nq, max_range * max_range, d_c, nullptr, 0,
                        nullptr, nullptr, nullptr);
   PCGX_HIP_TRY(hipGetLastError());
@@ -166,7 +172,7 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
     PCGX_TRY(xtree_launch_range(outer, true, d_q, qperm, nq, max_range * max_range, nullptr, d_off, total, d_id, d_key,
                                 d_query, st));
   else
-    hipLaunchKernelGGL(range_kernel<true>, dim3((unsigned)((nq + kRangeBlock - 1) / kRangeBlock)), dim3(kRangeBlock),
+    hipLaunchKernelGGL(range_kernel<true>, dim3(xcd_grid((unsigned)((nq + kRangeBlock - 1) / kRangeBlock))), dim3(kRangeBlock),
                        lds, st, tv, d_q, (const int32_t *)qperm, nq, max_range * max_range, nullptr, d_off, total, d_id,
                        d_key, d_query);
   const unsigned tb = (unsigned)((total + 255) / 256);
