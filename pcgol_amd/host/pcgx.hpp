@@ -11,6 +11,8 @@
 //   pcgx::RegionGrowing     <- pc/segmentation/regiongrowing.RegionGrowing
 //   pcgx::PointToPlaneICP   <- (extension, no counterpart in the reference) the same Fit shape with
 //                              the point-to-plane evaluator / Gauss-Newton updater, HasHessian() == true
+//   pcgx::Comm              <- (no counterpart: the reference is one process) the exchange of the
+//                              several-GPU paths: PointToPointICP::FitSharded, VoxelGrid::FilterSharded
 #pragma once
 #include <array>
 #include <cstring>
@@ -53,6 +55,25 @@ struct CloudView {
   const void *data;
   int64_t points;
   int32_t stride, xyz_offset;
+};
+
+// The exchange between the ranks of a several-GPU run (one process per GPU, include/pcgx.h
+// "sharded"): RCCL inside the library from an id that rank 0 makes and the host passes on, or a host
+// function that sums `count` float64 in place over the ranks.
+class Comm {
+ public:
+  static pcgx_comm_id UniqueId() { pcgx_comm_id id; check(pcgx_comm_unique_id(&id)); return id; }
+  Comm(int rank, int world, const pcgx_comm_id &id) { check(pcgx_comm_init(rank, world, &id, &h_)); }
+  Comm(int rank, int world, pcgx_allreduce_fn fn, void *user) { check(pcgx_comm_init_callback(rank, world, fn, user, &h_)); }
+  ~Comm() { pcgx_comm_free(h_); }
+  Comm(const Comm &) = delete;
+  Comm &operator=(const Comm &) = delete;
+  int Rank() const { int32_t r, w; check(pcgx_comm_rank(h_, &r, &w)); return r; }
+  int World() const { int32_t r, w; check(pcgx_comm_rank(h_, &r, &w)); return w; }
+  pcgx_comm *handle() const { return h_; }
+
+ private:
+  pcgx_comm *h_ = nullptr;
 };
 
 class KDTree {  // pc/storage/kdtree/kdtree.go:14-23
@@ -116,6 +137,16 @@ class VoxelGrid {  // pc/filter/voxelgrid/voxelgrid.go:23-33 + option.go:14-18
     std::vector<uint8_t> out((size_t)c.points * c.stride);
     int64_t m = 0;
     check(pcgx_voxel_filter(c.data, c.points, c.stride, c.xyz_offset, LeafSize.data(), ChunkSize.data(), out.data(), &m));
+    out.resize((size_t)m * c.stride);
+    return out;
+  }
+  // This rank's share of Filter(c) over the ranks of `comm` (every rank passes the same cloud); the
+  // ranks' results, rank 0's first, are Filter's output record for record.  Collective.
+  std::vector<uint8_t> FilterSharded(const CloudView &c, const Comm &comm) const {
+    std::vector<uint8_t> out((size_t)c.points * c.stride);
+    int64_t m = 0;
+    check(pcgx_voxel_filter_sharded(comm.handle(), c.data, c.points, c.stride, c.xyz_offset, LeafSize.data(),
+                                    ChunkSize.data(), out.data(), &m));
     out.resize((size_t)m * c.stride);
     return out;
   }
@@ -196,25 +227,66 @@ struct Stat {  // icp/stat.go:3-6
   int NumIteration;
 };
 
+// PointToPointEvaluator.WeightFn (evaluator.go:19-23,72): the reference takes any closure, the device
+// one of the built-in forms (include/pcgx.h PCGX_WEIGHT_*); Kind 0 = DefaultEvaluateWeightFn (w = 1).
+struct WeightFn {
+  int32_t Kind = PCGX_WEIGHT_ONE;
+  float A = 0.0f;
+};
+
 class PointToPointICP {  // icp.go:18-67 with evaluator.go:69-73 and updater.go:18-22 options
  public:
   float MaxDist = 0.0f;
   int MinPairs = 0;
+  WeightFn EvaluateWeight;  // evaluator.go:72
   std::array<float, 6> Weight{}, Threshold{};
   int MaxIteration = 0;
+  // Strict: the evaluator's sums as the reference forms them (sequential float32 additions in target
+  // order, evaluator.go:122-145): Evaluated and every pose bit-identical to the Go code's.  Off: float64
+  // reductions of the same float32 terms (faster; equal up to the reference's own rounding noise).
+  bool Strict = false;
   std::pair<Mat4, Stat> Fit(const KDTree &base, const std::vector<Vec3> &target) const {
+    const pcgx_icp_params p = params(base);
+    Mat4 t;
+    pcgx_icp_stat st{};
+    const float *tp = target.empty() ? nullptr : target[0].data();
+    if (!Strict) {
+      check(pcgx_icp_fit(base.handle(), tp, (int64_t)target.size(), &p, t.data(), &st));
+      return {t, Stat{st.evaluated, st.num_iteration}};
+    }
+    pcgx_icp_session *s = nullptr;
+    check(pcgx_icp_session_create(base.handle(), tp, (int64_t)target.size(), 0, &p, nullptr, &s));
+    pcgx_status rc = pcgx_icp_session_set_strict(s, 1);
+    const int iters = MaxIteration > 0 ? MaxIteration : 20;  // updater.go:26-28
+    for (int k = 0; k < iters && rc == PCGX_OK; k++) rc = pcgx_icp_session_step(s, nullptr);
+    if (rc == PCGX_OK) rc = pcgx_icp_session_result(s, nullptr, t.data(), &st, nullptr);
+    pcgx_icp_session_free(s);
+    check(rc);
+    return {t, Stat{st.evaluated, st.num_iteration}};
+  }
+  // Fit on this rank's tile of the target; every rank returns the same transform (float64 sums,
+  // all-reduced over the ranks of `comm` once per iteration).  Collective.
+  std::pair<Mat4, Stat> FitSharded(const KDTree &base, const std::vector<Vec3> &tile, const Comm &comm) const {
+    const pcgx_icp_params p = params(base);
+    Mat4 t;
+    pcgx_icp_stat st{};
+    check(pcgx_icp_fit_sharded(base.handle(), tile.empty() ? nullptr : tile[0].data(), (int64_t)tile.size(), &p,
+                               comm.handle(), t.data(), &st));
+    return {t, Stat{st.evaluated, st.num_iteration}};
+  }
+
+ private:
+  pcgx_icp_params params(const KDTree &base) const {
     pcgx_icp_params p{};
     p.max_dist = MaxDist;
     p.min_dist_sq = base.MinDistSq;
     p.min_pairs = MinPairs;
+    p.weight_fn = EvaluateWeight.Kind;
+    p.weight_fn_param = EvaluateWeight.A;
     std::memcpy(p.weight, Weight.data(), sizeof p.weight);
     std::memcpy(p.threshold, Threshold.data(), sizeof p.threshold);
     p.max_iteration = MaxIteration;
-    Mat4 t;
-    pcgx_icp_stat st{};
-    check(pcgx_icp_fit(base.handle(), target.empty() ? nullptr : target[0].data(), (int64_t)target.size(), &p,
-                       t.data(), &st));
-    return {t, Stat{st.evaluated, st.num_iteration}};
+    return p;
   }
 };
 

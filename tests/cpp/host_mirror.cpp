@@ -104,6 +104,21 @@ int main(int argc, char **argv) {
         std::printf("icp iters %d value %.9g trans", r.second.NumIteration, r.second.Evaluated.value);
         for (float v : r.first) std::printf(" %.9g", v);
         std::printf("\n");
+        {  // strict sums with a built-in weight; and the one-rank forms of the several-GPU entry points
+          pcgx::PointToPointICP st = reg;
+          st.Strict = true;
+          st.EvaluateWeight = pcgx::WeightFn{PCGX_WEIGHT_HUBER, 0.0004f};
+          auto rs = st.Fit(*tree, target);
+          std::printf("icp_strict iters %d value %.9g trans", rs.second.NumIteration, rs.second.Evaluated.value);
+          for (float v : rs.first) std::printf(" %.9g", v);
+          std::printf("\n");
+          pcgx::Comm comm(0, 1, [](double *, int32_t, void *) -> int32_t { return 0; }, nullptr);
+          auto r1 = reg.FitSharded(*tree, target, comm);
+          std::printf("sharded1_icp same %d\n", (int)(r1.first == r.first && r1.second.NumIteration == r.second.NumIteration));
+          pcgx::VoxelGrid vg(pcgx::Vec3{0.5f, 0.5f, 0.5f});
+          const pcgx::CloudView cv{base.data(), (int64_t)base.size(), 12, 0};
+          std::printf("sharded1_voxel same %d world %d\n", (int)(vg.FilterSharded(cv, comm) == vg.Filter(cv)), comm.World());
+        }
         try {
           reg.MinPairs = (int)base.size() + 1;
           reg.Fit(*tree, target);

@@ -113,3 +113,14 @@ def test_cpp_host_mirror_known_answers(tmp_path, golden):
     assert int(icp[2]) == st.NumIteration
     assert np.array_equal(np.array([float(v) for v in icp[6:22]], np.float32), tr)
     assert "icp_minpairs ErrNotEnoughPairs" in out and "empty ErrNoPoint" in out
+    # strict sums + a built-in weight through the C++ mirror == through the Python mirror, bit for bit
+    s = picp.IcpSession(kdtree.New(base), target, 2.0, 3, None, None, 0, WeightFn=picp.WeightHuber(0.0004))
+    s.set_strict(1)
+    for _ in range(20):
+        s.step()
+    tr_s, st_s, _ = s.result()
+    s.close()
+    strict = [l for l in out if l.startswith("icp_strict ")][0].split()
+    assert int(strict[2]) == st_s.NumIteration
+    assert np.array_equal(np.array([float(v) for v in strict[6:22]], np.float32), tr_s)
+    assert "sharded1_icp same 1" in out and "sharded1_voxel same 1 world 1" in out
