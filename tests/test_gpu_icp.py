@@ -361,6 +361,37 @@ def test_strict_sums_on_structured_terms():
         s.close()
 
 
+def test_strict_sums_that_hover_around_zero():
+    """Targets = base points + zero-mean noise, no transform: all six gradient sums wander around zero
+    from the first pair to the last -- sign changes and three binades inside one tile, so many tiles
+    have no window at all and go through their quarter records or are added up term by term.  Still
+    the oracle's Go-semantics sums, bit for bit."""
+    n = 200_000
+    rng = np.random.Generator(np.random.PCG64(77))
+    base = synth.uniform_cloud(n, 10.0 * (n / 1e6) ** (1 / 3), 2)
+    noise = ((rng.integers(0, 1 << 16, size=(n, 3)).astype(np.float32) / f32(1 << 16)) - f32(0.5)) * f32(0.02)
+    target = np.ascontiguousarray((base[rng.permutation(n)] + noise).astype(np.float32))
+    t, o = kdtree.New(base), O.KDTree(base)
+    s = icp.IcpSession(t, target, 0.5, 6, np.full(6, 0.3, np.float32), np.full(6, -1.0, np.float32), 3)
+    s.set_strict(1)
+    trans = O.translate(0, 0, 0)
+    it = 0
+    tt = target.copy()
+    resolved = 0
+    for k in range(3):
+        s.step()
+        tr, st, conv = s.result()
+        resolved += int(s.strict_stats()[2])
+        oe = O.icp_evaluate(o, tt, 0.5, 6, sums_mode=0)
+        assert st.Evaluated.Value == oe["value"] and st.Evaluated.DistRMS == oe["dist_rms"], k
+        assert np.array_equal(st.Evaluated.Gradient, oe["gradient"]), k
+        trans, oconv, it = O.icp_update(trans, oe["gradient"], it, np.full(6, 0.3, np.float32), np.full(6, -1.0, np.float32), 3)
+        assert np.array_equal(tr, trans), k
+        tt = synth.transform_points(trans, target)
+    s.close()
+    assert resolved >= 20  # the case does what it is for: many tiles recomputed from the exact state
+
+
 @pytest.mark.parametrize("wf", [icp.WeightConstant(0.25), icp.WeightInverse(0.01), icp.WeightHuber(0.0009),
                                 icp.WeightTukey(0.004)], ids=["constant", "inverse", "huber", "tukey"])
 def test_builtin_weight_fns_match_the_oracle(wf):
