@@ -34,5 +34,14 @@ for mode in (1, 0):
         st = s.strict_stats()
         extra = " | per iteration: runs %.0f, runs not covered %.0f, tiles recomputed %.0f, leaves term by term %.0f" % (
             st[0] / 20, st[1] / 20, st[2] / 20, st[3] / 20)
+        extra += " | us per sum: scans %.1f, walk %.1f (recomputing %.1f), slowest walk of the last launch %.1f" % (
+            st[8] / 180 / 100.0, st[9] / 180 / 100.0, (st[10] + st[11]) / 180 / 100.0, st[46] / 100.0)
     print("strict %d: %.1f us per iteration%s" % (mode, dt * 1e6, extra))
+    if mode:  # per iteration (a read-back after every step: the clocks differ from the timed loop's)
+        L.check(L.lib().pcgx_icp_session_reset(s._h, None))
+        for k in range(20):
+            s.step()
+            st = s.strict_stats()
+            print("  iteration %2d: tiles recomputed %3d, leaves term by term %4d, slowest sum's walk %.0f us" % (
+                k, st[2], st[3], st[46] / 100.0))
     s.close()
