@@ -7,7 +7,7 @@
 
 namespace pcgx {
 
-constexpr int kGridBlock = 256;
+constexpr int kGridBlock = 64;
 
 __global__ __launch_bounds__(256) void grid_key_points_kernel(const float *__restrict__ xyz, int64_t n, GridView g,
                                                               uint32_t *__restrict__ keys) {
