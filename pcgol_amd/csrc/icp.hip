@@ -137,6 +137,7 @@ __device__ __forceinline__ void reduce_block_range(uint32_t *s_scratch, const fl
 // could certify (knn_grid.h); only the rest (walk_list, this workgroup's segment, walk_count[slot]
 // entries) is walked here.
 constexpr int kIcpGridBlock = 256;
+constexpr int kIcpStrictGridBlock = 64;  // strict sessions: no workgroup reduction in the grid pass, one wave per workgroup
 
 template <bool kMinDist, bool kPlane, bool kGrid, bool kSums = true>
 __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
@@ -291,10 +292,12 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
   __shared__ float s_terms[NS][kIcpGridBlock + 16];  // + 16: the kSub-lane groups of one wave land on different banks
   if (state->done) return;  // uniform
   // targets are stored in cell order: an XCD takes a contiguous eighth of them (pcgx_internal.h, xcd_tile)
-  const uint32_t n_tiles = (uint32_t)((nt + kIcpGridBlock - 1) / kIcpGridBlock);
+  // (without the sums a workgroup may be smaller than kIcpGridBlock: kIcpStrictGridBlock)
+  const uint32_t block = kSums ? (uint32_t)kIcpGridBlock : blockDim.x;
+  const uint32_t n_tiles = (uint32_t)((nt + block - 1) / block);
   const uint32_t tile = xcd_tile(blockIdx.x, n_tiles);
   if (tile >= n_tiles) return;  // uniform
-  const int64_t i = (int64_t)tile * kIcpGridBlock + threadIdx.x;
+  const int64_t i = (int64_t)tile * block + threadIdx.x;
   double acc[NS];
 #pragma unroll
   for (int k = 0; k < NS; k++) acc[k] = 0.0;
@@ -987,7 +990,9 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
                          s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
                          s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
     else if (s->strict)
-      hipLaunchKernelGGL((icp_grid_kernel<false, false, false>), dim3(xcd_grid(gb)), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z,
+      hipLaunchKernelGGL((icp_grid_kernel<false, false, false>),
+                         dim3(xcd_grid((unsigned)((s->nt + kIcpStrictGridBlock - 1) / kIcpStrictGridBlock))),
+                         dim3(kIcpStrictGridBlock), 0, st, s->base->grid, x, y, z,
                          s->nt, s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals,
                          s->d_first_leaf, s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials,
                          (unsigned long long *)nullptr, (const uint32_t *)(s->caller_order_fresh ? s->d_orig_of : nullptr),
