@@ -13,7 +13,7 @@
 
 namespace pcgx {
 
-constexpr int kRangeWalkBlock = 256;  // threads per block of a kernel using range_walk
+constexpr int kRangeWalkBlock = 64;  // threads per block of a kernel using range_walk
 
 // stk: this lane's frame column in LDS ([level][stk_stride], walk_stack_bytes(tv, block)).
 // on_hit(id, dist_sq) is called for every point with dist_sq < bound, in discovery order.
