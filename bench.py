@@ -192,8 +192,7 @@ def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, ic
     # the float64-tree reduction mode (round 1's default; what the sharded path computes per GPU)
     c4 = synth.c4_icp()
     s0 = icp.IcpSession(tree, c4["target"], c4["max_dist"], c4["min_pairs"], c4["weight"], c4["threshold"],
-                        c4["max_iteration"])
-    s0.set_strict(0)
+                        c4["max_iteration"], SumsMode=icp.SumsF64Tree)
     time_session_steps(torch, L, s0, 20, 20, stream)
     dt = time_session_steps(torch, L, s0, 100, 20, stream) / 100
     out["icp_f64_tree_c4"] = {"mpoints_per_s": len(c4["target"]) / dt / 1e6, "ms_per_step": dt * 1e3,
@@ -307,8 +306,7 @@ def main():
     stream = side_stream.cuda_stream
     strict = world == 1 and not args.f64_tree
     sess = icp.IcpSession(tree, tile, cfg["max_dist"], cfg["min_pairs"], cfg["weight"], cfg["threshold"],
-                          cfg["max_iteration"])
-    sess.set_strict(1 if strict else 0)
+                          cfg["max_iteration"], SumsMode=icp.SumsReference if strict else icp.SumsF64Tree)
     comm = None
     exchange_fallback = None
     if world > 1:

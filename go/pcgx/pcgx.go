@@ -313,7 +313,21 @@ type Evaluator struct {
 	// closure, the device one of the built-in forms below.  Weight.Func() is the matching closure
 	// for the CPU evaluator, so both compute the same float32 weights.  Zero value: w = 1.
 	Weight WeightFn
+	// Sums selects how the nine sums of evaluator.go:122-145 are formed (include/pcgx.h PCGX_SUMS_*).
+	// Zero value SumsReference: the reference's own sequential float32 additions, evaluated exactly by
+	// the whole GPU -- Evaluate and Fit return what the CPU code returns, bit for bit, at any size.
+	// SumsF64Tree: a fixed-order float64 reduction of the same terms (about 3x faster per iteration at
+	// 1M pairs; differs from the reference by the reference's own rounding noise, 1.6e-5 on the pose
+	// at 1M pairs); it is what FitSharded computes when the target is spread over several ranks.
+	Sums int
 }
+
+// Evaluator.Sums (include/pcgx.h PCGX_SUMS_*).
+const (
+	SumsReference      = 0
+	SumsF64Tree        = 1
+	SumsReferenceChain = 2 // one wave adding term after term: the on-device cross-check
+)
 
 // WeightFn kinds (include/pcgx.h PCGX_WEIGHT_*).
 const (
@@ -390,6 +404,7 @@ func (e *Evaluator) Evaluate(base storage.Search, target pc.Vec3RandomAccessor) 
 	var p C.pcgx_icp_params
 	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(k.MinDistSq), C.int32_t(e.MinPairs)
 	p.weight_fn, p.weight_fn_param = C.int32_t(e.Weight.Kind), C.float(e.Weight.A)
+	p.sums_mode = C.int32_t(e.Sums)
 	rc := C.pcgx_icp_evaluate_params(k.h, tp, C.int64_t(target.Len()), &p, &ev)
 	runtime.KeepAlive(k)
 	if err := status(rc); err != nil {
@@ -411,6 +426,7 @@ func Fit(base *KDTree, target pc.Vec3RandomAccessor, e *Evaluator, u *icp.Gradie
 	var p C.pcgx_icp_params
 	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(base.MinDistSq), C.int32_t(e.MinPairs)
 	p.weight_fn, p.weight_fn_param = C.int32_t(e.Weight.Kind), C.float(e.Weight.A)
+	p.sums_mode = C.int32_t(e.Sums)
 	if u != nil {
 		for i := 0; i < 6; i++ {
 			p.weight[i], p.threshold[i] = C.float(u.Weight[i]), C.float(u.Threshold[i])
@@ -679,54 +695,16 @@ func (r *RegionGrowing) SegmentByID(p mat.Vec3, maxRange float32) []int {
 
 // ------------------------------------------ strict sums and the sharded Fit
 
-// FitStrict is Fit with the evaluator's sums formed exactly as the Go code forms them
-// (sequential float32 additions in target order, evaluator.go:122-145): the returned transform and
-// Stat are bit-identical to PointToPointICPGradient.Fit on the CPU at any size.  The sums are
-// evaluated by the whole GPU (csrc/strict_sum.h), about 6x the time of the float64 reduction.
+// FitStrict is Fit with Evaluator.Sums forced to SumsReference, whatever e.Sums says: the evaluator's
+// sums formed exactly as the Go code forms them (sequential float32 additions in target order,
+// evaluator.go:122-145), so the returned transform and Stat are bit-identical to
+// PointToPointICPGradient.Fit on the CPU at any size.  Since SumsReference is the zero value, Fit
+// already does this for an Evaluator that does not ask for anything else; the name is kept for callers
+// written against the earlier shim, where the float64 reduction was the default.
 func FitStrict(base *KDTree, target pc.Vec3RandomAccessor, e *Evaluator, u *icp.GradientDescentUpdaterFactory) (mat.Mat4, icp.Stat, error) {
-	runtime.LockOSThread()
-	defer runtime.UnlockOSThread()
-	defer runtime.KeepAlive(base)
-	var p C.pcgx_icp_params
-	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(base.MinDistSq), C.int32_t(e.MinPairs)
-	p.weight_fn, p.weight_fn_param = C.int32_t(e.Weight.Kind), C.float(e.Weight.A)
-	maxIter := 20
-	if u != nil {
-		for i := 0; i < 6; i++ {
-			p.weight[i], p.threshold[i] = C.float(u.Weight[i]), C.float(u.Threshold[i])
-		}
-		p.max_iteration = C.int32_t(u.MaxIteration)
-		if u.MaxIteration > 0 {
-			maxIter = u.MaxIteration
-		}
-	}
-	t := packVec3(target)
-	var tp *C.float
-	if len(t) > 0 {
-		tp = (*C.float)(unsafe.Pointer(&t[0]))
-	}
-	var trans mat.Mat4
-	var st C.pcgx_icp_stat
-	var s *C.pcgx_icp_session
-	if err := status(C.pcgx_icp_session_create(base.h, tp, C.int64_t(target.Len()), 0, &p, nil, &s)); err != nil {
-		return trans, icp.Stat{NumIteration: 1}, err
-	}
-	defer C.pcgx_icp_session_free(s)
-	if err := status(C.pcgx_icp_session_set_strict(s, 1)); err != nil {
-		return trans, icp.Stat{}, err
-	}
-	for i := 0; i < maxIter; i++ {
-		if err := status(C.pcgx_icp_session_step(s, nil)); err != nil {
-			return trans, icp.Stat{}, err
-		}
-	}
-	rc := C.pcgx_icp_session_result(s, nil, (*C.float)(unsafe.Pointer(&trans[0])), &st, nil)
-	stat := icp.Stat{NumIteration: int(st.num_iteration)}
-	stat.Value, stat.DistRMS = float32(st.evaluated.value), float32(st.evaluated.dist_rms)
-	for i := 0; i < 6; i++ {
-		stat.Gradient[i] = float32(st.evaluated.gradient[i])
-	}
-	return trans, stat, status(rc)
+	strict := *e
+	strict.Sums = SumsReference
+	return Fit(base, target, &strict, u)
 }
 
 // Comm is the exchange of the sharded Fit: one process per GPU, every rank with a replica of the
@@ -764,7 +742,8 @@ func (c *Comm) Close() {
 }
 
 // FitSharded runs Fit on this rank's tile of the target; every rank returns the same transform.
-// The sums are float64 reductions (a sum spread over ranks has no sequential order to reproduce).
+// Over several ranks the sums are float64 reductions whatever e.Sums says (a sum spread over ranks has
+// no sequential order to reproduce); a communicator of one rank is Fit.
 func FitSharded(base *KDTree, tile pc.Vec3RandomAccessor, e *Evaluator, u *icp.GradientDescentUpdaterFactory, c *Comm) (mat.Mat4, icp.Stat, error) {
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
@@ -773,6 +752,7 @@ func FitSharded(base *KDTree, tile pc.Vec3RandomAccessor, e *Evaluator, u *icp.G
 	var p C.pcgx_icp_params
 	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(base.MinDistSq), C.int32_t(e.MinPairs)
 	p.weight_fn, p.weight_fn_param = C.int32_t(e.Weight.Kind), C.float(e.Weight.A)
+	p.sums_mode = C.int32_t(e.Sums)
 	if u != nil {
 		for i := 0; i < 6; i++ {
 			p.weight[i], p.threshold[i] = C.float(u.Weight[i]), C.float(u.Threshold[i])

@@ -278,7 +278,29 @@ typedef struct {
    * default.  Not offered for the point-to-plane extension. */
   int32_t weight_fn;
   float weight_fn_param; /* a */
+  /* How the evaluator's nine sums (evaluator.go:122-145) are formed: PCGX_SUMS_* below.  0 = the
+   * reference's own sums wherever they are defined (one GPU: bit-identical Evaluated and pose). */
+  int32_t sums_mode;
 } pcgx_icp_params;
+
+/* pcgx_icp_params.sums_mode.  The reference adds float32 terms pair after pair in target order; its
+ * result carries that chain's rounding (~1.6e-5 on the final transform at 1M pairs), so only a sum
+ * formed the same way meets "within 1e-5 of the Go code" at every size.
+ *  PCGX_SUMS_REFERENCE  (0, default) the reference's sequential float32 additions, evaluated exactly by
+ *                       the whole GPU (csrc/strict_sum.h) -- pcgx_icp_fit / _evaluate / sessions on one
+ *                       GPU.  A sharded session (pcgx_icp_session_step_sharded, pcgx_icp_fit_sharded
+ *                       with world > 1) and the point-to-plane extension have no sequential order /
+ *                       no reference sums to reproduce: they form float64 sums whatever this says.
+ *  PCGX_SUMS_F64_TREE   fixed-order float64 reduction of the same float32 terms: more accurate than the
+ *                       reference, equal to it up to ITS rounding noise; what a sharded sum computes.
+ *  PCGX_SUMS_REFERENCE_CHAIN  the reference's additions by ONE wave, term after term (milliseconds per
+ *                       1M pairs): the on-device cross-check of PCGX_SUMS_REFERENCE. */
+enum {
+  PCGX_SUMS_REFERENCE = 0,
+  PCGX_SUMS_F64_TREE = 1,
+  PCGX_SUMS_REFERENCE_CHAIN = 2,
+  PCGX_SUMS_KINDS = 3
+};
 
 enum {
   PCGX_WEIGHT_ONE = 0,      /* DefaultEvaluateWeightFn: return 1 */
@@ -409,18 +431,19 @@ PCGX_API pcgx_status pcgx_voxel_filter_sharded_dev(pcgx_comm *c, const void *d_d
 PCGX_API pcgx_status pcgx_voxel_filter_sharded(pcgx_comm *c, const void *data, int64_t n, int32_t stride,
                                                int32_t xyz_off, const float leaf[3], const int32_t chunk[3],
                                                void *out_data, int64_t *out_n);
-/* STRICT sums.  By default the evaluator's sums are float64 reductions of the reference's float32
- * terms: more accurate than the reference, equal to it only up to ITS rounding noise (sequential
- * float32 additions, evaluator.go:122-145; ~1.6e-5 on the final transform at 1M pairs).  With
- * strict on, the sums are the reference's: float32 additions in target order, every rounding
- * included, so Evaluated and the resulting pose are bit-identical to the Go code's at any size.
- * on = 1: evaluated by the whole GPU (csrc/strict_sum.h: the additions of a stretch act on the
- *         state as a translation of its mantissa that is proven per rounding class, stretches are
- *         composed, one wave applies them; exact by construction);
- * on = 2: one wave adds the terms one after the other (~7 ms per 1M pairs; kept as a cross-check);
- * on = 0: the float64 reduction.
- * Single-GPU sessions only (a sharded sum has no sequential order).  Environment PCGX_ICP_STRICT=1
- * (or 2) turns it on for every new session (pcgx_icp_fit / pcgx_icp_evaluate included). */
+/* Change a session's sums after its creation (pcgx_icp_params.sums_mode sets them at creation; the
+ * default is the reference's).  With strict on, the sums are the reference's: float32 additions in
+ * target order, every rounding included, so Evaluated and the resulting pose are bit-identical to
+ * the Go code's at any size.
+ * on = 1: PCGX_SUMS_REFERENCE -- evaluated by the whole GPU (csrc/strict_sum.h: the additions of a
+ *         stretch act on the state as a translation of its mantissa that is proven per rounding
+ *         class, stretches are composed, one wave applies them; exact by construction);
+ * on = 2: PCGX_SUMS_REFERENCE_CHAIN -- one wave adds the terms one after the other (~7 ms per 1M pairs);
+ * on = 0: PCGX_SUMS_F64_TREE -- the float64 reduction.
+ * Single-GPU sessions only (a sharded sum has no sequential order: step_sharded with world > 1
+ * refuses a session whose strict sums were asked for explicitly and runs a default one with float64
+ * sums).  Environment PCGX_ICP_STRICT=0 / 1 / 2 overrides sums_mode for every new session
+ * (experiments). */
 PCGX_API pcgx_status pcgx_icp_session_set_strict(pcgx_icp_session *s, int32_t on);
 /* Synchronise and read back trans / stat / converged flag.  Returns
  * PCGX_E_NOT_ENOUGH_PAIRS if an iteration failed. */

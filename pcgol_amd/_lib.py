@@ -25,6 +25,7 @@ PCGX_E_CORRUPT = 13
 PCGX_E_BAD_HEADER = 14
 PCGX_E_RCCL = 15
 PCGX_WEIGHT_ONE, PCGX_WEIGHT_CONSTANT, PCGX_WEIGHT_INVERSE, PCGX_WEIGHT_HUBER, PCGX_WEIGHT_TUKEY = range(5)
+PCGX_SUMS_REFERENCE, PCGX_SUMS_F64_TREE, PCGX_SUMS_REFERENCE_CHAIN = range(3)  # pcgx_icp_params.sums_mode
 PCGX_PCD_MAX_FIELDS = 64
 
 PCGX_KNN_PRESORT = 1
@@ -104,7 +105,7 @@ class IcpEvaluated(C.Structure):
 class IcpParams(C.Structure):
     _fields_ = [("max_dist", C.c_float), ("min_dist_sq", C.c_float), ("min_pairs", C.c_int32),
                 ("weight", C.c_float * 6), ("threshold", C.c_float * 6), ("max_iteration", C.c_int32),
-                ("weight_fn", C.c_int32), ("weight_fn_param", C.c_float)]
+                ("weight_fn", C.c_int32), ("weight_fn_param", C.c_float), ("sums_mode", C.c_int32)]
 
 
 class PcdHeader(C.Structure):  # pcgx_pcd_header

@@ -646,6 +646,8 @@ struct pcgx_icp_session {
   float4 *d_match_caller = nullptr;   // strict sums: match[] in the caller's target order
   bool caller_order_fresh = false;    // the last correspondence pass wrote d_match_caller as well
   int strict = 0;                // sequential float32 sums: 1 = in parallel (strict.hip), 2 = one wave (icp_strict_sums_kernel)
+  bool strict_explicit = false;  // asked for by name (set_strict, PCGX_SUMS_REFERENCE_CHAIN, the environment): a sharded step refuses
+                                 // it; the default (sums_mode 0) quietly becomes float64 sums there
   pcgx::StrictBuffers *strict_buf = nullptr;  // strict 1
   float *d_terms = nullptr;      // strict 2: [9][nt_pad] float32 terms in the caller's target order
   unsigned long long *d_valid = nullptr;  // strict: [nt_pad / 64] matched-target bits
@@ -740,6 +742,7 @@ extern "C" pcgx_status pcgx_icp_session_set_strict(pcgx_icp_session *s, int32_t 
   if (on && s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_strict: point-to-plane sessions have no reference sums to reproduce");
   if (on < 0 || on > 2) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_strict: mode must be 0, 1 or 2");
   s->strict = on;
+  s->strict_explicit = on != 0;
   return PCGX_OK;
 }
 
@@ -801,6 +804,8 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
                                 "cannot run on the device)", params->weight_fn);
   if (normals && params->weight_fn != PCGX_WEIGHT_ONE)
     return fail(PCGX_E_INVALID, "the point-to-plane extension takes the default weight only");
+  if (params->sums_mode < 0 || params->sums_mode >= PCGX_SUMS_KINDS)
+    return fail(PCGX_E_INVALID, "pcgx_icp_session_create: sums_mode %d is none of PCGX_SUMS_*", params->sums_mode);
   PCGX_TRY(ensure_init());
   hipStream_t st = ctx().stream;
   const int64_t n_base_ids = base->n;  // normals are indexed by the original ids
@@ -815,7 +820,14 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
   const_cast<pcgx_kdtree *>(base)->sessions.fetch_add(1);
   s->nt = nt;
   s->plane = normals != nullptr;
-  if (const char *e = getenv("PCGX_ICP_STRICT")) s->strict = s->plane ? 0 : (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0));
+  // the reference's own sums unless the caller asks otherwise (include/pcgx.h, PCGX_SUMS_*); the
+  // point-to-plane extension has no reference sums to reproduce
+  s->strict = s->plane ? 0 : (params->sums_mode == PCGX_SUMS_REFERENCE ? 1 : (params->sums_mode == PCGX_SUMS_F64_TREE ? 0 : 2));
+  s->strict_explicit = s->strict == 2;
+  if (const char *e = getenv("PCGX_ICP_STRICT")) {  // experiments: overrides sums_mode
+    s->strict = s->plane ? 0 : (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : 0));
+    s->strict_explicit = s->strict != 0;
+  }
   s->kp = make_kernel_params(params);
   s->kp.gn.damping = damping;
   s->max_iteration = s->kp.upd.max_iteration;
@@ -1128,7 +1140,9 @@ extern "C" pcgx_status pcgx_icp_session_step_sharded(pcgx_icp_session *s, pcgx_c
   int32_t rank = 0, world = 1;
   PCGX_TRY(pcgx_comm_rank(c, &rank, &world));
   if (world == 1) return pcgx_icp_session_step(s, stream);
-  if (s->strict) return fail(PCGX_E_INVALID, "strict sums are not offered on a sharded target (no sequential order)");
+  if (s->strict && s->strict_explicit)
+    return fail(PCGX_E_INVALID, "strict sums are not offered on a sharded target (no sequential order)");
+  s->strict = 0;  // the default (PCGX_SUMS_REFERENCE) on a sharded target: float64 sums, all-reduced
   PCGX_TRY(pcgx_icp_session_partials(s, stream));
   PCGX_TRY(pcgx_comm_allreduce_f64(c, s->d_sums, s->n_sums(), stream));
   return pcgx_icp_session_update(s, stream);
@@ -1141,7 +1155,6 @@ extern "C" pcgx_status pcgx_icp_fit_sharded(const pcgx_kdtree *base, const float
   if (!base || !params || !trans16 || !c) return fail(PCGX_E_INVALID, "pcgx_icp_fit_sharded: NULL argument");
   pcgx_icp_session *s = nullptr;
   PCGX_TRY(pcgx_icp_session_create(base, tile, nt, 0, params, nullptr, &s));
-  s->strict = 0;
   pcgx_status rc = PCGX_OK;
   // every rank enqueues MaxIteration steps: the loop state is the same on all of them (same sums),
   // so they stop together, and a step after `done` is a no-op on the device

@@ -97,9 +97,10 @@ class Comm:
     torch.distributed.TCPStore).  Comm.callback(rank, world, fn): the exchange through a host
     function fn(numpy float64 array) that sums the array over the ranks in place (e.g. gloo)."""
 
-    def __init__(self, handle, keep=None):
+    def __init__(self, handle, keep=None, world=1):
         self._h = handle
         self._keep = keep
+        self.world = int(world)
 
     @classmethod
     def rccl(cls, rank, world, store, key="pcgx_comm_id"):
@@ -114,7 +115,7 @@ class Comm:
             buf = C.create_string_buffer(raw, 128)
         h = C.c_void_p()
         L.check(L.lib().pcgx_comm_init(rank, world, buf, C.byref(h)))
-        return cls(h)
+        return cls(h, world=world)
 
     @classmethod
     def callback(cls, rank, world, fn):
@@ -132,7 +133,7 @@ class Comm:
         cb = proto(tramp)
         h = C.c_void_p()
         L.check(L.lib().pcgx_comm_init_callback(rank, world, C.cast(cb, C.c_void_p), None, C.byref(h)))
-        return cls(h, keep=cb)
+        return cls(h, keep=cb, world=world)
 
     @classmethod
     def gloo(cls, group=None):
@@ -163,8 +164,10 @@ class ShardedIcp:
     pose update runs on every GPU redundantly, so no rank ever waits for the host."""
 
     def __init__(self, base_tree, target_tile, MaxDist, MinPairs=0, Weight=None, Threshold=None,
-                 MaxIteration=0, group=None, force_exchange=False, BaseNormals=None, Damping=0.0, comm=None):
-        """BaseNormals: point-to-plane / Gauss-Newton extension; the exchange is then the all-reduce
+                 MaxIteration=0, group=None, force_exchange=False, BaseNormals=None, Damping=0.0, comm=None,
+                 SumsMode=None):
+        """SumsMode: None = float64 sums wherever there is an exchange, the reference's sums on one rank.
+        BaseNormals: point-to-plane / Gauss-Newton extension; the exchange is then the all-reduce
         of 30 doubles (sum r^2, J^T r, upper triangle of J^T J, sum w, pairs) instead of 10.
         comm: a Comm -- the exchange then runs inside libpcgx.so (pcgx_icp_session_step_sharded: what
         a Go host calls); without it the all-reduce is torch.distributed's on the sums tensor."""
@@ -182,13 +185,18 @@ class ShardedIcp:
         self.stream = torch.cuda.Stream()
         self.sums = torch.zeros(30 if BaseNormals is not None else 10, dtype=torch.float64, device="cuda")
         torch.cuda.current_stream().synchronize()
-        self.sess = _icp.IcpSession(base_tree, target_tile, MaxDist, MinPairs, Weight, Threshold, MaxIteration,
-                                    d_sums10=self.sums.data_ptr(), BaseNormals=BaseNormals, Damping=Damping)
-        self.max_iteration = self.sess.max_iteration
         import torch.distributed as dist
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # force_exchange: take the partials -> all-reduce -> update path even with one rank (tests)
         self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
+        # a sum spread over ranks has no sequential order: float64 sums wherever there is an exchange, the
+        # reference's own sums (the library's default) on one rank
+        sharded = self.exchange or (comm is not None and comm.world > 1)
+        self.sess = _icp.IcpSession(base_tree, target_tile, MaxDist, MinPairs, Weight, Threshold, MaxIteration,
+                                    d_sums10=self.sums.data_ptr(), BaseNormals=BaseNormals, Damping=Damping,
+                                    SumsMode=SumsMode if SumsMode is not None else
+                                    (_icp.SumsF64Tree if sharded else _icp.SumsReference))
+        self.max_iteration = self.sess.max_iteration
 
     def step(self):
         """One ICP iteration, enqueued on self.stream."""

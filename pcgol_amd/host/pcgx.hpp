@@ -241,31 +241,21 @@ class PointToPointICP {  // icp.go:18-67 with evaluator.go:69-73 and updater.go:
   WeightFn EvaluateWeight;  // evaluator.go:72
   std::array<float, 6> Weight{}, Threshold{};
   int MaxIteration = 0;
-  // Strict: the evaluator's sums as the reference forms them (sequential float32 additions in target
-  // order, evaluator.go:122-145): Evaluated and every pose bit-identical to the Go code's.  Off: float64
-  // reductions of the same float32 terms (faster; equal up to the reference's own rounding noise).
-  bool Strict = false;
+  // Sums (include/pcgx.h PCGX_SUMS_*).  Default PCGX_SUMS_REFERENCE: the evaluator's sums as the reference
+  // forms them (sequential float32 additions in target order, evaluator.go:122-145): Evaluated and every
+  // pose bit-identical to the Go code's.  PCGX_SUMS_F64_TREE: float64 reductions of the same float32 terms
+  // (faster; equal up to the reference's own rounding noise; what FitSharded computes over several ranks).
+  int32_t Sums = PCGX_SUMS_REFERENCE;
   std::pair<Mat4, Stat> Fit(const KDTree &base, const std::vector<Vec3> &target) const {
     const pcgx_icp_params p = params(base);
     Mat4 t;
     pcgx_icp_stat st{};
     const float *tp = target.empty() ? nullptr : target[0].data();
-    if (!Strict) {
-      check(pcgx_icp_fit(base.handle(), tp, (int64_t)target.size(), &p, t.data(), &st));
-      return {t, Stat{st.evaluated, st.num_iteration}};
-    }
-    pcgx_icp_session *s = nullptr;
-    check(pcgx_icp_session_create(base.handle(), tp, (int64_t)target.size(), 0, &p, nullptr, &s));
-    pcgx_status rc = pcgx_icp_session_set_strict(s, 1);
-    const int iters = MaxIteration > 0 ? MaxIteration : 20;  // updater.go:26-28
-    for (int k = 0; k < iters && rc == PCGX_OK; k++) rc = pcgx_icp_session_step(s, nullptr);
-    if (rc == PCGX_OK) rc = pcgx_icp_session_result(s, nullptr, t.data(), &st, nullptr);
-    pcgx_icp_session_free(s);
-    check(rc);
+    check(pcgx_icp_fit(base.handle(), tp, (int64_t)target.size(), &p, t.data(), &st));
     return {t, Stat{st.evaluated, st.num_iteration}};
   }
-  // Fit on this rank's tile of the target; every rank returns the same transform (float64 sums,
-  // all-reduced over the ranks of `comm` once per iteration).  Collective.
+  // Fit on this rank's tile of the target; every rank returns the same transform (several ranks: float64
+  // sums, all-reduced over the ranks of `comm` once per iteration; one rank: Fit).  Collective.
   std::pair<Mat4, Stat> FitSharded(const KDTree &base, const std::vector<Vec3> &tile, const Comm &comm) const {
     const pcgx_icp_params p = params(base);
     Mat4 t;
@@ -283,6 +273,7 @@ class PointToPointICP {  // icp.go:18-67 with evaluator.go:69-73 and updater.go:
     p.min_pairs = MinPairs;
     p.weight_fn = EvaluateWeight.Kind;
     p.weight_fn_param = EvaluateWeight.A;
+    p.sums_mode = Sums;
     std::memcpy(p.weight, Weight.data(), sizeof p.weight);
     std::memcpy(p.threshold, Threshold.data(), sizeof p.threshold);
     p.max_iteration = MaxIteration;

@@ -95,8 +95,15 @@ def WeightTukey(c_sq):
     return WeightFn(L.PCGX_WEIGHT_TUKEY, c_sq)
 
 
+SumsReference = L.PCGX_SUMS_REFERENCE            # the reference's sequential float32 sums (default; one GPU)
+SumsF64Tree = L.PCGX_SUMS_F64_TREE                # fixed-order float64 reduction of the same terms
+SumsReferenceChain = L.PCGX_SUMS_REFERENCE_CHAIN  # the reference's sums by one wave (cross-check)
+
+
 class PointToPointEvaluator:  # evaluator.go:69-76
-    def __init__(self, Corresponder, MinPairs=0, WeightFn=None):
+    def __init__(self, Corresponder, MinPairs=0, WeightFn=None, SumsMode=SumsReference):
+        """SumsMode (not in the reference): include/pcgx.h PCGX_SUMS_*; the default forms the sums as
+        the Go code does, bit for bit."""
         if WeightFn is not None and not isinstance(WeightFn, globals()["WeightFn"]):
             raise NotImplementedError("a custom WeightFn closure cannot run on the device: use one of the built-in "
                                       "forms (icp.WeightConstant / WeightInverse / WeightHuber / WeightTukey)")
@@ -105,6 +112,7 @@ class PointToPointEvaluator:  # evaluator.go:69-76
         self.Corresponder = Corresponder
         self.MinPairs = int(MinPairs)
         self.WeightFn = WeightFn
+        self.SumsMode = int(SumsMode)
 
     def HasGradient(self):
         return True
@@ -117,14 +125,16 @@ class PointToPointEvaluator:  # evaluator.go:69-76
             raise TypeError("base must be a pcgol_amd KDTree")
         target = L.f32c(target).reshape(-1, 3)
         ev = L.IcpEvaluated()
-        p = _params(self.Corresponder.MaxDist, base.MinDistSq, self.MinPairs, np.zeros(6), np.zeros(6), 0, self.WeightFn)
+        p = _params(self.Corresponder.MaxDist, base.MinDistSq, self.MinPairs, np.zeros(6), np.zeros(6), 0, self.WeightFn,
+                    self.SumsMode)
         L.check(L.lib().pcgx_icp_evaluate_params(base._h, L.ptr(target), len(target), C.byref(p), C.byref(ev)))
         return Evaluated(ev)
 
 
-def _params(max_dist, min_dist_sq, min_pairs, weight, threshold, max_iteration, weight_fn=None):
+def _params(max_dist, min_dist_sq, min_pairs, weight, threshold, max_iteration, weight_fn=None, sums_mode=0):
     p = L.IcpParams()
     p.max_dist, p.min_dist_sq, p.min_pairs, p.max_iteration = max_dist, min_dist_sq, min_pairs, max_iteration
+    p.sums_mode = int(sums_mode)
     if weight_fn is not None:
         p.weight_fn, p.weight_fn_param = weight_fn.kind, float(weight_fn.a)
     for i in range(6):
@@ -186,7 +196,7 @@ class PointToPointICPGradient:  # icp.go:18-67
         uf = self.UpdaterFactory or GradientDescentUpdaterFactory()
         target = L.f32c(target).reshape(-1, 3)
         p = _params(ev.Corresponder.MaxDist, base.MinDistSq, ev.MinPairs, uf.Weight, uf.Threshold, uf.MaxIteration,
-                    ev.WeightFn)
+                    ev.WeightFn, ev.SumsMode)
         trans = np.empty(16, np.float32)
         st = L.IcpStat()
         rc = L.lib().pcgx_icp_fit(base._h, L.ptr(target), len(target), C.byref(p), L.ptr(trans), C.byref(st))
@@ -202,13 +212,15 @@ class IcpSession:
     """Device-resident Fit loop cut at the per-iteration exchange (include/pcgx.h)."""
 
     def __init__(self, base, target, MaxDist, MinPairs=0, Weight=None, Threshold=None, MaxIteration=0,
-                 d_sums10=0, target_on_device=False, nt=None, BaseNormals=None, Damping=0.0, WeightFn=None):
+                 d_sums10=0, target_on_device=False, nt=None, BaseNormals=None, Damping=0.0, WeightFn=None,
+                 SumsMode=SumsReference):
         """BaseNormals (unit normals per base point, id order; a device address when
         target_on_device) selects the point-to-plane / Gauss-Newton extension: the exchange
-        vector then has 30 doubles (d_sums10 must point to 30)."""
+        vector then has 30 doubles (d_sums10 must point to 30).  SumsMode: PCGX_SUMS_* (default: the
+        reference's sequential float32 sums; a session stepped through an exchange forms float64 sums)."""
         w = np.zeros(6, np.float32) if Weight is None else Weight
         th = np.zeros(6, np.float32) if Threshold is None else Threshold
-        self.params = _params(MaxDist, base.MinDistSq, MinPairs, w, th, MaxIteration, WeightFn)
+        self.params = _params(MaxDist, base.MinDistSq, MinPairs, w, th, MaxIteration, WeightFn, SumsMode)
         self.max_iteration = MaxIteration or 20
         self.base = base
         self.plane = BaseNormals is not None
@@ -257,9 +269,10 @@ class IcpSession:
         L.check(L.lib().pcgx_icp_session_set_pose(self._h, L.ptr(t), int(it), L.ptr(stream) if stream else None))
 
     def set_strict(self, on=True):
-        """Sequential float32 sums in target order, as the Go code adds them: bit-identical
-        Evaluated / pose at any size.  True / 1: evaluated in parallel by the whole GPU
-        (csrc/strict_sum.h); 2: one wave adding term after term (cross-check).  See include/pcgx.h."""
+        """Change the sums after creation (SumsMode sets them at creation; the default is 1).
+        True / 1: sequential float32 sums in target order, as the Go code adds them, evaluated in
+        parallel by the whole GPU (csrc/strict_sum.h): bit-identical Evaluated / pose at any size;
+        2: one wave adding term after term (cross-check); 0: float64 tree.  See include/pcgx.h."""
         L.check(L.lib().pcgx_icp_session_set_strict(self._h, int(on)))
 
     def strict_stats(self, stream=0):

@@ -104,9 +104,15 @@ int main(int argc, char **argv) {
         std::printf("icp iters %d value %.9g trans", r.second.NumIteration, r.second.Evaluated.value);
         for (float v : r.first) std::printf(" %.9g", v);
         std::printf("\n");
-        {  // strict sums with a built-in weight; and the one-rank forms of the several-GPU entry points
+        {  // the default (reference) sums with a built-in weight; the float64-tree mode; and the one-rank forms of
+           // the several-GPU entry points
+          pcgx::PointToPointICP f64 = reg;
+          f64.Sums = PCGX_SUMS_F64_TREE;
+          auto rf = f64.Fit(*tree, target);
+          std::printf("icp_f64 iters %d value %.9g trans", rf.second.NumIteration, rf.second.Evaluated.value);
+          for (float v : rf.first) std::printf(" %.9g", v);
+          std::printf("\n");
           pcgx::PointToPointICP st = reg;
-          st.Strict = true;
           st.EvaluateWeight = pcgx::WeightFn{PCGX_WEIGHT_HUBER, 0.0004f};
           auto rs = st.Fit(*tree, target);
           std::printf("icp_strict iters %d value %.9g trans", rs.second.NumIteration, rs.second.Evaluated.value);

@@ -113,9 +113,14 @@ def test_cpp_host_mirror_known_answers(tmp_path, golden):
     assert int(icp[2]) == st.NumIteration
     assert np.array_equal(np.array([float(v) for v in icp[6:22]], np.float32), tr)
     assert "icp_minpairs ErrNotEnoughPairs" in out and "empty ErrNoPoint" in out
-    # strict sums + a built-in weight through the C++ mirror == through the Python mirror, bit for bit
+    # the float64-tree mode through both mirrors
+    tr64, st64 = picp.PointToPointICPGradient(picp.PointToPointEvaluator(
+        picp.NearestPointCorresponder(2.0), 3, SumsMode=picp.SumsF64Tree)).Fit(kdtree.New(base), target)
+    f64 = [l for l in out if l.startswith("icp_f64 ")][0].split()
+    assert int(f64[2]) == st64.NumIteration
+    assert np.array_equal(np.array([float(v) for v in f64[6:22]], np.float32), tr64)
+    # default (reference) sums + a built-in weight through the C++ mirror == through a Python session, bit for bit
     s = picp.IcpSession(kdtree.New(base), target, 2.0, 3, None, None, 0, WeightFn=picp.WeightHuber(0.0004))
-    s.set_strict(1)
     for _ in range(20):
         s.step()
     tr_s, st_s, _ = s.result()

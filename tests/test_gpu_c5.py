@@ -87,7 +87,7 @@ def test_c5_partial_sums_reproducible_over_a_fit(c5):
                MaxIteration=20)
     runs = []
     for rep in range(2):
-        s = icp.IcpSession(tree, tile, **cfg)
+        s = icp.IcpSession(tree, tile, SumsMode=icp.SumsF64Tree, **cfg)
         sums = []
         for _ in range(20):
             s.partials()

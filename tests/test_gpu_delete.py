@@ -178,6 +178,10 @@ def test_delete_then_icp_pairs_on_a_lattice_equal_the_reference_walk(min_dist_sq
     assert np.array_equal(ti, ot) and np.array_equal(b, ob) and np.array_equal(d, od)
     assert not np.isin(b, gone).any()
     e = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=1.6), MinPairs=6)
+    ev = e.Evaluate(t, target)   # default: the reference's sums
+    o32 = O.icp_evaluate(o, target, 1.6, 6, sums_mode=0)
+    assert ev.NumPairs == o32["npairs"] and ev.Value == o32["value"] and np.array_equal(ev.Gradient, o32["gradient"])
+    e.SumsMode = icp.SumsF64Tree
     ev = e.Evaluate(t, target)
     oe = O.icp_evaluate(o, target, 1.6, 6, sums_mode=1)
     assert ev.NumPairs == oe["npairs"]
@@ -195,8 +199,7 @@ def test_delete_then_strict_fit_is_the_reference_fit_bit_for_bit():
     for i in gone:
         o.delete_point(int(i))
     sess = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
-                          c["max_iteration"])
-    sess.set_strict(True)
+                          c["max_iteration"])   # default sums: the reference's
     for _ in range(c["max_iteration"]):
         sess.step()
     trans, stat, conv = sess.result()
@@ -216,6 +219,10 @@ def test_delete_then_icp_uses_remaining_points():
     for i in gone:
         o.delete_point(int(i))
     e = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=6)
+    ev = e.Evaluate(t, c["target"])   # default: the reference's sums
+    o32 = O.icp_evaluate(o, c["target"], c["max_dist"], 6, sums_mode=0)
+    assert ev.NumPairs == o32["npairs"] and ev.Value == o32["value"] and np.array_equal(ev.Gradient, o32["gradient"])
+    e.SumsMode = icp.SumsF64Tree
     ev = e.Evaluate(t, c["target"])
     oe = O.icp_evaluate(o, c["target"], c["max_dist"], 6, sums_mode=1)
     assert ev.NumPairs == oe["npairs"]
@@ -235,7 +242,7 @@ def test_many_delete_query_cycles_with_an_open_session():
     for i in range(100):
         o.delete_point(i)
     early = icp.IcpSession(kdtree.New(pts), q, 1.0, 6)  # a handle without deletions: the implicit tree
-    sess = icp.IcpSession(t, q, 1.0, 6)  # on the patched tree without points 0..99
+    sess = icp.IcpSession(t, q, 1.0, 6, SumsMode=icp.SumsF64Tree)  # on the patched tree without points 0..99
     sess.partials()
     sums_before = sess.read_sums()
     assert np.allclose(sums_before, O.icp_evaluate(o, q, 1.0, 6, sums_mode=1)["raw10"], rtol=1e-12, atol=0)

@@ -163,7 +163,8 @@ def test_icp_pairs_grid_vs_walk_vs_oracle(monkeypatch):
     assert np.array_equal(b, ob) and np.array_equal(ti, ot) and np.array_equal(d, od)
 
     def fit():
-        s = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], 8)
+        s = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], 8,
+                           SumsMode=icp.SumsF64Tree)
         for _ in range(8):
             s.step()
         r = s.result()
