@@ -130,7 +130,7 @@ PCGX_API pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream
 /* Measurement aid: counters of the strict sums (set_strict 1) since the last call: out = {runs
  * applied, runs whose record did not cover the state, tiles recomputed exactly, leaves of those added
  * term by term, tile records that did not cover the state, -...}. */
-PCGX_API pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *stream, int64_t out[48]);
+PCGX_API pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *stream, int64_t out[64]);
 
 /* The strict-sum pipeline in plain host loops (no GPU): *out = the sequential float32 sum
  * 0 + t0 + t1 + ... computed the way the strict kernels compute it; stats as in csrc/strict_sum.h

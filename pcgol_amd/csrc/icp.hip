@@ -1076,14 +1076,14 @@ static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
 }
 
 // Measurement aid: counters of the strict chain since the last call (see include/pcgx.h).
-extern "C" pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *stream, int64_t out[48]) {
+extern "C" pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *stream, int64_t out[64]) {
   PCGX_API_LOCK();
   if (!s || !out) return fail(PCGX_E_INVALID, "pcgx_debug_icp_strict_stats: NULL argument");
-  for (int k = 0; k < 48; k++) out[k] = 0;
+  for (int k = 0; k < 64; k++) out[k] = 0;
   if (!s->strict_buf) return PCGX_OK;
-  unsigned long long h[48];
+  unsigned long long h[64];
   PCGX_TRY(strict_read_debug(s->strict_buf, h, pick_stream(stream)));
-  for (int k = 0; k < 48; k++) out[k] = (int64_t)h[k];
+  for (int k = 0; k < 64; k++) out[k] = (int64_t)h[k];
   return PCGX_OK;
 }
 

@@ -318,7 +318,7 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
 void strict_destroy(StrictBuffers *b);
 pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
                            double *sums10, const IcpKernelParams &kp, bool fuse_update, hipStream_t st);
-pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[48], hipStream_t st);
+pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[64], hipStream_t st);
 }  // namespace pcgx
 
 struct pcgx_kdtree {

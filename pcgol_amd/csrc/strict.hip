@@ -13,6 +13,8 @@
 //                        a record that does not cover the state -> that tile is recomputed exactly
 // Nothing here is approximate: a record is applied only when its interval proves the result.
 #include "pcgx_internal.h"
+#include <stddef.h>
+
 #include "strict_sum.h"
 
 namespace pcgx {
@@ -61,36 +63,215 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 struct LeafAux {  // per leaf of a tile with a level crossing: compositions of leaves 0..l and l..63
   Summary pre, suf;
 };
+static_assert(sizeof(LeafAux) == 96, "two summaries");
+
+// per leaf of a tile WITHOUT a window (a sum hovering around zero): the leaf's own window and the
+// composition of the leaves from the head of its run (neighbouring leaves of equal windows) up to it
+struct LeafRec {
+  int32_t key;  // -1: the leaf has no window (its 32 terms are added one by one)
+  int32_t pad[3];
+  Summary run;
+};
+static_assert(sizeof(LeafRec) == 64 && sizeof(LeafRec) <= sizeof(LeafAux), "a leaf record fits a LeafAux");
+
+struct JobDesc {  // a (row, tile) that crosses a level or has no window: strict_sum_kernel -> strict_job_kernel
+  int32_t row, kind, key, cons;
+  uint32_t in, out;
+  int64_t tile;
+  uint32_t g[kLanes];    // the leaves' guesses
+  int32_t lkey[kLanes];  // and the windows they are summarised under
+};
+
+// Slots are handed out by kAuxShards counters a cache line apart (shard = tile % kAuxShards, each with
+// naux / kAuxShards slots): one counter for all was ~100 returning atomics on one address per launch,
+// served one after the other -- the last job of a launch waited 30-40 us for its slot number.
+constexpr int kAuxShards = 64;
 
 struct StrictWork {
-  float *terms;                 // [9][ntiles][kLeaf / 4][64 lanes][4]: lane l of a tile holds its leaf's terms 4 by 4
   const float *xyz_caller;      // [nt][3] the targets in the caller's order
   double *tile_sum;             // [9][ntiles] float64 sums of the tiles' terms
-  double *bin_sum;              // [9][nbins] level-1 sums of kBinTiles tiles (atomics; zeroed by the chain kernel)
+  uint32_t *tile_pairs;         // [ntiles] matched targets of the tiles
   TileRec *recs;                // [9][ntiles]
-  LeafAux *aux;                 // [naux][64]
-  unsigned int *aux_count;      // slots handed out this iteration (zeroed by the chain kernel)
+  LeafAux *aux;                 // [naux][64]: what the chain kernel needs to recompute a tile that owns a slot
+  float4 *aux_terms;            // [naux][512]: that tile's terms (layout of tile_quad)
+  struct JobDesc *jobs;         // [naux]: what strict_job_kernel needs to know about the slot's tile
+  unsigned int *aux_count;      // [kAuxShards] x 32 words: slots handed out this iteration, per shard (zeroed by the chain kernel)
   unsigned int *done_rows;      // rows of the chain kernel that have finished (ticket of the fused update)
-  unsigned long long *pairs;    // matched targets of this iteration (atomic; zeroed by the chain kernel)
-  unsigned long long *dbg;      // [16] counters (measurement aid)
-  int64_t nt, nt_pad, ntiles, nbins;
+  unsigned long long *dbg;      // [64] counters (measurement aid)
+  unsigned long long *stamps;   // [ntiles][8] wall-clock stamps of the summary kernel's workgroups (measurement aid)
+  int64_t nt, ntiles;
   int32_t naux;
+  int32_t nrows;      // 9, or 8 with the default weight: the sum of the weights is then min(pairs, 2^24) exactly
   int32_t weight_fn;  // evaluator.go:130 (PCGX_WEIGHT_*)
   float weight_a;
   int32_t selfcheck;  // debugging: every step of the chain walk is re-derived term by term and compared (dbg[12..15])
 };
 
-// term i (caller's order) of a row lives at ((tile * 8 + j / 4) * 64 + l) * 4 + j % 4 with tile = i /
-// 2048, l = i % 2048 / 32, j = i % 32: leaves are interleaved 4 floats at a time so that the 64 lanes
-// of a wave read (and the terms kernel writes) them with fully coalesced 16-byte accesses
-__device__ __forceinline__ void load_leaf(const float *__restrict__ row, int64_t tile, int lane, float *t) {
-  const float4 *q = reinterpret_cast<const float4 *>(row) + tile * (kLeaf / 4) * kLanes + lane;
+// ---- the terms ------------------------------------------------------------------------------------
+// Nothing stores the nine float32 terms of a pair in HBM any more (round 2: 36 MB out of one kernel and
+// into the next per iteration): they are formed where they are needed, from the target in the caller's
+// order (12 B, coalesced) and its pair (16 B; the correspondence kernels leave every pair in the
+// caller's order as well, match_caller; sessions on a patched tree gather through pos_of).
+struct TermSrc {
+  const float4 *match;
+  const uint32_t *pos_of;  // nullptr: match[] is in the caller's order already
+  const float *xyz;        // caller's order
+  int64_t nt;
+  float m[16];
+  bool project;  // icp.go:27-30: the first Evaluate sees the raw target
+  int32_t weight_fn;
+  float weight_a;
+};
+
+__device__ __forceinline__ TermSrc make_term_src(const float4 *match, const uint32_t *pos_of, const IcpState *state,
+                                                 const StrictWork &W) {
+  TermSrc S;
+  S.match = match;
+  S.pos_of = pos_of;
+  S.xyz = W.xyz_caller;
+  S.nt = W.nt;
+#pragma unroll
+  for (int k = 0; k < 16; k++) S.m[k] = state->trans[k];
+  S.project = state->iter > 0;
+  S.weight_fn = W.weight_fn;
+  S.weight_a = W.weight_a;
+  return S;
+}
+
+// evaluator.go:122-145, every term in float32 as the reference forms it.  Unmatched targets and the
+// padding behind nt carry -0.0f: x + (-0.0f) == x for EVERY float x (both zeros included).
+__device__ __forceinline__ bool pair_terms(const TermSrc &S, float x0, float y0, float z0, const float4 &b, float *t /* [9] */) {
+#pragma unroll
+  for (int k = 0; k < kStrictRows; k++) t[k] = -0.0f;
+  if (!(b.w >= 0.0f)) return false;  // correspondence.go:27-29
+  if (S.project) {  // icp.go:62-64
+    float px, py, pz;
+    mat4_transform(S.m, x0, y0, z0, px, py, pz);
+    x0 = px; y0 = py; z0 = pz;
+  }
+  const float x1 = b.x, y1 = b.y, z1 = b.z;
+  const float w = eval_weight_fn(S.weight_fn, S.weight_a, b.w);  // evaluator.go:130
+  t[0] = w * b.w;
+  t[1] = w * (x0 - x1);
+  t[2] = w * (y0 - y1);
+  t[3] = w * (z0 - z1);
+  t[4] = w * (z0 * y1 - y0 * z1);
+  t[5] = w * (x0 * z1 - z0 * x1);
+  t[6] = w * (y0 * x1 - x0 * y1);
+  t[7] = w * norm_sq3(x0, y0, z0);
+  t[8] = w;
+  return true;
+}
+
+// the four consecutive targets i0 .. i0 + 3 (i0 a multiple of 4): pairs and coordinates
+__device__ __forceinline__ void load_quad(const TermSrc &S, int64_t i0, float4 *bp, float *tx, float *ty, float *tz) {
+  if (i0 + 3 < S.nt) {
+    if (S.pos_of) {
+      const uint4 p = *reinterpret_cast<const uint4 *>(S.pos_of + i0);
+      bp[0] = S.match[p.x]; bp[1] = S.match[p.y]; bp[2] = S.match[p.z]; bp[3] = S.match[p.w];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) bp[c] = S.match[i0 + c];
+    }
+    const float4 *x4 = reinterpret_cast<const float4 *>(S.xyz + 3 * i0);  // 48 B, 16-byte aligned
+    const float4 a = x4[0], b = x4[1], d = x4[2];
+    tx[0] = a.x; ty[0] = a.y; tz[0] = a.z;
+    tx[1] = a.w; ty[1] = b.x; tz[1] = b.y;
+    tx[2] = b.z; ty[2] = b.w; tz[2] = d.x;
+    tx[3] = d.y; ty[3] = d.z; tz[3] = d.w;
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int64_t i = i0 + c;
+    bp[c] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    tx[c] = ty[c] = tz[c] = 0.0f;
+    if (i < S.nt) {
+      bp[c] = S.pos_of ? S.match[S.pos_of[i]] : S.match[i];
+      tx[c] = S.xyz[3 * i];
+      ty[c] = S.xyz[3 * i + 1];
+      tz[c] = S.xyz[3 * i + 2];
+    }
+  }
+}
+
+// A tile's terms of one row, 2048 floats as 512 quads: quad v (terms 4v .. 4v + 3) of leaf l sits at
+// float4 index v * 64 + (l ^ v).  In LDS the 64 lanes of a wave read their leaves' quad v without bank
+// conflicts, and the 8 threads that write the quads of one leaf hit different banks (the xor); in HBM
+// (aux_terms) a wave reads and writes 64 consecutive quads per instruction.
+__device__ __forceinline__ int tile_quad(int l, int v) { return v * kLanes + (l ^ v); }
+
+struct LdsQuads {  // the leaf of `lane` in a tile staged in LDS, quad by quad (strict_sum.h chains)
+  const float4 *R;
+  int lane;
+  __device__ __forceinline__ float4 operator()(int v) const { return R[tile_quad(lane, v)]; }
+};
+
+__device__ __forceinline__ void load_leaf_quads(const float4 *R, int lane, float *t) {
 #pragma unroll
   for (int v = 0; v < kLeaf / 4; v++) {
-    const float4 a = q[v * kLanes];
+    const float4 a = R[tile_quad(lane, v)];
     t[4 * v] = a.x; t[4 * v + 1] = a.y; t[4 * v + 2] = a.z; t[4 * v + 3] = a.w;
   }
 }
+__device__ __forceinline__ void store_leaf_quads(float4 *R, int lane, const float *t) {
+#pragma unroll
+  for (int v = 0; v < kLeaf / 4; v++) R[tile_quad(lane, v)] = make_float4(t[4 * v], t[4 * v + 1], t[4 * v + 2], t[4 * v + 3]);
+}
+__device__ __forceinline__ void lds_fence_wave() {
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS accesses have landed
+}
+
+// the additions of leaves [l0, l1) of a tile staged in LDS, one after the other: every lane runs the
+// same chain (broadcast reads; the next leaf's eight quads are read while the 32 additions run)
+__device__ __forceinline__ uint32_t serial_leaves(uint32_t s, const float4 *R, int l0, int l1) {
+  float x = u2f(s);
+  if (l0 >= l1) return s;
+  float4 a[8], b[8];
+#pragma unroll
+  for (int v = 0; v < 8; v++) a[v] = R[tile_quad(l0, v)];
+  for (int l = l0; l < l1; l += 2) {
+    const int ln = l + 1 < l1 ? l + 1 : l0;
+#pragma unroll
+    for (int v = 0; v < 8; v++) b[v] = R[tile_quad(ln, v)];
+#pragma unroll
+    for (int v = 0; v < 8; v++) x = (((x + a[v].x) + a[v].y) + a[v].z) + a[v].w;
+    if (l + 1 >= l1) break;
+    const int ln2 = l + 2 < l1 ? l + 2 : l0;
+#pragma unroll
+    for (int v = 0; v < 8; v++) a[v] = R[tile_quad(ln2, v)];
+#pragma unroll
+    for (int v = 0; v < 8; v++) x = (((x + b[v].x) + b[v].y) + b[v].z) + b[v].w;
+  }
+  return f2u(x);
+}
+
+// Row `row` of `tile` formed again from the pairs and staged in lds (layout of tile_quad): the chain
+// kernel's way to a tile that owns no slot.  Rare, so small rather than fast: one quad per lane and
+// round, no array in registers (a version with the leaf in 32 registers behind a call put 256 bytes of
+// scratch into the chain kernel).
+__device__ __forceinline__ void recompute_tile_to_lds(const TermSrc &S, int row, int64_t tile, int lane, float4 *lds) {
+  const int64_t i0 = tile * kTile + (int64_t)lane * kLeaf;
+#pragma unroll 1
+  for (int v = 0; v < kLeaf / 4; v++) {
+    float4 bp[4];
+    float tx[4], ty[4], tz[4];
+    load_quad(S, i0 + 4 * v, bp, tx, ty, tz);
+    float r[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      float q[kStrictRows];
+      pair_terms(S, tx[c], ty[c], tz[c], bp[c], q);
+      r[c] = q[0];
+#pragma unroll
+      for (int k = 1; k < kStrictRows; k++) r[c] = row == k ? q[k] : r[c];
+    }
+    lds[tile_quad(lane, v)] = make_float4(r[0], r[1], r[2], r[3]);
+  }
+  lds_fence_wave();
+}
+
 __device__ __forceinline__ double leaf_sum_f64(const float *t) {
   double v = 0.0;
 #pragma unroll
@@ -98,97 +279,59 @@ __device__ __forceinline__ double leaf_sum_f64(const float *t) {
   return v;
 }
 
-// float64 prefix of `tile` from the level-1 bins and the tile sums inside its bin; every lane gets it
-__device__ __forceinline__ double tile_prefix(const double *__restrict__ tile_v, const double *__restrict__ bin_v,
-                                              int64_t ntiles, int64_t nbins, int row, int64_t tile, int lane) {
-  const int64_t bin = tile / kBinTiles;
+// float64 prefix of `tile`: the sums of all tiles before it, every lane gets it.  Eight independent
+// loads per lane and round (489 tiles at C4: one round).  No level-1 bins: round 2 filled them with
+// 4401 atomic adds on five cache lines, 12 of the 24 us of its terms kernel.
+// (Measured and rejected in round 3: no kernel for the tile sums at all -- every tile's workgroup
+// publishes its sums with agent-scope stores / exchanges, the last tile of every 32 their total, and
+// polls the ones before it.  Correct, and never faster than 80 us for the summary kernel: agent-scope
+// loads are served by the polling XCD's own L2, which keeps the "not yet" it saw first until the line
+// happens to be evicted, tens of microseconds later, whatever the poll interval; acquire fences before
+// every poll: slower still.)
+__device__ __forceinline__ double tile_prefix(const double *__restrict__ tile_v, int64_t ntiles, int row, int64_t tile,
+                                              int lane) {
+  const double *p = tile_v + (int64_t)row * ntiles;
   double v = 0.0;
-  for (int64_t b = lane; b < bin; b += 64) v += bin_v[row * nbins + b];
-  const int64_t t = bin * kBinTiles + lane;
-  if (t < tile) v += tile_v[row * ntiles + t];
+  for (int64_t base = 0; base < tile; base += 8 * 64) {
+    double x[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int64_t k = base + u * 64 + lane;
+      x[u] = k < tile ? p[k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) v += x[u];
+  }
   return wave_allsum_f64(v);
 }
 
-// ---- terms ---------------------------------------------------------------------------------------
-// One workgroup per tile of 2048 targets in the caller's order: the target itself is read in that
-// order (xyz_caller) and re-projected here exactly as the correspondence kernels do, only its pair
-// is a gather (pos_of: where the session keeps target i).  Unmatched targets and the padding behind
-// nt carry -0.0f: x + (-0.0f) == x for every x.
-constexpr int kTermsBlock = 256;
-// One workgroup per tile; a thread forms the terms of two QUADS (4 consecutive targets of one leaf):
-// its eight gathers are issued together and each row's four terms leave as one 16-byte store, lanes
-// side by side (the interleaved layout of terms[]).
-__global__ __launch_bounds__(kTermsBlock) void strict_terms_kernel(const float4 *__restrict__ match,
-                                                                   const uint32_t *__restrict__ pos_of,
-                                                                   const IcpState *__restrict__ state, StrictWork W) {
-  __shared__ double s_part[kTermsBlock / 64][kStrictRows];
-  __shared__ int s_pairs[kTermsBlock / 64];
+// ---- tile sums ------------------------------------------------------------------------------------
+// One workgroup per tile of 2048 targets in the caller's order: the float64 sums of the tile's terms,
+// per row (the guesses of strict_sum_kernel start from their prefix).
+constexpr int kTileSumBlock = 256;
+__global__ __launch_bounds__(kTileSumBlock) void strict_tilesum_kernel(const float4 *__restrict__ match,
+                                                                       const uint32_t *__restrict__ pos_of,
+                                                                       const IcpState *__restrict__ state, StrictWork W) {
+  __shared__ double s_part[kTileSumBlock / 64][kStrictRows];
   if (state->done) return;
-  float m[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) m[k] = state->trans[k];
-  const bool project = state->iter > 0;  // icp.go:27-30: the first Evaluate sees the raw target
+  const TermSrc S = make_term_src(match, pos_of, state, W);
   const int64_t tile = blockIdx.x;
   double acc[kStrictRows];
 #pragma unroll
   for (int k = 0; k < kStrictRows; k++) acc[k] = 0.0;
-  int npairs = 0;
-  constexpr int kQuads = kTile / 4 / kTermsBlock;  // 2
+  constexpr int kQuads = kTile / 4 / kTileSumBlock;  // 2
   float4 bp[kQuads][4];
   float tx[kQuads][4], ty[kQuads][4], tz[kQuads][4];
 #pragma unroll
-  for (int h = 0; h < kQuads; h++) {
-    const int q = h * kTermsBlock + threadIdx.x, l = q / (kLeaf / 4), v = q % (kLeaf / 4);  // consecutive threads, consecutive targets
-    const int64_t i0 = tile * kTile + l * kLeaf + 4 * v;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int64_t i = i0 + c;
-      bp[h][c] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-      tx[h][c] = ty[h][c] = tz[h][c] = 0.0f;
-      if (i < W.nt) {
-        bp[h][c] = pos_of ? match[pos_of[i]] : match[i];  // (nullptr: match[] is in the caller's order already)
-        tx[h][c] = W.xyz_caller[3 * i];
-        ty[h][c] = W.xyz_caller[3 * i + 1];
-        tz[h][c] = W.xyz_caller[3 * i + 2];
-      }
-    }
-  }
+  for (int h = 0; h < kQuads; h++)  // consecutive threads, consecutive quads: every load of the tile is issued before the first use
+    load_quad(S, tile * kTile + 4 * (int64_t)(h * kTileSumBlock + threadIdx.x), bp[h], tx[h], ty[h], tz[h]);
 #pragma unroll
   for (int h = 0; h < kQuads; h++) {
-    const int q = h * kTermsBlock + threadIdx.x, l = q / (kLeaf / 4), v = q % (kLeaf / 4);  // consecutive threads, consecutive targets
-    float t[kStrictRows][4];
+    float t[4][kStrictRows];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
+    for (int c = 0; c < 4; c++) pair_terms(S, tx[h][c], ty[h][c], tz[h][c], bp[h][c], t[c]);
 #pragma unroll
-      for (int k = 0; k < kStrictRows; k++) t[k][c] = -0.0f;
-      const float4 b = bp[h][c];
-      if (b.w >= 0.0f) {  // correspondence.go:27-29
-        npairs++;
-        float x0 = tx[h][c], y0 = ty[h][c], z0 = tz[h][c];
-        if (project) {
-          float px, py, pz;
-          mat4_transform(m, x0, y0, z0, px, py, pz);
-          x0 = px; y0 = py; z0 = pz;
-        }
-        const float x1 = b.x, y1 = b.y, z1 = b.z;
-        const float w = eval_weight_fn(W.weight_fn, W.weight_a, b.w);  // evaluator.go:130
-        t[0][c] = w * b.w;
-        t[1][c] = w * (x0 - x1);
-        t[2][c] = w * (y0 - y1);
-        t[3][c] = w * (z0 - z1);
-        t[4][c] = w * (z0 * y1 - y0 * z1);
-        t[5][c] = w * (x0 * z1 - z0 * x1);
-        t[6][c] = w * (y0 * x1 - x0 * y1);
-        t[7][c] = w * norm_sq3(x0, y0, z0);
-        t[8][c] = w;
-      }
-    }
-    float4 *out = reinterpret_cast<float4 *>(W.terms) + (tile * (kLeaf / 4) + v) * kLanes + l;
-#pragma unroll
-    for (int k = 0; k < kStrictRows; k++) {
-      out[(int64_t)k * (W.nt_pad / 4)] = make_float4(t[k][0], t[k][1], t[k][2], t[k][3]);
-      acc[k] += (((double)t[k][0] + (double)t[k][1]) + (double)t[k][2]) + (double)t[k][3];
-    }
+    for (int k = 0; k < kStrictRows; k++) acc[k] += (((double)t[0][k] + (double)t[1][k]) + (double)t[2][k]) + (double)t[3][k];
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -196,22 +339,11 @@ __global__ __launch_bounds__(kTermsBlock) void strict_terms_kernel(const float4 
     const double v = wave_allsum_f64(acc[k]);
     if (lane == 0) s_part[wave][k] = v;
   }
-  {
-    int p = npairs;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
-    if (lane == 0) s_pairs[wave] = p;
-  }
   __syncthreads();
-  if (threadIdx.x < kStrictRows) {
+  if (threadIdx.x < W.nrows) {
     double v = 0.0;
-    for (int w = 0; w < kTermsBlock / 64; w++) v += s_part[w][threadIdx.x];
+    for (int w = 0; w < kTileSumBlock / 64; w++) v += s_part[w][threadIdx.x];
     W.tile_sum[threadIdx.x * W.ntiles + tile] = v;
-    unsafeAtomicAdd(&W.bin_sum[threadIdx.x * W.nbins + tile / kBinTiles], v);  // global_atomic_add_f64, no CAS loop
-  } else if (threadIdx.x == 64) {
-    int p = 0;
-    for (int w = 0; w < kTermsBlock / 64; w++) p += s_pairs[w];
-    if (p) atomicAdd(W.pairs, (unsigned long long)p);
   }
 }
 
@@ -229,215 +361,260 @@ __global__ __launch_bounds__(256) void strict_xyz_caller_kernel(const float *__r
 }
 
 // ---- summaries ---------------------------------------------------------------------------------------
-// leaf guesses of a tile whose first state is (about) base: float64 prefix of the leaf sums, then one
-// refinement with the prefix of the rounding errors the chains make from those guesses
-__device__ __forceinline__ void tile_guesses(const float *t, double base, int lane, uint32_t &g, ChainRange &cr) {
-  const double lsum = leaf_sum_f64(t);
-  const double pre = wave_excl_scan_f64(lsum, lane);
+// leaf guesses of a tile whose first state is (about) base: float64 prefix of the leaf sums (pre), then
+// one refinement with the prefix of the rounding errors the chains make from those guesses (the first
+// pass needs the chains' ends only; the chain that is kept, with its extremes, runs once, from the
+// final guesses)
+__device__ __forceinline__ void tile_guesses(const LdsQuads &q, double base, double lsum, double pre, int lane, uint32_t &g,
+                                             ChainRange &cr) {
   g = f2u((float)(base + pre));
-  cr = guess_chain(t, g);
-  const double err = ((double)u2f(cr.end) - (double)u2f(g)) - lsum;
+  const float e = u2f(plain_chain_q(q, g));
+  const double err = ((double)e - (double)u2f(g)) - lsum;
   const double epre = wave_excl_scan_f64(err, lane);
   const uint32_t g2 = f2u((float)(base + pre + epre));
   // (guesses a couple of ulps off are as good: the intervals are thousands wide except next to a level)
   const int32_t moved = (int32_t)g2 - (int32_t)g;
-  if (__ballot(moved > 2 || moved < -2) != 0ull) {  // uniform
-    g = g2;
-    cr = guess_chain(t, g);
-  }
+  if (__ballot(moved > 2 || moved < -2) != 0ull) g = g2;  // uniform
+  cr = guess_chain_q(q, g);
 }
 
-// the 32 additions of leaf l, one after the other, on the state every lane holds
-__device__ __forceinline__ uint32_t serial_leaf(uint32_t s, const float *t, int l) {
-  float x = u2f(s);
-#pragma unroll
-  for (int j = 0; j < kLeaf; j++) x = x + u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(t[j]), l));
-  return f2u(x);
-}
-
-// all 2048 additions of a tile, one after the other: the terms go to LDS in their order and every
-// lane runs the same chain over them (broadcast reads; the next 32 terms are read while the 32
-// additions on the current ones run)
-// a tile's terms in their order in LDS (every lane its leaf)
-__device__ __forceinline__ void stage_tile(const float *t, int lane, float *lds /* [kTile] of this wave */) {
-  float4 *w4 = reinterpret_cast<float4 *>(lds) + lane * (kLeaf / 4);
-#pragma unroll
-  for (int v = 0; v < kLeaf / 4; v++) w4[v] = make_float4(t[4 * v], t[4 * v + 1], t[4 * v + 2], t[4 * v + 3]);
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own LDS writes have landed
-}
-
-// the additions of staged terms [first, first + count) (multiples of 64), one after the other: every
-// lane runs the same chain (broadcast reads; the next 32 terms are read while the 32 additions on
-// the current ones run)
-__device__ __forceinline__ uint32_t serial_span(uint32_t s, const float *lds, int first, int count) {
-  const float4 *r4 = reinterpret_cast<const float4 *>(lds) + first / 4;
-  const int n4 = count / 4;
-  float x = u2f(s);
-  float4 a[8], b[8];
-#pragma unroll
-  for (int u = 0; u < 8; u++) a[u] = r4[u];
-  for (int k = 0; k < n4; k += 16) {
-#pragma unroll
-    for (int u = 0; u < 8; u++) b[u] = r4[k + 8 + u];
-#pragma unroll
-    for (int u = 0; u < 8; u++) x = (((x + a[u].x) + a[u].y) + a[u].z) + a[u].w;
-    const int kn = k + 16 < n4 ? k + 16 : 0;
-#pragma unroll
-    for (int u = 0; u < 8; u++) a[u] = r4[kn + u];
-#pragma unroll
-    for (int u = 0; u < 8; u++) x = (((x + b[u].x) + b[u].y) + b[u].z) + b[u].w;
-  }
-  return f2u(x);
-}
-
-// all 2048 additions of a tile
-__device__ __forceinline__ uint32_t serial_tile(uint32_t s, const float *t, int lane, float *lds /* [kTile] of this wave */) {
-  stage_tile(t, lane, lds);
-  const uint32_t r = serial_span(s, lds, 0, kTile);
-  __builtin_amdgcn_wave_barrier();
-  return r;
-}
-
-// tiles at the start of every sum that are added up term by term in the summary kernel (by the wave
-// of tile 0, one after the other, beside the other waves' work).  A sum starts at 0.0f and runs
-// through a new binade every few terms, so no window holds its first tile.  More than one such tile
-// was measured (4: the summary kernel's slowest wave then outlasts the rest of it, 151.9 vs 147.7 us
-// per iteration at C4; the tiles where a sum hovers around zero are not the first ones)
+// tiles at the start of every sum that are added up term by term in the summary kernel.  A sum starts
+// at 0.0f and runs through a new binade every few terms, so no window holds its first tile.  More than
+// one such tile was measured (4: the summary kernel's slowest wave then outlasts the rest of it; the
+// tiles where a sum hovers around zero are not the first ones)
 constexpr int kExactTiles = 1;
 
-__global__ __launch_bounds__(256) void strict_sum_kernel(const IcpState *__restrict__ state, StrictWork W) {
+// One workgroup per tile, one wave per row.  The workgroup forms the tile's terms ONCE, into LDS (72 KB:
+// the CDNA4-sized LDS is what lets nine rows of 2048 terms sit next to each other, two workgroups per
+// CU), then every wave summarises its row: leaf guesses, guess chains, window, class summaries, ordered
+// composition -> one 64-byte record.  A row whose tile crosses a level, or has no window at all (a sum
+// hovering around zero), needs four class chains per leaf and two scans over the leaves -- five times
+// the work of a plain row, and what the launch used to wait for: it becomes a JOB that the whole
+// workgroup shares (four waves one class each, then two waves one scan each).
+constexpr int kSumBlock = 512;
+constexpr int kSumWaves = kSumBlock / 64;
+enum { JOB_CROSSING = 1, JOB_NOWINDOW = 2 };
+
+__global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void strict_sum_kernel(
+    const float4 *__restrict__ match, const uint32_t *__restrict__ pos_of, const IcpState *__restrict__ state, StrictWork W) {
+  __shared__ float4 s_terms[kStrictRows][kTile / 4];
+  __shared__ int s_np[kSumWaves];
   if (state->done) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (w >= kStrictRows * W.ntiles) return;  // whole wave
-  // the nine waves of the first tiles take longest (they carry out kExactTiles x 2048 additions): they go first
-  int row;
-  int64_t tile;
-  if (w < kStrictRows) {
-    row = (int)w;
-    tile = 0;
-  } else {
-    row = (int)((w - kStrictRows) / (W.ntiles - 1));
-    tile = 1 + (w - kStrictRows) % (W.ntiles - 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t tile = blockIdx.x;
+  const int NR = W.nrows;
+  const long long t_0 = wall_clock64();
+  // the float64 prefix of this wave's row (strict_tilesum_kernel's sums): its loads fly while phase 1 runs
+  double P0 = wave < NR ? tile_prefix(W.tile_sum, W.ntiles, wave, tile, lane) : 0.0;
+  // ---- phase 1: the tile's terms, every thread one quad
+  {
+    const TermSrc S = make_term_src(match, pos_of, state, W);
+    const int l = threadIdx.x >> 3, v = threadIdx.x & 7;
+    float4 bp[4];
+    float tx[4], ty[4], tz[4];
+    load_quad(S, tile * kTile + (int64_t)l * kLeaf + 4 * v, bp, tx, ty, tz);
+    float t[4][kStrictRows];
+    int np = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) np += pair_terms(S, tx[c], ty[c], tz[c], bp[c], t[c]) ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < kStrictRows; k++) s_terms[k][tile_quad(l, v)] = make_float4(t[0][k], t[1][k], t[2][k], t[3][k]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) np += __shfl_xor(np, o);
+    if (lane == 0) s_np[wave] = np;
   }
-  __shared__ float s_tile[4][kTile];
-  float t[kLeaf];
-  load_leaf(W.terms + (int64_t)row * W.nt_pad, tile, lane, t);
-  TileRec T;
-  T.s = summary_identity();
-  if (tile < kExactTiles) {
-    if (tile != 0) return;  // done by the wave of tile 0
-    // from the one state known in advance (0.0f, evaluator.go:122) the additions are simply carried
-    // out, here, off the chain kernel's critical path -> point records
-    uint32_t state = f2u(0.0f);
-    for (int64_t k = 0; k < kExactTiles && k < W.ntiles; k++) {
-      if (k > 0) load_leaf(W.terms + (int64_t)row * W.nt_pad, k, lane, t);
-      const uint32_t next = serial_tile(state, t, lane, s_tile[threadIdx.x >> 6]);
-      T.key = -1;
-      T.in = state;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int np = 0;
+    for (int w = 0; w < kSumWaves; w++) np += s_np[w];
+    W.tile_pairs[tile] = (uint32_t)np;
+  }
+  const long long t_1 = wall_clock64();
+  // ---- phase 2: every wave its row (one pass unless a weight function adds the ninth row)
+  for (int row = wave; row < NR; row += kSumWaves) {
+    if (row >= kSumWaves) P0 = tile_prefix(W.tile_sum, W.ntiles, row, tile, lane);
+    const LdsQuads q{s_terms[row], lane};
+    TileRec T;
+    T.s = summary_identity();
+    T.key = -1;
+    T.in = T.out = 0u;
+    T.cons = 0;
+    if (tile < kExactTiles) {
+      // from the one state known in advance (0.0f, evaluator.go:122) the additions are simply carried
+      // out, here, off the chain kernel's critical path -> a point record
+      const uint32_t next = serial_leaves(f2u(0.0f), s_terms[row], 0, kLanes);
+      T.in = f2u(0.0f);
       T.out = next;
       T.cons = 1;
-      if (lane == 0) W.recs[row * W.ntiles + k] = T;
-      state = next;
+      if (lane == 0) W.recs[row * W.ntiles + tile] = T;
+      continue;
     }
-    return;
+    double lsum = 0.0;
+#pragma unroll
+    for (int v = 0; v < kLeaf / 4; v++) {
+      const float4 a = q(v);
+      lsum += (double)a.x; lsum += (double)a.y; lsum += (double)a.z; lsum += (double)a.w;
+    }
+    const double pre = wave_excl_scan_f64(lsum, lane);
+    uint32_t g;
+    ChainRange cr;
+    tile_guesses(q, P0, lsum, pre, lane, g, cr);
+    // window of the tile
+    const uint32_t mn = wave_all_umin(cr.mn), mx = wave_all_umax(cr.mx);
+    const bool one_sign = __ballot(cr.sg_or != cr.sg_and) == 0ull &&
+                          (__ballot(cr.sg_or != 0u) == 0ull || __ballot(cr.sg_or == 0u) == 0ull);
+    const uint32_t g_first = (uint32_t)rfl((int)g);
+    const int32_t key = one_sign ? choose_window(mn, mx, g_first >> 31, g_first & 0x7fffffffu) : -1;
+    // point record: the guess chains join up exactly
+    const uint32_t g_next = (uint32_t)__shfl_down((int)g, 1);
+    const bool cons = __ballot(lane < 63 && g_next != cr.end) == 0ull;
+    T.key = key;
+    T.in = g_first;
+    T.out = (uint32_t)__shfl((int)cr.end, 63);
+    T.cons = cons ? 1 : 0;
+    if (key >= 0 && (mn >> 23) == (mx >> 23)) {  // uniform: a plain tile, all of it in one binade
+      const uint32_t E = mn >> 23;
+      Par S = leaf_parity_summary_q(q, g, cr, E, g_first >> 31);
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {  // ordered reduction over the 64 leaves
+        Par Y;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+          Y.c[p] = __shfl(S.c[p], lane + o);
+          Y.lo[p] = __shfl(S.lo[p], lane + o);
+          Y.hi[p] = __shfl(S.hi[p], lane + o);
+        }
+        if ((lane & (2 * o - 1)) == 0) S = par_compose(S, Y);
+      }
+      T.s = par_expand(S, E, key);
+      if (lane == 0) W.recs[row * W.ntiles + tile] = T;
+      continue;
+    }
+    // The tile crosses a level -- this is where a record is most likely not to cover the true state (a
+    // landing next to the level) -- or no window holds it (its sum changes sign, or runs through three
+    // binades: a sum hovering around zero).  Such a tile needs four class chains per leaf and scans over
+    // the leaves, five times the work of a plain one and what the launch used to wait for: it becomes a
+    // JOB of strict_job_kernel (a workgroup of its own), with its guesses, windows and terms.
+    unsigned slot = 0xffffffffu;
+    const unsigned shard = (unsigned)(tile % kAuxShards), per_shard = (unsigned)W.naux / kAuxShards;
+    if (lane == 0) {
+      const unsigned k = atomicAdd(&W.aux_count[shard * 32], 1u);
+      slot = k < per_shard ? shard * per_shard + k : 0xffffffffu;
+    }
+    slot = (unsigned)rfl((int)slot);
+    if (slot == 0xffffffffu) {  // no slot left (never seen): the chain kernel recomputes the tile from the pairs
+      T.key = -1;
+      if (lane == 0) W.recs[row * W.ntiles + tile] = T;
+      continue;
+    }
+    JobDesc *J = W.jobs + slot;
+    J->g[lane] = g;
+    J->lkey[lane] = key >= 0 ? key : leaf_key(cr, g);
+    if (lane == 0) {
+      J->row = row;
+      J->kind = key >= 0 ? JOB_CROSSING : JOB_NOWINDOW;
+      J->key = key;
+      J->cons = T.cons;
+      J->in = T.in;
+      J->out = T.out;
+      J->tile = tile;
+    }
+    float4 *dst = W.aux_terms + (size_t)slot * (kTile / 4);
+#pragma unroll
+    for (int v = 0; v < kLeaf / 4; v++) dst[v * kLanes + lane] = s_terms[row][v * kLanes + lane];
   }
-  const double P0 = tile_prefix(W.tile_sum, W.bin_sum, W.ntiles, W.nbins, row, tile, lane);
-  uint32_t g;
-  ChainRange cr;
-  tile_guesses(t, P0, lane, g, cr);
-  // window of the tile
-  const uint32_t mn = wave_all_umin(cr.mn), mx = wave_all_umax(cr.mx);
-  const bool one_sign = __ballot(cr.sg_or != cr.sg_and) == 0ull &&
-                        (__ballot(cr.sg_or != 0u) == 0ull || __ballot(cr.sg_or == 0u) == 0ull);
-  const uint32_t g_first = (uint32_t)rfl((int)g);
-  const int32_t key = one_sign ? choose_window(mn, mx, g_first >> 31, g_first & 0x7fffffffu) : -1;
-  // point record: the guess chains join up exactly
-  const uint32_t g_next = (uint32_t)__shfl_down((int)g, 1);
-  const bool cons = __ballot(lane < 63 && g_next != cr.end) == 0ull;
-  T.key = key;
-  T.in = g_first;
-  T.out = (uint32_t)__shfl((int)cr.end, 63);
-  T.cons = cons ? 1 : 0;
-  if (key >= 0) {  // uniform
-    const bool one_binade = (cr.mn >> 23) == (cr.mx >> 23);
-    Summary S;
-    if (__ballot(!one_binade) != 0ull) {  // uniform: some leaf crosses the level
-      if (one_binade) S = leaf_summary_binade(t, g, key);
-      else S = leaf_summary_general(t, g, key);
-      // this is where a record is most likely not to cover the true state (a landing next to the
-      // level): keep the compositions of leaves 0..l and l..63, so that the chain kernel finds the
-      // leaf in one parallel step and carries on behind it
-      Summary P = S, Q = S;
+  if (threadIdx.x == 0 && (W.selfcheck & 2)) {  // measurement aid (PCGX_STRICT_TRACE), plain stores only
+    W.stamps[tile * 16 + 0] = (unsigned long long)t_0;
+    W.stamps[tile * 16 + 1] = (unsigned long long)t_1;
+    W.stamps[tile * 16 + 5] = (unsigned long long)wall_clock64();
+  }
+}
+
+// One workgroup per slot that strict_sum_kernel handed out (the others leave at once): four waves, one
+// class of every leaf's summary each, through LDS; then wave 0 composes the leaves forwards and writes
+// the tile's record, wave 1 backwards (level crossing: the chain kernel finds the leaf that does not
+// cover the state in one parallel step and carries on behind it), or wave 0 alone composes the runs of
+// leaves under equal windows (no window: the chain kernel applies a run's last record).
+constexpr int kJobBlock = 256;
+__global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *__restrict__ state, StrictWork W) {
+  __shared__ float4 s_t[kTile / 4];
+  __shared__ int32_t s_S[12][kLanes];  // class pieces c[4] | lo[4] | hi[4] per leaf
+  if (state->done) return;
+  const unsigned per_shard = (unsigned)W.naux / kAuxShards;
+  const unsigned slot = blockIdx.x, shard = slot / per_shard, k = slot % per_shard;
+  if (k >= W.aux_count[shard * 32]) return;  // uniform
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const JobDesc *J = W.jobs + slot;
+  const float4 *src4 = W.aux_terms + (size_t)slot * (kTile / 4);
+  for (int i = threadIdx.x; i < kTile / 4; i += kJobBlock) s_t[i] = src4[i];
+  const uint32_t g = J->g[lane];
+  const int32_t lk = J->lkey[lane];
+  const int row = J->row, kind = J->kind;
+  const int64_t tile = J->tile;
+  __syncthreads();
+  {
+    int32_t c, lo, hi;
+    leaf_class_piece_q(LdsQuads{s_t, lane}, g, lk, part, c, lo, hi);
+    s_S[part][lane] = c;
+    s_S[4 + part][lane] = lo;
+    s_S[8 + part][lane] = hi;
+  }
+  __syncthreads();
+  if (part >= 2) return;
+  Summary S;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    S.c[r] = s_S[r][lane];
+    S.lo[r] = s_S[4 + r][lane];
+    S.hi[r] = s_S[8 + r][lane];
+  }
+  TileRec R;
+  R.s = summary_identity();
+  R.key = J->key;
+  R.in = J->in;
+  R.out = J->out;
+  R.cons = J->cons | (int32_t)((slot + 1u) << 8);
+  if (kind == JOB_CROSSING) {
+    if (part == 0) {
+      Summary P = S;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const Summary X = shfl_summary(P, lane - o);
         if (lane >= o) P = compose(X, P);
+      }
+      W.aux[(size_t)slot * kLanes + lane].pre = P;
+      R.s = shfl_summary(P, 63);
+      if (lane == 0) W.recs[row * W.ntiles + tile] = R;
+    } else {
+      Summary Q = S;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
         const Summary Y = shfl_summary(Q, lane + o);
         if (lane + o < 64) Q = compose(Q, Y);
       }
-      T.s = shfl_summary(P, 63);
-      unsigned slot = 0xffffffffu;
-      if (lane == 0) slot = atomicAdd(W.aux_count, 1u);
-      slot = (unsigned)rfl((int)slot);
-      if (slot < (unsigned)W.naux) {
-        LeafAux *a = W.aux + (size_t)slot * kLanes + lane;
-        a->pre = P;
-        a->suf = Q;
-        T.cons |= (int32_t)(slot + 1u) << 8;
-      }
-    } else {
-      S = leaf_summary_binade(t, g, key);
+      W.aux[(size_t)slot * kLanes + lane].suf = Q;
+    }
+  } else if (part == 0) {
+    const int32_t k_prev = __shfl_up(lk, 1);
+    Summary P = S;
+    int fp = (lane == 0 || lk < 0 || lk != k_prev) ? 1 : 0;
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {  // ordered reduction over the 64 leaves
-        const Summary Y = shfl_summary(S, lane + o);
-        if ((lane & (2 * o - 1)) == 0) S = compose(S, Y);
+    for (int o = 1; o < 64; o <<= 1) {
+      const Summary X = shfl_summary(P, lane - o);
+      const int xf = __shfl_up(fp, o);
+      if (lane >= o && !fp) {
+        P = compose(X, P);
+        fp = xf;
       }
-      T.s = S;
     }
-  } else {
-    // no window holds the tile (its sum changes sign, or runs through three binades: sums that hover
-    // around zero): four records of 16 leaves each, a window of its own for each that has one --
-    // the chain kernel then carries out 512 additions per quarter without one instead of 2048
-    const unsigned long long mixed = __ballot(cr.sg_or != cr.sg_and), neg = __ballot(cr.sg_or != 0u);
-    const int q = lane >> 4;
-    const uint32_t qmixed = (uint32_t)(mixed >> (16 * q)) & 0xffffu, qneg = (uint32_t)(neg >> (16 * q)) & 0xffffu;
-    uint32_t mnq = cr.mn, mxq = cr.mx;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      mnq = umin(mnq, (uint32_t)__shfl_xor((int)mnq, o));
-      mxq = umax(mxq, (uint32_t)__shfl_xor((int)mxq, o));
-    }
-    const uint32_t gq = (uint32_t)__shfl((int)g, q * 16);
-    int32_t kq = -1;
-    if (qmixed == 0u && (qneg == 0u || qneg == 0xffffu)) kq = choose_window(mnq, mxq, qneg ? 1u : 0u, gq & 0x7fffffffu);
-    Summary S = summary_identity();
-    if (kq >= 0) {
-      if ((cr.mn >> 23) == (cr.mx >> 23)) S = leaf_summary_binade(t, g, kq);
-      else S = leaf_summary_general(t, g, kq);
-    }
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {  // ordered composition over the 16 leaves of a quarter
-      const Summary Y = shfl_summary(S, lane + o);
-      if ((lane & (2 * o - 1)) == 0) S = compose(S, Y);
-    }
-    unsigned slot = 0xffffffffu;
-    if (lane == 0) slot = atomicAdd(W.aux_count, 1u);
-    slot = (unsigned)rfl((int)slot);
-    if (slot < (unsigned)W.naux) {
-      if ((lane & 15) == 0) {
-        TileRec Q;
-        Q.key = kq;
-        Q.in = Q.out = 0u;
-        Q.cons = 0;
-        Q.s = S;
-        reinterpret_cast<TileRec *>(W.aux + (size_t)slot * kLanes)[q] = Q;
-      }
-      T.cons |= (int32_t)(slot + 1u) << 8;
-    }
+    LeafRec L;
+    L.key = lk;
+    L.pad[0] = L.pad[1] = L.pad[2] = 0;
+    L.run = P;
+    *reinterpret_cast<LeafRec *>(&W.aux[(size_t)slot * kLanes + lane]) = L;
+    R.key = -1;
+    if (lane == 0) W.recs[row * W.ntiles + tile] = R;
   }
-  if (lane == 0) W.recs[row * W.ntiles + tile] = T;
 }
 
 // ---- chain -----------------------------------------------------------------------------------------
@@ -449,46 +626,74 @@ __device__ __forceinline__ bool apply_point(uint32_t &s, const TileRec &R) {
   return false;
 }
 
-// One tile, exactly, from the known state s (every lane holds it; returns it in every lane).
-// With aux (a tile with a level crossing whose record did not cover s): the first leaf whose prefix
-// composition fails is found by all lanes at once, that leaf is added term by term, and the suffix
-// composition behind it finishes the tile.  Without: the 2048 additions, one after the other.
-__device__ __forceinline__ uint32_t resolve_tile(uint32_t s, const float *__restrict__ row_terms, int64_t tile, int32_t key,
-                                             const LeafAux *__restrict__ aux, int lane, unsigned long long *dbg,
-                                             float *lds) {
-  const long long t_begin = wall_clock64();
-  float t[kLeaf];
-  load_leaf(row_terms, tile, lane, t);
-  int serial = 0;
-  int l = 0;
-  if (aux && key < 0) {
-    // a tile without a window: its four quarter records (strict_sum_kernel), 64 words, one per lane
-    const int32_t w = reinterpret_cast<const int32_t *>(aux)[lane];
-    stage_tile(t, lane, lds);
+// One tile, exactly, from the known state s (every lane holds it; returns it in every lane).  The
+// tile's terms are staged in `lds` (layout of tile_quad).
+//  kind JOB_CROSSING, aux = the leaf's LeafAux: the first leaf whose prefix composition does not cover
+//    s is found by all lanes at once, that leaf is added term by term, and the suffix composition
+//    behind it finishes the tile;
+//  kind JOB_NOWINDOW, aux reread as the leaf's LeafRec: the runs of leaves under equal windows are
+//    applied one after the other; a run that does not cover s, and a leaf without a window, are added
+//    term by term;
+//  kind 0 (a tile that owns no slot): all 2048 terms one after the other.
+// the 32 additions of leaf l, one after the other, on the state every lane holds; the leaf's terms are in
+// lane l's registers
+__device__ __forceinline__ uint32_t serial_leaf_regs(uint32_t s, const float *t, int l) {
+  float x = u2f(s);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int32_t kq = __builtin_amdgcn_readlane(w, 16 * q);
-      Summary S;
+  for (int j = 0; j < kLeaf; j++) x = x + u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(t[j]), l));
+  return f2u(x);
+}
+
+// (helpers: the leaf of every lane in its registers, t; the walker's tile without a slot: staged in lds, t unused)
+template <bool kRegs>
+__device__ __forceinline__ uint32_t resolve_staged(uint32_t s, int kind, int32_t key, const LeafAux &A, int lane,
+                                               const float4 *lds, const float *t, int &serial_out, int &tried_out,
+                                               int &applied_out) {
+  auto add_leaves = [&](uint32_t x, int l0, int l1) {
+    if (!kRegs) return serial_leaves(x, lds, l0, l1);
+    for (int l = l0; l < l1; l++) x = serial_leaf_regs(x, t, l);  // uniform
+    return x;
+  };
+  int serial = 0, n_try = 0, n_ok = 0;
+  if (kind == JOB_NOWINDOW) {
+    const int32_t lkey = A.pre.c[0];  // LeafRec{key, pad[3], run} laid over LeafAux{pre, suf}
+    Summary run;
+    run.c[0] = A.pre.lo[0]; run.c[1] = A.pre.lo[1]; run.c[2] = A.pre.lo[2]; run.c[3] = A.pre.lo[3];
+    run.lo[0] = A.pre.hi[0]; run.lo[1] = A.pre.hi[1]; run.lo[2] = A.pre.hi[2]; run.lo[3] = A.pre.hi[3];
+    run.hi[0] = A.suf.c[0]; run.hi[1] = A.suf.c[1]; run.hi[2] = A.suf.c[2]; run.hi[3] = A.suf.c[3];
+    const int32_t k_next = __shfl_down(lkey, 1);
+    const unsigned long long tails = __ballot(lane == 63 || lkey < 0 || lkey != k_next);
+    int l = 0;
+    while (l < kLanes) {  // uniform
+      n_try++;
+      const int e = l + __builtin_ctzll(tails >> l);
+      const int32_t rk = __builtin_amdgcn_readlane(lkey, e);
+      if (rk >= 0) {
+        Summary R;
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        S.c[k] = __builtin_amdgcn_readlane(w, 16 * q + 4 + k);
-        S.lo[k] = __builtin_amdgcn_readlane(w, 16 * q + 8 + k);
-        S.hi[k] = __builtin_amdgcn_readlane(w, 16 * q + 12 + k);
+        for (int r = 0; r < 4; r++) {
+          R.c[r] = __builtin_amdgcn_readlane(run.c[r], e);
+          R.lo[r] = __builtin_amdgcn_readlane(run.lo[r], e);
+          R.hi[r] = __builtin_amdgcn_readlane(run.hi[r], e);
+        }
+        if (apply(s, rk, R)) {  // (the record of lane e composes its run from the run's head, where the walk stands)
+          n_ok++;
+          l = e + 1;
+          continue;
+        }
       }
-      if (kq >= 0 && apply(s, kq, S)) continue;
-      s = serial_span(s, lds, q * (kTile / 4), kTile / 4);
-      serial += kLanes / 4;
+      s = add_leaves(s, l, e + 1);
+      serial += e + 1 - l;
+      l = e + 1;
     }
-    __builtin_amdgcn_wave_barrier();
-  } else if (aux) {
-    const LeafAux A = aux[lane];
+  } else if (kind == JOB_CROSSING) {
     uint32_t mine = s;
     const bool ok = apply(mine, key, A.pre);
     const unsigned long long bad = __ballot(!ok);
-    l = bad ? __builtin_ctzll(bad) : kLanes;  // leaves 0 .. l-1 are covered
+    int l = bad ? __builtin_ctzll(bad) : kLanes;  // leaves 0 .. l-1 are covered
     if (l > 0) s = (uint32_t)__builtin_amdgcn_readlane((int)mine, l - 1);
     while (l < kLanes) {
-      s = serial_leaf(s, t, l);
+      s = add_leaves(s, l, l + 1);
       serial++;
       l++;
       if (l == kLanes) break;
@@ -501,42 +706,64 @@ __device__ __forceinline__ uint32_t resolve_tile(uint32_t s, const float *__rest
       }
     }
   } else {
-    s = serial_tile(s, t, lane, lds);
+    s = add_leaves(s, 0, kLanes);
     serial = kLanes;
   }
-  if (lane == 0) {
-    atomicAdd(&dbg[2], 1ull);
-    atomicAdd(&dbg[3], (unsigned long long)serial);
-    if (!aux) atomicAdd(&dbg[5], 1ull);
-    atomicAdd(&dbg[aux ? 10 : 11], (unsigned long long)(wall_clock64() - t_begin));
+  serial_out = serial;
+  tried_out = n_try;
+  applied_out = n_ok;
+  return (uint32_t)rfl((int)s);
+}
+static_assert(sizeof(LeafRec) == 64 && offsetof(LeafRec, run) == 16, "resolve_staged reads a LeafRec out of a LeafAux");
+
+__device__ __forceinline__ void resolve_stats(const StrictWork &W, int kind, int serial, int tried, int applied, long long ticks) {
+  atomicAdd(&W.dbg[2], 1ull);
+  atomicAdd(&W.dbg[3], (unsigned long long)serial);
+  if (kind == 0) atomicAdd(&W.dbg[5], 1ull);
+  atomicAdd(&W.dbg[kind ? 10 : 11], (unsigned long long)ticks);
+  if (kind == JOB_NOWINDOW) {  // tiles without a window: leaf runs tried / applied, ticks
+    atomicAdd(&W.dbg[16], 1ull);
+    atomicAdd(&W.dbg[17], (unsigned long long)tried);
+    atomicAdd(&W.dbg[18], (unsigned long long)applied);
+    atomicAdd(&W.dbg[19], (unsigned long long)ticks);
+    atomicAdd(&W.dbg[22], (unsigned long long)serial);
+  } else if (kind == JOB_CROSSING) {
+    atomicAdd(&W.dbg[20], 1ull);
+    atomicAdd(&W.dbg[21], (unsigned long long)ticks);
+    atomicAdd(&W.dbg[23], (unsigned long long)serial);
   }
-  return s;
 }
 
 // debugging aid (W.selfcheck): the state after tiles [a, b) from `before`, term by term; mismatches
 // against what the walk produced are counted per path in dbg[12 + path]
-__device__ __forceinline__ void selfcheck(const StrictWork &W, const float *row_terms, uint32_t before, uint32_t after,
-                                          int64_t a, int64_t b, int path, int lane, float *lds) {
-  if (!W.selfcheck) return;
+__device__ __forceinline__ void selfcheck(const StrictWork &W, const TermSrc &src, int row, uint32_t before, uint32_t after,
+                                          int64_t a, int64_t b, int path, int lane, float4 *lds) {
+  if (!(W.selfcheck & 1)) return;
   uint32_t x = before;
   for (int64_t k = a; k < b; k++) {
-    float t[kLeaf];
-    load_leaf(row_terms, k, lane, t);
-    x = serial_tile(x, t, lane, lds);
+    __builtin_amdgcn_wave_barrier();
+    recompute_tile_to_lds(src, row, k, lane, lds);
+    x = serial_leaves(x, lds, 0, kLanes);
     __builtin_amdgcn_wave_barrier();
   }
-  if (x != after && lane == 0) {
-    const unsigned long long k = atomicAdd(&W.dbg[12 + path], 1ull);
-    if (0) {  // details of the first few: dbg[16 + 4k ..] = {a | b << 32, before | after << 32, expected, blockIdx}
-      W.dbg[16 + 4 * k] = (unsigned long long)a | ((unsigned long long)b << 32);
-      W.dbg[17 + 4 * k] = (unsigned long long)before | ((unsigned long long)after << 32);
-      W.dbg[18 + 4 * k] = x;
-      W.dbg[19 + 4 * k] = blockIdx.x;
-    }
-  }
+  if (x != after && lane == 0) atomicAdd(&W.dbg[12 + path], 1ull);
 }
 
-constexpr int kChainBlock = 512;
+// One workgroup per sum: a WALKER wave that applies the runs of equal windows to the exact state, one
+// after the other, and eight HELPER waves.  The helpers first compose the tiles' records into runs
+// (segmented scans over 64 tiles each, forwards -- then the walk starts -- and backwards).  Then each
+// takes the tiles that own a slot (level crossings, no window: where a record is most likely not to
+// cover the state) round robin, fetches such a tile's leaf records into registers and its terms into
+// LDS AHEAD of the walk, and waits: when the walker finds the tile's record does not cover its state
+// it hands the state over (an LDS mailbox) and gets the state behind the tile back; when the walker
+// passes the tile without trouble the helper goes on to its next one.  Round 2's walker fetched a
+// tile's 14 KB itself, after the failure: ~2.5 of the ~3.5 us a recomputed tile cost were that fetch,
+// on the critical path of a launch that waits for its slowest sum.
+constexpr int kChainSegs = 8;                 // waves = segments of 64 tiles per chunk
+constexpr int kChainTiles = kChainSegs * 64;  // tiles per chunk
+constexpr int kChainBlock = kChainTiles;
+constexpr int kWalker = kChainSegs - 1;       // the wave that walks (after the forward scan of its own segment)
+constexpr int kHelpers = kChainSegs - 1;      // the others (eight waves, two per SIMD: 256 registers each, no scratch)
 
 // a record every lane of the walking wave reads from the same LDS address, as scalars
 __device__ __forceinline__ TileRec load_rec_uniform(const TileRec *p) {
@@ -573,71 +800,165 @@ __device__ __forceinline__ TileRec compose_rec(const TileRec &X, const TileRec &
   return Z;
 }
 
-__global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(IcpState *__restrict__ state, StrictWork W,
+// words shared between the waves of the chain kernel (LDS), read and written with workgroup-scope atomics
+__device__ __forceinline__ int lds_get(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_put(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+struct ChainMail {  // walker <-> one helper
+  int req;          // ordinal + 1 of the tile the walker wants recomputed
+  int ack;          // ordinal + 1 of the tile the helper has recomputed
+  uint32_t s_in, s_out;
+};
+
+__global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 *__restrict__ match,
+                                                                  const uint32_t *__restrict__ pos_of,
+                                                                  IcpState *__restrict__ state, StrictWork W,
                                                                   double *__restrict__ sums10, IcpKernelParams kp,
                                                                   int fuse_update) {
-  __shared__ TileRec s_rec[kChainBlock];  // the tiles' own records
-  __shared__ TileRec s_pre[kChainBlock];  // composition from the tile's run head to the tile
-  __shared__ TileRec s_suf[kChainBlock];  // composition from the tile to its run's tail
-  __shared__ int16_t s_tail[kChainBlock];  // per wave: the tails of its runs, in order
-  __shared__ int16_t s_head[kChainBlock];
-  __shared__ int32_t s_count[kChainBlock / 64];
-  __shared__ float s_tile[kTile];
+  __shared__ TileRec s_rec[kChainTiles];   // the tiles' own records
+  __shared__ TileRec s_pre[kChainTiles];   // composition from the tile's run head to the tile
+  __shared__ TileRec s_suf[kChainTiles];   // composition from the tile to its run's tail
+  __shared__ int16_t s_tail[kChainTiles];  // per segment: the tails of its runs, in order
+  __shared__ int16_t s_head[kChainTiles];
+  __shared__ int16_t s_auxlist[kChainTiles];  // the tiles that own a slot, in order
+  __shared__ int16_t s_auxord[kChainTiles];   // a tile's place in that list, -1: owns no slot
+  __shared__ int32_t s_count[kChainSegs], s_auxcnt[kChainSegs];
+  __shared__ int s_sufok[kChainSegs];
+  __shared__ int s_progress;               // walker: the tile it stands at (tiles below are done)
+  __shared__ ChainMail s_mail[kChainSegs];
+  __shared__ float4 s_tile[kTile / 4];     // walker: the terms of a tile without a slot, formed again from the pairs
+  __shared__ unsigned long long s_np[kChainSegs];
   if (state->done) return;
   const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float *row_terms = W.terms + (int64_t)row * W.nt_pad;
-  uint32_t s = f2u(0.0f);  // walker state (wave 0), evaluator.go:122: the sums start at zero
-  for (int64_t chunk = 0; chunk < W.ntiles; chunk += kChainBlock) {
-    // ---- runs of equal windows: segmented scans inside each wave, forwards and backwards
+  const bool walker = wave == kWalker;
+  const TermSrc src = make_term_src(match, pos_of, state, W);
+  uint32_t s = f2u(0.0f);  // walker state, evaluator.go:122: the sums start at zero
+  for (int64_t chunk = 0; chunk < W.ntiles; chunk += kChainTiles) {
     const long long t_a = wall_clock64();
-    const int64_t tile = chunk + threadIdx.x;
-    const bool valid = tile < W.ntiles;
+    if (threadIdx.x < kChainSegs) {
+      s_sufok[threadIdx.x] = 0;
+      s_mail[threadIdx.x].req = 0;
+      s_mail[threadIdx.x].ack = 0;
+    }
+    if (threadIdx.x == 0) s_progress = 0;
+    // ---- helpers: runs of equal windows, segmented scan forwards inside each wave
     TileRec R;
-    if (valid) {
-      R = W.recs[row * W.ntiles + tile];
-    } else {
-      R.key = -2;
-      R.in = R.out = 0u;
-      R.cons = 0;
-      R.s = summary_identity();
-    }
-    s_rec[threadIdx.x] = R;
-    const int32_t key_prev = __shfl_up(R.key, 1), key_next = __shfl_down(R.key, 1);
-    const bool head = lane == 0 || R.key < 0 || R.key != key_prev;
-    const bool tail = lane == 63 || R.key < 0 || R.key != key_next;
-    TileRec P = R, Q = R;
-    int fp = head ? 1 : 0, fq = tail ? 1 : 0;
+    R.key = -2;
+    R.in = R.out = 0u;
+    R.cons = 0;
+    R.s = summary_identity();
+    bool head = true, tail = true, valid = false;
+    {
+      const int64_t tile = chunk + threadIdx.x;
+      valid = tile < W.ntiles;
+      if (valid) R = W.recs[row * W.ntiles + tile];
+      s_rec[threadIdx.x] = R;
+      const int32_t key_prev = __shfl_up(R.key, 1), key_next = __shfl_down(R.key, 1);
+      head = lane == 0 || R.key < 0 || R.key != key_prev;
+      tail = lane == 63 || R.key < 0 || R.key != key_next;
+      TileRec P = R;
+      int fp = head ? 1 : 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const TileRec X = shfl_rec(P, lane - o);
-      const int xf = __shfl_up(fp, o);
-      if (lane >= o && !fp) {
-        P = compose_rec(X, P);
-        fp = xf;
+      for (int o = 1; o < 64; o <<= 1) {
+        const TileRec X = shfl_rec(P, lane - o);
+        const int xf = __shfl_up(fp, o);
+        if (lane >= o && !fp) {
+          P = compose_rec(X, P);
+          fp = xf;
+        }
       }
-      const TileRec Y = shfl_rec(Q, lane + o);
-      const int yf = __shfl_down(fq, o);
-      if (lane + o < 64 && !fq) {
-        Q = compose_rec(Q, Y);
-        fq = yf;
+      s_pre[threadIdx.x] = P;
+      const unsigned long long tails = __ballot(tail && valid);
+      if (tail && valid) {
+        const unsigned long long below = tails & ((1ull << lane) - 1ull);  // the run starts behind the tail before this one
+        const int idx = wave * 64 + __popcll(below);
+        s_tail[idx] = (int16_t)threadIdx.x;
+        s_head[idx] = (int16_t)(wave * 64 + (below ? 64 - __builtin_clzll(below) : 0));
       }
+      if (lane == 0) s_count[wave] = __popcll(tails);
+      const unsigned long long aux = __ballot(valid && (R.cons >> 8) != 0);
+      if (lane == 0) s_auxcnt[wave] = __popcll(aux);
     }
-    s_pre[threadIdx.x] = P;
-    s_suf[threadIdx.x] = Q;
-    const unsigned long long tails = __ballot(tail && valid);
-    if (tail && valid) {
-      const unsigned long long below = tails & ((1ull << lane) - 1ull);  // the run starts behind the tail before this one
-      const int idx = wave * 64 + __popcll(below);
-      s_tail[idx] = (int16_t)threadIdx.x;
-      s_head[idx] = (int16_t)(wave * 64 + (below ? 64 - __builtin_clzll(below) : 0));
-    }
-    if (lane == 0) s_count[wave] = __popcll(tails);
     __syncthreads();
-    // ---- the walk: one wave, every lane with the same state
-    if (wave == 0) {
+    int naux = 0;
+    {  // the list of tiles that own a slot
+      int base = 0;
+      for (int w = 0; w < kChainSegs; w++) {
+        const int c = s_auxcnt[w];
+        base += w < wave ? c : 0;
+        naux += c;
+      }
+      const bool has = valid && (R.cons >> 8) != 0;
+      const unsigned long long aux = __ballot(has);
+      const int ord = base + __popcll(aux & ((1ull << lane) - 1ull));
+      s_auxord[threadIdx.x] = has ? (int16_t)ord : (int16_t)-1;
+      if (has) s_auxlist[ord] = (int16_t)threadIdx.x;
+    }
+    __syncthreads();
+    if (!walker) {
+      // ---- helper: compose the runs backwards (wave 0: the walker's segment as well), then serve the walker
+      auto scan_backwards = [&](int seg, TileRec Q, bool is_tail) {
+        int fq = is_tail ? 1 : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const TileRec Y = shfl_rec(Q, lane + o);
+          const int yf = __shfl_down(fq, o);
+          if (lane + o < 64 && !fq) {
+            Q = compose_rec(Q, Y);
+            fq = yf;
+          }
+        }
+        s_suf[seg * 64 + lane] = Q;
+        lds_fence_wave();
+        if (lane == 0) lds_put(&s_sufok[seg], 1);
+      };
+      scan_backwards(wave, R, tail);
+      if (wave == 0) {
+        const TileRec R7 = s_rec[kWalker * 64 + lane];
+        const int32_t kn = __shfl_down(R7.key, 1);
+        scan_backwards(kWalker, R7, lane == 63 || R7.key < 0 || R7.key != kn);
+      }
+      int k = wave;  // my tiles: ordinals wave, wave + 7, ...
+      while (k < naux) {  // uniform
+        // the tile's leaf records and terms (lane l: leaf l), in registers
+        const int cur_tile = s_auxlist[k];
+        const int32_t cur_key = s_rec[cur_tile].key;
+        const int slot = (s_rec[cur_tile].cons >> 8) - 1;
+        const int cur_kind = cur_key >= 0 ? JOB_CROSSING : JOB_NOWINDOW;
+        const LeafAux A = W.aux[(size_t)slot * kLanes + lane];
+        float t[kLeaf];
+        load_leaf_quads(W.aux_terms + (size_t)slot * (kTile / 4), lane, t);
+        bool serve = false;
+        while (true) {
+          if (lds_get(&s_mail[wave].req) == k + 1) {
+            serve = true;
+            break;
+          }
+          const int prog = lds_get(&s_progress);
+          if (prog > cur_tile) {  // the walker got past my tile without me (or is done with the chunk)
+            if (prog == 1 << 30) k = naux;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (serve) {
+          const long long t_begin = wall_clock64();
+          const uint32_t s_in = (uint32_t)rfl((int)__hip_atomic_load(&s_mail[wave].s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          int serial, tried, applied;
+          const uint32_t s_out = resolve_staged<true>(s_in, cur_kind, cur_key, A, lane, nullptr, t, serial, tried, applied);
+          if (lane == 0) {
+            __hip_atomic_store(&s_mail[wave].s_out, s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lds_put(&s_mail[wave].ack, k + 1);
+            resolve_stats(W, cur_kind, serial, tried, applied, wall_clock64() - t_begin);
+          }
+        }
+        k += kHelpers;
+      }
+    } else {
+      // ---- the walk: one wave, every lane with the same state
       const long long t_b = wall_clock64();
       unsigned long long n_run = 0, n_runfail = 0, n_recfail = 0;
-      for (int w = 0; w < kChainBlock / 64; w++) {
+      for (int w = 0; w < kChainSegs; w++) {
         const int cnt = s_count[w];
         for (int i = 0; i < cnt; i++) {
           const int e = s_tail[w * 64 + i], h = s_head[w * 64 + i];
@@ -646,30 +967,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(IcpState *__r
             const TileRec Qr = load_rec_uniform(&s_pre[e]);  // the whole run
             const uint32_t s_in = s;
             if ((Qr.key >= 0 && apply(s, Qr.key, Qr.s)) || apply_point(s, Qr)) {
-              selfcheck(W, row_terms, s_in, s, chunk + h, chunk + e + 1, 0, lane, s_tile);
-              if (W.selfcheck) {  // the same run composed tile after tile from the tiles' own records
-                TileRec acc = load_rec_uniform(&s_rec[h]);
-                for (int q = h + 1; q <= e; q++) acc = compose_rec(acc, load_rec_uniform(&s_rec[q]));
-                uint32_t y = s_in;
-                const bool okc = acc.key >= 0 && apply(y, acc.key, acc.s);
-                bool same = acc.key == Qr.key && acc.in == Qr.in && acc.out == Qr.out && (acc.cons & 1) == (Qr.cons & 1);
-                for (int r = 0; r < 4; r++) same = same && acc.s.c[r] == Qr.s.c[r] && acc.s.lo[r] == Qr.s.lo[r] && acc.s.hi[r] == Qr.s.hi[r];
-                if (lane == 0) {
-                  if (!same) atomicAdd(&W.dbg[6], 1ull);          // the wave scan disagrees with the serial composition
-                  if (okc && y != s) {
-                    const unsigned long long k = atomicAdd(&W.dbg[7], 1ull);  // and gives another result
-                    if (k < 2) {
-                      uint32_t z = s_in;
-                      const int32_t nn = state_to_n(s_in, Qr.key);
-                      const bool okq = apply(z, Qr.key, Qr.s);
-                      unsigned long long *d = W.dbg + 16 + 16 * k;
-                      d[0] = s_in; d[1] = s; d[2] = y; d[3] = (unsigned long long)(uint32_t)Qr.key; d[4] = (unsigned long long)(uint32_t)nn;
-                      d[5] = (uint32_t)Qr.s.c[nn & 3]; d[6] = (uint32_t)Qr.s.lo[nn & 3]; d[7] = (uint32_t)Qr.s.hi[nn & 3];
-                      d[8] = (uint32_t)acc.s.c[nn & 3]; d[9] = okq; d[10] = z; d[11] = Qr.in; d[12] = Qr.out; d[13] = Qr.cons;
-                    }
-                  }
-                }
-              }
+              selfcheck(W, src, row, s_in, s, chunk + h, chunk + e + 1, 0, lane, s_tile);
+              if (lane == 0) lds_put(&s_progress, e + 1);
               continue;
             }
           }
@@ -688,30 +987,53 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(IcpState *__r
             const uint32_t s_in = s;
             if (ngood > 0) s = (uint32_t)__builtin_amdgcn_readlane((int)mine, ngood - 1);
             f = h + ngood;
-            selfcheck(W, row_terms, s_in, s, chunk + h, chunk + f, 1, lane, s_tile);
+            selfcheck(W, src, row, s_in, s, chunk + h, chunk + f, 1, lane, s_tile);
           }
           while (f <= e) {
-            const TileRec T = load_rec_uniform(&s_rec[f]);
+            // tile f does not cover the state (its place in the run's prefix composition failed, or it is
+            // the run's head); its point record may still fit
             const uint32_t s_in = s;
+            const TileRec T = load_rec_uniform(&s_rec[f]);
             if (!(f > h && ((T.key >= 0 && apply(s, T.key, T.s)) || apply_point(s, T)))) {
               n_recfail++;
-              const int slot = (T.cons >> 8) - 1;
-              s = (uint32_t)rfl((int)resolve_tile(s, row_terms, chunk + f, T.key,
-                                                  slot >= 0 ? W.aux + (size_t)slot * kLanes : nullptr, lane, W.dbg, s_tile));
+              const int ord = s_auxord[f];
+              if (lane == 0) lds_put(&s_progress, f);
+              if (ord >= 0) {  // its helper has the tile's terms and leaf records at hand
+                ChainMail *M = &s_mail[ord % kHelpers];
+                if (lane == 0) {
+                  __hip_atomic_store(&M->s_in, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  lds_put(&M->req, ord + 1);
+                }
+                while (lds_get(&M->ack) != ord + 1) {
+                }
+                s = (uint32_t)rfl((int)__hip_atomic_load(&M->s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+              } else {  // a tile without a slot: its terms are formed again from the pairs, all 2048 are added
+                const long long t_begin = wall_clock64();
+                recompute_tile_to_lds(src, row, chunk + f, lane, s_tile);
+                LeafAux none;
+                int serial, tried, applied;
+                s = resolve_staged<false>(s, 0, -1, none, lane, s_tile, nullptr, serial, tried, applied);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) resolve_stats(W, 0, serial, tried, applied, wall_clock64() - t_begin);
+              }
             }
-            selfcheck(W, row_terms, s_in, s, chunk + f, chunk + f + 1, 2, lane, s_tile);
+            selfcheck(W, src, row, s_in, s, chunk + f, chunk + f + 1, 2, lane, s_tile);
             f++;
             if (f > e) break;
+            while (lds_get(&s_sufok[f >> 6]) == 0) {
+            }
             const TileRec Sf = load_rec_uniform(&s_suf[f]);  // the rest of the run in one step
             const uint32_t s_in2 = s;
             if ((Sf.key >= 0 && apply(s, Sf.key, Sf.s)) || apply_point(s, Sf)) {
-              selfcheck(W, row_terms, s_in2, s, chunk + f, chunk + e + 1, 3, lane, s_tile);
+              selfcheck(W, src, row, s_in2, s, chunk + f, chunk + e + 1, 3, lane, s_tile);
               break;
             }
           }
+          if (lane == 0) lds_put(&s_progress, e + 1);
         }
       }
       if (lane == 0) {
+        lds_put(&s_progress, 1 << 30);  // helpers that still wait for a tile: the chunk is done
         atomicAdd(&W.dbg[0], n_run);
         atomicAdd(&W.dbg[1], n_runfail);
         atomicAdd(&W.dbg[4], n_recfail);
@@ -722,23 +1044,40 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(IcpState *__r
     }
     __syncthreads();
   }
-  for (int64_t b = threadIdx.x; b < W.nbins; b += kChainBlock) W.bin_sum[row * W.nbins + b] = 0.0;
+  // the pair count of the iteration: row 0 adds up the tiles' counts (a fixed order is not needed: integers)
+  if (row == 0) {
+    unsigned long long v = 0ull;
+    for (int64_t k = threadIdx.x; k < W.ntiles; k += kChainTiles) v += W.tile_pairs[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) s_np[wave] = v;
+    __syncthreads();
+    if (walker && lane == 0) {
+      unsigned long long np = 0ull;
+      for (int w = 0; w < kChainSegs; w++) np += s_np[w];
+      __hip_atomic_store(&sums10[S_PAIRS], (double)np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   // component order of sums10: Value, G0..G5, DistRMS, Weight, Pairs
-  if (threadIdx.x == 0) {
+  if (walker && lane == 0) {
     const int slot = row == 0 ? S_VALUE : (row <= 6 ? S_G0 + row - 1 : (row == 7 ? S_DIST_RMS : S_WEIGHT));
     __hip_atomic_store(&sums10[slot], (double)u2f(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the row that finishes last has all nine sums: evaluate tail + pose update (evaluator.go:156-186,
     // updater.go:44-71) in the same launch
     __threadfence();
     const unsigned ticket = atomicAdd(W.done_rows, 1u);
-    if (ticket == (unsigned)kStrictRows - 1u) {
+    if (ticket == (unsigned)W.nrows - 1u) {
       __threadfence();
       double sums[S_COUNT];
       for (int k = 0; k < S_COUNT; k++) sums[k] = __hip_atomic_load(&sums10[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sums[S_PAIRS] = (double)__hip_atomic_load(W.pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sums10[S_PAIRS] = sums[S_PAIRS];
-      *W.pairs = 0ull;
-      *W.aux_count = 0u;
+      const unsigned long long np = (unsigned long long)sums[S_PAIRS];  // row 0 stored it before its ticket
+      if (W.nrows < kStrictRows) {
+        // default weight: every term of the ninth sum is 1.0f, and 0 + 1 + 1 + ... in float32 is the pair
+        // count up to 2^24, where it stays (2^24 + 1 rounds back to 2^24): no chain to evaluate
+        sums[S_WEIGHT] = (double)(np < (1ull << 24) ? np : (1ull << 24));
+        sums10[S_WEIGHT] = sums[S_WEIGHT];
+      }
+      for (int k = 0; k < kAuxShards; k++) W.aux_count[k * 32] = 0u;
       *W.done_rows = 0u;
       if (fuse_update) icp_update_step(state, sums, kp);
     }
@@ -757,37 +1096,43 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   StrictWork &W = b->w;
   W.nt = nt;
   W.ntiles = nt > 0 ? (nt + kTile - 1) / kTile : 1;
-  W.nt_pad = W.ntiles * kTile;
-  W.nbins = (W.ntiles + kBinTiles - 1) / kBinTiles;
-  W.selfcheck = getenv("PCGX_STRICT_SELFCHECK") ? 1 : 0;
+  W.nrows = kStrictRows;
+  W.selfcheck = (getenv("PCGX_STRICT_SELFCHECK") ? 1 : 0) | (getenv("PCGX_STRICT_TRACE") ? 2 : 0);
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t sz_terms = up((size_t)kStrictRows * W.nt_pad * sizeof(float));
   const size_t sz_tile = up((size_t)kStrictRows * W.ntiles * sizeof(double));
-  const size_t sz_bin = up((size_t)kStrictRows * W.nbins * sizeof(double));
+  const size_t sz_pairs = up((size_t)W.ntiles * sizeof(uint32_t));
   const size_t sz_rec = up((size_t)kStrictRows * W.ntiles * sizeof(TileRec));
-  W.naux = (int32_t)(kStrictRows * W.ntiles / 4 + 64);
+  // slots for the tiles that cross a level or have no window (6 KB of leaf records + 8 KB of terms each):
+  // a quarter of all tiles, far more than ever seen (C4: ~2 %; a sum hovering around zero over the whole
+  // row: ~15 %); a tile that finds none left is recomputed from the pairs by the chain kernel
+  W.naux = (int32_t)(kAuxShards * ((kStrictRows * W.ntiles / 4 + kAuxShards - 1) / kAuxShards + 4));
   const size_t sz_aux = up((size_t)W.naux * kLanes * sizeof(LeafAux));
-  const size_t sz_xyz = up((size_t)(nt ? nt : 1) * 12);
-  const size_t total = sz_terms + sz_tile + sz_bin + sz_rec + sz_aux + sz_xyz + 256 + 512;
+  const size_t sz_auxt = up((size_t)W.naux * kTile * sizeof(float));
+  const size_t sz_jobs = up((size_t)W.naux * sizeof(JobDesc));
+  const size_t sz_xyz = up((size_t)(nt ? nt : 1) * 12 + 64);
+  const size_t sz_stamps = up((size_t)W.ntiles * 16 * sizeof(unsigned long long));
+  const size_t sz_ctr = 256 + (size_t)kAuxShards * 128;
+  const size_t total = sz_tile + sz_pairs + sz_rec + sz_aux + sz_auxt + sz_jobs + sz_xyz + sz_ctr + 512 + sz_stamps;
   hipError_t e = dev_cache_alloc(&b->block, total);
   if (e != hipSuccess) {
     delete b;
     return fail(PCGX_E_OOM, "strict sums: allocation of %zu bytes failed: %s", total, hipGetErrorString(e));
   }
   uint8_t *p = (uint8_t *)b->block;
-  W.terms = (float *)p; p += sz_terms;
   W.tile_sum = (double *)p; p += sz_tile;
-  W.bin_sum = (double *)p; p += sz_bin;
+  W.tile_pairs = (uint32_t *)p; p += sz_pairs;
   W.recs = (TileRec *)p; p += sz_rec;
   W.aux = (LeafAux *)p; p += sz_aux;
+  W.aux_terms = (float4 *)p; p += sz_auxt;
+  W.jobs = (JobDesc *)p; p += sz_jobs;
   W.xyz_caller = (const float *)p; p += sz_xyz;
-  W.pairs = (unsigned long long *)p;
-  W.aux_count = (unsigned int *)(p + 8);
-  W.done_rows = (unsigned int *)(p + 12); p += 256;
-  W.dbg = (unsigned long long *)p;
-  // bins, pair counter and debug counters start at zero (the chain kernel re-zeroes what it consumed)
-  e = hipMemsetAsync(W.bin_sum, 0, sz_bin, st);
-  if (e == hipSuccess) e = hipMemsetAsync(W.pairs, 0, 768, st);
+  uint8_t *counters = p;
+  W.done_rows = (unsigned int *)(p + 12);
+  W.aux_count = (unsigned int *)(p + 256); p += sz_ctr;
+  W.dbg = (unsigned long long *)p; p += 512;
+  W.stamps = (unsigned long long *)p;
+  // slot / ticket counters and debug counters start at zero (the chain kernel re-zeroes what it consumed)
+  e = hipMemsetAsync(counters, 0, sz_ctr + 512, st);
   if (e == hipSuccess && nt > 0) {
     hipLaunchKernelGGL(strict_xyz_caller_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, tx, ty, tz, pos_of, nt,
                        const_cast<float *>(W.xyz_caller));
@@ -812,28 +1157,45 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
                            double *sums10, const IcpKernelParams &kp, bool fuse_update, hipStream_t st) {
   b->w.weight_fn = kp.weight_fn;
   b->w.weight_a = kp.weight_a;
+  // (the row count may only change between iterations: the chain kernel's ticket counts to it)
+  b->w.nrows = kp.weight_fn == PCGX_WEIGHT_ONE ? kStrictRows - 1 : kStrictRows;
   const StrictWork &W = b->w;
-  const unsigned waves = (unsigned)(kStrictRows * W.ntiles);
   {
     ProfScope prof(PCGX_PROF_STRICT_TERMS, st);
-    hipLaunchKernelGGL(strict_terms_kernel, dim3((unsigned)W.ntiles), dim3(kTermsBlock), 0, st, match, pos_of, (const IcpState *)state, W);
+    hipLaunchKernelGGL(strict_tilesum_kernel, dim3((unsigned)W.ntiles), dim3(kTileSumBlock), 0, st, match, pos_of,
+                       (const IcpState *)state, W);
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_SUM, st);
-    hipLaunchKernelGGL(strict_sum_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, (const IcpState *)state, W);
+    hipLaunchKernelGGL(strict_sum_kernel, dim3((unsigned)W.ntiles), dim3(kSumBlock), 0, st, match, pos_of,
+                       (const IcpState *)state, W);
+    hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
-    hipLaunchKernelGGL(strict_chain_kernel, dim3(kStrictRows), dim3(kChainBlock), 0, st, state, W, sums10, kp, fuse_update ? 1 : 0);
+    hipLaunchKernelGGL(strict_chain_kernel, dim3((unsigned)W.nrows), dim3(kChainBlock), 0, st, match, pos_of, state, W, sums10,
+                       kp, fuse_update ? 1 : 0);
   }
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }
 
-pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[48], hipStream_t st) {
-  PCGX_HIP_TRY(hipMemcpyAsync(out, b->w.dbg, 48 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[64], hipStream_t st) {
+  PCGX_HIP_TRY(hipMemcpyAsync(out, b->w.dbg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
-  PCGX_HIP_TRY(hipMemsetAsync(b->w.dbg, 0, 48 * sizeof(unsigned long long), st));
+  if (const char *path = getenv("PCGX_STRICT_TRACE")) {  // measurement aid: the last launch's workgroup stamps
+    std::vector<unsigned long long> h((size_t)b->w.ntiles * 16);
+    PCGX_HIP_TRY(hipMemcpy(h.data(), b->w.stamps, h.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE *f = fopen(path, "a")) {
+      for (int64_t k = 0; k < b->w.ntiles; k++) {
+        for (int j = 0; j < 16; j++) fprintf(f, "%llu ", h[(size_t)k * 16 + j]);
+        fprintf(f, "\n");
+      }
+      fprintf(f, "#\n");
+      fclose(f);
+    }
+  }
+  PCGX_HIP_TRY(hipMemsetAsync(b->w.dbg, 0, 64 * sizeof(unsigned long long), st));
   return PCGX_OK;
 }
 

@@ -154,22 +154,50 @@ struct ChainRange {
   uint32_t end;
 };
 
-SS_HD ChainRange guess_chain(const float *t, uint32_t g0) {
+// The chains take the leaf's terms four at a time from `quad(v)` (v = 0 .. kLeaf / 4 - 1: anything with
+// members x, y, z, w): the kernels read them from LDS as they go instead of holding 32 registers.
+struct Quad {
+  float x, y, z, w;
+};
+struct ArrayQuads {  // a leaf in an array
+  const float *t;
+  SS_HD Quad operator()(int v) const { return Quad{t[4 * v], t[4 * v + 1], t[4 * v + 2], t[4 * v + 3]}; }
+};
+
+template <class Q>
+SS_HD ChainRange guess_chain_q(Q quad, uint32_t g0) {
   ChainRange R;
   R.mn = R.mx = g0 & 0x7fffffffu;
   R.sg_or = R.sg_and = g0 >> 31;
   float s = u2f(g0);
-#pragma unroll
-  for (int j = 0; j < kLeaf; j++) {
-    s = s + t[j];
+  auto step = [&](float term) {
+    s = s + term;
     const uint32_t b = f2u(s), m = b & 0x7fffffffu;
     R.mn = umin(R.mn, m);
     R.mx = umax(R.mx, m);
     R.sg_or |= b >> 31;
     R.sg_and &= b >> 31;
+  };
+#pragma unroll
+  for (int v = 0; v < kLeaf / 4; v++) {
+    const auto a = quad(v);
+    step(a.x); step(a.y); step(a.z); step(a.w);
   }
   R.end = f2u(s);
   return R;
+}
+SS_HD ChainRange guess_chain(const float *t, uint32_t g0) { return guess_chain_q(ArrayQuads{t}, g0); }
+
+// the chain's end only
+template <class Q>
+SS_HD uint32_t plain_chain_q(Q quad, uint32_t g0) {
+  float s = u2f(g0);
+#pragma unroll
+  for (int v = 0; v < kLeaf / 4; v++) {
+    const auto a = quad(v);
+    s = (((s + a.x) + a.y) + a.z) + a.w;
+  }
+  return f2u(s);
 }
 
 // window of a range of magnitudes [mn, mx] with one sign: the two binades that hold it, the level
@@ -194,14 +222,14 @@ SS_HD int32_t choose_window(uint32_t mn, uint32_t mx, uint32_t sign, uint32_t re
 // General form: up to four class representatives next to the guess, each run through the leaf with
 // real float adds; per class the translation and the interval of inputs that land on the same side
 // of the level 2^24 (and inside the window) as the representative at every step.
-SS_HD void class_chain(const float *t, uint32_t rep, int32_t key, int32_t &c, int32_t &lo, int32_t &hi) {
+template <class Q>
+SS_HD void class_chain_q(Q quad, uint32_t rep, int32_t key, int32_t &c, int32_t &lo, int32_t &hi) {
   const uint32_t sign = (uint32_t)(key >> 8), e = (uint32_t)(key & 0xff);
   const uint32_t Lbits = e << 23, firstLow = (e - 1u) << 23, lastUp = Lbits | 0x7fffffu;
   float s = u2f(rep);
   uint32_t maxB = 0u, minA = 0xffffffffu, mnAll = 0xffffffffu, mxAll = 0u, sg_bad = 0u;
-#pragma unroll
-  for (int j = 0; j < kLeaf; j++) {
-    s = s + t[j];
+  auto step = [&](float term) {
+    s = s + term;
     const uint32_t b = f2u(s), m = b & 0x7fffffffu;
     sg_bad |= (b >> 31) ^ sign;
     const bool above = m >= Lbits;
@@ -209,6 +237,11 @@ SS_HD void class_chain(const float *t, uint32_t rep, int32_t key, int32_t &c, in
     minA = above ? umin(minA, m) : minA;
     mnAll = umin(mnAll, m);
     mxAll = umax(mxAll, m);
+  };
+#pragma unroll
+  for (int v = 0; v < kLeaf / 4; v++) {
+    const auto a = quad(v);
+    step(a.x); step(a.y); step(a.z); step(a.w);
   }
   const uint32_t r0 = rep & 0x7fffffffu;
   auto to_n = [&](uint32_t m) -> int32_t {
@@ -234,6 +267,9 @@ SS_HD void class_chain(const float *t, uint32_t rep, int32_t key, int32_t &c, in
   lo = n0 + dlo;
   hi = n0 + dhi;
 }
+SS_HD void class_chain(const float *t, uint32_t rep, int32_t key, int32_t &c, int32_t &lo, int32_t &hi) {
+  class_chain_q(ArrayQuads{t}, rep, key, c, lo, hi);
+}
 
 SS_HD Summary leaf_summary_general(const float *t, uint32_t guess, int32_t key) {
   Summary S;
@@ -252,24 +288,58 @@ SS_HD Summary leaf_summary_general(const float *t, uint32_t guess, int32_t key) 
   return S;
 }
 
+// One class of the general form, as a function of the class index: what leaf_summary_general puts
+// into S.c[r] / S.lo[r] / S.hi[r].  strict_sum_kernel hands the four classes of a leaf to four waves.
+template <class Q>
+SS_HD void leaf_class_piece_q(Q quad, uint32_t guess, int32_t key, int r, int32_t &c, int32_t &lo, int32_t &hi) {
+  c = 0;
+  lo = kBig;
+  hi = -kBig;
+  if (key < 0) return;
+  const uint32_t e = (uint32_t)(key & 0xff), E = (guess >> 23) & 0xffu;
+  if (E == e - 1u) {
+    class_chain_q(quad, (guess & ~3u) | (uint32_t)r, key, c, lo, hi);
+  } else if ((r & 1) == 0) {
+    class_chain_q(quad, (guess & ~1u) | (uint32_t)(r >> 1), key, c, lo, hi);
+  }
+}
+SS_HD void leaf_class_piece(const float *t, uint32_t guess, int32_t key, int r, int32_t &c, int32_t &lo, int32_t &hi) {
+  leaf_class_piece_q(ArrayQuads{t}, guess, key, r, c, lo, hi);
+}
+
+// Window of ONE leaf (tiles without a window of their own: sums that hover around zero): the two
+// binades that hold its guess chain, -1 if it changes sign or runs through three binades
+SS_HD int32_t leaf_key(const ChainRange &cr, uint32_t guess) {
+  if (cr.sg_or != cr.sg_and) return -1;
+  return choose_window(cr.mn, cr.mx, cr.sg_or, guess & 0x7fffffffu);
+}
+
 // Fast form for a leaf whose guess chain stays in ONE binade E of the window: two representatives
 // (mantissa even / odd), tracked in bit space (inside a binade the bit pattern IS the mantissa
 // integer and its order).
-SS_HD void binade_chain(const float *t, uint32_t rep, uint32_t &end, uint32_t &mn, uint32_t &mx, uint32_t &sg_bad) {
+template <class Q>
+SS_HD void binade_chain_q(Q quad, uint32_t rep, uint32_t &end, uint32_t &mn, uint32_t &mx, uint32_t &sg_bad) {
   float s = u2f(rep);
   mn = 0xffffffffu;
   mx = 0u;
   sg_bad = 0u;
   const uint32_t sign = rep >> 31;
-#pragma unroll
-  for (int j = 0; j < kLeaf; j++) {
-    s = s + t[j];
+  auto step = [&](float term) {
+    s = s + term;
     const uint32_t b = f2u(s), m = b & 0x7fffffffu;
     sg_bad |= (b >> 31) ^ sign;
     mn = umin(mn, m);
     mx = umax(mx, m);
+  };
+#pragma unroll
+  for (int v = 0; v < kLeaf / 4; v++) {
+    const auto a = quad(v);
+    step(a.x); step(a.y); step(a.z); step(a.w);
   }
   end = f2u(s) & 0x7fffffffu;
+}
+SS_HD void binade_chain(const float *t, uint32_t rep, uint32_t &end, uint32_t &mn, uint32_t &mx, uint32_t &sg_bad) {
+  binade_chain_q(ArrayQuads{t}, rep, end, mn, mx, sg_bad);
 }
 
 SS_HD Summary leaf_summary_binade(const float *t, uint32_t guess, int32_t key) {
@@ -315,12 +385,97 @@ SS_HD Summary leaf_summary_binade(const float *t, uint32_t guess, int32_t key) {
   return S;
 }
 
+// ---- tiles that stay in ONE binade: parity summaries --------------------------------------------------
+// Inside one binade E only the parity of the mantissa matters (classes r and r + 2 of the lower binade
+// coincide; the upper binade has the even classes only), so a summary needs two classes, not four, and
+// its composition a quarter of the work.  Units: magnitude bits relative to the binade's first float
+// (rel = bits - (E << 23), 0 .. 2^23 - 1).  For inputs of parity p with lo[p] <= rel <= hi[p]:
+// rel_out = rel + c[p].  par_expand() restates it as the four-class Summary of a window that holds E.
+struct Par {
+  int32_t c[2], lo[2], hi[2];
+};
+
+SS_HD void par_class(bool ok, uint32_t r0_mag, uint32_t end_mag, uint32_t mn, uint32_t mx, uint32_t E, int32_t &c, int32_t &lo,
+                       int32_t &hi) {
+  const uint32_t first = E << 23, last = first | 0x7fffffu;
+  if (!ok || (r0_mag >> 23) != E || mn < first + 1u || mx > last) {
+    c = 0;
+    lo = kBig;
+    hi = -kBig;
+    return;
+  }
+  const int32_t rel0 = (int32_t)(r0_mag - first);
+  c = (int32_t)end_mag - (int32_t)r0_mag;
+  lo = rel0 + ((int32_t)(first + 1u) - (int32_t)mn);
+  hi = rel0 + ((int32_t)last - (int32_t)mx);
+}
+
+// X first, then Y
+SS_HD Par par_compose(const Par &X, const Par &Y) {
+  Par Z;
+#pragma unroll
+  for (int p = 0; p < 2; p++) {
+    const int32_t xc = X.c[p];
+    const bool odd = ((p + xc) & 1) != 0;
+    Z.c[p] = iclamp(xc + (odd ? Y.c[1] : Y.c[0]), -kClamp, kClamp);
+    Z.lo[p] = imax(X.lo[p], iclamp((odd ? Y.lo[1] : Y.lo[0]) - xc, -kBig, kBig));
+    Z.hi[p] = imin(X.hi[p], iclamp((odd ? Y.hi[1] : Y.hi[0]) - xc, -kBig, kBig));
+  }
+  return Z;
+}
+
+SS_HD Par par_identity() {
+  Par S;
+  S.c[0] = S.c[1] = 0;
+  S.lo[0] = S.lo[1] = -kBig;
+  S.hi[0] = S.hi[1] = kBig;
+  return S;
+}
+
+// the four-class summary (units of window `key`) of a parity summary of binade E (E == e or e - 1)
+SS_HD Summary par_expand(const Par &P, uint32_t E, int32_t key) {
+  Summary S;
+  const uint32_t e = (uint32_t)(key & 0xff);
+  const bool upper = E == e;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int p = upper ? (r >> 1) : (r & 1);
+    const bool none = (upper && (r & 1)) || P.lo[p] > P.hi[p] || (E != e && E != e - 1u);
+    const int32_t f = upper ? 2 : 1;
+    S.c[r] = none ? 0 : P.c[p] * f;
+    S.lo[r] = none ? kBig : iclamp((N23 + P.lo[p]) * f, -kBig, kBig);
+    S.hi[r] = none ? -kBig : iclamp((N23 + P.hi[p]) * f, -kBig, kBig);
+  }
+  return S;
+}
+
+// one leaf: the guess chain `cr` (run from `guess`) serves as the chain of the guess's own parity, the
+// other parity gets a chain of its own
+template <class Q>
+SS_HD Par leaf_parity_summary_q(Q quad, uint32_t guess, const ChainRange &cr, uint32_t E, uint32_t sign) {
+  int32_t c0, lo0, hi0, c1, lo1, hi1;  // the guess's own parity | the other one
+  par_class(cr.sg_or == sign && cr.sg_and == sign, guess & 0x7fffffffu, cr.end & 0x7fffffffu, cr.mn, cr.mx, E, c0, lo0, hi0);
+  const uint32_t rep = guess ^ 1u;
+  uint32_t end, mn, mx, bad;
+  binade_chain_q(quad, rep, end, mn, mx, bad);
+  par_class(!bad && (rep >> 31) == sign, rep & 0x7fffffffu, end, mn, mx, E, c1, lo1, hi1);
+  const bool odd = (guess & 1u) != 0u;  // (selects, no indexing by a run-time value: that would put S into scratch memory)
+  Par S;
+  S.c[0] = odd ? c1 : c0; S.lo[0] = odd ? lo1 : lo0; S.hi[0] = odd ? hi1 : hi0;
+  S.c[1] = odd ? c0 : c1; S.lo[1] = odd ? lo0 : lo1; S.hi[1] = odd ? hi0 : hi1;
+  return S;
+}
+SS_HD Par leaf_parity_summary(const float *t, uint32_t guess, const ChainRange &cr, uint32_t E, uint32_t sign) {
+  return leaf_parity_summary_q(ArrayQuads{t}, guess, cr, E, sign);
+}
+
 // ---- host model ---------------------------------------------------------------------------------
 // The whole pipeline in plain loops (what the strict_* kernels do wave-parallel), for the CPU
 // tests.  terms[n] -> the sequential float32 sum of 0.0f + t0 + t1 + ... ; stats: [0] tiles,
 // [1] tiles without a record, [2] runs applied, [3] runs that failed, [4] tiles resolved exactly,
 // [5] leaves added serially, [6] leaves in the general (crossing) form, [7] tile records that failed.
-// mode bit 0: never use the in-binade fast form; bit 1: no refinement of the guesses inside a tile.
+// mode bit 0: never use the in-binade fast form; bit 1: no refinement of the guesses inside a tile;
+// bit 2: no parity summaries (tiles in one binade take the four-class forms).
 inline float ss_host_model(const float *terms_in, int64_t n, int64_t stats[8], int mode) {
   for (int k = 0; k < 8; k++) stats[k] = 0;
   const int64_t ntiles = n > 0 ? (n + kTile - 1) / kTile : 1;
@@ -404,7 +559,12 @@ inline float ss_host_model(const float *terms_in, int64_t n, int64_t stats[8], i
       T.out = cr[kLanes - 1].end;
       T.cons = 1;
       for (int l = 0; l + 1 < kLanes; l++) T.cons &= guess[l + 1] == cr[l].end;
-      if (T.key >= 0) {
+      if (T.key >= 0 && (mn >> 23) == (mx >> 23) && !(mode & 4)) {  // strict_sum_kernel's plain tiles
+        const uint32_t E = mn >> 23;
+        Par acc = par_identity();
+        for (int l = 0; l < kLanes; l++) acc = par_compose(acc, leaf_parity_summary(tt + l * kLeaf, guess[l], cr[l], E, sg_or));
+        T.s = par_expand(acc, E, T.key);
+      } else if (T.key >= 0) {
         Summary acc = summary_identity();
         for (int l = 0; l < kLanes; l++) {
           const float *t = tt + l * kLeaf;
@@ -452,10 +612,38 @@ inline float ss_host_model(const float *terms_in, int64_t n, int64_t stats[8], i
       }
       return;
     }
-    float x = u2f(s);
-    for (int i = 0; i < kTile; i++) x = x + tt[i];
-    s = f2u(x);
-    stats[5] += kLanes;
+    // a tile without a window (strict_sum_kernel's leaf records): every leaf under a window of its own
+    // where it has one, neighbouring leaves of equal windows composed into runs; a run that does not
+    // cover the state, and a leaf without a window, are added term by term
+    uint32_t guess[kLanes];
+    ChainRange cr[kLanes];
+    double P0 = 0.0;
+    for (int64_t q = 0; q < k; q++) P0 += tile_sum[q];
+    tile_guesses(tt, P0, guess, cr);
+    int l = 0;
+    while (l < kLanes) {
+      const int32_t kl = leaf_key(cr[l], guess[l]);
+      int e = l;
+      Summary acc = summary_identity();
+      if (kl >= 0) {
+        while (true) {
+          Summary S;
+          for (int r = 0; r < 4; r++) leaf_class_piece(tt + e * kLeaf, guess[e], kl, r, S.c[r], S.lo[r], S.hi[r]);
+          acc = compose(acc, S);
+          if (e + 1 < kLanes && leaf_key(cr[e + 1], guess[e + 1]) == kl) e++;
+          else break;
+        }
+        if (apply(s, kl, acc)) {
+          l = e + 1;
+          continue;
+        }
+      }
+      float x = u2f(s);
+      for (int i = l * kLeaf; i < (e + 1) * kLeaf; i++) x = x + tt[i];
+      s = f2u(x);
+      stats[5] += e + 1 - l;
+      l = e + 1;
+    }
   };
   int64_t k = 0;
   while (k < ntiles) {

@@ -278,7 +278,7 @@ class IcpSession:
     def strict_stats(self, stream=0):
         """Measurement aid: counters of the parallel strict sums since the last call
         (runs applied, runs failed, tiles recomputed, leaves added serially, tile records failed)."""
-        out = np.zeros(48, np.int64)
+        out = np.zeros(64, np.int64)
         L.check(L.lib().pcgx_debug_icp_strict_stats(self._h, L.ptr(stream) if stream else None, L.ptr(out)))
         return out
 
