@@ -15,6 +15,7 @@
 
 #include "knn_grid.h"
 #include "knn_xwalk.h"
+#include "strict_terms.h"
 
 namespace pcgx {
 
@@ -146,11 +147,21 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     IcpKernelParams kp, float4 *__restrict__ match, uint32_t *__restrict__ first_leaf,
     double *__restrict__ block_partials, uint32_t *__restrict__ match_id,
     const float4 *__restrict__ normals, uint32_t *__restrict__ walk_list, uint32_t *__restrict__ walk_count,
-    int32_t n_grid_rows, const uint32_t *__restrict__ orig_of = nullptr, float4 *__restrict__ match_caller = nullptr) {
+    int32_t n_grid_rows, const uint32_t *__restrict__ orig_of = nullptr, float4 *__restrict__ match_caller = nullptr,
+    StrictWork strict_w = StrictWork(), int32_t tile_sums = 0) {
   static_assert(!(kGrid && kMinDist), "the grid answers exact-mode queries only");
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
+  __shared__ double s_tile_part[kIcpBlock / 64][kStrictRows];
   if (state->done) return;  // uniform
+  // strict sessions (kGrid, no sums here): on its way out the workgroup forms the float64 tile sums the
+  // summary kernel's guesses start from (strict_terms.h) -- the pairs are all in place (icp_grid_kernel)
+  // except those of the few targets this launch still walks, and only guesses depend on the sums
+  auto strict_tile_sums = [&]() {
+    if (!tile_sums) return;  // uniform
+    const TermSrc S = make_term_src(match_caller, nullptr, state, strict_w);
+    for (int64_t tile = blockIdx.x; tile < strict_w.ntiles; tile += gridDim.x) tile_sums_block<kIcpBlock>(S, strict_w, tile, s_tile_part);
+  };
   // grid mode: what this workgroup has to do is known before any of the walk's set-up -- usually
   // nothing but folding its share of icp_grid_kernel's rows
   constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
@@ -159,7 +170,10 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
   if (kGrid && !kSums) {
     slot = block_slot(blockIdx.x, gridDim.x);
     left = walk_count[slot];  // uniform
-    if (left == 0) return;
+    if (left == 0) {
+      strict_tile_sums();
+      return;
+    }
   } else if (kGrid) {
     slot = block_slot(blockIdx.x, gridDim.x);
     left = walk_count[slot];  // uniform
@@ -250,7 +264,11 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
         },
         [&](int64_t j, const float4 &bp, float best_d) { emit(r_begin + walk_list[r_begin + j], bp, best_d); },
         [&](int64_t j, uint32_t leaf) { first_leaf[r_begin + walk_list[r_begin + j]] = kSums ? (leaf | 0x80000000u) : leaf; });
-    if (!kSums) return;
+    if (!kSums) {
+      __syncthreads();
+      strict_tile_sums();
+      return;
+    }
     __threadfence_block();
     __syncthreads();
     reduce_block_range<kPlane, true>(s_stack, tx, ty, tz, nt, chunk_begin, chunk_end, project, m, match, match_id,
@@ -645,6 +663,7 @@ struct pcgx_icp_session {
   uint32_t *d_orig_of = nullptr;      // strict sums: [nt] the caller's index of the target at a position
   float4 *d_match_caller = nullptr;   // strict sums: match[] in the caller's target order
   bool caller_order_fresh = false;    // the last correspondence pass wrote d_match_caller as well
+  bool tile_sums_fresh = false;       // ... and formed the strict sums' float64 tile sums on its way out
   int strict = 0;                // sequential float32 sums: 1 = in parallel (strict.hip), 2 = one wave (icp_strict_sums_kernel)
   bool strict_explicit = false;  // asked for by name (set_strict, PCGX_SUMS_REFERENCE_CHAIN, the environment): a sharded step refuses
                                  // it; the default (sums_mode 0) quietly becomes float64 sums there
@@ -969,6 +988,7 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   // (the same handle's Nearest / Range already do), without hints from earlier iterations
   if (!s->patched && s->base->n_deleted > 0) s->patched = true;
   s->caller_order_fresh = false;
+  s->tile_sums_fresh = false;
   if (s->patched) return enqueue_corr_patched(s, st);
   if (s->strict == 1 && !s->plane && s->nt > 0) {
     // the strict sums run in the caller's target order: the kernels below also leave every pair there
@@ -987,6 +1007,9 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
       }
     }
     s->caller_order_fresh = s->d_match_caller != nullptr;
+    if (!s->strict_buf)
+      PCGX_TRY(strict_create(s->nt, s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, (const uint32_t *)s->d_pos_of,
+                             &s->strict_buf, st));
   }
   TreeView tv = s->base->view();
   tv.tight_levels = tight;
@@ -994,6 +1017,10 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   const size_t lds = walk_lds_bytes(tv, kIcpBlock);
   const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
   const bool grid = grid_enabled(s->base) && !(s->kp.min_dist_sq > 0.0f) && s->nt > 0;
+  // with the grid pass before it the correspondence kernel finds (nearly) every pair in place: its workgroups
+  // form the strict sums' tile sums on their way out (else strict_tilesum_kernel does, after this launch)
+  s->tile_sums_fresh = grid && s->caller_order_fresh && s->strict == 1 && !s->plane;
+  const StrictWork strict_w = s->tile_sums_fresh ? *strict_work(s->strict_buf, s->kp) : StrictWork();
   if (grid) {
     ProfScope prof_grid(PCGX_PROF_ICP_GRID, st);
     const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
@@ -1025,7 +1052,8 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
                        (const float4 *)s->d_normals, s->d_walk_list, s->d_walk_count,                                 \
                        (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock),                                        \
                        (const uint32_t *)(s->caller_order_fresh ? s->d_orig_of : nullptr),                            \
-                       s->caller_order_fresh ? s->d_match_caller : nullptr);                                          \
+                       s->caller_order_fresh ? s->d_match_caller : nullptr, strict_w,                                 \
+                       (int32_t)((GR) && s->tile_sums_fresh ? 1 : 0));                                                \
   else                                                                                                                \
   hipLaunchKernelGGL((icp_corr_kernel<MD, PL, GR>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,     \
                      s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, s->d_match_id,                   \
@@ -1053,10 +1081,10 @@ static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
                              &s->strict_buf, st));
     if (s->caller_order_fresh)  // pairs already in the caller's order: no gather through pos_of
       PCGX_TRY(strict_enqueue(s->strict_buf, (const float4 *)s->d_match_caller, (const uint32_t *)nullptr, s->d_state,
-                              s->d_sums, s->kp, kFuseUpdate, st));
+                              s->d_sums, s->kp, kFuseUpdate, s->tile_sums_fresh, st));
     else
       PCGX_TRY(strict_enqueue(s->strict_buf, (const float4 *)s->d_match, (const uint32_t *)s->d_pos_of, s->d_state,
-                              s->d_sums, s->kp, kFuseUpdate, st));
+                              s->d_sums, s->kp, kFuseUpdate, false, st));
     return PCGX_OK;
   }
   // strict 2: the plain dependent chain, one wave (kept as the on-device cross-check of strict 1)

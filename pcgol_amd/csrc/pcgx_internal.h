@@ -313,11 +313,16 @@ __device__ __forceinline__ void icp_update_step(IcpState *__restrict__ state, co
 
 // strict.hip: the evaluator's sequential float32 sums (evaluator.go:122-145), bit for bit, in parallel
 struct StrictBuffers;
+struct StrictWork;
 pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const float *tz, const uint32_t *pos_of,
                           StrictBuffers **out, hipStream_t st);
 void strict_destroy(StrictBuffers *b);
+// the work descriptor as this iteration's kernels take it (strict_terms.h): the correspondence kernel forms the
+// tile sums on its way out when it is handed one
+const StrictWork *strict_work(StrictBuffers *b, const IcpKernelParams &kp);
+// have_tile_sums: the correspondence kernel formed them (else strict_tilesum_kernel runs first)
 pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
-                           double *sums10, const IcpKernelParams &kp, bool fuse_update, hipStream_t st);
+                           double *sums10, const IcpKernelParams &kp, bool fuse_update, bool have_tile_sums, hipStream_t st);
 pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[64], hipStream_t st);
 }  // namespace pcgx
 

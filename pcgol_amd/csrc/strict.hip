@@ -2,32 +2,31 @@
 // additions over the pairs in target order, pc/registration/icp/evaluator.go:122-145), computed by
 // the whole GPU instead of one dependent chain.  Arithmetic and the proof sketch: strict_sum.h.
 //
-// Per iteration, after the correspondence kernels left match[] (icp.hip):
-//   strict_terms_kernel  one thread per target in the CALLER's order: the nine float32 terms
-//                        (rows of terms[]), float64 tile sums, level-1 bins (atomics), pair count
-//   strict_sum_kernel    one wave per (row, tile): leaf guesses from the float64 prefix (refined once
-//                        inside the tile by the rounding errors the chains make from them), class
-//                        summaries of the 64 leaves, composed -> one 64-byte record per tile
-//   strict_chain_kernel  one workgroup per row: records of equal windows merged into runs
-//                        (segmented wave scan), one wave applies them in order to the exact state;
-//                        a record that does not cover the state -> that tile is recomputed exactly
+// Per iteration, after the correspondence kernels left every pair in the caller's target order
+// (match_caller, icp.hip) -- the nine float32 terms of a pair are formed where they are needed
+// (strict_terms.h), never stored as rows in HBM:
+//   (tile sums)          float64 sums of every tile's terms, per sum: formed by the correspondence kernel's
+//                        workgroups on their way out (strict_terms.h), or by strict_tilesum_kernel
+//   strict_sum_kernel    one workgroup per tile of 2048 targets: the tile's terms into LDS (72 KB), then
+//                        one wave per sum: leaf guesses from the float64 prefix (refined once inside the
+//                        tile by the rounding errors the chains make from them), parity summaries of
+//                        the 64 leaves, composed -> one 64-byte record per (sum, tile); tiles that cross
+//                        a level or have no window are handed on as jobs
+//   strict_job_kernel    one workgroup per job: four class chains per leaf, scans over the leaves ->
+//                        the tile's record and its leaves' records (what the chain kernel needs to
+//                        recompute the tile from a state the record does not cover)
+//   strict_chain_kernel  one workgroup per sum: records of equal windows merged into runs
+//                        (segmented wave scans), one wave applies them in order to the exact state;
+//                        a record that does not cover the state -> a helper wave, which holds that
+//                        tile's leaf records and terms in registers, recomputes the tile exactly
 // Nothing here is approximate: a record is applied only when its interval proves the result.
-#include "pcgx_internal.h"
 #include <stddef.h>
 
-#include "strict_sum.h"
+#include "strict_terms.h"
 
 namespace pcgx {
-using namespace ss;
-
-constexpr int kStrictRows = 9;  // Value, G0..G5, DistRMS, sum of weights (evaluator.go:132-144)
 
 // ---- wave helpers ---------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_allsum_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);  // a + b == b + a bit for bit: every lane ends with the same value
-  return v;
-}
 __device__ __forceinline__ double wave_excl_scan_f64(double v, int lane) {
   double inc = v;
 #pragma unroll
@@ -59,141 +58,6 @@ __device__ __forceinline__ Summary shfl_summary(const Summary &S, int src) {
   return R;
 }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-struct LeafAux {  // per leaf of a tile with a level crossing: compositions of leaves 0..l and l..63
-  Summary pre, suf;
-};
-static_assert(sizeof(LeafAux) == 96, "two summaries");
-
-// per leaf of a tile WITHOUT a window (a sum hovering around zero): the leaf's own window and the
-// composition of the leaves from the head of its run (neighbouring leaves of equal windows) up to it
-struct LeafRec {
-  int32_t key;  // -1: the leaf has no window (its 32 terms are added one by one)
-  int32_t pad[3];
-  Summary run;
-};
-static_assert(sizeof(LeafRec) == 64 && sizeof(LeafRec) <= sizeof(LeafAux), "a leaf record fits a LeafAux");
-
-struct JobDesc {  // a (row, tile) that crosses a level or has no window: strict_sum_kernel -> strict_job_kernel
-  int32_t row, kind, key, cons;
-  uint32_t in, out;
-  int64_t tile;
-  uint32_t g[kLanes];    // the leaves' guesses
-  int32_t lkey[kLanes];  // and the windows they are summarised under
-};
-
-// Slots are handed out by kAuxShards counters a cache line apart (shard = tile % kAuxShards, each with
-// naux / kAuxShards slots): one counter for all was ~100 returning atomics on one address per launch,
-// served one after the other -- the last job of a launch waited 30-40 us for its slot number.
-constexpr int kAuxShards = 64;
-
-struct StrictWork {
-  const float *xyz_caller;      // [nt][3] the targets in the caller's order
-  double *tile_sum;             // [9][ntiles] float64 sums of the tiles' terms
-  uint32_t *tile_pairs;         // [ntiles] matched targets of the tiles
-  TileRec *recs;                // [9][ntiles]
-  LeafAux *aux;                 // [naux][64]: what the chain kernel needs to recompute a tile that owns a slot
-  float4 *aux_terms;            // [naux][512]: that tile's terms (layout of tile_quad)
-  struct JobDesc *jobs;         // [naux]: what strict_job_kernel needs to know about the slot's tile
-  unsigned int *aux_count;      // [kAuxShards] x 32 words: slots handed out this iteration, per shard (zeroed by the chain kernel)
-  unsigned int *done_rows;      // rows of the chain kernel that have finished (ticket of the fused update)
-  unsigned long long *dbg;      // [64] counters (measurement aid)
-  unsigned long long *stamps;   // [ntiles][8] wall-clock stamps of the summary kernel's workgroups (measurement aid)
-  int64_t nt, ntiles;
-  int32_t naux;
-  int32_t nrows;      // 9, or 8 with the default weight: the sum of the weights is then min(pairs, 2^24) exactly
-  int32_t weight_fn;  // evaluator.go:130 (PCGX_WEIGHT_*)
-  float weight_a;
-  int32_t selfcheck;  // debugging: every step of the chain walk is re-derived term by term and compared (dbg[12..15])
-};
-
-// ---- the terms ------------------------------------------------------------------------------------
-// Nothing stores the nine float32 terms of a pair in HBM any more (round 2: 36 MB out of one kernel and
-// into the next per iteration): they are formed where they are needed, from the target in the caller's
-// order (12 B, coalesced) and its pair (16 B; the correspondence kernels leave every pair in the
-// caller's order as well, match_caller; sessions on a patched tree gather through pos_of).
-struct TermSrc {
-  const float4 *match;
-  const uint32_t *pos_of;  // nullptr: match[] is in the caller's order already
-  const float *xyz;        // caller's order
-  int64_t nt;
-  float m[16];
-  bool project;  // icp.go:27-30: the first Evaluate sees the raw target
-  int32_t weight_fn;
-  float weight_a;
-};
-
-__device__ __forceinline__ TermSrc make_term_src(const float4 *match, const uint32_t *pos_of, const IcpState *state,
-                                                 const StrictWork &W) {
-  TermSrc S;
-  S.match = match;
-  S.pos_of = pos_of;
-  S.xyz = W.xyz_caller;
-  S.nt = W.nt;
-#pragma unroll
-  for (int k = 0; k < 16; k++) S.m[k] = state->trans[k];
-  S.project = state->iter > 0;
-  S.weight_fn = W.weight_fn;
-  S.weight_a = W.weight_a;
-  return S;
-}
-
-// evaluator.go:122-145, every term in float32 as the reference forms it.  Unmatched targets and the
-// padding behind nt carry -0.0f: x + (-0.0f) == x for EVERY float x (both zeros included).
-__device__ __forceinline__ bool pair_terms(const TermSrc &S, float x0, float y0, float z0, const float4 &b, float *t /* [9] */) {
-#pragma unroll
-  for (int k = 0; k < kStrictRows; k++) t[k] = -0.0f;
-  if (!(b.w >= 0.0f)) return false;  // correspondence.go:27-29
-  if (S.project) {  // icp.go:62-64
-    float px, py, pz;
-    mat4_transform(S.m, x0, y0, z0, px, py, pz);
-    x0 = px; y0 = py; z0 = pz;
-  }
-  const float x1 = b.x, y1 = b.y, z1 = b.z;
-  const float w = eval_weight_fn(S.weight_fn, S.weight_a, b.w);  // evaluator.go:130
-  t[0] = w * b.w;
-  t[1] = w * (x0 - x1);
-  t[2] = w * (y0 - y1);
-  t[3] = w * (z0 - z1);
-  t[4] = w * (z0 * y1 - y0 * z1);
-  t[5] = w * (x0 * z1 - z0 * x1);
-  t[6] = w * (y0 * x1 - x0 * y1);
-  t[7] = w * norm_sq3(x0, y0, z0);
-  t[8] = w;
-  return true;
-}
-
-// the four consecutive targets i0 .. i0 + 3 (i0 a multiple of 4): pairs and coordinates
-__device__ __forceinline__ void load_quad(const TermSrc &S, int64_t i0, float4 *bp, float *tx, float *ty, float *tz) {
-  if (i0 + 3 < S.nt) {
-    if (S.pos_of) {
-      const uint4 p = *reinterpret_cast<const uint4 *>(S.pos_of + i0);
-      bp[0] = S.match[p.x]; bp[1] = S.match[p.y]; bp[2] = S.match[p.z]; bp[3] = S.match[p.w];
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; c++) bp[c] = S.match[i0 + c];
-    }
-    const float4 *x4 = reinterpret_cast<const float4 *>(S.xyz + 3 * i0);  // 48 B, 16-byte aligned
-    const float4 a = x4[0], b = x4[1], d = x4[2];
-    tx[0] = a.x; ty[0] = a.y; tz[0] = a.z;
-    tx[1] = a.w; ty[1] = b.x; tz[1] = b.y;
-    tx[2] = b.z; ty[2] = b.w; tz[2] = d.x;
-    tx[3] = d.y; ty[3] = d.z; tz[3] = d.w;
-    return;
-  }
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const int64_t i = i0 + c;
-    bp[c] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
-    tx[c] = ty[c] = tz[c] = 0.0f;
-    if (i < S.nt) {
-      bp[c] = S.pos_of ? S.match[S.pos_of[i]] : S.match[i];
-      tx[c] = S.xyz[3 * i];
-      ty[c] = S.xyz[3 * i + 1];
-      tz[c] = S.xyz[3 * i + 2];
-    }
-  }
-}
 
 // A tile's terms of one row, 2048 floats as 512 quads: quad v (terms 4v .. 4v + 3) of leaf l sits at
 // float4 index v * 64 + (l ^ v).  In LDS the 64 lanes of a wave read their leaves' quad v without bank
@@ -248,26 +112,29 @@ __device__ __forceinline__ uint32_t serial_leaves(uint32_t s, const float4 *R, i
 }
 
 // Row `row` of `tile` formed again from the pairs and staged in lds (layout of tile_quad): the chain
-// kernel's way to a tile that owns no slot.  Rare, so small rather than fast: one quad per lane and
-// round, no array in registers (a version with the leaf in 32 registers behind a call put 256 bytes of
-// scratch into the chain kernel).
+// kernel's way to a tile that owns no slot (rare).  One wave: eight rounds of 64 consecutive quads
+// (coalesced loads), two rounds in flight.
 __device__ __forceinline__ void recompute_tile_to_lds(const TermSrc &S, int row, int64_t tile, int lane, float4 *lds) {
-  const int64_t i0 = tile * kTile + (int64_t)lane * kLeaf;
 #pragma unroll 1
-  for (int v = 0; v < kLeaf / 4; v++) {
-    float4 bp[4];
-    float tx[4], ty[4], tz[4];
-    load_quad(S, i0 + 4 * v, bp, tx, ty, tz);
-    float r[4];
+  for (int r = 0; r < kTile / 4 / kLanes; r += 2) {
+    float4 bp[2][4];
+    float tx[2][4], ty[2][4], tz[2][4];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-      float q[kStrictRows];
-      pair_terms(S, tx[c], ty[c], tz[c], bp[c], q);
-      r[c] = q[0];
+    for (int h = 0; h < 2; h++) load_quad(S, tile * kTile + 4 * (int64_t)((r + h) * kLanes + lane), bp[h], tx[h], ty[h], tz[h]);
 #pragma unroll
-      for (int k = 1; k < kStrictRows; k++) r[c] = row == k ? q[k] : r[c];
+    for (int h = 0; h < 2; h++) {
+      float o[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        float q[kStrictRows];
+        pair_terms(S, tx[h][c], ty[h][c], tz[h][c], bp[h][c], q);
+        o[c] = q[0];
+#pragma unroll
+        for (int k = 1; k < kStrictRows; k++) o[c] = row == k ? q[k] : o[c];
+      }
+      const int quad = (r + h) * kLanes + lane;  // quad `quad & 7` of leaf `quad >> 3`
+      lds[tile_quad(quad >> 3, quad & 7)] = make_float4(o[0], o[1], o[2], o[3]);
     }
-    lds[tile_quad(lane, v)] = make_float4(r[0], r[1], r[2], r[3]);
   }
   lds_fence_wave();
 }
@@ -305,9 +172,7 @@ __device__ __forceinline__ double tile_prefix(const double *__restrict__ tile_v,
   return wave_allsum_f64(v);
 }
 
-// ---- tile sums ------------------------------------------------------------------------------------
-// One workgroup per tile of 2048 targets in the caller's order: the float64 sums of the tile's terms,
-// per row (the guesses of strict_sum_kernel start from their prefix).
+// ---- tile sums (strict_terms.h) as a kernel of their own: sessions whose correspondence kernels do not form them
 constexpr int kTileSumBlock = 256;
 __global__ __launch_bounds__(kTileSumBlock) void strict_tilesum_kernel(const float4 *__restrict__ match,
                                                                        const uint32_t *__restrict__ pos_of,
@@ -315,36 +180,7 @@ __global__ __launch_bounds__(kTileSumBlock) void strict_tilesum_kernel(const flo
   __shared__ double s_part[kTileSumBlock / 64][kStrictRows];
   if (state->done) return;
   const TermSrc S = make_term_src(match, pos_of, state, W);
-  const int64_t tile = blockIdx.x;
-  double acc[kStrictRows];
-#pragma unroll
-  for (int k = 0; k < kStrictRows; k++) acc[k] = 0.0;
-  constexpr int kQuads = kTile / 4 / kTileSumBlock;  // 2
-  float4 bp[kQuads][4];
-  float tx[kQuads][4], ty[kQuads][4], tz[kQuads][4];
-#pragma unroll
-  for (int h = 0; h < kQuads; h++)  // consecutive threads, consecutive quads: every load of the tile is issued before the first use
-    load_quad(S, tile * kTile + 4 * (int64_t)(h * kTileSumBlock + threadIdx.x), bp[h], tx[h], ty[h], tz[h]);
-#pragma unroll
-  for (int h = 0; h < kQuads; h++) {
-    float t[4][kStrictRows];
-#pragma unroll
-    for (int c = 0; c < 4; c++) pair_terms(S, tx[h][c], ty[h][c], tz[h][c], bp[h][c], t[c]);
-#pragma unroll
-    for (int k = 0; k < kStrictRows; k++) acc[k] += (((double)t[0][k] + (double)t[1][k]) + (double)t[2][k]) + (double)t[3][k];
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < kStrictRows; k++) {
-    const double v = wave_allsum_f64(acc[k]);
-    if (lane == 0) s_part[wave][k] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < W.nrows) {
-    double v = 0.0;
-    for (int w = 0; w < kTileSumBlock / 64; w++) v += s_part[w][threadIdx.x];
-    W.tile_sum[threadIdx.x * W.ntiles + tile] = v;
-  }
+  tile_sums_block<kTileSumBlock>(S, W, blockIdx.x, s_part);
 }
 
 // the targets in the caller's order, from the session's Morton-ordered SoA copy (once per session)
@@ -366,11 +202,12 @@ __global__ __launch_bounds__(256) void strict_xyz_caller_kernel(const float *__r
 // pass needs the chains' ends only; the chain that is kept, with its extremes, runs once, from the
 // final guesses)
 __device__ __forceinline__ void tile_guesses(const LdsQuads &q, double base, double lsum, double pre, int lane, uint32_t &g,
-                                             ChainRange &cr) {
+                                             ChainRange &cr, double &tile_err) {
   g = f2u((float)(base + pre));
   const float e = u2f(plain_chain_q(q, g));
   const double err = ((double)e - (double)u2f(g)) - lsum;
   const double epre = wave_excl_scan_f64(err, lane);
+  tile_err = __shfl(epre, 63) + __shfl(err, 63);  // what the float32 chain is off the exact sum by, over this tile
   const uint32_t g2 = f2u((float)(base + pre + epre));
   // (guesses a couple of ulps off are as good: the intervals are thousands wide except next to a level)
   const int32_t moved = (int32_t)g2 - (int32_t)g;
@@ -446,7 +283,10 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
       T.in = f2u(0.0f);
       T.out = next;
       T.cons = 1;
-      if (lane == 0) W.recs[row * W.ntiles + tile] = T;
+      if (lane == 0) {
+        W.recs[row * W.ntiles + tile] = T;
+        W.tile_err[(int64_t)row * W.ntiles + tile] = (double)u2f(next) - W.tile_sum[(int64_t)row * W.ntiles + tile];
+      }
       continue;
     }
     double lsum = 0.0;
@@ -458,7 +298,9 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     const double pre = wave_excl_scan_f64(lsum, lane);
     uint32_t g;
     ChainRange cr;
-    tile_guesses(q, P0, lsum, pre, lane, g, cr);
+    double terr;
+    tile_guesses(q, P0, lsum, pre, lane, g, cr, terr);
+    if (lane == 0) W.tile_err[(int64_t)row * W.ntiles + tile] = terr;
     // window of the tile
     const uint32_t mn = wave_all_umin(cr.mn), mx = wave_all_umax(cr.mx);
     const bool one_sign = __ballot(cr.sg_or != cr.sg_and) == 0ull &&
@@ -507,16 +349,9 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
       if (lane == 0) W.recs[row * W.ntiles + tile] = T;
       continue;
     }
-    JobDesc *J = W.jobs + slot;
-    J->g[lane] = g;
-    J->lkey[lane] = key >= 0 ? key : leaf_key(cr, g);
     if (lane == 0) {
+      JobDesc *J = W.jobs + slot;
       J->row = row;
-      J->kind = key >= 0 ? JOB_CROSSING : JOB_NOWINDOW;
-      J->key = key;
-      J->cons = T.cons;
-      J->in = T.in;
-      J->out = T.out;
       J->tile = tile;
     }
     float4 *dst = W.aux_terms + (size_t)slot * (kTile / 4);
@@ -539,6 +374,9 @@ constexpr int kJobBlock = 256;
 __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *__restrict__ state, StrictWork W) {
   __shared__ float4 s_t[kTile / 4];
   __shared__ int32_t s_S[12][kLanes];  // class pieces c[4] | lo[4] | hi[4] per leaf
+  __shared__ uint32_t s_g[kLanes];     // the leaves' guesses
+  __shared__ int32_t s_lk[kLanes];     // and the windows they are summarised under
+  __shared__ int32_t s_hdr[4];         // the tile's window, guess at its start, end of its last guess chain, "the chains join up"
   if (state->done) return;
   const unsigned per_shard = (unsigned)W.naux / kAuxShards;
   const unsigned slot = blockIdx.x, shard = slot / per_shard, k = slot % per_shard;
@@ -547,11 +385,51 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   const JobDesc *J = W.jobs + slot;
   const float4 *src4 = W.aux_terms + (size_t)slot * (kTile / 4);
   for (int i = threadIdx.x; i < kTile / 4; i += kJobBlock) s_t[i] = src4[i];
-  const uint32_t g = J->g[lane];
-  const int32_t lk = J->lkey[lane];
-  const int row = J->row, kind = J->kind;
+  const int row = J->row;
   const int64_t tile = J->tile;
   __syncthreads();
+  // ---- wave 0: the leaves' guesses once more, now from a start state that includes the rounding errors
+  // the float32 chain has made in all tiles before this one (strict_sum_kernel's tile_err, known only
+  // after that launch): where a sum has come back towards zero the float64 prefix alone is off by 10^5
+  // ulps of the small state (the chain's roundings were made at larger magnitudes), and leaf records
+  // made from such guesses cover the true state half of the time; with the errors added the guess is
+  // within a few ulps.  Then the tile's window (or its leaves' own) as strict_sum_kernel chose them.
+  if (part == 0) {
+    const LdsQuads q{s_t, lane};
+    double lsum = 0.0;
+#pragma unroll
+    for (int v = 0; v < kLeaf / 4; v++) {
+      const float4 a = q(v);
+      lsum += (double)a.x; lsum += (double)a.y; lsum += (double)a.z; lsum += (double)a.w;
+    }
+    const double pre = wave_excl_scan_f64(lsum, lane);
+    const double base = tile_prefix(W.tile_sum, W.ntiles, row, tile, lane) + tile_prefix(W.tile_err, W.ntiles, row, tile, lane);
+    uint32_t g;
+    ChainRange cr;
+    double terr;
+    tile_guesses(q, base, lsum, pre, lane, g, cr, terr);
+    const uint32_t mn = wave_all_umin(cr.mn), mx = wave_all_umax(cr.mx);
+    const bool one_sign = __ballot(cr.sg_or != cr.sg_and) == 0ull &&
+                          (__ballot(cr.sg_or != 0u) == 0ull || __ballot(cr.sg_or == 0u) == 0ull);
+    const uint32_t g_first = (uint32_t)rfl((int)g);
+    const int32_t key = one_sign ? choose_window(mn, mx, g_first >> 31, g_first & 0x7fffffffu) : -1;
+    const uint32_t g_next = (uint32_t)__shfl_down((int)g, 1);
+    const bool cons = __ballot(lane < 63 && g_next != cr.end) == 0ull;
+    s_g[lane] = g;
+    s_lk[lane] = key >= 0 ? key : leaf_key(cr, g);
+    const uint32_t out_last = (uint32_t)__shfl((int)cr.end, 63);
+    if (lane == 0) {
+      s_hdr[0] = key;
+      s_hdr[1] = (int32_t)g_first;
+      s_hdr[2] = (int32_t)out_last;
+      s_hdr[3] = cons ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  const uint32_t g = s_g[lane];
+  const int32_t lk = s_lk[lane];
+  const int32_t tkey = s_hdr[0];
+  const int kind = tkey >= 0 ? JOB_CROSSING : JOB_NOWINDOW;
   {
     int32_t c, lo, hi;
     leaf_class_piece_q(LdsQuads{s_t, lane}, g, lk, part, c, lo, hi);
@@ -570,10 +448,10 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   }
   TileRec R;
   R.s = summary_identity();
-  R.key = J->key;
-  R.in = J->in;
-  R.out = J->out;
-  R.cons = J->cons | (int32_t)((slot + 1u) << 8);
+  R.key = tkey;
+  R.in = (uint32_t)s_hdr[1];
+  R.out = (uint32_t)s_hdr[2];
+  R.cons = s_hdr[3] | (int32_t)((slot + 1u) << 8);
   if (kind == JOB_CROSSING) {
     if (part == 0) {
       Summary P = S;
@@ -1099,7 +977,7 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   W.nrows = kStrictRows;
   W.selfcheck = (getenv("PCGX_STRICT_SELFCHECK") ? 1 : 0) | (getenv("PCGX_STRICT_TRACE") ? 2 : 0);
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t sz_tile = up((size_t)kStrictRows * W.ntiles * sizeof(double));
+  const size_t sz_tile = up((size_t)kStrictRows * W.ntiles * sizeof(double));  // (twice: sums and errors)
   const size_t sz_pairs = up((size_t)W.ntiles * sizeof(uint32_t));
   const size_t sz_rec = up((size_t)kStrictRows * W.ntiles * sizeof(TileRec));
   // slots for the tiles that cross a level or have no window (6 KB of leaf records + 8 KB of terms each):
@@ -1112,7 +990,7 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   const size_t sz_xyz = up((size_t)(nt ? nt : 1) * 12 + 64);
   const size_t sz_stamps = up((size_t)W.ntiles * 16 * sizeof(unsigned long long));
   const size_t sz_ctr = 256 + (size_t)kAuxShards * 128;
-  const size_t total = sz_tile + sz_pairs + sz_rec + sz_aux + sz_auxt + sz_jobs + sz_xyz + sz_ctr + 512 + sz_stamps;
+  const size_t total = 2 * sz_tile + sz_pairs + sz_rec + sz_aux + sz_auxt + sz_jobs + sz_xyz + sz_ctr + 512 + sz_stamps;
   hipError_t e = dev_cache_alloc(&b->block, total);
   if (e != hipSuccess) {
     delete b;
@@ -1120,6 +998,7 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   }
   uint8_t *p = (uint8_t *)b->block;
   W.tile_sum = (double *)p; p += sz_tile;
+  W.tile_err = (double *)p; p += sz_tile;
   W.tile_pairs = (uint32_t *)p; p += sz_pairs;
   W.recs = (TileRec *)p; p += sz_rec;
   W.aux = (LeafAux *)p; p += sz_aux;
@@ -1153,14 +1032,18 @@ void strict_destroy(StrictBuffers *b) {
   delete b;
 }
 
-pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
-                           double *sums10, const IcpKernelParams &kp, bool fuse_update, hipStream_t st) {
+const StrictWork *strict_work(StrictBuffers *b, const IcpKernelParams &kp) {
   b->w.weight_fn = kp.weight_fn;
   b->w.weight_a = kp.weight_a;
   // (the row count may only change between iterations: the chain kernel's ticket counts to it)
   b->w.nrows = kp.weight_fn == PCGX_WEIGHT_ONE ? kStrictRows - 1 : kStrictRows;
-  const StrictWork &W = b->w;
-  {
+  return &b->w;
+}
+
+pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
+                           double *sums10, const IcpKernelParams &kp, bool fuse_update, bool have_tile_sums, hipStream_t st) {
+  const StrictWork &W = *strict_work(b, kp);
+  if (!have_tile_sums) {
     ProfScope prof(PCGX_PROF_STRICT_TERMS, st);
     hipLaunchKernelGGL(strict_tilesum_kernel, dim3((unsigned)W.ntiles), dim3(kTileSumBlock), 0, st, match, pos_of,
                        (const IcpState *)state, W);

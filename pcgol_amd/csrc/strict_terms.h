@@ -1,0 +1,193 @@
+// strict_terms.h -- what the kernels of the strict sums share with the correspondence kernels (icp.hip):
+// the work descriptor, the nine float32 terms of a pair formed exactly as evaluator.go:122-145 forms
+// them, and the float64 tile sums the summary kernel's guesses start from.  Device code only.
+#pragma once
+#include "pcgx_internal.h"
+#include "strict_sum.h"
+
+namespace pcgx {
+using namespace ss;
+
+constexpr int kStrictRows = 9;  // Value, G0..G5, DistRMS, sum of weights (evaluator.go:132-144)
+
+
+__device__ __forceinline__ double wave_allsum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);  // a + b == b + a bit for bit: every lane ends with the same value
+  return v;
+}
+
+struct LeafAux {  // per leaf of a tile with a level crossing: compositions of leaves 0..l and l..63
+  Summary pre, suf;
+};
+static_assert(sizeof(LeafAux) == 96, "two summaries");
+
+// per leaf of a tile WITHOUT a window (a sum hovering around zero): the leaf's own window and the
+// composition of the leaves from the head of its run (neighbouring leaves of equal windows) up to it
+struct LeafRec {
+  int32_t key;  // -1: the leaf has no window (its 32 terms are added one by one)
+  int32_t pad[3];
+  Summary run;
+};
+static_assert(sizeof(LeafRec) == 64 && sizeof(LeafRec) <= sizeof(LeafAux), "a leaf record fits a LeafAux");
+
+struct JobDesc {  // a (row, tile) that crosses a level or has no window: strict_sum_kernel -> strict_job_kernel
+  int64_t tile;
+  int32_t row, pad;
+};
+
+// Slots are handed out by kAuxShards counters a cache line apart (shard = tile % kAuxShards, each with
+// naux / kAuxShards slots): one counter for all was ~100 returning atomics on one address per launch,
+// served one after the other -- the last job of a launch waited 30-40 us for its slot number.
+constexpr int kAuxShards = 64;
+
+struct StrictWork {
+  const float *xyz_caller;      // [nt][3] the targets in the caller's order
+  double *tile_sum;             // [9][ntiles] float64 sums of the tiles' terms
+  double *tile_err;             // [9][ntiles] rounding error the float32 chain makes inside the tile (from its guess chains)
+  uint32_t *tile_pairs;         // [ntiles] matched targets of the tiles
+  TileRec *recs;                // [9][ntiles]
+  LeafAux *aux;                 // [naux][64]: what the chain kernel needs to recompute a tile that owns a slot
+  float4 *aux_terms;            // [naux][512]: that tile's terms (layout of tile_quad)
+  struct JobDesc *jobs;         // [naux]: what strict_job_kernel needs to know about the slot's tile
+  unsigned int *aux_count;      // [kAuxShards] x 32 words: slots handed out this iteration, per shard (zeroed by the chain kernel)
+  unsigned int *done_rows;      // rows of the chain kernel that have finished (ticket of the fused update)
+  unsigned long long *dbg;      // [64] counters (measurement aid)
+  unsigned long long *stamps;   // [ntiles][8] wall-clock stamps of the summary kernel's workgroups (measurement aid)
+  int64_t nt, ntiles;
+  int32_t naux;
+  int32_t nrows;      // 9, or 8 with the default weight: the sum of the weights is then min(pairs, 2^24) exactly
+  int32_t weight_fn;  // evaluator.go:130 (PCGX_WEIGHT_*)
+  float weight_a;
+  int32_t selfcheck;  // debugging: every step of the chain walk is re-derived term by term and compared (dbg[12..15])
+};
+
+// ---- the terms ------------------------------------------------------------------------------------
+// Nothing stores the nine float32 terms of a pair in HBM any more (round 2: 36 MB out of one kernel and
+// into the next per iteration): they are formed where they are needed, from the target in the caller's
+// order (12 B, coalesced) and its pair (16 B; the correspondence kernels leave every pair in the
+// caller's order as well, match_caller; sessions on a patched tree gather through pos_of).
+struct TermSrc {
+  const float4 *match;
+  const uint32_t *pos_of;  // nullptr: match[] is in the caller's order already
+  const float *xyz;        // caller's order
+  int64_t nt;
+  float m[16];
+  bool project;  // icp.go:27-30: the first Evaluate sees the raw target
+  int32_t weight_fn;
+  float weight_a;
+};
+
+__device__ __forceinline__ TermSrc make_term_src(const float4 *match, const uint32_t *pos_of, const IcpState *state,
+                                                 const StrictWork &W) {
+  TermSrc S;
+  S.match = match;
+  S.pos_of = pos_of;
+  S.xyz = W.xyz_caller;
+  S.nt = W.nt;
+#pragma unroll
+  for (int k = 0; k < 16; k++) S.m[k] = state->trans[k];
+  S.project = state->iter > 0;
+  S.weight_fn = W.weight_fn;
+  S.weight_a = W.weight_a;
+  return S;
+}
+
+// evaluator.go:122-145, every term in float32 as the reference forms it.  Unmatched targets and the
+// padding behind nt carry -0.0f: x + (-0.0f) == x for EVERY float x (both zeros included).
+__device__ __forceinline__ bool pair_terms(const TermSrc &S, float x0, float y0, float z0, const float4 &b, float *t /* [9] */) {
+#pragma unroll
+  for (int k = 0; k < kStrictRows; k++) t[k] = -0.0f;
+  if (!(b.w >= 0.0f)) return false;  // correspondence.go:27-29
+  if (S.project) {  // icp.go:62-64
+    float px, py, pz;
+    mat4_transform(S.m, x0, y0, z0, px, py, pz);
+    x0 = px; y0 = py; z0 = pz;
+  }
+  const float x1 = b.x, y1 = b.y, z1 = b.z;
+  const float w = eval_weight_fn(S.weight_fn, S.weight_a, b.w);  // evaluator.go:130
+  t[0] = w * b.w;
+  t[1] = w * (x0 - x1);
+  t[2] = w * (y0 - y1);
+  t[3] = w * (z0 - z1);
+  t[4] = w * (z0 * y1 - y0 * z1);
+  t[5] = w * (x0 * z1 - z0 * x1);
+  t[6] = w * (y0 * x1 - x0 * y1);
+  t[7] = w * norm_sq3(x0, y0, z0);
+  t[8] = w;
+  return true;
+}
+
+// the four consecutive targets i0 .. i0 + 3 (i0 a multiple of 4): pairs and coordinates
+__device__ __forceinline__ void load_quad(const TermSrc &S, int64_t i0, float4 *bp, float *tx, float *ty, float *tz) {
+  if (i0 + 3 < S.nt) {
+    if (S.pos_of) {
+      const uint4 p = *reinterpret_cast<const uint4 *>(S.pos_of + i0);
+      bp[0] = S.match[p.x]; bp[1] = S.match[p.y]; bp[2] = S.match[p.z]; bp[3] = S.match[p.w];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) bp[c] = S.match[i0 + c];
+    }
+    const float4 *x4 = reinterpret_cast<const float4 *>(S.xyz + 3 * i0);  // 48 B, 16-byte aligned
+    const float4 a = x4[0], b = x4[1], d = x4[2];
+    tx[0] = a.x; ty[0] = a.y; tz[0] = a.z;
+    tx[1] = a.w; ty[1] = b.x; tz[1] = b.y;
+    tx[2] = b.z; ty[2] = b.w; tz[2] = d.x;
+    tx[3] = d.y; ty[3] = d.z; tz[3] = d.w;
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int64_t i = i0 + c;
+    bp[c] = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+    tx[c] = ty[c] = tz[c] = 0.0f;
+    if (i < S.nt) {
+      bp[c] = S.pos_of ? S.match[S.pos_of[i]] : S.match[i];
+      tx[c] = S.xyz[3 * i];
+      ty[c] = S.xyz[3 * i + 1];
+      tz[c] = S.xyz[3 * i + 2];
+    }
+  }
+}
+
+// ---- tile sums ------------------------------------------------------------------------------------
+// The float64 sums of the nine rows' terms over tile `tile` (2048 targets in the caller's order): what
+// strict_sum_kernel's guesses start from (their prefix over the tiles).  Only guesses depend on them.
+// A workgroup of kThreads (256 or 512) threads, consecutive threads consecutive quads; s_part: LDS,
+// [kThreads / 64][kStrictRows] doubles.
+template <int kThreads>
+__device__ __forceinline__ void tile_sums_block(const TermSrc &S, const StrictWork &W, int64_t tile, double (*s_part)[kStrictRows]) {
+  constexpr int kQuads = kTile / 4 / kThreads;
+  static_assert(kQuads >= 1 && kQuads * kThreads * 4 == kTile, "the block covers the tile");
+  double acc[kStrictRows];
+#pragma unroll
+  for (int k = 0; k < kStrictRows; k++) acc[k] = 0.0;
+  float4 bp[kQuads][4];
+  float tx[kQuads][4], ty[kQuads][4], tz[kQuads][4];
+#pragma unroll
+  for (int h = 0; h < kQuads; h++)  // every load of the tile is issued before the first use
+    load_quad(S, tile * kTile + 4 * (int64_t)(h * kThreads + threadIdx.x), bp[h], tx[h], ty[h], tz[h]);
+#pragma unroll
+  for (int h = 0; h < kQuads; h++) {
+    float t[4][kStrictRows];
+#pragma unroll
+    for (int c = 0; c < 4; c++) pair_terms(S, tx[h][c], ty[h][c], tz[h][c], bp[h][c], t[c]);
+#pragma unroll
+    for (int k = 0; k < kStrictRows; k++) acc[k] += (((double)t[0][k] + (double)t[1][k]) + (double)t[2][k]) + (double)t[3][k];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kStrictRows; k++) {
+    const double v = wave_allsum_f64(acc[k]);
+    if (lane == 0) s_part[wave][k] = v;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < W.nrows) {
+    double v = 0.0;
+    for (int w = 0; w < kThreads / 64; w++) v += s_part[w][threadIdx.x];
+    W.tile_sum[threadIdx.x * W.ntiles + tile] = v;
+  }
+  __syncthreads();
+}
+
+}  // namespace pcgx

@@ -130,3 +130,26 @@ def test_plane_sharded_rccl_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_plane_c4_full_size():
+    """BASELINE.json's fourth config as it is worded: ICP point-to-plane, 1M source vs 1M target, 20
+    iterations (the extension: no reference to compare with).  The 30 sums of iteration 0 against the CPU
+    oracle's float64 restatement; the pose after 20 Gauss-Newton steps against the synthetic ground truth;
+    two runs bit-identical (fixed-order float64 reduction)."""
+    c = synth.c4_plane(1_000_000)
+    t = kdtree.New(c["base"])
+    ev = icp.PointToPlaneEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), c["normals"], MinPairs=6)
+    sums = ev.Sums(t, c["target"])
+    osums = O.plane_sums(O.KDTree(c["base"]), c["normals"], c["target"], c["max_dist"])
+    assert sums[29] == osums[29] and sums[28] == osums[28] and sums[29] > 0.99 * len(c["target"])
+    scale = np.maximum(np.abs(osums), 1e-30)
+    assert np.all(np.abs(sums - osums) <= 1e-11 * np.maximum(scale, osums[29]))
+    reg = icp.PointToPlaneICP(ev, icp.GaussNewtonUpdaterFactory(Threshold=c["threshold"], MaxIteration=c["max_iteration"]))
+    trans, stat = reg.Fit(t, c["target"])
+    trans2, stat2 = reg.Fit(t, c["target"])
+    assert stat.NumIteration == stat2.NumIteration == 20
+    assert np.array_equal(trans, trans2) and np.array_equal(stat.Evaluated.Hessian, stat2.Evaluated.Hessian)
+    inv = np.linalg.inv(synth.icp_pose().astype(np.float64).reshape(4, 4).T).T.reshape(-1)
+    assert np.max(np.abs(trans.astype(np.float64) - inv)) <= 2e-6
+    assert float(stat.Evaluated.Value) < 1e-9

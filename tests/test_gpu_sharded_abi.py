@@ -84,9 +84,10 @@ def test_two_ranks_on_one_gpu_through_the_abi_exchange():
     for r in res[1:]:
         assert np.array_equal(r[2], res[0][2]) and np.array_equal(r[4], res[0][4])
     assert np.array_equal(res[0][2], res[0][4]) and res[0][3] == res[0][5] == 20
-    # and it is the single-GPU Fit on the whole target (float64 sums in another order: ~1e-7)
+    # and it is the single-GPU Fit on the whole target in the same sums mode (float64 sums in another order: ~1e-7)
     reg = icp.PointToPointICPGradient(
-        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=c["min_pairs"]),
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=c["min_pairs"],
+                                  SumsMode=icp.SumsF64Tree),
         icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=c["threshold"], MaxIteration=c["max_iteration"]))
     trans1, stat1 = reg.Fit(kdtree.New(c["base"]), c["target"])
     assert np.max(np.abs(trans1 - res[0][2])) <= 1e-6

@@ -187,7 +187,13 @@ def test_unmarshal_dev_matches_host(golden):
     import torch
     from pcgol_amd import voxelgrid
     L.check(L.lib().pcgx_init(0))
-    bufs = [bytes.fromhex(c["pcd_hex"]) for c in golden("ref_pcd.json")["unmarshal"]["cases"] if "error" not in c]
+    cases = [c for c in golden("ref_pcd.json")["unmarshal"]["cases"] if "error" not in c]
+    # the device bytes against the reference's own expected points and labels (pc/io_test.go:27-110), not only
+    # against the library's host path
+    for c in cases:
+        hd, n, stride, t = pc.UnmarshalDev(bytes.fromhex(c["pcd_hex"]))
+        _check_points(pc.PointCloud(hd, n, t[: n * stride].cpu().numpy()), c["expected"])
+    bufs = [bytes.fromhex(c["pcd_hex"]) for c in cases]
     big, expect = make_compressed_pcd(200_000, 1)
     bufs += [big, pc.Marshal(pc.Unmarshal(big))]
     for buf in bufs:
