@@ -89,10 +89,12 @@ enum {
   PCGX_PROF_SORT_SCATTER = 3, /* rs_scatter_kernel (radix sort passes) */
   PCGX_PROF_ICP_GRID = 4,   /* icp_grid_kernel (re-projection + certified nearest + sums) */
   PCGX_PROF_KNN_GRID = 5,   /* grid_nearest_kernel */
-  PCGX_PROF_STRICT_TERMS = 6, /* strict_terms_kernel (strict sums: terms in the caller's order) */
-  PCGX_PROF_STRICT_SUM = 7,   /* strict_sum_kernel (class summaries, one record per tile) */
+  PCGX_PROF_STRICT_TERMS = 6, /* strict_tilesum_kernel (sessions whose correspondence kernel does not form the tile sums) */
+  PCGX_PROF_STRICT_SUM = 7,   /* strict_sum_kernel (terms into LDS, parity summaries, one record per (sum, tile)) */
   PCGX_PROF_STRICT_CHAIN = 8, /* strict_chain_kernel (runs applied in order + pose update) */
-  PCGX_PROF_KINDS = 9
+  PCGX_PROF_STRICT_JOB = 9,   /* strict_job_kernel (tiles that cross a level / have no window) */
+  PCGX_PROF_ICP_LEFTOVER = 10, /* icp_corr_kernel behind the grid pass (leftover walk; strict: + tile sums) */
+  PCGX_PROF_KINDS = 11
 };
 /* on: 0 = off, 1 = every launch, n > 1 = every n-th launch of each kind (a pair of events around a
  * 30 us kernel costs several us of stream time: sampling keeps the timed run close to the untimed one). */

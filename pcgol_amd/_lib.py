@@ -30,7 +30,7 @@ PCGX_PCD_MAX_FIELDS = 64
 
 PCGX_KNN_PRESORT = 1
 PROF_ICP_WALK, PROF_KNN_WALK, PROF_VOXEL_ALL, PROF_SORT_SCATTER, PROF_ICP_GRID, PROF_KNN_GRID = range(6)
-PROF_STRICT_TERMS, PROF_STRICT_SUM, PROF_STRICT_CHAIN = 6, 7, 8
+PROF_STRICT_TERMS, PROF_STRICT_SUM, PROF_STRICT_CHAIN, PROF_STRICT_JOB, PROF_ICP_LEFTOVER = 6, 7, 8, 9, 10
 
 
 def prof_enable(on=True):

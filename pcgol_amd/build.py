@@ -30,6 +30,17 @@ def flags():
         os.environ.get("PCGX_EXTRA_CFLAGS", "").split()  # experiments only (e.g. -DPCGX_WALK_TOP_LEVELS=6)
 
 
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources: profiles/*_pmc.json records the build its counters were
+    collected on, bench.py says whether that is the build it is timing."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in sorted(SOURCES + [x for x in HEADERS if not x.startswith("..")]):
+        with open(os.path.join(CSRC, s), "rb") as f:
+            h.update(s.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def needs_build():
     if not os.path.exists(SO):
         return True

@@ -1043,7 +1043,7 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   }
   // timed (pcgx_prof_enable) when it is the kernel that does the work: with the grid pass before it
   // it walks next to nothing, and a second pair of events per step costs more than it
-  ProfScope prof(grid ? -1 : PCGX_PROF_ICP_WALK, st);
+  ProfScope prof(grid ? PCGX_PROF_ICP_LEFTOVER : PCGX_PROF_ICP_WALK, st);
 #define PCGX_LAUNCH_CORR(MD, PL, GR)                                                                                  \
   do {                                                                                                                \
   if (s->strict && !PL)                                                                                               \

@@ -1052,6 +1052,9 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
     ProfScope prof(PCGX_PROF_STRICT_SUM, st);
     hipLaunchKernelGGL(strict_sum_kernel, dim3((unsigned)W.ntiles), dim3(kSumBlock), 0, st, match, pos_of,
                        (const IcpState *)state, W);
+  }
+  {
+    ProfScope prof(PCGX_PROF_STRICT_JOB, st);
     hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
   }
   {

@@ -107,7 +107,7 @@ def main():
     pmc = read_pmc(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"))
     summary = {k: {c: {"mean_per_dispatch": a[0] / max(a[1], 1), "dispatches": a[1]} for c, a in cs.items()}
                for k, cs in pmc.items()}
-    for k in summary:
+    for k in list(summary):
         gather = any(gk in k for gk in GATHER_KERNELS)
         summary[k]["fetch_scale"] = 1.0 if gather else fetch_scale_stream
         summary[k]["fetch_add_bytes"] = 0.0
@@ -126,6 +126,10 @@ def main():
         vox["WRITE_SIZE"]["mean_per_dispatch"] += times * summary[k]["WRITE_SIZE"]["mean_per_dispatch"]
     if ok:
         summary["voxel_pipeline (one C3 call, sum over its kernels, fetch already scaled)"] = vox
+    # the build the counters were collected on (bench.py compares it with the build it times)
+    sys.path.insert(0, os.path.dirname(here))
+    from pcgol_amd import build
+    summary["_build"] = {"source_hash": build.source_hash(), "tag": tag}
     with open(os.path.join(here, "%s_pmc.json" % tag), "w") as f:
         json.dump(summary, f, indent=1, sort_keys=True)
     print("wrote", tag, "kernels with PMC:", len(summary), "fetch scale streaming %.3f" % fetch_scale_stream)
