@@ -3,8 +3,9 @@ replicated 64M-point base tree and its ~8M-point target tile (synth.c5_tile: oct
 
 Checkers at this size: brute force on the device (torch elementwise float32 ops in the reference's
 expression order, (dx*dx + dy*dy) + dz*dz, no fusion) and the product's own tree walk in the
-reference's visit order (PCGX_GRID=0) against its certified grid pass.  The CPU oracle's tree is
-not built here: its O(N log^2 N) build takes ~5 minutes at 64M points."""
+reference's visit order (PCGX_GRID=0) against its certified grid pass; and the CPU oracle itself
+through committed digests (tests/golden/c5_digest.json, written by tests/golden/make_c5_digest.py:
+the oracle's O(N log^2 N) tree build takes ~9 minutes at 64M points, so it runs once, not per test run)."""
 import numpy as np
 import pytest
 
@@ -76,6 +77,43 @@ def test_c5_pairs_grid_pass_equals_reference_order_walk(c5, monkeypatch):
     ids_w, dsq_w = tree.NearestBatch(q, 0.5)
     assert np.array_equal(ids_g, ids_w) and np.array_equal(dsq_g, dsq_w)
     assert (ids_g >= 0).mean() > 0.99
+
+
+def test_c5_against_the_oracle_digest(c5):
+    """What the CPU oracle computed on this configuration (tests/golden/c5_digest.json): Nearest of the
+    first 100k targets of the tile against the 64M-point tree (ids and DistSq bits), iteration 0's pairs of
+    the first 1M targets, and its evaluator sums -- the float64 tree's ten sums to rounding of the
+    summation order, the reference's sequential float32 sums (the default mode) bit for bit."""
+    import json
+    import os
+    base, tile, tree = c5
+    with open(os.path.join(os.path.dirname(__file__), "golden", "c5_digest.json")) as f:
+        g = json.load(f)
+    assert g["n_base"] == len(base) and g["n_tile"] == len(tile)
+    q = np.ascontiguousarray(tile[: g["nearest"]["n"]])
+    ids, dsq = tree.NearestBatch(q, g["max_dist"])
+    assert int((ids >= 0).sum()) == g["nearest"]["found"] and int(ids.sum()) == g["nearest"]["ids_sum"]
+    assert int(np.bitwise_xor.reduce(ids)) == g["nearest"]["ids_xor"]
+    assert int(np.bitwise_xor.reduce(dsq.view(np.uint32))) == g["nearest"]["dsq_bits_xor"]
+    assert [int(v) for v in ids[:64]] == g["nearest"]["first_ids"]
+    t1m = np.ascontiguousarray(tile[: g["pairs"]["n_target"]])
+    b, t, d = icp.NearestPointCorresponder(MaxDist=g["max_dist"]).PairsArrays(tree, t1m)
+    assert len(b) == g["pairs"]["n_pairs"] and int(np.bitwise_xor.reduce(b)) == g["pairs"]["base_ids_xor"]
+    assert int(t.sum()) == g["pairs"]["target_ids_sum"]
+    assert int(np.bitwise_xor.reduce(d.view(np.uint32))) == g["pairs"]["dsq_bits_xor"]
+    # the sums of iteration 0 over those pairs
+    s64 = icp.IcpSession(tree, t1m, g["max_dist"], 6, SumsMode=icp.SumsF64Tree)
+    s64.partials()
+    got = s64.read_sums()
+    s64.close()
+    want = np.array(g["sums"]["f64_tree_raw10"])
+    assert got[9] == want[9] == g["pairs"]["n_pairs"]
+    scale = np.maximum(np.abs(want), want[9] * 1e-3)
+    assert np.all(np.abs(got - want) <= 1e-11 * scale), (got, want)
+    ev = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=g["max_dist"]), MinPairs=6).Evaluate(tree, t1m)
+    assert int(np.float32(ev.Value).view(np.uint32)) == g["sums"]["reference_value_bits"]
+    assert [int(v) for v in ev.Gradient.view(np.uint32)] == g["sums"]["reference_gradient_bits"]
+    assert int(np.float32(ev.DistRMS).view(np.uint32)) == g["sums"]["reference_dist_rms_bits"]
 
 
 def test_c5_partial_sums_reproducible_over_a_fit(c5):
