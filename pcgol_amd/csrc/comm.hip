@@ -36,6 +36,10 @@ Rccl &rccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
+    if (getenv("PCGX_RCCL_DISABLE")) {  // tests: a host without RCCL (every pcgx_comm_unique_id / _init fails)
+      r.err = "librccl.so not found: disabled by PCGX_RCCL_DISABLE";
+      return;
+    }
     // a library the process already holds first (RTLD_NOLOAD), then the default search path
     const char *names[] = {"librccl.so", "librccl.so.1"};
     for (const char *n : names)

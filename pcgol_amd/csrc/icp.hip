@@ -1182,10 +1182,38 @@ extern "C" pcgx_status pcgx_icp_fit_sharded(const pcgx_kdtree *base, const float
   PCGX_API_LOCK();
   if (!base || !params || !trans16 || !c) return fail(PCGX_E_INVALID, "pcgx_icp_fit_sharded: NULL argument");
   pcgx_icp_session *s = nullptr;
-  PCGX_TRY(pcgx_icp_session_create(base, tile, nt, 0, params, nullptr, &s));
-  pcgx_status rc = PCGX_OK;
+  pcgx_status rc = pcgx_icp_session_create(base, tile, nt, 0, params, nullptr, &s);
+  int32_t rank = 0, world = 1;
+  PCGX_TRY(pcgx_comm_rank(c, &rank, &world));
+  if (world > 1) {
+    // A rank whose session could not be made (out of memory, a bad argument) must not leave the others
+    // waiting in the first all-reduce: every rank reaches ONE exchange of an error flag first, and all of
+    // them give up together if any has failed.
+    double *d_flag = nullptr;
+    hipError_t e = dev_cache_alloc((void **)&d_flag, sizeof(double));
+    if (e != hipSuccess) {
+      if (s) pcgx_icp_session_free(s);
+      return fail(PCGX_E_OOM, "pcgx_icp_fit_sharded: %s", hipGetErrorString(e));
+    }
+    const double mine = rc == PCGX_OK ? 0.0 : 1.0;
+    double all = 1.0;
+    pcgx_status rx = PCGX_OK;
+    if (hipMemcpyAsync(d_flag, &mine, sizeof mine, hipMemcpyHostToDevice, ctx().stream) != hipSuccess) rx = PCGX_E_HIP;
+    if (rx == PCGX_OK) rx = pcgx_comm_allreduce_f64(c, d_flag, 1, nullptr);
+    if (rx == PCGX_OK && (hipMemcpyAsync(&all, d_flag, sizeof all, hipMemcpyDeviceToHost, ctx().stream) != hipSuccess ||
+                          hipStreamSynchronize(ctx().stream) != hipSuccess))
+      rx = PCGX_E_HIP;
+    dev_cache_free(d_flag);
+    if (rc == PCGX_OK && rx != PCGX_OK) rc = fail(rx, "pcgx_icp_fit_sharded: the ranks' error exchange failed");
+    if (rc == PCGX_OK && all != 0.0) rc = fail(PCGX_E_RCCL, "pcgx_icp_fit_sharded: another rank could not set up its session");
+  }
+  if (rc != PCGX_OK) {
+    if (s) pcgx_icp_session_free(s);
+    return rc;
+  }
   // every rank enqueues MaxIteration steps: the loop state is the same on all of them (same sums),
-  // so they stop together, and a step after `done` is a no-op on the device
+  // so they stop together, and a step after `done` is a no-op on the device (the all-reduce of a finished
+  // session still runs: pcgx_icp_session_read_sums is undefined after the last iteration of a sharded Fit)
   for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) rc = pcgx_icp_session_step_sharded(s, c, nullptr);
   if (rc == PCGX_OK) rc = pcgx_icp_session_result(s, nullptr, trans16, stat, nullptr);
   pcgx_icp_session_free(s);

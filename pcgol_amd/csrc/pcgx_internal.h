@@ -251,8 +251,10 @@ size_t radix_sort_workspace_bytes(int64_t n);
 // takes a position for its value: a 4n-byte write and read less)
 pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, int key_bits,
                              void *workspace, int *result, hipStream_t st, bool iota_vals = false);
+// sticky_first: a NaN coordinate of the FIRST point stays (min, max := Vec3At(0), minmax.go:13-23); false for a
+// later slice of a cloud whose min / max are folded over ranks
 pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
-                          hipStream_t st);
+                          hipStream_t st, bool sticky_first = true);
 // perm[pos] = index of the point visited at position pos (coarse Morton order over the box
 // [lo, hi]).  Uses the arena.
 pcgx_status morton_order(const float *d_q, int64_t n, const float lo[3], const float hi[3], int32_t *d_perm,

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void minmax_partial_packed_kernel(const float4
 // out6 = {min xyz, max xyz}; one block folds the per-block partials.
 __global__ __launch_bounds__(256) void minmax_final_kernel(const MinMaxAcc *__restrict__ partials, int nparts,
                                                            const uint8_t *__restrict__ data, int32_t off,
-                                                           float *__restrict__ out6) {
+                                                           float *__restrict__ out6, int sticky_first) {
   __shared__ MinMaxAcc s_acc[4];
   const float qnan = __uint_as_float(0x7fc00000u);
   MinMaxAcc a;
@@ -436,15 +436,17 @@ __global__ __launch_bounds__(256) void minmax_final_kernel(const MinMaxAcc *__re
     }
   for (int k = 0; k < 3; k++) {
     // min, max := Vec3At(0): a NaN there is never replaced (minmax.go:13-23)
+    // (sticky_first 0: `data` is a later slice of a cloud split over ranks -- its first point is no more
+    // special than any other, a NaN there is skipped like everywhere else)
     const float p0 = ld_f32_any(data + off + 4 * k);
-    if (p0 != p0) { a.mn[k] = p0; a.mx[k] = p0; }
+    if (sticky_first && p0 != p0) { a.mn[k] = p0; a.mx[k] = p0; }
     out6[k] = a.mn[k];
     out6[3 + k] = a.mx[k];
   }
 }
 
 pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
-                          hipStream_t st) {
+                          hipStream_t st, bool sticky_first) {
   if (n <= 0) return fail(PCGX_E_NO_POINT, "no point");
   int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
   if (blocks > 1024) blocks = 1024;
@@ -458,7 +460,7 @@ pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t
     hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t *)d_data, n,
                        stride, off, partials);
   hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, st, partials, blocks,
-                     (const uint8_t *)d_data, off, d_out6);
+                     (const uint8_t *)d_data, off, d_out6, sticky_first ? 1 : 0);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }

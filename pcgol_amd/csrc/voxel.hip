@@ -444,7 +444,7 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
     const int per = 7;
     std::vector<double> slots((size_t)per * world, 0.0);
     if (s1 > s0) {
-      PCGX_TRY(launch_minmax((const uint8_t *)d_data + s0 * stride, s1 - s0, stride, xyz_off, d_mm6, st));
+      PCGX_TRY(launch_minmax((const uint8_t *)d_data + s0 * stride, s1 - s0, stride, xyz_off, d_mm6, st, s0 == 0));
       PCGX_HIP_TRY(hipMemcpyAsync(mm6, d_mm6, sizeof mm6, hipMemcpyDeviceToHost, st));
       PCGX_HIP_TRY(hipStreamSynchronize(st));
       slots[(size_t)per * rank] = 1.0;

@@ -69,3 +69,17 @@ def test_bench_falls_back_when_rccl_refuses():
     d = _run(cmd, env)
     assert d["n_gpus"] == 2 and "RCCL set-up failed" in d["config"]["exchange"]
     assert d["final_value"] == d["final_value"] and d["final_value"] < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bench_falls_back_when_rank_0_cannot_make_an_rccl_id():
+    """No RCCL at all (PCGX_RCCL_DISABLE: pcgx_comm_unique_id fails on rank 0 before anybody has an id): the ranks
+    agree on that BEFORE the others wait for the id, and take the host callback over gloo."""
+    env = dict(os.environ, PCGX_BENCH_REHEARSE="2", PCGX_RCCL_DISABLE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4", "--points", "100000"]
+    d = _run(cmd, env)
+    assert d["n_gpus"] == 2 and "RCCL set-up failed" in d["config"]["exchange"]
+    assert d["final_value"] == d["final_value"] and d["final_value"] < 1e-3 and d["value_same_mode_n1"] > 0

@@ -382,11 +382,14 @@ def test_strict_sums_on_structured_terms():
         s.close()
 
 
-def test_strict_sums_that_hover_around_zero():
+def test_strict_sums_that_hover_around_zero(monkeypatch):
     """Targets = base points + zero-mean noise, no transform: all six gradient sums wander around zero
     from the first pair to the last -- sign changes and three binades inside one tile, so many tiles
-    have no window at all and go through their quarter records or are added up term by term.  Still
-    the oracle's Go-semantics sums, bit for bit."""
+    have no window at all and go through their leaves' records (runs of leaves under equal windows,
+    the rest added up term by term: the helper waves of the chain kernel).  Still the oracle's
+    Go-semantics sums, bit for bit; with PCGX_STRICT_SELFCHECK every step of the walk is re-derived term
+    by term inside the kernel as well (the device-only paths the host model does not mirror)."""
+    monkeypatch.setenv("PCGX_STRICT_SELFCHECK", "1")
     n = 200_000
     rng = np.random.Generator(np.random.PCG64(77))
     base = synth.uniform_cloud(n, 10.0 * (n / 1e6) ** (1 / 3), 2)
@@ -402,7 +405,10 @@ def test_strict_sums_that_hover_around_zero():
     for k in range(3):
         s.step()
         tr, st, conv = s.result()
-        resolved += int(s.strict_stats()[2])
+        sst = s.strict_stats()
+        resolved += int(sst[2])
+        assert not sst[12:16].any() and sst[6] == 0 and sst[7] == 0, (k, sst[:24])
+        assert sst[16] > 0 or k > 0   # tiles without a window were recomputed from their leaf records
         oe = O.icp_evaluate(o, tt, 0.5, 6, sums_mode=0)
         assert st.Evaluated.Value == oe["value"] and st.Evaluated.DistRMS == oe["dist_rms"], k
         assert np.array_equal(st.Evaluated.Gradient, oe["gradient"]), k
