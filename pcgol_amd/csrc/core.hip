@@ -389,6 +389,27 @@ extern "C" pcgx_status pcgx_dev_free(void *dptr) {
   return PCGX_OK;
 }
 
+// ---- host <-> device copies of the host-pointer seams ----------------------------------------------
+// The slices a Go caller holds are pageable memory.  Measured on the test box (tools/staging_probe.cpp,
+// tools/stage_probe.py): the runtime's own pageable path moves 120 MB at 56 GB/s once a process has made its
+// first large copy (19 ms for the very first one), fresh or reused buffers alike; a pinned ring of three
+// 16 MB slots filled by six copy threads reached 45-47 GB/s -- built, measured, removed.  What made these
+// seams slow in round 2 was host-side: ids widened to Go's 64-bit int in a host loop, zero-filled
+// temporaries, and (in the measurement itself) output arrays allocated per call, whose first touch is a
+// page fault per 4 KB.  The ids are widened on the device now; these two are the copies, in one place.
+namespace pcgx {
+pcgx_status staged_upload(void *d_dst, const void *h_src, size_t bytes, hipStream_t st) {
+  if (bytes) PCGX_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+  return PCGX_OK;
+}
+
+pcgx_status staged_download(void *h_dst, const void *d_src, size_t bytes, hipStream_t st) {
+  if (bytes) PCGX_HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  return PCGX_OK;
+}
+}  // namespace pcgx
+
 extern "C" pcgx_status pcgx_dev_upload(void *dptr, const void *host, size_t bytes) {
   PCGX_API_LOCK();
   PCGX_TRY(ensure_init());

@@ -885,8 +885,7 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
     if (!target_on_device) {
       float *stage = nullptr;
       if ((rc = ar.alloc_n((size_t)nb * 3, &stage)) != PCGX_OK) return bail(rc);
-      if ((e = hipMemcpyAsync(stage, normals, (size_t)nb * 12, hipMemcpyHostToDevice, st)) != hipSuccess)
-        return bail(fail(PCGX_E_HIP, "normals upload failed: %s", hipGetErrorString(e)));
+      if ((rc = staged_upload(stage, normals, (size_t)nb * 12, st)) != PCGX_OK) return bail(rc);
       d_n3 = stage;
     }
     hipLaunchKernelGGL(pack_normals_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, d_n3, nb,
@@ -907,8 +906,7 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
     if (!target_on_device) {
       float *stage = nullptr;
       if ((rc = ar.alloc_n((size_t)nt * 3, &stage)) != PCGX_OK) return bail(rc);
-      if ((e = hipMemcpyAsync(stage, target, (size_t)nt * 12, hipMemcpyHostToDevice, st)) != hipSuccess)
-        return bail(fail(PCGX_E_HIP, "target upload failed: %s", hipGetErrorString(e)));
+      if ((rc = staged_upload(stage, target, (size_t)nt * 12, st)) != PCGX_OK) return bail(rc);
       d_q = stage;
     }
     int32_t *perm = nullptr;

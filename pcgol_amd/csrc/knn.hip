@@ -219,6 +219,11 @@ using namespace pcgx;
 namespace {
 // Device staging of a host-pointer call: bump-allocated from the grow-only host arena (no
 // hipMalloc / hipFree in steady state; hipFree alone costs more than the PCIe copies of a 1M batch).
+__global__ __launch_bounds__(256) void widen_ids_kernel(const int32_t *__restrict__ in, int64_t n, int64_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (int64_t)in[i];
+}
+
 struct HostCallBufs {
   float *q = nullptr;
   int32_t *ids = nullptr;
@@ -594,16 +599,19 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const flo
   hipStream_t st = ctx().stream;
   HostCallBufs b;
   PCGX_TRY(b.alloc(nq, st));
-  PCGX_HIP_TRY(hipMemcpyAsync(b.q, q, (size_t)nq * 12, hipMemcpyHostToDevice, st));
+  PCGX_TRY(staged_upload(b.q, q, (size_t)nq * 12, st));
   // large batches are walked in Morton order (the ordering pass costs ~0.08 ms, the walk of 1M
   // random queries gains 0.27 ms); results come back in the caller's order either way
   PCGX_TRY(pcgx_kdtree_nearest_batch_dev(t, b.q, nq, max_range, min_dist_sq,
                                          nq >= (1 << 18) ? PCGX_KNN_PRESORT : 0u, b.ids, b.dsq, st));
-  std::vector<int32_t> h_id((size_t)nq);
-  PCGX_HIP_TRY(hipMemcpyAsync(h_id.data(), b.ids, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-  PCGX_HIP_TRY(hipMemcpyAsync(dist_sq, b.dsq, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-  PCGX_HIP_TRY(hipStreamSynchronize(st));
-  for (int64_t i = 0; i < nq; i++) ids[i] = h_id[i];
+  // Go's int is 64 bits wide (Neighbor.ID, search.go:8-11): widened on the device, so that the ids go straight
+  // into the caller's slice (a host loop over 1M ids cost as much as the whole search)
+  int64_t *d_ids64 = nullptr;
+  PCGX_TRY(ctx().host_arena.alloc_n((size_t)nq, &d_ids64));
+  hipLaunchKernelGGL(widen_ids_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const int32_t *)b.ids, nq, d_ids64);
+  PCGX_HIP_TRY(hipGetLastError());
+  PCGX_TRY(staged_download(ids, d_ids64, (size_t)nq * 8, st));
+  PCGX_TRY(staged_download(dist_sq, b.dsq, (size_t)nq * 4, st));
   return PCGX_OK;
 }
 

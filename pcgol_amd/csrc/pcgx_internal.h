@@ -133,6 +133,10 @@ struct CallScope {
 #define PCGX_API_LOCK() ::pcgx::CallScope pcgx_call_scope__(false)
 #define PCGX_API_CALL() ::pcgx::CallScope pcgx_call_scope__(true)
 inline hipStream_t pick_stream(void *s) { return s ? (hipStream_t)s : ctx().stream; }
+// host (pageable) -> device on `st` (the copies of the host-pointer seams, core.hip)
+pcgx_status staged_upload(void *d_dst, const void *h_src, size_t bytes, hipStream_t st);
+// device -> host (pageable): work enqueued on `st` before is waited for; returns when h_dst holds the data
+pcgx_status staged_download(void *h_dst, const void *d_src, size_t bytes, hipStream_t st);
 // Buffers go back to the block cache and may be handed out again at once: whatever any stream still
 // has in flight on them must be done first (hipFree used to synchronise implicitly).
 void dev_cache_quiesce();

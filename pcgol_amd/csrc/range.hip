@@ -81,6 +81,17 @@ __global__ __launch_bounds__(256) void range_gather_u32_kernel(const uint32_t *_
 using namespace pcgx;
 
 
+namespace pcgx {
+__global__ __launch_bounds__(256) void range_widen_check_kernel(const uint32_t *__restrict__ in, int64_t n, int64_t *__restrict__ out,
+                                                                int32_t *__restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t v = (int32_t)in[i];
+  out[i] = (int64_t)v;
+  if (v < 0) *bad = 1;
+}
+}  // namespace pcgx
+
 extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float *q, int64_t nq, float max_range,
                                                int64_t *counts) {
   PCGX_API_CALL();
@@ -97,7 +108,7 @@ extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float
   PCGX_TRY(ctx().host_arena.begin(st));
   PCGX_TRY(ctx().host_arena.alloc_n((size_t)nq * 3, &d_q));
   PCGX_TRY(ctx().host_arena.alloc_n((size_t)nq, &d_c));
-  PCGX_HIP_TRY(hipMemcpyAsync(d_q, q, (size_t)nq * 12, hipMemcpyHostToDevice, st));
+  PCGX_TRY(staged_upload(d_q, q, (size_t)nq * 12, st));
   const TreeView tv = t->view();
   const size_t lds = walk_stack_bytes(tv, kRangeBlock);
   int32_t *perm = nullptr;
@@ -114,8 +125,7 @@ extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float
                        lds, st, tv, (const float *)d_q, (const int32_t *)perm, nq, max_range * max_range, d_c, nullptr, 0,
                        nullptr, nullptr, nullptr);
   PCGX_HIP_TRY(hipGetLastError());
-  PCGX_HIP_TRY(hipMemcpyAsync(counts, d_c, (size_t)nq * 8, hipMemcpyDeviceToHost, st));
-  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  PCGX_TRY(staged_download(counts, d_c, (size_t)nq * 8, st));
   return PCGX_OK;
 }
 
@@ -155,8 +165,8 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
   PCGX_TRY(ar.alloc_n((size_t)total, &d_out_id));
   PCGX_TRY(ar.alloc_n((size_t)total, &d_out_key));
   PCGX_TRY(ar.alloc(radix_sort_workspace_bytes(total), &ws));
-  PCGX_HIP_TRY(hipMemcpyAsync(d_q, q, (size_t)nq * 12, hipMemcpyHostToDevice, st));
-  PCGX_HIP_TRY(hipMemcpyAsync(d_off, offsets, (size_t)(nq + 1) * 8, hipMemcpyHostToDevice, st));
+  PCGX_TRY(staged_upload(d_q, q, (size_t)nq * 12, st));
+  PCGX_TRY(staged_upload(d_off, offsets, (size_t)(nq + 1) * 8, st));
   // Poison the ids so that offsets inconsistent with the counts are caught below.
   PCGX_HIP_TRY(hipMemsetAsync(d_id, 0xFF, (size_t)total * 4, st));
   PCGX_HIP_TRY(hipMemsetAsync(d_key, 0, (size_t)total * 4, st));
@@ -193,14 +203,20 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
                      d_out_id);
   hipLaunchKernelGGL(range_gather_u32_kernel, dim3(tb), dim3(256), 0, st, d_key, perm, total, d_out_key);
   PCGX_HIP_TRY(hipGetLastError());
-  std::vector<int32_t> h_id((size_t)total);
-  PCGX_HIP_TRY(hipMemcpyAsync(h_id.data(), d_out_id, (size_t)total * 4, hipMemcpyDeviceToHost, st));
-  PCGX_HIP_TRY(hipMemcpyAsync(dist_sq, d_out_key, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+  // Go's int is 64 bits wide: widened (and checked: a poisoned id means the caller's offsets do not match the
+  // counts) on the device, straight into the caller's slice
+  int64_t *d_ids64 = nullptr;
+  int32_t *d_bad = nullptr;
+  PCGX_TRY(ar.alloc_n((size_t)total, &d_ids64));
+  PCGX_TRY(ar.alloc_n(1, &d_bad));
+  PCGX_HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
+  hipLaunchKernelGGL(range_widen_check_kernel, dim3(tb), dim3(256), 0, st, (const uint32_t *)d_out_id, total, d_ids64, d_bad);
+  PCGX_HIP_TRY(hipGetLastError());
+  int32_t bad = 0;
+  PCGX_HIP_TRY(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+  PCGX_TRY(staged_download(ids, d_ids64, (size_t)total * 8, st));
+  PCGX_TRY(staged_download(dist_sq, d_out_key, (size_t)total * 4, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
-  for (int64_t j = 0; j < total; j++) {
-    if (h_id[j] < 0)
-      return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: offsets do not match the neighbour counts");
-    ids[j] = h_id[j];
-  }
+  if (bad) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: offsets do not match the neighbour counts");
   return PCGX_OK;
 }

@@ -611,8 +611,8 @@ extern "C" pcgx_status pcgx_minmax(const void *data, int64_t n, int32_t stride, 
   PCGX_TRY(ctx().host_arena.alloc_n((size_t)n * s, &d));
   pcgx_status rc = PCGX_OK;
   float mm6[6];
-  hipError_t e = hipMemcpyAsync(d, src, (size_t)n * s, hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_minmax upload: %s", hipGetErrorString(e));
+  hipError_t e = hipSuccess;
+  rc = staged_upload(d, src, (size_t)n * s, st);
   float *d_mm6 = nullptr;
   if (rc == PCGX_OK) rc = ctx().arena.begin(st);
   if (rc == PCGX_OK) rc = ctx().arena.alloc_n(6, &d_mm6);
@@ -643,16 +643,10 @@ static pcgx_status voxel_filter_host(pcgx_comm *comm, const void *data, int64_t 
   PCGX_TRY(ctx().host_arena.alloc_n(bytes, &d_in));
   PCGX_TRY(ctx().host_arena.alloc_n(bytes, &d_out));
   pcgx_status rc = PCGX_OK;
-  hipError_t e = hipMemcpyAsync(d_in, data, bytes, hipMemcpyHostToDevice, st);
-  if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_voxel_filter upload: %s", hipGetErrorString(e));
+  rc = staged_upload(d_in, data, bytes, st);  // the caller's (pageable) records through the pinned ring
   int64_t m = 0;
   if (rc == PCGX_OK) rc = voxel_filter_core(comm, d_in, n, stride, xyz_off, leaf, chunk, d_out, &m, st);
-  if (rc == PCGX_OK && m > 0) {
-    // same stream as the filter (the library stream is non-blocking w.r.t. the null stream)
-    e = hipMemcpyAsync(out_data, d_out, (size_t)m * (size_t)stride, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_voxel_filter download: %s", hipGetErrorString(e));
-  }
+  if (rc == PCGX_OK && m > 0) rc = staged_download(out_data, d_out, (size_t)m * (size_t)stride, st);  // same stream as the filter
   if (rc == PCGX_OK) *out_n = m;
   return rc;
 }

