@@ -806,6 +806,31 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         const LeafAux A = W.aux[(size_t)slot * kLanes + lane];
         float t[kLeaf];
         load_leaf_quads(W.aux_terms + (size_t)slot * (kTile / 4), lane, t);
+        // A tile without a window (a sum hovering around zero) costs ~8 us however its leaves are summarised: a
+        // dozen runs to apply and a dozen leaves to add term by term, one after the other.  But its start state
+        // is known to a few ulps (the job kernel's guess includes the chain's rounding errors so far), and this
+        // wave has nothing to do until the walker arrives: it carries out all 2048 additions NOW, from 64
+        // candidate start states at once (lane c: the guess + (c - 32) ulps; every lane the same chain of terms,
+        // broadcast with v_readlane).  If the walker's state is one of the candidates the tile is a look-up.
+        uint32_t cand_in = 0u, cand_out = 0u;
+        bool have_cand = false;
+        if (cur_kind == JOB_NOWINDOW && !(W.selfcheck & 4)) {  // uniform
+          const uint32_t g0 = s_rec[cur_tile].in;
+          if ((g0 & 0x7fffffffu) > 64u && (g0 & 0x7f800000u) != 0x7f800000u) {  // (not next to zero, finite)
+            cand_in = g0 + (uint32_t)(lane - 32);   // same sign: 32 floats below, 31 above in magnitude
+            float x = u2f(cand_in);
+            have_cand = true;
+            for (int l = 0; l < kLanes; l++) {  // uniform
+#pragma unroll
+              for (int j = 0; j < kLeaf; j++) x = x + u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(t[j]), l));
+              if ((l & 7) == 7 && lds_get(&s_mail[wave].req) == k + 1) {  // the walker is here already: no time for this
+                have_cand = false;
+                break;
+              }
+            }
+            cand_out = f2u(x);
+          }
+        }
         bool serve = false;
         while (true) {
           if (lds_get(&s_mail[wave].req) == k + 1) {
@@ -822,8 +847,16 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         if (serve) {
           const long long t_begin = wall_clock64();
           const uint32_t s_in = (uint32_t)rfl((int)__hip_atomic_load(&s_mail[wave].s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-          int serial, tried, applied;
-          const uint32_t s_out = resolve_staged<true>(s_in, cur_kind, cur_key, A, lane, nullptr, t, serial, tried, applied);
+          int serial = 0, tried = 0, applied = 0;
+          uint32_t s_out;
+          const unsigned long long hit = have_cand ? __ballot(cand_in == s_in) : 0ull;
+          if (hit) {
+            s_out = (uint32_t)__builtin_amdgcn_readlane((int)cand_out, __builtin_ctzll(hit));
+            if (lane == 0) atomicAdd(&W.dbg[25], 1ull);
+          } else {
+            s_out = resolve_staged<true>(s_in, cur_kind, cur_key, A, lane, nullptr, t, serial, tried, applied);
+          }
+          if (lane == 0 && cur_kind == JOB_NOWINDOW) atomicAdd(&W.dbg[24], 1ull);
           if (lane == 0) {
             __hip_atomic_store(&s_mail[wave].s_out, s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             lds_put(&s_mail[wave].ack, k + 1);
@@ -975,7 +1008,8 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   W.nt = nt;
   W.ntiles = nt > 0 ? (nt + kTile - 1) / kTile : 1;
   W.nrows = kStrictRows;
-  W.selfcheck = (getenv("PCGX_STRICT_SELFCHECK") ? 1 : 0) | (getenv("PCGX_STRICT_TRACE") ? 2 : 0);
+  W.selfcheck = (getenv("PCGX_STRICT_SELFCHECK") ? 1 : 0) | (getenv("PCGX_STRICT_TRACE") ? 2 : 0) |
+                (getenv("PCGX_STRICT_NOSPEC") ? 4 : 0);  // (4: no candidate chains in the chain kernel's helpers: measurements)
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t sz_tile = up((size_t)kStrictRows * W.ntiles * sizeof(double));  // (twice: sums and errors)
   const size_t sz_pairs = up((size_t)W.ntiles * sizeof(uint32_t));

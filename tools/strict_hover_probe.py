@@ -42,6 +42,6 @@ for mode in (1, 0):
         for k in range(20):
             s.step()
             st = s.strict_stats()
-            print("  iteration %2d: tiles recomputed %3d, leaves term by term %4d, slowest sum's walk %.0f us | no window: %d tiles, %d runs tried, %d applied, %d leaves serial, %.1f us each | crossing: %d tiles, %d leaves serial, %.1f us each | no slot %d" % (
-                k, st[2], st[3], st[46] / 100.0, st[16], st[17], st[18], st[22], st[19] / 100.0 / max(st[16], 1), st[20], st[23], st[21] / 100.0 / max(st[20], 1), st[5]))
+            print("  iteration %2d: tiles recomputed %3d, leaves term by term %4d, slowest sum's walk %.0f us | no window: %d tiles, %d runs tried, %d applied, %d leaves serial, %.1f us each (candidate hits %d of %d) | crossing: %d tiles, %d leaves serial, %.1f us each | no slot %d" % (
+                k, st[2], st[3], st[46] / 100.0, st[16], st[17], st[18], st[22], st[19] / 100.0 / max(st[16], 1), st[25], st[24], st[20], st[23], st[21] / 100.0 / max(st[20], 1), st[5]))
     s.close()

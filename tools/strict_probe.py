@@ -30,8 +30,8 @@ for k in range(c["max_iteration"]):
     bad += not ok
     print("iter %2d %s runs %d runfail %d resolved %d (no aux %d) serial leaves %d recfail %d | us/row: phaseA %.1f walk %.1f (resolve aux %.1f serial %.1f)" % (
         k, "OK " if ok else "MISMATCH", st[0], st[1], st[2], st[5], st[3], st[4], st[8] / 900.0, st[9] / 900.0, st[10] / 900.0, st[11] / 900.0), "slowest row walk %.1f us" % (st[46] / 100.0), "selfcheck bad: run %d prefix %d tile %d suffix %d; scan != serial composition %d, other result %d" % (tuple(st[12:16]) + (st[6], st[7])))
-    print("      no window: %d tiles, %d runs tried, %d applied, %d leaves serial, %.1f us each | crossing: %d tiles, %d leaves serial, %.1f us each" % (
-        st[16], st[17], st[18], st[22], st[19] / 100.0 / max(st[16], 1), st[20], st[23], st[21] / 100.0 / max(st[20], 1)))
+    print("      no window: %d tiles, %d runs tried, %d applied, %d leaves serial, %.1f us each (candidate hits %d of %d) | crossing: %d tiles, %d leaves serial, %.1f us each" % (
+        st[16], st[17], st[18], st[22], st[19] / 100.0 / max(st[16], 1), st[25], st[24], st[20], st[23], st[21] / 100.0 / max(st[20], 1)))
     for q in range(0):
         d = st[16 + 16 * q: 32 + 16 * q]
         if d[0] or d[1]:
