@@ -17,6 +17,7 @@ GATHER_KERNELS = ("icp_grid_kernel", "grid_nearest_kernel", "seg_reduce_kernel",
                   "nearest_kernel", "range_kernel")
 # coalesced bytes the gather kernels read per launch at the bench's sizes (1M targets / queries, 10M voxel points)
 STREAMED = {"icp_grid_kernel<false": (12 + 16 * 19 / 20) * 1e6,          # target xyz + previous pair (19 of 20 iterations)
+            "icp_corr_kernel<false, false, true, false>": 28e6,           # strict sessions: the tile sums stream the caller-order pairs + targets
             "icp_grid_kernel<true": (12 + 16 * 19 / 20 + 4) * 1e6,       # + matched id
             "grid_nearest_kernel": (12 + 4) * 1e6,                        # query + its position in the batch
             "seg_reduce_kernel": 8 * 10e6}                                # sorted key + sorted index
