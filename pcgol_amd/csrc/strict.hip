@@ -1018,6 +1018,10 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   // a quarter of all tiles, far more than ever seen (C4: ~2 %; a sum hovering around zero over the whole
   // row: ~15 %); a tile that finds none left is recomputed from the pairs by the chain kernel
   W.naux = (int32_t)(kAuxShards * ((kStrictRows * W.ntiles / 4 + kAuxShards - 1) / kAuxShards + 4));
+  if (const char *e = getenv("PCGX_STRICT_SLOTS_PER_SHARD")) {  // tests: run out of slots (tiles then take the chain kernel's
+    const int per = atoi(e);                                    // recompute-from-the-pairs path)
+    if (per >= 0 && per * kAuxShards < W.naux) W.naux = per * kAuxShards;
+  }
   const size_t sz_aux = up((size_t)W.naux * kLanes * sizeof(LeafAux));
   const size_t sz_auxt = up((size_t)W.naux * kTile * sizeof(float));
   const size_t sz_jobs = up((size_t)W.naux * sizeof(JobDesc));
@@ -1089,7 +1093,8 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_JOB, st);
-    hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
+    if (W.naux > 0)
+      hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);

@@ -419,6 +419,59 @@ def test_strict_sums_that_hover_around_zero(monkeypatch):
     assert resolved >= 20  # the case does what it is for: many tiles recomputed from the exact state
 
 
+@pytest.mark.parametrize("slots", ["0", "1"])
+def test_strict_sums_when_the_job_slots_run_out(slots, monkeypatch):
+    """Tiles that cross a level or have no window normally get a slot (leaf records + terms for the chain kernel's
+    helpers).  With none / one per shard most of them find no slot: their records say so and the chain kernel forms
+    their terms again from the pairs and adds all 2048 one after the other.  Same bits as the oracle, every step
+    re-derived inside the kernel (PCGX_STRICT_SELFCHECK)."""
+    monkeypatch.setenv("PCGX_STRICT_SLOTS_PER_SHARD", slots)
+    monkeypatch.setenv("PCGX_STRICT_SELFCHECK", "1")
+    n = 150_000
+    rng = np.random.Generator(np.random.PCG64(78))
+    base = synth.uniform_cloud(n, 10.0 * (n / 1e6) ** (1 / 3), 2)
+    noise = ((rng.integers(0, 1 << 16, size=(n, 3)).astype(np.float32) / f32(1 << 16)) - f32(0.5)) * f32(0.02)
+    target = np.ascontiguousarray((base[rng.permutation(n)] + noise).astype(np.float32))
+    t, o = kdtree.New(base), O.KDTree(base)
+    s = icp.IcpSession(t, target, 0.5, 6, np.full(6, 0.3, np.float32), np.full(6, -1.0, np.float32), 2)
+    no_slot = 0
+    trans = O.translate(0, 0, 0)
+    it = 0
+    tt = target.copy()
+    for k in range(2):
+        s.step()
+        tr, st, conv = s.result()
+        sst = s.strict_stats()
+        no_slot += int(sst[5])
+        assert not sst[12:16].any() and sst[6] == 0 and sst[7] == 0, (k, sst[:24])
+        oe = O.icp_evaluate(o, tt, 0.5, 6, sums_mode=0)
+        assert st.Evaluated.Value == oe["value"] and np.array_equal(st.Evaluated.Gradient, oe["gradient"]), k
+        trans, oconv, it = O.icp_update(trans, oe["gradient"], it, np.full(6, 0.3, np.float32), np.full(6, -1.0, np.float32), 2)
+        assert np.array_equal(tr, trans), k
+        tt = synth.transform_points(trans, target)
+    s.close()
+    assert no_slot > 0   # the path was taken
+
+
+@pytest.mark.parametrize("n", [1, 7, 2047, 2048, 2049, 4100])
+def test_default_sums_on_small_and_ragged_targets(n):
+    """Targets of fewer pairs than a tile, exactly a tile, one more: the padding behind the last pair carries -0.0f
+    (x + (-0.0f) == x for every x), the default Evaluate / Fit return the oracle's bits."""
+    base = synth.uniform_cloud(5000, 2.0, 31)
+    rng = np.random.default_rng(n)
+    target = (base[rng.choice(len(base), n, replace=n > len(base))] + f32(0.003)).astype(np.float32)
+    t, o = kdtree.New(base), O.KDTree(base)
+    ev = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=0.5), MinPairs=1).Evaluate(t, target)
+    oe = O.icp_evaluate(o, target, 0.5, 1, sums_mode=0)
+    assert ev.NumPairs == oe["npairs"] and ev.Value == oe["value"] and ev.DistRMS == oe["dist_rms"]
+    assert np.array_equal(ev.Gradient, oe["gradient"])
+    reg = icp.PointToPointICPGradient(icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=0.5), MinPairs=1),
+                                      icp.GradientDescentUpdaterFactory(MaxIteration=5))
+    tr, st = reg.Fit(t, target)
+    of = O.icp_fit(o, target, 0.5, 1, None, None, 5)
+    assert st.NumIteration == of["num_iteration"] and np.array_equal(tr, of["trans"])
+
+
 @pytest.mark.parametrize("wf", [icp.WeightConstant(0.25), icp.WeightInverse(0.01), icp.WeightHuber(0.0009),
                                 icp.WeightTukey(0.004)], ids=["constant", "inverse", "huber", "tukey"])
 def test_builtin_weight_fns_match_the_oracle(wf):
