@@ -59,6 +59,11 @@ __device__ __forceinline__ Summary shfl_summary(const Summary &S, int src) {
 }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Wall-clock reads for the debug counters' tick columns (tools/strict_probe.py) and the PCGX_STRICT_TRACE stamps.
+// Off unless asked for (PCGX_STRICT_CLOCKS / PCGX_STRICT_TRACE): an s_memrealtime is a round trip of its own,
+// and the chain kernel's walker would make two per chunk and two per tile it has resolved.
+__device__ __forceinline__ long long stat_clock(const StrictWork &W) { return (W.selfcheck & 10) ? (long long)wall_clock64() : 0ll; }
+
 // A tile's terms of one row, 2048 floats as 512 quads: quad v (terms 4v .. 4v + 3) of leaf l sits at
 // float4 index v * 64 + (l ^ v).  In LDS the 64 lanes of a wave read their leaves' quad v without bank
 // conflicts, and the 8 threads that write the quads of one leaf hit different banks (the xor); in HBM
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tile = blockIdx.x;
   const int NR = W.nrows;
-  const long long t_0 = wall_clock64();
+  const long long t_0 = stat_clock(W);
   // the float64 prefix of this wave's row (strict_tilesum_kernel's sums): its loads fly while phase 1 runs
   double P0 = wave < NR ? tile_prefix(W.tile_sum, W.ntiles, wave, tile, lane) : 0.0;
   // ---- phase 1: the tile's terms, every thread one quad
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     for (int w = 0; w < kSumWaves; w++) np += s_np[w];
     W.tile_pairs[tile] = (uint32_t)np;
   }
-  const long long t_1 = wall_clock64();
+  const long long t_1 = stat_clock(W);
   // ---- phase 2: every wave its row (one pass unless a weight function adds the ninth row)
   for (int row = wave; row < NR; row += kSumWaves) {
     if (row >= kSumWaves) P0 = tile_prefix(W.tile_sum, W.ntiles, row, tile, lane);
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
   if (threadIdx.x == 0 && (W.selfcheck & 2)) {  // measurement aid (PCGX_STRICT_TRACE), plain stores only
     W.stamps[tile * 16 + 0] = (unsigned long long)t_0;
     W.stamps[tile * 16 + 1] = (unsigned long long)t_1;
-    W.stamps[tile * 16 + 5] = (unsigned long long)wall_clock64();
+    W.stamps[tile * 16 + 5] = (unsigned long long)stat_clock(W);
   }
 }
 
@@ -438,6 +443,39 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     s_S[8 + part][lane] = hi;
   }
   __syncthreads();
+  if (kind == JOB_NOWINDOW && part >= 1) {
+    // ---- waves 1..3 of a tile without a window: the tile's 2048 additions carried out from kCand candidate
+    // start states (strict_terms.h, cand_offset), every lane two of them (packed float32 adds), the terms
+    // broadcast out of LDS.  Such a tile costs the chain kernel 6-8 us however its leaves are summarised (a
+    // dozen leaf runs to apply, a dozen leaves to add term by term); here the additions cost the same few
+    // microseconds, but next to every other job of the launch instead of on the walk.  If the walker's state
+    // is one of the candidates the tile is a look-up.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const uint32_t g0 = (uint32_t)s_hdr[1];
+    const uint32_t mag = g0 & 0x7fffffffu;
+    const int i0 = (part - 1) * 2 * kLanes + lane;  // candidates i0 and i0 + 64
+    uint32_t out0 = 0x7fc00000u, out1 = 0x7fc00000u;  // "no table"
+    if (mag > kCandReach && mag < 0x7f800000u - kCandReach) {  // uniform
+      v2f x = {u2f(g0 + (uint32_t)cand_offset(i0)), u2f(g0 + (uint32_t)cand_offset(i0 + kLanes))};
+      for (int l = 0; l < kLanes; l++) {  // uniform
+        float4 a[kLeaf / 4];
+#pragma unroll
+        for (int v = 0; v < kLeaf / 4; v++) a[v] = s_t[tile_quad(l, v)];
+#pragma unroll
+        for (int v = 0; v < kLeaf / 4; v++) {
+          x = x + (v2f){a[v].x, a[v].x};
+          x = x + (v2f){a[v].y, a[v].y};
+          x = x + (v2f){a[v].z, a[v].z};
+          x = x + (v2f){a[v].w, a[v].w};
+        }
+      }
+      out0 = f2u(x.x);
+      out1 = f2u(x.y);
+    }
+    W.cand[(size_t)slot * kCand + i0] = out0;
+    W.cand[(size_t)slot * kCand + i0 + kLanes] = out1;
+    return;
+  }
   if (part >= 2) return;
   Summary S;
 #pragma unroll
@@ -711,8 +749,11 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   const bool walker = wave == kWalker;
   const TermSrc src = make_term_src(match, pos_of, state, W);
   uint32_t s = f2u(0.0f);  // walker state, evaluator.go:122: the sums start at zero
+  // walker: counters of the whole row, written once behind the last chunk (an atomic in flight holds up the
+  // next release store of its wave, and the walk is a chain of those)
+  unsigned long long n_run = 0, n_runfail = 0, n_recfail = 0, ticks_scan = 0, ticks_walk = 0;
   for (int64_t chunk = 0; chunk < W.ntiles; chunk += kChainTiles) {
-    const long long t_a = wall_clock64();
+    const long long t_a = stat_clock(W);
     if (threadIdx.x < kChainSegs) {
       s_sufok[threadIdx.x] = 0;
       s_mail[threadIdx.x].req = 0;
@@ -806,30 +847,15 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         const LeafAux A = W.aux[(size_t)slot * kLanes + lane];
         float t[kLeaf];
         load_leaf_quads(W.aux_terms + (size_t)slot * (kTile / 4), lane, t);
-        // A tile without a window (a sum hovering around zero) costs ~8 us however its leaves are summarised: a
-        // dozen runs to apply and a dozen leaves to add term by term, one after the other.  But its start state
-        // is known to a few ulps (the job kernel's guess includes the chain's rounding errors so far), and this
-        // wave has nothing to do until the walker arrives: it carries out all 2048 additions NOW, from 64
-        // candidate start states at once (lane c: the guess + (c - 32) ulps; every lane the same chain of terms,
-        // broadcast with v_readlane).  If the walker's state is one of the candidates the tile is a look-up.
-        uint32_t cand_in = 0u, cand_out = 0u;
-        bool have_cand = false;
-        if (cur_kind == JOB_NOWINDOW && !(W.selfcheck & 4)) {  // uniform
-          const uint32_t g0 = s_rec[cur_tile].in;
-          if ((g0 & 0x7fffffffu) > 64u && (g0 & 0x7f800000u) != 0x7f800000u) {  // (not next to zero, finite)
-            cand_in = g0 + (uint32_t)(lane - 32);   // same sign: 32 floats below, 31 above in magnitude
-            float x = u2f(cand_in);
-            have_cand = true;
-            for (int l = 0; l < kLanes; l++) {  // uniform
+        // A tile without a window (a sum hovering around zero): the job kernel has carried out its 2048
+        // additions from kCand start states around the guess (strict_terms.h, cand_offset); lane c holds the
+        // ends of candidates c, 64 + c, 128 + c, ...
+        uint32_t cand_out[kCand / kLanes];
+        const uint32_t g0 = s_rec[cur_tile].in;
+        const bool have_cand = cur_kind == JOB_NOWINDOW && !(W.selfcheck & 4);  // uniform
 #pragma unroll
-              for (int j = 0; j < kLeaf; j++) x = x + u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(t[j]), l));
-              if ((l & 7) == 7 && lds_get(&s_mail[wave].req) == k + 1) {  // the walker is here already: no time for this
-                have_cand = false;
-                break;
-              }
-            }
-            cand_out = f2u(x);
-          }
+        for (int j = 0; j < kCand / kLanes; j++) {
+          cand_out[j] = have_cand ? W.cand[(size_t)slot * kCand + j * kLanes + lane] : 0x7fc00000u;
         }
         bool serve = false;
         while (true) {
@@ -845,41 +871,107 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           __builtin_amdgcn_s_sleep(1);
         }
         if (serve) {
-          const long long t_begin = wall_clock64();
+          const long long t_begin = stat_clock(W);
           const uint32_t s_in = (uint32_t)rfl((int)__hip_atomic_load(&s_mail[wave].s_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
           int serial = 0, tried = 0, applied = 0;
           uint32_t s_out;
-          const unsigned long long hit = have_cand ? __ballot(cand_in == s_in) : 0ull;
-          if (hit) {
-            s_out = (uint32_t)__builtin_amdgcn_readlane((int)cand_out, __builtin_ctzll(hit));
-            if (lane == 0) atomicAdd(&W.dbg[25], 1ull);
-          } else {
-            s_out = resolve_staged<true>(s_in, cur_kind, cur_key, A, lane, nullptr, t, serial, tried, applied);
+          // candidates are in ascending magnitude: n_le of them are <= |s_in|, so candidate n_le - 1 is the last
+          // one not above the state, and (unless it IS the state) candidate n_le the first one above it; a state
+          // between two candidates with the same end has that end too (x -> fl(x + t) is monotone)
+          bool hit = false;
+          int hit_kind = 0;
+          if (have_cand && ((s_in ^ g0) >> 31) == 0u) {  // uniform
+            const uint32_t m = s_in & 0x7fffffffu;
+            int n_le = 0, n_lt = 0;
+#pragma unroll
+            for (int j = 0; j < kCand / kLanes; j++) {
+              const uint32_t cm = (g0 & 0x7fffffffu) + (uint32_t)cand_offset(j * kLanes + lane);
+              n_le += __popcll(__ballot(cm <= m));
+              n_lt += __popcll(__ballot(cm < m));
+            }
+            const int below = n_le - 1, above = n_le > n_lt ? below : n_le;
+            if (below >= 0 && above < kCand) {
+              uint32_t a = 0u, b = 0u;
+#pragma unroll
+              for (int j = 0; j < kCand / kLanes; j++) {
+                const uint32_t va = (uint32_t)__builtin_amdgcn_readlane((int)cand_out[j], below & 63);
+                const uint32_t vb = (uint32_t)__builtin_amdgcn_readlane((int)cand_out[j], above & 63);
+                a = (below >> 6) == j ? va : a;
+                b = (above >> 6) == j ? vb : b;
+              }
+              if (a == b && (a & 0x7f800000u) != 0x7f800000u) {
+                hit = true;
+                s_out = a;
+                hit_kind = above == below ? 25 : 26;
+              }
+            }
           }
-          if (lane == 0 && cur_kind == JOB_NOWINDOW) atomicAdd(&W.dbg[24], 1ull);
+          if (!hit) s_out = resolve_staged<true>(s_in, cur_kind, cur_key, A, lane, nullptr, t, serial, tried, applied);
           if (lane == 0) {
             __hip_atomic_store(&s_mail[wave].s_out, s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             lds_put(&s_mail[wave].ack, k + 1);
-            resolve_stats(W, cur_kind, serial, tried, applied, wall_clock64() - t_begin);
+            // (counters only behind the release: it waits for every memory operation of this wave before it)
+            if (cur_kind == JOB_NOWINDOW) atomicAdd(&W.dbg[24], 1ull);
+            if (hit) atomicAdd(&W.dbg[hit_kind], 1ull);
+            if (!hit && have_cand) {  // measurement aid: how far off the guess was (log2 of the distance in floats)
+              const uint32_t m = s_in & 0x7fffffffu, gm = g0 & 0x7fffffffu;
+              const uint32_t dist = m > gm ? m - gm : gm - m;
+              const int bucket = ((s_in ^ g0) >> 31) ? 15 : (dist == 0u ? 0 : (32 - __clz((int)dist) > 14 ? 14 : 32 - __clz((int)dist)));
+              atomicAdd(&W.dbg[48 + bucket], 1ull);
+            }
+            resolve_stats(W, cur_kind, serial, tried, applied, stat_clock(W) - t_begin);
           }
         }
         k += kHelpers;
       }
     } else {
       // ---- the walk: one wave, every lane with the same state
-      const long long t_b = wall_clock64();
-      unsigned long long n_run = 0, n_runfail = 0, n_recfail = 0;
-      for (int w = 0; w < kChainSegs; w++) {
-        const int cnt = s_count[w];
-        for (int i = 0; i < cnt; i++) {
-          const int e = s_tail[w * 64 + i], h = s_head[w * 64 + i];
+      const long long t_b = stat_clock(W);
+      // The runs of the chunk, 64 at a time: lane j fetches run j's ends and its composed record, the walk then
+      // takes them out of the registers one after the other (a run that covers the state costs sixteen
+      // v_readlane and the apply; fetched from LDS run by run, two dependent LDS round trips each came first).
+      int seg_base[kChainSegs + 1];
+      seg_base[0] = 0;
+#pragma unroll
+      for (int w = 0; w < kChainSegs; w++) seg_base[w + 1] = seg_base[w] + s_count[w];
+      const int n_runs = seg_base[kChainSegs];
+      for (int r0 = 0; r0 < n_runs; r0 += kLanes) {
+        int e_l = 0, h_l = 0;
+        TileRec R_l;
+        R_l.key = -2;
+        R_l.in = R_l.out = 0u;
+        R_l.cons = 0;
+        R_l.s = summary_identity();
+        if (r0 + lane < n_runs) {
+          int idx = 0;
+#pragma unroll
+          for (int w = 0; w < kChainSegs; w++)
+            if (r0 + lane >= seg_base[w] && r0 + lane < seg_base[w + 1]) idx = w * 64 + (r0 + lane - seg_base[w]);
+          e_l = s_tail[idx];
+          h_l = s_head[idx];
+          R_l = s_pre[e_l];
+        }
+        const int n_here = n_runs - r0 < kLanes ? n_runs - r0 : kLanes;
+        for (int j = 0; j < n_here; j++) {
+          const int e = __builtin_amdgcn_readlane(e_l, j), h = __builtin_amdgcn_readlane(h_l, j);
           n_run++;
           {
-            const TileRec Qr = load_rec_uniform(&s_pre[e]);  // the whole run
+            TileRec Qr;  // the whole run
+            Qr.key = __builtin_amdgcn_readlane(R_l.key, j);
+            Qr.in = (uint32_t)__builtin_amdgcn_readlane((int)R_l.in, j);
+            Qr.out = (uint32_t)__builtin_amdgcn_readlane((int)R_l.out, j);
+            Qr.cons = __builtin_amdgcn_readlane(R_l.cons, j);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              Qr.s.c[q] = __builtin_amdgcn_readlane(R_l.s.c[q], j);
+              Qr.s.lo[q] = __builtin_amdgcn_readlane(R_l.s.lo[q], j);
+              Qr.s.hi[q] = __builtin_amdgcn_readlane(R_l.s.hi[q], j);
+            }
             const uint32_t s_in = s;
             if ((Qr.key >= 0 && apply(s, Qr.key, Qr.s)) || apply_point(s, Qr)) {
               selfcheck(W, src, row, s_in, s, chunk + h, chunk + e + 1, 0, lane, s_tile);
-              if (lane == 0) lds_put(&s_progress, e + 1);
+              // (a hint for helpers whose tile the walk has passed: no ordering needed)
+              if (lane == 0) __hip_atomic_store(&s_progress, e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               continue;
             }
           }
@@ -919,13 +1011,13 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
                 }
                 s = (uint32_t)rfl((int)__hip_atomic_load(&M->s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
               } else {  // a tile without a slot: its terms are formed again from the pairs, all 2048 are added
-                const long long t_begin = wall_clock64();
+                const long long t_begin = stat_clock(W);
                 recompute_tile_to_lds(src, row, chunk + f, lane, s_tile);
                 LeafAux none;
                 int serial, tried, applied;
                 s = resolve_staged<false>(s, 0, -1, none, lane, s_tile, nullptr, serial, tried, applied);
                 __builtin_amdgcn_wave_barrier();
-                if (lane == 0) resolve_stats(W, 0, serial, tried, applied, wall_clock64() - t_begin);
+                if (lane == 0) resolve_stats(W, 0, serial, tried, applied, stat_clock(W) - t_begin);
               }
             }
             selfcheck(W, src, row, s_in, s, chunk + f, chunk + f + 1, 2, lane, s_tile);
@@ -945,15 +1037,21 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       }
       if (lane == 0) {
         lds_put(&s_progress, 1 << 30);  // helpers that still wait for a tile: the chunk is done
-        atomicAdd(&W.dbg[0], n_run);
-        atomicAdd(&W.dbg[1], n_runfail);
-        atomicAdd(&W.dbg[4], n_recfail);
-        atomicAdd(&W.dbg[8], (unsigned long long)(t_b - t_a));
-        atomicAdd(&W.dbg[9], (unsigned long long)(wall_clock64() - t_b));
-        atomicMax(&W.dbg[14 + 32], (unsigned long long)(wall_clock64() - t_b));   // slowest row of the launch
+        ticks_scan += (unsigned long long)(t_b - t_a);
+        ticks_walk += (unsigned long long)(stat_clock(W) - t_b);
       }
     }
     __syncthreads();
+  }
+  if (walker && lane == 0) {
+    atomicAdd(&W.dbg[0], n_run);
+    atomicAdd(&W.dbg[1], n_runfail);
+    atomicAdd(&W.dbg[4], n_recfail);
+    atomicAdd(&W.dbg[8], ticks_scan);
+    atomicAdd(&W.dbg[9], ticks_walk);
+    atomicMax(&W.dbg[14 + 32], ticks_walk);   // slowest row of the launch
+    atomicAdd(&W.dbg[27 + row], ticks_walk);  // per row: walk ticks, tiles resolved
+    atomicAdd(&W.dbg[36 + row], n_recfail);
   }
   // the pair count of the iteration: row 0 adds up the tiles' counts (a fixed order is not needed: integers)
   if (row == 0) {
@@ -1009,7 +1107,8 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   W.ntiles = nt > 0 ? (nt + kTile - 1) / kTile : 1;
   W.nrows = kStrictRows;
   W.selfcheck = (getenv("PCGX_STRICT_SELFCHECK") ? 1 : 0) | (getenv("PCGX_STRICT_TRACE") ? 2 : 0) |
-                (getenv("PCGX_STRICT_NOSPEC") ? 4 : 0);  // (4: no candidate chains in the chain kernel's helpers: measurements)
+                (getenv("PCGX_STRICT_NOSPEC") ? 4 : 0) | (getenv("PCGX_STRICT_CLOCKS") ? 8 : 0);
+  // (4: the chain kernel ignores the candidate tables of tiles without a window; 8: tick columns of the debug counters)
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t sz_tile = up((size_t)kStrictRows * W.ntiles * sizeof(double));  // (twice: sums and errors)
   const size_t sz_pairs = up((size_t)W.ntiles * sizeof(uint32_t));
@@ -1025,10 +1124,11 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   const size_t sz_aux = up((size_t)W.naux * kLanes * sizeof(LeafAux));
   const size_t sz_auxt = up((size_t)W.naux * kTile * sizeof(float));
   const size_t sz_jobs = up((size_t)W.naux * sizeof(JobDesc));
+  const size_t sz_cand = up((size_t)W.naux * kCand * sizeof(uint32_t));
   const size_t sz_xyz = up((size_t)(nt ? nt : 1) * 12 + 64);
   const size_t sz_stamps = up((size_t)W.ntiles * 16 * sizeof(unsigned long long));
   const size_t sz_ctr = 256 + (size_t)kAuxShards * 128;
-  const size_t total = 2 * sz_tile + sz_pairs + sz_rec + sz_aux + sz_auxt + sz_jobs + sz_xyz + sz_ctr + 512 + sz_stamps;
+  const size_t total = 2 * sz_tile + sz_pairs + sz_rec + sz_aux + sz_auxt + sz_jobs + sz_cand + sz_xyz + sz_ctr + 512 + sz_stamps;
   hipError_t e = dev_cache_alloc(&b->block, total);
   if (e != hipSuccess) {
     delete b;
@@ -1042,6 +1142,7 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   W.aux = (LeafAux *)p; p += sz_aux;
   W.aux_terms = (float4 *)p; p += sz_auxt;
   W.jobs = (JobDesc *)p; p += sz_jobs;
+  W.cand = (uint32_t *)p; p += sz_cand;
   W.xyz_caller = (const float *)p; p += sz_xyz;
   uint8_t *counters = p;
   W.done_rows = (unsigned int *)(p + 12);

@@ -1,9 +1,11 @@
 """Strict sums, worst case: a target whose gradient sums hover around zero from the first pair to the
 last (base points + zero-mean noise, no transform).  Time per iteration and what the chain did."""
+import os
 import sys
 import time
 
 import numpy as np
+
 
 sys.path.insert(0, ".")
 from pcgol_amd import _lib as L, icp, kdtree, synth  # noqa: E402
@@ -16,6 +18,7 @@ noise = ((rng.integers(0, 1 << 16, size=(n, 3)).astype(np.float32) / f32(1 << 16
 target = np.ascontiguousarray((base[rng.permutation(n)] + noise).astype(np.float32))
 t = kdtree.New(base)
 for mode in (1, 0):
+    os.environ.pop("PCGX_STRICT_CLOCKS", None)  # (read when a session is created: the timed one runs without the clock reads)
     s = icp.IcpSession(t, target, 0.5, 6, np.full(6, 0.3, f32), np.full(6, -1.0, f32), 20)
     s.set_strict(mode)
     for _ in range(20):
@@ -38,10 +41,15 @@ for mode in (1, 0):
             st[8] / 180 / 100.0, st[9] / 180 / 100.0, (st[10] + st[11]) / 180 / 100.0, st[46] / 100.0)
     print("strict %d: %.1f us per iteration%s" % (mode, dt * 1e6, extra))
     if mode:  # per iteration (a read-back after every step: the clocks differ from the timed loop's)
-        L.check(L.lib().pcgx_icp_session_reset(s._h, None))
+        s.close()
+        os.environ["PCGX_STRICT_CLOCKS"] = "1"
+        s = icp.IcpSession(t, target, 0.5, 6, np.full(6, 0.3, f32), np.full(6, -1.0, f32), 20)
+        s.set_strict(mode)
         for k in range(20):
             s.step()
             st = s.strict_stats()
-            print("  iteration %2d: tiles recomputed %3d, leaves term by term %4d, slowest sum's walk %.0f us | no window: %d tiles, %d runs tried, %d applied, %d leaves serial, %.1f us each (candidate hits %d of %d) | crossing: %d tiles, %d leaves serial, %.1f us each | no slot %d" % (
-                k, st[2], st[3], st[46] / 100.0, st[16], st[17], st[18], st[22], st[19] / 100.0 / max(st[16], 1), st[25], st[24], st[20], st[23], st[21] / 100.0 / max(st[20], 1), st[5]))
+            print("  iteration %2d: tiles recomputed %3d, leaves term by term %4d, slowest sum's walk %.0f us | no window: %d tiles, %d runs tried, %d applied, %d leaves serial, %.1f us each (table hits %d exact + %d between, of %d) | crossing: %d tiles, %d leaves serial, %.1f us each | no slot %d" % (
+                k, st[2], st[3], st[46] / 100.0, st[16], st[17], st[18], st[22], st[19] / 100.0 / max(st[16], 1), st[25], st[26], st[24], st[20], st[23], st[21] / 100.0 / max(st[20], 1), st[5]))
+            if sum(st[48:64]):
+                print("      table misses by log2(distance of the state from the guess): %s, other sign %d" % (list(int(v) for v in st[48:63]), st[63]))
     s.close()

@@ -1,10 +1,12 @@
 """GPU probe: parallel strict sums (set_strict 1) against the one-wave chain (set_strict 2) on C4,
 iteration by iteration, then timings.  Usage: python tools/strict_probe.py [n]"""
+import os
 import sys
 import time
 
 import numpy as np
 
+os.environ["PCGX_STRICT_CLOCKS"] = "1"  # the us columns below; read when a session is created, dropped for the timings
 sys.path.insert(0, ".")
 from pcgol_amd import _lib as L, icp, kdtree, synth  # noqa: E402
 
@@ -42,7 +44,9 @@ for k in range(c["max_iteration"]):
 ta, _, _ = a.result()
 tb, _, _ = b.result()
 print("final pose equal:", np.array_equal(ta, tb), "mismatching iterations:", bad)
-for mode, s in ((1, a), (2, b), (0, session(0))):
+del os.environ["PCGX_STRICT_CLOCKS"]
+for mode in (1, 2, 0):
+    s = session(mode)
     for rep in range(2):
         L.check(L.lib().pcgx_icp_session_reset(s._h, None))
         L.check(L.lib().pcgx_sync(None))
