@@ -681,18 +681,41 @@ constexpr int kChainBlock = kChainTiles;
 constexpr int kWalker = kChainSegs - 1;       // the wave that walks (after the forward scan of its own segment)
 constexpr int kHelpers = kChainSegs - 1;      // the others (eight waves, two per SIMD: 256 registers each, no scratch)
 
-// a record every lane of the walking wave reads from the same LDS address, as scalars
-__device__ __forceinline__ TileRec load_rec_uniform(const TileRec *p) {
-  const int4 *w4 = reinterpret_cast<const int4 *>(p);
-  const int4 a = w4[0], b = w4[1], c = w4[2], d = w4[3];  // four 16-byte LDS reads in flight, one wait
+// The chunk's records in LDS, one array per word ([word][tile]): lane-indexed reads and writes of whole records
+// then touch 64 consecutive words per instruction.  As an array of 64-byte structs every such access was a
+// 16-way bank conflict (lanes l and l + 4 on the same bank) -- the scans' stores and the walker's gathers.
+typedef int32_t RecArray[16][kChainTiles];
+__device__ __forceinline__ void rec_put(RecArray &a, int i, const TileRec &R) {
+  a[0][i] = R.key; a[1][i] = (int32_t)R.in; a[2][i] = (int32_t)R.out; a[3][i] = R.cons;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    a[4 + q][i] = R.s.c[q];
+    a[8 + q][i] = R.s.lo[q];
+    a[12 + q][i] = R.s.hi[q];
+  }
+}
+__device__ __forceinline__ TileRec rec_get(const RecArray &a, int i) {
   TileRec R;
-  R.key = rfl(a.x);
-  R.in = (uint32_t)rfl(a.y);
-  R.out = (uint32_t)rfl(a.z);
-  R.cons = rfl(a.w);
-  R.s.c[0] = rfl(b.x); R.s.c[1] = rfl(b.y); R.s.c[2] = rfl(b.z); R.s.c[3] = rfl(b.w);
-  R.s.lo[0] = rfl(c.x); R.s.lo[1] = rfl(c.y); R.s.lo[2] = rfl(c.z); R.s.lo[3] = rfl(c.w);
-  R.s.hi[0] = rfl(d.x); R.s.hi[1] = rfl(d.y); R.s.hi[2] = rfl(d.z); R.s.hi[3] = rfl(d.w);
+  R.key = a[0][i]; R.in = (uint32_t)a[1][i]; R.out = (uint32_t)a[2][i]; R.cons = a[3][i];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    R.s.c[q] = a[4 + q][i];
+    R.s.lo[q] = a[8 + q][i];
+    R.s.hi[q] = a[12 + q][i];
+  }
+  return R;
+}
+// a record every lane of the walking wave reads from the same LDS address, as scalars
+__device__ __forceinline__ TileRec load_rec_uniform(const RecArray &a, int i) {
+  const TileRec V = rec_get(a, i);  // sixteen LDS reads in flight, one wait
+  TileRec R;
+  R.key = rfl(V.key); R.in = (uint32_t)rfl((int)V.in); R.out = (uint32_t)rfl((int)V.out); R.cons = rfl(V.cons);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    R.s.c[q] = rfl(V.s.c[q]);
+    R.s.lo[q] = rfl(V.s.lo[q]);
+    R.s.hi[q] = rfl(V.s.hi[q]);
+  }
   return R;
 }
 
@@ -731,9 +754,9 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
                                                                   IcpState *__restrict__ state, StrictWork W,
                                                                   double *__restrict__ sums10, IcpKernelParams kp,
                                                                   int fuse_update) {
-  __shared__ TileRec s_rec[kChainTiles];   // the tiles' own records
-  __shared__ TileRec s_pre[kChainTiles];   // composition from the tile's run head to the tile
-  __shared__ TileRec s_suf[kChainTiles];   // composition from the tile to its run's tail
+  __shared__ RecArray s_rec;   // the tiles' own records
+  __shared__ RecArray s_pre;   // composition from the tile's run head to the tile
+  __shared__ RecArray s_suf;   // composition from the tile to its run's tail
   __shared__ int16_t s_tail[kChainTiles];  // per segment: the tails of its runs, in order
   __shared__ int16_t s_head[kChainTiles];
   __shared__ int16_t s_auxlist[kChainTiles];  // the tiles that own a slot, in order
@@ -771,7 +794,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       const int64_t tile = chunk + threadIdx.x;
       valid = tile < W.ntiles;
       if (valid) R = W.recs[row * W.ntiles + tile];
-      s_rec[threadIdx.x] = R;
+      rec_put(s_rec, threadIdx.x, R);
       const int32_t key_prev = __shfl_up(R.key, 1), key_next = __shfl_down(R.key, 1);
       head = lane == 0 || R.key < 0 || R.key != key_prev;
       tail = lane == 63 || R.key < 0 || R.key != key_next;
@@ -786,7 +809,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           fp = xf;
         }
       }
-      s_pre[threadIdx.x] = P;
+      rec_put(s_pre, threadIdx.x, P);
       const unsigned long long tails = __ballot(tail && valid);
       if (tail && valid) {
         const unsigned long long below = tails & ((1ull << lane) - 1ull);  // the run starts behind the tail before this one
@@ -827,13 +850,13 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             fq = yf;
           }
         }
-        s_suf[seg * 64 + lane] = Q;
+        rec_put(s_suf, seg * 64 + lane, Q);
         lds_fence_wave();
         if (lane == 0) lds_put(&s_sufok[seg], 1);
       };
       scan_backwards(wave, R, tail);
       if (wave == 0) {
-        const TileRec R7 = s_rec[kWalker * 64 + lane];
+        const TileRec R7 = rec_get(s_rec, kWalker * 64 + lane);
         const int32_t kn = __shfl_down(R7.key, 1);
         scan_backwards(kWalker, R7, lane == 63 || R7.key < 0 || R7.key != kn);
       }
@@ -841,8 +864,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       while (k < naux) {  // uniform
         // the tile's leaf records and terms (lane l: leaf l), in registers
         const int cur_tile = s_auxlist[k];
-        const int32_t cur_key = s_rec[cur_tile].key;
-        const int slot = (s_rec[cur_tile].cons >> 8) - 1;
+        const int32_t cur_key = s_rec[0][cur_tile];
+        const int slot = (s_rec[3][cur_tile] >> 8) - 1;
         const int cur_kind = cur_key >= 0 ? JOB_CROSSING : JOB_NOWINDOW;
         const LeafAux A = W.aux[(size_t)slot * kLanes + lane];
         float t[kLeaf];
@@ -851,7 +874,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         // additions from kCand start states around the guess (strict_terms.h, cand_offset); lane c holds the
         // ends of candidates c, 64 + c, 128 + c, ...
         uint32_t cand_out[kCand / kLanes];
-        const uint32_t g0 = s_rec[cur_tile].in;
+        const uint32_t g0 = (uint32_t)s_rec[1][cur_tile];
         const bool have_cand = cur_kind == JOB_NOWINDOW && !(W.selfcheck & 4);  // uniform
 #pragma unroll
         for (int j = 0; j < kCand / kLanes; j++) {
@@ -949,7 +972,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             if (r0 + lane >= seg_base[w] && r0 + lane < seg_base[w + 1]) idx = w * 64 + (r0 + lane - seg_base[w]);
           e_l = s_tail[idx];
           h_l = s_head[idx];
-          R_l = s_pre[e_l];
+          R_l = rec_get(s_pre, e_l);
         }
         const int n_here = n_runs - r0 < kLanes ? n_runs - r0 : kLanes;
         for (int j = 0; j < n_here; j++) {
@@ -982,7 +1005,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             uint32_t mine = s;
             bool ok = false;
             if (h + lane <= e) {
-              const TileRec Pj = s_pre[h + lane];
+              const TileRec Pj = rec_get(s_pre, h + lane);
               ok = Pj.key >= 0 && apply(mine, Pj.key, Pj.s);
             }
             const unsigned long long good = __ballot(ok);
@@ -996,7 +1019,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             // tile f does not cover the state (its place in the run's prefix composition failed, or it is
             // the run's head); its point record may still fit
             const uint32_t s_in = s;
-            const TileRec T = load_rec_uniform(&s_rec[f]);
+            const TileRec T = load_rec_uniform(s_rec, f);
             if (!(f > h && ((T.key >= 0 && apply(s, T.key, T.s)) || apply_point(s, T)))) {
               n_recfail++;
               const int ord = s_auxord[f];
@@ -1025,7 +1048,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             if (f > e) break;
             while (lds_get(&s_sufok[f >> 6]) == 0) {
             }
-            const TileRec Sf = load_rec_uniform(&s_suf[f]);  // the rest of the run in one step
+            const TileRec Sf = load_rec_uniform(s_suf, f);  // the rest of the run in one step
             const uint32_t s_in2 = s;
             if ((Sf.key >= 0 && apply(s, Sf.key, Sf.s)) || apply_point(s, Sf)) {
               selfcheck(W, src, row, s_in2, s, chunk + f, chunk + e + 1, 3, lane, s_tile);
