@@ -350,6 +350,13 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
       const int64_t r_begin = (int64_t)begin * 64;
       walk_list[r_begin + atomicAdd(&walk_count[slot], 1u)] = (uint32_t)(i - r_begin);
       first_leaf[i] = kSums ? 0x80000000u : 0u;  // "walked this iteration" (icp_corr_kernel adds its terms)
+      // strict sums: the float64 tile sums (guesses only) are formed by icp_corr_kernel's workgroups while others
+      // of them still walk; until the walk's answer arrives the target stands with the best point the grid has
+      // seen -- usually the answer -- instead of last iteration's pair (none at all in a Fit's first iteration)
+      if (!kSums && match_caller) {
+        const bool seen = __float_as_int(best.w) >= 0;
+        match_caller[orig_of[i]] = make_float4(best.x, best.y, best.z, seen ? best_d : -1.0f);
+      }
     } else {
       const bool found = __float_as_int(best.w) >= 0;
       const float4 bp = make_float4(best.x, best.y, best.z, found ? best_d : -1.0f);

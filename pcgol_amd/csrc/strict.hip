@@ -225,6 +225,7 @@ __device__ __forceinline__ void tile_guesses(const LdsQuads &q, double base, dou
 // one such tile was measured (4: the summary kernel's slowest wave then outlasts the rest of it; the
 // tiles where a sum hovers around zero are not the first ones)
 constexpr int kExactTiles = 1;
+constexpr uint32_t kPlainMargin = 512u;
 
 // One workgroup per tile, one wave per row.  The workgroup forms the tile's terms ONCE, into LDS (72 KB:
 // the CDNA4-sized LDS is what lets nine rows of 2048 terms sit next to each other, two workgroups per
@@ -305,7 +306,12 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     ChainRange cr;
     double terr;
     tile_guesses(q, P0, lsum, pre, lane, g, cr, terr);
-    if (lane == 0) W.tile_err[(int64_t)row * W.ntiles + tile] = terr;
+    // (plus what the stored tile sum is off the sum of the terms by: it was formed while a few of the tile's
+    // pairs were still being walked for, icp.hip -- the job kernel's guesses then start from prefixes that add
+    // up to the terms as they are)
+    const double tile_total = __shfl(pre, 63) + __shfl(lsum, 63);
+    if (lane == 0)
+      W.tile_err[(int64_t)row * W.ntiles + tile] = terr + (tile_total - W.tile_sum[(int64_t)row * W.ntiles + tile]);
     // window of the tile
     const uint32_t mn = wave_all_umin(cr.mn), mx = wave_all_umax(cr.mx);
     const bool one_sign = __ballot(cr.sg_or != cr.sg_and) == 0ull &&
@@ -319,7 +325,16 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     T.in = g_first;
     T.out = (uint32_t)__shfl((int)cr.end, 63);
     T.cons = cons ? 1 : 0;
-    if (key >= 0 && (mn >> 23) == (mx >> 23)) {  // uniform: a plain tile, all of it in one binade
+    // a plain tile: all of it in one binade, and not within kPlainMargin floats of the binade's ends -- the record
+    // of a plain tile covers exactly the states that stay inside the binade, the true state is some floats off
+    // the guess (the float32 chain's own drift since the row began is not in a guess made here: strict_job_kernel),
+    // and a plain tile that does not cover it owns no slot: the chain kernel forms its terms again from the pairs
+    // and adds all 2048 (~25 us; seen a few times in twenty iterations of C4).  Next to an end the tile goes
+    // the way of a level crossing instead (its window holds the binade beyond that end).  What is left: a row
+    // that drifts by 10^4 floats (C4's first iteration, where every term of a gradient sum has the same sign)
+    // still loses the one or two tiles in which it passes a binade end.
+    const uint32_t m_lo = mn & 0x7fffffu, m_hi = mx & 0x7fffffu;
+    if (key >= 0 && (mn >> 23) == (mx >> 23) && m_lo >= kPlainMargin && m_hi <= 0x7fffffu - kPlainMargin) {  // uniform
       const uint32_t E = mn >> 23;
       Par S = leaf_parity_summary_q(q, g, cr, E, g_first >> 31);
 #pragma unroll
@@ -376,6 +391,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
 // cover the state in one parallel step and carries on behind it), or wave 0 alone composes the runs of
 // leaves under equal windows (no window: the chain kernel applies a run's last record).
 constexpr int kJobBlock = 256;
+constexpr int kJobsPerShard = 8;
 __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *__restrict__ state, StrictWork W) {
   __shared__ float4 s_t[kTile / 4];
   __shared__ int32_t s_S[12][kLanes];  // class pieces c[4] | lo[4] | hi[4] per leaf
@@ -384,9 +400,15 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   __shared__ int32_t s_hdr[4];         // the tile's window, guess at its start, end of its last guess chain, "the chains join up"
   if (state->done) return;
   const unsigned per_shard = (unsigned)W.naux / kAuxShards;
-  const unsigned slot = blockIdx.x, shard = slot / per_shard, k = slot % per_shard;
-  if (k >= W.aux_count[shard * 32]) return;  // uniform
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  // kJobsPerShard workgroups per shard of slots, each takes every kJobsPerShard-th slot the summary kernel has
+  // handed out there (one workgroup per slot that COULD be handed out was a launch of ten thousand
+  // workgroups, a hundred of them with work)
+  const unsigned shard = blockIdx.x / kJobsPerShard;
+  const unsigned used = min(W.aux_count[shard * 32], per_shard);
+  for (unsigned k = blockIdx.x % kJobsPerShard; k < used; k += kJobsPerShard) {  // uniform
+  const unsigned slot = shard * per_shard + k;
+  __syncthreads();  // (the LDS of the slot before this one is done with)
   const JobDesc *J = W.jobs + slot;
   const float4 *src4 = W.aux_terms + (size_t)slot * (kTile / 4);
   for (int i = threadIdx.x; i < kTile / 4; i += kJobBlock) s_t[i] = src4[i];
@@ -474,9 +496,9 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     }
     W.cand[(size_t)slot * kCand + i0] = out0;
     W.cand[(size_t)slot * kCand + i0 + kLanes] = out1;
-    return;
+    continue;
   }
-  if (part >= 2) return;
+  if (part >= 2) continue;
   Summary S;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -531,6 +553,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     R.key = -1;
     if (lane == 0) W.recs[row * W.ntiles + tile] = R;
   }
+}  // slots of this workgroup
 }
 
 // ---- chain -----------------------------------------------------------------------------------------
@@ -1034,6 +1057,10 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
                 }
                 s = (uint32_t)rfl((int)__hip_atomic_load(&M->s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
               } else {  // a tile without a slot: its terms are formed again from the pairs, all 2048 are added
+                if (lane == 0) {  // (measurement aid: which tile, under which record)
+                  atomicMax(&W.dbg[45], (unsigned long long)(chunk + f));
+                  atomicMax(&W.dbg[47], ((unsigned long long)T.in << 32) | s);
+                }
                 const long long t_begin = stat_clock(W);
                 recompute_tile_to_lds(src, row, chunk + f, lane, s_tile);
                 LeafAux none;
@@ -1218,7 +1245,7 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
   {
     ProfScope prof(PCGX_PROF_STRICT_JOB, st);
     if (W.naux > 0)
-      hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
+      hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)(kAuxShards * kJobsPerShard)), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
