@@ -201,6 +201,15 @@ __global__ __launch_bounds__(256) void strict_xyz_caller_kernel(const float *__r
   out[3 * i + 2] = tz[pos];
 }
 
+// the 32 additions of leaf l, one after the other, on the state every lane holds; the leaf's terms are in
+// lane l's registers
+__device__ __forceinline__ uint32_t serial_leaf_regs(uint32_t s, const float *t, int l) {
+  float x = u2f(s);
+#pragma unroll
+  for (int j = 0; j < kLeaf; j++) x = x + u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(t[j]), l));
+  return f2u(x);
+}
+
 // ---- summaries ---------------------------------------------------------------------------------------
 // leaf guesses of a tile whose first state is (about) base: float64 prefix of the leaf sums (pre), then
 // one refinement with the prefix of the rounding errors the chains make from those guesses (the first
@@ -218,6 +227,20 @@ __device__ __forceinline__ void tile_guesses(const LdsQuads &q, double base, dou
   const int32_t moved = (int32_t)g2 - (int32_t)g;
   if (__ballot(moved > 2 || moved < -2) != 0ull) g = g2;  // uniform
   cr = guess_chain_q(q, g);
+}
+// the same, with the chain of the other parity (from g ^ 1) run next to the guess chain: the summary kernel's
+// plain tiles need both
+__device__ __forceinline__ void tile_guesses_pair(const LdsQuads &q, double base, double lsum, double pre, int lane, uint32_t &g,
+                                                  ChainRange &cr, ChainRange &crb, double &tile_err) {
+  g = f2u((float)(base + pre));
+  const float e = u2f(plain_chain_q(q, g));
+  const double err = ((double)e - (double)u2f(g)) - lsum;
+  const double epre = wave_excl_scan_f64(err, lane);
+  tile_err = __shfl(epre, 63) + __shfl(err, 63);
+  const uint32_t g2 = f2u((float)(base + pre + epre));
+  const int32_t moved = (int32_t)g2 - (int32_t)g;
+  if (__ballot(moved > 2 || moved < -2) != 0ull) g = g2;  // uniform
+  guess_chain_pair_q(q, g, cr, crb);
 }
 
 // tiles at the start of every sum that are added up term by term in the summary kernel.  A sum starts
@@ -282,19 +305,12 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     T.key = -1;
     T.in = T.out = 0u;
     T.cons = 0;
-    if (tile < kExactTiles) {
-      // from the one state known in advance (0.0f, evaluator.go:122) the additions are simply carried
-      // out, here, off the chain kernel's critical path -> a point record
-      const uint32_t next = serial_leaves(f2u(0.0f), s_terms[row], 0, kLanes);
-      T.in = f2u(0.0f);
-      T.out = next;
-      T.cons = 1;
-      if (lane == 0) {
-        W.recs[row * W.ntiles + tile] = T;
-        W.tile_err[(int64_t)row * W.ntiles + tile] = (double)u2f(next) - W.tile_sum[(int64_t)row * W.ntiles + tile];
-      }
-      continue;
-    }
+    // The first tile of a row is added up term by term from the one state known in advance (0.0f,
+    // evaluator.go:122) -> a point record.  2048 dependent additions take 5-15 us (one every 6 cycles at best,
+    // and the SIMD is shared): here they kept one workgroup busy 6 us longer than any other.  The tile goes to
+    // strict_job_kernel instead (a job like the tiles below), which has that time to spare; what this kernel
+    // keeps is the estimate of the tile's rounding error, from the guess chains like everywhere else.
+    const bool first = tile < kExactTiles;
     double lsum = 0.0;
 #pragma unroll
     for (int v = 0; v < kLeaf / 4; v++) {
@@ -303,9 +319,9 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
     const double pre = wave_excl_scan_f64(lsum, lane);
     uint32_t g;
-    ChainRange cr;
+    ChainRange cr, crb;
     double terr;
-    tile_guesses(q, P0, lsum, pre, lane, g, cr, terr);
+    tile_guesses_pair(q, P0, lsum, pre, lane, g, cr, crb, terr);
     // (plus what the stored tile sum is off the sum of the terms by: it was formed while a few of the tile's
     // pairs were still being walked for, icp.hip -- the job kernel's guesses then start from prefixes that add
     // up to the terms as they are)
@@ -334,9 +350,9 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     // that drifts by 10^4 floats (C4's first iteration, where every term of a gradient sum has the same sign)
     // still loses the one or two tiles in which it passes a binade end.
     const uint32_t m_lo = mn & 0x7fffffu, m_hi = mx & 0x7fffffu;
-    if (key >= 0 && (mn >> 23) == (mx >> 23) && m_lo >= kPlainMargin && m_hi <= 0x7fffffu - kPlainMargin) {  // uniform
+    if (!first && key >= 0 && (mn >> 23) == (mx >> 23) && m_lo >= kPlainMargin && m_hi <= 0x7fffffu - kPlainMargin) {  // uniform
       const uint32_t E = mn >> 23;
-      Par S = leaf_parity_summary_q(q, g, cr, E, g_first >> 31);
+      Par S = leaf_parity_summary_pair(g, cr, crb, E, g_first >> 31);
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {  // ordered reduction over the 64 leaves
         Par Y;
@@ -365,7 +381,8 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
     slot = (unsigned)rfl((int)slot);
     if (slot == 0xffffffffu) {  // no slot left (never seen): the chain kernel recomputes the tile from the pairs
-      T.key = -1;
+      T.key = -1;    // (the first tile as well: its walk starts at 0.0f)
+      T.cons = 0;
       if (lane == 0) W.recs[row * W.ntiles + tile] = T;
       continue;
     }
@@ -391,7 +408,6 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
 // cover the state in one parallel step and carries on behind it), or wave 0 alone composes the runs of
 // leaves under equal windows (no window: the chain kernel applies a run's last record).
 constexpr int kJobBlock = 256;
-constexpr int kJobsPerShard = 8;
 __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *__restrict__ state, StrictWork W) {
   __shared__ float4 s_t[kTile / 4];
   __shared__ int32_t s_S[12][kLanes];  // class pieces c[4] | lo[4] | hi[4] per leaf
@@ -401,12 +417,13 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   if (state->done) return;
   const unsigned per_shard = (unsigned)W.naux / kAuxShards;
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-  // kJobsPerShard workgroups per shard of slots, each takes every kJobsPerShard-th slot the summary kernel has
-  // handed out there (one workgroup per slot that COULD be handed out was a launch of ten thousand
-  // workgroups, a hundred of them with work)
-  const unsigned shard = blockIdx.x / kJobsPerShard;
+  // a workgroup per slot that could be handed out (most leave at once); with fewer workgroups than slots
+  // (gridDim.x = kAuxShards * n) a workgroup takes every n-th slot of its shard, one after the other -- measured:
+  // the launch is not shorter for its 10^4 idle workgroups less, and two jobs in a row double its length
+  const unsigned per_wg = gridDim.x / kAuxShards;
+  const unsigned shard = blockIdx.x / per_wg;
   const unsigned used = min(W.aux_count[shard * 32], per_shard);
-  for (unsigned k = blockIdx.x % kJobsPerShard; k < used; k += kJobsPerShard) {  // uniform
+  for (unsigned k = blockIdx.x % per_wg; k < used; k += per_wg) {  // uniform
   const unsigned slot = shard * per_shard + k;
   __syncthreads();  // (the LDS of the slot before this one is done with)
   const JobDesc *J = W.jobs + slot;
@@ -415,6 +432,22 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   const int row = J->row;
   const int64_t tile = J->tile;
   __syncthreads();
+  if (tile < kExactTiles) {  // uniform
+    // the first tile of a row, exactly, from 0.0f: the terms broadcast out of LDS a leaf ahead of the chain, so
+    // that the dependent path is the additions alone (one every 6 cycles: a wave that has its SIMD nearly to
+    // itself, as here, does the 2048 in ~6 us; out of registers through v_readlane each costs 10)
+    if (part == 0) {
+      const uint32_t x = serial_leaves(f2u(0.0f), s_t, 0, kLanes);
+      TileRec R;
+      R.s = summary_identity();
+      R.key = -1;
+      R.in = f2u(0.0f);
+      R.out = x;
+      R.cons = 1;  // (a point record that owns nothing the chain kernel would fetch)
+      if (lane == 0) W.recs[row * W.ntiles + tile] = R;
+    }
+    continue;
+  }
   // ---- wave 0: the leaves' guesses once more, now from a start state that includes the rounding errors
   // the float32 chain has made in all tiles before this one (strict_sum_kernel's tile_err, known only
   // after that launch): where a sum has come back towards zero the float64 prefix alone is off by 10^5
@@ -574,14 +607,6 @@ __device__ __forceinline__ bool apply_point(uint32_t &s, const TileRec &R) {
 //    applied one after the other; a run that does not cover s, and a leaf without a window, are added
 //    term by term;
 //  kind 0 (a tile that owns no slot): all 2048 terms one after the other.
-// the 32 additions of leaf l, one after the other, on the state every lane holds; the leaf's terms are in
-// lane l's registers
-__device__ __forceinline__ uint32_t serial_leaf_regs(uint32_t s, const float *t, int l) {
-  float x = u2f(s);
-#pragma unroll
-  for (int j = 0; j < kLeaf; j++) x = x + u2f((uint32_t)__builtin_amdgcn_readlane((int)f2u(t[j]), l));
-  return f2u(x);
-}
 
 // (helpers: the leaf of every lane in its registers, t; the walker's tile without a slot: staged in lds, t unused)
 template <bool kRegs>
@@ -1245,7 +1270,7 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
   {
     ProfScope prof(PCGX_PROF_STRICT_JOB, st);
     if (W.naux > 0)
-      hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)(kAuxShards * kJobsPerShard)), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
+      hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);

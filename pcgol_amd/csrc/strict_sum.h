@@ -164,27 +164,60 @@ struct ArrayQuads {  // a leaf in an array
   SS_HD Quad operator()(int v) const { return Quad{t[4 * v], t[4 * v + 1], t[4 * v + 2], t[4 * v + 3]}; }
 };
 
+// The extremes of a chain are tracked as float min / max of the states themselves (one instruction each per
+// term; the bit patterns' magnitude, sign-or and sign-and cost five) and turned into a ChainRange at the end:
+// with one sign throughout, the smallest and largest magnitude are |min| and |max| in some order; with both
+// signs sg_or != sg_and says so and no caller looks at mn / mx then.  min / max drop a NaN operand, but a chain
+// that has seen one ends in one: mx then reads as NaN's magnitude, as it did.
+SS_HD ChainRange chain_range_from(float lo, float hi, float end) {
+  ChainRange R;
+  const uint32_t bl = f2u(lo), bh = f2u(hi), ml = bl & 0x7fffffffu, mh = bh & 0x7fffffffu;
+  R.mn = umin(ml, mh);
+  R.mx = umax(ml, mh);
+  R.sg_or = (bl | bh) >> 31;
+  R.sg_and = (bl & bh) >> 31;
+  R.end = f2u(end);
+  if (end != end) R.mx = 0x7fc00000u;
+  return R;
+}
+
 template <class Q>
 SS_HD ChainRange guess_chain_q(Q quad, uint32_t g0) {
-  ChainRange R;
-  R.mn = R.mx = g0 & 0x7fffffffu;
-  R.sg_or = R.sg_and = g0 >> 31;
-  float s = u2f(g0);
+  float s = u2f(g0), lo = s, hi = s;
   auto step = [&](float term) {
     s = s + term;
-    const uint32_t b = f2u(s), m = b & 0x7fffffffu;
-    R.mn = umin(R.mn, m);
-    R.mx = umax(R.mx, m);
-    R.sg_or |= b >> 31;
-    R.sg_and &= b >> 31;
+    lo = __builtin_fminf(lo, s);
+    hi = __builtin_fmaxf(hi, s);
   };
 #pragma unroll
   for (int v = 0; v < kLeaf / 4; v++) {
     const auto a = quad(v);
     step(a.x); step(a.y); step(a.z); step(a.w);
   }
-  R.end = f2u(s);
-  return R;
+  return chain_range_from(lo, hi, s);
+}
+
+// Two chains over the same terms at once, from g0 and from g0 ^ 1 (the neighbour of the other parity): the
+// additions as packed float32 adds.
+template <class Q>
+SS_HD void guess_chain_pair_q(Q quad, uint32_t g0, ChainRange &A, ChainRange &B) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f s = {u2f(g0), u2f(g0 ^ 1u)};
+  float lo0 = s.x, hi0 = s.x, lo1 = s.y, hi1 = s.y;
+  auto step = [&](float term) {
+    s = s + (v2f){term, term};
+    lo0 = __builtin_fminf(lo0, s.x);
+    hi0 = __builtin_fmaxf(hi0, s.x);
+    lo1 = __builtin_fminf(lo1, s.y);
+    hi1 = __builtin_fmaxf(hi1, s.y);
+  };
+#pragma unroll
+  for (int v = 0; v < kLeaf / 4; v++) {
+    const auto a = quad(v);
+    step(a.x); step(a.y); step(a.z); step(a.w);
+  }
+  A = chain_range_from(lo0, hi0, s.x);
+  B = chain_range_from(lo1, hi1, s.y);
 }
 SS_HD ChainRange guess_chain(const float *t, uint32_t g0) { return guess_chain_q(ArrayQuads{t}, g0); }
 
@@ -319,24 +352,12 @@ SS_HD int32_t leaf_key(const ChainRange &cr, uint32_t guess) {
 // integer and its order).
 template <class Q>
 SS_HD void binade_chain_q(Q quad, uint32_t rep, uint32_t &end, uint32_t &mn, uint32_t &mx, uint32_t &sg_bad) {
-  float s = u2f(rep);
-  mn = 0xffffffffu;
-  mx = 0u;
-  sg_bad = 0u;
+  const ChainRange R = guess_chain_q(quad, rep);
   const uint32_t sign = rep >> 31;
-  auto step = [&](float term) {
-    s = s + term;
-    const uint32_t b = f2u(s), m = b & 0x7fffffffu;
-    sg_bad |= (b >> 31) ^ sign;
-    mn = umin(mn, m);
-    mx = umax(mx, m);
-  };
-#pragma unroll
-  for (int v = 0; v < kLeaf / 4; v++) {
-    const auto a = quad(v);
-    step(a.x); step(a.y); step(a.z); step(a.w);
-  }
-  end = f2u(s) & 0x7fffffffu;
+  sg_bad = (R.sg_or ^ sign) | (R.sg_and ^ sign);  // some state with the other sign
+  mn = R.mn;
+  mx = R.mx;
+  end = R.end & 0x7fffffffu;
 }
 SS_HD void binade_chain(const float *t, uint32_t rep, uint32_t &end, uint32_t &mn, uint32_t &mx, uint32_t &sg_bad) {
   binade_chain_q(ArrayQuads{t}, rep, end, mn, mx, sg_bad);
@@ -451,6 +472,18 @@ SS_HD Summary par_expand(const Par &P, uint32_t E, int32_t key) {
 
 // one leaf: the guess chain `cr` (run from `guess`) serves as the chain of the guess's own parity, the
 // other parity gets a chain of its own
+// (crb: the chain from guess ^ 1, guess_chain_pair_q)
+SS_HD Par leaf_parity_summary_pair(uint32_t guess, const ChainRange &cr, const ChainRange &crb, uint32_t E, uint32_t sign) {
+  int32_t c0, lo0, hi0, c1, lo1, hi1;  // the guess's own parity | the other one
+  par_class(cr.sg_or == sign && cr.sg_and == sign, guess & 0x7fffffffu, cr.end & 0x7fffffffu, cr.mn, cr.mx, E, c0, lo0, hi0);
+  const uint32_t rep = guess ^ 1u;
+  par_class(crb.sg_or == sign && crb.sg_and == sign, rep & 0x7fffffffu, crb.end & 0x7fffffffu, crb.mn, crb.mx, E, c1, lo1, hi1);
+  const bool odd = (guess & 1u) != 0u;  // (selects, no indexing by a run-time value: that would put S into scratch memory)
+  Par S;
+  S.c[0] = odd ? c1 : c0; S.lo[0] = odd ? lo1 : lo0; S.hi[0] = odd ? hi1 : hi0;
+  S.c[1] = odd ? c0 : c1; S.lo[1] = odd ? lo0 : lo1; S.hi[1] = odd ? hi0 : hi1;
+  return S;
+}
 template <class Q>
 SS_HD Par leaf_parity_summary_q(Q quad, uint32_t guess, const ChainRange &cr, uint32_t E, uint32_t sign) {
   int32_t c0, lo0, hi0, c1, lo1, hi1;  // the guess's own parity | the other one
