@@ -432,6 +432,7 @@ extern "C" pcgx_status pcgx_kdtree_free(pcgx_kdtree *t) {
   grid_free(t);
   if (t->d_nodes) dev_cache_free(t->d_nodes);
   if (t->d_dir) dev_cache_free(t->d_dir);
+  if (t->d_inv) dev_cache_free(t->d_inv);
   delete t;
   return PCGX_OK;
 }

@@ -337,6 +337,7 @@ struct pcgx_kdtree {
   int32_t depth = 0;
   float4 *d_nodes = nullptr;       // [2^depth] BFS-ordered nodes
   uint32_t *d_dir = nullptr;       // [8^dir_bits] leaf directory
+  uint32_t *d_inv = nullptr;       // [n] point id -> BFS index of its node (range.hip, made on first use, guarded by mu)
   int32_t dir_bits = 0;
   float dir_lo[3] = {0, 0, 0}, dir_scale[3] = {0, 0, 0};
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // of the base cloud

@@ -10,14 +10,25 @@
 // equal DistSq is unspecified in the reference; here (and in the oracle) ties keep the
 // discovery order of the walk.
 //
+// On a handle with a uniform grid (knn_grid.h) the neighbours are collected from the grid's cells instead of by
+// the walk: which points have DistSq < maxRange^2 does not depend on the order they are visited in (the walk's
+// pruning never drops one: kdtree.go:173-177 skips a side only when the plane alone is farther), the cells of
+// grid_cover hold all of them, and reading a few dozen consecutive records per row replaces ~100 dependent node
+// fetches per query.  The ORDER the walk would have found them in matters only among equal DistSq of one query;
+// those runs are put into it afterwards (range_tie_*_kernel: the walk is an in-order traversal that takes the
+// query's side of every node first, so a point's place in it follows from its node's BFS index).
+//
 // Two entry points because the result length is data dependent: pcgx_kdtree_range_count
 // (walk, count) and pcgx_kdtree_range_fill (walk again, write at the caller's offsets, then
 // one stable sort of the whole batch by (query, DistSq) with the radix sort of sort.hip).
 // One query per lane; 4-byte frames [level][thread] in LDS as in knn_walk.h.
+#include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
+#include "knn_grid.h"
 #include "range_walk.h"
 
 namespace pcgx {
@@ -64,6 +75,132 @@ __global__ __launch_bounds__(kRangeBlock) void range_kernel(TreeView tv, const f
   if (!kFill) counts[i] = found;
 }
 
+// The same on the grid: every point of the cells grid_cover names, row by row.  Hits in cell order.
+template <bool kFill>
+__global__ __launch_bounds__(kRangeBlock) void range_grid_kernel(GridView g, const float *__restrict__ q,
+                                                                 const int32_t *__restrict__ perm, int64_t nq, float bound,
+                                                                 int64_t *__restrict__ counts,
+                                                                 const int64_t *__restrict__ offsets, int64_t total,
+                                                                 uint4 *__restrict__ out_rec) {
+  const uint32_t n_tiles = (uint32_t)((nq + kRangeBlock - 1) / kRangeBlock);
+  const int64_t pos = (int64_t)xcd_tile(blockIdx.x, n_tiles) * kRangeBlock + threadIdx.x;
+  if (pos >= nq) return;
+  const int64_t i = perm ? (int64_t)perm[pos] : pos;
+  const float qx = q[3 * i], qy = q[3 * i + 1], qz = q[3 * i + 2];
+  int64_t found = 0;
+  const int64_t out0 = kFill ? offsets[i] : 0;
+  const int64_t cap = kFill ? offsets[i + 1] - out0 : 0;
+  const bool slice_ok = kFill && out0 >= 0 && cap >= 0 && out0 + cap <= total;
+  auto take = [&](const float4 &p) {
+    const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+    const float d = (dx * dx + dy * dy) + dz * dz;  // the reference's expression (mat/vec3.go:18-20,38-40)
+    if (d < bound) {  // kdtree.go:166,178
+      // one 16-byte store per neighbour (every lane writes into a slice of its own: three 4-byte stores into
+      // three arrays made the fill 2.3x the count); range_split_kernel spreads them afterwards, coalesced
+      if (kFill && slice_ok && found < cap)
+        out_rec[out0 + found] = make_uint4(__float_as_uint(p.w), __float_as_uint(d), (uint32_t)i, 0u);
+      ++found;
+    }
+  };
+  // (a NaN bound or query: the box is some cell or other and no distance compares below the bound, as in the walk)
+  const GridBox box = grid_cover(g, qx, qy, qz, bound);
+  for (int z = box.z0; z <= box.z1; z++) {
+    for (int y = box.y0; y <= box.y1; y++) {
+      const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+      uint32_t f = g.start[row + (uint32_t)box.x0];
+      const uint32_t e = g.start[row + (uint32_t)box.x1 + 1u];
+      for (; f + 4u <= e; f += 4u) {  // four records in flight
+        const float4 p0 = g.pts[f], p1 = g.pts[f + 1u], p2 = g.pts[f + 2u], p3 = g.pts[f + 3u];
+        take(p0); take(p1); take(p2); take(p3);
+      }
+      for (; f < e; f++) take(g.pts[f]);
+    }
+  }
+  if (!kFill) counts[i] = found;
+}
+
+// {id, DistSq bits, query} records -> the three arrays the sort works on (a slot no query wrote keeps the
+// poisoned id, query 0)
+__global__ __launch_bounds__(256) void range_split_kernel(const uint4 *__restrict__ rec, int64_t total, int32_t *__restrict__ out_id,
+                                                          uint32_t *__restrict__ out_key, uint32_t *__restrict__ out_query) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= total) return;
+  const uint4 v = rec[j];
+  out_id[j] = (int32_t)v.x;
+  out_key[j] = v.x == 0xffffffffu ? 0u : v.y;
+  out_query[j] = v.x == 0xffffffffu ? 0u : v.z;
+}
+
+// inv[id] = BFS index of the node that holds point id
+__global__ __launch_bounds__(256) void range_invert_nodes_kernel(TreeView tv, uint32_t *__restrict__ inv) {
+  const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+  if (b < 1u || b >= (1u << tv.depth)) return;
+  const uint32_t size = node_size(b, 31 - __clz((int)b), (uint32_t)tv.n + 1u);
+  if (size < 1u || size > (uint32_t)tv.n) return;  // no such node
+  const uint32_t id = __float_as_uint(node_at(tv.nodes, b).w);
+  if (id < (uint32_t)tv.n) inv[id] = b;
+}
+
+// Place of node b in the walk of query q (kdtree.go:148-197): the walk of a sub-tree takes the child on the
+// query's side first (searchLeafNode's choice, :208-216), then the node itself, then the other child.  One base-3
+// digit per level from the root: 0 = on the query's side, 1 = the node itself, 2 = on the other side.
+__device__ __forceinline__ unsigned long long range_walk_place(const TreeView &tv, uint32_t b, float qx, float qy, float qz) {
+  const int d = 31 - __clz((int)b);
+  const uint32_t m1 = (uint32_t)tv.n + 1u;
+  unsigned long long place = 0ull;
+  for (int j = 0; j < d; j++) {
+    const uint32_t anc = b >> (d - j);
+    const uint32_t bit = (b >> (d - j - 1)) & 1u;
+    const float pv = node_comp(tv.nodes, anc, j % 3), qv = sel3(j % 3, qx, qy, qz);
+    const bool go_left = node_size(anc, j, m1) == 2u || pv > qv;
+    place = place * 3ull + ((bit == 0u) == go_left ? 0ull : 2ull);
+  }
+  place = place * 3ull + 1ull;
+  for (int j = d + 1; j < tv.depth; j++) place *= 3ull;
+  return place;
+}
+
+// slot s of the sorted batch is tied with a neighbour (same query, same DistSq): its place in the walk
+__global__ __launch_bounds__(256) void range_tie_place_kernel(TreeView tv, const uint32_t *__restrict__ inv,
+                                                              const float *__restrict__ q, const uint32_t *__restrict__ query_of,
+                                                              const uint32_t *__restrict__ key, const uint32_t *__restrict__ ids,
+                                                              int64_t total, unsigned long long *__restrict__ place) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= total) return;
+  const uint32_t qi = query_of[s], k = key[s];
+  const bool tied = (s > 0 && query_of[s - 1] == qi && key[s - 1] == k) || (s + 1 < total && query_of[s + 1] == qi && key[s + 1] == k);
+  unsigned long long v = 0ull;
+  if (tied) {
+    const uint32_t id = ids[s];
+    if (id < (uint32_t)tv.n) v = range_walk_place(tv, inv[id], q[3 * (size_t)qi], q[3 * (size_t)qi + 1], q[3 * (size_t)qi + 2]);
+  }
+  place[s] = v;
+}
+
+// Every slot of a run of ties finds its own place in the run: the number of slots of the run that the walk reaches
+// earlier.  (Independent loads, a thread per slot: a lattice cloud with every site taken several times gives runs
+// of a hundred, and a run sorted by one thread was a chain of dependent memory accesses a millisecond long.)
+__global__ __launch_bounds__(256) void range_tie_sort_kernel(const uint32_t *__restrict__ query_of, const uint32_t *__restrict__ key,
+                                                             int64_t total, const unsigned long long *__restrict__ place,
+                                                             const uint32_t *__restrict__ ids, uint32_t *__restrict__ ids_out) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= total) return;
+  const unsigned long long mine = place[s];
+  const uint32_t id = ids[s];
+  if (mine == 0ull) {  // not tied (a tied slot's place has its own digit 1 in it)
+    ids_out[s] = id;
+    return;
+  }
+  const uint32_t qi = query_of[s], k = key[s];
+  int64_t a = s, before = 0;
+  while (a > 0 && query_of[a - 1] == qi && key[a - 1] == k) {
+    a--;
+    before += place[a] <= mine ? 1 : 0;  // (equal places do not occur: one node, one place; kept stable anyway)
+  }
+  for (int64_t x = s + 1; x < total && query_of[x] == qi && key[x] == k; x++) before += place[x] < mine ? 1 : 0;
+  ids_out[a + before] = id;
+}
+
 __global__ __launch_bounds__(256) void range_iota_kernel(uint32_t *__restrict__ a, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) a[i] = (uint32_t)i;
@@ -89,6 +226,38 @@ __global__ __launch_bounds__(256) void range_widen_check_kernel(const uint32_t *
   const int32_t v = (int32_t)in[i];
   out[i] = (int64_t)v;
   if (v < 0) *bad = 1;
+}
+}  // namespace pcgx
+
+namespace pcgx {
+// PCGX_RANGE_WALK=1: the tree walk even where the handle has a grid (measurements, tests of the walk)
+static bool range_on_grid(const pcgx_kdtree *t) {
+  const char *e = getenv("PCGX_RANGE_WALK");  // (read per call: the tests switch between the two)
+  return t->grid_ok && !(e && *e && *e != '0');
+}
+
+static pcgx_status range_inverse_map(const pcgx_kdtree *tc, const uint32_t **out, hipStream_t st) {
+  pcgx_kdtree *t = const_cast<pcgx_kdtree *>(tc);  // made once per handle, on first use
+  std::lock_guard<std::mutex> lock(t->mu);
+  if (!t->d_inv) {
+    uint32_t *p = nullptr;
+    hipError_t e = dev_cache_alloc((void **)&p, (size_t)(t->n > 0 ? t->n : 1) * sizeof(uint32_t));
+    if (e != hipSuccess) return fail(PCGX_E_OOM, "range: hipMalloc for the id -> node map failed: %s", hipGetErrorString(e));
+    e = hipMemsetAsync(p, 0, (size_t)(t->n > 0 ? t->n : 1) * sizeof(uint32_t), st);
+    const TreeView tv = t->view();
+    const unsigned slots = 1u << tv.depth;
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(range_invert_nodes_kernel, dim3((slots + 255u) / 256u), dim3(256), 0, st, tv, p);
+      e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+      dev_cache_free(p);
+      return fail(PCGX_E_HIP, "range: building the id -> node map failed: %s", hipGetErrorString(e));
+    }
+    t->d_inv = p;
+  }
+  *out = t->d_inv;
+  return PCGX_OK;
 }
 }  // namespace pcgx
 
@@ -120,6 +289,10 @@ extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float
   if (patched)
     PCGX_TRY(xtree_launch_range(outer, false, d_q, perm, nq, max_range * max_range, d_c, nullptr, 0, nullptr, nullptr,
                                 nullptr, st));
+  else if (range_on_grid(t))
+    hipLaunchKernelGGL(range_grid_kernel<false>, dim3(xcd_grid((unsigned)((nq + kRangeBlock - 1) / kRangeBlock))), dim3(kRangeBlock),
+                       0, st, t->grid, (const float *)d_q, (const int32_t *)perm, nq, max_range * max_range, d_c, nullptr, 0,
+                       (uint4 *)nullptr);
   else
     hipLaunchKernelGGL(range_kernel<false>, dim3(xcd_grid((unsigned)((nq + kRangeBlock - 1) / kRangeBlock))), dim3(kRangeBlock),
                        lds, st, tv, (const float *)d_q, (const int32_t *)perm, nq, max_range * max_range, d_c, nullptr, 0,
@@ -167,10 +340,13 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
   PCGX_TRY(ar.alloc(radix_sort_workspace_bytes(total), &ws));
   PCGX_TRY(staged_upload(d_q, q, (size_t)nq * 12, st));
   PCGX_TRY(staged_upload(d_off, offsets, (size_t)(nq + 1) * 8, st));
-  // Poison the ids so that offsets inconsistent with the counts are caught below.
-  PCGX_HIP_TRY(hipMemsetAsync(d_id, 0xFF, (size_t)total * 4, st));
-  PCGX_HIP_TRY(hipMemsetAsync(d_key, 0, (size_t)total * 4, st));
-  PCGX_HIP_TRY(hipMemsetAsync(d_query, 0, (size_t)total * 4, st));
+  const bool on_grid = !patched && range_on_grid(t);
+  if (!on_grid) {
+    // Poison the ids so that offsets inconsistent with the counts are caught below.
+    PCGX_HIP_TRY(hipMemsetAsync(d_id, 0xFF, (size_t)total * 4, st));
+    PCGX_HIP_TRY(hipMemsetAsync(d_key, 0, (size_t)total * 4, st));
+    PCGX_HIP_TRY(hipMemsetAsync(d_query, 0, (size_t)total * 4, st));
+  }
   const TreeView tv = t->view();
   const size_t lds = walk_stack_bytes(tv, kRangeBlock);
   int32_t *qperm = nullptr;
@@ -181,7 +357,16 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
   if (patched)
     PCGX_TRY(xtree_launch_range(outer, true, d_q, qperm, nq, max_range * max_range, nullptr, d_off, total, d_id, d_key,
                                 d_query, st));
-  else
+  else if (on_grid) {
+    uint4 *d_rec = nullptr;
+    PCGX_TRY(ar.alloc_n((size_t)total, &d_rec));
+    PCGX_HIP_TRY(hipMemsetAsync(d_rec, 0xFF, (size_t)total * 16, st));  // (poisoned ids as above)
+    hipLaunchKernelGGL(range_grid_kernel<true>, dim3(xcd_grid((unsigned)((nq + kRangeBlock - 1) / kRangeBlock))), dim3(kRangeBlock),
+                       0, st, t->grid, (const float *)d_q, (const int32_t *)qperm, nq, max_range * max_range, nullptr, d_off, total,
+                       d_rec);
+    hipLaunchKernelGGL(range_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint4 *)d_rec, total,
+                       d_id, d_key, d_query);
+  } else
     hipLaunchKernelGGL(range_kernel<true>, dim3(xcd_grid((unsigned)((nq + kRangeBlock - 1) / kRangeBlock))), dim3(kRangeBlock),
                        lds, st, tv, d_q, (const int32_t *)qperm, nq, max_range * max_range, nullptr, d_off, total, d_id,
                        d_key, d_query);
@@ -203,6 +388,19 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
                      d_out_id);
   hipLaunchKernelGGL(range_gather_u32_kernel, dim3(tb), dim3(256), 0, st, d_key, perm, total, d_out_key);
   PCGX_HIP_TRY(hipGetLastError());
+  if (on_grid) {  // equal DistSq of one query: into the walk's order (k2[r2]: the query of every sorted slot)
+    const uint32_t *d_inv = nullptr;
+    PCGX_TRY(range_inverse_map(t, &d_inv, st));
+    unsigned long long *d_place = nullptr;
+    PCGX_TRY(ar.alloc_n((size_t)total, &d_place));
+    hipLaunchKernelGGL(range_tie_place_kernel, dim3(tb), dim3(256), 0, st, tv, d_inv, (const float *)d_q, (const uint32_t *)k2[r2],
+                       (const uint32_t *)d_out_key, (const uint32_t *)d_out_id, total, d_place);
+    // (into d_id: the discovery-order ids are done with)
+    hipLaunchKernelGGL(range_tie_sort_kernel, dim3(tb), dim3(256), 0, st, (const uint32_t *)k2[r2], (const uint32_t *)d_out_key, total,
+                       (const unsigned long long *)d_place, (const uint32_t *)d_out_id, (uint32_t *)d_id);
+    PCGX_HIP_TRY(hipGetLastError());
+    d_out_id = (uint32_t *)d_id;
+  }
   // Go's int is 64 bits wide: widened (and checked: a poisoned id means the caller's offsets do not match the
   // counts) on the device, straight into the caller's slice
   int64_t *d_ids64 = nullptr;

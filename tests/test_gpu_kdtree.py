@@ -155,6 +155,48 @@ def test_range_batch_vs_oracle(n, nq, max_range):
         assert offs[i + 1] - offs[i] == int(np.sum(dn < f32(max_range) * f32(max_range)))
 
 
+@pytest.mark.parametrize("kind", ["uniform", "lattice", "surface"])
+def test_range_on_the_grid_equals_the_walk(kind, monkeypatch):
+    """Range collects the neighbours from the handle's uniform grid and puts equal DistSq of one query into the
+    walk's discovery order afterwards (csrc/range.hip); PCGX_RANGE_WALK=1 runs the reference's walk
+    (kdtree.go:148-197) instead.  Every offset, id and DistSq of the two must agree -- clouds with thousands of
+    exact ties and repeated points included -- and so must odd queries (NaN, inf, far outside, radius 0 / huge)."""
+    rng = np.random.default_rng(77)
+    n, nq = 120_000, 30_000
+    if kind == "uniform":
+        base = synth.uniform_cloud(n, 10.0, 5)
+        q = synth.uniform_cloud(nq, 10.0, 6)
+        radii = [0.25, 0.0, 1.0e-3]
+    elif kind == "lattice":  # integer lattice, every site several times: ties everywhere
+        base = rng.integers(0, 24, size=(n, 3)).astype(f32)
+        q = (rng.integers(0, 48, size=(nq, 3)).astype(f32) * f32(0.5))
+        radii = [1.6, 1.0]
+    else:  # a thin sheet: crowded cells, empty cells
+        base = np.stack([rng.uniform(0, 10, n), rng.uniform(0, 10, n), rng.normal(0, 0.01, n)], axis=1).astype(f32)
+        q = np.stack([rng.uniform(-1, 11, nq), rng.uniform(-1, 11, nq), rng.normal(0, 0.05, nq)], axis=1).astype(f32)
+        radii = [0.1, 3.0e38]
+    q[0] = [np.nan, 1.0, 1.0]
+    q[1] = [np.inf, 0.0, 0.0]
+    q[2] = [1.0e30, -1.0e30, 5.0]
+    q[3] = base[17]
+    t = kdtree.New(base)
+    for r in radii:
+        if r > 1.0e30:
+            qq = q[:40]  # (every point is a neighbour)
+        else:
+            qq = q
+        monkeypatch.delenv("PCGX_RANGE_WALK", raising=False)
+        og, ig, dg = t.RangeBatch(qq, r)
+        monkeypatch.setenv("PCGX_RANGE_WALK", "1")
+        ow, iw, dw = t.RangeBatch(qq, r)
+        monkeypatch.delenv("PCGX_RANGE_WALK", raising=False)
+        assert np.array_equal(og, ow), (kind, r)
+        assert np.array_equal(dg.view(np.uint32), dw.view(np.uint32)), (kind, r)
+        assert np.array_equal(ig, iw), (kind, r, int(np.sum(ig != iw)))
+        if kind == "lattice":
+            assert len(ig) > 10 * len(qq)  # (the case is about ties: make sure there are neighbours at all)
+
+
 def test_range_fill_rejects_wrong_offsets():
     import ctypes as C
     from pcgol_amd import _lib as L
