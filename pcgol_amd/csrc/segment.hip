@@ -25,7 +25,6 @@
 #include <unordered_set>
 #include <vector>
 
-#include "knn_grid.h"
 #include "range_walk.h"
 
 namespace pcgx {
@@ -247,33 +246,6 @@ __global__ __launch_bounds__(kRangeWalkBlock) void rg_union_kernel(TreeView tv, 
   range_walk(tv, s_stack + threadIdx.x, kRangeWalkBlock, nd.x, nd.y, nd.z, bound, [&](int32_t j, float) {
     if (j < id && labels[j] == mine) uf_union(parent, (uint32_t)id, (uint32_t)j);
   });
-}
-
-// The same over the handle's uniform grid (knn_grid.h): one lane per point, the neighbourhood read out of the
-// cells grid_cover names.  A union-find does not care in which order it is told the edges, and which points lie
-// within maxRange does not depend on the walk (range.hip).
-__global__ __launch_bounds__(256) void rg_union_grid_kernel(GridView g, int64_t n, const uint32_t *__restrict__ labels, float bound,
-                                                            uint32_t *__restrict__ parent) {
-  const int64_t f0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (f0 >= n) return;
-  const float4 me = g.pts[f0];
-  const uint32_t id = __float_as_uint(me.w);
-  const uint32_t mine = labels[id];
-  const GridBox box = grid_cover(g, me.x, me.y, me.z, bound);
-  for (int z = box.z0; z <= box.z1; z++) {
-    for (int y = box.y0; y <= box.y1; y++) {
-      const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
-      uint32_t f = g.start[row + (uint32_t)box.x0];
-      const uint32_t e = g.start[row + (uint32_t)box.x1 + 1u];
-      for (; f < e; f++) {
-        const float4 p = g.pts[f];
-        const float dx = p.x - me.x, dy = p.y - me.y, dz = p.z - me.z;
-        const float d = (dx * dx + dy * dy) + dz * dz;  // (mat/vec3.go:18-20,38-40, as in the walk)
-        const uint32_t j = __float_as_uint(p.w);
-        if (d < bound && j < id && labels[j] == mine) uf_union(parent, id, j);
-      }
-    }
-  }
 }
 
 }  // namespace pcgx
@@ -651,14 +623,9 @@ extern "C" pcgx_status pcgx_region_growing_components(const pcgx_kdtree *t, cons
   hipLaunchKernelGGL(uf_init_kernel, dim3(nb), dim3(256), 0, st, d_parent, n);
   const TreeView tv = t->view();
   const uint32_t slots = 1u << tv.depth;
-  const char *walk_env = getenv("PCGX_RANGE_WALK");  // (as in range.hip: the walk although the handle has a grid)
-  if (t->grid_ok && !(walk_env && *walk_env && *walk_env != '0'))
-    hipLaunchKernelGGL(rg_union_grid_kernel, dim3((unsigned)((t->n + 255) / 256)), dim3(256), 0, st, t->grid, t->n,
-                       (const uint32_t *)d_labels, max_range * max_range, d_parent);
-  else
-    hipLaunchKernelGGL(rg_union_kernel, dim3((slots + kRangeWalkBlock - 1) / kRangeWalkBlock), dim3(kRangeWalkBlock),
-                       walk_stack_bytes(tv, kRangeWalkBlock), st, tv, (const uint32_t *)d_labels, max_range * max_range,
-                       d_parent);
+  hipLaunchKernelGGL(rg_union_kernel, dim3((slots + kRangeWalkBlock - 1) / kRangeWalkBlock), dim3(kRangeWalkBlock),
+                     walk_stack_bytes(tv, kRangeWalkBlock), st, tv, (const uint32_t *)d_labels, max_range * max_range,
+                     d_parent);
   hipLaunchKernelGGL(uf_flatten_kernel, dim3(nb), dim3(256), 0, st, d_parent, n, d_root);
   PCGX_HIP_TRY(hipGetLastError());
   std::vector<uint32_t> h((size_t)n);
