@@ -39,7 +39,10 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *__restrict__ parent, uint3
     const uint32_t p = uf_load(parent + x);
     if (p == x) return x;
     const uint32_t gp = uf_load(parent + p);
-    if (gp != p) atomicMin(parent + x, gp);  // path halving
+    // path halving with a plain store: whatever another thread writes here at the same time is an ancestor of x
+    // too (parents only ever move towards the root), so either value keeps the structure -- and an atomic per hop
+    // is what the finds used to cost
+    if (gp != p) __atomic_store_n(parent + x, gp, __ATOMIC_RELAXED);
     x = p;
   }
 }
@@ -243,8 +246,15 @@ __global__ __launch_bounds__(kRangeWalkBlock) void rg_union_kernel(TreeView tv, 
   const float4 nd = node_at(tv.nodes, b);
   const int32_t id = __float_as_int(nd.w);
   const uint32_t mine = labels[id];
+  uint32_t my_root = (uint32_t)id;  // (a root this point was seen under: most neighbours are under it already)
   range_walk(tv, s_stack + threadIdx.x, kRangeWalkBlock, nd.x, nd.y, nd.z, bound, [&](int32_t j, float) {
-    if (j < id && labels[j] == mine) uf_union(parent, (uint32_t)id, (uint32_t)j);
+    if (j < id && labels[j] == mine) {
+      const uint32_t rj = uf_find(parent, (uint32_t)j);
+      if (rj != my_root) {
+        uf_union(parent, my_root, rj);
+        my_root = uf_find(parent, my_root);
+      }
+    }
   });
 }
 
