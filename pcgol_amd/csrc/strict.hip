@@ -116,6 +116,28 @@ __device__ __forceinline__ uint32_t serial_leaves(uint32_t s, const float4 *R, i
   return f2u(x);
 }
 
+// The same chain from kPerLane start states per lane: independent additions per term fill the pipeline a single
+// dependent chain leaves idle (tools/micro/dep_add.cpp: 4.9 ns per term for four against 2.6 for one).
+constexpr int kCandPerLane = kCandInner / kLanes;
+__device__ __forceinline__ void serial_leaves_n(float (&x)[kCandPerLane], const float4 *R, int l0, int l1) {
+  for (int l = l0; l < l1; l++) {  // uniform
+    float4 a[8];
+#pragma unroll
+    for (int v = 0; v < 8; v++) a[v] = R[tile_quad(l, v)];
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+#pragma unroll
+      for (int c = 0; c < kCandPerLane; c++) x[c] = x[c] + a[v].x;
+#pragma unroll
+      for (int c = 0; c < kCandPerLane; c++) x[c] = x[c] + a[v].y;
+#pragma unroll
+      for (int c = 0; c < kCandPerLane; c++) x[c] = x[c] + a[v].z;
+#pragma unroll
+      for (int c = 0; c < kCandPerLane; c++) x[c] = x[c] + a[v].w;
+    }
+  }
+}
+
 // Row `row` of `tile` formed again from the pairs and staged in lds (layout of tile_quad): the chain
 // kernel's way to a tile that owns no slot (rare).  One wave: eight rounds of 64 consecutive quads
 // (coalesced loads), two rounds in flight.
@@ -407,13 +429,15 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
 // the tile's record, wave 1 backwards (level crossing: the chain kernel finds the leaf that does not
 // cover the state in one parallel step and carries on behind it), or wave 0 alone composes the runs of
 // leaves under equal windows (no window: the chain kernel applies a run's last record).
-constexpr int kJobBlock = 256;
+constexpr int kJobBlock = 512;  // waves 0..3: a class each, then the scans; waves 4..7: candidate chains
 __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *__restrict__ state, StrictWork W) {
   __shared__ float4 s_t[kTile / 4];
   __shared__ int32_t s_S[12][kLanes];  // class pieces c[4] | lo[4] | hi[4] per leaf
   __shared__ uint32_t s_g[kLanes];     // the leaves' guesses
   __shared__ int32_t s_lk[kLanes];     // and the windows they are summarised under
   __shared__ int32_t s_hdr[4];         // the tile's window, guess at its start, end of its last guess chain, "the chains join up"
+  __shared__ uint32_t s_ctab[4][kCandInner];  // waves 4..7: the ends of their quarter's candidates
+  __shared__ int s_cdone;
   if (state->done) return;
   const unsigned per_shard = (unsigned)W.naux / kAuxShards;
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -426,6 +450,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   for (unsigned k = blockIdx.x % per_wg; k < used; k += per_wg) {  // uniform
   const unsigned slot = shard * per_shard + k;
   __syncthreads();  // (the LDS of the slot before this one is done with)
+  if (threadIdx.x == 0) s_cdone = 0;
   const JobDesc *J = W.jobs + slot;
   const float4 *src4 = W.aux_terms + (size_t)slot * (kTile / 4);
   for (int i = threadIdx.x; i < kTile / 4; i += kJobBlock) s_t[i] = src4[i];
@@ -490,7 +515,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   const int32_t lk = s_lk[lane];
   const int32_t tkey = s_hdr[0];
   const int kind = tkey >= 0 ? JOB_CROSSING : JOB_NOWINDOW;
-  {
+  if (part < 4) {
     int32_t c, lo, hi;
     leaf_class_piece_q(LdsQuads{s_t, lane}, g, lk, part, c, lo, hi);
     s_S[part][lane] = c;
@@ -498,37 +523,79 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     s_S[8 + part][lane] = hi;
   }
   __syncthreads();
+  // ---- the tile's additions carried out from candidate start states (strict_terms.h), by the waves with nothing
+  // else to do.  A tile without a window costs the chain kernel 6-8 us however its leaves are summarised (a dozen
+  // leaf runs to apply, a dozen leaves to add term by term), a level crossing whose record does not cover the state
+  // 1-2 us; if the walker's state is one of the candidates the tile is a look-up.  Four candidates per lane: four
+  // independent chains cost 1.9x one (tools/micro/dep_add.cpp).
   if (kind == JOB_NOWINDOW && part >= 1) {
-    // ---- waves 1..3 of a tile without a window: the tile's 2048 additions carried out from kCand candidate
-    // start states (strict_terms.h, cand_offset), every lane two of them (packed float32 adds), the terms
-    // broadcast out of LDS.  Such a tile costs the chain kernel 6-8 us however its leaves are summarised (a
-    // dozen leaf runs to apply, a dozen leaves to add term by term); here the additions cost the same few
-    // microseconds, but next to every other job of the launch instead of on the walk.  If the walker's state
-    // is one of the candidates the tile is a look-up.
-    typedef float v2f __attribute__((ext_vector_type(2)));
+    // no window: waves 1..3, the whole tile from 768 candidates around the tile's guess (10 us: the launch is that
+    // much longer in the few iterations that have such tiles; cut into quarters like a level crossing below, a
+    // third of these tiles were lost where one quarter's end fell outside the next quarter's candidates)
+    if (part >= 4) continue;
     const uint32_t g0 = (uint32_t)s_hdr[1];
     const uint32_t mag = g0 & 0x7fffffffu;
-    const int i0 = (part - 1) * 2 * kLanes + lane;  // candidates i0 and i0 + 64
-    uint32_t out0 = 0x7fc00000u, out1 = 0x7fc00000u;  // "no table"
+    uint32_t out[kCandPerLane];
+#pragma unroll
+    for (int c = 0; c < kCandPerLane; c++) out[c] = 0x7fc00000u;  // "no table"
+    const int i0 = (part - 1) * kCandInner + lane;
     if (mag > kCandReach && mag < 0x7f800000u - kCandReach) {  // uniform
-      v2f x = {u2f(g0 + (uint32_t)cand_offset(i0)), u2f(g0 + (uint32_t)cand_offset(i0 + kLanes))};
-      for (int l = 0; l < kLanes; l++) {  // uniform
-        float4 a[kLeaf / 4];
+      float x[kCandPerLane];
 #pragma unroll
-        for (int v = 0; v < kLeaf / 4; v++) a[v] = s_t[tile_quad(l, v)];
+      for (int c = 0; c < kCandPerLane; c++) x[c] = u2f(g0 + (uint32_t)cand_offset(i0 + c * kLanes));
+      serial_leaves_n(x, s_t, 0, kLanes);
 #pragma unroll
-        for (int v = 0; v < kLeaf / 4; v++) {
-          x = x + (v2f){a[v].x, a[v].x};
-          x = x + (v2f){a[v].y, a[v].y};
-          x = x + (v2f){a[v].z, a[v].z};
-          x = x + (v2f){a[v].w, a[v].w};
-        }
-      }
-      out0 = f2u(x.x);
-      out1 = f2u(x.y);
+      for (int c = 0; c < kCandPerLane; c++) out[c] = f2u(x[c]);
     }
-    W.cand[(size_t)slot * kCand + i0] = out0;
-    W.cand[(size_t)slot * kCand + i0 + kLanes] = out1;
+#pragma unroll
+    for (int c = 0; c < kCandPerLane; c++) W.cand[(size_t)slot * kCand + i0 + c * kLanes] = out[c];
+    continue;
+  }
+  if (part >= 4) {
+    // level crossing: 2048 dependent additions are 6-10 us -- longer than anything else this launch does -- so
+    // waves 4..7 take a QUARTER of the tile each: 16 leaves from the 256 candidates around that quarter's first
+    // leaf's guess, and wave 4 strings the quarters' tables together: a candidate's end in one quarter is looked up
+    // among the candidates of the next (the guesses of such a tile agree with one another to a few floats: they
+    // were refined by the chains' own rounding errors)
+    const int k = part - 4;
+    const uint32_t gk = s_g[k * (kLanes / 4)];
+    const uint32_t mag = gk & 0x7fffffffu;
+    constexpr int kMid = (kCand - kCandInner) / 2;  // the table's entries [kMid, kMid + kCandInner)
+    uint32_t out[kCandPerLane];
+#pragma unroll
+    for (int c = 0; c < kCandPerLane; c++) out[c] = 0x7fc00000u;  // "no table"
+    if (mag > kCandReach && mag < 0x7f800000u - kCandReach) {  // uniform
+      float x[kCandPerLane];
+#pragma unroll
+      for (int c = 0; c < kCandPerLane; c++) x[c] = u2f(gk + (uint32_t)cand_offset(kMid + c * kLanes + lane));
+      serial_leaves_n(x, s_t, k * (kLanes / 4), (k + 1) * (kLanes / 4));
+#pragma unroll
+      for (int c = 0; c < kCandPerLane; c++) out[c] = f2u(x[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < kCandPerLane; c++) s_ctab[k][c * kLanes + lane] = out[c];
+    if (k == 1 || k == 2) {  // the table's entries below / above the middle: none
+#pragma unroll
+      for (int c = 0; c < kCandPerLane; c++)
+        W.cand[(size_t)slot * kCand + (k == 1 ? 0 : kMid + kCandInner) + c * kLanes + lane] = 0x7fc00000u;
+    }
+    lds_fence_wave();
+    if (lane == 0) __hip_atomic_fetch_add(&s_cdone, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k != 0) continue;
+    while (__hip_atomic_load(&s_cdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+    for (int c = 0; c < kCandPerLane; c++) {
+      uint32_t v = out[c];
+#pragma unroll
+      for (int q = 1; q < 4; q++) {
+        const uint32_t gq = s_g[q * (kLanes / 4)];
+        const int32_t idx = (int32_t)((v & 0x7fffffffu) - (gq & 0x7fffffffu)) + kCandInner / 2;
+        const bool ok = (v & 0x7f800000u) != 0x7f800000u && ((v ^ gq) >> 31) == 0u && idx >= 0 && idx < kCandInner;
+        const uint32_t next = s_ctab[q][ok ? idx : 0];
+        v = ok ? next : 0x7fc00000u;  // (a quarter without a table holds NaNs: they carry through)
+      }
+      W.cand[(size_t)slot * kCand + kMid + c * kLanes + lane] = v;
+    }
     continue;
   }
   if (part >= 2) continue;
@@ -923,7 +990,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         // ends of candidates c, 64 + c, 128 + c, ...
         uint32_t cand_out[kCand / kLanes];
         const uint32_t g0 = (uint32_t)s_rec[1][cur_tile];
-        const bool have_cand = cur_kind == JOB_NOWINDOW && !(W.selfcheck & 4);  // uniform
+        const bool have_cand = !(W.selfcheck & 4);  // uniform
 #pragma unroll
         for (int j = 0; j < kCand / kLanes; j++) {
           cand_out[j] = have_cand ? W.cand[(size_t)slot * kCand + j * kLanes + lane] : 0x7fc00000u;
@@ -983,7 +1050,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             lds_put(&s_mail[wave].ack, k + 1);
             // (counters only behind the release: it waits for every memory operation of this wave before it)
             if (cur_kind == JOB_NOWINDOW) atomicAdd(&W.dbg[24], 1ull);
-            if (hit) atomicAdd(&W.dbg[hit_kind], 1ull);
+            if (hit) atomicAdd(&W.dbg[cur_kind == JOB_NOWINDOW ? hit_kind : 45], 1ull);
             if (!hit && have_cand) {  // measurement aid: how far off the guess was (log2 of the distance in floats)
               const uint32_t m = s_in & 0x7fffffffu, gm = g0 & 0x7fffffffu;
               const uint32_t dist = m > gm ? m - gm : gm - m;

@@ -41,14 +41,16 @@ struct JobDesc {  // a (row, tile) that crosses a level or has no window: strict
 // served one after the other -- the last job of a launch waited 30-40 us for its slot number.
 constexpr int kAuxShards = 64;
 
-// Candidate start states of a tile without a window (strict.hip, strict_job_kernel): candidate i stands
-// cand_offset(i) floats above the tile's guessed start state in magnitude -- every float within 192 of the
-// guess.  (Measured: wider, sparser candidates with "a state between two candidates that end in the same float
-// ends there too" -- x -> fl(x + t) is monotone -- caught one tile in ten of those the dense ones missed: around
-// a guess the tile's map is one-to-one nearly everywhere.  The guess of a tile behind other such tiles is 30-100
-// floats off, because their rounding errors are only known approximately.)
-constexpr int kCand = 384;
-constexpr uint32_t kCandReach = 256u;  // > |cand_offset|: the guess must be that far from zero (and from infinity)
+// Candidate start states of a job tile (strict.hip, strict_job_kernel): candidate i stands cand_offset(i) floats above
+// the tile's guessed start state in magnitude.  The table has room for every float within 384 of the guess; a level
+// crossing fills the 256 in the middle (its guess is a few floats off), a tile without a window all of it (the guess
+// of a tile behind other such tiles is 30-100 floats off: their rounding errors are only known approximately).
+// (Measured: wider, sparser candidates with "a state between two candidates that end in the same float ends there
+// too" -- x -> fl(x + t) is monotone -- caught one tile in ten of those the dense ones missed: around a guess the
+// tile's map is one-to-one nearly everywhere.)
+constexpr int kCand = 768;
+constexpr int kCandInner = 256;        // what one wave carries: four candidates per lane
+constexpr uint32_t kCandReach = 512u;  // > |cand_offset|: the guess must be that far from zero (and from infinity)
 __host__ __device__ __forceinline__ int32_t cand_offset(int i) { return i - kCand / 2; }
 
 struct StrictWork {
@@ -60,7 +62,7 @@ struct StrictWork {
   LeafAux *aux;                 // [naux][64]: what the chain kernel needs to recompute a tile that owns a slot
   float4 *aux_terms;            // [naux][512]: that tile's terms (layout of tile_quad)
   struct JobDesc *jobs;         // [naux]: what strict_job_kernel needs to know about the slot's tile
-  uint32_t *cand;               // [naux][kCand]: a tile without a window carried out from kCand start states (cand_offset)
+  uint32_t *cand;               // [naux][kCand]: the tile carried out from kCand start states (cand_offset)
   unsigned int *aux_count;      // [kAuxShards] x 32 words: slots handed out this iteration, per shard (zeroed by the chain kernel)
   unsigned int *done_rows;      // rows of the chain kernel that have finished (ticket of the fused update)
   unsigned long long *dbg;      // [64] counters (measurement aid)
