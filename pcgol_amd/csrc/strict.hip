@@ -880,6 +880,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   __shared__ int s_sufok[kChainSegs];
   __shared__ int s_progress;               // walker: the tile it stands at (tiles below are done)
   __shared__ ChainMail s_mail[kChainSegs];
+  __shared__ uint32_t s_tab[kHelpers][kCand];  // helper h: the candidate table of the tile it holds (strict_job_kernel)
+  __shared__ int s_tab_ord[kHelpers];          // ... and that tile's ordinal + 1 (0: none yet)
   __shared__ float4 s_tile[kTile / 4];     // walker: the terms of a tile without a slot, formed again from the pairs
   __shared__ unsigned long long s_np[kChainSegs];
   if (state->done) return;
@@ -889,13 +891,14 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   uint32_t s = f2u(0.0f);  // walker state, evaluator.go:122: the sums start at zero
   // walker: counters of the whole row, written once behind the last chunk (an atomic in flight holds up the
   // next release store of its wave, and the walk is a chain of those)
-  unsigned long long n_run = 0, n_runfail = 0, n_recfail = 0, ticks_scan = 0, ticks_walk = 0;
+  unsigned long long n_run = 0, n_runfail = 0, n_recfail = 0, ticks_scan = 0, ticks_walk = 0, n_tab_nw = 0, n_tab_cross = 0;
   for (int64_t chunk = 0; chunk < W.ntiles; chunk += kChainTiles) {
     const long long t_a = stat_clock(W);
     if (threadIdx.x < kChainSegs) {
       s_sufok[threadIdx.x] = 0;
       s_mail[threadIdx.x].req = 0;
       s_mail[threadIdx.x].ack = 0;
+      if (threadIdx.x < kHelpers) s_tab_ord[threadIdx.x] = 0;
     }
     if (threadIdx.x == 0) s_progress = 0;
     // ---- helpers: runs of equal windows, segmented scan forwards inside each wave
@@ -995,6 +998,12 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         for (int j = 0; j < kCand / kLanes; j++) {
           cand_out[j] = have_cand ? W.cand[(size_t)slot * kCand + j * kLanes + lane] : 0x7fc00000u;
         }
+        // the table goes to LDS, where the walker looks its state up by itself (a hand-over through the mailbox is
+        // 1.5-2.5 us: the helper's turn-around and two polling latencies); the mailbox is for states not in it
+#pragma unroll
+        for (int j = 0; j < kCand / kLanes; j++) s_tab[wave][j * kLanes + lane] = cand_out[j];
+        lds_fence_wave();
+        if (lane == 0) lds_put(&s_tab_ord[wave], k + 1);
         bool serve = false;
         while (true) {
           if (lds_get(&s_mail[wave].req) == k + 1) {
@@ -1139,7 +1148,22 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
               n_recfail++;
               const int ord = s_auxord[f];
               if (lane == 0) lds_put(&s_progress, f);
-              if (ord >= 0) {  // its helper has the tile's terms and leaf records at hand
+              bool from_table = false;
+              if (ord >= 0 && lds_get(&s_tab_ord[ord % kHelpers]) == ord + 1) {  // the tile's candidate table is up
+                const uint32_t g0 = (uint32_t)s_rec[1][f];
+                const int32_t idx = (int32_t)((s & 0x7fffffffu) - (g0 & 0x7fffffffu)) + kCand / 2;
+                if (((s ^ g0) >> 31) == 0u && idx >= 0 && idx < kCand) {
+                  const uint32_t v = s_tab[ord % kHelpers][idx];
+                  if ((v & 0x7f800000u) != 0x7f800000u) {  // (NaN: no such candidate)
+                    s = v;
+                    from_table = true;
+                    if (T.key >= 0) n_tab_cross++;
+                    else n_tab_nw++;
+                  }
+                }
+              }
+              if (from_table) {
+              } else if (ord >= 0) {  // its helper has the tile's terms and leaf records at hand
                 ChainMail *M = &s_mail[ord % kHelpers];
                 if (lane == 0) {
                   __hip_atomic_store(&M->s_in, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1149,10 +1173,6 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
                 }
                 s = (uint32_t)rfl((int)__hip_atomic_load(&M->s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
               } else {  // a tile without a slot: its terms are formed again from the pairs, all 2048 are added
-                if (lane == 0) {  // (measurement aid: which tile, under which record)
-                  atomicMax(&W.dbg[45], (unsigned long long)(chunk + f));
-                  atomicMax(&W.dbg[47], ((unsigned long long)T.in << 32) | s);
-                }
                 const long long t_begin = stat_clock(W);
                 recompute_tile_to_lds(src, row, chunk + f, lane, s_tile);
                 LeafAux none;
@@ -1194,6 +1214,9 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     atomicMax(&W.dbg[14 + 32], ticks_walk);   // slowest row of the launch
     atomicAdd(&W.dbg[27 + row], ticks_walk);  // per row: walk ticks, tiles resolved
     atomicAdd(&W.dbg[36 + row], n_recfail);
+    atomicAdd(&W.dbg[24], n_tab_nw);  // tiles without a window seen, and found in their candidate tables
+    atomicAdd(&W.dbg[25], n_tab_nw);
+    atomicAdd(&W.dbg[45], n_tab_cross);
   }
   // the pair count of the iteration: row 0 adds up the tiles' counts (a fixed order is not needed: integers)
   if (row == 0) {
