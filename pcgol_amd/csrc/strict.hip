@@ -116,27 +116,40 @@ __device__ __forceinline__ uint32_t serial_leaves(uint32_t s, const float4 *R, i
   return f2u(x);
 }
 
-// The same chain from kPerLane start states per lane: independent additions per term fill the pipeline a single
-// dependent chain leaves idle (tools/micro/dep_add.cpp: 4.9 ns per term for four against 2.6 for one).
-constexpr int kCandPerLane = kCandInner / kLanes;
-__device__ __forceinline__ void serial_leaves_n(float (&x)[kCandPerLane], const float4 *R, int l0, int l1) {
+// The chain of leaves l0 .. l1 - 1 from kN start states per lane (every lane the same terms), out of a LINEAR copy of
+// the tile's terms (L[8 l + v] = quad v of leaf l): eight reads at one base register plus immediate offsets per
+// leaf, a leaf ahead of the additions, and 32 x kN plain v_add_f32.  Out of the swizzled layout (serial_leaves
+// above) the compiler sets up 28 addresses and reads per leaf in a block in front of the 32 dependent additions:
+// 0.18 us per leaf where the additions alone are 0.08 (a dependent v_add_f32 issues every 6 cycles,
+// tools/micro/dep_add.cpp); terms as v_readlane scalars, or taken from a lane of the own quad by DPP: the same 0.18.
+// kN > 1: independent additions per term fill that pipeline -- four start states cost 1.9x one.
+template <int kN>
+__device__ __forceinline__ void serial_leaves_lin(float (&x)[kN], const float4 *L, int l0, int l1) {
+  if (l0 >= l1) return;
+  float4 a[kLeaf / 4];
+#pragma unroll
+  for (int v = 0; v < kLeaf / 4; v++) a[v] = L[8 * l0 + v];
   for (int l = l0; l < l1; l++) {  // uniform
-    float4 a[8];
+    const int ln = l + 1 < l1 ? l + 1 : l;
+    float4 b[kLeaf / 4];
 #pragma unroll
-    for (int v = 0; v < 8; v++) a[v] = R[tile_quad(l, v)];
+    for (int v = 0; v < kLeaf / 4; v++) b[v] = L[8 * ln + v];
 #pragma unroll
-    for (int v = 0; v < 8; v++) {
+    for (int v = 0; v < kLeaf / 4; v++) {
 #pragma unroll
-      for (int c = 0; c < kCandPerLane; c++) x[c] = x[c] + a[v].x;
+      for (int c = 0; c < kN; c++) x[c] = x[c] + a[v].x;
 #pragma unroll
-      for (int c = 0; c < kCandPerLane; c++) x[c] = x[c] + a[v].y;
+      for (int c = 0; c < kN; c++) x[c] = x[c] + a[v].y;
 #pragma unroll
-      for (int c = 0; c < kCandPerLane; c++) x[c] = x[c] + a[v].z;
+      for (int c = 0; c < kN; c++) x[c] = x[c] + a[v].z;
 #pragma unroll
-      for (int c = 0; c < kCandPerLane; c++) x[c] = x[c] + a[v].w;
+      for (int c = 0; c < kN; c++) x[c] = x[c] + a[v].w;
     }
+#pragma unroll
+    for (int v = 0; v < kLeaf / 4; v++) a[v] = b[v];
   }
 }
+constexpr int kCandPerLane = kCandInner / kLanes;
 
 // Row `row` of `tile` formed again from the pairs and staged in lds (layout of tile_quad): the chain
 // kernel's way to a tile that owns no slot (rare).  One wave: eight rounds of 64 consecutive quads
@@ -271,6 +284,7 @@ __device__ __forceinline__ void tile_guesses_pair(const LdsQuads &q, double base
 // tiles where a sum hovers around zero are not the first ones)
 constexpr int kExactTiles = 1;
 constexpr uint32_t kPlainMargin = 512u;
+constexpr uint32_t kMaybeMargin = 1u << 17;  // 1.6 % of a binade at either end: ~3 % of the plain tiles
 
 // One workgroup per tile, one wave per row.  The workgroup forms the tile's terms ONCE, into LDS (72 KB:
 // the CDNA4-sized LDS is what lets nine rows of 2048 terms sit next to each other, two workgroups per
@@ -372,6 +386,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     // that drifts by 10^4 floats (C4's first iteration, where every term of a gradient sum has the same sign)
     // still loses the one or two tiles in which it passes a binade end.
     const uint32_t m_lo = mn & 0x7fffffu, m_hi = mx & 0x7fffffu;
+    int32_t maybe_E = -1;  // >= 0: a plain tile (of that binade) that is a job as well
     if (!first && key >= 0 && (mn >> 23) == (mx >> 23) && m_lo >= kPlainMargin && m_hi <= 0x7fffffu - kPlainMargin) {  // uniform
       const uint32_t E = mn >> 23;
       Par S = leaf_parity_summary_pair(g, cr, crb, E, g_first >> 31);
@@ -388,7 +403,12 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
       }
       T.s = par_expand(S, E, key);
       if (lane == 0) W.recs[row * W.ntiles + tile] = T;
-      continue;
+      // Within kMaybeMargin of an end the tile is ALSO handed to strict_job_kernel, which knows how far the chain has
+      // drifted from the float64 sums by this tile (the prefix of the tiles' rounding errors: 10^4 floats in C4's
+      // first iteration, where every term of a gradient sum has the same sign) and replaces this record by a level
+      // crossing's if the corrected guesses say the tile leaves the binade, or lies in the other one.
+      maybe_E = (m_lo < kMaybeMargin || m_hi > 0x7fffffu - kMaybeMargin) ? (int32_t)E : -1;
+      if (maybe_E < 0) continue;
     }
     // The tile crosses a level -- this is where a record is most likely not to cover the true state (a
     // landing next to the level) -- or no window holds it (its sum changes sign, or runs through three
@@ -396,22 +416,26 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     // the leaves, five times the work of a plain one and what the launch used to wait for: it becomes a
     // JOB of strict_job_kernel (a workgroup of its own), with its guesses, windows and terms.
     unsigned slot = 0xffffffffu;
-    const unsigned shard = (unsigned)(tile % kAuxShards), per_shard = (unsigned)W.naux / kAuxShards;
+    // (the sums' jobs of one tile in different shards: the first tile is a job of every sum)
+    const unsigned shard = (unsigned)((tile + 7 * row) % kAuxShards), per_shard = (unsigned)W.naux / kAuxShards;
     if (lane == 0) {
       const unsigned k = atomicAdd(&W.aux_count[shard * 32], 1u);
       slot = k < per_shard ? shard * per_shard + k : 0xffffffffu;
     }
     slot = (unsigned)rfl((int)slot);
     if (slot == 0xffffffffu) {  // no slot left (never seen): the chain kernel recomputes the tile from the pairs
-      T.key = -1;    // (the first tile as well: its walk starts at 0.0f)
-      T.cons = 0;
-      if (lane == 0) W.recs[row * W.ntiles + tile] = T;
+      if (maybe_E < 0) {
+        T.key = -1;    // (the first tile as well: its walk starts at 0.0f)
+        T.cons = 0;
+        if (lane == 0) W.recs[row * W.ntiles + tile] = T;
+      }
       continue;
     }
     if (lane == 0) {
       JobDesc *J = W.jobs + slot;
       J->row = row;
       J->tile = tile;
+      J->pad = maybe_E >= 0 ? (1 | (maybe_E << 8)) : 0;
     }
     float4 *dst = W.aux_terms + (size_t)slot * (kTile / 4);
 #pragma unroll
@@ -431,38 +455,43 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
 // leaves under equal windows (no window: the chain kernel applies a run's last record).
 constexpr int kJobBlock = 512;  // waves 0..3: a class each, then the scans; waves 4..7: candidate chains
 __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *__restrict__ state, StrictWork W) {
-  __shared__ float4 s_t[kTile / 4];
+  __shared__ float4 s_t[kTile / 4];    // the tile's terms, a leaf per lane (tile_quad)
+  __shared__ float4 s_lin[kTile / 4];  // ... and leaf after leaf, for the chains that add them up one after the other
   __shared__ int32_t s_S[12][kLanes];  // class pieces c[4] | lo[4] | hi[4] per leaf
   __shared__ uint32_t s_g[kLanes];     // the leaves' guesses
   __shared__ int32_t s_lk[kLanes];     // and the windows they are summarised under
-  __shared__ int32_t s_hdr[4];         // the tile's window, guess at its start, end of its last guess chain, "the chains join up"
+  __shared__ int32_t s_hdr[5];         // the tile's window, guess at its start, end of its last guess chain, "the chains join up", "the plain record stands"
   __shared__ uint32_t s_ctab[4][kCandInner];  // waves 4..7: the ends of their quarter's candidates
   __shared__ int s_cdone;
   if (state->done) return;
   const unsigned per_shard = (unsigned)W.naux / kAuxShards;
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-  // a workgroup per slot that could be handed out (most leave at once); with fewer workgroups than slots
-  // (gridDim.x = kAuxShards * n) a workgroup takes every n-th slot of its shard, one after the other -- measured:
-  // the launch is not shorter for its 10^4 idle workgroups less, and two jobs in a row double its length
-  const unsigned per_wg = gridDim.x / kAuxShards;
-  const unsigned shard = blockIdx.x / per_wg;
-  const unsigned used = min(W.aux_count[shard * 32], per_shard);
-  for (unsigned k = blockIdx.x % per_wg; k < used; k += per_wg) {  // uniform
-  const unsigned slot = shard * per_shard + k;
-  __syncthreads();  // (the LDS of the slot before this one is done with)
+  // one workgroup per slot that could be handed out; most leave at once.  (A loop over the slots of a shard, tried
+  // twice: the loop alone takes the kernel from 67 to 146 VGPRs, and with fewer workgroups per CU the jobs queue.)
+  const unsigned slot = blockIdx.x, shard = slot / per_shard;
+  if (slot % per_shard >= min(W.aux_count[shard * 32], per_shard)) return;  // uniform
   if (threadIdx.x == 0) s_cdone = 0;
   const JobDesc *J = W.jobs + slot;
   const float4 *src4 = W.aux_terms + (size_t)slot * (kTile / 4);
-  for (int i = threadIdx.x; i < kTile / 4; i += kJobBlock) s_t[i] = src4[i];
+  for (int i = threadIdx.x; i < kTile / 4; i += kJobBlock) {
+    const float4 q = src4[i];  // quad v = i / 64 of leaf (i % 64) ^ v (tile_quad)
+    s_t[i] = q;
+    s_lin[8 * ((i & 63) ^ (i >> 6)) + (i >> 6)] = q;
+  }
   const int row = J->row;
   const int64_t tile = J->tile;
+  const int32_t pad = J->pad;
   __syncthreads();
   if (tile < kExactTiles) {  // uniform
     // the first tile of a row, exactly, from 0.0f: the terms broadcast out of LDS a leaf ahead of the chain, so
     // that the dependent path is the additions alone (one every 6 cycles: a wave that has its SIMD nearly to
     // itself, as here, does the 2048 in ~6 us; out of registers through v_readlane each costs 10)
     if (part == 0) {
-      const uint32_t x = serial_leaves(f2u(0.0f), s_t, 0, kLanes);
+      __builtin_amdgcn_s_setprio(3);  // (the longest chain of the launch: ahead of whatever shares its SIMD)
+      float x1[1] = {0.0f};
+      serial_leaves_lin(x1, s_lin, 0, kLanes);
+      const uint32_t x = f2u(x1[0]);
+      __builtin_amdgcn_s_setprio(0);
       TileRec R;
       R.s = summary_identity();
       R.key = -1;
@@ -471,7 +500,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
       R.cons = 1;  // (a point record that owns nothing the chain kernel would fetch)
       if (lane == 0) W.recs[row * W.ntiles + tile] = R;
     }
-    continue;
+    return;
   }
   // ---- wave 0: the leaves' guesses once more, now from a start state that includes the rounding errors
   // the float32 chain has made in all tiles before this one (strict_sum_kernel's tile_err, known only
@@ -503,14 +532,21 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     s_g[lane] = g;
     s_lk[lane] = key >= 0 ? key : leaf_key(cr, g);
     const uint32_t out_last = (uint32_t)__shfl((int)cr.end, 63);
+    // a plain tile handed over because it lies near an end of its binade (strict_sum_kernel): with the drift added
+    // the guesses say whether its record stands -- still one binade, the same one, clear of the ends
+    const uint32_t m_lo = mn & 0x7fffffu, m_hi = mx & 0x7fffffu;
+    const bool stands = (pad & 1) && key >= 0 && (mn >> 23) == (mx >> 23) && (int32_t)(mn >> 23) == (pad >> 8) &&
+                        m_lo >= kPlainMargin && m_hi <= 0x7fffffu - kPlainMargin;
     if (lane == 0) {
       s_hdr[0] = key;
       s_hdr[1] = (int32_t)g_first;
       s_hdr[2] = (int32_t)out_last;
       s_hdr[3] = cons ? 1 : 0;
+      s_hdr[4] = stands ? 1 : 0;
     }
   }
   __syncthreads();
+  if (s_hdr[4]) return;  // uniform
   const uint32_t g = s_g[lane];
   const int32_t lk = s_lk[lane];
   const int32_t tkey = s_hdr[0];
@@ -532,7 +568,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     // no window: waves 1..3, the whole tile from 768 candidates around the tile's guess (10 us: the launch is that
     // much longer in the few iterations that have such tiles; cut into quarters like a level crossing below, a
     // third of these tiles were lost where one quarter's end fell outside the next quarter's candidates)
-    if (part >= 4) continue;
+    if (part >= 4) return;
     const uint32_t g0 = (uint32_t)s_hdr[1];
     const uint32_t mag = g0 & 0x7fffffffu;
     uint32_t out[kCandPerLane];
@@ -543,13 +579,13 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
       float x[kCandPerLane];
 #pragma unroll
       for (int c = 0; c < kCandPerLane; c++) x[c] = u2f(g0 + (uint32_t)cand_offset(i0 + c * kLanes));
-      serial_leaves_n(x, s_t, 0, kLanes);
+      serial_leaves_lin(x, s_lin, 0, kLanes);
 #pragma unroll
       for (int c = 0; c < kCandPerLane; c++) out[c] = f2u(x[c]);
     }
 #pragma unroll
     for (int c = 0; c < kCandPerLane; c++) W.cand[(size_t)slot * kCand + i0 + c * kLanes] = out[c];
-    continue;
+    return;
   }
   if (part >= 4) {
     // level crossing: 2048 dependent additions are 6-10 us -- longer than anything else this launch does -- so
@@ -568,7 +604,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
       float x[kCandPerLane];
 #pragma unroll
       for (int c = 0; c < kCandPerLane; c++) x[c] = u2f(gk + (uint32_t)cand_offset(kMid + c * kLanes + lane));
-      serial_leaves_n(x, s_t, k * (kLanes / 4), (k + 1) * (kLanes / 4));
+      serial_leaves_lin(x, s_lin, k * (kLanes / 4), (k + 1) * (kLanes / 4));
 #pragma unroll
       for (int c = 0; c < kCandPerLane; c++) out[c] = f2u(x[c]);
     }
@@ -581,7 +617,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     }
     lds_fence_wave();
     if (lane == 0) __hip_atomic_fetch_add(&s_cdone, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (k != 0) continue;
+    if (k != 0) return;
     while (__hip_atomic_load(&s_cdone, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
 #pragma unroll
     for (int c = 0; c < kCandPerLane; c++) {
@@ -596,9 +632,9 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
       }
       W.cand[(size_t)slot * kCand + kMid + c * kLanes + lane] = v;
     }
-    continue;
+    return;
   }
-  if (part >= 2) continue;
+  if (part >= 2) return;
   Summary S;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -653,7 +689,6 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     R.key = -1;
     if (lane == 0) W.recs[row * W.ntiles + tile] = R;
   }
-}  // slots of this workgroup
 }
 
 // ---- chain -----------------------------------------------------------------------------------------

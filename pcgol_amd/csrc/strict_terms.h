@@ -36,9 +36,9 @@ struct JobDesc {  // a (row, tile) that crosses a level or has no window: strict
   int32_t row, pad;
 };
 
-// Slots are handed out by kAuxShards counters a cache line apart (shard = tile % kAuxShards, each with
-// naux / kAuxShards slots): one counter for all was ~100 returning atomics on one address per launch,
-// served one after the other -- the last job of a launch waited 30-40 us for its slot number.
+// Slots are handed out by kAuxShards counters a cache line apart (shard = (tile + 7 row) % kAuxShards, each with
+// naux / kAuxShards slots): one counter for all was ~100 returning atomics on one address per launch, served one
+// after the other -- the last job of a launch waited 30-40 us for its slot number.
 constexpr int kAuxShards = 64;
 
 // Candidate start states of a job tile (strict.hip, strict_job_kernel): candidate i stands cand_offset(i) floats above

@@ -382,14 +382,20 @@ def test_strict_sums_on_structured_terms():
         s.close()
 
 
-def test_strict_sums_that_hover_around_zero(monkeypatch):
+@pytest.mark.parametrize("tables", [True, False])
+def test_strict_sums_that_hover_around_zero(monkeypatch, tables):
     """Targets = base points + zero-mean noise, no transform: all six gradient sums wander around zero
     from the first pair to the last -- sign changes and three binades inside one tile, so many tiles
     have no window at all and go through their leaves' records (runs of leaves under equal windows,
     the rest added up term by term: the helper waves of the chain kernel).  Still the oracle's
     Go-semantics sums, bit for bit; with PCGX_STRICT_SELFCHECK every step of the walk is re-derived term
-    by term inside the kernel as well (the device-only paths the host model does not mirror)."""
+    by term inside the kernel as well (the device-only paths the host model does not mirror).
+    tables: the job kernel's candidate tables (a tile carried out from the start states around its guess: the
+    walker looks its state up) are in use, or switched off (PCGX_STRICT_NOSPEC) so that every such tile goes
+    through its leaves' records."""
     monkeypatch.setenv("PCGX_STRICT_SELFCHECK", "1")
+    if not tables:
+        monkeypatch.setenv("PCGX_STRICT_NOSPEC", "1")
     n = 200_000
     rng = np.random.Generator(np.random.PCG64(77))
     base = synth.uniform_cloud(n, 10.0 * (n / 1e6) ** (1 / 3), 2)
@@ -401,12 +407,13 @@ def test_strict_sums_that_hover_around_zero(monkeypatch):
     trans = O.translate(0, 0, 0)
     it = 0
     tt = target.copy()
-    resolved = 0
+    resolved = looked_up = 0
     for k in range(3):
         s.step()
         tr, st, conv = s.result()
         sst = s.strict_stats()
         resolved += int(sst[2])
+        looked_up += int(sst[25]) + int(sst[45])
         assert not sst[12:16].any() and sst[6] == 0 and sst[7] == 0, (k, sst[:24])
         assert sst[16] > 0 or k > 0   # tiles without a window were recomputed from their leaf records
         oe = O.icp_evaluate(o, tt, 0.5, 6, sums_mode=0)
@@ -416,7 +423,9 @@ def test_strict_sums_that_hover_around_zero(monkeypatch):
         assert np.array_equal(tr, trans), k
         tt = synth.transform_points(trans, target)
     s.close()
-    assert resolved >= 20  # the case does what it is for: many tiles recomputed from the exact state
+    # the case does what it is for: many tiles whose record does not cover the state
+    assert resolved + looked_up >= 20 and resolved >= 5, (resolved, looked_up)
+    assert (looked_up > 0) == tables
 
 
 @pytest.mark.parametrize("slots", ["0", "1"])
