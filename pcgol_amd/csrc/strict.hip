@@ -462,7 +462,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   __shared__ int32_t s_lk[kLanes];     // and the windows they are summarised under
   __shared__ int32_t s_hdr[5];         // the tile's window, guess at its start, end of its last guess chain, "the chains join up", "the plain record stands"
   __shared__ uint32_t s_ctab[4][kCandInner];  // waves 4..7: the ends of their quarter's candidates
-  __shared__ int s_cdone;
+  __shared__ int s_cdone, s_pieces;
   if (state->done) return;
   const unsigned per_shard = (unsigned)W.naux / kAuxShards;
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   // twice: the loop alone takes the kernel from 67 to 146 VGPRs, and with fewer workgroups per CU the jobs queue.)
   const unsigned slot = blockIdx.x, shard = slot / per_shard;
   if (slot % per_shard >= min(W.aux_count[shard * 32], per_shard)) return;  // uniform
-  if (threadIdx.x == 0) s_cdone = 0;
+  if (threadIdx.x == 0) s_cdone = s_pieces = 0;
   const JobDesc *J = W.jobs + slot;
   const float4 *src4 = W.aux_terms + (size_t)slot * (kTile / 4);
   for (int i = threadIdx.x; i < kTile / 4; i += kJobBlock) {
@@ -481,7 +481,17 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   const int row = J->row;
   const int64_t tile = J->tile;
   const int32_t pad = J->pad;
+  const long long tj_0 = stat_clock(W);
   __syncthreads();
+  const long long tj_1 = stat_clock(W);
+  auto stamp_end = [&](int what) {
+    if ((W.selfcheck & 2) && lane == 0) {
+      W.stamps[tile * 16 + 6] = (unsigned long long)tj_0;
+      W.stamps[tile * 16 + 7] = (unsigned long long)tj_1;
+      atomicMax(&W.stamps[tile * 16 + 8 + (part >= 4 ? 1 : 0)], (unsigned long long)stat_clock(W));
+      W.stamps[tile * 16 + 10] = (unsigned long long)(what | (row << 8));
+    }
+  };
   if (tile < kExactTiles) {  // uniform
     // the first tile of a row, exactly, from 0.0f: the terms broadcast out of LDS a leaf ahead of the chain, so
     // that the dependent path is the additions alone (one every 6 cycles: a wave that has its SIMD nearly to
@@ -499,6 +509,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
       R.out = x;
       R.cons = 1;  // (a point record that owns nothing the chain kernel would fetch)
       if (lane == 0) W.recs[row * W.ntiles + tile] = R;
+      stamp_end(3);
     }
     return;
   }
@@ -546,19 +557,25 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     }
   }
   __syncthreads();
-  if (s_hdr[4]) return;  // uniform
+  if (s_hdr[4]) { if (part == 0) stamp_end(4); return; }  // uniform
   const uint32_t g = s_g[lane];
   const int32_t lk = s_lk[lane];
   const int32_t tkey = s_hdr[0];
   const int kind = tkey >= 0 ? JOB_CROSSING : JOB_NOWINDOW;
+  // (no workgroup barrier from here on: waves 4..7 start their candidate chains at once, the waves that scan wait for
+  // the four class pieces through an LDS counter)
   if (part < 4) {
     int32_t c, lo, hi;
     leaf_class_piece_q(LdsQuads{s_t, lane}, g, lk, part, c, lo, hi);
     s_S[part][lane] = c;
     s_S[4 + part][lane] = lo;
     s_S[8 + part][lane] = hi;
+    lds_fence_wave();
+    if (lane == 0) __hip_atomic_fetch_add(&s_pieces, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  __syncthreads();
+  const bool scans = part == 0 || (part == 1 && kind == JOB_CROSSING);
+  if (scans)
+    while (__hip_atomic_load(&s_pieces, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
   // ---- the tile's additions carried out from candidate start states (strict_terms.h), by the waves with nothing
   // else to do.  A tile without a window costs the chain kernel 6-8 us however its leaves are summarised (a dozen
   // leaf runs to apply, a dozen leaves to add term by term), a level crossing whose record does not cover the state
@@ -585,6 +602,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     }
 #pragma unroll
     for (int c = 0; c < kCandPerLane; c++) W.cand[(size_t)slot * kCand + i0 + c * kLanes] = out[c];
+    stamp_end(2);
     return;
   }
   if (part >= 4) {
@@ -632,6 +650,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
       }
       W.cand[(size_t)slot * kCand + kMid + c * kLanes + lane] = v;
     }
+    stamp_end(1);
     return;
   }
   if (part >= 2) return;
@@ -689,6 +708,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     R.key = -1;
     if (lane == 0) W.recs[row * W.ntiles + tile] = R;
   }
+  if (part == 0) { atomicMax(&W.stamps[tile * 16 + 13], (unsigned long long)stat_clock(W)); }
 }
 
 // ---- chain -----------------------------------------------------------------------------------------

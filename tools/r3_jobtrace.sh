@@ -23,6 +23,5 @@ for bi in (2, 8):
             name, len(k), (k[:, 6].min() - base) / 100.0, (k[:, 6].max() - base) / 100.0, np.mean(k[:, 7] - k[:, 6]) / 100.0,
             (ends.min() - base) / 100.0, (ends.max() - base) / 100.0, (ends - k[:, 6]).min() / 100.0, (ends - k[:, 6]).max() / 100.0))
         if what == 1:
-            print("       after the guesses (sync 2) at %.1f us, after the class chains (sync 3) at %.1f us, candidates done at %.1f us (means, from entry)" % (
-                np.mean(k[:, 11] - k[:, 6]) / 100.0, np.mean(k[:, 12] - k[:, 6]) / 100.0, np.mean(k[:, 9] - k[:, 6]) / 100.0))
+            print("       scans (waves 0 / 1) end at %.1f..%.1f us after the first entry" % ((k[:, 13].min() - base) / 100.0, (k[:, 13].max() - base) / 100.0))
 PY
