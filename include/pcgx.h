@@ -141,6 +141,13 @@ PCGX_API pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *stre
 PCGX_API pcgx_status pcgx_debug_strict_sum_host(const float *terms, int64_t n, int32_t mode, float *out,
                                                 int64_t stats[8]);
 
+/* The same on the device: the strict_sum / strict_job / strict_chain kernels (csrc/strict.hip) run on terms given
+ * as they are -- terms[9][n] (row-major, host memory), out[k] = 0.0f + terms[k][0] + terms[k][1] + ... in sequential
+ * float32 -- instead of on the terms of a session's pairs.  For GPU tests with rows no registration produces (a tie
+ * at every step, cancellation to zero, subnormals, overflow, NaN).  stats (may be NULL): the counters of
+ * pcgx_debug_icp_strict_stats. */
+PCGX_API pcgx_status pcgx_debug_strict_sum_dev(const float *terms, int64_t n, float out[9], int64_t stats[64]);
+
 /* Device memory helpers for hosts that have no HIP binding of their own. */
 PCGX_API pcgx_status pcgx_dev_alloc(size_t bytes, void **dptr);
 PCGX_API pcgx_status pcgx_dev_free(void *dptr);

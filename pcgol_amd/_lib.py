@@ -185,6 +185,7 @@ SIGNATURES = {
     "pcgx_icp_fit_sharded": (_i32, [_vp, _vp, _i64, C.POINTER(IcpParams), _vp, _vp, C.POINTER(IcpStat)]),
     "pcgx_debug_icp_strict_stats": (_i32, [_vp, _vp, _vp]),
     "pcgx_debug_strict_sum_host": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "pcgx_debug_strict_sum_dev": (_i32, [_vp, _i64, _vp, _vp]),
     "pcgx_icp_session_result": (_i32, [_vp, _vp, _vp, C.POINTER(IcpStat), C.POINTER(_i32)]),
     "pcgx_bucket_grid_build": (_i32, [_vp, _i64, _i32, _i32, _f32, _vp, _vp, C.POINTER(_vp)]),
     "pcgx_bucket_grid_free": (_i32, [_vp]),

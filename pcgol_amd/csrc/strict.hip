@@ -1324,6 +1324,7 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   StrictBuffers *b = new StrictBuffers();
   StrictWork &W = b->w;
   W.nt = nt;
+  W.raw_terms = nullptr;
   W.ntiles = nt > 0 ? (nt + kTile - 1) / kTile : 1;
   W.nrows = kStrictRows;
   W.selfcheck = (getenv("PCGX_STRICT_SELFCHECK") ? 1 : 0) | (getenv("PCGX_STRICT_TRACE") ? 2 : 0) |
@@ -1446,6 +1447,76 @@ pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[64], hipS
 }
 
 }  // namespace pcgx
+
+// The device pipeline (strict_sum / strict_job / strict_chain kernels) on terms given as they are: nine rows of n
+// float32 terms -> the nine sequential float32 sums 0.0f + t0 + t1 + ...  What the GPU tests feed with the rows a
+// registration never produces (ties at every step, cancellation to zero, subnormals, overflow, NaN): see
+// include/pcgx.h.
+extern "C" pcgx_status pcgx_debug_strict_sum_dev(const float *terms, int64_t n, float out[9], int64_t stats[64]) {
+  PCGX_API_LOCK();
+  using namespace pcgx;
+  if (n < 1 || !terms || !out) return fail(PCGX_E_INVALID, "pcgx_debug_strict_sum_dev: bad argument");
+  if (n > 0x7fffffffll) return fail(PCGX_E_TOO_LARGE, "pcgx_debug_strict_sum_dev: more than 2^31-1 terms per row");
+  PCGX_TRY(ensure_init());
+  hipStream_t st = ctx().stream;
+  float *d_terms = nullptr, *d_zero = nullptr;
+  uint32_t *d_pos = nullptr;
+  IcpState *d_state = nullptr;
+  double *d_sums = nullptr;
+  StrictBuffers *b = nullptr;
+  pcgx_status rc = PCGX_OK;
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(st);
+    if (b) strict_destroy(b);
+    (void)hipFree(d_terms);
+    (void)hipFree(d_zero);
+    (void)hipFree(d_pos);
+    (void)hipFree(d_state);
+    (void)hipFree(d_sums);
+  };
+  hipError_t e = hipMalloc((void **)&d_terms, (size_t)kStrictRows * n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_zero, (size_t)n * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_pos, (size_t)n * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_state, sizeof(IcpState));
+  if (e == hipSuccess) e = hipMalloc((void **)&d_sums, 16 * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpyAsync(d_terms, terms, (size_t)kStrictRows * n * sizeof(float), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemsetAsync(d_zero, 0, (size_t)n * sizeof(float), st);
+  if (e == hipSuccess) e = hipMemsetAsync(d_pos, 0, (size_t)n * sizeof(uint32_t), st);
+  if (e == hipSuccess) e = hipMemsetAsync(d_state, 0, sizeof(IcpState), st);
+  if (e == hipSuccess) e = hipMemsetAsync(d_sums, 0, 16 * sizeof(double), st);
+  if (e != hipSuccess) {
+    cleanup();
+    return fail(PCGX_E_HIP, "pcgx_debug_strict_sum_dev: %s", hipGetErrorString(e));
+  }
+  rc = strict_create(n, d_zero, d_zero, d_zero, d_pos, &b, st);
+  if (rc != PCGX_OK) {
+    cleanup();
+    return rc;
+  }
+  b->w.raw_terms = d_terms;
+  IcpKernelParams kp;
+  memset(&kp, 0, sizeof kp);
+  kp.weight_fn = PCGX_WEIGHT_CONSTANT;  // nine rows: the ninth sum is chained like the others
+  kp.weight_a = 1.0f;
+  rc = strict_enqueue(b, nullptr, nullptr, d_state, d_sums, kp, false, false, st);
+  double h[16];
+  if (rc == PCGX_OK) {
+    e = hipMemcpyAsync(h, d_sums, sizeof h, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) rc = fail(PCGX_E_HIP, "pcgx_debug_strict_sum_dev: %s", hipGetErrorString(e));
+  }
+  if (rc == PCGX_OK) {
+    // component order of sums10: Value, G0..G5, DistRMS, Weight, Pairs = rows 0..8, then the pair count
+    for (int k = 0; k < kStrictRows; k++) out[k] = (float)h[k];
+    if (stats) {
+      unsigned long long dbg[64];
+      rc = strict_read_debug(b, dbg, st);
+      for (int k = 0; k < 64; k++) stats[k] = (int64_t)dbg[k];
+    }
+  }
+  cleanup();
+  return rc;
+}
 
 // Host model of the same pipeline (no GPU involved): the CPU tests run it against a plain
 // sequential float32 loop.  See include/pcgx.h.

@@ -72,6 +72,7 @@ struct StrictWork {
   int32_t nrows;      // 9, or 8 with the default weight: the sum of the weights is then min(pairs, 2^24) exactly
   int32_t weight_fn;  // evaluator.go:130 (PCGX_WEIGHT_*)
   float weight_a;
+  const float *raw_terms;  // testing (pcgx_debug_strict_sum_dev): [9][nt] float32 terms given as they are, no pairs
   int32_t selfcheck;  // bit 0: every step of the chain walk is re-derived term by term and compared (dbg[12..15]);
                       // 1: PCGX_STRICT_TRACE stamps; 2: no candidate tables; 3: wall-clock columns of the counters
 };
@@ -90,6 +91,7 @@ struct TermSrc {
   bool project;  // icp.go:27-30: the first Evaluate sees the raw target
   int32_t weight_fn;
   float weight_a;
+  const float *raw;  // testing: the terms themselves, [9][nt] (StrictWork::raw_terms)
 };
 
 __device__ __forceinline__ TermSrc make_term_src(const float4 *match, const uint32_t *pos_of, const IcpState *state,
@@ -104,6 +106,7 @@ __device__ __forceinline__ TermSrc make_term_src(const float4 *match, const uint
   S.project = state->iter > 0;
   S.weight_fn = W.weight_fn;
   S.weight_a = W.weight_a;
+  S.raw = W.raw_terms;
   return S;
 }
 
@@ -113,6 +116,12 @@ __device__ __forceinline__ bool pair_terms(const TermSrc &S, float x0, float y0,
 #pragma unroll
   for (int k = 0; k < kStrictRows; k++) t[k] = -0.0f;
   if (!(b.w >= 0.0f)) return false;  // correspondence.go:27-29
+  if (S.raw) {  // testing: load_quad left the target's index in x0
+    const int64_t i = (int64_t)__float_as_int(x0);
+#pragma unroll
+    for (int k = 0; k < kStrictRows; k++) t[k] = S.raw[(int64_t)k * S.nt + i];
+    return true;
+  }
   if (S.project) {  // icp.go:62-64
     float px, py, pz;
     mat4_transform(S.m, x0, y0, z0, px, py, pz);
@@ -134,6 +143,16 @@ __device__ __forceinline__ bool pair_terms(const TermSrc &S, float x0, float y0,
 
 // the four consecutive targets i0 .. i0 + 3 (i0 a multiple of 4): pairs and coordinates
 __device__ __forceinline__ void load_quad(const TermSrc &S, int64_t i0, float4 *bp, float *tx, float *ty, float *tz) {
+  if (S.raw) {  // testing: every target below nt is a pair, pair_terms fetches its nine terms by index
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int64_t i = i0 + c;
+      bp[c] = make_float4(0.0f, 0.0f, 0.0f, i < S.nt ? 0.0f : -1.0f);
+      tx[c] = __int_as_float((int)i);
+      ty[c] = tz[c] = 0.0f;
+    }
+    return;
+  }
   if (i0 + 3 < S.nt) {
     if (S.pos_of) {
       const uint4 p = *reinterpret_cast<const uint4 *>(S.pos_of + i0);
