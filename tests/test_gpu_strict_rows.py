@@ -74,3 +74,24 @@ def test_random_rows_property_on_the_device():
         got, stats = device_sums(rows9)
         for k in range(9):
             assert same_bits(got[k], sequential_f32(rows9[k])), (n, k, stats[:8])
+
+
+@pytest.mark.parametrize("env", [{}, {"PCGX_STRICT_SELFCHECK": "1"}])
+def test_nine_sums_that_hover_around_zero_at_full_size(env, monkeypatch):
+    """1M terms per row, every row a zero-mean random walk of its own scale (hundreds of tiles without a window per
+    row), plus rows that cross zero again and again on purpose: the jobs' candidate tables, leaf records and the
+    walker's look-ups at the size the bench runs."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.Generator(np.random.PCG64(99))
+    n = 1_000_000
+    rows9 = [(rng.standard_normal(n) * 10.0 ** (k - 5)).astype(np.float32) for k in range(7)]
+    saw = (np.arange(n) % 4096 < 2048).astype(np.float32) * 2 - 1          # +1 for 2048 terms, -1 for 2048, ...
+    rows9.append((saw * np.float32(0.37) + rng.standard_normal(n).astype(np.float32) * np.float32(1e-3)).astype(np.float32))
+    rows9.append((rng.integers(-3, 4, n) * 2.0 ** -20).astype(np.float32))  # exact terms: every guess is exact
+    got, stats = device_sums(rows9)
+    for k in range(9):
+        assert same_bits(got[k], sequential_f32(rows9[k])), (k, env, stats[:8])
+    assert stats[24] > 50, stats[:32]   # the case is about tiles without a window
+    if env:
+        assert not stats[12:16].any() and stats[6] == 0 and stats[7] == 0, stats[:24]
