@@ -17,6 +17,8 @@
 // floats are mapped to order-preserving integers with -0.0 folded onto +0.0 (they compare
 // equal under <).  NaN coordinates have no consistent order under <; clouds containing
 // NaNs are built on the host instead.
+#include <stdlib.h>
+
 #include "pcgx_internal.h"
 
 namespace pcgx {
@@ -121,6 +123,80 @@ __global__ __launch_bounds__(256) void kb_fill_bfs_kernel(const float *__restric
   nodes[b] = out;
 }
 
+// The levels below d0, where every sub-slice fits LDS: one workgroup per sub-slice of level d0 carries out ALL the
+// remaining levels there -- at every level each element counts the elements of its (ever smaller) sub-slice that
+// sort before it (smaller coordinate, or equal and earlier: the stable sort the levels above do with radix passes)
+// and moves to that place.  O(n x slice) compares, but in LDS and with no launch in between: eleven levels of a
+// 1M-point build were 60 radix passes (1.5 ms), this is one launch.  In place: a workgroup reads its slice before it
+// writes it, and the positions between the slices (the nodes of the levels above) are not touched.
+constexpr int kUnitMax = 1024;
+constexpr int kUnitThreads = 512;
+__global__ __launch_bounds__(kUnitThreads) void kb_finish_units_kernel(const float *__restrict__ xyz, uint32_t *__restrict__ order,
+                                                                       uint32_t n_total, int d0, int depth) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_key[2][3][kUnitMax];
+  __shared__ uint32_t s_id[2][kUnitMax];
+  uint32_t lo = 0, n = n_total;
+  for (int d = d0 - 1; d >= 0; d--) {  // the blockIdx.x-th sub-slice of level d0, path bits from the root
+    const uint32_t half = n >> 1;
+    if ((blockIdx.x >> d) & 1u) {
+      lo = lo + half + 1u;
+      n = n > half ? n - half - 1u : 0u;
+    } else {
+      n = half;
+    }
+  }
+  if (n <= 1u || n > (uint32_t)kUnitMax) return;  // (uniform; the host picks d0 so that every slice fits)
+  for (uint32_t i = threadIdx.x; i < n; i += kUnitThreads) {
+    const uint32_t id = order[lo + i];
+    s_id[0][i] = id;
+#pragma unroll
+    for (int k = 0; k < 3; k++) s_key[0][k][i] = ordered_bits(xyz[3 * (size_t)id + k]);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int d = d0; d + 1 < depth; d++) {
+    const int dim = d % 3;
+    for (uint32_t i = threadIdx.x; i < n; i += kUnitThreads) {
+      // the sub-slice of level d that holds position i (or i is the node of a level in between: it stays)
+      uint32_t slo = 0, sn = n;
+      bool fixed = false;
+      for (int dd = d0; dd < d && !fixed && sn > 0u; dd++) {
+        const uint32_t half = sn >> 1, mid = slo + half;
+        if (i == mid) {
+          fixed = true;
+        } else if (i < mid) {
+          sn = half;
+        } else {
+          slo = mid + 1u;
+          sn = sn - half - 1u;
+        }
+      }
+      uint32_t pos = i;
+      if (!fixed && sn > 1u) {
+        // (coordinate, position) pairs compared as one 64-bit number: smaller coordinate, or equal and earlier
+        const uint32_t *kd = s_key[cur][dim];
+        const unsigned long long mine = ((unsigned long long)kd[i] << 32) | i;
+        auto before = [&](uint32_t kj, uint32_t j) { return ((((unsigned long long)kj << 32) | j) < mine) ? 1u : 0u; };
+        uint32_t rank = 0, j = slo;
+        const uint32_t end = slo + sn;
+        for (; j < end && (j & 3u); j++) rank += before(kd[j], j);
+        for (; j + 4u <= end; j += 4u) {  // four keys per LDS read
+          const uint4 k4 = *reinterpret_cast<const uint4 *>(kd + j);
+          rank += before(k4.x, j) + before(k4.y, j + 1u) + before(k4.z, j + 2u) + before(k4.w, j + 3u);
+        }
+        for (; j < end; j++) rank += before(kd[j], j);
+        pos = slo + rank;
+      }
+      s_id[cur ^ 1][pos] = s_id[cur][i];
+#pragma unroll
+      for (int k = 0; k < 3; k++) s_key[cur ^ 1][k][pos] = s_key[cur][k][i];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  for (uint32_t i = threadIdx.x; i < n; i += kUnitThreads) order[lo + i] = s_id[cur][i];
+}
+
 // d_xyz: packed xyz of the base cloud on the device; d_order (out): in-order point ids;
 // d_nodes (out): BFS slots.  Uses the arena (caller has begun it).
 pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint32_t *d_order, float4 *d_nodes,
@@ -138,8 +214,14 @@ pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint
   PCGX_TRY(ar.alloc(radix_sort_workspace_bytes(n), &ws));
   uint32_t *cur = d_order, *nxt = order_tmp;
   hipLaunchKernelGGL(kb_iota_kernel, dim3(nb), dim3(256), 0, st, cur, un);
-  // levels 0 .. depth-2 have sub-slices longer than one element
-  for (int d = 0; d + 1 < depth; d++) {
+  // levels 0 .. depth-2 have sub-slices longer than one element; from level d0 on every sub-slice fits LDS
+  // (a child holds at most half of its parent's elements) and the rest is one launch.  PCGX_BUILD_LDS=0: radix
+  // passes all the way down (tests compare the two).
+  int d0 = 0;
+  while (d0 + 1 < depth && (n >> d0) > kUnitMax) d0++;
+  if (const char *e = getenv("PCGX_BUILD_LDS"))
+    if (*e == '0') d0 = depth;
+  for (int d = 0; d + 1 < depth && d < d0; d++) {
     hipLaunchKernelGGL(kb_coord_key_kernel, dim3(nb), dim3(256), 0, st, d_xyz, cur, un, d, keys[0], vals[0]);
     int r1 = 0;
     PCGX_TRY(radix_sort_pairs(keys, vals, n, 32, ws, &r1, st));
@@ -155,6 +237,8 @@ pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint
     cur = nxt;
     nxt = t;
   }
+  if (d0 + 1 < depth)
+    hipLaunchKernelGGL(kb_finish_units_kernel, dim3(1u << d0), dim3(kUnitThreads), 0, st, d_xyz, cur, un, d0, (int)depth);
   if (cur != d_order)
     PCGX_HIP_TRY(hipMemcpyAsync(d_order, cur, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
   const uint32_t slots = 1u << depth;

@@ -155,6 +155,26 @@ def test_range_batch_vs_oracle(n, nq, max_range):
         assert offs[i + 1] - offs[i] == int(np.sum(dn < f32(max_range) * f32(max_range)))
 
 
+@pytest.mark.parametrize("n", [40_000, 70_001, 300_000, 1_000_000])
+def test_build_with_the_lower_levels_in_lds_equals_radix_passes_all_the_way(n, monkeypatch):
+    """kdtree.New on the device sorts a level's sub-slices with radix passes over the whole array until every
+    sub-slice fits LDS, then one launch carries out all remaining levels there (csrc/kdtree_build_gpu.hip).
+    PCGX_BUILD_LDS=0 keeps the radix passes all the way down: the in-order ids must be the same -- on a lattice
+    (every split coordinate tied many times over: stability is what decides), with -0.0 / +0.0 mixed (equal under <)
+    and at sizes whose sub-slices are ragged."""
+    rng = np.random.default_rng(n)
+    clouds = [synth.uniform_cloud(n, 10.0, n % 97),
+              rng.integers(0, 12, size=(n, 3)).astype(f32),
+              np.stack([rng.uniform(-5, 5, n), rng.choice([0.0, -0.0, 1.0], n), rng.normal(0, 0.01, n)], axis=1).astype(f32)]
+    for c in clouds[:3 if n <= 300_000 else 1]:
+        monkeypatch.delenv("PCGX_BUILD_LDS", raising=False)
+        a = kdtree.New(c).InOrder()
+        monkeypatch.setenv("PCGX_BUILD_LDS", "0")
+        b = kdtree.New(c).InOrder()
+        monkeypatch.delenv("PCGX_BUILD_LDS", raising=False)
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("kind", ["uniform", "lattice", "surface"])
 def test_range_on_the_grid_equals_the_walk(kind, monkeypatch):
     """Range collects the neighbours from the handle's uniform grid and puts equal DistSq of one query into the
