@@ -272,11 +272,57 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
   pcgx_kdtree *t = new pcgx_kdtree();
   t->n = n;
   t->depth = tree_depth(n);
-  t->points.resize((size_t)n * 3);
   const uint8_t *src = (const uint8_t *)data;
-  if (stride == 12) memcpy(t->points.data(), src, (size_t)n * 12);
-  else
+  const size_t slots = (size_t)1 << t->depth;
+  hipError_t e = dev_cache_alloc((void **)&t->d_nodes, slots * sizeof(float4));
+  if (e != hipSuccess) {
+    delete t;
+    return fail(PCGX_E_OOM, "hipMalloc for %lld tree nodes failed: %s", (long long)n, hipGetErrorString(e));
+  }
+  // Build on the device for large clouds; NaN coordinates (no consistent order under <) and
+  // small clouds take the host build.  PCGX_BUILD=host|gpu forces one (tests).
+  bool gpu_wanted = n >= 32768;
+  if (const char *f = getenv("PCGX_BUILD")) {
+    if (!strcmp(f, "host")) gpu_wanted = false;
+    if (!strcmp(f, "gpu") && n >= 2) gpu_wanted = true;
+  }
+  // A packed cloud goes to the device straight from the caller's buffer and the device build is under way while
+  // the host makes its own copy and looks for the bounding box and for NaNs (1 ms at 1M points); a NaN -- the
+  // device build has no consistent order for one -- and the device's work is dropped.
+  const bool early = gpu_wanted && stride == 12 && xyz_off == 0;
+  hipStream_t st = ctx().stream;
+  Arena &ar = ctx().arena;
+  float *d_xyz = nullptr;
+  uint32_t *d_order = nullptr;
+  int32_t *d_labels = nullptr;
+  auto start_device_build = [&](const void *host_xyz) -> pcgx_status {
+    pcgx_status rc = ar.begin(st);
+    if (rc == PCGX_OK) rc = ar.alloc_n((size_t)n * 3, &d_xyz);
+    if (rc == PCGX_OK) rc = ar.alloc_n((size_t)n, &d_order);
+    if (rc == PCGX_OK && labels) rc = ar.alloc_n((size_t)n, &d_labels);
+    if (rc == PCGX_OK) {
+      hipError_t e2 = hipMemcpyAsync(d_xyz, host_xyz, (size_t)n * 12, hipMemcpyHostToDevice, st);
+      if (e2 == hipSuccess && labels) e2 = hipMemcpyAsync(d_labels, labels, (size_t)n * 4, hipMemcpyHostToDevice, st);
+      if (e2 != hipSuccess) rc = fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e2));
+    }
+    if (rc == PCGX_OK) rc = build_tree_device(d_xyz, n, t->depth, d_order, t->d_nodes, d_labels, st);
+    return rc;
+  };
+  if (early) {
+    const pcgx_status rc = start_device_build(src);
+    if (rc != PCGX_OK) {
+      (void)hipStreamSynchronize(st);
+      dev_cache_free(t->d_nodes);
+      delete t;
+      return rc;
+    }
+  }
+  if (stride == 12 && xyz_off == 0) {
+    t->points.assign(reinterpret_cast<const float *>(src), reinterpret_cast<const float *>(src) + (size_t)n * 3);
+  } else {
+    t->points.resize((size_t)n * 3);
     for (int64_t i = 0; i < n; i++) memcpy(&t->points[3 * i], src + i * (int64_t)stride + xyz_off, 12);
+  }
   // one pass: bounding box (first point, then strict < / >, so NaNs never replace a bound) and NaN scan
   float blo[3], bhi[3];
   bool has_nan = false;
@@ -297,36 +343,10 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
     for (int k = 0; k < 3; k++) { t->bbox_lo[k] = blo[k]; t->bbox_hi[k] = bhi[k]; }
   }
   t->inorder.resize((size_t)n);
-  const size_t slots = (size_t)1 << t->depth;
-  hipError_t e = dev_cache_alloc((void **)&t->d_nodes, slots * sizeof(float4));
-  if (e != hipSuccess) {
-    delete t;
-    return fail(PCGX_E_OOM, "hipMalloc for %lld tree nodes failed: %s", (long long)n, hipGetErrorString(e));
-  }
-  // Build on the device for large clouds; NaN coordinates (no consistent order under <) and
-  // small clouds take the host build.  PCGX_BUILD=host|gpu forces one (tests).
-  bool on_gpu = n >= 32768 && !has_nan;
-  if (const char *f = getenv("PCGX_BUILD")) {
-    if (!strcmp(f, "host")) on_gpu = false;
-    if (!strcmp(f, "gpu") && !has_nan && n >= 2) on_gpu = true;
-  }
+  const bool on_gpu = gpu_wanted && !has_nan;
+  if (early && !on_gpu) (void)hipStreamSynchronize(st);  // (a NaN: the host builds, what the device did is overwritten)
   if (on_gpu) {
-    hipStream_t st = ctx().stream;
-    Arena &ar = ctx().arena;
-    pcgx_status rc = ar.begin(st);
-    float *d_xyz = nullptr;
-    uint32_t *d_order = nullptr;
-    int32_t *d_labels = nullptr;
-    if (rc == PCGX_OK) rc = ar.alloc_n((size_t)n * 3, &d_xyz);
-    if (rc == PCGX_OK) rc = ar.alloc_n((size_t)n, &d_order);
-    if (rc == PCGX_OK && labels) rc = ar.alloc_n((size_t)n, &d_labels);
-    if (rc == PCGX_OK) {
-      e = hipMemcpyAsync(d_xyz, t->points.data(), (size_t)n * 12, hipMemcpyHostToDevice, st);
-      if (e == hipSuccess && labels)
-        e = hipMemcpyAsync(d_labels, labels, (size_t)n * 4, hipMemcpyHostToDevice, st);
-      if (e != hipSuccess) rc = fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
-    }
-    if (rc == PCGX_OK) rc = build_tree_device(d_xyz, n, t->depth, d_order, t->d_nodes, d_labels, st);
+    pcgx_status rc = early ? PCGX_OK : start_device_build(t->points.data());
     // (has_nan is false here.  A tree rebuilt over the points left after DeletePoint -- labels -- only
     // serves region growing's Range walks: no grid for it)
     if (rc == PCGX_OK && !labels) rc = grid_build(t, d_xyz, d_labels, st);
@@ -352,11 +372,7 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
       return fail(PCGX_E_HIP, "tree upload failed: %s", hipGetErrorString(e));
     }
     if (!has_nan && !labels) {  // the grid of the certified fast path (knn_grid.h)
-      hipStream_t st = ctx().stream;
-      Arena &ar = ctx().arena;
       pcgx_status rc = ar.begin(st);
-      float *d_xyz = nullptr;
-      int32_t *d_labels = nullptr;
       if (rc == PCGX_OK) rc = ar.alloc_n((size_t)n * 3, &d_xyz);
       if (rc == PCGX_OK && labels) rc = ar.alloc_n((size_t)n, &d_labels);
       if (rc == PCGX_OK) {

@@ -175,6 +175,31 @@ def test_build_with_the_lower_levels_in_lds_equals_radix_passes_all_the_way(n, m
         assert np.array_equal(a, b)
 
 
+def test_a_nan_in_a_large_cloud_takes_the_host_build(monkeypatch):
+    """A packed cloud of device-build size is on its way to the GPU before the host has looked for NaNs
+    (csrc/knn.hip, build_tree); when it finds one, the device's work is dropped and the host builds, as for any cloud
+    with a NaN coordinate (no consistent order under <): the same tree and the same answers as with the host build
+    asked for from the start (PCGX_BUILD=host)."""
+    n = 50_000
+    base = synth.uniform_cloud(n, 10.0, 21)
+    base[12_345, 1] = np.nan
+    base[40_000] = [np.nan, np.nan, 0.5]
+    q = synth.uniform_cloud(2000, 10.0, 22)
+    t = kdtree.New(base)
+    monkeypatch.setenv("PCGX_BUILD", "host")
+    h = kdtree.New(base)
+    monkeypatch.delenv("PCGX_BUILD")
+    assert np.array_equal(t.InOrder(), h.InOrder())
+    a, b = t.NearestBatch(q, 1.0), h.NearestBatch(q, 1.0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    clean = np.delete(base, [12_345, 40_000], axis=0)  # and every answer is a real nearest neighbour
+    for i in range(0, len(q), 97):
+        d = clean - q[i]
+        dn = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        best = dn.min()
+        assert (a[0][i] < 0 and not best < f32(1.0)) or a[1][i] == best, i
+
+
 @pytest.mark.parametrize("kind", ["uniform", "lattice", "surface"])
 def test_range_on_the_grid_equals_the_walk(kind, monkeypatch):
     """Range collects the neighbours from the handle's uniform grid and puts equal DistSq of one query into the
