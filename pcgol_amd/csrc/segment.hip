@@ -25,6 +25,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "knn_grid.h"
 #include "range_walk.h"
 
 namespace pcgx {
@@ -256,6 +257,99 @@ __global__ __launch_bounds__(kRangeWalkBlock) void rg_union_kernel(TreeView tv, 
       }
     }
   });
+}
+
+// The same components on a handle with a uniform grid (knn_grid.h).  Which points lie within maxRange of a point does
+// not depend on the walk (range.hip), and a union-find does not care in which order it is told the edges -- but it does
+// care how many trees it has to merge and who merges them at the same time: the single pass above spends 370 of its
+// 600 us at 300k points in finds and compare-and-swap retries.  Here the union-find works on the points' positions in
+// CELL ORDER (the grid's own order), one lane per point:
+//  (1) every point hooks itself under the same-valued neighbour with the SMALLEST position below its own (a store to
+//      its own word: no contention, no find).  In cell order "smallest" means lowest z, then y, then x: the trees
+//      are columns that run down through a region, and only points with nothing of their region below them are roots
+//      -- hooked by point id, whose order has nothing to do with space, every sixth point was one;
+//  (2) pointer jumping makes every parent a root;
+//  (3) a second pass over the neighbourhoods unions what is still apart (few trees, roots one hop away);
+//  (4) roots -> the component's smallest point id (what the walk's version returns).
+template <bool kHookMin>
+__global__ __launch_bounds__(256) void rg_grid_kernel(GridView g, int64_t n, const uint32_t *__restrict__ labels, float bound,
+                                                      uint32_t *__restrict__ parent) {
+  const int64_t f0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f0 >= n) return;
+  const float4 me = g.pts[f0];
+  const uint32_t mine = labels[__float_as_uint(me.w)];
+  uint32_t best = (uint32_t)f0;                                          // kHookMin: the lowest same-valued neighbour
+  uint32_t my_root = kHookMin ? (uint32_t)f0 : uf_find(parent, (uint32_t)f0);  // else: a root this point was seen under
+  const GridBox box = grid_cover(g, me.x, me.y, me.z, bound);
+  for (int z = box.z0; z <= box.z1; z++) {
+    for (int y = box.y0; y <= box.y1; y++) {
+      const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
+      uint32_t f = g.start[row + (uint32_t)box.x0];
+      uint32_t e = g.start[row + (uint32_t)box.x1 + 1u];
+      e = e < (uint32_t)f0 ? e : (uint32_t)f0;  // each edge from its higher end
+      for (; f < e; f++) {
+        const float4 p = g.pts[f];
+        const float dx = p.x - me.x, dy = p.y - me.y, dz = p.z - me.z;
+        const float d = (dx * dx + dy * dy) + dz * dz;  // (mat/vec3.go:18-20,38-40, as in the walk)
+        if (!(d < bound) || labels[__float_as_uint(p.w)] != mine) continue;  // regiongrowing.go:43-47
+        if (kHookMin) {
+          best = f < best ? f : best;
+        } else {
+          const uint32_t rj = uf_find(parent, f);
+          if (rj != my_root) {
+            uf_union(parent, my_root, rj);
+            my_root = uf_find(parent, my_root);
+          }
+        }
+      }
+    }
+  }
+  if (kHookMin) parent[f0] = best;
+}
+
+// (4): min_id[root position] = smallest point id under it, then root_of_point[id] = that id
+__global__ __launch_bounds__(256) void rg_min_id_kernel(GridView g, int64_t n, const uint32_t *__restrict__ parent,
+                                                        uint32_t *__restrict__ min_id) {
+  // The lanes of a wave are neighbours in space and mostly of one region: one atomic per distinct root of the wave,
+  // and none when the word already holds something smaller (150k atomicMin on the one word of a large region take
+  // 2 ms: same-address atomics are served one after the other)
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = f < n;
+  const uint32_t root = valid ? parent[f] : 0xffffffffu;
+  const uint32_t id = valid ? __float_as_uint(g.pts[f].w) : 0xffffffffu;
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {  // uniform
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)root, leader);
+    const unsigned long long same = __ballot(valid && root == r);
+    uint32_t m = (valid && root == r) ? id : 0xffffffffu;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint32_t v = (uint32_t)__shfl_xor((int)m, o);
+      m = v < m ? v : m;
+    }
+    if (lane == leader && m < __atomic_load_n(min_id + r, __ATOMIC_RELAXED)) atomicMin(min_id + r, m);
+    todo &= ~same;
+  }
+}
+__global__ __launch_bounds__(256) void rg_name_kernel(GridView g, int64_t n, const uint32_t *__restrict__ parent,
+                                                      const uint32_t *__restrict__ min_id, uint32_t *__restrict__ root_of_point) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f < n) root_of_point[__float_as_uint(g.pts[f].w)] = min_id[parent[f]];
+}
+
+// parent[i] := root of i (every chain descends: roots are their components' smallest members so far)
+__global__ __launch_bounds__(256) void uf_jump_kernel(uint32_t *__restrict__ parent, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t r = uf_load(parent + i);
+  for (;;) {
+    const uint32_t p = uf_load(parent + r);
+    if (p == r) break;
+    r = p;
+  }
+  __atomic_store_n(parent + i, r, __ATOMIC_RELAXED);
 }
 
 }  // namespace pcgx
@@ -633,10 +727,27 @@ extern "C" pcgx_status pcgx_region_growing_components(const pcgx_kdtree *t, cons
   hipLaunchKernelGGL(uf_init_kernel, dim3(nb), dim3(256), 0, st, d_parent, n);
   const TreeView tv = t->view();
   const uint32_t slots = 1u << tv.depth;
-  hipLaunchKernelGGL(rg_union_kernel, dim3((slots + kRangeWalkBlock - 1) / kRangeWalkBlock), dim3(kRangeWalkBlock),
-                     walk_stack_bytes(tv, kRangeWalkBlock), st, tv, (const uint32_t *)d_labels, max_range * max_range,
-                     d_parent);
-  hipLaunchKernelGGL(uf_flatten_kernel, dim3(nb), dim3(256), 0, st, d_parent, n, d_root);
+  const char *walk_env = getenv("PCGX_RANGE_WALK");  // (as in range.hip: the walk although the handle has a grid)
+  const bool on_grid = t->grid_ok && t->n == n && !(walk_env && *walk_env && *walk_env != '0');
+  if (on_grid) {
+    uint32_t *d_min = nullptr;
+    PCGX_TRY(ar.alloc_n((size_t)n, &d_min));
+    PCGX_HIP_TRY(hipMemsetAsync(d_min, 0xFF, (size_t)n * 4, st));
+    hipLaunchKernelGGL(rg_grid_kernel<true>, dim3(nb), dim3(256), 0, st, t->grid, n, (const uint32_t *)d_labels,
+                       max_range * max_range, d_parent);
+    hipLaunchKernelGGL(uf_jump_kernel, dim3(nb), dim3(256), 0, st, d_parent, n);
+    hipLaunchKernelGGL(rg_grid_kernel<false>, dim3(nb), dim3(256), 0, st, t->grid, n, (const uint32_t *)d_labels,
+                       max_range * max_range, d_parent);
+    hipLaunchKernelGGL(uf_jump_kernel, dim3(nb), dim3(256), 0, st, d_parent, n);
+    hipLaunchKernelGGL(rg_min_id_kernel, dim3(nb), dim3(256), 0, st, t->grid, n, (const uint32_t *)d_parent, d_min);
+    hipLaunchKernelGGL(rg_name_kernel, dim3(nb), dim3(256), 0, st, t->grid, n, (const uint32_t *)d_parent,
+                       (const uint32_t *)d_min, d_root);
+  } else {
+    hipLaunchKernelGGL(rg_union_kernel, dim3((slots + kRangeWalkBlock - 1) / kRangeWalkBlock), dim3(kRangeWalkBlock),
+                       walk_stack_bytes(tv, kRangeWalkBlock), st, tv, (const uint32_t *)d_labels, max_range * max_range,
+                       d_parent);
+  }
+  if (!on_grid) hipLaunchKernelGGL(uf_flatten_kernel, dim3(nb), dim3(256), 0, st, d_parent, n, d_root);
   PCGX_HIP_TRY(hipGetLastError());
   std::vector<uint32_t> h((size_t)n);
   PCGX_HIP_TRY(hipMemcpyAsync(h.data(), d_root, (size_t)n * 4, hipMemcpyDeviceToHost, st));

@@ -124,3 +124,30 @@ def test_region_growing_vs_oracle_random():
         assert np.array_equal(rg2.Segment(p, 0.2, order="id"), np.sort(exact))
         if k < 3:
             assert np.array_equal(rg2.Segment(p, 0.2), exact)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "lattice", "sheet"])
+def test_region_growing_on_the_grid_equals_the_walk(kind, monkeypatch):
+    """Components(maxRange) joins every point with its Range() neighbours of the same property value
+    (regiongrowing.go:43-47).  On a handle with a uniform grid the neighbourhoods come out of the grid's cells and
+    the union-find works in cell order (csrc/segment.hip); PCGX_RANGE_WALK=1 keeps the walk.  Same component for
+    every point -- named by its smallest id either way."""
+    rng = np.random.default_rng(5)
+    n = 150_000
+    if kind == "uniform":
+        pts, r = synth.uniform_cloud(n, 5.0, 31), 0.12
+    elif kind == "lattice":  # repeated sites, distances tied at the bound's doorstep
+        pts, r = rng.integers(0, 40, size=(n, 3)).astype(np.float32), 1.0001
+    else:
+        pts = np.stack([rng.uniform(0, 8, n), rng.uniform(0, 8, n), rng.normal(0, 0.005, n)], axis=1).astype(np.float32)
+        r = 0.05
+    labels = rng.integers(0, 3, n).astype(np.uint32)
+    t = kdtree.New(pts)
+    monkeypatch.delenv("PCGX_RANGE_WALK", raising=False)
+    a = segmentation.RegionGrowing(t, labels).Components(r)
+    monkeypatch.setenv("PCGX_RANGE_WALK", "1")
+    b = segmentation.RegionGrowing(t, labels).Components(r)
+    monkeypatch.delenv("PCGX_RANGE_WALK", raising=False)
+    assert np.array_equal(a, b)
+    assert np.all(a <= np.arange(n)) and np.array_equal(a[a], a)   # a component is named by its smallest member
+    assert np.array_equal(labels[a], labels)
