@@ -253,8 +253,17 @@ pcgx_status launch_nearest_listed(const TreeView &tv, const float *d_q, const in
 size_t radix_sort_workspace_bytes(int64_t n);
 // iota_vals: the values are the positions 0 .. n-1 and vals[0] need not be filled (the first pass
 // takes a position for its value: a 4n-byte write and read less)
+// first_hist_done: the caller's own kernel has filled the first pass's tile histograms while it made the keys
+// (radix_first_hist below says where and for which tiles)
 pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, int key_bits,
-                             void *workspace, int *result, hipStream_t st, bool iota_vals = false);
+                             void *workspace, int *result, hipStream_t st, bool iota_vals = false,
+                             bool first_hist_done = false);
+// The first pass's histograms: hist[digit * nblocks + tile], digit = key & 255, tile = 256 * items consecutive keys
+struct RadixFirstHist {
+  uint32_t *hist;
+  int nblocks, items;
+};
+RadixFirstHist radix_first_hist(int64_t n, void *workspace);
 // sticky_first: a NaN coordinate of the FIRST point stays (min, max := Vec3At(0), minmax.go:13-23); false for a
 // later slice of a cloud whose min / max are folded over ranks
 pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,

@@ -226,8 +226,16 @@ __global__ __launch_bounds__(256) void rs_iota_kernel(uint32_t *__restrict__ v, 
   if (i < n) v[i] = (uint32_t)i;
 }
 
+RadixFirstHist radix_first_hist(int64_t n, void *workspace) {
+  RadixFirstHist h;
+  h.items = rs_items(n);
+  h.nblocks = (int)((n + (int64_t)kRsThreads * h.items - 1) / ((int64_t)kRsThreads * h.items));
+  h.hist = (uint32_t *)workspace;
+  return h;
+}
+
 pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, int key_bits,
-                             void *workspace, int *result, hipStream_t st, bool iota_vals) {
+                             void *workspace, int *result, hipStream_t st, bool iota_vals, bool first_hist_done) {
   *result = 0;
   if (n <= 1 || key_bits <= 0) {  // nothing to sort: the values as they are -- or as they would have been
     if (iota_vals && n > 0) {
@@ -244,7 +252,9 @@ pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, in
   uint32_t *totals = block_hist + (int64_t)nblocks * kRadix;
   int cur = 0;
   for (int shift = 0; shift < key_bits; shift += 8) {
-    if (items == 8)
+    if (shift == 0 && first_hist_done) {
+      // (the kernel that made the keys counted the first digit on its way)
+    } else if (items == 8)
       hipLaunchKernelGGL(rs_hist_kernel<8>, dim3(nblocks), dim3(kRsThreads), 0, st, keys[cur], n, shift, block_hist,
                          nblocks);
     else

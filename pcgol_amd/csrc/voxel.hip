@@ -60,6 +60,12 @@ __device__ __forceinline__ void chunk_origin(const VoxelParams &vp, uint32_t cid
   o[2] = vp.vmin[2] + (float)z * vp.cs[2];
 }
 
+// the key of point i (and its by-products); returns it
+__device__ __forceinline__ uint32_t voxel_key_of(const uint8_t *__restrict__ data, int64_t i, int32_t stride, int32_t off,
+                                                 const VoxelParams &vp, uint32_t *__restrict__ key_a,
+                                                 uint32_t *__restrict__ a_orig, uint32_t *__restrict__ key_cid,
+                                                 uint32_t *__restrict__ idx, int32_t *__restrict__ err);
+
 __global__ __launch_bounds__(256) void voxel_key_kernel(const uint8_t *__restrict__ data, int64_t n,
                                                         int32_t stride, int32_t off, VoxelParams vp,
                                                         uint32_t *__restrict__ key_a,
@@ -69,6 +75,38 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(const uint8_t *__restric
                                                         int32_t *__restrict__ err) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  (void)voxel_key_of(data, i, stride, off, vp, key_a, a_orig, key_cid, idx, err);
+}
+
+// The same, a radix-sort tile per workgroup (256 x kItems consecutive points), counting the first digit of the keys
+// on its way: what rs_hist_kernel would do in a launch of its own with a 40 MB read of what was just written
+// (sort.hip, radix_first_hist)
+template <int kItems>
+__global__ __launch_bounds__(256) void voxel_key_hist_kernel(const uint8_t *__restrict__ data, int64_t n, int32_t stride,
+                                                             int32_t off, VoxelParams vp, uint32_t *__restrict__ key_a,
+                                                             uint32_t *__restrict__ a_orig, uint32_t *__restrict__ key_cid,
+                                                             int32_t *__restrict__ err, uint32_t *__restrict__ block_hist,
+                                                             int nblocks) {
+  __shared__ uint32_t hist[256];
+  hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * (256 * kItems);
+#pragma unroll
+  for (int r = 0; r < kItems; r++) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < n) {
+      const uint32_t k = voxel_key_of(data, i, stride, off, vp, key_a, a_orig, key_cid, nullptr, err);
+      atomicAdd(&hist[k & 255u], 1u);
+    }
+  }
+  __syncthreads();
+  block_hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];
+}
+
+__device__ __forceinline__ uint32_t voxel_key_of(const uint8_t *__restrict__ data, int64_t i, int32_t stride, int32_t off,
+                                                 const VoxelParams &vp, uint32_t *__restrict__ key_a,
+                                                 uint32_t *__restrict__ a_orig, uint32_t *__restrict__ key_cid,
+                                                 uint32_t *__restrict__ idx, int32_t *__restrict__ err) {
   const uint8_t *rec = data + i * stride + off;
   const float pt[3] = {ld_f32(rec), ld_f32(rec + 4), ld_f32(rec + 8)};
   float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
@@ -82,7 +120,7 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(const uint8_t *__restric
       key_a[i] = 0;
       if (idx) idx[i] = (uint32_t)i;
       if (key_cid) { key_cid[i] = 0; a_orig[i] = 0; }
-      return;
+      return 0u;
     }
     cid = (uint32_t)c;
     chunk_origin(vp, cid, origin);
@@ -94,9 +132,11 @@ __global__ __launch_bounds__(256) void voxel_key_kernel(const uint8_t *__restric
   uint32_t ka = 0;
   if (a < 0 || a >= vp.n_voxels) atomicOr(err, 1);  // f.voxels[a] would panic
   else ka = (uint32_t)a;
-  key_a[i] = vp.combined ? ((cid << vp.key_shift) | ka) : ka;
+  const uint32_t key = vp.combined ? ((cid << vp.key_shift) | ka) : ka;
+  key_a[i] = key;
   if (a_orig) a_orig[i] = ka;
   if (idx) idx[i] = (uint32_t)i;  // (nullptr: the sort takes positions for values)
+  return key;
 }
 
 // chunk id of sorted position j: its own array (two sorts), or the high bits of the combined key
@@ -515,8 +555,20 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
   PCGX_HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int32_t), st));
 
   unsigned nb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(256), 0, st, (const uint8_t *)d_data, n, stride, xyz_off,
-                     vp, keys[0], a_orig, cid_orig, (uint32_t *)nullptr, d_err);
+  // one GPU: the keys are sorted as they come out of the key kernel, which then counts the first digit as well
+  const bool hist_fused = world == 1 && n > 1 && key_bits > 0;
+  if (hist_fused) {
+    const RadixFirstHist fh = radix_first_hist(n, ws);
+    if (fh.items == 8)
+      hipLaunchKernelGGL(voxel_key_hist_kernel<8>, dim3(fh.nblocks), dim3(256), 0, st, (const uint8_t *)d_data, n, stride,
+                         xyz_off, vp, keys[0], a_orig, cid_orig, d_err, fh.hist, fh.nblocks);
+    else
+      hipLaunchKernelGGL(voxel_key_hist_kernel<16>, dim3(fh.nblocks), dim3(256), 0, st, (const uint8_t *)d_data, n, stride,
+                         xyz_off, vp, keys[0], a_orig, cid_orig, d_err, fh.hist, fh.nblocks);
+  } else {
+    hipLaunchKernelGGL(voxel_key_kernel, dim3(nb), dim3(256), 0, st, (const uint8_t *)d_data, n, stride, xyz_off,
+                       vp, keys[0], a_orig, cid_orig, (uint32_t *)nullptr, d_err);
+  }
   bool iota = true;  // the values of the sort are the points' indices 0 .. n-1
   if (world > 1) {
     // this rank's share of the output order: by chunk id (two sorts), else by the one key
@@ -548,7 +600,7 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
     nb = (unsigned)((n + 255) / 256);
   }
   int res = 0;
-  PCGX_TRY(radix_sort_pairs(keys, vals, n, key_bits, ws, &res, st, iota));
+  PCGX_TRY(radix_sort_pairs(keys, vals, n, key_bits, ws, &res, st, iota, hist_fused));
   const uint32_t *sa = keys[res], *sc = nullptr, *sidx = vals[res];
   if (two_level) {
     // second stable sort, by chunk id: (cid, a) order with input order kept inside a cell
