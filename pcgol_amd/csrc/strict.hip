@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     const float4 *__restrict__ match, const uint32_t *__restrict__ pos_of, const IcpState *__restrict__ state, StrictWork W) {
   __shared__ float4 s_terms[kStrictRows][kTile / 4];
   __shared__ int s_np[kSumWaves];
-  if (state->done) return;
+  const int done = state->done;  // (looked at behind phase 1, whose loads it would only hold up: nothing is written before)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tile = blockIdx.x;
   const int NR = W.nrows;
@@ -326,6 +326,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     if (lane == 0) s_np[wave] = np;
   }
   __syncthreads();
+  if (done) return;  // uniform
   if (threadIdx.x == 0) {
     int np = 0;
     for (int w = 0; w < kSumWaves; w++) np += s_np[w];
@@ -463,13 +464,15 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   __shared__ int32_t s_hdr[5];         // the tile's window, guess at its start, end of its last guess chain, "the chains join up", "the plain record stands"
   __shared__ uint32_t s_ctab[4][kCandInner];  // waves 4..7: the ends of their quarter's candidates
   __shared__ int s_cdone, s_pieces;
-  if (state->done) return;
   const unsigned per_shard = (unsigned)W.naux / kAuxShards;
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   // one workgroup per slot that could be handed out; most leave at once.  (A loop over the slots of a shard, tried
   // twice: the loop alone takes the kernel from 67 to 146 VGPRs, and with fewer workgroups per CU the jobs queue.)
   const unsigned slot = blockIdx.x, shard = slot / per_shard;
-  if (slot % per_shard >= min(W.aux_count[shard * 32], per_shard)) return;  // uniform
+  // ("done" and the shard's count in one round trip, not two)
+  const int done = state->done;
+  const unsigned handed_out = W.aux_count[shard * 32];
+  if (done || slot % per_shard >= min(handed_out, per_shard)) return;  // uniform
   if (threadIdx.x == 0) s_cdone = s_pieces = 0;
   const JobDesc *J = W.jobs + slot;
   const float4 *src4 = W.aux_terms + (size_t)slot * (kTile / 4);
@@ -939,7 +942,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   __shared__ int s_tab_ord[kHelpers];          // ... and that tile's ordinal + 1 (0: none yet)
   __shared__ float4 s_tile[kTile / 4];     // walker: the terms of a tile without a slot, formed again from the pairs
   __shared__ unsigned long long s_np[kChainSegs];
-  if (state->done) return;
+  const int done = state->done;  // (looked at behind the first chunk's loads, which it would only hold up)
   const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool walker = wave == kWalker;
   const TermSrc src = make_term_src(match, pos_of, state, W);
@@ -994,6 +997,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       const unsigned long long aux = __ballot(valid && (R.cons >> 8) != 0);
       if (lane == 0) s_auxcnt[wave] = __popcll(aux);
     }
+    if (done) return;  // uniform (nothing but LDS has been written)
     __syncthreads();
     int naux = 0;
     {  // the list of tiles that own a slot
