@@ -95,3 +95,18 @@ def test_nine_sums_that_hover_around_zero_at_full_size(env, monkeypatch):
     assert stats[24] > 50, stats[:32]   # the case is about tiles without a window
     if env:
         assert not stats[12:16].any() and stats[6] == 0 and stats[7] == 0, stats[:24]
+
+
+def test_more_tiles_than_one_chunk_of_the_chain_kernel():
+    """3M terms per row = 1465 tiles: the chain kernel walks them in three chunks of 512 (records, scans, helpers'
+    tables per chunk).  Hovering rows, drifting rows and a row with a NaN in the last chunk."""
+    rng = np.random.Generator(np.random.PCG64(123))
+    n = 3_000_000
+    rows9 = [(rng.standard_normal(n) * 10.0 ** (k - 4) + (k % 3 - 1) * 10.0 ** (k - 6)).astype(np.float32) for k in range(8)]
+    last = (rng.standard_normal(n) * 0.01).astype(np.float32)
+    last[2_900_000] = np.float32(np.inf)
+    last[2_950_000] = np.float32(-np.inf)
+    rows9.append(last)
+    got, stats = device_sums(rows9)
+    for k in range(9):
+        assert same_bits(got[k], sequential_f32(rows9[k])), (k, stats[:8])
