@@ -943,7 +943,10 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   __shared__ float4 s_tile[kTile / 4];     // walker: the terms of a tile without a slot, formed again from the pairs
   __shared__ unsigned long long s_np[kChainSegs];
   const int done = state->done;  // (looked at behind the first chunk's loads, which it would only hold up)
-  const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (rfl: "which wave" is the same in all lanes, and the compiler has to know -- or the branch between walker and
+  // helpers counts as divergent, the walker's state becomes a vector register, and every apply() of the walk runs
+  // on the vector unit at its dependent-instruction latency instead of on the scalar unit)
+  const int row = blockIdx.x, lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
   const bool walker = wave == kWalker;
   const TermSrc src = make_term_src(match, pos_of, state, W);
   uint32_t s = f2u(0.0f);  // walker state, evaluator.go:122: the sums start at zero
@@ -1212,7 +1215,9 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
                 const uint32_t g0 = (uint32_t)s_rec[1][f];
                 const int32_t idx = (int32_t)((s & 0x7fffffffu) - (g0 & 0x7fffffffu)) + kCand / 2;
                 if (((s ^ g0) >> 31) == 0u && idx >= 0 && idx < kCand) {
-                  const uint32_t v = s_tab[ord % kHelpers][idx];
+                  // (rfl: the state stays a scalar for the compiler -- one VGPR source and every run's apply() moves
+                  // from the scalar unit to the vector unit's dependent-instruction latency)
+                  const uint32_t v = (uint32_t)rfl((int)s_tab[ord % kHelpers][idx]);
                   if ((v & 0x7f800000u) != 0x7f800000u) {  // (NaN: no such candidate)
                     s = v;
                     from_table = true;
