@@ -1024,8 +1024,14 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   const bool grid = grid_enabled(s->base) && !(s->kp.min_dist_sq > 0.0f) && s->nt > 0;
   // with the grid pass before it the correspondence kernel finds (nearly) every pair in place: its workgroups
   // form the strict sums' tile sums on their way out (else strict_tilesum_kernel does, after this launch)
-  s->tile_sums_fresh = grid && s->caller_order_fresh && s->strict == 1 && !s->plane;
+  // (unless the summary kernel forms and exchanges them itself, StrictWork::exchange: the default)
+  s->tile_sums_fresh = grid && s->caller_order_fresh && s->strict == 1 && !s->plane && !strict_work(s->strict_buf, s->kp)->exchange;
   const StrictWork strict_w = s->tile_sums_fresh ? *strict_work(s->strict_buf, s->kp) : StrictWork();
+  // Strict sessions behind a grid pass: the correspondence kernel is there for the few targets the grid could not
+  // certify (none at C4) and forms no sums -- 128 workgroups instead of two per CU: the launch of 512 of them, 66 KB
+  // of LDS each, cost 4-6 us per iteration to find nothing to do.
+  static const int left_blocks = icp_knob("PCGX_ICP_LEFTOVER_BLOCKS", 128, 8, 4096) & ~7;
+  const int n_corr = (grid && s->strict && !s->plane && s->grid > left_blocks) ? left_blocks : s->grid;
   if (grid) {
     ProfScope prof_grid(PCGX_PROF_ICP_GRID, st);
     const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
@@ -1038,7 +1044,7 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
                          dim3(xcd_grid((unsigned)((s->nt + kIcpStrictGridBlock - 1) / kIcpStrictGridBlock))),
                          dim3(kIcpStrictGridBlock), 0, st, s->base->grid, x, y, z,
                          s->nt, s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals,
-                         s->d_first_leaf, s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials,
+                         s->d_first_leaf, s->d_walk_list, s->d_walk_count, (uint32_t)n_corr, s->d_partials,
                          (unsigned long long *)nullptr, (const uint32_t *)(s->caller_order_fresh ? s->d_orig_of : nullptr),
                          s->caller_order_fresh ? s->d_match_caller : nullptr);
     else
@@ -1052,7 +1058,7 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
 #define PCGX_LAUNCH_CORR(MD, PL, GR)                                                                                  \
   do {                                                                                                                \
   if (s->strict && !PL)                                                                                               \
-    hipLaunchKernelGGL((icp_corr_kernel<MD, false, GR, false>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, \
+    hipLaunchKernelGGL((icp_corr_kernel<MD, false, GR, false>), dim3(n_corr), dim3(kIcpBlock), lds, st, tv, x, y, z, \
                        s->nt, s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, s->d_match_id,           \
                        (const float4 *)s->d_normals, s->d_walk_list, s->d_walk_count,                                 \
                        (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock),                                        \

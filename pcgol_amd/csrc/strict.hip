@@ -212,6 +212,69 @@ __device__ __forceinline__ double tile_prefix(const double *__restrict__ tile_v,
   return wave_allsum_f64(v);
 }
 
+// The same prefix out of what the tiles' workgroups of THIS launch have published (StrictWork::tile_pub,
+// [row][ntiles_pad] doubles): 16-byte loads that bypass the vector L1 (sc1), lane l of a round the tiles 2 l and
+// 2 l + 1 -- a wave instruction reads 1 KB in one piece -- four rounds in flight, behind the arrival poll of
+// strict_sum_kernel and a workgroup barrier.  The producers' stores are write-through (sc1) and drained (s_waitcnt
+// vmcnt(0)) before their arrival bit is set (MI355X guide, inter-workgroup visibility: sc1 stores + drained flag +
+// sc1 loads).  Only guesses depend on the values: a sum read too early would cost time (records that do not cover
+// the state), never a wrong result.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double tile_prefix_pub(const double *__restrict__ pub, int64_t ntiles_pad, int row, int64_t tile,
+                                                  int lane) {
+  const char *p = reinterpret_cast<const char *>(pub + (int64_t)row * ntiles_pad);
+  double v = 0.0;
+  for (int64_t base = 0; base < tile; base += 4 * 128) {  // (ntiles_pad is a multiple of 128: every load lies inside the row)
+    u32x4 x[4];
+    const char *a[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t k = base + u * 128 + 2 * lane;
+      a[u] = p + (size_t)(k < tile ? k : 0) * 8;
+    }
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off sc1\n\t"
+        "global_load_dwordx4 %1, %5, off sc1\n\t"
+        "global_load_dwordx4 %2, %6, off sc1\n\t"
+        "global_load_dwordx4 %3, %7, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
+        : "memory");
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t k = base + u * 128 + 2 * lane;
+      const double d0 = __longlong_as_double((long long)((unsigned long long)x[u].y << 32 | x[u].x));
+      const double d1 = __longlong_as_double((long long)((unsigned long long)x[u].w << 32 | x[u].z));
+      v += k < tile ? d0 : 0.0;
+      v += k + 1 < tile ? d1 : 0.0;
+    }
+  }
+  return wave_allsum_f64(v);
+}
+
+// the prefixes of two arrays at once (strict_job_kernel: tile sums + tile errors), their loads in flight together
+__device__ __forceinline__ double tile_prefix2(const double *__restrict__ a, const double *__restrict__ b, int64_t ntiles, int row,
+                                               int64_t tile, int lane) {
+  const double *pa = a + (int64_t)row * ntiles, *pb = b + (int64_t)row * ntiles;
+  double v = 0.0, w = 0.0;
+  for (int64_t base = 0; base < tile; base += 8 * 64) {
+    double x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int64_t k = base + u * 64 + lane;
+      x[u] = k < tile ? pa[k] : 0.0;
+      y[u] = k < tile ? pb[k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      v += x[u];
+      w += y[u];
+    }
+  }
+  return wave_allsum_f64(v) + wave_allsum_f64(w);  // (each the sum tile_prefix() returns, bit for bit)
+}
+
 // ---- tile sums (strict_terms.h) as a kernel of their own: sessions whose correspondence kernels do not form them
 constexpr int kTileSumBlock = 256;
 __global__ __launch_bounds__(kTileSumBlock) void strict_tilesum_kernel(const float4 *__restrict__ match,
@@ -297,17 +360,31 @@ constexpr int kSumBlock = 512;
 constexpr int kSumWaves = kSumBlock / 64;
 enum { JOB_CROSSING = 1, JOB_NOWINDOW = 2 };
 
+// kExchange: nobody formed the tile sums before this launch.  Every workgroup forms its own tile's nine sums from the
+// terms it has just staged (phase 1), publishes them (one 128-byte line, write-through), sets its arrival bit and
+// waits for the bits of all tiles BEFORE its own; then its waves read their prefixes out of the published lines.
+// A workgroup waits for lower block indices only, and each XCD's dispatcher hands out its blocks in ascending
+// order, so the lowest unfinished tile is always resident or next in line on an XCD with room: the wait ends
+// whatever part of the grid is resident (C5's 3907 tiles on 512 places as well).  The poll is bounded all the same
+// (kExchangeSpins): a workgroup that gives up goes on with the lines as they are -- its guesses are then off, its
+// records do not cover the states, the chain kernel adds its tile term by term: slow and still exact (dbg[63]
+// counts; the tests require 0).  What this buys: the 28 MB pass over pairs and targets that formed the tile sums
+// in front of this kernel (12-14 us of the C4 step), for a wait of 2-4 us behind the slowest phase 1.
+constexpr int kExchangeSpins = 1 << 15;
+template <bool kExchange>
 __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void strict_sum_kernel(
     const float4 *__restrict__ match, const uint32_t *__restrict__ pos_of, const IcpState *__restrict__ state, StrictWork W) {
   __shared__ float4 s_terms[kStrictRows][kTile / 4];
   __shared__ int s_np[kSumWaves];
+  __shared__ double s_tot[16];
   const int done = state->done;  // (looked at behind phase 1, whose loads it would only hold up: nothing is written before)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tile = blockIdx.x;
   const int NR = W.nrows;
   const long long t_0 = stat_clock(W);
+  long long t_x0 = 0;
   // the float64 prefix of this wave's row (strict_tilesum_kernel's sums): its loads fly while phase 1 runs
-  double P0 = wave < NR ? tile_prefix(W.tile_sum, W.ntiles, wave, tile, lane) : 0.0;
+  double P0 = (!kExchange && wave < NR) ? tile_prefix(W.tile_sum, W.ntiles, wave, tile, lane) : 0.0;
   // ---- phase 1: the tile's terms, every thread one quad
   {
     const TermSrc S = make_term_src(match, pos_of, state, W);
@@ -332,10 +409,72 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     for (int w = 0; w < kSumWaves; w++) np += s_np[w];
     W.tile_pairs[tile] = (uint32_t)np;
   }
+  if (kExchange) {
+    // ---- the tile's own sums out, the earlier tiles' sums in
+    for (int row = wave; row < NR; row += kSumWaves) {
+      const LdsQuads q{s_terms[row], lane};
+      double lsum = 0.0;
+#pragma unroll
+      for (int v = 0; v < kLeaf / 4; v++) {
+        const float4 a = q(v);
+        lsum += (double)a.x; lsum += (double)a.y; lsum += (double)a.z; lsum += (double)a.w;
+      }
+      const double pre = wave_excl_scan_f64(lsum, lane);  // (the order phase 2 adds them up in: the same double)
+      if (lane == 63) s_tot[row] = pre + lsum;
+    }
+    __syncthreads();
+    t_x0 = stat_clock(W);
+    if (wave == 0) {
+      if (lane < NR) {
+        const double v = s_tot[lane];
+        __hip_atomic_store(&W.tile_pub[(int64_t)lane * W.ntiles_pad + tile], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        W.tile_sum[(int64_t)lane * W.ntiles + tile] = v;  // (for strict_job_kernel, a launch later)
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // arrival: my bit in my group's word; whoever completes a group of 32 tiles says so one level up
+      const int64_t g_mine = tile >> 5, n_groups = (W.ntiles + 31) >> 5;
+      if (lane == 0) {
+        const uint32_t bit = 1u << (tile & 31);
+        const uint32_t full = (g_mine == n_groups - 1 && (W.ntiles & 31)) ? (1u << (W.ntiles & 31)) - 1u : 0xffffffffu;
+        const uint32_t old = __hip_atomic_fetch_or(&W.tile_arrived[32 * g_mine], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((old | bit) == full)
+          __hip_atomic_fetch_or(&W.tile_arrived[32 * (n_groups + (g_mine >> 5))], 1u << (g_mine & 31), __ATOMIC_RELAXED,
+                                __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // wait for every tile before mine: lane 0 for the earlier tiles of my group, lanes 1.. for the groups before it
+      bool gave_up = false;
+      const int64_t G_mine = g_mine >> 5;
+      for (int64_t G0 = 0; G0 <= G_mine && !gave_up; G0 += kLanes - 1) {  // uniform (one round up to 64512 tiles)
+        const int64_t G = G0 + lane - 1;
+        uint32_t want = 0u;
+        const unsigned int *word = W.tile_arrived;
+        if (lane == 0) {
+          want = G0 == 0 ? (1u << (tile & 31)) - 1u : 0u;
+          word = W.tile_arrived + 32 * g_mine;
+        } else if (G <= G_mine) {
+          want = G < G_mine ? 0xffffffffu : (1u << (g_mine & 31)) - 1u;
+          word = W.tile_arrived + 32 * (n_groups + G);
+        }
+        for (int spins = 0;; spins++) {
+          uint32_t have = 0u;
+          if (want) have = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__ballot((have & want) != want) == 0ull) break;
+          if (spins >= kExchangeSpins) {
+            gave_up = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      if (gave_up && lane == 0) atomicAdd(&W.dbg[63], 1ull);
+    }
+    __syncthreads();
+  }
   const long long t_1 = stat_clock(W);
   // ---- phase 2: every wave its row (one pass unless a weight function adds the ninth row)
   for (int row = wave; row < NR; row += kSumWaves) {
-    if (row >= kSumWaves) P0 = tile_prefix(W.tile_sum, W.ntiles, row, tile, lane);
+    if (kExchange) P0 = tile_prefix_pub(W.tile_pub, W.ntiles_pad, row, tile, lane);
+    else if (row >= kSumWaves) P0 = tile_prefix(W.tile_sum, W.ntiles, row, tile, lane);
     const LdsQuads q{s_terms[row], lane};
     TileRec T;
     T.s = summary_identity();
@@ -364,7 +503,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     // up to the terms as they are)
     const double tile_total = __shfl(pre, 63) + __shfl(lsum, 63);
     if (lane == 0)
-      W.tile_err[(int64_t)row * W.ntiles + tile] = terr + (tile_total - W.tile_sum[(int64_t)row * W.ntiles + tile]);
+      W.tile_err[(int64_t)row * W.ntiles + tile] = terr + (tile_total - (kExchange ? s_tot[row] : W.tile_sum[(int64_t)row * W.ntiles + tile]));
     // window of the tile
     const uint32_t mn = wave_all_umin(cr.mn), mx = wave_all_umax(cr.mx);
     const bool one_sign = __ballot(cr.sg_or != cr.sg_and) == 0ull &&
@@ -439,12 +578,15 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
       J->pad = maybe_E >= 0 ? (1 | (maybe_E << 8)) : 0;
     }
     float4 *dst = W.aux_terms + (size_t)slot * (kTile / 4);
+    int lane_here = lane;  // (opaque: the eight store offsets are formed here, not kept in registers -- one of them in
+    asm volatile("" : "+v"(lane_here));  // scratch -- through the whole row loop)
 #pragma unroll
-    for (int v = 0; v < kLeaf / 4; v++) dst[v * kLanes + lane] = s_terms[row][v * kLanes + lane];
+    for (int v = 0; v < kLeaf / 4; v++) dst[v * kLanes + lane_here] = s_terms[row][v * kLanes + lane_here];
   }
   if (threadIdx.x == 0 && (W.selfcheck & 2)) {  // measurement aid (PCGX_STRICT_TRACE), plain stores only
     W.stamps[tile * 16 + 0] = (unsigned long long)t_0;
     W.stamps[tile * 16 + 1] = (unsigned long long)t_1;
+    W.stamps[tile * 16 + 2] = (unsigned long long)t_x0;
     W.stamps[tile * 16 + 5] = (unsigned long long)stat_clock(W);
   }
 }
@@ -468,7 +610,9 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
   // one workgroup per slot that could be handed out; most leave at once.  (A loop over the slots of a shard, tried
   // twice: the loop alone takes the kernel from 67 to 146 VGPRs, and with fewer workgroups per CU the jobs queue.)
-  const unsigned slot = blockIdx.x, shard = slot / per_shard;
+  // (block b looks after slot b / kAuxShards of shard b % kAuxShards: the slots a launch hands out -- the first few of
+  // every shard -- are the blocks dispatched first, whatever the number of blocks that leave at once behind them)
+  const unsigned shard = blockIdx.x % kAuxShards, slot = shard * per_shard + blockIdx.x / kAuxShards;
   // ("done" and the shard's count in one round trip, not two)
   const int done = state->done;
   const unsigned handed_out = W.aux_count[shard * 32];
@@ -531,7 +675,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
       lsum += (double)a.x; lsum += (double)a.y; lsum += (double)a.z; lsum += (double)a.w;
     }
     const double pre = wave_excl_scan_f64(lsum, lane);
-    const double base = tile_prefix(W.tile_sum, W.ntiles, row, tile, lane) + tile_prefix(W.tile_err, W.ntiles, row, tile, lane);
+    const double base = tile_prefix2(W.tile_sum, W.tile_err, W.ntiles, row, tile, lane);
     uint32_t g;
     ChainRange cr;
     double terr;
@@ -585,26 +729,30 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   // 1-2 us; if the walker's state is one of the candidates the tile is a look-up.  Four candidates per lane: four
   // independent chains cost 1.9x one (tools/micro/dep_add.cpp).
   if (kind == JOB_NOWINDOW && part >= 1) {
-    // no window: waves 1..3, the whole tile from 768 candidates around the tile's guess (10 us: the launch is that
-    // much longer in the few iterations that have such tiles; cut into quarters like a level crossing below, a
-    // third of these tiles were lost where one quarter's end fell outside the next quarter's candidates)
-    if (part >= 4) return;
+    // no window: waves 1..6, the whole tile from 768 candidates around the tile's guess, two per lane (two
+    // independent chains cost 1.3x one, four 1.9x, tools/micro/dep_add.cpp: 7-8 us where three waves with four
+    // each took 10-11 -- the launch is that much longer in the few iterations that have such tiles; cut into
+    // quarters like a level crossing below, a third of these tiles were lost where one quarter's end fell outside
+    // the next quarter's candidates)
+    constexpr int kPer = 2, kWavesNw = kCand / (kPer * kLanes);
+    static_assert(kWavesNw * kPer * kLanes == kCand && kWavesNw <= kJobBlock / 64 - 1, "waves 1 .. kWavesNw carry the table");
+    if (part > kWavesNw) return;
     const uint32_t g0 = (uint32_t)s_hdr[1];
     const uint32_t mag = g0 & 0x7fffffffu;
-    uint32_t out[kCandPerLane];
+    uint32_t out[kPer];
 #pragma unroll
-    for (int c = 0; c < kCandPerLane; c++) out[c] = 0x7fc00000u;  // "no table"
-    const int i0 = (part - 1) * kCandInner + lane;
+    for (int c = 0; c < kPer; c++) out[c] = 0x7fc00000u;  // "no table"
+    const int i0 = (part - 1) * kPer * kLanes + lane;
     if (mag > kCandReach && mag < 0x7f800000u - kCandReach) {  // uniform
-      float x[kCandPerLane];
+      float x[kPer];
 #pragma unroll
-      for (int c = 0; c < kCandPerLane; c++) x[c] = u2f(g0 + (uint32_t)cand_offset(i0 + c * kLanes));
+      for (int c = 0; c < kPer; c++) x[c] = u2f(g0 + (uint32_t)cand_offset(i0 + c * kLanes));
       serial_leaves_lin(x, s_lin, 0, kLanes);
 #pragma unroll
-      for (int c = 0; c < kCandPerLane; c++) out[c] = f2u(x[c]);
+      for (int c = 0; c < kPer; c++) out[c] = f2u(x[c]);
     }
 #pragma unroll
-    for (int c = 0; c < kCandPerLane; c++) W.cand[(size_t)slot * kCand + i0 + c * kLanes] = out[c];
+    for (int c = 0; c < kPer; c++) W.cand[(size_t)slot * kCand + i0 + c * kLanes] = out[c];
     stamp_end(2);
     return;
   }
@@ -941,7 +1089,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   __shared__ uint32_t s_tab[kHelpers][kCand];  // helper h: the candidate table of the tile it holds (strict_job_kernel)
   __shared__ int s_tab_ord[kHelpers];          // ... and that tile's ordinal + 1 (0: none yet)
   __shared__ float4 s_tile[kTile / 4];     // walker: the terms of a tile without a slot, formed again from the pairs
-  __shared__ unsigned long long s_np[kChainSegs];
+  __shared__ unsigned long long s_np;
+  __shared__ int s_np_ok;
   const int done = state->done;  // (looked at behind the first chunk's loads, which it would only hold up)
   // (rfl: "which wave" is the same in all lanes, and the compiler has to know -- or the branch between walker and
   // helpers counts as divergent, the walker's state becomes a vector register, and every apply() of the walk runs
@@ -961,7 +1110,10 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       s_mail[threadIdx.x].ack = 0;
       if (threadIdx.x < kHelpers) s_tab_ord[threadIdx.x] = 0;
     }
-    if (threadIdx.x == 0) s_progress = 0;
+    if (threadIdx.x == 0) {
+      s_progress = 0;
+      if (chunk == 0) s_np_ok = 0;
+    }
     // ---- helpers: runs of equal windows, segmented scan forwards inside each wave
     TileRec R;
     R.key = -2;
@@ -1039,6 +1191,18 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         const TileRec R7 = rec_get(s_rec, kWalker * 64 + lane);
         const int32_t kn = __shfl_down(R7.key, 1);
         scan_backwards(kWalker, R7, lane == 63 || R7.key < 0 || R7.key != kn);
+      }
+      // the pair count of the iteration: a helper of row 0 adds up the tiles' counts while the walk runs (integers: no
+      // order to keep); the walker stores it with its sum
+      if (row == 0 && wave == 1 && chunk == 0) {
+        unsigned long long v = 0ull;
+        for (int64_t t = lane; t < W.ntiles; t += kLanes) v += W.tile_pairs[t];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) {
+          s_np = v;
+          lds_put(&s_np_ok, 1);
+        }
       }
       int k = wave;  // my tiles: ordinals wave, wave + 7, ...
       while (k < naux) {  // uniform
@@ -1282,19 +1446,9 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     atomicAdd(&W.dbg[25], n_tab_nw);
     atomicAdd(&W.dbg[45], n_tab_cross);
   }
-  // the pair count of the iteration: row 0 adds up the tiles' counts (a fixed order is not needed: integers)
-  if (row == 0) {
-    unsigned long long v = 0ull;
-    for (int64_t k = threadIdx.x; k < W.ntiles; k += kChainTiles) v += W.tile_pairs[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) s_np[wave] = v;
-    __syncthreads();
-    if (walker && lane == 0) {
-      unsigned long long np = 0ull;
-      for (int w = 0; w < kChainSegs; w++) np += s_np[w];
-      __hip_atomic_store(&sums10[S_PAIRS], (double)np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  if (row == 0 && walker && lane == 0) {
+    while (lds_get(&s_np_ok) == 0) __builtin_amdgcn_s_sleep(1);
+    __hip_atomic_store(&sums10[S_PAIRS], (double)s_np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // component order of sums10: Value, G0..G5, DistRMS, Weight, Pairs
   if (walker && lane == 0) {
@@ -1316,6 +1470,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         sums10[S_WEIGHT] = sums[S_WEIGHT];
       }
       for (int k = 0; k < kAuxShards; k++) W.aux_count[k * 32] = 0u;
+      if (W.exchange)
+        for (int64_t k = 0, n = (W.ntiles + 31) / 32, m = n + (n + 31) / 32; k < m; k++) W.tile_arrived[32 * k] = 0u;
       *W.done_rows = 0u;
       if (fuse_update) icp_update_step(state, sums, kp);
     }
@@ -1342,6 +1498,12 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t sz_tile = up((size_t)kStrictRows * W.ntiles * sizeof(double));  // (twice: sums and errors)
   const size_t sz_pairs = up((size_t)W.ntiles * sizeof(uint32_t));
+  W.ntiles_pad = (W.ntiles + 127) & ~(int64_t)127;
+  const size_t sz_pub = up((size_t)W.ntiles_pad * 16 * sizeof(double));
+  const int64_t n_groups = (W.ntiles + 31) / 32;
+  const size_t sz_arr = up((size_t)(n_groups + (n_groups + 31) / 32) * 128);
+  // (PCGX_STRICT_EXCHANGE=0: the tile sums are formed by a pass of their own in front of the summaries, as in round 3)
+  W.exchange = (getenv("PCGX_STRICT_EXCHANGE") && atoi(getenv("PCGX_STRICT_EXCHANGE")) == 0) ? 0 : 1;
   const size_t sz_rec = up((size_t)kStrictRows * W.ntiles * sizeof(TileRec));
   // slots for the tiles that cross a level or have no window (6 KB of leaf records + 8 KB of terms each):
   // a quarter of all tiles, far more than ever seen (C4: ~2 %; a sum hovering around zero over the whole
@@ -1358,7 +1520,7 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   const size_t sz_xyz = up((size_t)(nt ? nt : 1) * 12 + 64);
   const size_t sz_stamps = up((size_t)W.ntiles * 16 * sizeof(unsigned long long));
   const size_t sz_ctr = 256 + (size_t)kAuxShards * 128;
-  const size_t total = 2 * sz_tile + sz_pairs + sz_rec + sz_aux + sz_auxt + sz_jobs + sz_cand + sz_xyz + sz_ctr + 512 + sz_stamps;
+  const size_t total = 2 * sz_tile + sz_pub + sz_arr + sz_pairs + sz_rec + sz_aux + sz_auxt + sz_jobs + sz_cand + sz_xyz + sz_ctr + 512 + sz_stamps;
   hipError_t e = dev_cache_alloc(&b->block, total);
   if (e != hipSuccess) {
     delete b;
@@ -1367,6 +1529,8 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   uint8_t *p = (uint8_t *)b->block;
   W.tile_sum = (double *)p; p += sz_tile;
   W.tile_err = (double *)p; p += sz_tile;
+  W.tile_pub = (double *)p; p += sz_pub;  // (256-byte aligned: a tile's line is one 128-byte line)
+  W.tile_arrived = (unsigned int *)p; p += sz_arr;
   W.tile_pairs = (uint32_t *)p; p += sz_pairs;
   W.recs = (TileRec *)p; p += sz_rec;
   W.aux = (LeafAux *)p; p += sz_aux;
@@ -1381,6 +1545,7 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   W.stamps = (unsigned long long *)p;
   // slot / ticket counters and debug counters start at zero (the chain kernel re-zeroes what it consumed)
   e = hipMemsetAsync(counters, 0, sz_ctr + 512, st);
+  if (e == hipSuccess) e = hipMemsetAsync(W.tile_arrived, 0, sz_arr, st);
   if (e == hipSuccess && nt > 0) {
     hipLaunchKernelGGL(strict_xyz_caller_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, tx, ty, tz, pos_of, nt,
                        const_cast<float *>(W.xyz_caller));
@@ -1412,15 +1577,19 @@ const StrictWork *strict_work(StrictBuffers *b, const IcpKernelParams &kp) {
 pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
                            double *sums10, const IcpKernelParams &kp, bool fuse_update, bool have_tile_sums, hipStream_t st) {
   const StrictWork &W = *strict_work(b, kp);
-  if (!have_tile_sums) {
+  if (!have_tile_sums && !W.exchange) {
     ProfScope prof(PCGX_PROF_STRICT_TERMS, st);
     hipLaunchKernelGGL(strict_tilesum_kernel, dim3((unsigned)W.ntiles), dim3(kTileSumBlock), 0, st, match, pos_of,
                        (const IcpState *)state, W);
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_SUM, st);
-    hipLaunchKernelGGL(strict_sum_kernel, dim3((unsigned)W.ntiles), dim3(kSumBlock), 0, st, match, pos_of,
-                       (const IcpState *)state, W);
+    if (W.exchange)
+      hipLaunchKernelGGL(strict_sum_kernel<true>, dim3((unsigned)W.ntiles), dim3(kSumBlock), 0, st, match, pos_of,
+                         (const IcpState *)state, W);
+    else
+      hipLaunchKernelGGL(strict_sum_kernel<false>, dim3((unsigned)W.ntiles), dim3(kSumBlock), 0, st, match, pos_of,
+                         (const IcpState *)state, W);
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_JOB, st);

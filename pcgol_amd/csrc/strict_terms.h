@@ -57,6 +57,12 @@ struct StrictWork {
   const float *xyz_caller;      // [nt][3] the targets in the caller's order
   double *tile_sum;             // [9][ntiles] float64 sums of the tiles' terms
   double *tile_err;             // [9][ntiles] rounding error the float32 chain makes inside the tile (from its guess chains)
+  double *tile_pub;             // [16][ntiles_pad] the same tile sums, written write-through by the tile's workgroup of
+                                // strict_sum_kernel and read by the later tiles' workgroups of the SAME launch
+  unsigned int *tile_arrived;   // arrival bits of that exchange, every word on a 128-byte line of its own: word g (at
+                                // [32 g]) bit t % 32 = tile 32 g + t has published; behind them, at [32 (ngroups + G)],
+                                // bit g % 32 of word G = g / 32: group g is complete (zeroed by the chain kernel)
+  int64_t ntiles_pad;           // ntiles rounded up to a multiple of 128 (16-byte loads of two tiles per lane stay inside a row)
   uint32_t *tile_pairs;         // [ntiles] matched targets of the tiles
   TileRec *recs;                // [9][ntiles]
   LeafAux *aux;                 // [naux][64]: what the chain kernel needs to recompute a tile that owns a slot
@@ -73,6 +79,7 @@ struct StrictWork {
   int32_t weight_fn;  // evaluator.go:130 (PCGX_WEIGHT_*)
   float weight_a;
   const float *raw_terms;  // testing (pcgx_debug_strict_sum_dev): [9][nt] float32 terms given as they are, no pairs
+  int32_t exchange;   // strict_sum_kernel forms the tile sums itself and its workgroups exchange them inside the launch
   int32_t selfcheck;  // bit 0: every step of the chain walk is re-derived term by term and compared (dbg[12..15]);
                       // 1: PCGX_STRICT_TRACE stamps; 2: no candidate tables; 3: wall-clock columns of the counters
 };
