@@ -973,9 +973,14 @@ __device__ __forceinline__ void resolve_stats(const StrictWork &W, int kind, int
 
 // debugging aid (W.selfcheck): the state after tiles [a, b) from `before`, term by term; mismatches
 // against what the walk produced are counted per path in dbg[12 + path]
-__device__ __forceinline__ void selfcheck(const StrictWork &W, const TermSrc &src, int row, uint32_t before, uint32_t after,
+// (kCheck: the chain kernel is built twice -- with these loops inlined at five places of the walk it is 130 KB of
+// code, and the walker of every launch started on a cold instruction cache, jumping over them)
+template <bool kCheck, class MakeSrc>
+__device__ __forceinline__ void selfcheck(const StrictWork &W, MakeSrc make_src, int row, uint32_t before, uint32_t after,
                                           int64_t a, int64_t b, int path, int lane, float4 *lds) {
+  if (!kCheck) return;
   if (!(W.selfcheck & 1)) return;
+  const TermSrc src = make_src();
   uint32_t x = before;
   for (int64_t k = a; k < b; k++) {
     __builtin_amdgcn_wave_barrier();
@@ -1070,6 +1075,7 @@ struct ChainMail {  // walker <-> one helper
   uint32_t s_in, s_out;
 };
 
+template <bool kCheck>
 __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 *__restrict__ match,
                                                                   const uint32_t *__restrict__ pos_of,
                                                                   IcpState *__restrict__ state, StrictWork W,
@@ -1097,11 +1103,17 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   // on the vector unit at its dependent-instruction latency instead of on the scalar unit)
   const int row = blockIdx.x, lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
   const bool walker = wave == kWalker;
-  const TermSrc src = make_term_src(match, pos_of, state, W);
+  // (the pairs' source is put together where a tile is formed again from the pairs -- rare -- and not kept: its
+  // eighteen words would sit in scalar registers through the whole walk, which runs on the scalar unit and had
+  // 188 of its registers spilled into vector lanes)
+  auto term_src = [&]() { return make_term_src(match, pos_of, state, W); };
   uint32_t s = f2u(0.0f);  // walker state, evaluator.go:122: the sums start at zero
   // walker: counters of the whole row, written once behind the last chunk (an atomic in flight holds up the
-  // next release store of its wave, and the walk is a chain of those)
-  unsigned long long n_run = 0, n_runfail = 0, n_recfail = 0, ticks_scan = 0, ticks_walk = 0, n_tab_nw = 0, n_tab_cross = 0;
+  // next release store of its wave, and the walk is a chain of those).  Vector registers (opaque to the compiler):
+  // as scalars they were written to and read from spill lanes around every run.
+  uint32_t n_run = 0, n_runfail = 0, n_recfail = 0, n_tab_nw = 0, n_tab_cross = 0;
+  asm volatile("" : "+v"(n_run), "+v"(n_runfail), "+v"(n_recfail), "+v"(n_tab_nw), "+v"(n_tab_cross));
+  unsigned long long ticks_scan = 0, ticks_walk = 0;
   for (int64_t chunk = 0; chunk < W.ntiles; chunk += kChainTiles) {
     const long long t_a = stat_clock(W);
     if (threadIdx.x < kChainSegs) {
@@ -1342,7 +1354,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             }
             const uint32_t s_in = s;
             if ((Qr.key >= 0 && apply(s, Qr.key, Qr.s)) || apply_point(s, Qr)) {
-              selfcheck(W, src, row, s_in, s, chunk + h, chunk + e + 1, 0, lane, s_tile);
+              selfcheck<kCheck>(W, term_src, row, s_in, s, chunk + h, chunk + e + 1, 0, lane, s_tile);
               // (a hint for helpers whose tile the walk has passed: no ordering needed)
               if (lane == 0) __hip_atomic_store(&s_progress, e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               continue;
@@ -1363,7 +1375,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             const uint32_t s_in = s;
             if (ngood > 0) s = (uint32_t)__builtin_amdgcn_readlane((int)mine, ngood - 1);
             f = h + ngood;
-            selfcheck(W, src, row, s_in, s, chunk + h, chunk + f, 1, lane, s_tile);
+            selfcheck<kCheck>(W, term_src, row, s_in, s, chunk + h, chunk + f, 1, lane, s_tile);
           }
           while (f <= e) {
             // tile f does not cover the state (its place in the run's prefix composition failed, or it is
@@ -1402,7 +1414,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
                 s = (uint32_t)rfl((int)__hip_atomic_load(&M->s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
               } else {  // a tile without a slot: its terms are formed again from the pairs, all 2048 are added
                 const long long t_begin = stat_clock(W);
-                recompute_tile_to_lds(src, row, chunk + f, lane, s_tile);
+                recompute_tile_to_lds(term_src(), row, chunk + f, lane, s_tile);
                 LeafAux none;
                 int serial, tried, applied;
                 s = resolve_staged<false>(s, 0, -1, none, lane, s_tile, nullptr, serial, tried, applied);
@@ -1410,7 +1422,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
                 if (lane == 0) resolve_stats(W, 0, serial, tried, applied, stat_clock(W) - t_begin);
               }
             }
-            selfcheck(W, src, row, s_in, s, chunk + f, chunk + f + 1, 2, lane, s_tile);
+            selfcheck<kCheck>(W, term_src, row, s_in, s, chunk + f, chunk + f + 1, 2, lane, s_tile);
             f++;
             if (f > e) break;
             while (lds_get(&s_sufok[f >> 6]) == 0) {
@@ -1418,7 +1430,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             const TileRec Sf = load_rec_uniform(s_suf, f);  // the rest of the run in one step
             const uint32_t s_in2 = s;
             if ((Sf.key >= 0 && apply(s, Sf.key, Sf.s)) || apply_point(s, Sf)) {
-              selfcheck(W, src, row, s_in2, s, chunk + f, chunk + e + 1, 3, lane, s_tile);
+              selfcheck<kCheck>(W, term_src, row, s_in2, s, chunk + f, chunk + e + 1, 3, lane, s_tile);
               break;
             }
           }
@@ -1434,17 +1446,17 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     __syncthreads();
   }
   if (walker && lane == 0) {
-    atomicAdd(&W.dbg[0], n_run);
-    atomicAdd(&W.dbg[1], n_runfail);
-    atomicAdd(&W.dbg[4], n_recfail);
+    atomicAdd(&W.dbg[0], (unsigned long long)n_run);
+    atomicAdd(&W.dbg[1], (unsigned long long)n_runfail);
+    atomicAdd(&W.dbg[4], (unsigned long long)n_recfail);
     atomicAdd(&W.dbg[8], ticks_scan);
     atomicAdd(&W.dbg[9], ticks_walk);
     atomicMax(&W.dbg[14 + 32], ticks_walk);   // slowest row of the launch
     atomicAdd(&W.dbg[27 + row], ticks_walk);  // per row: walk ticks, tiles resolved
-    atomicAdd(&W.dbg[36 + row], n_recfail);
-    atomicAdd(&W.dbg[24], n_tab_nw);  // tiles without a window seen, and found in their candidate tables
-    atomicAdd(&W.dbg[25], n_tab_nw);
-    atomicAdd(&W.dbg[45], n_tab_cross);
+    atomicAdd(&W.dbg[36 + row], (unsigned long long)n_recfail);
+    atomicAdd(&W.dbg[24], (unsigned long long)n_tab_nw);  // tiles without a window seen, and found in their candidate tables
+    atomicAdd(&W.dbg[25], (unsigned long long)n_tab_nw);
+    atomicAdd(&W.dbg[45], (unsigned long long)n_tab_cross);
   }
   if (row == 0 && walker && lane == 0) {
     while (lds_get(&s_np_ok) == 0) __builtin_amdgcn_s_sleep(1);
@@ -1598,8 +1610,12 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
-    hipLaunchKernelGGL(strict_chain_kernel, dim3((unsigned)W.nrows), dim3(kChainBlock), 0, st, match, pos_of, state, W, sums10,
-                       kp, fuse_update ? 1 : 0);
+    if (W.selfcheck & 1)
+      hipLaunchKernelGGL(strict_chain_kernel<true>, dim3((unsigned)W.nrows), dim3(kChainBlock), 0, st, match, pos_of, state, W,
+                         sums10, kp, fuse_update ? 1 : 0);
+    else
+      hipLaunchKernelGGL(strict_chain_kernel<false>, dim3((unsigned)W.nrows), dim3(kChainBlock), 0, st, match, pos_of, state, W,
+                         sums10, kp, fuse_update ? 1 : 0);
   }
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;

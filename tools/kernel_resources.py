@@ -51,6 +51,6 @@ if __name__ == "__main__":
     for name, r in ks.items():
         if want and not any(w in name for w in want):
             continue
-        print("%-60s VGPR %3s AGPR %3s SGPR %3s scratch %4s B/lane LDS %6s B occupancy %s" % (
-            short(name), r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize"), r.get("LDS Size"),
-            r.get("Occupancy")))
+        print("%-60s VGPR %3s AGPR %3s SGPR %3s (spilled: %s SGPRs, %s VGPRs) scratch %4s B/lane LDS %6s B occupancy %s" % (
+            short(name), r.get("VGPRs"), r.get("AGPRs"), r.get("TotalSGPRs"), r.get("SGPRs Spill"), r.get("VGPRs Spill"),
+            r.get("ScratchSize"), r.get("LDS Size"), r.get("Occupancy")))
