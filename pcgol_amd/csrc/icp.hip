@@ -1178,7 +1178,8 @@ extern "C" pcgx_status pcgx_icp_session_step_sharded(pcgx_icp_session *s, pcgx_c
   if (!s || !c) return fail(PCGX_E_INVALID, "pcgx_icp_session_step_sharded: NULL argument");
   int32_t rank = 0, world = 1;
   PCGX_TRY(pcgx_comm_rank(c, &rank, &world));
-  if (world == 1) return pcgx_icp_session_step(s, stream);
+  if (world == 1 && !(getenv("PCGX_COMM_FORCE_COLLECTIVE") && atoi(getenv("PCGX_COMM_FORCE_COLLECTIVE")) != 0))
+    return pcgx_icp_session_step(s, stream);
   if (s->strict && s->strict_explicit)
     return fail(PCGX_E_INVALID, "strict sums are not offered on a sharded target (no sequential order)");
   s->strict = 0;  // the default (PCGX_SUMS_REFERENCE) on a sharded target: float64 sums, all-reduced

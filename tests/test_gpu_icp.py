@@ -519,3 +519,45 @@ def test_builtin_weight_fns_match_the_oracle(wf):
 def test_custom_weight_closure_is_refused():
     with pytest.raises(NotImplementedError):
         icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=1.0), WeightFn=lambda d: 1.0)
+
+
+def test_more_than_two_to_the_24_pairs_default_sums_equal_the_oracle():
+    """Above 2^24 pairs the reference's ninth sum (0 + 1 + 1 + ... in float32, evaluator.go:143) stops at 2^24: with
+    the default weight the device does not chain that sum but takes min(pairs, 2^24) (csrc/strict.hip, chain kernel's
+    ticket) -- pinned here against the oracle's sequential float32 sums with 17.3M pairs on one GPU: Evaluated bit
+    for bit (its 1/sum-of-weights factor is 2^-24, not 1/pairs), and the pair count itself."""
+    n_base, n_t = 100_000, 17_300_000
+    base = synth.uniform_cloud(n_base, 4.0, 41)
+    rng = np.random.default_rng(43)
+    target = (base[rng.integers(0, n_base, n_t)] + rng.uniform(-0.004, 0.004, (n_t, 3)).astype(np.float32)).astype(np.float32)
+    t, o = kdtree.New(base), O.KDTree(base)
+    ev = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=1.0), MinPairs=6).Evaluate(t, target)
+    oe = O.icp_evaluate(o, target, 1.0, 6, sums_mode=0)
+    assert ev.NumPairs == oe["npairs"] == n_t > (1 << 24)
+    assert ev.Value == oe["value"] and ev.DistRMS == oe["dist_rms"] and np.array_equal(ev.Gradient, oe["gradient"])
+    # the stalled sum shows: Value is (sum of d^2) * 2^-24, above the mean squared distance by pairs / 2^24
+    o64 = O.icp_evaluate(o, target, 1.0, 6, sums_mode=1)
+    assert 1.02 < float(ev.Value) / float(o64["value"]) < 1.04
+
+
+@pytest.mark.parametrize("wf", [icp.WeightInverse(0.01), icp.WeightHuber(0.0009)], ids=["inverse", "huber"])
+def test_weight_fns_at_c4_full_size_match_the_oracle(wf):
+    """The built-in weight forms at C4's full size (1M x 1M): nine chained sums (the sum of the weights is a chain
+    of its own then), every iteration's Evaluated and the final pose equal to the Go-semantics oracle bit for bit."""
+    c = synth.c4_icp()
+    t, o = kdtree.New(c["base"]), O.KDTree(c["base"])
+    O.set_weight_fn(wf.kind, wf.a)
+    try:
+        s = icp.IcpSession(t, c["target"], c["max_dist"], 6, c["weight"], c["threshold"], c["max_iteration"], WeightFn=wf)
+        for _ in range(c["max_iteration"]):
+            s.step()
+        tr, st, conv = s.result()
+        sst = s.strict_stats()
+        s.close()
+        o32 = O.icp_fit(o, c["target"], c["max_dist"], 6, c["weight"], c["threshold"], c["max_iteration"], sums_mode=0)
+        assert st.NumIteration == o32["num_iteration"] == 20
+        assert np.array_equal(tr, o32["trans"]) and st.Evaluated.Value == o32["value"]
+        assert np.array_equal(st.Evaluated.Gradient, o32["gradient"]) and st.Evaluated.DistRMS == o32["dist_rms"]
+        assert sst[63] == 0   # no workgroup of the summary kernel gave up waiting for the tiles before it
+    finally:
+        O.set_weight_fn(0, 0.0)

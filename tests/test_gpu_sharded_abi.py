@@ -91,6 +91,48 @@ def test_two_ranks_on_one_gpu_through_the_abi_exchange():
         icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=c["threshold"], MaxIteration=c["max_iteration"]))
     trans1, stat1 = reg.Fit(kdtree.New(c["base"]), c["target"])
     assert np.max(np.abs(trans1 - res[0][2])) <= 1e-6
+    # ... and its distance from the Go-semantics oracle (sequential float32 sums, which a sum spread over ranks cannot
+    # form): the float32 chain's own rounding noise, inside north_star's 1e-5 at this size (120k pairs; it grows with
+    # the pair count: 1.6e-5 at 1M, tests/test_gpu_icp.py::test_c4_full_size_vs_oracle)
+    import oracle as O
+    o32 = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
+                    c["max_iteration"], sums_mode=0)
+    assert np.max(np.abs(res[0][2] - o32["trans"])) <= 1e-5
+
+
+def test_the_collective_runs_with_one_rank_when_forced(monkeypatch):
+    """PCGX_COMM_FORCE_COLLECTIVE=1: ncclAllReduce itself executes on a one-GPU box (csrc/comm.hip returns before it
+    when the world is one rank) -- on a buffer of known values, and as the exchange of a whole sharded Fit."""
+    import ctypes as C
+    import torch
+    from pcgol_amd import _lib as L
+    from pcgol_amd import icp, kdtree
+    from pcgol_amd.distributed import Comm, ShardedIcp
+
+    class Store(dict):
+        def set(self, k, v):
+            self[k] = v
+
+    monkeypatch.setenv("PCGX_COMM_FORCE_COLLECTIVE", "1")
+    comm = Comm.rccl(0, 1, Store())
+    buf = torch.arange(1, 31, dtype=torch.float64, device="cuda") * 0.125
+    torch.cuda.synchronize()
+    L.check(L.lib().pcgx_comm_allreduce_f64(comm._h, C.c_void_p(buf.data_ptr()), 30, None))
+    L.check(L.lib().pcgx_sync(None))
+    assert torch.equal(buf.cpu(), torch.arange(1, 31, dtype=torch.float64) * 0.125)
+    c = _case()
+    tree = kdtree.New(c["base"])
+    s = ShardedIcp(tree, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"],
+                   comm=comm, SumsMode=icp.SumsF64Tree)
+    t1, st1, _ = s.fit()
+    s.close()
+    comm.close()
+    reg = icp.PointToPointICPGradient(
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=c["min_pairs"],
+                                  SumsMode=icp.SumsF64Tree),
+        icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=c["threshold"], MaxIteration=c["max_iteration"]))
+    t0, st0 = reg.Fit(tree, c["target"])
+    assert np.array_equal(t0, t1) and st0.NumIteration == st1.NumIteration == 20
 
 
 def test_rccl_communicator_one_rank():
