@@ -25,40 +25,9 @@
 #include <utility>
 #include <vector>
 
-#include "pcgx_internal.h"
+#include "voxel_key.h"
 
 namespace pcgx {
-
-struct VoxelParams {
-  float vmin[3];
-  float leaf[3];
-  int64_t xs, ys;      // strides of the dense index (voxelgrid.go:137,151)
-  int64_t n_voxels;    // (xs+1)(ys+1)(zs+1) (voxelgrid.go:138)
-  // chunked mode (voxelgrid.go:49-79)
-  int32_t chunked;
-  float cs[3];         // clamped chunk size in metres
-  int64_t nx, ny, n_chunks;
-  // chunked mode with (chunk id, cell) fitting 32 bits: ONE sort key = cid << key_shift | cell
-  int32_t combined, key_shift;
-};
-
-__device__ __forceinline__ float ld_f32(const uint8_t *p) {
-  float v;
-  __builtin_memcpy(&v, p, 4);  // records may be 1-byte aligned (pc/iterator.go:71-76)
-  return v;
-}
-
-__device__ __forceinline__ void chunk_origin(const VoxelParams &vp, uint32_t cid, float o[3]) {
-  // cid2xyz + vMin.Add(cp.ElementMul(chunkSize))  (voxelgrid.go:69-75,109-110)
-  int64_t c = cid;
-  const int64_t x = c % vp.nx;
-  c = c / vp.nx;
-  const int64_t y = c % vp.ny;
-  const int64_t z = c / vp.ny;
-  o[0] = vp.vmin[0] + (float)x * vp.cs[0];
-  o[1] = vp.vmin[1] + (float)y * vp.cs[1];
-  o[2] = vp.vmin[2] + (float)z * vp.cs[2];
-}
 
 // the key of point i (and its by-products); returns it
 __device__ __forceinline__ uint32_t voxel_key_of(const uint8_t *__restrict__ data, int64_t i, int32_t stride, int32_t off,
@@ -109,31 +78,12 @@ __device__ __forceinline__ uint32_t voxel_key_of(const uint8_t *__restrict__ dat
                                                  uint32_t *__restrict__ idx, int32_t *__restrict__ err) {
   const uint8_t *rec = data + i * stride + off;
   const float pt[3] = {ld_f32(rec), ld_f32(rec + 4), ld_f32(rec + 8)};
-  float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
-  uint32_t cid = 0;
-  if (vp.chunked) {
-    const float q0 = pt[0] - vp.vmin[0], q1 = pt[1] - vp.vmin[1], q2 = pt[2] - vp.vmin[2];
-    const int64_t cx = (int64_t)(q0 / vp.cs[0]), cy = (int64_t)(q1 / vp.cs[1]), cz = (int64_t)(q2 / vp.cs[2]);
-    const int64_t c = ((cz * vp.ny) + cy) * vp.nx + cx;
-    if (c < 0 || c >= vp.n_chunks) {  // nIndices[cid] would panic
-      atomicOr(err, 1);
-      key_a[i] = 0;
-      if (idx) idx[i] = (uint32_t)i;
-      if (key_cid) { key_cid[i] = 0; a_orig[i] = 0; }
-      return 0u;
-    }
-    cid = (uint32_t)c;
-    chunk_origin(vp, cid, origin);
-    if (key_cid) key_cid[i] = cid;
-  }
-  const float p0 = pt[0] - origin[0], p1 = pt[1] - origin[1], p2 = pt[2] - origin[2];
-  const int64_t x = (int64_t)(p0 / vp.leaf[0]), y = (int64_t)(p1 / vp.leaf[1]), z = (int64_t)(p2 / vp.leaf[2]);
-  const int64_t a = x + vp.xs * (y + vp.ys * z);
-  uint32_t ka = 0;
-  if (a < 0 || a >= vp.n_voxels) atomicOr(err, 1);  // f.voxels[a] would panic
-  else ka = (uint32_t)a;
-  const uint32_t key = vp.combined ? ((cid << vp.key_shift) | ka) : ka;
+  uint32_t cid, ka;
+  bool bad;
+  const uint32_t key = voxel_key_xyz(pt, vp, cid, ka, bad);
+  if (bad) atomicOr(err, 1);  // nIndices[cid] / f.voxels[a] would panic
   key_a[i] = key;
+  if (key_cid) key_cid[i] = cid;
   if (a_orig) a_orig[i] = ka;
   if (idx) idx[i] = (uint32_t)i;  // (nullptr: the sort takes positions for values)
   return key;
@@ -539,6 +489,14 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
     vp.key_shift = key_bits;
     key_bits += bits_for(vp.n_chunks);
     two_level = false;
+  }
+  if (world == 1 && !two_level) {
+    // the points travel with their keys (voxel_bucket.hip) where the cloud allows it: no 12-byte gather per point
+    bool taken = false;
+    const uint64_t key_range = vp.combined ? ((uint64_t)vp.n_chunks << vp.key_shift) : (uint64_t)vp.n_voxels;
+    PCGX_TRY(voxel_bucket_filter(d_data, n, stride, xyz_off, vp, key_bits, key_range, d_out, out_n, &taken, st));
+    if (taken) return PCGX_OK;
+    PCGX_TRY(ar.begin(st));  // (the attempt's temporaries are free again)
   }
   PCGX_TRY(ar.alloc_n((size_t)n, &keys[0]));
   PCGX_TRY(ar.alloc_n((size_t)n, &keys[1]));

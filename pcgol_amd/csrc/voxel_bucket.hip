@@ -1,0 +1,699 @@
+// voxel_bucket.hip -- the VoxelGrid filter's bucket path: the points travel WITH their keys.
+//
+// Reference: pc/filter/voxelgrid/voxelgrid.go:136-187 (filterChunk).  The radix path (voxel.hip) sorts (key, index)
+// pairs and then gathers every point once more through its index: on a randomly ordered cloud that gather costs a
+// 64-byte sector per 12-byte point (0.8 GB of the 1.7 GB a C3 call moves, a third of its time).  Here the
+// coordinates are moved by the sort itself, and only as far as needed:
+//
+//   keys + histograms   one pass over the cloud: the reference's cell of every point (voxel_key.h), the first
+//                       pass's tile histograms, and the population of every BUCKET (bucket = key >> s: 2^s
+//                       consecutive cells, s chosen so that a bucket's points fit a workgroup's LDS)
+//   1-2 scatter passes  stable LSD partition by the bucket number (digits of <= 8 bits), 4096-element tiles
+//                       re-ordered in LDS so that every digit's run leaves in one piece; the elements are
+//                       {x, y, z} + key (+ the point's index when records carry more than xyz)
+//   bucket kernel       one workgroup per bucket: its points into LDS, counting sort by the key's low s bits, the
+//                       points of a cell put into input order by their position (the partition is stable), the
+//                       reference's sequential float32 sum per cell (voxelgrid.go:157), centroid, output record.
+//                       Where in the output a bucket's cells go is the number of occupied cells in all buckets
+//                       before it: the workgroups publish their counts and wait for the earlier ones inside the
+//                       launch (the exchange of strict_sum_kernel, strict.hip), so nothing is staged and compacted.
+//
+// What does not fit (a bucket with more points than the LDS tile holds, a cell with more than kMaxCell points, keys of
+// more than 24 bits, fewer points than a launch is worth) goes the radix path: the same bytes come out either way.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "voxel_key.h"
+
+namespace pcgx {
+
+constexpr int kVbThreads = 256, kVbItems = 8, kVbTile = kVbThreads * kVbItems;  // scatter tiles (36 KB of LDS: four per CU)
+constexpr int kVbWaves = kVbThreads / 64;
+constexpr int kVbMaxLowBits = 10;      // cells per bucket <= 1024
+constexpr int kVbMaxBucketBits = 14;   // two digits of <= 8 bits... and <= 16384 workgroups of the bucket kernel
+constexpr int kVbCap = 2560;           // points per bucket the bucket kernel holds in LDS (48 KB: three workgroups per CU)
+constexpr int kVbMaxCell = 255;        // points per cell it puts in order by itself
+constexpr int kVbFinalThreads = 256;
+constexpr int kVbSpins = 1 << 16;
+constexpr int kLanesWait = 63;  // group words one round of the arrival poll looks at (lanes 1 .. 63)
+constexpr int kVbSampleEvery = 32;     // every 32nd point is counted per bucket before anything is moved
+
+struct VbPlan {
+  int32_t low_bits;      // s
+  int32_t nbuckets;
+  int32_t d_bits[2];     // digits of the bucket number, low digit first; d_bits[1] == 0: one pass
+  int32_t ntiles;
+};
+
+// ---- keys, first tile histograms, a sample of the bucket populations ---------------------------------------------
+// (every kVbSampleEvery-th point is counted per bucket, with global atomics: a bucket that would hold more
+// than 1.5 LDS tiles by that estimate stops the attempt before anything is moved, vb_sample_check_kernel; the exact
+// check is the bucket kernel's)
+__global__ __launch_bounds__(256) void vb_key_hist_kernel(const uint8_t *__restrict__ data, int64_t n, int32_t stride,
+                                                          int32_t off, VoxelParams vp, VbPlan plan,
+                                                          uint32_t *__restrict__ key_out, uint32_t *__restrict__ block_hist,
+                                                          uint32_t *__restrict__ bucket_sample, int32_t *__restrict__ err) {
+  __shared__ uint32_t dh[256];
+  dh[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t m1 = (1u << plan.d_bits[0]) - 1u;
+  const bool sampled = threadIdx.x % kVbSampleEvery == 0 && bucket_sample != nullptr;
+  bool any_bad = false;
+  const int64_t base = (int64_t)blockIdx.x * kVbTile;
+#pragma unroll
+  for (int r = 0; r < kVbItems; r++) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < n) {
+      const uint8_t *rec = data + i * stride + off;
+      const float pt[3] = {ld_f32(rec), ld_f32(rec + 4), ld_f32(rec + 8)};
+      uint32_t cid, ka;
+      bool bad;
+      const uint32_t key = voxel_key_xyz(pt, vp, cid, ka, bad);
+      any_bad |= bad;
+      key_out[i] = key;
+      const uint32_t bkt = key >> plan.low_bits;
+      atomicAdd(&dh[bkt & m1], 1u);
+      if (sampled) atomicAdd(&bucket_sample[bkt], 1u);  // (two lanes of a wave: spread over all workgroups, no stragglers)
+    }
+  }
+  if (any_bad) atomicOr(err, 1);
+  __syncthreads();
+  block_hist[(int64_t)threadIdx.x * plan.ntiles + blockIdx.x] = dh[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void vb_sample_check_kernel(const uint32_t *__restrict__ bucket_sample, int nbuckets,
+                                                              int32_t *__restrict__ flags) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < nbuckets && (uint64_t)bucket_sample[b] * kVbSampleEvery > (uint64_t)kVbCap * 3 / 2) atomicOr(flags, 1);
+}
+
+// where the buckets begin in the sorted arrays: start[b] = first position whose bucket is >= b; start[nbuckets] = n
+// (four consecutive keys per thread)
+__global__ __launch_bounds__(256) void vb_bounds_kernel(const uint32_t *__restrict__ keys, int64_t n, int low_bits, int nbuckets,
+                                                        uint32_t *__restrict__ start, const int32_t *__restrict__ flags) {
+  if (*flags) return;  // uniform
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  uint32_t k[4];
+  if (i0 + 3 < n) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(keys + i0);
+    k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+  } else {
+    for (int q = 0; q < 4; q++) k[q] = i0 + q < n ? keys[i0 + q] : 0u;
+  }
+  int64_t bp = i0 > 0 ? (int64_t)(keys[i0 - 1] >> low_bits) : -1;
+  for (int q = 0; q < 4 && i0 + q < n; q++) {
+    const int64_t bi = k[q] >> low_bits;
+    for (int64_t b = bp + 1; b <= bi; b++) start[b] = (uint32_t)(i0 + q);
+    bp = bi;
+    if (i0 + q == n - 1)
+      for (int64_t b = bi + 1; b <= nbuckets; b++) start[b] = (uint32_t)n;
+  }
+}
+
+// tile histograms of the second pass's digit, from the keys as the first pass left them
+__global__ __launch_bounds__(256) void vb_hist2_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift, uint32_t mask,
+                                                       uint32_t *__restrict__ block_hist, int ntiles) {
+  __shared__ uint32_t dh[256];
+  dh[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kVbTile;
+#pragma unroll
+  for (int r = 0; r < kVbItems; r++) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&dh[(keys[i] >> shift) & mask], 1u);
+  }
+  __syncthreads();
+  block_hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = dh[threadIdx.x];
+}
+
+// every digit's row of tile counts -> its exclusive prefix over the tiles, and the row's total (as rs_scan_rows_kernel,
+// sort.hip, with 1024 threads per row: 4882 tiles at C3 are five rounds instead of twenty)
+__global__ __launch_bounds__(1024) void vb_scan_rows_kernel(uint32_t *__restrict__ block_hist, int ntiles,
+                                                            uint32_t *__restrict__ totals) {
+  __shared__ uint32_t wave_sum[16];
+  __shared__ uint32_t carry_s;
+  uint32_t *row = block_hist + (int64_t)blockIdx.x * ntiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int start = 0; start < ntiles; start += 1024) {
+    const int i = start + threadIdx.x;
+    const uint32_t v = i < ntiles ? row[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += wave_sum[w];
+    const uint32_t carry = carry_s;
+    if (i < ntiles) row[i] = carry + wbase + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + wbase + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+// ---- one stable partition pass over {x, y, z} + key (+ index) -----------------------------------------------------
+// kFirst: the coordinates come out of the caller's records (any stride / offset, voxel_key.h), the index is the
+// point's position; else out of the previous pass's arrays.  Ranking as rs_scatter_kernel (sort.hip): wave64 ballots
+// on the digit's bits, per-wave counts, the tile re-ordered in LDS so that a digit's run is written in one piece.
+template <bool kFirst, bool kIdx>
+__global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
+    const uint8_t *__restrict__ data, int32_t stride, int32_t off, const float *__restrict__ xyz_in,
+    const uint32_t *__restrict__ key_in, const uint32_t *__restrict__ idx_in, int64_t n, int shift, int dbits,
+    const uint32_t *__restrict__ block_hist, int ntiles, const uint32_t *__restrict__ totals, float *__restrict__ xyz_out,
+    uint32_t *__restrict__ key_out, uint32_t *__restrict__ idx_out, const int32_t *__restrict__ flags) {
+  __shared__ uint32_t cnt[kVbWaves][256];
+  __shared__ uint32_t tile_pref[256];
+  __shared__ uint32_t gbase[256];
+  __shared__ uint32_t wave_sum[kVbWaves];
+  __shared__ uint32_t gwave_sum[kVbWaves];
+  __shared__ uint32_t skey[kVbTile];
+  __shared__ float sx[kVbTile], sy[kVbTile], sz[kVbTile];
+  __shared__ uint32_t sidx[kIdx ? kVbTile : 1];
+  if (*flags) return;  // uniform: the call goes the radix path
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = (int)(gridDim.x >> 3);
+  const int tile = (gridDim.x & 7u) == 0u ? (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;  // XCD-contiguous (sort.hip)
+  if (tile >= ntiles) return;
+  const int64_t tile_base = (int64_t)tile * kVbTile;
+  const int64_t wave_base = tile_base + (int64_t)wave * (kVbTile / kVbWaves);
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const uint32_t mask = (1u << dbits) - 1u;
+#pragma unroll
+  for (int w = 0; w < kVbWaves; w++) cnt[w][threadIdx.x] = 0;
+  __syncthreads();
+
+  uint32_t key[kVbItems], rank[kVbItems];
+  volatile uint32_t *my_cnt = cnt[wave];
+#pragma unroll
+  for (int r = 0; r < kVbItems; r++) {
+    const int64_t i = wave_base + r * 64 + lane;
+    key[r] = i < n ? key_in[i] : 0u;
+  }
+#pragma unroll
+  for (int r = 0; r < kVbItems; r++) {
+    const int64_t i = wave_base + r * 64 + lane;
+    const bool valid = i < n;
+    const uint32_t d = (key[r] >> shift) & mask;
+    uint64_t m = __ballot(valid);
+    for (int b = 0; b < dbits; b++) {  // uniform
+      const bool bit = (d >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    uint32_t prev = 0;
+    if (valid) prev = my_cnt[d];
+    rank[r] = prev + (uint32_t)__popcll(m & lt_mask);
+    __builtin_amdgcn_wave_barrier();
+    if (valid && (m >> lane) == 1ull) my_cnt[d] = prev + (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {
+    const int t = threadIdx.x;
+    uint32_t run = 0;
+#pragma unroll
+    for (int w = 0; w < kVbWaves; w++) {
+      const uint32_t c = cnt[w][t];
+      cnt[w][t] = run;
+      run += c;
+    }
+    const uint32_t tot = totals[t];
+    uint32_t inc = run, ginc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t x = __shfl_up(inc, o), g = __shfl_up(ginc, o);
+      if (lane >= o) {
+        inc += x;
+        ginc += g;
+      }
+    }
+    if (lane == 63) {
+      wave_sum[wave] = inc;
+      gwave_sum[wave] = ginc;
+    }
+    __syncthreads();
+    uint32_t wbase = 0, gwbase = 0;
+    for (int w = 0; w < wave; w++) {
+      wbase += wave_sum[w];
+      gwbase += gwave_sum[w];
+    }
+    const uint32_t excl = wbase + inc - run;
+    tile_pref[t] = excl;
+    gbase[t] = (gwbase + ginc - tot) + block_hist[(int64_t)t * ntiles + tile] - excl;  // dst = gbase[d] + pos
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kVbItems; r++) {
+    const int64_t i = wave_base + r * 64 + lane;
+    if (i < n) {
+      const uint32_t d = (key[r] >> shift) & mask;
+      const uint32_t pos = tile_pref[d] + cnt[wave][d] + rank[r];
+      float x, y, z;
+      if (kFirst) {
+        const uint8_t *rec = data + i * stride + off;
+        x = ld_f32(rec);
+        y = ld_f32(rec + 4);
+        z = ld_f32(rec + 8);
+      } else {
+        x = xyz_in[i];
+        y = xyz_in[n + i];
+        z = xyz_in[2 * n + i];
+      }
+      skey[pos] = key[r];
+      sx[pos] = x;
+      sy[pos] = y;
+      sz[pos] = z;
+      if (kIdx) sidx[pos] = kFirst ? (uint32_t)i : idx_in[i];
+    }
+  }
+  __syncthreads();
+  const int64_t rem = n - tile_base;
+  const int count = rem < kVbTile ? (int)rem : kVbTile;
+  for (int p = threadIdx.x; p < count; p += kVbThreads) {
+    const uint32_t k = skey[p];
+    const uint32_t d = (k >> shift) & mask;
+    const int64_t dst = (int64_t)gbase[d] + p;
+    key_out[dst] = k;
+    xyz_out[dst] = sx[p];  // (three arrays x[n] y[n] z[n]: every store instruction writes consecutive words)
+    xyz_out[n + dst] = sy[p];
+    xyz_out[2 * n + dst] = sz[p];
+    if (kIdx) idx_out[dst] = sidx[p];
+  }
+}
+
+// ---- the bucket kernel --------------------------------------------------------------------------------------------
+struct VbExchange {
+  uint32_t *count;      // [nbuckets] occupied cells of the bucket (written write-through)
+  uint32_t *group_tot;  // [ngroups] occupied cells of a group of 32 buckets, written by whoever completes the group
+  unsigned int *arrived;  // as StrictWork::tile_arrived: word g at [32 g], then the groups' bits at [32 (ngroups + G)]
+};
+
+__device__ __forceinline__ uint32_t ld_sc1_u32(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool kIdx>
+__global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
+    const float *__restrict__ xyz, int64_t n, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ idx,
+    const uint32_t *__restrict__ bucket_start, VoxelParams vp, VbPlan plan, const uint8_t *__restrict__ data, int32_t stride,
+    int32_t off, uint8_t *__restrict__ out, VbExchange ex, int64_t *__restrict__ total, int32_t *__restrict__ flags) {
+  constexpr int kBins = 1 << kVbMaxLowBits, kWaves = kVbFinalThreads / 64;
+  constexpr int kPer = kVbCap / kVbFinalThreads;       // points per thread
+  constexpr int kBinsPer = kBins / kVbFinalThreads;    // cells per thread
+  __shared__ float sx[kVbCap], sy[kVbCap], sz[kVbCap];
+  __shared__ uint16_t slow[kVbCap];     // the key's low bits
+  __shared__ uint16_t order[kVbCap];    // positions cell after cell, as they arrived
+  __shared__ uint32_t cnt[kBins];       // points of the cell; then: its first place in order[]
+  __shared__ uint16_t ccount[kBins];    // points of the cell (kept)
+  __shared__ uint16_t vrank[kBins];     // occupied cells before it in the bucket
+  __shared__ uint32_t wsum[kWaves], wocc[kWaves];
+  __shared__ uint32_t s_prefix;
+  if (*flags & 1) return;  // uniform: a bucket does not fit (an earlier kernel's finding), the call goes the radix path
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nbins = 1 << plan.low_bits;
+  const uint32_t start = bucket_start[b], end = bucket_start[b + 1];
+  const bool fits = end - start <= (uint32_t)kVbCap;
+  const int P = fits ? (int)(end - start) : 0;
+  for (int l = threadIdx.x; l < nbins; l += kVbFinalThreads) cnt[l] = 0;
+  __syncthreads();
+  // ---- the bucket's points, in input order (the partition is stable); arrival order inside a cell is arbitrary
+  uint16_t arr[kPer];
+  const uint32_t lmask = (uint32_t)nbins - 1u;
+#pragma unroll
+  for (int r = 0; r < kPer; r++) {
+    const int i = r * kVbFinalThreads + threadIdx.x;
+    arr[r] = 0;
+    if (i < P) {
+      const int64_t g = (int64_t)start + i;
+      const uint32_t l = keys[g] & lmask;
+      sx[i] = xyz[g];
+      sy[i] = xyz[n + g];
+      sz[i] = xyz[2 * n + g];
+      slow[i] = (uint16_t)l;
+      arr[r] = (uint16_t)atomicAdd(&cnt[l], 1u);
+    }
+  }
+  __syncthreads();
+  // ---- cells -> first place (exclusive scan of the counts) and rank among the occupied ones; thread t: cells
+  // t * kBinsPer .. (consecutive, for the scan)
+  uint32_t occupied_total = 0;
+  bool crowded = false;
+  {
+    uint32_t c[kBinsPer], sum = 0, occ = 0;
+#pragma unroll
+    for (int k = 0; k < kBinsPer; k++) {
+      const int l = threadIdx.x * kBinsPer + k;
+      c[k] = l < nbins ? cnt[l] : 0u;
+      sum += c[k];
+      occ += c[k] ? 1u : 0u;
+      crowded |= c[k] > (uint32_t)kVbMaxCell;
+    }
+    uint32_t inc = sum, oinc = occ;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t x = __shfl_up(inc, o), y = __shfl_up(oinc, o);
+      if (lane >= o) {
+        inc += x;
+        oinc += y;
+      }
+    }
+    if (lane == 63) {
+      wsum[wave] = inc;
+      wocc[wave] = oinc;
+    }
+    __syncthreads();
+    uint32_t wb = 0, ob = 0;
+    for (int w = 0; w < kWaves; w++) {
+      if (w < wave) {
+        wb += wsum[w];
+        ob += wocc[w];
+      }
+      occupied_total += wocc[w];
+    }
+    uint32_t run = wb + inc - sum, orun = ob + oinc - occ;
+#pragma unroll
+    for (int k = 0; k < kBinsPer; k++) {
+      const int l = threadIdx.x * kBinsPer + k;
+      if (l < nbins) {
+        cnt[l] = run;
+        ccount[l] = (uint16_t)c[k];
+        vrank[l] = (uint16_t)orun;
+      }
+      run += c[k];
+      orun += c[k] ? 1u : 0u;
+    }
+  }
+  const bool skip = __syncthreads_or((crowded || !fits) ? 1 : 0) != 0;  // (also the barrier behind cnt[] / ccount[])
+  if (skip && threadIdx.x == 0) atomicOr(flags, fits ? 2 : 1);  // more points than the LDS tile / than a cell is ordered for: radix path
+  // ---- my count out at once (the later buckets wait for it); the wait for the earlier ones comes last.  Whoever
+  // completes a group of 32 buckets adds up the group (a lane per bucket: one round of loads, not 32 in a row --
+  // every bucket behind the group waits for this) and says so one level up.
+  if (wave == 0) {
+    const int64_t g_mine = b >> 5, n_groups = ((int64_t)plan.nbuckets + 31) >> 5;
+    const uint32_t bit = 1u << (b & 31);
+    const uint32_t full = (g_mine == n_groups - 1 && (plan.nbuckets & 31)) ? (1u << (plan.nbuckets & 31)) - 1u : 0xffffffffu;
+    uint32_t old = 0;
+    if (lane == 0) {
+      __hip_atomic_store(&ex.count[b], occupied_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      old = __hip_atomic_fetch_or(&ex.arrived[32 * g_mine], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+    if ((old | bit) == full) {  // uniform
+      const int64_t bk = (g_mine << 5) + lane;
+      uint32_t t = (lane < 32 && bk < plan.nbuckets) ? ld_sc1_u32(&ex.count[bk]) : 0u;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+      if (lane == 0) {
+        __hip_atomic_store(&ex.group_tot[g_mine], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_or(&ex.arrived[32 * (n_groups + (g_mine >> 5))], 1u << (g_mine & 31), __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  const bool last = b == plan.nbuckets - 1;
+  if ((P == 0 || skip) && !last) return;  // uniform: nothing to write (the last bucket also reports the total)
+  // ---- positions cell after cell (arrival order inside a cell)
+#pragma unroll
+  for (int r = 0; r < kPer; r++) {
+    const int i = r * kVbFinalThreads + threadIdx.x;
+    if (i < P) order[cnt[slow[i]] + arr[r]] = (uint16_t)i;
+  }
+  __syncthreads();
+  // ---- cell by cell: its points into input order (ascending position: a sorting network over eight registers; a
+  // cell with more points -- one in a thousand at three points per cell -- picks the next position by scanning), the
+  // reference's sequential float32 sum, centroid (kept in registers until the place is known); thread t: cells t,
+  // t + 256, ... (neighbouring lanes neighbouring cells: their stores are neighbours too)
+  float o0[kBinsPer], o1[kBinsPer], o2[kBinsPer];
+  int head[kBinsPer], cc[kBinsPer];
+#pragma unroll
+  for (int k = 0; k < kBinsPer; k++) {
+    const int l = k * kVbFinalThreads + threadIdx.x;
+    cc[k] = (l < nbins && !skip) ? ccount[l] : 0;
+    head[k] = 0;
+    o0[k] = o1[k] = o2[k] = 0.0f;
+    if (cc[k] == 0) continue;
+    const int first = (int)cnt[l], c = cc[k];
+    const uint32_t key = ((uint32_t)b << plan.low_bits) | (uint32_t)l;
+    float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
+    if (vp.chunked) chunk_origin(vp, vp.combined ? key >> vp.key_shift : 0u, origin);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
+    if (c <= 8) {
+      uint32_t e[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) e[j] = j < c ? (uint32_t)order[first + j] : 0xffffu + (uint32_t)j;  // (padding sorts behind every position)
+      auto cas = [&](int x, int y) {
+        const uint32_t lo = e[x] < e[y] ? e[x] : e[y], hi = e[x] < e[y] ? e[y] : e[x];
+        e[x] = lo;
+        e[y] = hi;
+      };
+      // 19 compare-exchanges (Batcher's odd-even merge sort of eight)
+      cas(0, 1); cas(2, 3); cas(4, 5); cas(6, 7);
+      cas(0, 2); cas(1, 3); cas(4, 6); cas(5, 7);
+      cas(1, 2); cas(5, 6);
+      cas(0, 4); cas(1, 5); cas(2, 6); cas(3, 7);
+      cas(2, 4); cas(3, 5);
+      cas(1, 2); cas(3, 4); cas(5, 6);
+      float px[8], py[8], pz[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int m = j < c ? (int)e[j] : (int)e[0];
+        px[j] = sx[m]; py[j] = sy[m]; pz[j] = sz[m];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (j < c) {  // p := it.Vec3().Sub(vMin); v.sum = v.sum.Add(p)   (voxelgrid.go:149,157)
+          s0 = s0 + (px[j] - origin[0]);
+          s1 = s1 + (py[j] - origin[1]);
+          s2 = s2 + (pz[j] - origin[2]);
+        }
+      }
+      head[k] = (int)e[0];
+      o0[k] = px[0]; o1[k] = py[0]; o2[k] = pz[0];
+    } else {
+      int last_pos = -1;
+      for (int t = 0; t < c; t++) {  // the next position above `last_pos`
+        int m = 0x7fffffff;
+        for (int j = 0; j < c; j++) {
+          const int v = order[first + j];
+          m = (v > last_pos && v < m) ? v : m;
+        }
+        if (t == 0) head[k] = m;
+        s0 = s0 + (sx[m] - origin[0]);
+        s1 = s1 + (sy[m] - origin[1]);
+        s2 = s2 + (sz[m] - origin[2]);
+        last_pos = m;
+      }
+      o0[k] = sx[head[k]]; o1[k] = sy[head[k]]; o2[k] = sz[head[k]];
+    }
+    if (c > 1) {  // jt.SetVec3(v.sum.Mul(1.0 / float32(n)).Add(vMin))  (voxelgrid.go:178-180)
+      const float inv = 1.0f / (float)c;
+      o0[k] = s0 * inv + origin[0];
+      o1[k] = s1 * inv + origin[1];
+      o2[k] = s2 * inv + origin[2];
+    }
+  }
+  // ---- where the bucket's cells go: the occupied cells of all buckets before it (they were dispatched before this
+  // one and have published their counts long since: the wait is a formality by now)
+  if (wave == 0) {
+    const int64_t g_mine = b >> 5, n_groups = ((int64_t)plan.nbuckets + 31) >> 5;
+    bool gave_up = false;
+    const int64_t G_mine = g_mine >> 5;
+    for (int64_t G0 = 0; G0 <= G_mine && !gave_up; G0 += kLanesWait) {  // uniform
+      const int64_t G = G0 + lane - 1;
+      uint32_t want = 0u;
+      const unsigned int *word = ex.arrived;
+      if (lane == 0) {
+        want = G0 == 0 ? (1u << (b & 31)) - 1u : 0u;
+        word = ex.arrived + 32 * g_mine;
+      } else if (G <= G_mine) {
+        want = G < G_mine ? 0xffffffffu : (1u << (g_mine & 31)) - 1u;
+        word = ex.arrived + 32 * (n_groups + G);
+      }
+      for (int spins = 0;; spins++) {
+        uint32_t have = 0u;
+        if (want) have = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__ballot((have & want) != want) == 0ull) break;
+        if (spins >= kVbSpins) {
+          gave_up = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    // the groups before mine, then the buckets of my group before me
+    uint32_t v = 0;
+    for (int64_t g = lane; g < g_mine; g += 64) v += ld_sc1_u32(&ex.group_tot[g]);
+    if (lane < (b & 31)) v += ld_sc1_u32(&ex.count[(g_mine << 5) + lane]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) {
+      s_prefix = v;
+      if (gave_up) atomicOr(flags, 4);
+      if (last && !gave_up) *total = (int64_t)v + (int64_t)occupied_total;
+    }
+  }
+  __syncthreads();
+  const uint32_t prefix = s_prefix;
+#pragma unroll
+  for (int k = 0; k < kBinsPer; k++) {
+    if (cc[k] == 0) continue;
+    const int l = k * kVbFinalThreads + threadIdx.x;
+    const int64_t slot = (int64_t)prefix + vrank[l];
+    uint8_t *dst = out + slot * stride;
+    if (!kIdx) {  // records are xyz and nothing else, 4-byte aligned
+      float *d = reinterpret_cast<float *>(dst);
+      d[0] = o0[k]; d[1] = o1[k]; d[2] = o2[k];
+    } else {  // v.index: the first point in input order; its whole record is copied (voxelgrid.go:152-155,173-177)
+      const uint8_t *src = data + (int64_t)idx[(int64_t)start + head[k]] * stride;
+      if ((stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out)) & 3) == 0) {
+        for (int q = 0; q < stride; q += 4) *reinterpret_cast<uint32_t *>(dst + q) = *reinterpret_cast<const uint32_t *>(src + q);
+      } else {
+        for (int q = 0; q < stride; q++) dst[q] = src[q];
+      }
+      __builtin_memcpy(dst + off, &o0[k], 4);
+      __builtin_memcpy(dst + off + 4, &o1[k], 4);
+      __builtin_memcpy(dst + off + 8, &o2[k], 4);
+    }
+  }
+}
+
+static int vb_knob(const char *name, int def) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : def;
+}
+
+// The bucket path of one filter call (one GPU, one sort key of key_bits bits over [0, key_range)).  *taken false: the
+// call is not for this path (too small, keys too wide, PCGX_VOXEL_BUCKET=0) or turned out not to fit (a crowded
+// bucket or cell; *out_n is then untouched and nothing the radix path does not overwrite has been written).
+pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, int32_t xyz_off, const VoxelParams &vp,
+                                int key_bits, uint64_t key_range, void *d_out, int64_t *out_n, bool *taken, hipStream_t st) {
+  *taken = false;
+  static const int enabled = vb_knob("PCGX_VOXEL_BUCKET", 1), min_n = vb_knob("PCGX_VOXEL_BUCKET_MIN_N", 400000);
+  if (!enabled || n < min_n || key_bits < 1 || key_bits > kVbMaxLowBits + kVbMaxBucketBits || key_range < 2) return PCGX_OK;
+  // s: as many cells per bucket as keep an evenly filled bucket at 0.6 of the LDS tile (C3: the fullest of 6505 holds 1.35x the mean)
+  VbPlan plan;
+  memset(&plan, 0, sizeof plan);
+  int s = key_bits < kVbMaxLowBits ? key_bits : kVbMaxLowBits;
+  while (s > 0 && (double)n * (double)((uint64_t)1 << s) / (double)key_range > 0.6 * kVbCap) s--;
+  const uint64_t nb = ((key_range - 1) >> s) + 1;
+  int bb = 0;
+  while (((uint64_t)1 << bb) < nb) bb++;
+  if (s == 0 || bb < 1 || bb > kVbMaxBucketBits) return PCGX_OK;
+  plan.low_bits = s;
+  plan.nbuckets = (int32_t)nb;
+  plan.d_bits[0] = bb <= 8 ? bb : bb - bb / 2;
+  plan.d_bits[1] = bb - plan.d_bits[0];
+  plan.ntiles = (int32_t)((n + kVbTile - 1) / kVbTile);
+  const bool with_idx = stride != 12 || xyz_off != 0 || ((reinterpret_cast<uintptr_t>(d_data) | reinterpret_cast<uintptr_t>(d_out)) & 3) != 0;
+
+  Arena &ar = ctx().arena;
+  uint32_t *key0 = nullptr, *keyb[2] = {nullptr, nullptr}, *idxb[2] = {nullptr, nullptr};
+  float *xyzb[2] = {nullptr, nullptr};
+  uint32_t *block_hist = nullptr, *totals = nullptr, *bucket_sample = nullptr, *bucket_start = nullptr;
+  int32_t *d_flags = nullptr;  // [0] flags (1 crowded bucket, 2 crowded cell, 4 the exchange gave up), [1] key out of range
+  int64_t *d_total = nullptr;
+  VbExchange ex;
+  const int64_t n_groups = ((int64_t)plan.nbuckets + 31) / 32;
+  const size_t arrived_words = (size_t)(n_groups + (n_groups + 31) / 32) * 32;
+  PCGX_TRY(ar.alloc_n((size_t)n, &key0));
+  const int passes = plan.d_bits[1] ? 2 : 1;
+  for (int k = 0; k < passes; k++) {
+    PCGX_TRY(ar.alloc_n((size_t)n, &keyb[k]));
+    PCGX_TRY(ar.alloc_n((size_t)n * 3, &xyzb[k]));
+    if (with_idx) PCGX_TRY(ar.alloc_n((size_t)n, &idxb[k]));
+  }
+  PCGX_TRY(ar.alloc_n((size_t)plan.ntiles * 256, &block_hist));
+  PCGX_TRY(ar.alloc_n(256, &totals));
+  PCGX_TRY(ar.alloc_n((size_t)plan.nbuckets + 1, &bucket_start));
+  // one block, zeroed at once: the exchange's words, flags, the sample of the bucket populations, the buckets' counts
+  const size_t zero_words = arrived_words + 8 + (size_t)plan.nbuckets * 2 + (size_t)n_groups;
+  uint32_t *zero_block = nullptr;
+  PCGX_TRY(ar.alloc_n(zero_words + 64, &zero_block));
+  zero_block = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(zero_block) + 127) & ~(uintptr_t)127);
+  ex.arrived = zero_block;
+  d_flags = reinterpret_cast<int32_t *>(zero_block + arrived_words);  // (128-byte aligned: arrived_words is a multiple of 32)
+  d_total = reinterpret_cast<int64_t *>(d_flags + 2);
+  bucket_sample = zero_block + arrived_words + 8;
+  ex.count = bucket_sample + plan.nbuckets;
+  ex.group_tot = ex.count + plan.nbuckets;
+  PCGX_HIP_TRY(hipMemsetAsync(zero_block, 0, zero_words * sizeof(uint32_t), st));
+
+  const uint8_t *data = (const uint8_t *)d_data;
+  static const int sample = vb_knob("PCGX_VOXEL_BUCKET_SAMPLE", 1);
+  hipLaunchKernelGGL(vb_key_hist_kernel, dim3(plan.ntiles), dim3(256), 0, st, data, n, stride, xyz_off, vp, plan, key0, block_hist,
+                     sample ? bucket_sample : (uint32_t *)nullptr, d_flags + 1);
+  hipLaunchKernelGGL(vb_sample_check_kernel, dim3((plan.nbuckets + 255) / 256), dim3(256), 0, st, (const uint32_t *)bucket_sample,
+                     plan.nbuckets, d_flags);
+  hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, plan.ntiles, totals);
+  const int grid = plan.ntiles >= 64 ? 8 * ((plan.ntiles + 7) / 8) : plan.ntiles;
+  if (with_idx)
+    hipLaunchKernelGGL((vb_scatter_kernel<true, true>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
+                       (const float *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, plan.low_bits, plan.d_bits[0],
+                       (const uint32_t *)block_hist, plan.ntiles, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0],
+                       (const int32_t *)d_flags);
+  else
+    hipLaunchKernelGGL((vb_scatter_kernel<true, false>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
+                       (const float *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, plan.low_bits, plan.d_bits[0],
+                       (const uint32_t *)block_hist, plan.ntiles, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0],
+                       (const int32_t *)d_flags);
+  int cur = 0;
+  if (passes == 2) {
+    const int shift = plan.low_bits + plan.d_bits[0];
+    hipLaunchKernelGGL(vb_hist2_kernel, dim3(plan.ntiles), dim3(256), 0, st, (const uint32_t *)keyb[0], n, shift,
+                       (1u << plan.d_bits[1]) - 1u, block_hist, plan.ntiles);
+    hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, plan.ntiles, totals);
+    if (with_idx)
+      hipLaunchKernelGGL((vb_scatter_kernel<false, true>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
+                         (const float *)xyzb[0], (const uint32_t *)keyb[0], (const uint32_t *)idxb[0], n, shift, plan.d_bits[1],
+                         (const uint32_t *)block_hist, plan.ntiles, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1],
+                         (const int32_t *)d_flags);
+    else
+      hipLaunchKernelGGL((vb_scatter_kernel<false, false>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
+                         (const float *)xyzb[0], (const uint32_t *)keyb[0], (const uint32_t *)idxb[0], n, shift, plan.d_bits[1],
+                         (const uint32_t *)block_hist, plan.ntiles, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1],
+                         (const int32_t *)d_flags);
+    cur = 1;
+  }
+  hipLaunchKernelGGL(vb_bounds_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (const uint32_t *)keyb[cur], n,
+                     plan.low_bits, plan.nbuckets, bucket_start, (const int32_t *)d_flags);
+  if (with_idx)
+    hipLaunchKernelGGL(vb_bucket_kernel<true>, dim3(plan.nbuckets), dim3(kVbFinalThreads), 0, st, (const float *)xyzb[cur], n,
+                       (const uint32_t *)keyb[cur], (const uint32_t *)idxb[cur], (const uint32_t *)bucket_start, vp, plan, data,
+                       stride, xyz_off, (uint8_t *)d_out, ex, d_total, d_flags);
+  else
+    hipLaunchKernelGGL(vb_bucket_kernel<false>, dim3(plan.nbuckets), dim3(kVbFinalThreads), 0, st, (const float *)xyzb[cur], n,
+                       (const uint32_t *)keyb[cur], (const uint32_t *)idxb[cur], (const uint32_t *)bucket_start, vp, plan, data,
+                       stride, xyz_off, (uint8_t *)d_out, ex, d_total, d_flags);
+  PCGX_HIP_TRY(hipGetLastError());
+  struct {
+    int32_t flags, err;
+    int64_t total;
+  } h;
+  static_assert(sizeof(h) == 16, "flags, err, total as they sit in the zeroed block");
+  PCGX_HIP_TRY(hipMemcpyAsync(&h, d_flags, sizeof h, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  if (h.err)
+    return fail(PCGX_E_OUT_OF_RANGE, "voxel filter: a point falls outside the dense grid (the reference panics: index out of range)");
+  if (h.flags) {  // crowded bucket / cell (or the exchange gave up): the radix path does the call
+    if (getenv("PCGX_VOXEL_BUCKET_TRACE"))
+      fprintf(stderr, "pcgx voxel bucket path: flags %d (1 bucket over %d points, 2 cell over %d points, 4 exchange gave up); low bits %d, %d buckets, digits %d + %d\n",
+              h.flags, kVbCap, kVbMaxCell, plan.low_bits, plan.nbuckets, plan.d_bits[0], plan.d_bits[1]);
+    return PCGX_OK;
+  }
+  *out_n = h.total;
+  *taken = true;
+  return PCGX_OK;
+}
+
+}  // namespace pcgx
