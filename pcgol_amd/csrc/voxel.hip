@@ -494,7 +494,8 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
     // the points travel with their keys (voxel_bucket.hip) where the cloud allows it: no 12-byte gather per point
     bool taken = false;
     const uint64_t key_range = vp.combined ? ((uint64_t)vp.n_chunks << vp.key_shift) : (uint64_t)vp.n_voxels;
-    PCGX_TRY(voxel_bucket_filter(d_data, n, stride, xyz_off, vp, key_bits, key_range, d_out, out_n, &taken, st));
+    const uint64_t key_population = vp.combined ? (uint64_t)vp.n_chunks * (uint64_t)vp.n_voxels : (uint64_t)vp.n_voxels;
+    PCGX_TRY(voxel_bucket_filter(d_data, n, stride, xyz_off, vp, key_bits, key_range, key_population, d_out, out_n, &taken, st));
     if (taken) return PCGX_OK;
     PCGX_TRY(ar.begin(st));  // (the attempt's temporaries are free again)
   }

@@ -31,12 +31,12 @@ namespace pcgx {
 constexpr int kVbThreads = 256, kVbItems = 8, kVbTile = kVbThreads * kVbItems;  // scatter tiles (36 KB of LDS: four per CU)
 constexpr int kVbWaves = kVbThreads / 64;
 constexpr int kVbMaxLowBits = 10;      // cells per bucket <= 1024
-constexpr int kVbMaxBucketBits = 14;   // two digits of <= 8 bits... and <= 16384 workgroups of the bucket kernel
-constexpr int kVbCap = 2560;           // points per bucket the bucket kernel holds in LDS (48 KB: three workgroups per CU)
+constexpr int kVbMaxBucketBits = 16;   // two digits of <= 8 bits
+constexpr int kVbCap = 1280;           // points per bucket the bucket kernel holds in LDS (26 KB: six workgroups per CU -- a
+                                       // workgroup is a chain of short dependent phases, what hides them is the other workgroups)
 constexpr int kVbMaxCell = 255;        // points per cell it puts in order by itself
 constexpr int kVbFinalThreads = 256;
 constexpr int kVbSpins = 1 << 16;
-constexpr int kLanesWait = 63;  // group words one round of the arrival poll looks at (lanes 1 .. 63)
 constexpr int kVbSampleEvery = 32;     // every 32nd point is counted per bucket before anything is moved
 
 struct VbPlan {
@@ -44,6 +44,7 @@ struct VbPlan {
   int32_t nbuckets;
   int32_t d_bits[2];     // digits of the bucket number, low digit first; d_bits[1] == 0: one pass
   int32_t ntiles;
+  int32_t dbg;           // measurement aid (PCGX_VOXEL_BUCKET_DBG): 1 no wait for the earlier buckets, 2 no cell phase (wrong output)
 };
 
 // ---- keys, first tile histograms, a sample of the bucket populations ---------------------------------------------
@@ -291,10 +292,24 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
 }
 
 // ---- the bucket kernel --------------------------------------------------------------------------------------------
+// Where a bucket's cells go in the output = the occupied cells of all buckets before it.  Tagged words (value | 2^31),
+// each written once with a write-through store and read with loads that bypass the vector L1 -- no atomics:
+//   count[b]      by every bucket, as soon as it has counted its cells (nothing to wait for);
+//   group_tot[g]  the 32 buckets of group g, by the group's LAST bucket once it has read the other 31 counts -- which
+//                 it does anyway, for its own place;
+//   super_tot[G]  the 32 groups (1024 buckets) of G, by G's last bucket, the same way from the group totals.
+// A bucket that needs its place reads super_tot of the 1024-groups before its own, group_tot of the groups before
+// its own inside its 1024-group and count of the buckets before it in its group: three loads per lane, a handful of
+// cache lines, until every word carries its tag.  It waits for lower block indices only, which were dispatched
+// before it (strict.hip, strict_sum_kernel: why that ends), and the totals it waits for depend on counts alone.
+// (Measured on the way: arrival bits + a returning atomic per bucket to find out who completes a group -- two round
+// trips on every workgroup's path, 50 us per C3 call; counts added into per-group 64-bit accumulators with
+// fire-and-forget atomics and read by every later workgroup -- the accumulators' lines ping-pong between the adding
+// and the polling XCDs, 0.25-0.6 ms of waiting per call.)
 struct VbExchange {
-  uint32_t *count;      // [nbuckets] occupied cells of the bucket (written write-through)
-  uint32_t *group_tot;  // [ngroups] occupied cells of a group of 32 buckets, written by whoever completes the group
-  unsigned int *arrived;  // as StrictWork::tile_arrived: word g at [32 g], then the groups' bits at [32 (ngroups + G)]
+  uint32_t *count;      // [nbuckets]
+  uint32_t *group_tot;  // [ceil(nbuckets / 32)]
+  uint32_t *super_tot;  // [ceil(nbuckets / 1024)] (<= 64)
 };
 
 __device__ __forceinline__ uint32_t ld_sc1_u32(const uint32_t *p) {
@@ -310,7 +325,6 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
   constexpr int kPer = kVbCap / kVbFinalThreads;       // points per thread
   constexpr int kBinsPer = kBins / kVbFinalThreads;    // cells per thread
   __shared__ float sx[kVbCap], sy[kVbCap], sz[kVbCap];
-  __shared__ uint16_t slow[kVbCap];     // the key's low bits
   __shared__ uint16_t order[kVbCap];    // positions cell after cell, as they arrived
   __shared__ uint32_t cnt[kBins];       // points of the cell; then: its first place in order[]
   __shared__ uint16_t ccount[kBins];    // points of the cell (kept)
@@ -326,19 +340,19 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
   for (int l = threadIdx.x; l < nbins; l += kVbFinalThreads) cnt[l] = 0;
   __syncthreads();
   // ---- the bucket's points, in input order (the partition is stable); arrival order inside a cell is arbitrary
-  uint16_t arr[kPer];
+  uint16_t arr[kPer], low[kPer];
   const uint32_t lmask = (uint32_t)nbins - 1u;
 #pragma unroll
   for (int r = 0; r < kPer; r++) {
     const int i = r * kVbFinalThreads + threadIdx.x;
-    arr[r] = 0;
+    arr[r] = low[r] = 0;
     if (i < P) {
       const int64_t g = (int64_t)start + i;
       const uint32_t l = keys[g] & lmask;
       sx[i] = xyz[g];
       sy[i] = xyz[n + g];
       sz[i] = xyz[2 * n + g];
-      slow[i] = (uint16_t)l;
+      low[r] = (uint16_t)l;
       arr[r] = (uint16_t)atomicAdd(&cnt[l], 1u);
     }
   }
@@ -394,31 +408,39 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
   }
   const bool skip = __syncthreads_or((crowded || !fits) ? 1 : 0) != 0;  // (also the barrier behind cnt[] / ccount[])
   if (skip && threadIdx.x == 0) atomicOr(flags, fits ? 2 : 1);  // more points than the LDS tile / than a cell is ordered for: radix path
-  // ---- my count out at once (the later buckets wait for it); the wait for the earlier ones comes last.  Whoever
-  // completes a group of 32 buckets adds up the group (a lane per bucket: one round of loads, not 32 in a row --
-  // every bucket behind the group waits for this) and says so one level up.
-  if (wave == 0) {
-    const int64_t g_mine = b >> 5, n_groups = ((int64_t)plan.nbuckets + 31) >> 5;
-    const uint32_t bit = 1u << (b & 31);
-    const uint32_t full = (g_mine == n_groups - 1 && (plan.nbuckets & 31)) ? (1u << (plan.nbuckets & 31)) - 1u : 0xffffffffu;
-    uint32_t old = 0;
-    if (lane == 0) {
-      __hip_atomic_store(&ex.count[b], occupied_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      old = __hip_atomic_fetch_or(&ex.arrived[32 * g_mine], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
-    if ((old | bit) == full) {  // uniform
-      const int64_t bk = (g_mine << 5) + lane;
-      uint32_t t = (lane < 32 && bk < plan.nbuckets) ? ld_sc1_u32(&ex.count[bk]) : 0u;
+  // ---- my count out at once, nothing to wait for (the later buckets read it); my own wait comes last
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&ex.count[b], occupied_total | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int n2 = b >> 10, n1 = (b >> 5) & 31, n0 = b & 31;
+  const bool closes_group = n0 == 31;  // (this bucket publishes its group's total, and its 1024-group's if it closes that too)
+  // The totals this bucket owes the later ones go out NOW, as soon as their parts are in -- a group's total needs its
+  // buckets' counts (published at this same point of their workgroups, a moment ago) and nothing else.  Published at
+  // the end of the workgroup instead, every bucket's own wait met totals that were still being made (two polls
+  // instead of one: 40 us per C3 call); published only behind the wait for the earlier groups, the groups chained
+  // one behind the other (0.28 ms).
+  if (closes_group && wave == 0) {
+    bool pub_group = false, pub_super = n1 != 31;
+    for (int spins = 0; spins < kVbSpins && !(pub_group && pub_super); spins++) {
+      const uint32_t w1 = (lane < n1 && !pub_super) ? ld_sc1_u32(&ex.group_tot[(n2 << 5) + lane]) : 0x80000000u;
+      const uint32_t w0 = lane < n0 ? ld_sc1_u32(&ex.count[((b >> 5) << 5) + lane]) : 0x80000000u;
+      const bool ok0 = __ballot((w0 >> 31) == 0u) == 0ull, ok1 = __ballot((w1 >> 31) == 0u) == 0ull;
+      uint32_t t0 = w0 & 0x7fffffffu, t1 = w1 & 0x7fffffffu;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-      if (lane == 0) {
-        __hip_atomic_store(&ex.group_tot[g_mine], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_or(&ex.arrived[32 * (n_groups + (g_mine >> 5))], 1u << (g_mine & 31), __ATOMIC_RELAXED,
-                              __HIP_MEMORY_SCOPE_AGENT);
+      for (int o = 32; o > 0; o >>= 1) {
+        t0 += __shfl_xor(t0, o);
+        t1 += __shfl_xor(t1, o);
       }
+      if (ok0 && !pub_group) {
+        if (lane == 0)
+          __hip_atomic_store(&ex.group_tot[b >> 5], (t0 + occupied_total) | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pub_group = true;
+      }
+      if (ok0 && ok1 && !pub_super) {
+        if (lane == 0)
+          __hip_atomic_store(&ex.super_tot[n2], (t1 + t0 + occupied_total) | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pub_super = true;
+      }
+      if (!(pub_group && pub_super)) __builtin_amdgcn_s_sleep(4);
     }
   }
   const bool last = b == plan.nbuckets - 1;
@@ -427,7 +449,7 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
 #pragma unroll
   for (int r = 0; r < kPer; r++) {
     const int i = r * kVbFinalThreads + threadIdx.x;
-    if (i < P) order[cnt[slow[i]] + arr[r]] = (uint16_t)i;
+    if (i < P) order[cnt[low[r]] + arr[r]] = (uint16_t)i;
   }
   __syncthreads();
   // ---- cell by cell: its points into input order (ascending position: a sorting network over eight registers; a
@@ -439,7 +461,7 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
 #pragma unroll
   for (int k = 0; k < kBinsPer; k++) {
     const int l = k * kVbFinalThreads + threadIdx.x;
-    cc[k] = (l < nbins && !skip) ? ccount[l] : 0;
+    cc[k] = (l < nbins && !skip && !(plan.dbg & 2)) ? ccount[l] : 0;
     head[k] = 0;
     o0[k] = o1[k] = o2[k] = 0.0f;
     if (cc[k] == 0) continue;
@@ -504,40 +526,33 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
     }
   }
   // ---- where the bucket's cells go: the occupied cells of all buckets before it (they were dispatched before this
-  // one and have published their counts long since: the wait is a formality by now)
+  // one and have published their counts long since: one round of loads as a rule)
   if (wave == 0) {
-    const int64_t g_mine = b >> 5, n_groups = ((int64_t)plan.nbuckets + 31) >> 5;
     bool gave_up = false;
-    const int64_t G_mine = g_mine >> 5;
-    for (int64_t G0 = 0; G0 <= G_mine && !gave_up; G0 += kLanesWait) {  // uniform
-      const int64_t G = G0 + lane - 1;
-      uint32_t want = 0u;
-      const unsigned int *word = ex.arrived;
-      if (lane == 0) {
-        want = G0 == 0 ? (1u << (b & 31)) - 1u : 0u;
-        word = ex.arrived + 32 * g_mine;
-      } else if (G <= G_mine) {
-        want = G < G_mine ? 0xffffffffu : (1u << (g_mine & 31)) - 1u;
-        word = ex.arrived + 32 * (n_groups + G);
+    uint32_t s2 = 0, s1 = 0, s0 = 0;
+    for (int spins = 0; !(plan.dbg & 1); spins++) {
+      // (issued before the cell phase and looked at here, the first poll was slower: 138 us against 124 for the kernel)
+      const uint32_t w2 = lane < n2 ? ld_sc1_u32(&ex.super_tot[lane]) : 0x80000000u;
+      const uint32_t w1 = lane < n1 ? ld_sc1_u32(&ex.group_tot[(n2 << 5) + lane]) : 0x80000000u;
+      const uint32_t w0 = lane < n0 ? ld_sc1_u32(&ex.count[((b >> 5) << 5) + lane]) : 0x80000000u;
+      s2 = w2 & 0x7fffffffu;
+      s1 = w1 & 0x7fffffffu;
+      s0 = w0 & 0x7fffffffu;
+      if (__ballot(((w2 & w1 & w0) >> 31) == 0u) == 0ull) break;
+      if (spins >= kVbSpins) {
+        gave_up = true;
+        break;
       }
-      for (int spins = 0;; spins++) {
-        uint32_t have = 0u;
-        if (want) have = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__ballot((have & want) != want) == 0ull) break;
-        if (spins >= kVbSpins) {
-          gave_up = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
+      __builtin_amdgcn_s_sleep(4);
     }
-    // the groups before mine, then the buckets of my group before me
-    uint32_t v = 0;
-    for (int64_t g = lane; g < g_mine; g += 64) v += ld_sc1_u32(&ex.group_tot[g]);
-    if (lane < (b & 31)) v += ld_sc1_u32(&ex.count[(g_mine << 5) + lane]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int o = 32; o > 0; o >>= 1) {
+      s2 += __shfl_xor(s2, o);
+      s1 += __shfl_xor(s1, o);
+      s0 += __shfl_xor(s0, o);
+    }
     if (lane == 0) {
+      const uint32_t v = s2 + s1 + s0;
       s_prefix = v;
       if (gave_up) atomicOr(flags, 4);
       if (last && !gave_up) *total = (int64_t)v + (int64_t)occupied_total;
@@ -573,11 +588,12 @@ static int vb_knob(const char *name, int def) {
   return e ? atoi(e) : def;
 }
 
-// The bucket path of one filter call (one GPU, one sort key of key_bits bits over [0, key_range)).  *taken false: the
+// The bucket path of one filter call (one GPU, one sort key of key_bits bits over [0, key_range)).  key_population: how many
+// of those keys can occur (chunked mode leaves gaps between the chunks' cell ranges).  *taken false: the
 // call is not for this path (too small, keys too wide, PCGX_VOXEL_BUCKET=0) or turned out not to fit (a crowded
 // bucket or cell; *out_n is then untouched and nothing the radix path does not overwrite has been written).
 pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, int32_t xyz_off, const VoxelParams &vp,
-                                int key_bits, uint64_t key_range, void *d_out, int64_t *out_n, bool *taken, hipStream_t st) {
+                                int key_bits, uint64_t key_range, uint64_t key_population, void *d_out, int64_t *out_n, bool *taken, hipStream_t st) {
   *taken = false;
   static const int enabled = vb_knob("PCGX_VOXEL_BUCKET", 1), min_n = vb_knob("PCGX_VOXEL_BUCKET_MIN_N", 400000);
   if (!enabled || n < min_n || key_bits < 1 || key_bits > kVbMaxLowBits + kVbMaxBucketBits || key_range < 2) return PCGX_OK;
@@ -585,7 +601,7 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   VbPlan plan;
   memset(&plan, 0, sizeof plan);
   int s = key_bits < kVbMaxLowBits ? key_bits : kVbMaxLowBits;
-  while (s > 0 && (double)n * (double)((uint64_t)1 << s) / (double)key_range > 0.6 * kVbCap) s--;
+  while (s > 0 && (double)n * (double)((uint64_t)1 << s) / (double)key_population > 0.6 * kVbCap) s--;
   const uint64_t nb = ((key_range - 1) >> s) + 1;
   int bb = 0;
   while (((uint64_t)1 << bb) < nb) bb++;
@@ -595,6 +611,7 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   plan.d_bits[0] = bb <= 8 ? bb : bb - bb / 2;
   plan.d_bits[1] = bb - plan.d_bits[0];
   plan.ntiles = (int32_t)((n + kVbTile - 1) / kVbTile);
+  plan.dbg = vb_knob("PCGX_VOXEL_BUCKET_DBG", 0);
   const bool with_idx = stride != 12 || xyz_off != 0 || ((reinterpret_cast<uintptr_t>(d_data) | reinterpret_cast<uintptr_t>(d_out)) & 3) != 0;
 
   Arena &ar = ctx().arena;
@@ -604,8 +621,7 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   int32_t *d_flags = nullptr;  // [0] flags (1 crowded bucket, 2 crowded cell, 4 the exchange gave up), [1] key out of range
   int64_t *d_total = nullptr;
   VbExchange ex;
-  const int64_t n_groups = ((int64_t)plan.nbuckets + 31) / 32;
-  const size_t arrived_words = (size_t)(n_groups + (n_groups + 31) / 32) * 32;
+  const int64_t n_groups = ((int64_t)plan.nbuckets + 31) / 32, n_super = ((int64_t)plan.nbuckets + 1023) / 1024;
   PCGX_TRY(ar.alloc_n((size_t)n, &key0));
   const int passes = plan.d_bits[1] ? 2 : 1;
   for (int k = 0; k < passes; k++) {
@@ -616,17 +632,17 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   PCGX_TRY(ar.alloc_n((size_t)plan.ntiles * 256, &block_hist));
   PCGX_TRY(ar.alloc_n(256, &totals));
   PCGX_TRY(ar.alloc_n((size_t)plan.nbuckets + 1, &bucket_start));
-  // one block, zeroed at once: the exchange's words, flags, the sample of the bucket populations, the buckets' counts
-  const size_t zero_words = arrived_words + 8 + (size_t)plan.nbuckets * 2 + (size_t)n_groups;
+  // one block, zeroed at once: flags, the exchange's words, the sample of the bucket populations
+  const size_t zero_words = 8 + (size_t)plan.nbuckets * 2 + (size_t)n_groups + (size_t)n_super;
   uint32_t *zero_block = nullptr;
   PCGX_TRY(ar.alloc_n(zero_words + 64, &zero_block));
   zero_block = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(zero_block) + 127) & ~(uintptr_t)127);
-  ex.arrived = zero_block;
-  d_flags = reinterpret_cast<int32_t *>(zero_block + arrived_words);  // (128-byte aligned: arrived_words is a multiple of 32)
+  d_flags = reinterpret_cast<int32_t *>(zero_block);
   d_total = reinterpret_cast<int64_t *>(d_flags + 2);
-  bucket_sample = zero_block + arrived_words + 8;
+  bucket_sample = zero_block + 8;
   ex.count = bucket_sample + plan.nbuckets;
   ex.group_tot = ex.count + plan.nbuckets;
+  ex.super_tot = ex.group_tot + n_groups;
   PCGX_HIP_TRY(hipMemsetAsync(zero_block, 0, zero_words * sizeof(uint32_t), st));
 
   const uint8_t *data = (const uint8_t *)d_data;

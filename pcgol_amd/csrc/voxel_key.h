@@ -71,6 +71,6 @@ __device__ __forceinline__ uint32_t voxel_key_xyz(const float pt[3], const Voxel
 
 // voxel_bucket.hip: the bucket path of a filter call on one GPU (see there); *taken false: the radix path does the call
 pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, int32_t xyz_off, const VoxelParams &vp,
-                                int key_bits, uint64_t key_range, void *d_out, int64_t *out_n, bool *taken, hipStream_t st);
+                                int key_bits, uint64_t key_range, uint64_t key_population, void *d_out, int64_t *out_n, bool *taken, hipStream_t st);
 
 }  // namespace pcgx
