@@ -175,6 +175,14 @@ static pcgx_status init_device(int device) {
     Context &s = g.slots[k];
     s.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     PCGX_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    void *mb = nullptr;
+    if (hipHostMalloc(&mb, 256, hipHostMallocDefault) == hipSuccess) {  // (not required: without it results are copied and waited for)
+      memset(mb, 0, 256);
+      s.mailbox = (volatile uint32_t *)mb;
+    } else {
+      (void)hipGetLastError();
+    }
+    s.mailbox_seq = 0;
     s.device = device;
   }
   for (int k = kPoolSlots; k >= 0; k--) g.slots[k].ready = true;
@@ -306,6 +314,8 @@ extern "C" pcgx_status pcgx_shutdown(void) {
     c.host_arena.release_all();
     (void)hipStreamDestroy(c.stream);
     c.stream = nullptr;
+    if (c.mailbox) (void)hipHostFree((void *)c.mailbox);
+    c.mailbox = nullptr;
     c.ready = false;
     c.device = -1;
   }

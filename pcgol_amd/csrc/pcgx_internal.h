@@ -119,6 +119,11 @@ struct Context {
   Arena arena;       // temporaries of the device-resident (_dev) entry points
   Arena host_arena;  // device staging of the host-pointer entry points (they call the _dev ones,
                      // which restart `arena`; separate so the staging survives that)
+  // 64 words of pinned host memory the device can write: small results the host waits for in the middle of a call
+  // (the voxel filter's min / max) land here directly, behind a sequence word the host spins on -- a copy to pageable
+  // memory plus hipStreamSynchronize cost 30 us of idle GPU per call
+  volatile uint32_t *mailbox = nullptr;
+  uint32_t mailbox_seq = 0;
 };
 Context &ctx();  // the calling thread's current context (the library's outside any call)
 pcgx_status ensure_init();
@@ -268,6 +273,9 @@ RadixFirstHist radix_first_hist(int64_t n, void *workspace);
 // later slice of a cloud whose min / max are folded over ranks
 pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
                           hipStream_t st, bool sticky_first = true);
+// the same, and the six floats on the host (through the context's mailbox; the stream is not synchronised)
+pcgx_status minmax_to_host(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6, float out6[6],
+                           hipStream_t st, bool sticky_first = true);
 // perm[pos] = index of the point visited at position pos (coarse Morton order over the box
 // [lo, hi]).  Uses the arena.
 pcgx_status morton_order(const float *d_q, int64_t n, const float lo[3], const float hi[3], int32_t *d_perm,

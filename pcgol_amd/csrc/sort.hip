@@ -416,7 +416,8 @@ __global__ __launch_bounds__(256) void minmax_partial_packed_kernel(const float4
 // out6 = {min xyz, max xyz}; one block folds the per-block partials.
 __global__ __launch_bounds__(256) void minmax_final_kernel(const MinMaxAcc *__restrict__ partials, int nparts,
                                                            const uint8_t *__restrict__ data, int32_t off,
-                                                           float *__restrict__ out6, int sticky_first) {
+                                                           float *__restrict__ out6, int sticky_first,
+                                                           volatile uint32_t *__restrict__ mailbox, uint32_t seq) {
   __shared__ MinMaxAcc s_acc[4];
   const float qnan = __uint_as_float(0x7fc00000u);
   MinMaxAcc a;
@@ -453,10 +454,18 @@ __global__ __launch_bounds__(256) void minmax_final_kernel(const MinMaxAcc *__re
     out6[k] = a.mn[k];
     out6[3 + k] = a.mx[k];
   }
+  if (mailbox) {  // the host waits for these: straight into its (pinned) memory, the sequence word last
+    for (int k = 0; k < 3; k++) {
+      mailbox[1 + k] = __float_as_uint(a.mn[k]);
+      mailbox[4 + k] = __float_as_uint(a.mx[k]);
+    }
+    __threadfence_system();
+    mailbox[0] = seq;
+  }
 }
 
-pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
-                          hipStream_t st, bool sticky_first) {
+static pcgx_status launch_minmax_impl(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
+                                      hipStream_t st, bool sticky_first, volatile uint32_t *mailbox, uint32_t seq) {
   if (n <= 0) return fail(PCGX_E_NO_POINT, "no point");
   int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
   if (blocks > 1024) blocks = 1024;
@@ -470,8 +479,47 @@ pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t
     hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t *)d_data, n,
                        stride, off, partials);
   hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, st, partials, blocks,
-                     (const uint8_t *)d_data, off, d_out6, sticky_first ? 1 : 0);
+                     (const uint8_t *)d_data, off, d_out6, sticky_first ? 1 : 0, mailbox, seq);
   PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
+pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
+                          hipStream_t st, bool sticky_first) {
+  return launch_minmax_impl(d_data, n, stride, off, d_out6, st, sticky_first, nullptr, 0u);
+}
+
+pcgx_status minmax_to_host(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6, float out6[6],
+                           hipStream_t st, bool sticky_first) {
+  Context &c = ctx();
+  volatile uint32_t *mb = c.mailbox;
+  if (mb) {
+    const uint32_t seq = ++c.mailbox_seq ? c.mailbox_seq : ++c.mailbox_seq;  // (never 0: the mailbox starts zeroed)
+    PCGX_TRY(launch_minmax_impl(d_data, n, stride, off, d_out6, st, sticky_first, mb, seq));
+    // the kernels are a few tens of microseconds; a device in trouble is found by the stream instead
+    for (long spins = 0;; spins++) {
+      if (__atomic_load_n((const uint32_t *)mb, __ATOMIC_ACQUIRE) == seq) {
+        for (int k = 0; k < 6; k++) {
+          const uint32_t bits = mb[1 + k];
+          memcpy(&out6[k], &bits, 4);
+        }
+        return PCGX_OK;
+      }
+      if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(st) != hipErrorNotReady) break;  // finished (or failed) without the word
+      __builtin_ia32_pause();
+    }
+    if (__atomic_load_n((const uint32_t *)mb, __ATOMIC_ACQUIRE) == seq) {
+      for (int k = 0; k < 6; k++) {
+        const uint32_t bits = mb[1 + k];
+        memcpy(&out6[k], &bits, 4);
+      }
+      return PCGX_OK;
+    }
+  } else {
+    PCGX_TRY(launch_minmax_impl(d_data, n, stride, off, d_out6, st, sticky_first, nullptr, 0u));
+  }
+  PCGX_HIP_TRY(hipMemcpyAsync(out6, d_out6, 6 * sizeof(float), hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
   return PCGX_OK;
 }
 

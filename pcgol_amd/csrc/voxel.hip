@@ -422,9 +422,7 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
   PCGX_TRY(ar.alloc_n(6, &d_mm6));
   float mm6[6];
   if (world == 1) {
-    PCGX_TRY(launch_minmax(d_data, n, stride, xyz_off, d_mm6, st));
-    PCGX_HIP_TRY(hipMemcpyAsync(mm6, d_mm6, sizeof mm6, hipMemcpyDeviceToHost, st));
-    PCGX_HIP_TRY(hipStreamSynchronize(st));
+    PCGX_TRY(minmax_to_host(d_data, n, stride, xyz_off, d_mm6, mm6, st));
   } else {
     // the slice's six floats travel as their bit patterns in slot `rank` of a vector of zeros: the
     // sum every rank receives holds all of them exactly (an all-gather out of the one collective the
