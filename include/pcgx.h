@@ -78,6 +78,13 @@ PCGX_API pcgx_status pcgx_sync(void *stream);
  * Measurement aid: out = {largest number of pooled calls in flight at once, pooled calls} since the
  * last reset. */
 PCGX_API pcgx_status pcgx_debug_call_stats(int64_t out[2], int32_t reset);
+/* Measurement / test aid: which path the VoxelGrid filter calls took since the last reset.  The filter
+ * (voxelgrid.go:136-187) has two device paths with identical output: the bucket path (the coordinates travel
+ * with the sort keys, a workgroup per bucket of cells; csrc/voxel_bucket.hip) and the radix path (stable sort of
+ * (key, index) pairs + gather; csrc/voxel.hip), which also takes what the bucket path gives up on.
+ * out = {calls the bucket path answered, bucket attempts given up (a bucket or a cell too crowded),
+ *        flags of the last attempt given up (1 bucket, 2 cell, 4 exchange), low key bits of the last plan}. */
+PCGX_API pcgx_status pcgx_debug_voxel_stats(int64_t out[4], int32_t reset);
 
 /* Optional in-library kernel timing (HIP events on the launch stream around
  * the named kernel class).  Used by bench.py for the live roofline figure. */

@@ -175,6 +175,7 @@ SIGNATURES = {
     "pcgx_icp_session_step": (_i32, [_vp, _vp]),
     "pcgx_icp_session_set_strict": (_i32, [_vp, _i32]),
     "pcgx_debug_call_stats": (_i32, [_vp, _i32]),
+    "pcgx_debug_voxel_stats": (_i32, [_vp, _i32]),
     "pcgx_comm_unique_id": (_i32, [_vp]),
     "pcgx_comm_init": (_i32, [_i32, _i32, _vp, C.POINTER(_vp)]),
     "pcgx_comm_init_callback": (_i32, [_i32, _i32, _vp, _vp, C.POINTER(_vp)]),

@@ -19,6 +19,7 @@
 //
 // Out-of-range cell indices make the Go code panic; here they raise
 // PCGX_E_OUT_OF_RANGE.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -89,10 +90,10 @@ __device__ __forceinline__ uint32_t voxel_key_of(const uint8_t *__restrict__ dat
   return key;
 }
 
-// chunk id of sorted position j: its own array (two sorts), or the high bits of the combined key
+// chunk id of sorted position j: its own array (two sorts), or the quotient of the combined key
 __device__ __forceinline__ uint32_t sorted_cid(const VoxelParams &vp, const uint32_t *__restrict__ sa,
                                                const uint32_t *__restrict__ sc, int64_t j) {
-  return sc ? sc[j] : (vp.combined ? sa[j] >> vp.key_shift : 0u);
+  return sc ? sc[j] : (vp.combined ? sa[j] / (uint32_t)vp.n_voxels : 0u);
 }
 
 __global__ __launch_bounds__(256) void gather_u32_kernel(const uint32_t *__restrict__ src,
@@ -480,19 +481,32 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
   bool two_level = vp.chunked && vp.n_chunks > 1;
   int key_bits = bits_for(vp.n_voxels);
   const char *force_two = getenv("PCGX_VOXEL_TWO_SORTS");  // tests: keep the two-sort path covered
-  if (two_level && key_bits + bits_for(vp.n_chunks) <= 32 && !(force_two && force_two[0] == '1')) {
-    // (chunk id, cell) in one 32-bit key: one stable sort gives the reference's output order
-    // (chunks ascending, cells ascending inside a chunk) without the second sort and its gathers
+  if (two_level && (double)vp.n_chunks * (double)vp.n_voxels <= 4294967296.0 && !(force_two && force_two[0] == '1')) {
+    // (chunk id, cell) in one 32-bit key, cid * n_voxels + cell -- dense: no unused values between the chunks' cell
+    // ranges, so the key is as short as it can be and the bucket path's buckets are evenly filled.  One stable sort
+    // gives the reference's output order (chunks ascending, cells ascending inside a chunk) without the second
+    // sort and its gathers
     vp.combined = 1;
-    vp.key_shift = key_bits;
-    key_bits += bits_for(vp.n_chunks);
+    key_bits = bits_for(vp.n_chunks * vp.n_voxels);
     two_level = false;
   }
   if (world == 1 && !two_level) {
     // the points travel with their keys (voxel_bucket.hip) where the cloud allows it: no 12-byte gather per point
     bool taken = false;
-    const uint64_t key_range = vp.combined ? ((uint64_t)vp.n_chunks << vp.key_shift) : (uint64_t)vp.n_voxels;
-    const uint64_t key_population = vp.combined ? (uint64_t)vp.n_chunks * (uint64_t)vp.n_voxels : (uint64_t)vp.n_voxels;
+    const uint64_t key_range = vp.combined ? (uint64_t)vp.n_chunks * (uint64_t)vp.n_voxels : (uint64_t)vp.n_voxels;
+    // how many keys can occur: not more than the cells the cloud's own extent spans (the non-chunked grid is sized by
+    // vMax, voxelgrid.go:46; a chunked grid's last chunks are partly empty, and every chunk seam splits a cell)
+    uint64_t key_population = vp.combined ? (uint64_t)vp.n_chunks * (uint64_t)vp.n_voxels : (uint64_t)vp.n_voxels;
+    {
+      double cells = 1.0;
+      const int64_t per_axis_chunks[3] = {vp.chunked ? vp.nx : 0, vp.chunked ? vp.ny : 0,
+                                          vp.chunked ? vp.n_chunks / (vp.nx * vp.ny) : 0};
+      for (int k = 0; k < 3; k++) {
+        const double ext = (double)mm6[3 + k] - (double)mm6[k];
+        cells *= (ext > 0.0 ? floor(ext / (double)leaf[k]) : 0.0) + 1.0 + (double)per_axis_chunks[k];
+      }
+      if (cells >= 1.0 && cells < (double)key_population) key_population = (uint64_t)cells;
+    }
     PCGX_TRY(voxel_bucket_filter(d_data, n, stride, xyz_off, vp, key_bits, key_range, key_population, d_out, out_n, &taken, st));
     if (taken) return PCGX_OK;
     PCGX_TRY(ar.begin(st));  // (the attempt's temporaries are free again)
@@ -531,7 +545,7 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
     // this rank's share of the output order: by chunk id (two sorts), else by the one key
     const uint32_t *primary = two_level ? cid_orig : keys[0];
     const uint64_t span = two_level ? (uint64_t)vp.n_chunks
-                                    : (vp.combined ? ((uint64_t)vp.n_chunks << vp.key_shift) : (uint64_t)vp.n_voxels);
+                                    : (vp.combined ? (uint64_t)vp.n_chunks * (uint64_t)vp.n_voxels : (uint64_t)vp.n_voxels);
     const uint64_t lo = span * (uint64_t)rank / (uint64_t)world, hi = span * (uint64_t)(rank + 1) / (uint64_t)world;
     const int mtiles = (int)((n + kMineTile - 1) / kMineTile);
     uint32_t *mine_count = nullptr;

@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "voxel_key.h"
 
 namespace pcgx {
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
     const int first = (int)cnt[l], c = cc[k];
     const uint32_t key = ((uint32_t)b << plan.low_bits) | (uint32_t)l;
     float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
-    if (vp.chunked) chunk_origin(vp, vp.combined ? key >> vp.key_shift : 0u, origin);
+    if (vp.chunked) chunk_origin(vp, vp.combined ? key / (uint32_t)vp.n_voxels : 0u, origin);
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
     if (c <= 8) {
       uint32_t e[8];
@@ -583,6 +585,8 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
   }
 }
 
+static std::atomic<long long> g_vb_taken{0}, g_vb_given_up{0}, g_vb_last_flags{0}, g_vb_last_low{0};
+
 static int vb_knob(const char *name, int def) {
   const char *e = getenv(name);
   return e ? atoi(e) : def;
@@ -595,7 +599,7 @@ static int vb_knob(const char *name, int def) {
 pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, int32_t xyz_off, const VoxelParams &vp,
                                 int key_bits, uint64_t key_range, uint64_t key_population, void *d_out, int64_t *out_n, bool *taken, hipStream_t st) {
   *taken = false;
-  static const int enabled = vb_knob("PCGX_VOXEL_BUCKET", 1), min_n = vb_knob("PCGX_VOXEL_BUCKET_MIN_N", 400000);
+  const int enabled = vb_knob("PCGX_VOXEL_BUCKET", 1), min_n = vb_knob("PCGX_VOXEL_BUCKET_MIN_N", 400000);
   if (!enabled || n < min_n || key_bits < 1 || key_bits > kVbMaxLowBits + kVbMaxBucketBits || key_range < 2) return PCGX_OK;
   // s: as many cells per bucket as keep an evenly filled bucket at 0.6 of the LDS tile (C3: the fullest of 6505 holds 1.35x the mean)
   VbPlan plan;
@@ -646,7 +650,7 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   PCGX_HIP_TRY(hipMemsetAsync(zero_block, 0, zero_words * sizeof(uint32_t), st));
 
   const uint8_t *data = (const uint8_t *)d_data;
-  static const int sample = vb_knob("PCGX_VOXEL_BUCKET_SAMPLE", 1);
+  const int sample = vb_knob("PCGX_VOXEL_BUCKET_SAMPLE", 1);
   hipLaunchKernelGGL(vb_key_hist_kernel, dim3(plan.ntiles), dim3(256), 0, st, data, n, stride, xyz_off, vp, plan, key0, block_hist,
                      sample ? bucket_sample : (uint32_t *)nullptr, d_flags + 1);
   hipLaunchKernelGGL(vb_sample_check_kernel, dim3((plan.nbuckets + 255) / 256), dim3(256), 0, st, (const uint32_t *)bucket_sample,
@@ -701,7 +705,10 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   PCGX_HIP_TRY(hipStreamSynchronize(st));
   if (h.err)
     return fail(PCGX_E_OUT_OF_RANGE, "voxel filter: a point falls outside the dense grid (the reference panics: index out of range)");
+  g_vb_last_low = plan.low_bits;
   if (h.flags) {  // crowded bucket / cell (or the exchange gave up): the radix path does the call
+    g_vb_given_up++;
+    g_vb_last_flags = h.flags;
     if (getenv("PCGX_VOXEL_BUCKET_TRACE"))
       fprintf(stderr, "pcgx voxel bucket path: flags %d (1 bucket over %d points, 2 cell over %d points, 4 exchange gave up); low bits %d, %d buckets, digits %d + %d\n",
               h.flags, kVbCap, kVbMaxCell, plan.low_bits, plan.nbuckets, plan.d_bits[0], plan.d_bits[1]);
@@ -709,7 +716,19 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   }
   *out_n = h.total;
   *taken = true;
+  g_vb_taken++;
   return PCGX_OK;
 }
 
 }  // namespace pcgx
+
+extern "C" pcgx_status pcgx_debug_voxel_stats(int64_t out[4], int32_t reset) {
+  using namespace pcgx;
+  if (!out) return fail(PCGX_E_INVALID, "pcgx_debug_voxel_stats: NULL argument");
+  out[0] = g_vb_taken;
+  out[1] = g_vb_given_up;
+  out[2] = g_vb_last_flags;
+  out[3] = g_vb_last_low;
+  if (reset) g_vb_taken = g_vb_given_up = g_vb_last_flags = 0;
+  return PCGX_OK;
+}

@@ -14,8 +14,8 @@ struct VoxelParams {
   int32_t chunked;
   float cs[3];         // clamped chunk size in metres
   int64_t nx, ny, n_chunks;
-  // chunked mode with (chunk id, cell) fitting 32 bits: ONE sort key = cid << key_shift | cell
-  int32_t combined, key_shift;
+  // chunked mode with (chunk id, cell) fitting 32 bits: ONE sort key = cid * n_voxels + cell
+  int32_t combined, pad_;
 };
 
 __device__ __forceinline__ float ld_f32(const uint8_t *p) {
@@ -66,7 +66,7 @@ __device__ __forceinline__ uint32_t voxel_key_xyz(const float pt[3], const Voxel
   if (a < 0 || a >= vp.n_voxels) bad = true;  // f.voxels[a] would panic
   else ka = (uint32_t)a;
   ka_out = ka;
-  return vp.combined ? ((cid << vp.key_shift) | ka) : ka;
+  return vp.combined ? cid * (uint32_t)vp.n_voxels + ka : ka;
 }
 
 // voxel_bucket.hip: the bucket path of a filter call on one GPU (see there); *taken false: the radix path does the call

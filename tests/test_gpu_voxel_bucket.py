@@ -1,0 +1,120 @@
+"""The VoxelGrid filter's bucket path (csrc/voxel_bucket.hip: the coordinates travel with the sort keys, one workgroup
+per bucket of cells) against the oracle, byte for byte -- forced onto clouds far smaller than it is meant for, so that
+every branch runs: one and two partition passes, records with fields around xyz (the first point's record is looked
+up through its index), unaligned records, chunked keys, empty buckets in front of / behind the occupied ones; and the
+clouds it gives up on (a bucket or a cell too crowded for its LDS tile), which the radix path answers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as O
+from pcgol_amd import _lib as L
+from pcgol_amd import synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _stats(reset=True):
+    st = np.zeros(4, np.int64)
+    L.check(L.lib().pcgx_debug_voxel_stats(L.ptr(st), 1 if reset else 0))
+    return st
+
+
+def _filter(rec, n, stride, off, leaf, chunk):
+    out = np.empty(n * stride, np.uint8)
+    m = C.c_int64()
+    leafv, chunkv = np.asarray(leaf, f32), np.asarray(chunk, np.int32)
+    L.check(L.lib().pcgx_voxel_filter(L.ptr(rec), n, stride, off, L.ptr(leafv), L.ptr(chunkv), L.ptr(out), C.byref(m)))
+    return out[: m.value * stride]
+
+
+def _records(pts, stride, off, rng):
+    n = len(pts)
+    rec = rng.integers(0, 256, size=(n, stride), dtype=np.uint8)
+    rec[:, off:off + 12] = pts.view(np.uint8).reshape(n, 12)
+    return np.ascontiguousarray(rec)
+
+
+@pytest.mark.parametrize("n,width,leaf,chunk,stride,off", [
+    (3000, 1.6, 0.05, (0, 0, 0), 12, 0),          # one partition pass, a handful of buckets
+    (100000, 1.6, 0.05, (0, 0, 0), 12, 0),        # BASELINE config C1
+    (100000, 1.6, 0.05, (0, 0, 0), 16, 0),        # x y z label: the first point's record through its index
+    (50000, 1.6, 0.05, (0, 0, 0), 20, 4),
+    (50000, 1.6, 0.05, (0, 0, 0), 15, 1),         # unaligned records
+    (100000, 1.6, 0.05, (8, 8, 8), 12, 0),        # chunk id and cell in one key
+    (100000, 1.6, 0.05, (3, 5, 7), 16, 0),
+    (300000, 3.0, 0.02, (0, 0, 0), 12, 0),        # two partition passes
+    (300000, 3.0, 0.02, (64, 64, 64), 12, 0),
+    (200000, 0.6, 0.02, (0, 0, 0), 12, 0),        # ~7 points per cell: cells beyond the eight-register sort
+])
+def test_bucket_path_vs_oracle(n, width, leaf, chunk, stride, off, monkeypatch):
+    monkeypatch.setenv("PCGX_VOXEL_BUCKET_MIN_N", "1")
+    rng = np.random.default_rng(n + stride)
+    pts = synth.uniform_cloud(n, width, 40 + n % 97)
+    rec = _records(pts, stride, off, rng)
+    exp = O.voxel_filter(rec, n, stride, off, (leaf,) * 3, chunk)
+    _stats()
+    got = _filter(rec, n, stride, off, (leaf,) * 3, chunk)
+    st = _stats()
+    assert st[0] == 1 and st[1] == 0, st      # the bucket path answered
+    assert len(got) == len(exp) and np.array_equal(got, exp)
+
+
+def test_bucket_path_slab_and_offset_clouds(monkeypatch):
+    """Most of the key range empty (a thin slab; a cloud far from the origin of a chunked grid): empty buckets in
+    front of, between and behind the occupied ones, the last bucket among them."""
+    monkeypatch.setenv("PCGX_VOXEL_BUCKET_MIN_N", "1")
+    pts = synth.uniform_cloud(200_000, 3.0, 5)
+    slab = pts.copy()
+    slab[:, 2] = slab[:, 2] * f32(0.001)
+    off_cloud = synth.uniform_cloud(50000, 2.0, 9) - f32(0.7)
+    for data, leaf, chunk in ((np.ascontiguousarray(slab), (0.004,) * 3, (0, 0, 0)),
+                              (off_cloud, (0.05, 0.04, 0.03), (16, 16, 16)),
+                              (synth.uniform_cloud(50000, 1.0, 11) + f32(0.5), (0.05,) * 3, (0, 0, 0))):
+        exp = O.voxel_filter(data, len(data), 12, 0, leaf, chunk)
+        _stats()
+        got = _filter(data, len(data), 12, 0, leaf, chunk)
+        st = _stats()
+        assert st[0] + st[1] == 1, st     # attempted; whichever path answered, the bytes are the reference's
+        assert len(got) == len(exp) and np.array_equal(got, exp), (leaf, chunk, st)
+
+
+def test_crowded_clouds_fall_back_to_the_radix_path(monkeypatch):
+    """What the bucket path gives up on: a cell with more points than it orders by itself (300 copies of one point),
+    and a cloud whose points sit in two tight clusters of a large box (buckets far over the LDS tile).  Both are
+    found on the device, the radix path answers, the bytes are the oracle's."""
+    monkeypatch.setenv("PCGX_VOXEL_BUCKET_MIN_N", "1")
+    pts = synth.uniform_cloud(100_000, 1.6, 3)
+    crowded_cell = pts.copy()
+    crowded_cell[5000:5300] = crowded_cell[4999]
+    exp = O.voxel_filter(crowded_cell, len(pts), 12, 0, (0.05,) * 3, (0, 0, 0))
+    _stats()
+    got = _filter(crowded_cell, len(pts), 12, 0, (0.05,) * 3, (0, 0, 0))
+    st = _stats()
+    assert st[0] == 0 and st[1] == 1 and (st[2] & 2), st
+    assert np.array_equal(got, exp)
+    rng = np.random.default_rng(7)
+    a = (rng.random((150_000, 3)) * 0.05).astype(f32)
+    b = (rng.random((150_000, 3)) * 0.05).astype(f32) + f32(7.9)
+    clusters = np.ascontiguousarray(np.concatenate([a, b])[rng.permutation(300_000)])
+    exp = O.voxel_filter(clusters, len(clusters), 12, 0, (0.02,) * 3, (0, 0, 0))
+    _stats()
+    got = _filter(clusters, len(clusters), 12, 0, (0.02,) * 3, (0, 0, 0))
+    st = _stats()
+    assert st[0] == 0 and st[1] == 1 and (st[2] & 1), st
+    assert np.array_equal(got, exp)
+
+
+def test_c3_takes_the_bucket_path():
+    """BASELINE config C3 at full size goes the bucket path, plain and chunked (its bytes are compared with the
+    oracle's in test_gpu_voxel.py::test_c3_full_size_against_the_oracle)."""
+    c = synth.c3_voxel()
+    pts = c["points"]
+    for chunk in ((0, 0, 0), (64, 64, 64)):
+        _stats()
+        got = _filter(pts, len(pts), 12, 0, c["leaf"], chunk)
+        st = _stats()
+        assert st[0] == 1 and st[1] == 0, (chunk, st)
+        assert 3_000_000 < len(got) // 12 < 3_400_000
