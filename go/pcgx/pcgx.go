@@ -95,44 +95,128 @@ func xyzLayout(pp *pc.PointCloud) (stride, off int, err error) {
 // KDTree.Nearest, pc/storage/kdtree/kdtree.go:33-56,83-146).
 type KDTree struct {
 	pc.Vec3RandomAccessor
-	h *C.pcgx_kdtree
+	t *devTree // shared by the shallow copies With() makes (kdtree.go:58-65)
 	// MinDistSq > 0 selects the reference's approximate search (kdtree.go:20-22).
 	MinDistSq float32
 }
 
+// devTree owns the device handle; the copies of a KDTree share it, the last one garbage-collected (or the
+// first Close) releases it.
+type devTree struct {
+	h *C.pcgx_kdtree
+}
+
+// KDTreeOption mirrors kdtree.KDTreeOption (kdtree.go:31): New(ra, opts...) and (*KDTree).With(opts...)
+// apply them to the tree value exactly as the reference does.  The reference defines no option of its
+// own (its one knob is the exported field MinDistSq); WithMinDistSq is the option form of that field.
+type KDTreeOption func(*KDTree)
+
+// WithMinDistSq sets KDTree.MinDistSq (kdtree.go:20-22).
+func WithMinDistSq(d float32) KDTreeOption { return func(k *KDTree) { k.MinDistSq = d } }
+
 var _ storage.Search = (*KDTree)(nil)
 
-// New builds the tree from any Vec3RandomAccessor (packed copy, one upload).
-func New(ra pc.Vec3RandomAccessor) (*KDTree, error) {
+// cloudLayout says where a Vec3RandomAccessor's points already lie packed in memory, so that New can
+// hand the caller's bytes to pcgx_kdtree_build as they are (data, stride, xyz offset -- the record layout
+// of pc/pointcloud.go:64-78) instead of copying them out through n Vec3At interface calls: at 1M points
+// that loop costs more than the 2.5 ms device build.
+func cloudLayout(ra pc.Vec3RandomAccessor) (data unsafe.Pointer, stride, off int, keep interface{}, ok bool) {
+	switch v := ra.(type) {
+	case pc.Vec3Slice: // pc/vec3slice.go:8-20: []mat.Vec3, 12-byte records
+		if len(v) == 0 {
+			return nil, 12, 0, nil, true
+		}
+		return unsafe.Pointer(&v[0]), 12, 0, v, true
+	}
+	return nil, 0, 0, nil, false
+}
+
+// New builds the tree (kdtree.New, kdtree.go:33-56).  A pc.Vec3Slice is uploaded straight from its own
+// memory (NewFromPointCloud does the same for a cloud's records); any other Vec3RandomAccessor through one
+// packed copy.
+func New(ra pc.Vec3RandomAccessor, opts ...KDTreeOption) (*KDTree, error) {
 	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
 	defer runtime.UnlockOSThread()
 	n := ra.Len()
-	xyz := make([]float32, 3*n)
-	for i := 0; i < n; i++ {
-		v := ra.Vec3At(i)
-		copy(xyz[3*i:], v[:])
+	data, stride, off, keep, ok := cloudLayout(ra)
+	if !ok {
+		xyz := packVec3(ra)
+		stride, off, keep = 12, 0, xyz
+		if n > 0 {
+			data = unsafe.Pointer(&xyz[0])
+		}
 	}
-	var data unsafe.Pointer
-	if n > 0 {
-		data = unsafe.Pointer(&xyz[0])
-	}
-	k := &KDTree{Vec3RandomAccessor: ra}
-	if err := status(C.pcgx_kdtree_build(data, C.int64_t(n), 12, 0, &k.h)); err != nil {
+	t := &devTree{}
+	rc := C.pcgx_kdtree_build(data, C.int64_t(n), C.int32_t(stride), C.int32_t(off), &t.h)
+	runtime.KeepAlive(keep)
+	if err := status(rc); err != nil {
 		return nil, err
 	}
-	runtime.SetFinalizer(k, func(k *KDTree) { k.Close() })
+	runtime.SetFinalizer(t, func(t *devTree) { t.release() })
+	k := &KDTree{Vec3RandomAccessor: ra, t: t}
+	for _, o := range opts {
+		o(k)
+	}
 	return k, nil
 }
 
-// Close releases the device tree.
-func (k *KDTree) Close() {
-	runtime.LockOSThread() // the error text is thread-local on the C side: call and pcgx_last_error on one OS thread
+// NewFromPointCloud builds the tree over a cloud's points straight from its records (Data, stride and xyz
+// offset as PointCloud.Vec3Iterator finds them, pc/pointcloud.go:130-163): what kdtree.New(it) does for
+// it, _ := pp.Vec3Iterator(), without reading the cloud point by point.  The tree's accessor is that iterator.
+func NewFromPointCloud(pp *pc.PointCloud, opts ...KDTreeOption) (*KDTree, error) {
+	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
+	it, err := pp.Vec3Iterator()
+	if err != nil {
+		return nil, err
+	}
+	stride, off, err := xyzLayout(pp)
+	if err != nil {
+		return nil, err
+	}
+	var data unsafe.Pointer
+	if pp.Points > 0 {
+		data = unsafe.Pointer(&pp.Data[0])
+	}
+	t := &devTree{}
+	rc := C.pcgx_kdtree_build(data, C.int64_t(pp.Points), C.int32_t(stride), C.int32_t(off), &t.h)
+	runtime.KeepAlive(pp)
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	runtime.SetFinalizer(t, func(t *devTree) { t.release() })
+	k := &KDTree{Vec3RandomAccessor: it, t: t}
+	for _, o := range opts {
+		o(k)
+	}
+	return k, nil
+}
+
+// With creates a shallow copy of the tree with the options applied (kdtree.go:58-65); the copy shares
+// the device tree.
+func (k *KDTree) With(opts ...KDTreeOption) *KDTree {
+	k2 := *k
+	for _, o := range opts {
+		o(&k2)
+	}
+	return &k2
+}
+
+func (t *devTree) release() {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	runtime.SetFinalizer(t, nil)
+	if t.h != nil {
+		C.pcgx_kdtree_free(t.h)
+		t.h = nil
+	}
+}
+
+// Close releases the device tree now (for every copy made by With) instead of at garbage collection.
+func (k *KDTree) Close() {
 	defer runtime.KeepAlive(k) // the finalizer must not free the handle while a call is in flight
-	runtime.SetFinalizer(k, nil)
-	if k.h != nil {
-		C.pcgx_kdtree_free(k.h)
-		k.h = nil
+	if k.t != nil {
+		k.t.release()
 	}
 }
 
@@ -142,7 +226,7 @@ func (k *KDTree) DeletePoint(pID int) error {
 	defer runtime.UnlockOSThread()
 	defer runtime.KeepAlive(k) // the finalizer must not free the handle while a call is in flight
 	id := C.int64_t(pID)
-	rc := C.pcgx_kdtree_delete_points(k.h, &id, 1)
+	rc := C.pcgx_kdtree_delete_points(k.t.h, &id, 1)
 	if rc == C.PCGX_E_OUT_OF_RANGE {
 		return fmt.Errorf("%d does not correspond to any point in the tree", pID) // kdtree.go:324
 	}
@@ -161,7 +245,7 @@ func (k *KDTree) NearestBatch(q []mat.Vec3, maxRange float32) ([]storage.Neighbo
 	}
 	ids := make([]int64, n)
 	dsq := make([]float32, n)
-	rc := C.pcgx_kdtree_nearest_batch(k.h, (*C.float)(unsafe.Pointer(&q[0])), C.int64_t(n),
+	rc := C.pcgx_kdtree_nearest_batch(k.t.h, (*C.float)(unsafe.Pointer(&q[0])), C.int64_t(n),
 		C.float(maxRange), C.float(k.MinDistSq), (*C.int64_t)(unsafe.Pointer(&ids[0])), (*C.float)(unsafe.Pointer(&dsq[0])))
 	if err := status(rc); err != nil {
 		return nil, err
@@ -194,7 +278,7 @@ func (k *KDTree) RangeBatch(q []mat.Vec3, maxRange float32) ([][]storage.Neighbo
 	}
 	counts := make([]int64, n)
 	qp := (*C.float)(unsafe.Pointer(&q[0]))
-	if err := status(C.pcgx_kdtree_range_count(k.h, qp, C.int64_t(n), C.float(maxRange),
+	if err := status(C.pcgx_kdtree_range_count(k.t.h, qp, C.int64_t(n), C.float(maxRange),
 		(*C.int64_t)(unsafe.Pointer(&counts[0])))); err != nil {
 		return nil, err
 	}
@@ -205,7 +289,7 @@ func (k *KDTree) RangeBatch(q []mat.Vec3, maxRange float32) ([][]storage.Neighbo
 	total := offs[n]
 	ids := make([]int64, total+1)
 	dsq := make([]float32, total+1)
-	if err := status(C.pcgx_kdtree_range_fill(k.h, qp, C.int64_t(n), C.float(maxRange),
+	if err := status(C.pcgx_kdtree_range_fill(k.t.h, qp, C.int64_t(n), C.float(maxRange),
 		(*C.int64_t)(unsafe.Pointer(&offs[0])), (*C.int64_t)(unsafe.Pointer(&ids[0])),
 		(*C.float)(unsafe.Pointer(&dsq[0])))); err != nil {
 		return nil, err
@@ -405,7 +489,7 @@ func (e *Evaluator) Evaluate(base storage.Search, target pc.Vec3RandomAccessor) 
 	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(k.MinDistSq), C.int32_t(e.MinPairs)
 	p.weight_fn, p.weight_fn_param = C.int32_t(e.Weight.Kind), C.float(e.Weight.A)
 	p.sums_mode = C.int32_t(e.Sums)
-	rc := C.pcgx_icp_evaluate_params(k.h, tp, C.int64_t(target.Len()), &p, &ev)
+	rc := C.pcgx_icp_evaluate_params(k.t.h, tp, C.int64_t(target.Len()), &p, &ev)
 	runtime.KeepAlive(k)
 	if err := status(rc); err != nil {
 		return nil, err
@@ -415,6 +499,47 @@ func (e *Evaluator) Evaluate(base storage.Search, target pc.Vec3RandomAccessor) 
 		out.Gradient[i] = float32(ev.gradient[i])
 	}
 	return out, nil
+}
+
+// Corresponder implements icp.PointToPointCorresponder (correspondence.go:14-16) over pcgx_icp_pairs: one batched
+// nearest-neighbour pass for all targets, the pairs compacted in target order exactly as
+// NearestPointCorresponder.Pairs emits them (correspondence.go:22-37).  The reference's own
+// icp.PointToPointEvaluator{Corresponder: &pcgx.Corresponder{MaxDist: d}} then runs its CPU reduction (and any Go
+// WeightFn closure) over GPU correspondences.  A base that is not a *pcgx.KDTree is answered by the reference's
+// loop over base.Nearest.
+type Corresponder struct {
+	MaxDist float32
+}
+
+var _ icp.PointToPointCorresponder = (*Corresponder)(nil)
+
+func (c *Corresponder) Pairs(base storage.Search, target pc.Vec3RandomAccessor) []icp.PointToPointCorrespondence {
+	k, ok := base.(*KDTree)
+	if !ok {
+		return (&icp.NearestPointCorresponder{MaxDist: c.MaxDist}).Pairs(base, target)
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	defer runtime.KeepAlive(k)
+	n := target.Len()
+	if n == 0 {
+		return []icp.PointToPointCorrespondence{}
+	}
+	t := packVec3(target)
+	baseID := make([]int64, n)
+	targetID := make([]int64, n)
+	dsq := make([]float32, n)
+	var np C.int64_t
+	rc := C.pcgx_icp_pairs(k.t.h, (*C.float)(unsafe.Pointer(&t[0])), C.int64_t(n), C.float(c.MaxDist), C.float(k.MinDistSq),
+		(*C.int64_t)(unsafe.Pointer(&baseID[0])), (*C.int64_t)(unsafe.Pointer(&targetID[0])), (*C.float)(unsafe.Pointer(&dsq[0])), &np)
+	if err := status(rc); err != nil {
+		panic(err) // the interface has no error result; the reference's loop cannot fail either
+	}
+	out := make([]icp.PointToPointCorrespondence, int(np))
+	for i := range out {
+		out[i] = icp.PointToPointCorrespondence{BaseID: int(baseID[i]), TargetID: int(targetID[i]), SquaredDistance: dsq[i]}
+	}
+	return out
 }
 
 // Fit runs the whole PointToPointICPGradient.Fit loop on the device
@@ -440,7 +565,7 @@ func Fit(base *KDTree, target pc.Vec3RandomAccessor, e *Evaluator, u *icp.Gradie
 	}
 	var trans mat.Mat4
 	var st C.pcgx_icp_stat
-	rc := C.pcgx_icp_fit(base.h, tp, C.int64_t(target.Len()), &p, (*C.float)(unsafe.Pointer(&trans[0])), &st)
+	rc := C.pcgx_icp_fit(base.t.h, tp, C.int64_t(target.Len()), &p, (*C.float)(unsafe.Pointer(&trans[0])), &st)
 	stat := icp.Stat{NumIteration: int(st.num_iteration)}
 	stat.Value, stat.DistRMS = float32(st.evaluated.value), float32(st.evaluated.dist_rms)
 	for i := 0; i < 6; i++ {
@@ -489,7 +614,7 @@ func (e *PlaneEvaluator) Evaluate(base storage.Search, target pc.Vec3RandomAcces
 	var p C.pcgx_icp_params
 	p.max_dist, p.min_pairs = C.float(e.MaxDist), C.int32_t(e.MinPairs)
 	var s *C.pcgx_icp_session
-	rc := C.pcgx_icp_plane_session_create(k.h, (*C.float)(unsafe.Pointer(&e.BaseNormals[0])), tp,
+	rc := C.pcgx_icp_plane_session_create(k.t.h, (*C.float)(unsafe.Pointer(&e.BaseNormals[0])), tp,
 		C.int64_t(target.Len()), 0, &p, 0, nil, &s)
 	if err := status(rc); err != nil {
 		return nil, err
@@ -537,7 +662,7 @@ func FitPlane(base *KDTree, target pc.Vec3RandomAccessor, e *PlaneEvaluator, thr
 	if len(e.BaseNormals) != base.Len() || len(e.BaseNormals) == 0 {
 		return trans, stat, errors.New("pcgx: one normal per base point is required")
 	}
-	rc := C.pcgx_icp_plane_fit(base.h, (*C.float)(unsafe.Pointer(&e.BaseNormals[0])), tp, C.int64_t(target.Len()), &p,
+	rc := C.pcgx_icp_plane_fit(base.t.h, (*C.float)(unsafe.Pointer(&e.BaseNormals[0])), tp, C.int64_t(target.Len()), &p,
 		C.float(damping), (*C.float)(unsafe.Pointer(&trans[0])), &st, (*C.float)(unsafe.Pointer(&stat.Hessian[0])))
 	stat.NumIteration = int(st.num_iteration)
 	stat.Value = float32(st.evaluated.value)
@@ -656,7 +781,7 @@ func (r *RegionGrowing) Segment(p mat.Vec3, maxRange float32) []int {
 	}
 	ids := make([]int64, n)
 	var cnt C.int64_t
-	if C.pcgx_region_growing_segment_bfs(r.search.h, (*C.uint32_t)(unsafe.Pointer(&r.labels[0])),
+	if C.pcgx_region_growing_segment_bfs(r.search.t.h, (*C.uint32_t)(unsafe.Pointer(&r.labels[0])),
 		(*C.float)(unsafe.Pointer(&p[0])), C.float(maxRange), (*C.int64_t)(unsafe.Pointer(&ids[0])), C.int64_t(n),
 		&cnt) != C.PCGX_OK {
 		return []int{}
@@ -676,7 +801,7 @@ func (r *RegionGrowing) SegmentByID(p mat.Vec3, maxRange float32) []int {
 	}
 	if r.comp == nil || r.maxRange != maxRange {
 		comp := make([]int64, n)
-		if C.pcgx_region_growing_components(r.search.h, (*C.uint32_t)(unsafe.Pointer(&r.labels[0])), C.float(maxRange),
+		if C.pcgx_region_growing_components(r.search.t.h, (*C.uint32_t)(unsafe.Pointer(&r.labels[0])), C.float(maxRange),
 			(*C.int64_t)(unsafe.Pointer(&comp[0]))) != C.PCGX_OK {
 			return []int{}
 		}
@@ -684,7 +809,7 @@ func (r *RegionGrowing) SegmentByID(p mat.Vec3, maxRange float32) []int {
 	}
 	ids := make([]int64, n)
 	var cnt C.int64_t
-	if C.pcgx_region_growing_segment(r.search.h, (*C.uint32_t)(unsafe.Pointer(&r.labels[0])),
+	if C.pcgx_region_growing_segment(r.search.t.h, (*C.uint32_t)(unsafe.Pointer(&r.labels[0])),
 		(*C.int64_t)(unsafe.Pointer(&r.comp[0])), (*C.float)(unsafe.Pointer(&p[0])), C.float(maxRange),
 		(*C.int64_t)(unsafe.Pointer(&ids[0])), C.int64_t(n), &cnt) != C.PCGX_OK {
 		return []int{}
@@ -766,7 +891,7 @@ func FitSharded(base *KDTree, tile pc.Vec3RandomAccessor, e *Evaluator, u *icp.G
 	}
 	var trans mat.Mat4
 	var st C.pcgx_icp_stat
-	rc := C.pcgx_icp_fit_sharded(base.h, tp, C.int64_t(tile.Len()), &p, c.h, (*C.float)(unsafe.Pointer(&trans[0])), &st)
+	rc := C.pcgx_icp_fit_sharded(base.t.h, tp, C.int64_t(tile.Len()), &p, c.h, (*C.float)(unsafe.Pointer(&trans[0])), &st)
 	stat := icp.Stat{NumIteration: int(st.num_iteration)}
 	stat.Value, stat.DistRMS = float32(st.evaluated.value), float32(st.evaluated.dist_rms)
 	for i := 0; i < 6; i++ {

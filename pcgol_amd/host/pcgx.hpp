@@ -15,6 +15,9 @@
 //                              several-GPU paths: PointToPointICP::FitSharded, VoxelGrid::FilterSharded
 #pragma once
 #include <array>
+#include <functional>
+#include <initializer_list>
+#include <memory>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -76,22 +79,35 @@ class Comm {
   pcgx_comm *h_ = nullptr;
 };
 
+class KDTree;
+// kdtree.KDTreeOption (kdtree.go:31): New(ra, opts...) / (*KDTree).With(opts...) apply them to the tree value.
+using KDTreeOption = std::function<void(KDTree &)>;
+
 class KDTree {  // pc/storage/kdtree/kdtree.go:14-23
  public:
   float MinDistSq = 0.0f;
-  explicit KDTree(const CloudView &c) { check(pcgx_kdtree_build(c.data, c.points, c.stride, c.xyz_offset, &h_)); }
-  explicit KDTree(const std::vector<Vec3> &pts)
-      : KDTree(CloudView{pts.data(), (int64_t)pts.size(), 12, 0}) {}
-  ~KDTree() { pcgx_kdtree_free(h_); }
-  KDTree(const KDTree &) = delete;
-  KDTree &operator=(const KDTree &) = delete;
-  int64_t Len() const { int64_t n; check(pcgx_kdtree_len(h_, &n)); return n; }
-  Vec3 Vec3At(int64_t i) const { Vec3 v; check(pcgx_kdtree_points(h_, &i, 1, v.data())); return v; }
+  explicit KDTree(const CloudView &c, std::initializer_list<KDTreeOption> opts = {}) {
+    pcgx_kdtree *h = nullptr;
+    check(pcgx_kdtree_build(c.data, c.points, c.stride, c.xyz_offset, &h));
+    h_ = std::shared_ptr<pcgx_kdtree>(h, [](pcgx_kdtree *p) { pcgx_kdtree_free(p); });
+    for (const auto &o : opts) o(*this);
+  }
+  explicit KDTree(const std::vector<Vec3> &pts, std::initializer_list<KDTreeOption> opts = {})
+      : KDTree(CloudView{pts.data(), (int64_t)pts.size(), 12, 0}, opts) {}
+  // With (kdtree.go:58-65): a shallow copy with the options applied; the copies share the device tree.
+  KDTree With(std::initializer_list<KDTreeOption> opts) const {
+    KDTree k2(*this);
+    for (const auto &o : opts) o(k2);
+    return k2;
+  }
+  static KDTreeOption WithMinDistSq(float d) { return [d](KDTree &k) { k.MinDistSq = d; }; }
+  int64_t Len() const { int64_t n; check(pcgx_kdtree_len(h_.get(), &n)); return n; }
+  Vec3 Vec3At(int64_t i) const { Vec3 v; check(pcgx_kdtree_points(h_.get(), &i, 1, v.data())); return v; }
   Neighbor Nearest(const Vec3 &p, float maxRange) const { return NearestBatch({p}, maxRange)[0]; }
   std::vector<Neighbor> NearestBatch(const std::vector<Vec3> &q, float maxRange) const {
     std::vector<int64_t> ids(q.size());
     std::vector<float> d(q.size());
-    check(pcgx_kdtree_nearest_batch(h_, q.empty() ? nullptr : q[0].data(), (int64_t)q.size(), maxRange, MinDistSq,
+    check(pcgx_kdtree_nearest_batch(h_.get(), q.empty() ? nullptr : q[0].data(), (int64_t)q.size(), maxRange, MinDistSq,
                                     ids.data(), d.data()));
     std::vector<Neighbor> out(q.size());
     for (size_t i = 0; i < q.size(); i++) out[i] = Neighbor{ids[i], d[i]};
@@ -100,18 +116,18 @@ class KDTree {  // pc/storage/kdtree/kdtree.go:14-23
   // KDTree.Range (kdtree.go:148-197): neighbours with DistSq < maxRange^2, sorted by DistSq.
   std::vector<Neighbor> Range(const Vec3 &p, float maxRange) const {
     int64_t cnt = 0;
-    check(pcgx_kdtree_range_count(h_, p.data(), 1, maxRange, &cnt));
+    check(pcgx_kdtree_range_count(h_.get(), p.data(), 1, maxRange, &cnt));
     const int64_t offs[2] = {0, cnt};
     std::vector<int64_t> ids((size_t)cnt);
     std::vector<float> d((size_t)cnt);
-    check(pcgx_kdtree_range_fill(h_, p.data(), 1, maxRange, offs, ids.data(), d.data()));
+    check(pcgx_kdtree_range_fill(h_.get(), p.data(), 1, maxRange, offs, ids.data(), d.data()));
     std::vector<Neighbor> out((size_t)cnt);
     for (int64_t i = 0; i < cnt; i++) out[(size_t)i] = Neighbor{ids[(size_t)i], d[(size_t)i]};
     return out;
   }
   // KDTree.DeletePoint (kdtree.go:322-332); std::out_of_range for an id outside [0, Len()).
   void DeletePoint(int64_t pID) {
-    pcgx_status rc = pcgx_kdtree_delete_points(h_, &pID, 1);
+    pcgx_status rc = pcgx_kdtree_delete_points(h_.get(), &pID, 1);
     if (rc == PCGX_E_OUT_OF_RANGE) {
       char buf[256];
       pcgx_last_error(buf, sizeof buf);
@@ -119,11 +135,12 @@ class KDTree {  // pc/storage/kdtree/kdtree.go:14-23
     }
     check(rc);
   }
-  int32_t MaxDepth() const { int32_t d; check(pcgx_kdtree_max_depth(h_, &d)); return d; }
-  const pcgx_kdtree *handle() const { return h_; }
+  int32_t MaxDepth() const { int32_t d; check(pcgx_kdtree_max_depth(h_.get(), &d)); return d; }
+  const pcgx_kdtree *handle() const { return h_.get(); }
 
  private:
-  pcgx_kdtree *h_ = nullptr;
+  KDTree(const KDTree &) = default;
+  std::shared_ptr<pcgx_kdtree> h_;
 };
 
 class VoxelGrid {  // pc/filter/voxelgrid/voxelgrid.go:23-33 + option.go:14-18
@@ -220,6 +237,27 @@ class RegionGrowing {
   std::vector<uint32_t> labels_;
   std::vector<int64_t> comp_;
   float range_ = 0.0f;
+};
+
+// icp.PointToPointCorrespondence / NearestPointCorresponder (correspondence.go:8-37): Pairs over pcgx_icp_pairs --
+// one batched nearest-neighbour pass, the matched targets compacted in target order.
+struct PointToPointCorrespondence {
+  int64_t BaseID, TargetID;
+  float SquaredDistance;
+};
+struct NearestPointCorresponder {
+  float MaxDist = 0.0f;
+  std::vector<PointToPointCorrespondence> Pairs(const KDTree &base, const std::vector<Vec3> &target) const {
+    const size_t n = target.size();
+    std::vector<int64_t> b(n), t(n);
+    std::vector<float> d(n);
+    int64_t np = 0;
+    check(pcgx_icp_pairs(base.handle(), n ? target[0].data() : nullptr, (int64_t)n, MaxDist, base.MinDistSq, b.data(), t.data(),
+                         d.data(), &np));
+    std::vector<PointToPointCorrespondence> out((size_t)np);
+    for (size_t i = 0; i < out.size(); i++) out[i] = PointToPointCorrespondence{b[i], t[i], d[i]};
+    return out;
+  }
 };
 
 struct Stat {  // icp/stat.go:3-6

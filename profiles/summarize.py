@@ -17,14 +17,19 @@ GATHER_KERNELS = ("icp_grid_kernel", "grid_nearest_kernel", "seg_reduce_kernel",
                   "nearest_kernel", "range_kernel")
 # coalesced bytes the gather kernels read per launch at the bench's sizes (1M targets / queries, 10M voxel points)
 STREAMED = {"icp_grid_kernel<false": (12 + 16 * 19 / 20) * 1e6,          # target xyz + previous pair (19 of 20 iterations)
-            "icp_corr_kernel<false, false, true, false>": 28e6,           # strict sessions: the tile sums stream the caller-order pairs + targets
             "icp_grid_kernel<true": (12 + 16 * 19 / 20 + 4) * 1e6,       # + matched id
             "grid_nearest_kernel": (12 + 4) * 1e6,                        # query + its position in the batch
             "seg_reduce_kernel": 8 * 10e6}                                # sorted key + sorted index
-# one VoxelGrid C3 call (plain mode, 22-bit key: three radix passes) in kernel launches
-VOXEL_CALL = {"minmax_partial_packed_kernel": 1, "minmax_final_kernel": 1, "voxel_key_kernel": 1,
-              "rs_hist_kernel<16>": 3, "rs_scan_rows_kernel": 3, "rs_scatter_kernel<16>": 3,
-              "seg_count_kernel": 1, "seg_scan_kernel": 1, "seg_reduce_kernel": 1}
+# One VoxelGrid C3 call in kernel launches: the bucket path (csrc/voxel_bucket.hip).  bench.py runs the plain and the
+# chunked filter as often as each other; every kernel below is launched once per call of either (scan_rows twice),
+# and by nothing else in the bench, so a call's bytes = the kernels' totals over all their dispatches / the number of
+# calls (= dispatches of the bucket kernel).  A kernel that is listed here and absent from the counters means the
+# pipeline has changed under this list: the summary then FAILS instead of leaving the row out (round 3's BENCH line
+# carried `"traffic": null` for the filter because of exactly that).
+VOXEL_KERNELS = ("minmax_partial_packed_kernel", "minmax_final_kernel", "vb_key_hist_kernel", "vb_sample_check_kernel",
+                 "vb_scan_rows_kernel", "vb_scatter_kernel<true, false>", "vb_hist2_kernel", "vb_scatter_kernel<false, false>",
+                 "vb_bounds_kernel", "vb_bucket_kernel<false>")
+VOXEL_CALLS_BY = "vb_bucket_kernel<false>"
 
 
 def short(name):
@@ -115,18 +120,22 @@ def main():
         for name, b in STREAMED.items():
             if gather and k.startswith(name):
                 summary[k]["fetch_add_bytes"] = b / 2
-    vox = {"FETCH_SIZE": {"mean_per_dispatch": 0.0, "dispatches": 1}, "WRITE_SIZE": {"mean_per_dispatch": 0.0, "dispatches": 1},
-           "fetch_scale": 1.0, "fetch_add_bytes": 0.0, "kernels": VOXEL_CALL}
-    ok = True
-    for k, times in VOXEL_CALL.items():
-        if k not in summary or "FETCH_SIZE" not in summary[k] or "WRITE_SIZE" not in summary[k]:
-            ok = False
-            continue
-        vox["FETCH_SIZE"]["mean_per_dispatch"] += times * (summary[k]["FETCH_SIZE"]["mean_per_dispatch"] * summary[k]["fetch_scale"] +
-                                                            summary[k]["fetch_add_bytes"] / 1024.0)
-        vox["WRITE_SIZE"]["mean_per_dispatch"] += times * summary[k]["WRITE_SIZE"]["mean_per_dispatch"]
-    if ok:
-        summary["voxel_pipeline (one C3 call, sum over its kernels, fetch already scaled)"] = vox
+    if any(k.startswith("vb_") or k.startswith("seg_reduce") for k in summary):  # (a run with the extras)
+        missing = [k for k in VOXEL_KERNELS if k not in summary or "FETCH_SIZE" not in summary[k] or "WRITE_SIZE" not in summary[k]]
+        if missing:
+            raise SystemExit("profiles/summarize.py: the VoxelGrid call no longer launches %s -- VOXEL_KERNELS is stale, "
+                             "bench.py's voxel traffic row would silently disappear" % ", ".join(missing))
+        calls = summary[VOXEL_CALLS_BY]["FETCH_SIZE"]["dispatches"]
+        vox = {"FETCH_SIZE": {"mean_per_dispatch": 0.0, "dispatches": calls}, "WRITE_SIZE": {"mean_per_dispatch": 0.0, "dispatches": calls},
+               "fetch_scale": 1.0, "fetch_add_bytes": 0.0, "kernels": {}}
+        for k in VOXEL_KERNELS:
+            f, w = summary[k]["FETCH_SIZE"], summary[k]["WRITE_SIZE"]
+            fetch = (f["mean_per_dispatch"] * summary[k]["fetch_scale"] + summary[k]["fetch_add_bytes"] / 1024.0) * f["dispatches"] / calls
+            write = w["mean_per_dispatch"] * w["dispatches"] / calls
+            vox["FETCH_SIZE"]["mean_per_dispatch"] += fetch
+            vox["WRITE_SIZE"]["mean_per_dispatch"] += write
+            vox["kernels"][k] = {"launches_per_call": f["dispatches"] / calls, "fetch_KiB_per_call": fetch, "write_KiB_per_call": write}
+        summary["voxel_pipeline (one C3 call -- plain and chunked averaged --, sum over its kernels, fetch already scaled)"] = vox
     # the build the counters were collected on (bench.py compares it with the build it times)
     sys.path.insert(0, os.path.dirname(here))
     from pcgol_amd import build

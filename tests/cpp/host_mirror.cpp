@@ -125,6 +125,18 @@ int main(int argc, char **argv) {
           const pcgx::CloudView cv{base.data(), (int64_t)base.size(), 12, 0};
           std::printf("sharded1_voxel same %d world %d\n", (int)(vg.FilterSharded(cv, comm) == vg.Filter(cv)), comm.World());
         }
+        {  // the Go seams: KDTreeOption / With (kdtree.go:31-65) and a corresponder over pcgx_icp_pairs (correspondence.go:14-37)
+          const pcgx::KDTree approx = tree->With({pcgx::KDTree::WithMinDistSq(0.25f)});
+          std::printf("with mindist %.9g shared %d len %" PRId64 "\n", approx.MinDistSq, (int)(approx.handle() == tree->handle()),
+                      approx.Len());
+          pcgx::NearestPointCorresponder cor;
+          cor.MaxDist = maxd;
+          const auto pairs = cor.Pairs(*tree, target);
+          std::printf("pairs %zu", pairs.size());
+          for (size_t i = 0; i < pairs.size() && i < 8; i++)
+            std::printf(" %" PRId64 ":%" PRId64 ":%.9g", pairs[i].BaseID, pairs[i].TargetID, pairs[i].SquaredDistance);
+          std::printf("\n");
+        }
         try {
           reg.MinPairs = (int)base.size() + 1;
           reg.Fit(*tree, target);

@@ -129,3 +129,13 @@ def test_cpp_host_mirror_known_answers(tmp_path, golden):
     assert int(strict[2]) == st_s.NumIteration
     assert np.array_equal(np.array([float(v) for v in strict[6:22]], np.float32), tr_s)
     assert "sharded1_icp same 1" in out and "sharded1_voxel same 1 world 1" in out
+    # the Go seams through the C++ mirror: With() shares the device tree and carries the option; the corresponder's
+    # pairs are the oracle's (correspondence.go:22-37), in target order
+    wl = [l for l in out if l.startswith("with ")][0].split()
+    assert float(wl[2]) == 0.25 and wl[4] == "1" and int(wl[6]) == len(base)
+    pl = [l for l in out if l.startswith("pairs ")][0].split()
+    ob, ot, od = O.icp_pairs(O.KDTree(base), target, 2.0)
+    assert int(pl[1]) == len(ob)
+    for k, tok in enumerate(pl[2:]):
+        b, t, d = tok.split(":")
+        assert int(b) == ob[k] and int(t) == ot[k] and np.float32(float(d)) == od[k]
