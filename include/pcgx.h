@@ -63,6 +63,16 @@ enum {
  * creates the library stream.  Idempotent. */
 PCGX_API pcgx_status pcgx_init(int32_t device);
 PCGX_API pcgx_status pcgx_shutdown(void);
+/* One process, several GPUs (threading row: "one process drives all 8 GPUs" -- the reference is one
+ * process, icp.go:23).  The library keeps one set of streams, workspaces and call contexts per DEVICE SLOT; slot k
+ * works on HIP device device_ids[k] (NULL: device k; the same device may be named several times, which is how the
+ * several-GPU paths run on a one-GPU test box).  A host thread names the slot its calls are for with
+ * pcgx_set_device (default 0, per thread, like HIP's current device); a handle (tree, session, communicator)
+ * belongs to the slot it was made on and is used from threads that have that slot current.
+ * pcgx_icp_fit_multi below needs nothing else from the caller: it starts a thread per slot itself. */
+PCGX_API pcgx_status pcgx_init_devices(int32_t n, const int32_t *device_ids);
+PCGX_API pcgx_status pcgx_set_device(int32_t slot);
+PCGX_API pcgx_status pcgx_get_device(int32_t *slot, int32_t *hip_device);
 /* Copies the last error message of the calling thread; returns its length. */
 PCGX_API int32_t pcgx_last_error(char *buf, size_t cap);
 PCGX_API const char *pcgx_version(void);
@@ -304,9 +314,9 @@ typedef struct {
  * formed the same way meets "within 1e-5 of the Go code" at every size.
  *  PCGX_SUMS_REFERENCE  (0, default) the reference's sequential float32 additions, evaluated exactly by
  *                       the whole GPU (csrc/strict_sum.h) -- pcgx_icp_fit / _evaluate / sessions on one
- *                       GPU.  A sharded session (pcgx_icp_session_step_sharded, pcgx_icp_fit_sharded
- *                       with world > 1) and the point-to-plane extension have no sequential order /
- *                       no reference sums to reproduce: they form float64 sums whatever this says.
+ *                       GPU, and sharded sessions (pcgx_icp_session_step_sharded, pcgx_icp_fit_sharded,
+ *                       pcgx_icp_fit_multi: the order is the ranks' tiles one after the other).  The
+ *                       point-to-plane extension has no reference sums to reproduce: float64 sums.
  *  PCGX_SUMS_F64_TREE   fixed-order float64 reduction of the same float32 terms: more accurate than the
  *                       reference, equal to it up to ITS rounding noise; what a sharded sum computes.
  *  PCGX_SUMS_REFERENCE_CHAIN  the reference's additions by ONE wave, term after term (milliseconds per
@@ -412,10 +422,23 @@ PCGX_API pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream);
  * never shards needs none.  pcgx_comm_init_callback is the same exchange through a host function
  * that sums `count` float64 in place over the ranks (the sums then make a round trip through host
  * memory): for hosts with a transport of their own, and for tests that run several ranks on one GPU.
- * pcgx_icp_session_step_sharded = partials -> all-reduce (sum) of the session's 10 (plane: 30)
- * float64 sums -> update on every rank; pcgx_icp_fit_sharded is the whole Fit (icp.go:23-67) on this
- * rank's tile: every rank returns the same transform.  Strict sums are not offered here: a sum
- * spread over ranks has no sequential order to reproduce. */
+ * pcgx_icp_session_step_sharded is one iteration on every rank, pcgx_icp_fit_sharded the whole Fit (icp.go:23-67) on
+ * this rank's tile: every rank returns the same transform.  The sums (pcgx_icp_params.sums_mode):
+ *  PCGX_SUMS_REFERENCE (default)  the reference's sequential float32 additions (evaluator.go:122-145) over the ranks'
+ *      tiles ONE AFTER THE OTHER, rank 0's first: the sharded Fit returns what the reference's Fit returns on that
+ *      concatenated target, bit for bit.  Correspondence, summaries and jobs run on all ranks at once; the ranks before
+ *      a rank hand it two float64 totals per sum (all-gathers of 9 doubles) and the states their walk ended in (the
+ *      walk is one dependent chain: it goes round the ranks) -- 2 + world collectives of <= 16 x world doubles per
+ *      iteration.
+ *  PCGX_SUMS_F64_TREE  partials -> ONE all-reduce of the 10 (plane: 30) float64 sums -> update: faster, and off the
+ *      reference by the reference's own rounding noise (1.6e-5 on the transform at 1M pairs).
+ * Every collective also carries the ranks' error flag: a rank whose step fails keeps calling the collectives with its
+ * flag up, and all ranks end the Fit in that same iteration (PCGX_E_RCCL on the others) -- none is left inside an
+ * all-reduce.  Callers that drive the exchange themselves (pcgx_icp_session_partials -> their own all-reduce ->
+ * pcgx_icp_session_update) MUST create the session with PCGX_SUMS_F64_TREE: sums of float32 chains cannot be added
+ * across ranks.
+ * One process, several GPUs: pcgx_icp_fit_multi (a host thread per device slot, pcgx_init_devices; the exchange runs
+ * in host memory, sums in rank order) -- the Go shim's FitMulti needs no second process. */
 typedef struct pcgx_comm pcgx_comm;
 typedef struct { char internal[128]; } pcgx_comm_id;   /* == ncclUniqueId */
 typedef int32_t (*pcgx_allreduce_fn)(double *host_buf, int32_t count, void *user);
@@ -430,6 +453,12 @@ PCGX_API pcgx_status pcgx_icp_session_step_sharded(pcgx_icp_session *s, pcgx_com
 PCGX_API pcgx_status pcgx_icp_fit_sharded(const pcgx_kdtree *base, const float *tile, int64_t nt,
                                           const pcgx_icp_params *params, pcgx_comm *c, float trans16[16],
                                           pcgx_icp_stat *stat);
+/* bases[r]: the tree replica built with slot r current; tiles[r] / nt[r]: slot r's part of the target (host memory). */
+PCGX_API pcgx_status pcgx_icp_fit_multi(int32_t n, const pcgx_kdtree *const *bases, const float *const *tiles,
+                                        const int64_t *nt, const pcgx_icp_params *params, float trans16[16],
+                                        pcgx_icp_stat *stat);
+/* all-reduce of a few doubles in host memory through `c` (set-up exchanges of the sharded paths) */
+PCGX_API pcgx_status pcgx_comm_allreduce_host_f64(pcgx_comm *c, double *h_buf, int32_t count);
 /* The voxel filter over several GPUs (second half).  Every rank holds the same cloud
  * in device memory.  Each runs the min/max pass (pc/minmax.go:9-26) over its n / world slice; the six
  * floats are exchanged through `c` (one all-reduce of 7 x world float64) and folded in rank order with

@@ -182,6 +182,11 @@ SIGNATURES = {
     "pcgx_comm_free": (_i32, [_vp]),
     "pcgx_comm_rank": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "pcgx_comm_allreduce_f64": (_i32, [_vp, _vp, _i32, _vp]),
+    "pcgx_comm_allreduce_host_f64": (_i32, [_vp, _vp, _i32]),
+    "pcgx_icp_fit_multi": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcgx_init_devices": (_i32, [_i32, _vp]),
+    "pcgx_set_device": (_i32, [_i32]),
+    "pcgx_get_device": (_i32, [_vp, _vp]),
     "pcgx_icp_session_step_sharded": (_i32, [_vp, _vp, _vp]),
     "pcgx_icp_fit_sharded": (_i32, [_vp, _vp, _i64, C.POINTER(IcpParams), _vp, _vp, C.POINTER(IcpStat)]),
     "pcgx_debug_icp_strict_stats": (_i32, [_vp, _vp, _vp]),

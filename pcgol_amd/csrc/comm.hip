@@ -141,6 +141,29 @@ extern "C" pcgx_status pcgx_comm_rank(const pcgx_comm *c, int32_t *rank, int32_t
   return PCGX_OK;
 }
 
+// the same for a few doubles in HOST memory (a rank that could not get device memory still has to answer the others)
+extern "C" pcgx_status pcgx_comm_allreduce_host_f64(pcgx_comm *c, double *h_buf, int32_t count) {
+  if (!c || !h_buf || count < 1) return fail(PCGX_E_INVALID, "pcgx_comm_allreduce_host_f64: bad argument");
+  if (c->world == 1 && !comm_force_collective()) return PCGX_OK;
+  if (!c->nccl) {
+    const int32_t rc = c->fn(h_buf, count, c->user);
+    if (rc != 0) return fail(PCGX_E_RCCL, "the host's all-reduce callback failed (%d)", rc);
+    return PCGX_OK;
+  }
+  PCGX_TRY(ensure_init());
+  double *d = nullptr;
+  PCGX_HIP_TRY(hipMalloc((void **)&d, (size_t)count * sizeof(double)));
+  hipStream_t st = ctx().stream;
+  pcgx_status rc = PCGX_OK;
+  if (hipMemcpyAsync(d, h_buf, (size_t)count * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) rc = PCGX_E_HIP;
+  if (rc == PCGX_OK) rc = pcgx_comm_allreduce_f64(c, d, count, st);
+  if (rc == PCGX_OK && (hipMemcpyAsync(h_buf, d, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess))
+    rc = PCGX_E_HIP;
+  (void)hipFree(d);
+  return rc;
+}
+
 // sum over the ranks of `count` float64 in device memory, in place, in stream order
 extern "C" pcgx_status pcgx_comm_allreduce_f64(pcgx_comm *c, double *d_buf, int32_t count, void *stream) {
   if (!c || !d_buf || count < 1) return fail(PCGX_E_INVALID, "pcgx_comm_allreduce_f64: bad argument");

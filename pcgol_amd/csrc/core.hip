@@ -13,6 +13,8 @@ namespace pcgx {
 
 static thread_local std::string g_last_error;
 
+const char *last_error_text() { return g_last_error.c_str(); }
+
 pcgx_status fail(pcgx_status code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
@@ -27,6 +29,7 @@ namespace {
 struct CachedBlock {
   void *p;
   size_t cap;
+  int device;  // the HIP device the block lives on (one process may drive several: pcgx_init_devices)
 };
 std::vector<CachedBlock> &cache_free_list() {
   static std::vector<CachedBlock> v;
@@ -49,10 +52,14 @@ void dev_cache_quiesce() { (void)hipDeviceSynchronize(); }
 hipError_t dev_cache_alloc(void **ptr, size_t bytes) {
   std::lock_guard<std::mutex> lk(g_cache_mu);
   bytes = bytes ? bytes : 1;
+  int device = 0;
+  (void)hipGetDevice(&device);
   auto &fl = cache_free_list();
   size_t best = fl.size();
   for (size_t i = 0; i < fl.size(); i++)
-    if (fl[i].cap >= bytes && fl[i].cap <= 2 * bytes + 4096 && (best == fl.size() || fl[i].cap < fl[best].cap)) best = i;
+    if (fl[i].device == device && fl[i].cap >= bytes && fl[i].cap <= 2 * bytes + 4096 &&
+        (best == fl.size() || fl[i].cap < fl[best].cap))
+      best = i;
   if (best != fl.size()) {
     *ptr = fl[best].p;
     cache_live_list().push_back(fl[best]);
@@ -65,7 +72,7 @@ hipError_t dev_cache_alloc(void **ptr, size_t bytes) {
     cache_release_all_locked();
     e = hipMalloc(ptr, cap);
   }
-  if (e == hipSuccess) cache_live_list().push_back(CachedBlock{*ptr, cap});
+  if (e == hipSuccess) cache_live_list().push_back(CachedBlock{*ptr, cap, device});
   return e;
 }
 
@@ -104,13 +111,21 @@ struct Global {
   int in_pool = 0, peak_in_pool = 0;
   long long pooled_calls = 0;
 };
-Global &glob() {
-  static Global g;
-  return g;
-}
+// One Global per DEVICE SLOT.  Slot 0 is what a process that drives one GPU uses and never thinks about
+// (pcgx_init).  A process that drives several (pcgx_init_devices) gives every slot its HIP device -- for tests, the
+// same device several times -- and every host thread says which slot its calls are for (pcgx_set_device, as with
+// HIP's own current device); handles live on the slot they were made on.
+constexpr int kMaxSlots = 16;
+Global g_slots[kMaxSlots];
+int g_slot_device[kMaxSlots] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1: pcgx_init's choice
+int g_num_slots = 1;
+thread_local int tl_slot = 0;
+Global &glob() { return g_slots[tl_slot]; }
 thread_local Context *tl_ctx = nullptr;
 thread_local int tl_depth = 0;
 }  // namespace
+
+int current_slot() { return tl_slot; }
 
 Context &ctx() { return tl_ctx ? *tl_ctx : glob().slots[0]; }
 
@@ -166,7 +181,7 @@ static pcgx_status init_device(int device) {
   if (e != hipSuccess || count == 0)
     return fail(PCGX_E_HIP, "no HIP device available (%s): libpcgx has no CPU fallback",
                 e != hipSuccess ? hipGetErrorString(e) : "device count 0");
-  if (device < 0) device = 0;
+  if (device < 0) device = g_slot_device[tl_slot] >= 0 ? g_slot_device[tl_slot] : 0;  // (pcgx_init_devices' choice for this slot)
   if (device >= count) return fail(PCGX_E_INVALID, "device %d out of range (%d devices)", device, count);
   PCGX_HIP_TRY(hipSetDevice(device));
   hipDeviceProp_t prop;
@@ -302,11 +317,59 @@ using namespace pcgx;
 
 extern "C" pcgx_status pcgx_init(int32_t device) { return init_device(device); }
 
-extern "C" pcgx_status pcgx_shutdown(void) {
+// One process, several GPUs: slot k of the library works on HIP device device_ids[k] (NULL: device k).  The same
+// device may be named more than once (several independent sets of streams and workspaces on one GPU: how the
+// several-GPU paths are tested on a one-GPU box).  Call before any other entry point, or with the assignment already
+// in force.
+extern "C" pcgx_status pcgx_init_devices(int32_t n, const int32_t *device_ids) {
+  if (n < 1 || n > kMaxSlots) return fail(PCGX_E_INVALID, "pcgx_init_devices: 1 .. %d device slots", kMaxSlots);
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0)
+    return fail(PCGX_E_HIP, "no HIP device available (%s): libpcgx has no CPU fallback",
+                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+  for (int k = 0; k < n; k++) {
+    const int d = device_ids ? device_ids[k] : k;
+    if (d < 0 || d >= count) return fail(PCGX_E_INVALID, "pcgx_init_devices: device %d out of range (%d devices)", d, count);
+    if (g_slots[k].slots[0].ready && g_slots[k].slots[0].device != d)
+      return fail(PCGX_E_INVALID, "pcgx_init_devices: slot %d already works on device %d", k, g_slots[k].slots[0].device);
+  }
+  const int keep = tl_slot;
+  pcgx_status rc = PCGX_OK;
+  for (int k = 0; k < n && rc == PCGX_OK; k++) {
+    g_slot_device[k] = device_ids ? device_ids[k] : k;
+    tl_slot = k;
+    rc = init_device(g_slot_device[k]);
+  }
+  tl_slot = keep;
+  if (rc == PCGX_OK && n > g_num_slots) g_num_slots = n;
+  if (g_slots[tl_slot].slots[0].ready) (void)hipSetDevice(g_slots[tl_slot].slots[0].device);
+  return rc;
+}
+
+// The calling thread's device slot for the calls that follow (default 0), as hipSetDevice is for HIP.
+extern "C" pcgx_status pcgx_set_device(int32_t slot) {
+  if (slot < 0 || slot >= kMaxSlots) return fail(PCGX_E_INVALID, "pcgx_set_device: slot %d out of range", slot);
+  if (tl_depth > 0) return fail(PCGX_E_INVALID, "pcgx_set_device: inside a library call");
+  if (slot >= g_num_slots && !g_slots[slot].slots[0].ready)
+    return fail(PCGX_E_INVALID, "pcgx_set_device: slot %d was not set up (pcgx_init_devices)", slot);
+  tl_slot = slot;
+  if (g_slots[slot].slots[0].ready) (void)hipSetDevice(g_slots[slot].slots[0].device);
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_get_device(int32_t *slot, int32_t *hip_device) {
+  if (slot) *slot = tl_slot;
+  if (hip_device) *hip_device = g_slots[tl_slot].slots[0].ready ? g_slots[tl_slot].slots[0].device : -1;
+  return PCGX_OK;
+}
+
+static void shutdown_slot() {
   PCGX_API_LOCK();
   Global &g = glob();
   std::lock_guard<std::mutex> lk(g.init_mu);
-  if (!g.slots[0].ready) return PCGX_OK;
+  if (!g.slots[0].ready) return;
+  (void)hipSetDevice(g.slots[0].device);
   (void)hipDeviceSynchronize();
   for (int k = 0; k <= kPoolSlots; k++) {
     Context &c = g.slots[k];
@@ -319,6 +382,18 @@ extern "C" pcgx_status pcgx_shutdown(void) {
     c.ready = false;
     c.device = -1;
   }
+}
+
+extern "C" pcgx_status pcgx_shutdown(void) {
+  if (tl_depth > 0) return fail(PCGX_E_INVALID, "pcgx_shutdown: inside a library call");
+  const int keep = tl_slot;
+  for (int k = 0; k < kMaxSlots; k++) {
+    tl_slot = k;
+    shutdown_slot();
+    g_slot_device[k] = -1;
+  }
+  tl_slot = keep;
+  g_num_slots = 1;
   dev_cache_release_all();
   return PCGX_OK;
 }

@@ -11,6 +11,13 @@
 // The reference has no such evaluator (only the Hessian slot): no reference parity.
 #include <string.h>
 
+#include <array>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+
 #include <vector>
 
 #include "knn_grid.h"
@@ -517,6 +524,25 @@ __global__ void icp_update_kernel(IcpState *__restrict__ state, const double *__
   else icp_update_step(state, sums, kp);
 }
 
+// The update behind a sharded step's all-reduce: xchg = the summed sums + the ranks' error flag behind them.  A flag
+// that is up ends the Fit on every rank in this same iteration (state->status PCGX_E_RCCL); the sums also go to the
+// session's own buffer (pcgx_icp_session_read_sums).
+template <bool kPlane>
+__global__ void icp_update_sharded_kernel(IcpState *__restrict__ state, const double *__restrict__ xchg, int n,
+                                          double *__restrict__ sums_out, IcpKernelParams kp) {
+  if (blockIdx.x != 0) return;
+  if (state->done) return;
+  if ((int)threadIdx.x < n && sums_out != xchg) sums_out[threadIdx.x] = xchg[threadIdx.x];
+  if (threadIdx.x != 0) return;
+  if (xchg[n] != 0.0) {
+    state->status = PCGX_E_RCCL;
+    state->done = 1;
+    return;
+  }
+  if (kPlane) icp_plane_update_step(state, xchg, kp);
+  else icp_update_step(state, xchg, kp);
+}
+
 // normals (packed xyz, base id order) -> float4 per base point
 __global__ __launch_bounds__(256) void pack_normals_kernel(const float *__restrict__ n3, int64_t n,
                                                            float4 *__restrict__ out) {
@@ -684,6 +710,9 @@ struct pcgx_icp_session {
   uint32_t *d_walk_count = nullptr;  // [grid] entries in each segment (zero between iterations)
   double *d_sums = nullptr;  // caller's buffer, or own
   bool own_sums = false;
+  double *d_xchg = nullptr;  // sharded float64 steps: the sums + the ranks' error flag, what the all-reduce carries
+  int32_t steps_sharded = 0; // sharded steps enqueued (fault injection of the tests counts them)
+  bool shard_failed = false; // this rank could not go on: it keeps calling the collectives with its flag up
   bool plane = false;              // point-to-plane / Gauss-Newton session (30 sums)
   uint32_t *d_match_id = nullptr;  // plane: [nt] matched base id
   float4 *d_normals = nullptr;     // plane: [base n] unit normals in base id order
@@ -811,6 +840,7 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   dev_cache_free(s->d_match_id);
   dev_cache_free(s->d_normals);
   if (s->own_sums) dev_cache_free(s->d_sums);
+  dev_cache_free(s->d_xchg);
   delete s;
   return PCGX_OK;
 }
@@ -1173,6 +1203,77 @@ extern "C" pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream) 
   return PCGX_OK;
 }
 
+// One iteration of a Fit whose target is spread over the ranks of `c`.  Two numeric modes:
+//  * the reference's sums (the default, sums_mode 0 / set_strict 1): its sequential float32 additions over the ranks'
+//    tiles one after the other, rank 0's first (strict.hip, strict_enqueue_sharded): the Fit of the concatenated
+//    target bit for bit, 2 + world small collectives per iteration;
+//  * float64 sums (PCGX_SUMS_F64_TREE): one all-reduce of the 10 (plane: 30) sums.
+// Either way every collective carries the ranks' error flag, and a rank that cannot go on (*local_rc) keeps calling
+// them with its flag up: all ranks end the Fit in the same iteration, nobody waits for a peer that has left.
+// Returns the COMMUNICATOR's status (a failed collective is the one thing that may not be survived).
+static pcgx_status step_sharded_impl(pcgx_icp_session *s, pcgx_comm *c, void *stream, pcgx_status *local_rc) {
+  int32_t rank = 0, world = 1;
+  PCGX_TRY(pcgx_comm_rank(c, &rank, &world));
+  hipStream_t st = pick_stream(stream);
+  const int step = s->steps_sharded++;
+  if (const char *e = getenv("PCGX_TEST_FAIL_RANK")) {  // fault injection (tests/test_gpu_multi.py)
+    const char *it = getenv("PCGX_TEST_FAIL_ITER");
+    if (atoi(e) == rank && it && atoi(it) == step && !s->shard_failed) {
+      *local_rc = fail(PCGX_E_HIP, "injected failure of rank %d in iteration %d (PCGX_TEST_FAIL_RANK)", rank, step);
+      s->shard_failed = true;
+    }
+  }
+  const bool reference = s->strict == 1 && !s->plane;
+  if (reference) {
+    if (!s->shard_failed) {
+      const pcgx_status rc = enqueue_corr(s, st);
+      if (rc != PCGX_OK) {
+        *local_rc = rc;
+        s->shard_failed = true;
+      }
+    }
+    if (!s->strict_buf) {
+      const pcgx_status rc = strict_create(s->nt, s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, (const uint32_t *)s->d_pos_of,
+                                           &s->strict_buf, st);
+      if (rc != PCGX_OK) return rc;  // (no buffers at all: this rank cannot even raise its flag)
+    }
+    if (s->caller_order_fresh)
+      return strict_enqueue_sharded(s->strict_buf, (const float4 *)s->d_match_caller, (const uint32_t *)nullptr, s->d_state,
+                                    s->d_sums, s->kp, c, rank, world, s->shard_failed, st);
+    return strict_enqueue_sharded(s->strict_buf, (const float4 *)s->d_match, (const uint32_t *)s->d_pos_of, s->d_state,
+                                  s->d_sums, s->kp, c, rank, world, s->shard_failed, st);
+  }
+  const int n = s->n_sums();
+  if (!s->d_xchg) {
+    if (dev_cache_alloc((void **)&s->d_xchg, (size_t)(n + 2) * sizeof(double)) != hipSuccess)
+      return fail(PCGX_E_OOM, "pcgx_icp_session_step_sharded: no memory for the exchange");
+  }
+  PCGX_HIP_TRY(hipMemsetAsync(s->d_xchg, 0, (size_t)(n + 2) * sizeof(double), st));
+  if (!s->shard_failed) {
+    double *keep = s->d_sums;
+    s->d_sums = s->d_xchg;  // the reduction writes where the all-reduce reads
+    const pcgx_status rc = pcgx_icp_session_partials(s, stream);
+    s->d_sums = keep;
+    if (rc != PCGX_OK) {
+      *local_rc = rc;
+      s->shard_failed = true;
+    }
+  }
+  if (s->shard_failed) {
+    static const double one = 1.0;
+    PCGX_HIP_TRY(hipMemcpyAsync(s->d_xchg + n, &one, sizeof one, hipMemcpyHostToDevice, st));
+  }
+  PCGX_TRY(pcgx_comm_allreduce_f64(c, s->d_xchg, n + 1, stream));
+  if (s->plane)
+    hipLaunchKernelGGL(icp_update_sharded_kernel<true>, dim3(1), dim3(64), 0, st, s->d_state, (const double *)s->d_xchg, n,
+                       s->d_sums, s->kp);
+  else
+    hipLaunchKernelGGL(icp_update_sharded_kernel<false>, dim3(1), dim3(64), 0, st, s->d_state, (const double *)s->d_xchg, n,
+                       s->d_sums, s->kp);
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
 extern "C" pcgx_status pcgx_icp_session_step_sharded(pcgx_icp_session *s, pcgx_comm *c, void *stream) {
   PCGX_API_LOCK();
   if (!s || !c) return fail(PCGX_E_INVALID, "pcgx_icp_session_step_sharded: NULL argument");
@@ -1180,12 +1281,11 @@ extern "C" pcgx_status pcgx_icp_session_step_sharded(pcgx_icp_session *s, pcgx_c
   PCGX_TRY(pcgx_comm_rank(c, &rank, &world));
   if (world == 1 && !(getenv("PCGX_COMM_FORCE_COLLECTIVE") && atoi(getenv("PCGX_COMM_FORCE_COLLECTIVE")) != 0))
     return pcgx_icp_session_step(s, stream);
-  if (s->strict && s->strict_explicit)
-    return fail(PCGX_E_INVALID, "strict sums are not offered on a sharded target (no sequential order)");
-  s->strict = 0;  // the default (PCGX_SUMS_REFERENCE) on a sharded target: float64 sums, all-reduced
-  PCGX_TRY(pcgx_icp_session_partials(s, stream));
-  PCGX_TRY(pcgx_comm_allreduce_f64(c, s->d_sums, s->n_sums(), stream));
-  return pcgx_icp_session_update(s, stream);
+  if (s->strict == 2)
+    return fail(PCGX_E_INVALID, "the one-wave chain (PCGX_SUMS_REFERENCE_CHAIN) is not offered on a sharded target");
+  pcgx_status local = PCGX_OK;
+  const pcgx_status comm_rc = step_sharded_impl(s, c, stream, &local);
+  return local != PCGX_OK ? local : comm_rc;
 }
 
 extern "C" pcgx_status pcgx_icp_fit_sharded(const pcgx_kdtree *base, const float *tile, int64_t nt,
@@ -1193,43 +1293,155 @@ extern "C" pcgx_status pcgx_icp_fit_sharded(const pcgx_kdtree *base, const float
                                             pcgx_icp_stat *stat) {
   PCGX_API_LOCK();
   if (!base || !params || !trans16 || !c) return fail(PCGX_E_INVALID, "pcgx_icp_fit_sharded: NULL argument");
+  int32_t rank = 0, world = 1;
+  PCGX_TRY(pcgx_comm_rank(c, &rank, &world));  // (before anything is made: nothing to give back, no collective missed)
   pcgx_icp_session *s = nullptr;
   pcgx_status rc = pcgx_icp_session_create(base, tile, nt, 0, params, nullptr, &s);
-  int32_t rank = 0, world = 1;
-  PCGX_TRY(pcgx_comm_rank(c, &rank, &world));
+  std::string first_error = rc != PCGX_OK ? std::string(last_error_text()) : std::string();
   if (world > 1) {
     // A rank whose session could not be made (out of memory, a bad argument) must not leave the others
-    // waiting in the first all-reduce: every rank reaches ONE exchange of an error flag first, and all of
-    // them give up together if any has failed.
+    // waiting in the first all-reduce: every rank reaches ONE exchange of an error flag first -- out of a host word
+    // if even the device word cannot be had -- and all of them give up together if any has failed.
     double *d_flag = nullptr;
-    hipError_t e = dev_cache_alloc((void **)&d_flag, sizeof(double));
-    if (e != hipSuccess) {
-      if (s) pcgx_icp_session_free(s);
-      return fail(PCGX_E_OOM, "pcgx_icp_fit_sharded: %s", hipGetErrorString(e));
-    }
     const double mine = rc == PCGX_OK ? 0.0 : 1.0;
     double all = 1.0;
     pcgx_status rx = PCGX_OK;
-    if (hipMemcpyAsync(d_flag, &mine, sizeof mine, hipMemcpyHostToDevice, ctx().stream) != hipSuccess) rx = PCGX_E_HIP;
-    if (rx == PCGX_OK) rx = pcgx_comm_allreduce_f64(c, d_flag, 1, nullptr);
-    if (rx == PCGX_OK && (hipMemcpyAsync(&all, d_flag, sizeof all, hipMemcpyDeviceToHost, ctx().stream) != hipSuccess ||
-                          hipStreamSynchronize(ctx().stream) != hipSuccess))
-      rx = PCGX_E_HIP;
-    dev_cache_free(d_flag);
+    if (dev_cache_alloc((void **)&d_flag, sizeof(double)) != hipSuccess) {
+      (void)hipGetLastError();
+      d_flag = nullptr;
+      rx = pcgx_comm_allreduce_host_f64(c, &all, 1);  // (all == 1: this rank reports a failure)
+      if (rc == PCGX_OK) rc = fail(PCGX_E_OOM, "pcgx_icp_fit_sharded: no device memory for the ranks' error exchange");
+    } else {
+      if (hipMemcpyAsync(d_flag, &mine, sizeof mine, hipMemcpyHostToDevice, ctx().stream) != hipSuccess) rx = PCGX_E_HIP;
+      if (rx == PCGX_OK) rx = pcgx_comm_allreduce_f64(c, d_flag, 1, nullptr);
+      if (rx == PCGX_OK && (hipMemcpyAsync(&all, d_flag, sizeof all, hipMemcpyDeviceToHost, ctx().stream) != hipSuccess ||
+                            hipStreamSynchronize(ctx().stream) != hipSuccess))
+        rx = PCGX_E_HIP;
+      dev_cache_free(d_flag);
+    }
     if (rc == PCGX_OK && rx != PCGX_OK) rc = fail(rx, "pcgx_icp_fit_sharded: the ranks' error exchange failed");
     if (rc == PCGX_OK && all != 0.0) rc = fail(PCGX_E_RCCL, "pcgx_icp_fit_sharded: another rank could not set up its session");
   }
   if (rc != PCGX_OK) {
     if (s) pcgx_icp_session_free(s);
+    if (!first_error.empty()) return fail(rc, "%s", first_error.c_str());
     return rc;
   }
-  // every rank enqueues MaxIteration steps: the loop state is the same on all of them (same sums),
-  // so they stop together, and a step after `done` is a no-op on the device (the all-reduce of a finished
-  // session still runs: pcgx_icp_session_read_sums is undefined after the last iteration of a sharded Fit)
-  for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) rc = pcgx_icp_session_step_sharded(s, c, nullptr);
+  // Every rank enqueues MaxIteration steps: the loop state is the same on all of them (same sums), so they stop
+  // together, and a step after `done` is a no-op on the device (its collectives still run).  A rank whose step fails
+  // goes on calling the collectives with its flag up (step_sharded_impl), so the others see the failure in a
+  // collective they all reach and end their Fits in that same iteration -- nobody is left inside an all-reduce.
+  pcgx_status local = PCGX_OK;
+  for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) {
+    pcgx_status l = PCGX_OK;
+    if (world == 1 && !(getenv("PCGX_COMM_FORCE_COLLECTIVE") && atoi(getenv("PCGX_COMM_FORCE_COLLECTIVE")) != 0)) {
+      rc = pcgx_icp_session_step(s, nullptr);
+      continue;
+    }
+    rc = step_sharded_impl(s, c, nullptr, &l);
+    if (l != PCGX_OK && local == PCGX_OK) {
+      local = l;
+      first_error = last_error_text();
+    }
+  }
   if (rc == PCGX_OK) rc = pcgx_icp_session_result(s, nullptr, trans16, stat, nullptr);
   pcgx_icp_session_free(s);
+  if (local != PCGX_OK) return fail(local, "%s", first_error.c_str());
   return rc;
+}
+
+// ---- one process, several GPUs: a host thread per device slot, the exchange between them in host memory ---------
+namespace {
+struct LocalExchange {  // all-reduce (sum, rank order: bitwise reproducible) of `count` doubles between the threads of one process
+  std::mutex mu;
+  std::condition_variable cv;
+  int world = 1, arrived = 0;
+  long generation = 0;
+  std::vector<std::vector<double>> parts;
+  std::vector<double> total;
+  bool broken = false;
+};
+struct LocalRank {
+  LocalExchange *x;
+  int rank;
+};
+int32_t local_allreduce(double *buf, int32_t count, void *user) {
+  LocalRank *me = (LocalRank *)user;
+  LocalExchange &x = *me->x;
+  std::unique_lock<std::mutex> lk(x.mu);
+  if (x.broken) return 2;
+  x.parts[(size_t)me->rank].assign(buf, buf + count);
+  const long gen = x.generation;
+  if (++x.arrived == x.world) {
+    x.total.assign((size_t)count, 0.0);
+    for (int r = 0; r < x.world; r++) {
+      if ((int)x.parts[(size_t)r].size() != count) x.broken = true;  // the ranks disagree about what they exchange
+      else
+        for (int k = 0; k < count; k++) x.total[(size_t)k] += x.parts[(size_t)r][(size_t)k];
+    }
+    x.arrived = 0;
+    x.generation++;
+    x.cv.notify_all();
+  } else {
+    // a peer that never arrives (it left its Fit on a path that skips a collective: a bug) must not hang the process
+    if (!x.cv.wait_for(lk, std::chrono::seconds(60), [&] { return x.generation != gen || x.broken; })) x.broken = true;
+  }
+  if (x.broken) {
+    x.cv.notify_all();
+    return 2;
+  }
+  memcpy(buf, x.total.data(), (size_t)count * sizeof(double));
+  return 0;
+}
+}  // namespace
+
+// Fit with the target spread over n device slots of THIS process (pcgx_init_devices): bases[r] is the tree replica made
+// on slot r, tiles[r] / nt[r] slot r's part of the target (host memory).  A thread per slot runs pcgx_icp_fit_sharded
+// with an exchange in host memory; the result is every slot's (they agree), the status the first slot's that failed.
+extern "C" pcgx_status pcgx_icp_fit_multi(int32_t n, const pcgx_kdtree *const *bases, const float *const *tiles,
+                                          const int64_t *nt, const pcgx_icp_params *params, float trans16[16],
+                                          pcgx_icp_stat *stat) {
+  if (n < 1 || !bases || !tiles || !nt || !params || !trans16)
+    return fail(PCGX_E_INVALID, "pcgx_icp_fit_multi: bad argument");
+  LocalExchange x;
+  x.world = n;
+  x.parts.resize((size_t)n);
+  std::vector<LocalRank> ranks((size_t)n);
+  std::vector<pcgx_status> rc((size_t)n, PCGX_OK);
+  std::vector<std::string> msg((size_t)n);
+  std::vector<std::array<float, 16>> tr((size_t)n);
+  std::vector<pcgx_icp_stat> stv((size_t)n);
+  std::vector<std::thread> th;
+  for (int r = 0; r < n; r++) {
+    ranks[(size_t)r] = LocalRank{&x, r};
+    th.emplace_back([&, r]() {
+      pcgx_status e = pcgx_set_device(r);
+      pcgx_comm *c = nullptr;
+      if (e == PCGX_OK) e = pcgx_comm_init_callback(r, n, local_allreduce, &ranks[(size_t)r], &c);
+      if (e == PCGX_OK) e = pcgx_icp_fit_sharded(bases[r], tiles[r], nt[r], params, c, tr[(size_t)r].data(), &stv[(size_t)r]);
+      if (e != PCGX_OK) {
+        msg[(size_t)r] = last_error_text();
+        std::lock_guard<std::mutex> lk(x.mu);  // (a rank that could not even start must not leave the others waiting)
+        if (!c) {
+          x.broken = true;
+          x.cv.notify_all();
+        }
+      }
+      if (c) pcgx_comm_free(c);
+      rc[(size_t)r] = e;
+    });
+  }
+  for (auto &t : th) t.join();
+  // the rank that failed by itself speaks first; PCGX_E_RCCL ("another rank ...") only if nobody has a better story
+  int pick = -1;
+  for (int r = 0; r < n && pick < 0; r++)
+    if (rc[(size_t)r] != PCGX_OK && rc[(size_t)r] != PCGX_E_RCCL) pick = r;
+  for (int r = 0; r < n && pick < 0; r++)
+    if (rc[(size_t)r] != PCGX_OK) pick = r;
+  if (pick >= 0) return fail(rc[(size_t)pick], "pcgx_icp_fit_multi: slot %d: %s", pick, msg[(size_t)pick].c_str());
+  memcpy(trans16, tr[0].data(), 16 * sizeof(float));
+  if (stat) *stat = stv[0];
+  return PCGX_OK;
 }
 
 extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream, float trans16[16],

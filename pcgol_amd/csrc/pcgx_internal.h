@@ -39,6 +39,7 @@ using RawVector = std::vector<T, DefaultInitAlloc<T>>;
 
 // ---- error handling --------------------------------------------------------
 pcgx_status fail(pcgx_status code, const char *fmt, ...);
+const char *last_error_text();  // the calling thread's last error message (what pcgx_last_error copies)
 
 #define PCGX_HIP_TRY(expr)                                                             \
   do {                                                                                 \
@@ -126,6 +127,7 @@ struct Context {
   uint32_t mailbox_seq = 0;
 };
 Context &ctx();  // the calling thread's current context (the library's outside any call)
+int current_slot();  // the calling thread's device slot (pcgx_set_device; 0 unless a process drives several GPUs)
 pcgx_status ensure_init();
 // Scope of one ABI call: binds the thread to a context (pooled: any free one of the pool, waiting for
 // one if all are busy; else the library's, exclusively) and to the library's device -- HIP's current
@@ -347,6 +349,11 @@ const StrictWork *strict_work(StrictBuffers *b, const IcpKernelParams &kp);
 pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
                            double *sums10, const IcpKernelParams &kp, bool fuse_update, bool have_tile_sums, hipStream_t st);
 pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[64], hipStream_t st);
+// the same sums over a target spread over the ranks of `c` (the sequential order: the ranks' tiles one after the
+// other); local_failed: this rank launches nothing but still takes part in every collective, with its flag up
+pcgx_status strict_enqueue_sharded(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
+                                   double *sums10, const IcpKernelParams &kp, pcgx_comm *c, int rank, int world,
+                                   bool local_failed, hipStream_t st);
 }  // namespace pcgx
 
 struct pcgx_kdtree {

@@ -475,6 +475,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
   for (int row = wave; row < NR; row += kSumWaves) {
     if (kExchange) P0 = tile_prefix_pub(W.tile_pub, W.ntiles_pad, row, tile, lane);
     else if (row >= kSumWaves) P0 = tile_prefix(W.tile_sum, W.ntiles, row, tile, lane);
+    const double P0r = P0 + (W.row_base ? W.row_base[row] : 0.0);  // (the ranks before this one, strict_enqueue_sharded)
     const LdsQuads q{s_terms[row], lane};
     TileRec T;
     T.s = summary_identity();
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     // and the SIMD is shared): here they kept one workgroup busy 6 us longer than any other.  The tile goes to
     // strict_job_kernel instead (a job like the tiles below), which has that time to spare; what this kernel
     // keeps is the estimate of the tile's rounding error, from the guess chains like everywhere else.
-    const bool first = tile < kExactTiles;
+    const bool first = tile < kExactTiles && W.first_exact;
     double lsum = 0.0;
 #pragma unroll
     for (int v = 0; v < kLeaf / 4; v++) {
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     uint32_t g;
     ChainRange cr, crb;
     double terr;
-    tile_guesses_pair(q, P0, lsum, pre, lane, g, cr, crb, terr);
+    tile_guesses_pair(q, P0r, lsum, pre, lane, g, cr, crb, terr);
     // (plus what the stored tile sum is off the sum of the terms by: it was formed while a few of the tile's
     // pairs were still being walked for, icp.hip -- the job kernel's guesses then start from prefixes that add
     // up to the terms as they are)
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
       W.stamps[tile * 16 + 10] = (unsigned long long)(what | (row << 8));
     }
   };
-  if (tile < kExactTiles) {  // uniform
+  if (tile < kExactTiles && W.first_exact) {  // uniform
     // the first tile of a row, exactly, from 0.0f: the terms broadcast out of LDS a leaf ahead of the chain, so
     // that the dependent path is the additions alone (one every 6 cycles: a wave that has its SIMD nearly to
     // itself, as here, does the 2048 in ~6 us; out of registers through v_readlane each costs 10)
@@ -675,7 +676,8 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
       lsum += (double)a.x; lsum += (double)a.y; lsum += (double)a.z; lsum += (double)a.w;
     }
     const double pre = wave_excl_scan_f64(lsum, lane);
-    const double base = tile_prefix2(W.tile_sum, W.tile_err, W.ntiles, row, tile, lane);
+    const double base = tile_prefix2(W.tile_sum, W.tile_err, W.ntiles, row, tile, lane) +
+                        (W.row_base ? W.row_base[row] + W.err_base[row] : 0.0);  // (+ the ranks before this one)
     uint32_t g;
     ChainRange cr;
     double terr;
@@ -1107,7 +1109,9 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   // eighteen words would sit in scalar registers through the whole walk, which runs on the scalar unit and had
   // 188 of its registers spilled into vector lanes)
   auto term_src = [&]() { return make_term_src(match, pos_of, state, W); };
-  uint32_t s = f2u(0.0f);  // walker state, evaluator.go:122: the sums start at zero
+  // walker state, evaluator.go:122: the sums start at zero -- or where the ranks before this one ended (a target
+  // spread over ranks, strict_enqueue_sharded)
+  uint32_t s = W.start_bits ? (uint32_t)rfl((int)W.start_bits[row]) : f2u(0.0f);
   // walker: counters of the whole row, written once behind the last chunk (an atomic in flight holds up the
   // next release store of its wave, and the walk is a chain of those).  Vector registers (opaque to the compiler):
   // as scalars they were written to and read from spill lanes around every run.
@@ -1460,17 +1464,23 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   }
   if (row == 0 && walker && lane == 0) {
     while (lds_get(&s_np_ok) == 0) __builtin_amdgcn_s_sleep(1);
-    __hip_atomic_store(&sums10[S_PAIRS], (double)s_np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!W.hop_out) __hip_atomic_store(&sums10[S_PAIRS], (double)s_np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // component order of sums10: Value, G0..G5, DistRMS, Weight, Pairs
   if (walker && lane == 0) {
     const int slot = row == 0 ? S_VALUE : (row <= 6 ? S_G0 + row - 1 : (row == 7 ? S_DIST_RMS : S_WEIGHT));
-    __hip_atomic_store(&sums10[slot], (double)u2f(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (W.hop_out) W.hop_out[row] = (double)s;  // the state's BITS, as a number: the next rank's walk starts there
+    else __hip_atomic_store(&sums10[slot], (double)u2f(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the row that finishes last has all nine sums: evaluate tail + pose update (evaluator.go:156-186,
     // updater.go:44-71) in the same launch
     __threadfence();
     const unsigned ticket = atomicAdd(W.done_rows, 1u);
-    if (ticket == (unsigned)W.nrows - 1u) {
+    if (ticket == (unsigned)W.nrows - 1u && W.hop_out) {  // (sharded: the sums are put together behind the last rank's walk)
+      for (int k = 0; k < kAuxShards; k++) W.aux_count[k * 32] = 0u;
+      if (W.exchange)
+        for (int64_t k = 0, n = (W.ntiles + 31) / 32, m = n + (n + 31) / 32; k < m; k++) W.tile_arrived[32 * k] = 0u;
+      *W.done_rows = 0u;
+    } else if (ticket == (unsigned)W.nrows - 1u) {
       __threadfence();
       double sums[S_COUNT];
       for (int k = 0; k < S_COUNT; k++) sums[k] = __hip_atomic_load(&sums10[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1494,6 +1504,10 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
 struct StrictBuffers {
   StrictWork w;
   void *block = nullptr;
+  // a target spread over ranks (strict_enqueue_sharded): [world][16] slots of the all-gathers, then row_base[16],
+  // err_base[16] ([9] = pairs of all ranks), hop[16], start_bits[16] (uint32)
+  double *shard = nullptr;
+  int shard_world = 0;
 };
 
 pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const float *tz, const uint32_t *pos_of,
@@ -1502,6 +1516,10 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   StrictWork &W = b->w;
   W.nt = nt;
   W.raw_terms = nullptr;
+  W.row_base = W.err_base = nullptr;
+  W.start_bits = nullptr;
+  W.hop_out = nullptr;
+  W.first_exact = 1;
   W.ntiles = nt > 0 ? (nt + kTile - 1) / kTile : 1;
   W.nrows = kStrictRows;
   W.selfcheck = (getenv("PCGX_STRICT_SELFCHECK") ? 1 : 0) | (getenv("PCGX_STRICT_TRACE") ? 2 : 0) |
@@ -1574,6 +1592,7 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
 
 void strict_destroy(StrictBuffers *b) {
   if (!b) return;
+  dev_cache_free(b->shard);
   dev_cache_free(b->block);
   delete b;
 }
@@ -1617,6 +1636,152 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
       hipLaunchKernelGGL(strict_chain_kernel<false>, dim3((unsigned)W.nrows), dim3(kChainBlock), 0, st, match, pos_of, state, W,
                          sums10, kp, fuse_update ? 1 : 0);
   }
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
+// ---- the reference's sums over a target spread over ranks ----------------------------------------------------------
+// The sequential order is the ranks' tiles one after the other, rank 0's first: a sharded Fit then returns what the
+// reference's Fit returns on that concatenated target, bit for bit.  Everything that is parallel on one GPU stays
+// parallel and local -- correspondence, tile sums, summaries, jobs; what a rank needs from the ranks before it is
+// three numbers per sum: the float64 total of their terms and of their chains' rounding errors (where its guesses
+// start: two all-gathers of 9 doubles per rank) and the state their walk ended in (where its walk starts: the walk is
+// one dependent chain, so it goes round the ranks, one hop of 9 states per rank).  2 + world small collectives per
+// iteration instead of one; slot [10] of every one carries the ranks' error flag.
+__global__ __launch_bounds__(64) void strict_row_totals_kernel(const double *__restrict__ per_tile, const uint32_t *__restrict__ tile_pairs,
+                                                               int64_t ntiles, int nrows, const IcpState *__restrict__ state,
+                                                               double *__restrict__ slot /* this rank's [16] */) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  if (state->done) return;
+  if (row < nrows) {
+    double v = 0.0;
+    for (int64_t t = lane; t < ntiles; t += 64) v += per_tile[(int64_t)row * ntiles + t];
+    v = wave_allsum_f64(v);
+    if (lane == 0) slot[row] = v;
+  } else if (row == kStrictRows && tile_pairs) {
+    double v = 0.0;
+    for (int64_t t = lane; t < ntiles; t += 64) v += (double)tile_pairs[t];
+    v = wave_allsum_f64(v);
+    if (lane == 0) slot[kStrictRows] = v;
+  }
+}
+// out[r] = sum over the ranks before `rank` of their slot [r] (rank order); out[9] = the pairs of ALL ranks
+__global__ void strict_base_kernel(const double *__restrict__ slots, int rank, int world, double *__restrict__ out) {
+  const int r = threadIdx.x;
+  if (r < kStrictRows) {
+    double v = 0.0;
+    for (int k = 0; k < rank; k++) v += slots[k * 16 + r];
+    out[r] = v;
+  } else if (r == kStrictRows) {
+    double v = 0.0;
+    for (int k = 0; k < world; k++) v += slots[k * 16 + r];
+    out[r] = v;
+  }
+}
+__global__ void strict_hop_kernel(const double *__restrict__ hop, uint32_t *__restrict__ start_bits) {
+  if (threadIdx.x < kStrictRows) start_bits[threadIdx.x] = (uint32_t)hop[threadIdx.x];
+}
+__global__ void strict_zero_kernel(double *__restrict__ p, int n, double last) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = ((int)threadIdx.x == n - 1) ? last : 0.0;
+}
+// the sums behind the last rank's walk + evaluate tail + pose update (every rank, redundantly)
+__global__ void strict_finish_kernel(const uint32_t *__restrict__ end_bits, const double *__restrict__ err_base /* [9] = pairs */,
+                                     const double *__restrict__ failed, int nrows, IcpState *__restrict__ state,
+                                     double *__restrict__ sums10, IcpKernelParams kp) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (state->done) return;
+  if (*failed != 0.0) {  // a rank could not go on: the Fit ends here on every rank
+    state->status = PCGX_E_RCCL;
+    state->done = 1;
+    return;
+  }
+  double sums[S_COUNT];
+  for (int row = 0; row < nrows; row++) {
+    const int slot = row == 0 ? S_VALUE : (row <= 6 ? S_G0 + row - 1 : (row == 7 ? S_DIST_RMS : S_WEIGHT));
+    sums[slot] = (double)u2f(end_bits[row]);
+  }
+  const double np = err_base[kStrictRows];
+  sums[S_PAIRS] = np;
+  if (nrows < kStrictRows) sums[S_WEIGHT] = np < 16777216.0 ? np : 16777216.0;  // 0 + 1 + 1 + ... in float32 (strict_chain_kernel)
+  for (int k = 0; k < S_COUNT; k++) sums10[k] = sums[k];
+  icp_update_step(state, sums, kp);
+}
+
+pcgx_status strict_enqueue_sharded(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state, double *sums10,
+                                   const IcpKernelParams &kp, pcgx_comm *c, int rank, int world, bool local_failed, hipStream_t st) {
+  if (!b->shard || b->shard_world != world) {
+    dev_cache_free(b->shard);
+    b->shard = nullptr;
+    if (dev_cache_alloc((void **)&b->shard, (size_t)(world + 4) * 16 * sizeof(double)) != hipSuccess)
+      return fail(PCGX_E_OOM, "strict sums over ranks: no memory for the exchange");
+    b->shard_world = world;
+  }
+  double *slots = b->shard, *row_base = slots + (size_t)world * 16, *err_base = row_base + 16, *hop = row_base + 32;
+  uint32_t *start_bits = reinterpret_cast<uint32_t *>(hop + 16);
+  (void)strict_work(b, kp);
+  StrictWork W = b->w;  // (the session's descriptor stays in its one-GPU form)
+  W.row_base = row_base;
+  W.err_base = err_base;
+  W.start_bits = start_bits;
+  W.hop_out = hop;
+  W.first_exact = rank == 0 ? 1 : 0;
+  // A rank that cannot go on (`local_failed`: a launch error, an injected fault) launches nothing but keeps calling the
+  // collectives with its flag up (word [10] of its slot): the others learn of it in a collective they all reach anyway,
+  // nobody is left waiting; strict_finish_kernel ends the Fit on every rank in the same iteration.
+  auto exchange = [&](double *d_buf, int count, int flag_at) -> pcgx_status {
+    if (local_failed) {
+      static const double one = 1.0;
+      PCGX_HIP_TRY(hipMemcpyAsync(d_buf + flag_at, &one, sizeof one, hipMemcpyHostToDevice, st));
+    }
+    return pcgx_comm_allreduce_f64(c, d_buf, count, st);
+  };
+  const int nslots = world * 16;
+  // 1. the float64 totals of this rank's terms -> everybody -> the totals of the ranks before this one
+  PCGX_HIP_TRY(hipMemsetAsync(slots, 0, (size_t)nslots * sizeof(double), st));
+  if (!local_failed) {
+    ProfScope prof(PCGX_PROF_STRICT_TERMS, st);
+    hipLaunchKernelGGL(strict_tilesum_kernel, dim3((unsigned)W.ntiles), dim3(kTileSumBlock), 0, st, match, pos_of,
+                       (const IcpState *)state, W);
+    hipLaunchKernelGGL(strict_row_totals_kernel, dim3(kStrictRows), dim3(64), 0, st, (const double *)W.tile_sum,
+                       (const uint32_t *)nullptr, W.ntiles, W.nrows, (const IcpState *)state, slots + (size_t)rank * 16);
+  }
+  PCGX_TRY(exchange(slots, nslots, rank * 16 + 10));
+  if (!local_failed) {
+    hipLaunchKernelGGL(strict_base_kernel, dim3(1), dim3(64), 0, st, (const double *)slots, rank, world, row_base);
+    ProfScope prof(PCGX_PROF_STRICT_SUM, st);
+    hipLaunchKernelGGL(strict_sum_kernel<false>, dim3((unsigned)W.ntiles), dim3(kSumBlock), 0, st, match, pos_of,
+                       (const IcpState *)state, W);
+  }
+  // 2. the chains' rounding errors and the pair counts -> everybody
+  PCGX_HIP_TRY(hipMemsetAsync(slots, 0, (size_t)nslots * sizeof(double), st));
+  if (!local_failed)
+    hipLaunchKernelGGL(strict_row_totals_kernel, dim3(kStrictRows + 1), dim3(64), 0, st, (const double *)W.tile_err,
+                       (const uint32_t *)W.tile_pairs, W.ntiles, W.nrows, (const IcpState *)state, slots + (size_t)rank * 16);
+  PCGX_TRY(exchange(slots, nslots, rank * 16 + 10));
+  hipLaunchKernelGGL(strict_base_kernel, dim3(1), dim3(64), 0, st, (const double *)slots, rank, world, err_base);
+  if (!local_failed) {
+    ProfScope prof(PCGX_PROF_STRICT_JOB, st);
+    if (W.naux > 0)
+      hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
+  }
+  // 3. the walk goes round the ranks: every hop hands on nine states (their bits as float64: exact under the sum)
+  hipLaunchKernelGGL(strict_zero_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<double *>(start_bits), 8, 0.0);  // 16 x 0.0f
+  for (int k = 0; k < world; k++) {
+    hipLaunchKernelGGL(strict_zero_kernel, dim3(1), dim3(64), 0, st, hop, 16, 0.0);
+    if (k == rank && !local_failed) {
+      ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
+      if (W.selfcheck & 1)
+        hipLaunchKernelGGL(strict_chain_kernel<true>, dim3((unsigned)W.nrows), dim3(kChainBlock), 0, st, match, pos_of, state, W,
+                           sums10, kp, 0);
+      else
+        hipLaunchKernelGGL(strict_chain_kernel<false>, dim3((unsigned)W.nrows), dim3(kChainBlock), 0, st, match, pos_of, state, W,
+                           sums10, kp, 0);
+    }
+    PCGX_TRY(exchange(hop, 16, 10));
+    hipLaunchKernelGGL(strict_hop_kernel, dim3(1), dim3(64), 0, st, (const double *)hop, start_bits);
+  }
+  hipLaunchKernelGGL(strict_finish_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)start_bits, (const double *)err_base,
+                     (const double *)(hop + 10), W.nrows, state, sums10, kp);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }

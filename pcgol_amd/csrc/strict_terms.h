@@ -80,6 +80,15 @@ struct StrictWork {
   float weight_a;
   const float *raw_terms;  // testing (pcgx_debug_strict_sum_dev): [9][nt] float32 terms given as they are, no pairs
   int32_t exchange;   // strict_sum_kernel forms the tile sums itself and its workgroups exchange them inside the launch
+  // A target spread over ranks (strict_enqueue_sharded): the sequential order is the ranks' tiles one after the other,
+  // rank 0's first.  This rank's guesses start from the float64 sums (row_base) and chain rounding errors (err_base)
+  // of the ranks before it, its walk from the states they ended in (start_bits), and leaves its own end states in
+  // hop_out (the float's bits as a float64: exact under the all-reduce that hands them on).  All nullptr on one GPU.
+  const double *row_base;     // [9]
+  const double *err_base;     // [9]
+  const uint32_t *start_bits; // [9]
+  double *hop_out;            // [16]
+  int32_t first_exact;        // this rank holds the first tile of the whole target (added up term by term from 0.0f)
   int32_t selfcheck;  // bit 0: every step of the chain walk is re-derived term by term and compared (dbg[12..15]);
                       // 1: PCGX_STRICT_TRACE stamps; 2: no candidate tables; 3: wall-clock columns of the counters
 };

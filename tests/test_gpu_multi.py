@@ -1,0 +1,95 @@
+"""One process, several device slots (pcgx_init_devices / pcgx_set_device / pcgx_icp_fit_multi; SURVEY 8(b) threading
+row: "one process drives all 8 GPUs").  On the one-GPU test box the slots all name device 0: three independent sets of
+streams and workspaces, a tree replica per slot, a host thread per slot inside the library, the exchange in host memory.
+
+* the default sums (the reference's, over the slots' tiles one after the other) == the Go-semantics oracle's Fit on the
+  whole target, bit for bit; the float64 mode == the one-GPU float64 Fit to rounding;
+* a slot whose step fails in the middle of the Fit (fault injection) makes EVERY slot return within the timeout --
+  nobody is left inside an all-reduce (ADVICE round 2 / VERDICT round 3)."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+import oracle as O
+from pcgol_amd import _lib as L
+from pcgol_amd import icp, kdtree, synth
+
+pytestmark = pytest.mark.gpu
+N_SLOTS = 3
+
+
+@pytest.fixture(scope="module")
+def slots():
+    ids = np.zeros(N_SLOTS, np.int32)
+    L.check(L.lib().pcgx_init_devices(N_SLOTS, L.ptr(ids)))
+    yield N_SLOTS
+    L.check(L.lib().pcgx_set_device(0))
+
+
+def _fit_multi(c, trees, tiles, sums_mode=0):
+    n = len(trees)
+    params = icp._params(c["max_dist"], 0.0, c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"], sums_mode=sums_mode)
+    bases = (C.c_void_p * n)(*[t._h for t in trees])
+    tps = (C.c_void_p * n)(*[t.ctypes.data for t in tiles])
+    nts = (C.c_int64 * n)(*[len(t) for t in tiles])
+    trans = np.empty(16, np.float32)
+    st = L.IcpStat()
+    rc = L.lib().pcgx_icp_fit_multi(n, bases, tps, nts, C.byref(params), L.ptr(trans), C.byref(st))
+    return rc, trans, st
+
+
+def _trees(base, n):
+    trees = []
+    for r in range(n):
+        L.check(L.lib().pcgx_set_device(r))
+        trees.append(kdtree.New(base))     # the replica of slot r
+    L.check(L.lib().pcgx_set_device(0))
+    return trees
+
+
+def test_fit_multi_reference_sums_equal_the_oracle(slots):
+    n = 200_000
+    c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
+    trees = _trees(c["base"], slots)
+    cuts = [0, 70_001, 130_000, n]          # ragged, not tile aligned
+    tiles = [np.ascontiguousarray(c["target"][cuts[r]:cuts[r + 1]]) for r in range(slots)]
+    rc, trans, st = _fit_multi(c, trees, tiles)
+    L.check(rc)
+    o32 = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
+                    c["max_iteration"], sums_mode=0)
+    assert st.num_iteration == o32["num_iteration"] == 20
+    assert np.array_equal(trans.ravel(), np.asarray(o32["trans"]).ravel())
+    assert np.float32(st.evaluated.value) == o32["value"]
+    assert np.array_equal(np.array(st.evaluated.gradient, np.float32), o32["gradient"])
+    # the float64 mode: one all-reduce per iteration, the one-GPU float64 Fit to rounding
+    rc, t64, st64 = _fit_multi(c, trees, tiles, sums_mode=icp.SumsF64Tree)
+    L.check(rc)
+    reg = icp.PointToPointICPGradient(
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=c["min_pairs"],
+                                  SumsMode=icp.SumsF64Tree),
+        icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=c["threshold"], MaxIteration=c["max_iteration"]))
+    t1, s1 = reg.Fit(trees[0], c["target"])
+    assert st64.num_iteration == s1.NumIteration == 20 and np.max(np.abs(t64.ravel() - np.asarray(t1).ravel())) <= 1e-6
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["reference", "f64"])
+def test_a_failing_slot_ends_the_fit_on_every_slot(slots, mode, monkeypatch):
+    n = 60_000
+    c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
+    trees = _trees(c["base"], slots)
+    tiles = [np.ascontiguousarray(c["target"][r::slots]) for r in range(slots)]
+    monkeypatch.setenv("PCGX_TEST_FAIL_RANK", "1")
+    monkeypatch.setenv("PCGX_TEST_FAIL_ITER", "7")
+    t0 = time.time()
+    rc, trans, st = _fit_multi(c, trees, tiles, sums_mode=icp.SumsF64Tree if mode else 0)
+    assert time.time() - t0 < 30.0
+    assert rc != 0
+    buf = C.create_string_buffer(512)
+    L.lib().pcgx_last_error(buf, 512)
+    assert b"injected failure of rank 1 in iteration 7" in buf.value, buf.value
+    monkeypatch.delenv("PCGX_TEST_FAIL_RANK")
+    rc, trans, st = _fit_multi(c, trees, tiles, sums_mode=icp.SumsF64Tree if mode else 0)   # and the library still works
+    L.check(rc)
+    assert st.num_iteration == 20

@@ -26,9 +26,64 @@ def _free_port():
     return p
 
 
-def _case():
+def _case(n=120_000):
     from pcgol_amd import synth
-    return synth.c4_icp(n=120_000, width=10.0 * 0.12 ** (1 / 3))
+    return synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
+
+
+def _ref_worker(rank, world, port, q, n):
+    """The default sums on a sharded target: the reference's, over the ranks' tiles one after the other."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ctypes as C
+        from pcgol_amd import _lib as L
+        from pcgol_amd import icp, kdtree
+        from pcgol_amd.distributed import Comm
+        c = _case(n)
+        nt = len(c["target"])
+        lo, hi = nt * rank // world, nt * (rank + 1) // world      # contiguous shards of the caller's order
+        tile = np.ascontiguousarray(c["target"][lo:hi])
+        tree = kdtree.New(c["base"])
+        comm = Comm.gloo()
+        params = icp._params(c["max_dist"], 0.0, c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])  # sums_mode 0
+        trans = np.empty(16, np.float32)
+        st = L.IcpStat()
+        L.check(L.lib().pcgx_icp_fit_sharded(tree._h, L.ptr(tile), len(tile), C.byref(params), comm._h, L.ptr(trans),
+                                             C.byref(st)))
+        comm.close()
+        q.put((rank, trans, int(st.num_iteration), float(st.evaluated.value), np.array(st.evaluated.gradient, np.float32)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 200_000), (3, 200_000), (2, 1_000_000)], ids=["2x200k", "3x200k", "2xC4"])
+def test_reference_sums_on_a_sharded_target_equal_the_oracle_bit_for_bit(world, n):
+    """pcgx_icp_fit_sharded with the default sums over 2 and 3 processes (one GPU, callback communicator): the
+    transform, Value and Gradient of the Go-semantics oracle's Fit on the whole target -- the ranks hold contiguous
+    pieces of it -- bit for bit, at 200k pairs and at C4's full 1M (evaluator.go:122-145 summed over ranks)."""
+    import torch.multiprocessing as mp
+    import oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ref_worker, args=(r, world, port, q, n)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    c = _case(n)
+    o32 = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
+                    c["max_iteration"], sums_mode=0)
+    for r in res:
+        assert r[2] == o32["num_iteration"] == 20
+        assert np.array_equal(r[1].ravel(), np.asarray(o32["trans"]).ravel())
+        assert np.float32(r[3]) == o32["value"] and np.array_equal(r[4], o32["gradient"])
 
 
 def _worker(rank, world, port, q):
@@ -49,7 +104,8 @@ def _worker(rank, world, port, q):
         tree = kdtree.New(c["base"])
         comm = Comm.gloo()
         # (1) the whole Fit in one call
-        params = icp._params(c["max_dist"], 0.0, c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+        params = icp._params(c["max_dist"], 0.0, c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"],
+                             sums_mode=icp.SumsF64Tree)
         trans = np.empty(16, np.float32)
         st = L.IcpStat()
         L.check(L.lib().pcgx_icp_fit_sharded(tree._h, L.ptr(tile), len(tile), C.byref(params), comm._h, L.ptr(trans),
