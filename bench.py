@@ -225,6 +225,41 @@ def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, ic
                            "exchange_doubles": 30, "parity": "none in the reference (extension)"}
     ps.close()
     del ptree
+    # Four independent Fits at once (the library's four pooled call contexts, pcgx_icp_fit from four host threads): the
+    # latency-bound kernels of one Fit's sums run under the grid pass of another
+    try:
+        import threading
+        c4 = synth.c4_icp()
+        reg = icp.PointToPointICPGradient(
+            icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c4["max_dist"]), MinPairs=c4["min_pairs"]),
+            icp.GradientDescentUpdaterFactory(Weight=c4["weight"], Threshold=c4["threshold"], MaxIteration=c4["max_iteration"]))
+        ctree = kdtree.New(c4["base"])
+        reg.Fit(ctree, c4["target"])   # warm
+        t0 = time.perf_counter()
+        reg.Fit(ctree, c4["target"])
+        one = time.perf_counter() - t0
+        res = [None] * 4
+
+        def worker(k):
+            res[k] = reg.Fit(ctree, c4["target"])[0]
+        for rep in range(2):
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            four = time.perf_counter() - t0
+        its = c4["max_iteration"]
+        out["icp_c4_concurrent4"] = {
+            "fits_in_flight": 4, "seconds_one_fit_alone": one, "seconds_four_fits": four,
+            "gpoints_per_s_aggregate": 4 * its * len(c4["target"]) / four / 1e9,
+            "gpoints_per_s_one_fit_alone": its * len(c4["target"]) / one / 1e9,
+            "identical_results": bool(all(np.array_equal(res[0], r) for r in res[1:])),
+            "note": "host-pointer Fits (12 MB target upload + session set-up inside each call), reference sums"}
+        del ctree
+    except Exception as e:  # noqa: BLE001
+        out["icp_c4_concurrent4"] = {"error": str(e)[:200]}
     c3 = synth.c3_voxel()
     dp = torch.from_numpy(c3["points"]).to(dev)
     dout = torch.empty_like(dp)
@@ -274,6 +309,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--f64-tree", action="store_true", help="N = 1: time the float64-tree reduction instead of the reference's sums")
+    ap.add_argument("--no-reference-sharded", action="store_true", help="N > 1: skip the second timing with the reference's sums")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -468,6 +504,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t64 = float(t.item())
     f64_one_gpu = n_tile / t64 / 1e6
+    # N > 1: the same sharded step with the REFERENCE's sums (the library's default: its sequential float32 additions
+    # over the ranks' tiles one after the other -- the concatenated target's Fit bit for bit, tests/test_gpu_sharded_abi.py,
+    # tests/test_gpu_multi.py; 2 + N small collectives per step instead of one)
+    ref_sharded = None
+    if world > 1 and comm is not None and not args.no_reference_sharded:
+        try:
+            sref = icp.IcpSession(tree, tile, cfg["max_dist"], cfg["min_pairs"], cfg["weight"], cfg["threshold"],
+                                  cfg["max_iteration"], SumsMode=icp.SumsReference)
+
+            def ref_steps(k):
+                for i in range(k):
+                    if i % cfg["max_iteration"] == 0:
+                        L.check(L.lib().pcgx_icp_session_reset(sref._h, L.ptr(stream)))
+                    L.check(L.lib().pcgx_icp_session_step_sharded(sref._h, comm._h, L.ptr(stream)))
+            ref_steps(cfg["max_iteration"])
+            barrier()
+            t0 = time.perf_counter()
+            ref_steps(2 * cfg["max_iteration"])
+            L.check(L.lib().pcgx_sync(L.ptr(stream)))
+            torch.cuda.synchronize()
+            tr = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+            ref_sharded = float(tr.item()) / (2 * cfg["max_iteration"])
+            sref.close()
+            barrier()
+        except Exception as e:  # noqa: BLE001  (never at the price of the headline line)
+            ref_sharded = "failed: %s" % str(e)[:160]
 
     # What the grid pass reads per iteration (an untimed Fit, one instrumented launch before each step)
     grid_pts = grid_words = grid_walked = 0
@@ -570,6 +633,15 @@ def main():
         if world > 1:
             # one of these GPUs alone, same numeric mode, no exchange: N x this is perfect weak scaling
             line["value_same_mode_n1"] = f64_one_gpu
+            if isinstance(ref_sharded, float):
+                line["value_reference_sums"] = n_total / ref_sharded / 1e6
+                line["ms_per_step_reference_sums"] = ref_sharded * 1e3
+                line["reference_sums_note"] = ("the same sharded step with the library's default sums: bit-identical to the "
+                                               "reference's Fit of the ranks' tiles one after the other; %d collectives per "
+                                               "step (the walk goes round the ranks)" % (2 + world))
+            elif ref_sharded is not None:
+                line["value_reference_sums"] = None
+                line["reference_sums_note"] = ref_sharded
         else:
             line["value_f64_tree"] = f64_one_gpu
         if world == 1 and not args.no_extras and args.workload == "c4":

@@ -866,9 +866,101 @@ func (c *Comm) Close() {
 	}
 }
 
+// InitDevices: one process drives several GPUs (SURVEY 8(b): the reference is one process, icp.go:23).  Slot k of
+// the library works on HIP device ids[k] (nil: device k).  A goroutine names the slot its calls are for with
+// SetDevice -- after runtime.LockOSThread: the slot is per OS thread, like HIP's current device -- and a tree
+// belongs to the slot it was built on.  FitMulti needs none of that from the caller.
+func InitDevices(n int, ids []int32) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var p *C.int32_t
+	if len(ids) > 0 {
+		p = (*C.int32_t)(unsafe.Pointer(&ids[0]))
+	}
+	return status(C.pcgx_init_devices(C.int32_t(n), p))
+}
+
+// SetDevice selects the calling OS thread's device slot (call runtime.LockOSThread first).
+func SetDevice(slot int) error { return status(C.pcgx_set_device(C.int32_t(slot))) }
+
+// NewReplicas builds the same tree on the first n device slots (one upload and build per slot).
+func NewReplicas(ra pc.Vec3RandomAccessor, n int, opts ...KDTreeOption) ([]*KDTree, error) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	defer C.pcgx_set_device(0)
+	out := make([]*KDTree, 0, n)
+	for r := 0; r < n; r++ {
+		if err := SetDevice(r); err != nil {
+			return nil, err
+		}
+		k, err := New(ra, opts...)
+		if err != nil {
+			return nil, err
+		}
+		out = append(out, k)
+	}
+	return out, nil
+}
+
+// FitMulti is Fit with the target spread over the device slots of THIS process: bases[r] is the replica on slot r
+// (NewReplicas), tiles[r] slot r's part of the target.  With the default sums (e.Sums == 0) the result is the
+// reference's Fit of the tiles one after the other, bit for bit (icp.go:23-67, evaluator.go:122-145); no second
+// process, no communicator to set up.  A slot whose step fails ends the Fit on every slot (the error names it).
+func FitMulti(bases []*KDTree, tiles []pc.Vec3RandomAccessor, e *Evaluator, u *icp.GradientDescentUpdaterFactory) (mat.Mat4, icp.Stat, error) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	n := len(bases)
+	if n == 0 || len(tiles) != n {
+		return mat.Mat4{}, icp.Stat{}, errors.New("pcgx: FitMulti needs one tile per base replica")
+	}
+	var p C.pcgx_icp_params
+	p.max_dist, p.min_dist_sq, p.min_pairs = C.float(e.MaxDist), C.float(bases[0].MinDistSq), C.int32_t(e.MinPairs)
+	p.weight_fn, p.weight_fn_param = C.int32_t(e.Weight.Kind), C.float(e.Weight.A)
+	p.sums_mode = C.int32_t(e.Sums)
+	if u != nil {
+		for i := 0; i < 6; i++ {
+			p.weight[i], p.threshold[i] = C.float(u.Weight[i]), C.float(u.Threshold[i])
+		}
+		p.max_iteration = C.int32_t(u.MaxIteration)
+	}
+	// the C side reads the arrays of pointers during the call only; they live in C memory (cgo: no Go pointers to Go pointers)
+	hb := (*[1 << 20]*C.pcgx_kdtree)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	ht := (*[1 << 20]*C.float)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))
+	hn := (*[1 << 20]C.int64_t)(C.malloc(C.size_t(n) * 8))
+	defer C.free(unsafe.Pointer(hb))
+	defer C.free(unsafe.Pointer(ht))
+	defer C.free(unsafe.Pointer(hn))
+	packed := make([][]float32, n)
+	var pin runtime.Pinner // the tiles' memory is referenced from C memory for the length of the call
+	defer pin.Unpin()
+	for r := 0; r < n; r++ {
+		packed[r] = packVec3(tiles[r])
+		hb[r] = bases[r].t.h
+		hn[r] = C.int64_t(tiles[r].Len())
+		ht[r] = nil
+		if len(packed[r]) > 0 {
+			pin.Pin(&packed[r][0])
+			ht[r] = (*C.float)(unsafe.Pointer(&packed[r][0]))
+		}
+	}
+	var trans mat.Mat4
+	var st C.pcgx_icp_stat
+	rc := C.pcgx_icp_fit_multi(C.int32_t(n), (**C.pcgx_kdtree)(unsafe.Pointer(hb)), (**C.float)(unsafe.Pointer(ht)),
+		(*C.int64_t)(unsafe.Pointer(hn)), &p, (*C.float)(unsafe.Pointer(&trans[0])), &st)
+	runtime.KeepAlive(bases)
+	runtime.KeepAlive(packed)
+	stat := icp.Stat{NumIteration: int(st.num_iteration)}
+	stat.Value, stat.DistRMS = float32(st.evaluated.value), float32(st.evaluated.dist_rms)
+	for i := 0; i < 6; i++ {
+		stat.Gradient[i] = float32(st.evaluated.gradient[i])
+	}
+	return trans, stat, status(rc)
+}
+
 // FitSharded runs Fit on this rank's tile of the target; every rank returns the same transform.
-// Over several ranks the sums are float64 reductions whatever e.Sums says (a sum spread over ranks has
-// no sequential order to reproduce); a communicator of one rank is Fit.
+// With the default sums (e.Sums == 0) that is the reference's Fit of the ranks' tiles one after the other, rank 0's
+// first, bit for bit (its sequential float32 sums go round the ranks); SumsF64Tree is one all-reduce of ten float64
+// per iteration.  A communicator of one rank is Fit.
 func FitSharded(base *KDTree, tile pc.Vec3RandomAccessor, e *Evaluator, u *icp.GradientDescentUpdaterFactory, c *Comm) (mat.Mat4, icp.Stat, error) {
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()

@@ -366,11 +366,14 @@ enum { JOB_CROSSING = 1, JOB_NOWINDOW = 2 };
 // A workgroup waits for lower block indices only, and each XCD's dispatcher hands out its blocks in ascending
 // order, so the lowest unfinished tile is always resident or next in line on an XCD with room: the wait ends
 // whatever part of the grid is resident (C5's 3907 tiles on 512 places as well).  The poll is bounded all the same
-// (kExchangeSpins): a workgroup that gives up goes on with the lines as they are -- its guesses are then off, its
+// (kExchangeTicks): a workgroup that gives up goes on with the lines as they are -- its guesses are then off, its
 // records do not cover the states, the chain kernel adds its tile term by term: slow and still exact (dbg[63]
 // counts; the tests require 0).  What this buys: the 28 MB pass over pairs and targets that formed the tile sums
 // in front of this kernel (12-14 us of the C4 step), for a wait of 2-4 us behind the slowest phase 1.
-constexpr int kExchangeSpins = 1 << 15;
+// (The bound is wall-clock time, 2 ms: two such launches running side by side -- two Fits in two of the library's call
+// contexts -- could in principle hold each other's next-in-line workgroups out of the XCDs they need, each side's
+// residents waiting; giving up frees the places.)
+constexpr long long kExchangeTicks = 200000;  // s_memrealtime runs at 100 MHz
 template <bool kExchange>
 __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void strict_sum_kernel(
     const float4 *__restrict__ match, const uint32_t *__restrict__ pos_of, const IcpState *__restrict__ state, StrictWork W) {
@@ -444,6 +447,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
       // wait for every tile before mine: lane 0 for the earlier tiles of my group, lanes 1.. for the groups before it
       bool gave_up = false;
       const int64_t G_mine = g_mine >> 5;
+      long long t_first = 0;
       for (int64_t G0 = 0; G0 <= G_mine && !gave_up; G0 += kLanes - 1) {  // uniform (one round up to 64512 tiles)
         const int64_t G = G0 + lane - 1;
         uint32_t want = 0u;
@@ -459,9 +463,13 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
           uint32_t have = 0u;
           if (want) have = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (__ballot((have & want) != want) == 0ull) break;
-          if (spins >= kExchangeSpins) {
-            gave_up = true;
-            break;
+          if ((spins & 63) == 63) {  // (a clock read is a memory round trip: now and then)
+            const long long now = (long long)wall_clock64();
+            if (t_first == 0) t_first = now;
+            if (now - t_first > kExchangeTicks) {
+              gave_up = true;
+              break;
+            }
           }
           __builtin_amdgcn_s_sleep(4);
         }

@@ -38,7 +38,7 @@ constexpr int kVbCap = 1280;           // points per bucket the bucket kernel ho
                                        // workgroup is a chain of short dependent phases, what hides them is the other workgroups)
 constexpr int kVbMaxCell = 255;        // points per cell it puts in order by itself
 constexpr int kVbFinalThreads = 256;
-constexpr int kVbSpins = 1 << 16;
+constexpr long long kVbWaitTicks = 500000;  // 5 ms of s_memrealtime (100 MHz): a bucket that waits longer gives up, the radix path answers
 constexpr int kVbSampleEvery = 32;     // every 32nd point is counted per bucket before anything is moved
 
 struct VbPlan {
@@ -422,7 +422,13 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
   // one behind the other (0.28 ms).
   if (closes_group && wave == 0) {
     bool pub_group = false, pub_super = n1 != 31;
-    for (int spins = 0; spins < kVbSpins && !(pub_group && pub_super); spins++) {
+    long long t_first = 0;
+    for (int spins = 0; !(pub_group && pub_super); spins++) {
+      if ((spins & 63) == 63) {
+        const long long now = (long long)wall_clock64();
+        if (t_first == 0) t_first = now;
+        if (now - t_first > kVbWaitTicks) break;  // (the buckets behind this group then give up as well)
+      }
       const uint32_t w1 = (lane < n1 && !pub_super) ? ld_sc1_u32(&ex.group_tot[(n2 << 5) + lane]) : 0x80000000u;
       const uint32_t w0 = lane < n0 ? ld_sc1_u32(&ex.count[((b >> 5) << 5) + lane]) : 0x80000000u;
       const bool ok0 = __ballot((w0 >> 31) == 0u) == 0ull, ok1 = __ballot((w1 >> 31) == 0u) == 0ull;
@@ -532,6 +538,7 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
   if (wave == 0) {
     bool gave_up = false;
     uint32_t s2 = 0, s1 = 0, s0 = 0;
+    long long t_first = 0;
     for (int spins = 0; !(plan.dbg & 1); spins++) {
       // (issued before the cell phase and looked at here, the first poll was slower: 138 us against 124 for the kernel)
       const uint32_t w2 = lane < n2 ? ld_sc1_u32(&ex.super_tot[lane]) : 0x80000000u;
@@ -541,9 +548,13 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
       s1 = w1 & 0x7fffffffu;
       s0 = w0 & 0x7fffffffu;
       if (__ballot(((w2 & w1 & w0) >> 31) == 0u) == 0ull) break;
-      if (spins >= kVbSpins) {
-        gave_up = true;
-        break;
+      if ((spins & 63) == 63) {
+        const long long now = (long long)wall_clock64();
+        if (t_first == 0) t_first = now;
+        if (now - t_first > kVbWaitTicks) {
+          gave_up = true;
+          break;
+        }
       }
       __builtin_amdgcn_s_sleep(4);
     }

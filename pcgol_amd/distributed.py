@@ -166,7 +166,9 @@ class ShardedIcp:
     def __init__(self, base_tree, target_tile, MaxDist, MinPairs=0, Weight=None, Threshold=None,
                  MaxIteration=0, group=None, force_exchange=False, BaseNormals=None, Damping=0.0, comm=None,
                  SumsMode=None):
-        """SumsMode: None = float64 sums wherever there is an exchange, the reference's sums on one rank.
+        """SumsMode: None = float64 sums wherever there is an exchange (one all-reduce per iteration), the reference's sums
+        on one rank; icp.SumsReference with comm=...: the reference's sums over the ranks' tiles one after the other
+        (the library's default for a sharded Fit: bit-identical to the Fit of the concatenated target).
         BaseNormals: point-to-plane / Gauss-Newton extension; the exchange is then the all-reduce
         of 30 doubles (sum r^2, J^T r, upper triangle of J^T J, sum w, pairs) instead of 10.
         comm: a Comm -- the exchange then runs inside libpcgx.so (pcgx_icp_session_step_sharded: what
@@ -189,7 +191,8 @@ class ShardedIcp:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # force_exchange: take the partials -> all-reduce -> update path even with one rank (tests)
         self.exchange = self.world > 1 or (force_exchange and dist.is_initialized())
-        # a sum spread over ranks has no sequential order: float64 sums wherever there is an exchange, the
+        # float64 sums wherever there is an exchange unless asked otherwise (partials / update around torch's all-reduce
+        # can only add float64 sums; the library's own step forms the reference's sums over the ranks as well), the
         # reference's own sums (the library's default) on one rank
         sharded = self.exchange or (comm is not None and comm.world > 1)
         self.sess = _icp.IcpSession(base_tree, target_tile, MaxDist, MinPairs, Weight, Threshold, MaxIteration,

@@ -292,8 +292,26 @@ class PointToPointICP {  // icp.go:18-67 with evaluator.go:69-73 and updater.go:
     check(pcgx_icp_fit(base.handle(), tp, (int64_t)target.size(), &p, t.data(), &st));
     return {t, Stat{st.evaluated, st.num_iteration}};
   }
-  // Fit on this rank's tile of the target; every rank returns the same transform (several ranks: float64
-  // sums, all-reduced over the ranks of `comm` once per iteration; one rank: Fit).  Collective.
+  // Fit with the target spread over the device slots of THIS process (pcgx_init_devices): bases[r] the replica built
+  // with slot r current, tiles[r] slot r's part.  Default sums: the reference's Fit of the tiles one after the other.
+  std::pair<Mat4, Stat> FitMulti(const std::vector<const KDTree *> &bases, const std::vector<std::vector<Vec3>> &tiles) const {
+    const pcgx_icp_params p = params(*bases.at(0));
+    std::vector<const pcgx_kdtree *> hb;
+    std::vector<const float *> ht;
+    std::vector<int64_t> hn;
+    for (size_t r = 0; r < bases.size(); r++) {
+      hb.push_back(bases[r]->handle());
+      ht.push_back(tiles.at(r).empty() ? nullptr : tiles[r][0].data());
+      hn.push_back((int64_t)tiles[r].size());
+    }
+    Mat4 t;
+    pcgx_icp_stat st{};
+    check(pcgx_icp_fit_multi((int32_t)bases.size(), hb.data(), ht.data(), hn.data(), &p, t.data(), &st));
+    return {t, Stat{st.evaluated, st.num_iteration}};
+  }
+  // Fit on this rank's tile of the target; every rank returns the same transform (default sums: the reference's over
+  // the ranks' tiles one after the other; PCGX_SUMS_F64_TREE: one all-reduce of float64 sums per iteration; one
+  // rank: Fit).  Collective.
   std::pair<Mat4, Stat> FitSharded(const KDTree &base, const std::vector<Vec3> &tile, const Comm &comm) const {
     const pcgx_icp_params p = params(base);
     Mat4 t;
