@@ -67,6 +67,13 @@ func status(rc C.pcgx_status) error {
 // Init selects the GPU of this process (one process per GPU).
 func Init(device int) error { return status(C.pcgx_init(C.int32_t(device))) }
 
+func init() {
+	// the struct layouts this file was compiled against (include/pcgx.h) must be the library's
+	if v := int(C.pcgx_abi_version()); v != C.PCGX_ABI_VERSION {
+		panic(fmt.Sprintf("pcgx: libpcgx.so speaks ABI version %d, this package was built against %d", v, int(C.PCGX_ABI_VERSION)))
+	}
+}
+
 // xyzLayout finds stride and xyz byte offset of a cloud exactly as
 // PointCloud.Vec3Iterator does (pc/pointcloud.go:130-150).
 func xyzLayout(pp *pc.PointCloud) (stride, off int, err error) {

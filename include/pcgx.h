@@ -76,6 +76,14 @@ PCGX_API pcgx_status pcgx_get_device(int32_t *slot, int32_t *hip_device);
 /* Copies the last error message of the calling thread; returns its length. */
 PCGX_API int32_t pcgx_last_error(char *buf, size_t cap);
 PCGX_API const char *pcgx_version(void);
+/* The layout version of this header's structs and fixed-size output arrays (pcgx_icp_params gained sums_mode in 3;
+ * pcgx_debug_icp_strict_stats writes 64 words since 3; 4: device slots, pcgx_icp_fit_multi, pcgx_debug_voxel_stats).
+ * A binding built against another version of the header must not call into the library: the mirrors (go/pcgx,
+ * host/pcgx.hpp, pcgol_amd/_lib.py) compare PCGX_ABI_VERSION with pcgx_abi_version() when they load it.
+ * pcgx_icp_params_init zeroes a parameter block of THIS version (all defaults); sizeof_params is the caller's
+ * sizeof(pcgx_icp_params): a mismatch is PCGX_E_INVALID instead of a read past a shorter struct. */
+#define PCGX_ABI_VERSION 4
+PCGX_API int32_t pcgx_abi_version(void);
 /* Block until all work enqueued on `stream` (NULL = library stream) is done. */
 PCGX_API pcgx_status pcgx_sync(void *stream);
 /* Threading.  Handles are immutable after build (DeletePoint excepted, as in the reference,
@@ -308,6 +316,8 @@ typedef struct {
    * reference's own sums wherever they are defined (one GPU: bit-identical Evaluated and pose). */
   int32_t sums_mode;
 } pcgx_icp_params;
+
+PCGX_API pcgx_status pcgx_icp_params_init(pcgx_icp_params *p, size_t sizeof_params);
 
 /* pcgx_icp_params.sums_mode.  The reference adds float32 terms pair after pair in target order; its
  * result carries that chain's rounding (~1.6e-5 on the final transform at 1M pairs), so only a sum

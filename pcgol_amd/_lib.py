@@ -122,11 +122,15 @@ class IcpStat(C.Structure):
 
 # name -> (restype, argtypes); the complete export list of include/pcgx.h
 _vp, _i64, _i32, _u32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float, C.c_size_t
+ABI_VERSION = 4   # include/pcgx.h PCGX_ABI_VERSION
+
 SIGNATURES = {
     "pcgx_init": (_i32, [_i32]),
     "pcgx_shutdown": (_i32, []),
     "pcgx_last_error": (_i32, [C.c_char_p, _sz]),
     "pcgx_version": (C.c_char_p, []),
+    "pcgx_abi_version": (_i32, []),
+    "pcgx_icp_params_init": (_i32, [_vp, C.c_size_t]),
     "pcgx_sync": (_i32, [_vp]),
     "pcgx_prof_enable": (_i32, [_i32]),
     "pcgx_prof_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i64)]),
@@ -245,6 +249,9 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if L.pcgx_abi_version() != ABI_VERSION:   # the struct layouts below belong to ONE version of include/pcgx.h
+            raise ImportError("libpcgx.so speaks ABI version %d, this binding %d: rebuild (python -c 'import __graft_entry__ as g; g.build()')"
+                              % (L.pcgx_abi_version(), ABI_VERSION))
         _lib = L
     return _lib
 

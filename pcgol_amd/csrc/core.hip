@@ -422,6 +422,15 @@ extern "C" int32_t pcgx_last_error(char *buf, size_t cap) {
 }
 
 extern "C" const char *pcgx_version(void) { return "pcgx 0.1 (gfx950)"; }
+extern "C" int32_t pcgx_abi_version(void) { return PCGX_ABI_VERSION; }
+extern "C" pcgx_status pcgx_icp_params_init(pcgx_icp_params *p, size_t sizeof_params) {
+  if (!p) return fail(PCGX_E_INVALID, "pcgx_icp_params_init: NULL argument");
+  if (sizeof_params != sizeof(pcgx_icp_params))
+    return fail(PCGX_E_INVALID, "pcgx_icp_params_init: the caller's pcgx_icp_params has %zu bytes, the library's %zu (ABI version %d)",
+                sizeof_params, sizeof(pcgx_icp_params), PCGX_ABI_VERSION);
+  memset(p, 0, sizeof *p);
+  return PCGX_OK;
+}
 
 extern "C" pcgx_status pcgx_sync(void *stream) {
   PCGX_API_LOCK();

@@ -122,10 +122,14 @@ __global__ __launch_bounds__(kRangeBlock) void range_grid_kernel(GridView g, con
 // {id, DistSq bits, query} records -> the three arrays the sort works on (a slot no query wrote keeps the
 // poisoned id, query 0)
 __global__ __launch_bounds__(256) void range_split_kernel(const uint4 *__restrict__ rec, int64_t total, int32_t *__restrict__ out_id,
-                                                          uint32_t *__restrict__ out_key, uint32_t *__restrict__ out_query) {
+                                                          uint32_t *__restrict__ out_key, uint32_t *__restrict__ out_query,
+                                                          int32_t *__restrict__ bad) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= total) return;
   const uint4 v = rec[j];
+  // a slot no query wrote: the caller's offsets leave room the counts do not fill.  Said HERE: behind the sort such a
+  // slot stands among query 0's neighbours at DistSq 0, where the tie pass may move it onto a real one (ADVICE)
+  if (v.x == 0xffffffffu) *bad = 1;
   out_id[j] = (int32_t)v.x;
   out_key[j] = v.x == 0xffffffffu ? 0u : v.y;
   out_query[j] = v.x == 0xffffffffu ? 0u : v.z;
@@ -354,6 +358,7 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
     PCGX_TRY(ar.alloc_n((size_t)nq, &qperm));
     PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, qperm, st));
   }
+  int32_t *d_bad = nullptr;
   if (patched)
     PCGX_TRY(xtree_launch_range(outer, true, d_q, qperm, nq, max_range * max_range, nullptr, d_off, total, d_id, d_key,
                                 d_query, st));
@@ -361,11 +366,13 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
     uint4 *d_rec = nullptr;
     PCGX_TRY(ar.alloc_n((size_t)total, &d_rec));
     PCGX_HIP_TRY(hipMemsetAsync(d_rec, 0xFF, (size_t)total * 16, st));  // (poisoned ids as above)
+    PCGX_TRY(ar.alloc_n(1, &d_bad));
+    PCGX_HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
     hipLaunchKernelGGL(range_grid_kernel<true>, dim3(xcd_grid((unsigned)((nq + kRangeBlock - 1) / kRangeBlock))), dim3(kRangeBlock),
                        0, st, t->grid, (const float *)d_q, (const int32_t *)qperm, nq, max_range * max_range, nullptr, d_off, total,
                        d_rec);
     hipLaunchKernelGGL(range_split_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint4 *)d_rec, total,
-                       d_id, d_key, d_query);
+                       d_id, d_key, d_query, d_bad);
   } else
     hipLaunchKernelGGL(range_kernel<true>, dim3(xcd_grid((unsigned)((nq + kRangeBlock - 1) / kRangeBlock))), dim3(kRangeBlock),
                        lds, st, tv, d_q, (const int32_t *)qperm, nq, max_range * max_range, nullptr, d_off, total, d_id,
@@ -404,10 +411,11 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
   // Go's int is 64 bits wide: widened (and checked: a poisoned id means the caller's offsets do not match the
   // counts) on the device, straight into the caller's slice
   int64_t *d_ids64 = nullptr;
-  int32_t *d_bad = nullptr;
   PCGX_TRY(ar.alloc_n((size_t)total, &d_ids64));
-  PCGX_TRY(ar.alloc_n(1, &d_bad));
-  PCGX_HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
+  if (!d_bad) {
+    PCGX_TRY(ar.alloc_n(1, &d_bad));
+    PCGX_HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
+  }
   hipLaunchKernelGGL(range_widen_check_kernel, dim3(tb), dim3(256), 0, st, (const uint32_t *)d_out_id, total, d_ids64, d_bad);
   PCGX_HIP_TRY(hipGetLastError());
   int32_t bad = 0;

@@ -79,6 +79,12 @@ class Comm {
   pcgx_comm *h_ = nullptr;
 };
 
+// the struct layouts this header was compiled against must be the library's (call once after loading it)
+inline void CheckAbi() {
+  if (pcgx_abi_version() != PCGX_ABI_VERSION)
+    throw Error(PCGX_E_INVALID, "libpcgx.so speaks another ABI version than the pcgx.h this program was built against");
+}
+
 class KDTree;
 // kdtree.KDTreeOption (kdtree.go:31): New(ra, opts...) / (*KDTree).With(opts...) apply them to the tree value.
 using KDTreeOption = std::function<void(KDTree &)>;
