@@ -594,13 +594,17 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch_dev(const pcgx_kdtree *t, const
   }
   PCGX_TRY(ctx().arena.begin(st));
   int32_t *perm = nullptr;
+  const bool on_grid = !(min_dist_sq > 0.0f) && grid_enabled(t);
+  static const bool partition_off = getenv("PCGX_KNN_PARTITION") && atoi(getenv("PCGX_KNN_PARTITION")) == 0;
+  if (on_grid && (flags & PCGX_KNN_PRESORT) && nq > 1 && nq < 0x7fffffffll && !partition_off)
+    return grid_launch_nearest_partitioned(t, d_q, nq, max_range_sq, d_ids, d_dist_sq, st);  // (the queries themselves, by coarse cell)
   if ((flags & PCGX_KNN_PRESORT) && nq > 1) {
     PCGX_TRY(ctx().arena.alloc_n((size_t)nq, &perm));
     PCGX_TRY(morton_order(d_q, nq, t->bbox_lo, t->bbox_hi, perm, st));
   }
   // exact mode: answers the uniform grid can certify come from there, the rest from the walk
   // (knn_grid.h); MinDistSq > 0 depends on the visit order: walk only
-  if (!(min_dist_sq > 0.0f) && grid_enabled(t))
+  if (on_grid)
     return grid_launch_nearest(t, d_q, perm, nq, max_range_sq, d_ids, d_dist_sq, st);
   return launch_nearest(t->view(), d_q, perm, nq, max_range_sq, min_dist_sq, d_ids, d_dist_sq, st);
 }

@@ -396,5 +396,9 @@ void grid_free(pcgx_kdtree *t);
 bool grid_enabled(const pcgx_kdtree *t);
 pcgx_status grid_launch_nearest(const pcgx_kdtree *t, const float *d_q, const int32_t *d_perm, int64_t nq,
                                 float max_range_sq, int32_t *d_ids, float *d_dsq, hipStream_t st);
+// the same for a batch whose search order is the library's to choose: the queries are partitioned by a coarse cell
+// once ({x, y, z, index} records) and searched in that order
+pcgx_status grid_launch_nearest_partitioned(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range_sq,
+                                            int32_t *d_ids, float *d_dsq, hipStream_t st);
 
 }  // namespace pcgx

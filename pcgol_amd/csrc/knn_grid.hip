@@ -99,6 +99,153 @@ __global__ __launch_bounds__(kGridBlock) void grid_nearest_kernel(GridView g, co
   }
 }
 
+// ---- the queries of a large batch, partitioned once by a coarse cell ------------------------------------------------
+// Large batches are searched in a spatial order (the lanes of a wave then read the same cells).  Round 1-3 made that
+// order with a 16-bit Morton key, two radix passes over (key, index) pairs and a gather of every query through the
+// resulting permutation: 47 of the 134 us a C2 call took.  Here ONE counting partition by an 8-bit cell (3 + 3 + 2
+// bits over the base cloud's box) moves the queries themselves, {x, y, z, index} as 16-byte records: a histogram
+// kernel, then a kernel that re-orders a 2048-query tile in LDS and writes every cell's run in one piece.  Where a
+// tile's runs go needs no scan over the tiles: a returning atomic per (tile, cell) on the cell's cursor -- the order
+// of the queries inside a cell is then whatever order the tiles arrive in, which no result depends on (the search is
+// exact; ties and the like go to the walk by query index).  The search kernel reads its queries coalesced and
+// scatters only the answers.
+struct QueryBox {
+  float lo[3], scale[3];
+};
+__device__ __forceinline__ uint32_t query_cell8(const QueryBox &b, float x, float y, float z) {
+  // (points outside the box clamp to its faces; NaN -> 0)
+  const uint32_t cx = (uint32_t)fminf(fmaxf((x - b.lo[0]) * b.scale[0], 0.0f), 7.0f);
+  const uint32_t cy = (uint32_t)fminf(fmaxf((y - b.lo[1]) * b.scale[1], 0.0f), 7.0f);
+  const uint32_t cz = (uint32_t)fminf(fmaxf((z - b.lo[2]) * b.scale[2], 0.0f), 3.0f);
+  auto spread = [](uint32_t v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4); };  // 3 bits -> every third bit
+  return spread(cx) | (spread(cy) << 1) | (spread(cz) << 2);  // z has two bits: the key has eight
+}
+constexpr int kQpItems = 8, kQpTile = 256 * kQpItems;
+
+__global__ __launch_bounds__(256) void qp_hist_kernel(const float *__restrict__ q, int64_t nq, QueryBox box,
+                                                      uint32_t *__restrict__ totals) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kQpTile;
+#pragma unroll
+  for (int r = 0; r < kQpItems; r++) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < nq) atomicAdd(&h[query_cell8(box, q[3 * i], q[3 * i + 1], q[3 * i + 2])], 1u);
+  }
+  __syncthreads();
+  // (eight copies of the totals and of the cursors, a tile uses copy blockIdx % 8: 489 tiles adding to ONE word per
+  // cell were served one after the other, 13 us for this kernel where the pass over the queries takes 4)
+  const uint32_t c = h[threadIdx.x];
+  if (c) atomicAdd(&totals[(blockIdx.x & 7u) * 256 + threadIdx.x], c);
+}
+
+__global__ __launch_bounds__(256) void qp_scatter_kernel(const float *__restrict__ q, int64_t nq, QueryBox box,
+                                                         const uint32_t *__restrict__ totals, uint32_t *__restrict__ cursors,
+                                                         float4 *__restrict__ out) {
+  __shared__ uint32_t lcnt[256], tile_pref[256], gbase[256], wsum[4], gwsum[4];
+  __shared__ float4 srec[kQpTile];
+  __shared__ uint8_t sdig[kQpTile];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  lcnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kQpTile;
+  float x[kQpItems], y[kQpItems], z[kQpItems];
+  uint32_t d[kQpItems], rank[kQpItems];
+#pragma unroll
+  for (int r = 0; r < kQpItems; r++) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    x[r] = y[r] = z[r] = 0.0f;
+    if (i < nq) {
+      x[r] = q[3 * i];
+      y[r] = q[3 * i + 1];
+      z[r] = q[3 * i + 2];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kQpItems; r++) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    d[r] = query_cell8(box, x[r], y[r], z[r]);
+    rank[r] = i < nq ? atomicAdd(&lcnt[d[r]], 1u) : 0u;
+  }
+  __syncthreads();
+  {  // cell t: its place in the tile (exclusive scan of the tile's counts), its run's place in the output (the cell's
+     // start = exclusive scan of the totals, + what earlier tiles have taken of the cell: the cursor)
+    const int t = threadIdx.x;
+    const uint32_t c = lcnt[t];
+    // the cell's part of the output is cut into eight pieces, one per copy: piece k holds what the tiles with
+    // blockIdx % 8 == k bring
+    uint32_t tot = 0, before_mine = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t v = totals[k * 256 + t];
+      before_mine += k < (int)(blockIdx.x & 7u) ? v : 0u;
+      tot += v;
+    }
+    uint32_t inc = c, ginc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t a = __shfl_up(inc, o), b = __shfl_up(ginc, o);
+      if (lane >= o) {
+        inc += a;
+        ginc += b;
+      }
+    }
+    if (lane == 63) {
+      wsum[wave] = inc;
+      gwsum[wave] = ginc;
+    }
+    __syncthreads();
+    uint32_t wb = 0, gwb = 0;
+    for (int w = 0; w < wave; w++) {
+      wb += wsum[w];
+      gwb += gwsum[w];
+    }
+    const uint32_t excl = wb + inc - c;
+    tile_pref[t] = excl;
+    const uint32_t taken = c ? atomicAdd(&cursors[(blockIdx.x & 7u) * 256 + t], c) : 0u;
+    gbase[t] = (gwb + ginc - tot) + before_mine + taken - excl;  // dst = gbase[cell] + position in the tile
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < kQpItems; r++) {
+    const int64_t i = base + r * 256 + threadIdx.x;
+    if (i < nq) {
+      const uint32_t pos = tile_pref[d[r]] + rank[r];
+      srec[pos] = make_float4(x[r], y[r], z[r], __int_as_float((int)i));
+      sdig[pos] = (uint8_t)d[r];
+    }
+  }
+  __syncthreads();
+  const int64_t rem = nq - base;
+  const int count = rem < kQpTile ? (int)rem : kQpTile;
+  for (int p = threadIdx.x; p < count; p += 256) out[(int64_t)gbase[sdig[p]] + p] = srec[p];
+}
+
+// One query record per lane (qp_scatter_kernel's output: cell after cell); the answer goes to the query's own index.
+__global__ __launch_bounds__(kGridBlock) void grid_nearest_rec_kernel(GridView g, const float4 *__restrict__ qrec, int64_t nq,
+                                                                      float max_range_sq, int32_t *__restrict__ out_id,
+                                                                      float *__restrict__ out_dsq, int32_t *__restrict__ walk_list,
+                                                                      uint32_t *__restrict__ walk_count) {
+  const uint32_t n_tiles = (uint32_t)((nq + kGridBlock - 1) / kGridBlock);
+  const int64_t pos = (int64_t)xcd_tile(blockIdx.x, n_tiles) * kGridBlock + threadIdx.x;  // an XCD: a contiguous eighth of the cells
+  if (pos >= nq) return;
+  const float4 r = qrec[pos];
+  const int32_t i = __float_as_int(r.w);
+  float4 best;
+  float best_d;
+  const GridVerdict v = grid_nearest(g, r.x, r.y, r.z, max_range_sq, __builtin_inff(), best, best_d, nullptr);
+  if (v == GRID_FOUND) {
+    out_id[i] = __float_as_int(best.w);
+    out_dsq[i] = best_d;
+  } else if (v == GRID_NONE) {
+    out_id[i] = -1;
+    out_dsq[i] = max_range_sq;
+  } else {
+    walk_list[atomicAdd(walk_count, 1u)] = i;
+  }
+}
+
 void grid_free(pcgx_kdtree *t) {
   dev_cache_free(t->d_gpts);
   dev_cache_free(t->d_gstart);
@@ -261,6 +408,38 @@ pcgx_status grid_launch_nearest(const pcgx_kdtree *t, const float *d_q, const in
   }
   PCGX_HIP_TRY(hipGetLastError());
   return launch_nearest_listed(t->view(), d_q, d_list, d_count, nq, max_range_sq, d_ids, d_dsq, st);
+}
+
+// The same for a large batch whose order is the library's to choose (PCGX_KNN_PRESORT): the queries partitioned by
+// coarse cell, searched in that order.
+pcgx_status grid_launch_nearest_partitioned(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range_sq,
+                                            int32_t *d_ids, float *d_dsq, hipStream_t st) {
+  if (nq == 0) return PCGX_OK;
+  Arena &ar = ctx().arena;  // begun by the caller
+  int32_t *d_list = nullptr;
+  uint32_t *d_words = nullptr;  // [8][256] totals, [8][256] cursors, [4096] walk count
+  float4 *d_rec = nullptr;
+  PCGX_TRY(ar.alloc_n((size_t)nq, &d_list));
+  PCGX_TRY(ar.alloc_n(4104, &d_words));
+  PCGX_TRY(ar.alloc_n((size_t)nq, &d_rec));
+  PCGX_HIP_TRY(hipMemsetAsync(d_words, 0, 4104 * sizeof(uint32_t), st));
+  QueryBox box;
+  const float cells[3] = {8.0f, 8.0f, 4.0f};
+  for (int k = 0; k < 3; k++) {
+    const float ext = t->bbox_hi[k] - t->bbox_lo[k];
+    box.lo[k] = t->bbox_lo[k] == t->bbox_lo[k] ? t->bbox_lo[k] : 0.0f;
+    box.scale[k] = (ext > 0.0f && ext < 3.0e38f) ? cells[k] / ext : 0.0f;
+  }
+  const unsigned tiles = (unsigned)((nq + kQpTile - 1) / kQpTile);
+  hipLaunchKernelGGL(qp_hist_kernel, dim3(tiles), dim3(256), 0, st, d_q, nq, box, d_words);
+  hipLaunchKernelGGL(qp_scatter_kernel, dim3(tiles), dim3(256), 0, st, d_q, nq, box, (const uint32_t *)d_words, d_words + 2048, d_rec);
+  {
+    ProfScope prof(PCGX_PROF_KNN_GRID, st);
+    hipLaunchKernelGGL(grid_nearest_rec_kernel, dim3(xcd_grid((unsigned)((nq + kGridBlock - 1) / kGridBlock))), dim3(kGridBlock), 0, st,
+                       t->grid, (const float4 *)d_rec, nq, max_range_sq, d_ids, d_dsq, d_list, d_words + 4096);
+  }
+  PCGX_HIP_TRY(hipGetLastError());
+  return launch_nearest_listed(t->view(), d_q, d_list, d_words + 4096, nq, max_range_sq, d_ids, d_dsq, st);
 }
 
 }  // namespace pcgx

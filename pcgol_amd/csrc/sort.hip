@@ -13,6 +13,7 @@
 // (8 per element round: a match-any on the 8-bit digit), re-orders the tile in
 // LDS by digit and writes each digit run contiguously, so global writes are
 // coalesced runs rather than 4-byte scatters.
+#include <stdlib.h>
 #include <string.h>
 
 #include "pcgx_internal.h"
@@ -573,7 +574,9 @@ pcgx_status morton_order(const float *d_q, int64_t n, const float lo[3], const f
   PCGX_TRY(ar.alloc_n((size_t)n, &vals[1]));
   PCGX_TRY(ar.alloc(radix_sort_workspace_bytes(n), &wsp));
   MortonBox box;
-  box.bits = kMortonBitsPerAxis;
+  static const int bits_env = [] { const char *e = getenv("PCGX_MORTON_BITS"); return e ? atoi(e) : 0; }();
+  const int bits_per_axis = (bits_env >= 1 && bits_env <= 10) ? bits_env : kMortonBitsPerAxis;
+  box.bits = bits_per_axis;
   for (int k = 0; k < 3; k++) {
     const float ext = hi[k] - lo[k];
     box.lo[k] = lo[k] == lo[k] ? lo[k] : 0.0f;
@@ -581,7 +584,7 @@ pcgx_status morton_order(const float *d_q, int64_t n, const float lo[3], const f
   }
   hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_q, n, box, keys[0]);
   int res = 0;
-  PCGX_TRY(radix_sort_pairs(keys, vals, n, 3 * kMortonBitsPerAxis + 1, wsp, &res, st, true));
+  PCGX_TRY(radix_sort_pairs(keys, vals, n, bits_per_axis == kMortonBitsPerAxis ? 3 * kMortonBitsPerAxis + 1 : 3 * bits_per_axis, wsp, &res, st, true));
   if (res != 0) PCGX_HIP_TRY(hipMemcpyAsync(d_perm, vals[res], nb, hipMemcpyDeviceToDevice, st));
   return PCGX_OK;
 }

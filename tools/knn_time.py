@@ -19,3 +19,10 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 10
 ms, cnt = L.prof_read(L.PROF_KNN_GRID)
 print(f"call {dt*1e3:.3f} ms (with timing events), grid kernel {ms/max(cnt,1)*1e3:.1f} us ({cnt} launches)")
+L.prof_enable(0)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    t.NearestBatchDev(dq.data_ptr(), n, 10.0, ids.data_ptr(), dsq.data_ptr(), presort=True)
+torch.cuda.synchronize()
+print(f"call {(time.perf_counter() - t0) / 20 * 1e3:.4f} ms (profiling off)")
