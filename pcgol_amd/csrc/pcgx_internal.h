@@ -349,6 +349,10 @@ const StrictWork *strict_work(StrictBuffers *b, const IcpKernelParams &kp);
 pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
                            double *sums10, const IcpKernelParams &kp, bool fuse_update, bool have_tile_sums, hipStream_t st);
 pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[64], hipStream_t st);
+// strict_check.hip: the same sums by one wave, term after term (the on-device cross-check; set_strict 2)
+pcgx_status strict_check_enqueue(const float *d_xyz, int64_t nt, int64_t nt_pad, const float4 *match, const uint32_t *pos_of,
+                                 IcpState *state, const IcpKernelParams &kp, float *d_terms, unsigned long long *d_valid,
+                                 double *d_sums, bool fuse_update, hipStream_t st);
 // the same sums over a target spread over the ranks of `c` (the sequential order: the ranks' tiles one after the
 // other); local_failed: this rank launches nothing but still takes part in every collective, with its flag up
 pcgx_status strict_enqueue_sharded(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
