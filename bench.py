@@ -199,9 +199,14 @@ def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, ic
                     "walk_kernel_ms": kms / max(kn, 1)}
         if gn > 0:
             kernel_s = gms / gn * 1e-3
-            traffic, src = load_traffic("grid_nearest_kernel<false> [queries in %s order]" % ("Morton" if presort else "caller"))
-            if traffic is None:
-                traffic, src = load_traffic("grid_nearest_kernel")
+            if presort:   # the search kernel of the partitioned path; the whole call's bytes beside it
+                traffic, src = load_traffic("grid_nearest_rec_kernel")
+                call = [load_traffic(k)[0] for k in ("qp_hist_kernel", "qp_scatter_kernel", "grid_nearest_rec_kernel")]
+                out[key]["call_traffic"] = sum(call) if all(c is not None for c in call) else None
+                if out[key]["call_traffic"]:
+                    out[key]["call_frac_traffic"] = out[key]["call_traffic"] / dt / 1e9 / HBM_PEAK_GBS
+            else:
+                traffic, src = load_traffic("grid_nearest_kernel<false>")
             out[key].update({"grid_kernel_ms": gms / gn,
                              "frac_survey_8d": ref / kernel_s / 1e9 / HBM_PEAK_GBS,  # > 1 possible: the grid reads less than the reference's walk
                              "frac_compulsory": (20 * len(c2q) + 16 * tree.Len()) / kernel_s / 1e9 / HBM_PEAK_GBS,

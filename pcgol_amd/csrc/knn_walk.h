@@ -56,7 +56,7 @@
 //     it and in the same relative order, and candidates farther than d* never
 //     decide the outcome (a leaf at d* replaces, a pivot at d* replaces only a
 //     strictly larger best -- the same in both walks).  The returned {id, dist}
-//     hence equals the reference's, exact ties included.
+//     hence equals the reference's, exact ties included (HISTORY.md 3.1).
 //   * with MinDistSq > 0 (approximate, visit-order dependent search) only the
 //     running best is used; the first-descent levels are filtered with the best
 //     right after the verified leaf, which is when the reference tests them.

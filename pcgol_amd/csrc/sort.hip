@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
   }
 }
 
-// Measured and rejected: a single-kernel pass with decoupled look-back
+// Measured and rejected (HISTORY.md 3.2): a single-kernel pass with decoupled look-back
 // ("onesweep": global digit histograms up front, per-(tile, digit) status words walked back with
 // agent-scope loads).  Correct, but 105 us per 10M-pair pass against 91 us for the four launches
 // here: the pass is bound by the VALU work of the ballot ranking, and every look-back hop is a

@@ -13,12 +13,13 @@ from collections import defaultdict
 # element (the sector it costs; 49 G elements/s = 3.1 TB/s of sectors), a random 16-byte row at 64-128
 # bytes.  So: streaming kernels x 2; kernels whose loads are mostly scattered gathers x 1, plus half
 # of their (known) coalesced reads, which the counter under-reports like any streaming read.
-GATHER_KERNELS = ("icp_grid_kernel", "grid_nearest_kernel", "seg_reduce_kernel", "icp_corr_kernel",
+GATHER_KERNELS = ("icp_grid_kernel", "grid_nearest_kernel", "grid_nearest_rec_kernel", "seg_reduce_kernel", "icp_corr_kernel",
                   "nearest_kernel", "range_kernel")
 # coalesced bytes the gather kernels read per launch at the bench's sizes (1M targets / queries, 10M voxel points)
 STREAMED = {"icp_grid_kernel<false": (12 + 16 * 19 / 20) * 1e6,          # target xyz + previous pair (19 of 20 iterations)
             "icp_grid_kernel<true": (12 + 16 * 19 / 20 + 4) * 1e6,       # + matched id
-            "grid_nearest_kernel": (12 + 4) * 1e6,                        # query + its position in the batch
+            "grid_nearest_kernel": 12 * 1e6,                              # queries in the caller's order
+            "grid_nearest_rec_kernel": 16 * 1e6,                          # {x, y, z, index} records, cell after cell
             "seg_reduce_kernel": 8 * 10e6}                                # sorted key + sorted index
 # One VoxelGrid C3 call in kernel launches: the bucket path (csrc/voxel_bucket.hip).  bench.py runs the plain and the
 # chunked filter as often as each other; every kernel below is launched once per call of either (scan_rows twice),
@@ -40,7 +41,7 @@ def short(name):
 
 
 # kernels that bench.py launches first on one kind of input, then as often on another: counters per half
-HALVES = {"grid_nearest_kernel<false>": ("queries in Morton order", "queries in caller order")}
+HALVES = {}   # (round 3: grid_nearest_kernel ran on Morton-ordered, then on caller-ordered queries; the ordered batches have a kernel of their own now)
 
 
 def read_pmc(pattern):

@@ -93,3 +93,37 @@ def test_a_failing_slot_ends_the_fit_on_every_slot(slots, mode, monkeypatch):
     rc, trans, st = _fit_multi(c, trees, tiles, sums_mode=icp.SumsF64Tree if mode else 0)   # and the library still works
     L.check(rc)
     assert st.num_iteration == 20
+
+
+def test_fit_multi_edge_shards(slots):
+    """The reference's sums over slots whose shards are awkward: one slot with NO targets at all, one with a single
+    target, targets that find no partner scattered through the order, a built-in weight (nine chained sums: the sum of
+    the weights goes round the slots like the others) -- Evaluated and pose of the oracle's Fit on the concatenated
+    target, bit for bit."""
+    n = 90_000
+    c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
+    target = c["target"].copy()
+    far = target[::41] + np.float32(50.0)
+    target = np.ascontiguousarray(np.insert(target, np.arange(0, len(far)) * 33, far, axis=0))
+    trees = _trees(c["base"], slots)
+    tiles = [np.ascontiguousarray(target[:0]), np.ascontiguousarray(target[:1]), np.ascontiguousarray(target[1:])]
+    wf = icp.WeightHuber(0.0009)
+    O.set_weight_fn(wf.kind, wf.a)
+    try:
+        n_s = len(trees)
+        params = icp._params(0.05, 0.0, c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"], weight_fn=wf)
+        bases = (C.c_void_p * n_s)(*[t._h for t in trees])
+        tps = (C.c_void_p * n_s)(*[t.ctypes.data for t in tiles])
+        nts = (C.c_int64 * n_s)(*[len(t) for t in tiles])
+        trans = np.empty(16, np.float32)
+        st = L.IcpStat()
+        L.check(L.lib().pcgx_icp_fit_multi(n_s, bases, tps, nts, C.byref(params), L.ptr(trans), C.byref(st)))
+        o32 = O.icp_fit(O.KDTree(c["base"]), target, 0.05, c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"],
+                        sums_mode=0)
+        assert st.num_iteration == o32["num_iteration"]
+        assert np.array_equal(trans.ravel(), np.asarray(o32["trans"]).ravel())
+        assert np.float32(st.evaluated.value) == o32["value"]
+        assert np.array_equal(np.array(st.evaluated.gradient, np.float32), o32["gradient"])
+        assert 6 <= st.evaluated.num_pairs < len(target)
+    finally:
+        O.set_weight_fn(0, 0.0)

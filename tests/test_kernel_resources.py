@@ -1,6 +1,6 @@
 """No kernel of the ICP step (and of the VoxelGrid bucket path) may spill: hipcc's own resource report
 (-Rpass-analysis=kernel-resource-usage, tools/kernel_resources.py) for the production instantiations.
-DESIGN.md records what spilled dwords cost on this chip (5 us phases became 40 us ones); round 3 shipped
+HISTORY.md (3.9) records what spilled dwords cost on this chip (5 us phases became 40 us ones); round 3 shipped
 strict_sum_kernel with 8 bytes of scratch per lane under its occupancy attribute."""
 import os
 import sys
