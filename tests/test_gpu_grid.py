@@ -275,3 +275,28 @@ def test_icp_strict_fit_grid_equals_walk_on_random_setups(monkeypatch):
             assert a == b, case
         else:
             assert np.array_equal(a[0], b[0]) and a[1:] == b[1:], (case, a[1:], b[1:])
+
+
+def test_large_batch_partitioned_by_coarse_cell_equals_the_oracle():
+    """A batch large enough for the library to choose its own search order (>= 2^18 queries from host pointers): the
+    queries are partitioned by an 8-bit coarse cell (csrc/knn_grid.hip, qp_* kernels) and searched in that order.
+    Queries inside the cloud, far outside its box (they clamp to the faces' cells), on exact base points, NaN and
+    infinite ones (the walk answers those), a maxRange that leaves most without a partner: ids and DistSq bits of the
+    oracle, in the caller's order."""
+    base = synth.uniform_cloud(200_000, 4.0, 31)
+    rng = np.random.default_rng(5)
+    n = 300_000
+    q = synth.uniform_cloud(n, 4.0, 32)
+    q[::7] = q[::7] * f32(3.0) - f32(4.0)                 # far outside on all sides
+    q[1::1000] = base[rng.integers(0, len(base), len(q[1::1000]))]   # exact hits
+    q[5::9973] = np.nan
+    q[11::9973, 1] = np.inf
+    q[13::9973, 2] = -np.inf
+    t, o = kdtree.New(base), O.KDTree(base)
+    for max_range in (10.0, 0.02):
+        ids, dsq = t.NearestBatch(q, max_range)
+        oi, od = o.nearest_batch(q, max_range)
+        assert np.array_equal(ids, oi), max_range
+        nan = np.isnan(od)
+        assert np.array_equal(np.isnan(dsq), nan), max_range                       # (a NaN's payload is not pinned)
+        assert np.array_equal(dsq[~nan].view(np.uint32), od[~nan].view(np.uint32)), max_range
