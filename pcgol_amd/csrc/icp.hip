@@ -160,6 +160,11 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
   __shared__ double s_tile_part[kIcpBlock / 64][kStrictRows];
+  if (kGrid && !kSums) {  // (both words in one round trip: a strict session's launch usually finds nothing to walk)
+    const uint32_t left0 = walk_count[block_slot(blockIdx.x, gridDim.x)];
+    const int done0 = state->done;
+    if (done0 || (left0 == 0 && !tile_sums)) return;  // uniform
+  }
   if (state->done) return;  // uniform
   // strict sessions (kGrid, no sums here): on its way out the workgroup forms the float64 tile sums the
   // summary kernel's guesses start from (strict_terms.h) -- the pairs are all in place (icp_grid_kernel)
@@ -315,7 +320,9 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
     const uint32_t *__restrict__ orig_of = nullptr, float4 *__restrict__ match_caller = nullptr) {
   constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
   __shared__ float s_terms[NS][kIcpGridBlock + 16];  // + 16: the kSub-lane groups of one wave land on different banks
-  if (state->done) return;  // uniform
+  // ("done" is looked at behind the target's loads, which it would only hold up: a workgroup of this kernel is five
+  // dependent round trips long, this was one of them; nothing is written before)
+  const int done = state->done;
   // targets are stored in cell order: an XCD takes a contiguous eighth of them (pcgx_internal.h, xcd_tile)
   // (without the sums a workgroup may be smaller than kIcpGridBlock: kIcpStrictGridBlock)
   const uint32_t block = kSums ? (uint32_t)kIcpGridBlock : blockDim.x;
@@ -326,12 +333,19 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
   double acc[NS];
 #pragma unroll
   for (int k = 0; k < NS; k++) acc[k] = 0.0;
+  const bool project = state->iter > 0;  // icp.go:27-30
+  float x = 0.0f, y = 0.0f, z = 0.0f;
+  float4 pm = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
   if (i < nt) {
-    const bool project = state->iter > 0;  // icp.go:27-30
-    float x = tx[i], y = ty[i], z = tz[i];
+    x = tx[i];
+    y = ty[i];
+    z = tz[i];
+    if (project) pm = match[i];  // previous iteration's pair (w = NaN before the first one)
+  }
+  if (done) return;  // uniform
+  if (i < nt) {
     float ub = __builtin_inff();
     if (project) {
-      const float4 pm = match[i];  // previous iteration's pair (w = NaN before the first one)
       const float *m = state->trans;
       float px, py, pz;
       mat4_transform(m, x, y, z, px, py, pz);
