@@ -62,7 +62,16 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // Wall-clock reads for the debug counters' tick columns (tools/strict_probe.py) and the PCGX_STRICT_TRACE stamps.
 // Off unless asked for (PCGX_STRICT_CLOCKS / PCGX_STRICT_TRACE): an s_memrealtime is a round trip of its own,
 // and the chain kernel's walker would make two per chunk and two per tile it has resolved.
-__device__ __forceinline__ long long stat_clock(const StrictWork &W) { return (W.selfcheck & 10) ? (long long)wall_clock64() : 0ll; }
+__device__ __forceinline__ long long stat_clock(const StrictWork &W) { return (W.selfcheck & 8) ? (long long)wall_clock64() : 0ll; }
+// (PCGX_STRICT_TRACE alone: a stamp when a workgroup comes and when it goes, and where it says so; nothing inside the walk)
+__device__ __forceinline__ long long trace_clock(const StrictWork &W) { return (W.selfcheck & 10) ? (long long)wall_clock64() : 0ll; }
+// a stamp that cannot be taken before `dep` is known (the clock read has no inputs of its own: the compiler moves it
+// up past the arithmetic it is meant to time)
+__device__ __forceinline__ unsigned long long clock_after(uint32_t dep) {
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(dep) : "memory");
+  return t;
+}
 
 // A tile's terms of one row, 2048 floats as 512 quads: quad v (terms 4v .. 4v + 3) of leaf l sits at
 // float4 index v * 64 + (l ^ v).  In LDS the 64 lanes of a wave read their leaves' quad v without bank
@@ -384,7 +393,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tile = blockIdx.x;
   const int NR = W.nrows;
-  const long long t_0 = stat_clock(W);
+  const long long t_0 = trace_clock(W);
   long long t_x0 = 0;
   // the float64 prefix of this wave's row (strict_tilesum_kernel's sums): its loads fly while phase 1 runs
   double P0 = (!kExchange && wave < NR) ? tile_prefix(W.tile_sum, W.ntiles, wave, tile, lane) : 0.0;
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
       if (lane == 63) s_tot[row] = pre + lsum;
     }
     __syncthreads();
-    t_x0 = stat_clock(W);
+    t_x0 = trace_clock(W);
     if (wave == 0) {
       if (lane < NR) {
         const double v = s_tot[lane];
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
     __syncthreads();
   }
-  const long long t_1 = stat_clock(W);
+  const long long t_1 = trace_clock(W);
   // ---- phase 2: every wave its row (one pass unless a weight function adds the ninth row)
   for (int row = wave; row < NR; row += kSumWaves) {
     if (kExchange) P0 = tile_prefix_pub(W.tile_pub, W.ntiles_pad, row, tile, lane);
@@ -596,7 +605,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     W.stamps[tile * 16 + 0] = (unsigned long long)t_0;
     W.stamps[tile * 16 + 1] = (unsigned long long)t_1;
     W.stamps[tile * 16 + 2] = (unsigned long long)t_x0;
-    W.stamps[tile * 16 + 5] = (unsigned long long)stat_clock(W);
+    W.stamps[tile * 16 + 5] = (unsigned long long)trace_clock(W);
   }
 }
 
@@ -606,6 +615,10 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
 // cover the state in one parallel step and carries on behind it), or wave 0 alone composes the runs of
 // leaves under equal windows (no window: the chain kernel applies a run's last record).
 constexpr int kJobBlock = 512;  // waves 0..3: a class each, then the scans; waves 4..7: candidate chains
+template <bool kRegs>
+__device__ __forceinline__ uint32_t resolve_staged(uint32_t s, int kind, int32_t key, const LeafAux &A, int lane,
+                                               const float4 *lds, const float *t, int &serial_out, int &tried_out,
+                                               int &applied_out);
 __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *__restrict__ state, StrictWork W) {
   __shared__ float4 s_t[kTile / 4];    // the tile's terms, a leaf per lane (tile_quad)
   __shared__ float4 s_lin[kTile / 4];  // ... and leaf after leaf, for the chains that add them up one after the other
@@ -637,38 +650,32 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   const int row = J->row;
   const int64_t tile = J->tile;
   const int32_t pad = J->pad;
-  const long long tj_0 = stat_clock(W);
+  const long long tj_0 = trace_clock(W);
   __syncthreads();
-  const long long tj_1 = stat_clock(W);
+  const long long tj_1 = trace_clock(W);
   auto stamp_end = [&](int what) {
     if ((W.selfcheck & 2) && lane == 0) {
       W.stamps[tile * 16 + 6] = (unsigned long long)tj_0;
       W.stamps[tile * 16 + 7] = (unsigned long long)tj_1;
-      atomicMax(&W.stamps[tile * 16 + 8 + (part >= 4 ? 1 : 0)], (unsigned long long)stat_clock(W));
+      atomicMax(&W.stamps[tile * 16 + 8 + (part >= 4 ? 1 : 0)], (unsigned long long)trace_clock(W));
       W.stamps[tile * 16 + 10] = (unsigned long long)(what | (row << 8));
     }
   };
-  if (tile < kExactTiles && W.first_exact) {  // uniform
-    // the first tile of a row, exactly, from 0.0f: the terms broadcast out of LDS a leaf ahead of the chain, so
-    // that the dependent path is the additions alone (one every 6 cycles: a wave that has its SIMD nearly to
-    // itself, as here, does the 2048 in ~6 us; out of registers through v_readlane each costs 10)
-    if (part == 0) {
-      __builtin_amdgcn_s_setprio(3);  // (the longest chain of the launch: ahead of whatever shares its SIMD)
-      float x1[1] = {0.0f};
-      serial_leaves_lin(x1, s_lin, 0, kLanes);
-      const uint32_t x = f2u(x1[0]);
-      __builtin_amdgcn_s_setprio(0);
-      TileRec R;
-      R.s = summary_identity();
-      R.key = -1;
-      R.in = f2u(0.0f);
-      R.out = x;
-      R.cons = 1;  // (a point record that owns nothing the chain kernel would fetch)
-      if (lane == 0) W.recs[row * W.ntiles + tile] = R;
-      stamp_end(3);
+  // The first tile of a row starts from 0.0f, and exactly so (evaluator.go:122): its job carries the tile out from
+  // there.  Its sum runs through a binade every few terms at first, so no window holds the tile -- it is summarised
+  // leaf by leaf like any tile without one, and wave 0 then walks the leaves' runs itself: the few leaves at the
+  // start whose windows do not hold the state are added term by term (C4: 1 to 7 of the 64), the others are one
+  // apply() per run.  (Round 3 added all 2048 terms one after the other: 10 us of dependent additions.)
+  const bool first = tile < kExactTiles && W.first_exact;  // uniform
+  // (PCGX_STRICT_TRACE: wave 0's way through the job, words 11 .. 15 of the tile's line -- the rows' own stamps are in
+  // the first lines, strict_chain_kernel)
+  const bool traced = (W.selfcheck & 2) && part == 0 && !first && tile > kStrictRows;
+  auto stage = [&](int word, uint32_t dep) {
+    if (traced) {
+      const unsigned long long tt = clock_after(dep);
+      if (lane == 0) W.stamps[tile * 16 + word] = tt;
     }
-    return;
-  }
+  };
   // ---- wave 0: the leaves' guesses once more, now from a start state that includes the rounding errors
   // the float32 chain has made in all tiles before this one (strict_sum_kernel's tile_err, known only
   // after that launch): where a sum has come back towards zero the float64 prefix alone is off by 10^5
@@ -694,7 +701,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     const bool one_sign = __ballot(cr.sg_or != cr.sg_and) == 0ull &&
                           (__ballot(cr.sg_or != 0u) == 0ull || __ballot(cr.sg_or == 0u) == 0ull);
     const uint32_t g_first = (uint32_t)rfl((int)g);
-    const int32_t key = one_sign ? choose_window(mn, mx, g_first >> 31, g_first & 0x7fffffffu) : -1;
+    const int32_t key = (one_sign && !first) ? choose_window(mn, mx, g_first >> 31, g_first & 0x7fffffffu) : -1;
     const uint32_t g_next = (uint32_t)__shfl_down((int)g, 1);
     const bool cons = __ballot(lane < 63 && g_next != cr.end) == 0ull;
     s_g[lane] = g;
@@ -705,6 +712,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     const uint32_t m_lo = mn & 0x7fffffu, m_hi = mx & 0x7fffffu;
     const bool stands = (pad & 1) && key >= 0 && (mn >> 23) == (mx >> 23) && (int32_t)(mn >> 23) == (pad >> 8) &&
                         m_lo >= kPlainMargin && m_hi <= 0x7fffffu - kPlainMargin;
+    stage(11, g ^ (uint32_t)key);
     if (lane == 0) {
       s_hdr[0] = key;
       s_hdr[1] = (int32_t)g_first;
@@ -727,6 +735,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     s_S[part][lane] = c;
     s_S[4 + part][lane] = lo;
     s_S[8 + part][lane] = hi;
+    stage(12, (uint32_t)(c ^ lo ^ hi));
     lds_fence_wave();
     if (lane == 0) __hip_atomic_fetch_add(&s_pieces, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
@@ -738,6 +747,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   // leaf runs to apply, a dozen leaves to add term by term), a level crossing whose record does not cover the state
   // 1-2 us; if the walker's state is one of the candidates the tile is a look-up.  Four candidates per lane: four
   // independent chains cost 1.9x one (tools/micro/dep_add.cpp).
+  if (first && part >= 1) return;  // (no candidates: the state the tile starts from is known)
   if (kind == JOB_NOWINDOW && part >= 1) {
     // no window: waves 1..6, the whole tile from 768 candidates around the tile's guess, two per lane (two
     // independent chains cost 1.3x one, four 1.9x, tools/micro/dep_add.cpp: 7-8 us where three waves with four
@@ -822,6 +832,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     S.lo[r] = s_S[4 + r][lane];
     S.hi[r] = s_S[8 + r][lane];
   }
+  stage(13, (uint32_t)(S.c[0] ^ S.c[3] ^ S.hi[3]));
   TileRec R;
   R.s = summary_identity();
   R.key = tkey;
@@ -836,6 +847,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
         const Summary X = shfl_summary(P, lane - o);
         if (lane >= o) P = compose(X, P);
       }
+      stage(14, (uint32_t)(P.c[0] ^ P.hi[3]));
       W.aux[(size_t)slot * kLanes + lane].pre = P;
       R.s = shfl_summary(P, 63);
       if (lane == 0) W.recs[row * W.ntiles + tile] = R;
@@ -865,11 +877,24 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     L.key = lk;
     L.pad[0] = L.pad[1] = L.pad[2] = 0;
     L.run = P;
+    stage(14, (uint32_t)(P.c[0] ^ P.hi[3]));
+    if (first) {
+      LeafAux A;
+      __builtin_memset(&A, 0, sizeof A);
+      __builtin_memcpy(&A, &L, sizeof L);  // (resolve_staged reads a LeafRec out of a LeafAux)
+      int serial, tried, applied;
+      R.key = -1;
+      R.in = f2u(0.0f);
+      R.out = resolve_staged<false>(f2u(0.0f), JOB_NOWINDOW, -1, A, lane, s_t, nullptr, serial, tried, applied);
+      R.cons = 1;  // (a point record that owns nothing the chain kernel would fetch)
+      if (lane == 0) W.recs[row * W.ntiles + tile] = R;
+      stamp_end(3);
+      return;
+    }
     *reinterpret_cast<LeafRec *>(&W.aux[(size_t)slot * kLanes + lane]) = L;
     R.key = -1;
     if (lane == 0) W.recs[row * W.ntiles + tile] = R;
   }
-  if (part == 0) { atomicMax(&W.stamps[tile * 16 + 13], (unsigned long long)stat_clock(W)); }
 }
 
 // ---- chain -----------------------------------------------------------------------------------------
@@ -1107,6 +1132,9 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   __shared__ float4 s_tile[kTile / 4];     // walker: the terms of a tile without a slot, formed again from the pairs
   __shared__ unsigned long long s_np;
   __shared__ int s_np_ok;
+  __shared__ uint32_t s_stat[8];
+  __shared__ unsigned long long s_wk[8];  // PCGX_STRICT_CLOCKS: where the walker's ticks go
+  __shared__ unsigned long long s_stat_ticks[2];
   const int done = state->done;  // (looked at behind the first chunk's loads, which it would only hold up)
   // (rfl: "which wave" is the same in all lanes, and the compiler has to know -- or the branch between walker and
   // helpers counts as divergent, the walker's state becomes a vector register, and every apply() of the walk runs
@@ -1126,6 +1154,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   uint32_t n_run = 0, n_runfail = 0, n_recfail = 0, n_tab_nw = 0, n_tab_cross = 0;
   asm volatile("" : "+v"(n_run), "+v"(n_runfail), "+v"(n_recfail), "+v"(n_tab_nw), "+v"(n_tab_cross));
   unsigned long long ticks_scan = 0, ticks_walk = 0;
+  const long long t_enter = trace_clock(W);  // (PCGX_STRICT_TRACE: the row's stamps)
   for (int64_t chunk = 0; chunk < W.ntiles; chunk += kChainTiles) {
     const long long t_a = stat_clock(W);
     if (threadIdx.x < kChainSegs) {
@@ -1138,6 +1167,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       s_progress = 0;
       if (chunk == 0) s_np_ok = 0;
     }
+    if (chunk == 0 && threadIdx.x < 8) s_wk[threadIdx.x] = 0ull;
     // ---- helpers: runs of equal windows, segmented scan forwards inside each wave
     TileRec R;
     R.key = -2;
@@ -1324,55 +1354,84 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     } else {
       // ---- the walk: one wave, every lane with the same state
       const long long t_b = stat_clock(W);
-      // The runs of the chunk, 64 at a time: lane j fetches run j's ends and its composed record, the walk then
-      // takes them out of the registers one after the other (a run that covers the state costs sixteen
-      // v_readlane and the apply; fetched from LDS run by run, two dependent LDS round trips each came first).
+      // The runs of the chunk, sixteen at a time: the four lanes 4 j .. 4 j + 3 fetch run j's ends and its composed
+      // record, lane 4 j + r the piece of class r.  The walk then takes a run out of the registers: its window, and --
+      // once the state says which class it is in -- that class's bounds and step from lane 4 j + r: five v_readlane
+      // for a run that covers the state.  (A wave issues one instruction every four cycles, scalar ones included: with
+      // a whole record per lane the sixteen v_readlane and the scalar selects behind them made a run ~80
+      // instructions, 0.33 us, and a row's fifteen runs 5 of the 7.5 us its walk takes.)
+      constexpr int kBatch = kLanes / 4;
       int seg_base[kChainSegs + 1];
       seg_base[0] = 0;
 #pragma unroll
       for (int w = 0; w < kChainSegs; w++) seg_base[w + 1] = seg_base[w] + s_count[w];
       const int n_runs = seg_base[kChainSegs];
-      for (int r0 = 0; r0 < n_runs; r0 += kLanes) {
+      for (int r0 = 0; r0 < n_runs; r0 += kBatch) {
+        const long long t_f0 = stat_clock(W);
+        const int my_run = r0 + (lane >> 2), my_class = lane & 3;
         int e_l = 0, h_l = 0;
-        TileRec R_l;
-        R_l.key = -2;
-        R_l.in = R_l.out = 0u;
-        R_l.cons = 0;
-        R_l.s = summary_identity();
-        if (r0 + lane < n_runs) {
+        int32_t key_l = -2, cons_l = 0, c_l = 0, lo_l = kBig, hi_l = -kBig;
+        uint32_t in_l = 0u, out_l = 0u;
+        if (my_run < n_runs) {
           int idx = 0;
 #pragma unroll
           for (int w = 0; w < kChainSegs; w++)
-            if (r0 + lane >= seg_base[w] && r0 + lane < seg_base[w + 1]) idx = w * 64 + (r0 + lane - seg_base[w]);
+            if (my_run >= seg_base[w] && my_run < seg_base[w + 1]) idx = w * 64 + (my_run - seg_base[w]);
           e_l = s_tail[idx];
           h_l = s_head[idx];
-          R_l = rec_get(s_pre, e_l);
+          key_l = s_pre[0][e_l];
+          in_l = (uint32_t)s_pre[1][e_l];
+          out_l = (uint32_t)s_pre[2][e_l];
+          cons_l = s_pre[3][e_l];
+          c_l = s_pre[4 + my_class][e_l];
+          lo_l = s_pre[8 + my_class][e_l];
+          hi_l = s_pre[12 + my_class][e_l];
         }
-        const int n_here = n_runs - r0 < kLanes ? n_runs - r0 : kLanes;
+        const int n_here = n_runs - r0 < kBatch ? n_runs - r0 : kBatch;
+        // (the records are in their registers HERE: left to the compiler, the wait for them sits at the top of the
+        // loop below, where every turn it also waits for the turn before's store of the progress word)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(key_l), "+v"(in_l), "+v"(out_l), "+v"(cons_l), "+v"(c_l), "+v"(lo_l), "+v"(hi_l), "+v"(e_l), "+v"(h_l));
+        if ((W.selfcheck & 8)) {
+          const unsigned long long tt = clock_after((uint32_t)(key_l ^ hi_l ^ e_l));
+          if (lane == 0) s_wk[4] += tt - (unsigned long long)t_f0;
+        }
+        const long long t_j0 = stat_clock(W);
         for (int j = 0; j < n_here; j++) {
-          const int e = __builtin_amdgcn_readlane(e_l, j), h = __builtin_amdgcn_readlane(h_l, j);
+          const int l0 = 4 * j;
           n_run++;
           {
-            TileRec Qr;  // the whole run
-            Qr.key = __builtin_amdgcn_readlane(R_l.key, j);
-            Qr.in = (uint32_t)__builtin_amdgcn_readlane((int)R_l.in, j);
-            Qr.out = (uint32_t)__builtin_amdgcn_readlane((int)R_l.out, j);
-            Qr.cons = __builtin_amdgcn_readlane(R_l.cons, j);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              Qr.s.c[q] = __builtin_amdgcn_readlane(R_l.s.c[q], j);
-              Qr.s.lo[q] = __builtin_amdgcn_readlane(R_l.s.lo[q], j);
-              Qr.s.hi[q] = __builtin_amdgcn_readlane(R_l.s.hi[q], j);
-            }
             const uint32_t s_in = s;
-            if ((Qr.key >= 0 && apply(s, Qr.key, Qr.s)) || apply_point(s, Qr)) {
-              selfcheck<kCheck>(W, term_src, row, s_in, s, chunk + h, chunk + e + 1, 0, lane, s_tile);
-              // (a hint for helpers whose tile the walk has passed: no ordering needed)
-              if (lane == 0) __hip_atomic_store(&s_progress, e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // apply() (strict_sum.h: state_to_n, the class's bounds, n_to_state) without a branch before the verdict:
+            // the walker's time is its instruction count (a taken branch costs several issue slots)
+            const int32_t key = __builtin_amdgcn_readlane(key_l, l0);
+            const int32_t sg = (int32_t)(s >> 31), E = (int32_t)((s >> 23) & 0xffu), e = key & 0xff;
+            const int32_t mant = (int32_t)((s & 0x7fffffu) | 0x800000u);
+            const int32_t n = E == e ? mant << 1 : mant;
+            const int in_window = (int)(key >= 0) & (int)(sg == (key >> 8)) & ((int)(E == e) | (int)(E == e - 1));
+            const int lc = l0 | (n & 3);
+            const int32_t lo = __builtin_amdgcn_readlane(lo_l, lc), hi = __builtin_amdgcn_readlane(hi_l, lc);
+            const int32_t m = n + __builtin_amdgcn_readlane(c_l, lc);
+            const uint32_t sgb = (uint32_t)sg << 31;
+            const uint32_t below = sgb | ((uint32_t)(e - 1) << 23) | ((uint32_t)m & 0x7fffffu);
+            const uint32_t above = sgb | ((uint32_t)e << 23) | (((uint32_t)m >> 1) & 0x7fffffu);
+            bool ok = (in_window & (int)(n >= lo) & (int)(n <= hi)) != 0;
+            s = ok ? (m < N24 ? below : above) : s;
+            if (!ok && (__builtin_amdgcn_readlane(cons_l, l0) & 1) && (uint32_t)__builtin_amdgcn_readlane((int)in_l, l0) == s) {
+              s = (uint32_t)__builtin_amdgcn_readlane((int)out_l, l0);  // apply_point()
+              ok = true;
+            }
+            if (ok) {
+              selfcheck<kCheck>(W, term_src, row, s_in, s, chunk + __builtin_amdgcn_readlane(h_l, l0),
+                                chunk + __builtin_amdgcn_readlane(e_l, l0) + 1, 0, lane, s_tile);
+              // (a hint for helpers whose tile the walk has passed: no ordering needed; every lane stores the same word)
+              __hip_atomic_store(&s_progress, __builtin_amdgcn_readlane(e_l, l0) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               continue;
             }
           }
+          const int e = __builtin_amdgcn_readlane(e_l, l0), h = __builtin_amdgcn_readlane(h_l, l0);
           n_runfail++;
+          const long long t_fail = stat_clock(W);
           // which tile?  lane j tries the composition h .. h + j
           int f = h;
           if (e > h) {
@@ -1421,8 +1480,10 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
                   __hip_atomic_store(&M->s_in, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                   lds_put(&M->req, ord + 1);
                 }
+                const long long t_m = stat_clock(W);
                 while (lds_get(&M->ack) != ord + 1) {
                 }
+                if ((W.selfcheck & 8) && lane == 0) { s_wk[1] += (unsigned long long)(stat_clock(W) - t_m); s_wk[2] += 1ull; }
                 s = (uint32_t)rfl((int)__hip_atomic_load(&M->s_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
               } else {  // a tile without a slot: its terms are formed again from the pairs, all 2048 are added
                 const long long t_begin = stat_clock(W);
@@ -1437,8 +1498,10 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             selfcheck<kCheck>(W, term_src, row, s_in, s, chunk + f, chunk + f + 1, 2, lane, s_tile);
             f++;
             if (f > e) break;
+            const long long t_s = stat_clock(W);
             while (lds_get(&s_sufok[f >> 6]) == 0) {
             }
+            if ((W.selfcheck & 8) && lane == 0) s_wk[3] += (unsigned long long)(stat_clock(W) - t_s);
             const TileRec Sf = load_rec_uniform(s_suf, f);  // the rest of the run in one step
             const uint32_t s_in2 = s;
             if ((Sf.key >= 0 && apply(s, Sf.key, Sf.s)) || apply_point(s, Sf)) {
@@ -1447,28 +1510,46 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             }
           }
           if (lane == 0) lds_put(&s_progress, e + 1);
+          if ((W.selfcheck & 8) && lane == 0) s_wk[0] += (unsigned long long)(stat_clock(W) - t_fail);
+        }
+        if (W.selfcheck & 8) {
+          const unsigned long long tt = clock_after(s);
+          if (lane == 0) s_wk[5] += tt - (unsigned long long)t_j0;
         }
       }
       if (lane == 0) {
         lds_put(&s_progress, 1 << 30);  // helpers that still wait for a tile: the chunk is done
         ticks_scan += (unsigned long long)(t_b - t_a);
         ticks_walk += (unsigned long long)(stat_clock(W) - t_b);
+        // (the row's counters so far: a helper adds them to the launch's behind the last chunk -- a dozen atomics
+        // that the walker's own release, in front of its ticket, would wait for)
+        s_stat[0] = n_run; s_stat[1] = n_runfail; s_stat[2] = n_recfail; s_stat[3] = n_tab_nw; s_stat[4] = n_tab_cross;
+        s_stat_ticks[0] = ticks_scan; s_stat_ticks[1] = ticks_walk;
       }
     }
     __syncthreads();
   }
-  if (walker && lane == 0) {
-    atomicAdd(&W.dbg[0], (unsigned long long)n_run);
-    atomicAdd(&W.dbg[1], (unsigned long long)n_runfail);
-    atomicAdd(&W.dbg[4], (unsigned long long)n_recfail);
-    atomicAdd(&W.dbg[8], ticks_scan);
-    atomicAdd(&W.dbg[9], ticks_walk);
-    atomicMax(&W.dbg[14 + 32], ticks_walk);   // slowest row of the launch
-    atomicAdd(&W.dbg[27 + row], ticks_walk);  // per row: walk ticks, tiles resolved
-    atomicAdd(&W.dbg[36 + row], (unsigned long long)n_recfail);
-    atomicAdd(&W.dbg[24], (unsigned long long)n_tab_nw);  // tiles without a window seen, and found in their candidate tables
-    atomicAdd(&W.dbg[25], (unsigned long long)n_tab_nw);
-    atomicAdd(&W.dbg[45], (unsigned long long)n_tab_cross);
+  if (wave == 0 && lane == 0) {
+    const unsigned long long scan_ticks = s_stat_ticks[0], walk_ticks = s_stat_ticks[1];
+    atomicAdd(&W.dbg[0], (unsigned long long)s_stat[0]);
+    atomicAdd(&W.dbg[1], (unsigned long long)s_stat[1]);
+    atomicAdd(&W.dbg[4], (unsigned long long)s_stat[2]);
+    atomicAdd(&W.dbg[8], scan_ticks);
+    atomicAdd(&W.dbg[9], walk_ticks);
+    atomicMax(&W.dbg[14 + 32], walk_ticks);   // slowest row of the launch
+    atomicAdd(&W.dbg[27 + row], walk_ticks);  // per row: walk ticks, tiles resolved
+    if (W.selfcheck & 8) {  // (the rows' own counts of tiles resolved give way to the walkers' tick columns)
+      for (int k = 0; k < 6; k++) atomicAdd(&W.dbg[36 + k], s_wk[k]);
+    } else {
+      atomicAdd(&W.dbg[36 + row], (unsigned long long)s_stat[2]);
+    }
+    atomicAdd(&W.dbg[24], (unsigned long long)s_stat[3]);  // tiles without a window seen, and found in their candidate tables
+    atomicAdd(&W.dbg[25], (unsigned long long)s_stat[3]);
+    atomicAdd(&W.dbg[45], (unsigned long long)s_stat[4]);
+  }
+  if (walker && lane == 0 && (W.selfcheck & 2)) {  // (row r's stamps ride in tile r's line: words 11, 15)
+    W.stamps[row * 16 + 11] = (unsigned long long)t_enter;
+    W.stamps[row * 16 + 15] = (unsigned long long)trace_clock(W);
   }
   if (row == 0 && walker && lane == 0) {
     while (lds_get(&s_np_ok) == 0) __builtin_amdgcn_s_sleep(1);
@@ -1503,7 +1584,13 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       if (W.exchange)
         for (int64_t k = 0, n = (W.ntiles + 31) / 32, m = n + (n + 31) / 32; k < m; k++) W.tile_arrived[32 * k] = 0u;
       *W.done_rows = 0u;
+      const long long t_u0 = trace_clock(W);
       if (fuse_update) icp_update_step(state, sums, kp);
+      if (W.selfcheck & 2) {  // (the launch's last steps, in the line behind the rows')
+        __threadfence();
+        W.stamps[kStrictRows * 16 + 14] = (unsigned long long)t_u0;
+        W.stamps[kStrictRows * 16 + 15] = (unsigned long long)trace_clock(W);
+      }
     }
   }
 }

@@ -34,6 +34,7 @@ for k in range(c["max_iteration"]):
         k, "OK " if ok else "MISMATCH", st[0], st[1], st[2], st[5], st[3], st[4], st[8] / 900.0, st[9] / 900.0, st[10] / 900.0, st[11] / 900.0), "slowest row walk %.1f us" % (st[46] / 100.0), "selfcheck bad: run %d prefix %d tile %d suffix %d; scan != serial composition %d, other result %d" % (tuple(st[12:16]) + (st[6], st[7])))
     print("      no window: %d tiles, %d runs tried, %d applied, %d leaves serial, %.1f us each (candidate hits %d of %d) | crossing: %d tiles, %d leaves serial, %.1f us each" % (
         st[16], st[17], st[18], st[22], st[19] / 100.0 / max(st[16], 1), st[25], st[24], st[20], st[23], st[21] / 100.0 / max(st[20], 1)))
+    print("      walker, us/row: in failed runs %.1f (waiting for a helper %.1f, %d times; for the backward scan %.1f); fetching the runs' records %.1f, all runs %.1f" % (st[36] / 900.0, st[37] / 900.0, st[38], st[39] / 900.0, st[40] / 900.0, st[41] / 900.0))
     if st[5]:
         print("      last tile without a slot that was recomputed: %d, guess %08x, state %08x" % (st[45], int(st[47]) >> 32, int(st[47]) & 0xffffffff))
     for q in range(0):
