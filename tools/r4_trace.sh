@@ -2,7 +2,7 @@
 # per-workgroup wall-clock stamps of strict_sum_kernel (PCGX_STRICT_TRACE): start, terms formed, exchange done, end
 mkdir -p gpurun_out
 rm -f gpurun_out/r4_trace.txt
-PCGX_STRICT_TRACE=gpurun_out/r4_trace.txt timeout -k 10 300 python tools/strict_probe.py > gpurun_out/r4_trace.log 2>&1
+PCGX_STRICT_TRACE=gpurun_out/r4_trace.txt timeout -k 10 300 python tools/strict_trace_run.py > gpurun_out/r4_trace.log 2>&1
 echo rc=$?; grep "^strict 1\|final\|MISMATCH" gpurun_out/r4_trace.log
 python3 - <<'PY'
 import numpy as np
