@@ -237,6 +237,11 @@ def lib():
             raise ImportError("pcgol_amd/libpcgx.so is missing: run `python -c 'import __graft_entry__ as g; "
                               "g.build()'` (hipcc, gfx950). There is no CPU fallback.")
         # PyTorch-ROCm wheels bundle their own HIP runtime (same soname as /opt/rocm's).  One process
+        if not os.environ.get("PCGX_LIB"):
+            from . import build as _build
+            if _build.stale():
+                raise ImportError("pcgol_amd/libpcgx.so was not built from the sources beside it (csrc/ changed since): "
+                                  "run `python -c 'import __graft_entry__ as g; g.build()'`")
         # must use ONE runtime: when torch is installed, load it first so that libpcgx.so binds to
         # the runtime torch (and RCCL) will use; loading libpcgx first was seen to make a later
         # ProcessGroupNCCL report "no GPUs found".  Without torch the system runtime is used.

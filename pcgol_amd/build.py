@@ -44,8 +44,10 @@ def source_hash():
 def needs_build():
     if not os.path.exists(SO):
         return True
+    if stale():
+        return True
     t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -75,7 +77,19 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc failed")
     cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] + objs + ["-lpthread", "-ldl"]
     subprocess.check_call(cmd)  # (-ldl is part of libc on this image; RCCL is bound at run time, csrc/comm.hip)
+    with open(SO + ".hash", "w") as f:  # what the library was built from (_lib.py refuses a library older than its sources)
+        f.write(source_hash() + "\n")
     return SO
+
+
+def stale():
+    """True when libpcgx.so was built from other sources than the ones beside it (a checkout, an edit): measuring or
+    testing such a library says nothing about the tree."""
+    try:
+        with open(SO + ".hash") as f:
+            return f.read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 if __name__ == "__main__":
