@@ -103,57 +103,53 @@ int32_t build_xnodes(pcgx_kdtree *t, int64_t lo, int64_t cnt, int depth) {
   const int64_t half = cnt / 2, mid = lo + half;
   pcgx_kdtree::XNode &n = t->xnodes[(size_t)mid];
   n.id = t->inorder[(size_t)mid];
-  n.x = t->points[3 * (size_t)n.id];
-  n.y = t->points[3 * (size_t)n.id + 1];
-  n.z = t->points[3 * (size_t)n.id + 2];
   n.dim = depth % 3;
-  n.pad = 0;
   n.c0 = build_xnodes(t, lo, half, depth + 1);
   n.c1 = build_xnodes(t, mid + 1, cnt - half - 1, depth + 1);
   return (int32_t)mid;
 }
 
-inline float coord(const pcgx_kdtree::XNode &n, int dim) { return dim == 0 ? n.x : (dim == 1 ? n.y : n.z); }
+inline float coord(const pcgx_kdtree *t, int32_t id, int dim) { return t->points[3 * (size_t)id + (size_t)dim]; }
 
-// kdtree.go:224-262 findMinimumImpl: the NODE that holds the id with the smallest coordinate `dim` in the subtree,
-// -1 if empty
+// kdtree.go:224-262 findMinimumImpl: id with the smallest coordinate `dim` in the subtree, -1 if empty
 int32_t find_minimum(const pcgx_kdtree *t, int32_t n, int dim) {
   if (n < 0) return -1;
   const pcgx_kdtree::XNode &nd = t->xnodes[(size_t)n];
   if (nd.dim == dim) {
-    if (nd.c0 < 0) return n;
+    if (nd.c0 < 0) return nd.id;
     return find_minimum(t, nd.c0, dim);
   }
   const int32_t m0 = find_minimum(t, nd.c0, dim), m1 = find_minimum(t, nd.c1, dim);
-  int32_t m = n;  // minNode(dim, n.id, min0, min1): strict <, in this order (:234-241)
-  if (m0 != -1 && coord(t->xnodes[(size_t)m0], dim) < coord(t->xnodes[(size_t)m], dim)) m = m0;
-  if (m1 != -1 && coord(t->xnodes[(size_t)m1], dim) < coord(t->xnodes[(size_t)m], dim)) m = m1;
+  int32_t m = nd.id;  // minNode(dim, n.id, min0, min1): strict <, in this order (:234-241)
+  if (m0 != -1 && coord(t, m0, dim) < coord(t, m, dim)) m = m0;
+  if (m1 != -1 && coord(t, m1, dim) < coord(t, m, dim)) m = m1;
   return m;
 }
 
-// kdtree.go:264-320 deleteNodeImpl (pid at p[3]); returns the (possibly nil) node that replaces n
-int32_t delete_node(pcgx_kdtree *t, int32_t n, int32_t pid, const float *p) {
+// kdtree.go:264-320 deleteNodeImpl; returns the (possibly nil) node that replaces n
+int32_t delete_node(pcgx_kdtree *t, int32_t n, int32_t pid) {
   if (n < 0) return -1;
   pcgx_kdtree::XNode &nd = t->xnodes[(size_t)n];
   if (pid == nd.id) {
-    const bool right = nd.c1 >= 0;
-    if (!right && nd.c0 < 0) return -1;
-    // the minimum of the right subtree (of the left one, which then becomes the right one) takes this node's place
-    const int32_t sub = right ? nd.c1 : nd.c0;
-    const pcgx_kdtree::XNode mn = t->xnodes[(size_t)find_minimum(t, sub, nd.dim)];  // (a copy: its node is patched below)
-    const float mp[3] = {mn.x, mn.y, mn.z};
-    const int32_t child = delete_node(t, sub, mn.id, mp);
-    nd.id = mn.id;
-    nd.x = mn.x;
-    nd.y = mn.y;
-    nd.z = mn.z;
-    if (!right) nd.c0 = -1;
-    nd.c1 = child;
+    if (nd.c1 >= 0) {
+      const int32_t m = find_minimum(t, nd.c1, nd.dim);
+      const int32_t child = delete_node(t, nd.c1, m);
+      nd.id = m;
+      nd.c1 = child;
+    } else if (nd.c0 >= 0) {
+      const int32_t m = find_minimum(t, nd.c0, nd.dim);
+      const int32_t child = delete_node(t, nd.c0, m);
+      nd.id = m;
+      nd.c0 = -1;
+      nd.c1 = child;
+    } else {
+      return -1;
+    }
     return n;
   }
-  const float at = coord(nd, nd.dim), q = p[nd.dim];
-  if (q <= at) nd.c0 = delete_node(t, nd.c0, pid, p);
-  if (q >= at) nd.c1 = delete_node(t, nd.c1, pid, p);
+  const float at = coord(t, nd.id, nd.dim), p = coord(t, pid, nd.dim);
+  if (p <= at) nd.c0 = delete_node(t, nd.c0, pid);
+  if (p >= at) t->xnodes[(size_t)n].c1 = delete_node(t, t->xnodes[(size_t)n].c1, pid);
   return n;
 }
 
@@ -165,7 +161,7 @@ static void xtree_init(pcgx_kdtree *t);
 // Caller holds t->mu.
 void xtree_delete(pcgx_kdtree *t, int64_t pid) {
   xtree_init(t);
-  t->xroot = delete_node(t, t->xroot, (int32_t)pid, &t->points[3 * (size_t)pid]);
+  t->xroot = delete_node(t, t->xroot, (int32_t)pid);
   t->x_dirty = true;
 }
 
@@ -244,7 +240,8 @@ pcgx_status xtree_view(const pcgx_kdtree *tc, XTreeView *xv, hipStream_t st) {
     std::vector<int4> links(n);
     for (size_t k = 0; k < n; k++) {
       const pcgx_kdtree::XNode &nd = t->xnodes[k];
-      pts[k] = make_float4(nd.x, nd.y, nd.z, __builtin_bit_cast(float, nd.id));
+      pts[k] = make_float4(t->points[3 * (size_t)nd.id], t->points[3 * (size_t)nd.id + 1], t->points[3 * (size_t)nd.id + 2],
+                           __builtin_bit_cast(float, nd.id));
       links[k] = make_int4(nd.c0, nd.c1, nd.dim, 0);
     }
     PCGX_HIP_TRY(hipMemcpyAsync(t->d_xpts, pts.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));

@@ -377,13 +377,10 @@ struct pcgx_kdtree {
   // A tree replaced by a later rebuild is freed at once unless ICP sessions still run on it
   // (`sessions`); those are retired and freed by a later rebuild or with the handle.
   // ... and, for Nearest / Range, the reference's own patched tree (knn_explicit.hip): host mirror
-  // {point, id, child0, child1, dim} with node index = in-order position, patched by deleteNodeImpl's
-  // rules, plus its explicit device copy.  (The point rides in the node: findMinimumImpl looks at every node of a
-  // subtree whose split is along another axis, and a second cache miss per node -- its coordinates in `points` --
-  // was half of a deletion's time.)
+  // {id, child0, child1, dim} with node index = in-order position, patched by deleteNodeImpl's
+  // rules, plus its explicit device copy.
   struct XNode {
-    float x, y, z;
-    int32_t id, c0, c1, dim, pad;
+    int32_t id, c0, c1, dim;
   };
   std::vector<XNode> xnodes;
   int32_t xroot = -1;
