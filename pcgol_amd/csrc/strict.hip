@@ -800,8 +800,9 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
 #pragma unroll
     for (int c = 0; c < kCandPerLane; c++) s_ctab[k][c * kLanes + lane] = out[c];
     if (k == 1 || k == 2) {  // the table's entries below / above the middle: none
+      static_assert(kMid % kLanes == 0, "whole waves of entries on either side of the middle");
 #pragma unroll
-      for (int c = 0; c < kCandPerLane; c++)
+      for (int c = 0; c < kMid / kLanes; c++)
         W.cand[(size_t)slot * kCand + (k == 1 ? 0 : kMid + kCandInner) + c * kLanes + lane] = 0x7fc00000u;
     }
     lds_fence_wave();

@@ -49,7 +49,11 @@ constexpr int kAuxShards = 64;
 // too" -- x -> fl(x + t) is monotone -- caught one tile in ten of those the dense ones missed: around a guess the
 // tile's map is one-to-one nearly everywhere.)
 constexpr int kCand = 768;
+#ifdef PCGX_CAND_INNER
+constexpr int kCandInner = PCGX_CAND_INNER;
+#else
 constexpr int kCandInner = 256;        // what one wave carries: four candidates per lane
+#endif
 constexpr uint32_t kCandReach = 512u;  // > |cand_offset|: the guess must be that far from zero (and from infinity)
 __host__ __device__ __forceinline__ int32_t cand_offset(int i) { return i - kCand / 2; }
 
