@@ -311,6 +311,30 @@ void Arena::release_all() {
   blocks_.clear();
 }
 
+pcgx_status Arena::zeroed_words(size_t count, uint32_t **out) {
+  if (!words_) {
+    constexpr size_t kWords = 8192;
+    hipError_t e = hipMalloc((void **)&words_, kWords * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(words_, 0, kWords * sizeof(uint32_t));  // (once; synchronous)
+    if (e != hipSuccess) {
+      (void)hipFree(words_);
+      words_ = nullptr;
+      return fail(PCGX_E_OOM, "arena: no memory for the persistent counters: %s", hipGetErrorString(e));
+    }
+    n_words_ = kWords;
+  }
+  if (count > n_words_) return fail(PCGX_E_INVALID, "arena: %zu persistent words asked for, %zu there", count, n_words_);
+  *out = words_;
+  return PCGX_OK;
+}
+
+void Arena::release_words() {
+  (void)hipFree(words_);
+  words_ = nullptr;
+  n_words_ = 0;
+  turn_ = 0;
+}
+
 }  // namespace pcgx
 
 using namespace pcgx;
@@ -374,6 +398,7 @@ static void shutdown_slot() {
   for (int k = 0; k <= kPoolSlots; k++) {
     Context &c = g.slots[k];
     c.arena.release_all();
+    c.arena.release_words();
     c.host_arena.release_all();
     (void)hipStreamDestroy(c.stream);
     c.stream = nullptr;

@@ -226,7 +226,15 @@ __global__ __launch_bounds__(256) void qp_scatter_kernel(const float *__restrict
 __global__ __launch_bounds__(kGridBlock) void grid_nearest_rec_kernel(GridView g, const float4 *__restrict__ qrec, int64_t nq,
                                                                       float max_range_sq, int32_t *__restrict__ out_id,
                                                                       float *__restrict__ out_dsq, int32_t *__restrict__ walk_list,
-                                                                      uint32_t *__restrict__ walk_count) {
+                                                                      uint32_t *__restrict__ walk_count,
+                                                                      uint32_t *__restrict__ spent, int n_spent,
+                                                                      uint32_t *__restrict__ next_walk_count) {
+  // (the partition's totals and cursors are spent, the NEXT call's walk count is not in use yet: left at zero here,
+  // so that no call starts with a memset launch -- Arena::zeroed_words)
+  if (blockIdx.x == 0) {
+    for (int k = threadIdx.x; k < n_spent; k += kGridBlock) spent[k] = 0u;
+    if (threadIdx.x == 0) *next_walk_count = 0u;
+  }
   const uint32_t n_tiles = (uint32_t)((nq + kGridBlock - 1) / kGridBlock);
   const int64_t pos = (int64_t)xcd_tile(blockIdx.x, n_tiles) * kGridBlock + threadIdx.x;  // an XCD: a contiguous eighth of the cells
   if (pos >= nq) return;
@@ -417,12 +425,15 @@ pcgx_status grid_launch_nearest_partitioned(const pcgx_kdtree *t, const float *d
   if (nq == 0) return PCGX_OK;
   Arena &ar = ctx().arena;  // begun by the caller
   int32_t *d_list = nullptr;
-  uint32_t *d_words = nullptr;  // [8][256] totals, [8][256] cursors, [4096] walk count
+  // [8][256] totals, [8][256] cursors, then the walk counts of this call and of the next one (they take turns), each
+  // on a line of its own: all zero when a call begins, left at zero by grid_nearest_rec_kernel
+  uint32_t *d_words = nullptr;
   float4 *d_rec = nullptr;
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_list));
-  PCGX_TRY(ar.alloc_n(4104, &d_words));
+  PCGX_TRY(ar.zeroed_words(4096 + 128, &d_words));
   PCGX_TRY(ar.alloc_n((size_t)nq, &d_rec));
-  PCGX_HIP_TRY(hipMemsetAsync(d_words, 0, 4104 * sizeof(uint32_t), st));
+  const uint32_t mine = ar.take_turn();
+  uint32_t *d_walk_count = d_words + 4096 + 64 * mine, *d_walk_count_next = d_words + 4096 + 64 * (mine ^ 1u);
   QueryBox box;
   const float cells[3] = {8.0f, 8.0f, 4.0f};
   for (int k = 0; k < 3; k++) {
@@ -436,10 +447,18 @@ pcgx_status grid_launch_nearest_partitioned(const pcgx_kdtree *t, const float *d
   {
     ProfScope prof(PCGX_PROF_KNN_GRID, st);
     hipLaunchKernelGGL(grid_nearest_rec_kernel, dim3(xcd_grid((unsigned)((nq + kGridBlock - 1) / kGridBlock))), dim3(kGridBlock), 0, st,
-                       t->grid, (const float4 *)d_rec, nq, max_range_sq, d_ids, d_dsq, d_list, d_words + 4096);
+                       t->grid, (const float4 *)d_rec, nq, max_range_sq, d_ids, d_dsq, d_list, d_walk_count, d_words, 4096,
+                       d_walk_count_next);
   }
-  PCGX_HIP_TRY(hipGetLastError());
-  return launch_nearest_listed(t->view(), d_q, d_list, d_words + 4096, nq, max_range_sq, d_ids, d_dsq, st);
+  // (a call that fails half-way may leave the counters in any state: they are dropped, the next call gets fresh ones)
+  const hipError_t le = hipGetLastError();
+  if (le != hipSuccess) {
+    ar.release_words();
+    return fail(PCGX_E_HIP, "Nearest batch: launch failed: %s", hipGetErrorString(le));
+  }
+  const pcgx_status rc = launch_nearest_listed(t->view(), d_q, d_list, d_walk_count, nq, max_range_sq, d_ids, d_dsq, st);
+  if (rc != PCGX_OK) ar.release_words();
+  return rc;
 }
 
 }  // namespace pcgx
