@@ -1156,6 +1156,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   asm volatile("" : "+v"(n_run), "+v"(n_runfail), "+v"(n_recfail), "+v"(n_tab_nw), "+v"(n_tab_cross));
   unsigned long long ticks_scan = 0, ticks_walk = 0;
   const long long t_enter = trace_clock(W);  // (PCGX_STRICT_TRACE: the row's stamps)
+  const unsigned long long c_enter = (W.selfcheck & 2) ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
   for (int64_t chunk = 0; chunk < W.ntiles; chunk += kChainTiles) {
     const long long t_a = stat_clock(W);
     if (threadIdx.x < kChainSegs) {
@@ -1371,7 +1372,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         const long long t_f0 = stat_clock(W);
         const int my_run = r0 + (lane >> 2), my_class = lane & 3;
         int e_l = 0, h_l = 0;
-        int32_t key_l = -2, cons_l = 0, c_l = 0, lo_l = kBig, hi_l = -kBig;
+        int32_t key_l = -2, cons_l = 0, c_l = 0, lo_l = kBig, hi_l = -kBig, ord_l = -1;
         uint32_t in_l = 0u, out_l = 0u;
         if (my_run < n_runs) {
           int idx = 0;
@@ -1387,45 +1388,87 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           c_l = s_pre[4 + my_class][e_l];
           lo_l = s_pre[8 + my_class][e_l];
           hi_l = s_pre[12 + my_class][e_l];
+          // a run of ONE tile that owns a slot (a tile without a window always is one): its place among the job tiles
+          if (h_l == e_l) ord_l = s_auxord[e_l];
         }
-        const int n_here = n_runs - r0 < kBatch ? n_runs - r0 : kBatch;
+        const int n_here = rfl(n_runs - r0 < kBatch ? n_runs - r0 : kBatch);  // (a scalar for the compiler: the loops below are uniform)
         // (the records are in their registers HERE: left to the compiler, the wait for them sits at the top of the
         // loop below, where every turn it also waits for the turn before's store of the progress word)
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(key_l), "+v"(in_l), "+v"(out_l), "+v"(cons_l), "+v"(c_l), "+v"(lo_l), "+v"(hi_l), "+v"(e_l), "+v"(h_l));
+                     : "+v"(key_l), "+v"(in_l), "+v"(out_l), "+v"(cons_l), "+v"(c_l), "+v"(lo_l), "+v"(hi_l), "+v"(e_l), "+v"(h_l),
+                       "+v"(ord_l));
         if ((W.selfcheck & 8)) {
           const unsigned long long tt = clock_after((uint32_t)(key_l ^ hi_l ^ e_l));
           if (lane == 0) s_wk[4] += tt - (unsigned long long)t_f0;
         }
         const long long t_j0 = stat_clock(W);
-        for (int j = 0; j < n_here; j++) {
+        // The runs that cover the state -- nearly all -- in a loop of their own: window, class, bounds, step, the
+        // progress word; the first one that does not leaves it for the slow way below (its point record, its table,
+        // its tiles one by one) and the loop is entered again behind it.  (As one loop the compiler's block layout
+        // put three taken branches and a dozen register copies for the slow way's sake into every run: 75
+        // instructions, 0.3 us.)
+        auto run_covers = [&](int l0, uint32_t &state) -> bool {
+          // apply() (strict_sum.h: state_to_n, the class's bounds, n_to_state) without a branch before the verdict
+          const int32_t key = __builtin_amdgcn_readlane(key_l, l0);
+          const int32_t sg = (int32_t)(state >> 31), E = (int32_t)((state >> 23) & 0xffu), e = key & 0xff;
+          const int32_t mant = (int32_t)((state & 0x7fffffu) | 0x800000u);
+          const int32_t n = E == e ? mant << 1 : mant;
+          const int in_window = (int)(key >= 0) & (int)(sg == (key >> 8)) & ((int)(E == e) | (int)(E == e - 1));
+          const int lc = l0 | (n & 3);
+          const int32_t lo = __builtin_amdgcn_readlane(lo_l, lc), hi = __builtin_amdgcn_readlane(hi_l, lc);
+          const int32_t m = n + __builtin_amdgcn_readlane(c_l, lc);
+          const uint32_t sgb = (uint32_t)sg << 31;
+          const uint32_t below = sgb | ((uint32_t)(e - 1) << 23) | ((uint32_t)m & 0x7fffffu);
+          const uint32_t above = sgb | ((uint32_t)e << 23) | (((uint32_t)m >> 1) & 0x7fffffu);
+          const bool ok = (in_window & (int)(n >= lo) & (int)(n <= hi)) != 0;
+          state = ok ? (m < N24 ? below : above) : state;
+          return ok;
+        };
+        int j = 0;
+        while (true) {  // uniform
+          if (!kCheck) {
+            for (; j < n_here; j++) {
+              if (!run_covers(4 * j, s)) break;
+              n_run++;
+              // (a hint for helpers whose tile the walk has passed: no ordering needed; every lane stores the same word)
+              __hip_atomic_store(&s_progress, __builtin_amdgcn_readlane(e_l, 4 * j) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          }
+          if (j >= n_here) break;
           const int l0 = 4 * j;
+          j++;
           n_run++;
           {
             const uint32_t s_in = s;
-            // apply() (strict_sum.h: state_to_n, the class's bounds, n_to_state) without a branch before the verdict:
-            // the walker's time is its instruction count (a taken branch costs several issue slots)
             const int32_t key = __builtin_amdgcn_readlane(key_l, l0);
-            const int32_t sg = (int32_t)(s >> 31), E = (int32_t)((s >> 23) & 0xffu), e = key & 0xff;
-            const int32_t mant = (int32_t)((s & 0x7fffffu) | 0x800000u);
-            const int32_t n = E == e ? mant << 1 : mant;
-            const int in_window = (int)(key >= 0) & (int)(sg == (key >> 8)) & ((int)(E == e) | (int)(E == e - 1));
-            const int lc = l0 | (n & 3);
-            const int32_t lo = __builtin_amdgcn_readlane(lo_l, lc), hi = __builtin_amdgcn_readlane(hi_l, lc);
-            const int32_t m = n + __builtin_amdgcn_readlane(c_l, lc);
-            const uint32_t sgb = (uint32_t)sg << 31;
-            const uint32_t below = sgb | ((uint32_t)(e - 1) << 23) | ((uint32_t)m & 0x7fffffu);
-            const uint32_t above = sgb | ((uint32_t)e << 23) | (((uint32_t)m >> 1) & 0x7fffffu);
-            bool ok = (in_window & (int)(n >= lo) & (int)(n <= hi)) != 0;
-            s = ok ? (m < N24 ? below : above) : s;
+            bool ok = kCheck ? run_covers(l0, s) : false;  // (kCheck: every run comes this way, for its term-by-term check)
             if (!ok && (__builtin_amdgcn_readlane(cons_l, l0) & 1) && (uint32_t)__builtin_amdgcn_readlane((int)in_l, l0) == s) {
               s = (uint32_t)__builtin_amdgcn_readlane((int)out_l, l0);  // apply_point()
               ok = true;
             }
+            if (!ok) {
+              // A job tile on its own whose candidate table is up (its helper holds it): the look-up HERE, not at the
+              // end of the failure path below -- a row whose sum hovers around zero is a string of such tiles (none of
+              // them has a window: their records never apply), and the way through "which tile of the run? its
+              // record? its helper?" costs each 1-2 us of LDS round trips.
+              const int ord = __builtin_amdgcn_readlane(ord_l, l0);
+              if (ord >= 0 && lds_get(&s_tab_ord[ord % kHelpers]) == ord + 1) {
+                const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)in_l, l0);
+                const int32_t idx = (int32_t)((s & 0x7fffffffu) - (g0 & 0x7fffffffu)) + kCand / 2;
+                if (((s ^ g0) >> 31) == 0u && idx >= 0 && idx < kCand) {
+                  const uint32_t v = (uint32_t)rfl((int)s_tab[ord % kHelpers][idx]);
+                  if ((v & 0x7f800000u) != 0x7f800000u) {  // (NaN: no such candidate)
+                    s = v;
+                    ok = true;
+                    if (key >= 0) n_tab_cross++;
+                    else n_tab_nw++;
+                  }
+                }
+              }
+            }
             if (ok) {
               selfcheck<kCheck>(W, term_src, row, s_in, s, chunk + __builtin_amdgcn_readlane(h_l, l0),
                                 chunk + __builtin_amdgcn_readlane(e_l, l0) + 1, 0, lane, s_tile);
-              // (a hint for helpers whose tile the walk has passed: no ordering needed; every lane stores the same word)
               __hip_atomic_store(&s_progress, __builtin_amdgcn_readlane(e_l, l0) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               continue;
             }
@@ -1436,17 +1479,22 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           // which tile?  lane j tries the composition h .. h + j
           int f = h;
           if (e > h) {
-            uint32_t mine = s;
-            bool ok = false;
-            if (h + lane <= e) {
-              const TileRec Pj = rec_get(s_pre, h + lane);
-              ok = Pj.key >= 0 && apply(mine, Pj.key, Pj.s);
-            }
-            const unsigned long long good = __ballot(ok);
-            const int ngood = __builtin_ctzll(~good);  // tiles h .. h + ngood - 1 are covered
+            // (sixty-four tiles of the run at a time, every composition from the run's head and the state there: a run
+            // longer than that used to be walked tile by tile behind the sixty-fourth, 0.5 us each)
             const uint32_t s_in = s;
-            if (ngood > 0) s = (uint32_t)__builtin_amdgcn_readlane((int)mine, ngood - 1);
-            f = h + ngood;
+            for (int base = h; base <= e; base += kLanes) {  // uniform
+              uint32_t mine = s_in;
+              bool ok = false;
+              if (base + lane <= e) {
+                const TileRec Pj = rec_get(s_pre, base + lane);
+                ok = Pj.key >= 0 && apply(mine, Pj.key, Pj.s);
+              }
+              const unsigned long long good = __ballot(ok);
+              const int ngood = good == ~0ull ? kLanes : __builtin_ctzll(~good);  // tiles base .. base + ngood - 1 are covered
+              if (ngood > 0) s = (uint32_t)__builtin_amdgcn_readlane((int)mine, ngood - 1);
+              f = base + ngood;
+              if (ngood < kLanes) break;
+            }
             selfcheck<kCheck>(W, term_src, row, s_in, s, chunk + h, chunk + f, 1, lane, s_tile);
           }
           while (f <= e) {
@@ -1548,8 +1596,13 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     atomicAdd(&W.dbg[25], (unsigned long long)s_stat[3]);
     atomicAdd(&W.dbg[45], (unsigned long long)s_stat[4]);
   }
-  if (walker && lane == 0 && (W.selfcheck & 2)) {  // (row r's stamps ride in tile r's line: words 11, 15)
+  if (walker && lane == 0 && (W.selfcheck & 2)) {  // (row r's stamps ride in tile r's line: words 11 .. 15)
     W.stamps[row * 16 + 11] = (unsigned long long)t_enter;
+    W.stamps[row * 16 + 10] = (unsigned long long)__builtin_readcyclecounter() - c_enter;  // shader clocks in the kernel
+    W.stamps[row * 16 + 12] = s_wk[0];                                   // ticks in failed runs (PCGX_STRICT_CLOCKS)
+    W.stamps[row * 16 + 13] = s_wk[1] | (s_wk[2] << 48);                 // ticks waiting for a helper | times
+    W.stamps[row * 16 + 14] = (unsigned long long)n_run | ((unsigned long long)n_runfail << 16) |
+                              ((unsigned long long)n_recfail << 32) | ((unsigned long long)(n_tab_nw + n_tab_cross) << 48);
     W.stamps[row * 16 + 15] = (unsigned long long)trace_clock(W);
   }
   if (row == 0 && walker && lane == 0) {
