@@ -1950,6 +1950,18 @@ pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[64], hipS
       fclose(f);
     }
   }
+  if (const char *path = getenv("PCGX_STRICT_KEYS")) {  // measurement aid: the windows of every row's tiles (last launch)
+    std::vector<TileRec> h((size_t)kStrictRows * b->w.ntiles);
+    PCGX_HIP_TRY(hipMemcpy(h.data(), b->w.recs, h.size() * sizeof(TileRec), hipMemcpyDeviceToHost));
+    if (FILE *f = fopen(path, "a")) {
+      for (int r = 0; r < kStrictRows; r++) {
+        for (int64_t k = 0; k < b->w.ntiles; k++) fprintf(f, "%d:%d ", h[(size_t)r * b->w.ntiles + k].key, h[(size_t)r * b->w.ntiles + k].cons);
+        fprintf(f, "\n");
+      }
+      fprintf(f, "#\n");
+      fclose(f);
+    }
+  }
   PCGX_HIP_TRY(hipMemsetAsync(b->w.dbg, 0, 64 * sizeof(unsigned long long), st));
   return PCGX_OK;
 }
