@@ -1181,6 +1181,10 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       const int64_t tile = chunk + threadIdx.x;
       valid = tile < W.ntiles;
       if (valid) R = W.recs[row * W.ntiles + tile];
+      if ((W.selfcheck & 2) && chunk == 0 && walker) {
+        const unsigned long long tt = clock_after((uint32_t)R.key);
+        if (lane == 0) s_wk[4] = tt;  // (PCGX_STRICT_TRACE: the row's records have arrived)
+      }
       rec_put(s_rec, threadIdx.x, R);
       const int32_t key_prev = __shfl_up(R.key, 1), key_next = __shfl_down(R.key, 1);
       head = lane == 0 || R.key < 0 || R.key != key_prev;
@@ -1356,6 +1360,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     } else {
       // ---- the walk: one wave, every lane with the same state
       const long long t_b = stat_clock(W);
+      if ((W.selfcheck & 2) && chunk == 0 && lane == 0) s_wk[5] = (unsigned long long)trace_clock(W);  // the walk starts
       // The runs of the chunk, sixteen at a time: the four lanes 4 j .. 4 j + 3 fetch run j's ends and its composed
       // record, lane 4 j + r the piece of class r.  The walk then takes a run out of the registers: its window, and --
       // once the state says which class it is in -- that class's bounds and step from lane 4 j + r: five v_readlane
@@ -1599,8 +1604,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   if (walker && lane == 0 && (W.selfcheck & 2)) {  // (row r's stamps ride in tile r's line: words 11 .. 15)
     W.stamps[row * 16 + 11] = (unsigned long long)t_enter;
     W.stamps[row * 16 + 10] = (unsigned long long)__builtin_readcyclecounter() - c_enter;  // shader clocks in the kernel
-    W.stamps[row * 16 + 12] = s_wk[0];                                   // ticks in failed runs (PCGX_STRICT_CLOCKS)
-    W.stamps[row * 16 + 13] = s_wk[1] | (s_wk[2] << 48);                 // ticks waiting for a helper | times
+    W.stamps[row * 16 + 12] = s_wk[4];                                   // the row's records have arrived
+    W.stamps[row * 16 + 13] = s_wk[5];                                   // the walk starts
     W.stamps[row * 16 + 14] = (unsigned long long)n_run | ((unsigned long long)n_runfail << 16) |
                               ((unsigned long long)n_recfail << 32) | ((unsigned long long)(n_tab_nw + n_tab_cross) << 48);
     W.stamps[row * 16 + 15] = (unsigned long long)trace_clock(W);

@@ -8,6 +8,7 @@ for bi in range(len(blocks)-1):
     if max(walks) < 30: continue
     print("iteration %d" % bi)
     for r in range(9):
-        w14=int(a[r,14]); w13=int(a[r,13])
-        print("  row %d: in kernel %.1f us; runs %d, failed %d, records failed %d, table look-ups %d; in failed runs %.1f us, waiting for helpers %.1f us (%d times)" % (
-            r, walks[r], w14&0xffff, (w14>>16)&0xffff, (w14>>32)&0xffff, w14>>48, int(a[r,12])/100, (w13&((1<<48)-1))/100, w13>>48))
+        w14 = int(a[r, 14])
+        print("  row %d: in kernel %.1f us (records in after %.1f, walk from %.1f); run pieces %d, failed %d, records failed %d, table look-ups %d" % (
+            r, walks[r], (int(a[r, 12]) - int(a[r, 11])) / 100, (int(a[r, 13]) - int(a[r, 11])) / 100,
+            w14 & 0xffff, (w14 >> 16) & 0xffff, (w14 >> 32) & 0xffff, w14 >> 48))
