@@ -614,7 +614,8 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
 // the tile's record, wave 1 backwards (level crossing: the chain kernel finds the leaf that does not
 // cover the state in one parallel step and carries on behind it), or wave 0 alone composes the runs of
 // leaves under equal windows (no window: the chain kernel applies a run's last record).
-constexpr int kJobBlock = 512;  // waves 0..3: a class each, then the scans; waves 4..7: candidate chains
+constexpr int kJobBlock = 256;  // four waves: a class each, then the scans (role 0); candidate chains (roles 1, 2)
+constexpr int kJobRoles = 3;
 template <bool kRegs>
 __device__ __forceinline__ uint32_t resolve_staged(uint32_t s, int kind, int32_t key, const LeafAux &A, int lane,
                                                const float4 *lds, const float *t, int &serial_out, int &tried_out,
@@ -630,26 +631,56 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   __shared__ int s_cdone, s_pieces;
   const unsigned per_shard = (unsigned)W.naux / kAuxShards;
   const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-  // one workgroup per slot that could be handed out; most leave at once.  (A loop over the slots of a shard, tried
-  // twice: the loop alone takes the kernel from 67 to 146 VGPRs, and with fewer workgroups per CU the jobs queue.)
-  // (block b looks after slot b / kAuxShards of shard b % kAuxShards: the slots a launch hands out -- the first few of
-  // every shard -- are the blocks dispatched first, whatever the number of blocks that leave at once behind them)
-  const unsigned shard = blockIdx.x % kAuxShards, slot = shard * per_shard + blockIdx.x / kAuxShards;
-  // ("done" and the shard's count in one round trip, not two)
+  // THREE workgroups of four waves per slot that could be handed out (most leave at once): role 0 for the tile's
+  // record and leaf records, role 1 for its candidate table (a level crossing's four quarters; four of the six waves
+  // of a tile without a window), role 2 for the other two waves of a tile without a window.  As one workgroup of
+  // eight waves the candidate chains finished 8.7-11 us after the terms were in LDS and the launch waited for them
+  // (7.0 now), and a CU held two jobs; it holds four workgroups now, so every job of a launch starts at once -- with
+  // two per CU the fifth job of a shard waited for a place, and ended at 15 us.  Every role forms the guesses
+  // (wave 0) for itself.
+  // (A loop over the slots of a shard, tried twice: the loop alone takes the kernel from 67 to 146 VGPRs, and with
+  // fewer workgroups per CU the jobs queue.)
+  // (blocks 3 b .. 3 b + 2 look after slot b / kAuxShards of shard b % kAuxShards: the slots a launch hands out -- the
+  // first few of every shard -- are the blocks dispatched first, whatever the number of blocks that leave at once
+  // behind them)
+  const int role = (int)(blockIdx.x % kJobRoles);
+  const unsigned jb = blockIdx.x / kJobRoles;
+  const unsigned shard = jb % kAuxShards, slot = shard * per_shard + jb / kAuxShards;
+  // ("done", the shard's count, and -- for the first slots of a shard, where the jobs of a launch are -- the job's
+  // description and terms in ONE round trip: the guesses behind them are two more dependent ones as it is)
+  const JobDesc *J = W.jobs + slot;
+  const float4 *src4 = W.aux_terms + (size_t)slot * (kTile / 4);
+  static_assert(kTile / 4 == 2 * kJobBlock, "two quads of the tile per thread");
+  const bool early = jb / kAuxShards < 6;  // uniform
+  float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0;
+  int row = 0, pad = 0;
+  int64_t tile = 0;
+  if (early) {
+    q0 = src4[threadIdx.x];
+    q1 = src4[threadIdx.x + kJobBlock];
+    row = J->row;
+    tile = J->tile;
+    pad = J->pad;
+  }
   const int done = state->done;
   const unsigned handed_out = W.aux_count[shard * 32];
   if (done || slot % per_shard >= min(handed_out, per_shard)) return;  // uniform
   if (threadIdx.x == 0) s_cdone = s_pieces = 0;
-  const JobDesc *J = W.jobs + slot;
-  const float4 *src4 = W.aux_terms + (size_t)slot * (kTile / 4);
-  for (int i = threadIdx.x; i < kTile / 4; i += kJobBlock) {
-    const float4 q = src4[i];  // quad v = i / 64 of leaf (i % 64) ^ v (tile_quad)
-    s_t[i] = q;
-    s_lin[8 * ((i & 63) ^ (i >> 6)) + (i >> 6)] = q;
+  if (!early) {
+    q0 = src4[threadIdx.x];
+    q1 = src4[threadIdx.x + kJobBlock];
+    row = J->row;
+    tile = J->tile;
+    pad = J->pad;
   }
-  const int row = J->row;
-  const int64_t tile = J->tile;
-  const int32_t pad = J->pad;
+  {
+    int i = threadIdx.x;  // quad v = i / 64 of leaf (i % 64) ^ v (tile_quad)
+    s_t[i] = q0;
+    s_lin[8 * ((i & 63) ^ (i >> 6)) + (i >> 6)] = q0;
+    i += kJobBlock;
+    s_t[i] = q1;
+    s_lin[8 * ((i & 63) ^ (i >> 6)) + (i >> 6)] = q1;
+  }
   const long long tj_0 = trace_clock(W);
   __syncthreads();
   const long long tj_1 = trace_clock(W);
@@ -667,6 +698,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   // start whose windows do not hold the state are added term by term (C4: 1 to 7 of the 64), the others are one
   // apply() per run.  (Round 3 added all 2048 terms one after the other: 10 us of dependent additions.)
   const bool first = tile < kExactTiles && W.first_exact;  // uniform
+  if (first && role != 0) return;  // uniform (no table: the state the tile starts from is known)
   // (PCGX_STRICT_TRACE: wave 0's way through the job, words 11 .. 15 of the tile's line -- the rows' own stamps are in
   // the first lines, strict_chain_kernel)
   const bool traced = (W.selfcheck & 2) && part == 0 && !first && tile > kStrictRows;
@@ -722,14 +754,14 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     }
   }
   __syncthreads();
-  if (s_hdr[4]) { if (part == 0) stamp_end(4); return; }  // uniform
+  if (s_hdr[4]) { if (part == 0 && role == 0) stamp_end(4); return; }  // uniform
   const uint32_t g = s_g[lane];
   const int32_t lk = s_lk[lane];
   const int32_t tkey = s_hdr[0];
   const int kind = tkey >= 0 ? JOB_CROSSING : JOB_NOWINDOW;
   // (no workgroup barrier from here on: waves 4..7 start their candidate chains at once, the waves that scan wait for
   // the four class pieces through an LDS counter)
-  if (part < 4) {
+  if (part < 4 && role == 0) {
     int32_t c, lo, hi;
     leaf_class_piece_q(LdsQuads{s_t, lane}, g, lk, part, c, lo, hi);
     s_S[part][lane] = c;
@@ -739,7 +771,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     lds_fence_wave();
     if (lane == 0) __hip_atomic_fetch_add(&s_pieces, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
-  const bool scans = part == 0 || (part == 1 && kind == JOB_CROSSING);
+  const bool scans = role == 0 && (part == 0 || (part == 1 && kind == JOB_CROSSING));
   if (scans)
     while (__hip_atomic_load(&s_pieces, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 4) __builtin_amdgcn_s_sleep(1);
   // ---- the tile's additions carried out from candidate start states (strict_terms.h), by the waves with nothing
@@ -748,21 +780,23 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   // 1-2 us; if the walker's state is one of the candidates the tile is a look-up.  Four candidates per lane: four
   // independent chains cost 1.9x one (tools/micro/dep_add.cpp).
   if (first && part >= 1) return;  // (no candidates: the state the tile starts from is known)
-  if (kind == JOB_NOWINDOW && part >= 1) {
+  if (kind == JOB_NOWINDOW && (role != 0 || part >= 1)) {
+    if (role == 0) return;  // (waves 1 .. 3 of the records' workgroup: their class pieces are in)
     // no window: waves 1..6, the whole tile from 768 candidates around the tile's guess, two per lane (two
     // independent chains cost 1.3x one, four 1.9x, tools/micro/dep_add.cpp: 7-8 us where three waves with four
     // each took 10-11 -- the launch is that much longer in the few iterations that have such tiles; cut into
     // quarters like a level crossing below, a third of these tiles were lost where one quarter's end fell outside
     // the next quarter's candidates)
     constexpr int kPer = 2, kWavesNw = kCand / (kPer * kLanes);
-    static_assert(kWavesNw * kPer * kLanes == kCand && kWavesNw <= kJobBlock / 64 - 1, "waves 1 .. kWavesNw carry the table");
-    if (part > kWavesNw) return;
+    static_assert(kWavesNw * kPer * kLanes == kCand && kWavesNw <= (kJobRoles - 1) * (kJobBlock / 64), "roles 1, 2 carry the table");
+    const int wave_nw = (role - 1) * (kJobBlock / 64) + part;  // 0 .. kWavesNw - 1: this wave's part of the table
+    if (wave_nw >= kWavesNw) return;
     const uint32_t g0 = (uint32_t)s_hdr[1];
     const uint32_t mag = g0 & 0x7fffffffu;
     uint32_t out[kPer];
 #pragma unroll
     for (int c = 0; c < kPer; c++) out[c] = 0x7fc00000u;  // "no table"
-    const int i0 = (part - 1) * kPer * kLanes + lane;
+    const int i0 = wave_nw * kPer * kLanes + lane;
     if (mag > kCandReach && mag < 0x7f800000u - kCandReach) {  // uniform
       float x[kPer];
 #pragma unroll
@@ -776,13 +810,14 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
     stamp_end(2);
     return;
   }
-  if (part >= 4) {
+  if (role == 2) return;  // uniform (a level crossing has no second half of a table)
+  if (role == 1) {
     // level crossing: 2048 dependent additions are 6-10 us -- longer than anything else this launch does -- so
-    // waves 4..7 take a QUARTER of the tile each: 16 leaves from the 256 candidates around that quarter's first
-    // leaf's guess, and wave 4 strings the quarters' tables together: a candidate's end in one quarter is looked up
+    // the four waves take a QUARTER of the tile each: 16 leaves from the 256 candidates around that quarter's first
+    // leaf's guess, and wave 0 strings the quarters' tables together: a candidate's end in one quarter is looked up
     // among the candidates of the next (the guesses of such a tile agree with one another to a few floats: they
     // were refined by the chains' own rounding errors)
-    const int k = part - 4;
+    const int k = part;
     const uint32_t gk = s_g[k * (kLanes / 4)];
     const uint32_t mag = gk & 0x7fffffffu;
     constexpr int kMid = (kCand - kCandInner) / 2;  // the table's entries [kMid, kMid + kCandInner)
@@ -1779,7 +1814,7 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
   {
     ProfScope prof(PCGX_PROF_STRICT_JOB, st);
     if (W.naux > 0)
-      hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
+      hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)kJobRoles * (unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
@@ -1916,7 +1951,7 @@ pcgx_status strict_enqueue_sharded(StrictBuffers *b, const float4 *match, const 
   if (!local_failed) {
     ProfScope prof(PCGX_PROF_STRICT_JOB, st);
     if (W.naux > 0)
-      hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
+      hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)kJobRoles * (unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
   }
   // 3. the walk goes round the ranks: every hop hands on nine states (their bits as float64: exact under the sum)
   hipLaunchKernelGGL(strict_zero_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<double *>(start_bits), 8, 0.0);  // 16 x 0.0f
