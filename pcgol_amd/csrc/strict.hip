@@ -1125,6 +1125,28 @@ __device__ __forceinline__ TileRec shfl_rec(const TileRec &R, int src) {
   X.s = shfl_summary(R.s, src);
   return X;
 }
+// A record from the lane a DPP control names (row_shr:n inside the rows of 16 lanes, row_bcast:15 / :31 across them): a
+// register move per word, no trip through the LDS crossbar and no wait for it (ds_bpermute: shfl_rec) -- the forward scan
+// of the chain kernel's prologue is six such steps on the walk's critical path.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_int(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, kCtrl, kRowMask, 0xf, false);
+}
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ TileRec dpp_rec(const TileRec &R) {
+  TileRec X;
+  X.key = dpp_int<kCtrl, kRowMask>(R.key);
+  X.in = (uint32_t)dpp_int<kCtrl, kRowMask>((int)R.in);
+  X.out = (uint32_t)dpp_int<kCtrl, kRowMask>((int)R.out);
+  X.cons = dpp_int<kCtrl, kRowMask>(R.cons);
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    X.s.c[q] = dpp_int<kCtrl, kRowMask>(R.s.c[q]);
+    X.s.lo[q] = dpp_int<kCtrl, kRowMask>(R.s.lo[q]);
+    X.s.hi[q] = dpp_int<kCtrl, kRowMask>(R.s.hi[q]);
+  }
+  return X;
+}
 // X (earlier tiles) then Y, same window
 __device__ __forceinline__ TileRec compose_rec(const TileRec &X, const TileRec &Y) {
   TileRec Z;
@@ -1226,15 +1248,21 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       tail = lane == 63 || R.key < 0 || R.key != key_next;
       TileRec P = R;
       int fp = head ? 1 : 0;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const TileRec X = shfl_rec(P, lane - o);
-        const int xf = __shfl_up(fp, o);
-        if (lane >= o && !fp) {
+      // (inside the rows of 16 lanes by 1, 2, 4, 8; then every lane of rows 1 and 3 takes what lane 15 of the row before
+      // has -- its run's composition up to there --, then rows 2 and 3 what lane 31 has: the same compositions as
+      // doubling over the whole wave, the operands fetched by DPP)
+      auto step = [&](const TileRec &X, int xf, bool takes) {
+        if (takes && !fp) {
           P = compose_rec(X, P);
           fp = xf;
         }
-      }
+      };
+      step(dpp_rec<0x111, 0xf>(P), dpp_int<0x111, 0xf>(fp), (lane & 15) >= 1);
+      step(dpp_rec<0x112, 0xf>(P), dpp_int<0x112, 0xf>(fp), (lane & 15) >= 2);
+      step(dpp_rec<0x114, 0xf>(P), dpp_int<0x114, 0xf>(fp), (lane & 15) >= 4);
+      step(dpp_rec<0x118, 0xf>(P), dpp_int<0x118, 0xf>(fp), (lane & 15) >= 8);
+      step(dpp_rec<0x142, 0xa>(P), dpp_int<0x142, 0xa>(fp), (lane & 16) != 0);
+      step(dpp_rec<0x143, 0xc>(P), dpp_int<0x143, 0xc>(fp), lane >= 32);
       rec_put(s_pre, threadIdx.x, P);
       const unsigned long long tails = __ballot(tail && valid);
       if (tail && valid) {
