@@ -27,25 +27,46 @@
 namespace pcgx {
 
 // ---- wave helpers ---------------------------------------------------------------------------------
+// (scans and reductions over a wave by DPP: a partner's value is a register move -- row_shr:n inside a row of 16 lanes,
+// row_bcast:15 / :31 from a row's last lane to the rows behind it, wave_shr:1 -- where __shfl is a trip through the LDS
+// crossbar and a wait; lanes without a partner get `old`)
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+  const unsigned long long o = (unsigned long long)__double_as_longlong(old), x = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)x, kCtrl, kRowMask, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(x >> 32), kCtrl, kRowMask, 0xf, false);
+  return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+}
 __device__ __forceinline__ double wave_excl_scan_f64(double v, int lane) {
   double inc = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double u = __shfl_up(inc, o);
-    if (lane >= o) inc += u;
-  }
-  const double ex = __shfl_up(inc, 1);
-  return lane == 0 ? 0.0 : ex;
+  inc += dpp_f64<0x111, 0xf>(0.0, inc);
+  inc += dpp_f64<0x112, 0xf>(0.0, inc);
+  inc += dpp_f64<0x114, 0xf>(0.0, inc);
+  inc += dpp_f64<0x118, 0xf>(0.0, inc);
+  inc += dpp_f64<0x142, 0xa>(0.0, inc);  // rows 1, 3: the row before
+  inc += dpp_f64<0x143, 0xc>(0.0, inc);  // rows 2, 3: rows 0 and 1
+  (void)lane;
+  return dpp_f64<0x138, 0xf>(0.0, inc);  // wave_shr:1 (lane 0: nothing before it)
 }
 __device__ __forceinline__ uint32_t wave_all_umin(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = umin(v, (uint32_t)__shfl_xor((int)v, o));
-  return v;
+#define PCGX_DPP_U32(CTRL, MASK) (uint32_t) __builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, MASK, 0xf, false)
+  v = umin(v, PCGX_DPP_U32(0x111, 0xf));
+  v = umin(v, PCGX_DPP_U32(0x112, 0xf));
+  v = umin(v, PCGX_DPP_U32(0x114, 0xf));
+  v = umin(v, PCGX_DPP_U32(0x118, 0xf));
+  v = umin(v, PCGX_DPP_U32(0x142, 0xa));
+  v = umin(v, PCGX_DPP_U32(0x143, 0xc));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);  // (lane 63 has seen every lane)
 }
 __device__ __forceinline__ uint32_t wave_all_umax(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = umax(v, (uint32_t)__shfl_xor((int)v, o));
-  return v;
+  v = umax(v, PCGX_DPP_U32(0x111, 0xf));
+  v = umax(v, PCGX_DPP_U32(0x112, 0xf));
+  v = umax(v, PCGX_DPP_U32(0x114, 0xf));
+  v = umax(v, PCGX_DPP_U32(0x118, 0xf));
+  v = umax(v, PCGX_DPP_U32(0x142, 0xa));
+  v = umax(v, PCGX_DPP_U32(0x143, 0xc));
+#undef PCGX_DPP_U32
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ Summary shfl_summary(const Summary &S, int src) {
   Summary R;
@@ -548,8 +569,28 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     if (!first && key >= 0 && (mn >> 23) == (mx >> 23) && m_lo >= kPlainMargin && m_hi <= 0x7fffffu - kPlainMargin) {  // uniform
       const uint32_t E = mn >> 23;
       Par S = leaf_parity_summary_pair(g, cr, crb, E, g_first >> 31);
+      // ordered reduction over the 64 leaves (the partner's summary by DPP inside a row of 16 lanes -- row_shl:o, a move
+      // per word -- and through the LDS crossbar for the two steps across rows)
+      auto fold = [&](const Par &Y, int o) {
+        if ((lane & (2 * o - 1)) == 0) S = par_compose(S, Y);
+      };
+#define PCGX_PAR_DPP(CTRL, O)                                                                         \
+  do {                                                                                                \
+    Par Y;                                                                                            \
+    _Pragma("unroll") for (int p = 0; p < 2; p++) {                                                   \
+      Y.c[p] = __builtin_amdgcn_update_dpp(S.c[p], S.c[p], CTRL, 0xf, 0xf, false);                    \
+      Y.lo[p] = __builtin_amdgcn_update_dpp(S.lo[p], S.lo[p], CTRL, 0xf, 0xf, false);                 \
+      Y.hi[p] = __builtin_amdgcn_update_dpp(S.hi[p], S.hi[p], CTRL, 0xf, 0xf, false);                 \
+    }                                                                                                 \
+    fold(Y, O);                                                                                       \
+  } while (0)
+      PCGX_PAR_DPP(0x101, 1);
+      PCGX_PAR_DPP(0x102, 2);
+      PCGX_PAR_DPP(0x104, 4);
+      PCGX_PAR_DPP(0x108, 8);
+#undef PCGX_PAR_DPP
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {  // ordered reduction over the 64 leaves
+      for (int o = 16; o < 64; o <<= 1) {
         Par Y;
 #pragma unroll
         for (int p = 0; p < 2; p++) {
@@ -557,7 +598,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
           Y.lo[p] = __shfl(S.lo[p], lane + o);
           Y.hi[p] = __shfl(S.hi[p], lane + o);
         }
-        if ((lane & (2 * o - 1)) == 0) S = par_compose(S, Y);
+        fold(Y, o);
       }
       T.s = par_expand(S, E, key);
       if (lane == 0) W.recs[row * W.ntiles + tile] = T;
