@@ -30,13 +30,9 @@ namespace pcgx {
 // (scans and reductions over a wave by DPP: a partner's value is a register move -- row_shr:n inside a row of 16 lanes,
 // row_bcast:15 / :31 from a row's last lane to the rows behind it, wave_shr:1 -- where __shfl is a trip through the LDS
 // crossbar and a wait; lanes without a partner get `old`)
-template <int kCtrl, int kRowMask>
-__device__ __forceinline__ double dpp_f64(double old, double v) {
-  const unsigned long long o = (unsigned long long)__double_as_longlong(old), x = (unsigned long long)__double_as_longlong(v);
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)x, kCtrl, kRowMask, 0xf, false);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(x >> 32), kCtrl, kRowMask, 0xf, false);
-  return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
-}
+// the lane behind / in front (wave_shl:1 / wave_shr:1); the last / first lane keeps `edge`
+__device__ __forceinline__ int lane_next(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int lane_prev(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false); }
 __device__ __forceinline__ double wave_excl_scan_f64(double v, int lane) {
   double inc = v;
   inc += dpp_f64<0x111, 0xf>(0.0, inc);
@@ -349,7 +345,7 @@ __device__ __forceinline__ void tile_guesses(const LdsQuads &q, double base, dou
   const float e = u2f(plain_chain_q(q, g));
   const double err = ((double)e - (double)u2f(g)) - lsum;
   const double epre = wave_excl_scan_f64(err, lane);
-  tile_err = __shfl(epre, 63) + __shfl(err, 63);  // what the float32 chain is off the exact sum by, over this tile
+  tile_err = lane_f64(epre, 63) + lane_f64(err, 63);  // what the float32 chain is off the exact sum by, over this tile
   const uint32_t g2 = f2u((float)(base + pre + epre));
   // (guesses a couple of ulps off are as good: the intervals are thousands wide except next to a level)
   const int32_t moved = (int32_t)g2 - (int32_t)g;
@@ -364,7 +360,7 @@ __device__ __forceinline__ void tile_guesses_pair(const LdsQuads &q, double base
   const float e = u2f(plain_chain_q(q, g));
   const double err = ((double)e - (double)u2f(g)) - lsum;
   const double epre = wave_excl_scan_f64(err, lane);
-  tile_err = __shfl(epre, 63) + __shfl(err, 63);
+  tile_err = lane_f64(epre, 63) + lane_f64(err, 63);
   const uint32_t g2 = f2u((float)(base + pre + epre));
   const int32_t moved = (int32_t)g2 - (int32_t)g;
   if (__ballot(moved > 2 || moved < -2) != 0ull) g = g2;  // uniform
@@ -540,7 +536,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     // (plus what the stored tile sum is off the sum of the terms by: it was formed while a few of the tile's
     // pairs were still being walked for, icp.hip -- the job kernel's guesses then start from prefixes that add
     // up to the terms as they are)
-    const double tile_total = __shfl(pre, 63) + __shfl(lsum, 63);
+    const double tile_total = lane_f64(pre, 63) + lane_f64(lsum, 63);
     if (lane == 0)
       W.tile_err[(int64_t)row * W.ntiles + tile] = terr + (tile_total - (kExchange ? s_tot[row] : W.tile_sum[(int64_t)row * W.ntiles + tile]));
     // window of the tile
@@ -550,11 +546,11 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     const uint32_t g_first = (uint32_t)rfl((int)g);
     const int32_t key = one_sign ? choose_window(mn, mx, g_first >> 31, g_first & 0x7fffffffu) : -1;
     // point record: the guess chains join up exactly
-    const uint32_t g_next = (uint32_t)__shfl_down((int)g, 1);
+    const uint32_t g_next = (uint32_t)lane_next((int)g, (int)g);  // (lane 63's is not looked at)
     const bool cons = __ballot(lane < 63 && g_next != cr.end) == 0ull;
     T.key = key;
     T.in = g_first;
-    T.out = (uint32_t)__shfl((int)cr.end, 63);
+    T.out = (uint32_t)__builtin_amdgcn_readlane((int)cr.end, 63);
     T.cons = cons ? 1 : 0;
     // a plain tile: all of it in one binade, and not within kPlainMargin floats of the binade's ends -- the record
     // of a plain tile covers exactly the states that stay inside the binade, the true state is some floats off
@@ -775,11 +771,11 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
                           (__ballot(cr.sg_or != 0u) == 0ull || __ballot(cr.sg_or == 0u) == 0ull);
     const uint32_t g_first = (uint32_t)rfl((int)g);
     const int32_t key = (one_sign && !first) ? choose_window(mn, mx, g_first >> 31, g_first & 0x7fffffffu) : -1;
-    const uint32_t g_next = (uint32_t)__shfl_down((int)g, 1);
+    const uint32_t g_next = (uint32_t)lane_next((int)g, (int)g);  // (lane 63's is not looked at)
     const bool cons = __ballot(lane < 63 && g_next != cr.end) == 0ull;
     s_g[lane] = g;
     s_lk[lane] = key >= 0 ? key : leaf_key(cr, g);
-    const uint32_t out_last = (uint32_t)__shfl((int)cr.end, 63);
+    const uint32_t out_last = (uint32_t)__builtin_amdgcn_readlane((int)cr.end, 63);
     // a plain tile handed over because it lies near an end of its binade (strict_sum_kernel): with the drift added
     // the guesses say whether its record stands -- still one binade, the same one, clear of the ends
     const uint32_t m_lo = mn & 0x7fffffu, m_hi = mx & 0x7fffffu;

@@ -11,10 +11,29 @@ using namespace ss;
 constexpr int kStrictRows = 9;  // Value, G0..G5, DistRMS, sum of weights (evaluator.go:132-144)
 
 
+// (by DPP: a partner's value is a register move -- row_shr:n inside a row of 16 lanes, row_bcast:15 / :31 from a row's
+// last lane to the rows behind it -- where __shfl is a trip through the LDS crossbar and a wait; lane 63 ends with the
+// sum of all lanes, every lane reads it from there)
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+  const unsigned long long o = (unsigned long long)__double_as_longlong(old), x = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)x, kCtrl, kRowMask, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(x >> 32), kCtrl, kRowMask, 0xf, false);
+  return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+}
+__device__ __forceinline__ double lane_f64(double v, int src) {  // lane `src`'s value (a wave-uniform lane number), in every lane
+  const unsigned long long x = (unsigned long long)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, src), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), src);
+  return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+}
 __device__ __forceinline__ double wave_allsum_f64(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);  // a + b == b + a bit for bit: every lane ends with the same value
-  return v;
+  v += dpp_f64<0x111, 0xf>(0.0, v);
+  v += dpp_f64<0x112, 0xf>(0.0, v);
+  v += dpp_f64<0x114, 0xf>(0.0, v);
+  v += dpp_f64<0x118, 0xf>(0.0, v);
+  v += dpp_f64<0x142, 0xa>(0.0, v);
+  v += dpp_f64<0x143, 0xc>(0.0, v);
+  return lane_f64(v, 63);
 }
 
 struct LeafAux {  // per leaf of a tile with a level crossing: compositions of leaves 0..l and l..63
