@@ -75,6 +75,18 @@ __device__ __forceinline__ Summary shfl_summary(const Summary &S, int src) {
   return R;
 }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a summary from the lane a DPP control names (see wave_excl_scan_f64)
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ Summary dpp_summary(const Summary &S) {
+  Summary R;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    R.c[r] = __builtin_amdgcn_update_dpp(S.c[r], S.c[r], kCtrl, kRowMask, 0xf, false);
+    R.lo[r] = __builtin_amdgcn_update_dpp(S.lo[r], S.lo[r], kCtrl, kRowMask, 0xf, false);
+    R.hi[r] = __builtin_amdgcn_update_dpp(S.hi[r], S.hi[r], kCtrl, kRowMask, 0xf, false);
+  }
+  return R;
+}
 
 // Wall-clock reads for the debug counters' tick columns (tools/strict_probe.py) and the PCGX_STRICT_TRACE stamps.
 // Off unless asked for (PCGX_STRICT_CLOCKS / PCGX_STRICT_TRACE): an s_memrealtime is a round trip of its own,
@@ -915,37 +927,61 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   if (kind == JOB_CROSSING) {
     if (part == 0) {
       Summary P = S;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const Summary X = shfl_summary(P, lane - o);
-        if (lane >= o) P = compose(X, P);
-      }
+      // (the leaves before, by DPP: inside the rows of 16 lanes by 1, 2, 4, 8, then the rows before through their last lanes)
+      // (the partner's summary is fetched by ALL lanes, in front of the condition: a DPP read of a lane that is switched
+      // off returns the reader's own value)
+      auto before = [&](const Summary &X, bool takes) {
+        if (takes) P = compose(X, P);
+      };
+      before(dpp_summary<0x111, 0xf>(P), (lane & 15) >= 1);
+      before(dpp_summary<0x112, 0xf>(P), (lane & 15) >= 2);
+      before(dpp_summary<0x114, 0xf>(P), (lane & 15) >= 4);
+      before(dpp_summary<0x118, 0xf>(P), (lane & 15) >= 8);
+      before(dpp_summary<0x142, 0xa>(P), (lane & 16) != 0);
+      before(dpp_summary<0x143, 0xc>(P), lane >= 32);
       stage(14, (uint32_t)(P.c[0] ^ P.hi[3]));
       W.aux[(size_t)slot * kLanes + lane].pre = P;
       R.s = shfl_summary(P, 63);
       if (lane == 0) W.recs[row * W.ntiles + tile] = R;
     } else {
       Summary Q = S;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const Summary Y = shfl_summary(Q, lane + o);
-        if (lane + o < 64) Q = compose(Q, Y);
+      // (the leaves behind: inside the rows of 16 lanes by DPP, row_shl; then rows 0 and 2 take what the first lane of the
+      // row behind them has, rows 0 and 1 what lane 32 has)
+      auto behind = [&](const Summary &Y, bool takes) {  // (fetched by all lanes, in front of the condition)
+        if (takes) Q = compose(Q, Y);
+      };
+      behind(dpp_summary<0x101, 0xf>(Q), (lane & 15) + 1 < 16);
+      behind(dpp_summary<0x102, 0xf>(Q), (lane & 15) + 2 < 16);
+      behind(dpp_summary<0x104, 0xf>(Q), (lane & 15) + 4 < 16);
+      behind(dpp_summary<0x108, 0xf>(Q), (lane & 15) + 8 < 16);
+      {
+        const Summary Y = shfl_summary(Q, (lane & ~15) + 16);
+        if (!(lane & 16)) Q = compose(Q, Y);
+      }
+      {
+        const Summary Y = shfl_summary(Q, 32);
+        if (lane < 32) Q = compose(Q, Y);
       }
       W.aux[(size_t)slot * kLanes + lane].suf = Q;
     }
   } else if (part == 0) {
-    const int32_t k_prev = __shfl_up(lk, 1);
+    const int32_t k_prev = lane_prev(lk, -1);
     Summary P = S;
     int fp = (lane == 0 || lk < 0 || lk != k_prev) ? 1 : 0;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const Summary X = shfl_summary(P, lane - o);
-      const int xf = __shfl_up(fp, o);
-      if (lane >= o && !fp) {
+    auto step = [&](const Summary &X, int xf, bool takes) {
+      if (takes && !fp) {
         P = compose(X, P);
         fp = xf;
       }
-    }
+    };
+#define PCGX_FP(CTRL, MASK) __builtin_amdgcn_update_dpp(fp, fp, CTRL, MASK, 0xf, false)
+    step(dpp_summary<0x111, 0xf>(P), PCGX_FP(0x111, 0xf), (lane & 15) >= 1);
+    step(dpp_summary<0x112, 0xf>(P), PCGX_FP(0x112, 0xf), (lane & 15) >= 2);
+    step(dpp_summary<0x114, 0xf>(P), PCGX_FP(0x114, 0xf), (lane & 15) >= 4);
+    step(dpp_summary<0x118, 0xf>(P), PCGX_FP(0x118, 0xf), (lane & 15) >= 8);
+    step(dpp_summary<0x142, 0xa>(P), PCGX_FP(0x142, 0xa), (lane & 16) != 0);
+    step(dpp_summary<0x143, 0xc>(P), PCGX_FP(0x143, 0xc), lane >= 32);
+#undef PCGX_FP
     LeafRec L;
     L.key = lk;
     L.pad[0] = L.pad[1] = L.pad[2] = 0;
