@@ -1369,14 +1369,28 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       // ---- helper: compose the runs backwards (wave 0: the walker's segment as well), then serve the walker
       auto scan_backwards = [&](int seg, TileRec Q, bool is_tail) {
         int fq = is_tail ? 1 : 0;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const TileRec Y = shfl_rec(Q, lane + o);
-          const int yf = __shfl_down(fq, o);
-          if (lane + o < 64 && !fq) {
+        // (inside the rows of 16 lanes by DPP, row_shl; then rows 0 and 2 take what the first lane of the row behind
+        // them has, rows 0 and 1 what lane 32 has -- every partner fetched by all lanes, in front of the condition)
+        auto behind = [&](const TileRec &Y, int yf, bool takes) {
+          if (takes && !fq) {
             Q = compose_rec(Q, Y);
             fq = yf;
           }
+        };
+        behind(dpp_rec<0x101, 0xf>(Q), dpp_int<0x101, 0xf>(fq), (lane & 15) + 1 < 16);
+        behind(dpp_rec<0x102, 0xf>(Q), dpp_int<0x102, 0xf>(fq), (lane & 15) + 2 < 16);
+        behind(dpp_rec<0x104, 0xf>(Q), dpp_int<0x104, 0xf>(fq), (lane & 15) + 4 < 16);
+        behind(dpp_rec<0x108, 0xf>(Q), dpp_int<0x108, 0xf>(fq), (lane & 15) + 8 < 16);
+        {
+          const int src = (lane & ~15) + 16;
+          const TileRec Y = shfl_rec(Q, src);
+          const int yf = __shfl(fq, src);
+          behind(Y, yf, !(lane & 16));
+        }
+        {
+          const TileRec Y = shfl_rec(Q, 32);
+          const int yf = __shfl(fq, 32);
+          behind(Y, yf, lane < 32);
         }
         rec_put(s_suf, seg * 64 + lane, Q);
         lds_fence_wave();
