@@ -182,15 +182,7 @@ __global__ __launch_bounds__(256) void qp_scatter_kernel(const float *__restrict
       before_mine += k < (int)(blockIdx.x & 7u) ? v : 0u;
       tot += v;
     }
-    uint32_t inc = c, ginc = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t a = __shfl_up(inc, o), b = __shfl_up(ginc, o);
-      if (lane >= o) {
-        inc += a;
-        ginc += b;
-      }
-    }
+    const uint32_t inc = wave_incl_scan_u32(c), ginc = wave_incl_scan_u32(tot);
     if (lane == 63) {
       wsum[wave] = inc;
       gwsum[wave] = ginc;

@@ -321,6 +321,21 @@ struct IcpKernelParams {
 
 
 #if defined(__HIPCC__)
+// Inclusive sum over the lanes of a wave by DPP (row_shr:n inside a row of 16 lanes, row_bcast:15 / :31 from a row's last
+// lane to the rows behind it): a partner's value is a register move, where __shfl_up is a trip through the LDS crossbar
+// and a wait.  Call with all lanes of the wave active (a DPP read of a lane that is switched off returns the reader's own
+// operand).
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+#define PCGX_DPP_ADD(CTRL, MASK) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, MASK, 0xf, false)
+  PCGX_DPP_ADD(0x111, 0xf);
+  PCGX_DPP_ADD(0x112, 0xf);
+  PCGX_DPP_ADD(0x114, 0xf);
+  PCGX_DPP_ADD(0x118, 0xf);
+  PCGX_DPP_ADD(0x142, 0xa);
+  PCGX_DPP_ADD(0x143, 0xc);
+#undef PCGX_DPP_ADD
+  return v;
+}
 // Evaluate tail (evaluator.go:92-105,156-186) + Update (updater.go:44-71) + the loop
 // bookkeeping of Fit (icp.go:49-60); one thread.
 __device__ __forceinline__ void icp_update_step(IcpState *__restrict__ state, const double *__restrict__ sums10,

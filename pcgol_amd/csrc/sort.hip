@@ -62,12 +62,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scan_rows_kernel(uint32_t *__re
   for (int start = 0; start < nblocks; start += kRsThreads) {
     int i = start + threadIdx.x;
     uint32_t v = i < nblocks ? row[i] : 0u;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t t = __shfl_up(inc, o);
-      if (lane >= o) inc += t;
-    }
+    const uint32_t inc = wave_incl_scan_u32(v);
     if (lane == 63) wave_sum[wave] = inc;
     __syncthreads();
     uint32_t wbase = 0;
@@ -151,15 +146,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(
       run += c;
     }
     const uint32_t tot = totals[t];
-    uint32_t inc = run, ginc = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t x = __shfl_up(inc, o), g = __shfl_up(ginc, o);
-      if (lane >= o) {
-        inc += x;
-        ginc += g;
-      }
-    }
+    const uint32_t inc = wave_incl_scan_u32(run), ginc = wave_incl_scan_u32(tot);
     if (lane == 63) {
       wave_sum[wave] = inc;
       gwave_sum[wave] = ginc;

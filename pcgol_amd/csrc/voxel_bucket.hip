@@ -144,12 +144,7 @@ __global__ __launch_bounds__(1024) void vb_scan_rows_kernel(uint32_t *__restrict
   for (int start = 0; start < ntiles; start += 1024) {
     const int i = start + threadIdx.x;
     const uint32_t v = i < ntiles ? row[i] : 0u;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = __shfl_up(inc, o);
-      if (lane >= o) inc += t;
-    }
+    const uint32_t inc = wave_incl_scan_u32(v);
     if (lane == 63) wave_sum[wave] = inc;
     __syncthreads();
     uint32_t wbase = 0;
@@ -230,15 +225,7 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
       run += c;
     }
     const uint32_t tot = totals[t];
-    uint32_t inc = run, ginc = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t x = __shfl_up(inc, o), g = __shfl_up(ginc, o);
-      if (lane >= o) {
-        inc += x;
-        ginc += g;
-      }
-    }
+    const uint32_t inc = wave_incl_scan_u32(run), ginc = wave_incl_scan_u32(tot);
     if (lane == 63) {
       wave_sum[wave] = inc;
       gwave_sum[wave] = ginc;
@@ -373,15 +360,7 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
       occ += c[k] ? 1u : 0u;
       crowded |= c[k] > (uint32_t)kVbMaxCell;
     }
-    uint32_t inc = sum, oinc = occ;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t x = __shfl_up(inc, o), y = __shfl_up(oinc, o);
-      if (lane >= o) {
-        inc += x;
-        oinc += y;
-      }
-    }
+    const uint32_t inc = wave_incl_scan_u32(sum), oinc = wave_incl_scan_u32(occ);
     if (lane == 63) {
       wsum[wave] = inc;
       wocc[wave] = oinc;
