@@ -450,9 +450,15 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     for (int w = 0; w < kSumWaves; w++) np += s_np[w];
     W.tile_pairs[tile] = (uint32_t)np;
   }
+  // (a wave's rows are the same before and behind the exchange: its leaves' float64 sums and their scan are kept)
+  static_assert(kStrictRows <= 2 * kSumWaves, "a wave has at most two rows");
+  double lsum_kept[2] = {0.0, 0.0}, pre_kept[2] = {0.0, 0.0};
   if (kExchange) {
     // ---- the tile's own sums out, the earlier tiles' sums in
-    for (int row = wave; row < NR; row += kSumWaves) {
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const int row = wave + pass * kSumWaves;
+      if (row >= NR) break;  // uniform
       const LdsQuads q{s_terms[row], lane};
       double lsum = 0.0;
 #pragma unroll
@@ -461,6 +467,8 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
         lsum += (double)a.x; lsum += (double)a.y; lsum += (double)a.z; lsum += (double)a.w;
       }
       const double pre = wave_excl_scan_f64(lsum, lane);  // (the order phase 2 adds them up in: the same double)
+      lsum_kept[pass] = lsum;
+      pre_kept[pass] = pre;
       if (lane == 63) s_tot[row] = pre + lsum;
     }
     __syncthreads();
@@ -534,13 +542,18 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
     // strict_job_kernel instead (a job like the tiles below), which has that time to spare; what this kernel
     // keeps is the estimate of the tile's rounding error, from the guess chains like everywhere else.
     const bool first = tile < kExactTiles && W.first_exact;
-    double lsum = 0.0;
+    double lsum = 0.0, pre;
+    if (kExchange) {
+      lsum = row < kSumWaves ? lsum_kept[0] : lsum_kept[1];
+      pre = row < kSumWaves ? pre_kept[0] : pre_kept[1];
+    } else {
 #pragma unroll
-    for (int v = 0; v < kLeaf / 4; v++) {
-      const float4 a = q(v);
-      lsum += (double)a.x; lsum += (double)a.y; lsum += (double)a.z; lsum += (double)a.w;
+      for (int v = 0; v < kLeaf / 4; v++) {
+        const float4 a = q(v);
+        lsum += (double)a.x; lsum += (double)a.y; lsum += (double)a.z; lsum += (double)a.w;
+      }
+      pre = wave_excl_scan_f64(lsum, lane);
     }
-    const double pre = wave_excl_scan_f64(lsum, lane);
     uint32_t g;
     ChainRange cr, crb;
     double terr;
