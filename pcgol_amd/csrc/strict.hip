@@ -1329,7 +1329,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         if (lane == 0) s_wk[4] = tt;  // (PCGX_STRICT_TRACE: the row's records have arrived)
       }
       rec_put(s_rec, threadIdx.x, R);
-      const int32_t key_prev = __shfl_up(R.key, 1), key_next = __shfl_down(R.key, 1);
+      const int32_t key_prev = lane_prev(R.key, R.key), key_next = lane_next(R.key, R.key);  // (lane 0's / 63's: not looked at)
       head = lane == 0 || R.key < 0 || R.key != key_prev;
       tail = lane == 63 || R.key < 0 || R.key != key_next;
       TileRec P = R;
