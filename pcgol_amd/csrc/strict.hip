@@ -1784,7 +1784,11 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     else __hip_atomic_store(&sums10[slot], (double)u2f(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the row that finishes last has all nine sums: evaluate tail + pose update (evaluator.go:156-186,
     // updater.go:44-71) in the same launch
-    __threadfence();
+    // (the sum went out write-through, and the last row reads the sums past the caches: what the ticket has to wait
+    // for is that one store's arrival, not a write-back of everything the workgroup has written -- a release fence
+    // here and an acquire fence behind the ticket were 0.6 us of the launch's tail)
+    if (W.hop_out) __threadfence();
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned ticket = atomicAdd(W.done_rows, 1u);
     if (ticket == (unsigned)W.nrows - 1u && W.hop_out) {  // (sharded: the sums are put together behind the last rank's walk)
       for (int k = 0; k < kAuxShards; k++) W.aux_count[k * 32] = 0u;
@@ -1792,7 +1796,6 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         for (int64_t k = 0, n = (W.ntiles + 31) / 32, m = n + (n + 31) / 32; k < m; k++) W.tile_arrived[32 * k] = 0u;
       *W.done_rows = 0u;
     } else if (ticket == (unsigned)W.nrows - 1u) {
-      __threadfence();
       double sums[S_COUNT];
       for (int k = 0; k < S_COUNT; k++) sums[k] = __hip_atomic_load(&sums10[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned long long np = (unsigned long long)sums[S_PAIRS];  // row 0 stored it before its ticket
