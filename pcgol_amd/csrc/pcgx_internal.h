@@ -326,7 +326,7 @@ struct IcpKernelParams {
 // and a wait.  Call with all lanes of the wave active (a DPP read of a lane that is switched off returns the reader's own
 // operand).
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-#define PCGX_DPP_ADD(CTRL, MASK) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, MASK, 0xf, false)
+#define PCGX_DPP_ADD(CTRL, MASK) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, MASK, 0xf, (MASK) == 0xf)
   PCGX_DPP_ADD(0x111, 0xf);
   PCGX_DPP_ADD(0x112, 0xf);
   PCGX_DPP_ADD(0x114, 0xf);

@@ -75,15 +75,22 @@ __device__ __forceinline__ Summary shfl_summary(const Summary &S, int src) {
   return R;
 }
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// A word from the lane a DPP control names, for scans whose steps look at it only in the lanes that HAVE such a partner:
+// the others' result is not defined (no `old` operand to set up in front of every move: that was one v_mov per
+// word and step, a quarter of a scan's instructions).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_partner(int v) {
+  return __builtin_amdgcn_mov_dpp(v, kCtrl, kRowMask, 0xf, kRowMask == 0xf);
+}
 // a summary from the lane a DPP control names (see wave_excl_scan_f64)
 template <int kCtrl, int kRowMask>
 __device__ __forceinline__ Summary dpp_summary(const Summary &S) {
   Summary R;
 #pragma unroll
   for (int r = 0; r < 4; r++) {
-    R.c[r] = __builtin_amdgcn_update_dpp(S.c[r], S.c[r], kCtrl, kRowMask, 0xf, false);
-    R.lo[r] = __builtin_amdgcn_update_dpp(S.lo[r], S.lo[r], kCtrl, kRowMask, 0xf, false);
-    R.hi[r] = __builtin_amdgcn_update_dpp(S.hi[r], S.hi[r], kCtrl, kRowMask, 0xf, false);
+    R.c[r] = dpp_partner<kCtrl, kRowMask>(S.c[r]);
+    R.lo[r] = dpp_partner<kCtrl, kRowMask>(S.lo[r]);
+    R.hi[r] = dpp_partner<kCtrl, kRowMask>(S.hi[r]);
   }
   return R;
 }
@@ -599,9 +606,9 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
   do {                                                                                                \
     Par Y;                                                                                            \
     _Pragma("unroll") for (int p = 0; p < 2; p++) {                                                   \
-      Y.c[p] = __builtin_amdgcn_update_dpp(S.c[p], S.c[p], CTRL, 0xf, 0xf, false);                    \
-      Y.lo[p] = __builtin_amdgcn_update_dpp(S.lo[p], S.lo[p], CTRL, 0xf, 0xf, false);                 \
-      Y.hi[p] = __builtin_amdgcn_update_dpp(S.hi[p], S.hi[p], CTRL, 0xf, 0xf, false);                 \
+      Y.c[p] = dpp_partner<CTRL, 0xf>(S.c[p]);                    \
+      Y.lo[p] = dpp_partner<CTRL, 0xf>(S.lo[p]);                 \
+      Y.hi[p] = dpp_partner<CTRL, 0xf>(S.hi[p]);                 \
     }                                                                                                 \
     fold(Y, O);                                                                                       \
   } while (0)
@@ -987,7 +994,7 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
         fp = xf;
       }
     };
-#define PCGX_FP(CTRL, MASK) __builtin_amdgcn_update_dpp(fp, fp, CTRL, MASK, 0xf, false)
+#define PCGX_FP(CTRL, MASK) dpp_partner<CTRL, MASK>(fp)
     step(dpp_summary<0x111, 0xf>(P), PCGX_FP(0x111, 0xf), (lane & 15) >= 1);
     step(dpp_summary<0x112, 0xf>(P), PCGX_FP(0x112, 0xf), (lane & 15) >= 2);
     step(dpp_summary<0x114, 0xf>(P), PCGX_FP(0x114, 0xf), (lane & 15) >= 4);
@@ -1216,7 +1223,7 @@ __device__ __forceinline__ TileRec shfl_rec(const TileRec &R, int src) {
 // of the chain kernel's prologue is six such steps on the walk's critical path.
 template <int kCtrl, int kRowMask>
 __device__ __forceinline__ int dpp_int(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, kCtrl, kRowMask, 0xf, false);
+  return dpp_partner<kCtrl, kRowMask>(v);
 }
 template <int kCtrl, int kRowMask>
 __device__ __forceinline__ TileRec dpp_rec(const TileRec &R) {

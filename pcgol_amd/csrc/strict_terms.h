@@ -14,11 +14,14 @@ constexpr int kStrictRows = 9;  // Value, G0..G5, DistRMS, sum of weights (evalu
 // (by DPP: a partner's value is a register move -- row_shr:n inside a row of 16 lanes, row_bcast:15 / :31 from a row's
 // last lane to the rows behind it -- where __shfl is a trip through the LDS crossbar and a wait; lane 63 ends with the
 // sum of all lanes, every lane reads it from there)
+// (moves inside a row of 16 lanes, or by one lane over the wave: a lane without a partner gets 0.0 whatever `old` is --
+// bound_ctrl -- and the move needs no `old` set up in front of it; the broadcasts leave the rows they do not write at `old`)
 template <int kCtrl, int kRowMask>
 __device__ __forceinline__ double dpp_f64(double old, double v) {
+  constexpr bool kZeroFill = kRowMask == 0xf;  // (every caller's `old` is 0.0 there)
   const unsigned long long o = (unsigned long long)__double_as_longlong(old), x = (unsigned long long)__double_as_longlong(v);
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)x, kCtrl, kRowMask, 0xf, false);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(x >> 32), kCtrl, kRowMask, 0xf, false);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)o, (int)(uint32_t)x, kCtrl, kRowMask, 0xf, kZeroFill);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(o >> 32), (int)(uint32_t)(x >> 32), kCtrl, kRowMask, 0xf, kZeroFill);
   return __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
 }
 __device__ __forceinline__ double lane_f64(double v, int src) {  // lane `src`'s value (a wave-uniform lane number), in every lane
