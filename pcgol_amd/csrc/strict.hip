@@ -1416,11 +1416,15 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         lds_fence_wave();
         if (lane == 0) lds_put(&s_sufok[seg], 1);
       };
-      scan_backwards(wave, R, tail);
-      if (wave == 0) {
-        const TileRec R7 = rec_get(s_rec, kWalker * 64 + lane);
-        const int32_t kn = __shfl_down(R7.key, 1);
-        scan_backwards(kWalker, R7, lane == 63 || R7.key < 0 || R7.key != kn);
+      // (the helper whose wave shares the walker's SIMD -- waves go to the four SIMDs in turn -- leaves its segment
+      // to another wave: the walk's first microsecond ran at half its rate next to that scan's 700 instructions)
+      constexpr int kQuiet = kWalker - 4;
+      if (wave != kQuiet) scan_backwards(wave, R, tail);
+      if (wave == 0 || wave == 2) {
+        const int seg = wave == 0 ? kWalker : kQuiet;
+        const TileRec Ro = rec_get(s_rec, seg * 64 + lane);
+        const int32_t kn = lane_next(Ro.key, Ro.key);
+        scan_backwards(seg, Ro, lane == 63 || Ro.key < 0 || Ro.key != kn);
       }
       // the pair count of the iteration: a helper of row 0 adds up the tiles' counts while the walk runs (integers: no
       // order to keep); the walker stores it with its sum
