@@ -44,17 +44,21 @@ __device__ __forceinline__ double wave_excl_scan_f64(double v, int lane) {
   (void)lane;
   return dpp_f64<0x138, 0xf>(0.0, inc);  // wave_shr:1 (lane 0: nothing before it)
 }
+// (a lane without a partner gets the operation's identity for `old`: the compiler then folds the move into the
+// v_min_u32 / v_max_u32 itself, one instruction per step instead of three)
 __device__ __forceinline__ uint32_t wave_all_umin(uint32_t v) {
-#define PCGX_DPP_U32(CTRL, MASK) (uint32_t) __builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, MASK, 0xf, false)
+#define PCGX_DPP_U32(CTRL, MASK) (uint32_t) __builtin_amdgcn_update_dpp(-1, (int)v, CTRL, MASK, 0xf, false)
   v = umin(v, PCGX_DPP_U32(0x111, 0xf));
   v = umin(v, PCGX_DPP_U32(0x112, 0xf));
   v = umin(v, PCGX_DPP_U32(0x114, 0xf));
   v = umin(v, PCGX_DPP_U32(0x118, 0xf));
   v = umin(v, PCGX_DPP_U32(0x142, 0xa));
   v = umin(v, PCGX_DPP_U32(0x143, 0xc));
+#undef PCGX_DPP_U32
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);  // (lane 63 has seen every lane)
 }
 __device__ __forceinline__ uint32_t wave_all_umax(uint32_t v) {
+#define PCGX_DPP_U32(CTRL, MASK) (uint32_t) __builtin_amdgcn_update_dpp(0, (int)v, CTRL, MASK, 0xf, false)
   v = umax(v, PCGX_DPP_U32(0x111, 0xf));
   v = umax(v, PCGX_DPP_U32(0x112, 0xf));
   v = umax(v, PCGX_DPP_U32(0x114, 0xf));
