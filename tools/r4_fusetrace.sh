@@ -32,5 +32,6 @@ for bi in (2, 8, 12):
     print("   the last row's ticket: sums read at %.1f, pose updated at %.1f us" % (us(a[9, 14]), us(a[9, 15])))
     for r in range(9):
         if a[r, 11] == 0: continue
-        print("   row %d: enters %.1f, walk starts %.1f, ends %.1f us; waited for records %.1f us" % (r, us(a[r, 11]), us(a[r, 12]), us(a[r, 15]), a[r, 14] / 100.0))
+        print("   row %d: enters %.1f, records in %.1f, walk starts %.1f, ends %.1f us; runs %d (failed %d, records %d, tables %d)" % (
+            r, us(a[r, 11]), us(a[r, 12]), us(a[r, 13]), us(a[r, 15]), a[r, 14] & 0xffff, (a[r, 14] >> 16) & 0xffff, (a[r, 14] >> 32) & 0xffff, (a[r, 14] >> 48) & 0xffff))
 PY
