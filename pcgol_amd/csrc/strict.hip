@@ -1280,6 +1280,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   __shared__ int16_t s_auxord[kChainTiles];   // a tile's place in that list, -1: owns no slot
   __shared__ int32_t s_count[kChainSegs], s_auxcnt[kChainSegs];
   __shared__ int s_sufok[kChainSegs];
+  __shared__ int s_pre_cnt[2];             // forward scans done, of segments 0 .. 3 | 4 .. 7
   __shared__ int s_progress;               // walker: the tile it stands at (tiles below are done)
   __shared__ ChainMail s_mail[kChainSegs];
   __shared__ uint32_t s_tab[kHelpers][kCand];  // helper h: the candidate table of the tile it holds (strict_job_kernel)
@@ -1321,6 +1322,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     }
     if (threadIdx.x == 0) {
       s_progress = 0;
+      s_pre_cnt[0] = s_pre_cnt[1] = 0;
       if (chunk == 0) s_np_ok = 0;
     }
     if (chunk == 0 && threadIdx.x < 8) s_wk[threadIdx.x] = 0ull;
@@ -1343,24 +1345,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       const int32_t key_prev = lane_prev(R.key, R.key), key_next = lane_next(R.key, R.key);  // (lane 0's / 63's: not looked at)
       head = lane == 0 || R.key < 0 || R.key != key_prev;
       tail = lane == 63 || R.key < 0 || R.key != key_next;
-      TileRec P = R;
-      int fp = head ? 1 : 0;
-      // (inside the rows of 16 lanes by 1, 2, 4, 8; then every lane of rows 1 and 3 takes what lane 15 of the row before
-      // has -- its run's composition up to there --, then rows 2 and 3 what lane 31 has: the same compositions as
-      // doubling over the whole wave, the operands fetched by DPP)
-      auto step = [&](const TileRec &X, int xf, bool takes) {
-        if (takes && !fp) {
-          P = compose_rec(X, P);
-          fp = xf;
-        }
-      };
-      step(dpp_rec<0x111, 0xf>(P), dpp_int<0x111, 0xf>(fp), (lane & 15) >= 1);
-      step(dpp_rec<0x112, 0xf>(P), dpp_int<0x112, 0xf>(fp), (lane & 15) >= 2);
-      step(dpp_rec<0x114, 0xf>(P), dpp_int<0x114, 0xf>(fp), (lane & 15) >= 4);
-      step(dpp_rec<0x118, 0xf>(P), dpp_int<0x118, 0xf>(fp), (lane & 15) >= 8);
-      step(dpp_rec<0x142, 0xa>(P), dpp_int<0x142, 0xa>(fp), (lane & 16) != 0);
-      step(dpp_rec<0x143, 0xc>(P), dpp_int<0x143, 0xc>(fp), lane >= 32);
-      rec_put(s_pre, threadIdx.x, P);
+      // (the runs' ends are known from the windows alone: the lists below do not wait for the compositions)
       const unsigned long long tails = __ballot(tail && valid);
       if (tail && valid) {
         const unsigned long long below = tails & ((1ull << lane) - 1ull);  // the run starts behind the tail before this one
@@ -1390,7 +1375,61 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     }
     __syncthreads();
     if (!walker) {
-      // ---- helper: compose the runs backwards (wave 0: the walker's segment as well), then serve the walker
+      // ---- helper: compose the runs forwards, segments 0 .. 3 first.  The walk starts at tile 0 and a forward scan is
+      // 840 vector instructions: eight of them on four SIMDs are 2.9 us of issue slots however they are spread, so
+      // the waves of the first four segments run theirs at the higher priority (one each per SIMD: 1.5 us) and the
+      // walker starts with those segments' runs while the other four are composed.  The walker does not scan: its
+      // segment -- the last the walk gets to -- is the second scan of the wave that shares its SIMD.
+      // (inside the rows of 16 lanes by 1, 2, 4, 8; then every lane of rows 1 and 3 takes what lane 15 of the row before
+      // has -- its run's composition up to there --, then rows 2 and 3 what lane 31 has: the same compositions as
+      // doubling over the whole wave, the operands fetched by DPP)
+      auto scan_forwards = [&](int seg, TileRec P, bool is_head) {
+        int fp = is_head ? 1 : 0;
+        auto step = [&](const TileRec &X, int xf, bool takes) {
+          if (takes && !fp) {
+            P = compose_rec(X, P);
+            fp = xf;
+          }
+        };
+        step(dpp_rec<0x111, 0xf>(P), dpp_int<0x111, 0xf>(fp), (lane & 15) >= 1);
+        step(dpp_rec<0x112, 0xf>(P), dpp_int<0x112, 0xf>(fp), (lane & 15) >= 2);
+        step(dpp_rec<0x114, 0xf>(P), dpp_int<0x114, 0xf>(fp), (lane & 15) >= 4);
+        step(dpp_rec<0x118, 0xf>(P), dpp_int<0x118, 0xf>(fp), (lane & 15) >= 8);
+        step(dpp_rec<0x142, 0xa>(P), dpp_int<0x142, 0xa>(fp), (lane & 16) != 0);
+        step(dpp_rec<0x143, 0xc>(P), dpp_int<0x143, 0xc>(fp), lane >= 32);
+        rec_put(s_pre, seg * 64 + lane, P);
+        lds_fence_wave();
+        if (lane == 0) __hip_atomic_fetch_add(&s_pre_cnt[seg >> 2], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      // (this helper's first tile with a candidate table: the table is asked for in front of the scan and put up right
+      // behind it -- the walker, on its way two scans earlier than the helpers get to their tiles, would find none up
+      // at its first failures and go through the mailbox)
+      const bool have_cand = !(W.selfcheck & 4);  // uniform
+      uint32_t cand_out[kCand / kLanes];
+#pragma unroll
+      for (int j = 0; j < kCand / kLanes; j++) cand_out[j] = 0x7fc00000u;
+      if (wave < naux && have_cand) {  // uniform
+        const int slot = (s_rec[3][s_auxlist[wave]] >> 8) - 1;
+        const uint32_t *tab = W.cand + (size_t)slot * kCand + lane;
+#pragma unroll
+        for (int j = 0; j < kCand / kLanes; j++) cand_out[j] = tab[j * kLanes];
+      }
+      if (wave < 4) __builtin_amdgcn_s_setprio(3);
+      scan_forwards(wave, R, head);
+      if (wave < naux) {
+#pragma unroll
+        for (int j = 0; j < kCand / kLanes; j++) s_tab[wave][j * kLanes + lane] = cand_out[j];
+        lds_fence_wave();
+        if (lane == 0) lds_put(&s_tab_ord[wave], wave + 1);
+      }
+      if (wave < 4) __builtin_amdgcn_s_setprio(1);
+      if (wave == kWalker - 4) {
+        const TileRec Ro = rec_get(s_rec, kWalker * 64 + lane);
+        const int32_t kp = lane_prev(Ro.key, Ro.key);
+        scan_forwards(kWalker, Ro, lane == 0 || Ro.key < 0 || Ro.key != kp);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      // ---- compose the runs backwards (wave 0: the walker's segment as well), then serve the walker
       auto scan_backwards = [&](int seg, TileRec Q, bool is_tail) {
         int fq = is_tail ? 1 : 0;
         // (inside the rows of 16 lanes by DPP, row_shl; then rows 0 and 2 take what the first lane of the row behind
@@ -1455,19 +1494,22 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         // A tile without a window (a sum hovering around zero): the job kernel has carried out its 2048
         // additions from kCand start states around the guess (strict_terms.h, cand_offset); lane c holds the
         // ends of candidates c, 64 + c, 128 + c, ...
-        uint32_t cand_out[kCand / kLanes];
         const uint32_t g0 = (uint32_t)s_rec[1][cur_tile];
-        const bool have_cand = !(W.selfcheck & 4);  // uniform
-#pragma unroll
-        for (int j = 0; j < kCand / kLanes; j++) {
-          cand_out[j] = have_cand ? W.cand[(size_t)slot * kCand + j * kLanes + lane] : 0x7fc00000u;
-        }
         // the table goes to LDS, where the walker looks its state up by itself (a hand-over through the mailbox is
         // 1.5-2.5 us: the helper's turn-around and two polling latencies); the mailbox is for states not in it
+        if (k != wave) {  // uniform (the first tile's is up already)
 #pragma unroll
-        for (int j = 0; j < kCand / kLanes; j++) s_tab[wave][j * kLanes + lane] = cand_out[j];
-        lds_fence_wave();
-        if (lane == 0) lds_put(&s_tab_ord[wave], k + 1);
+          for (int j = 0; j < kCand / kLanes; j++) cand_out[j] = 0x7fc00000u;
+          if (have_cand) {  // uniform
+            const uint32_t *tab = W.cand + (size_t)slot * kCand + lane;
+#pragma unroll
+            for (int j = 0; j < kCand / kLanes; j++) cand_out[j] = tab[j * kLanes];
+          }
+#pragma unroll
+          for (int j = 0; j < kCand / kLanes; j++) s_tab[wave][j * kLanes + lane] = cand_out[j];
+          lds_fence_wave();
+          if (lane == 0) lds_put(&s_tab_ord[wave], k + 1);
+        }
         bool serve = false;
         while (true) {
           if (lds_get(&s_mail[wave].req) == k + 1) {
@@ -1538,7 +1580,6 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     } else {
       // ---- the walk: one wave, every lane with the same state
       const long long t_b = stat_clock(W);
-      if ((W.selfcheck & 2) && chunk == 0 && lane == 0) s_wk[5] = (unsigned long long)trace_clock(W);  // the walk starts
       // The runs of the chunk, sixteen at a time: the four lanes 4 j .. 4 j + 3 fetch run j's ends and its composed
       // record, lane 4 j + r the piece of class r.  The walk then takes a run out of the registers: its window, and --
       // once the state says which class it is in -- that class's bounds and step from lane 4 j + r: five v_readlane
@@ -1550,14 +1591,21 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       seg_base[0] = 0;
 #pragma unroll
       for (int w = 0; w < kChainSegs; w++) seg_base[w + 1] = seg_base[w] + s_count[w];
-      const int n_runs = seg_base[kChainSegs];
-      for (int r0 = 0; r0 < n_runs; r0 += kBatch) {
+      const int n_runs = rfl(seg_base[kChainSegs]), n_runs_lo = rfl(seg_base[kChainSegs / 2]);
+      __builtin_amdgcn_s_setprio(3);
+      for (int r0 = 0, r1 = 0; r0 < n_runs; r0 = r1) {
+        // (a batch stays inside one half of the segments: the first half's compositions are there first)
+        const int half = r0 < n_runs_lo ? 0 : 1;
+        const int bound = half == 0 ? n_runs_lo : n_runs;
+        r1 = r0 + kBatch < bound ? r0 + kBatch : bound;
+        while (lds_get(&s_pre_cnt[half]) < kChainSegs / 2) __builtin_amdgcn_s_sleep(1);
+        if ((W.selfcheck & 2) && chunk == 0 && r0 == 0 && lane == 0) s_wk[5] = (unsigned long long)trace_clock(W);  // the walk starts
         const long long t_f0 = stat_clock(W);
         const int my_run = r0 + (lane >> 2), my_class = lane & 3;
         int e_l = 0, h_l = 0;
         int32_t key_l = -2, cons_l = 0, c_l = 0, lo_l = kBig, hi_l = -kBig, ord_l = -1;
         uint32_t in_l = 0u, out_l = 0u;
-        if (my_run < n_runs) {
+        if (my_run < r1) {
           int idx = 0;
 #pragma unroll
           for (int w = 0; w < kChainSegs; w++)
@@ -1574,7 +1622,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           // a run of ONE tile that owns a slot (a tile without a window always is one): its place among the job tiles
           if (h_l == e_l) ord_l = s_auxord[e_l];
         }
-        const int n_here = rfl(n_runs - r0 < kBatch ? n_runs - r0 : kBatch);  // (a scalar for the compiler: the loops below are uniform)
+        const int n_here = rfl(r1 - r0);  // (a scalar for the compiler: the loops below are uniform)
         // (the records are in their registers HERE: left to the compiler, the wait for them sits at the top of the
         // loop below, where every turn it also waits for the turn before's store of the progress word)
         asm volatile("s_waitcnt lgkmcnt(0)"
