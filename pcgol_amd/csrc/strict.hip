@@ -1376,9 +1376,10 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     __syncthreads();
     if (!walker) {
       // ---- helper: compose the runs forwards, segments 0 .. 3 first.  The walk starts at tile 0 and a forward scan is
-      // 840 vector instructions: eight of them on four SIMDs are 2.9 us of issue slots however they are spread, so
-      // the waves of the first four segments run theirs at the higher priority (one each per SIMD: 1.5 us) and the
-      // walker starts with those segments' runs while the other four are composed.  The walker does not scan: its
+      // 840 vector instructions: eight of them on four SIMDs are 2.9 us of issue slots however they are spread, so the
+      // walker starts with the first four segments' runs as soon as those are composed.  (With s_setprio 3 on those
+      // four waves' scans the step was 0.5 us LONGER: the other four segments' scans, which the walk needs a few
+      // microseconds later, were starved.)  The walker does not scan: its
       // segment -- the last the walk gets to -- is the second scan of the wave that shares its SIMD.
       // (inside the rows of 16 lanes by 1, 2, 4, 8; then every lane of rows 1 and 3 takes what lane 15 of the row before
       // has -- its run's composition up to there --, then rows 2 and 3 what lane 31 has: the same compositions as
@@ -1414,7 +1415,6 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
 #pragma unroll
         for (int j = 0; j < kCand / kLanes; j++) cand_out[j] = tab[j * kLanes];
       }
-      if (wave < 4) __builtin_amdgcn_s_setprio(3);
       scan_forwards(wave, R, head);
       if (wave < naux) {
 #pragma unroll
@@ -1422,13 +1422,11 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         lds_fence_wave();
         if (lane == 0) lds_put(&s_tab_ord[wave], wave + 1);
       }
-      if (wave < 4) __builtin_amdgcn_s_setprio(1);
       if (wave == kWalker - 4) {
         const TileRec Ro = rec_get(s_rec, kWalker * 64 + lane);
         const int32_t kp = lane_prev(Ro.key, Ro.key);
         scan_forwards(kWalker, Ro, lane == 0 || Ro.key < 0 || Ro.key != kp);
       }
-      __builtin_amdgcn_s_setprio(0);
       // ---- compose the runs backwards (wave 0: the walker's segment as well), then serve the walker
       auto scan_backwards = [&](int seg, TileRec Q, bool is_tail) {
         int fq = is_tail ? 1 : 0;
