@@ -1255,6 +1255,27 @@ __device__ __forceinline__ TileRec compose_rec(const TileRec &X, const TileRec &
   return Z;
 }
 
+// A job tile with a window whose record covers few states (a level crossing: its classes' intervals end at the level)
+// is a run of its own: inside a run of its neighbours it is what makes the run fail -- search for the tile, its record,
+// its table, the rest of the run: 1 us -- while a run of one job tile is looked up in its candidate table at once.
+// (The narrowest class interval below 64 mantissa steps: +3 runs a row at 0.1 us each, a third of the failed runs gone,
+// 0.0838 -> 0.0830 ms; at 16 nothing changes, at 128 / 256 / 1024 / 16384 the extra runs -- +5 to +15 a row -- cost what
+// the failures saved or more.  0: off.)
+#ifndef PCGX_NARROW_RECORD
+#define PCGX_NARROW_RECORD 64
+#endif
+constexpr int32_t kNarrowRecord = PCGX_NARROW_RECORD;
+__device__ __forceinline__ bool stands_alone(const TileRec &R) {
+  if (kNarrowRecord <= 0 || R.key < 0 || (R.cons >> 8) == 0) return false;
+  int32_t w = kBig;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int32_t d = R.s.hi[r] - R.s.lo[r];
+    w = d >= 0 ? imin(w, d) : w;
+  }
+  return w < kNarrowRecord || w == kBig;
+}
+
 // words shared between the waves of the chain kernel (LDS), read and written with workgroup-scope atomics
 __device__ __forceinline__ int lds_get(const int *p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void lds_put(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -1343,8 +1364,9 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       }
       rec_put(s_rec, threadIdx.x, R);
       const int32_t key_prev = lane_prev(R.key, R.key), key_next = lane_next(R.key, R.key);  // (lane 0's / 63's: not looked at)
-      head = lane == 0 || R.key < 0 || R.key != key_prev;
-      tail = lane == 63 || R.key < 0 || R.key != key_next;
+      const int alone = stands_alone(R) ? 1 : 0, alone_prev = lane_prev(alone, 0), alone_next = lane_next(alone, 0);
+      head = lane == 0 || R.key < 0 || R.key != key_prev || alone || alone_prev;
+      tail = lane == 63 || R.key < 0 || R.key != key_next || alone || alone_next;
       // (the runs' ends are known from the windows alone: the lists below do not wait for the compositions)
       const unsigned long long tails = __ballot(tail && valid);
       if (tail && valid) {
@@ -1425,7 +1447,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       if (wave == kWalker - 4) {
         const TileRec Ro = rec_get(s_rec, kWalker * 64 + lane);
         const int32_t kp = lane_prev(Ro.key, Ro.key);
-        scan_forwards(kWalker, Ro, lane == 0 || Ro.key < 0 || Ro.key != kp);
+        const int ao = stands_alone(Ro) ? 1 : 0, ao_prev = lane_prev(ao, 0);  // (fetched by all lanes, in front of the condition)
+        scan_forwards(kWalker, Ro, lane == 0 || Ro.key < 0 || Ro.key != kp || ao || ao_prev);
       }
       // ---- compose the runs backwards (wave 0: the walker's segment as well), then serve the walker
       auto scan_backwards = [&](int seg, TileRec Q, bool is_tail) {
@@ -1465,7 +1488,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         const int seg = wave == 0 ? kWalker : kQuiet;
         const TileRec Ro = rec_get(s_rec, seg * 64 + lane);
         const int32_t kn = lane_next(Ro.key, Ro.key);
-        scan_backwards(seg, Ro, lane == 63 || Ro.key < 0 || Ro.key != kn);
+        const int ao = stands_alone(Ro) ? 1 : 0, ao_next = lane_next(ao, 0);
+        scan_backwards(seg, Ro, lane == 63 || Ro.key < 0 || Ro.key != kn || ao || ao_next);
       }
       // the pair count of the iteration: a helper of row 0 adds up the tiles' counts while the walk runs (integers: no
       // order to keep); the walker stores it with its sum
