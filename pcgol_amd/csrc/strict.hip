@@ -1173,6 +1173,7 @@ constexpr int kChainSegs = 8;                 // waves = segments of 64 tiles pe
 constexpr int kChainTiles = kChainSegs * 64;  // tiles per chunk
 constexpr int kChainBlock = kChainTiles;
 constexpr int kWalker = kChainSegs - 1;       // the wave that walks (after the forward scan of its own segment)
+constexpr int kTabSlots = 2 * (kChainSegs - 1);  // candidate tables in LDS: two per helper
 constexpr int kHelpers = kChainSegs - 1;      // the others (eight waves, two per SIMD: 256 registers each, no scratch)
 
 // The chunk's records in LDS, one array per word ([word][tile]): lane-indexed reads and writes of whole records
@@ -1304,8 +1305,12 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   __shared__ int s_pre_cnt[2];             // forward scans done, of segments 0 .. 3 | 4 .. 7
   __shared__ int s_progress;               // walker: the tile it stands at (tiles below are done)
   __shared__ ChainMail s_mail[kChainSegs];
-  __shared__ uint32_t s_tab[kHelpers][kCand];  // helper h: the candidate table of the tile it holds (strict_job_kernel)
-  __shared__ int s_tab_ord[kHelpers];          // ... and that tile's ordinal + 1 (0: none yet)
+  // candidate tables (strict_job_kernel) of the job tiles the walk gets to next: helper h puts up its tiles' -- ordinals
+  // h, h + 7, ... -- two ahead (slot = ordinal % kTabSlots; with one slot each the table of a helper's next tile went
+  // up when the walker had passed the one before, ~1 us of loads: of fifty tiles a Fit handed to a helper through the
+  // mailbox, forty-eight were in tables that were not up yet)
+  __shared__ uint32_t s_tab[kTabSlots][kCand];
+  __shared__ int s_tab_ord[kTabSlots];         // the ordinal + 1 of the tile whose table a slot holds (0: none yet)
   __shared__ float4 s_tile[kTile / 4];     // walker: the terms of a tile without a slot, formed again from the pairs
   __shared__ unsigned long long s_np;
   __shared__ int s_np_ok;
@@ -1329,7 +1334,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   // next release store of its wave, and the walk is a chain of those).  Vector registers (opaque to the compiler):
   // as scalars they were written to and read from spill lanes around every run.
   uint32_t n_run = 0, n_runfail = 0, n_recfail = 0, n_tab_nw = 0, n_tab_cross = 0;
-  asm volatile("" : "+v"(n_run), "+v"(n_runfail), "+v"(n_recfail), "+v"(n_tab_nw), "+v"(n_tab_cross));
+  uint32_t n_mail = 0;  // why a tile went to its helper, 8 bits each: table not up | state outside the table | no such candidate
+  asm volatile("" : "+v"(n_run), "+v"(n_runfail), "+v"(n_recfail), "+v"(n_tab_nw), "+v"(n_tab_cross), "+v"(n_mail));
   unsigned long long ticks_scan = 0, ticks_walk = 0;
   const long long t_enter = trace_clock(W);  // (PCGX_STRICT_TRACE: the row's stamps)
   const unsigned long long c_enter = (W.selfcheck & 2) ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
@@ -1339,8 +1345,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       s_sufok[threadIdx.x] = 0;
       s_mail[threadIdx.x].req = 0;
       s_mail[threadIdx.x].ack = 0;
-      if (threadIdx.x < kHelpers) s_tab_ord[threadIdx.x] = 0;
     }
+    if (threadIdx.x < kTabSlots) s_tab_ord[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
       s_progress = 0;
       s_pre_cnt[0] = s_pre_cnt[1] = 0;
@@ -1444,6 +1450,19 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         lds_fence_wave();
         if (lane == 0) lds_put(&s_tab_ord[wave], wave + 1);
       }
+      // (... and its second tile's, asked for here and put up behind the backward scans: until the helpers get to their
+      // tiles -- two to four scans from now -- these fourteen tables are all the walker finds)
+      const bool second_early = wave + kHelpers < naux;  // uniform
+      if (second_early) {
+#pragma unroll
+        for (int j = 0; j < kCand / kLanes; j++) cand_out[j] = 0x7fc00000u;
+        if (have_cand) {
+          const int slot = (s_rec[3][s_auxlist[wave + kHelpers]] >> 8) - 1;
+          const uint32_t *tab = W.cand + (size_t)slot * kCand + lane;
+#pragma unroll
+          for (int j = 0; j < kCand / kLanes; j++) cand_out[j] = tab[j * kLanes];
+        }
+      }
       if (wave == kWalker - 4) {
         const TileRec Ro = rec_get(s_rec, kWalker * 64 + lane);
         const int32_t kp = lane_prev(Ro.key, Ro.key);
@@ -1491,6 +1510,12 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         const int ao = stands_alone(Ro) ? 1 : 0, ao_next = lane_next(ao, 0);
         scan_backwards(seg, Ro, lane == 63 || Ro.key < 0 || Ro.key != kn || ao || ao_next);
       }
+      if (second_early) {
+#pragma unroll
+        for (int j = 0; j < kCand / kLanes; j++) s_tab[wave + kHelpers][j * kLanes + lane] = cand_out[j];
+        lds_fence_wave();
+        if (lane == 0) lds_put(&s_tab_ord[wave + kHelpers], wave + kHelpers + 1);
+      }
       // the pair count of the iteration: a helper of row 0 adds up the tiles' counts while the walk runs (integers: no
       // order to keep); the walker stores it with its sum
       if (row == 0 && wave == 1 && chunk == 0) {
@@ -1519,19 +1544,23 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         const uint32_t g0 = (uint32_t)s_rec[1][cur_tile];
         // the table goes to LDS, where the walker looks its state up by itself (a hand-over through the mailbox is
         // 1.5-2.5 us: the helper's turn-around and two polling latencies); the mailbox is for states not in it
-        if (k != wave) {  // uniform (the first tile's is up already)
+        if (k != wave && k + kHelpers < naux) {  // uniform: my next tile's table goes up now (this tile's went up a turn ago; my first two: above)
+          const int next_slot = (s_rec[3][s_auxlist[k + kHelpers]] >> 8) - 1;
 #pragma unroll
           for (int j = 0; j < kCand / kLanes; j++) cand_out[j] = 0x7fc00000u;
           if (have_cand) {  // uniform
-            const uint32_t *tab = W.cand + (size_t)slot * kCand + lane;
+            const uint32_t *tab = W.cand + (size_t)next_slot * kCand + lane;
 #pragma unroll
             for (int j = 0; j < kCand / kLanes; j++) cand_out[j] = tab[j * kLanes];
           }
 #pragma unroll
-          for (int j = 0; j < kCand / kLanes; j++) s_tab[wave][j * kLanes + lane] = cand_out[j];
+          for (int j = 0; j < kCand / kLanes; j++) s_tab[(k + kHelpers) % kTabSlots][j * kLanes + lane] = cand_out[j];
           lds_fence_wave();
-          if (lane == 0) lds_put(&s_tab_ord[wave], k + 1);
+          if (lane == 0) lds_put(&s_tab_ord[(k + kHelpers) % kTabSlots], k + kHelpers + 1);
         }
+        // (this tile's table, for the states the walker does not find in it: the candidates either side of the state)
+#pragma unroll
+        for (int j = 0; j < kCand / kLanes; j++) cand_out[j] = s_tab[k % kTabSlots][j * kLanes + lane];
         bool serve = false;
         while (true) {
           if (lds_get(&s_mail[wave].req) == k + 1) {
@@ -1705,11 +1734,11 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
               // them has a window: their records never apply), and the way through "which tile of the run? its
               // record? its helper?" costs each 1-2 us of LDS round trips.
               const int ord = __builtin_amdgcn_readlane(ord_l, l0);
-              if (ord >= 0 && lds_get(&s_tab_ord[ord % kHelpers]) == ord + 1) {
+              if (ord >= 0 && lds_get(&s_tab_ord[ord % kTabSlots]) == ord + 1) {
                 const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)in_l, l0);
                 const int32_t idx = (int32_t)((s & 0x7fffffffu) - (g0 & 0x7fffffffu)) + kCand / 2;
                 if (((s ^ g0) >> 31) == 0u && idx >= 0 && idx < kCand) {
-                  const uint32_t v = (uint32_t)rfl((int)s_tab[ord % kHelpers][idx]);
+                  const uint32_t v = (uint32_t)rfl((int)s_tab[ord % kTabSlots][idx]);
                   if ((v & 0x7f800000u) != 0x7f800000u) {  // (NaN: no such candidate)
                     s = v;
                     ok = true;
@@ -1760,13 +1789,16 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
               const int ord = s_auxord[f];
               if (lane == 0) lds_put(&s_progress, f);
               bool from_table = false;
-              if (ord >= 0 && lds_get(&s_tab_ord[ord % kHelpers]) == ord + 1) {  // the tile's candidate table is up
+              int why = 0;
+              if (ord >= 0 && lds_get(&s_tab_ord[ord % kTabSlots]) == ord + 1) {  // the tile's candidate table is up
                 const uint32_t g0 = (uint32_t)s_rec[1][f];
                 const int32_t idx = (int32_t)((s & 0x7fffffffu) - (g0 & 0x7fffffffu)) + kCand / 2;
+                why = 8;
                 if (((s ^ g0) >> 31) == 0u && idx >= 0 && idx < kCand) {
+                  why = 16;
                   // (rfl: the state stays a scalar for the compiler -- one VGPR source and every run's apply() moves
                   // from the scalar unit to the vector unit's dependent-instruction latency)
-                  const uint32_t v = (uint32_t)rfl((int)s_tab[ord % kHelpers][idx]);
+                  const uint32_t v = (uint32_t)rfl((int)s_tab[ord % kTabSlots][idx]);
                   if ((v & 0x7f800000u) != 0x7f800000u) {  // (NaN: no such candidate)
                     s = v;
                     from_table = true;
@@ -1777,6 +1809,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
               }
               if (from_table) {
               } else if (ord >= 0) {  // its helper has the tile's terms and leaf records at hand
+                n_mail += 1u << why;
                 ChainMail *M = &s_mail[ord % kHelpers];
                 if (lane == 0) {
                   __hip_atomic_store(&M->s_in, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1825,7 +1858,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         ticks_walk += (unsigned long long)(stat_clock(W) - t_b);
         // (the row's counters so far: a helper adds them to the launch's behind the last chunk -- a dozen atomics
         // that the walker's own release, in front of its ticket, would wait for)
-        s_stat[0] = n_run; s_stat[1] = n_runfail; s_stat[2] = n_recfail; s_stat[3] = n_tab_nw; s_stat[4] = n_tab_cross;
+        s_stat[0] = n_run; s_stat[1] = n_runfail; s_stat[2] = n_recfail; s_stat[3] = n_tab_nw; s_stat[4] = n_tab_cross; s_stat[5] = n_mail;
         s_stat_ticks[0] = ticks_scan; s_stat_ticks[1] = ticks_walk;
       }
     }
@@ -1848,6 +1881,11 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     atomicAdd(&W.dbg[24], (unsigned long long)s_stat[3]);  // tiles without a window seen, and found in their candidate tables
     atomicAdd(&W.dbg[25], (unsigned long long)s_stat[3]);
     atomicAdd(&W.dbg[45], (unsigned long long)s_stat[4]);
+    if (W.selfcheck & 8) {  // (PCGX_STRICT_CLOCKS: why tiles went to their helpers)
+      atomicAdd(&W.dbg[42], (unsigned long long)(s_stat[5] & 0xffu));
+      atomicAdd(&W.dbg[43], (unsigned long long)((s_stat[5] >> 8) & 0xffu));
+      atomicAdd(&W.dbg[44], (unsigned long long)((s_stat[5] >> 16) & 0xffu));
+    }
   }
   if (walker && lane == 0 && (W.selfcheck & 2)) {  // (row r's stamps ride in tile r's line: words 11 .. 15)
     W.stamps[row * 16 + 11] = (unsigned long long)t_enter;

@@ -35,6 +35,7 @@ for k in range(c["max_iteration"]):
     print("      no window: %d tiles, %d runs tried, %d applied, %d leaves serial, %.1f us each (candidate hits %d of %d) | crossing: %d tiles, %d leaves serial, %.1f us each" % (
         st[16], st[17], st[18], st[22], st[19] / 100.0 / max(st[16], 1), st[25], st[24], st[20], st[23], st[21] / 100.0 / max(st[20], 1)))
     print("      walker, us/row: in failed runs %.1f (waiting for a helper %.1f, %d times; for the backward scan %.1f); fetching the runs' records %.1f, all runs %.1f" % (st[36] / 900.0, st[37] / 900.0, st[38], st[39] / 900.0, st[40] / 900.0, st[41] / 900.0))
+    print("      tiles handed to a helper: table not up %d, state outside the table %d, no such candidate %d" % (st[42], st[43], st[44]))
     if st[46] / 100.0 > 20.0:
         print("      walk per row, us:", " ".join("%.1f" % (st[27 + r] / 100.0) for r in range(9)))
     if any(st[48:63]):
