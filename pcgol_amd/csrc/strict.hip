@@ -1503,18 +1503,18 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       // to another wave: the walk's first microsecond ran at half its rate next to that scan's 700 instructions)
       constexpr int kQuiet = kWalker - 4;
       if (wave != kQuiet) scan_backwards(wave, R, tail);
+      if (second_early) {
+#pragma unroll
+        for (int j = 0; j < kCand / kLanes; j++) s_tab[wave + kHelpers][j * kLanes + lane] = cand_out[j];
+        lds_fence_wave();
+        if (lane == 0) lds_put(&s_tab_ord[wave + kHelpers], wave + kHelpers + 1);
+      }
       if (wave == 0 || wave == 2) {
         const int seg = wave == 0 ? kWalker : kQuiet;
         const TileRec Ro = rec_get(s_rec, seg * 64 + lane);
         const int32_t kn = lane_next(Ro.key, Ro.key);
         const int ao = stands_alone(Ro) ? 1 : 0, ao_next = lane_next(ao, 0);
         scan_backwards(seg, Ro, lane == 63 || Ro.key < 0 || Ro.key != kn || ao || ao_next);
-      }
-      if (second_early) {
-#pragma unroll
-        for (int j = 0; j < kCand / kLanes; j++) s_tab[wave + kHelpers][j * kLanes + lane] = cand_out[j];
-        lds_fence_wave();
-        if (lane == 0) lds_put(&s_tab_ord[wave + kHelpers], wave + kHelpers + 1);
       }
       // the pair count of the iteration: a helper of row 0 adds up the tiles' counts while the walk runs (integers: no
       // order to keep); the walker stores it with its sum
