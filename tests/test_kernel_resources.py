@@ -28,3 +28,15 @@ def test_no_scratch_in_the_hot_kernels(source):
         for name, r in hits.items():
             assert r.get("ScratchSize") == 0, (name, r)
             assert r.get("VGPRs Spill") == 0, (name, r)
+
+
+def test_the_chain_kernel_fits_a_cu():
+    """strict_chain_kernel keeps its chunk's records, their compositions both ways and fourteen candidate tables in LDS
+    (154 KB): both builds of it must stay inside the CU's 160 KB, and at 256 registers or fewer a lane (eight waves of
+    a workgroup, two per SIMD)."""
+    ks = KR.resources("strict.hip")
+    hits = {n: r for n, r in ks.items() if "strict_chain_kernel" in n}
+    assert len(hits) == 2, sorted(ks)
+    for name, r in hits.items():
+        assert 0 < r.get("LDS Size", 0) <= 160 * 1024, (name, r)
+        assert r.get("VGPRs", 999) <= 256 and r.get("VGPRs Spill") == 0, (name, r)
