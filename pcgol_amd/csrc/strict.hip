@@ -1901,43 +1901,47 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     if (!W.hop_out) __hip_atomic_store(&sums10[S_PAIRS], (double)s_np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // component order of sums10: Value, G0..G5, DistRMS, Weight, Pairs
-  if (walker && lane == 0) {
-    const int slot = row == 0 ? S_VALUE : (row <= 6 ? S_G0 + row - 1 : (row == 7 ? S_DIST_RMS : S_WEIGHT));
-    if (W.hop_out) W.hop_out[row] = (double)s;  // the state's BITS, as a number: the next rank's walk starts there
-    else __hip_atomic_store(&sums10[slot], (double)u2f(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // the row that finishes last has all nine sums: evaluate tail + pose update (evaluator.go:156-186,
-    // updater.go:44-71) in the same launch
-    // (the sum went out write-through, and the last row reads the sums past the caches: what the ticket has to wait
-    // for is that one store's arrival, not a write-back of everything the workgroup has written -- a release fence
-    // here and an acquire fence behind the ticket were 0.6 us of the launch's tail)
-    if (W.hop_out) __threadfence();
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned ticket = atomicAdd(W.done_rows, 1u);
-    if (ticket == (unsigned)W.nrows - 1u && W.hop_out) {  // (sharded: the sums are put together behind the last rank's walk)
-      for (int k = 0; k < kAuxShards; k++) W.aux_count[k * 32] = 0u;
+  if (walker) {
+    unsigned ticket = 0u;
+    if (lane == 0) {
+      const int slot = row == 0 ? S_VALUE : (row <= 6 ? S_G0 + row - 1 : (row == 7 ? S_DIST_RMS : S_WEIGHT));
+      if (W.hop_out) W.hop_out[row] = (double)s;  // the state's BITS, as a number: the next rank's walk starts there
+      else __hip_atomic_store(&sums10[slot], (double)u2f(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // the row that finishes last has all nine sums: evaluate tail + pose update (evaluator.go:156-186,
+      // updater.go:44-71) in the same launch
+      // (the sum went out write-through, and the last row reads the sums past the caches: what the ticket has to wait
+      // for is that one store's arrival, not a write-back of everything the workgroup has written -- a release fence
+      // here and an acquire fence behind the ticket were 0.6 us of the launch's tail)
+      if (W.hop_out) __threadfence();
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ticket = atomicAdd(W.done_rows, 1u);
+    }
+    ticket = (unsigned)rfl((int)ticket);  // (lane 0's, in every lane: the launch's last steps are the whole wave's)
+    if (ticket == (unsigned)W.nrows - 1u) {  // uniform
+      // the counters of this iteration's exchange and job slots, for the next one: a word per lane (one lane took
+      // eighty stores, one after the other, between the ticket and the pose update)
+      static_assert(kAuxShards == kLanes, "a shard's counter per lane");
+      W.aux_count[lane * 32] = 0u;
       if (W.exchange)
-        for (int64_t k = 0, n = (W.ntiles + 31) / 32, m = n + (n + 31) / 32; k < m; k++) W.tile_arrived[32 * k] = 0u;
-      *W.done_rows = 0u;
-    } else if (ticket == (unsigned)W.nrows - 1u) {
-      double sums[S_COUNT];
-      for (int k = 0; k < S_COUNT; k++) sums[k] = __hip_atomic_load(&sums10[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long np = (unsigned long long)sums[S_PAIRS];  // row 0 stored it before its ticket
-      if (W.nrows < kStrictRows) {
-        // default weight: every term of the ninth sum is 1.0f, and 0 + 1 + 1 + ... in float32 is the pair
-        // count up to 2^24, where it stays (2^24 + 1 rounds back to 2^24): no chain to evaluate
-        sums[S_WEIGHT] = (double)(np < (1ull << 24) ? np : (1ull << 24));
-        sums10[S_WEIGHT] = sums[S_WEIGHT];
-      }
-      for (int k = 0; k < kAuxShards; k++) W.aux_count[k * 32] = 0u;
-      if (W.exchange)
-        for (int64_t k = 0, n = (W.ntiles + 31) / 32, m = n + (n + 31) / 32; k < m; k++) W.tile_arrived[32 * k] = 0u;
-      *W.done_rows = 0u;
-      const long long t_u0 = trace_clock(W);
-      if (fuse_update) icp_update_step(state, sums, kp);
-      if (W.selfcheck & 2) {  // (the launch's last steps, in the line behind the rows')
-        __threadfence();
-        W.stamps[kStrictRows * 16 + 14] = (unsigned long long)t_u0;
-        W.stamps[kStrictRows * 16 + 15] = (unsigned long long)trace_clock(W);
+        for (int64_t k = lane, n = (W.ntiles + 31) / 32, m = n + (n + 31) / 32; k < m; k += kLanes) W.tile_arrived[32 * k] = 0u;
+      if (lane == 0) *W.done_rows = 0u;
+      if (!W.hop_out && lane == 0) {  // (sharded: the sums are put together behind the last rank's walk)
+        double sums[S_COUNT];
+        for (int k = 0; k < S_COUNT; k++) sums[k] = __hip_atomic_load(&sums10[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long np = (unsigned long long)sums[S_PAIRS];  // row 0 stored it before its ticket
+        if (W.nrows < kStrictRows) {
+          // default weight: every term of the ninth sum is 1.0f, and 0 + 1 + 1 + ... in float32 is the pair
+          // count up to 2^24, where it stays (2^24 + 1 rounds back to 2^24): no chain to evaluate
+          sums[S_WEIGHT] = (double)(np < (1ull << 24) ? np : (1ull << 24));
+          sums10[S_WEIGHT] = sums[S_WEIGHT];
+        }
+        const long long t_u0 = trace_clock(W);
+        if (fuse_update) icp_update_step(state, sums, kp);
+        if (W.selfcheck & 2) {  // (the launch's last steps, in the line behind the rows')
+          __threadfence();
+          W.stamps[kStrictRows * 16 + 14] = (unsigned long long)t_u0;
+          W.stamps[kStrictRows * 16 + 15] = (unsigned long long)trace_clock(W);
+        }
       }
     }
   }
