@@ -25,8 +25,12 @@ def hipcc():
 
 
 def flags():
+    # (-align-all-nofallthru-blocks=6: loop heads and branch targets on 64-byte instruction-cache lines -- the walker
+    # wave of strict_chain_kernel is one wave's instruction stream, and where its blocks fall was worth 0.4-0.5 us of
+    # the ICP step either way, HISTORY.md)
     return ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-            "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-x", "hip"] + \
+            "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-result", "-mllvm", "-align-all-nofallthru-blocks=6",
+            "-x", "hip"] + \
         os.environ.get("PCGX_EXTRA_CFLAGS", "").split()  # experiments only (e.g. -DPCGX_WALK_TOP_LEVELS=6)
 
 
@@ -35,6 +39,7 @@ def source_hash():
     collected on, bench.py says whether that is the build it is timing."""
     import hashlib
     h = hashlib.sha256()
+    h.update(" ".join(flags()).encode())  # (the compiler's switches are part of what a library was built from)
     for s in sorted(SOURCES + [x for x in HEADERS if not x.startswith("..")]):
         with open(os.path.join(CSRC, s), "rb") as f:
             h.update(s.encode() + b"\0" + f.read())
