@@ -1301,6 +1301,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   __shared__ int16_t s_auxlist[kChainTiles];  // the tiles that own a slot, in order
   __shared__ int16_t s_auxord[kChainTiles];   // a tile's place in that list, -1: owns no slot
   __shared__ int32_t s_count[kChainSegs], s_auxcnt[kChainSegs];
+  __shared__ uint32_t s_auxmask[kChainSegs][2];  // which tiles of a segment own a slot
   __shared__ int s_sufok[kChainSegs];
   __shared__ int s_pre_cnt[2];             // forward scans done, of segments 0 .. 3 | 4 .. 7
   __shared__ int s_progress;               // walker: the tile it stands at (tiles below are done)
@@ -1383,7 +1384,11 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       }
       if (lane == 0) s_count[wave] = __popcll(tails);
       const unsigned long long aux = __ballot(valid && (R.cons >> 8) != 0);
-      if (lane == 0) s_auxcnt[wave] = __popcll(aux);
+      if (lane == 0) {
+        s_auxcnt[wave] = __popcll(aux);
+        s_auxmask[wave][0] = (uint32_t)aux;
+        s_auxmask[wave][1] = (uint32_t)(aux >> 32);
+      }
     }
     if (done) return;  // uniform (nothing but LDS has been written)
     __syncthreads();
@@ -1653,7 +1658,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         if ((W.selfcheck & 2) && chunk == 0 && r0 == 0 && lane == 0) s_wk[5] = (unsigned long long)trace_clock(W);  // the walk starts
         const long long t_f0 = stat_clock(W);
         const int my_run = r0 + (lane >> 2), my_class = lane & 3;
-        int e_l = 0, h_l = 0;
+        int e_l = 0, h_l = 0, j_l = -1;
         int32_t key_l = -2, cons_l = 0, c_l = 0, lo_l = kBig, hi_l = -kBig, ord_l = -1;
         uint32_t in_l = 0u, out_l = 0u;
         if (my_run < r1) {
@@ -1672,13 +1677,18 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           hi_l = s_pre[12 + my_class][e_l];
           // a run of ONE tile that owns a slot (a tile without a window always is one): its place among the job tiles
           if (h_l == e_l) ord_l = s_auxord[e_l];
+          // a longer run: its first tile that owns a slot (-1: none) -- where such a run fails, nearly always
+          const unsigned long long owners = ((unsigned long long)s_auxmask[h_l >> 6][1] << 32 | s_auxmask[h_l >> 6][0]) >> (h_l & 63);
+          const int len = e_l - h_l + 1;
+          const unsigned long long inside = len < 64 ? owners & ((1ull << len) - 1ull) : owners;
+          if (inside != 0ull) j_l = h_l + __builtin_ctzll(inside);
         }
         const int n_here = rfl(r1 - r0);  // (a scalar for the compiler: the loops below are uniform)
         // (the records are in their registers HERE: left to the compiler, the wait for them sits at the top of the
         // loop below, where every turn it also waits for the turn before's store of the progress word)
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(key_l), "+v"(in_l), "+v"(out_l), "+v"(cons_l), "+v"(c_l), "+v"(lo_l), "+v"(hi_l), "+v"(e_l), "+v"(h_l),
-                       "+v"(ord_l));
+                       "+v"(ord_l), "+v"(j_l));
         if ((W.selfcheck & 8)) {
           const unsigned long long tt = clock_after((uint32_t)(key_l ^ hi_l ^ e_l));
           if (lane == 0) s_wk[4] += tt - (unsigned long long)t_f0;
@@ -1758,6 +1768,50 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           const int e = __builtin_amdgcn_readlane(e_l, l0), h = __builtin_amdgcn_readlane(h_l, l0);
           n_runfail++;
           const long long t_fail = stat_clock(W);
+          // Where a run of several tiles fails it is nearly always at a tile that owns a slot (a level crossing whose
+          // record covers the states next to its guess only).  The run's first such tile j straight away: the
+          // composition h .. j - 1 (the forward scan's), j's candidate table, the composition j + 1 .. e (the backward
+          // scan's) -- three look-ups instead of the search below for the tile that fails, that tile's own record,
+          // its table and the rest.  Any of the three not covering the state: the search below, from the run's head.
+          if (!kCheck && e > h) {
+            const int jt = __builtin_amdgcn_readlane(j_l, l0);
+            if (jt >= 0) {
+              const int ord = rfl((int)s_auxord[jt]);
+              uint32_t st = s;
+              bool okj = true;
+              if (jt > h) {
+                const TileRec P = load_rec_uniform(s_pre, jt - 1);
+                okj = P.key >= 0 && apply(st, P.key, P.s);
+              }
+              if (okj) {
+                okj = false;
+                if (lds_get(&s_tab_ord[ord % kTabSlots]) == ord + 1) {  // the tile's candidate table is up
+                  const uint32_t g0 = (uint32_t)rfl(s_rec[1][jt]);
+                  const int32_t idx = (int32_t)((st & 0x7fffffffu) - (g0 & 0x7fffffffu)) + kCand / 2;
+                  if (((st ^ g0) >> 31) == 0u && idx >= 0 && idx < kCand) {
+                    const uint32_t v = (uint32_t)rfl((int)s_tab[ord % kTabSlots][idx]);
+                    if ((v & 0x7f800000u) != 0x7f800000u) {  // (NaN: no such candidate)
+                      st = v;
+                      okj = true;
+                    }
+                  }
+                }
+              }
+              if (okj && jt < e) {
+                while (lds_get(&s_sufok[(jt + 1) >> 6]) == 0) {
+                }
+                const TileRec Sf = load_rec_uniform(s_suf, jt + 1);
+                okj = (Sf.key >= 0 && apply(st, Sf.key, Sf.s)) || apply_point(st, Sf);
+              }
+              if (okj) {
+                s = st;
+                n_recfail++;
+                n_tab_cross++;
+                __hip_atomic_store(&s_progress, e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                continue;
+              }
+            }
+          }
           // which tile?  lane j tries the composition h .. h + j
           int f = h;
           if (e > h) {

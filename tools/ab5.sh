@@ -1,6 +1,6 @@
 out=gpurun_out/ab5.log; : > $out
-for i in 1 2 3 4 5 6; do
-  for lib in tree experiments/ab/libpcgx_noalign.so experiments/ab/libpcgx_align7.so; do
+for i in 1 2 3 4 5 6 7 8 9 10 11 12; do
+  for lib in tree experiments/ab/libpcgx_head.so; do
     if [ $lib = tree ]; then unset PCGX_LIB; else export PCGX_LIB=$lib; fi
     echo -n "$lib $i: " >> $out
     python bench.py --steps 4000 --warmup 400 --no-cpu-baseline --no-extras 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])" >> $out 2>&1
