@@ -1,6 +1,10 @@
 // Package pcgx binds libpcgx.so (include/pcgx.h), the MI355X hot path, behind
 // seqsense/pcgol's interfaces: storage.Search, filter.Filter, icp.Evaluator.
 //
+// The reference's package surface over this binding -- kdtree.New, voxelgrid.New / WithChunkSize,
+// icp.NearestPointCorresponder / PointToPointEvaluator / PointToPointICPGradient under their own names and
+// signatures -- is in ../pc/storage/kdtree, ../pc/filter/voxelgrid, ../pc/registration/icp.
+//
 // NOT compiled in the build image (no Go toolchain there); see go/README.md.
 package pcgx
 
@@ -17,6 +21,7 @@ import (
 	"fmt"
 	"math"
 	"runtime"
+	"sync/atomic"
 	"unsafe"
 
 	"github.com/seqsense/pcgol/mat"
@@ -26,9 +31,23 @@ import (
 	"github.com/seqsense/pcgol/pc/storage"
 )
 
+// (import path of this package: github.com/seqsense/pcgol/gpu/pcgx, go/go.mod)
+
 // ErrOutOfRange is returned where the pure-Go filter would panic with
 // "index out of range" (pc/filter/voxelgrid/voxelgrid.go:151).
 var ErrOutOfRange = errors.New("pcgx: point outside the dense voxel grid")
+
+// ErrNeedsDevice: a sharded Fit was asked of an evaluator that cannot run on the device (a WeightFn closure, a
+// Corresponder of the caller's own).
+var ErrNeedsDevice = errors.New("pcgx: this evaluator cannot run on the device (WeightFn closure or foreign Corresponder)")
+
+// singlePointCalls counts KDTree.Nearest / Range calls for ONE point: each is a blocking GPU call (tens of
+// microseconds), so a loop over them -- the reference's own correspondence.go:25-36, regiongrowing.go:26,47 -- is
+// slower than the CPU tree.  Tests of callers that were moved to the batch seams assert the counter stays put.
+var singlePointCalls int64
+
+// SinglePointCalls returns how many single-point Nearest / Range calls this process has made.
+func SinglePointCalls() int64 { return atomic.LoadInt64(&singlePointCalls) }
 
 func lastError() string {
 	buf := make([]byte, 512)
@@ -265,6 +284,7 @@ func (k *KDTree) NearestBatch(q []mat.Vec3, maxRange float32) ([]storage.Neighbo
 
 // Nearest keeps storage.Search working for single points (one tiny batch).
 func (k *KDTree) Nearest(p mat.Vec3, maxRange float32) storage.Neighbor {
+	atomic.AddInt64(&singlePointCalls, 1)
 	r, err := k.NearestBatch([]mat.Vec3{p}, maxRange)
 	if err != nil {
 		panic(err)
@@ -313,6 +333,7 @@ func (k *KDTree) RangeBatch(q []mat.Vec3, maxRange float32) ([][]storage.Neighbo
 
 // Range keeps storage.Search working for single points.
 func (k *KDTree) Range(p mat.Vec3, maxRange float32) []storage.Neighbor {
+	atomic.AddInt64(&singlePointCalls, 1)
 	r, err := k.RangeBatch([]mat.Vec3{p}, maxRange)
 	if err != nil {
 		panic(err)

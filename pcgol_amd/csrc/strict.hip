@@ -1175,6 +1175,7 @@ constexpr int kChainBlock = kChainTiles;
 constexpr int kWalker = kChainSegs - 1;       // the wave that walks (after the forward scan of its own segment)
 constexpr int kTabSlots = 2 * (kChainSegs - 1);  // candidate tables in LDS: two per helper
 constexpr int kHelpers = kChainSegs - 1;      // the others (eight waves, two per SIMD: 256 registers each, no scratch)
+constexpr long long kChunkWaitTicks = 5000000;  // 50 ms (s_memrealtime runs at 100 MHz): a later chunk's wait for its start state
 
 // The chunk's records in LDS, one array per word ([word][tile]): lane-indexed reads and writes of whole records
 // then touch 64 consecutive words per instruction.  As an array of 64-byte structs every such access was a
@@ -1322,14 +1323,19 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   // (rfl: "which wave" is the same in all lanes, and the compiler has to know -- or the branch between walker and
   // helpers counts as divergent, the walker's state becomes a vector register, and every apply() of the walk runs
   // on the vector unit at its dependent-instruction latency instead of on the scalar unit)
-  const int row = blockIdx.x, lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
+  // (blocks chunk-major: the walkers wait for LOWER block indices only, and an XCD hands out a launch's blocks in
+  // ascending order -- the lowest unfinished chunk is resident or next in line whatever part of the grid is)
+  const int row = (int)(blockIdx.x % (unsigned)W.nrows), my_chunk = (int)(blockIdx.x / (unsigned)W.nrows);
+  const int lane = threadIdx.x & 63, wave = rfl((int)(threadIdx.x >> 6));
   const bool walker = wave == kWalker;
+  const bool last_chunk = my_chunk == W.nchunks - 1;  // uniform: this workgroup's walker ends the row
   // (the pairs' source is put together where a tile is formed again from the pairs -- rare -- and not kept: its
   // eighteen words would sit in scalar registers through the whole walk, which runs on the scalar unit and had
   // 188 of its registers spilled into vector lanes)
   auto term_src = [&]() { return make_term_src(match, pos_of, state, W); };
   // walker state, evaluator.go:122: the sums start at zero -- or where the ranks before this one ended (a target
   // spread over ranks, strict_enqueue_sharded)
+  // (a later chunk's walker: the state the chunk before it ended in, below)
   uint32_t s = W.start_bits ? (uint32_t)rfl((int)W.start_bits[row]) : f2u(0.0f);
   // walker: counters of the whole row, written once behind the last chunk (an atomic in flight holds up the
   // next release store of its wave, and the walk is a chain of those).  Vector registers (opaque to the compiler):
@@ -1340,7 +1346,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   unsigned long long ticks_scan = 0, ticks_walk = 0;
   const long long t_enter = trace_clock(W);  // (PCGX_STRICT_TRACE: the row's stamps)
   const unsigned long long c_enter = (W.selfcheck & 2) ? (unsigned long long)__builtin_readcyclecounter() : 0ull;
-  for (int64_t chunk = 0; chunk < W.ntiles; chunk += kChainTiles) {
+  {
+    const int64_t chunk = (int64_t)my_chunk * kChainTiles;
     const long long t_a = stat_clock(W);
     if (threadIdx.x < kChainSegs) {
       s_sufok[threadIdx.x] = 0;
@@ -1351,9 +1358,9 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     if (threadIdx.x == 0) {
       s_progress = 0;
       s_pre_cnt[0] = s_pre_cnt[1] = 0;
-      if (chunk == 0) s_np_ok = 0;
+      s_np_ok = 0;
     }
-    if (chunk == 0 && threadIdx.x < 8) s_wk[threadIdx.x] = 0ull;
+    if (threadIdx.x < 8) s_wk[threadIdx.x] = 0ull;
     // ---- helpers: runs of equal windows, segmented scan forwards inside each wave
     TileRec R;
     R.key = -2;
@@ -1365,7 +1372,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       const int64_t tile = chunk + threadIdx.x;
       valid = tile < W.ntiles;
       if (valid) R = W.recs[row * W.ntiles + tile];
-      if ((W.selfcheck & 2) && chunk == 0 && walker) {
+      if ((W.selfcheck & 2) && last_chunk && walker) {
         const unsigned long long tt = clock_after((uint32_t)R.key);
         if (lane == 0) s_wk[4] = tt;  // (PCGX_STRICT_TRACE: the row's records have arrived)
       }
@@ -1523,7 +1530,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       }
       // the pair count of the iteration: a helper of row 0 adds up the tiles' counts while the walk runs (integers: no
       // order to keep); the walker stores it with its sum
-      if (row == 0 && wave == 1 && chunk == 0) {
+      if (row == 0 && wave == 1 && last_chunk) {
         unsigned long long v = 0ull;
         for (int64_t t = lane; t < W.ntiles; t += kLanes) v += W.tile_pairs[t];
 #pragma unroll
@@ -1625,7 +1632,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             if (!hit && have_cand) {  // measurement aid: how far off the guess was (log2 of the distance in floats)
               const uint32_t m = s_in & 0x7fffffffu, gm = g0 & 0x7fffffffu;
               const uint32_t dist = m > gm ? m - gm : gm - m;
-              const int bucket = ((s_in ^ g0) >> 31) ? 15 : (dist == 0u ? 0 : (32 - __clz((int)dist) > 14 ? 14 : 32 - __clz((int)dist)));
+              // (dbg[48 .. 59]; [60 .. 63] belong to the chunks' hand-over and the summary kernel's exchange)
+              const int bucket = ((s_in ^ g0) >> 31) ? 11 : (dist == 0u ? 0 : (32 - __clz((int)dist) > 10 ? 10 : 32 - __clz((int)dist)));
               atomicAdd(&W.dbg[48 + bucket], 1ull);
             }
             resolve_stats(W, cur_kind, serial, tried, applied, stat_clock(W) - t_begin);
@@ -1636,6 +1644,53 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     } else {
       // ---- the walk: one wave, every lane with the same state
       const long long t_b = stat_clock(W);
+      if (my_chunk > 0) {  // uniform
+        // The state the chunk before this one ended in: ONE 64-bit word, bits | epoch, stored write-through by that
+        // chunk's walker and read past the caches here (a word of an earlier launch carries an earlier epoch).  The wait
+        // is for a lower block index of this launch, which is resident or next in line (above); it is bounded by
+        // wall-clock time all the same (launches running side by side could hold each other's next workgroups out):
+        // a walker that gives up walks the row's earlier tiles ALONE -- their records are all in memory since the
+        // launch before this one -- applying what covers its state and adding the other tiles term by term from the
+        // pairs: slow, and the same state (dbg[62] counts; the tests require 0).
+        const unsigned long long *src = W.chunk_state + ((size_t)row * W.nchunks + my_chunk) * 16;
+        bool have = false;
+        long long t_first = 0;
+        for (int spins = 0;; spins++) {  // uniform
+          const unsigned long long v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)rfl((int)(uint32_t)(v >> 32)) == W.epoch) {
+            s = (uint32_t)rfl((int)(uint32_t)v);
+            have = true;
+            break;
+          }
+          if ((spins & 31) == 31) {  // (a clock read is a memory round trip: now and then)
+            const long long now = (long long)wall_clock64();
+            if (t_first == 0) t_first = now;
+            if (now - t_first > kChunkWaitTicks) break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (!have) {
+          uint32_t x = s;  // (the row's first state)
+          for (int64_t t = 0; t < chunk; t++) {  // uniform
+            const TileRec V = W.recs[row * W.ntiles + t];
+            TileRec T;
+            T.key = rfl(V.key); T.in = (uint32_t)rfl((int)V.in); T.out = (uint32_t)rfl((int)V.out); T.cons = rfl(V.cons);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              T.s.c[q] = rfl(V.s.c[q]);
+              T.s.lo[q] = rfl(V.s.lo[q]);
+              T.s.hi[q] = rfl(V.s.hi[q]);
+            }
+            if ((T.key >= 0 && apply(x, T.key, T.s)) || apply_point(x, T)) continue;
+            recompute_tile_to_lds(term_src(), row, t, lane, s_tile);
+            x = (uint32_t)rfl((int)serial_leaves(x, s_tile, 0, kLanes));
+            __builtin_amdgcn_wave_barrier();
+          }
+          s = x;
+          if (lane == 0) atomicAdd(&W.dbg[62], 1ull);
+        }
+        if ((W.selfcheck & 8) && lane == 0) s_wk[6] = (unsigned long long)(stat_clock(W) - t_b);  // (waited for the chunk before)
+      }
       // The runs of the chunk, sixteen at a time: the four lanes 4 j .. 4 j + 3 fetch run j's ends and its composed
       // record, lane 4 j + r the piece of class r.  The walk then takes a run out of the registers: its window, and --
       // once the state says which class it is in -- that class's bounds and step from lane 4 j + r: five v_readlane
@@ -1655,7 +1710,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
         const int bound = half == 0 ? n_runs_lo : n_runs;
         r1 = r0 + kBatch < bound ? r0 + kBatch : bound;
         while (lds_get(&s_pre_cnt[half]) < kChainSegs / 2) __builtin_amdgcn_s_sleep(1);
-        if ((W.selfcheck & 2) && chunk == 0 && r0 == 0 && lane == 0) s_wk[5] = (unsigned long long)trace_clock(W);  // the walk starts
+        if ((W.selfcheck & 2) && last_chunk && r0 == 0 && lane == 0) s_wk[5] = (unsigned long long)trace_clock(W);  // the walk starts
         const long long t_f0 = stat_clock(W);
         const int my_run = r0 + (lane >> 2), my_class = lane & 3;
         int e_l = 0, h_l = 0, j_l = -1;
@@ -1906,6 +1961,9 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           if (lane == 0) s_wk[5] += tt - (unsigned long long)t_j0;
         }
       }
+      if (!last_chunk && lane == 0)  // the next chunk's walker starts here
+        __hip_atomic_store(W.chunk_state + ((size_t)row * W.nchunks + my_chunk + 1) * 16, (unsigned long long)W.epoch << 32 | s,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (lane == 0) {
         lds_put(&s_progress, 1 << 30);  // helpers that still wait for a tile: the chunk is done
         ticks_scan += (unsigned long long)(t_b - t_a);
@@ -1929,6 +1987,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     atomicAdd(&W.dbg[27 + row], walk_ticks);  // per row: walk ticks, tiles resolved
     if (W.selfcheck & 8) {  // (the rows' own counts of tiles resolved give way to the walkers' tick columns)
       for (int k = 0; k < 6; k++) atomicAdd(&W.dbg[36 + k], s_wk[k]);
+      atomicAdd(&W.dbg[60], s_wk[6]);  // walkers of later chunks: waiting for their start state (part of the walk ticks)
+      if (last_chunk) atomicAdd(&W.dbg[61], s_wk[6]);  // ... the rows' last chunks alone: the row's walk up to there
     } else {
       atomicAdd(&W.dbg[36 + row], (unsigned long long)s_stat[2]);
     }
@@ -1941,6 +2001,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       atomicAdd(&W.dbg[44], (unsigned long long)((s_stat[5] >> 16) & 0xffu));
     }
   }
+  if (!last_chunk) return;  // uniform
   if (walker && lane == 0 && (W.selfcheck & 2)) {  // (row r's stamps ride in tile r's line: words 11 .. 15)
     W.stamps[row * 16 + 11] = (unsigned long long)t_enter;
     W.stamps[row * 16 + 10] = (unsigned long long)__builtin_readcyclecounter() - c_enter;  // shader clocks in the kernel
@@ -2051,7 +2112,10 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   const size_t sz_xyz = up((size_t)(nt ? nt : 1) * 12 + 64);
   const size_t sz_stamps = up((size_t)W.ntiles * 16 * sizeof(unsigned long long));
   const size_t sz_ctr = 256 + (size_t)kAuxShards * 128;
-  const size_t total = 2 * sz_tile + sz_pub + sz_arr + sz_pairs + sz_rec + sz_aux + sz_auxt + sz_jobs + sz_cand + sz_xyz + sz_ctr + 512 + sz_stamps;
+  W.nchunks = (int32_t)((W.ntiles + kChainTiles - 1) / kChainTiles);
+  W.epoch = 0u;
+  const size_t sz_chunk = up((size_t)kStrictRows * W.nchunks * 16 * sizeof(unsigned long long));
+  const size_t total = 2 * sz_tile + sz_pub + sz_arr + sz_pairs + sz_rec + sz_aux + sz_auxt + sz_jobs + sz_cand + sz_xyz + sz_ctr + 512 + sz_stamps + sz_chunk;
   hipError_t e = dev_cache_alloc(&b->block, total);
   if (e != hipSuccess) {
     delete b;
@@ -2073,10 +2137,12 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   W.done_rows = (unsigned int *)(p + 12);
   W.aux_count = (unsigned int *)(p + 256); p += sz_ctr;
   W.dbg = (unsigned long long *)p; p += 512;
-  W.stamps = (unsigned long long *)p;
+  W.stamps = (unsigned long long *)p; p += sz_stamps;
+  W.chunk_state = (unsigned long long *)p;
   // slot / ticket counters and debug counters start at zero (the chain kernel re-zeroes what it consumed)
   e = hipMemsetAsync(counters, 0, sz_ctr + 512, st);
   if (e == hipSuccess) e = hipMemsetAsync(W.tile_arrived, 0, sz_arr, st);
+  if (e == hipSuccess) e = hipMemsetAsync(W.chunk_state, 0, sz_chunk, st);  // (epoch 0: no launch's)
   if (e == hipSuccess && nt > 0) {
     hipLaunchKernelGGL(strict_xyz_caller_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, tx, ty, tz, pos_of, nt,
                        const_cast<float *>(W.xyz_caller));
@@ -2105,10 +2171,16 @@ const StrictWork *strict_work(StrictBuffers *b, const IcpKernelParams &kp) {
   b->w.nrows = kp.weight_fn == PCGX_WEIGHT_ONE ? kStrictRows - 1 : kStrictRows;
   return &b->w;
 }
+// a launch of the chain kernel: its epoch (the chunks' hand-over words, StrictWork::chunk_state)
+static const StrictWork &next_epoch(StrictBuffers *b) {
+  if (++b->w.epoch == 0u) b->w.epoch = 1u;  // (a wrap after 2^32 launches: stale words are 2^32 launches old by then)
+  return b->w;
+}
 
 pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
                            double *sums10, const IcpKernelParams &kp, bool fuse_update, bool have_tile_sums, hipStream_t st) {
-  const StrictWork &W = *strict_work(b, kp);
+  (void)strict_work(b, kp);
+  const StrictWork &W = next_epoch(b);
   if (!have_tile_sums && !W.exchange) {
     ProfScope prof(PCGX_PROF_STRICT_TERMS, st);
     hipLaunchKernelGGL(strict_tilesum_kernel, dim3((unsigned)W.ntiles), dim3(kTileSumBlock), 0, st, match, pos_of,
@@ -2131,10 +2203,10 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
   {
     ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
     if (W.selfcheck & 1)
-      hipLaunchKernelGGL(strict_chain_kernel<true>, dim3((unsigned)W.nrows), dim3(kChainBlock), 0, st, match, pos_of, state, W,
+      hipLaunchKernelGGL(strict_chain_kernel<true>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
                          sums10, kp, fuse_update ? 1 : 0);
     else
-      hipLaunchKernelGGL(strict_chain_kernel<false>, dim3((unsigned)W.nrows), dim3(kChainBlock), 0, st, match, pos_of, state, W,
+      hipLaunchKernelGGL(strict_chain_kernel<false>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
                          sums10, kp, fuse_update ? 1 : 0);
   }
   PCGX_HIP_TRY(hipGetLastError());
@@ -2220,7 +2292,7 @@ pcgx_status strict_enqueue_sharded(StrictBuffers *b, const float4 *match, const 
   double *slots = b->shard, *row_base = slots + (size_t)world * 16, *err_base = row_base + 16, *hop = row_base + 32;
   uint32_t *start_bits = reinterpret_cast<uint32_t *>(hop + 16);
   (void)strict_work(b, kp);
-  StrictWork W = b->w;  // (the session's descriptor stays in its one-GPU form)
+  StrictWork W = next_epoch(b);  // (the session's descriptor stays in its one-GPU form)
   W.row_base = row_base;
   W.err_base = err_base;
   W.start_bits = start_bits;
@@ -2272,10 +2344,10 @@ pcgx_status strict_enqueue_sharded(StrictBuffers *b, const float4 *match, const 
     if (k == rank && !local_failed) {
       ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
       if (W.selfcheck & 1)
-        hipLaunchKernelGGL(strict_chain_kernel<true>, dim3((unsigned)W.nrows), dim3(kChainBlock), 0, st, match, pos_of, state, W,
+        hipLaunchKernelGGL(strict_chain_kernel<true>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
                            sums10, kp, 0);
       else
-        hipLaunchKernelGGL(strict_chain_kernel<false>, dim3((unsigned)W.nrows), dim3(kChainBlock), 0, st, match, pos_of, state, W,
+        hipLaunchKernelGGL(strict_chain_kernel<false>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
                            sums10, kp, 0);
     }
     PCGX_TRY(exchange(hop, 16, 10));

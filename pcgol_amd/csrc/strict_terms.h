@@ -115,6 +115,13 @@ struct StrictWork {
   const uint32_t *start_bits; // [9]
   double *hop_out;            // [16]
   int32_t first_exact;        // this rank holds the first tile of the whole target (added up term by term from 0.0f)
+  // The chain kernel runs one workgroup per (sum, chunk of 512 tiles): everything but the walk is independent between
+  // chunks.  chunk_state[(row * nchunks + c) * 16] = the state row `row` has in front of chunk c, bits in the low word
+  // and `epoch` in the high one: ONE 64-bit word written write-through by chunk c - 1's walker and polled by chunk
+  // c's -- a word of an earlier launch carries an earlier epoch, nothing is ever reset.
+  unsigned long long *chunk_state;
+  int32_t nchunks;
+  uint32_t epoch;             // this launch's (counted by the host, from 1)
   int32_t selfcheck;  // bit 0: every step of the chain walk is re-derived term by term and compared (dbg[12..15]);
                       // 1: PCGX_STRICT_TRACE stamps; 2: no candidate tables; 3: wall-clock columns of the counters
 };

@@ -559,5 +559,35 @@ def test_weight_fns_at_c4_full_size_match_the_oracle(wf):
         assert np.array_equal(tr, o32["trans"]) and st.Evaluated.Value == o32["value"]
         assert np.array_equal(st.Evaluated.Gradient, o32["gradient"]) and st.Evaluated.DistRMS == o32["dist_rms"]
         assert sst[63] == 0   # no workgroup of the summary kernel gave up waiting for the tiles before it
+        assert sst[62] == 0   # no walker of the chain kernel gave up waiting for the chunk before its own
     finally:
         O.set_weight_fn(0, 0.0)
+
+
+def test_chain_kernel_chunks_hand_the_walk_on():
+    """2.6M targets = 1270 tiles per sum = three chunks of the chain kernel, each a workgroup of its own whose walker
+    starts where the chunk before it ended (csrc/strict.hip, StrictWork::chunk_state): iteration 0's Evaluated against
+    the oracle's sequential float32 sums bit for bit, then five iterations against the one-wave chain on the device;
+    no walker gave up its wait (it would have walked the earlier chunks alone: same sums, no parallelism)."""
+    n_base, n_t = 300_000, 2_600_000
+    base = synth.uniform_cloud(n_base, 6.7, 51)
+    rng = np.random.default_rng(53)
+    target = synth.transform_points(synth.icp_pose(), base[rng.integers(0, n_base, n_t)] +
+                                    rng.uniform(-0.01, 0.01, (n_t, 3)).astype(np.float32)).astype(np.float32)
+    t, o = kdtree.New(base), O.KDTree(base)
+    ev = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=0.5), MinPairs=6).Evaluate(t, target)
+    oe = O.icp_evaluate(o, target, 0.5, 6, sums_mode=0)
+    assert ev.NumPairs == oe["npairs"] > 2_500_000
+    assert ev.Value == oe["value"] and ev.DistRMS == oe["dist_rms"] and np.array_equal(ev.Gradient, oe["gradient"])
+    cfg = dict(MaxDist=0.5, MinPairs=6, Weight=np.full(6, 0.3, np.float32), Threshold=np.full(6, -1.0, np.float32), MaxIteration=20)
+    a, b = icp.IcpSession(t, target, **cfg), icp.IcpSession(t, target, **cfg)
+    a.set_strict(1)
+    b.set_strict(2)
+    for k in range(5):
+        a.step()
+        b.step()
+        assert np.array_equal(a.read_sums().view(np.uint64), b.read_sums().view(np.uint64)), k
+        st = a.strict_stats()
+        assert st[62] == 0 and st[63] == 0, (k, st[60:64])
+    a.close()
+    b.close()

@@ -35,11 +35,12 @@ for k in range(c["max_iteration"]):
     print("      no window: %d tiles, %d runs tried, %d applied, %d leaves serial, %.1f us each (candidate hits %d of %d) | crossing: %d tiles, %d leaves serial, %.1f us each" % (
         st[16], st[17], st[18], st[22], st[19] / 100.0 / max(st[16], 1), st[25], st[24], st[20], st[23], st[21] / 100.0 / max(st[20], 1)))
     print("      walker, us/row: in failed runs %.1f (waiting for a helper %.1f, %d times; for the backward scan %.1f); fetching the runs' records %.1f, all runs %.1f" % (st[36] / 900.0, st[37] / 900.0, st[38], st[39] / 900.0, st[40] / 900.0, st[41] / 900.0))
+    print("      later chunks' walkers waited %.1f us in all (the rows' last chunks %.1f us per row); walked alone %d" % (st[60] / 100.0, st[61] / 100.0 / 9, st[62]))
     print("      tiles handed to a helper: table not up %d, state outside the table %d, no such candidate %d" % (st[42], st[43], st[44]))
     if st[46] / 100.0 > 20.0:
         print("      walk per row, us:", " ".join("%.1f" % (st[27 + r] / 100.0) for r in range(9)))
-    if any(st[48:63]):
-        print("      states that missed their tile's table, by log2 of the distance to the guess (0: equal .. 14: >= 2^13, 15: other sign):", " ".join("%d:%d" % (b, st[48 + b]) for b in range(16) if st[48 + b]))
+    if any(st[48:60]):
+        print("      states that missed their tile's table, by log2 of the distance to the guess (0: equal .. 10: >= 2^9, 11: other sign):", " ".join("%d:%d" % (b, st[48 + b]) for b in range(12) if st[48 + b]))
     if st[5]:
         print("      last tile without a slot that was recomputed: %d, guess %08x, state %08x" % (st[45], int(st[47]) >> 32, int(st[47]) & 0xffffffff))
     for q in range(0):
