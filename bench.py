@@ -314,7 +314,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--f64-tree", action="store_true", help="N = 1: time the float64-tree reduction instead of the reference's sums")
-    ap.add_argument("--no-reference-sharded", action="store_true", help="N > 1: skip the second timing with the reference's sums")
+    ap.add_argument("--no-reference-sharded", action="store_true", help="N > 1: skip the second timing (the float64-tree step beside the headline)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -371,7 +371,9 @@ def main():
 
     side_stream = torch.cuda.Stream()  # a real (non-zero) stream handle
     stream = side_stream.cuda_stream
-    strict = world == 1 and not args.f64_tree
+    # the library's default sums at every N: the reference's sequential float32 additions, over the ranks' tiles one
+    # after the other when the target is spread over ranks (bit-identical to the Go code's Fit of the whole target)
+    strict = not args.f64_tree
     sess = icp.IcpSession(tree, tile, cfg["max_dist"], cfg["min_pairs"], cfg["weight"], cfg["threshold"],
                           cfg["max_iteration"], SumsMode=icp.SumsReference if strict else icp.SumsF64Tree)
     comm = None
@@ -450,6 +452,7 @@ def main():
     # have been timed and report per step (the JSON's `steps` stays the driver's K)
     rounds = 0
     elapsed = 0.0
+    round_ms = []   # per step, of every timed round of K steps: the line's spread
     barrier()
     while True:
         t0 = time.perf_counter()
@@ -464,6 +467,7 @@ def main():
             dt = float(t.item())
         elapsed += dt
         rounds += 1
+        round_ms.append(dt / args.steps * 1e3)
         barrier()
         if elapsed >= 0.05 or rounds >= 200:
             break
@@ -483,10 +487,12 @@ def main():
         step()
     barrier()
     kernel_ms = {}
+    kernel_max_ms = {}
     for name, kind in kinds.items():
         ms, cnt = L.prof_read(kind)
         if cnt > 0:
             kernel_ms[name] = ms / cnt
+            kernel_max_ms[name] = L.prof_read_max(kind)
     L.prof_enable(0)
     n_tile = len(tile)
     n_total = n_tile
@@ -502,40 +508,37 @@ def main():
         s64 = sess
     time_session_steps(torch, L, s64, 20, 20, stream)
     t64 = time_session_steps(torch, L, s64, 60, 20, stream) / 60
-    if s64 is not sess:
-        s64.close()
     if world > 1:
         t = torch.tensor([t64], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t64 = float(t.item())
     f64_one_gpu = n_tile / t64 / 1e6
-    # N > 1: the same sharded step with the REFERENCE's sums (the library's default: its sequential float32 additions
-    # over the ranks' tiles one after the other -- the concatenated target's Fit bit for bit, tests/test_gpu_sharded_abi.py,
-    # tests/test_gpu_multi.py; 2 + N small collectives per step instead of one)
-    ref_sharded = None
-    if world > 1 and comm is not None and not args.no_reference_sharded:
+    # N > 1, beside the headline: the same sharded step with float64 sums (PCGX_SUMS_F64_TREE: ONE all-reduce of ten
+    # doubles per step; differs from the reference by the reference's own rounding noise) -- N = 1's `value_f64_tree`
+    f64_sharded = None
+    if world > 1 and comm is not None and strict and not args.no_reference_sharded:
         try:
-            sref = icp.IcpSession(tree, tile, cfg["max_dist"], cfg["min_pairs"], cfg["weight"], cfg["threshold"],
-                                  cfg["max_iteration"], SumsMode=icp.SumsReference)
-
-            def ref_steps(k):
+            def f64_steps(k):
                 for i in range(k):
                     if i % cfg["max_iteration"] == 0:
-                        L.check(L.lib().pcgx_icp_session_reset(sref._h, L.ptr(stream)))
-                    L.check(L.lib().pcgx_icp_session_step_sharded(sref._h, comm._h, L.ptr(stream)))
-            ref_steps(cfg["max_iteration"])
+                        L.check(L.lib().pcgx_icp_session_reset(s64._h, L.ptr(stream)))
+                    L.check(L.lib().pcgx_icp_session_step_sharded(s64._h, comm._h, L.ptr(stream)))
+            f64_steps(cfg["max_iteration"])
             barrier()
             t0 = time.perf_counter()
-            ref_steps(2 * cfg["max_iteration"])
+            f64_steps(2 * cfg["max_iteration"])
             L.check(L.lib().pcgx_sync(L.ptr(stream)))
             torch.cuda.synchronize()
             tr = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
             dist.all_reduce(tr, op=dist.ReduceOp.MAX)
-            ref_sharded = float(tr.item()) / (2 * cfg["max_iteration"])
-            sref.close()
+            f64_sharded = float(tr.item()) / (2 * cfg["max_iteration"])
             barrier()
         except Exception as e:  # noqa: BLE001  (never at the price of the headline line)
-            ref_sharded = "failed: %s" % str(e)[:160]
+            f64_sharded = "failed: %s" % str(e)[:160]
+    if s64 is not sess:
+        s64.close()
+    shard_stats = np.zeros(4, np.int64)
+    L.check(L.lib().pcgx_debug_shard_stats(L.ptr(shard_stats), 0))
 
     # What the grid pass reads per iteration (an untimed Fit, one instrumented launch before each step)
     grid_pts = grid_words = grid_walked = 0
@@ -557,7 +560,7 @@ def main():
         v_icp = visits["c4_icp"]["mean_visits_per_point"]
         its = cfg["max_iteration"]
         summary, traffic_src, same_build = load_pmc_summary()
-        usable = same_build and args.workload == "c4" and n == 1_000_000
+        usable = same_build and args.workload == "c4" and n == 1_000_000 and world == 1
         # ---- the step, kernel by kernel: time (this run), HBM traffic (PMC summary of the same command)
         kernels = {}
         step_traffic = 0.0
@@ -611,14 +614,17 @@ def main():
         mode = ("reference: the evaluator's sequential float32 sums, bit-identical to the Go code (the library's default; "
                 "tests/test_gpu_icp.py)"
                 if strict else "f64-tree: float64 reduction of the reference's float32 terms (differs from the Go code by "
-                               "its own rounding noise, 1.6e-5 on the final transform at 1M pairs; a sum spread over "
-                               "ranks has no sequential order to reproduce)")
+                               "its own rounding noise, 1.6e-5 on the final transform at 1M pairs)")
         line = {
             "metric": "Mpoints/sec ICP iter (corr+reduce) + kNN queries/sec, 1M-pt cloud",
             "value": n_total / per_step / 1e6,
             "unit": "Mpoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": per_step * 1e3,
+            # the spread of the timed rounds (each K steps, clocked by itself), and the slowest single launch of the
+            # chain kernel in two profiled Fits (the iterations in which a sum hovers around zero)
+            "ms_per_step_min": min(round_ms), "ms_per_step_median": float(np.median(round_ms)), "ms_per_step_max": max(round_ms),
+            "worst_iteration_us": {k.split(" ")[0]: v * 1e3 for k, v in kernel_max_ms.items() if k.startswith("strict_")},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "parity_mode": mode,
@@ -627,26 +633,32 @@ def main():
                        "base_points": n, "target_points_total": n_total,
                        "parallelism": "spatial target tiles x%d (%s), tree replicated" % (
                            world, "synth.c5_tile: octants" if args.workload == "c5" else "synth.spatial_cell"),
-                       "exchange": "none" if world == 1 else "all-reduce 10 x f64 per step (%s)"
-                                   % ("callback over gloo: REHEARSAL on one GPU, not a measurement" if rehearse
-                                      else (exchange_fallback or "RCCL inside libpcgx.so"))},
+                       "exchange": "none" if world == 1 else (
+                           ("%s; communicator: %s" % (
+                               ("reference sums over the ranks: ring of tagged words in shared host memory, no collective per step "
+                                "(csrc/strict.hip strict_enqueue_ring)" if shard_stats[0] > 0 and shard_stats[1] == 0 else
+                                "reference sums over the ranks: 2 + N all-reduces per step (no shared-memory ring between these ranks)")
+                               if strict else "all-reduce 10 x f64 per step",
+                               "callback over gloo: REHEARSAL on one GPU, not a measurement" if rehearse
+                               else (exchange_fallback or "RCCL inside libpcgx.so"))))},
             "roofline": roof,
             "tree_build_s": build_s,
             "final_value": float(stat.Evaluated.Value),
             "source_hash": build.source_hash(),
         }
         if world > 1:
-            # one of these GPUs alone, same numeric mode, no exchange: N x this is perfect weak scaling
-            line["value_same_mode_n1"] = f64_one_gpu
-            if isinstance(ref_sharded, float):
-                line["value_reference_sums"] = n_total / ref_sharded / 1e6
-                line["ms_per_step_reference_sums"] = ref_sharded * 1e3
-                line["reference_sums_note"] = ("the same sharded step with the library's default sums: bit-identical to the "
-                                               "reference's Fit of the ranks' tiles one after the other; %d collectives per "
-                                               "step (the walk goes round the ranks)" % (2 + world))
-            elif ref_sharded is not None:
-                line["value_reference_sums"] = None
-                line["reference_sums_note"] = ref_sharded
+            line["shard_stats"] = {"ring_steps": int(shard_stats[0]), "collective_steps": int(shard_stats[1]),
+                                   "rings_made": int(shard_stats[2]), "ring_setups_fallen_back": int(shard_stats[3])}
+            # one of these GPUs alone in the float64 mode, no exchange
+            line["value_f64_tree_one_gpu_alone"] = f64_one_gpu
+            if isinstance(f64_sharded, float):
+                line["value_f64_tree"] = n_total / f64_sharded / 1e6
+                line["ms_per_step_f64_tree"] = f64_sharded * 1e3
+            elif f64_sharded is not None:
+                line["value_f64_tree"] = None
+                line["f64_tree_note"] = f64_sharded
+            if strict:   # (the name earlier rounds' lines carried the reference-sums step under)
+                line["ms_per_step_reference_sums"] = per_step * 1e3
         else:
             line["value_f64_tree"] = f64_one_gpu
         if world == 1 and not args.no_extras and args.workload == "c4":

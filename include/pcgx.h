@@ -103,6 +103,11 @@ PCGX_API pcgx_status pcgx_debug_call_stats(int64_t out[2], int32_t reset);
  * out = {calls the bucket path answered, bucket attempts given up (a bucket or a cell too crowded),
  *        flags of the last attempt given up (1 bucket, 2 cell, 4 exchange), low key bits of the last plan}. */
 PCGX_API pcgx_status pcgx_debug_voxel_stats(int64_t out[4], int32_t reset);
+/* Measurement / test aid: how the sharded steps with the reference's sums were exchanged since the last reset
+ * (see "The sharded ICP path" below).  out = {steps enqueued in the ring form, steps in the collective form,
+ * rings made (shared memory of the node's processes, or the one process's pinned block), ring set-ups that
+ * ended with the collective form (no shared memory between the ranks, PCGX_SHARD_RING=0)}. */
+PCGX_API pcgx_status pcgx_debug_shard_stats(int64_t out[4], int32_t reset);
 
 /* Optional in-library kernel timing (HIP events on the launch stream around
  * the named kernel class).  Used by bench.py for the live roofline figure. */
@@ -127,6 +132,8 @@ PCGX_API pcgx_status pcgx_prof_enable(int32_t on);
 /* Resolves pending events; returns accumulated milliseconds and launch count
  * of `kind` since the last pcgx_prof_reset(). */
 PCGX_API pcgx_status pcgx_prof_read(int32_t kind, double *total_ms, int64_t *launches);
+/* ... and the longest single launch of `kind` since the last reset (the iteration a latency-bound kernel took longest in) */
+PCGX_API pcgx_status pcgx_prof_read_max(int32_t kind, double *max_ms);
 PCGX_API pcgx_status pcgx_prof_reset(void);
 
 /* Profiling aid (not part of the drop-in surface): counters of the instrumented exact-mode walk
@@ -437,9 +444,14 @@ PCGX_API pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream);
  *  PCGX_SUMS_REFERENCE (default)  the reference's sequential float32 additions (evaluator.go:122-145) over the ranks'
  *      tiles ONE AFTER THE OTHER, rank 0's first: the sharded Fit returns what the reference's Fit returns on that
  *      concatenated target, bit for bit.  Correspondence, summaries and jobs run on all ranks at once; the ranks before
- *      a rank hand it two float64 totals per sum (all-gathers of 9 doubles) and the states their walk ended in (the
- *      walk is one dependent chain: it goes round the ranks) -- 2 + world collectives of <= 16 x world doubles per
- *      iteration.
+ *      a rank hand it two float64 totals per sum and the states their walk ended in (the walk is one dependent
+ *      chain: it goes round the ranks).  Where the ranks can share host memory -- the processes of one node (a POSIX
+ *      shared-memory segment every rank maps and registers with HIP, agreed on through the communicator's own
+ *      all-reduce on first use), or the device slots of one process -- that is the RING form: no collective per
+ *      iteration; every rank owns an inbox of tagged 64-bit words in host-coherent memory that the other GPUs' kernels
+ *      write and its own kernels poll, every rank's kernels are resident at once and only the walkers wait, each for
+ *      one word from the rank before it (csrc/strict.hip, strict_enqueue_ring).  Elsewhere (ranks on several nodes,
+ *      PCGX_SHARD_RING=0): 2 + world collectives of <= 16 x world doubles per iteration.  Same bits either way.
  *  PCGX_SUMS_F64_TREE  partials -> ONE all-reduce of the 10 (plane: 30) float64 sums -> update: faster, and off the
  *      reference by the reference's own rounding noise (1.6e-5 on the transform at 1M pairs).
  * Every collective also carries the ranks' error flag: a rank whose step fails keeps calling the collectives with its
@@ -447,8 +459,13 @@ PCGX_API pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream);
  * all-reduce.  Callers that drive the exchange themselves (pcgx_icp_session_partials -> their own all-reduce ->
  * pcgx_icp_session_update) MUST create the session with PCGX_SUMS_F64_TREE: sums of float32 chains cannot be added
  * across ranks.
- * One process, several GPUs: pcgx_icp_fit_multi (a host thread per device slot, pcgx_init_devices; the exchange runs
- * in host memory, sums in rank order) -- the Go shim's FitMulti needs no second process. */
+ * In the ring form a failing rank raises an abort word in every inbox instead; a wait for a state that never comes is
+ * bounded (10 s) and raises it too.
+ * One process, several GPUs: pcgx_icp_fit_multi (a host thread per device slot, pcgx_init_devices; the ring in pinned
+ * host memory, or the exchange in host memory, sums in rank order) -- the Go shim's FitMulti needs no second
+ * process.  (Slots that share ONE HIP device share its hardware queues, and kernels that wait for one another must
+ * not queue up behind each other: there the ring form is taken only with PCGX_SHARD_RING=force, under a
+ * GPU_MAX_HW_QUEUES that gives every slot its queue -- the tests' configuration.) */
 typedef struct pcgx_comm pcgx_comm;
 typedef struct { char internal[128]; } pcgx_comm_id;   /* == ncclUniqueId */
 typedef int32_t (*pcgx_allreduce_fn)(double *host_buf, int32_t count, void *user);

@@ -49,6 +49,13 @@ def prof_read(kind):
     return ms.value, n.value
 
 
+def prof_read_max(kind):
+    """milliseconds of the longest single launch of kernel class `kind` since prof_reset()."""
+    ms = C.c_double()
+    check(lib().pcgx_prof_read_max(kind, C.byref(ms)))
+    return ms.value
+
+
 class PcgxError(RuntimeError):
     def __init__(self, code, msg):
         self.code = code
@@ -135,6 +142,7 @@ SIGNATURES = {
     "pcgx_prof_enable": (_i32, [_i32]),
     "pcgx_prof_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "pcgx_prof_reset": (_i32, []),
+    "pcgx_prof_read_max": (_i32, [_i32, C.POINTER(C.c_double)]),
     "pcgx_debug_walk_stats": (_i32, [_vp, _vp, _i64, _f32, _i32, _vp, _vp, _vp]),
     "pcgx_dev_alloc": (_i32, [_sz, C.POINTER(_vp)]),
     "pcgx_dev_free": (_i32, [_vp]),
@@ -180,6 +188,7 @@ SIGNATURES = {
     "pcgx_icp_session_set_strict": (_i32, [_vp, _i32]),
     "pcgx_debug_call_stats": (_i32, [_vp, _i32]),
     "pcgx_debug_voxel_stats": (_i32, [_vp, _i32]),
+    "pcgx_debug_shard_stats": (_i32, [_vp, _i32]),
     "pcgx_comm_unique_id": (_i32, [_vp]),
     "pcgx_comm_init": (_i32, [_i32, _i32, _vp, C.POINTER(_vp)]),
     "pcgx_comm_init_callback": (_i32, [_i32, _i32, _vp, _vp, C.POINTER(_vp)]),

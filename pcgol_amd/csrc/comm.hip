@@ -10,9 +10,15 @@
 // pcgx_comm_init_callback is the same exchange through a host function (tests on one GPU, hosts with
 // their own transport): the sums make a round trip through host memory.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "pcgx_internal.h"
+#include "strict_terms.h"
 
 namespace {
 
@@ -75,6 +81,8 @@ bool comm_force_collective() {
 
 constexpr int kNcclFloat64 = 8, kNcclSum = 0;  // rccl.h: ncclDataType_t, ncclRedOp_t
 
+std::atomic<long long> g_shard_stats[4];  // pcgx_debug_shard_stats
+
 }  // namespace
 
 struct pcgx_comm {
@@ -82,7 +90,149 @@ struct pcgx_comm {
   void *nccl = nullptr;
   pcgx_allreduce_fn fn = nullptr;
   void *user = nullptr;
+  // The ring of the reference-sums steps (strict.hip, strict_enqueue_ring): every rank's inbox in ONE block of
+  // host-coherent memory that all GPUs of the node write and poll -- pinned host memory of the one process
+  // (pcgx_icp_fit_multi hands it in), or a POSIX shared-memory segment that every process of the node maps and
+  // registers with HIP (made here, collectively, on first use: the communicator's own all-reduce carries the segment's
+  // name and whether every rank could map it).  Ranks that cannot share memory (several nodes) keep the collectives.
+  bool ring_tried = false;
+  unsigned long long *ring_host = nullptr, *ring_dev = nullptr;
+  int32_t ring_words = 0;
+  uint32_t ring_epoch = 0;
+  void *ring_map = nullptr;  // a mapping this communicator owns (shared memory); nullptr: somebody else's block
+  size_t ring_bytes = 0;
 };
+
+namespace {
+
+void ring_unmap(pcgx_comm *c) {
+  if (c->ring_map) {
+    (void)hipHostUnregister(c->ring_map);
+    (void)munmap(c->ring_map, c->ring_bytes);
+  }
+  c->ring_map = nullptr;
+  c->ring_host = c->ring_dev = nullptr;
+}
+
+// collective: every rank of `c` calls it at the same point (the first sharded step / Fit with the reference's sums)
+void ring_setup(pcgx_comm *c) {
+  c->ring_tried = true;
+  if (c->world < 2 || c->world > 64 || c->ring_dev) return;
+  const pcgx::RingLayout RL{c->world};
+  const size_t bytes = ((size_t)c->world * RL.words() * sizeof(unsigned long long) + 4095) & ~(size_t)4095;
+  const char *off = getenv("PCGX_SHARD_RING");
+  const bool disabled = off && atoi(off) == 0;
+  static std::atomic<unsigned> counter{0};
+  double v[3] = {0.0, 0.0, disabled ? 1.0 : 0.0};  // segment name: rank 0's pid and a number of its own; ranks that cannot
+  char name[64];
+  int fd = -1;
+  if (c->rank == 0 && !disabled) {
+    const unsigned nonce = (counter++ * 2654435761u + (unsigned)time(nullptr)) & 0x3fffffffu;
+    snprintf(name, sizeof name, "/pcgx_ring_%d_%u", (int)getpid(), nonce);
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0) v[2] += 1.0;  // (a fresh segment reads as zeros: epoch 0, nobody's)
+    v[0] = (double)getpid();
+    v[1] = (double)nonce;
+  }
+  bool ok = pcgx_comm_allreduce_host_f64(c, v, 3) == PCGX_OK && v[2] == 0.0;
+  if (ok && c->rank != 0) {
+    snprintf(name, sizeof name, "/pcgx_ring_%d_%u", (int)v[0], (unsigned)v[1]);
+    fd = shm_open(name, O_RDWR, 0600);  // (a rank on another node finds no such segment)
+    struct stat sb;
+    if (fd < 0 || fstat(fd, &sb) != 0 || (size_t)sb.st_size != bytes) ok = false;
+  }
+  void *map = MAP_FAILED;
+  void *dev = nullptr;
+  bool mine = ok;
+  if (mine) {
+    map = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    mine = map != MAP_FAILED;
+  }
+  if (fd >= 0) close(fd);
+  if (mine && pcgx::ensure_init() != PCGX_OK) mine = false;
+  bool registered = false;
+  if (mine) {
+    registered = hipHostRegister(map, bytes, hipHostRegisterMapped | hipHostRegisterPortable) == hipSuccess;
+    mine = registered && hipHostGetDevicePointer(&dev, map, 0) == hipSuccess && dev != nullptr;
+    if (!mine) (void)hipGetLastError();
+  }
+  double bad = mine ? 0.0 : 1.0;
+  const bool agreed = pcgx_comm_allreduce_host_f64(c, &bad, 1) == PCGX_OK && bad == 0.0;
+  if (c->rank == 0 && !disabled && v[0] != 0.0) (void)shm_unlink(name);  // (every rank that could has it mapped by now)
+  if (!agreed) {
+    if (registered) (void)hipHostUnregister(map);
+    if (map != MAP_FAILED) (void)munmap(map, bytes);
+    g_shard_stats[3]++;
+    return;
+  }
+  g_shard_stats[2]++;
+  c->ring_map = map;
+  c->ring_bytes = bytes;
+  c->ring_host = (unsigned long long *)map;
+  c->ring_dev = (unsigned long long *)dev;
+  c->ring_words = RL.words();
+}
+
+}  // namespace
+
+extern "C" pcgx_status pcgx_debug_shard_stats(int64_t out[4], int32_t reset) {
+  if (!out) return pcgx::fail(PCGX_E_INVALID, "pcgx_debug_shard_stats: NULL argument");
+  for (int k = 0; k < 4; k++) {
+    out[k] = (int64_t)g_shard_stats[k].load();
+    if (reset) g_shard_stats[k].store(0);
+  }
+  return PCGX_OK;
+}
+
+namespace pcgx {
+
+void shard_count(int what) { g_shard_stats[what & 3]++; }
+
+void comm_attach_local_ring(pcgx_comm *c, unsigned long long *block, int32_t words_per_rank) {
+  c->ring_tried = true;
+  c->ring_host = c->ring_dev = block;
+  c->ring_words = words_per_rank;
+  if (c->rank == 0) shard_count(2);
+}
+
+void comm_ring_clear_abort(pcgx_comm *c) {
+  if (!c->ring_tried) ring_setup(c);
+  if (!c->ring_host) return;
+  const RingLayout RL{c->world};
+  __atomic_store_n(c->ring_host + (size_t)c->rank * c->ring_words + RL.abort(), 0ull, __ATOMIC_SEQ_CST);
+}
+
+bool comm_ring_step(pcgx_comm *c, RingView *out) {
+  if (!c->ring_tried) ring_setup(c);
+  if (!c->ring_dev) {
+    shard_count(1);
+    return false;
+  }
+  shard_count(0);
+  if (++c->ring_epoch == 0u) c->ring_epoch = 1u;
+  out->words = c->ring_dev;
+  out->host = c->ring_host;
+  out->words_per_rank = c->ring_words;
+  out->rank = c->rank;
+  out->world = c->world;
+  out->epoch = c->ring_epoch;
+  return true;
+}
+
+// the abort word of every inbox: {reason, epoch}, the EARLIEST epoch wins (the host runs ahead of the device: a rank
+// that fails while enqueuing step 12 must not wipe out what told the others about step 7)
+void ring_abort_from_host(const RingView &ring, uint32_t reason) {
+  const RingLayout RL{ring.world};
+  const unsigned long long mine = (unsigned long long)ring.epoch << 32 | reason;
+  for (int k = 0; k < ring.world; k++) {
+    unsigned long long *w = ring.host + (size_t)k * ring.words_per_rank + RL.abort();
+    unsigned long long old = __atomic_load_n(w, __ATOMIC_SEQ_CST);
+    while ((old >> 32) == 0ull || (old >> 32) > (unsigned long long)ring.epoch)
+      if (__atomic_compare_exchange_n(w, &old, mine, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) break;
+  }
+}
+
+}  // namespace pcgx
 
 using namespace pcgx;
 
@@ -130,6 +280,7 @@ extern "C" pcgx_status pcgx_comm_init_callback(int32_t rank, int32_t world, pcgx
 extern "C" pcgx_status pcgx_comm_free(pcgx_comm *c) {
   if (!c) return PCGX_OK;
   if (c->nccl) (void)rccl().comm_destroy(c->nccl);
+  ring_unmap(c);
   delete c;
   return PCGX_OK;
 }

@@ -127,6 +127,20 @@ thread_local int tl_depth = 0;
 
 int current_slot() { return tl_slot; }
 
+// Do two of the first n device slots run on the same HIP device (a one-GPU test box standing in for a node)?  Kernels of
+// such slots share the device's few hardware queues, so a kernel of one slot may sit in a queue BEHIND a kernel of
+// another that waits for it: the ring form of the sharded sums, whose kernels wait for one another, then needs a
+// hardware queue per slot (GPU_MAX_HW_QUEUES) -- pcgx_icp_fit_multi takes it only when told to (PCGX_SHARD_RING=force).
+bool slots_share_a_device(int n) {
+  for (int a = 0; a < n && a < kMaxSlots; a++)
+    for (int b = a + 1; b < n && b < kMaxSlots; b++) {
+      const int da = g_slot_device[a] >= 0 ? g_slot_device[a] : (g_slots[a].slots[0].ready ? g_slots[a].slots[0].device : a);
+      const int db = g_slot_device[b] >= 0 ? g_slot_device[b] : (g_slots[b].slots[0].ready ? g_slots[b].slots[0].device : b);
+      if (da == db) return true;
+    }
+  return false;
+}
+
 Context &ctx() { return tl_ctx ? *tl_ctx : glob().slots[0]; }
 
 CallScope::CallScope(bool pooled) {
@@ -221,6 +235,7 @@ int64_t g_prof_seen[PCGX_PROF_KINDS];  // scopes opened per kind
 std::vector<ProfRec> g_prof_pending;
 std::vector<hipEvent_t> g_prof_pool;
 double g_prof_ms[PCGX_PROF_KINDS];
+double g_prof_max_ms[PCGX_PROF_KINDS];
 int64_t g_prof_n[PCGX_PROF_KINDS];
 std::mutex g_prof_mu;
 
@@ -240,6 +255,7 @@ void prof_resolve() {
     if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
       g_prof_ms[r.kind] += ms;
       g_prof_n[r.kind] += 1;
+      if ((double)ms > g_prof_max_ms[r.kind]) g_prof_max_ms[r.kind] = (double)ms;
     }
     g_prof_pool.push_back(r.a);
     g_prof_pool.push_back(r.b);
@@ -489,7 +505,16 @@ extern "C" pcgx_status pcgx_prof_reset(void) {
   PCGX_API_LOCK();
   std::lock_guard<std::mutex> lk(g_prof_mu);
   prof_resolve();
-  for (int k = 0; k < PCGX_PROF_KINDS; k++) { g_prof_ms[k] = 0.0; g_prof_n[k] = 0; }
+  for (int k = 0; k < PCGX_PROF_KINDS; k++) { g_prof_ms[k] = 0.0; g_prof_max_ms[k] = 0.0; g_prof_n[k] = 0; }
+  return PCGX_OK;
+}
+
+extern "C" pcgx_status pcgx_prof_read_max(int32_t kind, double *max_ms) {
+  PCGX_API_LOCK();
+  if (kind < 0 || kind >= PCGX_PROF_KINDS || !max_ms) return fail(PCGX_E_INVALID, "pcgx_prof_read_max: bad argument");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  prof_resolve();
+  *max_ms = g_prof_max_ms[kind];
   return PCGX_OK;
 }
 

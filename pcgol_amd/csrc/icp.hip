@@ -660,6 +660,11 @@ __global__ void icp_reset_kernel(IcpState *__restrict__ state) {
 static pcgx_status reset_state(pcgx_icp_session *s, hipStream_t st) {
   hipLaunchKernelGGL(icp_reset_kernel, dim3(1), dim3(64), 0, st, s->d_state);
   PCGX_HIP_TRY(hipGetLastError());
+  if (s->shard_failed || s->steps_sharded > 0) {  // (a sharded Fit may have ended inside a launch: its counters)
+    PCGX_TRY(strict_reset(s->strict_buf, st));
+    s->shard_failed = false;
+    s->steps_sharded = 0;
+  }
   return PCGX_OK;
 }
 
@@ -1122,6 +1127,10 @@ static pcgx_status step_sharded_impl(pcgx_icp_session *s, pcgx_comm *c, void *st
   }
   const bool reference = s->strict == 1 && !s->plane;
   if (reference) {
+    // the ring form (strict.hip, strict_enqueue_ring) wherever the ranks can share memory: no collective per step.
+    // (Asked for first, by every rank whatever its own state: making the ring is collective.)
+    RingView ring;
+    const bool have_ring = comm_ring_step(c, &ring);
     if (!s->shard_failed) {
       const pcgx_status rc = enqueue_corr(s, st);
       if (rc != PCGX_OK) {
@@ -1133,6 +1142,13 @@ static pcgx_status step_sharded_impl(pcgx_icp_session *s, pcgx_comm *c, void *st
       const pcgx_status rc = strict_create(s->nt, s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, (const uint32_t *)s->d_pos_of,
                                            &s->strict_buf, st);
       if (rc != PCGX_OK) return rc;  // (no buffers at all: this rank cannot even raise its flag)
+    }
+    if (have_ring) {
+      if (s->caller_order_fresh)
+        return strict_enqueue_ring(s->strict_buf, (const float4 *)s->d_match_caller, (const uint32_t *)nullptr, s->d_state,
+                                   s->d_sums, s->kp, ring, s->shard_failed, st);
+      return strict_enqueue_ring(s->strict_buf, (const float4 *)s->d_match, (const uint32_t *)s->d_pos_of, s->d_state,
+                                 s->d_sums, s->kp, ring, s->shard_failed, st);
     }
     if (s->caller_order_fresh)
       return strict_enqueue_sharded(s->strict_buf, (const float4 *)s->d_match_caller, (const uint32_t *)nullptr, s->d_state,
@@ -1195,6 +1211,7 @@ extern "C" pcgx_status pcgx_icp_fit_sharded(const pcgx_kdtree *base, const float
   pcgx_icp_session *s = nullptr;
   pcgx_status rc = pcgx_icp_session_create(base, tile, nt, 0, params, nullptr, &s);
   std::string first_error = rc != PCGX_OK ? std::string(last_error_text()) : std::string();
+  if (world > 1) comm_ring_clear_abort(c);  // (makes the communicator's ring on first use -- collective; the exchange below is the barrier behind it)
   if (world > 1) {
     // A rank whose session could not be made (out of memory, a bad argument) must not leave the others
     // waiting in the first all-reduce: every rank reaches ONE exchange of an error flag first -- out of a host word
@@ -1303,6 +1320,25 @@ extern "C" pcgx_status pcgx_icp_fit_multi(int32_t n, const pcgx_kdtree *const *b
   LocalExchange x;
   x.world = n;
   x.parts.resize((size_t)n);
+  // the ring of the reference-sums steps: every slot's inbox in pinned host memory that all the process's GPUs write
+  // and poll (strict.hip, strict_enqueue_ring); without it (no such memory to be had, PCGX_SHARD_RING=0) the slots
+  // exchange through the host all-reduce above
+  unsigned long long *ring_block = nullptr;
+  const RingLayout RL{n};
+  {
+    // (slots that share one HIP device -- a one-GPU test box -- share its hardware queues: kernels that wait for one
+    // another may then queue up behind each other; the ring only when told that there is a queue per slot)
+    const char *off = getenv("PCGX_SHARD_RING");
+    const bool forced = off && strcmp(off, "force") == 0;
+    if (n > 1 && n <= 64 && (forced || (!(off && atoi(off) == 0) && !slots_share_a_device(n))) && ensure_init() == PCGX_OK) {
+      const size_t bytes = (size_t)n * RL.words() * sizeof(unsigned long long);
+      if (hipHostMalloc((void **)&ring_block, bytes, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) memset(ring_block, 0, bytes);
+      else {
+        (void)hipGetLastError();
+        ring_block = nullptr;
+      }
+    }
+  }
   std::vector<LocalRank> ranks((size_t)n);
   std::vector<pcgx_status> rc((size_t)n, PCGX_OK);
   std::vector<std::string> msg((size_t)n);
@@ -1315,9 +1351,19 @@ extern "C" pcgx_status pcgx_icp_fit_multi(int32_t n, const pcgx_kdtree *const *b
       pcgx_status e = pcgx_set_device(r);
       pcgx_comm *c = nullptr;
       if (e == PCGX_OK) e = pcgx_comm_init_callback(r, n, local_allreduce, &ranks[(size_t)r], &c);
+      if (e == PCGX_OK && ring_block) comm_attach_local_ring(c, ring_block, RL.words());
       if (e == PCGX_OK) e = pcgx_icp_fit_sharded(bases[r], tiles[r], nt[r], params, c, tr[(size_t)r].data(), &stv[(size_t)r]);
       if (e != PCGX_OK) {
         msg[(size_t)r] = last_error_text();
+        if (ring_block) {  // (... nor in a kernel's wait for a word of this slot's: the ring is broken from its first step on)
+          RingView v;
+          v.words = v.host = ring_block;
+          v.words_per_rank = RL.words();
+          v.rank = r;
+          v.world = n;
+          v.epoch = 1u;
+          ring_abort_from_host(v, 1u);
+        }
         std::lock_guard<std::mutex> lk(x.mu);  // (a rank that could not even start must not leave the others waiting)
         if (!c) {
           x.broken = true;
@@ -1329,6 +1375,7 @@ extern "C" pcgx_status pcgx_icp_fit_multi(int32_t n, const pcgx_kdtree *const *b
     });
   }
   for (auto &t : th) t.join();
+  if (ring_block) (void)hipHostFree(ring_block);
   // the rank that failed by itself speaks first; PCGX_E_RCCL ("another rank ...") only if nobody has a better story
   int pick = -1;
   for (int r = 0; r < n && pick < 0; r++)

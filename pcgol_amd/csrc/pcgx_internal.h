@@ -138,6 +138,7 @@ struct Context {
   uint32_t mailbox_seq = 0;
 };
 Context &ctx();  // the calling thread's current context (the library's outside any call)
+bool slots_share_a_device(int n);  // (a one-GPU box standing in for a node: see core.hip)
 int current_slot();  // the calling thread's device slot (pcgx_set_device; 0 unless a process drives several GPUs)
 pcgx_status ensure_init();
 // Scope of one ABI call: binds the thread to a context (pooled: any free one of the pool, waiting for
@@ -384,6 +385,23 @@ pcgx_status strict_check_enqueue(const float *d_xyz, int64_t nt, int64_t nt_pad,
 pcgx_status strict_enqueue_sharded(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
                                    double *sums10, const IcpKernelParams &kp, pcgx_comm *c, int rank, int world,
                                    bool local_failed, hipStream_t st);
+// ... the RING form of the same (strict.hip, strict_enqueue_ring; comm.hip makes the ring): every rank's inbox in
+// host-coherent memory that all GPUs of the node write and poll, no collective per step
+struct RingView {
+  unsigned long long *words = nullptr;  // device-visible address of the inboxes (rank k's at words + k * words_per_rank)
+  unsigned long long *host = nullptr;   // the same memory as this process's host sees it
+  int32_t words_per_rank = 0, rank = 0, world = 1;
+  uint32_t epoch = 0;                   // this step's number on the communicator (every rank counts alike)
+};
+pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state, double *sums10,
+                                const IcpKernelParams &kp, const RingView &ring, bool local_failed, hipStream_t st);
+void ring_abort_from_host(const RingView &ring, uint32_t reason);
+pcgx_status strict_reset(StrictBuffers *b, hipStream_t st);
+// comm.hip: the communicator's ring (made on first use, collectively; nullptr: this communicator exchanges through
+// collectives only -- ranks on several nodes, no shared memory, PCGX_SHARD_RING=0), and a step's view of it
+bool comm_ring_step(pcgx_comm *c, RingView *out);
+void comm_ring_clear_abort(pcgx_comm *c);
+void comm_attach_local_ring(pcgx_comm *c, unsigned long long *block, int32_t words_per_rank);
 }  // namespace pcgx
 
 struct pcgx_kdtree {

@@ -422,13 +422,23 @@ enum { JOB_CROSSING = 1, JOB_NOWINDOW = 2 };
 // (The bound is wall-clock time, 2 ms: two such launches running side by side -- two Fits in two of the library's call
 // contexts -- could in principle hold each other's next-in-line workgroups out of the XCDs they need, each side's
 // residents waiting; giving up frees the places.)
+// kSharded (a target spread over ranks, the ring form: strict_enqueue_ring; with kExchange): the guesses of rank r > 0
+// start from the float64 totals of the ranks before it.  A rank's totals are known to its LAST tile as soon as its
+// exchange is through (the prefix over all earlier tiles + its own sums): that tile's waves put them into the inboxes
+// of the ranks behind this one.  Tile 0's first wave fetches the totals of the ranks before this one from the rank's
+// inbox (host-coherent memory: one workgroup polls over PCIe, not five hundred), adds them up in rank order and puts
+// the result up in device memory like a tile's sums (W.ring_base, write-through, then W.ring_flag); every workgroup
+// waits for that flag behind its wait for the earlier tiles.  All of it bounded like the exchange itself, and only
+// guesses depend on it.  No rank waits for anything that depends on ANOTHER rank's wait: the totals leave a rank
+// without row_base in them, so the ranks' launches do not chain up.
 constexpr long long kExchangeTicks = 200000;  // s_memrealtime runs at 100 MHz
-template <bool kExchange>
+template <bool kExchange, bool kSharded = false>
 __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void strict_sum_kernel(
     const float4 *__restrict__ match, const uint32_t *__restrict__ pos_of, const IcpState *__restrict__ state, StrictWork W) {
   __shared__ float4 s_terms[kStrictRows][kTile / 4];
   __shared__ int s_np[kSumWaves];
   __shared__ double s_tot[16];
+  static_assert(!kSharded || kExchange, "the ring form rides on the exchange");
   const int done = state->done;  // (looked at behind phase 1, whose loads it would only hold up: nothing is written before)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t tile = blockIdx.x;
@@ -532,6 +542,37 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
         }
       }
       if (gave_up && lane == 0) atomicAdd(&W.dbg[63], 1ull);
+      if (kSharded && W.rank > 0) {  // uniform
+        if (tile == 0) {
+          // the totals of the ranks before this one: lane (k, row) fetches rank k's, lanes 0 .. 8 add them up in rank order
+          const RingLayout RL{W.world};
+          double acc = 0.0;
+          for (int k0 = 0; k0 < W.rank; k0 += 7) {  // uniform (seven ranks a round)
+            const int k = k0 + lane / kStrictRows, row = lane % kStrictRows;
+            double v = 0.0;
+            if (lane < 7 * kStrictRows && k < W.rank && row < NR) (void)ring_wait_f64(W, RL.row_tot(k, row), v, kRingGuessTicks);
+#pragma unroll
+            for (int j = 0; j < 7; j++) {
+              const double vj = __shfl(v, j * kStrictRows + (lane < kStrictRows ? lane : 0));
+              acc += vj;  // (rank order; a rank beyond `rank`, or a word that never came: 0.0)
+            }
+          }
+          if (lane < NR) __hip_atomic_store(&W.ring_base[lane], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_store(W.ring_flag, W.ring_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          long long t_first = 0;
+          for (int spins = 0;; spins++) {  // uniform
+            if (__hip_atomic_load(W.ring_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == W.ring_epoch) break;
+            if ((spins & 63) == 63) {
+              const long long now = (long long)wall_clock64();
+              if (t_first == 0) t_first = now;
+              if (now - t_first > 2 * kRingGuessTicks) break;  // (guesses without the ranks before this one: slow, still exact)
+            }
+            __builtin_amdgcn_s_sleep(4);
+          }
+        }
+      }
     }
     __syncthreads();
   }
@@ -540,7 +581,16 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
   for (int row = wave; row < NR; row += kSumWaves) {
     if (kExchange) P0 = tile_prefix_pub(W.tile_pub, W.ntiles_pad, row, tile, lane);
     else if (row >= kSumWaves) P0 = tile_prefix(W.tile_sum, W.ntiles, row, tile, lane);
-    const double P0r = P0 + (W.row_base ? W.row_base[row] : 0.0);  // (the ranks before this one, strict_enqueue_sharded)
+    double P0r = P0 + ((!kSharded && W.row_base) ? W.row_base[row] : 0.0);  // (the ranks before this one, strict_enqueue_sharded)
+    if (kSharded) {
+      // (... in the ring form: what tile 0 has put up, read past the caches like the tiles' sums)
+      if (W.rank > 0) P0r = P0 + __hip_atomic_load(&W.ring_base[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // this rank's own total, to the ranks behind it: the last tile has it here
+      if (tile == W.ntiles - 1 && lane < W.world - 1 - W.rank) {
+        const RingLayout RL{W.world};
+        ring_put_f64(W.ring + (size_t)(W.rank + 1 + lane) * W.ring_words + RL.row_tot(W.rank, row), P0 + s_tot[row], W.ring_epoch);
+      }
+    }
     const LdsQuads q{s_terms[row], lane};
     TileRec T;
     T.s = summary_identity();
@@ -1335,8 +1385,19 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   auto term_src = [&]() { return make_term_src(match, pos_of, state, W); };
   // walker state, evaluator.go:122: the sums start at zero -- or where the ranks before this one ended (a target
   // spread over ranks, strict_enqueue_sharded)
-  // (a later chunk's walker: the state the chunk before it ended in, below)
+  // (a later chunk's walker: the state the chunk before it ended in, below; the ring form: what the rank before this
+  // one sends, row_start() below)
   uint32_t s = W.start_bits ? (uint32_t)rfl((int)W.start_bits[row]) : f2u(0.0f);
+  int ring_rc = 0;  // walker: 1 = the ring was aborted, 2 = a wait ran out of time (the Fit ends here, on every rank)
+  // the state the row starts in on this rank: 0.0f (evaluator.go:122), or where the rank before this one ended it
+  auto row_start = [&]() -> uint32_t {
+    if (!W.ring || W.rank == 0) return W.start_bits ? (uint32_t)rfl((int)W.start_bits[row]) : f2u(0.0f);
+    const RingLayout RL{W.world};
+    uint32_t v = 0u;
+    ring_rc = ring_wait(W, RL.start(row), v, kRingWalkTicks);
+    if (ring_rc == 2 && lane == 0) ring_raise_abort(W, 2u);  // (nobody else needs to wait that long)
+    return (uint32_t)rfl((int)v);
+  };
   // walker: counters of the whole row, written once behind the last chunk (an atomic in flight holds up the
   // next release store of its wave, and the walk is a chain of those).  Vector registers (opaque to the compiler):
   // as scalars they were written to and read from spill lanes around every run.
@@ -1670,8 +1731,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           __builtin_amdgcn_s_sleep(2);
         }
         if (!have) {
-          uint32_t x = s;  // (the row's first state)
-          for (int64_t t = 0; t < chunk; t++) {  // uniform
+          uint32_t x = row_start();
+          for (int64_t t = 0; t < chunk && ring_rc == 0; t++) {  // uniform
             const TileRec V = W.recs[row * W.ntiles + t];
             TileRec T;
             T.key = rfl(V.key); T.in = (uint32_t)rfl((int)V.in); T.out = (uint32_t)rfl((int)V.out); T.cons = rfl(V.cons);
@@ -1690,6 +1751,9 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           if (lane == 0) atomicAdd(&W.dbg[62], 1ull);
         }
         if ((W.selfcheck & 8) && lane == 0) s_wk[6] = (unsigned long long)(stat_clock(W) - t_b);  // (waited for the chunk before)
+      } else if (W.ring && W.rank > 0) {  // uniform
+        s = row_start();
+        if ((W.selfcheck & 8) && lane == 0) s_wk[6] = (unsigned long long)(stat_clock(W) - t_b);  // (waited for the rank before)
       }
       // The runs of the chunk, sixteen at a time: the four lanes 4 j .. 4 j + 3 fetch run j's ends and its composed
       // record, lane 4 j + r the piece of class r.  The walk then takes a run out of the registers: its window, and --
@@ -1704,7 +1768,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       for (int w = 0; w < kChainSegs; w++) seg_base[w + 1] = seg_base[w] + s_count[w];
       const int n_runs = rfl(seg_base[kChainSegs]), n_runs_lo = rfl(seg_base[kChainSegs / 2]);
       __builtin_amdgcn_s_setprio(3);
-      for (int r0 = 0, r1 = 0; r0 < n_runs; r0 = r1) {
+      for (int r0 = 0, r1 = 0; r0 < n_runs && ring_rc == 0; r0 = r1) {
         // (a batch stays inside one half of the segments: the first half's compositions are there first)
         const int half = r0 < n_runs_lo ? 0 : 1;
         const int bound = half == 0 ? n_runs_lo : n_runs;
@@ -1961,9 +2025,17 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           if (lane == 0) s_wk[5] += tt - (unsigned long long)t_j0;
         }
       }
-      if (!last_chunk && lane == 0)  // the next chunk's walker starts here
+      if (!last_chunk && lane == 0 && ring_rc == 0)  // the next chunk's walker starts here
         __hip_atomic_store(W.chunk_state + ((size_t)row * W.nchunks + my_chunk + 1) * 16, (unsigned long long)W.epoch << 32 | s,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (a broken ring: a later chunk's walker finds it broken too, in its own wait for the row's first state)
+      if (last_chunk && W.ring && ring_rc == 0 && lane == 0) {
+        // the ring form: this rank's end state to the rank behind it -- or, from the last rank, the sum itself to all
+        const RingLayout RL{W.world};
+        if (W.rank < W.world - 1) ring_put(W.ring + (size_t)(W.rank + 1) * W.ring_words + RL.start(row), s, W.ring_epoch);
+        else
+          for (int k = 0; k < W.world - 1; k++) ring_put(W.ring + (size_t)k * W.ring_words + RL.final(row), s, W.ring_epoch);
+      }
       if (lane == 0) {
         lds_put(&s_progress, 1 << 30);  // helpers that still wait for a tile: the chunk is done
         ticks_scan += (unsigned long long)(t_b - t_a);
@@ -2011,7 +2083,56 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
                               ((unsigned long long)n_recfail << 32) | ((unsigned long long)(n_tab_nw + n_tab_cross) << 48);
     W.stamps[row * 16 + 15] = (unsigned long long)trace_clock(W);
   }
-  if (row == 0 && walker && lane == 0) {
+  if (W.ring && walker) {  // uniform
+    // The ring form: the pairs go round with sum 0 (every rank adds its own count to what it was sent); then every
+    // rank's walkers wait for the LAST rank's end states -- the sums of the whole target -- and go on as on one GPU:
+    // sums10, ticket, evaluate tail + pose update on every rank alike.
+    const RingLayout RL{W.world};
+    unsigned long long pairs = 0ull;
+    if (row == 0) {
+      while (lds_get(&s_np_ok) == 0) __builtin_amdgcn_s_sleep(1);
+      pairs = s_np;
+      if (W.rank > 0 && ring_rc == 0) {
+        uint32_t lo = 0u, hi = 0u;
+        ring_rc = ring_wait(W, RL.start_pairs(), lo, kRingWalkTicks);
+        if (ring_rc == 0) ring_rc = ring_wait(W, RL.start_pairs() + 1, hi, kRingWalkTicks);
+        pairs += (unsigned long long)hi << 32 | lo;
+      }
+      if (ring_rc == 0 && lane == 0) {
+        if (W.rank < W.world - 1) {
+          unsigned long long *dst = W.ring + (size_t)(W.rank + 1) * W.ring_words + RL.start_pairs();
+          ring_put(dst, (uint32_t)pairs, W.ring_epoch);
+          ring_put(dst + 1, (uint32_t)(pairs >> 32), W.ring_epoch);
+        } else {
+          for (int k = 0; k < W.world - 1; k++) {
+            unsigned long long *dst = W.ring + (size_t)k * W.ring_words + RL.final_pairs();
+            ring_put(dst, (uint32_t)pairs, W.ring_epoch);
+            ring_put(dst + 1, (uint32_t)(pairs >> 32), W.ring_epoch);
+          }
+        }
+      }
+    }
+    if (W.rank < W.world - 1 && ring_rc == 0) {
+      uint32_t v = 0u;
+      ring_rc = ring_wait(W, RL.final(row), v, kRingWalkTicks);
+      s = (uint32_t)rfl((int)v);
+      if (row == 0 && ring_rc == 0) {
+        uint32_t lo = 0u, hi = 0u;
+        ring_rc = ring_wait(W, RL.final_pairs(), lo, kRingWalkTicks);
+        if (ring_rc == 0) ring_rc = ring_wait(W, RL.final_pairs() + 1, hi, kRingWalkTicks);
+        pairs = (unsigned long long)hi << 32 | lo;
+      }
+    }
+    if (ring_rc != 0) {  // uniform: the ring is broken -- this rank's Fit ends here, like everybody's
+      if (lane == 0) {
+        if (ring_rc == 2) ring_raise_abort(W, 2u);
+        state->status = PCGX_E_RCCL;
+        state->done = 1;
+      }
+      return;
+    }
+    if (row == 0 && lane == 0) __hip_atomic_store(&sums10[S_PAIRS], (double)pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (row == 0 && walker && lane == 0) {
     while (lds_get(&s_np_ok) == 0) __builtin_amdgcn_s_sleep(1);
     if (!W.hop_out) __hip_atomic_store(&sums10[S_PAIRS], (double)s_np, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -2070,6 +2191,8 @@ struct StrictBuffers {
   // err_base[16] ([9] = pairs of all ranks), hop[16], start_bits[16] (uint32)
   double *shard = nullptr;
   int shard_world = 0;
+  void *counters = nullptr;  // slot / ticket counters (strict_reset)
+  size_t counters_bytes = 0, arrived_bytes = 0;
 };
 
 pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const float *tz, const uint32_t *pos_of,
@@ -2082,6 +2205,13 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   W.start_bits = nullptr;
   W.hop_out = nullptr;
   W.first_exact = 1;
+  W.ring = nullptr;
+  W.ring_words = 0;
+  W.rank = 0;
+  W.world = 1;
+  W.ring_epoch = 0u;
+  W.ring_base = nullptr;
+  W.ring_flag = nullptr;
   W.ntiles = nt > 0 ? (nt + kTile - 1) / kTile : 1;
   W.nrows = kStrictRows;
   W.selfcheck = (getenv("PCGX_STRICT_SELFCHECK") ? 1 : 0) | (getenv("PCGX_STRICT_TRACE") ? 2 : 0) |
@@ -2134,6 +2264,9 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   W.cand = (uint32_t *)p; p += sz_cand;
   W.xyz_caller = (const float *)p; p += sz_xyz;
   uint8_t *counters = p;
+  b->counters = counters;
+  b->counters_bytes = sz_ctr;
+  b->arrived_bytes = sz_arr;
   W.done_rows = (unsigned int *)(p + 12);
   W.aux_count = (unsigned int *)(p + 256); p += sz_ctr;
   W.dbg = (unsigned long long *)p; p += 512;
@@ -2356,6 +2489,113 @@ pcgx_status strict_enqueue_sharded(StrictBuffers *b, const float4 *match, const 
   hipLaunchKernelGGL(strict_finish_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)start_bits, (const double *)err_base,
                      (const double *)(hop + 10), W.nrows, state, sums10, kp);
   PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
+// ---- the same sums, the RING form: no collective, every rank's kernels resident at once -------------------------------
+// What a rank needs from the ranks before it has not changed -- the float64 totals of their terms (before its
+// summaries' guesses), of their chains' rounding errors (before its job tiles' guesses), and the state their walk
+// ended in (before its walk) -- but nothing is a collective any more: every rank owns an inbox in host-coherent memory
+// (pinned host memory of the one process, or a shared-memory segment of the node's processes: comm.hip) that the other
+// GPUs' kernels write with plain 64-bit stores and its own kernels poll; a word carries its step's number
+// (StrictWork::ring, RingLayout).  Per step and rank: the summary kernel (its last tile sends the rank's totals on,
+// its first tile fetches the earlier ranks'), one small kernel for the rounding errors' totals, the job kernel, the
+// chain kernel -- every rank's compositions, run lists and candidate tables are made at once, only the walkers
+// wait, each for ONE word from the rank before it; the last rank's walkers send the sums to everybody and every rank
+// runs the evaluate tail + pose update in its own chain kernel, as on one GPU.  A rank that cannot go on raises the
+// abort word in every inbox from the host (ring_abort_from_host); a wait for a state is bounded by kRingWalkTicks and
+// raises it too.
+__global__ __launch_bounds__(64) void strict_ring_err_kernel(const IcpState *__restrict__ state, StrictWork W) {
+  const int lane = threadIdx.x, b = blockIdx.x;
+  if (state->done) return;
+  const RingLayout RL{W.world};
+  if (b < kStrictRows) {  // this rank's total of sum b's rounding errors, to the ranks behind it
+    if (b >= W.nrows || W.rank >= W.world - 1) return;
+    double v = 0.0;
+    for (int64_t t = lane; t < W.ntiles; t += 64) v += W.tile_err[(int64_t)b * W.ntiles + t];
+    v = wave_allsum_f64(v);
+    if (lane < W.world - 1 - W.rank)
+      ring_put_f64(W.ring + (size_t)(W.rank + 1 + lane) * W.ring_words + RL.err_tot(W.rank, b), v, W.ring_epoch);
+    return;
+  }
+  // the totals of the ranks before this one, added up in rank order: where the job tiles' guesses start
+  double acc = 0.0;
+  for (int k0 = 0; k0 < W.rank; k0 += 7) {  // uniform
+    const int k = k0 + lane / kStrictRows, row = lane % kStrictRows;
+    double v = 0.0;
+    if (lane < 7 * kStrictRows && k < W.rank && row < W.nrows) (void)ring_wait_f64(W, RL.err_tot(k, row), v, 10 * kRingGuessTicks);
+#pragma unroll
+    for (int j = 0; j < 7; j++) acc += __shfl(v, j * kStrictRows + (lane < kStrictRows ? lane : 0));
+  }
+  if (lane < kStrictRows) W.ring_base[16 + lane] = lane < W.nrows ? acc : 0.0;
+}
+__global__ void strict_ring_fail_kernel(IcpState *__restrict__ state) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && !state->done) {
+    state->status = PCGX_E_RCCL;
+    state->done = 1;
+  }
+}
+
+pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state, double *sums10,
+                                const IcpKernelParams &kp, const RingView &ring, bool local_failed, hipStream_t st) {
+  if (!b->shard) {  // (the ring form keeps 32 doubles + a flag word of it)
+    if (dev_cache_alloc((void **)&b->shard, (size_t)(ring.world + 4) * 16 * sizeof(double)) != hipSuccess)
+      return fail(PCGX_E_OOM, "strict sums over ranks: no memory for the exchange");
+    b->shard_world = ring.world;
+    PCGX_HIP_TRY(hipMemsetAsync(b->shard, 0, (size_t)(ring.world + 4) * 16 * sizeof(double), st));
+  }
+  if (local_failed) {
+    // this rank launches nothing more: the others learn of it from the abort word, in whatever wait they are in
+    ring_abort_from_host(ring, 1u);
+    hipLaunchKernelGGL(strict_ring_fail_kernel, dim3(1), dim3(64), 0, st, state);
+    PCGX_HIP_TRY(hipGetLastError());
+    return PCGX_OK;
+  }
+  (void)strict_work(b, kp);
+  StrictWork W = next_epoch(b);  // (the session's descriptor stays in its one-GPU form)
+  W.ring = ring.words;
+  W.ring_words = ring.words_per_rank;
+  W.rank = ring.rank;
+  W.world = ring.world;
+  W.ring_epoch = ring.epoch;
+  W.ring_base = b->shard;
+  W.ring_flag = reinterpret_cast<unsigned int *>(b->shard + 32);
+  W.first_exact = ring.rank == 0 ? 1 : 0;
+  W.exchange = 1;  // (the ring form rides on the summary kernel's own exchange)
+  {
+    ProfScope prof(PCGX_PROF_STRICT_SUM, st);
+    hipLaunchKernelGGL((strict_sum_kernel<true, true>), dim3((unsigned)W.ntiles), dim3(kSumBlock), 0, st, match, pos_of,
+                       (const IcpState *)state, W);
+  }
+  if (ring.world > 1)
+    hipLaunchKernelGGL(strict_ring_err_kernel, dim3(kStrictRows + (ring.rank > 0 ? 1 : 0)), dim3(64), 0, st, (const IcpState *)state, W);
+  if (ring.rank > 0) {  // (the job tiles' guesses: + the ranks before this one)
+    W.row_base = W.ring_base;
+    W.err_base = W.ring_base + 16;
+  }
+  {
+    ProfScope prof(PCGX_PROF_STRICT_JOB, st);
+    if (W.naux > 0)
+      hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)kJobRoles * (unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
+  }
+  {
+    ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
+    if (W.selfcheck & 1)
+      hipLaunchKernelGGL(strict_chain_kernel<true>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
+                         sums10, kp, 1);
+    else
+      hipLaunchKernelGGL(strict_chain_kernel<false>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
+                         sums10, kp, 1);
+  }
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
+// a session between two Fits: whatever a launch that ended early (a broken ring) left in the counters
+pcgx_status strict_reset(StrictBuffers *b, hipStream_t st) {
+  if (!b) return PCGX_OK;
+  PCGX_HIP_TRY(hipMemsetAsync(b->counters, 0, b->counters_bytes, st));
+  PCGX_HIP_TRY(hipMemsetAsync(b->w.tile_arrived, 0, b->arrived_bytes, st));
   return PCGX_OK;
 }
 

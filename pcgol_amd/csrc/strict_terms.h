@@ -122,9 +122,93 @@ struct StrictWork {
   unsigned long long *chunk_state;
   int32_t nchunks;
   uint32_t epoch;             // this launch's (counted by the host, from 1)
+  // A target spread over ranks, the RING form (strict_enqueue_ring): every rank owns an inbox of 64-bit words in
+  // host-coherent memory that all GPUs of the node write and poll directly (RingLayout below); a word is a 32-bit
+  // payload under a 32-bit tag -- the communicator's step count, `ring_epoch` -- so it says by itself whether it
+  // is this step's: no flags, no fences, no resets.  ring == nullptr: one GPU, or the collective form above.
+  unsigned long long *ring;   // inbox of rank k at ring + k * ring_words
+  int32_t ring_words;
+  int32_t rank, world;
+  uint32_t ring_epoch;
+  double *ring_base;          // device: [0..8] row_base, [16..24] err_base of this step, as fetched from the inbox
+  unsigned int *ring_flag;    // device: == ring_epoch once tile 0 of strict_sum_kernel has put row_base up
   int32_t selfcheck;  // bit 0: every step of the chain walk is re-derived term by term and compared (dbg[12..15]);
                       // 1: PCGX_STRICT_TRACE stamps; 2: no candidate tables; 3: wall-clock columns of the counters
 };
+
+// ---- the ring (a target spread over ranks, strict_enqueue_ring) -------------------------------------------------
+// Inbox of one rank, 64-bit words {payload | tag << 32}; a float64 travels as two words (low, high half):
+//   row_tot[k][row][2]  float64 total of rank k's terms of sum `row` (written by rank k < me: my guesses start there)
+//   err_tot[k][row][2]  float64 total of the rounding errors rank k's chains make (the same, for the job tiles)
+//   start[row], start_pairs[2]   the state the rank before me ended sum `row` in (my walk starts there), and the pairs so far
+//   final[row], final_pairs[2]   the state the LAST rank ended in: the sums of the whole target, to every rank
+//   abort                        {reason, epoch}: a rank could not go on in that step (or a wait ran out of time)
+struct RingLayout {
+  int world;
+  __host__ __device__ int row_tot(int k, int row) const { return (k * kStrictRows + row) * 2; }
+  __host__ __device__ int err_tot(int k, int row) const { return world * 2 * kStrictRows + (k * kStrictRows + row) * 2; }
+  __host__ __device__ int start(int row) const { return world * 4 * kStrictRows + row; }
+  __host__ __device__ int start_pairs() const { return world * 4 * kStrictRows + kStrictRows; }
+  __host__ __device__ int final(int row) const { return world * 4 * kStrictRows + 16 + row; }
+  __host__ __device__ int final_pairs() const { return world * 4 * kStrictRows + 16 + kStrictRows; }
+  __host__ __device__ int abort() const { return world * 4 * kStrictRows + 32; }
+  __host__ __device__ int words() const { return (world * 4 * kStrictRows + 33 + 15) & ~15; }
+};
+constexpr long long kRingGuessTicks = 200000;     // 2 ms: waits for what only guesses depend on (a late word costs time, not bits)
+constexpr long long kRingWalkTicks = 1000000000;  // 10 s: waits for the state a walk starts from (there is no going on without it)
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ void ring_put(unsigned long long *w, uint32_t payload, uint32_t epoch) {
+  __hip_atomic_store(w, (unsigned long long)epoch << 32 | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void ring_put_f64(unsigned long long *w, double v, uint32_t epoch) {
+  const unsigned long long x = (unsigned long long)__double_as_longlong(v);
+  ring_put(w, (uint32_t)x, epoch);
+  ring_put(w + 1, (uint32_t)(x >> 32), epoch);
+}
+__device__ __forceinline__ bool ring_peek(const unsigned long long *w, uint32_t epoch, uint32_t &payload) {
+  const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  payload = (uint32_t)v;
+  return (uint32_t)(v >> 32) == epoch;
+}
+// this step's abort word of MY inbox: set (a tag of this step or an earlier one: the ring stays broken until its
+// owner clears it, pcgx_icp_fit_sharded)
+__device__ __forceinline__ bool ring_aborted(const StrictWork &W) {
+  const RingLayout RL{W.world};
+  const unsigned long long v = __hip_atomic_load(W.ring + (size_t)W.rank * W.ring_words + RL.abort(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const uint32_t tag = (uint32_t)(v >> 32);
+  return tag != 0u && tag <= W.ring_epoch;
+}
+// Wait for word `off` of MY inbox (every lane of the wave: the same address, one request).  0: here; 1: the ring was
+// aborted; 2: out of time.
+__device__ __forceinline__ int ring_wait(const StrictWork &W, int off, uint32_t &payload, long long max_ticks) {
+  const unsigned long long *p = W.ring + (size_t)W.rank * W.ring_words + off;
+  long long t_first = 0;
+  for (int spins = 0;; spins++) {
+    if (ring_peek(p, W.ring_epoch, payload)) return 0;
+    if ((spins & 7) == 7) {  // (a clock read is a memory round trip, a look at the abort word one over PCIe: now and then)
+      if (ring_aborted(W)) return 1;
+      const long long now = (long long)wall_clock64();
+      if (t_first == 0) t_first = now;
+      if (now - t_first > max_ticks) return 2;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+// ... of a float64 (two words)
+__device__ __forceinline__ int ring_wait_f64(const StrictWork &W, int off, double &v, long long max_ticks) {
+  uint32_t lo = 0u, hi = 0u;
+  int rc = ring_wait(W, off, lo, max_ticks);
+  if (rc == 0) rc = ring_wait(W, off + 1, hi, max_ticks);
+  v = __longlong_as_double((long long)((unsigned long long)hi << 32 | lo));
+  return rc;
+}
+// a wait that ran out of time breaks the ring for everybody (they would wait as long otherwise)
+__device__ __forceinline__ void ring_raise_abort(const StrictWork &W, uint32_t reason) {
+  const RingLayout RL{W.world};
+  for (int k = 0; k < W.world; k++) ring_put(W.ring + (size_t)k * W.ring_words + RL.abort(), reason, W.ring_epoch);
+}
+#endif
 
 // ---- the terms ------------------------------------------------------------------------------------
 // Nothing stores the nine float32 terms of a pair in HBM any more (round 2: 36 MB out of one kernel and

@@ -5,7 +5,12 @@ streams and workspaces, a tree replica per slot, a host thread per slot inside t
 * the default sums (the reference's, over the slots' tiles one after the other) == the Go-semantics oracle's Fit on the
   whole target, bit for bit; the float64 mode == the one-GPU float64 Fit to rounding;
 * a slot whose step fails in the middle of the Fit (fault injection) makes EVERY slot return within the timeout --
-  nobody is left inside an all-reduce (ADVICE round 2 / VERDICT round 3)."""
+  nobody is left inside an all-reduce (ADVICE round 2 / VERDICT round 3).
+
+The ring form of the reference sums (csrc/strict.hip, strict_enqueue_ring) lets every slot's kernels wait for the slot
+before it ON THE DEVICE.  Slots that share one GPU share its hardware queues, so the test session raises HIP's
+GPU_MAX_HW_QUEUES (tests/conftest.py) -- a queue per slot, as separate GPUs have by themselves -- and asks for the ring
+by name (PCGX_SHARD_RING=force; the library's own default for slots on one device is the collective form)."""
 import ctypes as C
 import time
 
@@ -17,7 +22,7 @@ from pcgol_amd import _lib as L
 from pcgol_amd import icp, kdtree, synth
 
 pytestmark = pytest.mark.gpu
-N_SLOTS = 3
+N_SLOTS = 8   # the target machine's GPU count; every test below runs with 3 and with 8 of them
 
 
 @pytest.fixture(scope="module")
@@ -49,14 +54,25 @@ def _trees(base, n):
     return trees
 
 
-def test_fit_multi_reference_sums_equal_the_oracle(slots):
+@pytest.mark.parametrize("ring", ["force", "0"], ids=["ring", "collectives"])
+@pytest.mark.parametrize("ns", [3, 8])
+def test_fit_multi_reference_sums_equal_the_oracle(slots, ns, ring, monkeypatch):
+    """ring: every slot's kernels resident at once, the walk handed from slot to slot through host-coherent words
+    (csrc/strict.hip, strict_enqueue_ring); collectives (PCGX_SHARD_RING=0): the 2 + world all-reduces it replaces."""
+    monkeypatch.setenv("PCGX_SHARD_RING", ring)
+    slots = ns
     n = 200_000
     c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
     trees = _trees(c["base"], slots)
-    cuts = [0, 70_001, 130_000, n]          # ragged, not tile aligned
+    cuts = [0, 70_001, 130_000, n] if ns == 3 else [0, 70_001, 70_002, 70_002, 130_000, 131_000, 150_000, 199_999, n]   # ragged, not tile aligned
     tiles = [np.ascontiguousarray(c["target"][cuts[r]:cuts[r + 1]]) for r in range(slots)]
+    stats = np.zeros(4, np.int64)
+    L.check(L.lib().pcgx_debug_shard_stats(L.ptr(stats), 1))
     rc, trans, st = _fit_multi(c, trees, tiles)
     L.check(rc)
+    L.check(L.lib().pcgx_debug_shard_stats(L.ptr(stats), 1))
+    # every slot enqueued its 20 steps in the form asked for (one ring per Fit, in the process's pinned memory)
+    assert (stats[0], stats[1], stats[2]) == ((20 * ns, 0, 1) if ring == "force" else (0, 20 * ns, 0)), stats
     o32 = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
                     c["max_iteration"], sums_mode=0)
     assert st.num_iteration == o32["num_iteration"] == 20
@@ -74,8 +90,11 @@ def test_fit_multi_reference_sums_equal_the_oracle(slots):
     assert st64.num_iteration == s1.NumIteration == 20 and np.max(np.abs(t64.ravel() - np.asarray(t1).ravel())) <= 1e-6
 
 
-@pytest.mark.parametrize("mode", [0, 1], ids=["reference", "f64"])
-def test_a_failing_slot_ends_the_fit_on_every_slot(slots, mode, monkeypatch):
+@pytest.mark.parametrize("ns", [3, 8])
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["reference", "f64", "reference-collectives"])
+def test_a_failing_slot_ends_the_fit_on_every_slot(slots, mode, ns, monkeypatch):
+    slots = ns
+    monkeypatch.setenv("PCGX_SHARD_RING", "0" if mode == 2 else "force")
     n = 60_000
     c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
     trees = _trees(c["base"], slots)
@@ -83,30 +102,36 @@ def test_a_failing_slot_ends_the_fit_on_every_slot(slots, mode, monkeypatch):
     monkeypatch.setenv("PCGX_TEST_FAIL_RANK", "1")
     monkeypatch.setenv("PCGX_TEST_FAIL_ITER", "7")
     t0 = time.time()
-    rc, trans, st = _fit_multi(c, trees, tiles, sums_mode=icp.SumsF64Tree if mode else 0)
+    rc, trans, st = _fit_multi(c, trees, tiles, sums_mode=icp.SumsF64Tree if mode == 1 else 0)
     assert time.time() - t0 < 30.0
     assert rc != 0
     buf = C.create_string_buffer(512)
     L.lib().pcgx_last_error(buf, 512)
     assert b"injected failure of rank 1 in iteration 7" in buf.value, buf.value
     monkeypatch.delenv("PCGX_TEST_FAIL_RANK")
-    rc, trans, st = _fit_multi(c, trees, tiles, sums_mode=icp.SumsF64Tree if mode else 0)   # and the library still works
+    rc, trans, st = _fit_multi(c, trees, tiles, sums_mode=icp.SumsF64Tree if mode == 1 else 0)   # and the library still works
     L.check(rc)
     assert st.num_iteration == 20
 
 
-def test_fit_multi_edge_shards(slots):
+@pytest.mark.parametrize("ns", [3, 8])
+def test_fit_multi_edge_shards(slots, ns, monkeypatch):
     """The reference's sums over slots whose shards are awkward: one slot with NO targets at all, one with a single
     target, targets that find no partner scattered through the order, a built-in weight (nine chained sums: the sum of
     the weights goes round the slots like the others) -- Evaluated and pose of the oracle's Fit on the concatenated
     target, bit for bit."""
+    monkeypatch.setenv("PCGX_SHARD_RING", "force")
     n = 90_000
     c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
     target = c["target"].copy()
     far = target[::41] + np.float32(50.0)
     target = np.ascontiguousarray(np.insert(target, np.arange(0, len(far)) * 33, far, axis=0))
-    trees = _trees(c["base"], slots)
-    tiles = [np.ascontiguousarray(target[:0]), np.ascontiguousarray(target[:1]), np.ascontiguousarray(target[1:])]
+    trees = _trees(c["base"], ns)
+    if ns == 3:
+        tiles = [np.ascontiguousarray(target[:0]), np.ascontiguousarray(target[:1]), np.ascontiguousarray(target[1:])]
+    else:   # empty slots at either end and in the middle, a single target, a slot that holds less than one tile
+        cuts = [0, 0, 1, 1, 1501, 40_000, 40_000, len(target), len(target)]
+        tiles = [np.ascontiguousarray(target[cuts[r]:cuts[r + 1]]) for r in range(ns)]
     wf = icp.WeightHuber(0.0009)
     O.set_weight_fn(wf.kind, wf.a)
     try:

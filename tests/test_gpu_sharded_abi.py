@@ -55,18 +55,27 @@ def _ref_worker(rank, world, port, q, n):
         L.check(L.lib().pcgx_icp_fit_sharded(tree._h, L.ptr(tile), len(tile), C.byref(params), comm._h, L.ptr(trans),
                                              C.byref(st)))
         comm.close()
-        q.put((rank, trans, int(st.num_iteration), float(st.evaluated.value), np.array(st.evaluated.gradient, np.float32)))
+        stats = np.zeros(4, np.int64)
+        L.check(L.lib().pcgx_debug_shard_stats(L.ptr(stats), 0))
+        q.put((rank, trans, int(st.num_iteration), float(st.evaluated.value), np.array(st.evaluated.gradient, np.float32),
+               stats.tolist()))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n", [(2, 200_000), (3, 200_000), (2, 1_000_000)], ids=["2x200k", "3x200k", "2xC4"])
-def test_reference_sums_on_a_sharded_target_equal_the_oracle_bit_for_bit(world, n):
+@pytest.mark.parametrize("ring", ["1", "0"], ids=["ring", "collectives"])
+@pytest.mark.parametrize("world,n", [(2, 200_000), (3, 200_000), (4, 200_000), (2, 1_000_000)], ids=["2x200k", "3x200k", "4x200k", "2xC4"])
+def test_reference_sums_on_a_sharded_target_equal_the_oracle_bit_for_bit(world, n, ring, monkeypatch):
     """pcgx_icp_fit_sharded with the default sums over 2 and 3 processes (one GPU, callback communicator): the
     transform, Value and Gradient of the Go-semantics oracle's Fit on the whole target -- the ranks hold contiguous
     pieces of it -- bit for bit, at 200k pairs and at C4's full 1M (evaluator.go:122-145 summed over ranks)."""
     import torch.multiprocessing as mp
     import oracle as O
+    # ring: the processes share a POSIX shared-memory segment (made through the communicator itself on first use), the
+    # walk goes from GPU kernel to GPU kernel through it; collectives: the 2 + world all-reduces per step it replaces
+    monkeypatch.setenv("PCGX_SHARD_RING", ring)   # (inherited by the spawned ranks)
+    if ring == "0" and (world, n) != (3, 200_000):
+        pytest.skip("the collective form: one shape is enough")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -84,6 +93,81 @@ def test_reference_sums_on_a_sharded_target_equal_the_oracle_bit_for_bit(world, 
         assert r[2] == o32["num_iteration"] == 20
         assert np.array_equal(r[1].ravel(), np.asarray(o32["trans"]).ravel())
         assert np.float32(r[3]) == o32["value"] and np.array_equal(r[4], o32["gradient"])
+        # every rank's 20 steps went the way asked for (a ring set-up that fell back would show in [3])
+        assert r[5] == ([20, 0, 1, 0] if ring == "1" else [0, 20, 0, 1]), r[5]
+
+
+def test_eight_slots_with_callback_communicators_share_a_ring():
+    """Eight ranks as the C ABI offers them to a host that brings its own transport: eight device slots of this
+    process (all on the one GPU of the box), a host thread each, a callback communicator each (the callback sums over
+    the threads in rank order).  The communicators agree on a shared-memory ring through that callback on their first
+    step; the Fit's twenty steps then need it for nothing.  Result: the oracle's Fit of the concatenated target."""
+    import ctypes as C
+    import threading
+    import oracle as O
+    from pcgol_amd import _lib as L
+    from pcgol_amd import icp, kdtree
+    from pcgol_amd.distributed import Comm
+    ns = 8
+    L.check(L.lib().pcgx_init_devices(ns, L.ptr(np.zeros(ns, np.int32))))
+    try:
+        c = _case(160_000)
+        nt = len(c["target"])
+        cuts = [nt * r // ns for r in range(ns + 1)]
+        barrier = threading.Barrier(ns)
+        parts = [None] * ns
+        calls = [0] * ns
+
+        def make_fn(r):
+            def fn(a):
+                calls[r] += 1
+                parts[r] = a.copy()
+                barrier.wait(timeout=120)
+                tot = np.zeros_like(a)
+                for k in range(ns):
+                    tot += parts[k]
+                barrier.wait(timeout=120)
+                a[:] = tot
+            return fn
+        out = [None] * ns
+        errs = []
+
+        def rank_main(r):
+            try:
+                L.check(L.lib().pcgx_set_device(r))
+                tree = kdtree.New(c["base"])
+                tile = np.ascontiguousarray(c["target"][cuts[r]:cuts[r + 1]])
+                comm = Comm.callback(r, ns, make_fn(r))
+                params = icp._params(c["max_dist"], 0.0, c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+                trans = np.empty(16, np.float32)
+                st = L.IcpStat()
+                L.check(L.lib().pcgx_icp_fit_sharded(tree._h, L.ptr(tile), len(tile), C.byref(params), comm._h, L.ptr(trans),
+                                                     C.byref(st)))
+                comm.close()
+                out[r] = (trans, int(st.num_iteration), float(st.evaluated.value), np.array(st.evaluated.gradient, np.float32))
+            except Exception as e:  # noqa: BLE001
+                errs.append((r, repr(e)))
+                barrier.abort()
+        stats = np.zeros(4, np.int64)
+        L.check(L.lib().pcgx_debug_shard_stats(L.ptr(stats), 1))
+        th = [threading.Thread(target=rank_main, args=(r,)) for r in range(ns)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        assert not errs, errs
+        L.check(L.lib().pcgx_debug_shard_stats(L.ptr(stats), 1))
+        assert stats.tolist() == [20 * ns, 0, ns, 0], stats
+        # the callback carried the ring's set-up and the Fit's start-up flags, nothing per step
+        assert max(calls) <= 4, calls
+        o32 = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
+                        c["max_iteration"], sums_mode=0)
+        for r in range(ns):
+            assert out[r][1] == o32["num_iteration"] == 20
+            assert np.array_equal(out[r][0].ravel(), np.asarray(o32["trans"]).ravel())
+            assert np.float32(out[r][2]) == o32["value"] and np.array_equal(out[r][3], o32["gradient"])
+    finally:
+        L.check(L.lib().pcgx_set_device(0))
 
 
 def _worker(rank, world, port, q):
