@@ -1726,7 +1726,10 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
           if ((spins & 31) == 31) {  // (a clock read is a memory round trip: now and then)
             const long long now = (long long)wall_clock64();
             if (t_first == 0) t_first = now;
-            if (now - t_first > kChunkWaitTicks) break;
+            // (kCheck, the debugging build: every run of a chunk is re-derived term by term, a chunk takes 10+ ms and its
+            // successors would give up one after the other -- and a row that ends by walking alone lets the launch
+            // end, pose update and all, under the feet of the chunks it no longer waits for: no bound there)
+            if (!kCheck && now - t_first > kChunkWaitTicks) break;
           }
           __builtin_amdgcn_s_sleep(2);
         }

@@ -380,4 +380,92 @@ class PointToPlaneICP {
   }
 };
 
+// ---- the reference's package surface, name for name ------------------------------------------------------------
+// What go/pc/storage/kdtree, go/pc/filter/voxelgrid and go/pc/registration/icp are to a Go caller (see go/README.md):
+// the exported names of the three reference packages over the classes above, so that code written against
+// kdtree.New(ra, opts...), voxelgrid.New(leaf, voxelgrid.WithChunkSize(s)), icp.PointToPointICPGradient{Evaluator,
+// UpdaterFactory}.Fit(base, target) reads the same here.  tests/test_cpp_host.py runs them.
+namespace kdtree {  // pc/storage/kdtree/kdtree.go:14-65
+using KDTree = ::pcgx::KDTree;
+using KDTreeOption = ::pcgx::KDTreeOption;
+inline KDTree New(const std::vector<Vec3> &ra, std::initializer_list<KDTreeOption> opts = {}) { return KDTree(ra, opts); }
+inline KDTree New(const CloudView &ra, std::initializer_list<KDTreeOption> opts = {}) { return KDTree(ra, opts); }
+inline KDTreeOption WithMinDistSq(float d) { return KDTree::WithMinDistSq(d); }
+}  // namespace kdtree
+
+namespace voxelgrid {  // pc/filter/voxelgrid/voxelgrid.go:23-33, option.go:7-18
+struct Options {
+  Vec3 LeafSize{};
+  std::array<int32_t, 3> ChunkSize{0, 0, 0};
+};
+using Option = std::function<void(Options &)>;
+inline Option WithChunkSize(std::array<int32_t, 3> s) { return [s](Options &o) { o.ChunkSize = s; }; }
+// filter.Filter (pc/filter/filter.go:7-9): Filter(cloud) -> the output records
+inline ::pcgx::VoxelGrid New(Vec3 leafSize, std::initializer_list<Option> opts = {}) {
+  Options o;
+  o.LeafSize = leafSize;
+  for (const auto &f : opts) f(o);
+  ::pcgx::VoxelGrid vg(o.LeafSize);
+  vg.WithChunkSize(o.ChunkSize);
+  return vg;
+}
+}  // namespace voxelgrid
+
+namespace icp {  // pc/registration/icp
+using PointToPointCorrespondence = ::pcgx::PointToPointCorrespondence;  // correspondence.go:8-12
+using NearestPointCorresponder = ::pcgx::NearestPointCorresponder;      // correspondence.go:18-37
+using Stat = ::pcgx::Stat;                                              // stat.go:3-6
+using Evaluated = pcgx_icp_evaluated;                                   // evaluator.go:25-30
+using Weight = ::pcgx::WeightFn;
+// PointToPointEvaluator (evaluator.go:69-73); WeightFn closures cannot cross to the device: Weight names a built-in form
+struct PointToPointEvaluator {
+  NearestPointCorresponder Corresponder;
+  int MinPairs = 0;
+  icp::Weight Weight;
+  int32_t Sums = PCGX_SUMS_REFERENCE;
+  bool HasGradient() const { return true; }
+  bool HasHessian() const { return false; }
+  Evaluated Evaluate(const KDTree &base, const std::vector<Vec3> &target) const {  // evaluator.go:91-189
+    pcgx_icp_params p{};
+    p.max_dist = Corresponder.MaxDist;
+    p.min_dist_sq = base.MinDistSq;
+    p.min_pairs = MinPairs;
+    p.weight_fn = Weight.Kind;
+    p.weight_fn_param = Weight.A;
+    p.sums_mode = Sums;
+    Evaluated ev{};
+    check(pcgx_icp_evaluate_params(base.handle(), target.empty() ? nullptr : target[0].data(), (int64_t)target.size(), &p, &ev));
+    return ev;
+  }
+};
+struct GradientDescentUpdaterFactory {  // updater.go:18-37 (zero values: the reference's defaults)
+  std::array<float, 6> Weight{}, Threshold{};
+  int MaxIteration = 0;
+};
+struct PointToPointICPGradient {  // icp.go:18-67
+  PointToPointEvaluator Evaluator;
+  GradientDescentUpdaterFactory UpdaterFactory;
+  std::pair<Mat4, Stat> Fit(const KDTree &base, const std::vector<Vec3> &target) const { return impl().Fit(base, target); }
+  std::pair<Mat4, Stat> FitSharded(const KDTree &base, const std::vector<Vec3> &tile, const Comm &comm) const {
+    return impl().FitSharded(base, tile, comm);
+  }
+  std::pair<Mat4, Stat> FitMulti(const std::vector<const KDTree *> &bases, const std::vector<std::vector<Vec3>> &tiles) const {
+    return impl().FitMulti(bases, tiles);
+  }
+
+ private:
+  PointToPointICP impl() const {
+    PointToPointICP r;
+    r.MaxDist = Evaluator.Corresponder.MaxDist;
+    r.MinPairs = Evaluator.MinPairs;
+    r.EvaluateWeight = Evaluator.Weight;
+    r.Sums = Evaluator.Sums;
+    r.Weight = UpdaterFactory.Weight;
+    r.Threshold = UpdaterFactory.Threshold;
+    r.MaxIteration = UpdaterFactory.MaxIteration;
+    return r;
+  }
+};
+}  // namespace icp
+
 }  // namespace pcgx

@@ -137,6 +137,22 @@ int main(int argc, char **argv) {
             std::printf(" %" PRId64 ":%" PRId64 ":%.9g", pairs[i].BaseID, pairs[i].TargetID, pairs[i].SquaredDistance);
           std::printf("\n");
         }
+        {  // the reference's package surface, name for name (pcgx::kdtree / voxelgrid / icp): the same results
+          const pcgx::kdtree::KDTree kt = pcgx::kdtree::New(base);
+          pcgx::icp::PointToPointICPGradient pp;
+          pp.Evaluator.Corresponder.MaxDist = maxd;
+          pp.Evaluator.MinPairs = minp;
+          const auto rn = pp.Fit(kt, target);
+          const pcgx::icp::Evaluated ev = pp.Evaluator.Evaluate(kt, target);
+          std::printf("named_icp same %d has_gradient %d value0 %.9g\n",
+                      (int)(rn.first == r.first && rn.second.NumIteration == r.second.NumIteration), (int)pp.Evaluator.HasGradient(),
+                      ev.value);
+          const pcgx::CloudView cv{base.data(), (int64_t)base.size(), 12, 0};
+          const auto a = pcgx::voxelgrid::New(pcgx::Vec3{0.5f, 0.5f, 0.5f}, {pcgx::voxelgrid::WithChunkSize({3, 3, 3})}).Filter(cv);
+          pcgx::VoxelGrid vg2(pcgx::Vec3{0.5f, 0.5f, 0.5f});
+          vg2.WithChunkSize({3, 3, 3});
+          std::printf("named_voxel same %d records %zu\n", (int)(a == vg2.Filter(cv)), a.size() / 12);
+        }
         try {
           reg.MinPairs = (int)base.size() + 1;
           reg.Fit(*tree, target);

@@ -11,7 +11,12 @@ and octant 0 of its target (synth.c5_tile) -- condensed into digests the GPU sui
             of the float32 terms (sums_mode 1: what a sharded rank computes and all-reduces) and the
             reference's sequential float32 sums (sums_mode 0), Value / Gradient / DistRMS of Evaluate
 
-Run from the repo root:  python tests/golden/make_c5_digest.py   (about 10 min, 1 core, 4 GB)
+  tile      the WHOLE ~8M-target tile (3907 tiles of the strict sums, eight chunks of the chain kernel): iteration 0's
+            Evaluate with the reference's sequential float32 sums, and a three-iteration Fit (MaxIteration 3,
+            Threshold -1): pose, Value, Gradient, DistRMS bits -- what test_c5_strict_sums_on_the_tile pins the
+            device's parallel sums to (before round 5 that test compared them with the device's own one-wave chain)
+
+Run from the repo root:  python tests/golden/make_c5_digest.py   (about 20 min, 1 core, 5 GB)
 """
 import json
 import os
@@ -57,6 +62,20 @@ def main():
                    "reference_value_bits": int(np.float32(e32["value"]).view(np.uint32)),
                    "reference_gradient_bits": [int(v) for v in e32["gradient"].view(np.uint32)],
                    "reference_dist_rms_bits": int(np.float32(e32["dist_rms"]).view(np.uint32))}
+    et = O.icp_evaluate(tree, tile, 0.5, 6, sums_mode=0)
+    print("tile evaluate", et["npairs"], time.time() - t0, flush=True)
+    w, th = np.full(6, 0.3, np.float32), np.full(6, -1.0, np.float32)
+    ft = O.icp_fit(tree, tile, 0.5, 6, w, th, 3, sums_mode=0)
+    print("tile fit", ft["num_iteration"], time.time() - t0, flush=True)
+    out["tile"] = {"n_pairs": int(et["npairs"]),
+                   "evaluate_value_bits": int(np.float32(et["value"]).view(np.uint32)),
+                   "evaluate_gradient_bits": [int(v) for v in et["gradient"].view(np.uint32)],
+                   "evaluate_dist_rms_bits": int(np.float32(et["dist_rms"]).view(np.uint32)),
+                   "fit3_num_iteration": int(ft["num_iteration"]),
+                   "fit3_trans_bits": [int(v) for v in np.asarray(ft["trans"], np.float32).ravel().view(np.uint32)],
+                   "fit3_value_bits": int(np.float32(ft["value"]).view(np.uint32)),
+                   "fit3_gradient_bits": [int(v) for v in np.asarray(ft["gradient"], np.float32).view(np.uint32)],
+                   "fit3_dist_rms_bits": int(np.float32(ft["dist_rms"]).view(np.uint32))}
     with open(os.path.join(ROOT, "tests", "golden", "c5_digest.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("done", time.time() - t0)

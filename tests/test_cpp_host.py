@@ -129,6 +129,11 @@ def test_cpp_host_mirror_known_answers(tmp_path, golden):
     assert int(strict[2]) == st_s.NumIteration
     assert np.array_equal(np.array([float(v) for v in strict[6:22]], np.float32), tr_s)
     assert "sharded1_icp same 1" in out and "sharded1_voxel same 1 world 1" in out
+    # the reference's package surface name for name (pcgx::kdtree::New, pcgx::voxelgrid::New + WithChunkSize,
+    # pcgx::icp::PointToPointICPGradient{Evaluator, UpdaterFactory}.Fit): the same transform, the same records
+    nl = [l for l in out if l.startswith("named_icp ")][0].split()
+    assert nl[2] == "1" and nl[4] == "1" and float(nl[6]) > 0.0
+    assert any(l.startswith("named_voxel same 1 records ") and int(l.split()[-1]) >= 1 for l in out)
     # the Go seams through the C++ mirror: With() shares the device tree and carries the option; the corresponder's
     # pairs are the oracle's (correspondence.go:22-37), in target order
     wl = [l for l in out if l.startswith("with ")][0].split()
