@@ -77,12 +77,13 @@ PCGX_API pcgx_status pcgx_get_device(int32_t *slot, int32_t *hip_device);
 PCGX_API int32_t pcgx_last_error(char *buf, size_t cap);
 PCGX_API const char *pcgx_version(void);
 /* The layout version of this header's structs and fixed-size output arrays (pcgx_icp_params gained sums_mode in 3;
- * pcgx_debug_icp_strict_stats writes 64 words since 3; 4: device slots, pcgx_icp_fit_multi, pcgx_debug_voxel_stats).
+ * pcgx_debug_icp_strict_stats writes 64 words since 3; 4: device slots, pcgx_icp_fit_multi, pcgx_debug_voxel_stats;
+ * 5: pcgx_debug_shard_stats, pcgx_prof_read_max, words 48 .. 63 of pcgx_debug_icp_strict_stats re-assigned).
  * A binding built against another version of the header must not call into the library: the mirrors (go/pcgx,
  * host/pcgx.hpp, pcgol_amd/_lib.py) compare PCGX_ABI_VERSION with pcgx_abi_version() when they load it.
  * pcgx_icp_params_init zeroes a parameter block of THIS version (all defaults); sizeof_params is the caller's
  * sizeof(pcgx_icp_params): a mismatch is PCGX_E_INVALID instead of a read past a shorter struct. */
-#define PCGX_ABI_VERSION 4
+#define PCGX_ABI_VERSION 5
 PCGX_API int32_t pcgx_abi_version(void);
 /* Block until all work enqueued on `stream` (NULL = library stream) is done. */
 PCGX_API pcgx_status pcgx_sync(void *stream);
@@ -163,7 +164,11 @@ PCGX_API pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream
 
 /* Measurement aid: counters of the strict sums (set_strict 1) since the last call: out = {runs
  * applied, runs whose record did not cover the state, tiles recomputed exactly, leaves of those added
- * term by term, tile records that did not cover the state, -...}. */
+ * term by term, tile records that did not cover the state, -...}; words [48 .. 57]: states that missed their
+ * tile's candidate table by log2 of the distance ([57]: other sign), [58]: plain tiles the repair pass of a Fit's first
+ * Evaluate turned into jobs, [60] / [61]: ticks later chunks' walkers waited for their start state (all / the rows' last
+ * chunks), [62]: walkers that gave up that wait and walked the earlier chunks alone, [63]: workgroups of the summary
+ * kernel that gave up its exchange (both 0 in a healthy run: the tests require it). */
 PCGX_API pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *stream, int64_t out[64]);
 
 /* The strict-sum pipeline in plain host loops (no GPU): *out = the sequential float32 sum

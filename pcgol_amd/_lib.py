@@ -129,7 +129,7 @@ class IcpStat(C.Structure):
 
 # name -> (restype, argtypes); the complete export list of include/pcgx.h
 _vp, _i64, _i32, _u32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float, C.c_size_t
-ABI_VERSION = 4   # include/pcgx.h PCGX_ABI_VERSION
+ABI_VERSION = 5   # include/pcgx.h PCGX_ABI_VERSION
 
 SIGNATURES = {
     "pcgx_init": (_i32, [_i32]),

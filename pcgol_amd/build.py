@@ -40,9 +40,9 @@ def source_hash():
     import hashlib
     h = hashlib.sha256()
     h.update(" ".join(flags()).encode())  # (the compiler's switches are part of what a library was built from)
-    for s in sorted(SOURCES + [x for x in HEADERS if not x.startswith("..")]):
+    for s in sorted(SOURCES + HEADERS):   # (the public header too: its ABI version and struct layouts are compiled in)
         with open(os.path.join(CSRC, s), "rb") as f:
-            h.update(s.encode() + b"\0" + f.read())
+            h.update(os.path.basename(s).encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 

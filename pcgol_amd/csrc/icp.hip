@@ -614,6 +614,7 @@ struct pcgx_icp_session {
   bool own_sums = false;
   double *d_xchg = nullptr;  // sharded float64 steps: the sums + the ranks' error flag, what the all-reduce carries
   int32_t steps_sharded = 0; // sharded steps enqueued (fault injection of the tests counts them)
+  int32_t host_iter = 0;     // Evaluates enqueued since the session was made / reset (0: the next one sees the raw target)
   bool shard_failed = false; // this rank could not go on: it keeps calling the collectives with its flag up
   bool plane = false;              // point-to-plane / Gauss-Newton session (30 sums)
   uint32_t *d_match_id = nullptr;  // plane: [nt] matched base id
@@ -660,6 +661,7 @@ __global__ void icp_reset_kernel(IcpState *__restrict__ state) {
 static pcgx_status reset_state(pcgx_icp_session *s, hipStream_t st) {
   hipLaunchKernelGGL(icp_reset_kernel, dim3(1), dim3(64), 0, st, s->d_state);
   PCGX_HIP_TRY(hipGetLastError());
+  s->host_iter = 0;
   if (s->shard_failed || s->steps_sharded > 0) {  // (a sharded Fit may have ended inside a launch: its counters)
     PCGX_TRY(strict_reset(s->strict_buf, st));
     s->shard_failed = false;
@@ -683,6 +685,7 @@ extern "C" pcgx_status pcgx_icp_session_set_pose(pcgx_icp_session *s, const floa
   memset(&h, 0, sizeof h);
   memcpy(h.trans, trans16, sizeof h.trans);
   h.iter = iter;
+  s->host_iter = iter;
   PCGX_HIP_TRY(hipMemcpyAsync(s->d_state, &h, sizeof h, hipMemcpyHostToDevice, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
   return PCGX_OK;
@@ -1027,12 +1030,13 @@ static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
     if (!s->strict_buf)
       PCGX_TRY(strict_create(s->nt, s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, (const uint32_t *)s->d_pos_of,
                              &s->strict_buf, st));
+    const bool first_iter = s->host_iter++ == 0;
     if (s->caller_order_fresh)  // pairs already in the caller's order: no gather through pos_of
       PCGX_TRY(strict_enqueue(s->strict_buf, (const float4 *)s->d_match_caller, (const uint32_t *)nullptr, s->d_state,
-                              s->d_sums, s->kp, kFuseUpdate, s->tile_sums_fresh, st));
+                              s->d_sums, s->kp, kFuseUpdate, s->tile_sums_fresh, first_iter, st));
     else
       PCGX_TRY(strict_enqueue(s->strict_buf, (const float4 *)s->d_match, (const uint32_t *)s->d_pos_of, s->d_state,
-                              s->d_sums, s->kp, kFuseUpdate, false, st));
+                              s->d_sums, s->kp, kFuseUpdate, false, first_iter, st));
     return PCGX_OK;
   }
   // strict 2: the plain dependent chain, one wave (kept as the on-device cross-check of strict 1)
@@ -1144,11 +1148,12 @@ static pcgx_status step_sharded_impl(pcgx_icp_session *s, pcgx_comm *c, void *st
       if (rc != PCGX_OK) return rc;  // (no buffers at all: this rank cannot even raise its flag)
     }
     if (have_ring) {
+      const bool first_iter = s->host_iter++ == 0;
       if (s->caller_order_fresh)
         return strict_enqueue_ring(s->strict_buf, (const float4 *)s->d_match_caller, (const uint32_t *)nullptr, s->d_state,
-                                   s->d_sums, s->kp, ring, s->shard_failed, st);
+                                   s->d_sums, s->kp, ring, s->shard_failed, first_iter, st);
       return strict_enqueue_ring(s->strict_buf, (const float4 *)s->d_match, (const uint32_t *)s->d_pos_of, s->d_state,
-                                 s->d_sums, s->kp, ring, s->shard_failed, st);
+                                 s->d_sums, s->kp, ring, s->shard_failed, first_iter, st);
     }
     if (s->caller_order_fresh)
       return strict_enqueue_sharded(s->strict_buf, (const float4 *)s->d_match_caller, (const uint32_t *)nullptr, s->d_state,

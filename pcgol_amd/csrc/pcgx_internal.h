@@ -373,8 +373,10 @@ void strict_destroy(StrictBuffers *b);
 // tile sums on its way out when it is handed one
 const StrictWork *strict_work(StrictBuffers *b, const IcpKernelParams &kp);
 // have_tile_sums: the correspondence kernel formed them (else strict_tilesum_kernel runs first)
+// first_iter: (as far as the host can tell) the first Evaluate of a Fit -- the repair pass runs (strict.hip)
 pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
-                           double *sums10, const IcpKernelParams &kp, bool fuse_update, bool have_tile_sums, hipStream_t st);
+                           double *sums10, const IcpKernelParams &kp, bool fuse_update, bool have_tile_sums, bool first_iter,
+                           hipStream_t st);
 pcgx_status strict_read_debug(StrictBuffers *b, unsigned long long out[64], hipStream_t st);
 // strict_check.hip: the same sums by one wave, term after term (the on-device cross-check; set_strict 2)
 pcgx_status strict_check_enqueue(const float *d_xyz, int64_t nt, int64_t nt_pad, const float4 *match, const uint32_t *pos_of,
@@ -394,7 +396,7 @@ struct RingView {
   uint32_t epoch = 0;                   // this step's number on the communicator (every rank counts alike)
 };
 pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state, double *sums10,
-                                const IcpKernelParams &kp, const RingView &ring, bool local_failed, hipStream_t st);
+                                const IcpKernelParams &kp, const RingView &ring, bool local_failed, bool first_iter, hipStream_t st);
 void ring_abort_from_host(const RingView &ring, uint32_t reason);
 pcgx_status strict_reset(StrictBuffers *b, hipStream_t st);
 // comm.hip: the communicator's ring (made on first use, collectively; nullptr: this communicator exchanges through

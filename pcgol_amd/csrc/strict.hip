@@ -1080,6 +1080,85 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
   }
 }
 
+// ---- repair (the first Evaluate of a Fit) ---------------------------------------------------------------------------
+// A plain tile's record covers the states that stay inside the tile's binade; strict_sum_kernel hands a tile that lies
+// within kMaybeMargin floats of a binade's end to strict_job_kernel as well, which knows how far the float32 chain has
+// drifted from the float64 sums by then.  In the FIRST Evaluate of a Fit (the raw target: every term of a gradient sum
+// has the same sign) the drift outgrows that margin -- 10^4 floats by the end of C4's rows, 10^5 and more at C5's 8M
+// targets -- and the tiles in which a row passes a binade's end within that drift of the guess own no slot: the
+// walker forms their terms again from the pairs and adds all 2048, 25 us each, on the launch's critical path (one or
+// two tiles at C4; 55 of them, 1.3 ms, at C5's share).  This kernel runs between the summaries and the jobs, in that
+// iteration only: one workgroup per sum predicts every plain tile's start state as the job kernel would (float64
+// prefix of the tiles' sums + of their chains' rounding errors) and tests the tile's record on it, kRepairMargin
+// floats either side; a tile that does not cover them becomes a job like any level crossing -- slot, description,
+// terms formed again from the pairs, by a whole wave, off the critical path.
+constexpr int kRepairBlock = 512;
+constexpr uint32_t kRepairMargin = 64u;
+constexpr int kRepairList = 512;
+__global__ __launch_bounds__(kRepairBlock) void strict_repair_kernel(const float4 *__restrict__ match, const uint32_t *__restrict__ pos_of,
+                                                                     const IcpState *__restrict__ state, StrictWork W) {
+  __shared__ double s_wsum[kRepairBlock / 64];
+  __shared__ int s_list[kRepairList];
+  __shared__ int s_n;
+  const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (state->done || state->iter != 0) return;  // uniform
+  if (threadIdx.x == 0) s_n = 0;
+  const int64_t per = (W.ntiles + kRepairBlock - 1) / kRepairBlock;
+  const int64_t t0 = (int64_t)threadIdx.x * per < W.ntiles ? (int64_t)threadIdx.x * per : W.ntiles;
+  const int64_t t1 = t0 + per < W.ntiles ? t0 + per : W.ntiles;
+  const double *ts = W.tile_sum + (int64_t)row * W.ntiles, *te = W.tile_err + (int64_t)row * W.ntiles;
+  double local = 0.0;
+  for (int64_t t = t0; t < t1; t++) local += ts[t] + te[t];
+  const double pre = wave_excl_scan_f64(local, lane);
+  const double wtot = lane_f64(pre, 63) + lane_f64(local, 63);
+  if (lane == 0) s_wsum[wave] = wtot;
+  __syncthreads();
+  double base = pre + (W.row_base ? W.row_base[row] + W.err_base[row] : 0.0);  // (+ the ranks before this one)
+  for (int w = 0; w < wave; w++) base += s_wsum[w];
+  for (int64_t t = t0; t < t1; t++) {
+    const TileRec T = W.recs[(int64_t)row * W.ntiles + t];
+    const bool plain = T.key >= 0 && (T.cons >> 8) == 0 && !(t < kExactTiles && W.first_exact);
+    if (plain) {
+      const uint32_t g = f2u((float)base), mag = g & 0x7fffffffu;
+      bool ok = mag > 2u * kRepairMargin && mag < 0x7f800000u - 2u * kRepairMargin;
+#pragma unroll
+      for (int j = 0; j < 4 && ok; j++) {  // (every parity class at either end of the margin)
+        uint32_t a = g - kRepairMargin + (uint32_t)j, b = g + kRepairMargin - (uint32_t)j;
+        ok = apply(a, T.key, T.s) && apply(b, T.key, T.s);
+      }
+      if (!ok) {
+        const int k = atomicAdd(&s_n, 1);
+        if (k < kRepairList) s_list[k] = (int)t;
+      }
+    }
+    base += ts[t] + te[t];
+  }
+  __syncthreads();
+  const int n = s_n < kRepairList ? s_n : kRepairList;
+  if (n == 0) return;  // uniform
+  const TermSrc S = make_term_src(match, pos_of, state, W);
+  const unsigned per_shard = (unsigned)W.naux / kAuxShards;
+  for (int i = wave; i < n; i += kRepairBlock / 64) {  // uniform per wave
+    const int64_t tile = s_list[i];
+    unsigned slot = 0xffffffffu;
+    if (lane == 0) {
+      const unsigned shard = (unsigned)((tile + 7 * row) % kAuxShards);
+      const unsigned k = atomicAdd(&W.aux_count[shard * 32], 1u);
+      slot = k < per_shard ? shard * per_shard + k : 0xffffffffu;
+    }
+    slot = (unsigned)rfl((int)slot);
+    if (slot == 0xffffffffu) continue;  // (no slot left: the walker's own way, as before)
+    if (lane == 0) {
+      JobDesc *J = W.jobs + slot;
+      J->row = row;
+      J->tile = tile;
+      J->pad = 0;
+      atomicAdd(&W.dbg[58], 1ull);
+    }
+    recompute_tile_to_lds(S, row, tile, lane, W.aux_terms + (size_t)slot * (kTile / 4));  // (the same layout: tile_quad)
+  }
+}
+
 // ---- chain -----------------------------------------------------------------------------------------
 __device__ __forceinline__ bool apply_point(uint32_t &s, const TileRec &R) {
   if ((R.cons & 1) && R.in == s) {
@@ -1693,8 +1772,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
             if (!hit && have_cand) {  // measurement aid: how far off the guess was (log2 of the distance in floats)
               const uint32_t m = s_in & 0x7fffffffu, gm = g0 & 0x7fffffffu;
               const uint32_t dist = m > gm ? m - gm : gm - m;
-              // (dbg[48 .. 59]; [60 .. 63] belong to the chunks' hand-over and the summary kernel's exchange)
-              const int bucket = ((s_in ^ g0) >> 31) ? 11 : (dist == 0u ? 0 : (32 - __clz((int)dist) > 10 ? 10 : 32 - __clz((int)dist)));
+              // (dbg[48 .. 57]; [58 .. 63] belong to the repair pass, the chunks' hand-over and the summary kernel's exchange)
+              const int bucket = ((s_in ^ g0) >> 31) ? 9 : (dist == 0u ? 0 : (32 - __clz((int)dist) > 8 ? 8 : 32 - __clz((int)dist)));
               atomicAdd(&W.dbg[48 + bucket], 1ull);
             }
             resolve_stats(W, cur_kind, serial, tried, applied, stat_clock(W) - t_begin);
@@ -2307,6 +2386,11 @@ const StrictWork *strict_work(StrictBuffers *b, const IcpKernelParams &kp) {
   b->w.nrows = kp.weight_fn == PCGX_WEIGHT_ONE ? kStrictRows - 1 : kStrictRows;
   return &b->w;
 }
+// (PCGX_STRICT_REPAIR=0: no repair pass in a Fit's first Evaluate -- measurement)
+static bool repair_enabled() {
+  static const bool on = !(getenv("PCGX_STRICT_REPAIR") && atoi(getenv("PCGX_STRICT_REPAIR")) == 0);
+  return on;
+}
 // a launch of the chain kernel: its epoch (the chunks' hand-over words, StrictWork::chunk_state)
 static const StrictWork &next_epoch(StrictBuffers *b) {
   if (++b->w.epoch == 0u) b->w.epoch = 1u;  // (a wrap after 2^32 launches: stale words are 2^32 launches old by then)
@@ -2314,7 +2398,8 @@ static const StrictWork &next_epoch(StrictBuffers *b) {
 }
 
 pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
-                           double *sums10, const IcpKernelParams &kp, bool fuse_update, bool have_tile_sums, hipStream_t st) {
+                           double *sums10, const IcpKernelParams &kp, bool fuse_update, bool have_tile_sums, bool first_iter,
+                           hipStream_t st) {
   (void)strict_work(b, kp);
   const StrictWork &W = next_epoch(b);
   if (!have_tile_sums && !W.exchange) {
@@ -2333,6 +2418,9 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_JOB, st);
+    // (the first Evaluate of a Fit: the plain tiles the rows' drift has carried across a binade's end become jobs)
+    if (first_iter && W.naux > 0 && repair_enabled())
+      hipLaunchKernelGGL(strict_repair_kernel, dim3((unsigned)W.nrows), dim3(kRepairBlock), 0, st, match, pos_of, (const IcpState *)state, W);
     if (W.naux > 0)
       hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)kJobRoles * (unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
   }
@@ -2540,7 +2628,7 @@ __global__ void strict_ring_fail_kernel(IcpState *__restrict__ state) {
 }
 
 pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state, double *sums10,
-                                const IcpKernelParams &kp, const RingView &ring, bool local_failed, hipStream_t st) {
+                                const IcpKernelParams &kp, const RingView &ring, bool local_failed, bool first_iter, hipStream_t st) {
   if (!b->shard) {  // (the ring form keeps 32 doubles + a flag word of it)
     if (dev_cache_alloc((void **)&b->shard, (size_t)(ring.world + 4) * 16 * sizeof(double)) != hipSuccess)
       return fail(PCGX_E_OOM, "strict sums over ranks: no memory for the exchange");
@@ -2578,6 +2666,8 @@ pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uin
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_JOB, st);
+    if (first_iter && W.naux > 0 && repair_enabled())
+      hipLaunchKernelGGL(strict_repair_kernel, dim3((unsigned)W.nrows), dim3(kRepairBlock), 0, st, match, pos_of, (const IcpState *)state, W);
     if (W.naux > 0)
       hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)kJobRoles * (unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
   }
@@ -2685,7 +2775,7 @@ extern "C" pcgx_status pcgx_debug_strict_sum_dev(const float *terms, int64_t n, 
   memset(&kp, 0, sizeof kp);
   kp.weight_fn = PCGX_WEIGHT_CONSTANT;  // nine rows: the ninth sum is chained like the others
   kp.weight_a = 1.0f;
-  rc = strict_enqueue(b, nullptr, nullptr, d_state, d_sums, kp, false, false, st);
+  rc = strict_enqueue(b, nullptr, nullptr, d_state, d_sums, kp, false, false, true, st);
   double h[16];
   if (rc == PCGX_OK) {
     e = hipMemcpyAsync(h, d_sums, sizeof h, hipMemcpyDeviceToHost, st);

@@ -141,9 +141,39 @@ def test_c5_partial_sums_reproducible_over_a_fit(c5):
     assert np.max(np.abs(runs[0][1].astype(np.float64) - inv)) < 0.02
 
 
+def test_c5_reference_sums_on_the_whole_tile_against_the_oracle_digest(c5):
+    """The reference's sums over the WHOLE 8M-target tile (3907 tiles per sum, eight chunk workgroups of the chain
+    kernel per sum) against what the CPU oracle computed there (tests/golden/c5_digest.json "tile": its sequential
+    float32 sums): iteration 0's Evaluated, and pose + Evaluated of a three-iteration Fit, bit for bit."""
+    import json
+    import os
+    base, tile, tree = c5
+    with open(os.path.join(os.path.dirname(__file__), "golden", "c5_digest.json")) as f:
+        g = json.load(f)["tile"]
+    ev = icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=0.5), MinPairs=6).Evaluate(tree, tile)
+    assert ev.NumPairs == g["n_pairs"]
+    assert int(np.float32(ev.Value).view(np.uint32)) == g["evaluate_value_bits"]
+    assert [int(v) for v in ev.Gradient.view(np.uint32)] == g["evaluate_gradient_bits"]
+    assert int(np.float32(ev.DistRMS).view(np.uint32)) == g["evaluate_dist_rms_bits"]
+    s = icp.IcpSession(tree, tile, MaxDist=0.5, MinPairs=6, Weight=np.full(6, 0.3, np.float32),
+                       Threshold=np.full(6, -1.0, np.float32), MaxIteration=3)
+    for _ in range(3):
+        s.step()
+    tr, st, _ = s.result()
+    sst = s.strict_stats()
+    s.close()
+    assert st.NumIteration == g["fit3_num_iteration"] == 3
+    assert [int(v) for v in np.asarray(tr, np.float32).ravel().view(np.uint32)] == g["fit3_trans_bits"]
+    assert int(np.float32(st.Evaluated.Value).view(np.uint32)) == g["fit3_value_bits"]
+    assert [int(v) for v in np.asarray(st.Evaluated.Gradient, np.float32).view(np.uint32)] == g["fit3_gradient_bits"]
+    assert int(np.float32(st.Evaluated.DistRMS).view(np.uint32)) == g["fit3_dist_rms_bits"]
+    assert sst[62] == 0 and sst[63] == 0   # no walker walked alone, no workgroup gave up the exchange
+
+
 def test_c5_strict_sums_on_the_tile(c5, monkeypatch):
     """The parallel strict sums over 8M targets (3907 tiles per sum: eight chunks of the chain kernel,
-    62 level-1 bins) against the one-wave chain, three iterations, with the in-kernel self-check."""
+    62 level-1 bins) against the one-wave chain, three iterations, with the in-kernel self-check (the oracle's own
+    sums over this tile: the test above)."""
     monkeypatch.setenv("PCGX_STRICT_SELFCHECK", "1")
     base, tile, tree = c5
     cfg = dict(MaxDist=0.5, MinPairs=6, Weight=np.full(6, 0.3, np.float32), Threshold=np.full(6, -1.0, np.float32),

@@ -51,5 +51,5 @@ for mode in (1, 0):
             print("  iteration %2d: tiles recomputed %3d, leaves term by term %4d, slowest sum's walk %.0f us | no window: %d tiles, %d runs tried, %d applied, %d leaves serial, %.1f us each (table hits %d exact + %d between, of %d) | crossing: %d tiles, %d leaves serial, %.1f us each | no slot %d" % (
                 k, st[2], st[3], st[46] / 100.0, st[16], st[17], st[18], st[22], st[19] / 100.0 / max(st[16], 1), st[25], st[26], st[24], st[20], st[23], st[21] / 100.0 / max(st[20], 1), st[5]))
             if sum(st[48:64]):
-                print("      table misses by log2(distance of the state from the guess): %s, other sign %d" % (list(int(v) for v in st[48:59]), st[59]))
+                print("      table misses by log2(distance of the state from the guess): %s, other sign %d" % (list(int(v) for v in st[48:57]), st[57]))
     s.close()

@@ -39,8 +39,10 @@ for k in range(c["max_iteration"]):
     print("      tiles handed to a helper: table not up %d, state outside the table %d, no such candidate %d" % (st[42], st[43], st[44]))
     if st[46] / 100.0 > 20.0:
         print("      walk per row, us:", " ".join("%.1f" % (st[27 + r] / 100.0) for r in range(9)))
-    if any(st[48:60]):
-        print("      states that missed their tile's table, by log2 of the distance to the guess (0: equal .. 10: >= 2^9, 11: other sign):", " ".join("%d:%d" % (b, st[48 + b]) for b in range(12) if st[48 + b]))
+    if any(st[48:58]):
+        print("      states that missed their tile's table, by log2 of the distance to the guess (0: equal .. 8: >= 2^7, 9: other sign):", " ".join("%d:%d" % (b, st[48 + b]) for b in range(10) if st[48 + b]))
+    if st[58]:
+        print("      plain tiles the repair pass turned into jobs: %d" % st[58])
     if st[5]:
         print("      last tile without a slot that was recomputed: %d, guess %08x, state %08x" % (st[45], int(st[47]) >> 32, int(st[47]) & 0xffffffff))
     for q in range(0):
