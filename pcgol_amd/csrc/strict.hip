@@ -1092,54 +1092,57 @@ __global__ __launch_bounds__(kJobBlock) void strict_job_kernel(const IcpState *_
 // prefix of the tiles' sums + of their chains' rounding errors) and tests the tile's record on it, kRepairMargin
 // floats either side; a tile that does not cover them becomes a job like any level crossing -- slot, description,
 // terms formed again from the pairs, by a whole wave, off the critical path.
-constexpr int kRepairBlock = 512;
+constexpr int kRepairBlock = 512;  // a workgroup per (sum, 512 tiles), a tile per thread
 constexpr uint32_t kRepairMargin = 64u;
-constexpr int kRepairList = 512;
+// (rows of fewer tiles are left alone: at C4's 489 tiles the pass costs 36 us in the first iteration and saves nothing
+// measurable -- the one or two tiles it catches are not what that launch waits for; at C5's 3907 it takes the first
+// iteration's chain kernel from 1.3 ms to 0.26)
+constexpr int64_t kRepairMinTiles = 1024;
 __global__ __launch_bounds__(kRepairBlock) void strict_repair_kernel(const float4 *__restrict__ match, const uint32_t *__restrict__ pos_of,
                                                                      const IcpState *__restrict__ state, StrictWork W) {
-  __shared__ double s_wsum[kRepairBlock / 64];
-  __shared__ int s_list[kRepairList];
+  __shared__ double s_before[kRepairBlock / 64], s_wtot[kRepairBlock / 64];
+  __shared__ int s_list[kRepairBlock];
   __shared__ int s_n;
-  const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = (int)(blockIdx.x % (unsigned)W.nrows), part = (int)(blockIdx.x / (unsigned)W.nrows);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (state->done || state->iter != 0) return;  // uniform
   if (threadIdx.x == 0) s_n = 0;
-  const int64_t per = (W.ntiles + kRepairBlock - 1) / kRepairBlock;
-  const int64_t t0 = (int64_t)threadIdx.x * per < W.ntiles ? (int64_t)threadIdx.x * per : W.ntiles;
-  const int64_t t1 = t0 + per < W.ntiles ? t0 + per : W.ntiles;
   const double *ts = W.tile_sum + (int64_t)row * W.ntiles, *te = W.tile_err + (int64_t)row * W.ntiles;
-  double local = 0.0;
-  for (int64_t t = t0; t < t1; t++) local += ts[t] + te[t];
-  const double pre = wave_excl_scan_f64(local, lane);
-  const double wtot = lane_f64(pre, 63) + lane_f64(local, 63);
-  if (lane == 0) s_wsum[wave] = wtot;
+  const int64_t first = (int64_t)part * kRepairBlock, t = first + threadIdx.x;
+  // what the parts before this one add up to (every workgroup for itself: a few thousand doubles), then the scan inside
+  double before = 0.0;
+  for (int64_t k = threadIdx.x; k < first; k += kRepairBlock) before += ts[k] + te[k];
+  before = wave_allsum_f64(before);
+  const double mine = t < W.ntiles ? ts[t] + te[t] : 0.0;
+  const double pre = wave_excl_scan_f64(mine, lane);
+  if (lane == 63) {
+    s_before[wave] = before;
+    s_wtot[wave] = pre + mine;
+  }
   __syncthreads();
   double base = pre + (W.row_base ? W.row_base[row] + W.err_base[row] : 0.0);  // (+ the ranks before this one)
-  for (int w = 0; w < wave; w++) base += s_wsum[w];
-  for (int64_t t = t0; t < t1; t++) {
+  for (int w = 0; w < kRepairBlock / 64; w++) base += s_before[w] + (w < wave ? s_wtot[w] : 0.0);
+  if (t < W.ntiles) {
     const TileRec T = W.recs[(int64_t)row * W.ntiles + t];
     const bool plain = T.key >= 0 && (T.cons >> 8) == 0 && !(t < kExactTiles && W.first_exact);
     if (plain) {
       const uint32_t g = f2u((float)base), mag = g & 0x7fffffffu;
       bool ok = mag > 2u * kRepairMargin && mag < 0x7f800000u - 2u * kRepairMargin;
 #pragma unroll
-      for (int j = 0; j < 4 && ok; j++) {  // (every parity class at either end of the margin)
+      for (int j = 0; j < 4; j++) {  // (every parity class at either end of the margin)
         uint32_t a = g - kRepairMargin + (uint32_t)j, b = g + kRepairMargin - (uint32_t)j;
-        ok = apply(a, T.key, T.s) && apply(b, T.key, T.s);
+        ok = ok && apply(a, T.key, T.s) && apply(b, T.key, T.s);
       }
-      if (!ok) {
-        const int k = atomicAdd(&s_n, 1);
-        if (k < kRepairList) s_list[k] = (int)t;
-      }
+      if (!ok) s_list[atomicAdd(&s_n, 1)] = (int)threadIdx.x;
     }
-    base += ts[t] + te[t];
   }
   __syncthreads();
-  const int n = s_n < kRepairList ? s_n : kRepairList;
+  const int n = s_n;
   if (n == 0) return;  // uniform
   const TermSrc S = make_term_src(match, pos_of, state, W);
   const unsigned per_shard = (unsigned)W.naux / kAuxShards;
   for (int i = wave; i < n; i += kRepairBlock / 64) {  // uniform per wave
-    const int64_t tile = s_list[i];
+    const int64_t tile = first + s_list[i];
     unsigned slot = 0xffffffffu;
     if (lane == 0) {
       const unsigned shard = (unsigned)((tile + 7 * row) % kAuxShards);
@@ -2419,8 +2422,9 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
   {
     ProfScope prof(PCGX_PROF_STRICT_JOB, st);
     // (the first Evaluate of a Fit: the plain tiles the rows' drift has carried across a binade's end become jobs)
-    if (first_iter && W.naux > 0 && repair_enabled())
-      hipLaunchKernelGGL(strict_repair_kernel, dim3((unsigned)W.nrows), dim3(kRepairBlock), 0, st, match, pos_of, (const IcpState *)state, W);
+    if (first_iter && W.naux > 0 && W.ntiles >= kRepairMinTiles && repair_enabled())
+      hipLaunchKernelGGL(strict_repair_kernel, dim3((unsigned)(W.nrows * ((W.ntiles + kRepairBlock - 1) / kRepairBlock))), dim3(kRepairBlock), 0,
+                         st, match, pos_of, (const IcpState *)state, W);
     if (W.naux > 0)
       hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)kJobRoles * (unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
   }
@@ -2666,8 +2670,9 @@ pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uin
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_JOB, st);
-    if (first_iter && W.naux > 0 && repair_enabled())
-      hipLaunchKernelGGL(strict_repair_kernel, dim3((unsigned)W.nrows), dim3(kRepairBlock), 0, st, match, pos_of, (const IcpState *)state, W);
+    if (first_iter && W.naux > 0 && W.ntiles >= kRepairMinTiles && repair_enabled())
+      hipLaunchKernelGGL(strict_repair_kernel, dim3((unsigned)(W.nrows * ((W.ntiles + kRepairBlock - 1) / kRepairBlock))), dim3(kRepairBlock), 0,
+                         st, match, pos_of, (const IcpState *)state, W);
     if (W.naux > 0)
       hipLaunchKernelGGL(strict_job_kernel, dim3((unsigned)kJobRoles * (unsigned)W.naux), dim3(kJobBlock), 0, st, (const IcpState *)state, W);
   }
