@@ -212,6 +212,8 @@ static pcgx_status init_device(int device) {
       (void)hipGetLastError();
     }
     s.mailbox_seq = 0;
+    PCGX_HIP_TRY(hipMalloc((void **)&s.tickets, 256));
+    PCGX_HIP_TRY(hipMemset(s.tickets, 0, 256));
     s.device = device;
   }
   for (int k = kPoolSlots; k >= 0; k--) g.slots[k].ready = true;
@@ -420,6 +422,8 @@ static void shutdown_slot() {
     c.stream = nullptr;
     if (c.mailbox) (void)hipHostFree((void *)c.mailbox);
     c.mailbox = nullptr;
+    if (c.tickets) (void)hipFree(c.tickets);
+    c.tickets = nullptr;
     c.ready = false;
     c.device = -1;
   }

@@ -136,6 +136,8 @@ struct Context {
   // memory plus hipStreamSynchronize cost 30 us of idle GPU per call
   volatile uint32_t *mailbox = nullptr;
   uint32_t mailbox_seq = 0;
+  // a few zeroed device words that kernels use as "last workgroup" tickets and put back to zero themselves
+  unsigned int *tickets = nullptr;
 };
 Context &ctx();  // the calling thread's current context (the library's outside any call)
 bool slots_share_a_device(int n);  // (a one-GPU box standing in for a node: see core.hip)

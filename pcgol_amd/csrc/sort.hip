@@ -271,12 +271,16 @@ pcgx_status radix_sort_pairs(uint32_t *keys[2], uint32_t *vals[2], int64_t n, in
 }
 
 // ---------------------------------------------------------------- min / max
-// pc.MinMaxVec3 (pc/minmax.go:9-26): per-axis min and max with strict
-// comparisons starting from point 0.  For equal values (only -0 vs +0 differ
-// in bits) the sequential loop keeps the FIRST occurrence, and a NaN never
-// replaces anything but a NaN at index 0 sticks: the reduction therefore
-// carries (value, index) and prefers the lower index on equality; NaNs lose
-// against everything, and point 0 is folded in last with the reference's rule.
+// pc.MinMaxVec3 (pc/minmax.go:9-26): per-axis min and max with strict comparisons starting from point 0.  A NaN never
+// replaces anything (its comparisons are false) but a NaN at index 0 sticks; of equal values the sequential loop keeps
+// the FIRST -- and the only equal values with different bits are +0 and -0.  So the reduction is IEEE minNum / maxNum
+// (a NaN operand loses: v_min_f32 / v_max_f32 behind the compiler's canonicalisation of the loaded value) over
+// everything, plus, per axis, the index and sign of the FIRST zero of the cloud: when an axis' min (or max) is zero, it
+// became zero at the first zero in index order (every running value before it was > 0, resp. < 0) and no later zero
+// replaced it -- that zero's sign is the result's.  Four vector instructions per coordinate (canonicalise, min, max,
+// compare with zero; the zero's bookkeeping runs only where a wave has seen one) where the (value, index) pairs of
+// rounds 1-4 took sixteen: the pass is a stream of 12-byte records and was bound by its arithmetic (3.2 TB/s).
+// Point 0 is folded in last with the reference's rule.
 __device__ __forceinline__ float ld_f32_any(const uint8_t *p) {
   float v;
   __builtin_memcpy(&v, p, 4);  // records may be byte aligned (pc/iterator.go:71-76)
@@ -285,58 +289,128 @@ __device__ __forceinline__ float ld_f32_any(const uint8_t *p) {
 
 struct MinMaxAcc {
   float mn[3], mx[3];
-  int32_t imn[3], imx[3];
+  uint32_t zf[3];  // (index << 1 | sign bit) of the first zero coordinate seen, 0xffffffff: none
 };
-
-__device__ __forceinline__ void mm_take(float &m, int32_t &im, float v, int32_t iv, bool is_min) {
-  // true if (v, iv) should replace (m, im)
-  const bool better = is_min ? (v < m) : (v > m);
-  const bool tie = (v == m) && (iv < im);
-  const bool m_nan = m != m;
-  if (better || tie || (m_nan && !(v != v))) {
-    m = v;
-    im = iv;
-  }
-}
-
-// wave shuffle -> LDS -> one partial per workgroup
-__device__ __forceinline__ void minmax_block_fold(MinMaxAcc &a, MinMaxAcc *__restrict__ partials) {
-  __shared__ MinMaxAcc s_acc[4];
-  for (int o = 32; o > 0; o >>= 1) {
-    for (int k = 0; k < 3; k++) {
-      float v = __shfl_down(a.mn[k], o); int32_t iv = __shfl_down(a.imn[k], o);
-      mm_take(a.mn[k], a.imn[k], v, iv, true);
-      v = __shfl_down(a.mx[k], o); iv = __shfl_down(a.imx[k], o);
-      mm_take(a.mx[k], a.imx[k], v, iv, false);
-    }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) s_acc[wave] = a;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; w++)
-      for (int k = 0; k < 3; k++) {
-        mm_take(a.mn[k], a.imn[k], s_acc[w].mn[k], s_acc[w].imn[k], true);
-        mm_take(a.mx[k], a.imx[k], s_acc[w].mx[k], s_acc[w].imx[k], false);
-      }
-    partials[blockIdx.x] = a;
-  }
-}
 
 __device__ __forceinline__ void minmax_init(MinMaxAcc &a) {
   const float qnan = __uint_as_float(0x7fc00000u);
   for (int k = 0; k < 3; k++) {
-    a.mn[k] = qnan; a.mx[k] = qnan;
-    a.imn[k] = 0x7fffffff; a.imx[k] = 0x7fffffff;
+    a.mn[k] = qnan; a.mx[k] = qnan;  // (minNum / maxNum: the first number replaces it; all NaN: stays NaN)
+    a.zf[k] = 0xffffffffu;
+  }
+}
+__device__ __forceinline__ void mm_value(MinMaxAcc &a, int k, float v) {
+  a.mn[k] = fminf(a.mn[k], v);
+  a.mx[k] = fmaxf(a.mx[k], v);
+}
+__device__ __forceinline__ void mm_zero(MinMaxAcc &a, int k, float v, int64_t i) {
+  if (v == 0.0f) a.zf[k] = min(a.zf[k], ((uint32_t)i << 1) | (__float_as_uint(v) >> 31));
+}
+__device__ __forceinline__ void mm_merge(MinMaxAcc &a, const MinMaxAcc &b) {
+  for (int k = 0; k < 3; k++) {
+    a.mn[k] = fminf(a.mn[k], b.mn[k]);
+    a.mx[k] = fmaxf(a.mx[k], b.mx[k]);
+    a.zf[k] = min(a.zf[k], b.zf[k]);
+  }
+}
+// the reference's result out of the fold: a zero takes the sign of the cloud's first zero
+__device__ __forceinline__ void mm_finish(MinMaxAcc &a) {
+  for (int k = 0; k < 3; k++) {
+    const float z = __uint_as_float((a.zf[k] & 1u) << 31);
+    if (a.mn[k] == 0.0f) a.mn[k] = z;
+    if (a.mx[k] == 0.0f) a.mx[k] = z;
+  }
+}
+
+// What the launch's LAST workgroup does with the partials (a ticket: one returning atomic per workgroup): the fold,
+// point 0's rule, out6 = {min xyz, max xyz} -- and, where the host waits for them, the six floats straight into its
+// pinned mailbox, the sequence word last.  (A kernel of its own for this was 13.6 us of the filter's call: a launch
+// behind a 120 MB stream, and 1024 partials read by one workgroup.)
+struct MinMaxTail {
+  MinMaxAcc *partials;
+  unsigned int *ticket;
+  const uint8_t *data;
+  int32_t off, sticky_first;
+  float *out6;
+  volatile uint32_t *mailbox;
+  uint32_t seq;
+};
+__device__ __forceinline__ void minmax_block_fold(MinMaxAcc &a, const MinMaxTail &T) {
+  __shared__ MinMaxAcc s_acc[4];
+  __shared__ unsigned int s_last;
+  auto wave_fold = [&](MinMaxAcc &x) {
+    for (int o = 32; o > 0; o >>= 1) {
+      MinMaxAcc y;
+      for (int k = 0; k < 3; k++) {
+        y.mn[k] = __shfl_down(x.mn[k], o);
+        y.mx[k] = __shfl_down(x.mx[k], o);
+        y.zf[k] = (uint32_t)__shfl_down((int)x.zf[k], o);
+      }
+      mm_merge(x, y);
+    }
+  };
+  wave_fold(a);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) s_acc[wave] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) mm_merge(a, s_acc[w]);
+    // (write-through: the last workgroup reads the partials past its own XCD's L2)
+    MinMaxAcc *dst = &T.partials[blockIdx.x];
+    for (int k = 0; k < 3; k++) {
+      __hip_atomic_store(&dst->mn[k], a.mn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&dst->mx[k], a.mx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&dst->zf[k], a.zf[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(T.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;  // uniform
+  MinMaxAcc f;
+  minmax_init(f);
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {
+    MinMaxAcc p;
+    const MinMaxAcc *src = &T.partials[b];
+    for (int k = 0; k < 3; k++) {
+      p.mn[k] = __hip_atomic_load(&src->mn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      p.mx[k] = __hip_atomic_load(&src->mx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      p.zf[k] = __hip_atomic_load(&src->zf[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    mm_merge(f, p);
+  }
+  wave_fold(f);
+  __syncthreads();  // (s_acc is read above by thread 0 only, before its ticket)
+  if (lane == 0) s_acc[wave] = f;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int w = 1; w < 4; w++) mm_merge(f, s_acc[w]);
+  mm_finish(f);
+  *T.ticket = 0u;  // (for the next launch that uses this word)
+  for (int k = 0; k < 3; k++) {
+    // min, max := Vec3At(0): a NaN there is never replaced (minmax.go:13-23)
+    // (sticky_first 0: `data` is a later slice of a cloud split over ranks -- its first point is no more
+    // special than any other, a NaN there is skipped like everywhere else)
+    const float p0 = ld_f32_any(T.data + T.off + 4 * k);
+    if (T.sticky_first && p0 != p0) { f.mn[k] = p0; f.mx[k] = p0; }
+    T.out6[k] = f.mn[k];
+    T.out6[3 + k] = f.mx[k];
+  }
+  if (T.mailbox) {  // the host waits for these: straight into its (pinned) memory, the sequence word last
+    for (int k = 0; k < 3; k++) {
+      T.mailbox[1 + k] = __float_as_uint(f.mn[k]);
+      T.mailbox[4 + k] = __float_as_uint(f.mx[k]);
+    }
+    __threadfence_system();
+    T.mailbox[0] = T.seq;
   }
 }
 
 __global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__restrict__ data, int64_t n,
-                                                             int32_t stride, int32_t off,
-                                                             MinMaxAcc *__restrict__ partials) {
+                                                             int32_t stride, int32_t off, MinMaxTail T) {
   MinMaxAcc a;
   minmax_init(a);
-  // four independent loads in flight per thread; indices still increase per thread
+  // four independent loads in flight per thread
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * step) {
     float v[4][3];
@@ -346,24 +420,28 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__re
       const uint8_t *p = data + (i < n ? i : i0) * stride + off;
       v[u][0] = ld_f32_any(p); v[u][1] = ld_f32_any(p + 4); v[u][2] = ld_f32_any(p + 8);
     }
+    bool zero = false;
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int64_t i = i0 + u * step;
-      if (i < n)
-        for (int k = 0; k < 3; k++) {
-          mm_take(a.mn[k], a.imn[k], v[u][k], (int32_t)i, true);
-          mm_take(a.mx[k], a.imx[k], v[u][k], (int32_t)i, false);
-        }
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {  // (an index beyond n re-reads point i0: harmless for min / max, and for the zeros below)
+        mm_value(a, k, v[u][k]);
+        zero |= v[u][k] == 0.0f;
+      }
+    if (__ballot(zero) != 0ull) {  // uniform, rare: somebody's coordinate is a zero
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int64_t i = i0 + u * step < n ? i0 + u * step : i0;
+        for (int k = 0; k < 3; k++) mm_zero(a, k, v[u][k], i);
+      }
     }
   }
-  minmax_block_fold(a, partials);
+  minmax_block_fold(a, T);
 }
 
 // Packed xyz clouds (stride 12, offset 0, 16-byte aligned base): a thread takes 4 consecutive
-// points = three 16-byte loads, two such groups in flight.  Same (value, index) rule, so the
-// same result as the general kernel.
-__global__ __launch_bounds__(256) void minmax_partial_packed_kernel(const float4 *__restrict__ data, int64_t n,
-                                                                    MinMaxAcc *__restrict__ partials) {
+// points = three 16-byte loads, two such groups in flight.
+__global__ __launch_bounds__(256) void minmax_partial_packed_kernel(const float4 *__restrict__ data, int64_t n, MinMaxTail T) {
   MinMaxAcc a;
   minmax_init(a);
   const int64_t groups = n >> 2;  // whole groups of 4 points; the tail is handled by one thread below
@@ -375,18 +453,24 @@ __global__ __launch_bounds__(256) void minmax_partial_packed_kernel(const float4
       const int64_t g = g0 + u * step < groups ? g0 + u * step : g0;
       r[u][0] = data[3 * g]; r[u][1] = data[3 * g + 1]; r[u][2] = data[3 * g + 2];
     }
+    bool zero = false;
+    float f[2][12];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-      const int64_t g = g0 + u * step;
-      if (g < groups) {
-        const float f[12] = {r[u][0].x, r[u][0].y, r[u][0].z, r[u][0].w, r[u][1].x, r[u][1].y,
-                             r[u][1].z, r[u][1].w, r[u][2].x, r[u][2].y, r[u][2].z, r[u][2].w};
+      const float t[12] = {r[u][0].x, r[u][0].y, r[u][0].z, r[u][0].w, r[u][1].x, r[u][1].y,
+                           r[u][1].z, r[u][1].w, r[u][2].x, r[u][2].y, r[u][2].z, r[u][2].w};
 #pragma unroll
-        for (int p = 0; p < 4; p++)
-          for (int k = 0; k < 3; k++) {
-            mm_take(a.mn[k], a.imn[k], f[3 * p + k], (int32_t)(4 * g + p), true);
-            mm_take(a.mx[k], a.imx[k], f[3 * p + k], (int32_t)(4 * g + p), false);
-          }
+      for (int j = 0; j < 12; j++) {
+        f[u][j] = t[j];
+        mm_value(a, j % 3, t[j]);
+        zero |= t[j] == 0.0f;
+      }
+    }
+    if (__ballot(zero) != 0ull) {  // uniform, rare
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int64_t g = g0 + u * step < groups ? g0 + u * step : g0;
+        for (int j = 0; j < 12; j++) mm_zero(a, j % 3, f[u][j], 4 * g + j / 3);
       }
     }
   }
@@ -394,62 +478,11 @@ __global__ __launch_bounds__(256) void minmax_partial_packed_kernel(const float4
     const float *f = reinterpret_cast<const float *>(data);
     for (int64_t i = groups << 2; i < n; i++)
       for (int k = 0; k < 3; k++) {
-        mm_take(a.mn[k], a.imn[k], f[3 * i + k], (int32_t)i, true);
-        mm_take(a.mx[k], a.imx[k], f[3 * i + k], (int32_t)i, false);
+        mm_value(a, k, f[3 * i + k]);
+        mm_zero(a, k, f[3 * i + k], i);
       }
   }
-  minmax_block_fold(a, partials);
-}
-
-// out6 = {min xyz, max xyz}; one block folds the per-block partials.
-__global__ __launch_bounds__(256) void minmax_final_kernel(const MinMaxAcc *__restrict__ partials, int nparts,
-                                                           const uint8_t *__restrict__ data, int32_t off,
-                                                           float *__restrict__ out6, int sticky_first,
-                                                           volatile uint32_t *__restrict__ mailbox, uint32_t seq) {
-  __shared__ MinMaxAcc s_acc[4];
-  const float qnan = __uint_as_float(0x7fc00000u);
-  MinMaxAcc a;
-  for (int k = 0; k < 3; k++) {
-    a.mn[k] = qnan; a.mx[k] = qnan;
-    a.imn[k] = 0x7fffffff; a.imx[k] = 0x7fffffff;
-  }
-  for (int b = threadIdx.x; b < nparts; b += 256)
-    for (int k = 0; k < 3; k++) {
-      mm_take(a.mn[k], a.imn[k], partials[b].mn[k], partials[b].imn[k], true);
-      mm_take(a.mx[k], a.imx[k], partials[b].mx[k], partials[b].imx[k], false);
-    }
-  for (int o = 32; o > 0; o >>= 1)
-    for (int k = 0; k < 3; k++) {
-      float v = __shfl_down(a.mn[k], o); int32_t iv = __shfl_down(a.imn[k], o);
-      mm_take(a.mn[k], a.imn[k], v, iv, true);
-      v = __shfl_down(a.mx[k], o); iv = __shfl_down(a.imx[k], o);
-      mm_take(a.mx[k], a.imx[k], v, iv, false);
-    }
-  if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6] = a;
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  for (int w = 1; w < 4; w++)
-    for (int k = 0; k < 3; k++) {
-      mm_take(a.mn[k], a.imn[k], s_acc[w].mn[k], s_acc[w].imn[k], true);
-      mm_take(a.mx[k], a.imx[k], s_acc[w].mx[k], s_acc[w].imx[k], false);
-    }
-  for (int k = 0; k < 3; k++) {
-    // min, max := Vec3At(0): a NaN there is never replaced (minmax.go:13-23)
-    // (sticky_first 0: `data` is a later slice of a cloud split over ranks -- its first point is no more
-    // special than any other, a NaN there is skipped like everywhere else)
-    const float p0 = ld_f32_any(data + off + 4 * k);
-    if (sticky_first && p0 != p0) { a.mn[k] = p0; a.mx[k] = p0; }
-    out6[k] = a.mn[k];
-    out6[3 + k] = a.mx[k];
-  }
-  if (mailbox) {  // the host waits for these: straight into its (pinned) memory, the sequence word last
-    for (int k = 0; k < 3; k++) {
-      mailbox[1 + k] = __float_as_uint(a.mn[k]);
-      mailbox[4 + k] = __float_as_uint(a.mx[k]);
-    }
-    __threadfence_system();
-    mailbox[0] = seq;
-  }
+  minmax_block_fold(a, T);
 }
 
 static pcgx_status launch_minmax_impl(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
@@ -458,16 +491,19 @@ static pcgx_status launch_minmax_impl(const void *d_data, int64_t n, int32_t str
   int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  MinMaxAcc *partials = nullptr;
-  PCGX_TRY(ctx().arena.alloc_n(blocks, &partials));
+  MinMaxTail T;
+  PCGX_TRY(ctx().arena.alloc_n(blocks, &T.partials));
+  T.ticket = ctx().tickets;  // (zero between launches: the last workgroup puts it back; one launch at a time per context)
+  T.data = (const uint8_t *)d_data;
+  T.off = off;
+  T.sticky_first = sticky_first ? 1 : 0;
+  T.out6 = d_out6;
+  T.mailbox = mailbox;
+  T.seq = seq;
   if (stride == 12 && off == 0 && (reinterpret_cast<uintptr_t>(d_data) & 15) == 0)
-    hipLaunchKernelGGL(minmax_partial_packed_kernel, dim3(blocks), dim3(256), 0, st, (const float4 *)d_data, n,
-                       partials);
+    hipLaunchKernelGGL(minmax_partial_packed_kernel, dim3(blocks), dim3(256), 0, st, (const float4 *)d_data, n, T);
   else
-    hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t *)d_data, n,
-                       stride, off, partials);
-  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, st, partials, blocks,
-                     (const uint8_t *)d_data, off, d_out6, sticky_first ? 1 : 0, mailbox, seq);
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t *)d_data, n, stride, off, T);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }

@@ -14,7 +14,7 @@ for _ in range(2):
     m = vg.FilterDev(dp.data_ptr(), n, 12, 0, dout.data_ptr(), st)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
-for _ in range(5):
+for _ in range(40):
     m = vg.FilterDev(dp.data_ptr(), n, 12, 0, dout.data_ptr(), st)
 torch.cuda.synchronize()
-print("voxel ms/call", (time.perf_counter() - t0) / 5 * 1e3, "M", m)
+print("voxel ms/call", (time.perf_counter() - t0) / 40 * 1e3, "M", m)
