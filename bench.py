@@ -214,6 +214,26 @@ def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, ic
                              "frac_traffic": traffic / kernel_s / 1e9 / HBM_PEAK_GBS if traffic else None})
         elif kn > 0:
             out[key]["frac_survey_8d"] = ref / (kms / kn * 1e-3) / 1e9 / HBM_PEAK_GBS
+    out["knn_c2_unsorted"]["what"] = ("flags 0 of pcgx_kdtree_nearest_batch_dev: the queries are searched in the order they "
+                                      "arrive -- the seam for batches that come spatially ordered (scan lines, the output of a "
+                                      "voxel filter); on C2's random order it is the slower choice, and the host-pointer entry "
+                                      "points never take it for 2^18 queries or more")
+    # ... the case that seam is for: the same queries arriving ordered by cell (sorted once on the host here)
+    cell = (np.floor(c2q / np.float32(0.625)).astype(np.int64) * np.array([1, 16, 256])).sum(axis=1)
+    dqs = torch.from_numpy(np.ascontiguousarray(c2q[np.argsort(cell, kind="stable")])).to(dev)
+    rows = {}
+    for presort, key in ((False, "caller_order"), (True, "partitioned_again")):
+        for _ in range(2):
+            tree.NearestBatchDev(dqs.data_ptr(), len(c2q), 10.0, ids.data_ptr(), dsq.data_ptr(), presort, stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            tree.NearestBatchDev(dqs.data_ptr(), len(c2q), 10.0, ids.data_ptr(), dsq.data_ptr(), presort, stream)
+        torch.cuda.synchronize()
+        rows[key] = (time.perf_counter() - t0) / 20 * 1e3
+    out["knn_c2_ordered_input"] = {"ms_per_call_caller_order": rows["caller_order"],
+                                   "ms_per_call_partitioned_again": rows["partitioned_again"],
+                                   "what": "C2's queries arriving sorted by 0.625 m cell: flags 0 against PCGX_KNN_PRESORT"}
     # Point-to-plane / Gauss-Newton extension (BASELINE.json config "ICP point-to-plane, 1M source vs
     # 1M target, 20 iters"; the reference has no such evaluator: no reference parity).
     cp = synth.c4_plane(1_000_000)

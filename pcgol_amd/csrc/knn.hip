@@ -465,8 +465,8 @@ extern "C" pcgx_status pcgx_kdtree_delete_points(pcgx_kdtree *t, const int64_t *
       return fail(PCGX_E_OUT_OF_RANGE, "%lld does not correspond to any point in the tree", (long long)ids[i]);
   std::lock_guard<std::mutex> lock(t->mu);
   if (t->deleted.empty()) t->deleted.assign((size_t)t->n, 0);
+  xtree_delete_batch(t, ids, m);  // the reference's patching, in call order (a repeated id finds nothing)
   for (int64_t i = 0; i < m; i++) {
-    xtree_delete(t, ids[i]);  // the reference's patching, in call order (a repeated id finds nothing)
     if (t->deleted[(size_t)ids[i]]) continue;
     t->deleted[(size_t)ids[i]] = 1;
     t->n_deleted++;

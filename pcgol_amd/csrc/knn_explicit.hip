@@ -18,6 +18,8 @@
 // Range hits are a set, whatever the tree's shape.
 #include <string.h>
 
+#include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "knn_xwalk.h"
@@ -88,6 +90,19 @@ __global__ __launch_bounds__(kXBlock) void xrange_kernel(XTreeView xv, const flo
   };
   xwalk(xv, s_stack + threadIdx.x, kXBlock, qx, qy, qz, guard, [&]() { return bound; }, hit, hit);
   if (!kFill) counts[i] = found;
+}
+
+// The device copy out of the host mirror as it is ({id, child0, child1, dim} per node, uploaded in one piece) and the
+// cloud's points by id (uploaded once per handle): node k's point record and links.  (The host used to put both arrays
+// together point by point and copy them from pageable memory: 8-14 ms per refresh at 1M nodes.)
+__global__ __launch_bounds__(256) void xtree_expand_kernel(const int4 *__restrict__ xnodes, const float *__restrict__ pts_by_id,
+                                                           int64_t n, float4 *__restrict__ pts, int4 *__restrict__ links) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int4 nd = xnodes[k];  // {id, c0, c1, dim}
+  const int64_t id = nd.x >= 0 && nd.x < n ? nd.x : 0;
+  pts[k] = make_float4(pts_by_id[3 * id], pts_by_id[3 * id + 1], pts_by_id[3 * id + 2], __int_as_float(nd.x));
+  links[k] = make_int4(nd.y, nd.z, nd.w, 0);
 }
 
 }  // namespace pcgx
@@ -165,12 +180,179 @@ void xtree_delete(pcgx_kdtree *t, int64_t pid) {
   t->x_dirty = true;
 }
 
+namespace {
+int host_threads() {
+  static const int n = [] {
+    int v = (int)std::thread::hardware_concurrency();
+    if (const char *e = getenv("PCGX_HOST_THREADS")) v = atoi(e);
+    return v < 1 ? 1 : (v > 16 ? 16 : v);
+  }();
+  return n;
+}
+
+// the original tree's nodes at depth `cut` (the tree's shape depends on n alone: node = middle of its in-order range)
+struct SubTree {
+  int64_t lo, cnt;  // in-order index range of the original subtree
+  int32_t root;     // its root's node index (= lo + cnt / 2)
+  int depth;
+};
+void collect_subtrees(int64_t lo, int64_t cnt, int depth, int cut, std::vector<SubTree> &out, std::vector<int32_t> *top) {
+  if (cnt <= 0) return;
+  const int64_t half = cnt / 2, mid = lo + half;
+  if (depth == cut) {
+    out.push_back(SubTree{lo, cnt, (int32_t)mid, depth});
+    return;
+  }
+  if (top) top->push_back((int32_t)mid);
+  collect_subtrees(lo, half, depth + 1, cut, out, top);
+  collect_subtrees(mid + 1, cnt - half - 1, depth + 1, cut, out, top);
+}
+}  // namespace
+
 static void xtree_init(pcgx_kdtree *t) {
   if (t->x_init) return;
   t->xnodes.resize((size_t)t->n);
-  t->xroot = build_xnodes(t, 0, t->n, 0);
+  const int nth = host_threads();
+  if (t->n >= (1 << 16) && nth > 1) {
+    // the levels above depth 6 by this thread (it needs the subtrees' roots as children: their indices are arithmetic),
+    // the 64 subtrees below by the host's threads: disjoint node ranges
+    const int cut = 6;
+    std::vector<SubTree> subs;
+    collect_subtrees(0, t->n, 0, cut, subs, nullptr);
+    std::vector<std::thread> th;
+    std::atomic<size_t> next{0};
+    for (int k = 0; k < nth; k++)
+      th.emplace_back([&]() {
+        for (size_t j = next++; j < subs.size(); j = next++) (void)build_xnodes(t, subs[j].lo, subs[j].cnt, subs[j].depth);
+      });
+    struct Top {
+      static int32_t build(pcgx_kdtree *t, int64_t lo, int64_t cnt, int depth, int cut) {
+        if (cnt <= 0) return -1;
+        const int64_t half = cnt / 2, mid = lo + half;
+        if (depth == cut) return (int32_t)mid;  // (a subtree's root: built by the threads)
+        pcgx_kdtree::XNode &n = t->xnodes[(size_t)mid];
+        n.id = t->inorder[(size_t)mid];
+        n.dim = depth % 3;
+        n.c0 = build(t, lo, half, depth + 1, cut);
+        n.c1 = build(t, mid + 1, cnt - half - 1, depth + 1, cut);
+        return (int32_t)mid;
+      }
+    };
+    t->xroot = Top::build(t, 0, t->n, 0, cut);
+    for (auto &x : th) x.join();
+  } else {
+    t->xroot = build_xnodes(t, 0, t->n, 0);
+  }
   t->x_init = true;
   t->x_dirty = true;
+}
+
+// DeletePoint(ids[0]), DeletePoint(ids[1]), ... (kdtree.go:322-332) with the work shared out over the host's threads
+// where the ORDER allows it.  A deletion touches the subtree below the node that holds the point (findMinimumImpl /
+// deleteNodeImpl recurse downwards, kdtree.go:224-320) and only reads the nodes above it; points only ever move UP
+// (a node takes over the minimum of a subtree below it).  So, with the tree cut at depth 6: deletions of points that sit
+// in different depth-6 subtrees commute -- each subtree's deletions run in call order on one thread, the subtrees side
+// by side -- and a deletion of a point that sits in one of the 63 nodes above the cut (a few per 100k) is carried out
+// alone, in its place in the order, between two such batches.  Which subtree a point sits in: the one its ORIGINAL
+// node lies in (in-order index ranges: nodes never move), unless it has been pulled up above the cut (the 63 ids there
+// are looked up).  Caller holds t->mu.
+void xtree_delete_batch(pcgx_kdtree *t, const int64_t *ids, int64_t m) {
+  xtree_init(t);
+  t->x_dirty = true;
+  const int nth = host_threads();
+  static const int64_t min_batch = getenv("PCGX_DELETE_PARALLEL_MIN") ? atoll(getenv("PCGX_DELETE_PARALLEL_MIN")) : 4096;
+  if (nth < 2 || m < min_batch || t->n < (1 << 16)) {
+    for (int64_t i = 0; i < m; i++) t->xroot = delete_node(t, t->xroot, (int32_t)ids[i]);
+    return;
+  }
+  const int cut = 6;
+  std::vector<SubTree> subs;
+  std::vector<int32_t> top;
+  collect_subtrees(0, t->n, 0, cut, subs, &top);  // (in-order: ascending lo)
+  static_assert((1 << 6) < 255, "a subtree's number fits a byte");
+  if (t->xsub.empty()) {  // the subtree of every id's original node
+    t->xsub.assign((size_t)t->n, 255);
+    std::atomic<size_t> next{0};
+    auto fill = [&]() {
+      for (size_t j = next++; j < subs.size(); j = next++)
+        for (int64_t k = subs[j].lo; k < subs[j].lo + subs[j].cnt; k++) t->xsub[(size_t)t->inorder[(size_t)k]] = (uint8_t)j;
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < nth; k++) th.emplace_back(fill);
+    fill();
+    for (auto &x : th) x.join();
+  }
+  std::vector<uint8_t> is_above((size_t)t->n, 0);  // the ids that sit above the cut now
+  auto top_ids = [&]() {  // the ids that sit above the cut NOW (nodes still attached)
+    std::vector<int32_t> v;
+    struct W {
+      static void walk(const pcgx_kdtree *t, int32_t n, int depth, int cut, std::vector<int32_t> &v) {
+        if (n < 0 || depth >= cut) return;
+        v.push_back(t->xnodes[(size_t)n].id);
+        walk(t, t->xnodes[(size_t)n].c0, depth + 1, cut, v);
+        walk(t, t->xnodes[(size_t)n].c1, depth + 1, cut, v);
+      }
+    };
+    W::walk(t, t->xroot, 0, cut, v);
+    std::sort(v.begin(), v.end());
+    return v;
+  };
+  std::vector<int32_t> above = top_ids();
+  for (int32_t id : above) is_above[(size_t)id] = 1;
+  std::vector<std::vector<int32_t>> bucket(subs.size());
+  for (auto &b : bucket) b.reserve((size_t)(m / (int64_t)subs.size() + m / (4 * (int64_t)subs.size()) + 16));
+  auto flush = [&]() {
+    std::vector<size_t> work;
+    for (size_t j = 0; j < subs.size(); j++)
+      if (!bucket[j].empty()) work.push_back(j);
+    if (work.empty()) return;
+    std::vector<int32_t> new_root(subs.size());
+    std::atomic<size_t> next{0};
+    auto run = [&]() {
+      for (size_t w = next++; w < work.size(); w = next++) {
+        const size_t j = work[w];
+        int32_t r = subs[j].root;
+        for (int32_t pid : bucket[j]) {
+          if (r < 0) break;  // (the subtree is gone: nothing left to find)
+          r = delete_node(t, r, pid);
+        }
+        new_root[j] = r;
+      }
+    };
+    std::vector<std::thread> th;
+    const int use = (int)std::min<size_t>((size_t)nth, work.size());
+    for (int k = 1; k < use; k++) th.emplace_back(run);
+    run();
+    for (auto &x : th) x.join();
+    // a subtree that went empty: its parent's link (deleteNodeImpl's `n.children[k] = child` with child == nil)
+    for (size_t j : work) {
+      if (new_root[j] >= 0) continue;
+      const int32_t r = subs[j].root;
+      if (t->xroot == r) t->xroot = -1;
+      for (int32_t p : top) {
+        pcgx_kdtree::XNode &nd = t->xnodes[(size_t)p];
+        if (nd.c0 == r) nd.c0 = -1;
+        if (nd.c1 == r) nd.c1 = -1;
+      }
+    }
+    for (size_t j : work) bucket[j].clear();
+  };
+  for (int64_t i = 0; i < m; i++) {
+    const int32_t pid = (int32_t)ids[i];
+    if (is_above[(size_t)pid]) {
+      flush();
+      t->xroot = delete_node(t, t->xroot, pid);  // (reads and writes across the cut: alone)
+      for (int32_t id : above) is_above[(size_t)id] = 0;
+      above = top_ids();
+      for (int32_t id : above) is_above[(size_t)id] = 1;
+      continue;
+    }
+    // the subtree the point's original node lies in (255: an original node above the cut whose point has been
+    // deleted already -- nothing to find)
+    const uint8_t j = t->xsub[(size_t)pid];
+    if (j != 255) bucket[j].push_back(pid);
+  }
+  flush();
 }
 
 namespace {
@@ -216,8 +398,10 @@ int xtree_max_depth(const pcgx_kdtree *t) { return depth_rec(t, t->xroot, 0); }
 void xtree_free(pcgx_kdtree *t) {
   dev_cache_free(t->d_xpts);
   dev_cache_free(t->d_xlinks);
+  dev_cache_free(t->d_xsrc);
   t->d_xpts = nullptr;
   t->d_xlinks = nullptr;
+  t->d_xsrc = nullptr;
 }
 
 namespace pcgx {
@@ -236,17 +420,21 @@ pcgx_status xtree_view(const pcgx_kdtree *tc, XTreeView *xv, hipStream_t st) {
   if (t->x_dirty) {
     // uploaded in place: walks other streams still run on the previous copy must have finished
     dev_cache_quiesce();
-    std::vector<float4> pts(n);
-    std::vector<int4> links(n);
-    for (size_t k = 0; k < n; k++) {
-      const pcgx_kdtree::XNode &nd = t->xnodes[k];
-      pts[k] = make_float4(t->points[3 * (size_t)nd.id], t->points[3 * (size_t)nd.id + 1], t->points[3 * (size_t)nd.id + 2],
-                           __builtin_bit_cast(float, nd.id));
-      links[k] = make_int4(nd.c0, nd.c1, nd.dim, 0);
+    static_assert(sizeof(pcgx_kdtree::XNode) == sizeof(int4), "the mirror's nodes are uploaded as they are");
+    if (!t->d_xsrc) {  // the cloud's points by id, once per handle
+      PCGX_HIP_TRY(dev_cache_alloc((void **)&t->d_xsrc, n * 3 * sizeof(float)));
+      PCGX_TRY(staged_upload(t->d_xsrc, t->points.data(), n * 3 * sizeof(float), st));
     }
-    PCGX_HIP_TRY(hipMemcpyAsync(t->d_xpts, pts.data(), n * sizeof(float4), hipMemcpyHostToDevice, st));
-    PCGX_HIP_TRY(hipMemcpyAsync(t->d_xlinks, links.data(), n * sizeof(int4), hipMemcpyHostToDevice, st));
-    PCGX_HIP_TRY(hipStreamSynchronize(st));  // host temporaries
+    int4 *d_raw = nullptr;
+    PCGX_HIP_TRY(dev_cache_alloc((void **)&d_raw, n * sizeof(int4)));
+    pcgx_status rc = staged_upload(d_raw, t->xnodes.data(), n * sizeof(int4), st);
+    if (rc == PCGX_OK) {
+      hipLaunchKernelGGL(xtree_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const int4 *)d_raw,
+                         (const float *)t->d_xsrc, (int64_t)n, t->d_xpts, (int4 *)t->d_xlinks);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(PCGX_E_HIP, "explicit tree: expansion failed");
+    }
+    dev_cache_free(d_raw);
+    PCGX_TRY(rc);
     t->x_dirty = false;
   }
   xv->pts = t->d_xpts;

@@ -231,6 +231,7 @@ pcgx_status build_tree_device(const float *d_xyz, int64_t n, int32_t depth, uint
 pcgx_status resolve_tree(const pcgx_kdtree *t, const pcgx_kdtree **active, bool *empty);
 // knn_explicit.hip: the reference's patched tree of a handle that has seen DeletePoint
 void xtree_delete(pcgx_kdtree *t, int64_t pid);  // caller holds t->mu
+void xtree_delete_batch(pcgx_kdtree *t, const int64_t *ids, int64_t m);  // ... in call order, on the host's threads where the order allows
 void xtree_free(pcgx_kdtree *t);
 int xtree_max_depth(const pcgx_kdtree *t);  // caller holds t->mu
 pcgx_status xtree_launch_nearest(const pcgx_kdtree *t, const float *d_q, const int32_t *d_perm, int64_t nq,
@@ -430,11 +431,13 @@ struct pcgx_kdtree {
   struct XNode {
     int32_t id, c0, c1, dim;
   };
-  std::vector<XNode> xnodes;
+  pcgx::RawVector<XNode> xnodes;   // (no zero fill: every node is written by the build)
   int32_t xroot = -1;
   bool x_init = false, x_dirty = false;
   float4 *d_xpts = nullptr;
   void *d_xlinks = nullptr;
+  float *d_xsrc = nullptr;         // the cloud's points by id on the device (the patched tree's copy is put together there)
+  std::vector<uint8_t> xsub;       // id -> the depth-6 subtree its ORIGINAL node lies in, 255: above the cut (batched deletions)
   // uniform grid of the certified-nearest fast path (knn_grid.h); grid_ok false: tree walk only
   float4 *d_gpts = nullptr;
   uint32_t *d_gstart = nullptr;

@@ -265,3 +265,47 @@ def test_many_delete_query_cycles_with_an_open_session():
     assert early.read_sums()[9] == 500
     early.close()
     sess.close()
+
+
+def _dump(t):
+    import ctypes as C
+    from pcgol_amd import _lib as L
+    n = C.c_int64()
+    L.check(L.lib().pcgx_kdtree_dump(t._h, None, 0, C.byref(n)))
+    d = np.empty((max(n.value, 1), 4), np.int64)
+    L.check(L.lib().pcgx_kdtree_dump(t._h, L.ptr(d), n.value, C.byref(n)))
+    return d[: n.value]
+
+
+@pytest.mark.parametrize("threads", ["1", "8"])
+def test_batched_deletions_on_host_threads_leave_the_reference_tree(threads, monkeypatch):
+    """A batch of deletions is carried out in call order -- on several host threads where the order allows it
+    (csrc/knn_explicit.hip, xtree_delete_batch: deletions below different depth-6 nodes commute, a deletion above
+    the cut runs alone in its place).  The batch holds the root, nodes above the cut, duplicates and ids deleted
+    before; the tree afterwards is the oracle's after the same DeletePoint calls one by one, node for node (pre-order
+    dump: id, dim, children), and so are Nearest's answers."""
+    monkeypatch.setenv("PCGX_HOST_THREADS", threads)
+    monkeypatch.setenv("PCGX_DELETE_PARALLEL_MIN", "64")
+    n = 150_000
+    pts = synth.uniform_cloud(n, 7.0, 23)
+    t, o = kdtree.New(pts), O.KDTree(pts)
+    rng = np.random.default_rng(29)
+    d0 = _dump(t)
+    assert np.array_equal(d0, o.dump())
+    # the ids of the first 40 nodes in pre-order (the root, and nodes of the levels above the cut) go into the batches
+    top = d0[:40, 0]
+    first = np.concatenate([rng.permutation(n)[:20_000], top[:10], rng.integers(0, n, 500)])
+    rng.shuffle(first)
+    second = np.concatenate([rng.permutation(n)[:15_000], top[10:], first[:300]])
+    rng.shuffle(second)
+    for batch in (first, second):
+        t.DeletePoints(batch)
+        for i in batch:
+            o.delete_point(int(i))
+        assert np.array_equal(_dump(t), o.dump())
+    gone = np.unique(np.concatenate([first, second]))
+    assert t.LiveCount() == n - len(gone)
+    q = synth.uniform_cloud(20_000, 7.0, 31)
+    gi, gd = t.NearestBatch(q, 0.5)
+    oi, od = o.nearest_batch(q, 0.5)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
