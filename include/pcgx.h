@@ -468,9 +468,8 @@ PCGX_API pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream);
  * bounded (10 s) and raises it too.
  * One process, several GPUs: pcgx_icp_fit_multi (a host thread per device slot, pcgx_init_devices; the ring in pinned
  * host memory, or the exchange in host memory, sums in rank order) -- the Go shim's FitMulti needs no second
- * process.  (Slots that share ONE HIP device share its hardware queues, and kernels that wait for one another must
- * not queue up behind each other: there the ring form is taken only with PCGX_SHARD_RING=force, under a
- * GPU_MAX_HW_QUEUES that gives every slot its queue -- the tests' configuration.) */
+ * process.  (Kernels that wait for one another must not queue up behind each other in one hardware queue: where slots
+ * share ONE HIP device -- a test box -- pcgx_init_devices gives every slot's stream a hardware queue of its own.) */
 typedef struct pcgx_comm pcgx_comm;
 typedef struct { char internal[128]; } pcgx_comm_id;   /* == ncclUniqueId */
 typedef int32_t (*pcgx_allreduce_fn)(double *host_buf, int32_t count, void *user);

@@ -119,6 +119,7 @@ constexpr int kMaxSlots = 16;
 Global g_slots[kMaxSlots];
 int g_slot_device[kMaxSlots] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};  // -1: pcgx_init's choice
 int g_num_slots = 1;
+bool g_private_queues = false;  // pcgx_init_devices found several slots on one device
 thread_local int tl_slot = 0;
 Global &glob() { return g_slots[tl_slot]; }
 thread_local Context *tl_ctx = nullptr;
@@ -126,20 +127,6 @@ thread_local int tl_depth = 0;
 }  // namespace
 
 int current_slot() { return tl_slot; }
-
-// Do two of the first n device slots run on the same HIP device (a one-GPU test box standing in for a node)?  Kernels of
-// such slots share the device's few hardware queues, so a kernel of one slot may sit in a queue BEHIND a kernel of
-// another that waits for it: the ring form of the sharded sums, whose kernels wait for one another, then needs a
-// hardware queue per slot (GPU_MAX_HW_QUEUES) -- pcgx_icp_fit_multi takes it only when told to (PCGX_SHARD_RING=force).
-bool slots_share_a_device(int n) {
-  for (int a = 0; a < n && a < kMaxSlots; a++)
-    for (int b = a + 1; b < n && b < kMaxSlots; b++) {
-      const int da = g_slot_device[a] >= 0 ? g_slot_device[a] : (g_slots[a].slots[0].ready ? g_slots[a].slots[0].device : a);
-      const int db = g_slot_device[b] >= 0 ? g_slot_device[b] : (g_slots[b].slots[0].ready ? g_slots[b].slots[0].device : b);
-      if (da == db) return true;
-    }
-  return false;
-}
 
 Context &ctx() { return tl_ctx ? *tl_ctx : glob().slots[0]; }
 
@@ -203,7 +190,21 @@ static pcgx_status init_device(int device) {
   for (int k = 0; k <= kPoolSlots; k++) {
     Context &s = g.slots[k];
     s.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    PCGX_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    if (k == 0 && g_private_queues) {
+      // Slots that share ONE device (pcgx_init_devices on a test box): the library's own stream of every slot gets a
+      // hardware queue to itself.  HIP hands its few hardware queues to streams as they have work, so two slots'
+      // streams may land in one queue -- and the ring form of the sharded sums has slot A's kernel wait for slot B's:
+      // queued behind it, B's never starts (measured: a Fit over eight slots stood still until A's wait ran out of
+      // time).  A stream made with a CU mask owns its queue; the mask names every CU.
+      uint32_t mask[32];
+      for (auto &m : mask) m = 0xffffffffu;
+      const uint32_t words = (uint32_t)((s.num_cu + 31) / 32);
+      if (hipExtStreamCreateWithCUMask(&s.stream, words < 32u ? words : 32u, mask) != hipSuccess) {
+        (void)hipGetLastError();
+        s.stream = nullptr;
+      }
+    }
+    if (!s.stream) PCGX_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     void *mb = nullptr;
     if (hipHostMalloc(&mb, 256, hipHostMallocDefault) == hipSuccess) {  // (not required: without it results are copied and waited for)
       memset(mb, 0, 256);
@@ -376,6 +377,9 @@ extern "C" pcgx_status pcgx_init_devices(int32_t n, const int32_t *device_ids) {
     if (g_slots[k].slots[0].ready && g_slots[k].slots[0].device != d)
       return fail(PCGX_E_INVALID, "pcgx_init_devices: slot %d already works on device %d", k, g_slots[k].slots[0].device);
   }
+  for (int a = 0; a < n; a++)
+    for (int b = a + 1; b < n; b++)
+      if ((device_ids ? device_ids[a] : a) == (device_ids ? device_ids[b] : b)) g_private_queues = true;
   const int keep = tl_slot;
   pcgx_status rc = PCGX_OK;
   for (int k = 0; k < n && rc == PCGX_OK; k++) {

@@ -1331,13 +1331,15 @@ extern "C" pcgx_status pcgx_icp_fit_multi(int32_t n, const pcgx_kdtree *const *b
   unsigned long long *ring_block = nullptr;
   const RingLayout RL{n};
   {
-    // (slots that share one HIP device -- a one-GPU test box -- share its hardware queues: kernels that wait for one
-    // another may then queue up behind each other; the ring only when told that there is a queue per slot)
+    // (slots that share one HIP device -- a one-GPU test box -- have a hardware queue each for this: pcgx_init_devices)
     const char *off = getenv("PCGX_SHARD_RING");
-    const bool forced = off && strcmp(off, "force") == 0;
-    if (n > 1 && n <= 64 && (forced || (!(off && atoi(off) == 0) && !slots_share_a_device(n))) && ensure_init() == PCGX_OK) {
+    if (n > 1 && n <= 64 && !(off && off[0] == '0') && ensure_init() == PCGX_OK) {
       const size_t bytes = (size_t)n * RL.words() * sizeof(unsigned long long);
-      if (hipHostMalloc((void **)&ring_block, bytes, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) memset(ring_block, 0, bytes);
+      // (Coherent by name: fine-grained memory the GPUs never cache.  Left to the runtime's default the block may be
+      // coarse-grained -- a walker that polled a word before it arrived then kept reading the stale line out of its L2:
+      // one Fit in a fresh process out of a few ended in the walk's time-out.)
+      if (hipHostMalloc((void **)&ring_block, bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess)
+        memset(ring_block, 0, bytes);
       else {
         (void)hipGetLastError();
         ring_block = nullptr;
@@ -1380,14 +1382,23 @@ extern "C" pcgx_status pcgx_icp_fit_multi(int32_t n, const pcgx_kdtree *const *b
     });
   }
   for (auto &t : th) t.join();
-  if (ring_block) (void)hipHostFree(ring_block);
+  unsigned long long ring_abort_word = 0ull;  // (what broke the ring, if anything did: reason | step << 32)
+  if (ring_block) {
+    ring_abort_word = ring_block[RL.abort()];
+    (void)hipHostFree(ring_block);
+  }
   // the rank that failed by itself speaks first; PCGX_E_RCCL ("another rank ...") only if nobody has a better story
   int pick = -1;
   for (int r = 0; r < n && pick < 0; r++)
     if (rc[(size_t)r] != PCGX_OK && rc[(size_t)r] != PCGX_E_RCCL) pick = r;
   for (int r = 0; r < n && pick < 0; r++)
     if (rc[(size_t)r] != PCGX_OK) pick = r;
-  if (pick >= 0) return fail(rc[(size_t)pick], "pcgx_icp_fit_multi: slot %d: %s", pick, msg[(size_t)pick].c_str());
+  if (pick >= 0) {
+    if (ring_abort_word)
+      return fail(rc[(size_t)pick], "pcgx_icp_fit_multi: slot %d: %s (the ring's abort word: reason 0x%x in step %u)", pick,
+                  msg[(size_t)pick].c_str(), (unsigned)(ring_abort_word & 0xffffffffu), (unsigned)(ring_abort_word >> 32));
+    return fail(rc[(size_t)pick], "pcgx_icp_fit_multi: slot %d: %s", pick, msg[(size_t)pick].c_str());
+  }
   memcpy(trans16, tr[0].data(), 16 * sizeof(float));
   if (stat) *stat = stv[0];
   return PCGX_OK;
@@ -1415,6 +1426,9 @@ extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream
                 (long long)h.ev.num_pairs, s->kp.min_pairs, h.num_iteration);
   if (h.status == PCGX_E_SINGULAR)
     return fail(PCGX_E_SINGULAR, "normal equations are not positive definite at iteration %d", h.num_iteration);
+  if (h.status == PCGX_E_RCCL)  // (a sharded Fit: strict_finish_kernel / the ring's abort word, strict.hip)
+    return fail(PCGX_E_RCCL, "the sharded Fit ended after %d iterations: another rank could not go on, or a wait for another rank's "
+                             "state ran out of time", h.num_iteration);
   return PCGX_OK;
 }
 

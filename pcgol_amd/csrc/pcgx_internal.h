@@ -140,7 +140,6 @@ struct Context {
   unsigned int *tickets = nullptr;
 };
 Context &ctx();  // the calling thread's current context (the library's outside any call)
-bool slots_share_a_device(int n);  // (a one-GPU box standing in for a node: see core.hip)
 int current_slot();  // the calling thread's device slot (pcgx_set_device; 0 unless a process drives several GPUs)
 pcgx_status ensure_init();
 // Scope of one ABI call: binds the thread to a context (pooled: any free one of the pool, waiting for

@@ -1470,14 +1470,14 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
   // (a later chunk's walker: the state the chunk before it ended in, below; the ring form: what the rank before this
   // one sends, row_start() below)
   uint32_t s = W.start_bits ? (uint32_t)rfl((int)W.start_bits[row]) : f2u(0.0f);
-  int ring_rc = 0;  // walker: 1 = the ring was aborted, 2 = a wait ran out of time (the Fit ends here, on every rank)
   // the state the row starts in on this rank: 0.0f (evaluator.go:122), or where the rank before this one ended it
+  int ring_rc = 0;  // walker: 1 = the ring was aborted, 2 = a wait ran out of time (the Fit ends here, on every rank)
   auto row_start = [&]() -> uint32_t {
     if (!W.ring || W.rank == 0) return W.start_bits ? (uint32_t)rfl((int)W.start_bits[row]) : f2u(0.0f);
     const RingLayout RL{W.world};
     uint32_t v = 0u;
     ring_rc = ring_wait(W, RL.start(row), v, kRingWalkTicks);
-    if (ring_rc == 2 && lane == 0) ring_raise_abort(W, 2u);  // (nobody else needs to wait that long)
+    if (ring_rc == 2 && lane == 0) ring_raise_abort(W, 0x100u | (uint32_t)row);  // (nobody else needs to wait that long)
     return (uint32_t)rfl((int)v);
   };
   // walker: counters of the whole row, written once behind the last chunk (an atomic in flight holds up the
@@ -2210,7 +2210,7 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     }
     if (ring_rc != 0) {  // uniform: the ring is broken -- this rank's Fit ends here, like everybody's
       if (lane == 0) {
-        if (ring_rc == 2) ring_raise_abort(W, 2u);
+        if (ring_rc == 2) ring_raise_abort(W, 0x200u | (uint32_t)row);
         state->status = PCGX_E_RCCL;
         state->done = 1;
       }

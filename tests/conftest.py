@@ -10,10 +10,6 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# tests/test_gpu_multi.py stands eight device slots on the ONE GPU of the test box, and the ring form of the sharded sums
-# lets their kernels wait for one another on the device: every slot needs a hardware queue of its own there (HIP's
-# default is four per device, shared round robin by all streams).  Read by the HIP runtime when it starts.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 
 def pytest_configure(config):

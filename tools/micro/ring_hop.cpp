@@ -60,7 +60,7 @@ int main() {
   long long *d_ticks;
   CHECK(hipMalloc((void **)&d_ticks, 8));
   unsigned long long *h;  // pinned host memory, two words a cache line apart
-  CHECK(hipHostMalloc((void **)&h, 4096, hipHostMallocPortable | hipHostMallocMapped));
+  CHECK(hipHostMalloc((void **)&h, 4096, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
   run<true, 1>("pinned host memory, system scope", h, h + 64, d_ticks, s0, s1);
   run<true, 8>("pinned host memory, system scope", h, h + 64, d_ticks, s0, s1);
   run<true, 32>("pinned host memory, system scope", h, h + 64, d_ticks, s0, s1);
