@@ -206,8 +206,8 @@ static pcgx_status init_device(int device) {
     }
     if (!s.stream) PCGX_HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     void *mb = nullptr;
-    if (hipHostMalloc(&mb, 256, hipHostMallocDefault) == hipSuccess) {  // (not required: without it results are copied and waited for)
-      memset(mb, 0, 256);
+    if (hipHostMalloc(&mb, kMailboxBytes, hipHostMallocDefault) == hipSuccess) {  // (not required: without it results are copied and waited for)
+      memset(mb, 0, kMailboxBytes);
       s.mailbox = (volatile uint32_t *)mb;
     } else {
       (void)hipGetLastError();

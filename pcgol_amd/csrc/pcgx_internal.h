@@ -289,6 +289,10 @@ RadixFirstHist radix_first_hist(int64_t n, void *workspace);
 // later slice of a cloud whose min / max are folded over ranks
 pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
                           hipStream_t st, bool sticky_first = true);
+// a few result words of a call on the host: through the context's mailbox where there is one (a one-wave kernel behind
+// the call's kernels, the host polls; the stream is not synchronised), else copy + wait.  bytes: a multiple of 4
+constexpr size_t kMailboxBytes = 512;
+pcgx_status read_back_small(const void *d_src, size_t bytes, void *host_dst, hipStream_t st);
 // the same, and the six floats on the host (through the context's mailbox; the stream is not synchronised)
 pcgx_status minmax_to_host(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6, float out6[6],
                            hipStream_t st, bool sticky_first = true);

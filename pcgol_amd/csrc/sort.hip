@@ -16,7 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "pcgx_internal.h"
+#include "voxel_key.h"
 
 namespace pcgx {
 
@@ -334,7 +334,15 @@ struct MinMaxTail {
   float *out6;
   volatile uint32_t *mailbox;
   uint32_t seq;
+  VoxelPlanHook hook;  // the voxel filter's plan, made right behind the six floats (voxel_key.h); hook.dp == nullptr: none
 };
+// (a slice per workgroup of the words the filter wants cleared: 16 bytes per thread and round)
+__device__ __forceinline__ void minmax_clear_slice(const MinMaxTail &T) {
+  if (T.hook.zero == nullptr) return;
+  const uint32_t quads = T.hook.zero_words >> 2, per = (quads + gridDim.x - 1u) / gridDim.x;
+  const uint32_t q0 = blockIdx.x * per, q1 = min(q0 + per, quads);
+  for (uint32_t q = q0 + threadIdx.x; q < q1; q += blockDim.x) reinterpret_cast<uint4 *>(T.hook.zero)[q] = make_uint4(0u, 0u, 0u, 0u);
+}
 __device__ __forceinline__ void minmax_block_fold(MinMaxAcc &a, const MinMaxTail &T) {
   __shared__ MinMaxAcc s_acc[4];
   __shared__ unsigned int s_last;
@@ -396,6 +404,10 @@ __device__ __forceinline__ void minmax_block_fold(MinMaxAcc &a, const MinMaxTail
     T.out6[k] = f.mn[k];
     T.out6[3 + k] = f.mx[k];
   }
+  if (T.hook.dp) {
+    const float mm6[6] = {f.mn[0], f.mn[1], f.mn[2], f.mx[0], f.mx[1], f.mx[2]};
+    voxel_plan_on_device(mm6, T.hook);
+  }
   if (T.mailbox) {  // the host waits for these: straight into its (pinned) memory, the sequence word last
     for (int k = 0; k < 3; k++) {
       T.mailbox[1 + k] = __float_as_uint(f.mn[k]);
@@ -410,6 +422,7 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__re
                                                              int32_t stride, int32_t off, MinMaxTail T) {
   MinMaxAcc a;
   minmax_init(a);
+  minmax_clear_slice(T);
   // four independent loads in flight per thread
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * step) {
@@ -444,6 +457,7 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__re
 __global__ __launch_bounds__(256) void minmax_partial_packed_kernel(const float4 *__restrict__ data, int64_t n, MinMaxTail T) {
   MinMaxAcc a;
   minmax_init(a);
+  minmax_clear_slice(T);
   const int64_t groups = n >> 2;  // whole groups of 4 points; the tail is handled by one thread below
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
   for (int64_t g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < groups; g0 += 2 * step) {
@@ -486,7 +500,8 @@ __global__ __launch_bounds__(256) void minmax_partial_packed_kernel(const float4
 }
 
 static pcgx_status launch_minmax_impl(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
-                                      hipStream_t st, bool sticky_first, volatile uint32_t *mailbox, uint32_t seq) {
+                                      hipStream_t st, bool sticky_first, volatile uint32_t *mailbox, uint32_t seq,
+                                      const VoxelPlanHook *hook = nullptr) {
   if (n <= 0) return fail(PCGX_E_NO_POINT, "no point");
   int blocks = (int)((n + 256 * 8 - 1) / (256 * 8));
   if (blocks > 1024) blocks = 1024;
@@ -500,6 +515,8 @@ static pcgx_status launch_minmax_impl(const void *d_data, int64_t n, int32_t str
   T.out6 = d_out6;
   T.mailbox = mailbox;
   T.seq = seq;
+  memset(&T.hook, 0, sizeof T.hook);
+  if (hook) T.hook = *hook;
   if (stride == 12 && off == 0 && (reinterpret_cast<uintptr_t>(d_data) & 15) == 0)
     hipLaunchKernelGGL(minmax_partial_packed_kernel, dim3(blocks), dim3(256), 0, st, (const float4 *)d_data, n, T);
   else
@@ -511,6 +528,48 @@ static pcgx_status launch_minmax_impl(const void *d_data, int64_t n, int32_t str
 pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
                           hipStream_t st, bool sticky_first) {
   return launch_minmax_impl(d_data, n, stride, off, d_out6, st, sticky_first, nullptr, 0u);
+}
+
+pcgx_status launch_minmax_with_plan(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6,
+                                    const VoxelPlanHook &hook, hipStream_t st) {
+  return launch_minmax_impl(d_data, n, stride, off, d_out6, st, true, nullptr, 0u, &hook);
+}
+
+// A call's few result words on the host without a copy command and without waiting on the stream: a one-wave kernel
+// behind the call's last kernel stores them into the context's pinned mailbox, the sequence word last, and the host
+// polls that word.  (hipMemcpyAsync into pageable memory + hipStreamSynchronize: a staging copy, a blit kernel and two
+// waits -- 20 us behind the voxel filter's last kernel.)  The kernel boundary in front of the one wave is what makes
+// the call's output complete when the word arrives.
+__global__ __launch_bounds__(64) void read_back_kernel(const uint32_t *__restrict__ src, int words, volatile uint32_t *mailbox, uint32_t seq) {
+  for (int i = threadIdx.x; i < words; i += 64) mailbox[2 + i] = src[i];
+  __threadfence_system();
+  __builtin_amdgcn_s_barrier();  // (one wave: every lane's stores are out before lane 0's)
+  if (threadIdx.x == 0) mailbox[0] = seq;
+}
+
+pcgx_status read_back_small(const void *d_src, size_t bytes, void *host_dst, hipStream_t st) {
+  Context &c = ctx();
+  volatile uint32_t *mb = c.mailbox;
+  if (mb && bytes % 4 == 0 && bytes + 8 <= kMailboxBytes) {
+    const uint32_t seq = ++c.mailbox_seq ? c.mailbox_seq : ++c.mailbox_seq;
+    hipLaunchKernelGGL(read_back_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)d_src, (int)(bytes / 4), mb, seq);
+    PCGX_HIP_TRY(hipGetLastError());
+    for (long spins = 0;; spins++) {
+      if (__atomic_load_n((const uint32_t *)mb, __ATOMIC_ACQUIRE) == seq) break;
+      if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(st) != hipErrorNotReady) {  // finished (or failed) without the word?
+        if (__atomic_load_n((const uint32_t *)mb, __ATOMIC_ACQUIRE) == seq) break;
+        PCGX_HIP_TRY(hipStreamSynchronize(st));
+        if (__atomic_load_n((const uint32_t *)mb, __ATOMIC_ACQUIRE) == seq) break;
+        return fail(PCGX_E_HIP, "the result words did not arrive in the mailbox");
+      }
+      __builtin_ia32_pause();
+    }
+    memcpy(host_dst, (const void *)(mb + 2), bytes);
+    return PCGX_OK;
+  }
+  PCGX_HIP_TRY(hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  return PCGX_OK;
 }
 
 pcgx_status minmax_to_host(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6, float out6[6],

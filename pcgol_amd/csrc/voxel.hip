@@ -338,56 +338,10 @@ __global__ __launch_bounds__(256) void vx_mine_compact_kernel(
   }
 }
 
-static int bits_for(int64_t count) {  // bits needed for values in [0, count)
-  int b = 0;
-  while (b < 63 && ((int64_t)1 << b) < count) b++;
-  return b;
-}
+static int bits_for(int64_t count) { return voxel_bits_for(count); }
 
-// Host-side grid set-up in the reference's float32 arithmetic (voxelgrid.go:45-62,137-138).
-static pcgx_status make_params(const float mm6[6], const float leaf[3], const int32_t chunk[3],
-                               VoxelParams &vp) {
-  memset(&vp, 0, sizeof vp);
-  const float *vmin = mm6, *vmax = mm6 + 3;
-  for (int k = 0; k < 3; k++) {
-    vp.vmin[k] = vmin[k];
-    vp.leaf[k] = leaf[k];
-  }
-  float size[3];
-  if ((int64_t)chunk[0] * chunk[1] * chunk[2] == 0) {
-    for (int k = 0; k < 3; k++) size[k] = vmax[k];  // sic (voxelgrid.go:46)
-    vp.chunked = 0;
-    vp.nx = vp.ny = vp.n_chunks = 1;
-  } else {
-    float ext[3];
-    for (int k = 0; k < 3; k++) {
-      ext[k] = vmax[k] - vmin[k];
-      vp.cs[k] = leaf[k] * (float)chunk[k];
-    }
-    for (int k = 0; k < 3; k++)
-      if (vp.cs[k] > ext[k] + leaf[k]) vp.cs[k] = ext[k] + leaf[k];
-    vp.chunked = 1;
-    vp.nx = (int64_t)(ext[0] / vp.cs[0]) + 1;
-    vp.ny = (int64_t)(ext[1] / vp.cs[1]) + 1;
-    const int64_t nz = (int64_t)(ext[2] / vp.cs[2]) + 1;
-    if (vp.nx <= 0 || vp.ny <= 0 || nz <= 0 || (double)vp.nx * (double)vp.ny * (double)nz >= 4294967296.0)
-      return fail(PCGX_E_OUT_OF_RANGE, "voxel filter: chunk grid %lld x %lld x %lld is not addressable",
-                  (long long)vp.nx, (long long)vp.ny, (long long)nz);
-    vp.n_chunks = vp.nx * vp.ny * nz;
-    for (int k = 0; k < 3; k++) size[k] = vp.cs[k];
-  }
-  const int64_t xs = (int64_t)(size[0] / leaf[0]), ys = (int64_t)(size[1] / leaf[1]),
-                zs = (int64_t)(size[2] / leaf[2]);
-  const double nv = ((double)xs + 1) * ((double)ys + 1) * ((double)zs + 1);
-  if (xs < 0 || ys < 0 || zs < 0 || !(nv >= 1.0) || nv >= 4294967296.0)
-    return fail(PCGX_E_OUT_OF_RANGE,
-                "voxel filter: dense grid (%lld+1)(%lld+1)(%lld+1) is empty or exceeds 2^32 cells "
-                "(the reference would panic or need >128 GiB)",
-                (long long)xs, (long long)ys, (long long)zs);
-  vp.xs = xs;
-  vp.ys = ys;
-  vp.n_voxels = (xs + 1) * (ys + 1) * (zs + 1);
-  return PCGX_OK;
+static pcgx_status make_params(const float mm6[6], const float leaf[3], const int32_t chunk[3], VoxelParams &vp) {
+  return voxel_grid_params_or_fail(mm6, leaf, chunk, vp);
 }
 
 }  // namespace pcgx
@@ -423,7 +377,19 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
   PCGX_TRY(ar.alloc_n(6, &d_mm6));
   float mm6[6];
   if (world == 1) {
-    PCGX_TRY(minmax_to_host(d_data, n, stride, xyz_off, d_mm6, mm6, st));
+    // the points travel with their keys (voxel_bucket.hip) where the cloud allows it: no 12-byte gather per point, and
+    // min/max, the grid and every kernel behind them in one go, without the host in between
+    bool attempted = false, taken = false;
+    VoxelDevPlan dp;
+    PCGX_TRY(voxel_bucket_filter(d_data, n, stride, xyz_off, leaf, chunk, d_out, out_n, &attempted, &taken, &dp, st));
+    if (taken) return PCGX_OK;
+    if (attempted) {
+      memcpy(mm6, dp.mm6, sizeof mm6);
+      PCGX_TRY(ar.begin(st));  // (the attempt's temporaries are free again)
+      PCGX_TRY(ar.alloc_n(6, &d_mm6));
+    } else {
+      PCGX_TRY(minmax_to_host(d_data, n, stride, xyz_off, d_mm6, mm6, st));
+    }
   } else {
     // the slice's six floats travel as their bit patterns in slot `rank` of a vector of zeros: the
     // sum every rank receives holds all of them exactly (an all-gather out of the one collective the
@@ -478,39 +444,9 @@ static pcgx_status voxel_filter_core(pcgx_comm *comm, const void *d_data, int64_
   int64_t *d_total = nullptr;
   uint32_t *tile_count = nullptr;
   int ntiles = (int)((n + kSegTile - 1) / kSegTile);
-  bool two_level = vp.chunked && vp.n_chunks > 1;
-  int key_bits = bits_for(vp.n_voxels);
   const char *force_two = getenv("PCGX_VOXEL_TWO_SORTS");  // tests: keep the two-sort path covered
-  if (two_level && (double)vp.n_chunks * (double)vp.n_voxels <= 4294967296.0 && !(force_two && force_two[0] == '1')) {
-    // (chunk id, cell) in one 32-bit key, cid * n_voxels + cell -- dense: no unused values between the chunks' cell
-    // ranges, so the key is as short as it can be and the bucket path's buckets are evenly filled.  One stable sort
-    // gives the reference's output order (chunks ascending, cells ascending inside a chunk) without the second
-    // sort and its gathers
-    vp.combined = 1;
-    key_bits = bits_for(vp.n_chunks * vp.n_voxels);
-    two_level = false;
-  }
-  if (world == 1 && !two_level) {
-    // the points travel with their keys (voxel_bucket.hip) where the cloud allows it: no 12-byte gather per point
-    bool taken = false;
-    const uint64_t key_range = vp.combined ? (uint64_t)vp.n_chunks * (uint64_t)vp.n_voxels : (uint64_t)vp.n_voxels;
-    // how many keys can occur: not more than the cells the cloud's own extent spans (the non-chunked grid is sized by
-    // vMax, voxelgrid.go:46; a chunked grid's last chunks are partly empty, and every chunk seam splits a cell)
-    uint64_t key_population = vp.combined ? (uint64_t)vp.n_chunks * (uint64_t)vp.n_voxels : (uint64_t)vp.n_voxels;
-    {
-      double cells = 1.0;
-      const int64_t per_axis_chunks[3] = {vp.chunked ? vp.nx : 0, vp.chunked ? vp.ny : 0,
-                                          vp.chunked ? vp.n_chunks / (vp.nx * vp.ny) : 0};
-      for (int k = 0; k < 3; k++) {
-        const double ext = (double)mm6[3 + k] - (double)mm6[k];
-        cells *= (ext > 0.0 ? floor(ext / (double)leaf[k]) : 0.0) + 1.0 + (double)per_axis_chunks[k];
-      }
-      if (cells >= 1.0 && cells < (double)key_population) key_population = (uint64_t)cells;
-    }
-    PCGX_TRY(voxel_bucket_filter(d_data, n, stride, xyz_off, vp, key_bits, key_range, key_population, d_out, out_n, &taken, st));
-    if (taken) return PCGX_OK;
-    PCGX_TRY(ar.begin(st));  // (the attempt's temporaries are free again)
-  }
+  bool two_level = false;
+  const int key_bits = voxel_key_layout(vp, force_two && force_two[0] == '1', &two_level);
   PCGX_TRY(ar.alloc_n((size_t)n, &keys[0]));
   PCGX_TRY(ar.alloc_n((size_t)n, &keys[1]));
   PCGX_TRY(ar.alloc_n((size_t)n, &vals[0]));

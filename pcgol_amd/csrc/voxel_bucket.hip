@@ -32,32 +32,24 @@ namespace pcgx {
 
 constexpr int kVbThreads = 256, kVbItems = 8, kVbTile = kVbThreads * kVbItems;  // scatter tiles (36 KB of LDS: four per CU)
 constexpr int kVbWaves = kVbThreads / 64;
-constexpr int kVbMaxLowBits = 10;      // cells per bucket <= 1024
-constexpr int kVbMaxBucketBits = 16;   // two digits of <= 8 bits
-constexpr int kVbCap = 1280;           // points per bucket the bucket kernel holds in LDS (26 KB: six workgroups per CU -- a
-                                       // workgroup is a chain of short dependent phases, what hides them is the other workgroups)
 constexpr int kVbMaxCell = 255;        // points per cell it puts in order by itself
 constexpr int kVbFinalThreads = 256;
 constexpr long long kVbWaitTicks = 500000;  // 5 ms of s_memrealtime (100 MHz): a bucket that waits longer gives up, the radix path answers
 constexpr int kVbSampleEvery = 32;     // every 32nd point is counted per bucket before anything is moved
 
-struct VbPlan {
-  int32_t low_bits;      // s
-  int32_t nbuckets;
-  int32_t d_bits[2];     // digits of the bucket number, low digit first; d_bits[1] == 0: one pass
-  int32_t ntiles;
-  int32_t dbg;           // measurement aid (PCGX_VOXEL_BUCKET_DBG): 1 no wait for the earlier buckets, 2 no cell phase (wrong output)
-};
-
 // ---- keys, first tile histograms, a sample of the bucket populations ---------------------------------------------
 // (every kVbSampleEvery-th point is counted per bucket, with global atomics: a bucket that would hold more
-// than 1.5 LDS tiles by that estimate stops the attempt before anything is moved, vb_sample_check_kernel; the exact
+// than 1.5 LDS tiles by that estimate stops the attempt before anything is moved, vb_scan_rows_kernel; the exact
 // check is the bucket kernel's)
 __global__ __launch_bounds__(256) void vb_key_hist_kernel(const uint8_t *__restrict__ data, int64_t n, int32_t stride,
-                                                          int32_t off, VoxelParams vp, VbPlan plan,
+                                                          int32_t off, const VoxelDevPlan *__restrict__ dp,
                                                           uint32_t *__restrict__ key_out, uint32_t *__restrict__ block_hist,
-                                                          uint32_t *__restrict__ bucket_sample, int32_t *__restrict__ err) {
+                                                          uint32_t *__restrict__ bucket_sample, int32_t *__restrict__ err,
+                                                          const int32_t *__restrict__ flags) {
   __shared__ uint32_t dh[256];
+  if (*flags) return;  // uniform: not a call for this path
+  const VoxelParams vp = dp->vp;
+  const VbPlan plan = dp->plan;
   dh[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t m1 = (1u << plan.d_bits[0]) - 1u;
@@ -85,40 +77,32 @@ __global__ __launch_bounds__(256) void vb_key_hist_kernel(const uint8_t *__restr
   block_hist[(int64_t)threadIdx.x * plan.ntiles + blockIdx.x] = dh[threadIdx.x];
 }
 
-__global__ __launch_bounds__(256) void vb_sample_check_kernel(const uint32_t *__restrict__ bucket_sample, int nbuckets,
-                                                              int32_t *__restrict__ flags) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b < nbuckets && (uint64_t)bucket_sample[b] * kVbSampleEvery > (uint64_t)kVbCap * 3 / 2) atomicOr(flags, 1);
-}
-
-// where the buckets begin in the sorted arrays: start[b] = first position whose bucket is >= b; start[nbuckets] = n
-// (four consecutive keys per thread)
-__global__ __launch_bounds__(256) void vb_bounds_kernel(const uint32_t *__restrict__ keys, int64_t n, int low_bits, int nbuckets,
-                                                        uint32_t *__restrict__ start, const int32_t *__restrict__ flags) {
+// (measurement aid, PCGX_VOXEL_BUCKET_BOUNDS_KERNEL=1: the buckets' starts found in the sorted keys by a kernel of its
+// own instead of by the last scatter pass's atomics; four consecutive keys per thread)
+__global__ __launch_bounds__(256) void vb_bounds_kernel(const uint32_t *__restrict__ keys0, const uint32_t *__restrict__ keys1,
+                                                        int64_t n, const VoxelDevPlan *__restrict__ dp,
+                                                        uint32_t *__restrict__ inv_start, const int32_t *__restrict__ flags) {
   if (*flags) return;  // uniform
+  const int low_bits = dp->plan.low_bits;
+  const uint32_t *__restrict__ keys = dp->plan.d_bits[1] ? keys1 : keys0;  // (the last pass's)
   const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i0 >= n) return;
-  uint32_t k[4];
-  if (i0 + 3 < n) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(keys + i0);
-    k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
-  } else {
-    for (int q = 0; q < 4; q++) k[q] = i0 + q < n ? keys[i0 + q] : 0u;
-  }
-  int64_t bp = i0 > 0 ? (int64_t)(keys[i0 - 1] >> low_bits) : -1;
+  uint32_t bp = i0 > 0 ? keys[i0 - 1] >> low_bits : 0xffffffffu;
   for (int q = 0; q < 4 && i0 + q < n; q++) {
-    const int64_t bi = k[q] >> low_bits;
-    for (int64_t b = bp + 1; b <= bi; b++) start[b] = (uint32_t)(i0 + q);
+    const uint32_t bi = keys[i0 + q] >> low_bits;
+    if (bi != bp) inv_start[bi] = ~(uint32_t)(i0 + q);
     bp = bi;
-    if (i0 + q == n - 1)
-      for (int64_t b = bi + 1; b <= nbuckets; b++) start[b] = (uint32_t)n;
   }
 }
 
 // tile histograms of the second pass's digit, from the keys as the first pass left them
-__global__ __launch_bounds__(256) void vb_hist2_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift, uint32_t mask,
-                                                       uint32_t *__restrict__ block_hist, int ntiles) {
+__global__ __launch_bounds__(256) void vb_hist2_kernel(const uint32_t *__restrict__ keys, int64_t n,
+                                                       const VoxelDevPlan *__restrict__ dp, uint32_t *__restrict__ block_hist,
+                                                       int ntiles, const int32_t *__restrict__ flags) {
   __shared__ uint32_t dh[256];
+  if (*flags || dp->plan.d_bits[1] == 0) return;  // uniform
+  const int shift = dp->plan.low_bits + dp->plan.d_bits[0];
+  const uint32_t mask = (1u << dp->plan.d_bits[1]) - 1u;
   dh[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * kVbTile;
@@ -134,9 +118,19 @@ __global__ __launch_bounds__(256) void vb_hist2_kernel(const uint32_t *__restric
 // every digit's row of tile counts -> its exclusive prefix over the tiles, and the row's total (as rs_scan_rows_kernel,
 // sort.hip, with 1024 threads per row: 4882 tiles at C3 are five rounds instead of twenty)
 __global__ __launch_bounds__(1024) void vb_scan_rows_kernel(uint32_t *__restrict__ block_hist, int ntiles,
-                                                            uint32_t *__restrict__ totals) {
+                                                            uint32_t *__restrict__ totals, const VoxelDevPlan *__restrict__ dp,
+                                                            int pass, const uint32_t *__restrict__ bucket_sample,
+                                                            int32_t *__restrict__ flags) {
   __shared__ uint32_t wave_sum[16];
   __shared__ uint32_t carry_s;
+  __shared__ int32_t s_flags;  // (read once per workgroup: the sample's verdict below changes the word while others start)
+  if (threadIdx.x == 0) s_flags = *flags;
+  __syncthreads();
+  if (s_flags || (pass == 1 && dp->plan.d_bits[1] == 0)) return;  // uniform
+  if (bucket_sample) {  // (first pass: the sample's verdict rides along -- 256 x 1024 threads, at most 65536 buckets)
+    const int b = blockIdx.x * 1024 + threadIdx.x;
+    if (b < dp->plan.nbuckets && (uint64_t)bucket_sample[b] * kVbSampleEvery > (uint64_t)kVbCap * 3 / 2) atomicOr(flags, 1);
+  }
   uint32_t *row = block_hist + (int64_t)blockIdx.x * ntiles;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry_s = 0;
@@ -165,9 +159,10 @@ __global__ __launch_bounds__(1024) void vb_scan_rows_kernel(uint32_t *__restrict
 template <bool kFirst, bool kIdx>
 __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
     const uint8_t *__restrict__ data, int32_t stride, int32_t off, const float *__restrict__ xyz_in,
-    const uint32_t *__restrict__ key_in, const uint32_t *__restrict__ idx_in, int64_t n, int shift, int dbits,
+    const uint32_t *__restrict__ key_in, const uint32_t *__restrict__ idx_in, int64_t n, const VoxelDevPlan *__restrict__ dp,
     const uint32_t *__restrict__ block_hist, int ntiles, const uint32_t *__restrict__ totals, float *__restrict__ xyz_out,
-    uint32_t *__restrict__ key_out, uint32_t *__restrict__ idx_out, const int32_t *__restrict__ flags) {
+    uint32_t *__restrict__ key_out, uint32_t *__restrict__ idx_out, uint32_t *__restrict__ inv_start,
+    const int32_t *__restrict__ flags) {
   __shared__ uint32_t cnt[kVbWaves][256];
   __shared__ uint32_t tile_pref[256];
   __shared__ uint32_t gbase[256];
@@ -177,6 +172,9 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
   __shared__ float sx[kVbTile], sy[kVbTile], sz[kVbTile];
   __shared__ uint32_t sidx[kIdx ? kVbTile : 1];
   if (*flags) return;  // uniform: the call goes the radix path
+  const int shift = kFirst ? dp->plan.low_bits : dp->plan.low_bits + dp->plan.d_bits[0];
+  const int dbits = dp->plan.d_bits[kFirst ? 0 : 1];
+  if (dbits == 0) return;  // uniform: one pass was enough
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int per = (int)(gridDim.x >> 3);
   const int tile = (gridDim.x & 7u) == 0u ? (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3) : (int)blockIdx.x;  // XCD-contiguous (sort.hip)
@@ -268,10 +266,18 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
   __syncthreads();
   const int64_t rem = n - tile_base;
   const int count = rem < kVbTile ? (int)rem : kVbTile;
+  // Where the buckets begin.  Behind the LAST pass the tile in LDS is grouped by bucket: this pass's digit stably, the
+  // earlier digit ascending inside it (the tile came sorted by that one).  The first element of a bucket's run here
+  // lands at the lowest place any of this tile's elements of the bucket get; the lowest over all tiles is the
+  // bucket's start: one atomic per run (a hundred per tile), kept as the complement's maximum so that the cleared
+  // word means "no points" (a kernel of its own that found the bounds in the sorted keys: 11 us per C3 call).
+  const bool last_pass = inv_start != nullptr && (kFirst ? dp->plan.d_bits[1] == 0 : true);
+  const int low_bits = dp->plan.low_bits;
   for (int p = threadIdx.x; p < count; p += kVbThreads) {
     const uint32_t k = skey[p];
     const uint32_t d = (k >> shift) & mask;
     const int64_t dst = (int64_t)gbase[d] + p;
+    if (last_pass && (p == 0 || (skey[p - 1] >> low_bits) != (k >> low_bits))) atomicMax(&inv_start[k >> low_bits], ~(uint32_t)dst);
     key_out[dst] = k;
     xyz_out[dst] = sx[p];  // (three arrays x[n] y[n] z[n]: every store instruction writes consecutive words)
     xyz_out[n + dst] = sy[p];
@@ -307,8 +313,9 @@ __device__ __forceinline__ uint32_t ld_sc1_u32(const uint32_t *p) {
 
 template <bool kIdx>
 __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
-    const float *__restrict__ xyz, int64_t n, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ idx,
-    const uint32_t *__restrict__ bucket_start, VoxelParams vp, VbPlan plan, const uint8_t *__restrict__ data, int32_t stride,
+    const float *__restrict__ xyz0, const float *__restrict__ xyz1, int64_t n, const uint32_t *__restrict__ keys0,
+    const uint32_t *__restrict__ keys1, const uint32_t *__restrict__ idx0, const uint32_t *__restrict__ idx1,
+    const uint32_t *__restrict__ bucket_start, const VoxelDevPlan *__restrict__ dp, const uint8_t *__restrict__ data, int32_t stride,
     int32_t off, uint8_t *__restrict__ out, VbExchange ex, int64_t *__restrict__ total, int32_t *__restrict__ flags) {
   constexpr int kBins = 1 << kVbMaxLowBits, kWaves = kVbFinalThreads / 64;
   constexpr int kPer = kVbCap / kVbFinalThreads;       // points per thread
@@ -320,10 +327,32 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
   __shared__ uint16_t vrank[kBins];     // occupied cells before it in the bucket
   __shared__ uint32_t wsum[kWaves], wocc[kWaves];
   __shared__ uint32_t s_prefix;
-  if (*flags & 1) return;  // uniform: a bucket does not fit (an earlier kernel's finding), the call goes the radix path
+  if (*flags & 9) return;  // uniform: not a call for this path / a bucket does not fit (an earlier kernel's finding): the radix path
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (b >= dp->plan.nbuckets) return;  // uniform (the grid is the most buckets a plan can have: the host does not know the plan)
+  const VoxelParams vp = dp->vp;
+  const VbPlan plan = dp->plan;
+  const bool two = plan.d_bits[1] != 0;  // the arrays the last pass wrote
+  const float *__restrict__ xyz = two ? xyz1 : xyz0;
+  const uint32_t *__restrict__ keys = two ? keys1 : keys0;
+  const uint32_t *__restrict__ idx = two ? idx1 : idx0;
   const int nbins = 1 << plan.low_bits;
-  const uint32_t start = bucket_start[b], end = bucket_start[b + 1];
+  // the bucket's points: from its start (the last pass's finding, kept as the complement; a cleared word: no points) to
+  // the start of the next bucket that has any
+  const uint32_t inv = bucket_start[b];
+  uint32_t start = 0, end = 0;
+  if (inv != 0u) {  // uniform
+    start = ~inv;
+    for (int base = b + 1;; base += 64) {
+      const int j = base + lane;
+      const uint32_t v = j < plan.nbuckets ? bucket_start[j] : ~(uint32_t)n;  // (behind the last bucket: n)
+      const uint64_t found = __ballot(v != 0u);
+      if (found) {
+        end = ~(uint32_t)__shfl((int)v, __ffsll((long long)found) - 1);
+        break;
+      }
+    }
+  }
   const bool fits = end - start <= (uint32_t)kVbCap;
   const int P = fits ? (int)(end - start) : 0;
   for (int l = threadIdx.x; l < nbins; l += kVbFinalThreads) cnt[l] = 0;
@@ -582,126 +611,149 @@ static int vb_knob(const char *name, int def) {
   return e ? atoi(e) : def;
 }
 
-// The bucket path of one filter call (one GPU, one sort key of key_bits bits over [0, key_range)).  key_population: how many
-// of those keys can occur (chunked mode leaves gaps between the chunks' cell ranges).  *taken false: the
-// call is not for this path (too small, keys too wide, PCGX_VOXEL_BUCKET=0) or turned out not to fit (a crowded
-// bucket or cell; *out_n is then untouched and nothing the radix path does not overwrite has been written).
-pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, int32_t xyz_off, const VoxelParams &vp,
-                                int key_bits, uint64_t key_range, uint64_t key_population, void *d_out, int64_t *out_n, bool *taken, hipStream_t st) {
-  *taken = false;
+// The bucket path of one filter call on one GPU (voxel_key.h).  The host does not wait for the cloud's min / max:
+// the plan is made on the device (vb_plan_kernel), every kernel reads it from there, buffers and grids are sized for
+// the largest plan there is (the bucket kernel's grid: kVbMaxBuckets workgroups, those without a bucket return at
+// once), and what came of it all -- plan, flags, the number of output points -- is read back in one copy at the end.
+// Before: 34 us of a C3 call in which the GPU waited for the host (six floats back, the plan, a dozen launches).
+pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, int32_t xyz_off, const float leaf[3],
+                                const int32_t chunk[3], void *d_out, int64_t *out_n, bool *attempted, bool *taken,
+                                VoxelDevPlan *dp_host, hipStream_t st) {
+  *attempted = *taken = false;
   const int enabled = vb_knob("PCGX_VOXEL_BUCKET", 1), min_n = vb_knob("PCGX_VOXEL_BUCKET_MIN_N", 400000);
-  if (!enabled || n < min_n || key_bits < 1 || key_bits > kVbMaxLowBits + kVbMaxBucketBits || key_range < 2) return PCGX_OK;
-  // s: as many cells per bucket as keep an evenly filled bucket at 0.6 of the LDS tile (C3: the fullest of 6505 holds 1.35x the mean)
-  VbPlan plan;
-  memset(&plan, 0, sizeof plan);
-  int s = key_bits < kVbMaxLowBits ? key_bits : kVbMaxLowBits;
-  while (s > 0 && (double)n * (double)((uint64_t)1 << s) / (double)key_population > 0.6 * kVbCap) s--;
-  const uint64_t nb = ((key_range - 1) >> s) + 1;
-  int bb = 0;
-  while (((uint64_t)1 << bb) < nb) bb++;
-  if (s == 0 || bb < 1 || bb > kVbMaxBucketBits) return PCGX_OK;
-  plan.low_bits = s;
-  plan.nbuckets = (int32_t)nb;
-  plan.d_bits[0] = bb <= 8 ? bb : bb - bb / 2;
-  plan.d_bits[1] = bb - plan.d_bits[0];
-  plan.ntiles = (int32_t)((n + kVbTile - 1) / kVbTile);
-  plan.dbg = vb_knob("PCGX_VOXEL_BUCKET_DBG", 0);
+  if (!enabled || n < min_n) return PCGX_OK;
+  *attempted = true;
+  VoxelPlanHook kn;
+  memset(&kn, 0, sizeof kn);
+  kn.n = n;
+  for (int k = 0; k < 3; k++) {
+    kn.leaf[k] = leaf[k];
+    kn.chunk[k] = chunk[k];
+  }
+  const char *force_two = getenv("PCGX_VOXEL_TWO_SORTS");  // tests: keep the two-sort path covered
+  kn.force_two_sorts = force_two && force_two[0] == '1';
+  kn.dbg = vb_knob("PCGX_VOXEL_BUCKET_DBG", 0);
+  const int ntiles = kn.ntiles = (int32_t)((n + kVbTile - 1) / kVbTile);
+  kn.grid = vb_knob("PCGX_VOXEL_BUCKET_GRID", kVbMaxBuckets);  // (measurement aid: a plan with more buckets goes the radix path)
+  if (kn.grid < 1 || kn.grid > kVbMaxBuckets) kn.grid = kVbMaxBuckets;
   const bool with_idx = stride != 12 || xyz_off != 0 || ((reinterpret_cast<uintptr_t>(d_data) | reinterpret_cast<uintptr_t>(d_out)) & 3) != 0;
 
   Arena &ar = ctx().arena;
   uint32_t *key0 = nullptr, *keyb[2] = {nullptr, nullptr}, *idxb[2] = {nullptr, nullptr};
   float *xyzb[2] = {nullptr, nullptr};
-  uint32_t *block_hist = nullptr, *totals = nullptr, *bucket_sample = nullptr, *bucket_start = nullptr;
-  int32_t *d_flags = nullptr;  // [0] flags (1 crowded bucket, 2 crowded cell, 4 the exchange gave up), [1] key out of range
+  uint32_t *block_hist = nullptr, *totals = nullptr, *bucket_sample = nullptr, *inv_start = nullptr;
+  float *d_mm6 = nullptr;
+  VoxelDevPlan *d_plan = nullptr;
+  int32_t *d_flags = nullptr;  // [0] flags (1 crowded bucket, 2 crowded cell, 4 the exchange gave up, 8 no plan), [1] key out of range
   int64_t *d_total = nullptr;
   VbExchange ex;
-  const int64_t n_groups = ((int64_t)plan.nbuckets + 31) / 32, n_super = ((int64_t)plan.nbuckets + 1023) / 1024;
+  constexpr int64_t kGroups = kVbMaxBuckets / 32, kSuper = kVbMaxBuckets / 1024;
   PCGX_TRY(ar.alloc_n((size_t)n, &key0));
-  const int passes = plan.d_bits[1] ? 2 : 1;
-  for (int k = 0; k < passes; k++) {
+  for (int k = 0; k < 2; k++) {
     PCGX_TRY(ar.alloc_n((size_t)n, &keyb[k]));
     PCGX_TRY(ar.alloc_n((size_t)n * 3, &xyzb[k]));
     if (with_idx) PCGX_TRY(ar.alloc_n((size_t)n, &idxb[k]));
   }
-  PCGX_TRY(ar.alloc_n((size_t)plan.ntiles * 256, &block_hist));
+  PCGX_TRY(ar.alloc_n((size_t)ntiles * 256, &block_hist));
   PCGX_TRY(ar.alloc_n(256, &totals));
-  PCGX_TRY(ar.alloc_n((size_t)plan.nbuckets + 1, &bucket_start));
-  // one block, zeroed at once: flags, the exchange's words, the sample of the bucket populations
-  const size_t zero_words = 8 + (size_t)plan.nbuckets * 2 + (size_t)n_groups + (size_t)n_super;
+  PCGX_TRY(ar.alloc_n(8, &d_mm6));
+  // one block, zeroed at once: flags, the exchange's words, the sample of the bucket populations.  What the host
+  // reads back at the end is at its start: flags, err, total, the plan
+  struct Readback {
+    int32_t flags, err;
+    int64_t total;
+    VoxelDevPlan plan;
+  };
+  static_assert(sizeof(Readback) % 8 == 0, "words");
+  constexpr size_t kHeadWords = (sizeof(Readback) + 127) / 128 * 32;
+  const size_t zero_words = kHeadWords + (size_t)kVbMaxBuckets * 3 + (size_t)kGroups + (size_t)kSuper;
   uint32_t *zero_block = nullptr;
   PCGX_TRY(ar.alloc_n(zero_words + 64, &zero_block));
   zero_block = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(zero_block) + 127) & ~(uintptr_t)127);
-  d_flags = reinterpret_cast<int32_t *>(zero_block);
-  d_total = reinterpret_cast<int64_t *>(d_flags + 2);
-  bucket_sample = zero_block + 8;
-  ex.count = bucket_sample + plan.nbuckets;
-  ex.group_tot = ex.count + plan.nbuckets;
-  ex.super_tot = ex.group_tot + n_groups;
-  PCGX_HIP_TRY(hipMemsetAsync(zero_block, 0, zero_words * sizeof(uint32_t), st));
+  Readback *d_rb = reinterpret_cast<Readback *>(zero_block);
+  d_flags = &d_rb->flags;
+  d_total = &d_rb->total;
+  d_plan = &d_rb->plan;
+  bucket_sample = zero_block + kHeadWords;
+  ex.count = bucket_sample + kVbMaxBuckets;
+  ex.group_tot = ex.count + kVbMaxBuckets;
+  ex.super_tot = ex.group_tot + kGroups;
+  inv_start = ex.super_tot + kSuper;
+  // (no memset, no kernel for the plan: the min/max launch clears the words behind the head as it goes, and its last
+  // workgroup writes the head -- flags, the plan -- behind the six floats)
+  static_assert(kHeadWords % 4 == 0 && (kVbMaxBuckets * 3 + kGroups + kSuper) % 4 == 0, "cleared 16 bytes at a time");
+  kn.dp = d_plan;
+  kn.head = d_flags;
+  kn.zero = zero_block + kHeadWords;
+  kn.zero_words = (uint32_t)(zero_words - kHeadWords);
 
   const uint8_t *data = (const uint8_t *)d_data;
+  PCGX_TRY(launch_minmax_with_plan(d_data, n, stride, xyz_off, d_mm6, kn, st));
   const int sample = vb_knob("PCGX_VOXEL_BUCKET_SAMPLE", 1);
-  hipLaunchKernelGGL(vb_key_hist_kernel, dim3(plan.ntiles), dim3(256), 0, st, data, n, stride, xyz_off, vp, plan, key0, block_hist,
-                     sample ? bucket_sample : (uint32_t *)nullptr, d_flags + 1);
-  hipLaunchKernelGGL(vb_sample_check_kernel, dim3((plan.nbuckets + 255) / 256), dim3(256), 0, st, (const uint32_t *)bucket_sample,
-                     plan.nbuckets, d_flags);
-  hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, plan.ntiles, totals);
-  const int grid = plan.ntiles >= 64 ? 8 * ((plan.ntiles + 7) / 8) : plan.ntiles;
+  const bool bounds_kernel = vb_knob("PCGX_VOXEL_BUCKET_BOUNDS_KERNEL", 0) != 0;
+  uint32_t *scatter_bounds = bounds_kernel ? nullptr : inv_start;
+  hipLaunchKernelGGL(vb_key_hist_kernel, dim3(ntiles), dim3(256), 0, st, data, n, stride, xyz_off, (const VoxelDevPlan *)d_plan, key0,
+                     block_hist, sample ? bucket_sample : (uint32_t *)nullptr, d_flags + 1, (const int32_t *)d_flags);
+  hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, ntiles, totals, (const VoxelDevPlan *)d_plan, 0,
+                     sample ? (const uint32_t *)bucket_sample : (const uint32_t *)nullptr, d_flags);
+  const int grid = ntiles >= 64 ? 8 * ((ntiles + 7) / 8) : ntiles;
   if (with_idx)
     hipLaunchKernelGGL((vb_scatter_kernel<true, true>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
-                       (const float *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, plan.low_bits, plan.d_bits[0],
-                       (const uint32_t *)block_hist, plan.ntiles, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0],
+                       (const float *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
+                       (const uint32_t *)block_hist, ntiles, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0], scatter_bounds,
                        (const int32_t *)d_flags);
   else
     hipLaunchKernelGGL((vb_scatter_kernel<true, false>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
-                       (const float *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, plan.low_bits, plan.d_bits[0],
-                       (const uint32_t *)block_hist, plan.ntiles, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0],
+                       (const float *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
+                       (const uint32_t *)block_hist, ntiles, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0], scatter_bounds,
                        (const int32_t *)d_flags);
-  int cur = 0;
-  if (passes == 2) {
-    const int shift = plan.low_bits + plan.d_bits[0];
-    hipLaunchKernelGGL(vb_hist2_kernel, dim3(plan.ntiles), dim3(256), 0, st, (const uint32_t *)keyb[0], n, shift,
-                       (1u << plan.d_bits[1]) - 1u, block_hist, plan.ntiles);
-    hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, plan.ntiles, totals);
-    if (with_idx)
-      hipLaunchKernelGGL((vb_scatter_kernel<false, true>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
-                         (const float *)xyzb[0], (const uint32_t *)keyb[0], (const uint32_t *)idxb[0], n, shift, plan.d_bits[1],
-                         (const uint32_t *)block_hist, plan.ntiles, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1],
-                         (const int32_t *)d_flags);
-    else
-      hipLaunchKernelGGL((vb_scatter_kernel<false, false>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
-                         (const float *)xyzb[0], (const uint32_t *)keyb[0], (const uint32_t *)idxb[0], n, shift, plan.d_bits[1],
-                         (const uint32_t *)block_hist, plan.ntiles, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1],
-                         (const int32_t *)d_flags);
-    cur = 1;
-  }
-  hipLaunchKernelGGL(vb_bounds_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (const uint32_t *)keyb[cur], n,
-                     plan.low_bits, plan.nbuckets, bucket_start, (const int32_t *)d_flags);
+  // the second digit (every plan above some ten thousand points has one; a plan without returns from these at once)
+  hipLaunchKernelGGL(vb_hist2_kernel, dim3(ntiles), dim3(256), 0, st, (const uint32_t *)keyb[0], n, (const VoxelDevPlan *)d_plan,
+                     block_hist, ntiles, (const int32_t *)d_flags);
+  hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, ntiles, totals, (const VoxelDevPlan *)d_plan, 1,
+                     (const uint32_t *)nullptr, d_flags);
   if (with_idx)
-    hipLaunchKernelGGL(vb_bucket_kernel<true>, dim3(plan.nbuckets), dim3(kVbFinalThreads), 0, st, (const float *)xyzb[cur], n,
-                       (const uint32_t *)keyb[cur], (const uint32_t *)idxb[cur], (const uint32_t *)bucket_start, vp, plan, data,
-                       stride, xyz_off, (uint8_t *)d_out, ex, d_total, d_flags);
+    hipLaunchKernelGGL((vb_scatter_kernel<false, true>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
+                       (const float *)xyzb[0], (const uint32_t *)keyb[0], (const uint32_t *)idxb[0], n, (const VoxelDevPlan *)d_plan,
+                       (const uint32_t *)block_hist, ntiles, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1], scatter_bounds,
+                       (const int32_t *)d_flags);
   else
-    hipLaunchKernelGGL(vb_bucket_kernel<false>, dim3(plan.nbuckets), dim3(kVbFinalThreads), 0, st, (const float *)xyzb[cur], n,
-                       (const uint32_t *)keyb[cur], (const uint32_t *)idxb[cur], (const uint32_t *)bucket_start, vp, plan, data,
-                       stride, xyz_off, (uint8_t *)d_out, ex, d_total, d_flags);
+    hipLaunchKernelGGL((vb_scatter_kernel<false, false>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
+                       (const float *)xyzb[0], (const uint32_t *)keyb[0], (const uint32_t *)idxb[0], n, (const VoxelDevPlan *)d_plan,
+                       (const uint32_t *)block_hist, ntiles, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1], scatter_bounds,
+                       (const int32_t *)d_flags);
+  if (bounds_kernel)
+    hipLaunchKernelGGL(vb_bounds_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (const uint32_t *)keyb[0],
+                       (const uint32_t *)keyb[1], n, (const VoxelDevPlan *)d_plan, inv_start, (const int32_t *)d_flags);
+  const int bucket_grid = kn.grid;
+  if (with_idx)
+    hipLaunchKernelGGL(vb_bucket_kernel<true>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float *)xyzb[0],
+                       (const float *)xyzb[1], n, (const uint32_t *)keyb[0], (const uint32_t *)keyb[1], (const uint32_t *)idxb[0],
+                       (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off,
+                       (uint8_t *)d_out, ex, d_total, d_flags);
+  else
+    hipLaunchKernelGGL(vb_bucket_kernel<false>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float *)xyzb[0],
+                       (const float *)xyzb[1], n, (const uint32_t *)keyb[0], (const uint32_t *)keyb[1], (const uint32_t *)idxb[0],
+                       (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off,
+                       (uint8_t *)d_out, ex, d_total, d_flags);
   PCGX_HIP_TRY(hipGetLastError());
-  struct {
-    int32_t flags, err;
-    int64_t total;
-  } h;
-  static_assert(sizeof(h) == 16, "flags, err, total as they sit in the zeroed block");
-  PCGX_HIP_TRY(hipMemcpyAsync(&h, d_flags, sizeof h, hipMemcpyDeviceToHost, st));
-  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  Readback h;
+  PCGX_TRY(read_back_small(d_rb, sizeof h, &h, st));
+  *dp_host = h.plan;
+  if (h.plan.status == 1 || h.plan.status == 2) {  // the grid itself is not to be had: the host's words for it
+    VoxelParams vp;
+    return voxel_grid_params_or_fail(h.plan.mm6, leaf, chunk, vp);
+  }
   if (h.err)
     return fail(PCGX_E_OUT_OF_RANGE, "voxel filter: a point falls outside the dense grid (the reference panics: index out of range)");
-  g_vb_last_low = plan.low_bits;
+  if (h.plan.status) return PCGX_OK;  // keys too wide, two sorts, too few keys: the radix path
+  g_vb_last_low = h.plan.plan.low_bits;
   if (h.flags) {  // crowded bucket / cell (or the exchange gave up): the radix path does the call
     g_vb_given_up++;
     g_vb_last_flags = h.flags;
     if (getenv("PCGX_VOXEL_BUCKET_TRACE"))
       fprintf(stderr, "pcgx voxel bucket path: flags %d (1 bucket over %d points, 2 cell over %d points, 4 exchange gave up); low bits %d, %d buckets, digits %d + %d\n",
-              h.flags, kVbCap, kVbMaxCell, plan.low_bits, plan.nbuckets, plan.d_bits[0], plan.d_bits[1]);
+              h.flags, kVbCap, kVbMaxCell, h.plan.plan.low_bits, h.plan.plan.nbuckets, h.plan.plan.d_bits[0], h.plan.plan.d_bits[1]);
     return PCGX_OK;
   }
   *out_n = h.total;

@@ -118,3 +118,66 @@ def test_c3_takes_the_bucket_path():
         st = _stats()
         assert st[0] == 1 and st[1] == 0, (chunk, st)
         assert 3_000_000 < len(got) // 12 < 3_400_000
+
+
+def _last_error():
+    buf = C.create_string_buffer(512)
+    L.lib().pcgx_last_error(buf, 512)
+    return buf.value
+
+
+def test_the_plan_made_on_the_device_fails_as_the_hosts_does(monkeypatch):
+    """The bucket path's grid and plan are made by the min/max launch's last workgroup (csrc/voxel_key.h: one piece of
+    code for host and device).  A grid the reference cannot address must end the call with the same status and the same
+    words whichever side found it; a point outside the dense grid (negative vMin, non-chunked: the Go code panics) is
+    found by the key kernel on either path."""
+    pts = synth.uniform_cloud(5000, 1.0, 5)
+    neg = pts - f32(10.0)
+    cases = [(pts, (1e-7,) * 3, (0, 0, 0)),            # (xs+1)(ys+1)(zs+1) >= 2^32
+             (pts, (1e-6,) * 3, (1, 1, 1)),            # chunk grid of >= 2^32 chunks
+             (neg, (0.05,) * 3, (0, 0, 0))]            # a key out of range
+    for data, leaf, chunk in cases:
+        seen = []
+        for min_n in ("1", "1000000000"):              # the device's plan / the host's
+            monkeypatch.setenv("PCGX_VOXEL_BUCKET_MIN_N", min_n)
+            out = np.empty(len(data) * 12, np.uint8)
+            m = C.c_int64()
+            leafv, chunkv = np.asarray(leaf, f32), np.asarray(chunk, np.int32)
+            rc = L.lib().pcgx_voxel_filter(L.ptr(data), len(data), 12, 0, L.ptr(leafv), L.ptr(chunkv), L.ptr(out), C.byref(m))
+            seen.append((rc, _last_error()))
+        assert seen[0][0] == seen[1][0] == 7 and seen[0][1] == seen[1][1], (leaf, chunk, seen)
+
+
+def test_calls_the_device_plan_turns_away_go_the_radix_path(monkeypatch):
+    """Not a call for the bucket path by what only the device knows when the launches are made -- sort keys of more than
+    26 bits (a sparse cloud on a fine grid), the two-sort layout: every kernel behind the plan returns at once, neither
+    counter moves, and the radix path answers from the min / max the attempt read back."""
+    monkeypatch.setenv("PCGX_VOXEL_BUCKET_MIN_N", "1")
+    pts = synth.uniform_cloud(20000, 4.0, 13)
+    exp = O.voxel_filter(pts, len(pts), 12, 0, (0.004,) * 3, (0, 0, 0))      # 1000^3 cells: 30 bits
+    _stats()
+    got = _filter(pts, len(pts), 12, 0, (0.004,) * 3, (0, 0, 0))
+    st = _stats()
+    assert st[0] == 0 and st[1] == 0, st
+    assert np.array_equal(got, exp)
+    monkeypatch.setenv("PCGX_VOXEL_TWO_SORTS", "1")
+    pts = synth.uniform_cloud(60000, 3.0, 77) - f32(0.7)
+    exp = O.voxel_filter(pts, len(pts), 12, 0, (0.05, 0.04, 0.06), (7, 5, 9))
+    got = _filter(pts, len(pts), 12, 0, (0.05, 0.04, 0.06), (7, 5, 9))
+    st = _stats()
+    assert st[0] == 0 and st[1] == 0, st
+    assert np.array_equal(got, exp)
+
+
+def test_bounds_by_a_kernel_of_their_own_give_the_same_bytes(monkeypatch):
+    """PCGX_VOXEL_BUCKET_BOUNDS_KERNEL=1 (a measurement aid: the buckets' starts from the sorted keys instead of from
+    the last scatter pass's atomics)."""
+    monkeypatch.setenv("PCGX_VOXEL_BUCKET_MIN_N", "1")
+    monkeypatch.setenv("PCGX_VOXEL_BUCKET_BOUNDS_KERNEL", "1")
+    for n, width, leaf in ((3000, 1.6, 0.05), (300000, 3.0, 0.02)):
+        pts = synth.uniform_cloud(n, width, 40 + n % 97)
+        exp = O.voxel_filter(pts, n, 12, 0, (leaf,) * 3, (0, 0, 0))
+        _stats()
+        got = _filter(pts, n, 12, 0, (leaf,) * 3, (0, 0, 0))
+        assert _stats()[0] == 1
+        assert np.array_equal(got, exp)
