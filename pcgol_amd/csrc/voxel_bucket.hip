@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void vb_key_hist_kernel(const uint8_t *__restr
                                                           int32_t off, const VoxelDevPlan *__restrict__ dp,
                                                           uint32_t *__restrict__ key_out, uint32_t *__restrict__ block_hist,
                                                           uint32_t *__restrict__ bucket_sample, int32_t *__restrict__ err,
-                                                          const int32_t *__restrict__ flags) {
+                                                          int hstride, const int32_t *__restrict__ flags) {
   __shared__ uint32_t dh[256];
   if (*flags) return;  // uniform: not a call for this path
   const VoxelParams vp = dp->vp;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void vb_key_hist_kernel(const uint8_t *__restr
   }
   if (any_bad) atomicOr(err, 1);
   __syncthreads();
-  block_hist[(int64_t)threadIdx.x * plan.ntiles + blockIdx.x] = dh[threadIdx.x];
+  block_hist[(int64_t)threadIdx.x * hstride + blockIdx.x] = dh[threadIdx.x];
 }
 
 // (measurement aid, PCGX_VOXEL_BUCKET_BOUNDS_KERNEL=1: the buckets' starts found in the sorted keys by a kernel of its
@@ -95,29 +95,44 @@ __global__ __launch_bounds__(256) void vb_bounds_kernel(const uint32_t *__restri
   }
 }
 
-// tile histograms of the second pass's digit, from the keys as the first pass left them
-__global__ __launch_bounds__(256) void vb_hist2_kernel(const uint32_t *__restrict__ keys, int64_t n,
-                                                       const VoxelDevPlan *__restrict__ dp, uint32_t *__restrict__ block_hist,
-                                                       int ntiles, const int32_t *__restrict__ flags) {
-  __shared__ uint32_t dh[256];
+// tile histograms of the second pass's digit, from the keys as the first pass left them.  Sixteen tiles per workgroup,
+// a wave each: the counts of a digit for sixteen consecutive tiles leave as ONE 64-byte piece of the digit's row (rows
+// begin on 128-byte lines: hstride).  A workgroup per tile stored 256 single words, each into another row: a million
+// and a quarter partial lines per call, and the kernel took 26 us for 40 MB.
+constexpr int kVbHistTiles = 16;
+__global__ __launch_bounds__(1024) void vb_hist2_kernel(const uint32_t *__restrict__ keys, int64_t n,
+                                                        const VoxelDevPlan *__restrict__ dp, uint32_t *__restrict__ block_hist,
+                                                        int ntiles, int hstride, const int32_t *__restrict__ flags) {
+  __shared__ uint32_t dh[kVbHistTiles][256];
   if (*flags || dp->plan.d_bits[1] == 0) return;  // uniform
   const int shift = dp->plan.low_bits + dp->plan.d_bits[0];
   const uint32_t mask = (1u << dp->plan.d_bits[1]) - 1u;
-  dh[threadIdx.x] = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * kVbTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int l = lane; l < 256; l += 64) dh[wave][l] = 0;
+  const int tile = blockIdx.x * kVbHistTiles + wave;
+  const int64_t base = (int64_t)tile * kVbTile;
+  __builtin_amdgcn_wave_barrier();
+  if (tile < ntiles) {
+    uint32_t k[kVbTile / 64];
 #pragma unroll
-  for (int r = 0; r < kVbItems; r++) {
-    const int64_t i = base + r * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&dh[(keys[i] >> shift) & mask], 1u);
+    for (int r = 0; r < kVbTile / 64; r++) {
+      const int64_t i = base + r * 64 + lane;
+      k[r] = i < n ? keys[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int r = 0; r < kVbTile / 64; r++)
+      if (base + r * 64 + lane < n) atomicAdd(&dh[wave][(k[r] >> shift) & mask], 1u);
   }
   __syncthreads();
-  block_hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = dh[threadIdx.x];
+  const int j = threadIdx.x & (kVbHistTiles - 1);
+  if (blockIdx.x * kVbHistTiles + j < ntiles)
+    for (int d = threadIdx.x / kVbHistTiles; d < 256; d += 1024 / kVbHistTiles)
+      block_hist[(int64_t)d * hstride + blockIdx.x * kVbHistTiles + j] = dh[j][d];
 }
 
 // every digit's row of tile counts -> its exclusive prefix over the tiles, and the row's total (as rs_scan_rows_kernel,
 // sort.hip, with 1024 threads per row: 4882 tiles at C3 are five rounds instead of twenty)
-__global__ __launch_bounds__(1024) void vb_scan_rows_kernel(uint32_t *__restrict__ block_hist, int ntiles,
+__global__ __launch_bounds__(1024) void vb_scan_rows_kernel(uint32_t *__restrict__ block_hist, int ntiles, int hstride,
                                                             uint32_t *__restrict__ totals, const VoxelDevPlan *__restrict__ dp,
                                                             int pass, const uint32_t *__restrict__ bucket_sample,
                                                             int32_t *__restrict__ flags) {
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(1024) void vb_scan_rows_kernel(uint32_t *__restrict
     const int b = blockIdx.x * 1024 + threadIdx.x;
     if (b < dp->plan.nbuckets && (uint64_t)bucket_sample[b] * kVbSampleEvery > (uint64_t)kVbCap * 3 / 2) atomicOr(flags, 1);
   }
-  uint32_t *row = block_hist + (int64_t)blockIdx.x * ntiles;
+  uint32_t *row = block_hist + (int64_t)blockIdx.x * hstride;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
@@ -160,7 +175,7 @@ template <bool kFirst, bool kIdx>
 __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
     const uint8_t *__restrict__ data, int32_t stride, int32_t off, const float *__restrict__ xyz_in,
     const uint32_t *__restrict__ key_in, const uint32_t *__restrict__ idx_in, int64_t n, const VoxelDevPlan *__restrict__ dp,
-    const uint32_t *__restrict__ block_hist, int ntiles, const uint32_t *__restrict__ totals, float *__restrict__ xyz_out,
+    const uint32_t *__restrict__ block_hist, int ntiles, int hstride, const uint32_t *__restrict__ totals, float *__restrict__ xyz_out,
     uint32_t *__restrict__ key_out, uint32_t *__restrict__ idx_out, uint32_t *__restrict__ inv_start,
     const int32_t *__restrict__ flags) {
   __shared__ uint32_t cnt[kVbWaves][256];
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
     }
     const uint32_t excl = wbase + inc - run;
     tile_pref[t] = excl;
-    gbase[t] = (gwbase + ginc - tot) + block_hist[(int64_t)t * ntiles + tile] - excl;  // dst = gbase[d] + pos
+    gbase[t] = (gwbase + ginc - tot) + block_hist[(int64_t)t * hstride + tile] - excl;  // dst = gbase[d] + pos
   }
   __syncthreads();
 #pragma unroll
@@ -654,7 +669,9 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
     PCGX_TRY(ar.alloc_n((size_t)n * 3, &xyzb[k]));
     if (with_idx) PCGX_TRY(ar.alloc_n((size_t)n, &idxb[k]));
   }
-  PCGX_TRY(ar.alloc_n((size_t)ntiles * 256, &block_hist));
+  const int hstride = (ntiles + 31) & ~31;  // (a digit's row of tile counts begins on a 128-byte line)
+  PCGX_TRY(ar.alloc_n((size_t)hstride * 256 + 32, &block_hist));
+  block_hist = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(block_hist) + 127) & ~(uintptr_t)127);
   PCGX_TRY(ar.alloc_n(256, &totals));
   PCGX_TRY(ar.alloc_n(8, &d_mm6));
   // one block, zeroed at once: flags, the exchange's words, the sample of the bucket populations.  What the host
@@ -693,34 +710,34 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   const bool bounds_kernel = vb_knob("PCGX_VOXEL_BUCKET_BOUNDS_KERNEL", 0) != 0;
   uint32_t *scatter_bounds = bounds_kernel ? nullptr : inv_start;
   hipLaunchKernelGGL(vb_key_hist_kernel, dim3(ntiles), dim3(256), 0, st, data, n, stride, xyz_off, (const VoxelDevPlan *)d_plan, key0,
-                     block_hist, sample ? bucket_sample : (uint32_t *)nullptr, d_flags + 1, (const int32_t *)d_flags);
-  hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, ntiles, totals, (const VoxelDevPlan *)d_plan, 0,
+                     block_hist, sample ? bucket_sample : (uint32_t *)nullptr, d_flags + 1, hstride, (const int32_t *)d_flags);
+  hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, ntiles, hstride, totals, (const VoxelDevPlan *)d_plan, 0,
                      sample ? (const uint32_t *)bucket_sample : (const uint32_t *)nullptr, d_flags);
   const int grid = ntiles >= 64 ? 8 * ((ntiles + 7) / 8) : ntiles;
   if (with_idx)
     hipLaunchKernelGGL((vb_scatter_kernel<true, true>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
                        (const float *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
-                       (const uint32_t *)block_hist, ntiles, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0], scatter_bounds,
+                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0], scatter_bounds,
                        (const int32_t *)d_flags);
   else
     hipLaunchKernelGGL((vb_scatter_kernel<true, false>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
                        (const float *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
-                       (const uint32_t *)block_hist, ntiles, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0], scatter_bounds,
+                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0], scatter_bounds,
                        (const int32_t *)d_flags);
   // the second digit (every plan above some ten thousand points has one; a plan without returns from these at once)
-  hipLaunchKernelGGL(vb_hist2_kernel, dim3(ntiles), dim3(256), 0, st, (const uint32_t *)keyb[0], n, (const VoxelDevPlan *)d_plan,
-                     block_hist, ntiles, (const int32_t *)d_flags);
-  hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, ntiles, totals, (const VoxelDevPlan *)d_plan, 1,
+  hipLaunchKernelGGL(vb_hist2_kernel, dim3((ntiles + kVbHistTiles - 1) / kVbHistTiles), dim3(1024), 0, st, (const uint32_t *)keyb[0], n,
+                     (const VoxelDevPlan *)d_plan, block_hist, ntiles, hstride, (const int32_t *)d_flags);
+  hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, ntiles, hstride, totals, (const VoxelDevPlan *)d_plan, 1,
                      (const uint32_t *)nullptr, d_flags);
   if (with_idx)
     hipLaunchKernelGGL((vb_scatter_kernel<false, true>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
                        (const float *)xyzb[0], (const uint32_t *)keyb[0], (const uint32_t *)idxb[0], n, (const VoxelDevPlan *)d_plan,
-                       (const uint32_t *)block_hist, ntiles, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1], scatter_bounds,
+                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1], scatter_bounds,
                        (const int32_t *)d_flags);
   else
     hipLaunchKernelGGL((vb_scatter_kernel<false, false>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
                        (const float *)xyzb[0], (const uint32_t *)keyb[0], (const uint32_t *)idxb[0], n, (const VoxelDevPlan *)d_plan,
-                       (const uint32_t *)block_hist, ntiles, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1], scatter_bounds,
+                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1], scatter_bounds,
                        (const int32_t *)d_flags);
   if (bounds_kernel)
     hipLaunchKernelGGL(vb_bounds_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (const uint32_t *)keyb[0],

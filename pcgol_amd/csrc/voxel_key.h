@@ -28,22 +28,32 @@ __device__ __forceinline__ float ld_f32(const uint8_t *p) {
 
 __device__ __forceinline__ void chunk_origin(const VoxelParams &vp, uint32_t cid, float o[3]) {
   // cid2xyz + vMin.Add(cp.ElementMul(chunkSize))  (voxelgrid.go:69-75,109-110)
-  int64_t c = cid;
-  const int64_t x = c % vp.nx;
-  c = c / vp.nx;
-  const int64_t y = c % vp.ny;
-  const int64_t z = c / vp.ny;
+  // (cid, nx, ny < 2^32, voxel_grid_params: the reference's int arithmetic in 32-bit registers)
+  const uint32_t nx = (uint32_t)vp.nx, ny = (uint32_t)vp.ny;
+  const uint32_t c2 = cid / nx;
+  const uint32_t x = cid - c2 * nx;
+  const uint32_t z = c2 / ny;
+  const uint32_t y = c2 - z * ny;
   o[0] = vp.vmin[0] + (float)x * vp.cs[0];
   o[1] = vp.vmin[1] + (float)y * vp.cs[1];
   o[2] = vp.vmin[2] + (float)z * vp.cs[2];
 }
 
+// (int64_t)q of a float32 quotient that lies in (-1, 2^31): the truncation is 0 for the negative ones, the value fits a
+// register -- every point of a cloud whose min / max the grid was made from, NaN and a negative vMin (non-chunked)
+// aside.  The general conversion (float -> int64: a dozen instructions) and the 64-bit index arithmetic behind it
+// were two thirds of the key kernels' instructions: those kernels were bound by vector issue, not by memory.
+__device__ __forceinline__ bool cell_u32(float q, uint32_t &v) {
+  const bool ok = q > -1.0f && q < 2147483648.0f;
+  v = (uint32_t)(int32_t)(ok ? q : 0.0f);
+  return ok;
+}
+
 // The cell of a point in the reference's arithmetic (float32 subtract and divide, truncation, the xs / ys strides of
 // voxelgrid.go:137-151; chunked mode: the chunk first, voxelgrid.go:76-79): the sort key (cell, or chunk id and cell
 // in one word), the chunk id and the cell by themselves.  bad: the Go code would panic (index out of range); the
-// key is then 0 (an out-of-range chunk) or carries cell 0.
-__device__ __forceinline__ uint32_t voxel_key_xyz(const float pt[3], const VoxelParams &vp, uint32_t &cid_out, uint32_t &ka_out,
-                                                  bool &bad) {
+// key is then 0 (an out-of-range chunk) or carries cell 0.  (The general form: any float, 64-bit indices.)
+__device__ inline uint32_t voxel_key_xyz_any(const float pt[3], const VoxelParams &vp, uint32_t &cid_out, uint32_t &ka_out, bool &bad) {
   float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
   uint32_t cid = 0;
   bad = false;
@@ -69,6 +79,52 @@ __device__ __forceinline__ uint32_t voxel_key_xyz(const float pt[3], const Voxel
   else ka = (uint32_t)a;
   ka_out = ka;
   return vp.combined ? cid * (uint32_t)vp.n_voxels + ka : ka;
+}
+
+// The same result through 32-bit registers where every quotient allows it (cell_u32) and no product leaves 32 bits on
+// its way; the general form for the lanes where one does.  xs, ys, nx, ny, n_chunks, n_voxels are all below 2^32
+// (voxel_grid_params).
+__device__ __forceinline__ uint32_t voxel_key_xyz(const float pt[3], const VoxelParams &vp, uint32_t &cid_out, uint32_t &ka_out,
+                                                  bool &bad) {
+  float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
+  uint32_t cid = 0;
+  bool fast = true;
+  if (vp.chunked) {
+    const float q0 = pt[0] - vp.vmin[0], q1 = pt[1] - vp.vmin[1], q2 = pt[2] - vp.vmin[2];
+    uint32_t cx, cy, cz;
+    fast = cell_u32(q0 / vp.cs[0], cx) & cell_u32(q1 / vp.cs[1], cy) & cell_u32(q2 / vp.cs[2], cz);
+    // cid2xyz(cid) is (cx, cy, cz) again when cx < nx and cy < ny; cz < 2^31 and ny, nx < 2^32: no product leaves 64 bits
+    const uint64_t c = ((uint64_t)cz * (uint32_t)vp.ny + cy) * (uint32_t)vp.nx + cx;
+    fast = fast && cx < (uint32_t)vp.nx && cy < (uint32_t)vp.ny && (c >> 32) == 0ull;
+    if (fast) {
+      if (c >= (uint64_t)vp.n_chunks) {  // nIndices[cid] would panic
+        bad = true;
+        cid_out = 0;
+        ka_out = 0;
+        return 0u;
+      }
+      cid = (uint32_t)c;
+      origin[0] = vp.vmin[0] + (float)cx * vp.cs[0];  // vMin.Add(cp.ElementMul(chunkSize))  (voxelgrid.go:69-75,109-110)
+      origin[1] = vp.vmin[1] + (float)cy * vp.cs[1];
+      origin[2] = vp.vmin[2] + (float)cz * vp.cs[2];
+    }
+  }
+  if (fast) {
+    const float p0 = pt[0] - origin[0], p1 = pt[1] - origin[1], p2 = pt[2] - origin[2];
+    uint32_t x, y, z;
+    fast = cell_u32(p0 / vp.leaf[0], x) & cell_u32(p1 / vp.leaf[1], y) & cell_u32(p2 / vp.leaf[2], z);
+    const uint64_t t = (uint64_t)(uint32_t)vp.ys * z + y;                 // < 2^63
+    fast = fast && (t >> 32) == 0ull;
+    if (fast) {
+      const uint64_t a = (uint64_t)(uint32_t)vp.xs * (uint32_t)t + x;     // < 2^64
+      bad = a >= (uint64_t)vp.n_voxels;                                    // f.voxels[a] would panic
+      const uint32_t ka = bad ? 0u : (uint32_t)a;
+      cid_out = cid;
+      ka_out = ka;
+      return vp.combined ? cid * (uint32_t)vp.n_voxels + ka : ka;
+    }
+  }
+  return voxel_key_xyz_any(pt, vp, cid_out, ka_out, bad);
 }
 
 // ---- the grid of a call, from the cloud's min / max (voxelgrid.go:45-62,137-138), in the reference's float32
