@@ -55,22 +55,10 @@ constexpr int kGridWide = 4;  // a search region may reach this many cells from 
 
 struct GridBest {
   float4 p;  // {x, y, z, bits(id)}; id < 0: none seen
-  float d;   // +inf: none seen
-  bool tie;  // a second point at exactly d
+  float d;   // the smallest DistSq seen; +inf: none seen
+  float d2;  // the second smallest (of the multiset): == d exactly when a second point sits at d
+  __device__ __forceinline__ bool tie() const { return d2 == d; }  // (asked only of a finite d)
 };
-
-__device__ __forceinline__ void grid_take(GridBest &b, const float4 &p, float qx, float qy, float qz, bool valid) {
-  const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-  const float d = (dx * dx + dy * dy) + dz * dz;  // the reference's expression (mat/vec3.go:18-20,38-40)
-  // selects, not branches: the lanes of a wave rarely agree on which of them improves
-  const bool lt = valid & (d < b.d), eq = valid & (d == b.d);
-  b.p.x = lt ? p.x : b.p.x;
-  b.p.y = lt ? p.y : b.p.y;
-  b.p.z = lt ? p.z : b.p.z;
-  b.p.w = lt ? p.w : b.p.w;
-  b.d = lt ? d : b.d;
-  b.tie = (b.tie & !lt) | eq;
-}
 
 // start[row + cx - 1 .. row + cx + 2]: the bounds of the three cells cx - 1 .. cx + 1 of a row in one
 // 16-byte load (4-byte aligned; start[] is padded by one element on either side)
@@ -129,21 +117,57 @@ __device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint
     if (N == 9) tr->rounds9 = (int)((total + 3) / 4);
     if (N == 4) tr->rounds4 = (int)((total + 3) / 4);
   }
-  for (uint32_t f0 = 0; f0 < total; f0 += 4) {
+  // The loop is what the searches spend their vector instructions on (the C2 search kernel: two thirds of its time is
+  // vector issue), so per point, beside the distance (dx, dy as one packed operation each): the smallest and the second
+  // smallest distance so far -- a minimum and a median of three, no comparison; "tied" is their equality at the end --
+  // one comparison and one select for the winner's id, one more select for where it sits when the caller wants its
+  // x, y, z (read again, once).  Whole groups of four are taken without any masking; the last, partial group reads up
+  // to three positions behind the sequence (pts[] is padded by three records, the segments behind the last used one
+  // begin at 0) and counts them as infinitely far.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 qxy = {qx, qy};
+  float d1 = best.d, d2 = best.d2, bw = best.p.w;
+  uint32_t bf = 0xffffffffu;  // where the winner sits in pts[] (none of this scan's: the caller's stays)
+  auto group = [&](uint32_t f0, bool partial) {
     float4 p[4];
-    bool ok[4];
+    uint32_t at[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      ok[u] = f0 + u < total;
-      const uint32_t f = ok[u] ? f0 + u : f0;
+      const uint32_t f = f0 + u;
       uint32_t sh = shift[0];
 #pragma unroll
       for (int j = 1; j < N; j++) sh = f >= first[j] ? shift[j] : sh;
-      p[u] = g.pts[f + sh];
+      at[u] = f + sh;
+      p[u] = g.pts[at[u]];
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) grid_take(best, p[u], qx, qy, qz, ok[u]);
+    for (int u = 0; u < 4; u++) {
+      asm volatile("" : "+v"(p[u].w));  // (the id arrives with x, y, z: not fetched by a branch of its own when the point wins)
+      const f32x2 pxy = {p[u].x, p[u].y};
+      const f32x2 dxy = pxy - qxy, sq = dxy * dxy;
+      const float dz = p[u].z - qz;
+      float d = (sq.x + sq.y) + dz * dz;  // the reference's expression (mat/vec3.go:18-20,38-40)
+      if (partial && u > 0) d = f0 + u < total ? d : __builtin_inff();
+      // selects, not branches: the lanes of a wave rarely agree on which of them improves
+      const bool lt = d < d1;
+      bw = lt ? p[u].w : bw;
+      bf = lt ? at[u] : bf;
+      d2 = __builtin_amdgcn_fmed3f(d1, d2, d);  // the second smallest of {d1 <= d2, d}
+      d1 = fminf(d1, d);
+    }
+  };
+  uint32_t f0 = 0;
+  for (; f0 + 4 <= total; f0 += 4) group(f0, false);
+  if (f0 < total) group(f0, true);
+  if (bf != 0xffffffffu) {
+    const float4 r = g.pts[bf];
+    best.p.x = r.x;
+    best.p.y = r.y;
+    best.p.z = r.z;
   }
+  best.p.w = bw;
+  best.d = d1;
+  best.d2 = d2;
 }
 
 // Nearest of an exact-mode query (MinDistSq == 0) if the grid can certify it.  ub: squared distance
@@ -179,8 +203,7 @@ __device__ __forceinline__ void grid_nearest_begin(const GridView &g, const floa
                                                    GridTrace *tr = nullptr) {
   S.early = S.cold = S.guess = S.more = false;
   S.b.p = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-  S.b.d = __builtin_inff();
-  S.b.tie = false;
+  S.b.d = S.b.d2 = __builtin_inff();
   S.bound = fminf(ub, max_range_sq);
   // non-finite queries: NaN distances follow the walk's comparisons, not an ordering
   if (!(fabsf(qx) < 3.0e38f && fabsf(qy) < 3.0e38f && fabsf(qz) < 3.0e38f) || max_range_sq != max_range_sq) {
@@ -332,8 +355,7 @@ __device__ __forceinline__ GridVerdict grid_nearest_end(const GridView &g, const
       }
       PCGX_GRID_WHY(7);
       b.p = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-      b.d = __builtin_inff();
-      b.tie = false;
+      b.d = b.d2 = __builtin_inff();
       for (int z = box.z0; z <= box.z1; z++)
         for (int y0 = box.y0; y0 <= box.y1; y0 += 5) {  // up to 5 rows at a time: bounds in one round, points in one sequence
           uint32_t seg_s[5], seg_e[5];
@@ -367,7 +389,7 @@ __device__ __forceinline__ GridVerdict grid_nearest_end(const GridView &g, const
       PCGX_GRID_WHY(4);
       return GRID_WALK;
     }
-    if (b.tie) {  // the winner depends on the visit order
+    if (b.tie()) {  // the winner depends on the visit order
       PCGX_GRID_WHY(5);
       return GRID_WALK;
     }

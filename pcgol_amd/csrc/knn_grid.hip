@@ -214,27 +214,169 @@ __global__ __launch_bounds__(256) void qp_scatter_kernel(const float *__restrict
   for (int p = threadIdx.x; p < count; p += 256) out[(int64_t)gbase[sdig[p]] + p] = srec[p];
 }
 
+// The partition's output put into a finer order, tile by tile and in place: 2048 consecutive records (one coarse cell's
+// as a rule, 3900 queries a cell at C2) counting-sorted in LDS by their place INSIDE the coarse cell, 8 x 8 x 8 sub-cells
+// with x running fastest -- the base cloud's grid keeps a row of cells along x contiguous.  The search kernel's bound is
+// the lines its waves miss in the vector L1 (tools/micro/vmem_mask.cpp: eight to ten cycles of a CU's texture path per
+// missed line, whatever the lanes, loads in flight or waves per SIMD): sixty-four queries from anywhere in a 1.25 m
+// coarse cell share next to nothing, sixty-four from two rows of sub-cells read the same few rows of the grid.
+// No result depends on the order (exact search; ties go to the walk by query index).
+#ifndef PCGX_QP_SUB
+#define PCGX_QP_SUB 12
+#endif
+// (1024 threads, two records each: 489 tiles are two workgroups per CU, and four waves per CU hide nothing)
+constexpr int kQpRefineThreads = 1024, kQpRefineItems = kQpTile / kQpRefineThreads;
+__global__ __launch_bounds__(kQpRefineThreads) void qp_refine_kernel(float4 *__restrict__ rec, int64_t nq, QueryBox box) {
+  constexpr int kSub = PCGX_QP_SUB, kSubZ = 2 * kSub, kCell = kSub * kSub * kSubZ;  // sub-cells of a coarse cell (twice as tall as wide)
+  constexpr int kBins = ((2 * kCell + 1023) / 1024) * 1024, kT = kQpRefineThreads, kI = kQpRefineItems, kBinsPer = kBins / kT;
+  __shared__ uint32_t bins[kBins];
+  __shared__ float4 srec[kQpTile];
+  __shared__ uint32_t wsum[kT / 64];
+  __shared__ uint32_t s_first;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kQpTile;
+  const int64_t rem = nq - base;
+  const int count = rem < kQpTile ? (int)rem : kQpTile;
+#pragma unroll
+  for (int k = 0; k < kBinsPer; k++) bins[k * kT + threadIdx.x] = 0;
+  float4 r[kI];
+#pragma unroll
+  for (int k = 0; k < kI; k++) {
+    const int p = k * kT + threadIdx.x;
+    r[k] = p < count ? rec[base + p] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  }
+  if (threadIdx.x == 0) s_first = query_cell8(box, r[0].x, r[0].y, r[0].z);  // (the tile's records ascend by coarse cell)
+  __syncthreads();
+  const uint32_t first = s_first;
+  uint32_t key[kI], rank[kI];
+#pragma unroll
+  for (int k = 0; k < kI; k++) {
+    const int p = k * kT + threadIdx.x;
+    const float fx = fminf(fmaxf((r[k].x - box.lo[0]) * box.scale[0], 0.0f), 7.999f),
+                fy = fminf(fmaxf((r[k].y - box.lo[1]) * box.scale[1], 0.0f), 7.999f),
+                fz = fminf(fmaxf((r[k].z - box.lo[2]) * box.scale[2], 0.0f), 3.999f);
+    const uint32_t sx = min((uint32_t)((fx - floorf(fx)) * (float)kSub), (uint32_t)kSub - 1u),
+                   sy = min((uint32_t)((fy - floorf(fy)) * (float)kSub), (uint32_t)kSub - 1u),
+                   sz = min((uint32_t)((fz - floorf(fz)) * (float)kSubZ), (uint32_t)kSubZ - 1u);
+    const uint32_t rel = min(query_cell8(box, r[k].x, r[k].y, r[k].z) - first, 1u);  // (a tile over more than two cells: the rest share the second's bins)
+    key[k] = rel * (uint32_t)kCell + (sz * (uint32_t)kSub + sy) * (uint32_t)kSub + sx;
+    rank[k] = p < count ? atomicAdd(&bins[key[k]], 1u) : 0u;
+  }
+  __syncthreads();
+  {  // bins -> their first places: thread t the bins kBinsPer t ..
+    uint32_t c[kBinsPer], sum = 0;
+#pragma unroll
+    for (int k = 0; k < kBinsPer; k++) {
+      c[k] = bins[threadIdx.x * kBinsPer + k];
+      sum += c[k];
+    }
+    const uint32_t inc = wave_incl_scan_u32(sum);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int k = 0; k < kBinsPer; k++) {
+      bins[threadIdx.x * kBinsPer + k] = run;
+      run += c[k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kI; k++)
+    if (k * kT + threadIdx.x < count) srec[bins[key[k]] + rank[k]] = r[k];
+  __syncthreads();
+  for (int p = threadIdx.x; p < count; p += kT) rec[base + p] = srec[p];
+}
+
 // One query record per lane (qp_scatter_kernel's output: cell after cell); the answer goes to the query's own index.
-__global__ __launch_bounds__(kGridBlock) void grid_nearest_rec_kernel(GridView g, const float4 *__restrict__ qrec, int64_t nq,
-                                                                      float max_range_sq, int32_t *__restrict__ out_id,
-                                                                      float *__restrict__ out_dsq, int32_t *__restrict__ walk_list,
-                                                                      uint32_t *__restrict__ walk_count,
-                                                                      uint32_t *__restrict__ spent, int n_spent,
-                                                                      uint32_t *__restrict__ next_walk_count) {
+// Four waves per workgroup, and the SECOND scan of a search -- the cells of the 3 x 3 x 3 block outside the octant, needed
+// by one query in four -- is not done by the lane that owns the query: the lanes that need one queue it in LDS (query,
+// nine segments, what the octant gave), and the queue is scanned by as many lanes as it has entries, densely.  One query
+// per lane all the way, the second scan cost a wave as many rounds as its slowest lane took with a quarter of its lanes
+// switched on: 32 of a query's 56 lane-slots of point loads for 2.9 of its 14.7 records (tools/grid_probe.py) -- and
+// the kernel is bound by the instructions it issues (vector ALU 66 % busy, the texture path 73 %), masked or not.
+constexpr int kGridRecBlock = 256;
+__global__ __launch_bounds__(kGridRecBlock) void grid_nearest_rec_kernel(GridView g, const float4 *__restrict__ qrec, int64_t nq,
+                                                                         float max_range_sq, int32_t *__restrict__ out_id,
+                                                                         float *__restrict__ out_dsq, int32_t *__restrict__ walk_list,
+                                                                         uint32_t *__restrict__ walk_count,
+                                                                         uint32_t *__restrict__ spent, int n_spent,
+                                                                         uint32_t *__restrict__ next_walk_count) {
+  __shared__ float s_q[3][kGridRecBlock];
+  __shared__ uint32_t s_seg[18][kGridRecBlock];
+  __shared__ float s_best[3][kGridRecBlock];  // d, d2, id bits: in by queue slot, out by owner
+  __shared__ uint16_t s_owner[kGridRecBlock];
+  __shared__ uint32_t s_n;
   // (the partition's totals and cursors are spent, the NEXT call's walk count is not in use yet: left at zero here,
   // so that no call starts with a memset launch -- Arena::zeroed_words)
   if (blockIdx.x == 0) {
-    for (int k = threadIdx.x; k < n_spent; k += kGridBlock) spent[k] = 0u;
+    for (int k = threadIdx.x; k < n_spent; k += kGridRecBlock) spent[k] = 0u;
     if (threadIdx.x == 0) *next_walk_count = 0u;
   }
-  const uint32_t n_tiles = (uint32_t)((nq + kGridBlock - 1) / kGridBlock);
-  const int64_t pos = (int64_t)xcd_tile(blockIdx.x, n_tiles) * kGridBlock + threadIdx.x;  // an XCD: a contiguous eighth of the cells
-  if (pos >= nq) return;
-  const float4 r = qrec[pos];
+  if (threadIdx.x == 0) s_n = 0u;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_tiles = (uint32_t)((nq + kGridRecBlock - 1) / kGridRecBlock);
+  const int64_t pos = (int64_t)xcd_tile(blockIdx.x, n_tiles) * kGridRecBlock + threadIdx.x;  // an XCD: a contiguous eighth of the cells
+  const bool active = pos < nq;
+  const float4 r = active ? qrec[pos] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   const int32_t i = __float_as_int(r.w);
+  GridSearch S;
+  S.more = false;
+  if (active) grid_nearest_begin(g, r.x, r.y, r.z, max_range_sq, __builtin_inff(), S, nullptr);
+  const bool more = active && S.more;
+  {
+    const unsigned long long m = __ballot(more);
+    uint32_t base = 0;
+    if (m != 0ull) {  // uniform
+      if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
+      base = (uint32_t)__shfl((int)base, __ffsll((long long)m) - 1);
+    }
+    if (more) {
+      const uint32_t e = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      s_q[0][e] = r.x; s_q[1][e] = r.y; s_q[2][e] = r.z;
+#pragma unroll
+      for (int j = 0; j < 9; j++) {
+        s_seg[j][e] = S.seg_s[j];
+        s_seg[9 + j][e] = S.seg_e[j];
+      }
+      s_best[0][e] = S.b.d; s_best[1][e] = S.b.d2; s_best[2][e] = S.b.p.w;
+      s_owner[e] = (uint16_t)threadIdx.x;
+    }
+  }
+  __syncthreads();
+  const uint32_t n_more = s_n;
+  float res_d = 0.0f, res_d2 = 0.0f, res_w = 0.0f;
+  uint32_t res_owner = 0xffffffffu;
+  if (threadIdx.x < n_more) {  // (at most one entry per thread: every thread queued at most one)
+    const uint32_t e = threadIdx.x;
+    uint32_t seg_s[9], seg_e[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+      seg_s[j] = s_seg[j][e];
+      seg_e[j] = s_seg[9 + j][e];
+    }
+    GridBest b;
+    b.p = make_float4(0.0f, 0.0f, 0.0f, s_best[2][e]);
+    b.d = s_best[0][e];
+    b.d2 = s_best[1][e];
+    grid_scan_segments<9>(g, seg_s, seg_e, s_q[0][e], s_q[1][e], s_q[2][e], b, nullptr);
+    res_d = b.d; res_d2 = b.d2; res_w = b.p.w;
+    res_owner = s_owner[e];
+  }
+  __syncthreads();  // (the queue has been read: its slots take the answers, by owner)
+  if (res_owner != 0xffffffffu) {
+    s_best[0][res_owner] = res_d; s_best[1][res_owner] = res_d2; s_best[2][res_owner] = res_w;
+  }
+  __syncthreads();
+  if (!active) return;
+  if (more) {
+    S.b.d = s_best[0][threadIdx.x]; S.b.d2 = s_best[1][threadIdx.x]; S.b.p.w = s_best[2][threadIdx.x];
+  }
   float4 best;
   float best_d;
-  const GridVerdict v = grid_nearest(g, r.x, r.y, r.z, max_range_sq, __builtin_inff(), best, best_d, nullptr);
+  const GridVerdict v = grid_nearest_end(g, r.x, r.y, r.z, max_range_sq, S, best, best_d, nullptr);
   if (v == GRID_FOUND) {
     out_id[i] = __float_as_int(best.w);
     out_dsq[i] = best_d;
@@ -366,7 +508,8 @@ pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labe
     if (crowding <= 4.0 || attempt == 2 || finer > 0.7 * occ) break;
     occ = finer;
   }
-  hipError_t e = dev_cache_alloc((void **)&t->d_gpts, (size_t)n * sizeof(float4));
+  // (three records of padding: grid_scan_segments reads up to three positions behind a sequence's end, unused)
+  hipError_t e = dev_cache_alloc((void **)&t->d_gpts, ((size_t)n + 3) * sizeof(float4));
   if (e != hipSuccess) {
     (void)hipGetLastError();
     grid_free(t);
@@ -436,9 +579,11 @@ pcgx_status grid_launch_nearest_partitioned(const pcgx_kdtree *t, const float *d
   const unsigned tiles = (unsigned)((nq + kQpTile - 1) / kQpTile);
   hipLaunchKernelGGL(qp_hist_kernel, dim3(tiles), dim3(256), 0, st, d_q, nq, box, d_words);
   hipLaunchKernelGGL(qp_scatter_kernel, dim3(tiles), dim3(256), 0, st, d_q, nq, box, (const uint32_t *)d_words, d_words + 2048, d_rec);
+  static const bool refine = !(getenv("PCGX_KNN_REFINE") && getenv("PCGX_KNN_REFINE")[0] == '0');  // (measurement aid)
+  if (refine) hipLaunchKernelGGL(qp_refine_kernel, dim3(tiles), dim3(kQpRefineThreads), 0, st, d_rec, nq, box);
   {
     ProfScope prof(PCGX_PROF_KNN_GRID, st);
-    hipLaunchKernelGGL(grid_nearest_rec_kernel, dim3(xcd_grid((unsigned)((nq + kGridBlock - 1) / kGridBlock))), dim3(kGridBlock), 0, st,
+    hipLaunchKernelGGL(grid_nearest_rec_kernel, dim3(xcd_grid((unsigned)((nq + kGridRecBlock - 1) / kGridRecBlock))), dim3(kGridRecBlock), 0, st,
                        t->grid, (const float4 *)d_rec, nq, max_range_sq, d_ids, d_dsq, d_list, d_walk_count, d_words, 4096,
                        d_walk_count_next);
   }
