@@ -120,14 +120,13 @@ __device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint
   // The loop is what the searches spend their vector instructions on (the C2 search kernel: two thirds of its time is
   // vector issue), so per point, beside the distance (dx, dy as one packed operation each): the smallest and the second
   // smallest distance so far -- a minimum and a median of three, no comparison; "tied" is their equality at the end --
-  // one comparison and one select for the winner's id, one more select for where it sits when the caller wants its
-  // x, y, z (read again, once).  Whole groups of four are taken without any masking; the last, partial group reads up
-  // to three positions behind the sequence (pts[] is padded by three records, the segments behind the last used one
-  // begin at 0) and counts them as infinitely far.
+  // one comparison and one select for the winner's id (three more for its x, y, z where the caller wants them).  Whole
+  // groups of four are taken without any masking; the last, partial group reads up to three positions behind the
+  // sequence (pts[] is padded by three records, the segments behind the last used one begin at 0) and counts them as
+  // infinitely far.
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   const f32x2 qxy = {qx, qy};
-  float d1 = best.d, d2 = best.d2, bw = best.p.w;
-  uint32_t bf = 0xffffffffu;  // where the winner sits in pts[] (none of this scan's: the caller's stays)
+  float d1 = best.d, d2 = best.d2, bw = best.p.w, bx = best.p.x, by = best.p.y, bz = best.p.z;
   auto group = [&](uint32_t f0, bool partial) {
     float4 p[4];
     uint32_t at[4];
@@ -151,7 +150,9 @@ __device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint
       // selects, not branches: the lanes of a wave rarely agree on which of them improves
       const bool lt = d < d1;
       bw = lt ? p[u].w : bw;
-      bf = lt ? at[u] : bf;
+      bx = lt ? p[u].x : bx;  // (a caller that does not look at the winner's coordinates does not pay for these)
+      by = lt ? p[u].y : by;
+      bz = lt ? p[u].z : bz;
       d2 = __builtin_amdgcn_fmed3f(d1, d2, d);  // the second smallest of {d1 <= d2, d}
       d1 = fminf(d1, d);
     }
@@ -159,13 +160,7 @@ __device__ __forceinline__ void grid_scan_segments(const GridView &g, const uint
   uint32_t f0 = 0;
   for (; f0 + 4 <= total; f0 += 4) group(f0, false);
   if (f0 < total) group(f0, true);
-  if (bf != 0xffffffffu) {
-    const float4 r = g.pts[bf];
-    best.p.x = r.x;
-    best.p.y = r.y;
-    best.p.z = r.z;
-  }
-  best.p.w = bw;
+  best.p = make_float4(bx, by, bz, bw);
   best.d = d1;
   best.d2 = d2;
 }
