@@ -155,7 +155,8 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     double *__restrict__ block_partials, uint32_t *__restrict__ match_id,
     const float4 *__restrict__ normals, uint32_t *__restrict__ walk_list, uint32_t *__restrict__ walk_count,
     int32_t n_grid_rows, const uint32_t *__restrict__ orig_of = nullptr, float4 *__restrict__ match_caller = nullptr,
-    StrictWork strict_w = StrictWork(), int32_t tile_sums = 0) {
+    StrictWork strict_w = StrictWork(), int32_t tile_sums = 0, float *__restrict__ match_cert = nullptr,
+    const float *__restrict__ cert_by_id = nullptr) {
   static_assert(!(kGrid && kMinDist), "the grid answers exact-mode queries only");
   extern __shared__ uint32_t s_stack[];
   __shared__ uint32_t s_next_chunk;
@@ -255,6 +256,8 @@ __global__ __launch_bounds__(kIcpBlock) void icp_corr_kernel(
     match[i] = rec;
     if (match_caller) match_caller[orig_of[i]] = rec;  // strict sums: see icp_grid_kernel
     if (kPlane) match_id[i] = __float_as_uint(bp.w);
+    // (the walked partner's certificate, for the next iteration's grid pass: icp_grid_kernel)
+    if (match_cert) match_cert[i] = (cert_by_id && __float_as_int(bp.w) >= 0) ? cert_by_id[__float_as_uint(bp.w)] : 0.0f;
   };
   if (kGrid) {
     // icp_grid_kernel answered what the grid could certify and summed those terms; this workgroup
@@ -317,7 +320,8 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
     uint32_t *__restrict__ match_id, const float4 *__restrict__ normals, uint32_t *__restrict__ first_leaf,
     uint32_t *__restrict__ walk_list, uint32_t *__restrict__ walk_count, uint32_t n_corr_blocks,
     double *__restrict__ block_partials, unsigned long long *__restrict__ trace = nullptr,
-    const uint32_t *__restrict__ orig_of = nullptr, float4 *__restrict__ match_caller = nullptr) {
+    const uint32_t *__restrict__ orig_of = nullptr, float4 *__restrict__ match_caller = nullptr,
+    float *__restrict__ match_cert = nullptr, int caller_has_pairs = 0) {
   constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
   __shared__ float s_terms[NS][kIcpGridBlock + 16];  // + 16: the kSub-lane groups of one wave land on different banks
   // ("done" is looked at behind the target's loads, which it would only hold up: a workgroup of this kernel is five
@@ -336,28 +340,48 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
   const bool project = state->iter > 0;  // icp.go:27-30
   float x = 0.0f, y = 0.0f, z = 0.0f;
   float4 pm = make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+  float pm_cert = 0.0f;
+  const bool use_cert = !kTrace && match_cert != nullptr && grid.cert != nullptr;
   if (i < nt) {
     x = tx[i];
     y = ty[i];
     z = tz[i];
-    if (project) pm = match[i];  // previous iteration's pair (w = NaN before the first one)
+    if (project) {
+      pm = match[i];  // previous iteration's pair (w = NaN before the first one)
+      if (use_cert) pm_cert = match_cert[i];  // ... and its partner's certificate (0: none)
+    }
   }
   if (done) return;  // uniform
   if (i < nt) {
     float ub = __builtin_inff();
+    bool kept = false;  // last iteration's partner is this one's, by its certificate
+    float dm = 0.0f;
     if (project) {
       const float *m = state->trans;
       float px, py, pz;
       mat4_transform(m, x, y, z, px, py, pz);
       x = px; y = py; z = pz;
       const float dx = pm.x - x, dy = pm.y - y, dz = pm.z - z;
-      const float dm = (dx * dx + dy * dy) + dz * dz;
+      dm = (dx * dx + dy * dy) + dz * dz;  // (the scan's expression for this point: knn_grid.h)
       if (pm.w >= 0.0f && dm == dm) ub = dm;
+      // Every other base point is strictly farther from the moved target than last iteration's partner when its DistSq
+      // is below the partner's certificate (knn_grid.hip, grid_cert_kernel): Nearest returns that point again, with
+      // this distance -- no search.  (C4: 54 % of the targets in a Fit's second iteration, 98.5 % in its third, 99.9 %
+      // from the tenth on, tools/cert_probe.py; the search is 5.8 scattered loads per target, this is none.)
+      kept = pm.w >= 0.0f && dm < pm_cert && dm < kp.max_dist_sq;
     }
     float4 best = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
     float best_d = kp.max_dist_sq;
     GridTrace tr;
-    const GridVerdict v = grid_nearest(grid, x, y, z, kp.max_dist_sq, ub, best, best_d, kTrace ? &tr : nullptr);
+    GridVerdict v = GRID_FOUND;
+    if (kept) {
+      best = make_float4(pm.x, pm.y, pm.z, __int_as_float(0));  // (the id is not looked at below: match_id[] keeps it)
+      best_d = dm;
+    } else {
+      v = grid_nearest(grid, x, y, z, kp.max_dist_sq, ub, best, best_d, kTrace ? &tr : nullptr);
+    }
+    if (use_cert && !kept)  // the new partner's certificate (none: not found, left to the walk)
+      match_cert[i] = (v == GRID_FOUND && __float_as_int(best.w) >= 0) ? grid.cert[__float_as_uint(best.w)] : 0.0f;
     if (kTrace) {
       if (v == GRID_WALK) atomicAdd(&trace[0], 1ull);
       atomicAdd(&trace[1], (unsigned long long)tr.points);
@@ -381,13 +405,15 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
     } else {
       const bool found = __float_as_int(best.w) >= 0;
       const float4 bp = make_float4(best.x, best.y, best.z, found ? best_d : -1.0f);
-      match[i] = bp;
+      // (a kept pair: the point is in place, only the distance is new -- 4 bytes of each record instead of 16)
+      if (kept) reinterpret_cast<float *>(&match[i])[3] = bp.w;
+      else match[i] = bp;
       // strict sums add the pairs' terms in the CALLER's target order: the pair goes there as well (a
       // 16-byte scatter here, +6 us at C4, instead of a gather through pos_of in the terms kernel, 10 us)
-      if (!kSums && match_caller) match_caller[orig_of[i]] = bp;
-      if (kPlane) match_id[i] = __float_as_uint(best.w);
+      if (!kSums && match_caller && !(kept && caller_has_pairs)) match_caller[orig_of[i]] = bp;  // (a kept pair is there, and its reader forms the distance from the points: strict_terms.h, pair_terms)
+      if (kPlane && !kept) match_id[i] = __float_as_uint(best.w);
       if (found && kSums) {  // correspondence.go:27-29
-        if (kPlane) accumulate_plane_terms(acc, x, y, z, bp, normals[__float_as_uint(best.w)]);
+        if (kPlane) accumulate_plane_terms(acc, x, y, z, bp, normals[kept ? match_id[i] : __float_as_uint(best.w)]);
         else accumulate_terms(acc, x, y, z, bp, kp);
       }
     }
@@ -607,6 +633,7 @@ struct pcgx_icp_session {
   unsigned long long *d_valid = nullptr;  // strict: [nt_pad / 64] matched-target bits
   int64_t nt_pad = 0;
   float4 *d_match = nullptr;       // [nt] matched base point + DistSq per target
+  float *d_match_cert = nullptr;   // [nt] the matched point's certificate (GridView::cert; 0: none): icp_grid_kernel
   uint32_t *d_first_leaf = nullptr;  // [nt] leaf the target's first descent ended in (0: unknown)
   uint32_t *d_walk_list = nullptr;   // [nt] per workgroup segment: targets the grid pass left to the walk
   uint32_t *d_walk_count = nullptr;  // [grid] entries in each segment (zero between iterations)
@@ -744,6 +771,7 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   dev_cache_free(s->d_valid);
   strict_destroy(s->strict_buf);
   dev_cache_free(s->d_match);
+  dev_cache_free(s->d_match_cert);
   dev_cache_free(s->d_first_leaf);
   dev_cache_free(s->d_walk_list);
   dev_cache_free(s->d_walk_count);
@@ -810,6 +838,7 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
                            ((size_t)s->grid + (size_t)(nt / kIcpGridBlock) + 1) * s->n_sums() * sizeof(double))) != hipSuccess ||
       (e = dev_cache_alloc((void **)&s->d_pos_of, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
       (e = dev_cache_alloc((void **)&s->d_match, (size_t)(nt ? nt : 1) * sizeof(float4))) != hipSuccess ||
+      (e = dev_cache_alloc((void **)&s->d_match_cert, (size_t)(nt ? nt : 1) * sizeof(float))) != hipSuccess ||
       (e = dev_cache_alloc((void **)&s->d_first_leaf, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
       (e = dev_cache_alloc((void **)&s->d_walk_list, (size_t)(nt ? nt : 1) * sizeof(uint32_t))) != hipSuccess ||
       (e = dev_cache_alloc((void **)&s->d_walk_count, (size_t)s->grid * sizeof(uint32_t))) != hipSuccess)
@@ -843,6 +872,7 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
   if ((rc = reset_state(s, st)) != PCGX_OK) return bail(rc);
   // no previous match yet: w = NaN (icp_corr_kernel takes pruning hints from match[] only when w >= 0)
   if ((e = hipMemsetAsync(s->d_match, 0xFF, (size_t)(nt ? nt : 1) * sizeof(float4), st)) != hipSuccess ||
+      (e = hipMemsetAsync(s->d_match_cert, 0, (size_t)(nt ? nt : 1) * sizeof(float), st)) != hipSuccess ||
       (e = hipMemsetAsync(s->d_first_leaf, 0, (size_t)(nt ? nt : 1) * sizeof(uint32_t), st)) != hipSuccess ||
       (e = hipMemsetAsync(s->d_walk_count, 0, (size_t)s->grid * sizeof(uint32_t), st)) != hipSuccess)
     return bail(fail(PCGX_E_HIP, "icp session: hipMemsetAsync failed: %s", hipGetErrorString(e)));
@@ -932,6 +962,7 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   // a deletion made after the session was created: from now on the reference's patched tree is walked
   // (the same handle's Nearest / Range already do), without hints from earlier iterations
   if (!s->patched && s->base->n_deleted > 0) s->patched = true;
+  const bool caller_had_pairs = s->caller_order_fresh;  // the pass before this one left every pair in the caller's order too
   s->caller_order_fresh = false;
   s->tile_sums_fresh = false;
   if (s->patched) return enqueue_corr_patched(s, st);
@@ -972,13 +1003,16 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   // of LDS each, cost 4-6 us per iteration to find nothing to do.
   static const int left_blocks = icp_knob("PCGX_ICP_LEFTOVER_BLOCKS", 128, 8, 4096) & ~7;
   const int n_corr = (grid && s->strict && !s->plane && s->grid > left_blocks) ? left_blocks : s->grid;
+  static const bool cert_on = icp_knob("PCGX_ICP_CERT", 1, 0, 1) != 0;  // (0: every pair is searched for, as before round 5)
+  float *cert = (grid && cert_on && s->base->grid.cert) ? s->d_match_cert : nullptr;
   if (grid) {
     ProfScope prof_grid(PCGX_PROF_ICP_GRID, st);
     const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
     if (s->plane)
       hipLaunchKernelGGL(icp_grid_kernel<true>, dim3(xcd_grid(gb)), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
                          s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
-                         s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
+                         s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials, (unsigned long long *)nullptr,
+                         (const uint32_t *)nullptr, (float4 *)nullptr, cert);
     else if (s->strict)
       hipLaunchKernelGGL((icp_grid_kernel<false, false, false>),
                          dim3(xcd_grid((unsigned)((s->nt + kIcpStrictGridBlock - 1) / kIcpStrictGridBlock))),
@@ -986,11 +1020,12 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
                          s->nt, s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals,
                          s->d_first_leaf, s->d_walk_list, s->d_walk_count, (uint32_t)n_corr, s->d_partials,
                          (unsigned long long *)nullptr, (const uint32_t *)(s->caller_order_fresh ? s->d_orig_of : nullptr),
-                         s->caller_order_fresh ? s->d_match_caller : nullptr);
+                         s->caller_order_fresh ? s->d_match_caller : nullptr, cert, caller_had_pairs ? 1 : 0);
     else
       hipLaunchKernelGGL(icp_grid_kernel<false>, dim3(xcd_grid(gb)), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
                          s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
-                         s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials);
+                         s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials, (unsigned long long *)nullptr,
+                         (const uint32_t *)nullptr, (float4 *)nullptr, cert);
   }
   // timed (pcgx_prof_enable) when it is the kernel that does the work: with the grid pass before it
   // it walks next to nothing, and a second pair of events per step costs more than it
@@ -1004,12 +1039,13 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
                        (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock),                                        \
                        (const uint32_t *)(s->caller_order_fresh ? s->d_orig_of : nullptr),                            \
                        s->caller_order_fresh ? s->d_match_caller : nullptr, strict_w,                                 \
-                       (int32_t)((GR) && s->tile_sums_fresh ? 1 : 0));                                                \
+                       (int32_t)((GR) && s->tile_sums_fresh ? 1 : 0), cert, s->base->grid.cert);                      \
   else                                                                                                                \
   hipLaunchKernelGGL((icp_corr_kernel<MD, PL, GR>), dim3(s->grid), dim3(kIcpBlock), lds, st, tv, x, y, z, s->nt,     \
                      s->d_state, s->kp, s->d_match, s->d_first_leaf, s->d_partials, s->d_match_id,                   \
                      (const float4 *)s->d_normals, s->d_walk_list, s->d_walk_count,                                  \
-                     (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock));                                         \
+                     (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock), (const uint32_t *)nullptr,               \
+                     (float4 *)nullptr, StrictWork(), 0, cert, s->base->grid.cert);                                   \
   } while (0)
   if (s->plane) {
     if (grid) PCGX_LAUNCH_CORR(false, true, true);

@@ -56,6 +56,43 @@ __global__ __launch_bounds__(256) void grid_start_kernel(const uint32_t *__restr
   }
 }
 
+// A point's certificate (GridView::cert): p is the nearest base point of EVERY query q whose computed DistSq(q, p) is
+// below cert[p].  In real numbers: with rho the distance from p to its nearest other point and |q - p| < rho / 2, any
+// other point p' has |q - p'| >= rho - |q - p| > |q - p|.  In float32, with margins that swallow every rounding on the
+// way (a computed DistSq is within 3e-7 of the real one): cert = 0.24 L^2 where L^2 is a lower bound of rho^2 -- the
+// smallest computed DistSq to the other points of the 3 x 3 x 3 cells around p, less 2e-6 of itself, or (0.999 h)^2
+// where that is smaller (a point outside those cells is a cell's edge away).  |q - p| < 0.49 L then, every other point
+// is more than 1.04 times as far, its computed DistSq more than 1.07 times the one of p: strictly larger, no tie.  A
+// point with a twin (rho = 0) has cert 0: never certified.  The ICP loop keeps a pair on this alone (icp.hip).
+__global__ __launch_bounds__(256) void grid_cert_kernel(GridView g, int64_t n, float *__restrict__ cert) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= n) return;
+  const float4 p = g.pts[f];
+  const int cx = grid_cell(p.x, g.lo[0], g.inv_h, g.nx), cy = grid_cell(p.y, g.lo[1], g.inv_h, g.ny),
+            cz = grid_cell(p.z, g.lo[2], g.inv_h, g.nz);
+  const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+  float dmin = __builtin_inff();
+  for (int z = max(cz - 1, 0); z <= min(cz + 1, g.nz - 1); z++)
+    for (int y = max(cy - 1, 0); y <= min(cy + 1, g.ny - 1); y++) {
+      const uint32_t row = (uint32_t)((z * g.ny + y) * g.nx);
+      const uint32_t s = g.start[row + (uint32_t)x0], e = g.start[row + (uint32_t)x1 + 1u];
+      for (uint32_t k = s; k < e; k++) {
+        if ((int64_t)k == f) continue;
+        const float4 o = g.pts[k];
+        const float dx = o.x - p.x, dy = o.y - p.y, dz = o.z - p.z;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        dmin = d < dmin ? d : dmin;  // (NaN never: the grid holds finite points only)
+      }
+    }
+  // (a cell's edge in coordinates: the cell numbers are rounded products of up to max(nx, ny, nz), their rounding is
+  // part of the margin)
+  const float slack = 1.0f - 1.0e-3f - 4.0e-7f * (float)max(g.nx, max(g.ny, g.nz));
+  const float edge = slack * g.h;
+  float l2 = fminf(dmin - 2.0e-6f * dmin, edge * edge);
+  if (!(l2 > 0.0f) || !(slack > 0.5f)) l2 = 0.0f;
+  cert[__float_as_int(p.w)] = 0.24f * l2;  // by the point's id (ids are 0 .. n - 1: grid_build makes no certificates for labelled trees)
+}
+
 // One query per lane.  Certified answers are written; the rest is appended to walk_list (query
 // indices) for the tree walk.
 template <bool kWhy>
@@ -391,8 +428,10 @@ __global__ __launch_bounds__(kGridRecBlock) void grid_nearest_rec_kernel(GridVie
 void grid_free(pcgx_kdtree *t) {
   dev_cache_free(t->d_gpts);
   dev_cache_free(t->d_gstart);
+  dev_cache_free(t->d_gcert);
   t->d_gpts = nullptr;
   t->d_gstart = nullptr;
+  t->d_gcert = nullptr;
   t->grid_ok = false;
 }
 
@@ -518,6 +557,15 @@ pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labe
   g.pts = t->d_gpts;
   hipLaunchKernelGGL(grid_gather_kernel, dim3(nb), dim3(256), 0, st, d_xyz, (const uint32_t *)vals[res], d_labels, n,
                      t->d_gpts);
+  // the points' certificates (not required: without them every pair is searched for)
+  g.cert = nullptr;
+  if (d_labels == nullptr && dev_cache_alloc((void **)&t->d_gcert, (size_t)n * sizeof(float)) == hipSuccess) {
+    hipLaunchKernelGGL(grid_cert_kernel, dim3(nb), dim3(256), 0, st, g, n, t->d_gcert);
+    g.cert = t->d_gcert;
+  } else {
+    (void)hipGetLastError();
+    t->d_gcert = nullptr;
+  }
   PCGX_HIP_TRY(hipStreamSynchronize(st));  // vals[] live in the arena
   t->grid = g;
   // clouds that still crowd their cells (tight clusters) are better served by the tree
@@ -526,8 +574,10 @@ pcgx_status grid_build(pcgx_kdtree *t, const float *d_xyz, const int32_t *d_labe
   if (!t->grid_ok) {
     dev_cache_free(t->d_gpts);
     dev_cache_free(t->d_gstart);
+    dev_cache_free(t->d_gcert);
     t->d_gpts = nullptr;
     t->d_gstart = nullptr;
+    t->d_gcert = nullptr;
   }
   return PCGX_OK;
 }

@@ -194,6 +194,8 @@ struct TreeView {
 struct GridView {
   const float4 *pts;      // [n] {x, y, z, bits(id)} in cell order
   const uint32_t *start;  // [cells + 1] first point of each cell, cell = (z * ny + y) * nx + x
+  const float *cert;      // [n] by point id: a query whose DistSq to the point is below this has it as its nearest
+                          // (knn_grid.hip, grid_cert_kernel); nullptr: not made (labelled trees)
   float lo[3];
   float h, inv_h;  // cell edge
   int32_t nx, ny, nz;
@@ -444,6 +446,7 @@ struct pcgx_kdtree {
   // uniform grid of the certified-nearest fast path (knn_grid.h); grid_ok false: tree walk only
   float4 *d_gpts = nullptr;
   uint32_t *d_gstart = nullptr;
+  float *d_gcert = nullptr;
   pcgx::GridView grid;
   bool grid_ok = false;
   double grid_crowding = 0.0;  // mean number of other points in a point's cell

@@ -261,8 +261,15 @@ __device__ __forceinline__ bool pair_terms(const TermSrc &S, float x0, float y0,
     x0 = px; y0 = py; z0 = pz;
   }
   const float x1 = b.x, y1 = b.y, z1 = b.z;
-  const float w = eval_weight_fn(S.weight_fn, S.weight_a, b.w);  // evaluator.go:130
-  t[0] = w * b.w;
+  // The pair's DistSq is formed again here, from the two points, by the expression the searches use (knn_grid.h,
+  // knn_walk.h: mat/vec3.go:18-20,38-40) -- the same bits as the search returned, since the operands are the same
+  // floats.  b.w only says that there is a pair: a target that keeps its partner from one iteration to the next
+  // (icp.hip, the certificate) then has nothing to write into the caller-order copy of the pairs, which was a
+  // million scattered 4-byte stores per iteration.  (strict_check.hip adds the stored distances: the cross-check.)
+  const float ddx = x1 - x0, ddy = y1 - y0, ddz = z1 - z0;
+  const float dsq = (ddx * ddx + ddy * ddy) + ddz * ddz;
+  const float w = eval_weight_fn(S.weight_fn, S.weight_a, dsq);  // evaluator.go:130
+  t[0] = w * dsq;
   t[1] = w * (x0 - x1);
   t[2] = w * (y0 - y1);
   t[3] = w * (z0 - z1);
