@@ -561,7 +561,7 @@ def main():
     L.check(L.lib().pcgx_debug_shard_stats(L.ptr(shard_stats), 0))
 
     # What the grid pass reads per iteration (an untimed Fit, one instrumented launch before each step)
-    grid_pts = grid_words = grid_walked = 0
+    grid_pts = grid_words = grid_walked = grid_kept = 0
     have_grid = "icp_grid_kernel" in kernel_ms
     if have_grid:
         L.check(L.lib().pcgx_icp_session_reset(sess._h, L.ptr(stream)))
@@ -571,6 +571,7 @@ def main():
             grid_walked += g[1]
             grid_pts += g[2]
             grid_words += g[3]
+            grid_kept += g[5]
             step()
         barrier()
 
@@ -628,9 +629,15 @@ def main():
                         "kernel of this step; the sums' kernels are latency-bound (8 workgroups walk the chain)"}
         if have_grid:
             v_pts, v_words = grid_pts / (its * n_tile), grid_words / (its * n_tile)
-            roof["grid_pass"] = {"point_records_per_target": v_pts, "bound_words_per_target": v_words,
+            kept_share = grid_kept / (its * n_tile)
+            roof["grid_pass"] = {"point_records_per_searched_target": v_pts, "bound_words_per_searched_target": v_words,
                                  "targets_left_to_walk_per_fit": grid_walked,
-                                 "bytes_the_kernel_chooses_to_read": (12 + 16 * (its - 1) / its + 16 + 16 * v_pts + 4 * v_words) * n_tile}
+                                 "share_of_targets_kept_on_a_certificate_without_a_search": kept_share,
+                                 "bytes_the_kernel_chooses_to_read": (12 + 20 * (its - 1) / its + 16
+                                                                      + (1.0 - kept_share) * (16 * v_pts + 4 * v_words)) * n_tile,
+                                 "what": "a target whose DistSq to last iteration's partner is below the partner's certificate keeps "
+                                         "it (csrc/knn_grid.hip, grid_cert_kernel); the records and words are those of the targets "
+                                         "that are searched for"}
         mode = ("reference: the evaluator's sequential float32 sums, bit-identical to the Go code (the library's default; "
                 "tests/test_gpu_icp.py)"
                 if strict else "f64-tree: float64 reduction of the reference's float32 terms (differs from the Go code by "

@@ -156,11 +156,18 @@ PCGX_API pcgx_status pcgx_debug_walk_stats(const pcgx_kdtree *t, const float *d_
 PCGX_API pcgx_status pcgx_debug_grid_stats(const pcgx_kdtree *t, const float *d_q, int64_t nq, float max_range,
                                            int64_t out[14]);
 
+/* Test aid: the points' certificates (csrc/knn_grid.hip, grid_cert_kernel), by point id, n floats into host memory.
+ * A query whose DistSq to point i is below cert[i] has i as its one nearest base point; 0: no certificate (a point
+ * with a twin).  PCGX_E_INVALID when the tree has none (no grid, labelled points). */
+PCGX_API pcgx_status pcgx_debug_grid_cert(const pcgx_kdtree *t, float *cert, int64_t n);
+
 /* Measurement aid: what the grid pass of the session's NEXT iteration would read, without changing
  * the session: out = {targets, targets left to the walk, point records read, cell-bound words read,
- * lane-slots its scan loops run (64 per round of 4 records per wave, idle lanes included)}. */
+ * lane-slots its scan loops run (64 per round of 4 records per wave, idle lanes included), targets that keep last
+ * iteration's partner on its certificate and are not searched for at all (the counts before it are those of searching
+ * for every target)}. */
 typedef struct pcgx_icp_session pcgx_icp_session;
-PCGX_API pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream, int64_t out[5]);
+PCGX_API pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream, int64_t out[6]);
 
 /* Measurement aid: counters of the strict sums (set_strict 1) since the last call: out = {runs
  * applied, runs whose record did not cover the state, tiles recomputed exactly, leaves of those added

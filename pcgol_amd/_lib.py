@@ -156,6 +156,7 @@ SIGNATURES = {
     "pcgx_kdtree_points": (_i32, [_vp, _vp, _i64, _vp]),
     "pcgx_debug_icp_grid_stats": (_i32, [_vp, _vp, C.POINTER(_i64)]),
     "pcgx_debug_grid_stats": (_i32, [_vp, _vp, _i64, C.c_float, C.POINTER(_i64)]),
+    "pcgx_debug_grid_cert": (_i32, [_vp, _vp, _i64]),
     "pcgx_kdtree_dump": (_i32, [_vp, _vp, _i64, C.POINTER(_i64)]),
     "pcgx_kdtree_delete_points": (_i32, [_vp, _vp, _i64]),
     "pcgx_kdtree_live_count": (_i32, [_vp, C.POINTER(_i64)]),

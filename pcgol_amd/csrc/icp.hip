@@ -369,6 +369,8 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
       // this distance -- no search.  (C4: 54 % of the targets in a Fit's second iteration, 98.5 % in its third, 99.9 %
       // from the tenth on, tools/cert_probe.py; the search is 5.8 scattered loads per target, this is none.)
       kept = pm.w >= 0.0f && dm < pm_cert && dm < kp.max_dist_sq;
+      if (kTrace && match_cert != nullptr && grid.cert != nullptr && pm.w >= 0.0f && dm < match_cert[i] && dm < kp.max_dist_sq)
+        atomicAdd(&trace[36], 1ull);  // (the trace counts what a certificate would keep and searches all the same)
     }
     float4 best = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
     float best_d = kp.max_dist_sq;
@@ -1572,22 +1574,23 @@ extern "C" pcgx_status pcgx_icp_pairs(const pcgx_kdtree *base, const float *targ
 }
 
 // Measurement aid: see include/pcgx.h.
-extern "C" pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream, int64_t out[5]) {
+extern "C" pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stream, int64_t out[6]) {
   PCGX_API_LOCK();
   if (!s || !out) return fail(PCGX_E_INVALID, "pcgx_debug_icp_grid_stats: NULL argument");
   out[0] = s->nt;
-  out[1] = out[2] = out[3] = out[4] = 0;
+  out[1] = out[2] = out[3] = out[4] = out[5] = 0;
   if (s->patched || !grid_enabled(s->base) || s->kp.min_dist_sq > 0.0f || s->nt == 0) return PCGX_OK;
   hipStream_t st = pick_stream(stream);
   unsigned long long *d_trace = nullptr;
-  PCGX_HIP_TRY(dev_cache_alloc((void **)&d_trace, 36 * sizeof(unsigned long long)));
-  PCGX_HIP_TRY(hipMemsetAsync(d_trace, 0, 36 * sizeof(unsigned long long), st));
+  PCGX_HIP_TRY(dev_cache_alloc((void **)&d_trace, 40 * sizeof(unsigned long long)));
+  PCGX_HIP_TRY(hipMemsetAsync(d_trace, 0, 40 * sizeof(unsigned long long), st));
   const float *x = s->d_xyz, *y = s->d_xyz + s->nt, *z = s->d_xyz + 2 * s->nt;
   const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
   hipLaunchKernelGGL((icp_grid_kernel<false, true>), dim3(xcd_grid(gb)), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
                      s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
-                     s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials, d_trace);
-  unsigned long long h[36];
+                     s->d_walk_list, s->d_walk_count, (uint32_t)s->grid, s->d_partials, d_trace, (const uint32_t *)nullptr,
+                     (float4 *)nullptr, s->base->grid.cert ? s->d_match_cert : nullptr);
+  unsigned long long h[40];
   hipError_t e = hipMemcpyAsync(h, d_trace, sizeof h, hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   dev_cache_free(d_trace);
@@ -1596,6 +1599,7 @@ extern "C" pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stre
   out[2] = (int64_t)h[1];
   out[3] = (int64_t)h[2];
   out[4] = (int64_t)h[3];
+  out[5] = (int64_t)h[36];
   if (getenv("PCGX_GRID_TRACE_PRINT"))
     for (int b = 0; b < 2; b++) {
       fprintf(stderr, "%d-segment scan per target: none %.4f, rounds of 4:", b ? 9 : 4, (double)h[4 + 16 * b] / (double)s->nt);

@@ -650,6 +650,15 @@ pcgx_status grid_launch_nearest_partitioned(const pcgx_kdtree *t, const float *d
 
 }  // namespace pcgx
 
+extern "C" pcgx_status pcgx_debug_grid_cert(const pcgx_kdtree *t, float *cert, int64_t n) {
+  PCGX_API_LOCK();
+  if (!t || !cert || n != t->n) return pcgx::fail(PCGX_E_INVALID, "pcgx_debug_grid_cert: bad argument");
+  if (!pcgx::grid_enabled(t) || !t->d_gcert) return pcgx::fail(PCGX_E_INVALID, "pcgx_debug_grid_cert: the tree has no certificates");
+  PCGX_TRY(pcgx::ensure_init());
+  PCGX_HIP_TRY(hipMemcpy(cert, t->d_gcert, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  return PCGX_OK;
+}
+
 // Debug / tuning aid (not part of the drop-in surface): how many of the queries the grid pass leaves
 // to the tree walk, and the tree's grid parameters.  out[0] = queries left to the walk, out[1] =
 // cells, out[2] = crowding * 1000, out[3] = grid enabled, out[4 + k] = queries with reason k (knn_grid.h,

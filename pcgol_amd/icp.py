@@ -249,9 +249,9 @@ class IcpSession:
 
     def grid_stats(self, stream=0):
         """Measurement aid: (targets, targets left to the walk, point records, cell-bound words,
-        lane-slots of the scan loops) the grid pass of the NEXT iteration would read; zeros when the
-        base tree has no grid."""
-        out = (C.c_int64 * 5)()
+        lane-slots of the scan loops, targets kept on their partner's certificate without a search)
+        of the grid pass of the NEXT iteration; zeros when the base tree has no grid."""
+        out = (C.c_int64 * 6)()
         L.check(L.lib().pcgx_debug_icp_grid_stats(self._h, L.ptr(stream) if stream else None, out))
         return tuple(out)
 

@@ -302,3 +302,48 @@ def test_large_batch_partitioned_by_coarse_cell_equals_the_oracle():
         nan = np.isnan(od)
         assert np.array_equal(np.isnan(dsq), nan), max_range                       # (a NaN's payload is not pinned)
         assert np.array_equal(dsq[~nan].view(np.uint32), od[~nan].view(np.uint32)), max_range
+
+
+def test_point_certificates_hold_against_brute_force(monkeypatch):
+    """GridView::cert (csrc/knn_grid.hip, grid_cert_kernel; what lets the ICP loop keep a pair without a search): a query
+    whose float32 DistSq to base point i is below cert[i] has i as its ONE nearest point -- every other point's
+    float32 DistSq is strictly larger.  Checked against brute force on a cloud with a cluster, a sparse corner, twins
+    (cert 0) and a lattice patch (many points at exactly equal distances), with queries placed just inside the bound."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(11)
+    pts = np.concatenate([
+        rng.random((20000, 3)) * 4.0,                               # the cloud
+        rng.random((3000, 3)) * 0.05 + 1.0,                         # a tight cluster
+        rng.random((40, 3)) * 3.0 + 6.0,                            # a sparse corner
+        np.stack(np.meshgrid(*[np.arange(8) * 0.125 + 2.0] * 3), -1).reshape(-1, 3),   # a lattice patch
+    ]).astype(np.float32)
+    pts = np.concatenate([pts, pts[:50]])                           # twins of the first fifty points
+    monkeypatch.setenv("PCGX_GRID", "2")                            # (the grid is kept whatever the cluster does to its cells)
+    t = kdtree.New(pts)
+    cert = np.empty(len(pts), np.float32)
+    L.check(L.lib().pcgx_debug_grid_cert(t._h, L.ptr(cert), len(pts)))
+    assert np.all(cert >= 0.0) and np.all(np.isfinite(cert))
+    assert np.all(cert[:50] == 0.0) and np.all(cert[-50:] == 0.0)   # twins: never certified
+    tree = cKDTree(pts.astype(np.float64))
+    d2nn = tree.query(pts.astype(np.float64), k=2)[0][:, 1] ** 2
+    assert np.all(cert <= 0.25 * d2nn * (1.0 + 1e-5))               # never beyond half the way to the nearest other point
+    assert np.mean(cert > 0.0) > 0.9                                 # and most points have one
+    # queries at 0.97 of the bound, in random directions: float32 DistSq as the searches form it, brute force over all points
+    idx = rng.choice(len(pts), 400, replace=False)
+    idx = idx[cert[idx] > 0.0]
+    dirs = rng.normal(size=(len(idx), 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    q = (pts[idx].astype(np.float64) + dirs * (np.sqrt(cert[idx].astype(np.float64)) * 0.97)[:, None]).astype(np.float32)
+    f = np.float32
+    for k, i in enumerate(idx):
+        d = pts - q[k]                                              # float32 throughout, (dx^2 + dy^2) + dz^2
+        dsq = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        if dsq[i] < cert[i]:
+            others = np.delete(dsq, i)
+            assert others.min() > dsq[i], (i, dsq[i], others.min(), cert[i])
+    # and the library's own Nearest agrees on those queries
+    ids, dsq = t.NearestBatch(q, 100.0)
+    d = pts[idx] - q
+    mine = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    ok = mine < cert[idx]
+    assert np.array_equal(np.asarray(ids)[ok], idx[ok]) and np.array_equal(np.asarray(dsq, np.float32)[ok], mine[ok])

@@ -591,3 +591,31 @@ def test_chain_kernel_chunks_hand_the_walk_on():
         assert st[62] == 0 and st[63] == 0, (k, st[60:64])
     a.close()
     b.close()
+
+
+def test_pairs_kept_on_certificates_are_the_searched_ones():
+    """From a Fit's second iteration on a target keeps last iteration's partner when its DistSq to it is below the
+    partner's certificate (csrc/icp.hip, icp_grid_kernel; csrc/knn_grid.hip, grid_cert_kernel) -- no search.  On a cloud
+    with twins and a lattice patch (exact ties: never certified): the share that is kept grows over the iterations,
+    and the Fit is the oracle's bit for bit (every kept pair is the pair a search would have returned)."""
+    rng = np.random.default_rng(3)
+    base = np.concatenate([
+        synth.uniform_cloud(60_000, 4.0, 21),
+        np.stack(np.meshgrid(*[np.arange(10, dtype=np.float32) * np.float32(0.0625) + np.float32(1.0)] * 3), -1).reshape(-1, 3),
+    ]).astype(np.float32)
+    base = np.ascontiguousarray(np.concatenate([base, base[:200]]))                  # twins
+    target = synth.transform_points(synth.icp_pose(), base[rng.permutation(len(base))[:50_000]])
+    w, th = np.full(6, 0.3, np.float32), np.full(6, -1.0, np.float32)
+    t = kdtree.New(base)
+    s = icp.IcpSession(t, target, 0.5, 6, w, th, 12)
+    kept = []
+    for it in range(12):
+        kept.append(s.grid_stats()[5])
+        s.step()
+    trans, st, _ = s.result()
+    assert kept[0] == 0 and kept[1] > 0.3 * len(target) and kept[-1] > 0.9 * len(target), kept
+    o = O.icp_fit(O.KDTree(base), target, 0.5, 6, w, th, 12, sums_mode=0)
+    assert st.NumIteration == o["num_iteration"] == 12
+    assert np.array_equal(np.asarray(trans).ravel(), np.asarray(o["trans"]).ravel())
+    assert np.float32(st.Evaluated.Value) == o["value"]
+    assert np.array_equal(np.asarray(st.Evaluated.Gradient, np.float32), o["gradient"])
