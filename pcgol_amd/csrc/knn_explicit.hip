@@ -19,6 +19,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -282,6 +284,38 @@ void xtree_delete_batch(pcgx_kdtree *t, const int64_t *ids, int64_t m) {
     fill();
     for (auto &x : th) x.join();
   }
+  // The call's threads are started once and handed one piece of work after the other (a generation counter they poll:
+  // the call is ten milliseconds long, starting fifteen threads per phase was a tenth of that).
+  struct Pool {
+    std::vector<std::thread> th;
+    std::atomic<int> gen{0}, finished{0};
+    std::atomic<bool> stop{false};
+    std::function<void(int)> job;
+    explicit Pool(int n) {
+      for (int k = 1; k < n; k++)
+        th.emplace_back([this, k]() {
+          int seen = 0;
+          for (;;) {
+            while (gen.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_acquire)) std::this_thread::yield();
+            if (stop.load(std::memory_order_acquire)) return;
+            seen++;
+            job(k);
+            finished.fetch_add(1, std::memory_order_release);
+          }
+        });
+    }
+    void run(const std::function<void(int)> &f) {  // f(0) on the caller's thread, f(1 ..) on the others; returns when all are through
+      job = f;
+      finished.store(0, std::memory_order_relaxed);
+      gen.fetch_add(1, std::memory_order_release);
+      f(0);
+      while (finished.load(std::memory_order_acquire) != (int)th.size()) std::this_thread::yield();
+    }
+    ~Pool() {
+      stop.store(true, std::memory_order_release);
+      for (auto &x : th) x.join();
+    }
+  } pool(nth);
   std::vector<uint8_t> is_above((size_t)t->n, 0);  // the ids that sit above the cut now
   auto top_ids = [&]() {  // the ids that sit above the cut NOW (nodes still attached)
     std::vector<int32_t> v;
@@ -299,34 +333,41 @@ void xtree_delete_batch(pcgx_kdtree *t, const int64_t *ids, int64_t m) {
   };
   std::vector<int32_t> above = top_ids();
   for (int32_t id : above) is_above[(size_t)id] = 1;
-  std::vector<std::vector<int32_t>> bucket(subs.size());
-  for (auto &b : bucket) b.reserve((size_t)(m / (int64_t)subs.size() + m / (4 * (int64_t)subs.size()) + 16));
-  auto flush = [&]() {
+  // bucket[k][j]: thread k's share of a window of the ids, those of subtree j, in call order; the threads' shares one
+  // behind the other are the window's order
+  const size_t ns = subs.size();
+  std::vector<std::vector<std::vector<int32_t>>> bucket((size_t)nth, std::vector<std::vector<int32_t>>(ns));
+  std::vector<int64_t> first_top((size_t)nth);
+  int n_flush = 0;
+  auto flush = [&](int upto_thread) {  // the deletions bucketed by threads 0 .. upto_thread, subtree by subtree
+    n_flush++;
     std::vector<size_t> work;
-    for (size_t j = 0; j < subs.size(); j++)
-      if (!bucket[j].empty()) work.push_back(j);
+    for (size_t j = 0; j < ns; j++)
+      for (int k = 0; k <= upto_thread; k++)
+        if (!bucket[(size_t)k][j].empty()) {
+          work.push_back(j);
+          break;
+        }
     if (work.empty()) return;
-    std::vector<int32_t> new_root(subs.size());
+    std::vector<int32_t> new_root(ns);
     std::atomic<size_t> next{0};
-    auto run = [&]() {
+    pool.run([&](int) {
       for (size_t w = next++; w < work.size(); w = next++) {
         const size_t j = work[w];
         int32_t r = subs[j].root;
-        for (int32_t pid : bucket[j]) {
-          if (r < 0) break;  // (the subtree is gone: nothing left to find)
-          r = delete_node(t, r, pid);
-        }
+        for (int k = 0; k <= upto_thread && r >= 0; k++)
+          for (int32_t pid : bucket[(size_t)k][j]) {
+            if (r < 0) break;  // (the subtree is gone: nothing left to find)
+            r = delete_node(t, r, pid);
+          }
         new_root[j] = r;
       }
-    };
-    std::vector<std::thread> th;
-    const int use = (int)std::min<size_t>((size_t)nth, work.size());
-    for (int k = 1; k < use; k++) th.emplace_back(run);
-    run();
-    for (auto &x : th) x.join();
+    });
     // a subtree that went empty: its parent's link (deleteNodeImpl's `n.children[k] = child` with child == nil)
     for (size_t j : work) {
-      if (new_root[j] >= 0) continue;
+      if (new_root[j] >= 0) {
+        continue;
+      }
       const int32_t r = subs[j].root;
       if (t->xroot == r) t->xroot = -1;
       for (int32_t p : top) {
@@ -335,24 +376,48 @@ void xtree_delete_batch(pcgx_kdtree *t, const int64_t *ids, int64_t m) {
         if (nd.c1 == r) nd.c1 = -1;
       }
     }
-    for (size_t j : work) bucket[j].clear();
   };
-  for (int64_t i = 0; i < m; i++) {
-    const int32_t pid = (int32_t)ids[i];
-    if (is_above[(size_t)pid]) {
-      flush();
-      t->xroot = delete_node(t, t->xroot, pid);  // (reads and writes across the cut: alone)
-      for (int32_t id : above) is_above[(size_t)id] = 0;
-      above = top_ids();
-      for (int32_t id : above) is_above[(size_t)id] = 1;
+  // Windows of the ids, a slice per thread: every thread buckets its slice up to the first id that sits above the cut;
+  // what lies in front of the FIRST such id of the window is flushed, that deletion is carried out alone, and the next
+  // window begins behind it (the slices behind it were bucketed for nothing: a few times per call).
+  const int64_t window = (int64_t)nth * 8192;
+  for (int64_t w0 = 0; w0 < m;) {
+    const int64_t w1 = std::min(m, w0 + window);
+    pool.run([&](int k) {
+      const int64_t a = w0 + (w1 - w0) * k / nth, b = w0 + (w1 - w0) * (k + 1) / nth;
+      auto &mine = bucket[(size_t)k];
+      for (auto &v : mine) v.clear();
+      first_top[(size_t)k] = -1;
+      for (int64_t i = a; i < b; i++) {
+        const int32_t pid = (int32_t)ids[i];
+        if (is_above[(size_t)pid]) {
+          first_top[(size_t)k] = i;
+          return;
+        }
+        // the subtree the point's original node lies in (255: an original node above the cut whose point has been
+        // deleted already -- nothing to find)
+        const uint8_t j = t->xsub[(size_t)pid];
+        if (j != 255) mine[j].push_back(pid);
+      }
+    });
+    int hit = -1;
+    for (int k = 0; k < nth && hit < 0; k++)
+      if (first_top[(size_t)k] >= 0) hit = k;
+    if (hit < 0) {
+      flush(nth - 1);
+      w0 = w1;
       continue;
     }
-    // the subtree the point's original node lies in (255: an original node above the cut whose point has been
-    // deleted already -- nothing to find)
-    const uint8_t j = t->xsub[(size_t)pid];
-    if (j != 255) bucket[j].push_back(pid);
+    flush(hit);
+    const int64_t i = first_top[(size_t)hit];
+    t->xroot = delete_node(t, t->xroot, (int32_t)ids[i]);  // (reads and writes across the cut: alone)
+    for (int32_t id : above) is_above[(size_t)id] = 0;
+    above = top_ids();
+    for (int32_t id : above) is_above[(size_t)id] = 1;
+    w0 = i + 1;
   }
-  flush();
+  if (getenv("PCGX_DELETE_TRACE"))
+    fprintf(stderr, "delete batch: %lld ids, %d flushes, %d threads, %zu subtrees\n", (long long)m, n_flush, nth, ns);
 }
 
 namespace {
