@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
     uint32_t *__restrict__ walk_list, uint32_t *__restrict__ walk_count, uint32_t n_corr_blocks,
     double *__restrict__ block_partials, unsigned long long *__restrict__ trace = nullptr,
     const uint32_t *__restrict__ orig_of = nullptr, float4 *__restrict__ match_caller = nullptr,
-    float *__restrict__ match_cert = nullptr, int caller_has_pairs = 0) {
+    float *__restrict__ match_cert = nullptr, int caller_has_pairs = 0, int walk_follows = 1, int test_force_walk = 0) {
   constexpr int NS = kPlane ? (int)P_COUNT : (int)S_COUNT;
   __shared__ float s_terms[NS][kIcpGridBlock + 16];  // + 16: the kSub-lane groups of one wave land on different banks
   // ("done" is looked at behind the target's loads, which it would only hold up: a workgroup of this kernel is five
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
       best_d = dm;
     } else {
       v = grid_nearest(grid, x, y, z, kp.max_dist_sq, ub, best, best_d, kTrace ? &tr : nullptr);
+      if (test_force_walk && project && i % test_force_walk == 0) v = GRID_WALK;  // (tests: targets for the walk where the grid leaves none)
     }
     if (use_cert && !kept)  // the new partner's certificate (none: not found, left to the walk)
       match_cert[i] = (v == GRID_FOUND && __float_as_int(best.w) >= 0) ? grid.cert[__float_as_uint(best.w)] : 0.0f;
@@ -397,6 +398,10 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
       const int64_t r_begin = (int64_t)begin * 64;
       walk_list[r_begin + atomicAdd(&walk_count[slot], 1u)] = (uint32_t)(i - r_begin);
       first_leaf[i] = kSums ? 0x80000000u : 0u;  // "walked this iteration" (icp_corr_kernel adds its terms)
+      // No walk was launched behind this pass (enqueue_corr: it finds nothing to do in iteration after iteration, and
+      // the host cannot know): the step ends here -- `done` 2 makes every kernel behind this one return, this step's
+      // and the later ones' -- and the host enqueues it again, with the walk, when it next looks (settle()).
+      if (!walk_follows) const_cast<IcpState *>(state)->done = 2;
       // strict sums: the float64 tile sums (guesses only) are formed by icp_corr_kernel's workgroups while others
       // of them still walk; until the walk's answer arrives the target stands with the best point the grid has
       // seen -- usually the answer -- instead of last iteration's pair (none at all in a Fit's first iteration)
@@ -644,6 +649,8 @@ struct pcgx_icp_session {
   double *d_xchg = nullptr;  // sharded float64 steps: the sums + the ranks' error flag, what the all-reduce carries
   int32_t steps_sharded = 0; // sharded steps enqueued (fault injection of the tests counts them)
   int32_t host_iter = 0;     // Evaluates enqueued since the session was made / reset (0: the next one sees the raw target)
+  bool spec_walk = true;     // the leftover walk is not launched behind a grid pass from a Fit's second Evaluate on (enqueue_corr)
+  bool spec_pending = false; // ... and steps enqueued that way have not been looked at yet (settle())
   bool shard_failed = false; // this rank could not go on: it keeps calling the collectives with its flag up
   bool plane = false;              // point-to-plane / Gauss-Newton session (30 sums)
   uint32_t *d_match_id = nullptr;  // plane: [nt] matched base id
@@ -653,6 +660,8 @@ struct pcgx_icp_session {
   IcpKernelParams kp;
   int32_t max_iteration = 20;
 };
+
+static pcgx_status settle(pcgx_icp_session *s, hipStream_t st);
 
 static IcpKernelParams make_kernel_params(const pcgx_icp_params *p) {
   IcpKernelParams kp;
@@ -691,6 +700,10 @@ static pcgx_status reset_state(pcgx_icp_session *s, hipStream_t st) {
   hipLaunchKernelGGL(icp_reset_kernel, dim3(1), dim3(64), 0, st, s->d_state);
   PCGX_HIP_TRY(hipGetLastError());
   s->host_iter = 0;
+  if (s->spec_pending) {  // (steps enqueued without the leftover walk and never looked at: whatever they left in the lists)
+    s->spec_pending = false;
+    if (s->d_walk_count) PCGX_HIP_TRY(hipMemsetAsync(s->d_walk_count, 0, (size_t)s->grid * sizeof(uint32_t), st));
+  }
   if (s->shard_failed || s->steps_sharded > 0) {  // (a sharded Fit may have ended inside a launch: its counters)
     PCGX_TRY(strict_reset(s->strict_buf, st));
     s->shard_failed = false;
@@ -710,6 +723,7 @@ extern "C" pcgx_status pcgx_icp_session_set_pose(pcgx_icp_session *s, const floa
   PCGX_API_LOCK();
   if (!s || !trans16 || iter < 0) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_pose: bad argument");
   hipStream_t st = pick_stream(stream);
+  PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   IcpState h;
   memset(&h, 0, sizeof h);
   memcpy(h.trans, trans16, sizeof h.trans);
@@ -725,6 +739,7 @@ extern "C" pcgx_status pcgx_icp_session_read_sums(pcgx_icp_session *s, double su
   if (!s || !sums10) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums: bad argument");
   if (s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums: plane session (30 sums): use pcgx_icp_session_read_sums_n");
   hipStream_t st = pick_stream(stream);
+  PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   PCGX_HIP_TRY(hipMemcpyAsync(sums10, s->d_sums, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
   return PCGX_OK;
@@ -751,6 +766,7 @@ extern "C" pcgx_status pcgx_icp_session_read_sums_n(pcgx_icp_session *s, double 
   PCGX_API_LOCK();
   if (!s || !sums || cap < s->n_sums()) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums_n: bad argument");
   hipStream_t st = pick_stream(stream);
+  PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   PCGX_HIP_TRY(hipMemcpyAsync(sums, s->d_sums, (size_t)s->n_sums() * sizeof(double), hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
   return PCGX_OK;
@@ -959,7 +975,7 @@ static pcgx_status enqueue_corr_patched(pcgx_icp_session *s, hipStream_t st) {
   return PCGX_OK;
 }
 
-static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
+static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st, bool may_speculate = false) {
   static const int tight = icp_knob("PCGX_ICP_TIGHT", 32, 0, 32), chunks = icp_knob("PCGX_ICP_CHUNKS", 2, 1, 64);
   // a deletion made after the session was created: from now on the reference's patched tree is walked
   // (the same handle's Nearest / Range already do), without hints from earlier iterations
@@ -1007,6 +1023,15 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
   const int n_corr = (grid && s->strict && !s->plane && s->grid > left_blocks) ? left_blocks : s->grid;
   static const bool cert_on = icp_knob("PCGX_ICP_CERT", 1, 0, 1) != 0;  // (0: every pair is searched for, as before round 5)
   float *cert = (grid && cert_on && s->base->grid.cert) ? s->d_match_cert : nullptr;
+  // The leftover walk behind the grid pass finds nothing to do in iteration after iteration (C4: never anything), and
+  // its launch is 5 us of a 70 us step.  From a Fit's second Evaluate on it is therefore NOT launched behind a strict
+  // session's grid pass -- on the speculation that the grid answers every target; a target it cannot answer ends the
+  // step on the device (icp_grid_kernel: `done` 2) and settle() enqueues it again with the walk, as every step after it.
+  static const bool spec_on = icp_knob("PCGX_ICP_SPEC_WALK", 1, 0, 1) != 0;
+  static const int test_force_walk = icp_knob("PCGX_TEST_ICP_FORCE_WALK", 0, 0, 1 << 30);
+  const bool no_walk = may_speculate && spec_on && s->spec_walk && grid && s->strict == 1 && !s->plane && s->host_iter >= 1 &&
+                       !s->tile_sums_fresh;
+  if (no_walk) s->spec_pending = true;
   if (grid) {
     ProfScope prof_grid(PCGX_PROF_ICP_GRID, st);
     const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
@@ -1022,7 +1047,7 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
                          s->nt, s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals,
                          s->d_first_leaf, s->d_walk_list, s->d_walk_count, (uint32_t)n_corr, s->d_partials,
                          (unsigned long long *)nullptr, (const uint32_t *)(s->caller_order_fresh ? s->d_orig_of : nullptr),
-                         s->caller_order_fresh ? s->d_match_caller : nullptr, cert, caller_had_pairs ? 1 : 0);
+                         s->caller_order_fresh ? s->d_match_caller : nullptr, cert, caller_had_pairs ? 1 : 0, no_walk ? 0 : 1, test_force_walk);
     else
       hipLaunchKernelGGL(icp_grid_kernel<false>, dim3(xcd_grid(gb)), dim3(kIcpGridBlock), 0, st, s->base->grid, x, y, z, s->nt,
                          s->d_state, s->kp, s->d_match, s->d_match_id, (const float4 *)s->d_normals, s->d_first_leaf,
@@ -1049,7 +1074,9 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st) {
                      (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock), (const uint32_t *)nullptr,               \
                      (float4 *)nullptr, StrictWork(), 0, cert, s->base->grid.cert);                                   \
   } while (0)
-  if (s->plane) {
+  if (no_walk) {
+    // (nothing behind the grid pass)
+  } else if (s->plane) {
     if (grid) PCGX_LAUNCH_CORR(false, true, true);
     else PCGX_LAUNCH_CORR(false, true, false);
   } else if (s->kp.min_dist_sq > 0.0f) {
@@ -1088,6 +1115,33 @@ static pcgx_status enqueue_strict(pcgx_icp_session *s, hipStream_t st) {
                               s->d_terms, s->d_valid, s->d_sums, kFuseUpdate, st);
 }
 
+// Steps enqueued without the leftover walk (enqueue_corr) are looked at: if one of them met a target the grid could not
+// answer, the device stopped there (`done` 2) -- that step and the ones enqueued behind it are enqueued again, with the
+// walk, and the session keeps the walk from then on.  Called by everything that reads the session's state.
+static pcgx_status settle(pcgx_icp_session *s, hipStream_t st) {
+  if (!s->spec_pending) return PCGX_OK;
+  s->spec_pending = false;
+  IcpState h;
+  PCGX_HIP_TRY(hipMemcpyAsync(&h, s->d_state, sizeof h, hipMemcpyDeviceToHost, st));
+  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  if (h.done != 2) return PCGX_OK;
+  s->spec_walk = false;
+  const int32_t missing = s->host_iter - h.num_iteration;  // (Evaluates enqueued, Evaluates carried out)
+  if (getenv("PCGX_ICP_SPEC_TRACE"))
+    fprintf(stderr, "pcgx icp: a step without the leftover walk met a target the grid could not answer: %d of %d Evaluates enqueued again, with the walk\n",
+            (int)missing, (int)s->host_iter);
+  const int32_t zero = 0;
+  PCGX_HIP_TRY(hipMemcpyAsync(&s->d_state->done, &zero, sizeof zero, hipMemcpyHostToDevice, st));
+  PCGX_HIP_TRY(hipMemsetAsync(s->d_walk_count, 0, (size_t)s->grid * sizeof(uint32_t), st));
+  s->host_iter = h.num_iteration;
+  for (int32_t k = 0; k < missing; k++) {
+    PCGX_TRY(enqueue_corr(s, st, false));
+    PCGX_TRY(enqueue_strict<true>(s, st));
+  }
+  PCGX_HIP_TRY(hipGetLastError());
+  return PCGX_OK;
+}
+
 // Measurement aid: counters of the strict chain since the last call (see include/pcgx.h).
 extern "C" pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *stream, int64_t out[64]) {
   PCGX_API_LOCK();
@@ -1104,6 +1158,7 @@ extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stre
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_partials: NULL session");
   hipStream_t st = pick_stream(stream);
+  PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   PCGX_TRY(enqueue_corr(s, st));
   if (s->strict)
     PCGX_TRY(enqueue_strict<false>(s, st));
@@ -1121,6 +1176,7 @@ extern "C" pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_update: NULL session");
   hipStream_t st = pick_stream(stream);
+  PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   if (s->plane)
     hipLaunchKernelGGL(icp_update_kernel<true>, dim3(1), dim3(64), 0, st, s->d_state, s->d_sums, s->kp);
   else
@@ -1134,7 +1190,7 @@ extern "C" pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream) 
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_step: NULL session");
   hipStream_t st = pick_stream(stream);
-  PCGX_TRY(enqueue_corr(s, st));
+  PCGX_TRY(enqueue_corr(s, st, true));
   if (s->strict)
     PCGX_TRY(enqueue_strict<true>(s, st));
   else if (s->plane)
@@ -1159,6 +1215,7 @@ static pcgx_status step_sharded_impl(pcgx_icp_session *s, pcgx_comm *c, void *st
   int32_t rank = 0, world = 1;
   PCGX_TRY(pcgx_comm_rank(c, &rank, &world));
   hipStream_t st = pick_stream(stream);
+  PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   const int step = s->steps_sharded++;
   if (const char *e = getenv("PCGX_TEST_FAIL_RANK")) {  // fault injection (tests/test_gpu_multi.py)
     const char *it = getenv("PCGX_TEST_FAIL_ITER");
@@ -1447,6 +1504,7 @@ extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_result: NULL session");
   hipStream_t st = pick_stream(stream);
+  PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   IcpState h;
   PCGX_HIP_TRY(hipMemcpyAsync(&h, s->d_state, sizeof h, hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
@@ -1458,7 +1516,7 @@ extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream
     stat->evaluated.num_pairs = h.ev.num_pairs;
     stat->num_iteration = h.num_iteration;
   }
-  if (converged) *converged = (h.done && h.status == PCGX_OK) ? 1 : 0;
+  if (converged) *converged = (h.done == 1 && h.status == PCGX_OK) ? 1 : 0;
   if (h.status == PCGX_E_NOT_ENOUGH_PAIRS)
     return fail(PCGX_E_NOT_ENOUGH_PAIRS, "not enough correspondence pairs (%lld < %d) at iteration %d",
                 (long long)h.ev.num_pairs, s->kp.min_pairs, h.num_iteration);
@@ -1475,6 +1533,7 @@ extern "C" pcgx_status pcgx_icp_session_hessian(pcgx_icp_session *s, void *strea
   if (!s || !hessian36) return fail(PCGX_E_INVALID, "pcgx_icp_session_hessian: bad argument");
   if (!s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_hessian: not a plane session (HasHessian() == false)");
   hipStream_t st = pick_stream(stream);
+  PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   IcpState h;
   PCGX_HIP_TRY(hipMemcpyAsync(&h, s->d_state, sizeof h, hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
@@ -1581,6 +1640,7 @@ extern "C" pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stre
   out[1] = out[2] = out[3] = out[4] = out[5] = 0;
   if (s->patched || !grid_enabled(s->base) || s->kp.min_dist_sq > 0.0f || s->nt == 0) return PCGX_OK;
   hipStream_t st = pick_stream(stream);
+  PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   unsigned long long *d_trace = nullptr;
   PCGX_HIP_TRY(dev_cache_alloc((void **)&d_trace, 40 * sizeof(unsigned long long)));
   PCGX_HIP_TRY(hipMemsetAsync(d_trace, 0, 40 * sizeof(unsigned long long), st));

@@ -1,6 +1,8 @@
 """GPU parity: ICP correspondence / evaluate / update / Fit (through the C ABI)
 vs the CPU oracle and the reference's known-answer tables.
 Tolerance: transform within 1e-5 absolute (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,7 @@ from pcgol_amd import icp, kdtree, mat, synth
 pytestmark = pytest.mark.gpu
 f32 = np.float32
 TOL = 1e-5
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_corresponder_golden(golden):
@@ -619,3 +622,44 @@ def test_pairs_kept_on_certificates_are_the_searched_ones():
     assert np.array_equal(np.asarray(trans).ravel(), np.asarray(o["trans"]).ravel())
     assert np.float32(st.Evaluated.Value) == o["value"]
     assert np.array_equal(np.asarray(st.Evaluated.Gradient, np.float32), o["gradient"])
+
+
+def test_a_step_without_the_leftover_walk_is_enqueued_again_when_the_grid_leaves_a_target():
+    """From a Fit's second Evaluate on the leftover walk is not launched behind a strict session's grid pass (csrc/icp.hip,
+    enqueue_corr: it finds nothing to do, and its launch is 5 us of a 70 us step).  A target the grid cannot answer then
+    stops the step on the device, and settle() enqueues it again with the walk.  Forced here (PCGX_TEST_ICP_FORCE_WALK:
+    every 1000th target goes to the walk from the second Evaluate on), in a process of its own (the knob is read once):
+    the Fit is the oracle's bit for bit, and the trace line says that steps were enqueued again."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np
+        import oracle as O
+        from pcgol_amd import icp, kdtree, synth
+        n = 120_000
+        c = synth.c4_icp(n=n, width=10.0 * (n / 1e6) ** (1 / 3))
+        reg = icp.PointToPointICPGradient(
+            icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=c["min_pairs"]),
+            icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=c["threshold"], MaxIteration=c["max_iteration"]))
+        t = kdtree.New(c["base"])
+        trans, st = reg.Fit(t, c["target"])
+        o = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"], sums_mode=0)
+        assert st.NumIteration == o["num_iteration"] == 20
+        assert np.array_equal(np.asarray(trans).ravel(), np.asarray(o["trans"]).ravel())
+        assert np.float32(st.Evaluated.Value) == o["value"]
+        assert np.array_equal(np.asarray(st.Evaluated.Gradient, np.float32), o["gradient"])
+        # a session stepped by hand, looked at in the middle (read_sums) and at the end
+        s = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+        for _ in range(7):
+            s.step()
+        s.read_sums()
+        for _ in range(13):
+            s.step()
+        tr2, st2, _ = s.result()
+        assert st2.NumIteration == 20 and np.array_equal(np.asarray(tr2).ravel(), np.asarray(o["trans"]).ravel())
+        print("fit ok")
+    """)
+    env = dict(os.environ, PCGX_TEST_ICP_FORCE_WALK="1000", PCGX_ICP_SPEC_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n" % ROOT + code], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "fit ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.stderr.count("enqueued again") == 2, r.stderr[-3000:]   # once per session: the walk stays on afterwards
