@@ -33,7 +33,10 @@ namespace pcgx {
 constexpr int kVbThreads = 256, kVbItems = 8, kVbTile = kVbThreads * kVbItems;  // scatter tiles (36 KB of LDS: four per CU)
 constexpr int kVbWaves = kVbThreads / 64;
 constexpr int kVbMaxCell = 255;        // points per cell it puts in order by itself
-constexpr int kVbFinalThreads = 256;
+#ifndef PCGX_VB_FINAL_THREADS
+#define PCGX_VB_FINAL_THREADS 256
+#endif
+constexpr int kVbFinalThreads = PCGX_VB_FINAL_THREADS;
 constexpr long long kVbWaitTicks = 500000;  // 5 ms of s_memrealtime (100 MHz): a bucket that waits longer gives up, the radix path answers
 constexpr int kVbSampleEvery = 32;     // every 32nd point is counted per bucket before anything is moved
 
