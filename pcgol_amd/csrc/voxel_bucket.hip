@@ -8,9 +8,9 @@
 //   keys + histograms   one pass over the cloud: the reference's cell of every point (voxel_key.h), the first
 //                       pass's tile histograms, and the population of every BUCKET (bucket = key >> s: 2^s
 //                       consecutive cells, s chosen so that a bucket's points fit a workgroup's LDS)
-//   1-2 scatter passes  stable LSD partition by the bucket number (digits of <= 8 bits), 4096-element tiles
-//                       re-ordered in LDS so that every digit's run leaves in one piece; the elements are
-//                       {x, y, z} + key (+ the point's index when records carry more than xyz)
+//   1-2 scatter passes  stable LSD partition by the bucket number (digits of <= 8 bits), 2048-element tiles
+//                       re-ordered in LDS so that every digit's run leaves in one piece; the elements are 16-byte
+//                       records {x, y, z, key} (+ the point's index, by itself, when records carry more than xyz)
 //   bucket kernel       one workgroup per bucket: its points into LDS, counting sort by the key's low s bits, the
 //                       points of a cell put into input order by their position (the partition is stable), the
 //                       reference's sequential float32 sum per cell (voxelgrid.go:157), centroid, output record.
@@ -78,24 +78,6 @@ __global__ __launch_bounds__(256) void vb_key_hist_kernel(const uint8_t *__restr
   if (any_bad) atomicOr(err, 1);
   __syncthreads();
   block_hist[(int64_t)threadIdx.x * hstride + blockIdx.x] = dh[threadIdx.x];
-}
-
-// (measurement aid, PCGX_VOXEL_BUCKET_BOUNDS_KERNEL=1: the buckets' starts found in the sorted keys by a kernel of its
-// own instead of by the last scatter pass's atomics; four consecutive keys per thread)
-__global__ __launch_bounds__(256) void vb_bounds_kernel(const uint32_t *__restrict__ keys0, const uint32_t *__restrict__ keys1,
-                                                        int64_t n, const VoxelDevPlan *__restrict__ dp,
-                                                        uint32_t *__restrict__ inv_start, const int32_t *__restrict__ flags) {
-  if (*flags) return;  // uniform
-  const int low_bits = dp->plan.low_bits;
-  const uint32_t *__restrict__ keys = dp->plan.d_bits[1] ? keys1 : keys0;  // (the last pass's)
-  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (i0 >= n) return;
-  uint32_t bp = i0 > 0 ? keys[i0 - 1] >> low_bits : 0xffffffffu;
-  for (int q = 0; q < 4 && i0 + q < n; q++) {
-    const uint32_t bi = keys[i0 + q] >> low_bits;
-    if (bi != bp) inv_start[bi] = ~(uint32_t)(i0 + q);
-    bp = bi;
-  }
 }
 
 // tile histograms of the second pass's digit, from the keys as the first pass left them.  Sixteen tiles per workgroup,
@@ -176,9 +158,9 @@ __global__ __launch_bounds__(1024) void vb_scan_rows_kernel(uint32_t *__restrict
 // on the digit's bits, per-wave counts, the tile re-ordered in LDS so that a digit's run is written in one piece.
 template <bool kFirst, bool kIdx>
 __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
-    const uint8_t *__restrict__ data, int32_t stride, int32_t off, const float *__restrict__ xyz_in,
+    const uint8_t *__restrict__ data, int32_t stride, int32_t off, const float4 *__restrict__ rec_in,
     const uint32_t *__restrict__ key_in, const uint32_t *__restrict__ idx_in, int64_t n, const VoxelDevPlan *__restrict__ dp,
-    const uint32_t *__restrict__ block_hist, int ntiles, int hstride, const uint32_t *__restrict__ totals, float *__restrict__ xyz_out,
+    const uint32_t *__restrict__ block_hist, int ntiles, int hstride, const uint32_t *__restrict__ totals, float4 *__restrict__ rec_out,
     uint32_t *__restrict__ key_out, uint32_t *__restrict__ idx_out, uint32_t *__restrict__ inv_start,
     const int32_t *__restrict__ flags) {
   __shared__ uint32_t cnt[kVbWaves][256];
@@ -186,8 +168,7 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
   __shared__ uint32_t gbase[256];
   __shared__ uint32_t wave_sum[kVbWaves];
   __shared__ uint32_t gwave_sum[kVbWaves];
-  __shared__ uint32_t skey[kVbTile];
-  __shared__ float sx[kVbTile], sy[kVbTile], sz[kVbTile];
+  __shared__ float4 srec[kVbTile];  // {x, y, z, bits(key)}
   __shared__ uint32_t sidx[kIdx ? kVbTile : 1];
   if (*flags) return;  // uniform: the call goes the radix path
   const int shift = kFirst ? dp->plan.low_bits : dp->plan.low_bits + dp->plan.d_bits[0];
@@ -206,11 +187,19 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
   __syncthreads();
 
   uint32_t key[kVbItems], rank[kVbItems];
+  float4 rec[kVbItems];  // (every load of the tile in flight before the ranking: one round trip, not one per phase)
   volatile uint32_t *my_cnt = cnt[wave];
 #pragma unroll
   for (int r = 0; r < kVbItems; r++) {
     const int64_t i = wave_base + r * 64 + lane;
-    key[r] = i < n ? key_in[i] : 0u;
+    if (kFirst) {
+      key[r] = i < n ? key_in[i] : 0u;
+      const uint8_t *src = data + (i < n ? i : 0) * stride + off;
+      rec[r] = make_float4(ld_f32(src), ld_f32(src + 4), ld_f32(src + 8), __uint_as_float(key[r]));
+    } else {
+      rec[r] = i < n ? rec_in[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      key[r] = __float_as_uint(rec[r].w);
+    }
   }
 #pragma unroll
   for (int r = 0; r < kVbItems; r++) {
@@ -263,21 +252,7 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
     if (i < n) {
       const uint32_t d = (key[r] >> shift) & mask;
       const uint32_t pos = tile_pref[d] + cnt[wave][d] + rank[r];
-      float x, y, z;
-      if (kFirst) {
-        const uint8_t *rec = data + i * stride + off;
-        x = ld_f32(rec);
-        y = ld_f32(rec + 4);
-        z = ld_f32(rec + 8);
-      } else {
-        x = xyz_in[i];
-        y = xyz_in[n + i];
-        z = xyz_in[2 * n + i];
-      }
-      skey[pos] = key[r];
-      sx[pos] = x;
-      sy[pos] = y;
-      sz[pos] = z;
+      srec[pos] = rec[r];
       if (kIdx) sidx[pos] = kFirst ? (uint32_t)i : idx_in[i];
     }
   }
@@ -291,15 +266,20 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
   // word means "no points" (a kernel of its own that found the bounds in the sorted keys: 11 us per C3 call).
   const bool last_pass = inv_start != nullptr && (kFirst ? dp->plan.d_bits[1] == 0 : true);
   const int low_bits = dp->plan.low_bits;
+  // The elements travel as ONE 16-byte record {x, y, z, key}: a load or store of sixteen bytes per lane costs a CU's
+  // texture path twice what one of four bytes does (tools/micro/vmem_shape.cpp: 70 against 36 cycles per instruction,
+  // consecutive lanes) and moves four times as much -- with x[] y[] z[] key[] as four arrays the two passes were bound
+  // by that path (eight 4-byte instructions per sixty-four elements: 85 and 104 us).  Only the pass in front of the
+  // second histograms writes the keys a second time, by themselves (vb_hist2_kernel reads 40 MB instead of 160).
   for (int p = threadIdx.x; p < count; p += kVbThreads) {
-    const uint32_t k = skey[p];
+    const float4 e = srec[p];
+    const uint32_t k = __float_as_uint(e.w);
     const uint32_t d = (k >> shift) & mask;
     const int64_t dst = (int64_t)gbase[d] + p;
-    if (last_pass && (p == 0 || (skey[p - 1] >> low_bits) != (k >> low_bits))) atomicMax(&inv_start[k >> low_bits], ~(uint32_t)dst);
-    key_out[dst] = k;
-    xyz_out[dst] = sx[p];  // (three arrays x[n] y[n] z[n]: every store instruction writes consecutive words)
-    xyz_out[n + dst] = sy[p];
-    xyz_out[2 * n + dst] = sz[p];
+    if (last_pass && (p == 0 || (__float_as_uint(srec[p - 1].w) >> low_bits) != (k >> low_bits)))
+      atomicMax(&inv_start[k >> low_bits], ~(uint32_t)dst);
+    rec_out[dst] = e;
+    if (key_out) key_out[dst] = k;
     if (kIdx) idx_out[dst] = sidx[p];
   }
 }
@@ -331,8 +311,8 @@ __device__ __forceinline__ uint32_t ld_sc1_u32(const uint32_t *p) {
 
 template <bool kIdx>
 __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
-    const float *__restrict__ xyz0, const float *__restrict__ xyz1, int64_t n, const uint32_t *__restrict__ keys0,
-    const uint32_t *__restrict__ keys1, const uint32_t *__restrict__ idx0, const uint32_t *__restrict__ idx1,
+    const float4 *__restrict__ rec0, const float4 *__restrict__ rec1, int64_t n, const uint32_t *__restrict__ idx0,
+    const uint32_t *__restrict__ idx1,
     const uint32_t *__restrict__ bucket_start, const VoxelDevPlan *__restrict__ dp, const uint8_t *__restrict__ data, int32_t stride,
     int32_t off, uint8_t *__restrict__ out, VbExchange ex, int64_t *__restrict__ total, int32_t *__restrict__ flags) {
   constexpr int kBins = 1 << kVbMaxLowBits, kWaves = kVbFinalThreads / 64;
@@ -351,8 +331,7 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
   const VoxelParams vp = dp->vp;
   const VbPlan plan = dp->plan;
   const bool two = plan.d_bits[1] != 0;  // the arrays the last pass wrote
-  const float *__restrict__ xyz = two ? xyz1 : xyz0;
-  const uint32_t *__restrict__ keys = two ? keys1 : keys0;
+  const float4 *__restrict__ rec = two ? rec1 : rec0;  // {x, y, z, bits(key)} (vb_scatter_kernel)
   const uint32_t *__restrict__ idx = two ? idx1 : idx0;
   const int nbins = 1 << plan.low_bits;
   // the bucket's points: from its start (the last pass's finding, kept as the complement; a cleared word: no points) to
@@ -384,10 +363,11 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
     arr[r] = low[r] = 0;
     if (i < P) {
       const int64_t g = (int64_t)start + i;
-      const uint32_t l = keys[g] & lmask;
-      sx[i] = xyz[g];
-      sy[i] = xyz[n + g];
-      sz[i] = xyz[2 * n + g];
+      const float4 e = rec[g];
+      const uint32_t l = __float_as_uint(e.w) & lmask;
+      sx[i] = e.x;
+      sy[i] = e.y;
+      sz[i] = e.z;
       low[r] = (uint16_t)l;
       arr[r] = (uint16_t)atomicAdd(&cnt[l], 1u);
     }
@@ -657,8 +637,8 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   const bool with_idx = stride != 12 || xyz_off != 0 || ((reinterpret_cast<uintptr_t>(d_data) | reinterpret_cast<uintptr_t>(d_out)) & 3) != 0;
 
   Arena &ar = ctx().arena;
-  uint32_t *key0 = nullptr, *keyb[2] = {nullptr, nullptr}, *idxb[2] = {nullptr, nullptr};
-  float *xyzb[2] = {nullptr, nullptr};
+  uint32_t *key0 = nullptr, *key1 = nullptr, *idxb[2] = {nullptr, nullptr};  // key1: the first pass's keys again, for the second histograms
+  float4 *recb[2] = {nullptr, nullptr};                                       // {x, y, z, bits(key)} behind each pass
   uint32_t *block_hist = nullptr, *totals = nullptr, *bucket_sample = nullptr, *inv_start = nullptr;
   float *d_mm6 = nullptr;
   VoxelDevPlan *d_plan = nullptr;
@@ -667,9 +647,9 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   VbExchange ex;
   constexpr int64_t kGroups = kVbMaxBuckets / 32, kSuper = kVbMaxBuckets / 1024;
   PCGX_TRY(ar.alloc_n((size_t)n, &key0));
+  PCGX_TRY(ar.alloc_n((size_t)n, &key1));
   for (int k = 0; k < 2; k++) {
-    PCGX_TRY(ar.alloc_n((size_t)n, &keyb[k]));
-    PCGX_TRY(ar.alloc_n((size_t)n * 3, &xyzb[k]));
+    PCGX_TRY(ar.alloc_n((size_t)n, &recb[k]));
     if (with_idx) PCGX_TRY(ar.alloc_n((size_t)n, &idxb[k]));
   }
   const int hstride = (ntiles + 31) & ~31;  // (a digit's row of tile counts begins on a 128-byte line)
@@ -710,8 +690,7 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   const uint8_t *data = (const uint8_t *)d_data;
   PCGX_TRY(launch_minmax_with_plan(d_data, n, stride, xyz_off, d_mm6, kn, st));
   const int sample = vb_knob("PCGX_VOXEL_BUCKET_SAMPLE", 1);
-  const bool bounds_kernel = vb_knob("PCGX_VOXEL_BUCKET_BOUNDS_KERNEL", 0) != 0;
-  uint32_t *scatter_bounds = bounds_kernel ? nullptr : inv_start;
+  uint32_t *scatter_bounds = inv_start;
   hipLaunchKernelGGL(vb_key_hist_kernel, dim3(ntiles), dim3(256), 0, st, data, n, stride, xyz_off, (const VoxelDevPlan *)d_plan, key0,
                      block_hist, sample ? bucket_sample : (uint32_t *)nullptr, d_flags + 1, hstride, (const int32_t *)d_flags);
   hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, ntiles, hstride, totals, (const VoxelDevPlan *)d_plan, 0,
@@ -719,42 +698,37 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   const int grid = ntiles >= 64 ? 8 * ((ntiles + 7) / 8) : ntiles;
   if (with_idx)
     hipLaunchKernelGGL((vb_scatter_kernel<true, true>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
-                       (const float *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
-                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0], scatter_bounds,
+                       (const float4 *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
+                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, recb[0], key1, idxb[0], scatter_bounds,
                        (const int32_t *)d_flags);
   else
     hipLaunchKernelGGL((vb_scatter_kernel<true, false>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
-                       (const float *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
-                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, xyzb[0], keyb[0], idxb[0], scatter_bounds,
+                       (const float4 *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
+                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, recb[0], key1, idxb[0], scatter_bounds,
                        (const int32_t *)d_flags);
   // the second digit (every plan above some ten thousand points has one; a plan without returns from these at once)
-  hipLaunchKernelGGL(vb_hist2_kernel, dim3((ntiles + kVbHistTiles - 1) / kVbHistTiles), dim3(1024), 0, st, (const uint32_t *)keyb[0], n,
+  hipLaunchKernelGGL(vb_hist2_kernel, dim3((ntiles + kVbHistTiles - 1) / kVbHistTiles), dim3(1024), 0, st, (const uint32_t *)key1, n,
                      (const VoxelDevPlan *)d_plan, block_hist, ntiles, hstride, (const int32_t *)d_flags);
   hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, ntiles, hstride, totals, (const VoxelDevPlan *)d_plan, 1,
                      (const uint32_t *)nullptr, d_flags);
   if (with_idx)
     hipLaunchKernelGGL((vb_scatter_kernel<false, true>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
-                       (const float *)xyzb[0], (const uint32_t *)keyb[0], (const uint32_t *)idxb[0], n, (const VoxelDevPlan *)d_plan,
-                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1], scatter_bounds,
+                       (const float4 *)recb[0], (const uint32_t *)nullptr, (const uint32_t *)idxb[0], n, (const VoxelDevPlan *)d_plan,
+                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, recb[1], (uint32_t *)nullptr, idxb[1], scatter_bounds,
                        (const int32_t *)d_flags);
   else
     hipLaunchKernelGGL((vb_scatter_kernel<false, false>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
-                       (const float *)xyzb[0], (const uint32_t *)keyb[0], (const uint32_t *)idxb[0], n, (const VoxelDevPlan *)d_plan,
-                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, xyzb[1], keyb[1], idxb[1], scatter_bounds,
+                       (const float4 *)recb[0], (const uint32_t *)nullptr, (const uint32_t *)idxb[0], n, (const VoxelDevPlan *)d_plan,
+                       (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, recb[1], (uint32_t *)nullptr, idxb[1], scatter_bounds,
                        (const int32_t *)d_flags);
-  if (bounds_kernel)
-    hipLaunchKernelGGL(vb_bounds_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, (const uint32_t *)keyb[0],
-                       (const uint32_t *)keyb[1], n, (const VoxelDevPlan *)d_plan, inv_start, (const int32_t *)d_flags);
   const int bucket_grid = kn.grid;
   if (with_idx)
-    hipLaunchKernelGGL(vb_bucket_kernel<true>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float *)xyzb[0],
-                       (const float *)xyzb[1], n, (const uint32_t *)keyb[0], (const uint32_t *)keyb[1], (const uint32_t *)idxb[0],
-                       (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off,
+    hipLaunchKernelGGL(vb_bucket_kernel<true>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float4 *)recb[0],
+                       (const float4 *)recb[1], n, (const uint32_t *)idxb[0], (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off,
                        (uint8_t *)d_out, ex, d_total, d_flags);
   else
-    hipLaunchKernelGGL(vb_bucket_kernel<false>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float *)xyzb[0],
-                       (const float *)xyzb[1], n, (const uint32_t *)keyb[0], (const uint32_t *)keyb[1], (const uint32_t *)idxb[0],
-                       (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off,
+    hipLaunchKernelGGL(vb_bucket_kernel<false>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float4 *)recb[0],
+                       (const float4 *)recb[1], n, (const uint32_t *)idxb[0], (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off,
                        (uint8_t *)d_out, ex, d_total, d_flags);
   PCGX_HIP_TRY(hipGetLastError());
   Readback h;

@@ -167,17 +167,3 @@ def test_calls_the_device_plan_turns_away_go_the_radix_path(monkeypatch):
     st = _stats()
     assert st[0] == 0 and st[1] == 0, st
     assert np.array_equal(got, exp)
-
-
-def test_bounds_by_a_kernel_of_their_own_give_the_same_bytes(monkeypatch):
-    """PCGX_VOXEL_BUCKET_BOUNDS_KERNEL=1 (a measurement aid: the buckets' starts from the sorted keys instead of from
-    the last scatter pass's atomics)."""
-    monkeypatch.setenv("PCGX_VOXEL_BUCKET_MIN_N", "1")
-    monkeypatch.setenv("PCGX_VOXEL_BUCKET_BOUNDS_KERNEL", "1")
-    for n, width, leaf in ((3000, 1.6, 0.05), (300000, 3.0, 0.02)):
-        pts = synth.uniform_cloud(n, width, 40 + n % 97)
-        exp = O.voxel_filter(pts, n, 12, 0, (leaf,) * 3, (0, 0, 0))
-        _stats()
-        got = _filter(pts, n, 12, 0, (leaf,) * 3, (0, 0, 0))
-        assert _stats()[0] == 1
-        assert np.array_equal(got, exp)
