@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void vb_key_hist_kernel(const uint8_t *__restr
       bool bad;
       const uint32_t key = voxel_key_xyz(pt, vp, cid, ka, bad);
       any_bad |= bad;
-      key_out[i] = key;
+      if (key_out) key_out[i] = key;
       const uint32_t bkt = key >> plan.low_bits;
       atomicAdd(&dh[bkt & m1], 1u);
       if (sampled) atomicAdd(&bucket_sample[bkt], 1u);  // (two lanes of a wave: spread over all workgroups, no stragglers)
@@ -193,9 +193,17 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
   for (int r = 0; r < kVbItems; r++) {
     const int64_t i = wave_base + r * 64 + lane;
     if (kFirst) {
-      key[r] = i < n ? key_in[i] : 0u;
       const uint8_t *src = data + (i < n ? i : 0) * stride + off;
-      rec[r] = make_float4(ld_f32(src), ld_f32(src + 4), ld_f32(src + 8), __uint_as_float(key[r]));
+      const float pt[3] = {ld_f32(src), ld_f32(src + 4), ld_f32(src + 8)};
+      if (key_in) {
+        key[r] = i < n ? key_in[i] : 0u;
+      } else {  // the key formed again from the point (vb_key_hist_kernel counted it and did not write it)
+        uint32_t cid, ka;
+        bool bad;
+        key[r] = voxel_key_xyz(pt, dp->vp, cid, ka, bad);
+        if (i >= n) key[r] = 0u;
+      }
+      rec[r] = make_float4(pt[0], pt[1], pt[2], __uint_as_float(key[r]));
     } else {
       rec[r] = i < n ? rec_in[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       key[r] = __float_as_uint(rec[r].w);
@@ -690,20 +698,22 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   const uint8_t *data = (const uint8_t *)d_data;
   PCGX_TRY(launch_minmax_with_plan(d_data, n, stride, xyz_off, d_mm6, kn, st));
   const int sample = vb_knob("PCGX_VOXEL_BUCKET_SAMPLE", 1);
+  const bool rekey = vb_knob("PCGX_VOXEL_BUCKET_REKEY", 1) != 0;  // the first pass forms the keys again instead of reading an array of them
+  uint32_t *key0_arg = rekey ? nullptr : key0;
   uint32_t *scatter_bounds = inv_start;
-  hipLaunchKernelGGL(vb_key_hist_kernel, dim3(ntiles), dim3(256), 0, st, data, n, stride, xyz_off, (const VoxelDevPlan *)d_plan, key0,
+  hipLaunchKernelGGL(vb_key_hist_kernel, dim3(ntiles), dim3(256), 0, st, data, n, stride, xyz_off, (const VoxelDevPlan *)d_plan, key0_arg,
                      block_hist, sample ? bucket_sample : (uint32_t *)nullptr, d_flags + 1, hstride, (const int32_t *)d_flags);
   hipLaunchKernelGGL(vb_scan_rows_kernel, dim3(256), dim3(1024), 0, st, block_hist, ntiles, hstride, totals, (const VoxelDevPlan *)d_plan, 0,
                      sample ? (const uint32_t *)bucket_sample : (const uint32_t *)nullptr, d_flags);
   const int grid = ntiles >= 64 ? 8 * ((ntiles + 7) / 8) : ntiles;
   if (with_idx)
     hipLaunchKernelGGL((vb_scatter_kernel<true, true>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
-                       (const float4 *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
+                       (const float4 *)nullptr, (const uint32_t *)key0_arg, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
                        (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, recb[0], key1, idxb[0], scatter_bounds,
                        (const int32_t *)d_flags);
   else
     hipLaunchKernelGGL((vb_scatter_kernel<true, false>), dim3(grid), dim3(kVbThreads), 0, st, data, stride, xyz_off,
-                       (const float4 *)nullptr, (const uint32_t *)key0, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
+                       (const float4 *)nullptr, (const uint32_t *)key0_arg, (const uint32_t *)nullptr, n, (const VoxelDevPlan *)d_plan,
                        (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, recb[0], key1, idxb[0], scatter_bounds,
                        (const int32_t *)d_flags);
   // the second digit (every plan above some ten thousand points has one; a plan without returns from these at once)
