@@ -1056,6 +1056,7 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st, bool may_sp
   }
   // timed (pcgx_prof_enable) when it is the kernel that does the work: with the grid pass before it
   // it walks next to nothing, and a second pair of events per step costs more than it
+  if (no_walk) return PCGX_OK;  // (nothing behind the grid pass)
   ProfScope prof(grid ? PCGX_PROF_ICP_LEFTOVER : PCGX_PROF_ICP_WALK, st);
 #define PCGX_LAUNCH_CORR(MD, PL, GR)                                                                                  \
   do {                                                                                                                \
@@ -1074,9 +1075,7 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st, bool may_sp
                      (int32_t)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock), (const uint32_t *)nullptr,               \
                      (float4 *)nullptr, StrictWork(), 0, cert, s->base->grid.cert);                                   \
   } while (0)
-  if (no_walk) {
-    // (nothing behind the grid pass)
-  } else if (s->plane) {
+  if (s->plane) {
     if (grid) PCGX_LAUNCH_CORR(false, true, true);
     else PCGX_LAUNCH_CORR(false, true, false);
   } else if (s->kp.min_dist_sq > 0.0f) {
