@@ -186,11 +186,17 @@ __global__ __launch_bounds__(256) void range_tie_place_kernel(TreeView tv, const
 // of a hundred, and a run sorted by one thread was a chain of dependent memory accesses a millisecond long.)
 __global__ __launch_bounds__(256) void range_tie_sort_kernel(const uint32_t *__restrict__ query_of, const uint32_t *__restrict__ key,
                                                              int64_t total, const unsigned long long *__restrict__ place,
-                                                             const uint32_t *__restrict__ ids, uint32_t *__restrict__ ids_out) {
+                                                             const uint32_t *__restrict__ ids, uint32_t *__restrict__ ids_out,
+                                                             int32_t *__restrict__ bad) {
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= total) return;
   const unsigned long long mine = place[s];
   const uint32_t id = ids[s];
+  if (id == 0xffffffffu) {  // a slot nothing was written to: the caller's offsets do not match the counts.  Said here,
+    *bad = 1;               // where it is still certain -- such slots carry query 0 / key 0 and, mixed into a run of query
+    ids_out[s] = id;        // 0's ties at DistSq 0, could be written over before range_widen_check_kernel looks
+    return;
+  }
   if (mine == 0ull) {  // not tied (a tied slot's place has its own digit 1 in it)
     ids_out[s] = id;
     return;
@@ -403,8 +409,12 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
     hipLaunchKernelGGL(range_tie_place_kernel, dim3(tb), dim3(256), 0, st, tv, d_inv, (const float *)d_q, (const uint32_t *)k2[r2],
                        (const uint32_t *)d_out_key, (const uint32_t *)d_out_id, total, d_place);
     // (into d_id: the discovery-order ids are done with)
+    if (!d_bad) {
+      PCGX_TRY(ar.alloc_n(1, &d_bad));
+      PCGX_HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
+    }
     hipLaunchKernelGGL(range_tie_sort_kernel, dim3(tb), dim3(256), 0, st, (const uint32_t *)k2[r2], (const uint32_t *)d_out_key, total,
-                       (const unsigned long long *)d_place, (const uint32_t *)d_out_id, (uint32_t *)d_id);
+                       (const unsigned long long *)d_place, (const uint32_t *)d_out_id, (uint32_t *)d_id, d_bad);
     PCGX_HIP_TRY(hipGetLastError());
     d_out_id = (uint32_t *)d_id;
   }
