@@ -213,8 +213,8 @@ static pcgx_status init_device(int device) {
       (void)hipGetLastError();
     }
     s.mailbox_seq = 0;
-    PCGX_HIP_TRY(hipMalloc((void **)&s.tickets, 256));
-    PCGX_HIP_TRY(hipMemset(s.tickets, 0, 256));
+    PCGX_HIP_TRY(hipMalloc((void **)&s.tickets, kTicketBytes));
+    PCGX_HIP_TRY(hipMemset(s.tickets, 0, kTicketBytes));
     s.device = device;
   }
   for (int k = kPoolSlots; k >= 0; k--) g.slots[k].ready = true;

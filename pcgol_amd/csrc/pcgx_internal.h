@@ -136,7 +136,7 @@ struct Context {
   // memory plus hipStreamSynchronize cost 30 us of idle GPU per call
   volatile uint32_t *mailbox = nullptr;
   uint32_t mailbox_seq = 0;
-  // a few zeroed device words that kernels use as "last workgroup" tickets and put back to zero themselves
+  // zeroed device words (kTicketBytes) that kernels use as "last workgroup" tickets and put back to zero themselves
   unsigned int *tickets = nullptr;
 };
 Context &ctx();  // the calling thread's current context (the library's outside any call)
@@ -293,6 +293,7 @@ pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t
                           hipStream_t st, bool sticky_first = true);
 // a few result words of a call on the host: through the context's mailbox where there is one (a one-wave kernel behind
 // the call's kernels, the host polls; the stream is not synchronised), else copy + wait.  bytes: a multiple of 4
+constexpr size_t kTicketBytes = 8192;
 constexpr size_t kMailboxBytes = 512;
 pcgx_status read_back_small(const void *d_src, size_t bytes, void *host_dst, hipStream_t st);
 // the same, and the six floats on the host (through the context's mailbox; the stream is not synchronised)

@@ -14,6 +14,7 @@
 // LDS by digit and writes each digit run contiguously, so global writes are
 // coalesced runs rather than 4-byte scatters.
 #include <stdlib.h>
+#include <algorithm>
 #include <string.h>
 
 #include "voxel_key.h"
@@ -326,6 +327,8 @@ __device__ __forceinline__ void mm_finish(MinMaxAcc &a) {
 // point 0's rule, out6 = {min xyz, max xyz} -- and, where the host waits for them, the six floats straight into its
 // pinned mailbox, the sequence word last.  (A kernel of its own for this was 13.6 us of the filter's call: a launch
 // behind a 120 MB stream, and 1024 partials read by one workgroup.)
+constexpr unsigned int kTicketGroups = 32u, kTicketStride = 32u;  // (words; core.hip allocates kTicketBytes)
+static_assert((1u + kTicketGroups) * kTicketStride * 4u <= kTicketBytes, "the context's ticket words");
 struct MinMaxTail {
   MinMaxAcc *partials;
   unsigned int *ticket;
@@ -371,22 +374,38 @@ __device__ __forceinline__ void minmax_block_fold(MinMaxAcc &a, const MinMaxTail
       __hip_atomic_store(&dst->zf[k], a.zf[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_last = atomicAdd(T.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    // Returning atomics on ONE word are served one after the other, 10 ns each: 1024 workgroups that finish their
+    // stream within 3 us of each other waited up to 10 us for their turn.  Two steps instead: 32 ticket words (a 128-byte
+    // line each) taken by 32 workgroups each, and the last of a word's takers takes one of the top word.
+    const unsigned int g = blockIdx.x & (kTicketGroups - 1u), groups = min(gridDim.x, kTicketGroups);
+    const unsigned int members = (gridDim.x - g + kTicketGroups - 1u) / kTicketGroups;
+    unsigned int *mine = T.ticket + kTicketStride * (1u + g);
+    unsigned int last = 0u;
+    if (atomicAdd(mine, 1u) == members - 1u) {
+      __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch)
+      last = atomicAdd(T.ticket, 1u) == groups - 1u ? 1u : 0u;
+    }
+    s_last = last;
   }
   __syncthreads();
   if (!s_last) return;  // uniform
   MinMaxAcc f;
   minmax_init(f);
-  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {
-    MinMaxAcc p;
-    const MinMaxAcc *src = &T.partials[b];
+  // (at most 1024 workgroups: every thread's four partials asked for at once, one round trip instead of four)
+  MinMaxAcc p[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int b = (int)threadIdx.x + 256 * r;
+    const MinMaxAcc *src = &T.partials[b < (int)gridDim.x ? b : 0];
+#pragma unroll
     for (int k = 0; k < 3; k++) {
-      p.mn[k] = __hip_atomic_load(&src->mn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      p.mx[k] = __hip_atomic_load(&src->mx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      p.zf[k] = __hip_atomic_load(&src->zf[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      p[r].mn[k] = __hip_atomic_load(&src->mn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      p[r].mx[k] = __hip_atomic_load(&src->mx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      p[r].zf[k] = __hip_atomic_load(&src->zf[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    mm_merge(f, p);
   }
+#pragma unroll
+  for (int r = 0; r < 4; r++) mm_merge(f, p[r]);
   wave_fold(f);
   __syncthreads();  // (s_acc is read above by thread 0 only, before its ticket)
   if (lane == 0) s_acc[wave] = f;
@@ -452,49 +471,77 @@ __global__ __launch_bounds__(256) void minmax_partial_kernel(const uint8_t *__re
   minmax_block_fold(a, T);
 }
 
-// Packed xyz clouds (stride 12, offset 0, 16-byte aligned base): a thread takes 4 consecutive
-// points = three 16-byte loads, two such groups in flight.
+// Packed xyz clouds (stride 12, offset 0, 16-byte aligned base) as a plain stream of 16-byte words: float j of word q is
+// coordinate (q + j) mod 3 of point (4q + j) / 3.  A thread takes the words base + u T + t (u = 0, 1, 2; T threads,
+// T = 1 mod 3, base a multiple of 3T), so that word u's float j has coordinate (t + u + j) mod 3: the accumulators are
+// kept by (u + j) mod 3 and turned by t mod 3 once at the end.  (Ordinary loads: streaming ones -- `nt`, which leave the
+// caches' dirty lines where they are instead of pushing them out, 5.5 against 2.7 TB/s in tools/micro/stream_read.cpp
+// -- take 9 us off this pass and put 27 on the two behind it, which then find no cloud in the Infinity Cache.)
 __global__ __launch_bounds__(256) void minmax_partial_packed_kernel(const float4 *__restrict__ data, int64_t n, MinMaxTail T) {
   MinMaxAcc a;
   minmax_init(a);
   minmax_clear_slice(T);
-  const int64_t groups = n >> 2;  // whole groups of 4 points; the tail is handled by one thread below
-  const int64_t step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t g0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g0 < groups; g0 += 2 * step) {
-    float4 r[2][3];
+  const int64_t words = (3 * n) >> 2;  // whole 16-byte words; the floats behind them are taken by one thread below
+  const int64_t threads = (int64_t)gridDim.x * 256, t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  float mn[3], mx[3];
+  for (int k = 0; k < 3; k++) { mn[k] = a.mn[k]; mx[k] = a.mx[k]; }
+  for (int64_t base = 0; base < words; base += 3 * threads) {
+    float4 r[3];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const int64_t g = g0 + u * step < groups ? g0 + u * step : g0;
-      r[u][0] = data[3 * g]; r[u][1] = data[3 * g + 1]; r[u][2] = data[3 * g + 2];
+    for (int u = 0; u < 3; u++) {
+      // (a word beyond the end: the thread's first word of the same u -- there is one, the launch sees to 3T <= words)
+      const int64_t q = base + u * threads + t;
+      r[u] = data[q < words ? q : u * threads + t];
     }
     bool zero = false;
-    float f[2][12];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const float t[12] = {r[u][0].x, r[u][0].y, r[u][0].z, r[u][0].w, r[u][1].x, r[u][1].y,
-                           r[u][1].z, r[u][1].w, r[u][2].x, r[u][2].y, r[u][2].z, r[u][2].w};
+    for (int u = 0; u < 3; u++) {
+      const float f[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
 #pragma unroll
-      for (int j = 0; j < 12; j++) {
-        f[u][j] = t[j];
-        mm_value(a, j % 3, t[j]);
-        zero |= t[j] == 0.0f;
+      for (int j = 0; j < 4; j++) {
+        mn[(u + j) % 3] = fminf(mn[(u + j) % 3], f[j]);
+        mx[(u + j) % 3] = fmaxf(mx[(u + j) % 3], f[j]);
+        zero |= f[j] == 0.0f;
       }
     }
     if (__ballot(zero) != 0ull) {  // uniform, rare
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int64_t g = g0 + u * step < groups ? g0 + u * step : g0;
-        for (int j = 0; j < 12; j++) mm_zero(a, j % 3, f[u][j], 4 * g + j / 3);
+      for (int u = 0; u < 3; u++) {
+        const int64_t q0 = base + u * threads + t, q = q0 < words ? q0 : u * threads + t;
+        const float f[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+        for (int j = 0; j < 4; j++) {
+          const int64_t fl = 4 * q + j;
+          const int k = (int)(fl % 3);
+          const uint32_t z = f[j] == 0.0f ? ((uint32_t)(fl / 3) << 1) | (__float_as_uint(f[j]) >> 31) : 0xffffffffu;
+          // (no a.zf[k]: an array indexed at run time is moved to LDS, and finding one's slice there takes the workgroup's
+          // size out of the dispatch packet -- host memory, 10 us before the last XCD's workgroups have it)
+          a.zf[0] = min(a.zf[0], k == 0 ? z : 0xffffffffu);
+          a.zf[1] = min(a.zf[1], k == 1 ? z : 0xffffffffu);
+          a.zf[2] = min(a.zf[2], k == 2 ? z : 0xffffffffu);
+        }
       }
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // up to 3 points behind the last whole group
+  {
+    const int turn = (int)(t % 3);  // slot s holds coordinate (s + t) mod 3
+    for (int k = 0; k < 3; k++) {
+      const int sl = (k + 3 - turn) % 3;
+      a.mn[k] = sl == 0 ? mn[0] : sl == 1 ? mn[1] : mn[2];
+      a.mx[k] = sl == 0 ? mx[0] : sl == 1 ? mx[1] : mx[2];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // up to 3 floats behind the last whole word
     const float *f = reinterpret_cast<const float *>(data);
-    for (int64_t i = groups << 2; i < n; i++)
-      for (int k = 0; k < 3; k++) {
-        mm_value(a, k, f[3 * i + k]);
-        mm_zero(a, k, f[3 * i + k], i);
-      }
+    for (int64_t fl = words << 2; fl < 3 * n; fl++) {
+      MinMaxAcc one;
+      minmax_init(one);
+      for (int k = 0; k < 3; k++)
+        if (fl % 3 == k) {
+          mm_value(one, k, f[fl]);
+          mm_zero(one, k, f[fl], fl / 3);
+        }
+      mm_merge(a, one);
+    }
   }
   minmax_block_fold(a, T);
 }
@@ -507,7 +554,7 @@ static pcgx_status launch_minmax_impl(const void *d_data, int64_t n, int32_t str
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
   MinMaxTail T;
-  PCGX_TRY(ctx().arena.alloc_n(blocks, &T.partials));
+  PCGX_TRY(ctx().arena.alloc_n(1024, &T.partials));
   T.ticket = ctx().tickets;  // (zero between launches: the last workgroup puts it back; one launch at a time per context)
   T.data = (const uint8_t *)d_data;
   T.off = off;
@@ -517,8 +564,11 @@ static pcgx_status launch_minmax_impl(const void *d_data, int64_t n, int32_t str
   T.seq = seq;
   memset(&T.hook, 0, sizeof T.hook);
   if (hook) T.hook = *hook;
-  if (stride == 12 && off == 0 && (reinterpret_cast<uintptr_t>(d_data) & 15) == 0)
-    hipLaunchKernelGGL(minmax_partial_packed_kernel, dim3(blocks), dim3(256), 0, st, (const float4 *)d_data, n, T);
+  // (the packed kernel wants a thread count that is 1 mod 3 -- 256 is -- and three words for every thread)
+  int pblocks = (int)std::min<int64_t>(1024, ((3 * n) >> 2) / (3 * 256));
+  pblocks -= (pblocks + 2) % 3;
+  if (stride == 12 && off == 0 && (reinterpret_cast<uintptr_t>(d_data) & 15) == 0 && pblocks >= 1)
+    hipLaunchKernelGGL(minmax_partial_packed_kernel, dim3(pblocks), dim3(256), 0, st, (const float4 *)d_data, n, T);
   else
     hipLaunchKernelGGL(minmax_partial_kernel, dim3(blocks), dim3(256), 0, st, (const uint8_t *)d_data, n, stride, off, T);
   PCGX_HIP_TRY(hipGetLastError());

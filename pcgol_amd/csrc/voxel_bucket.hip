@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
     const int64_t dst = (int64_t)gbase[d] + p;
     if (last_pass && (p == 0 || (__float_as_uint(srec[p - 1].w) >> low_bits) != (k >> low_bits)))
       atomicMax(&inv_start[k >> low_bits], ~(uint32_t)dst);
-    rec_out[dst] = e;
+    rec_out[dst] = e;  // (streaming stores here: +35 us on this pass, +17 on the bucket kernel)
     if (key_out) key_out[dst] = k;
     if (kIdx) idx_out[dst] = sidx[p];
   }
@@ -595,7 +595,7 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
     uint8_t *dst = out + slot * stride;
     if (!kIdx) {  // records are xyz and nothing else, 4-byte aligned
       float *d = reinterpret_cast<float *>(dst);
-      d[0] = o0[k]; d[1] = o1[k]; d[2] = o2[k];
+      d[0] = o0[k]; d[1] = o1[k]; d[2] = o2[k];  // (streaming stores: nothing, 393 against 394 us a call)
     } else {  // v.index: the first point in input order; its whole record is copied (voxelgrid.go:152-155,173-177)
       const uint8_t *src = data + (int64_t)idx[(int64_t)start + head[k]] * stride;
       if ((stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out)) & 3) == 0) {

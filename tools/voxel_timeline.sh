@@ -1,12 +1,12 @@
 #!/bin/bash
 # Where a C3 filter call's time goes on the GPU: every kernel of the steady-state calls with its start (relative to the
 # call's first kernel), duration and the gap in front of it -- median over the calls of tools/voxel_probe.py.
-#   bash tools/voxel_timeline.sh [tag]
+#   bash tools/voxel_timeline.sh [tag]          (PROBE_N=<points> for another cloud size)
 TAG=${1:-voxtl}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 tools/voxel_probe.py > $OUT/probe.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 tools/voxel_probe.py $PROBE_N > $OUT/probe.log 2>&1
 tail -1 $OUT/probe.log
 python3 - "$OUT" <<'PY' | tee $OUT/timeline.txt
 import csv, glob, sys, statistics
@@ -19,6 +19,8 @@ rows.sort()
 calls, cur = [], []
 for s, e, name in rows:
     cur.append((s, e, name))
+    if not any(w in name for w in ("pcgx", "minmax", "vb_", "copyBuffer", "radix", "voxel")):
+        cur.pop()  # (the probe's own kernels between calls)
     if "copyBuffer" in name or "read_back_kernel" in name:
         calls.append(cur); cur = []
 calls = [c for c in calls if any("bucket_kernel" in n for _, _, n in c)][5:]
