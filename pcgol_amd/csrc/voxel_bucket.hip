@@ -32,12 +32,10 @@ namespace pcgx {
 
 constexpr int kVbThreads = 256, kVbItems = 8, kVbTile = kVbThreads * kVbItems;  // scatter tiles (36 KB of LDS: four per CU)
 constexpr int kVbWaves = kVbThreads / 64;
-constexpr int kVbMaxCell = 255;        // points per cell it puts in order by itself
 #ifndef PCGX_VB_FINAL_THREADS
 #define PCGX_VB_FINAL_THREADS 256
 #endif
 constexpr int kVbFinalThreads = PCGX_VB_FINAL_THREADS;
-constexpr long long kVbWaitTicks = 500000;  // 5 ms of s_memrealtime (100 MHz): a bucket that waits longer gives up, the radix path answers
 constexpr int kVbSampleEvery = 32;     // every 32nd point is counted per bucket before anything is moved
 
 // ---- keys, first tile histograms, a sample of the bucket populations ---------------------------------------------
@@ -292,325 +290,303 @@ __global__ __launch_bounds__(kVbThreads) void vb_scatter_kernel(
   }
 }
 
-// ---- the bucket kernel --------------------------------------------------------------------------------------------
-// Where a bucket's cells go in the output = the occupied cells of all buckets before it.  Tagged words (value | 2^31),
-// each written once with a write-through store and read with loads that bypass the vector L1 -- no atomics:
-//   count[b]      by every bucket, as soon as it has counted its cells (nothing to wait for);
-//   group_tot[g]  the 32 buckets of group g, by the group's LAST bucket once it has read the other 31 counts -- which
-//                 it does anyway, for its own place;
-//   super_tot[G]  the 32 groups (1024 buckets) of G, by G's last bucket, the same way from the group totals.
-// A bucket that needs its place reads super_tot of the 1024-groups before its own, group_tot of the groups before
-// its own inside its 1024-group and count of the buckets before it in its group: three loads per lane, a handful of
-// cache lines, until every word carries its tag.  It waits for lower block indices only, which were dispatched
-// before it (strict.hip, strict_sum_kernel: why that ends), and the totals it waits for depend on counts alone.
-// (Measured on the way: arrival bits + a returning atomic per bucket to find out who completes a group -- two round
-// trips on every workgroup's path, 50 us per C3 call; counts added into per-group 64-bit accumulators with
-// fire-and-forget atomics and read by every later workgroup -- the accumulators' lines ping-pong between the adding
-// and the polling XCDs, 0.25-0.6 ms of waiting per call.)
-struct VbExchange {
-  uint32_t *count;      // [nbuckets]
-  uint32_t *group_tot;  // [ceil(nbuckets / 32)]
-  uint32_t *super_tot;  // [ceil(nbuckets / 1024)] (<= 64)
-};
+// ---- the bucket kernel and the placing kernel -----------------------------------------------------------------------
+// Where a bucket's cells go in the output = the occupied cells of all buckets before it -- which no bucket knows
+// while it works.  Two kernels: the bucket kernel does everything but the placing -- a cell's result {x, y, z, the
+// first point's index} goes to cells[bucket's first point + the cell's rank among the bucket's occupied ones], an array
+// the passes are through with, and the bucket's count of occupied cells into count[b] and, with fire-and-forget
+// atomics, into its group's (32 buckets) and its 1024-group's totals; the placing kernel, a wave per bucket, adds up
+// what is before its bucket (three loads, final values: nothing to wait for) and copies the bucket's cells to their
+// place.  38 MB written and read once more at C3, 20 us.
+//
+// One kernel with the buckets WAITING for their place took 118 us.  Workgroup by workgroup (wall clock stamps, C3, 13010
+// buckets): 6.5 us of work -- bounds 0.8, points into LDS 2.3, cells scanned 0.9, order[] 0.4, cell phase 1.8 --
+// and 7 us of waiting with 26 KB of LDS held, ten looks at words that were not there yet: a count is out 4.3 us into
+// its workgroup's life, visible to another XCD 2 us later, and the buckets right before a bucket were dispatched
+// within the same microsecond (up to 3 us AFTER it on another XCD); a look (agent-scope loads, past the L2) takes 3 us
+// under the kernel's traffic.  Reading the last 14 groups' counts directly instead of their totals (which their last
+// bucket publishes another poll later): 4.4 us of waiting, 2 looks, 113 us.  (Earlier forms of the exchange, all
+// slower: arrival bits + a returning atomic per bucket; per-group accumulators polled by every later workgroup; totals
+// published at the end of a workgroup or behind its own wait.)
 
-__device__ __forceinline__ uint32_t ld_sc1_u32(const uint32_t *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// the bucket's points: from its start (the last pass's finding, kept as the complement; a cleared word: no points) to
+// the start of the next bucket that has any.  One wave's worth of words at once: the bucket's own and the 63 behind it.
+__device__ __forceinline__ void vb_bucket_bounds(const uint32_t *__restrict__ bucket_start, int b, int nbuckets, int64_t n, int lane,
+                                                 uint32_t &start, uint32_t &end) {
+  start = end = 0;
+  for (int base = b;; base += 64) {
+    const int j = base + lane;
+    uint32_t v = j < nbuckets ? bucket_start[j] : ~(uint32_t)n;  // (behind the last bucket: n)
+    if (base == b) {
+      const uint32_t own = (uint32_t)__shfl((int)v, 0);
+      if (own == 0u) return;  // uniform: no points
+      start = ~own;
+      if (lane == 0) v = 0u;
+    }
+    const uint64_t found = __ballot(v != 0u);
+    if (found) {
+      end = ~(uint32_t)__shfl((int)v, __ffsll((long long)found) - 1);
+      return;
+    }
+  }
 }
 
 template <bool kIdx>
 __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
     const float4 *__restrict__ rec0, const float4 *__restrict__ rec1, int64_t n, const uint32_t *__restrict__ idx0,
-    const uint32_t *__restrict__ idx1,
-    const uint32_t *__restrict__ bucket_start, const VoxelDevPlan *__restrict__ dp, const uint8_t *__restrict__ data, int32_t stride,
-    int32_t off, uint8_t *__restrict__ out, VbExchange ex, int64_t *__restrict__ total, int32_t *__restrict__ flags) {
+    const uint32_t *__restrict__ idx1, const uint32_t *__restrict__ bucket_start, const VoxelDevPlan *__restrict__ dp,
+    float4 *cells0, float4 *cells1, uint32_t *__restrict__ count, int32_t *__restrict__ flags) {
   constexpr int kBins = 1 << kVbMaxLowBits, kWaves = kVbFinalThreads / 64;
-  constexpr int kPer = kVbCap / kVbFinalThreads;       // points per thread
+  constexpr int kRounds = kVbCap / kVbFinalThreads;    // points per thread: a wave takes a quarter of the bucket, 64 at a time
   constexpr int kBinsPer = kBins / kVbFinalThreads;    // cells per thread
-  __shared__ float sx[kVbCap], sy[kVbCap], sz[kVbCap];
-  __shared__ uint16_t order[kVbCap];    // positions cell after cell, as they arrived
-  __shared__ uint32_t cnt[kBins];       // points of the cell; then: its first place in order[]
-  __shared__ uint16_t ccount[kBins];    // points of the cell (kept)
-  __shared__ uint16_t vrank[kBins];     // occupied cells before it in the bucket
+  static_assert(kVbCap % kVbFinalThreads == 0 && kVbCap < 65536, "whole rounds; places are 16 bits");
+  __shared__ float sx[kVbCap], sy[kVbCap], sz[kVbCap];   // the bucket's points, cell after cell, input order inside a cell
+  __shared__ uint16_t sfrom[kIdx ? kVbCap : 1];          // (records with more than xyz: the point's place in the bucket's input order)
+  __shared__ uint16_t cnt[kWaves][kBins + 1];            // a wave's points of the cell; then: where they begin in sx / sy / sz
+  __shared__ uint16_t vrank[kBins];                      // occupied cells before it in the bucket
   __shared__ uint32_t wsum[kWaves], wocc[kWaves];
-  __shared__ uint32_t s_prefix;
   if (*flags & 9) return;  // uniform: not a call for this path / a bucket does not fit (an earlier kernel's finding): the radix path
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (b >= dp->plan.nbuckets) return;  // uniform (the grid is the most buckets a plan can have: the host does not know the plan)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const VoxelParams vp = dp->vp;
   const VbPlan plan = dp->plan;
   const bool two = plan.d_bits[1] != 0;  // the arrays the last pass wrote
   const float4 *__restrict__ rec = two ? rec1 : rec0;  // {x, y, z, bits(key)} (vb_scatter_kernel)
   const uint32_t *__restrict__ idx = two ? idx1 : idx0;
+  float4 *cells = two ? cells0 : cells1;  // (the array the last pass did not write)
   const int nbins = 1 << plan.low_bits;
-  // the bucket's points: from its start (the last pass's finding, kept as the complement; a cleared word: no points) to
-  // the start of the next bucket that has any
-  const uint32_t inv = bucket_start[b];
-  uint32_t start = 0, end = 0;
-  if (inv != 0u) {  // uniform
-    start = ~inv;
-    for (int base = b + 1;; base += 64) {
-      const int j = base + lane;
-      const uint32_t v = j < plan.nbuckets ? bucket_start[j] : ~(uint32_t)n;  // (behind the last bucket: n)
-      const uint64_t found = __ballot(v != 0u);
-      if (found) {
-        end = ~(uint32_t)__shfl((int)v, __ffsll((long long)found) - 1);
-        break;
-      }
-    }
-  }
-  const bool fits = end - start <= (uint32_t)kVbCap;
-  const int P = fits ? (int)(end - start) : 0;
-  for (int l = threadIdx.x; l < nbins; l += kVbFinalThreads) cnt[l] = 0;
-  __syncthreads();
-  // ---- the bucket's points, in input order (the partition is stable); arrival order inside a cell is arbitrary
-  uint16_t arr[kPer], low[kPer];
   const uint32_t lmask = (uint32_t)nbins - 1u;
-#pragma unroll
-  for (int r = 0; r < kPer; r++) {
-    const int i = r * kVbFinalThreads + threadIdx.x;
-    arr[r] = low[r] = 0;
-    if (i < P) {
-      const int64_t g = (int64_t)start + i;
-      const float4 e = rec[g];
-      const uint32_t l = __float_as_uint(e.w) & lmask;
-      sx[i] = e.x;
-      sy[i] = e.y;
-      sz[i] = e.z;
-      low[r] = (uint16_t)l;
-      arr[r] = (uint16_t)atomicAdd(&cnt[l], 1u);
+  const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  // (the grid is what fits the device at once, whatever the plan: the host does not know the plan)
+  for (int b = blockIdx.x; b < plan.nbuckets; b += gridDim.x) {
+    uint32_t start, end;
+    vb_bucket_bounds(bucket_start, b, plan.nbuckets, n, lane, start, end);
+    if (end - start > (uint32_t)kVbCap) {  // uniform: more points than the LDS tile -- the radix path does the call
+      if (threadIdx.x == 0) atomicOr(flags, 1);
+      return;
     }
-  }
-  __syncthreads();
-  // ---- cells -> first place (exclusive scan of the counts) and rank among the occupied ones; thread t: cells
-  // t * kBinsPer .. (consecutive, for the scan)
-  uint32_t occupied_total = 0;
-  bool crowded = false;
-  {
-    uint32_t c[kBinsPer], sum = 0, occ = 0;
+    const int P = (int)(end - start);
+    if (P == 0) continue;  // uniform: no points, no cells, nothing to count (the words are cleared)
+    // ---- the bucket's points: wave w takes the w-th quarter, 64 at a time -- (wave, round, lane) is input order (the
+    // partition passes are stable)
+    const int quarter = (P + kWaves - 1) / kWaves, w_begin = wave * quarter, w_end = min(P, w_begin + quarter);
+    float4 e[kRounds];
 #pragma unroll
-    for (int k = 0; k < kBinsPer; k++) {
-      const int l = threadIdx.x * kBinsPer + k;
-      c[k] = l < nbins ? cnt[l] : 0u;
-      sum += c[k];
-      occ += c[k] ? 1u : 0u;
-      crowded |= c[k] > (uint32_t)kVbMaxCell;
+    for (int r = 0; r < kRounds; r++) {
+      const int i = w_begin + r * 64 + lane;
+      e[r] = i < w_end ? rec[(int64_t)start + i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    const uint32_t inc = wave_incl_scan_u32(sum), oinc = wave_incl_scan_u32(occ);
-    if (lane == 63) {
-      wsum[wave] = inc;
-      wocc[wave] = oinc;
+    for (int l = threadIdx.x; l < kWaves * (kBins + 1); l += kVbFinalThreads) (&cnt[0][0])[l] = 0;
+    __syncthreads();
+    // ---- a point's rank among its wave's points of the same cell, in input order: the lanes of a round with the same
+    // cell by ballots over the cell number's bits (vb_scatter_kernel's ranking), the earlier rounds by the wave's count
+    uint16_t rank[kRounds];
+    {
+      volatile uint16_t *my_cnt = cnt[wave];
+#pragma unroll
+      for (int r = 0; r < kRounds; r++) {
+        const bool valid = w_begin + r * 64 + lane < w_end;
+        const uint32_t d = __float_as_uint(e[r].w) & lmask;
+        uint64_t m = __ballot(valid);
+        if (m == 0ull) {  // uniform
+          rank[r] = 0;
+          continue;
+        }
+        for (int bit = 0; bit < plan.low_bits; bit++) {  // uniform
+          const bool one = (d >> bit) & 1u;
+          const uint64_t bal = __ballot(one);
+          m &= one ? bal : ~bal;
+        }
+        uint32_t prev = 0;
+        if (valid) prev = my_cnt[d];
+        rank[r] = (uint16_t)(prev + (uint32_t)__popcll(m & lt_mask));
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (m >> lane) == 1ull) my_cnt[d] = (uint16_t)(prev + (uint32_t)__popcll(m));
+        __builtin_amdgcn_wave_barrier();
+      }
     }
     __syncthreads();
-    uint32_t wb = 0, ob = 0;
-    for (int w = 0; w < kWaves; w++) {
-      if (w < wave) {
-        wb += wsum[w];
-        ob += wocc[w];
+    // ---- cells -> where their points begin (exclusive scan of the counts, wave after wave inside a cell) and their rank
+    // among the occupied ones; thread t: cells t * kBinsPer .. (consecutive, for the scan)
+    uint32_t occupied_total = 0;
+    {
+      uint32_t c[kBinsPer][kWaves], sum = 0, occ = 0;
+#pragma unroll
+      for (int k = 0; k < kBinsPer; k++) {
+        const int l = threadIdx.x * kBinsPer + k;
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) {
+          c[k][w] = l < nbins ? cnt[w][l] : 0u;
+          t += c[k][w];
+        }
+        sum += t;
+        occ += t ? 1u : 0u;
       }
-      occupied_total += wocc[w];
+      const uint32_t inc = wave_incl_scan_u32(sum), oinc = wave_incl_scan_u32(occ);
+      if (lane == 63) {
+        wsum[wave] = inc;
+        wocc[wave] = oinc;
+      }
+      __syncthreads();
+      uint32_t wb = 0, ob = 0;
+      for (int w = 0; w < kWaves; w++) {
+        if (w < wave) {
+          wb += wsum[w];
+          ob += wocc[w];
+        }
+        occupied_total += wocc[w];
+      }
+      uint32_t run = wb + inc - sum, orun = ob + oinc - occ;
+#pragma unroll
+      for (int k = 0; k < kBinsPer; k++) {
+        const int l = threadIdx.x * kBinsPer + k;
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) {
+          if (l < nbins) cnt[w][l] = (uint16_t)(run + t);
+          t += c[k][w];
+        }
+        if (l < nbins) vrank[l] = (uint16_t)orun;
+        run += t;
+        orun += t ? 1u : 0u;
+      }
+      if (threadIdx.x == kVbFinalThreads - 1) cnt[0][nbins] = (uint16_t)P;  // (a cell's points end where the next one's begin)
     }
-    uint32_t run = wb + inc - sum, orun = ob + oinc - occ;
+    __syncthreads();
+    if (threadIdx.x == 0) count[b] = occupied_total;
+    // ---- the points to their places
+#pragma unroll
+    for (int r = 0; r < kRounds; r++) {
+      const int i = w_begin + r * 64 + lane;
+      if (i < w_end) {
+        const int pos = (int)cnt[wave][__float_as_uint(e[r].w) & lmask] + (int)rank[r];
+        sx[pos] = e[r].x;
+        sy[pos] = e[r].y;
+        sz[pos] = e[r].z;
+        if (kIdx) sfrom[pos] = (uint16_t)i;
+      }
+    }
+    __syncthreads();
+    // ---- cell by cell: the reference's sequential float32 sum over its points in input order, the centroid; thread t:
+    // cells t, t + 256, ... (neighbouring lanes neighbouring cells: their points are neighbours in LDS, their stores too)
 #pragma unroll
     for (int k = 0; k < kBinsPer; k++) {
-      const int l = threadIdx.x * kBinsPer + k;
-      if (l < nbins) {
-        cnt[l] = run;
-        ccount[l] = (uint16_t)c[k];
-        vrank[l] = (uint16_t)orun;
+      const int l = k * kVbFinalThreads + threadIdx.x;
+      if (l >= nbins || (plan.dbg & 2)) continue;
+      const int first = (int)cnt[0][l], c = (int)cnt[0][l + 1] - first;
+      if (c == 0) continue;
+      float o0 = sx[first], o1 = sy[first], o2 = sz[first];
+      if (c > 1) {
+        const uint32_t key = ((uint32_t)b << plan.low_bits) | (uint32_t)l;
+        float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
+        if (vp.chunked) chunk_origin(vp, vp.combined ? key / (uint32_t)vp.n_voxels : 0u, origin);
+        // p := it.Vec3().Sub(vMin); v.sum = v.sum.Add(p)   (voxelgrid.go:149,157)
+        float s0 = 0.0f + (o0 - origin[0]), s1 = 0.0f + (o1 - origin[1]), s2 = 0.0f + (o2 - origin[2]);
+        for (int j = 1; j < c; j++) {
+          s0 = s0 + (sx[first + j] - origin[0]);
+          s1 = s1 + (sy[first + j] - origin[1]);
+          s2 = s2 + (sz[first + j] - origin[2]);
+        }
+        const float inv = 1.0f / (float)c;  // jt.SetVec3(v.sum.Mul(1.0 / float32(n)).Add(vMin))  (voxelgrid.go:178-180)
+        o0 = s0 * inv + origin[0];
+        o1 = s1 * inv + origin[1];
+        o2 = s2 * inv + origin[2];
       }
-      run += c[k];
-      orun += c[k] ? 1u : 0u;
+      // v.index: the cell's first point in input order (voxelgrid.go:152-155); the placing kernel copies its record
+      const uint32_t src = kIdx ? idx[(int64_t)start + sfrom[first]] : 0u;
+      cells[(int64_t)start + vrank[l]] = make_float4(o0, o1, o2, __uint_as_float(src));
     }
+    __syncthreads();  // (the next bucket clears cnt[] and fills sx / sy / sz)
   }
-  const bool skip = __syncthreads_or((crowded || !fits) ? 1 : 0) != 0;  // (also the barrier behind cnt[] / ccount[])
-  if (skip && threadIdx.x == 0) atomicOr(flags, fits ? 2 : 1);  // more points than the LDS tile / than a cell is ordered for: radix path
-  // ---- my count out at once, nothing to wait for (the later buckets read it); my own wait comes last
-  if (threadIdx.x == 0)
-    __hip_atomic_store(&ex.count[b], occupied_total | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int n2 = b >> 10, n1 = (b >> 5) & 31, n0 = b & 31;
-  const bool closes_group = n0 == 31;  // (this bucket publishes its group's total, and its 1024-group's if it closes that too)
-  // The totals this bucket owes the later ones go out NOW, as soon as their parts are in -- a group's total needs its
-  // buckets' counts (published at this same point of their workgroups, a moment ago) and nothing else.  Published at
-  // the end of the workgroup instead, every bucket's own wait met totals that were still being made (two polls
-  // instead of one: 40 us per C3 call); published only behind the wait for the earlier groups, the groups chained
-  // one behind the other (0.28 ms).
-  if (closes_group && wave == 0) {
-    bool pub_group = false, pub_super = n1 != 31;
-    long long t_first = 0;
-    for (int spins = 0; !(pub_group && pub_super); spins++) {
-      if ((spins & 63) == 63) {
-        const long long now = (long long)wall_clock64();
-        if (t_first == 0) t_first = now;
-        if (now - t_first > kVbWaitTicks) break;  // (the buckets behind this group then give up as well)
-      }
-      const uint32_t w1 = (lane < n1 && !pub_super) ? ld_sc1_u32(&ex.group_tot[(n2 << 5) + lane]) : 0x80000000u;
-      const uint32_t w0 = lane < n0 ? ld_sc1_u32(&ex.count[((b >> 5) << 5) + lane]) : 0x80000000u;
-      const bool ok0 = __ballot((w0 >> 31) == 0u) == 0ull, ok1 = __ballot((w1 >> 31) == 0u) == 0ull;
-      uint32_t t0 = w0 & 0x7fffffffu, t1 = w1 & 0x7fffffffu;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        t0 += __shfl_xor(t0, o);
-        t1 += __shfl_xor(t1, o);
-      }
-      if (ok0 && !pub_group) {
-        if (lane == 0)
-          __hip_atomic_store(&ex.group_tot[b >> 5], (t0 + occupied_total) | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pub_group = true;
-      }
-      if (ok0 && ok1 && !pub_super) {
-        if (lane == 0)
-          __hip_atomic_store(&ex.super_tot[n2], (t1 + t0 + occupied_total) | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pub_super = true;
-      }
-      if (!(pub_group && pub_super)) __builtin_amdgcn_s_sleep(4);
-    }
-  }
-  const bool last = b == plan.nbuckets - 1;
-  if ((P == 0 || skip) && !last) return;  // uniform: nothing to write (the last bucket also reports the total)
-  // ---- positions cell after cell (arrival order inside a cell)
-#pragma unroll
-  for (int r = 0; r < kPer; r++) {
-    const int i = r * kVbFinalThreads + threadIdx.x;
-    if (i < P) order[cnt[low[r]] + arr[r]] = (uint16_t)i;
-  }
+}
+
+// The buckets' counts of occupied cells -> where each bucket's cells begin in the output (their exclusive prefix, over
+// the counts in place) and the call's total: one workgroup, a run of consecutive buckets per thread.  (Totals per 32 and
+// per 1024 buckets added up by the bucket kernel with fire-and-forget atomics instead: atomics on words of ONE 128-byte
+// line are served one after the other, 10 ns each -- 13010 of them on the thirteen 1024-bucket totals made the
+// bucket kernel 189 us long.)
+__global__ __launch_bounds__(1024) void vb_prefix_kernel(uint32_t *__restrict__ count, const VoxelDevPlan *__restrict__ dp,
+                                                         int64_t *__restrict__ total, const int32_t *__restrict__ flags) {
+  __shared__ uint32_t wsum[16];
+  if (*flags) return;  // uniform
+  const int nb = dp->plan.nbuckets, per = (nb + 1023) / 1024, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b0 = (int)threadIdx.x * per, b1 = min(b0 + per, nb);
+  uint32_t sum = 0;
+  for (int b = b0; b < b1; b++) sum += count[b];
+  const uint32_t inc = wave_incl_scan_u32(sum);
+  if (lane == 63) wsum[wave] = inc;
   __syncthreads();
-  // ---- cell by cell: its points into input order (ascending position: a sorting network over eight registers; a
-  // cell with more points -- one in a thousand at three points per cell -- picks the next position by scanning), the
-  // reference's sequential float32 sum, centroid (kept in registers until the place is known); thread t: cells t,
-  // t + 256, ... (neighbouring lanes neighbouring cells: their stores are neighbours too)
-  float o0[kBinsPer], o1[kBinsPer], o2[kBinsPer];
-  int head[kBinsPer], cc[kBinsPer];
-#pragma unroll
-  for (int k = 0; k < kBinsPer; k++) {
-    const int l = k * kVbFinalThreads + threadIdx.x;
-    cc[k] = (l < nbins && !skip && !(plan.dbg & 2)) ? ccount[l] : 0;
-    head[k] = 0;
-    o0[k] = o1[k] = o2[k] = 0.0f;
-    if (cc[k] == 0) continue;
-    const int first = (int)cnt[l], c = cc[k];
-    const uint32_t key = ((uint32_t)b << plan.low_bits) | (uint32_t)l;
-    float origin[3] = {vp.vmin[0], vp.vmin[1], vp.vmin[2]};
-    if (vp.chunked) chunk_origin(vp, vp.combined ? key / (uint32_t)vp.n_voxels : 0u, origin);
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f;
-    if (c <= 8) {
-      uint32_t e[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) e[j] = j < c ? (uint32_t)order[first + j] : 0xffffu + (uint32_t)j;  // (padding sorts behind every position)
-      auto cas = [&](int x, int y) {
-        const uint32_t lo = e[x] < e[y] ? e[x] : e[y], hi = e[x] < e[y] ? e[y] : e[x];
-        e[x] = lo;
-        e[y] = hi;
-      };
-      // 19 compare-exchanges (Batcher's odd-even merge sort of eight)
-      cas(0, 1); cas(2, 3); cas(4, 5); cas(6, 7);
-      cas(0, 2); cas(1, 3); cas(4, 6); cas(5, 7);
-      cas(1, 2); cas(5, 6);
-      cas(0, 4); cas(1, 5); cas(2, 6); cas(3, 7);
-      cas(2, 4); cas(3, 5);
-      cas(1, 2); cas(3, 4); cas(5, 6);
-      float px[8], py[8], pz[8];
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int m = j < c ? (int)e[j] : (int)e[0];
-        px[j] = sx[m]; py[j] = sy[m]; pz[j] = sz[m];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        if (j < c) {  // p := it.Vec3().Sub(vMin); v.sum = v.sum.Add(p)   (voxelgrid.go:149,157)
-          s0 = s0 + (px[j] - origin[0]);
-          s1 = s1 + (py[j] - origin[1]);
-          s2 = s2 + (pz[j] - origin[2]);
-        }
-      }
-      head[k] = (int)e[0];
-      o0[k] = px[0]; o1[k] = py[0]; o2[k] = pz[0];
-    } else {
-      int last_pos = -1;
-      for (int t = 0; t < c; t++) {  // the next position above `last_pos`
-        int m = 0x7fffffff;
-        for (int j = 0; j < c; j++) {
-          const int v = order[first + j];
-          m = (v > last_pos && v < m) ? v : m;
-        }
-        if (t == 0) head[k] = m;
-        s0 = s0 + (sx[m] - origin[0]);
-        s1 = s1 + (sy[m] - origin[1]);
-        s2 = s2 + (sz[m] - origin[2]);
-        last_pos = m;
-      }
-      o0[k] = sx[head[k]]; o1[k] = sy[head[k]]; o2[k] = sz[head[k]];
-    }
-    if (c > 1) {  // jt.SetVec3(v.sum.Mul(1.0 / float32(n)).Add(vMin))  (voxelgrid.go:178-180)
-      const float inv = 1.0f / (float)c;
-      o0[k] = s0 * inv + origin[0];
-      o1[k] = s1 * inv + origin[1];
-      o2[k] = s2 * inv + origin[2];
-    }
+  uint32_t run = inc - sum, all = 0;
+  for (int w = 0; w < 16; w++) {
+    if (w < wave) run += wsum[w];
+    all += wsum[w];
   }
-  // ---- where the bucket's cells go: the occupied cells of all buckets before it (they were dispatched before this
-  // one and have published their counts long since: one round of loads as a rule)
-  if (wave == 0) {
-    bool gave_up = false;
-    uint32_t s2 = 0, s1 = 0, s0 = 0;
-    long long t_first = 0;
-    for (int spins = 0; !(plan.dbg & 1); spins++) {
-      // (issued before the cell phase and looked at here, the first poll was slower: 138 us against 124 for the kernel)
-      const uint32_t w2 = lane < n2 ? ld_sc1_u32(&ex.super_tot[lane]) : 0x80000000u;
-      const uint32_t w1 = lane < n1 ? ld_sc1_u32(&ex.group_tot[(n2 << 5) + lane]) : 0x80000000u;
-      const uint32_t w0 = lane < n0 ? ld_sc1_u32(&ex.count[((b >> 5) << 5) + lane]) : 0x80000000u;
-      s2 = w2 & 0x7fffffffu;
-      s1 = w1 & 0x7fffffffu;
-      s0 = w0 & 0x7fffffffu;
-      if (__ballot(((w2 & w1 & w0) >> 31) == 0u) == 0ull) break;
-      if ((spins & 63) == 63) {
-        const long long now = (long long)wall_clock64();
-        if (t_first == 0) t_first = now;
-        if (now - t_first > kVbWaitTicks) {
-          gave_up = true;
-          break;
-        }
-      }
-      __builtin_amdgcn_s_sleep(4);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      s2 += __shfl_xor(s2, o);
-      s1 += __shfl_xor(s1, o);
-      s0 += __shfl_xor(s0, o);
-    }
-    if (lane == 0) {
-      const uint32_t v = s2 + s1 + s0;
-      s_prefix = v;
-      if (gave_up) atomicOr(flags, 4);
-      if (last && !gave_up) *total = (int64_t)v + (int64_t)occupied_total;
-    }
+  for (int b = b0; b < b1; b++) {
+    const uint32_t c = count[b];
+    count[b] = run;
+    run += c;
   }
-  __syncthreads();
-  const uint32_t prefix = s_prefix;
-#pragma unroll
-  for (int k = 0; k < kBinsPer; k++) {
-    if (cc[k] == 0) continue;
-    const int l = k * kVbFinalThreads + threadIdx.x;
-    const int64_t slot = (int64_t)prefix + vrank[l];
-    uint8_t *dst = out + slot * stride;
-    if (!kIdx) {  // records are xyz and nothing else, 4-byte aligned
-      float *d = reinterpret_cast<float *>(dst);
-      d[0] = o0[k]; d[1] = o1[k]; d[2] = o2[k];  // (streaming stores: nothing, 393 against 394 us a call)
-    } else {  // v.index: the first point in input order; its whole record is copied (voxelgrid.go:152-155,173-177)
-      const uint8_t *src = data + (int64_t)idx[(int64_t)start + head[k]] * stride;
-      if ((stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out)) & 3) == 0) {
-        for (int q = 0; q < stride; q += 4) *reinterpret_cast<uint32_t *>(dst + q) = *reinterpret_cast<const uint32_t *>(src + q);
-      } else {
-        for (int q = 0; q < stride; q++) dst[q] = src[q];
+  if (threadIdx.x == 0) *total = (int64_t)all;
+}
+
+// A wave per bucket: its cells from where the bucket kernel left them to their place in the output.  (How many: to the
+// next bucket's place, or the total.)
+template <bool kIdx>
+__global__ __launch_bounds__(256) void vb_place_kernel(const float4 *__restrict__ cells0, const float4 *__restrict__ cells1,
+                                                       const uint32_t *__restrict__ bucket_start, const VoxelDevPlan *__restrict__ dp,
+                                                       const uint8_t *__restrict__ data, int32_t stride, int32_t off,
+                                                       uint8_t *__restrict__ out, const uint32_t *__restrict__ place,
+                                                       const int64_t *__restrict__ total, const int32_t *__restrict__ flags) {
+  if (*flags) return;  // uniform: the radix path does the call
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nbuckets = dp->plan.nbuckets;
+  const float4 *__restrict__ cells = dp->plan.d_bits[1] != 0 ? cells0 : cells1;
+  const bool words = (stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out)) & 3) == 0;
+  for (int b = (int)blockIdx.x * 4 + wave; b < nbuckets; b += (int)gridDim.x * 4) {
+    const uint32_t inv = bucket_start[b];
+    const uint32_t s = place[b], next = b + 1 < nbuckets ? place[b + 1] : (uint32_t)*total;
+    const uint32_t mine = next - s;
+    if (mine == 0u) continue;  // uniform in the wave
+    const int64_t from = (int64_t)(~inv), to = (int64_t)s;
+    for (uint32_t j = lane; j < mine; j += 64) {
+      const float4 c = cells[from + j];
+      uint8_t *dst = out + (to + j) * stride;
+      if (!kIdx) {  // records are xyz and nothing else, 4-byte aligned
+        float *d = reinterpret_cast<float *>(dst);
+        d[0] = c.x; d[1] = c.y; d[2] = c.z;
+      } else {  // the first point's whole record, its xyz replaced (voxelgrid.go:173-184)
+        const uint8_t *src = data + (int64_t)__float_as_uint(c.w) * stride;
+        if (words) {
+          for (int q = 0; q < stride; q += 4) *reinterpret_cast<uint32_t *>(dst + q) = *reinterpret_cast<const uint32_t *>(src + q);
+        } else {
+          for (int q = 0; q < stride; q++) dst[q] = src[q];
+        }
+        __builtin_memcpy(dst + off, &c.x, 4);
+        __builtin_memcpy(dst + off + 4, &c.y, 4);
+        __builtin_memcpy(dst + off + 8, &c.z, 4);
       }
-      __builtin_memcpy(dst + off, &o0[k], 4);
-      __builtin_memcpy(dst + off + 4, &o1[k], 4);
-      __builtin_memcpy(dst + off + 8, &o2[k], 4);
     }
   }
 }
 
 static std::atomic<long long> g_vb_taken{0}, g_vb_given_up{0}, g_vb_last_flags{0}, g_vb_last_low{0};
+
+// the bucket kernel's grid: the workgroups the device holds at once (each walks the buckets blockIdx.x, + grid, ...)
+static int vb_resident_grid(bool with_idx) {
+  static int grid[2] = {0, 0};
+  int &g = grid[with_idx ? 1 : 0];
+  if (g == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    hipError_t e = with_idx ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vb_bucket_kernel<true>, kVbFinalThreads, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, vb_bucket_kernel<false>, kVbFinalThreads, 0);
+    if (e == hipSuccess) e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+    g = (e == hipSuccess && per_cu > 0) ? per_cu * prop.multiProcessorCount : 1024;
+    (void)hipGetLastError();
+  }
+  return g;
+}
 
 static int vb_knob(const char *name, int def) {
   const char *e = getenv(name);
@@ -650,10 +626,9 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   uint32_t *block_hist = nullptr, *totals = nullptr, *bucket_sample = nullptr, *inv_start = nullptr;
   float *d_mm6 = nullptr;
   VoxelDevPlan *d_plan = nullptr;
-  int32_t *d_flags = nullptr;  // [0] flags (1 crowded bucket, 2 crowded cell, 4 the exchange gave up, 8 no plan), [1] key out of range
+  int32_t *d_flags = nullptr;  // [0] flags (1 crowded bucket, 8 no plan), [1] key out of range
   int64_t *d_total = nullptr;
-  VbExchange ex;
-  constexpr int64_t kGroups = kVbMaxBuckets / 32, kSuper = kVbMaxBuckets / 1024;
+  uint32_t *cell_count = nullptr;  // [buckets] occupied cells; then: where the bucket's cells begin in the output
   PCGX_TRY(ar.alloc_n((size_t)n, &key0));
   PCGX_TRY(ar.alloc_n((size_t)n, &key1));
   for (int k = 0; k < 2; k++) {
@@ -674,7 +649,7 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   };
   static_assert(sizeof(Readback) % 8 == 0, "words");
   constexpr size_t kHeadWords = (sizeof(Readback) + 127) / 128 * 32;
-  const size_t zero_words = kHeadWords + (size_t)kVbMaxBuckets * 3 + (size_t)kGroups + (size_t)kSuper;
+  const size_t zero_words = kHeadWords + (size_t)kVbMaxBuckets * 3;
   uint32_t *zero_block = nullptr;
   PCGX_TRY(ar.alloc_n(zero_words + 64, &zero_block));
   zero_block = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(zero_block) + 127) & ~(uintptr_t)127);
@@ -683,13 +658,11 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   d_total = &d_rb->total;
   d_plan = &d_rb->plan;
   bucket_sample = zero_block + kHeadWords;
-  ex.count = bucket_sample + kVbMaxBuckets;
-  ex.group_tot = ex.count + kVbMaxBuckets;
-  ex.super_tot = ex.group_tot + kGroups;
-  inv_start = ex.super_tot + kSuper;
+  cell_count = bucket_sample + kVbMaxBuckets;
+  inv_start = cell_count + kVbMaxBuckets;
   // (no memset, no kernel for the plan: the min/max launch clears the words behind the head as it goes, and its last
   // workgroup writes the head -- flags, the plan -- behind the six floats)
-  static_assert(kHeadWords % 4 == 0 && (kVbMaxBuckets * 3 + kGroups + kSuper) % 4 == 0, "cleared 16 bytes at a time");
+  static_assert(kHeadWords % 4 == 0 && (kVbMaxBuckets * 3) % 4 == 0, "cleared 16 bytes at a time");
   kn.dp = d_plan;
   kn.head = d_flags;
   kn.zero = zero_block + kHeadWords;
@@ -731,15 +704,26 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
                        (const float4 *)recb[0], (const uint32_t *)nullptr, (const uint32_t *)idxb[0], n, (const VoxelDevPlan *)d_plan,
                        (const uint32_t *)block_hist, ntiles, hstride, (const uint32_t *)totals, recb[1], (uint32_t *)nullptr, idxb[1], scatter_bounds,
                        (const int32_t *)d_flags);
-  const int bucket_grid = kn.grid;
-  if (with_idx)
-    hipLaunchKernelGGL(vb_bucket_kernel<true>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float4 *)recb[0],
-                       (const float4 *)recb[1], n, (const uint32_t *)idxb[0], (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off,
-                       (uint8_t *)d_out, ex, d_total, d_flags);
-  else
-    hipLaunchKernelGGL(vb_bucket_kernel<false>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float4 *)recb[0],
-                       (const float4 *)recb[1], n, (const uint32_t *)idxb[0], (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off,
-                       (uint8_t *)d_out, ex, d_total, d_flags);
+  // (grids: what the device holds at once -- the host does not know how many buckets the plan has; kn.grid bounds them)
+  const int bucket_grid = vb_knob("PCGX_VOXEL_BUCKET_WGS", vb_resident_grid(with_idx)), place_grid = 2048;
+  if (getenv("PCGX_VOXEL_BUCKET_TRACE")) fprintf(stderr, "pcgx voxel bucket path: bucket kernel grid %d\n", bucket_grid);
+  if (with_idx) {
+    hipLaunchKernelGGL(vb_bucket_kernel<true>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float4 *)recb[0], (const float4 *)recb[1],
+                       n, (const uint32_t *)idxb[0], (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan,
+                       recb[0], recb[1], cell_count, d_flags);
+    hipLaunchKernelGGL(vb_prefix_kernel, dim3(1), dim3(1024), 0, st, cell_count, (const VoxelDevPlan *)d_plan, d_total, (const int32_t *)d_flags);
+    hipLaunchKernelGGL(vb_place_kernel<true>, dim3(place_grid), dim3(256), 0, st, (const float4 *)recb[0], (const float4 *)recb[1],
+                       (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off, (uint8_t *)d_out,
+                       (const uint32_t *)cell_count, (const int64_t *)d_total, (const int32_t *)d_flags);
+  } else {
+    hipLaunchKernelGGL(vb_bucket_kernel<false>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float4 *)recb[0], (const float4 *)recb[1],
+                       n, (const uint32_t *)idxb[0], (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan,
+                       recb[0], recb[1], cell_count, d_flags);
+    hipLaunchKernelGGL(vb_prefix_kernel, dim3(1), dim3(1024), 0, st, cell_count, (const VoxelDevPlan *)d_plan, d_total, (const int32_t *)d_flags);
+    hipLaunchKernelGGL(vb_place_kernel<false>, dim3(place_grid), dim3(256), 0, st, (const float4 *)recb[0], (const float4 *)recb[1],
+                       (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off, (uint8_t *)d_out,
+                       (const uint32_t *)cell_count, (const int64_t *)d_total, (const int32_t *)d_flags);
+  }
   PCGX_HIP_TRY(hipGetLastError());
   Readback h;
   PCGX_TRY(read_back_small(d_rb, sizeof h, &h, st));
@@ -752,12 +736,12 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
     return fail(PCGX_E_OUT_OF_RANGE, "voxel filter: a point falls outside the dense grid (the reference panics: index out of range)");
   if (h.plan.status) return PCGX_OK;  // keys too wide, two sorts, too few keys: the radix path
   g_vb_last_low = h.plan.plan.low_bits;
-  if (h.flags) {  // crowded bucket / cell (or the exchange gave up): the radix path does the call
+  if (h.flags) {  // a crowded bucket: the radix path does the call
     g_vb_given_up++;
     g_vb_last_flags = h.flags;
     if (getenv("PCGX_VOXEL_BUCKET_TRACE"))
-      fprintf(stderr, "pcgx voxel bucket path: flags %d (1 bucket over %d points, 2 cell over %d points, 4 exchange gave up); low bits %d, %d buckets, digits %d + %d\n",
-              h.flags, kVbCap, kVbMaxCell, h.plan.plan.low_bits, h.plan.plan.nbuckets, h.plan.plan.d_bits[0], h.plan.plan.d_bits[1]);
+      fprintf(stderr, "pcgx voxel bucket path: flags %d (1: a bucket over %d points); low bits %d, %d buckets, digits %d + %d\n",
+              h.flags, kVbCap, h.plan.plan.low_bits, h.plan.plan.nbuckets, h.plan.plan.d_bits[0], h.plan.plan.d_bits[1]);
     return PCGX_OK;
   }
   *out_n = h.total;

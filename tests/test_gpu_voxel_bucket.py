@@ -82,18 +82,20 @@ def test_bucket_path_slab_and_offset_clouds(monkeypatch):
 
 
 def test_crowded_clouds_fall_back_to_the_radix_path(monkeypatch):
-    """What the bucket path gives up on: a cell with more points than it orders by itself (300 copies of one point),
-    and a cloud whose points sit in two tight clusters of a large box (buckets far over the LDS tile).  Both are
-    found on the device, the radix path answers, the bytes are the oracle's."""
+    """A cell with many points (300 copies of one point: the float32 sum over them in input order, inside the
+    bucket's LDS tile) is the bucket path's own; a cloud whose points sit in two tight clusters of a large box (buckets
+    far over the LDS tile) is what it gives up on -- found on the device, the radix path answers.  The bytes are the
+    oracle's either way."""
     monkeypatch.setenv("PCGX_VOXEL_BUCKET_MIN_N", "1")
     pts = synth.uniform_cloud(100_000, 1.6, 3)
     crowded_cell = pts.copy()
     crowded_cell[5000:5300] = crowded_cell[4999]
+    crowded_cell[20_000:21_000:2] = crowded_cell[19_999]   # and one whose points alternate with others' in input order
     exp = O.voxel_filter(crowded_cell, len(pts), 12, 0, (0.05,) * 3, (0, 0, 0))
     _stats()
     got = _filter(crowded_cell, len(pts), 12, 0, (0.05,) * 3, (0, 0, 0))
     st = _stats()
-    assert st[0] == 0 and st[1] == 1 and (st[2] & 2), st
+    assert st[0] == 1 and st[1] == 0, st
     assert np.array_equal(got, exp)
     rng = np.random.default_rng(7)
     a = (rng.random((150_000, 3)) * 0.05).astype(f32)
