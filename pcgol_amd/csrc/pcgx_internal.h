@@ -331,6 +331,26 @@ struct IcpKernelParams {
 
 
 #if defined(__HIPCC__)
+// "Am I the launch's last workgroup?" -- one thread per workgroup asks, when the workgroup's results are out (stores
+// that the last workgroup reads: write-through and waited for, the caller's business).  Returning atomics on ONE word
+// are served one after the other, 10 ns each (and so are atomics on different words of one 128-byte line): 1024
+// workgroups that come within 3 us of each other waited up to 10 us for their turn.  Two steps instead: 32 ticket words
+// (a line each) taken by the workgroups of the same index mod 32, and the last of a word's takers takes one of the top
+// word.  `tickets`: the context's zeroed words (kTicketBytes); the words are zero again when the last workgroup has
+// its answer -- one launch at a time per context may use them.
+constexpr unsigned int kTicketGroups = 32u, kTicketStride = 32u;  // (words)
+static_assert((1u + kTicketGroups) * kTicketStride * 4u <= kTicketBytes, "the context's ticket words");
+__device__ __forceinline__ bool last_workgroup_ticket(unsigned int *tickets) {
+  const unsigned int g = blockIdx.x & (kTicketGroups - 1u), groups = min(gridDim.x, kTicketGroups);
+  const unsigned int members = (gridDim.x - g + kTicketGroups - 1u) / kTicketGroups;
+  unsigned int *mine = tickets + kTicketStride * (1u + g);
+  if (atomicAdd(mine, 1u) != members - 1u) return false;
+  __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (atomicAdd(tickets, 1u) != groups - 1u) return false;
+  __hip_atomic_store(tickets, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return true;
+}
+
 // Inclusive sum over the lanes of a wave by DPP (row_shr:n inside a row of 16 lanes, row_bcast:15 / :31 from a row's last
 // lane to the rows behind it): a partner's value is a register move, where __shfl_up is a trip through the LDS crossbar
 // and a wait.  Call with all lanes of the wave active (a DPP read of a lane that is switched off returns the reader's own

@@ -327,8 +327,6 @@ __device__ __forceinline__ void mm_finish(MinMaxAcc &a) {
 // point 0's rule, out6 = {min xyz, max xyz} -- and, where the host waits for them, the six floats straight into its
 // pinned mailbox, the sequence word last.  (A kernel of its own for this was 13.6 us of the filter's call: a launch
 // behind a 120 MB stream, and 1024 partials read by one workgroup.)
-constexpr unsigned int kTicketGroups = 32u, kTicketStride = 32u;  // (words; core.hip allocates kTicketBytes)
-static_assert((1u + kTicketGroups) * kTicketStride * 4u <= kTicketBytes, "the context's ticket words");
 struct MinMaxTail {
   MinMaxAcc *partials;
   unsigned int *ticket;
@@ -374,18 +372,7 @@ __device__ __forceinline__ void minmax_block_fold(MinMaxAcc &a, const MinMaxTail
       __hip_atomic_store(&dst->zf[k], a.zf[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // Returning atomics on ONE word are served one after the other, 10 ns each: 1024 workgroups that finish their
-    // stream within 3 us of each other waited up to 10 us for their turn.  Two steps instead: 32 ticket words (a 128-byte
-    // line each) taken by 32 workgroups each, and the last of a word's takers takes one of the top word.
-    const unsigned int g = blockIdx.x & (kTicketGroups - 1u), groups = min(gridDim.x, kTicketGroups);
-    const unsigned int members = (gridDim.x - g + kTicketGroups - 1u) / kTicketGroups;
-    unsigned int *mine = T.ticket + kTicketStride * (1u + g);
-    unsigned int last = 0u;
-    if (atomicAdd(mine, 1u) == members - 1u) {
-      __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (for the next launch)
-      last = atomicAdd(T.ticket, 1u) == groups - 1u ? 1u : 0u;
-    }
-    s_last = last;
+    s_last = last_workgroup_ticket(T.ticket) ? 1u : 0u;
   }
   __syncthreads();
   if (!s_last) return;  // uniform
@@ -413,7 +400,6 @@ __device__ __forceinline__ void minmax_block_fold(MinMaxAcc &a, const MinMaxTail
   if (threadIdx.x != 0) return;
   for (int w = 1; w < 4; w++) mm_merge(f, s_acc[w]);
   mm_finish(f);
-  *T.ticket = 0u;  // (for the next launch that uses this word)
   for (int k = 0; k < 3; k++) {
     // min, max := Vec3At(0): a NaN there is never replaced (minmax.go:13-23)
     // (sticky_first 0: `data` is a later slice of a cloud split over ranks -- its first point is no more

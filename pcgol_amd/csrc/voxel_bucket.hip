@@ -381,7 +381,10 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
     // cell by ballots over the cell number's bits (vb_scatter_kernel's ranking), the earlier rounds by the wave's count
     uint16_t rank[kRounds];
     {
-      volatile uint16_t *my_cnt = cnt[wave];
+      // (an LDS pointer by type: as a generic one the compiler (ROCm 7.2) tests it for the LDS aperture with an
+      // instruction it then fails to select)
+      typedef __attribute__((address_space(3))) volatile uint16_t lds_vu16;
+      lds_vu16 *my_cnt = (lds_vu16 *)cnt[wave];
 #pragma unroll
       for (int r = 0; r < kRounds; r++) {
         const bool valid = w_begin + r * 64 + lane < w_end;
@@ -500,72 +503,66 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
   }
 }
 
-// The buckets' counts of occupied cells -> where each bucket's cells begin in the output (their exclusive prefix, over
-// the counts in place) and the call's total: one workgroup, a run of consecutive buckets per thread.  (Totals per 32 and
-// per 1024 buckets added up by the bucket kernel with fire-and-forget atomics instead: atomics on words of ONE 128-byte
-// line are served one after the other, 10 ns each -- 13010 of them on the thirteen 1024-bucket totals made the
-// bucket kernel 189 us long.)
-__global__ __launch_bounds__(1024) void vb_prefix_kernel(uint32_t *__restrict__ count, const VoxelDevPlan *__restrict__ dp,
-                                                         int64_t *__restrict__ total, const int32_t *__restrict__ flags) {
-  __shared__ uint32_t wsum[16];
-  if (*flags) return;  // uniform
-  const int nb = dp->plan.nbuckets, per = (nb + 1023) / 1024, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b0 = (int)threadIdx.x * per, b1 = min(b0 + per, nb);
-  uint32_t sum = 0;
-  for (int b = b0; b < b1; b++) sum += count[b];
-  const uint32_t inc = wave_incl_scan_u32(sum);
-  if (lane == 63) wsum[wave] = inc;
-  __syncthreads();
-  uint32_t run = inc - sum, all = 0;
-  for (int w = 0; w < 16; w++) {
-    if (w < wave) run += wsum[w];
-    all += wsum[w];
-  }
-  for (int b = b0; b < b1; b++) {
-    const uint32_t c = count[b];
-    count[b] = run;
-    run += c;
-  }
-  if (threadIdx.x == 0) *total = (int64_t)all;
-}
-
-// A wave per bucket: its cells from where the bucket kernel left them to their place in the output.  (How many: to the
-// next bucket's place, or the total.)
+// Sixteen buckets per workgroup, four per wave: their cells from where the bucket kernel left them to their place in the
+// output = the occupied cells of all buckets before.  Every workgroup adds up the counts before its sixteen by itself
+// -- ordinary loads, 52 KB at most at C3, out of the L2: 21 MB over the whole launch.  (A kernel of its own for the
+// counts' prefix, one workgroup: 12 us of the call.  The bucket kernel's last workgroup -- a ticket, then loads past
+// the L2, 3 us a round trip under that kernel's traffic: 12 us as well.  Totals per 32 and per 1024 buckets added up by
+// the bucket kernel with fire-and-forget atomics: atomics on words of ONE 128-byte line are served one after the
+// other, 10 ns each -- 13010 of them on the thirteen 1024-bucket totals made the bucket kernel 189 us long.)
+constexpr int kVbPlaceBuckets = 16;
 template <bool kIdx>
 __global__ __launch_bounds__(256) void vb_place_kernel(const float4 *__restrict__ cells0, const float4 *__restrict__ cells1,
                                                        const uint32_t *__restrict__ bucket_start, const VoxelDevPlan *__restrict__ dp,
                                                        const uint8_t *__restrict__ data, int32_t stride, int32_t off,
-                                                       uint8_t *__restrict__ out, const uint32_t *__restrict__ place,
-                                                       const int64_t *__restrict__ total, const int32_t *__restrict__ flags) {
+                                                       uint8_t *__restrict__ out, const uint32_t *__restrict__ count,
+                                                       int64_t *__restrict__ total, const int32_t *__restrict__ flags) {
+  __shared__ uint32_t wsum[4];
   if (*flags) return;  // uniform: the radix path does the call
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nbuckets = dp->plan.nbuckets;
   const float4 *__restrict__ cells = dp->plan.d_bits[1] != 0 ? cells0 : cells1;
   const bool words = (stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(data) | reinterpret_cast<uintptr_t>(out)) & 3) == 0;
-  for (int b = (int)blockIdx.x * 4 + wave; b < nbuckets; b += (int)gridDim.x * 4) {
-    const uint32_t inv = bucket_start[b];
-    const uint32_t s = place[b], next = b + 1 < nbuckets ? place[b + 1] : (uint32_t)*total;
-    const uint32_t mine = next - s;
-    if (mine == 0u) continue;  // uniform in the wave
-    const int64_t from = (int64_t)(~inv), to = (int64_t)s;
-    for (uint32_t j = lane; j < mine; j += 64) {
-      const float4 c = cells[from + j];
-      uint8_t *dst = out + (to + j) * stride;
-      if (!kIdx) {  // records are xyz and nothing else, 4-byte aligned
-        float *d = reinterpret_cast<float *>(dst);
-        d[0] = c.x; d[1] = c.y; d[2] = c.z;
-      } else {  // the first point's whole record, its xyz replaced (voxelgrid.go:173-184)
-        const uint8_t *src = data + (int64_t)__float_as_uint(c.w) * stride;
-        if (words) {
-          for (int q = 0; q < stride; q += 4) *reinterpret_cast<uint32_t *>(dst + q) = *reinterpret_cast<const uint32_t *>(src + q);
-        } else {
-          for (int q = 0; q < stride; q++) dst[q] = src[q];
+  for (int b0 = (int)blockIdx.x * kVbPlaceBuckets; b0 < nbuckets; b0 += (int)gridDim.x * kVbPlaceBuckets) {  // uniform
+    uint32_t s = 0;
+    for (int i = (int)threadIdx.x * 4; i < b0; i += 1024) {  // (b0 is a multiple of 16: whole 16-byte pieces)
+      const uint4 v = *reinterpret_cast<const uint4 *>(count + i);
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    const uint32_t before = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    const uint32_t c = lane < kVbPlaceBuckets && b0 + lane < nbuckets ? count[b0 + lane] : 0u;
+    const uint32_t inc = wave_incl_scan_u32(c);
+    if (wave == 0 && b0 + kVbPlaceBuckets >= nbuckets && lane == 63) *total = (int64_t)before + (int64_t)inc;  // the call's total
+#pragma unroll
+    for (int q = 0; q < kVbPlaceBuckets / 4; q++) {
+      const int slot = wave * (kVbPlaceBuckets / 4) + q, b = b0 + slot;
+      const uint32_t mine = (uint32_t)__shfl((int)c, slot), to0 = before + (uint32_t)__shfl((int)(inc - c), slot);
+      if (b >= nbuckets || mine == 0u) continue;  // uniform in the wave
+      const int64_t from = (int64_t)(~bucket_start[b]), to = (int64_t)to0;
+      for (uint32_t j = lane; j < mine; j += 64) {
+        const float4 cell = cells[from + j];
+        uint8_t *dst = out + (to + j) * stride;
+        if (!kIdx) {  // records are xyz and nothing else, 4-byte aligned
+          float *d = reinterpret_cast<float *>(dst);
+          d[0] = cell.x; d[1] = cell.y; d[2] = cell.z;
+        } else {  // the first point's whole record, its xyz replaced (voxelgrid.go:173-184)
+          const uint8_t *src = data + (int64_t)__float_as_uint(cell.w) * stride;
+          if (words) {
+            for (int k = 0; k < stride; k += 4) *reinterpret_cast<uint32_t *>(dst + k) = *reinterpret_cast<const uint32_t *>(src + k);
+          } else {
+            for (int k = 0; k < stride; k++) dst[k] = src[k];
+          }
+          __builtin_memcpy(dst + off, &cell.x, 4);
+          __builtin_memcpy(dst + off + 4, &cell.y, 4);
+          __builtin_memcpy(dst + off + 8, &cell.z, 4);
         }
-        __builtin_memcpy(dst + off, &c.x, 4);
-        __builtin_memcpy(dst + off + 4, &c.y, 4);
-        __builtin_memcpy(dst + off + 8, &c.z, 4);
       }
     }
+    __syncthreads();  // (wsum)
   }
 }
 
@@ -711,18 +708,16 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
     hipLaunchKernelGGL(vb_bucket_kernel<true>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float4 *)recb[0], (const float4 *)recb[1],
                        n, (const uint32_t *)idxb[0], (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan,
                        recb[0], recb[1], cell_count, d_flags);
-    hipLaunchKernelGGL(vb_prefix_kernel, dim3(1), dim3(1024), 0, st, cell_count, (const VoxelDevPlan *)d_plan, d_total, (const int32_t *)d_flags);
     hipLaunchKernelGGL(vb_place_kernel<true>, dim3(place_grid), dim3(256), 0, st, (const float4 *)recb[0], (const float4 *)recb[1],
                        (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off, (uint8_t *)d_out,
-                       (const uint32_t *)cell_count, (const int64_t *)d_total, (const int32_t *)d_flags);
+                       (const uint32_t *)cell_count, d_total, (const int32_t *)d_flags);
   } else {
     hipLaunchKernelGGL(vb_bucket_kernel<false>, dim3(bucket_grid), dim3(kVbFinalThreads), 0, st, (const float4 *)recb[0], (const float4 *)recb[1],
                        n, (const uint32_t *)idxb[0], (const uint32_t *)idxb[1], (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan,
                        recb[0], recb[1], cell_count, d_flags);
-    hipLaunchKernelGGL(vb_prefix_kernel, dim3(1), dim3(1024), 0, st, cell_count, (const VoxelDevPlan *)d_plan, d_total, (const int32_t *)d_flags);
     hipLaunchKernelGGL(vb_place_kernel<false>, dim3(place_grid), dim3(256), 0, st, (const float4 *)recb[0], (const float4 *)recb[1],
                        (const uint32_t *)inv_start, (const VoxelDevPlan *)d_plan, data, stride, xyz_off, (uint8_t *)d_out,
-                       (const uint32_t *)cell_count, (const int64_t *)d_total, (const int32_t *)d_flags);
+                       (const uint32_t *)cell_count, d_total, (const int32_t *)d_flags);
   }
   PCGX_HIP_TRY(hipGetLastError());
   Readback h;
