@@ -331,8 +331,11 @@ __device__ __forceinline__ void vb_bucket_bounds(const uint32_t *__restrict__ bu
   }
 }
 
+#ifndef PCGX_VB_MIN_WAVES
+#define PCGX_VB_MIN_WAVES 5
+#endif
 template <bool kIdx>
-__global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
+__global__ __launch_bounds__(kVbFinalThreads, PCGX_VB_MIN_WAVES) void vb_bucket_kernel(
     const float4 *__restrict__ rec0, const float4 *__restrict__ rec1, int64_t n, const uint32_t *__restrict__ idx0,
     const uint32_t *__restrict__ idx1, const uint32_t *__restrict__ bucket_start, const VoxelDevPlan *__restrict__ dp,
     float4 *cells0, float4 *cells1, uint32_t *__restrict__ count, int32_t *__restrict__ flags) {
@@ -342,8 +345,13 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
   static_assert(kVbCap % kVbFinalThreads == 0 && kVbCap < 65536, "whole rounds; places are 16 bits");
   __shared__ float sx[kVbCap], sy[kVbCap], sz[kVbCap];   // the bucket's points, cell after cell, input order inside a cell
   __shared__ uint16_t sfrom[kIdx ? kVbCap : 1];          // (records with more than xyz: the point's place in the bucket's input order)
-  __shared__ uint16_t cnt[kWaves][kBins + 1];            // a wave's points of the cell; then: where they begin in sx / sy / sz
-  __shared__ uint16_t vrank[kBins];                      // occupied cells before it in the bucket
+  // (rows of kBins + 4: the word behind a row's last cell is its end marker, and the rows begin on 8-byte words -- a
+  // thread's four consecutive cells are one 8-byte access.  The kernel is bound by what a CU's LDS pipe and VALUs get
+  // through, a bucket every 1.3 us per CU: 16-bit accesses cost what wider ones do)
+  constexpr int kRow = kBins + 4;
+  __shared__ __attribute__((aligned(16))) uint16_t cnt[kWaves][kRow];  // a wave's points of the cell; then: where they begin in sx / sy / sz
+  __shared__ __attribute__((aligned(8))) uint16_t vrank[kBins];         // occupied cells before it in the bucket
+  static_assert(kBinsPer == 4 && (kWaves * kRow * 2) % 16 == 0, "four cells per thread: 8-byte words; cleared 16 bytes at a time");
   __shared__ uint32_t wsum[kWaves], wocc[kWaves];
   if (*flags & 9) return;  // uniform: not a call for this path / a bucket does not fit (an earlier kernel's finding): the radix path
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
       const int i = w_begin + r * 64 + lane;
       e[r] = i < w_end ? rec[(int64_t)start + i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    for (int l = threadIdx.x; l < kWaves * (kBins + 1); l += kVbFinalThreads) (&cnt[0][0])[l] = 0;
+    for (int l = threadIdx.x; l < kWaves * kRow * 2 / 16; l += kVbFinalThreads) reinterpret_cast<uint4 *>(&cnt[0][0])[l] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     // ---- a point's rank among its wave's points of the same cell, in input order: the lanes of a round with the same
     // cell by ballots over the cell number's bits (vb_scatter_kernel's ranking), the earlier rounds by the wave's count
@@ -385,20 +393,27 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
       // instruction it then fails to select)
       typedef __attribute__((address_space(3))) volatile uint16_t lds_vu16;
       lds_vu16 *my_cnt = (lds_vu16 *)cnt[wave];
+      // (all kVbMaxLowBits bits, whatever the plan's: a bit above them is zero in every lane and leaves the mask as it
+      // is.  As a loop over the plan's bits it was eight instructions and a branch per bit, 2 us of a bucket's 6; all
+      // rounds' masks first, fifty independent steps, took 114 registers and a workgroup per CU with them)
 #pragma unroll
       for (int r = 0; r < kRounds; r++) {
         const bool valid = w_begin + r * 64 + lane < w_end;
         const uint32_t d = __float_as_uint(e[r].w) & lmask;
-        uint64_t m = __ballot(valid);
-        if (m == 0ull) {  // uniform
+        const uint64_t v = __ballot(valid);
+        if (v == 0ull) {  // uniform
           rank[r] = 0;
           continue;
         }
-        for (int bit = 0; bit < plan.low_bits; bit++) {  // uniform
-          const bool one = (d >> bit) & 1u;
-          const uint64_t bal = __ballot(one);
-          m &= one ? bal : ~bal;
+        uint32_t m_lo = (uint32_t)v, m_hi = (uint32_t)(v >> 32);
+#pragma unroll
+        for (int bit = 0; bit < kVbMaxLowBits; bit++) {
+          const uint32_t sel = (uint32_t)(((int32_t)(d << (31 - bit))) >> 31);  // all ones: my bit is set
+          const uint64_t bal = __ballot(sel != 0u);
+          m_lo &= ~((uint32_t)bal ^ sel);        // the lanes whose bit is mine
+          m_hi &= ~((uint32_t)(bal >> 32) ^ sel);
         }
+        const uint64_t m = (uint64_t)m_hi << 32 | m_lo;
         uint32_t prev = 0;
         if (valid) prev = my_cnt[d];
         rank[r] = (uint16_t)(prev + (uint32_t)__popcll(m & lt_mask));
@@ -413,15 +428,17 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
     uint32_t occupied_total = 0;
     {
       uint32_t c[kBinsPer][kWaves], sum = 0, occ = 0;
+      const bool mine = (int)threadIdx.x * kBinsPer < nbins;  // (nbins is a power of two: all four cells or none)
+#pragma unroll
+      for (int w = 0; w < kWaves; w++) {
+        const uint2 q = mine ? *reinterpret_cast<const uint2 *>(&cnt[w][threadIdx.x * kBinsPer]) : make_uint2(0u, 0u);
+        c[0][w] = q.x & 0xffffu; c[1][w] = q.x >> 16; c[2][w] = q.y & 0xffffu; c[3][w] = q.y >> 16;
+      }
 #pragma unroll
       for (int k = 0; k < kBinsPer; k++) {
-        const int l = threadIdx.x * kBinsPer + k;
         uint32_t t = 0;
 #pragma unroll
-        for (int w = 0; w < kWaves; w++) {
-          c[k][w] = l < nbins ? cnt[w][l] : 0u;
-          t += c[k][w];
-        }
+        for (int w = 0; w < kWaves; w++) t += c[k][w];
         sum += t;
         occ += t ? 1u : 0u;
       }
@@ -440,18 +457,24 @@ __global__ __launch_bounds__(kVbFinalThreads) void vb_bucket_kernel(
         occupied_total += wocc[w];
       }
       uint32_t run = wb + inc - sum, orun = ob + oinc - occ;
+      uint32_t first[kBinsPer][kWaves], vr[kBinsPer];
 #pragma unroll
       for (int k = 0; k < kBinsPer; k++) {
-        const int l = threadIdx.x * kBinsPer + k;
         uint32_t t = 0;
 #pragma unroll
         for (int w = 0; w < kWaves; w++) {
-          if (l < nbins) cnt[w][l] = (uint16_t)(run + t);
+          first[k][w] = run + t;
           t += c[k][w];
         }
-        if (l < nbins) vrank[l] = (uint16_t)orun;
+        vr[k] = orun;
         run += t;
         orun += t ? 1u : 0u;
+      }
+      if (mine) {
+#pragma unroll
+        for (int w = 0; w < kWaves; w++)
+          *reinterpret_cast<uint2 *>(&cnt[w][threadIdx.x * kBinsPer]) = make_uint2(first[0][w] | first[1][w] << 16, first[2][w] | first[3][w] << 16);
+        *reinterpret_cast<uint2 *>(&vrank[threadIdx.x * kBinsPer]) = make_uint2(vr[0] | vr[1] << 16, vr[2] | vr[3] << 16);
       }
       if (threadIdx.x == kVbFinalThreads - 1) cnt[0][nbins] = (uint16_t)P;  // (a cell's points end where the next one's begin)
     }

@@ -211,7 +211,10 @@ __host__ __device__ inline int voxel_key_layout(VoxelParams &vp, bool force_two_
 constexpr int kVbMaxLowBits = 10;      // cells per bucket <= 1024
 constexpr int kVbMaxBucketBits = 16;   // two digits of <= 8 bits
 constexpr int kVbMaxBuckets = 1 << kVbMaxBucketBits;
-constexpr int kVbCap = 1280;           // points per bucket the bucket kernel holds in LDS (26 KB: six workgroups per CU -- a
+#ifndef PCGX_VB_CAP
+#define PCGX_VB_CAP 1280
+#endif
+constexpr int kVbCap = PCGX_VB_CAP;           // points per bucket the bucket kernel holds in LDS (26 KB: six workgroups per CU -- a
                                        // workgroup is a chain of short dependent phases, what hides them is the other workgroups)
 
 struct VbPlan {
