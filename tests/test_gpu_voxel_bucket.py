@@ -169,3 +169,36 @@ def test_calls_the_device_plan_turns_away_go_the_radix_path(monkeypatch):
     st = _stats()
     assert st[0] == 0 and st[1] == 0, st
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("leaf,chunk", [(0.02, (0, 0, 0)), (0.013, (0, 0, 0)), (0.05, (8, 8, 8)), (0.0371, (5, 3, 4)),
+                                        ((0.02, 0.031, 0.0173), (0, 0, 0))])
+@pytest.mark.parametrize("min_n", ["1", "100000000"])
+def test_points_on_and_next_to_cell_faces(leaf, chunk, min_n, monkeypatch):
+    """The cell of a point is int(float32 quotient); the kernels take the quotient's integer part from a product with
+    the size's reciprocal where that proves it and divide where it does not (voxel_key.h, cell_by_reciprocal).  A cloud
+    made to sit ON the faces: coordinates k * leaf (as float64, rounded to float32, and from float32 products) and their
+    neighbours up to three steps of the float32 grid to either side -- every one decided as the reference decides it.
+    Both paths (the bucket path forced, and switched off)."""
+    monkeypatch.setenv("PCGX_VOXEL_BUCKET_MIN_N", min_n)
+    rng = np.random.default_rng(23)
+    lf = np.asarray(leaf if isinstance(leaf, tuple) else (leaf,) * 3, np.float64)
+    n = 120_000
+    k = rng.integers(0, 160, size=(n, 3))
+    exact = (k * lf).astype(f32)                                       # k * leaf in float64, rounded once
+    prod = (k.astype(f32) * lf.astype(f32)).astype(f32)                # the float32 product
+    pts = np.where(rng.random((n, 3)) < 0.5, exact, prod).astype(f32)
+    steps = rng.integers(-3, 4, size=(n, 3))
+    for s in range(1, 4):                                              # up to three steps of the float32 grid away
+        pts = np.where(steps >= s, np.nextafter(pts, f32(np.inf)), pts)
+        pts = np.where(steps <= -s, np.nextafter(pts, f32(-np.inf)), pts)
+    pts = np.ascontiguousarray(np.abs(pts).astype(f32))
+    pts[0] = 0.0                                                       # vMin = 0: the faces are where the cloud was put
+    leafs = tuple(float(v) for v in lf)
+    exp = O.voxel_filter(pts, n, 12, 0, leafs, chunk)
+    got = _filter(pts, n, 12, 0, leafs, chunk)
+    assert len(got) == len(exp) and np.array_equal(got, exp)
+    shifted = np.ascontiguousarray((pts + f32(0.37)).astype(f32))     # vMin != 0: the subtraction's rounding in front
+    exp = O.voxel_filter(shifted, n, 12, 0, leafs, chunk)
+    got = _filter(shifted, n, 12, 0, leafs, chunk)
+    assert len(got) == len(exp) and np.array_equal(got, exp)
