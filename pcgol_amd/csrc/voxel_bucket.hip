@@ -633,7 +633,7 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
                                 const int32_t chunk[3], void *d_out, int64_t *out_n, bool *attempted, bool *taken,
                                 VoxelDevPlan *dp_host, hipStream_t st) {
   *attempted = *taken = false;
-  const int enabled = vb_knob("PCGX_VOXEL_BUCKET", 1), min_n = vb_knob("PCGX_VOXEL_BUCKET_MIN_N", 400000);
+  const int enabled = vb_knob("PCGX_VOXEL_BUCKET", 1), min_n = vb_knob("PCGX_VOXEL_BUCKET_MIN_N", 1024);  // (0.067 against 0.112 ms at a thousand points, 0.091 against 0.142 at 400k)
   if (!enabled || n < min_n) return PCGX_OK;
   *attempted = true;
   VoxelPlanHook kn;
