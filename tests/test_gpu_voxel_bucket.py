@@ -202,3 +202,48 @@ def test_points_on_and_next_to_cell_faces(leaf, chunk, min_n, monkeypatch):
     exp = O.voxel_filter(shifted, n, 12, 0, leafs, chunk)
     got = _filter(shifted, n, 12, 0, leafs, chunk)
     assert len(got) == len(exp) and np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_clouds_and_grids(seed):
+    """Clouds and grids drawn at random -- uniform boxes, slabs, clusters of very different density in one cloud (crowded
+    cells next to empty buckets; some clouds the bucket path hands to the radix path), leaf sizes per axis, chunks,
+    records with fields around xyz -- byte for byte against the oracle, whichever path answers (the library's own
+    threshold decides: every cloud here is over it)."""
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1500, 180_000))
+    kind = seed % 4
+    if kind == 0:
+        pts = (rng.random((n, 3)) * rng.uniform(0.5, 6.0, 3)).astype(f32)
+    elif kind == 1:                                               # a slab: one axis a few cells thick
+        pts = (rng.random((n, 3)) * np.array([rng.uniform(2, 8), rng.uniform(2, 8), rng.uniform(0.01, 0.2)])).astype(f32)
+    elif kind == 2:                                               # clusters of different spread, a sparse background
+        k = int(rng.integers(2, 7))
+        centers = rng.random((k, 3)) * 5.0
+        spread = 10.0 ** rng.uniform(-2.5, -0.3, k)
+        which = rng.integers(0, k, n)
+        pts = (centers[which] + rng.normal(size=(n, 3)) * spread[which, None]).astype(f32)
+        pts[: n // 10] = (rng.random((n // 10, 3)) * 5.0).astype(f32)
+    else:                                                         # far from the origin, negative coordinates
+        pts = (rng.random((n, 3)) * rng.uniform(0.5, 3.0, 3) + rng.uniform(-500, 500, 3)).astype(f32)
+    pts = np.ascontiguousarray(pts[rng.permutation(n)])
+    leaf = tuple(float(v) for v in (10.0 ** rng.uniform(-2.0, -0.7, 3) if seed % 3 else np.repeat(10.0 ** rng.uniform(-2.0, -0.7), 3)))
+    chunk = (0, 0, 0) if seed % 2 else tuple(int(v) for v in rng.integers(2, 40, 3))
+    # (without chunks the reference's dense array is sized by vMax, voxelgrid.go:46: far from the origin that is 10^11
+    # voxels, which the oracle would allocate and scan as the Go code would -- such clouds are filtered in chunks)
+    if chunk == (0, 0, 0) and abs(float(np.prod(np.floor(pts.max(0) / np.asarray(leaf, f32)) + 1.0))) > 2e7:
+        chunk = tuple(int(v) for v in rng.integers(2, 40, 3))
+    stride, off = [(12, 0), (16, 0), (20, 4), (15, 1)][int(rng.integers(0, 4))]
+    rec = _records(pts, stride, off, rng)
+    try:
+        exp = O.voxel_filter(rec, n, stride, off, leaf, chunk)
+    except O.OracleError:                                          # the Go code would panic (a grid sized by a negative vMax,
+        with pytest.raises(L.PcgxError) as ei:                     # voxelgrid.go:46, an index out of range): an error here
+            _filter(rec, n, stride, off, leaf, chunk)
+        assert ei.value.code == L.PCGX_E_OUT_OF_RANGE, ei.value
+        return
+    _stats()
+    got = _filter(rec, n, stride, off, leaf, chunk)
+    st = _stats()
+    assert st[0] + st[1] == 1, st
+    assert len(got) == len(exp) and np.array_equal(got, exp), (seed, n, leaf, chunk, stride, off, st)
