@@ -28,7 +28,7 @@ STREAMED = {"icp_grid_kernel<false": (12 + 16 * 19 / 20) * 1e6,          # targe
 # pipeline has changed under this list: the summary then FAILS instead of leaving the row out (round 3's BENCH line
 # carried `"traffic": null` for the filter because of exactly that).
 VOXEL_KERNELS = ("minmax_partial_packed_kernel", "vb_key_hist_kernel", "vb_scan_rows_kernel", "vb_scatter_kernel<true, false>",
-                 "vb_hist2_kernel", "vb_scatter_kernel<false, false>", "vb_bucket_kernel<false>")
+                 "vb_hist2_kernel", "vb_scatter_kernel<false, false>", "vb_bucket_kernel<false>", "vb_place_kernel<false>")
 VOXEL_CALLS_BY = "vb_bucket_kernel<false>"
 
 
