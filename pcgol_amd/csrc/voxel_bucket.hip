@@ -11,15 +11,15 @@
 //   1-2 scatter passes  stable LSD partition by the bucket number (digits of <= 8 bits), 2048-element tiles
 //                       re-ordered in LDS so that every digit's run leaves in one piece; the elements are 16-byte
 //                       records {x, y, z, key} (+ the point's index, by itself, when records carry more than xyz)
-//   bucket kernel       one workgroup per bucket: its points into LDS, counting sort by the key's low s bits, the
-//                       points of a cell put into input order by their position (the partition is stable), the
-//                       reference's sequential float32 sum per cell (voxelgrid.go:157), centroid, output record.
-//                       Where in the output a bucket's cells go is the number of occupied cells in all buckets
-//                       before it: the workgroups publish their counts and wait for the earlier ones inside the
-//                       launch (the exchange of strict_sum_kernel, strict.hip), so nothing is staged and compacted.
+//   bucket kernel       the device's workgroups walk the buckets: a bucket's points sorted by the key's low s bits in
+//                       LDS -- stably, so that a cell's points lie in input order (the partition is stable too) -- the
+//                       reference's sequential float32 sum per cell (voxelgrid.go:157), centroid; the cell's result is
+//                       left at the bucket's first point + the cell's rank among the bucket's occupied cells
+//   placing kernel      where in the output a bucket's cells go is the number of occupied cells in all buckets before
+//                       it: every workgroup adds up the counts before its sixteen buckets and copies their cells
 //
-// What does not fit (a bucket with more points than the LDS tile holds, a cell with more than kMaxCell points, keys of
-// more than 24 bits, fewer points than a launch is worth) goes the radix path: the same bytes come out either way.
+// What does not fit (a bucket with more points than the LDS tile holds, keys of more than 26 bits, fewer points than a
+// launch is worth) goes the radix path: the same bytes come out either way.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -625,9 +625,9 @@ static int vb_knob(const char *name, int def) {
 }
 
 // The bucket path of one filter call on one GPU (voxel_key.h).  The host does not wait for the cloud's min / max:
-// the plan is made on the device (vb_plan_kernel), every kernel reads it from there, buffers and grids are sized for
-// the largest plan there is (the bucket kernel's grid: kVbMaxBuckets workgroups, those without a bucket return at
-// once), and what came of it all -- plan, flags, the number of output points -- is read back in one copy at the end.
+// the plan is made on the device (the min/max launch's last workgroup, sort.hip), every kernel reads it from there,
+// buffers are sized for the largest plan there is, the grids for the device (the bucket and the placing kernel's
+// workgroups walk the buckets), and what came of it all -- plan, flags, the number of output points -- is read back in one copy at the end.
 // Before: 34 us of a C3 call in which the GPU waited for the host (six floats back, the plan, a dozen launches).
 pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, int32_t xyz_off, const float leaf[3],
                                 const int32_t chunk[3], void *d_out, int64_t *out_n, bool *attempted, bool *taken,
@@ -671,7 +671,7 @@ pcgx_status voxel_bucket_filter(const void *d_data, int64_t n, int32_t stride, i
   block_hist = reinterpret_cast<uint32_t *>((reinterpret_cast<uintptr_t>(block_hist) + 127) & ~(uintptr_t)127);
   PCGX_TRY(ar.alloc_n(256, &totals));
   PCGX_TRY(ar.alloc_n(8, &d_mm6));
-  // one block, zeroed at once: flags, the exchange's words, the sample of the bucket populations.  What the host
+  // one block, zeroed at once: flags, the buckets' cell counts and starts, the sample of the bucket populations.  What the host
   // reads back at the end is at its start: flags, err, total, the plan
   struct Readback {
     int32_t flags, err;

@@ -277,7 +277,7 @@ struct VoxelPlanHook {
   int64_t n;
   VoxelDevPlan *dp;
   int32_t *head;        // flags, key-out-of-range, total (two words): zero, but flags = 8 when there is no plan
-  uint32_t *zero;       // cleared by the launch's workgroups, a slice each (sample counts, the exchange's words)
+  uint32_t *zero;       // cleared by the launch's workgroups, a slice each (sample counts, the buckets' cell counts and starts)
   uint32_t zero_words;  // (a multiple of 4)
 };
 
