@@ -27,6 +27,7 @@
 #include <atomic>
 
 #include "voxel_key.h"
+#include "wg_stamps.h"
 
 namespace pcgx {
 
@@ -342,6 +343,8 @@ __device__ __forceinline__ void vb_bucket_bounds(const uint32_t *__restrict__ bu
   }
 }
 
+// (measurements only, -DPCGX_STAMPS: a bucket's phases by the wall clock -- tools/stamps.py vb_bucket)
+PCGX_STAMPS_DECLARE(vb_bucket, kVbMaxBuckets, 8)
 #ifndef PCGX_VB_MIN_WAVES
 #define PCGX_VB_MIN_WAVES 5
 #endif
@@ -377,8 +380,10 @@ __global__ __launch_bounds__(kVbFinalThreads, PCGX_VB_MIN_WAVES) void vb_bucket_
   const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   // (the grid is what fits the device at once, whatever the plan: the host does not know the plan)
   for (int b = blockIdx.x; b < plan.nbuckets; b += gridDim.x) {
+    PCGX_STAMP(vb_bucket, 8, b, 0);
     uint32_t start, end;
     vb_bucket_bounds(bucket_start, b, plan.nbuckets, n, lane, start, end);
+    PCGX_STAMP(vb_bucket, 8, b, 1);  // bounds
     if (end - start > (uint32_t)kVbCap) {  // uniform: more points than the LDS tile -- the radix path does the call
       if (threadIdx.x == 0) atomicOr(flags, 1);
       return;
@@ -396,6 +401,7 @@ __global__ __launch_bounds__(kVbFinalThreads, PCGX_VB_MIN_WAVES) void vb_bucket_
     }
     for (int l = threadIdx.x; l < kWaves * kRow * 2 / 16; l += kVbFinalThreads) reinterpret_cast<uint4 *>(&cnt[0][0])[l] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
+    PCGX_STAMP(vb_bucket, 8, b, 2);  // points asked for, counts cleared
     // ---- a point's rank among its wave's points of the same cell, in input order: the lanes of a round with the same
     // cell by ballots over the cell number's bits (vb_scatter_kernel's ranking), the earlier rounds by the wave's count
     uint16_t rank[kRounds];
@@ -434,6 +440,7 @@ __global__ __launch_bounds__(kVbFinalThreads, PCGX_VB_MIN_WAVES) void vb_bucket_
       }
     }
     __syncthreads();
+    PCGX_STAMP(vb_bucket, 8, b, 3);  // ranks
     // ---- cells -> where their points begin (exclusive scan of the counts, wave after wave inside a cell) and their rank
     // among the occupied ones; thread t: cells t * kBinsPer .. (consecutive, for the scan)
     uint32_t occupied_total = 0;
@@ -490,6 +497,7 @@ __global__ __launch_bounds__(kVbFinalThreads, PCGX_VB_MIN_WAVES) void vb_bucket_
       if (threadIdx.x == kVbFinalThreads - 1) cnt[0][nbins] = (uint16_t)P;  // (a cell's points end where the next one's begin)
     }
     __syncthreads();
+    PCGX_STAMP(vb_bucket, 8, b, 4);  // cells scanned
     if (threadIdx.x == 0) count[b] = occupied_total;
     // ---- the points to their places
 #pragma unroll
@@ -504,6 +512,7 @@ __global__ __launch_bounds__(kVbFinalThreads, PCGX_VB_MIN_WAVES) void vb_bucket_
       }
     }
     __syncthreads();
+    PCGX_STAMP(vb_bucket, 8, b, 5);  // points at their places
     // ---- cell by cell: the reference's sequential float32 sum over its points in input order, the centroid; thread t:
     // cells t, t + 256, ... (neighbouring lanes neighbouring cells: their points are neighbours in LDS, their stores too)
 #pragma unroll
@@ -533,6 +542,7 @@ __global__ __launch_bounds__(kVbFinalThreads, PCGX_VB_MIN_WAVES) void vb_bucket_
       const uint32_t src = kIdx ? idx[(int64_t)start + sfrom[first]] : 0u;
       cells[(int64_t)start + vrank[l]] = make_float4(o0, o1, o2, __uint_as_float(src));
     }
+    PCGX_STAMP(vb_bucket, 8, b, 6);  // cell phase, stores issued
     __syncthreads();  // (the next bucket clears cnt[] and fills sx / sy / sz)
   }
 }
