@@ -564,6 +564,8 @@ def main():
         s64.close()
     shard_stats = np.zeros(4, np.int64)
     L.check(L.lib().pcgx_debug_shard_stats(L.ptr(shard_stats), 0))
+    ring_kinds = np.zeros(2, np.int64)   # rank 0's count: {rings with the inboxes in the ranks' device memory, in host memory}
+    L.check(L.lib().pcgx_debug_ring_kinds(L.ptr(ring_kinds), 0))
 
     # What the grid pass reads per iteration (an untimed Fit, one instrumented launch before each step)
     grid_pts = grid_words = grid_walked = grid_kept = 0
@@ -670,8 +672,12 @@ def main():
                            world, "synth.c5_tile: octants" if args.workload == "c5" else "synth.spatial_cell"),
                        "exchange": "none" if world == 1 else (
                            ("%s; communicator: %s" % (
-                               ("reference sums over the ranks: ring of tagged words in shared host memory, no collective per step "
-                                "(csrc/strict.hip strict_enqueue_ring)" if shard_stats[0] > 0 and shard_stats[1] == 0 else
+                               ("reference sums over the ranks: ring of tagged words, no collective per step (csrc/strict.hip "
+                                "strict_enqueue_ring); inboxes in %s" % (
+                                    "the ranks' DEVICE memory, mapped by the peers through HIP IPC handles (a hop: one store over "
+                                    "xGMI, a poll of local HBM)" if ring_kinds[0] > 0 else
+                                    "shared HOST memory (a rank could not export or map a device inbox: a PCIe round trip per poll)")
+                                if shard_stats[0] > 0 and shard_stats[1] == 0 else
                                 "reference sums over the ranks: 2 + N all-reduces per step (no shared-memory ring between these ranks)")
                                if strict else "all-reduce 10 x f64 per step",
                                "callback over gloo: REHEARSAL on one GPU, not a measurement" if rehearse
@@ -683,7 +689,8 @@ def main():
         }
         if world > 1:
             line["shard_stats"] = {"ring_steps": int(shard_stats[0]), "collective_steps": int(shard_stats[1]),
-                                   "rings_made": int(shard_stats[2]), "ring_setups_fallen_back": int(shard_stats[3])}
+                                   "rings_made": int(shard_stats[2]), "ring_setups_fallen_back": int(shard_stats[3]),
+                                   "rings_in_device_memory": int(ring_kinds[0]), "rings_in_host_memory": int(ring_kinds[1])}
             # one of these GPUs alone in the float64 mode, no exchange
             line["value_f64_tree_one_gpu_alone"] = f64_one_gpu
             if isinstance(f64_sharded, float):

@@ -78,12 +78,13 @@ PCGX_API int32_t pcgx_last_error(char *buf, size_t cap);
 PCGX_API const char *pcgx_version(void);
 /* The layout version of this header's structs and fixed-size output arrays (pcgx_icp_params gained sums_mode in 3;
  * pcgx_debug_icp_strict_stats writes 64 words since 3; 4: device slots, pcgx_icp_fit_multi, pcgx_debug_voxel_stats;
- * 5: pcgx_debug_shard_stats, pcgx_prof_read_max, words 48 .. 63 of pcgx_debug_icp_strict_stats re-assigned).
+ * 5: pcgx_debug_shard_stats, pcgx_prof_read_max, words 48 .. 63 of pcgx_debug_icp_strict_stats re-assigned;
+ * 6: pcgx_debug_ring_kinds).
  * A binding built against another version of the header must not call into the library: the mirrors (go/pcgx,
  * host/pcgx.hpp, pcgol_amd/_lib.py) compare PCGX_ABI_VERSION with pcgx_abi_version() when they load it.
  * pcgx_icp_params_init zeroes a parameter block of THIS version (all defaults); sizeof_params is the caller's
  * sizeof(pcgx_icp_params): a mismatch is PCGX_E_INVALID instead of a read past a shorter struct. */
-#define PCGX_ABI_VERSION 5
+#define PCGX_ABI_VERSION 6
 PCGX_API int32_t pcgx_abi_version(void);
 /* Block until all work enqueued on `stream` (NULL = library stream) is done. */
 PCGX_API pcgx_status pcgx_sync(void *stream);
@@ -109,6 +110,12 @@ PCGX_API pcgx_status pcgx_debug_voxel_stats(int64_t out[4], int32_t reset);
  * rings made (shared memory of the node's processes, or the one process's pinned block), ring set-ups that
  * ended with the collective form (no shared memory between the ranks, PCGX_SHARD_RING=0)}. */
 PCGX_API pcgx_status pcgx_debug_shard_stats(int64_t out[4], int32_t reset);
+/* ... and where the rings made since the last reset keep their inboxes' data words: out = {rings whose inboxes live
+ * in the ranks' DEVICE memory, mapped by their peers (hipIpcOpenMemHandle between processes, peer access between the
+ * device slots of one process: a hop is one store over xGMI and a poll of local HBM), rings whose data words stay in
+ * host-coherent memory (a rank could not export / map an inbox, PCGX_RING_MEM=host: a PCIe round trip per poll)}.
+ * Counted once per communicator, by its rank 0 (pcgx_icp_fit_multi: by slot 0). */
+PCGX_API pcgx_status pcgx_debug_ring_kinds(int64_t out[2], int32_t reset);
 
 /* Optional in-library kernel timing (HIP events on the launch stream around
  * the named kernel class).  Used by bench.py for the live roofline figure. */
@@ -460,8 +467,12 @@ PCGX_API pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream);
  *      chain: it goes round the ranks).  Where the ranks can share host memory -- the processes of one node (a POSIX
  *      shared-memory segment every rank maps and registers with HIP, agreed on through the communicator's own
  *      all-reduce on first use), or the device slots of one process -- that is the RING form: no collective per
- *      iteration; every rank owns an inbox of tagged 64-bit words in host-coherent memory that the other GPUs' kernels
- *      write and its own kernels poll, every rank's kernels are resident at once and only the walkers wait, each for
+ *      iteration; every rank owns an inbox of tagged 64-bit words that the other GPUs' kernels write and its own
+ *      kernels poll -- in its OWN GPU's memory, mapped by the peers (hipIpcGetMemHandle / hipIpcOpenMemHandle between
+ *      processes, hipDeviceEnablePeerAccess between the slots of one: a store over xGMI, a poll of local HBM; the
+ *      handles ride on the same set-up all-reduce), or in the host-coherent block where a rank cannot export or map
+ *      one (pcgx_debug_ring_kinds says which); the abort words stay in the host block, hosts write them.  Every rank's
+ *      kernels are resident at once and only the walkers wait, each for
  *      one word from the rank before it (csrc/strict.hip, strict_enqueue_ring).  Elsewhere (ranks on several nodes,
  *      PCGX_SHARD_RING=0): 2 + world collectives of <= 16 x world doubles per iteration.  Same bits either way.
  *  PCGX_SUMS_F64_TREE  partials -> ONE all-reduce of the 10 (plane: 30) float64 sums -> update: faster, and off the

@@ -129,7 +129,7 @@ class IcpStat(C.Structure):
 
 # name -> (restype, argtypes); the complete export list of include/pcgx.h
 _vp, _i64, _i32, _u32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float, C.c_size_t
-ABI_VERSION = 5   # include/pcgx.h PCGX_ABI_VERSION
+ABI_VERSION = 6   # include/pcgx.h PCGX_ABI_VERSION
 
 SIGNATURES = {
     "pcgx_init": (_i32, [_i32]),
@@ -190,6 +190,7 @@ SIGNATURES = {
     "pcgx_debug_call_stats": (_i32, [_vp, _i32]),
     "pcgx_debug_voxel_stats": (_i32, [_vp, _i32]),
     "pcgx_debug_shard_stats": (_i32, [_vp, _i32]),
+    "pcgx_debug_ring_kinds": (_i32, [_vp, _i32]),
     "pcgx_comm_unique_id": (_i32, [_vp]),
     "pcgx_comm_init": (_i32, [_i32, _i32, _vp, C.POINTER(_vp)]),
     "pcgx_comm_init_callback": (_i32, [_i32, _i32, _vp, _vp, C.POINTER(_vp)]),

@@ -13,7 +13,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libpcgx.so")
 SOURCES = ["core.hip", "knn.hip", "knn_explicit.hip", "knn_grid.hip", "sort.hip", "icp.hip", "strict.hip", "strict_check.hip", "comm.hip", "voxel.hip", "voxel_bucket.hip", "range.hip", "segment.hip", "pcd.hip", "kdtree_build_gpu.hip", "kdtree_build.cpp"]
-HEADERS = ["pcgx_internal.h", "pcgx_math.h", "knn_walk.h", "knn_xwalk.h", "knn_grid.h", "range_walk.h", "strict_sum.h", "strict_terms.h", "voxel_key.h", os.path.join("..", "..", "include", "pcgx.h")]
+# every header beside the sources, whoever includes it (round 5's wg_stamps.h was missing from a hand-kept list: an
+# edit there changed kernels without changing source_hash), and the public header
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "pcgx.h")]
 ARCH = "gfx950"
 
 

@@ -82,6 +82,7 @@ bool comm_force_collective() {
 constexpr int kNcclFloat64 = 8, kNcclSum = 0;  // rccl.h: ncclDataType_t, ncclRedOp_t
 
 std::atomic<long long> g_shard_stats[4];  // pcgx_debug_shard_stats
+std::atomic<long long> g_ring_kinds[2];   // pcgx_debug_ring_kinds
 
 }  // namespace
 
@@ -98,14 +99,33 @@ struct pcgx_comm {
   bool ring_tried = false;
   unsigned long long *ring_host = nullptr, *ring_dev = nullptr;
   int32_t ring_words = 0;
-  uint32_t ring_epoch = 0;
   void *ring_map = nullptr;  // a mapping this communicator owns (shared memory); nullptr: somebody else's block
   size_t ring_bytes = 0;
+  uint32_t ring_fit = 0;  // Fits begun on this communicator (comm_ring_new_fit; every rank counts alike): the upper bits of a word's tag
+  // The inboxes' DATA words in DEVICE memory (ring_setup_device, collective, behind the host block): every rank's
+  // inbox lives in its own GPU's memory and is mapped by the others -- hipIpcOpenMemHandle between processes, the
+  // plain pointer (+ hipDeviceEnablePeerAccess) between the device slots of one process.  A store into a peer's inbox
+  // crosses xGMI once; the owner polls its own HBM (0.55 us per hop against 2.2 through pinned host memory,
+  // tools/micro/ipc_hop.cpp).  Where that cannot be had on EVERY rank the data words stay in the host block.
+  bool dev_tried = false;
+  unsigned long long *inbox = nullptr;               // mine
+  std::vector<unsigned long long *> peers;            // [world] every rank's inbox as this process addresses it
+  std::vector<void *> ipc_open;                       // mappings to close
+  unsigned long long **ring_tab = nullptr;            // the same table in this rank's device memory (StrictWork::ring_tab)
+  int ring_kind = 0;                                  // 0: no ring (collectives); 1: host-coherent memory; 2: device memory
+  bool ranks_share_device = true;                     // two ranks on one physical GPU (or unknown): the short wait bounds
 };
 
 namespace {
 
 void ring_unmap(pcgx_comm *c) {
+  for (void *p : c->ipc_open) (void)hipIpcCloseMemHandle(p);
+  c->ipc_open.clear();
+  if (c->ring_tab) (void)hipFree(c->ring_tab);
+  if (c->inbox) (void)hipFree(c->inbox);
+  c->ring_tab = nullptr;
+  c->inbox = nullptr;
+  c->peers.clear();
   if (c->ring_map) {
     (void)hipHostUnregister(c->ring_map);
     (void)munmap(c->ring_map, c->ring_bytes);
@@ -173,7 +193,146 @@ void ring_setup(pcgx_comm *c) {
   c->ring_words = RL.words();
 }
 
+// The data words' inboxes in device memory.  Collective: every rank of `c` calls it at the same point, behind the host
+// block (which keeps the abort words -- hosts write those -- and is where the data words stay if any rank fails here).
+// What the ranks tell each other rides on the communicator's own host all-reduce, a rank's record in its slot of a
+// vector of zeros, every number an integer below 2^32 (exact in a float64 sum): pid, HIP device, the inbox's address
+// (for the slots of one process) and its 64-byte IPC handle (for everybody else).
+void ring_setup_device(pcgx_comm *c) {
+  c->dev_tried = true;
+  if (!c->ring_dev || c->world < 2) return;
+  c->ring_kind = 1;
+  const pcgx::RingLayout RL{c->world};
+  // the table for the host-memory form (what is used if anything below fails on any rank)
+  auto host_table = [&]() {
+    c->peers.assign((size_t)c->world, nullptr);
+    for (int k = 0; k < c->world; k++) c->peers[(size_t)k] = c->ring_dev + (size_t)k * c->ring_words;
+  };
+  const char *knob = getenv("PCGX_RING_MEM");  // host: the data words stay in host memory (the round-5 form; measurement)
+  const bool want_dev = !(knob && (knob[0] == 'h' || knob[0] == '0'));
+  constexpr int kRec = 22;  // pid, device, address (2), ok, handle (16), PCI bus id
+  std::vector<double> v((size_t)c->world * kRec, 0.0);
+  const size_t bytes = ((size_t)RL.words() * sizeof(unsigned long long) + 4095) & ~(size_t)4095;
+  bool mine = want_dev && pcgx::ensure_init() == PCGX_OK;
+  int device = -1;
+  hipIpcMemHandle_t handle;
+  memset(&handle, 0, sizeof handle);
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as sixteen 32-bit words");
+  if (mine) {
+    mine = hipGetDevice(&device) == hipSuccess;
+    // uncached device memory: a peer's store must be seen by the owner's next poll whatever its L2 holds
+    if (mine && hipExtMallocWithFlags((void **)&c->inbox, bytes, hipDeviceMallocUncached) != hipSuccess) {
+      (void)hipGetLastError();
+      c->inbox = nullptr;
+      if (hipExtMallocWithFlags((void **)&c->inbox, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        c->inbox = nullptr;
+        mine = false;
+      }
+    }
+    if (mine) mine = hipMemset(c->inbox, 0, bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess;  // (tag 0: nobody's)
+    if (mine) mine = hipIpcGetMemHandle(&handle, c->inbox) == hipSuccess;
+    if (!mine) (void)hipGetLastError();
+  }
+  {
+    double *r = v.data() + (size_t)c->rank * kRec;
+    const unsigned long long a = (unsigned long long)(uintptr_t)c->inbox;
+    r[0] = (double)getpid();
+    r[1] = (double)device;
+    r[2] = (double)(uint32_t)a;
+    r[3] = (double)(uint32_t)(a >> 32);
+    r[4] = mine ? 1.0 : 0.0;
+    uint32_t w[16];
+    memcpy(w, &handle, sizeof w);
+    for (int k = 0; k < 16; k++) r[5 + k] = (double)w[k];
+    // which physical GPU this rank works on (two processes number their devices as they please): domain:bus:device.function
+    char bus[64] = {0};
+    int cur = -1;
+    unsigned dom = 0, b = 0, d = 0, f = 0;
+    if (pcgx::ensure_init() == PCGX_OK && hipGetDevice(&cur) == hipSuccess && hipDeviceGetPCIBusId(bus, (int)sizeof bus, cur) == hipSuccess &&
+        sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) == 4)
+      r[21] = (double)(1u + ((dom & 0xfffu) << 16 | (b & 0xffu) << 8 | (d & 0x1fu) << 3 | (f & 7u)));
+    else
+      (void)hipGetLastError();
+  }
+  bool all = pcgx_comm_allreduce_host_f64(c, v.data(), c->world * kRec) == PCGX_OK;
+  c->ranks_share_device = !all;
+  for (int k = 0; k < c->world && all; k++) {
+    if (v[(size_t)k * kRec + 21] == 0.0) c->ranks_share_device = true;  // (unknown: as if shared)
+    for (int j = 0; j < k; j++)
+      if (v[(size_t)k * kRec + 21] == v[(size_t)j * kRec + 21]) c->ranks_share_device = true;
+  }
+  for (int k = 0; k < c->world && all; k++) all = v[(size_t)k * kRec + 4] == 1.0;
+  bool ok = all;
+  if (ok) {
+    c->peers.assign((size_t)c->world, nullptr);
+    for (int k = 0; k < c->world && ok; k++) {
+      const double *r = v.data() + (size_t)k * kRec;
+      if (k == c->rank) {
+        c->peers[(size_t)k] = c->inbox;
+        continue;
+      }
+      if ((pid_t)r[0] == getpid()) {  // a device slot of this process: its pointer is mine too
+        const int peer_dev = (int)r[1];
+        if (peer_dev != device) {
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, device, peer_dev) != hipSuccess || !can) ok = false;
+          if (ok) {
+            const hipError_t e = hipDeviceEnablePeerAccess(peer_dev, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = false;
+            (void)hipGetLastError();
+          }
+        }
+        c->peers[(size_t)k] = (unsigned long long *)(uintptr_t)((unsigned long long)(uint32_t)r[2] | (unsigned long long)(uint32_t)r[3] << 32);
+      } else {
+        hipIpcMemHandle_t h;
+        uint32_t w[16];
+        for (int j = 0; j < 16; j++) w[j] = (uint32_t)r[5 + j];
+        memcpy(&h, w, sizeof h);
+        void *p = nullptr;
+        if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !p) {
+          (void)hipGetLastError();
+          ok = false;
+        } else {
+          c->ipc_open.push_back(p);
+          c->peers[(size_t)k] = (unsigned long long *)p;
+        }
+      }
+    }
+  }
+  // every rank with every peer's inbox mapped, or nobody: a rank writing into host memory that its peer does not poll
+  // would be a Fit that waits out its bound
+  double bad = ok ? 0.0 : 1.0;
+  const bool agreed = pcgx_comm_allreduce_host_f64(c, &bad, 1) == PCGX_OK && bad == 0.0;
+  if (!agreed) {
+    for (void *p : c->ipc_open) (void)hipIpcCloseMemHandle(p);
+    c->ipc_open.clear();
+    if (c->inbox) (void)hipFree(c->inbox);
+    c->inbox = nullptr;
+    (void)hipGetLastError();
+    host_table();
+  } else {
+    c->ring_kind = 2;
+  }
+  bool tab_ok = pcgx::ensure_init() == PCGX_OK && hipMalloc((void **)&c->ring_tab, (size_t)c->world * sizeof(void *)) == hipSuccess &&
+                hipMemcpy(c->ring_tab, c->peers.data(), (size_t)c->world * sizeof(void *), hipMemcpyHostToDevice) == hipSuccess;
+  if (!tab_ok) {  // (no table, no ring: the collectives)
+    (void)hipGetLastError();
+    c->ring_kind = 0;
+  }
+  if (c->rank == 0 && c->ring_kind > 0) g_ring_kinds[c->ring_kind == 2 ? 0 : 1]++;
+}
+
 }  // namespace
+
+extern "C" pcgx_status pcgx_debug_ring_kinds(int64_t out[2], int32_t reset) {
+  if (!out) return pcgx::fail(PCGX_E_INVALID, "pcgx_debug_ring_kinds: NULL argument");
+  for (int k = 0; k < 2; k++) {
+    out[k] = (int64_t)g_ring_kinds[k].load();
+    if (reset) g_ring_kinds[k].store(0);
+  }
+  return PCGX_OK;
+}
 
 extern "C" pcgx_status pcgx_debug_shard_stats(int64_t out[4], int32_t reset) {
   if (!out) return pcgx::fail(PCGX_E_INVALID, "pcgx_debug_shard_stats: NULL argument");
@@ -195,40 +354,70 @@ void comm_attach_local_ring(pcgx_comm *c, unsigned long long *block, int32_t wor
   if (c->rank == 0) shard_count(2);
 }
 
-void comm_ring_clear_abort(pcgx_comm *c) {
+static void ring_ensure(pcgx_comm *c) {  // collective on first use
   if (!c->ring_tried) ring_setup(c);
-  if (!c->ring_host) return;
-  const RingLayout RL{c->world};
-  __atomic_store_n(c->ring_host + (size_t)c->rank * c->ring_words + RL.abort(), 0ull, __ATOMIC_SEQ_CST);
+  if (!c->dev_tried) ring_setup_device(c);
 }
 
-bool comm_ring_step(pcgx_comm *c, RingView *out) {
-  if (!c->ring_tried) ring_setup(c);
-  if (!c->ring_dev) {
+// A Fit begins on the communicator: every rank calls this ONCE per Fit, at the same point of its call sequence (the
+// first sharded step of a session since it was made or reset; pcgx_icp_fit_sharded, also on a rank that can go no
+// further).  A word's tag is {Fit number, step + 1} (ring_tag): what an earlier Fit left in the inboxes -- data or
+// abort words, or what a laggard of that Fit still writes -- carries another Fit's number and is nobody's business;
+// and a rank that STOPS stepping in the middle of a Fit (its caller saw an error) is in step with the others again at
+// the next Fit, which a count of steps taken would not be.  The owner wipes its own abort word if an earlier Fit's.
+// (kRingTagStepBits, strict_terms.h: steps 0 .. 4094 of a Fit ride the ring; beyond: the collective form)
+static uint32_t ring_tag(uint32_t fit, int32_t step) { return (fit & 0xfffffu) << kRingTagStepBits | (uint32_t)(step + 1); }
+void comm_ring_new_fit(pcgx_comm *c) {
+  ring_ensure(c);
+  if (++c->ring_fit == 0u || (c->ring_fit & 0xfffffu) == 0u) c->ring_fit = 1u;
+  if (!c->ring_host) return;
+  const RingLayout RL{c->world};
+  unsigned long long *w = c->ring_host + (size_t)c->rank * c->ring_words + RL.abort();
+  unsigned long long old = __atomic_load_n(w, __ATOMIC_SEQ_CST);
+  while (old != 0ull && (uint32_t)(old >> 32) >> kRingTagStepBits != (c->ring_fit & 0xfffffu))
+    if (__atomic_compare_exchange_n(w, &old, 0ull, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) break;
+}
+
+int comm_ring_kind(pcgx_comm *c) { return c->ring_kind; }
+
+bool comm_ring_step(pcgx_comm *c, int32_t step, RingView *out) {
+  ring_ensure(c);
+  if (c->ring_kind == 0 || step < 0 || step + 1 >= (1 << kRingTagStepBits) || c->ring_fit == 0u) {
     shard_count(1);
     return false;
   }
   shard_count(0);
-  if (++c->ring_epoch == 0u) c->ring_epoch = 1u;
   out->words = c->ring_dev;
   out->host = c->ring_host;
+  out->tab = c->ring_tab;
+  out->mine = c->peers[(size_t)c->rank];
   out->words_per_rank = c->ring_words;
   out->rank = c->rank;
   out->world = c->world;
-  out->epoch = c->ring_epoch;
+  out->epoch = ring_tag(c->ring_fit, step);
+  out->kind = c->ring_kind;
+  {
+    static const long long knob = getenv("PCGX_RING_GUESS_WAIT_US") ? atoll(getenv("PCGX_RING_GUESS_WAIT_US")) * 100 : 0;  // (tests)
+    out->guess_ticks = knob > 0 ? knob : (c->ranks_share_device ? kRingGuessTicks : kRingGuessTicksApart);
+  }
   return true;
 }
 
-// the abort word of every inbox: {reason, epoch}, the EARLIEST epoch wins (the host runs ahead of the device: a rank
-// that fails while enqueuing step 12 must not wipe out what told the others about step 7)
+// the abort word of every inbox: {reason, tag}, the EARLIEST step of this Fit wins (the host runs ahead of the device:
+// a rank that fails while enqueuing step 12 must not wipe out what told the others about step 7); another Fit's word
+// is overwritten like an empty one
 void ring_abort_from_host(const RingView &ring, uint32_t reason) {
   const RingLayout RL{ring.world};
   const unsigned long long mine = (unsigned long long)ring.epoch << 32 | reason;
   for (int k = 0; k < ring.world; k++) {
     unsigned long long *w = ring.host + (size_t)k * ring.words_per_rank + RL.abort();
     unsigned long long old = __atomic_load_n(w, __ATOMIC_SEQ_CST);
-    while ((old >> 32) == 0ull || (old >> 32) > (unsigned long long)ring.epoch)
+    while (true) {
+      const uint32_t tag = (uint32_t)(old >> 32);
+      const bool earlier_of_this_fit = tag != 0u && tag >> kRingTagStepBits == ring.epoch >> kRingTagStepBits && tag <= ring.epoch;
+      if (earlier_of_this_fit) break;
       if (__atomic_compare_exchange_n(w, &old, mine, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) break;
+    }
   }
 }
 

@@ -648,10 +648,14 @@ struct pcgx_icp_session {
   bool own_sums = false;
   double *d_xchg = nullptr;  // sharded float64 steps: the sums + the ranks' error flag, what the all-reduce carries
   int32_t steps_sharded = 0; // sharded steps enqueued (fault injection of the tests counts them)
-  int32_t host_iter = 0;     // Evaluates enqueued since the session was made / reset (0: the next one sees the raw target)
+  int32_t host_iter = 0;     // Evaluates enqueued since the device's loop state was last WRITTEN (session made, reset, set_pose):
+                             // what settle() compares with the device's num_iteration, which those writes zero -- not the updater's
+                             // `iter`, which set_pose may start anywhere
   bool spec_walk = true;     // the leftover walk is not launched behind a grid pass from a Fit's second Evaluate on (enqueue_corr)
   bool spec_pending = false; // ... and steps enqueued that way have not been looked at yet (settle())
+  hipStream_t spec_stream = nullptr;  // ... on this stream (entry points without a stream argument settle there)
   bool shard_failed = false; // this rank could not go on: it keeps calling the collectives with its flag up
+  bool ring_fit_open = false; // pcgx_icp_fit_sharded has told the communicator that a Fit begins (comm_ring_new_fit: once per Fit)
   bool plane = false;              // point-to-plane / Gauss-Newton session (30 sums)
   uint32_t *d_match_id = nullptr;  // plane: [nt] matched base id
   float4 *d_normals = nullptr;     // plane: [base n] unit normals in base id order
@@ -728,7 +732,7 @@ extern "C" pcgx_status pcgx_icp_session_set_pose(pcgx_icp_session *s, const floa
   memset(&h, 0, sizeof h);
   memcpy(h.trans, trans16, sizeof h.trans);
   h.iter = iter;
-  s->host_iter = iter;
+  s->host_iter = 0;  // (num_iteration restarts at 0 with the state written below; the next step is not speculated on: enqueue_corr)
   PCGX_HIP_TRY(hipMemcpyAsync(s->d_state, &h, sizeof h, hipMemcpyHostToDevice, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
   return PCGX_OK;
@@ -750,6 +754,8 @@ extern "C" pcgx_status pcgx_icp_session_set_strict(pcgx_icp_session *s, int32_t 
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_strict: NULL session");
   if (on && s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_strict: point-to-plane sessions have no reference sums to reproduce");
   if (on < 0 || on > 2) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_strict: mode must be 0, 1 or 2");
+  // steps enqueued without the leftover walk are replayed by settle() in the mode they were asked for in: before it changes
+  if (s->spec_pending) PCGX_TRY(settle(s, s->spec_stream));
   s->strict = on;
   s->strict_explicit = on != 0;
   return PCGX_OK;
@@ -1031,7 +1037,10 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st, bool may_sp
   static const int test_force_walk = icp_knob("PCGX_TEST_ICP_FORCE_WALK", 0, 0, 1 << 30);
   const bool no_walk = may_speculate && spec_on && s->spec_walk && grid && s->strict == 1 && !s->plane && s->host_iter >= 1 &&
                        !s->tile_sums_fresh;
-  if (no_walk) s->spec_pending = true;
+  if (no_walk) {
+    s->spec_pending = true;
+    s->spec_stream = st;
+  }
   if (grid) {
     ProfScope prof_grid(PCGX_PROF_ICP_GRID, st);
     const unsigned gb = (unsigned)((s->nt + kIcpGridBlock - 1) / kIcpGridBlock);
@@ -1147,6 +1156,7 @@ extern "C" pcgx_status pcgx_debug_icp_strict_stats(pcgx_icp_session *s, void *st
   if (!s || !out) return fail(PCGX_E_INVALID, "pcgx_debug_icp_strict_stats: NULL argument");
   for (int k = 0; k < 64; k++) out[k] = 0;
   if (!s->strict_buf) return PCGX_OK;
+  PCGX_TRY(settle(s, pick_stream(stream)));  // (the counters of steps the device skipped would be missing)
   unsigned long long h[64];
   PCGX_TRY(strict_read_debug(s->strict_buf, h, pick_stream(stream)));
   for (int k = 0; k < 64; k++) out[k] = (int64_t)h[k];
@@ -1216,6 +1226,10 @@ static pcgx_status step_sharded_impl(pcgx_icp_session *s, pcgx_comm *c, void *st
   hipStream_t st = pick_stream(stream);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   const int step = s->steps_sharded++;
+  // the first sharded step since the session was made or reset: a Fit begins on the communicator -- whatever an earlier
+  // Fit left in the ring's abort words is not this one's business (every rank gets here at the same point of its calls)
+  if (step == 0 && world > 1 && s->strict == 1 && !s->plane && !s->ring_fit_open) comm_ring_new_fit(c);
+  s->ring_fit_open = false;
   if (const char *e = getenv("PCGX_TEST_FAIL_RANK")) {  // fault injection (tests/test_gpu_multi.py)
     const char *it = getenv("PCGX_TEST_FAIL_ITER");
     if (atoi(e) == rank && it && atoi(it) == step && !s->shard_failed) {
@@ -1228,7 +1242,7 @@ static pcgx_status step_sharded_impl(pcgx_icp_session *s, pcgx_comm *c, void *st
     // the ring form (strict.hip, strict_enqueue_ring) wherever the ranks can share memory: no collective per step.
     // (Asked for first, by every rank whatever its own state: making the ring is collective.)
     RingView ring;
-    const bool have_ring = comm_ring_step(c, &ring);
+    const bool have_ring = comm_ring_step(c, step, &ring);
     if (!s->shard_failed) {
       const pcgx_status rc = enqueue_corr(s, st);
       if (rc != PCGX_OK) {
@@ -1310,7 +1324,8 @@ extern "C" pcgx_status pcgx_icp_fit_sharded(const pcgx_kdtree *base, const float
   pcgx_icp_session *s = nullptr;
   pcgx_status rc = pcgx_icp_session_create(base, tile, nt, 0, params, nullptr, &s);
   std::string first_error = rc != PCGX_OK ? std::string(last_error_text()) : std::string();
-  if (world > 1) comm_ring_clear_abort(c);  // (makes the communicator's ring on first use -- collective; the exchange below is the barrier behind it)
+  if (world > 1) comm_ring_new_fit(c);  // (makes the communicator's ring on first use -- collective; a rank without a session counts the Fit too)
+  if (s) s->ring_fit_open = true;
   if (world > 1) {
     // A rank whose session could not be made (out of memory, a bad argument) must not leave the others
     // waiting in the first all-reduce: every rank reaches ONE exchange of an error flag first -- out of a host word
@@ -1462,7 +1477,7 @@ extern "C" pcgx_status pcgx_icp_fit_multi(int32_t n, const pcgx_kdtree *const *b
           v.words_per_rank = RL.words();
           v.rank = r;
           v.world = n;
-          v.epoch = 1u;
+          v.epoch = 1u << kRingTagStepBits | 1u;  // (the communicators of this call are fresh: Fit 1, its first step)
           ring_abort_from_host(v, 1u);
         }
         std::lock_guard<std::mutex> lk(x.mu);  // (a rank that could not even start must not leave the others waiting)

@@ -419,10 +419,14 @@ pcgx_status strict_enqueue_sharded(StrictBuffers *b, const float4 *match, const 
 // ... the RING form of the same (strict.hip, strict_enqueue_ring; comm.hip makes the ring): every rank's inbox in
 // host-coherent memory that all GPUs of the node write and poll, no collective per step
 struct RingView {
-  unsigned long long *words = nullptr;  // device-visible address of the inboxes (rank k's at words + k * words_per_rank)
+  unsigned long long *words = nullptr;  // device-visible address of the host-coherent block (rank k's part at words + k * words_per_rank): the abort words
   unsigned long long *host = nullptr;   // the same memory as this process's host sees it
+  unsigned long long *const *tab = nullptr;  // device memory: [world] every rank's inbox (data words) as this device addresses it
+  unsigned long long *mine = nullptr;        // tab[rank]
   int32_t words_per_rank = 0, rank = 0, world = 1;
-  uint32_t epoch = 0;                   // this step's number on the communicator (every rank counts alike)
+  uint32_t epoch = 0;                   // this step's tag: {the communicator's Fit number, step + 1} (comm.hip, ring_tag; every rank counts alike)
+  int32_t kind = 0;                     // 1: the data words in host-coherent memory; 2: in the ranks' device memory
+  long long guess_ticks = 0;            // bound of the waits only guesses depend on (strict_terms.h, kRingGuessTicks*)
 };
 pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state, double *sums10,
                                 const IcpKernelParams &kp, const RingView &ring, bool local_failed, bool first_iter, hipStream_t st);
@@ -430,8 +434,9 @@ void ring_abort_from_host(const RingView &ring, uint32_t reason);
 pcgx_status strict_reset(StrictBuffers *b, hipStream_t st);
 // comm.hip: the communicator's ring (made on first use, collectively; nullptr: this communicator exchanges through
 // collectives only -- ranks on several nodes, no shared memory, PCGX_SHARD_RING=0), and a step's view of it
-bool comm_ring_step(pcgx_comm *c, RingView *out);
-void comm_ring_clear_abort(pcgx_comm *c);
+bool comm_ring_step(pcgx_comm *c, int32_t step, RingView *out);
+void comm_ring_new_fit(pcgx_comm *c);
+int comm_ring_kind(pcgx_comm *c);
 void comm_attach_local_ring(pcgx_comm *c, unsigned long long *block, int32_t words_per_rank);
 }  // namespace pcgx
 

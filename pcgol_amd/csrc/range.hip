@@ -164,14 +164,19 @@ __device__ __forceinline__ unsigned long long range_walk_place(const TreeView &t
   return place;
 }
 
+constexpr int kTieRunLimit = 128;
 // slot s of the sorted batch is tied with a neighbour (same query, same DistSq): its place in the walk
 __global__ __launch_bounds__(256) void range_tie_place_kernel(TreeView tv, const uint32_t *__restrict__ inv,
                                                               const float *__restrict__ q, const uint32_t *__restrict__ query_of,
                                                               const uint32_t *__restrict__ key, const uint32_t *__restrict__ ids,
-                                                              int64_t total, unsigned long long *__restrict__ place) {
+                                                              int64_t total, unsigned long long *__restrict__ place,
+                                                              int32_t *__restrict__ long_run) {
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= total) return;
   const uint32_t qi = query_of[s], k = key[s];
+  // (the slots are sorted by (query, DistSq): the same pair kTieRunLimit slots back means one run of ties longer than that
+  // -- range_tie_sort_kernel's per-slot scan is quadratic in a run; the host then orders the runs by sorting)
+  if (s >= kTieRunLimit && query_of[s - kTieRunLimit] == qi && key[s - kTieRunLimit] == k) *long_run = 1;
   const bool tied = (s > 0 && query_of[s - 1] == qi && key[s - 1] == k) || (s + 1 < total && query_of[s + 1] == qi && key[s + 1] == k);
   unsigned long long v = 0ull;
   if (tied) {
@@ -209,6 +214,13 @@ __global__ __launch_bounds__(256) void range_tie_sort_kernel(const uint32_t *__r
   }
   for (int64_t x = s + 1; x < total && query_of[x] == qi && key[x] == k; x++) before += place[x] < mine ? 1 : 0;
   ids_out[a + before] = id;
+}
+
+// 32 bits of the walk's place of the slot at index[j] (nullptr: j) -- the keys of the long tie runs' sort
+__global__ __launch_bounds__(256) void range_place_bits_kernel(const unsigned long long *__restrict__ place, const uint32_t *__restrict__ index,
+                                                               int64_t n, int shift, uint32_t *__restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) out[j] = (uint32_t)(place[index ? index[j] : (uint32_t)j] >> shift);
 }
 
 __global__ __launch_bounds__(256) void range_iota_kernel(uint32_t *__restrict__ a, int64_t n) {
@@ -406,15 +418,67 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
     PCGX_TRY(range_inverse_map(t, &d_inv, st));
     unsigned long long *d_place = nullptr;
     PCGX_TRY(ar.alloc_n((size_t)total, &d_place));
+    int32_t *d_long = nullptr;
+    PCGX_TRY(ar.alloc_n(1, &d_long));
+    PCGX_HIP_TRY(hipMemsetAsync(d_long, 0, 4, st));
     hipLaunchKernelGGL(range_tie_place_kernel, dim3(tb), dim3(256), 0, st, tv, d_inv, (const float *)d_q, (const uint32_t *)k2[r2],
-                       (const uint32_t *)d_out_key, (const uint32_t *)d_out_id, total, d_place);
+                       (const uint32_t *)d_out_key, (const uint32_t *)d_out_id, total, d_place, d_long);
     // (into d_id: the discovery-order ids are done with)
     if (!d_bad) {
       PCGX_TRY(ar.alloc_n(1, &d_bad));
       PCGX_HIP_TRY(hipMemsetAsync(d_bad, 0, 4, st));
     }
-    hipLaunchKernelGGL(range_tie_sort_kernel, dim3(tb), dim3(256), 0, st, (const uint32_t *)k2[r2], (const uint32_t *)d_out_key, total,
-                       (const unsigned long long *)d_place, (const uint32_t *)d_out_id, (uint32_t *)d_id, d_bad);
+    int32_t long_run = 0;
+    PCGX_HIP_TRY(hipMemcpyAsync(&long_run, d_long, 4, hipMemcpyDeviceToHost, st));
+    PCGX_HIP_TRY(hipStreamSynchronize(st));
+    if (!long_run) {
+      hipLaunchKernelGGL(range_tie_sort_kernel, dim3(tb), dim3(256), 0, st, (const uint32_t *)k2[r2], (const uint32_t *)d_out_key, total,
+                         (const unsigned long long *)d_place, (const uint32_t *)d_out_id, (uint32_t *)d_id, d_bad);
+    } else {
+      // A run of more than kTieRunLimit exact ties (a cloud with one point taken a hundred thousand times): the per-slot
+      // scan above is quadratic in the run.  Every slot instead by (query, DistSq, place) with stable LSD passes -- place
+      // (low word, high word), DistSq, query: the slots keep their (query, DistSq) runs, inside a run they come out in
+      // the walk's order, untied slots (place 0, a run each) where they were.  Four sorts: a rare input's price.
+      const uint32_t *query_sorted = k2[r2];  // (lives in keys[]: copied out before the passes reuse them)
+      uint32_t *d_qs = nullptr;
+      PCGX_TRY(ar.alloc_n((size_t)total, &d_qs));
+      PCGX_HIP_TRY(hipMemcpyAsync(d_qs, query_sorted, (size_t)total * 4, hipMemcpyDeviceToDevice, st));
+      int place_bits = 0;  // place < 3^depth
+      {
+        unsigned long long lim = 1ull;
+        for (int j = 0; j < tv.depth; j++) lim *= 3ull;
+        while (place_bits < 64 && (lim >> place_bits) != 0ull) place_bits++;
+      }
+      uint32_t *kk[2] = {keys[0], keys[1]}, *vv[2] = {vals[0], vals[1]};
+      hipLaunchKernelGGL(range_iota_kernel, dim3(tb), dim3(256), 0, st, vv[0], total);
+      hipLaunchKernelGGL(range_place_bits_kernel, dim3(tb), dim3(256), 0, st, (const unsigned long long *)d_place, (const uint32_t *)nullptr,
+                         total, 0, kk[0]);
+      int r = 0;
+      PCGX_TRY(radix_sort_pairs(kk, vv, total, place_bits < 32 ? place_bits : 32, ws, &r, st));
+      auto next_pass = [&](int bits, auto fill) -> pcgx_status {  // keys of the next pass: by the order so far
+        uint32_t *k_in = kk[r ^ 1], *v_in = vv[r];
+        fill(k_in, (const uint32_t *)v_in);
+        uint32_t *k3[2] = {k_in, kk[r]}, *v3[2] = {v_in, vv[r ^ 1]};
+        int rr = 0;
+        PCGX_TRY(radix_sort_pairs(k3, v3, total, bits, ws, &rr, st));
+        kk[0] = k3[rr]; kk[1] = k3[rr ^ 1];
+        vv[0] = v3[rr]; vv[1] = v3[rr ^ 1];
+        r = 0;
+        return PCGX_OK;
+      };
+      if (place_bits > 32)
+        PCGX_TRY(next_pass(place_bits - 32, [&](uint32_t *k_in, const uint32_t *v_in) {
+          hipLaunchKernelGGL(range_place_bits_kernel, dim3(tb), dim3(256), 0, st, (const unsigned long long *)d_place, v_in, total, 32, k_in);
+        }));
+      PCGX_TRY(next_pass(32, [&](uint32_t *k_in, const uint32_t *v_in) {
+        hipLaunchKernelGGL(range_gather_u32_kernel, dim3(tb), dim3(256), 0, st, (const uint32_t *)d_out_key, v_in, total, k_in);
+      }));
+      PCGX_TRY(next_pass(qbits > 0 ? qbits : 1, [&](uint32_t *k_in, const uint32_t *v_in) {
+        hipLaunchKernelGGL(range_gather_u32_kernel, dim3(tb), dim3(256), 0, st, (const uint32_t *)d_qs, v_in, total, k_in);
+      }));
+      hipLaunchKernelGGL(range_gather_u32_kernel, dim3(tb), dim3(256), 0, st, (const uint32_t *)d_out_id, (const uint32_t *)vv[0], total,
+                         (uint32_t *)d_id);
+    }
     PCGX_HIP_TRY(hipGetLastError());
     d_out_id = (uint32_t *)d_id;
   }

@@ -550,7 +550,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
           for (int k0 = 0; k0 < W.rank; k0 += 7) {  // uniform (seven ranks a round)
             const int k = k0 + lane / kStrictRows, row = lane % kStrictRows;
             double v = 0.0;
-            if (lane < 7 * kStrictRows && k < W.rank && row < NR) (void)ring_wait_f64(W, RL.row_tot(k, row), v, kRingGuessTicks);
+            if (lane < 7 * kStrictRows && k < W.rank && row < NR) (void)ring_wait_f64(W, RL.row_tot(k, row), v, W.ring_guess_ticks);
 #pragma unroll
             for (int j = 0; j < 7; j++) {
               const double vj = __shfl(v, j * kStrictRows + (lane < kStrictRows ? lane : 0));
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
             if ((spins & 63) == 63) {
               const long long now = (long long)wall_clock64();
               if (t_first == 0) t_first = now;
-              if (now - t_first > 2 * kRingGuessTicks) break;  // (guesses without the ranks before this one: slow, still exact)
+              if (now - t_first > 2 * W.ring_guess_ticks) break;  // (guesses without the ranks before this one: slow, still exact)
             }
             __builtin_amdgcn_s_sleep(4);
           }
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(kSumBlock) __attribute__((amdgpu_waves_per_eu(4, 4)
       // this rank's own total, to the ranks behind it: the last tile has it here
       if (tile == W.ntiles - 1 && lane < W.world - 1 - W.rank) {
         const RingLayout RL{W.world};
-        ring_put_f64(W.ring + (size_t)(W.rank + 1 + lane) * W.ring_words + RL.row_tot(W.rank, row), P0 + s_tot[row], W.ring_epoch);
+        ring_put_f64(ring_inbox(W, W.rank + 1 + lane) + RL.row_tot(W.rank, row), P0 + s_tot[row], W.ring_epoch);
       }
     }
     const LdsQuads q{s_terms[row], lane};
@@ -2117,9 +2117,9 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       if (last_chunk && W.ring && ring_rc == 0 && lane == 0) {
         // the ring form: this rank's end state to the rank behind it -- or, from the last rank, the sum itself to all
         const RingLayout RL{W.world};
-        if (W.rank < W.world - 1) ring_put(W.ring + (size_t)(W.rank + 1) * W.ring_words + RL.start(row), s, W.ring_epoch);
+        if (W.rank < W.world - 1) ring_put(ring_inbox(W, W.rank + 1) + RL.start(row), s, W.ring_epoch);
         else
-          for (int k = 0; k < W.world - 1; k++) ring_put(W.ring + (size_t)k * W.ring_words + RL.final(row), s, W.ring_epoch);
+          for (int k = 0; k < W.world - 1; k++) ring_put(ring_inbox(W, k) + RL.final(row), s, W.ring_epoch);
       }
       if (lane == 0) {
         lds_put(&s_progress, 1 << 30);  // helpers that still wait for a tile: the chunk is done
@@ -2185,12 +2185,12 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       }
       if (ring_rc == 0 && lane == 0) {
         if (W.rank < W.world - 1) {
-          unsigned long long *dst = W.ring + (size_t)(W.rank + 1) * W.ring_words + RL.start_pairs();
+          unsigned long long *dst = ring_inbox(W, W.rank + 1) + RL.start_pairs();
           ring_put(dst, (uint32_t)pairs, W.ring_epoch);
           ring_put(dst + 1, (uint32_t)(pairs >> 32), W.ring_epoch);
         } else {
           for (int k = 0; k < W.world - 1; k++) {
-            unsigned long long *dst = W.ring + (size_t)k * W.ring_words + RL.final_pairs();
+            unsigned long long *dst = ring_inbox(W, k) + RL.final_pairs();
             ring_put(dst, (uint32_t)pairs, W.ring_epoch);
             ring_put(dst + 1, (uint32_t)(pairs >> 32), W.ring_epoch);
           }
@@ -2276,6 +2276,7 @@ struct StrictBuffers {
   // err_base[16] ([9] = pairs of all ranks), hop[16], start_bits[16] (uint32)
   double *shard = nullptr;
   int shard_world = 0;
+  bool shard_ring = false;  // `shard` was last laid out (and zeroed) for the ring form
   void *counters = nullptr;  // slot / ticket counters (strict_reset)
   size_t counters_bytes = 0, arrived_bytes = 0;
 };
@@ -2292,6 +2293,9 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   W.first_exact = 1;
   W.ring = nullptr;
   W.ring_words = 0;
+  W.ring_tab = nullptr;
+  W.ring_mine = nullptr;
+  W.ring_guess_ticks = kRingGuessTicks;
   W.rank = 0;
   W.world = 1;
   W.ring_epoch = 0u;
@@ -2517,6 +2521,7 @@ pcgx_status strict_enqueue_sharded(StrictBuffers *b, const float4 *match, const 
       return fail(PCGX_E_OOM, "strict sums over ranks: no memory for the exchange");
     b->shard_world = world;
   }
+  b->shard_ring = false;
   double *slots = b->shard, *row_base = slots + (size_t)world * 16, *err_base = row_base + 16, *hop = row_base + 32;
   uint32_t *start_bits = reinterpret_cast<uint32_t *>(hop + 16);
   (void)strict_work(b, kp);
@@ -2610,7 +2615,7 @@ __global__ __launch_bounds__(64) void strict_ring_err_kernel(const IcpState *__r
     for (int64_t t = lane; t < W.ntiles; t += 64) v += W.tile_err[(int64_t)b * W.ntiles + t];
     v = wave_allsum_f64(v);
     if (lane < W.world - 1 - W.rank)
-      ring_put_f64(W.ring + (size_t)(W.rank + 1 + lane) * W.ring_words + RL.err_tot(W.rank, b), v, W.ring_epoch);
+      ring_put_f64(ring_inbox(W, W.rank + 1 + lane) + RL.err_tot(W.rank, b), v, W.ring_epoch);
     return;
   }
   // the totals of the ranks before this one, added up in rank order: where the job tiles' guesses start
@@ -2618,7 +2623,7 @@ __global__ __launch_bounds__(64) void strict_ring_err_kernel(const IcpState *__r
   for (int k0 = 0; k0 < W.rank; k0 += 7) {  // uniform
     const int k = k0 + lane / kStrictRows, row = lane % kStrictRows;
     double v = 0.0;
-    if (lane < 7 * kStrictRows && k < W.rank && row < W.nrows) (void)ring_wait_f64(W, RL.err_tot(k, row), v, 10 * kRingGuessTicks);
+    if (lane < 7 * kStrictRows && k < W.rank && row < W.nrows) (void)ring_wait_f64(W, RL.err_tot(k, row), v, 10 * W.ring_guess_ticks);
 #pragma unroll
     for (int j = 0; j < 7; j++) acc += __shfl(v, j * kStrictRows + (lane < kStrictRows ? lane : 0));
   }
@@ -2633,11 +2638,18 @@ __global__ void strict_ring_fail_kernel(IcpState *__restrict__ state) {
 
 pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state, double *sums10,
                                 const IcpKernelParams &kp, const RingView &ring, bool local_failed, bool first_iter, hipStream_t st) {
-  if (!b->shard) {  // (the ring form keeps 32 doubles + a flag word of it)
-    if (dev_cache_alloc((void **)&b->shard, (size_t)(ring.world + 4) * 16 * sizeof(double)) != hipSuccess)
-      return fail(PCGX_E_OOM, "strict sums over ranks: no memory for the exchange");
-    b->shard_world = ring.world;
+  // (the ring form keeps 32 doubles + a flag word of it; a block the collective form used holds that form's doubles
+  // where the flag word lies -- one equal to this step's number would let tiles read ring_base before tile 0 wrote it)
+  if (!b->shard || b->shard_world != ring.world || !b->shard_ring) {
+    if (!b->shard || b->shard_world != ring.world) {
+      dev_cache_free(b->shard);
+      b->shard = nullptr;
+      if (dev_cache_alloc((void **)&b->shard, (size_t)(ring.world + 4) * 16 * sizeof(double)) != hipSuccess)
+        return fail(PCGX_E_OOM, "strict sums over ranks: no memory for the exchange");
+      b->shard_world = ring.world;
+    }
     PCGX_HIP_TRY(hipMemsetAsync(b->shard, 0, (size_t)(ring.world + 4) * 16 * sizeof(double), st));
+    b->shard_ring = true;
   }
   if (local_failed) {
     // this rank launches nothing more: the others learn of it from the abort word, in whatever wait they are in
@@ -2650,6 +2662,9 @@ pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uin
   StrictWork W = next_epoch(b);  // (the session's descriptor stays in its one-GPU form)
   W.ring = ring.words;
   W.ring_words = ring.words_per_rank;
+  W.ring_tab = ring.tab;
+  W.ring_mine = ring.mine;
+  W.ring_guess_ticks = ring.guess_ticks > 0 ? ring.guess_ticks : kRingGuessTicks;
   W.rank = ring.rank;
   W.world = ring.world;
   W.ring_epoch = ring.epoch;

@@ -126,10 +126,18 @@ struct StrictWork {
   // host-coherent memory that all GPUs of the node write and poll directly (RingLayout below); a word is a 32-bit
   // payload under a 32-bit tag -- the communicator's step count, `ring_epoch` -- so it says by itself whether it
   // is this step's: no flags, no fences, no resets.  ring == nullptr: one GPU, or the collective form above.
-  unsigned long long *ring;   // inbox of rank k at ring + k * ring_words
-  int32_t ring_words;
+  // (a word's tag, `ring_epoch` for this step: {the communicator's Fit number, step + 1}, kRingTagStepBits for the step)
+  unsigned long long *ring;   // the ranks' ABORT words: rank k's at ring + k * ring_words + RingLayout::abort(), in the
+  int32_t ring_words;         // host-coherent block every host can write (comm.hip); != nullptr: the ring form
+  // the DATA words of the inboxes: ring_tab[k] = rank k's inbox as THIS device addresses it -- the rank's own GPU's
+  // memory, mapped by its peers (hipIpcOpenMemHandle between processes, peer access inside one: a store crosses xGMI,
+  // the owner polls its own HBM), or, where that cannot be had, its part of the host-coherent block (a PCIe round
+  // trip per poll).  ring_mine == ring_tab[rank].
+  unsigned long long *const *ring_tab;
+  unsigned long long *ring_mine;
   int32_t rank, world;
   uint32_t ring_epoch;
+  long long ring_guess_ticks; // bound (100 MHz ticks) of the waits for what only guesses depend on (RingView::guess_ticks)
   double *ring_base;          // device: [0..8] row_base, [16..24] err_base of this step, as fetched from the inbox
   unsigned int *ring_flag;    // device: == ring_epoch once tile 0 of strict_sum_kernel has put row_base up
   int32_t selfcheck;  // bit 0: every step of the chain walk is re-derived term by term and compared (dbg[12..15]);
@@ -154,7 +162,15 @@ struct RingLayout {
   __host__ __device__ int abort() const { return world * 4 * kStrictRows + 32; }
   __host__ __device__ int words() const { return (world * 4 * kStrictRows + 33 + 15) & ~15; }
 };
-constexpr long long kRingGuessTicks = 200000;     // 2 ms: waits for what only guesses depend on (a late word costs time, not bits)
+// Waits for what only guesses depend on -- the earlier ranks' float64 totals: a late word costs time, not bits.  A rank
+// cannot END its step before the rank in front of it has ended its walk, which lies behind that rank's totals in stream
+// order: on a GPU of its own a rank loses nothing by waiting for them as long as it takes (kRingGuessTicksApart: a rank
+// that is late by milliseconds costs the others those milliseconds, where giving up after 2 ms cost them the slow paths
+// of hundreds of tiles with guesses off: 37 ms a step, round 5's rehearsals).  Ranks that SHARE a device (tests and
+// rehearsals on the one-GPU box) keep the short bound: there a waiting launch may hold the places the awaited one needs.
+constexpr int kRingTagStepBits = 12;                    // a word's tag: {Fit number (20 bits), step + 1 (12 bits)}, comm.hip ring_tag
+constexpr long long kRingGuessTicks = 200000;          // 2 ms
+constexpr long long kRingGuessTicksApart = 20000000;   // 200 ms
 constexpr long long kRingWalkTicks = 1000000000;  // 10 s: waits for the state a walk starts from (there is no going on without it)
 
 #if defined(__HIPCC__)
@@ -171,22 +187,25 @@ __device__ __forceinline__ bool ring_peek(const unsigned long long *w, uint32_t 
   payload = (uint32_t)v;
   return (uint32_t)(v >> 32) == epoch;
 }
-// this step's abort word of MY inbox: set (a tag of this step or an earlier one: the ring stays broken until its
-// owner clears it, pcgx_icp_fit_sharded)
+// the abort word of MY inbox: set in this step or an earlier one of THIS Fit (hosts run ahead of devices: a rank that
+// fails while enqueuing step 12 tells the others' step 7).  Another Fit's number in the tag: what an earlier Fit on the
+// communicator left, or a laggard of that Fit raised late -- not this Fit's business (comm.hip, comm_ring_new_fit).
 __device__ __forceinline__ bool ring_aborted(const StrictWork &W) {
   const RingLayout RL{W.world};
   const unsigned long long v = __hip_atomic_load(W.ring + (size_t)W.rank * W.ring_words + RL.abort(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const uint32_t tag = (uint32_t)(v >> 32);
-  return tag != 0u && tag <= W.ring_epoch;
+  return tag != 0u && tag >> kRingTagStepBits == W.ring_epoch >> kRingTagStepBits && tag <= W.ring_epoch;
 }
+// rank k's inbox (data words), as this device addresses it
+__device__ __forceinline__ unsigned long long *ring_inbox(const StrictWork &W, int k) { return W.ring_tab[k]; }
 // Wait for word `off` of MY inbox (every lane of the wave: the same address, one request).  0: here; 1: the ring was
 // aborted; 2: out of time.
 __device__ __forceinline__ int ring_wait(const StrictWork &W, int off, uint32_t &payload, long long max_ticks) {
-  const unsigned long long *p = W.ring + (size_t)W.rank * W.ring_words + off;
+  const unsigned long long *p = W.ring_mine + off;
   long long t_first = 0;
   for (int spins = 0;; spins++) {
     if (ring_peek(p, W.ring_epoch, payload)) return 0;
-    if ((spins & 7) == 7) {  // (a clock read is a memory round trip, a look at the abort word one over PCIe: now and then)
+    if ((spins & 15) == 15) {  // (a clock read is a memory round trip, a look at the abort word one over PCIe: now and then)
       if (ring_aborted(W)) return 1;
       const long long now = (long long)wall_clock64();
       if (t_first == 0) t_first = now;

@@ -62,8 +62,9 @@ class VoxelGrid:
         if getattr(self, "_dev_args", None) is None or self._dev_args[0] != key:
             leaf = (C.c_float * 3)(*[float(v) for v in self.LeafSize])
             chunk = (C.c_int32 * 3)(*[int(v) for v in self.ChunkSize])
-            self._dev_args = (key, leaf, chunk, C.c_int64(), L.lib().pcgx_voxel_filter_dev)
-        _, leaf, chunk, m, fn = self._dev_args
+            self._dev_args = (key, leaf, chunk, L.lib().pcgx_voxel_filter_dev)
+        _, leaf, chunk, fn = self._dev_args
+        m = C.c_int64()  # per call: ctypes releases the GIL, two threads on one filter object must not share the out-parameter
         rc = fn(C.c_void_p(d_data), n, stride, off, leaf, chunk, C.c_void_p(d_out), C.byref(m), C.c_void_p(stream) if stream else None)
         if rc:
             L.check(rc)

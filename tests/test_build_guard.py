@@ -27,3 +27,17 @@ def test_stale_when_hash_differs(tmp_path, monkeypatch):
     assert B.stale()
     os.remove(str(so) + ".hash")
     assert B.stale()   # no record at all: not trusted
+
+
+def test_every_file_the_kernels_are_built_from_is_hashed():
+    """source_hash() ties profiles/*_pmc.json to the build bench.py times: every translation unit under csrc/ is in
+    SOURCES, and every file any of them includes with quotes is in SOURCES + HEADERS."""
+    import re
+    hashed = {os.path.normpath(os.path.join(B.CSRC, f)) for f in B.SOURCES + B.HEADERS}
+    units = [f for f in os.listdir(B.CSRC) if f.endswith((".hip", ".cpp"))]
+    assert sorted(units) == sorted(B.SOURCES)
+    for f in os.listdir(B.CSRC):
+        with open(os.path.join(B.CSRC, f)) as fh:
+            for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', fh.read(), re.M):
+                cand = [os.path.normpath(os.path.join(B.CSRC, inc)), os.path.normpath(os.path.join(B.CSRC, "..", "..", "include", inc))]
+                assert any(c in hashed for c in cand), "%s includes %s, which source_hash() does not cover" % (f, inc)

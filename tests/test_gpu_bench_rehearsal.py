@@ -32,6 +32,8 @@ def _check(d):
     # step is reported beside it, as at N = 1
     assert d["parity_mode"].startswith("reference") and "callback" in d["config"]["exchange"] and "ring" in d["config"]["exchange"]
     assert d["shard_stats"]["ring_steps"] > 0 and d["shard_stats"]["collective_steps"] == 0
+    # ... with every rank's inbox in its GPU's memory, mapped by the other process (HIP IPC; same-device here)
+    assert d["shard_stats"]["rings_in_device_memory"] == 1 and "DEVICE memory" in d["config"]["exchange"]
     assert d["ms_per_step_reference_sums"] == d["ms_per_step"] and d["value_f64_tree"] > 0
     assert d["ms_per_step_min"] <= d["ms_per_step_median"] <= d["ms_per_step_max"]
     assert "cpu_baseline" not in d and "extra" not in d

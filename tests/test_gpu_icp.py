@@ -656,10 +656,33 @@ def test_a_step_without_the_leftover_walk_is_enqueued_again_when_the_grid_leaves
             s.step()
         tr2, st2, _ = s.result()
         assert st2.NumIteration == 20 and np.array_equal(np.asarray(tr2).ravel(), np.asarray(o["trans"]).ravel())
+        # a Fit picked up in its middle (set_pose with the updater's count > 0: the device's NumIteration restarts at 0,
+        # and settle() must count the Evaluates enqueued since THAT write, not the updater's iterations -- ADVICE r5):
+        # five iterations, the pose carried into a fresh session, fifteen more = the oracle's twenty
+        s3 = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+        for _ in range(5):
+            s3.step()
+        tr5, st5, _ = s3.result()
+        assert st5.NumIteration == 5
+        s4 = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], c["max_iteration"])
+        s4.set_pose(np.asarray(tr5, np.float32), 5)
+        for _ in range(15):
+            s4.step()
+        tr4, st4, _ = s4.result()
+        assert st4.NumIteration == 15, st4.NumIteration
+        assert np.array_equal(np.asarray(tr4).ravel(), np.asarray(o["trans"]).ravel())
+        assert np.float32(st4.Evaluated.Value) == o["value"]
+        # ... and the same session turned back in its middle: set_pose behind steps that were speculated on
+        s4.set_pose(np.asarray(tr5, np.float32), 5)
+        for _ in range(15):
+            s4.step()
+        s4.set_strict(True)   # (settles what is pending before the mode could change)
+        tr4b, st4b, _ = s4.result()
+        assert st4b.NumIteration == 15 and np.array_equal(np.asarray(tr4b).ravel(), np.asarray(o["trans"]).ravel())
         print("fit ok")
     """)
     env = dict(os.environ, PCGX_TEST_ICP_FORCE_WALK="1000", PCGX_ICP_SPEC_TRACE="1")
     r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n" % ROOT + code], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "fit ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
-    assert r.stderr.count("enqueued again") == 2, r.stderr[-3000:]   # once per session: the walk stays on afterwards
+    assert r.stderr.count("enqueued again") == 4, r.stderr[-3000:]   # once per session: the walk stays on afterwards
