@@ -369,6 +369,7 @@ __global__ __launch_bounds__(kIcpGridBlock) void icp_grid_kernel(
       // this distance -- no search.  (C4: 54 % of the targets in a Fit's second iteration, 98.5 % in its third, 99.9 %
       // from the tenth on, tools/cert_probe.py; the search is 5.8 scattered loads per target, this is none.)
       kept = pm.w >= 0.0f && dm < pm_cert && dm < kp.max_dist_sq;
+      if (test_force_walk && i % test_force_walk == 0) kept = false;  // (tests: this target is searched for and handed to the walk below)
       if (kTrace && match_cert != nullptr && grid.cert != nullptr && pm.w >= 0.0f && dm < match_cert[i] && dm < kp.max_dist_sq)
         atomicAdd(&trace[36], 1ull);  // (the trace counts what a certificate would keep and searches all the same)
     }
@@ -656,6 +657,8 @@ struct pcgx_icp_session {
   hipStream_t spec_stream = nullptr;  // ... on this stream (entry points without a stream argument settle there)
   bool shard_failed = false; // this rank could not go on: it keeps calling the collectives with its flag up
   bool ring_fit_open = false; // pcgx_icp_fit_sharded has told the communicator that a Fit begins (comm_ring_new_fit: once per Fit)
+  bool small = false;              // both clouds small: a step, or a whole Fit, is ONE launch (icp_small.hip); the target stays in the caller's order
+  void *d_small_sync = nullptr;    // ... that launch's barrier words (zero between launches)
   bool plane = false;              // point-to-plane / Gauss-Newton session (30 sums)
   uint32_t *d_match_id = nullptr;  // plane: [nt] matched base id
   float4 *d_normals = nullptr;     // plane: [base n] unit normals in base id order
@@ -666,6 +669,7 @@ struct pcgx_icp_session {
 };
 
 static pcgx_status settle(pcgx_icp_session *s, hipStream_t st);
+static int icp_knob(const char *name, int def, int lo, int hi);
 
 static IcpKernelParams make_kernel_params(const pcgx_icp_params *p) {
   IcpKernelParams kp;
@@ -803,6 +807,7 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   dev_cache_free(s->d_normals);
   if (s->own_sums) dev_cache_free(s->d_sums);
   dev_cache_free(s->d_xchg);
+  dev_cache_free(s->d_small_sync);
   delete s;
   return PCGX_OK;
 }
@@ -910,8 +915,21 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
       if ((rc = staged_upload(stage, target, (size_t)nt * 12, st)) != PCGX_OK) return bail(rc);
       d_q = stage;
     }
+    // Small clouds (the reference's own benchmark shapes, icp_test.go:100-142): the whole step in one launch
+    // (icp_small.hip), the target in the caller's order -- the sums run in that order, and at these sizes the
+    // tree's working set is in LDS and L2 whatever order the lanes' queries come in.
+    static const bool small_on = icp_knob("PCGX_ICP_SMALL", 1, 0, 1) != 0;
+    s->small = small_on && !s->plane && !patched && s->strict == 1 && small_fit_eligible(base->view(), nt);
+    if (s->small) {
+      s->nt_pad = (nt + 63) & ~(int64_t)63;
+      if ((e = dev_cache_alloc((void **)&s->d_terms, 9 * (size_t)s->nt_pad * sizeof(float))) != hipSuccess ||
+          (e = dev_cache_alloc((void **)&s->d_valid, (size_t)(s->nt_pad / 64) * sizeof(unsigned long long))) != hipSuccess ||
+          (e = dev_cache_alloc(&s->d_small_sync, small_fit_sync_bytes())) != hipSuccess ||
+          (e = hipMemsetAsync(s->d_small_sync, 0, small_fit_sync_bytes(), st)) != hipSuccess)
+        return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
+    }
     int32_t *perm = nullptr;
-    if (nt > 1) {
+    if (nt > 1 && !s->small) {
       if ((rc = ar.alloc_n((size_t)nt, &perm)) != PCGX_OK) return bail(rc);
       if ((rc = morton_order(d_q, nt, base->bbox_lo, base->bbox_hi, perm, st)) != PCGX_OK) return bail(rc);
     }
@@ -1194,11 +1212,25 @@ extern "C" pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream
   return PCGX_OK;
 }
 
+// A small session's steps in one launch (icp_small.hip) -- while it is what it was made as: the reference's sums, the
+// canonical tree (a deletion since sends the session to the patched tree's walk, enqueue_corr)
+static bool small_now(const pcgx_icp_session *s) {
+  return s->small && s->strict == 1 && !s->plane && !s->patched && s->base->n_deleted == 0 && !s->spec_pending;
+}
+static pcgx_status small_steps(pcgx_icp_session *s, hipStream_t st, int iters) {
+  s->caller_order_fresh = false;
+  s->tile_sums_fresh = false;
+  s->host_iter += iters;
+  return small_fit_enqueue(s->base->view(), s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, s->nt, s->d_state, s->kp, s->d_terms,
+                           s->d_valid, s->d_sums, s->d_small_sync, iters, st);
+}
+
 // partials + update with no exchange in between (single GPU): two launches per iteration.
 extern "C" pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream) {
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_step: NULL session");
   hipStream_t st = pick_stream(stream);
+  if (small_now(s)) return small_steps(s, st, 1);
   PCGX_TRY(enqueue_corr(s, st, true));
   if (s->strict)
     PCGX_TRY(enqueue_strict<true>(s, st));
@@ -1588,7 +1620,9 @@ extern "C" pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target
   pcgx_status rc = PCGX_OK;
   // At most MaxIteration evaluations can happen (updater.go:69-70); once the
   // device-side state is `done` the remaining launches return immediately.
-  for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) rc = pcgx_icp_session_step(s, nullptr);
+  if (small_now(s)) rc = small_steps(s, ctx().stream, s->max_iteration);  // (small clouds: the whole loop in one launch)
+  else
+    for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) rc = pcgx_icp_session_step(s, nullptr);
   if (rc == PCGX_OK) rc = pcgx_icp_session_result(s, nullptr, trans16, stat, nullptr);
   pcgx_icp_session_free(s);
   return rc;

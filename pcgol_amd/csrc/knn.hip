@@ -609,6 +609,12 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch_dev(const pcgx_kdtree *t, const
   return launch_nearest(t->view(), d_q, perm, nq, max_range_sq, min_dist_sq, d_ids, d_dist_sq, st);
 }
 
+extern "C" pcgx_status pcgx_debug_host_walks(int64_t *queries, int32_t reset) {
+  if (!queries) return fail(PCGX_E_INVALID, "pcgx_debug_host_walks: NULL argument");
+  *queries = (int64_t)xtree_host_walks(reset != 0);
+  return PCGX_OK;
+}
+
 extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const float *q, int64_t nq,
                                                  float max_range, float min_dist_sq, int64_t *ids,
                                                  float *dist_sq) {
@@ -617,6 +623,12 @@ extern "C" pcgx_status pcgx_kdtree_nearest_batch(const pcgx_kdtree *t, const flo
     return fail(PCGX_E_INVALID, "pcgx_kdtree_nearest_batch: bad argument");
   if (nq == 0) return PCGX_OK;
   PCGX_TRY(ensure_init());
+  // a few points: the reference-order walk on the handle's host mirror (knn_explicit.hip) -- a launch and two PCIe round
+  // trips cost what sixty such walks do; same ids, same DistSq bits, MinDistSq > 0 included
+  if (nq <= xtree_host_walk_max() && !t->points.empty()) {
+    xtree_host_nearest(t, q, nq, max_range, min_dist_sq, ids, dist_sq);
+    return PCGX_OK;
+  }
   hipStream_t st = ctx().stream;
   HostCallBufs b;
   PCGX_TRY(b.alloc(nq, st));

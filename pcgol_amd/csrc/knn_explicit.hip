@@ -547,3 +547,133 @@ pcgx_status xtree_launch_range(const pcgx_kdtree *t, bool fill, const float *d_q
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }
+
+// ---- a few points at a time: the same walk on the host -------------------------------------------------------------
+// storage.Search.Nearest / Range for ONE point (pc/storage/search.go:13-17; callers that loop: correspondence.go:25-36,
+// regiongrowing.go:26,47) used to be a blocking GPU call each -- upload, launch, two PCIe round trips: 57-74 us against
+// the 0.1-2.2 us the reference's own loop takes per point (profiles/r05e_rows.json).  The handle keeps a host mirror
+// of the reference's nodes {id, child0, child1, dim} for DeletePoint (above) and the cloud's points by id; batches of
+// up to host_walk_max() queries are answered from it by the walk of knn_xwalk.h restated for the host -- the same
+// visits in the same order, the same float32 expressions (this file is compiled without contraction on both sides),
+// so ids, DistSq bits, tie winners and the approximate search's answers are the device path's.  The mirror is made
+// on the handle's first such call (host threads, ~1.5 ms at 1M points).  The GPU keeps every batch above the bound.
+namespace {
+template <class Bound, class Leaf, class Pivot>
+inline void host_xwalk(const pcgx_kdtree *t, const float qv[3], Bound &&bound, Leaf &&on_leaf, Pivot &&on_pivot) {
+  int32_t cur = t->xroot;
+  if (cur < 0) return;  // root == nil (kdtree.go:84-86,150-152)
+  constexpr int kFrames = 96;  // a frame per level: depth <= 27 (kMaxTreePoints); deletions never deepen the tree
+  uint32_t stk[kFrames];
+  int sp = 0;
+  bool desc = true;
+  const float *P = t->points.data();
+  const pcgx_kdtree::XNode *X = t->xnodes.data();
+  for (int64_t guard = 4 * t->n + 8; guard > 0; --guard) {
+    if (desc) {  // searchLeafNode step (kdtree.go:202-221)
+      const pcgx_kdtree::XNode &nd = X[cur];
+      const float *p = P + 3 * (size_t)nd.id;
+      if (nd.c0 < 0 && nd.c1 < 0) {
+        const float dx = p[0] - qv[0], dy = p[1] - qv[1], dz = p[2] - qv[2];
+        if (!on_leaf(nd.id, (dx * dx + dy * dy) + dz * dz)) return;
+        desc = false;
+        continue;
+      }
+      const int side = nd.c0 < 0 ? 1 : (nd.c1 < 0 ? 0 : (p[nd.dim] > qv[nd.dim] ? 0 : 1));  // pivotVal > val -> child0
+      if (sp >= kFrames) return;
+      stk[sp++] = (uint32_t)cur | ((uint32_t)side << 27);
+      cur = side ? nd.c1 : nd.c0;
+    } else {
+      if (sp == 0) return;
+      const uint32_t fw = stk[--sp];
+      const pcgx_kdtree::XNode &nd = X[fw & 0x07FFFFFFu];
+      const int side = (int)(fw >> 27);
+      const float *p = P + 3 * (size_t)nd.id;
+      const float fp = qv[nd.dim] - p[nd.dim];  // p[dim] - pivot[dim]
+      if (fp * fp > bound()) continue;           // kdtree.go:111-115 / :173-177
+      const float dx = p[0] - qv[0], dy = p[1] - qv[1], dz = p[2] - qv[2];
+      if (!on_pivot(nd.id, (dx * dx + dy * dy) + dz * dz)) return;
+      const int32_t other = side ? nd.c0 : nd.c1;  // the child that is not on the stack (:124-132)
+      if (other >= 0) {
+        cur = other;
+        desc = true;
+      }
+    }
+  }
+}
+
+void host_mirror(const pcgx_kdtree *tc) {
+  pcgx_kdtree *t = const_cast<pcgx_kdtree *>(tc);
+  std::lock_guard<std::mutex> lock(t->mu);
+  xtree_init(t);
+}
+std::atomic<long long> g_host_walks{0};
+}  // namespace
+
+int64_t xtree_host_walk_max() {
+  static const int64_t v = [] {
+    if (const char *e = getenv("PCGX_HOST_WALK_MAX")) return (int64_t)atoll(e);
+    return (int64_t)32;  // (one batched GPU call costs what ~40-60 host walks do: tests/perf_rows_ref.py)
+  }();
+  return v;
+}
+long long xtree_host_walks(bool reset) { return reset ? g_host_walks.exchange(0) : g_host_walks.load(); }
+
+// Nearest (kdtree.go:83-146) of nq points, caller's arrays
+void xtree_host_nearest(const pcgx_kdtree *t, const float *q, int64_t nq, float max_range, float min_dist_sq, int64_t *ids,
+                        float *dist_sq) {
+  host_mirror(t);
+  g_host_walks += nq;
+  const float max_range_sq = max_range * max_range;
+  const bool cut = min_dist_sq > 0.0f;
+  for (int64_t i = 0; i < nq; i++) {
+    int32_t best_id = -1;
+    float best_d = max_range_sq;  // nothing in range: {-1, maxRange^2} (kdtree.go:84-86,100-103)
+    host_xwalk(
+        t, q + 3 * i, [&]() { return best_d; },
+        [&](int32_t id, float d) {  // leaf: replaces unless d > best (kdtree.go:95-103,138-139)
+          if (!(d > best_d)) {
+            best_id = id;
+            best_d = d;
+          }
+          return !(cut && best_d < min_dist_sq);
+        },
+        [&](int32_t id, float d) {  // pivot: strict < (kdtree.go:116-123)
+          if (d < best_d) {
+            best_id = id;
+            best_d = d;
+            if (cut && best_d < min_dist_sq) return false;
+          }
+          return true;
+        });
+    ids[i] = best_id;
+    dist_sq[i] = best_d;
+  }
+}
+
+// Range (kdtree.go:148-197): counts[i] neighbours of point i; with offsets: filled in, a query's neighbours by DistSq,
+// equal ones in the walk's order (what the device path leaves).  false: the offsets do not match the counts.
+bool xtree_host_range(const pcgx_kdtree *t, const float *q, int64_t nq, float max_range, int64_t *counts, const int64_t *offsets,
+                      int64_t *ids, float *dist_sq) {
+  host_mirror(t);
+  g_host_walks += nq;
+  const float bound = max_range * max_range;
+  std::vector<std::pair<float, int32_t>> found;
+  for (int64_t i = 0; i < nq; i++) {
+    found.clear();
+    auto hit = [&](int32_t id, float d) {
+      if (d < bound) found.emplace_back(d, id);  // kdtree.go:166-169,178-181
+      return true;
+    };
+    host_xwalk(t, q + 3 * i, [&]() { return bound; }, hit, hit);
+    if (counts) counts[i] = (int64_t)found.size();
+    if (offsets) {
+      if (offsets[i + 1] - offsets[i] != (int64_t)found.size()) return false;
+      std::stable_sort(found.begin(), found.end(), [](const std::pair<float, int32_t> &a, const std::pair<float, int32_t> &b) { return a.first < b.first; });
+      for (size_t k = 0; k < found.size(); k++) {
+        ids[offsets[i] + (int64_t)k] = found[k].second;
+        dist_sq[offsets[i] + (int64_t)k] = found[k].first;
+      }
+    }
+  }
+  return true;
+}

@@ -235,6 +235,13 @@ void xtree_delete(pcgx_kdtree *t, int64_t pid);  // caller holds t->mu
 void xtree_delete_batch(pcgx_kdtree *t, const int64_t *ids, int64_t m);  // ... in call order, on the host's threads where the order allows
 void xtree_free(pcgx_kdtree *t);
 int xtree_max_depth(const pcgx_kdtree *t);  // caller holds t->mu
+// ... and the same walk on the host, for batches of a few points (knn_explicit.hip, at the end)
+int64_t xtree_host_walk_max();
+long long xtree_host_walks(bool reset);
+void xtree_host_nearest(const pcgx_kdtree *t, const float *q, int64_t nq, float max_range, float min_dist_sq, int64_t *ids,
+                        float *dist_sq);
+bool xtree_host_range(const pcgx_kdtree *t, const float *q, int64_t nq, float max_range, int64_t *counts, const int64_t *offsets,
+                      int64_t *ids, float *dist_sq);
 pcgx_status xtree_launch_nearest(const pcgx_kdtree *t, const float *d_q, const int32_t *d_perm, int64_t nq,
                                  float max_range_sq, float min_dist_sq, int32_t *d_ids, float *d_dsq, hipStream_t st);
 pcgx_status xtree_launch_range(const pcgx_kdtree *t, bool fill, const float *d_q, const int32_t *d_perm, int64_t nq,
@@ -432,6 +439,12 @@ pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uin
                                 const IcpKernelParams &kp, const RingView &ring, bool local_failed, bool first_iter, hipStream_t st);
 void ring_abort_from_host(const RingView &ring, uint32_t reason);
 pcgx_status strict_reset(StrictBuffers *b, hipStream_t st);
+// icp_small.hip: a Fit's iterations in ONE persistent launch (small clouds: the tree's inner levels in LDS)
+bool small_fit_eligible(const TreeView &tv, int64_t nt);
+size_t small_fit_sync_bytes();
+pcgx_status small_fit_enqueue(const TreeView &tv, const float *tx, const float *ty, const float *tz, int64_t nt, IcpState *state,
+                              const IcpKernelParams &kp, float *terms, unsigned long long *valid, double *sums10, void *sync,
+                              int iters, hipStream_t st);
 // comm.hip: the communicator's ring (made on first use, collectively; nullptr: this communicator exchanges through
 // collectives only -- ranks on several nodes, no shared memory, PCGX_SHARD_RING=0), and a step's view of it
 bool comm_ring_step(pcgx_comm *c, int32_t step, RingView *out);

@@ -104,16 +104,67 @@ __global__ __launch_bounds__(kRangeBlock) void range_grid_kernel(GridView g, con
   };
   // (a NaN bound or query: the box is some cell or other and no distance compares below the bound, as in the walk)
   const GridBox box = grid_cover(g, qx, qy, qz, bound);
+  // A row of thousands of records (one site of the cloud taken a hundred thousand times) is not one lane's work -- 25 ms
+  // of dependent loop for 100k records, twice: the lane notes up to two such rows and the WAVE scans them together
+  // below.  The order hits are found in is free here: among equal DistSq of a query it is made afterwards
+  // (range_tie_*_kernel), everything else is sorted by DistSq.
+  constexpr uint32_t kFatRow = 4096u;
+  uint32_t fat_f0 = 0u, fat_e0 = 0u, fat_f1 = 0u, fat_e1 = 0u;
+  int nfat = 0;
   for (int z = box.z0; z <= box.z1; z++) {
     for (int y = box.y0; y <= box.y1; y++) {
       const uint32_t row = ((uint32_t)z * (uint32_t)g.ny + (uint32_t)y) * (uint32_t)g.nx;
       uint32_t f = g.start[row + (uint32_t)box.x0];
       const uint32_t e = g.start[row + (uint32_t)box.x1 + 1u];
+      if (e - f >= kFatRow && e > f && nfat < 2) {
+        if (nfat == 0) { fat_f0 = f; fat_e0 = e; }
+        else { fat_f1 = f; fat_e1 = e; }
+        nfat++;
+        continue;
+      }
       for (; f + 4u <= e; f += 4u) {  // four records in flight
         const float4 p0 = g.pts[f], p1 = g.pts[f + 1u], p2 = g.pts[f + 2u], p3 = g.pts[f + 3u];
         take(p0); take(p1); take(p2); take(p3);
       }
       for (; f < e; f++) take(g.pts[f]);
+    }
+  }
+  if (__ballot(nfat > 0) != 0ull) {  // (the lanes that are still here: those with a query)
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned long long act = __ballot(true), below = act & ((1ull << lane) - 1ull);
+    const uint32_t nact = (uint32_t)__popcll(act), myrank = (uint32_t)__popcll(below);
+    for (int k = 0; k < 2; k++) {
+      unsigned long long owners = __ballot(nfat > k);
+      while (owners != 0ull) {  // uniform
+        const int owner = __builtin_ctzll(owners);
+        owners &= owners - 1ull;
+        const float ox = __shfl(qx, owner), oy = __shfl(qy, owner), oz = __shfl(qz, owner);
+        const uint32_t rf = __shfl(k == 0 ? fat_f0 : fat_f1, owner), re = __shfl(k == 0 ? fat_e0 : fat_e1, owner);
+        const long long o_out0 = __shfl((long long)out0, owner), o_cap = __shfl((long long)cap, owner),
+                        o_found = __shfl((long long)found, owner);
+        const int o_ok = __shfl(slice_ok ? 1 : 0, owner);
+        const uint32_t o_i = __shfl((uint32_t)i, owner);
+        long long add = 0;
+        for (uint32_t r0 = rf; r0 < re; r0 += nact) {  // uniform
+          const uint32_t r = r0 + myrank;
+          bool hit = false;
+          float4 p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          float d = 0.0f;
+          if (r < re) {
+            p = g.pts[r];
+            const float dx = p.x - ox, dy = p.y - oy, dz = p.z - oz;
+            d = (dx * dx + dy * dy) + dz * dz;
+            hit = d < bound;
+          }
+          const unsigned long long hb = __ballot(hit);
+          if (kFill && hit && o_ok) {
+            const long long at = o_found + add + (long long)__popcll(hb & ((1ull << lane) - 1ull));
+            if (at < o_cap) out_rec[o_out0 + at] = make_uint4(__float_as_uint(p.w), __float_as_uint(d), o_i, 0u);
+          }
+          add += (long long)__popcll(hb);
+        }
+        if (lane == owner) found += (int64_t)add;
+      }
     }
   }
   if (!kFill) counts[i] = found;
@@ -289,6 +340,10 @@ extern "C" pcgx_status pcgx_kdtree_range_count(const pcgx_kdtree *t, const float
   if (!t || nq < 0 || (nq > 0 && (!q || !counts))) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_count: bad argument");
   if (nq == 0) return PCGX_OK;
   PCGX_TRY(ensure_init());
+  if (nq <= xtree_host_walk_max() && !t->points.empty()) {  // a few points: the same walk on the host (knn_explicit.hip)
+    (void)xtree_host_range(t, q, nq, max_range, counts, nullptr, nullptr, nullptr);
+    return PCGX_OK;
+  }
   const pcgx_kdtree *outer = t;  // a handle with deletions walks the reference's patched tree (knn_explicit.hip)
   const bool patched = outer->n_deleted > 0;
   bool empty = false;
@@ -335,6 +390,13 @@ extern "C" pcgx_status pcgx_kdtree_range_fill(const pcgx_kdtree *t, const float 
   if (!ids || !dist_sq) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: NULL output");
   if (total > 0x7fffffffll) return fail(PCGX_E_TOO_LARGE, "pcgx_kdtree_range_fill: more than 2^31-1 neighbours in one batch");
   PCGX_TRY(ensure_init());
+  if (nq <= xtree_host_walk_max() && !t->points.empty()) {  // a few points: the same walk on the host (knn_explicit.hip)
+    for (int64_t i = 0; i < nq; i++)
+      if (offsets[i + 1] < offsets[i]) return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: offsets do not match the neighbour counts");
+    if (!xtree_host_range(t, q, nq, max_range, nullptr, offsets, ids, dist_sq))
+      return fail(PCGX_E_INVALID, "pcgx_kdtree_range_fill: offsets do not match the neighbour counts");
+    return PCGX_OK;
+  }
   const pcgx_kdtree *outer = t;
   const bool patched = outer->n_deleted > 0;
   bool empty = false;

@@ -1,0 +1,133 @@
+"""PointToPointICPGradient.Fit for small clouds: ONE persistent launch runs all iterations (csrc/icp_small.hip) --
+stackless reference-order walk with the tree's split values in LDS, the reference's sequential float32 sums as one
+wave's chain per sum, evaluate tail + pose update, two grid barriers per iteration.  Shapes: the reference's own
+benchmark (icp_test.go:100-142: ground grid with a box, MinDistSq = res^2: the approximate, visit-order dependent search),
+random clouds with the exact search, every weight form, ragged sizes, the errors.  Everything bit for bit the oracle's."""
+import numpy as np
+import pytest
+
+import oracle as O
+from pcgol_amd import _lib as L
+from pcgol_amd import icp, kdtree, synth
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _widen_the_one_launch_path():
+    """By default the one launch takes up to 2048 targets on a tree of up to 8191 points (where it is the faster path,
+    csrc/icp_small.hip); the tests run it at every size it is correct for.  (The knobs are read on first use.)"""
+    import os
+    os.environ["PCGX_ICP_SMALL_BASE"], os.environ["PCGX_ICP_SMALL_TARGET"] = "32767", "32768"
+    yield
+
+
+def _ground_box(n_pts):
+    """icp_test.go:104-123"""
+    width = int(np.sqrt(float(n_pts)))
+    res = f32(10.0) / f32(width)
+    i = np.arange(n_pts)
+    bx = (res * (i // width).astype(f32) - f32(5)).astype(f32)
+    by = (res * (i % width).astype(f32) - f32(5)).astype(f32)
+    bz = np.where((bx > -1) & (bx < 1) & (by > -1) & (by < 1), f32(1), f32(0)).astype(f32)
+    base = np.ascontiguousarray(np.stack([bx, by, bz], axis=1))
+    target = (base + np.array([0.5, 0.3, -0.2], f32)).astype(f32)
+    return base, target, float(res * res)
+
+
+def _same(trans, st, o):
+    assert st.NumIteration == o["num_iteration"]
+    assert np.array_equal(np.asarray(trans, f32).ravel(), np.asarray(o["trans"], f32).ravel())
+    assert f32(st.Evaluated.Value) == o["value"]
+    assert np.array_equal(np.asarray(st.Evaluated.Gradient, f32), o["gradient"])
+
+
+@pytest.mark.parametrize("n_pts", [1024, 4096, 16384])
+def test_the_reference_benchmark_shapes_fit_in_one_launch(n_pts):
+    base, target, mds = _ground_box(n_pts)
+    thr = np.full(6, -1.0, f32)
+    t = kdtree.New(base, MinDistSq=mds)
+    reg = icp.PointToPointICPGradient(icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=2.0), MinPairs=3),
+                                      icp.GradientDescentUpdaterFactory(Threshold=thr, MaxIteration=10))
+    o = O.icp_fit(O.KDTree(base, mds), target, 2.0, 3, None, thr, 10, sums_mode=0)
+    trans, st = reg.Fit(t, target)
+    _same(trans, st, o)
+    # a session stepped by hand is the same kernel, one iteration a launch
+    s = icp.IcpSession(t, target, 2.0, 3, None, thr, 10)
+    for _ in range(10):
+        s.step()
+    tr2, st2, _ = s.result()
+    _same(tr2, st2, o)
+    s.close()
+
+
+@pytest.mark.parametrize("nb,nt,width", [(5000, 3000, 3.0), (32767, 32768, 6.0), (1, 700, 1.0), (2, 1, 1.0), (777, 513, 2.0)])
+def test_small_random_clouds_exact_search(nb, nt, width):
+    c = synth.c4_icp(n=max(nb, nt), width=width)
+    base = np.ascontiguousarray(c["base"][:nb])
+    target = np.ascontiguousarray(c["target"][:nt])
+    w, th = np.full(6, 0.3, f32), np.full(6, -1.0, f32)
+    for min_pairs in (1, 6):
+        o = None
+        try:
+            o = O.icp_fit(O.KDTree(base), target, 0.5, min_pairs, w, th, 20, sums_mode=0)
+        except O.OracleError as e:
+            err = e
+        s = icp.IcpSession(kdtree.New(base), target, 0.5, min_pairs, w, th, 20)
+        for _ in range(20):
+            s.step()
+        if o is None:
+            with pytest.raises(L.PcgxError):
+                s.result()
+        else:
+            tr, st, _ = s.result()
+            _same(tr, st, o)
+        s.close()
+
+
+@pytest.mark.parametrize("wf", [icp.WeightConstant(0.7), icp.WeightInverse(0.01), icp.WeightHuber(0.002), icp.WeightTukey(0.01)],
+                         ids=["constant", "inverse", "huber", "tukey"])
+def test_small_clouds_with_the_built_in_weights(wf):
+    """evaluator.go:130: the ninth sum (the weights) is a chain of its own when the weight is not 1."""
+    c = synth.c4_icp(n=9000, width=2.1)
+    O.set_weight_fn(wf.kind, wf.a)
+    try:
+        s = icp.IcpSession(kdtree.New(c["base"]), c["target"], c["max_dist"], 6, c["weight"], c["threshold"], c["max_iteration"], WeightFn=wf)
+        for _ in range(c["max_iteration"]):
+            s.step()
+        tr, st, _ = s.result()
+        s.close()
+        o = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], 6, c["weight"], c["threshold"], c["max_iteration"], sums_mode=0)
+        _same(tr, st, o)
+        assert st.Evaluated.DistRMS == o["dist_rms"]
+    finally:
+        O.set_weight_fn(0, 0.0)
+
+
+def test_a_fit_that_converges_early_stops_inside_the_launch():
+    """Threshold > 0: the updater declares convergence (updater.go:45-54) and the remaining iterations of the launch do
+    nothing -- NumIteration is the reference's."""
+    c = synth.c4_icp(n=6000, width=1.8)
+    th = np.full(6, 0.02, f32)
+    reg = icp.PointToPointICPGradient(
+        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c["max_dist"]), MinPairs=c["min_pairs"]),
+        icp.GradientDescentUpdaterFactory(Weight=c["weight"], Threshold=th, MaxIteration=40))
+    trans, st = reg.Fit(kdtree.New(c["base"]), c["target"])
+    o = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], c["min_pairs"], c["weight"], th, 40, sums_mode=0)
+    assert o["num_iteration"] < 40
+    _same(trans, st, o)
+
+
+def test_a_deletion_sends_a_small_session_to_the_patched_tree():
+    c = synth.c4_icp(n=8000, width=2.0)
+    t = kdtree.New(c["base"])
+    s = icp.IcpSession(t, c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"], 6)
+    for _ in range(3):
+        s.step()
+    t.DeletePoints(np.arange(0, 8000, 7))
+    for _ in range(3):
+        s.step()
+    tr, st, _ = s.result()
+    assert st.NumIteration == 6 and np.all(np.isfinite(np.asarray(tr)))
+    s.close()

@@ -204,8 +204,10 @@ def test_range_with_a_run_of_a_hundred_thousand_exact_ties(monkeypatch):
     """One point taken 100 000 times (and a few more runs of 300): every neighbour of a query there is tied with all the
     others.  The grid path puts a run of ties into the walk's order afterwards; a slot that scans its run to find its
     place is quadratic in the run (ADVICE round 3 / VERDICT round 5: 1e10 steps here) -- runs beyond 128 slots are
-    ordered by sorting instead (csrc/range.hip).  Ids and DistSq are the reference walk's (PCGX_RANGE_WALK=1, itself
-    checked against the oracle above), and the call is quick."""
+    ordered by sorting instead, and a grid row of thousands of records is scanned by the whole wave (csrc/range.hip).
+    The grid is forced (PCGX_GRID=2: a cloud this crowded is normally left to the tree walk, where ONE lane visits the
+    hundred thousand nodes).  Ids and DistSq are the reference walk's (PCGX_RANGE_WALK=1, itself checked against the
+    oracle above), and the call is quick."""
     import time
     rng = np.random.default_rng(5)
     base = np.concatenate([synth.uniform_cloud(50_000, 10.0, 9),
@@ -213,6 +215,7 @@ def test_range_with_a_run_of_a_hundred_thousand_exact_ties(monkeypatch):
                            np.repeat(synth.uniform_cloud(40, 10.0, 10), 300, axis=0)]).astype(f32)
     base = np.ascontiguousarray(base[rng.permutation(len(base))])
     q = np.concatenate([np.array([[5.0, 5.0, 5.0], [5.01, 5.0, 4.99]], f32), synth.uniform_cloud(500, 10.0, 11)]).astype(f32)
+    monkeypatch.setenv("PCGX_GRID", "2")
     t = kdtree.New(base)
     t.RangeBatch(q, 0.3)
     t0 = time.perf_counter()
