@@ -267,7 +267,7 @@ def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, ic
 
         def worker(k):
             res[k] = reg.Fit(ctree, c4["target"])[0]
-        for rep in range(2):
+        for rep in range(3):   # (the first rounds grow the four contexts' workspaces; the last one is timed)
             th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
             t0 = time.perf_counter()
             for t in th:
@@ -707,6 +707,12 @@ def main():
             line["extra"] = side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, icp, hbm_gbs)
             # the second half of BASELINE.json's metric ("+ kNN queries/sec, 1M-pt cloud", config C2)
             line["knn_queries_per_s"] = line["extra"]["knn_c2_presort"]["mqueries_per_s"] * 1e6
+            c4c = line["extra"].get("icp_c4_concurrent4", {})
+            if "seconds_one_fit_alone" in c4c:
+                # what PointToPointICPGradient.Fit(base, target) (icp.go:23) costs a caller that holds host slices: the
+                # 12 MB target up, session set-up, twenty iterations, the result back -- PCIe included, never `value`
+                line["fit_host_pointer_ms"] = c4c["seconds_one_fit_alone"] * 1e3
+                line["four_fits_in_flight_ms"] = c4c["seconds_four_fits"] * 1e3
         if world == 1 and not args.no_cpu_baseline and args.workload == "c4":
             line["cpu_baseline"] = cpu_baseline(synth, base, tile, cfg)   # (C5: the oracle's tree build alone takes minutes)
         print(json.dumps(line), flush=True)

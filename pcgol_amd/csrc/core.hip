@@ -169,6 +169,11 @@ CallScope::~CallScope() {
 }
 
 static pcgx_status init_device(int device) {
+  // (HIP hands its streams to a few hardware queues, four by default: the library's own stream, its four pooled call
+  // contexts and the host's streams then share them, and kernels of independent calls queue up behind one another --
+  // four host-pointer Fits in flight: 4.6 ms with four queues, 4.0 with eight, tools/conc4_probe.py.  Only a wish: it
+  // counts if the runtime has not been initialised by the host already, and the host's own setting stands.)
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
   Global &g = glob();
   std::lock_guard<std::mutex> lk(g.init_mu);
   Context &c = g.slots[0];
@@ -190,7 +195,9 @@ static pcgx_status init_device(int device) {
   for (int k = 0; k <= kPoolSlots; k++) {
     Context &s = g.slots[k];
     s.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (k == 0 && g_private_queues) {
+    // (PCGX_POOL_QUEUES=1, measurement: the pooled contexts' streams with a hardware queue each too)
+    static const bool pool_queues = getenv("PCGX_POOL_QUEUES") && atoi(getenv("PCGX_POOL_QUEUES")) != 0;
+    if ((k == 0 && g_private_queues) || (k > 0 && pool_queues)) {
       // Slots that share ONE device (pcgx_init_devices on a test box): the library's own stream of every slot gets a
       // hardware queue to itself.  HIP hands its few hardware queues to streams as they have work, so two slots'
       // streams may land in one queue -- and the ring form of the sharded sums has slot A's kernel wait for slot B's:
@@ -293,12 +300,17 @@ pcgx_status Arena::begin(hipStream_t st) {
   last_stream_ = st;
   has_last_ = true;
   if (blocks_.size() > 1) {
+    // One block from the next call on.  The blocks go back to the block cache, not to hipFree: hipFree waits for the
+    // WHOLE device -- a context that grows its arena then stands still until every other context's Fit has drained
+    // (four host-pointer Fits in flight: 13 ms in a session's set-up, tools/conc4_probe.py).  What may still read the
+    // old blocks is this context's own earlier work: waited for here, on this stream alone.
+    PCGX_HIP_TRY(hipStreamSynchronize(st));
     size_t total = 0;
     for (auto &b : blocks_) total += b.cap;
     release_all();
     total = round_up(total + total / 4, 1 << 20);
     uint8_t *p = nullptr;
-    hipError_t e = hipMalloc((void **)&p, total);
+    hipError_t e = dev_cache_alloc((void **)&p, total);
     if (e != hipSuccess) return fail(PCGX_E_OOM, "arena hipMalloc(%zu) failed: %s", total, hipGetErrorString(e));
     blocks_.push_back(Block{p, total, 0});
   }
@@ -318,7 +330,7 @@ pcgx_status Arena::alloc(size_t bytes, void **out) {
   }
   size_t cap = round_up(bytes, 1 << 20);
   uint8_t *p = nullptr;
-  hipError_t e = hipMalloc((void **)&p, cap);
+  hipError_t e = dev_cache_alloc((void **)&p, cap);
   if (e != hipSuccess) return fail(PCGX_E_OOM, "arena hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
   blocks_.push_back(Block{p, cap, bytes});
   *out = p;
@@ -326,7 +338,7 @@ pcgx_status Arena::alloc(size_t bytes, void **out) {
 }
 
 void Arena::release_all() {
-  for (auto &b : blocks_) (void)hipFree(b.p);
+  for (auto &b : blocks_) dev_cache_free(b.p);
   blocks_.clear();
 }
 
@@ -550,8 +562,17 @@ extern "C" pcgx_status pcgx_dev_free(void *dptr) {
 // temporaries, and (in the measurement itself) output arrays allocated per call, whose first touch is a
 // page fault per 4 KB.  The ids are widened on the device now; these two are the copies, in one place.
 namespace pcgx {
+// (Large copies one at a time: the runtime pins the caller's pages for the transfer, and four threads doing that at once --
+// four host-pointer Fits in flight, 12 MB each -- stood in each other's way for up to 7.5 ms where one copy alone
+// takes 0.4: tools/conc4_probe.py with PCGX_FIT_TRACE.  The copies overlap with the other contexts' kernels all the same.)
 pcgx_status staged_upload(void *d_dst, const void *h_src, size_t bytes, hipStream_t st) {
-  if (bytes) PCGX_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+  static std::mutex big_copy;
+  if (bytes >= ((size_t)1 << 20)) {
+    std::lock_guard<std::mutex> lk(big_copy);
+    PCGX_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+  } else if (bytes) {
+    PCGX_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
+  }
   return PCGX_OK;
 }
 

@@ -655,6 +655,17 @@ struct pcgx_icp_session {
   bool spec_walk = true;     // the leftover walk is not launched behind a grid pass from a Fit's second Evaluate on (enqueue_corr)
   bool spec_pending = false; // ... and steps enqueued that way have not been looked at yet (settle())
   hipStream_t spec_stream = nullptr;  // ... on this stream (entry points without a stream argument settle there)
+  hipStream_t used[4] = {nullptr, nullptr, nullptr, nullptr};  // the streams work on this session's buffers was enqueued on
+  int n_used = 0;                                               // (5: more than four -- pcgx_icp_session_free waits for the device)
+  void touch(hipStream_t st) {
+    for (int k = 0; k < n_used && k < 4; k++)
+      if (used[k] == st) return;
+    // a stream the session has not been used on: the set-up (upload, order, gather: enqueued on used[0], not waited
+    // for) must be through before work there reads the session's buffers
+    if (n_used > 0) (void)hipStreamSynchronize(used[0]);
+    if (n_used < 4) used[n_used] = st;
+    n_used++;
+  }
   bool shard_failed = false; // this rank could not go on: it keeps calling the collectives with its flag up
   bool ring_fit_open = false; // pcgx_icp_fit_sharded has told the communicator that a Fit begins (comm_ring_new_fit: once per Fit)
   bool small = false;              // both clouds small: a step, or a whole Fit, is ONE launch (icp_small.hip); the target stays in the caller's order
@@ -723,6 +734,7 @@ static pcgx_status reset_state(pcgx_icp_session *s, hipStream_t st) {
 extern "C" pcgx_status pcgx_icp_session_reset(pcgx_icp_session *s, void *stream) {
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_reset: NULL session");
+  s->touch(pick_stream(stream));
   return reset_state(s, pick_stream(stream));
 }
 
@@ -731,6 +743,7 @@ extern "C" pcgx_status pcgx_icp_session_set_pose(pcgx_icp_session *s, const floa
   PCGX_API_LOCK();
   if (!s || !trans16 || iter < 0) return fail(PCGX_E_INVALID, "pcgx_icp_session_set_pose: bad argument");
   hipStream_t st = pick_stream(stream);
+  s->touch(st);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   IcpState h;
   memset(&h, 0, sizeof h);
@@ -747,6 +760,7 @@ extern "C" pcgx_status pcgx_icp_session_read_sums(pcgx_icp_session *s, double su
   if (!s || !sums10) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums: bad argument");
   if (s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums: plane session (30 sums): use pcgx_icp_session_read_sums_n");
   hipStream_t st = pick_stream(stream);
+  s->touch(st);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   PCGX_HIP_TRY(hipMemcpyAsync(sums10, s->d_sums, S_COUNT * sizeof(double), hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
@@ -776,6 +790,7 @@ extern "C" pcgx_status pcgx_icp_session_read_sums_n(pcgx_icp_session *s, double 
   PCGX_API_LOCK();
   if (!s || !sums || cap < s->n_sums()) return fail(PCGX_E_INVALID, "pcgx_icp_session_read_sums_n: bad argument");
   hipStream_t st = pick_stream(stream);
+  s->touch(st);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   PCGX_HIP_TRY(hipMemcpyAsync(sums, s->d_sums, (size_t)s->n_sums() * sizeof(double), hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));
@@ -786,9 +801,12 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   PCGX_API_LOCK();
   if (!s) return PCGX_OK;
   if (s->base) const_cast<pcgx_kdtree *>(s->base)->sessions.fetch_sub(1);
-  // the buffers go back to the block cache and may be handed out again at once: work the caller
-  // enqueued on its own streams must have finished with them (hipFree synchronised, too)
-  (void)hipDeviceSynchronize();
+  // the buffers go back to the block cache and may be handed out again at once: work enqueued on them must have
+  // finished -- on the streams this session was used on (a session knows them: every entry point names its stream),
+  // not on the whole device: that wait ended only when every OTHER context's Fit had drained too
+  if (s->n_used > 4) (void)hipDeviceSynchronize();
+  else
+    for (int k = 0; k < s->n_used; k++) (void)hipStreamSynchronize(s->used[k]);
   dev_cache_free(s->d_xyz);
   dev_cache_free(s->d_state);
   dev_cache_free(s->d_partials);
@@ -837,8 +855,13 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
   const bool patched = base->n_deleted > 0;
   if (patched && base->n_deleted >= base->n)
     return fail(PCGX_E_NOT_ENOUGH_PAIRS, "not enough correspondence pairs (every base point was deleted)");
+  static const bool trace = getenv("PCGX_FIT_TRACE") != nullptr;  // (where a session's set-up time goes, per phase)
+  auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t_phase[6] = {0, 0, 0, 0, 0, 0};
+  t_phase[0] = trace ? now_us() : 0.0;
   pcgx_icp_session *s = new pcgx_icp_session();
   s->base = base;
+  s->touch(st);
   s->patched = patched;
   const_cast<pcgx_kdtree *>(base)->sessions.fetch_add(1);
   s->nt = nt;
@@ -898,6 +921,7 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
     if ((e = hipStreamSynchronize(st)) != hipSuccess)
       return bail(fail(PCGX_E_HIP, "icp session setup failed: %s", hipGetErrorString(e)));
   }
+  t_phase[1] = trace ? now_us() : 0.0;  // buffers
   if ((rc = reset_state(s, st)) != PCGX_OK) return bail(rc);
   // no previous match yet: w = NaN (icp_corr_kernel takes pruning hints from match[] only when w >= 0)
   if ((e = hipMemsetAsync(s->d_match, 0xFF, (size_t)(nt ? nt : 1) * sizeof(float4), st)) != hipSuccess ||
@@ -912,8 +936,10 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
     if (!target_on_device) {
       float *stage = nullptr;
       if ((rc = ar.alloc_n((size_t)nt * 3, &stage)) != PCGX_OK) return bail(rc);
+      t_phase[2] = trace ? now_us() : 0.0;  // memsets, arena
       if ((rc = staged_upload(stage, target, (size_t)nt * 12, st)) != PCGX_OK) return bail(rc);
       d_q = stage;
+      t_phase[3] = trace ? now_us() : 0.0;  // upload enqueued (pageable memory: staged by the runtime)
     }
     // Small clouds (the reference's own benchmark shapes, icp_test.go:100-142): the whole step in one launch
     // (icp_small.hip), the target in the caller's order -- the sums run in that order, and at these sizes the
@@ -935,9 +961,17 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
     }
     hipLaunchKernelGGL(gather_soa_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d_q, perm, nt,
                        s->d_xyz, s->d_xyz + nt, s->d_xyz + 2 * nt, s->d_pos_of);
-    if ((e = hipStreamSynchronize(st)) != hipSuccess)
+    t_phase[4] = trace ? now_us() : 0.0;  // order + gather enqueued
+    // No wait here: what follows on this session is enqueued on this stream, behind the gather, or on another stream
+    // through an entry point that names it -- those wait for this one first (touch(): a session's first use on a stream
+    // that is not the one it was made on).  The host's twenty step enqueues (0.3 ms) used to start only when upload,
+    // order and gather had drained (0.25 ms of idle host and, behind it, idle GPU per host-pointer Fit).
+    if ((e = hipGetLastError()) != hipSuccess)
       return bail(fail(PCGX_E_HIP, "icp session setup failed: %s", hipGetErrorString(e)));
   }
+  if (trace)
+    fprintf(stderr, "pcgx session trace: buffers %.0f us, memsets + arena %.0f, upload %.0f, order + gather enqueued %.0f\n",
+            t_phase[1] - t_phase[0], t_phase[2] - t_phase[1], t_phase[3] - t_phase[2], t_phase[4] - t_phase[3]);
   *out = s;
   return PCGX_OK;
 }
@@ -1185,6 +1219,7 @@ extern "C" pcgx_status pcgx_icp_session_partials(pcgx_icp_session *s, void *stre
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_partials: NULL session");
   hipStream_t st = pick_stream(stream);
+  s->touch(st);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   PCGX_TRY(enqueue_corr(s, st));
   if (s->strict)
@@ -1203,6 +1238,7 @@ extern "C" pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_update: NULL session");
   hipStream_t st = pick_stream(stream);
+  s->touch(st);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   if (s->plane)
     hipLaunchKernelGGL(icp_update_kernel<true>, dim3(1), dim3(64), 0, st, s->d_state, s->d_sums, s->kp);
@@ -1230,6 +1266,7 @@ extern "C" pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream) 
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_step: NULL session");
   hipStream_t st = pick_stream(stream);
+  s->touch(st);
   if (small_now(s)) return small_steps(s, st, 1);
   PCGX_TRY(enqueue_corr(s, st, true));
   if (s->strict)
@@ -1256,6 +1293,7 @@ static pcgx_status step_sharded_impl(pcgx_icp_session *s, pcgx_comm *c, void *st
   int32_t rank = 0, world = 1;
   PCGX_TRY(pcgx_comm_rank(c, &rank, &world));
   hipStream_t st = pick_stream(stream);
+  s->touch(st);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   const int step = s->steps_sharded++;
   // the first sharded step since the session was made or reset: a Fit begins on the communicator -- whatever an earlier
@@ -1550,6 +1588,7 @@ extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream
   PCGX_API_LOCK();
   if (!s) return fail(PCGX_E_INVALID, "pcgx_icp_session_result: NULL session");
   hipStream_t st = pick_stream(stream);
+  s->touch(st);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   IcpState h;
   PCGX_HIP_TRY(hipMemcpyAsync(&h, s->d_state, sizeof h, hipMemcpyDeviceToHost, st));
@@ -1579,6 +1618,7 @@ extern "C" pcgx_status pcgx_icp_session_hessian(pcgx_icp_session *s, void *strea
   if (!s || !hessian36) return fail(PCGX_E_INVALID, "pcgx_icp_session_hessian: bad argument");
   if (!s->plane) return fail(PCGX_E_INVALID, "pcgx_icp_session_hessian: not a plane session (HasHessian() == false)");
   hipStream_t st = pick_stream(stream);
+  s->touch(st);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   IcpState h;
   PCGX_HIP_TRY(hipMemcpyAsync(&h, s->d_state, sizeof h, hipMemcpyDeviceToHost, st));
@@ -1615,16 +1655,26 @@ extern "C" pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target
       stat->num_iteration = 1;
     }
   }
+  // (PCGX_FIT_TRACE: where a host-pointer Fit's wall time goes, per thread -- tools/conc4_probe.py)
+  static const bool trace = getenv("PCGX_FIT_TRACE") != nullptr;
+  auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = trace ? now_us() : 0.0;
   pcgx_icp_session *s = nullptr;
   PCGX_TRY(pcgx_icp_session_create(base, target, nt, 0, params, nullptr, &s));
+  const double t1 = trace ? now_us() : 0.0;
   pcgx_status rc = PCGX_OK;
   // At most MaxIteration evaluations can happen (updater.go:69-70); once the
   // device-side state is `done` the remaining launches return immediately.
   if (small_now(s)) rc = small_steps(s, ctx().stream, s->max_iteration);  // (small clouds: the whole loop in one launch)
   else
     for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) rc = pcgx_icp_session_step(s, nullptr);
+  const double t2 = trace ? now_us() : 0.0;
   if (rc == PCGX_OK) rc = pcgx_icp_session_result(s, nullptr, trans16, stat, nullptr);
+  const double t3 = trace ? now_us() : 0.0;
   pcgx_icp_session_free(s);
+  if (trace)
+    fprintf(stderr, "pcgx fit trace: stream %p begin %.0f us: create %.0f, enqueue %.0f, result (wait) %.0f, free %.0f\n", (void *)ctx().stream,
+            fmod(t0, 1e8), t1 - t0, t2 - t1, t3 - t2, now_us() - t3);
   return rc;
 }
 
@@ -1688,6 +1738,7 @@ extern "C" pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stre
   out[1] = out[2] = out[3] = out[4] = out[5] = 0;
   if (s->patched || !grid_enabled(s->base) || s->kp.min_dist_sq > 0.0f || s->nt == 0) return PCGX_OK;
   hipStream_t st = pick_stream(stream);
+  s->touch(st);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   unsigned long long *d_trace = nullptr;
   PCGX_HIP_TRY(dev_cache_alloc((void **)&d_trace, 40 * sizeof(unsigned long long)));

@@ -11,10 +11,13 @@ tree = kdtree.New(c4["base"])
 reg.Fit(tree, c4["target"])
 t0 = time.perf_counter(); reg.Fit(tree, c4["target"]); one = time.perf_counter() - t0
 nthreads = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-for rep in range(2):
+reps = []
+for rep in range(8):
     th = [threading.Thread(target=lambda: reg.Fit(tree, c4["target"])) for _ in range(nthreads)]
     t0 = time.perf_counter()
     for t in th: t.start()
     for t in th: t.join()
     four = time.perf_counter() - t0
-print("one fit %.3f ms; %d at once %.3f ms (%.2f x one)" % (one * 1e3, nthreads, four * 1e3, four / one))
+    reps.append(four * 1e3)
+print("one fit %.3f ms; %d at once, round by round: %s ms; last %.3f (%.2f x one), best %.3f (%.2f x one)" % (
+    one * 1e3, nthreads, " ".join("%.2f" % r for r in reps), four * 1e3, four / one, min(reps), min(reps) / (one * 1e3)))
