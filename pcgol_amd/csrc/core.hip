@@ -170,10 +170,11 @@ CallScope::~CallScope() {
 
 static pcgx_status init_device(int device) {
   // (HIP hands its streams to a few hardware queues, four by default: the library's own stream, its four pooled call
-  // contexts and the host's streams then share them, and kernels of independent calls queue up behind one another --
-  // four host-pointer Fits in flight: 4.6 ms with four queues, 4.0 with eight, tools/conc4_probe.py.  Only a wish: it
-  // counts if the runtime has not been initialised by the host already, and the host's own setting stands.)
-  (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+  // contexts and the host's streams share them, and kernels of independent calls queue up behind one another -- four
+  // host-pointer Fits in flight: 4.6 ms with four queues, 4.0 with GPU_MAX_HW_QUEUES=8, tools/conc4_probe.py.  The host's
+  // to set, not the library's: with several PROCESSES on one GPU -- the sharded tests and rehearsals on the one-GPU box --
+  // more queues than the hardware has are time-sliced by the driver, and a kernel that waits for another process's
+  // kernel then waits for a time slice: a skewed three-rank Fit took 97 ms instead of 10 when this library asked for 8.)
   Global &g = glob();
   std::lock_guard<std::mutex> lk(g.init_mu);
   Context &c = g.slots[0];

@@ -1420,7 +1420,12 @@ struct ChainMail {  // walker <-> one helper
   uint32_t s_in, s_out;
 };
 
-template <bool kCheck>
+// kSpec (rows of several chunks, a target spread over ranks: the launches whose walkers WAIT for a start state): a
+// walker that has to wait walks ahead of the wait -- from the 256 states around the float64 guess of its start state, four
+// per lane, through the runs' compositions, point records and candidate tables -- and when the real state arrives and is one
+// of them, the chunk's end state is that candidate's: a hand-over then costs a hop (0.5 us), not a hop and a walk (6 us),
+// and the walks of all chunks and all ranks run side by side instead of one after the other (spec_walk below).
+template <bool kCheck, bool kSpec = false>
 __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 *__restrict__ match,
                                                                   const uint32_t *__restrict__ pos_of,
                                                                   IcpState *__restrict__ state, StrictWork W,
@@ -1787,6 +1792,183 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
     } else {
       // ---- the walk: one wave, every lane with the same state
       const long long t_b = stat_clock(W);
+      // ---- ahead of the wait (kSpec): the walk from the states around the guess
+      constexpr int kSpecPer = 4, kSpecStates = kSpecPer * kLanes;
+      uint32_t spec_s[kSpecPer] = {0u, 0u, 0u, 0u};  // lane l, k: where the walk from candidate 4 l + k ends
+      uint32_t spec_alive = 0u;                      // bit k: that candidate got through
+      uint32_t spec_g = 0u;                          // the guess: candidate kSpecStates / 2
+      bool spec_done = false;                        // uniform
+      // (... where it can pay: the walk ahead takes about three real walks' time -- four candidates a lane on the vector
+      // unit -- so a walker with up to three walks in front of it does better to wait for them: StrictWork::spec_depth, PCGX_STRICT_SPEC_DEPTH)
+      const int walks_before = (W.ring ? W.rank : 0) * W.nchunks + my_chunk;
+      if (kSpec && !kCheck && walks_before >= W.spec_depth) {  // uniform
+        bool here = false;  // the start state is there already: nothing to be ahead of
+        if (my_chunk > 0) {
+          const unsigned long long v = __hip_atomic_load(W.chunk_state + ((size_t)row * W.nchunks + my_chunk) * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          here = (uint32_t)rfl((int)(uint32_t)(v >> 32)) == W.epoch;
+        } else {
+          const RingLayout RL{W.world};
+          uint32_t v;
+          here = ring_peek(W.ring_mine + RL.start(row), W.ring_epoch, v);
+          here = rfl(here ? 1 : 0) != 0;
+        }
+        if (!here) {
+          // the state the row has in front of this chunk, as strict_job_kernel guesses a tile's: the float64 prefix of
+          // the tiles' sums and of their chains' rounding errors (+ the ranks before this one)
+          const double base = tile_prefix2(W.tile_sum, W.tile_err, W.ntiles, row, chunk, lane) +
+                              (W.row_base ? W.row_base[row] + W.err_base[row] : 0.0);
+          spec_g = (uint32_t)rfl((int)f2u((float)base));
+          if (W.selfcheck & 16) spec_g += 100000u;  // (tests, PCGX_TEST_SPEC_MISS: the state that comes is none of the candidates)
+          const uint32_t gm = spec_g & 0x7fffffffu;
+          if (gm > 4096u && gm < 0x7f000000u) {  // uniform (the candidates keep the guess's sign and stay finite)
+            spec_alive = (1u << kSpecPer) - 1u;
+#pragma unroll
+            for (int k = 0; k < kSpecPer; k++)
+              spec_s[k] = (spec_g & 0x80000000u) | (gm + (uint32_t)(kSpecPer * lane + k) - (uint32_t)(kSpecStates / 2));
+            int seg_base[kChainSegs + 1];
+            seg_base[0] = 0;
+#pragma unroll
+            for (int w = 0; w < kChainSegs; w++) seg_base[w + 1] = seg_base[w] + s_count[w];
+            const int n_runs = rfl(seg_base[kChainSegs]), n_runs_lo = rfl(seg_base[kChainSegs / 2]);
+            constexpr int kBatch = kLanes / 4;
+            const bool have_cand = !(W.selfcheck & 4);
+            // A job tile's candidate table: out of LDS where a helper has put it up (the first fourteen of the chunk are,
+            // before anything walks), else out of global memory, a load per lane -- this walk leaves the helpers where
+            // they are (they follow the REAL walk's progress word, and a real walk may still have to come).
+            auto from_table = [&](int ord, int tile_in_chunk, uint32_t g0, uint32_t &st) -> bool {  // per lane
+              if (!have_cand) return false;
+              const int32_t idx = (int32_t)((st & 0x7fffffffu) - (g0 & 0x7fffffffu)) + kCand / 2;
+              if (((st ^ g0) >> 31) != 0u || idx < 0 || idx >= kCand) return false;
+              uint32_t v;
+              if (lds_get(&s_tab_ord[ord % kTabSlots]) == ord + 1) {  // uniform
+                v = s_tab[ord % kTabSlots][idx];
+              } else {
+                const int slot = (s_rec[3][tile_in_chunk] >> 8) - 1;
+                v = W.cand[(size_t)slot * kCand + (size_t)idx];
+              }
+              if ((v & 0x7f800000u) == 0x7f800000u) return false;  // (NaN: no such candidate)
+              st = v;
+              return true;
+            };
+            bool overtaken = false;  // uniform: the state came while this walk was on its way -- the real walk is the shorter way now
+            for (int r0 = 0, r1 = 0; r0 < n_runs && __ballot(spec_alive != 0u) != 0ull; r0 = r1) {  // uniform
+              if (r0 > 0) {
+                bool arrived;
+                if (my_chunk > 0) {
+                  const unsigned long long v = __hip_atomic_load(W.chunk_state + ((size_t)row * W.nchunks + my_chunk) * 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  arrived = (uint32_t)rfl((int)(uint32_t)(v >> 32)) == W.epoch;
+                } else {
+                  const RingLayout RL{W.world};
+                  uint32_t v;
+                  arrived = rfl(ring_peek(W.ring_mine + RL.start(row), W.ring_epoch, v) ? 1 : 0) != 0;
+                }
+                if (arrived && n_runs - r0 > kBatch) {  // (with a batch or less to go the walk ahead is through sooner)
+                  overtaken = true;
+                  break;
+                }
+              }
+              const int half = r0 < n_runs_lo ? 0 : 1;
+              const int bound = half == 0 ? n_runs_lo : n_runs;
+              r1 = r0 + kBatch < bound ? r0 + kBatch : bound;
+              while (lds_get(&s_pre_cnt[half]) < kChainSegs / 2) __builtin_amdgcn_s_sleep(1);
+              const int my_run = r0 + (lane >> 2), my_class = lane & 3;
+              int e_l = 0, h_l = 0, j_l = -1;
+              int32_t key_l = -2, cons_l = 0, c_l = 0, lo_l = kBig, hi_l = -kBig, ord_l = -1;
+              uint32_t in_l = 0u, out_l = 0u;
+              if (my_run < r1) {
+                int idx = 0;
+#pragma unroll
+                for (int w = 0; w < kChainSegs; w++)
+                  if (my_run >= seg_base[w] && my_run < seg_base[w + 1]) idx = w * 64 + (my_run - seg_base[w]);
+                e_l = s_tail[idx];
+                h_l = s_head[idx];
+                key_l = s_pre[0][e_l];
+                in_l = (uint32_t)s_pre[1][e_l];
+                out_l = (uint32_t)s_pre[2][e_l];
+                cons_l = s_pre[3][e_l];
+                c_l = s_pre[4 + my_class][e_l];
+                lo_l = s_pre[8 + my_class][e_l];
+                hi_l = s_pre[12 + my_class][e_l];
+                if (h_l == e_l) ord_l = s_auxord[e_l];
+                const unsigned long long owners = ((unsigned long long)s_auxmask[h_l >> 6][1] << 32 | s_auxmask[h_l >> 6][0]) >> (h_l & 63);
+                const int len = e_l - h_l + 1;
+                const unsigned long long inside = len < 64 ? owners & ((1ull << len) - 1ull) : owners;
+                if (inside != 0ull) j_l = h_l + __builtin_ctzll(inside);
+              }
+              const int n_here = rfl(r1 - r0);
+              for (int j = 0; j < n_here && __ballot(spec_alive != 0u) != 0ull; j++) {  // uniform
+                const int l0 = 4 * j;
+                TileRec R;  // the run's composed record, the same in every lane
+                R.key = __builtin_amdgcn_readlane(key_l, l0);
+                R.in = (uint32_t)__builtin_amdgcn_readlane((int)in_l, l0);
+                R.out = (uint32_t)__builtin_amdgcn_readlane((int)out_l, l0);
+                R.cons = __builtin_amdgcn_readlane(cons_l, l0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                  R.s.c[q] = __builtin_amdgcn_readlane(c_l, l0 + q);
+                  R.s.lo[q] = __builtin_amdgcn_readlane(lo_l, l0 + q);
+                  R.s.hi[q] = __builtin_amdgcn_readlane(hi_l, l0 + q);
+                }
+                const int e = __builtin_amdgcn_readlane(e_l, l0), h = __builtin_amdgcn_readlane(h_l, l0);
+                uint32_t failed = 0u;
+#pragma unroll
+                for (int k = 0; k < kSpecPer; k++) {
+                  if (!((spec_alive >> k) & 1u)) continue;
+                  uint32_t st = spec_s[k];
+                  const bool ok = (R.key >= 0 && apply(st, R.key, R.s)) || apply_point(st, R);
+                  spec_s[k] = st;
+                  failed |= ok ? 0u : 1u << k;
+                }
+                if (__ballot(failed != 0u) != 0ull) {  // uniform: the slow ways, for the candidates that need them
+                  const int ord = __builtin_amdgcn_readlane(ord_l, l0), jt = __builtin_amdgcn_readlane(j_l, l0);
+                  if (ord >= 0) {  // a job tile on its own: its candidate table
+                    const uint32_t g0 = R.in;
+#pragma unroll
+                    for (int k = 0; k < kSpecPer; k++)
+                      if ((failed >> k) & 1u) {
+                        uint32_t st = spec_s[k];
+                        if (from_table(ord, e, g0, st)) {
+                          spec_s[k] = st;
+                          failed &= ~(1u << k);
+                        }
+                      }
+                  } else if (e > h && jt >= 0) {  // a run that fails at its first job tile: up to it, its table, the rest of the run
+                    const int ordj = rfl((int)s_auxord[jt]);
+                    TileRec P;
+                    P.key = -1;
+                    P.s = summary_identity();
+                    if (jt > h) P = load_rec_uniform(s_pre, jt - 1);
+                    const uint32_t g0 = (uint32_t)rfl(s_rec[1][jt]);
+                    TileRec Sf;
+                    Sf.key = -1;
+                    Sf.cons = 0;
+                    Sf.in = Sf.out = 0u;
+                    Sf.s = summary_identity();
+                    if (jt < e) {
+                      while (lds_get(&s_sufok[(jt + 1) >> 6]) == 0) __builtin_amdgcn_s_sleep(1);
+                      Sf = load_rec_uniform(s_suf, jt + 1);
+                    }
+#pragma unroll
+                    for (int k = 0; k < kSpecPer; k++)
+                      if ((failed >> k) & 1u) {
+                        uint32_t st = spec_s[k];
+                        bool ok = jt == h || (P.key >= 0 && apply(st, P.key, P.s));
+                        if (ok) ok = from_table(ordj, jt, g0, st);
+                        if (ok && jt < e) ok = (Sf.key >= 0 && apply(st, Sf.key, Sf.s)) || apply_point(st, Sf);
+                        if (ok) {
+                          spec_s[k] = st;
+                          failed &= ~(1u << k);
+                        }
+                      }
+                  }
+                  spec_alive &= ~failed;  // (whatever else a run may need -- its helper, the pairs -- is the real walk's)
+                }
+              }
+            }
+            spec_done = !overtaken;
+          }
+        }
+      }
       if (my_chunk > 0) {  // uniform
         // The state the chunk before this one ended in: ONE 64-bit word, bits | epoch, stored write-through by that
         // chunk's walker and read past the caches here (a word of an earlier launch carries an earlier epoch).  The wait
@@ -1846,12 +2028,38 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       // for a run that covers the state.  (A wave issues one instruction every four cycles, scalar ones included: with
       // a whole record per lane the sixteen v_readlane and the scalar selects behind them made a run ~80
       // instructions, 0.33 us, and a row's fifteen runs 5 of the 7.5 us its walk takes.)
+      // ---- (kSpec) the start state is here: one of the candidates?  Then the chunk's end state is that candidate's
+      bool spec_hit = false;  // uniform
+      if (kSpec && spec_done && ring_rc == 0) {
+        const int32_t off = (int32_t)((s & 0x7fffffffu) - (spec_g & 0x7fffffffu)) + kSpecStates / 2;
+        bool found = false;
+        if (((s ^ spec_g) >> 31) == 0u && off >= 0 && off < kSpecStates) {  // uniform
+          const int src = off / kSpecPer, k = off % kSpecPer;
+          const uint32_t alive_src = (uint32_t)__builtin_amdgcn_readlane((int)spec_alive, src);
+          uint32_t end = 0u;
+#pragma unroll
+          for (int q = 0; q < kSpecPer; q++) {
+            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)spec_s[q], src);
+            end = q == k ? v : end;
+          }
+          if ((alive_src >> k) & 1u) {
+            s = end;
+            found = true;
+          }
+        }
+        spec_hit = found;
+        if (lane == 0) {
+          atomicAdd(&W.dbg[10], 1ull);  // walks ahead of a wait, carried through
+          if (found) atomicAdd(&W.dbg[11], 1ull);  // ... whose candidates held the state that came
+          else if (!(((s ^ spec_g) >> 31) == 0u && off >= 0 && off < kSpecStates)) atomicAdd(&W.dbg[26], 1ull);  // ... the state lay outside them
+        }
+      }
       constexpr int kBatch = kLanes / 4;
       int seg_base[kChainSegs + 1];
       seg_base[0] = 0;
 #pragma unroll
       for (int w = 0; w < kChainSegs; w++) seg_base[w + 1] = seg_base[w] + s_count[w];
-      const int n_runs = rfl(seg_base[kChainSegs]), n_runs_lo = rfl(seg_base[kChainSegs / 2]);
+      const int n_runs = spec_hit ? 0 : rfl(seg_base[kChainSegs]), n_runs_lo = rfl(seg_base[kChainSegs / 2]);
       __builtin_amdgcn_s_setprio(3);
       for (int r0 = 0, r1 = 0; r0 < n_runs && ring_rc == 0; r0 = r1) {
         // (a batch stays inside one half of the segments: the first half's compositions are there first)
@@ -2303,8 +2511,9 @@ pcgx_status strict_create(int64_t nt, const float *tx, const float *ty, const fl
   W.ring_flag = nullptr;
   W.ntiles = nt > 0 ? (nt + kTile - 1) / kTile : 1;
   W.nrows = kStrictRows;
+  W.spec_depth = getenv("PCGX_STRICT_SPEC_DEPTH") ? atoi(getenv("PCGX_STRICT_SPEC_DEPTH")) : 4;
   W.selfcheck = (getenv("PCGX_STRICT_SELFCHECK") ? 1 : 0) | (getenv("PCGX_STRICT_TRACE") ? 2 : 0) |
-                (getenv("PCGX_STRICT_NOSPEC") ? 4 : 0) | (getenv("PCGX_STRICT_CLOCKS") ? 8 : 0);
+                (getenv("PCGX_STRICT_NOSPEC") ? 4 : 0) | (getenv("PCGX_STRICT_CLOCKS") ? 8 : 0) | (getenv("PCGX_TEST_SPEC_MISS") ? 16 : 0);
   // (4: the chain kernel ignores the candidate tables of tiles without a window; 8: tick columns of the debug counters)
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   const size_t sz_tile = up((size_t)kStrictRows * W.ntiles * sizeof(double));  // (twice: sums and errors)
@@ -2404,6 +2613,24 @@ static const StrictWork &next_epoch(StrictBuffers *b) {
   return b->w;
 }
 
+// (PCGX_STRICT_SPEC=0: no walk ahead of a wait -- measurement)
+static bool spec_enabled() {
+  static const bool on = !(getenv("PCGX_STRICT_SPEC") && atoi(getenv("PCGX_STRICT_SPEC")) == 0);
+  return on;
+}
+// the chain kernel of a step; spec: some walker of the launch waits for its start state (several chunks, a rank behind
+// another) -- the instantiation whose walkers walk ahead of that wait.  One chunk on one GPU: the kernel without that code.
+static void launch_chain(const StrictWork &W, const float4 *match, const uint32_t *pos_of, IcpState *state, double *sums10,
+                         const IcpKernelParams &kp, int fuse_update, bool waits, hipStream_t st) {
+  const dim3 grid((unsigned)(W.nrows * W.nchunks)), block(kChainBlock);
+  if (W.selfcheck & 1)
+    hipLaunchKernelGGL((strict_chain_kernel<true, false>), grid, block, 0, st, match, pos_of, state, W, sums10, kp, fuse_update);
+  else if (waits && spec_enabled())
+    hipLaunchKernelGGL((strict_chain_kernel<false, true>), grid, block, 0, st, match, pos_of, state, W, sums10, kp, fuse_update);
+  else
+    hipLaunchKernelGGL((strict_chain_kernel<false, false>), grid, block, 0, st, match, pos_of, state, W, sums10, kp, fuse_update);
+}
+
 pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t *pos_of, IcpState *state,
                            double *sums10, const IcpKernelParams &kp, bool fuse_update, bool have_tile_sums, bool first_iter,
                            hipStream_t st) {
@@ -2434,12 +2661,7 @@ pcgx_status strict_enqueue(StrictBuffers *b, const float4 *match, const uint32_t
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
-    if (W.selfcheck & 1)
-      hipLaunchKernelGGL(strict_chain_kernel<true>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
-                         sums10, kp, fuse_update ? 1 : 0);
-    else
-      hipLaunchKernelGGL(strict_chain_kernel<false>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
-                         sums10, kp, fuse_update ? 1 : 0);
+    launch_chain(W, match, pos_of, state, sums10, kp, fuse_update ? 1 : 0, W.nchunks > 1, st);
   }
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
@@ -2576,12 +2798,7 @@ pcgx_status strict_enqueue_sharded(StrictBuffers *b, const float4 *match, const 
     hipLaunchKernelGGL(strict_zero_kernel, dim3(1), dim3(64), 0, st, hop, 16, 0.0);
     if (k == rank && !local_failed) {
       ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
-      if (W.selfcheck & 1)
-        hipLaunchKernelGGL(strict_chain_kernel<true>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
-                           sums10, kp, 0);
-      else
-        hipLaunchKernelGGL(strict_chain_kernel<false>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
-                           sums10, kp, 0);
+      launch_chain(W, match, pos_of, state, sums10, kp, 0, W.nchunks > 1, st);
     }
     PCGX_TRY(exchange(hop, 16, 10));
     hipLaunchKernelGGL(strict_hop_kernel, dim3(1), dim3(64), 0, st, (const double *)hop, start_bits);
@@ -2693,12 +2910,7 @@ pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uin
   }
   {
     ProfScope prof(PCGX_PROF_STRICT_CHAIN, st);
-    if (W.selfcheck & 1)
-      hipLaunchKernelGGL(strict_chain_kernel<true>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
-                         sums10, kp, 1);
-    else
-      hipLaunchKernelGGL(strict_chain_kernel<false>, dim3((unsigned)(W.nrows * W.nchunks)), dim3(kChainBlock), 0, st, match, pos_of, state, W,
-                         sums10, kp, 1);
+    launch_chain(W, match, pos_of, state, sums10, kp, 1, true, st);
   }
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;

@@ -140,6 +140,7 @@ struct StrictWork {
   long long ring_guess_ticks; // bound (100 MHz ticks) of the waits for what only guesses depend on (RingView::guess_ticks)
   double *ring_base;          // device: [0..8] row_base, [16..24] err_base of this step, as fetched from the inbox
   unsigned int *ring_flag;    // device: == ring_epoch once tile 0 of strict_sum_kernel has put row_base up
+  int32_t spec_depth; // a walker with at least this many walks in front of it walks ahead of its wait (strict_chain_kernel<., kSpec>)
   int32_t selfcheck;  // bit 0: every step of the chain walk is re-derived term by term and compared (dbg[12..15]);
                       // 1: PCGX_STRICT_TRACE stamps; 2: no candidate tables; 3: wall-clock columns of the counters
 };

@@ -191,3 +191,41 @@ def test_c5_strict_sums_on_the_tile(c5, monkeypatch):
         assert not st[12:16].any() and st[6] == 0 and st[7] == 0, (k, st[:16])
     a.close()
     b.close()
+
+
+def test_c5_walks_ahead_of_the_chunks_hand_overs(c5, monkeypatch):
+    """Round 6: a chunk's walker that has to wait for its start state walks ahead of the wait, from the 256 states around
+    the float64 guess (csrc/strict.hip, strict_chain_kernel<., kSpec>): at C5's eight chunks per sum the seven later
+    chunks' walks run beside the first one's instead of behind it.  Counted (strict stats [10] walks carried through,
+    [11] whose candidates held the state that came), and the sums are the one-wave chain's.  With the guess pushed off
+    by 100 000 floats (PCGX_TEST_SPEC_MISS) every such walk MISSES, and the real walk runs behind it as it always
+    did (the walk ahead leaves the helper waves and their tables where they are): the same bits."""
+    base, tile, tree = c5
+    cfg = dict(MaxDist=0.5, MinPairs=6, Weight=np.full(6, 0.3, np.float32), Threshold=np.full(6, -1.0, np.float32),
+               MaxIteration=20)
+    b = icp.IcpSession(tree, tile, **cfg)
+    b.set_strict(2)
+    ref = []
+    for k in range(3):
+        b.step()
+        ref.append(b.read_sums().copy())
+    b.close()
+    for miss in (False, True):
+        if miss:
+            monkeypatch.setenv("PCGX_TEST_SPEC_MISS", "1")
+        a = icp.IcpSession(tree, tile, **cfg)
+        a.strict_stats()
+        walked, hit = 0, 0
+        for k in range(3):
+            a.step()
+            assert np.array_equal(a.read_sums().view(np.uint64), ref[k].view(np.uint64)), (miss, k)
+            st = a.strict_stats()
+            walked += int(st[10])
+            hit += int(st[11])
+            assert st[62] == 0
+        a.close()
+        if miss:
+            assert walked > 0 and hit == 0, (walked, hit)
+        else:
+            assert walked > 0 and hit >= 0.5 * walked, (walked, hit)   # (measured: 85 % of the walks at this size)
+    monkeypatch.delenv("PCGX_TEST_SPEC_MISS")
