@@ -1,5 +1,6 @@
 """GPU robustness: degenerate inputs must neither hang nor fault, and must not disturb the
 well-formed queries of the same batch."""
+import os
 import numpy as np
 import pytest
 
@@ -192,33 +193,44 @@ def test_four_host_pointer_fits_in_flight_do_not_stand_in_each_others_way():
     worse than one after the other: a session's release waited for the whole DEVICE, a context's growing workspace went
     through hipFree (the same wait), and four 12 MB uploads from pageable memory at once stalled each other for
     milliseconds.  Now: the results are identical and the four cost at most 3.2 x one (measured 2.1-2.5: the GPU side of
-    four Fits is 4 x 1.2 ms of mostly dependent launches)."""
-    import threading
-    import time
-    from pcgol_amd import icp, kdtree, synth
-    c4 = synth.c4_icp()
-    reg = icp.PointToPointICPGradient(
-        icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c4["max_dist"]), MinPairs=c4["min_pairs"]),
-        icp.GradientDescentUpdaterFactory(Weight=c4["weight"], Threshold=c4["threshold"], MaxIteration=c4["max_iteration"]))
-    tree = kdtree.New(c4["base"])
-    ref = reg.Fit(tree, c4["target"])[0]
-    ones = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        reg.Fit(tree, c4["target"])
-        ones.append(time.perf_counter() - t0)
-    res = [None] * 4
-
-    def worker(k):
-        res[k] = reg.Fit(tree, c4["target"])[0]
-    rounds = []
-    for rep in range(6):
-        th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
-        t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        rounds.append(time.perf_counter() - t0)
-        assert all(np.array_equal(ref, r) for r in res)
-    assert min(rounds[2:]) <= 3.2 * min(ones), (rounds, ones)
+    four Fits is 4 x 1.2 ms of mostly dependent launches).  In a process of its own: this one has made eight device
+    slots on the one GPU by now (test_gpu_multi.py), forty streams that share the hardware queues with the four."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import threading, time
+        import numpy as np
+        from pcgol_amd import icp, kdtree, synth
+        c4 = synth.c4_icp()
+        reg = icp.PointToPointICPGradient(
+            icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=c4["max_dist"]), MinPairs=c4["min_pairs"]),
+            icp.GradientDescentUpdaterFactory(Weight=c4["weight"], Threshold=c4["threshold"], MaxIteration=c4["max_iteration"]))
+        tree = kdtree.New(c4["base"])
+        ref = reg.Fit(tree, c4["target"])[0]
+        ones = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            reg.Fit(tree, c4["target"])
+            ones.append(time.perf_counter() - t0)
+        res = [None] * 4
+        def worker(k):
+            res[k] = reg.Fit(tree, c4["target"])[0]
+        rounds = []
+        for rep in range(6):
+            th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            rounds.append(time.perf_counter() - t0)
+            assert all(np.array_equal(ref, r) for r in res)
+        print("ratio %.3f" % (min(rounds[2:]) / min(ones)), rounds, ones)
+        assert min(rounds[2:]) <= 3.2 * min(ones), (rounds, ones)
+        print("conc ok")
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n" % root + code], cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "conc ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Round 6's evidence in one gpurun call (on ONE build): rocprofv3 trace + PMC passes of the bench command
+# (profiles/collect.sh), the bench line, the per-row timings (section 8 rows + the reference's own benchmarks), the C5
+# share's bench line, one hop of the ring through host memory / device memory of one process (ring_hop) and through
+# another PROCESS's device memory (ipc_hop), four Fits in flight (conc4_probe).  Summaries are copied under gpurun_out/
+# for the way back (gpurun merges gpurun_out/ only); the raw CSVs are dropped (tens of MB).
+TAG=${1:-r06a}
+mkdir -p gpurun_out
+bash profiles/collect.sh $TAG > gpurun_out/${TAG}_collect.log 2>&1
+echo collect rc=$?
+cp profiles/${TAG}_kernel_stats.csv profiles/${TAG}_pmc.json profiles/${TAG}_fetch_probe.json gpurun_out/ 2>/dev/null
+rm -rf gpurun_out/prof_$TAG
+timeout -k 10 600 python bench.py > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/${TAG}_bench_n1.err
+echo bench rc=$?
+timeout -k 10 900 python tests/perf_rows.py > gpurun_out/${TAG}_rows.json 2> gpurun_out/${TAG}_rows.err
+echo rows rc=$?
+timeout -k 10 600 python tests/perf_rows_ref.py >> gpurun_out/${TAG}_rows.json 2>> gpurun_out/${TAG}_rows.err
+echo rows_ref rc=$?
+timeout -k 10 600 python bench.py --workload c5 --steps 40 --warmup 20 > gpurun_out/${TAG}_bench_c5_n1.json 2> gpurun_out/${TAG}_bench_c5_n1.err
+echo c5 rc=$?
+{ timeout -k 5 120 tools/micro/ring_hop.bin; timeout -k 5 120 tools/micro/ipc_hop.bin; } > gpurun_out/${TAG}_ring_hop.txt 2>&1
+echo hop rc=$?
+timeout -k 10 200 python tools/conc4_probe.py 4 2>&1 | tail -1 > gpurun_out/${TAG}_conc4.txt
+echo conc4 rc=$?
+tail -3 gpurun_out/${TAG}_collect.log
