@@ -22,4 +22,11 @@ echo c5 rc=$?
 echo hop rc=$?
 timeout -k 10 200 python tools/conc4_probe.py 4 2>&1 | tail -1 > gpurun_out/${TAG}_conc4.txt
 echo conc4 rc=$?
+for mem in dev host; do
+  for n in 2 4 5; do
+    [ $mem = host ] && [ $n = 5 ] && continue
+    PCGX_RING_MEM=$mem PCGX_BENCH_REHEARSE=1 timeout -k 10 200 python bench.py --gpus $n --steps 100 --warmup 20 --points 125000 > gpurun_out/${TAG}_rehearse_${mem}_n${n}.json 2> gpurun_out/${TAG}_rehearse_${mem}_n${n}.err
+    echo "rehearsal $mem n=$n rc=$?"
+  done
+done
 tail -3 gpurun_out/${TAG}_collect.log
