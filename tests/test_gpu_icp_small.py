@@ -131,3 +131,36 @@ def test_a_deletion_sends_a_small_session_to_the_patched_tree():
     tr, st, _ = s.result()
     assert st.NumIteration == 6 and np.all(np.isfinite(np.asarray(tr)))
     s.close()
+
+
+def test_small_fit_with_targets_that_find_nothing_and_non_finite_ones():
+    """Targets outside MaxDist of everything: no pair for those (correspondence.go:27-29), the rest as ever -- the oracle's
+    bits; and a Fit whose pairs run out ends like the reference's (ErrNotEnoughPairs, evaluator.go:92-105).  (A NaN target
+    is another matter -- and so is an infinite one from the second iteration on, when the re-projection has made a NaN of
+    it: the reference PAIRS it -- a NaN DistSq is not greater than maxRange^2, kdtree.go:100 -- and its sums, pose and
+    every later iteration are NaN; the device paths, this one and the general one, leave such a target without a pair.
+    Not a parity case: INTEGRATION.md section 4.)"""
+    c = synth.c4_icp(n=3000, width=1.4)
+    target = c["target"].copy()
+    target[5] = [50.0, 50.0, 50.0]
+    target[40] = [-1e6, 3e5, 0.0]
+    target[900:950] += f32(30.0)
+    w, th = np.full(6, 0.3, f32), np.full(6, -1.0, f32)
+    s = icp.IcpSession(kdtree.New(c["base"]), target, 0.5, 6, w, th, 20)
+    for _ in range(20):
+        s.step()
+    tr, st, _ = s.result()
+    s.close()
+    o = O.icp_fit(O.KDTree(c["base"]), target, 0.5, 6, w, th, 20, sums_mode=0)
+    _same(tr, st, o)
+    # every target far away but a handful: fewer pairs than MinPairs from the first Evaluate on
+    far = (c["target"] + f32(40.0)).astype(f32)
+    far[:3] = c["target"][:3]
+    s = icp.IcpSession(kdtree.New(c["base"]), far, 0.5, 6, w, th, 20)
+    for _ in range(20):
+        s.step()
+    with pytest.raises(L.PcgxError):
+        s.result()
+    s.close()
+    with pytest.raises(O.OracleError):
+        O.icp_fit(O.KDTree(c["base"]), far, 0.5, 6, w, th, 20, sums_mode=0)

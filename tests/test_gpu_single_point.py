@@ -103,3 +103,49 @@ def test_a_single_point_call_costs_microseconds():
             fn(*a)
     per_call = (time.perf_counter() - t0) / 2000
     assert per_call < 10e-6, per_call   # (ctypes' own call overhead is ~1 us of it)
+
+
+def test_odd_single_point_queries_and_tiny_or_emptied_trees():
+    """NaN / inf / far-away queries, a radius of zero and a huge one, trees of one to three points, all points identical,
+    and a tree every point of which was deleted (root == nil: Nearest returns {-1, maxRange^2}, kdtree.go:84-86): the host
+    walk answers what the device's batch path answers (and the oracle, where it defines the case)."""
+    rng = np.random.default_rng(8)
+    base = synth.uniform_cloud(4000, 10.0, 61)
+    odd = np.array([[np.nan, 1, 1], [np.inf, 0, 0], [1e30, -1e30, 5], [5, 5, 5], [-3, 20, 0.5], [0, 0, 0]], f32)
+    fill = synth.uniform_cloud(40, 10.0, 62)
+    o_base = O.KDTree(base)
+    for maxr in (0.0, 1.0, 1e18):
+        t = kdtree.New(base)
+        ids_b, dsq_b = t.NearestBatch(np.concatenate([odd, fill]), maxr)      # 46 queries: the device
+        for i in range(len(odd)):
+            nb = t.Nearest(odd[i], maxr)                                       # one: the host
+            oi, od = o_base.nearest(odd[i], maxr)
+            # the oracle's answer, a NaN query's included: every comparison with NaN is false, the walk prunes nothing and
+            # the LAST leaf it reaches replaces the best (kdtree.go:100-103,138-139) -- id 727 here, DistSq NaN
+            assert nb.ID == oi and f32(nb.DistSq).tobytes() == f32(od).tobytes(), (maxr, i)
+            if np.isfinite(odd[i]).all():   # (the device's batch path promises nothing about WHICH id a NaN query gets)
+                assert nb.ID == ids_b[i] and f32(nb.DistSq).tobytes() == f32(dsq_b[i]).tobytes(), (maxr, i)
+        offs, ids, dsq = t.RangeBatch(np.concatenate([odd, fill]), min(maxr, 3.0))
+        for i in range(len(odd)):
+            nb = t.Range(odd[i], min(maxr, 3.0))
+            assert [n.ID for n in nb] == ids[offs[i]:offs[i + 1]].tolist(), (maxr, i)
+            oi, od = o_base.range(odd[i], min(maxr, 3.0))
+            assert [n.ID for n in nb] == list(oi), (maxr, i)
+    for n in (1, 2, 3):
+        t = kdtree.New(base[:n])
+        o = O.KDTree(base[:n])
+        for q in (odd[3], odd[4], base[0]):
+            nb = t.Nearest(q, 100.0)
+            oi, od = o.nearest(q, 100.0)
+            assert nb.ID == oi and f32(nb.DistSq) == od
+    same = np.tile(np.array([[1.5, -2.0, 0.25]], f32), (500, 1))
+    t, o = kdtree.New(same, MinDistSq=0.01), O.KDTree(same, min_dist_sq=0.01)
+    for q in (same[0], np.array([1.0, 1.0, 1.0], f32)):
+        nb = t.Nearest(q, 10.0)
+        oi, od = o.nearest(q, 10.0)
+        assert nb.ID == oi and f32(nb.DistSq) == od
+    t = kdtree.New(base[:5])
+    t.DeletePoints(np.arange(5))
+    nb = t.Nearest(base[0], 2.0)
+    assert nb.ID == -1 and f32(nb.DistSq) == f32(4.0)
+    assert t.Range(base[0], 2.0) == []
