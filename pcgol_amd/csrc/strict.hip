@@ -1301,6 +1301,9 @@ __device__ __forceinline__ void selfcheck(const StrictWork &W, MakeSrc make_src,
 // passes the tile without trouble the helper goes on to its next one.  Round 2's walker fetched a
 // tile's 14 KB itself, after the failure: ~2.5 of the ~3.5 us a recomputed tile cost were that fetch,
 // on the critical path of a launch that waits for its slowest sum.
+#ifndef PCGX_SPEC_PER
+#define PCGX_SPEC_PER 4
+#endif
 constexpr int kChainSegs = 8;                 // waves = segments of 64 tiles per chunk
 constexpr int kChainTiles = kChainSegs * 64;  // tiles per chunk
 constexpr int kChainBlock = kChainTiles;
@@ -1793,8 +1796,8 @@ __global__ __launch_bounds__(kChainBlock) void strict_chain_kernel(const float4 
       // ---- the walk: one wave, every lane with the same state
       const long long t_b = stat_clock(W);
       // ---- ahead of the wait (kSpec): the walk from the states around the guess
-      constexpr int kSpecPer = 4, kSpecStates = kSpecPer * kLanes;
-      uint32_t spec_s[kSpecPer] = {0u, 0u, 0u, 0u};  // lane l, k: where the walk from candidate 4 l + k ends
+      constexpr int kSpecPer = PCGX_SPEC_PER, kSpecStates = kSpecPer * kLanes;
+      uint32_t spec_s[kSpecPer] = {};  // lane l, k: where the walk from candidate 4 l + k ends
       uint32_t spec_alive = 0u;                      // bit k: that candidate got through
       uint32_t spec_g = 0u;                          // the guess: candidate kSpecStates / 2
       bool spec_done = false;                        // uniform
