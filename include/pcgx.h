@@ -476,8 +476,9 @@ PCGX_API pcgx_status pcgx_icp_session_step(pcgx_icp_session *s, void *stream);
  *      iteration; every rank owns an inbox of tagged 64-bit words that the other GPUs' kernels write and its own
  *      kernels poll -- in its OWN GPU's memory, mapped by the peers (hipIpcGetMemHandle / hipIpcOpenMemHandle between
  *      processes, hipDeviceEnablePeerAccess between the slots of one: a store over xGMI, a poll of local HBM; the
- *      handles ride on the same set-up all-reduce), or in the host-coherent block where a rank cannot export or map
- *      one (pcgx_debug_ring_kinds says which); the abort words stay in the host block, hosts write them.  Every rank's
+ *      handles ride on the same set-up all-reduce; the mappings are tried out with a round of tagged words before a
+ *      Fit depends on them), or in the host-coherent block where a rank cannot export or map one or the trial fails
+ *      (pcgx_debug_ring_kinds says which); the abort words stay in the host block, hosts write them.  Every rank's
  *      kernels are resident at once and only the walkers wait, each for
  *      one word from the rank before it (csrc/strict.hip, strict_enqueue_ring).  Elsewhere (ranks on several nodes,
  *      PCGX_SHARD_RING=0): 2 + world collectives of <= 16 x world doubles per iteration.  Same bits either way.

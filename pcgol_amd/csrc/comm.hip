@@ -193,6 +193,31 @@ void ring_setup(pcgx_comm *c) {
   c->ring_words = RL.words();
 }
 
+// The mapped inboxes tried out before a Fit depends on them: every rank stores a tagged word into the test slot it owns
+// in every peer's inbox (behind the layout's words) and waits -- bounded -- for every peer's word in its own.  What it
+// proves is what the ring needs: a store through the mapping is seen by the owner's poll, in both directions, between
+// these very devices.  (No box of this pipeline has two GPUs: the first node that does must not find out in the walkers'
+// ten-second wait.)
+__global__ __launch_bounds__(64) void ring_selftest_kernel(unsigned long long *const *tab, unsigned long long *mine, int world, int rank,
+                                                          int off, unsigned long long tag, long long max_ticks, int *ok) {
+  const int k = (int)threadIdx.x;
+  if (k < world && k != rank)
+    __hip_atomic_store(tab[k] + off + rank, tag | (unsigned long long)rank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  bool seen = !(k < world && k != rank);
+  long long t0 = 0;
+  for (int spins = 0; !seen; spins++) {
+    seen = __hip_atomic_load(mine + off + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == (tag | (unsigned long long)k);
+    if (!seen && (spins & 15) == 15) {
+      const long long now = (long long)wall_clock64();
+      if (t0 == 0) t0 = now;
+      if (now - t0 > max_ticks) break;  // (an exit every lane reaches)
+    }
+    if (!seen) __builtin_amdgcn_s_sleep(8);
+  }
+  const unsigned long long all = __ballot(seen);
+  if (threadIdx.x == 0) *ok = all == ~0ull ? 1 : 0;
+}
+
 // The data words' inboxes in device memory.  Collective: every rank of `c` calls it at the same point, behind the host
 // block (which keeps the abort words -- hosts write those -- and is where the data words stay if any rank fails here).
 // What the ranks tell each other rides on the communicator's own host all-reduce, a rank's record in its slot of a
@@ -212,7 +237,7 @@ void ring_setup_device(pcgx_comm *c) {
   const bool want_dev = !(knob && (knob[0] == 'h' || knob[0] == '0'));
   constexpr int kRec = 22;  // pid, device, address (2), ok, handle (16), PCI bus id
   std::vector<double> v((size_t)c->world * kRec, 0.0);
-  const size_t bytes = ((size_t)RL.words() * sizeof(unsigned long long) + 4095) & ~(size_t)4095;
+  const size_t bytes = (((size_t)RL.words() + 64) * sizeof(unsigned long long) + 4095) & ~(size_t)4095;  // (+ the self-test's slots)
   bool mine = want_dev && pcgx::ensure_init() == PCGX_OK;
   int device = -1;
   hipIpcMemHandle_t handle;
@@ -303,19 +328,49 @@ void ring_setup_device(pcgx_comm *c) {
   // every rank with every peer's inbox mapped, or nobody: a rank writing into host memory that its peer does not poll
   // would be a Fit that waits out its bound
   double bad = ok ? 0.0 : 1.0;
-  const bool agreed = pcgx_comm_allreduce_host_f64(c, &bad, 1) == PCGX_OK && bad == 0.0;
-  if (!agreed) {
+  bool agreed = pcgx_comm_allreduce_host_f64(c, &bad, 1) == PCGX_OK && bad == 0.0;
+  auto drop_device_inboxes = [&]() {
     for (void *p : c->ipc_open) (void)hipIpcCloseMemHandle(p);
     c->ipc_open.clear();
     if (c->inbox) (void)hipFree(c->inbox);
     c->inbox = nullptr;
     (void)hipGetLastError();
     host_table();
+  };
+  auto upload_table = [&]() -> bool {
+    if (!c->ring_tab && (pcgx::ensure_init() != PCGX_OK || hipMalloc((void **)&c->ring_tab, (size_t)c->world * sizeof(void *)) != hipSuccess)) return false;
+    return hipMemcpy(c->ring_tab, c->peers.data(), (size_t)c->world * sizeof(void *), hipMemcpyHostToDevice) == hipSuccess;
+  };
+  bool tab_ok = true;
+  if (!agreed) {
+    drop_device_inboxes();
+    tab_ok = upload_table();
   } else {
-    c->ring_kind = 2;
+    // the mappings tried out (ring_selftest_kernel): every rank or nobody again
+    tab_ok = upload_table();
+    int *d_ok = nullptr;
+    int h_ok = 0;
+    bool tried = tab_ok && c->world <= 64 && hipMalloc((void **)&d_ok, sizeof(int)) == hipSuccess && hipMemset(d_ok, 0, sizeof(int)) == hipSuccess;
+    if (tried) {
+      // (one value on every rank, whatever process or thread it lives in; the inboxes are fresh and zeroed: nothing stale to mistake for it)
+      const unsigned long long tag = 0x5e1f7e5700000100ull;
+      const bool forced_fail = getenv("PCGX_TEST_RING_SELFTEST_FAIL") != nullptr;  // (tests: the fall-back to host memory)
+      hipLaunchKernelGGL(ring_selftest_kernel, dim3(1), dim3(64), 0, pcgx::ctx().stream, (unsigned long long *const *)c->ring_tab, c->inbox, c->world,
+                         c->rank, (int)RL.words(), forced_fail && c->rank == c->world - 1 ? tag ^ 1ull << 40 : tag, (long long)50000000 /* 0.5 s */, d_ok);
+      // (the library's streams do not synchronise with the NULL stream: wait for the kernel by name)
+      tried = hipStreamSynchronize(pcgx::ctx().stream) == hipSuccess && hipMemcpy(&h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (d_ok) (void)hipFree(d_ok);
+    if (!tried) (void)hipGetLastError();
+    double failed = (tried && h_ok == 1) ? 0.0 : 1.0;
+    const bool all_ok = pcgx_comm_allreduce_host_f64(c, &failed, 1) == PCGX_OK && failed == 0.0;
+    if (all_ok) {
+      c->ring_kind = 2;
+    } else {
+      drop_device_inboxes();
+      tab_ok = upload_table();
+    }
   }
-  bool tab_ok = pcgx::ensure_init() == PCGX_OK && hipMalloc((void **)&c->ring_tab, (size_t)c->world * sizeof(void *)) == hipSuccess &&
-                hipMemcpy(c->ring_tab, c->peers.data(), (size_t)c->world * sizeof(void *), hipMemcpyHostToDevice) == hipSuccess;
   if (!tab_ok) {  // (no table, no ring: the collectives)
     (void)hipGetLastError();
     c->ring_kind = 0;

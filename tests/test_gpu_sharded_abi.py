@@ -67,7 +67,7 @@ def _ref_worker(rank, world, port, q, n):
 
 # (five ranks: the most the GPU box's process guard lets one test start beside the test process itself -- six
 # processes on the card; eight ranks run as eight device slots of one process, below and in test_gpu_multi.py)
-@pytest.mark.parametrize("ring", ["1", "host", "0"], ids=["ring", "ring-in-host-memory", "collectives"])
+@pytest.mark.parametrize("ring", ["1", "host", "selftest", "0"], ids=["ring", "ring-in-host-memory", "ring-whose-mappings-fail-their-test", "collectives"])
 @pytest.mark.parametrize("world,n", [(2, 200_000), (3, 200_000), (4, 200_000), (5, 250_000), (2, 1_000_000)],
                          ids=["2x200k", "3x200k", "4x200k", "5x250k", "2xC4"])
 def test_reference_sums_on_a_sharded_target_equal_the_oracle_bit_for_bit(world, n, ring, monkeypatch):
@@ -84,6 +84,10 @@ def test_reference_sums_on_a_sharded_target_equal_the_oracle_bit_for_bit(world, 
     monkeypatch.setenv("PCGX_SHARD_RING", "0" if ring == "0" else "1")   # (inherited by the spawned ranks)
     if ring == "host":
         monkeypatch.setenv("PCGX_RING_MEM", "host")
+    if ring == "selftest":
+        # the mapped inboxes are tried out before a Fit depends on them (csrc/comm.hip, ring_selftest_kernel): one rank's
+        # words made unrecognisable -> every rank's test fails (0.5 s) -> all of them fall back to the host-memory form
+        monkeypatch.setenv("PCGX_TEST_RING_SELFTEST_FAIL", "1")
     if ring != "1" and (world, n) != (3, 200_000):
         pytest.skip("the collective form and the ring in host memory: one shape is enough")
     ctx = mp.get_context("spawn")
@@ -106,7 +110,7 @@ def test_reference_sums_on_a_sharded_target_equal_the_oracle_bit_for_bit(world, 
         # every rank's 20 steps went the way asked for (a ring set-up that fell back would show in [3])
         assert r[5] == ([20, 0, 1, 0] if ring != "0" else [0, 20, 0, 1]), r[5]
     # ... and the inboxes were where the case says (counted by rank 0)
-    assert res[0][6] == {"1": [1, 0], "host": [0, 1], "0": [0, 0]}[ring], res[0][6]
+    assert res[0][6] == {"1": [1, 0], "host": [0, 1], "selftest": [0, 1], "0": [0, 0]}[ring], res[0][6]
 
 
 def _session_worker(rank, world, port, q, n, mode):
