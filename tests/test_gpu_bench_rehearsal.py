@@ -91,3 +91,19 @@ def test_bench_falls_back_when_rank_0_cannot_make_an_rccl_id():
     d = _run(cmd, env)
     assert d["n_gpus"] == 2 and "RCCL set-up failed" in d["config"]["exchange"]
     assert d["final_value"] == d["final_value"] and d["final_value"] < 1e-3 and d["value_f64_tree_one_gpu_alone"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_bench_takes_the_collectives_when_the_ring_breaks_in_the_warm_up():
+    """The ring between the ranks has never run on two GPUs in this pipeline: should the warm-up break it on any rank (here:
+    pretended, PCGX_BENCH_TEST_BREAK_RING), every rank goes on with the collective form of the same sums through a fresh
+    communicator, and the line says so -- a line with the slower exchange, not no line."""
+    env = dict(os.environ, PCGX_BENCH_REHEARSE="1", PCGX_BENCH_TEST_BREAK_RING="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4", "--points", "100000"]
+    d = _run(cmd, env)
+    assert d["n_gpus"] == 2 and "ring broke" in d["exchange_note"] and "all-reduces per step" in d["config"]["exchange"]
+    assert d["shard_stats"]["collective_steps"] > 0 and d["shard_stats"]["ring_steps"] == 0
+    assert d["final_value"] == d["final_value"] and d["final_value"] < 1e-3 and d["parity_mode"].startswith("reference")
