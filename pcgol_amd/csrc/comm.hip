@@ -237,7 +237,7 @@ void ring_setup_device(pcgx_comm *c) {
   const bool want_dev = !(knob && (knob[0] == 'h' || knob[0] == '0'));
   constexpr int kRec = 22;  // pid, device, address (2), ok, handle (16), PCI bus id
   std::vector<double> v((size_t)c->world * kRec, 0.0);
-  const size_t bytes = (((size_t)RL.words() + 64) * sizeof(unsigned long long) + 4095) & ~(size_t)4095;  // (+ the self-test's slots)
+  const size_t bytes = (((size_t)RL.words() + 128) * sizeof(unsigned long long) + 4095) & ~(size_t)4095;  // (+ the trial's slots and its verdict)
   bool mine = want_dev && pcgx::ensure_init() == PCGX_OK;
   int device = -1;
   hipIpcMemHandle_t handle;
@@ -256,6 +256,9 @@ void ring_setup_device(pcgx_comm *c) {
       }
     }
     if (mine) mine = hipMemset(c->inbox, 0, bytes) == hipSuccess && hipDeviceSynchronize() == hipSuccess;  // (tag 0: nobody's)
+    // (the table of the inboxes too, now: nothing is allocated or freed between the ranks' agreement and the trial below --
+    // an allocation call in one thread may wait for the device, on which another slot's trial kernel waits for this one's)
+    if (mine) mine = hipMalloc((void **)&c->ring_tab, (size_t)c->world * sizeof(void *)) == hipSuccess;
     if (mine) mine = hipIpcGetMemHandle(&handle, c->inbox) == hipSuccess;
     if (!mine) (void)hipGetLastError();
   }
@@ -337,9 +340,14 @@ void ring_setup_device(pcgx_comm *c) {
     (void)hipGetLastError();
     host_table();
   };
+  // (on the library's own stream, by name: a copy on the NULL stream waits for every blocking stream of the device -- the
+  // slots' streams with a hardware queue of their own are such -- and on one of those another slot's trial kernel may be
+  // waiting for THIS rank's word: eight slots of one process then stood in each other's way until a trial ran out of time)
   auto upload_table = [&]() -> bool {
     if (!c->ring_tab && (pcgx::ensure_init() != PCGX_OK || hipMalloc((void **)&c->ring_tab, (size_t)c->world * sizeof(void *)) != hipSuccess)) return false;
-    return hipMemcpy(c->ring_tab, c->peers.data(), (size_t)c->world * sizeof(void *), hipMemcpyHostToDevice) == hipSuccess;
+    hipStream_t st = pcgx::ctx().stream;
+    return hipMemcpyAsync(c->ring_tab, c->peers.data(), (size_t)c->world * sizeof(void *), hipMemcpyHostToDevice, st) == hipSuccess &&
+           hipStreamSynchronize(st) == hipSuccess;
   };
   bool tab_ok = true;
   if (!agreed) {
@@ -348,21 +356,21 @@ void ring_setup_device(pcgx_comm *c) {
   } else {
     // the mappings tried out (ring_selftest_kernel): every rank or nobody again
     tab_ok = upload_table();
-    int *d_ok = nullptr;
+    int *d_ok = reinterpret_cast<int *>(c->inbox + RL.words() + 64);  // (a word of the inbox's own block: zero since it was made)
     int h_ok = 0;
-    bool tried = tab_ok && c->world <= 64 && hipMalloc((void **)&d_ok, sizeof(int)) == hipSuccess && hipMemset(d_ok, 0, sizeof(int)) == hipSuccess;
+    bool tried = tab_ok && c->world <= 64;
     if (tried) {
       // (one value on every rank, whatever process or thread it lives in; the inboxes are fresh and zeroed: nothing stale to mistake for it)
       const unsigned long long tag = 0x5e1f7e5700000100ull;
       const bool forced_fail = getenv("PCGX_TEST_RING_SELFTEST_FAIL") != nullptr;  // (tests: the fall-back to host memory)
       hipLaunchKernelGGL(ring_selftest_kernel, dim3(1), dim3(64), 0, pcgx::ctx().stream, (unsigned long long *const *)c->ring_tab, c->inbox, c->world,
-                         c->rank, (int)RL.words(), forced_fail && c->rank == c->world - 1 ? tag ^ 1ull << 40 : tag, (long long)50000000 /* 0.5 s */, d_ok);
-      // (the library's streams do not synchronise with the NULL stream: wait for the kernel by name)
-      tried = hipStreamSynchronize(pcgx::ctx().stream) == hipSuccess && hipMemcpy(&h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+                         c->rank, (int)RL.words(), forced_fail && c->rank == c->world - 1 ? tag ^ 1ull << 40 : tag, (long long)200000000 /* 2 s */, d_ok);
+      tried = hipMemcpyAsync(&h_ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, pcgx::ctx().stream) == hipSuccess &&
+              hipStreamSynchronize(pcgx::ctx().stream) == hipSuccess;
     }
-    if (d_ok) (void)hipFree(d_ok);
     if (!tried) (void)hipGetLastError();
     double failed = (tried && h_ok == 1) ? 0.0 : 1.0;
+    if (getenv("PCGX_RING_TRACE")) fprintf(stderr, "pcgx ring set-up, rank %d: the inboxes' trial %s (launched and read back: %d)\n", c->rank, h_ok == 1 ? "passed" : "FAILED", tried ? 1 : 0);
     const bool all_ok = pcgx_comm_allreduce_host_f64(c, &failed, 1) == PCGX_OK && failed == 0.0;
     if (all_ok) {
       c->ring_kind = 2;
@@ -375,6 +383,9 @@ void ring_setup_device(pcgx_comm *c) {
     (void)hipGetLastError();
     c->ring_kind = 0;
   }
+  if (getenv("PCGX_RING_TRACE"))
+    fprintf(stderr, "pcgx ring set-up, rank %d of %d: inbox %s, every rank's %s, mapped %s, agreed %s -> kind %d\n", c->rank, c->world,
+            mine ? "made" : "not made", all ? "made" : "not all made", ok ? "yes" : "no", agreed ? "yes" : "no", c->ring_kind);
   if (c->rank == 0 && c->ring_kind > 0) g_ring_kinds[c->ring_kind == 2 ? 0 : 1]++;
 }
 

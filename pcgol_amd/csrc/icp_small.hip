@@ -35,7 +35,10 @@
 
 namespace pcgx {
 
-constexpr int kSmallBlock = 512;
+#ifndef PCGX_SMALL_BLOCK
+#define PCGX_SMALL_BLOCK 512
+#endif
+constexpr int kSmallBlock = PCGX_SMALL_BLOCK;
 constexpr long long kSmallBarrierTicks = 200000000;  // 2 s (s_memrealtime: 100 MHz)
 
 struct SmallSync {  // device words, zero between launches

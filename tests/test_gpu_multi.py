@@ -70,9 +70,14 @@ def test_fit_multi_reference_sums_equal_the_oracle(slots, ns, ring, monkeypatch)
     tiles = [np.ascontiguousarray(c["target"][cuts[r]:cuts[r + 1]]) for r in range(slots)]
     stats = np.zeros(4, np.int64)
     L.check(L.lib().pcgx_debug_shard_stats(L.ptr(stats), 1))
+    kinds = np.zeros(2, np.int64)
+    L.check(L.lib().pcgx_debug_ring_kinds(L.ptr(kinds), 1))
     rc, trans, st = _fit_multi(c, trees, tiles)
     L.check(rc)
     L.check(L.lib().pcgx_debug_shard_stats(L.ptr(stats), 1))
+    L.check(L.lib().pcgx_debug_ring_kinds(L.ptr(kinds), 1))
+    # the slots' inboxes: in device memory, one another's plain pointers (one process)
+    assert kinds.tolist() == ([1, 0] if ring == "1" else [0, 0]), kinds
     # every slot enqueued its 20 steps in the form asked for (one ring per Fit, in the process's pinned memory)
     assert (stats[0], stats[1], stats[2]) == ((20 * ns, 0, 1) if ring == "1" else (0, 20 * ns, 0)), stats
     o32 = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],

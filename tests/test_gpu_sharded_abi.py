@@ -300,6 +300,8 @@ def test_eight_slots_with_callback_communicators_share_a_ring():
                 barrier.abort()
         stats = np.zeros(4, np.int64)
         L.check(L.lib().pcgx_debug_shard_stats(L.ptr(stats), 1))
+        kinds = np.zeros(2, np.int64)
+        L.check(L.lib().pcgx_debug_ring_kinds(L.ptr(kinds), 1))   # (what earlier tests of this process made)
         th = [threading.Thread(target=rank_main, args=(r,)) for r in range(ns)]
         for t in th:
             t.start()
@@ -311,7 +313,6 @@ def test_eight_slots_with_callback_communicators_share_a_ring():
         # the callback carried the ring's set-up (the shared segment's name, the inboxes' addresses / IPC handles, the two
         # agreements) and the Fit's start-up flags, nothing per step
         assert max(calls) <= 6, calls
-        kinds = np.zeros(2, np.int64)
         L.check(L.lib().pcgx_debug_ring_kinds(L.ptr(kinds), 1))
         assert kinds[0] >= 1 and kinds[1] == 0, kinds   # the slots' inboxes are in device memory (one process: plain pointers)
         o32 = O.icp_fit(O.KDTree(c["base"]), c["target"], c["max_dist"], c["min_pairs"], c["weight"], c["threshold"],
