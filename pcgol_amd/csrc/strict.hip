@@ -2628,7 +2628,8 @@ static void launch_chain(const StrictWork &W, const float4 *match, const uint32_
   const dim3 grid((unsigned)(W.nrows * W.nchunks)), block(kChainBlock);
   if (W.selfcheck & 1)
     hipLaunchKernelGGL((strict_chain_kernel<true, false>), grid, block, 0, st, match, pos_of, state, W, sums10, kp, fuse_update);
-  else if (waits && spec_enabled())
+  else if (waits && spec_enabled() && (W.ring ? W.rank : 0) * W.nchunks + W.nchunks - 1 >= W.spec_depth)  // (some walker of THIS launch walks ahead:
+    // the instantiation with that code spills thirty scalar registers more, which the real walk pays for -- 0.7 us a step)
     hipLaunchKernelGGL((strict_chain_kernel<false, true>), grid, block, 0, st, match, pos_of, state, W, sums10, kp, fuse_update);
   else
     hipLaunchKernelGGL((strict_chain_kernel<false, false>), grid, block, 0, st, match, pos_of, state, W, sums10, kp, fuse_update);
