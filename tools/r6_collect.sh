@@ -4,7 +4,7 @@
 # share's bench line, one hop of the ring through host memory / device memory of one process (ring_hop) and through
 # another PROCESS's device memory (ipc_hop), four Fits in flight (conc4_probe).  Summaries are copied under gpurun_out/
 # for the way back (gpurun merges gpurun_out/ only); the raw CSVs are dropped (tens of MB).
-TAG=${1:-r06a}
+TAG=${1:-r06c}
 mkdir -p gpurun_out
 bash profiles/collect.sh $TAG > gpurun_out/${TAG}_collect.log 2>&1
 echo collect rc=$?
