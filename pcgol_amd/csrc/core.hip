@@ -221,6 +221,13 @@ static pcgx_status init_device(int device) {
       (void)hipGetLastError();
     }
     s.mailbox_seq = 0;
+    if (hipHostMalloc(&s.up, kSmallUploadBytes, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&s.up_read, hipEventDisableTiming) != hipSuccess) {  // (not required)
+      (void)hipGetLastError();
+      if (s.up) (void)hipHostFree(s.up);
+      s.up = nullptr;
+    }
+    s.up_pending = false;
     PCGX_HIP_TRY(hipMalloc((void **)&s.tickets, kTicketBytes));
     PCGX_HIP_TRY(hipMemset(s.tickets, 0, kTicketBytes));
     s.device = device;
@@ -439,6 +446,11 @@ static void shutdown_slot() {
     c.stream = nullptr;
     if (c.mailbox) (void)hipHostFree((void *)c.mailbox);
     c.mailbox = nullptr;
+    if (c.up) (void)hipHostFree(c.up);
+    c.up = nullptr;
+    if (c.up_read) (void)hipEventDestroy(c.up_read);
+    c.up_read = nullptr;
+    c.up_pending = false;
     if (c.tickets) (void)hipFree(c.tickets);
     c.tickets = nullptr;
     c.ready = false;
@@ -575,6 +587,29 @@ pcgx_status staged_upload(void *d_dst, const void *h_src, size_t bytes, hipStrea
     PCGX_HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st));
   }
   return PCGX_OK;
+}
+
+const void *small_upload(const void *h_src, size_t bytes) {
+  Context &c = ctx();
+  if (!c.up || bytes > kSmallUploadBytes) return nullptr;
+  if (c.up_pending) {
+    if (hipEventQuery(c.up_read) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    c.up_pending = false;
+  }
+  memcpy(c.up, h_src, bytes);
+  return c.up;
+}
+void small_upload_read(hipStream_t st) {
+  Context &c = ctx();
+  if (hipEventRecord(c.up_read, st) == hipSuccess) {
+    c.up_pending = true;
+  } else {  // (cannot tell when it is read: wait for it now)
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(st);
+  }
 }
 
 pcgx_status staged_download(void *h_dst, const void *d_src, size_t bytes, hipStream_t st) {

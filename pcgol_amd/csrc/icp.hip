@@ -668,7 +668,9 @@ struct pcgx_icp_session {
   }
   bool shard_failed = false; // this rank could not go on: it keeps calling the collectives with its flag up
   bool ring_fit_open = false; // pcgx_icp_fit_sharded has told the communicator that a Fit begins (comm_ring_new_fit: once per Fit)
+  bool general_ready = true;       // d_match / d_match_cert / d_first_leaf / d_walk_count hold their start values (a small session: at its first step outside the one launch)
   bool small = false;              // both clouds small: a step, or a whole Fit, is ONE launch (icp_small.hip); the target stays in the caller's order
+  int32_t *d_small_perm = nullptr; // ... its order of the targets (position -> caller's index; nullptr: the caller's order)
   void *d_small_sync = nullptr;    // ... that launch's barrier words (zero between launches)
   bool plane = false;              // point-to-plane / Gauss-Newton session (30 sums)
   uint32_t *d_match_id = nullptr;  // plane: [nt] matched base id
@@ -713,6 +715,20 @@ __global__ void icp_reset_kernel(IcpState *__restrict__ state) {
   const Mat4 id = mat4_translate(0.0f, 0.0f, 0.0f);
   for (int i = 0; i < 16; i++) h.trans[i] = id.m[i];
   *state = h;
+}
+
+// The general path's per-target arrays at their start values: no previous match yet (w = NaN: icp_corr_kernel takes pruning
+// hints from match[] only when w >= 0), no certificate, no first leaf, empty walk lists.  A session made for the one
+// launch (icp_small.hip) has not paid for this when it is made: four launches in front of a 0.16 ms Fit.
+static pcgx_status general_prepare(pcgx_icp_session *s, hipStream_t st) {
+  if (s->general_ready) return PCGX_OK;
+  const size_t n1 = (size_t)(s->nt ? s->nt : 1);
+  PCGX_HIP_TRY(hipMemsetAsync(s->d_match, 0xFF, n1 * sizeof(float4), st));
+  PCGX_HIP_TRY(hipMemsetAsync(s->d_match_cert, 0, n1 * sizeof(float), st));
+  PCGX_HIP_TRY(hipMemsetAsync(s->d_first_leaf, 0, n1 * sizeof(uint32_t), st));
+  PCGX_HIP_TRY(hipMemsetAsync(s->d_walk_count, 0, (size_t)s->grid * sizeof(uint32_t), st));
+  s->general_ready = true;
+  return PCGX_OK;
 }
 
 static pcgx_status reset_state(pcgx_icp_session *s, hipStream_t st) {
@@ -826,6 +842,7 @@ extern "C" pcgx_status pcgx_icp_session_free(pcgx_icp_session *s) {
   if (s->own_sums) dev_cache_free(s->d_sums);
   dev_cache_free(s->d_xchg);
   dev_cache_free(s->d_small_sync);
+  dev_cache_free(s->d_small_perm);
   delete s;
   return PCGX_OK;
 }
@@ -922,18 +939,33 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
       return bail(fail(PCGX_E_HIP, "icp session setup failed: %s", hipGetErrorString(e)));
   }
   t_phase[1] = trace ? now_us() : 0.0;  // buffers
-  if ((rc = reset_state(s, st)) != PCGX_OK) return bail(rc);
-  // no previous match yet: w = NaN (icp_corr_kernel takes pruning hints from match[] only when w >= 0)
-  if ((e = hipMemsetAsync(s->d_match, 0xFF, (size_t)(nt ? nt : 1) * sizeof(float4), st)) != hipSuccess ||
-      (e = hipMemsetAsync(s->d_match_cert, 0, (size_t)(nt ? nt : 1) * sizeof(float), st)) != hipSuccess ||
-      (e = hipMemsetAsync(s->d_first_leaf, 0, (size_t)(nt ? nt : 1) * sizeof(uint32_t), st)) != hipSuccess ||
-      (e = hipMemsetAsync(s->d_walk_count, 0, (size_t)s->grid * sizeof(uint32_t), st)) != hipSuccess)
-    return bail(fail(PCGX_E_HIP, "icp session: hipMemsetAsync failed: %s", hipGetErrorString(e)));
+  // Small clouds (the reference's own benchmark shapes, icp_test.go:100-142): the whole Fit in one launch
+  // (icp_small.hip), the target in the caller's order -- the sums run in that order.  Such a session's start values,
+  // its words' zeroes and its target's coordinates are ONE launch's work (small_prepare_kernel) behind the upload: a
+  // host-pointer Fit is then upload, that launch, the Fit's, the result -- it was ten operations on the stream, 5 us apart.
+  static const bool small_on = icp_knob("PCGX_ICP_SMALL", 1, 0, 1) != 0;
+  s->small = small_on && nt > 0 && !s->plane && !patched && s->strict == 1 && !base->has_nan && small_fit_eligible(base->view(), nt, base->many_ties);
+  if (s->small) {
+    s->general_ready = false;
+    s->host_iter = 0;
+  } else {
+    if ((rc = reset_state(s, st)) != PCGX_OK) return bail(rc);
+    s->general_ready = false;
+    if ((rc = general_prepare(s, st)) != PCGX_OK) return bail(rc);
+  }
   if (nt > 0) {
     Arena &ar = ctx().arena;
     if ((rc = ar.begin(st)) != PCGX_OK) return bail(rc);
     const float *d_q = target;
-    if (!target_on_device) {
+    bool from_pinned = false;
+    if (!target_on_device && s->small) {  // (a small target: read by small_prepare_kernel out of the context's pinned memory)
+      if (const void *up = small_upload(target, (size_t)nt * 12)) {
+        d_q = static_cast<const float *>(up);
+        from_pinned = true;
+        t_phase[2] = t_phase[3] = trace ? now_us() : 0.0;
+      }
+    }
+    if (!target_on_device && !from_pinned) {
       float *stage = nullptr;
       if ((rc = ar.alloc_n((size_t)nt * 3, &stage)) != PCGX_OK) return bail(rc);
       t_phase[2] = trace ? now_us() : 0.0;  // memsets, arena
@@ -941,26 +973,27 @@ static pcgx_status session_create(const pcgx_kdtree *base, const float *normals,
       d_q = stage;
       t_phase[3] = trace ? now_us() : 0.0;  // upload enqueued (pageable memory: staged by the runtime)
     }
-    // Small clouds (the reference's own benchmark shapes, icp_test.go:100-142): the whole step in one launch
-    // (icp_small.hip), the target in the caller's order -- the sums run in that order, and at these sizes the
-    // tree's working set is in LDS and L2 whatever order the lanes' queries come in.
-    static const bool small_on = icp_knob("PCGX_ICP_SMALL", 1, 0, 1) != 0;
-    s->small = small_on && !s->plane && !patched && s->strict == 1 && small_fit_eligible(base->view(), nt);
     if (s->small) {
       s->nt_pad = (nt + 63) & ~(int64_t)63;
-      if ((e = dev_cache_alloc((void **)&s->d_terms, 9 * (size_t)s->nt_pad * sizeof(float))) != hipSuccess ||
+      if ((e = dev_cache_alloc((void **)&s->d_terms, small_fit_terms_bytes(nt))) != hipSuccess ||
           (e = dev_cache_alloc((void **)&s->d_valid, (size_t)(s->nt_pad / 64) * sizeof(unsigned long long))) != hipSuccess ||
-          (e = dev_cache_alloc(&s->d_small_sync, small_fit_sync_bytes())) != hipSuccess ||
-          (e = hipMemsetAsync(s->d_small_sync, 0, small_fit_sync_bytes(), st)) != hipSuccess)
+          (e = dev_cache_alloc(&s->d_small_sync, small_fit_sync_bytes())) != hipSuccess)
         return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
+      if (small_fit_wants_order(nt) && (e = dev_cache_alloc((void **)&s->d_small_perm, (size_t)nt * sizeof(int32_t))) != hipSuccess)
+        return bail(fail(PCGX_E_OOM, "icp session allocation failed: %s", hipGetErrorString(e)));
+      if ((rc = small_fit_prepare(d_q, nt, base->bbox_lo, base->bbox_hi, s->d_small_perm, s->d_xyz, s->d_pos_of, s->d_state, s->d_terms,
+                                  s->d_small_sync, st)) != PCGX_OK)
+        return bail(rc);
+      if (from_pinned) small_upload_read(st);
     }
     int32_t *perm = nullptr;
     if (nt > 1 && !s->small) {
       if ((rc = ar.alloc_n((size_t)nt, &perm)) != PCGX_OK) return bail(rc);
       if ((rc = morton_order(d_q, nt, base->bbox_lo, base->bbox_hi, perm, st)) != PCGX_OK) return bail(rc);
     }
-    hipLaunchKernelGGL(gather_soa_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d_q, perm, nt,
-                       s->d_xyz, s->d_xyz + nt, s->d_xyz + 2 * nt, s->d_pos_of);
+    if (!s->small)
+      hipLaunchKernelGGL(gather_soa_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, d_q, perm, nt,
+                         s->d_xyz, s->d_xyz + nt, s->d_xyz + 2 * nt, s->d_pos_of);
     t_phase[4] = trace ? now_us() : 0.0;  // order + gather enqueued
     // No wait here: what follows on this session is enqueued on this stream, behind the gather, or on another stream
     // through an entry point that names it -- those wait for this one first (touch(): a session's first use on a stream
@@ -1038,6 +1071,7 @@ static pcgx_status enqueue_corr(pcgx_icp_session *s, hipStream_t st, bool may_sp
   // a deletion made after the session was created: from now on the reference's patched tree is walked
   // (the same handle's Nearest / Range already do), without hints from earlier iterations
   if (!s->patched && s->base->n_deleted > 0) s->patched = true;
+  PCGX_TRY(general_prepare(s, st));
   const bool caller_had_pairs = s->caller_order_fresh;  // the pass before this one left every pair in the caller's order too
   s->caller_order_fresh = false;
   s->tile_sums_fresh = false;
@@ -1251,14 +1285,25 @@ extern "C" pcgx_status pcgx_icp_session_update(pcgx_icp_session *s, void *stream
 // A small session's steps in one launch (icp_small.hip) -- while it is what it was made as: the reference's sums, the
 // canonical tree (a deletion since sends the session to the patched tree's walk, enqueue_corr)
 static bool small_now(const pcgx_icp_session *s) {
-  return s->small && s->strict == 1 && !s->plane && !s->patched && s->base->n_deleted == 0 && !s->spec_pending;
+  return s->small && s->strict == 1 && !s->plane && !s->patched && s->base->n_deleted == 0 && !s->spec_pending &&
+         !(s->kp.max_dist_sq < s->kp.min_dist_sq);  // (maxRange^2 < MinDistSq: the walk ends at its first leaf, kdtree.go:100-106)
 }
-static pcgx_status small_steps(pcgx_icp_session *s, hipStream_t st, int iters) {
+static pcgx_status small_steps(pcgx_icp_session *s, hipStream_t st, int iters, uint32_t *mail_seq = nullptr) {
   s->caller_order_fresh = false;
   s->tile_sums_fresh = false;
   s->host_iter += iters;
-  return small_fit_enqueue(s->base->view(), s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, s->nt, s->d_state, s->kp, s->d_terms,
-                           s->d_valid, s->d_sums, s->d_small_sync, iters, st);
+  static std::atomic<uint32_t> launches{0};  // (one count for the process: a block of the cache keeps its last session's words)
+  while (iters > 0) {
+    const int now = iters < small_fit_max_iters() ? iters : small_fit_max_iters();
+    // (mail_seq: the launch that ends the Fit leaves the loop state in the context's mailbox -- pcgx_icp_fit)
+    const bool mail = mail_seq != nullptr && iters == now && ctx().mailbox != nullptr;
+    if (mail) *mail_seq = mailbox_next_seq();
+    PCGX_TRY(small_fit_enqueue(s->base->view(), s->d_xyz, s->d_xyz + s->nt, s->d_xyz + 2 * s->nt, s->nt, s->d_state, s->kp, s->d_terms,
+                               s->d_valid, s->d_sums, s->d_small_sync, ++launches, now, s->d_small_perm, st, mail ? ctx().mailbox : nullptr,
+                               mail ? *mail_seq : 0u));
+    iters -= now;
+  }
+  return PCGX_OK;
 }
 
 // partials + update with no exchange in between (single GPU): two launches per iteration.
@@ -1583,6 +1628,8 @@ extern "C" pcgx_status pcgx_icp_fit_multi(int32_t n, const pcgx_kdtree *const *b
   return PCGX_OK;
 }
 
+static pcgx_status result_of(const pcgx_icp_session *s, const IcpState &h, float trans16[16], pcgx_icp_stat *stat, int32_t *converged);
+
 extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream, float trans16[16],
                                                pcgx_icp_stat *stat, int32_t *converged) {
   PCGX_API_LOCK();
@@ -1591,8 +1638,11 @@ extern "C" pcgx_status pcgx_icp_session_result(pcgx_icp_session *s, void *stream
   s->touch(st);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
   IcpState h;
-  PCGX_HIP_TRY(hipMemcpyAsync(&h, s->d_state, sizeof h, hipMemcpyDeviceToHost, st));
-  PCGX_HIP_TRY(hipStreamSynchronize(st));
+  PCGX_TRY(read_back_small(s->d_state, sizeof h, &h, st));  // (the stream is not waited for: a word from behind its last kernel is)
+  return result_of(s, h, trans16, stat, converged);
+}
+
+static pcgx_status result_of(const pcgx_icp_session *s, const IcpState &h, float trans16[16], pcgx_icp_stat *stat, int32_t *converged) {
   if (trans16) memcpy(trans16, h.trans, sizeof h.trans);
   if (stat) {
     stat->evaluated.value = h.ev.value;
@@ -1665,11 +1715,18 @@ extern "C" pcgx_status pcgx_icp_fit(const pcgx_kdtree *base, const float *target
   pcgx_status rc = PCGX_OK;
   // At most MaxIteration evaluations can happen (updater.go:69-70); once the
   // device-side state is `done` the remaining launches return immediately.
-  if (small_now(s)) rc = small_steps(s, ctx().stream, s->max_iteration);  // (small clouds: the whole loop in one launch)
+  uint32_t mail_seq = 0u;
+  if (small_now(s) && s->max_iteration >= 1) rc = small_steps(s, ctx().stream, s->max_iteration, &mail_seq);  // (small clouds: the whole loop in one launch)
   else
     for (int it = 0; it < s->max_iteration && rc == PCGX_OK; it++) rc = pcgx_icp_session_step(s, nullptr);
   const double t2 = trace ? now_us() : 0.0;
-  if (rc == PCGX_OK) rc = pcgx_icp_session_result(s, nullptr, trans16, stat, nullptr);
+  if (rc == PCGX_OK && mail_seq != 0u) {  // (the launch mails the loop state itself)
+    IcpState h;
+    rc = mailbox_wait_tagged(mail_seq, (int)(sizeof h / 4), reinterpret_cast<uint32_t *>(&h), ctx().stream);
+    if (rc == PCGX_OK) rc = result_of(s, h, trans16, stat, nullptr);
+  } else if (rc == PCGX_OK) {
+    rc = pcgx_icp_session_result(s, nullptr, trans16, stat, nullptr);
+  }
   const double t3 = trace ? now_us() : 0.0;
   pcgx_icp_session_free(s);
   if (trace)
@@ -1740,6 +1797,7 @@ extern "C" pcgx_status pcgx_debug_icp_grid_stats(pcgx_icp_session *s, void *stre
   hipStream_t st = pick_stream(stream);
   s->touch(st);
   PCGX_TRY(settle(s, st));  // (steps enqueued without the leftover walk: enqueue_corr)
+  PCGX_TRY(general_prepare(s, st));
   unsigned long long *d_trace = nullptr;
   PCGX_HIP_TRY(dev_cache_alloc((void **)&d_trace, 40 * sizeof(unsigned long long)));
   PCGX_HIP_TRY(hipMemsetAsync(d_trace, 0, 40 * sizeof(unsigned long long), st));

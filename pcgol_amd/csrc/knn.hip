@@ -1,5 +1,6 @@
 // knn.hip -- batched KDTree.Nearest on gfx950 + the pcgx_kdtree_* C ABI.
 // Reference: pc/storage/kdtree/kdtree.go (New :33-56, Nearest :83-146).
+#include <algorithm>
 #include <stdlib.h>
 #include <string.h>
 
@@ -340,6 +341,21 @@ static pcgx_status build_tree(const void *data, int64_t n, int32_t stride, int32
     blo[0] = l0; blo[1] = l1; blo[2] = l2;
     bhi[0] = h0; bhi[1] = h1; bhi[2] = h2;
     has_nan = nan_count != 0;
+    t->has_nan = has_nan;
+    // Do coordinates repeat?  (up to 1024 points, evenly spaced: of each axis' values, how many are different.)  A walk of
+    // the reference's kind rules a sub-tree out by its distance from a split plane; where the points of both sides lie ON
+    // the plane -- a ground plane's z, a lattice's columns -- it rules out nothing, and a 16384-point Fit's walks are ten
+    // times a random cloud's.  The one-launch Fit (icp_small.hip) takes such clouds up to sizes where it would not pay else.
+    if (n >= 64 && n <= 65535 && !has_nan) {
+      const int64_t m = n < 1024 ? n : 1024, step = n / m;
+      std::vector<float> v((size_t)m);
+      for (int k = 0; k < 3 && !t->many_ties; k++) {
+        for (int64_t j = 0; j < m; j++) v[(size_t)j] = pp[3 * (j * step) + k];
+        std::sort(v.begin(), v.end());
+        const int64_t distinct = (int64_t)(std::unique(v.begin(), v.end()) - v.begin());
+        if (2 * distinct <= m) t->many_ties = true;
+      }
+    }
     for (int k = 0; k < 3; k++) { t->bbox_lo[k] = blo[k]; t->bbox_hi[k] = bhi[k]; }
   }
   t->inorder.resize((size_t)n);

@@ -138,7 +138,19 @@ struct Context {
   uint32_t mailbox_seq = 0;
   // zeroed device words (kTicketBytes) that kernels use as "last workgroup" tickets and put back to zero themselves
   unsigned int *tickets = nullptr;
+  // pinned host memory the device READS: a small host-pointer input (a one-launch Fit's target, icp_small.hip) is copied
+  // here by the host and read over the bus by the kernel that wants it -- hipMemcpyAsync from pageable memory is a copy
+  // into the runtime's staging buffer, a copy command and its start-up: 25 us in front of a 160 us Fit.  One user at a
+  // time: an event behind the reading kernel says when the next may write (small_upload / small_upload_read, core.hip).
+  void *up = nullptr;
+  hipEvent_t up_read = nullptr;
+  bool up_pending = false;
 };
+constexpr size_t kSmallUploadBytes = 256 * 1024;
+// the calling context's pinned copy of a small host input, readable by kernels enqueued on st -- or nullptr (too large, no
+// such memory, the last one not read yet): the caller copies as ever.  small_upload_read: the kernels that read it are enqueued.
+const void *small_upload(const void *h_src, size_t bytes);
+void small_upload_read(hipStream_t st);
 Context &ctx();  // the calling thread's current context (the library's outside any call)
 int current_slot();  // the calling thread's device slot (pcgx_set_device; 0 unless a process drives several GPUs)
 pcgx_status ensure_init();
@@ -301,8 +313,15 @@ pcgx_status launch_minmax(const void *d_data, int64_t n, int32_t stride, int32_t
 // a few result words of a call on the host: through the context's mailbox where there is one (a one-wave kernel behind
 // the call's kernels, the host polls; the stream is not synchronised), else copy + wait.  bytes: a multiple of 4
 constexpr size_t kTicketBytes = 8192;
-constexpr size_t kMailboxBytes = 512;
+constexpr size_t kMailboxBytes = 2048;
 pcgx_status read_back_small(const void *d_src, size_t bytes, void *host_dst, hipStream_t st);
+// ... for a kernel that stores its result words into the mailbox itself (words from mailbox[2] on, then `seq` into
+// mailbox[0], system scope): the number to give it, and the host's wait for it
+uint32_t mailbox_next_seq();
+pcgx_status mailbox_wait(uint32_t seq, size_t bytes, void *host_dst, hipStream_t st);
+// ... for a kernel that stores every result word together with `seq` as ONE 64-bit word {word, seq} from byte 8 of the
+// mailbox on (no order among the stores needed, nothing to wait for on the device)
+pcgx_status mailbox_wait_tagged(uint32_t seq, int words, uint32_t *host_dst, hipStream_t st);
 // the same, and the six floats on the host (through the context's mailbox; the stream is not synchronised)
 pcgx_status minmax_to_host(const void *d_data, int64_t n, int32_t stride, int32_t off, float *d_out6, float out6[6],
                            hipStream_t st, bool sticky_first = true);
@@ -440,11 +459,18 @@ pcgx_status strict_enqueue_ring(StrictBuffers *b, const float4 *match, const uin
 void ring_abort_from_host(const RingView &ring, uint32_t reason);
 pcgx_status strict_reset(StrictBuffers *b, hipStream_t st);
 // icp_small.hip: a Fit's iterations in ONE persistent launch (small clouds: the tree's inner levels in LDS)
-bool small_fit_eligible(const TreeView &tv, int64_t nt);
+bool small_fit_eligible(const TreeView &tv, int64_t nt, bool many_ties);
 size_t small_fit_sync_bytes();
+size_t small_fit_terms_bytes(int64_t nt);
+int small_fit_max_iters();
+bool small_fit_wants_order(int64_t nt);
+// d_perm: [nt] the session's order of the targets (position -> caller's index), made here -- or nullptr: the caller's order
+pcgx_status small_fit_prepare(const float *d_target_aos, int64_t nt, const float box_lo[3], const float box_hi[3], int32_t *d_perm, float *d_xyz,
+                               uint32_t *d_pos_of, IcpState *state, void *terms, void *sync, hipStream_t st);
 pcgx_status small_fit_enqueue(const TreeView &tv, const float *tx, const float *ty, const float *tz, int64_t nt, IcpState *state,
-                              const IcpKernelParams &kp, float *terms, unsigned long long *valid, double *sums10, void *sync,
-                              int iters, hipStream_t st);
+                              const IcpKernelParams &kp, void *terms, unsigned long long *valid, double *sums10, void *sync,
+                              uint32_t launch_no, int iters, const int32_t *perm, hipStream_t st, volatile uint32_t *mailbox = nullptr,
+                              uint32_t mailbox_seq = 0u);
 // comm.hip: the communicator's ring (made on first use, collectively; nullptr: this communicator exchanges through
 // collectives only -- ranks on several nodes, no shared memory, PCGX_SHARD_RING=0), and a step's view of it
 bool comm_ring_step(pcgx_comm *c, int32_t step, RingView *out);
@@ -462,6 +488,9 @@ struct pcgx_kdtree {
   int32_t dir_bits = 0;
   float dir_lo[3] = {0, 0, 0}, dir_scale[3] = {0, 0, 0};
   float bbox_lo[3] = {0, 0, 0}, bbox_hi[3] = {0, 0, 0};  // of the base cloud
+  bool has_nan = false;            // a NaN coordinate among the points (host build; no one-launch Fit: icp_small.hip)
+  bool many_ties = false;          // along some axis most coordinates come several times (a scan of a plane, a lattice): the
+                                   // reference's plane test (kdtree.go:111-115) rules out little there -- icp_small.hip
   pcgx::RawVector<int32_t> inorder;  // host copy of the in-order ids
   pcgx::RawVector<float> points;   // host copy of xyz (accessor order), for Vec3At
   // KDTree.DeletePoint (kdtree.go:322-332).  The implicit layout cannot express the reference's

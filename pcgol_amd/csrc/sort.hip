@@ -583,25 +583,56 @@ __global__ __launch_bounds__(64) void read_back_kernel(const uint32_t *__restric
   if (threadIdx.x == 0) mailbox[0] = seq;
 }
 
+// the host's side of the mailbox: the words of sequence number `seq` (mailbox_next_seq) into host_dst
+uint32_t mailbox_next_seq() {
+  Context &c = ctx();
+  return ++c.mailbox_seq ? c.mailbox_seq : ++c.mailbox_seq;  // (never 0: the mailbox starts zeroed)
+}
+pcgx_status mailbox_wait(uint32_t seq, size_t bytes, void *host_dst, hipStream_t st) {
+  volatile uint32_t *mb = ctx().mailbox;
+  for (long spins = 0;; spins++) {
+    if (__atomic_load_n((const uint32_t *)mb, __ATOMIC_ACQUIRE) == seq) break;
+    if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(st) != hipErrorNotReady) {  // finished (or failed) without the word?
+      if (__atomic_load_n((const uint32_t *)mb, __ATOMIC_ACQUIRE) == seq) break;
+      PCGX_HIP_TRY(hipStreamSynchronize(st));
+      if (__atomic_load_n((const uint32_t *)mb, __ATOMIC_ACQUIRE) == seq) break;
+      return fail(PCGX_E_HIP, "the result words did not arrive in the mailbox");
+    }
+    __builtin_ia32_pause();
+  }
+  memcpy(host_dst, (const void *)(mb + 2), bytes);
+  return PCGX_OK;
+}
+
+pcgx_status mailbox_wait_tagged(uint32_t seq, int words, uint32_t *host_dst, hipStream_t st) {
+  const unsigned long long *mb = reinterpret_cast<const unsigned long long *>(const_cast<const uint32_t *>(ctx().mailbox) + 2);
+  auto all_in = [&]() {
+    for (int k = words - 1; k >= 0; k--)
+      if ((uint32_t)(__atomic_load_n(&mb[k], __ATOMIC_ACQUIRE) >> 32) != seq) return false;
+    return true;
+  };
+  for (long spins = 0;; spins++) {
+    if (all_in()) break;
+    if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(st) != hipErrorNotReady) {  // finished (or failed) without the words?
+      if (all_in()) break;
+      PCGX_HIP_TRY(hipStreamSynchronize(st));
+      if (all_in()) break;
+      return fail(PCGX_E_HIP, "the result words did not arrive in the mailbox");
+    }
+    __builtin_ia32_pause();
+  }
+  for (int k = 0; k < words; k++) host_dst[k] = (uint32_t)__atomic_load_n(&mb[k], __ATOMIC_RELAXED);
+  return PCGX_OK;
+}
+
 pcgx_status read_back_small(const void *d_src, size_t bytes, void *host_dst, hipStream_t st) {
   Context &c = ctx();
   volatile uint32_t *mb = c.mailbox;
   if (mb && bytes % 4 == 0 && bytes + 8 <= kMailboxBytes) {
-    const uint32_t seq = ++c.mailbox_seq ? c.mailbox_seq : ++c.mailbox_seq;
+    const uint32_t seq = mailbox_next_seq();
     hipLaunchKernelGGL(read_back_kernel, dim3(1), dim3(64), 0, st, (const uint32_t *)d_src, (int)(bytes / 4), mb, seq);
     PCGX_HIP_TRY(hipGetLastError());
-    for (long spins = 0;; spins++) {
-      if (__atomic_load_n((const uint32_t *)mb, __ATOMIC_ACQUIRE) == seq) break;
-      if ((spins & 0xfffff) == 0xfffff && hipStreamQuery(st) != hipErrorNotReady) {  // finished (or failed) without the word?
-        if (__atomic_load_n((const uint32_t *)mb, __ATOMIC_ACQUIRE) == seq) break;
-        PCGX_HIP_TRY(hipStreamSynchronize(st));
-        if (__atomic_load_n((const uint32_t *)mb, __ATOMIC_ACQUIRE) == seq) break;
-        return fail(PCGX_E_HIP, "the result words did not arrive in the mailbox");
-      }
-      __builtin_ia32_pause();
-    }
-    memcpy(host_dst, (const void *)(mb + 2), bytes);
-    return PCGX_OK;
+    return mailbox_wait(seq, bytes, host_dst, st);
   }
   PCGX_HIP_TRY(hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, st));
   PCGX_HIP_TRY(hipStreamSynchronize(st));

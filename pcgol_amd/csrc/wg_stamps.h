@@ -27,7 +27,18 @@
   do {                                                                                                       \
     if (threadIdx.x == 0) g_stamps_##NAME[(size_t)(WG) * (PER) + (K)] = (unsigned long long)wall_clock64(); \
   } while (0)
+#define PCGX_STAMP_IF(COND, NAME, PER, WG, K) \
+  do {                                       \
+    if (COND) PCGX_STAMP(NAME, PER, WG, K);  \
+  } while (0)
+/* by whichever wave's first lane gets here (the caller says which wave) */
+#define PCGX_STAMP_WAVE_IF(COND, NAME, PER, WG, K)                                                                   \
+  do {                                                                                                               \
+    if ((COND) && (threadIdx.x & 63) == 0) g_stamps_##NAME[(size_t)(WG) * (PER) + (K)] = (unsigned long long)wall_clock64(); \
+  } while (0)
 #else
 #define PCGX_STAMPS_DECLARE(NAME, WGS, PER)
 #define PCGX_STAMP(NAME, PER, WG, K) ((void)0)
+#define PCGX_STAMP_IF(COND, NAME, PER, WG, K) ((void)0)
+#define PCGX_STAMP_WAVE_IF(COND, NAME, PER, WG, K) ((void)0)
 #endif
