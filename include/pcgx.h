@@ -79,7 +79,7 @@ PCGX_API const char *pcgx_version(void);
 /* The layout version of this header's structs and fixed-size output arrays (pcgx_icp_params gained sums_mode in 3;
  * pcgx_debug_icp_strict_stats writes 64 words since 3; 4: device slots, pcgx_icp_fit_multi, pcgx_debug_voxel_stats;
  * 5: pcgx_debug_shard_stats, pcgx_prof_read_max, words 48 .. 63 of pcgx_debug_icp_strict_stats re-assigned;
- * 6: pcgx_debug_ring_kinds, pcgx_debug_host_walks).
+ * 6: pcgx_debug_ring_kinds, pcgx_debug_host_walks, pcgx_debug_icp_one_launch).
  * A binding built against another version of the header must not call into the library: the mirrors (go/pcgx,
  * host/pcgx.hpp, pcgol_amd/_lib.py) compare PCGX_ABI_VERSION with pcgx_abi_version() when they load it.
  * pcgx_icp_params_init zeroes a parameter block of THIS version (all defaults); sizeof_params is the caller's
@@ -104,6 +104,10 @@ PCGX_API pcgx_status pcgx_debug_call_stats(int64_t out[2], int32_t reset);
  * handle's host mirror of the tree, the one DeletePoint patches: no launch, no PCIe round trip; ids, DistSq bits, tie
  * winners and MinDistSq > 0 answers are those of the device path (csrc/knn_explicit.hip). */
 PCGX_API pcgx_status pcgx_debug_host_walks(int64_t *queries, int32_t reset);
+/* Measurement / test aid: launches of the ONE-LAUNCH Fit since the last reset (csrc/icp_small.hip: PointToPointICPGradient.Fit,
+ * icp.go:23-67, for small clouds -- every iteration of the loop inside one launch).  out = {launches, of them band by band
+ * (the tree's chunks looked at only below chunks that could not be ruled out), of them with the targets grouped by place}. */
+PCGX_API pcgx_status pcgx_debug_icp_one_launch(int64_t out[3], int32_t reset);
 /* Measurement / test aid: which path the VoxelGrid filter calls took since the last reset.  The filter
  * (voxelgrid.go:136-187) has two device paths with identical output: the bucket path (the coordinates travel
  * with the sort keys, a workgroup per bucket of cells; csrc/voxel_bucket.hip) and the radix path (stable sort of

@@ -192,6 +192,7 @@ SIGNATURES = {
     "pcgx_debug_shard_stats": (_i32, [_vp, _i32]),
     "pcgx_debug_ring_kinds": (_i32, [_vp, _i32]),
     "pcgx_debug_host_walks": (_i32, [_vp, _i32]),
+    "pcgx_debug_icp_one_launch": (_i32, [_vp, _i32]),
     "pcgx_comm_unique_id": (_i32, [_vp]),
     "pcgx_comm_init": (_i32, [_i32, _i32, _vp, C.POINTER(_vp)]),
     "pcgx_comm_init_callback": (_i32, [_i32, _i32, _vp, _vp, C.POINTER(_vp)]),

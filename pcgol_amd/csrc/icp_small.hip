@@ -1185,6 +1185,8 @@ __global__ __launch_bounds__(256) void small_prepare_kernel(const float *__restr
   for (int64_t i = t; i < n_sync16; i += stride) sync16[i] = zero;
 }
 
+static std::atomic<long long> g_small_launches[3];
+
 // ---- host side --------------------------------------------------------------------------------------------------
 static int64_t small_knob(const char *name, int64_t def) {
   if (const char *e = getenv(name)) return (int64_t)atoll(e);
@@ -1283,6 +1285,9 @@ pcgx_status small_fit_enqueue(const TreeView &tv, const float *tx, const float *
   (void)nchunks;
   const int hier = hier_forced >= 0 ? (hier_forced != 0) : (per_wave >= 64);
   const int seeded = hier || per_wave >= 8;
+  g_small_launches[0]++;
+  if (hier) g_small_launches[1]++;
+  if (perm) g_small_launches[2]++;
   launch_no &= (1u << (32 - kSmallTagIterBits)) - 1u;
   if (kp.min_dist_sq > 0.0f)
     hipLaunchKernelGGL(icp_small_fit_kernel<true>, dim3((unsigned)(Q * P)), dim3(kSmallBlock), 0, st, tv, tx, ty, tz, nt, ntp, state, kp,
@@ -1295,3 +1300,12 @@ pcgx_status small_fit_enqueue(const TreeView &tv, const float *tx, const float *
 }
 
 }  // namespace pcgx
+
+extern "C" pcgx_status pcgx_debug_icp_one_launch(int64_t out[3], int32_t reset) {
+  if (!out) return pcgx::fail(PCGX_E_INVALID, "pcgx_debug_icp_one_launch: NULL argument");
+  for (int k = 0; k < 3; k++) {
+    out[k] = (int64_t)pcgx::g_small_launches[k].load();
+    if (reset) pcgx::g_small_launches[k].store(0);
+  }
+  return PCGX_OK;
+}

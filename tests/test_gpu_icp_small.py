@@ -1,6 +1,6 @@
 """PointToPointICPGradient.Fit for small clouds: ONE persistent launch runs all iterations (csrc/icp_small.hip) --
-stackless reference-order walk with the tree's split values in LDS, the reference's sequential float32 sums as one
-wave's chain per sum, evaluate tail + pose update, two grid barriers per iteration.  Shapes: the reference's own
+the search as ALL distances, the walk's answer picked out of them by visit order (no walk), the reference's sequential
+float32 sums as one wave's chain per sum, evaluate tail + pose update, everything between workgroups as tagged words.  Shapes: the reference's own
 benchmark (icp_test.go:100-142: ground grid with a box, MinDistSq = res^2: the approximate, visit-order dependent search),
 random clouds with the exact search, every weight form, ragged sizes, the errors.  Everything bit for bit the oracle's."""
 import numpy as np
@@ -21,6 +21,15 @@ def _widen_the_one_launch_path():
     import os
     os.environ["PCGX_ICP_SMALL_BASE"], os.environ["PCGX_ICP_SMALL_TARGET"] = "32767", "32768"
     yield
+    for k in ("PCGX_ICP_SMALL_BASE", "PCGX_ICP_SMALL_TARGET", "PCGX_ICP_SMALL_HIER", "PCGX_ICP_SMALL_P", "PCGX_ICP_SMALL_ORDER_FROM"):
+        os.environ.pop(k, None)
+
+
+def _one_launches(reset=True):
+    import ctypes as C
+    out = (C.c_int64 * 3)()
+    L.check(L.lib().pcgx_debug_icp_one_launch(out, 1 if reset else 0))
+    return tuple(out)
 
 
 def _ground_box(n_pts):
@@ -62,7 +71,7 @@ def test_the_reference_benchmark_shapes_fit_in_one_launch(n_pts):
     s.close()
 
 
-@pytest.mark.parametrize("nb,nt,width", [(5000, 3000, 3.0), (32767, 32768, 6.0), (1, 700, 1.0), (2, 1, 1.0), (777, 513, 2.0)])
+@pytest.mark.parametrize("nb,nt,width", [(5000, 3000, 3.0), (32767, 16384, 6.0), (32767, 32768, 6.0), (1, 700, 1.0), (2, 1, 1.0), (777, 513, 2.0)])
 def test_small_random_clouds_exact_search(nb, nt, width):
     c = synth.c4_icp(n=max(nb, nt), width=width)
     base = np.ascontiguousarray(c["base"][:nb])
@@ -164,3 +173,107 @@ def test_small_fit_with_targets_that_find_nothing_and_non_finite_ones():
     s.close()
     with pytest.raises(O.OracleError):
         O.icp_fit(O.KDTree(c["base"]), far, 0.5, 6, w, th, 20, sums_mode=0)
+
+
+
+@pytest.mark.parametrize("hier,p,order_from", [(0, 0, 100000), (1, 0, 100000), (1, 1, 0), (0, 3, 0), (1, 2, 0), (0, 1, 100000)],
+                         ids=["flat", "bands", "bands-P1-grouped", "flat-P3-grouped", "bands-P2-grouped", "flat-P1"])
+def test_every_way_through_the_tree_gives_the_same_fit(hier, p, order_from):
+    """The tree's chunks one after the other or band by band below what could not be ruled out; one workgroup a group of
+    64 targets or several; the targets in the caller's order or grouped by place: how much work a Fit is, never what comes
+    out.  The benchmark's ground plane (the approximate search: MinDistSq = res^2) and a random surface (exact)."""
+    import os
+    os.environ["PCGX_ICP_SMALL_HIER"], os.environ["PCGX_ICP_SMALL_ORDER_FROM"] = str(hier), str(order_from)
+    if p:
+        os.environ["PCGX_ICP_SMALL_P"] = str(p)
+    try:
+        _one_launches()
+        base, target, mds = _ground_box(4096)
+        thr = np.full(6, -1.0, f32)
+        reg = icp.PointToPointICPGradient(icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=2.0), MinPairs=3),
+                                          icp.GradientDescentUpdaterFactory(Threshold=thr, MaxIteration=10))
+        trans, st = reg.Fit(kdtree.New(base, MinDistSq=mds), target)
+        _same(trans, st, O.icp_fit(O.KDTree(base, mds), target, 2.0, 3, None, thr, 10, sums_mode=0))
+        c = synth.c4_icp(n=6000, width=2.2)
+        base, target = np.ascontiguousarray(c["base"][:6000]), np.ascontiguousarray(c["target"][:2900])
+        w, th = np.full(6, 0.3, f32), np.full(6, -1.0, f32)
+        reg = icp.PointToPointICPGradient(icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=0.5), MinPairs=6),
+                                          icp.GradientDescentUpdaterFactory(Weight=w, Threshold=th, MaxIteration=12))
+        trans, st = reg.Fit(kdtree.New(base), target)
+        _same(trans, st, O.icp_fit(O.KDTree(base), target, 0.5, 6, w, th, 12, sums_mode=0))
+        n, bands, grouped = _one_launches()
+        assert n == 2 and bands == (2 if hier else 0) and grouped == (2 if order_from == 0 else 0)
+    finally:
+        for k in ("PCGX_ICP_SMALL_HIER", "PCGX_ICP_SMALL_P", "PCGX_ICP_SMALL_ORDER_FROM"):
+            os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("kind", ["lattice", "plane", "twins", "far"])
+@pytest.mark.parametrize("max_dist,mds", [(10.0, 0.0), (1.0, 0.0), (1.0, 0.25), (2.0, 1.0), (1.5, 2.25), (0.5, 0.0), (1.0, 2.0)])
+def test_ties_and_cuts_as_the_walk_decides_them(kind, max_dist, mds):
+    """Which of several points at the SAME distance the reference's walk returns depends on its visit order and on whether
+    the later one is a leaf (kdtree.go:100-103 replaces unless strictly farther, :117 needs strictly nearer); with MinDistSq
+    > 0 the first point under the cut in visit order wins (:104-106,120-122,140-142); a point at exactly maxRange^2 is a
+    partner only as a leaf.  Clouds made of ties: integer lattices, a plane, points that come twice -- and queries on the
+    lattice, between its points and far outside (maxRange^2 == MinDistSq included).  One Evaluate's pairs through the pose
+    they produce: bit for bit the oracle's, three iterations."""
+    rng = np.random.default_rng(["lattice", "plane", "twins", "far"].index(kind) * 1000 + int(max_dist * 10) * 10 + int(mds * 4))
+    n = int(rng.integers(40, 700))
+    if kind == "lattice":
+        base = rng.integers(0, 5, (n, 3)).astype(f32)
+    elif kind == "plane":
+        base = np.concatenate([rng.integers(0, 9, (n, 2)).astype(f32), np.zeros((n, 1), f32)], axis=1)
+    elif kind == "twins":
+        half = rng.uniform(-2, 2, (n // 2 + 1, 3)).astype(f32)
+        base = np.concatenate([half, half])[:n]
+    else:
+        base = (rng.integers(0, 4, (n, 3)) * 1000.0).astype(f32)
+    target = np.concatenate([rng.integers(0, 5, (150, 3)).astype(f32), (rng.integers(0, 10, (150, 3)) * 0.5).astype(f32),
+                             rng.uniform(-1, 6, (150, 3)).astype(f32), base[: min(n, 100)]]).astype(f32)
+    if kind == "far":
+        target = (target * f32(700.0)).astype(f32)
+        max_dist = max_dist * 800.0
+        mds = mds * 640000.0
+    w, th = np.full(6, 0.05, f32), np.full(6, -1.0, f32)
+    o = err = None
+    try:
+        o = O.icp_fit(O.KDTree(base, mds), target, max_dist, 1, w, th, 3, sums_mode=0)
+    except O.OracleError as e:
+        err = e
+    _one_launches()
+    reg = icp.PointToPointICPGradient(icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=max_dist), MinPairs=1),
+                                      icp.GradientDescentUpdaterFactory(Weight=w, Threshold=th, MaxIteration=3))
+    if o is None:
+        with pytest.raises(L.PcgxError):
+            reg.Fit(kdtree.New(base, MinDistSq=mds), target)
+    else:
+        trans, st = reg.Fit(kdtree.New(base, MinDistSq=mds), target)
+        _same(trans, st, o)
+    assert err is None or o is None
+    # (maxRange^2 < MinDistSq: the walk ends at its first leaf -- the general path's business, icp.hip small_now)
+    assert _one_launches()[0] == (0 if max_dist * max_dist < mds else 1)
+
+
+def test_which_clouds_get_the_one_launch_by_default():
+    """Without the test knobs: small clouds, and larger ones whose coordinates repeat (the reference's benchmark's ground
+    plane: its walk rules out nothing across a plane all points lie on) -- csrc/icp_small.hip, small_fit_eligible."""
+    import os
+    saved = {k: os.environ.pop(k) for k in ("PCGX_ICP_SMALL_BASE", "PCGX_ICP_SMALL_TARGET") if k in os.environ}
+    try:
+        thr = np.full(6, -1.0, f32)
+        def fits(base, target, mds, max_dist):
+            _one_launches()
+            reg = icp.PointToPointICPGradient(icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=max_dist), MinPairs=3),
+                                              icp.GradientDescentUpdaterFactory(Threshold=thr, MaxIteration=4))
+            trans, st = reg.Fit(kdtree.New(base, MinDistSq=mds), target)
+            _same(trans, st, O.icp_fit(O.KDTree(base, mds), target, max_dist, 3, None, thr, 4, sums_mode=0))
+            return _one_launches()
+        base, target, mds = _ground_box(16384)
+        assert fits(base, target, mds, 2.0) == (1, 1, 1)  # band by band, grouped
+        base, target, mds = _ground_box(1024)
+        assert fits(base, target, mds, 2.0) == (1, 0, 0)
+        c = synth.c4_icp(n=16000, width=4.0)
+        assert fits(c["base"], c["target"], 0.0, 0.5)[0] == 0  # a random surface of this size: the general path
+        assert fits(np.ascontiguousarray(c["base"][:1500]), np.ascontiguousarray(c["target"][:1500]), 0.0, 0.5)[0] == 1
+    finally:
+        os.environ.update(saved)
