@@ -285,6 +285,33 @@ def side_benchmarks(torch, L, kdtree, voxelgrid, synth, tree, stream, visits, ic
         del ctree
     except Exception as e:  # noqa: BLE001
         out["icp_c4_concurrent4"] = {"error": str(e)[:200]}
+    try:
+        # the reference's own ICP benchmark (icp_test.go:100-142: a 10 x 10 m ground grid with a box, MinDistSq = res^2,
+        # 10 iterations): one host-pointer Fit -- all iterations in ONE launch (csrc/icp_small.hip)
+        small = {}
+        for n_pts in (1024, 4096, 16384):
+            width = int(np.sqrt(float(n_pts)))
+            res = np.float32(10.0) / np.float32(width)
+            i = np.arange(n_pts)
+            bx = (res * (i // width).astype(np.float32) - np.float32(5)).astype(np.float32)
+            by = (res * (i % width).astype(np.float32) - np.float32(5)).astype(np.float32)
+            bz = np.where((bx > -1) & (bx < 1) & (by > -1) & (by < 1), np.float32(1), np.float32(0)).astype(np.float32)
+            gbase = np.ascontiguousarray(np.stack([bx, by, bz], axis=1))
+            gtarget = (gbase + np.array([0.5, 0.3, -0.2], np.float32)).astype(np.float32)
+            gt = kdtree.New(gbase, MinDistSq=float(res * res))
+            greg = icp.PointToPointICPGradient(
+                icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=2.0), MinPairs=3),
+                icp.GradientDescentUpdaterFactory(Threshold=np.full(6, -1.0, np.float32), MaxIteration=10))
+            best = 1e9
+            for _ in range(6):
+                t0 = time.perf_counter()
+                greg.Fit(gt, gtarget)
+                best = min(best, time.perf_counter() - t0)
+            small[str(n_pts)] = best * 1e3
+            del gt
+        out["reference_icp_benchmark_fit_ms"] = small
+    except Exception as e:  # noqa: BLE001
+        out["reference_icp_benchmark_fit_ms"] = {"error": str(e)[:200]}
     c3 = synth.c3_voxel()
     dp = torch.from_numpy(c3["points"]).to(dev)
     dout = torch.empty_like(dp)

@@ -1293,6 +1293,22 @@ static pcgx_status small_steps(pcgx_icp_session *s, hipStream_t st, int iters, u
   s->tile_sums_fresh = false;
   s->host_iter += iters;
   static std::atomic<uint32_t> launches{0};  // (one count for the process: a block of the cache keeps its last session's words)
+  // ONE such launch at a time on a device: its workgroups wait for each other inside the launch, all of them have to be
+  // on the chip together -- and two launches dealt out side by side from two streams' queues may each get a part of
+  // the chip and wait for the rest (until their 2 s run out and the Fits end with PCGX_E_HIP).  A launch starts behind
+  // the one before it, whatever stream that was on (an event; the hosts' threads do not wait for each other's Fits).
+  // (Kernels that end by themselves may share the chip with it: they make room.)
+  static std::mutex one_at_a_time;
+  static hipEvent_t last_done[16] = {};
+  std::lock_guard<std::mutex> lk(one_at_a_time);
+  const int slot = current_slot() & 15;
+  if (!last_done[slot]) PCGX_HIP_TRY(hipEventCreateWithFlags(&last_done[slot], hipEventDisableTiming));
+  else PCGX_HIP_TRY(hipStreamWaitEvent(st, last_done[slot], 0));
+  struct Record {  // (whatever way this function is left: the next launch waits for what was enqueued here)
+    hipEvent_t ev;
+    hipStream_t st;
+    ~Record() { (void)hipEventRecord(ev, st); }
+  } record{last_done[slot], st};
   while (iters > 0) {
     const int now = iters < small_fit_max_iters() ? iters : small_fit_max_iters();
     // (mail_seq: the launch that ends the Fit leaves the loop state in the context's mailbox -- pcgx_icp_fit)

@@ -277,3 +277,35 @@ def test_which_clouds_get_the_one_launch_by_default():
         assert fits(np.ascontiguousarray(c["base"][:1500]), np.ascontiguousarray(c["target"][:1500]), 0.0, 0.5)[0] == 1
     finally:
         os.environ.update(saved)
+
+
+def test_one_launch_fits_from_several_threads_at_once():
+    """Host-pointer Fits from four threads land on four streams: a one-launch Fit's workgroups wait for each other inside
+    the launch, so two of them dealt out side by side could each hold a part of the chip and wait for the rest -- the
+    launches start one behind the other (csrc/icp.hip, small_steps).  Every Fit the oracle's, none out of time."""
+    import threading
+    thr = np.full(6, -1.0, f32)
+    shapes = {}
+    for n_pts in (1024, 4096):
+        base, target, mds = _ground_box(n_pts)
+        shapes[n_pts] = (kdtree.New(base, MinDistSq=mds), target, O.icp_fit(O.KDTree(base, mds), target, 2.0, 3, None, thr, 10, sums_mode=0))
+    reg = icp.PointToPointICPGradient(icp.PointToPointEvaluator(icp.NearestPointCorresponder(MaxDist=2.0), MinPairs=3),
+                                      icp.GradientDescentUpdaterFactory(Threshold=thr, MaxIteration=10))
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(12):
+                t, target, o = shapes[1024 if (k + rep) % 2 else 4096]
+                trans, st = reg.Fit(t, target)
+                _same(trans, st, o)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+    _one_launches()
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:2]
+    assert _one_launches()[0] == 48

@@ -2,9 +2,11 @@
 # Round 6's evidence in one gpurun call (on ONE build): rocprofv3 trace + PMC passes of the bench command
 # (profiles/collect.sh), the bench line, the per-row timings (section 8 rows + the reference's own benchmarks), the C5
 # share's bench line, one hop of the ring through host memory / device memory of one process (ring_hop) and through
-# another PROCESS's device memory (ipc_hop), four Fits in flight (conc4_probe).  Summaries are copied under gpurun_out/
+# another PROCESS's device memory (ipc_hop), four Fits in flight (conc4_probe), the one-launch Fit's own measurements
+# (the reference's benchmark shapes, where the launch's iteration goes, the default's choice against the general path,
+# the two microbenchmarks its design rests on).  Summaries are copied under gpurun_out/
 # for the way back (gpurun merges gpurun_out/ only); the raw CSVs are dropped (tens of MB).
-TAG=${1:-r06c}
+TAG=${1:-r06d}
 mkdir -p gpurun_out
 bash profiles/collect.sh $TAG > gpurun_out/${TAG}_collect.log 2>&1
 echo collect rc=$?
@@ -22,6 +24,16 @@ echo c5 rc=$?
 echo hop rc=$?
 timeout -k 10 200 python tools/conc4_probe.py 4 2>&1 | tail -1 > gpurun_out/${TAG}_conc4.txt
 echo conc4 rc=$?
+{
+  for n in 1024 4096 16384; do timeout -k 10 100 python tools/small_fit_probe.py $n 10 2>&1 | grep points; done
+  if [ -f experiments/ab/libpcgx_stamps.so ]; then
+    for n in 1024 4096 16384; do echo "stamps, $n points:"; PCGX_STAMPS_POINTS=$n PCGX_LIB=experiments/ab/libpcgx_stamps.so timeout -k 10 120 python tools/stamps.py small_fit 2>&1 | grep -v amdgpu.ids; done
+  fi
+  for s in 1 0; do PCGX_ICP_SMALL=$s timeout -k 10 300 python tools/small_vs_general.py 2>&1 | grep PCGX_ICP; done
+  timeout -k 5 120 tools/micro/xcd_pingpong.bin
+  timeout -k 5 120 tools/micro/dpp_chain.bin
+} > gpurun_out/${TAG}_small_fit.txt 2>&1
+echo small rc=$?
 for mem in dev host; do
   for n in 2 4 5; do
     [ $mem = host ] && [ $n = 5 ] && continue
