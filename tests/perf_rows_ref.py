@@ -100,6 +100,7 @@ for n_pts in (1024, 4096, 16384):
     row("BenchmarkPointToPointICPGradient Points%d: one 10-iteration Fit" % n_pts, "pc/registration/icp/icp_test.go:100-142",
         1, "fits", g, cs, 1,
         "ms per Fit -- oracle %.3f; GPU host-pointer Fit %.3f (session made, target uploaded, result read back per call), "
-        "session-resident Fit %.3f; MinDistSq = res^2: the approximate search, every pair from the reference-order walk; "
+        "a session's ten one-iteration launches %.3f; MinDistSq = res^2: the approximate search, every pair the reference-order "
+        "walk's (picked out of all distances by visit order, csrc/icp_small.hip); "
         "pose and Value bit-identical to the oracle" % (cs * 1e3, g * 1e3, gs * 1e3))
     del gt, ot
