@@ -53,6 +53,7 @@
 // the kernel and the Fit ends with PCGX_E_HIP -- the grid drains whatever happens.
 #include "knn_walk.h"
 #include "strict_terms.h"
+#include "strict_sum.h"
 #include "wg_stamps.h"
 
 namespace pcgx {
@@ -63,12 +64,17 @@ namespace pcgx {
 PCGX_STAMPS_DECLARE(small_fit, 256, 8)
 #if defined(PCGX_STAMPS)
 __device__ unsigned long long g_small_dbg[8];
+__device__ unsigned long long g_small_fail[16];  // the stamped iteration: row r's tiles whose record did not cover the state (low byte: key < 0)
 __device__ unsigned long long g_small_iter_t[64];  // workgroup 0's first wave: wall clock at the kernel's start, every iteration's top, the end  // chunks looked at / ruled out whole / gone through, of the stamped iteration
 #if defined(PCGX_SMALL_COUNTS)  // (an atomic per chunk and wave: not beside time measurements)
 #define PCGX_SMALL_COUNT(K) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_small_dbg[K], 1ull); } while (0)
 #else
 #define PCGX_SMALL_COUNT(K) ((void)0)
 #endif
+extern "C" __attribute__((visibility("default"))) int pcgx_debug_small_fails(unsigned long long *out) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_fail), 16 * 8) == hipSuccess ? 0 : 1;
+}
 extern "C" __attribute__((visibility("default"))) int pcgx_debug_small_iter_times(unsigned long long *out) {
   if (hipDeviceSynchronize() != hipSuccess) return 1;
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_small_iter_t), 64 * 8) == hipSuccess ? 0 : 1;
@@ -131,6 +137,10 @@ constexpr size_t kSmallCountsAt = 512;                        // [256] a group's
 constexpr size_t kSmallExitedAt = 3584;                        // workgroups that have left the launch (the last one zeroes it and the abort word)
 constexpr size_t kSmallPartAt = 4096;                         // [256 workgroups][kPartWords][64]
 constexpr size_t kSmallPartnersAt = kSmallPartAt + (size_t)256 * kPartWords * 64 * 8;  // [16384] a target's partner last time (a node; 0: none)
+constexpr int kSmallMaxTiles = 8;  // 16384 terms in tiles of ss::kTile
+constexpr size_t kSmallTileSumsAt = kSmallPartnersAt + (size_t)16384 * 4;                      // [kStrictRows][kSmallMaxTiles][2] a tile's terms' float64 sum
+constexpr size_t kSmallTileRecsAt = kSmallTileSumsAt + (size_t)kStrictRows * kSmallMaxTiles * 2 * 8;  // [kStrictRows][kSmallMaxTiles][16] a tile's record (ss::TileRec)
+constexpr size_t kSmallScratchBytes = kSmallTileRecsAt + (size_t)kStrictRows * kSmallMaxTiles * 16 * 8;
 
 // kdtree.go:94-146 on the implicit tree (pcgx_internal.h: node b's children are 2b and 2b + 1, its depth floor(log2 b),
 // its size a closed form of b: node_size), as the in-order walk  visit(near) ; test node ; visit(far)  with one running
@@ -442,6 +452,119 @@ __device__ __forceinline__ uint32_t small_chunk_go(const SmallChunk &C, int c, i
   }
   return live;
 }
+
+// ---- the sums of LONG rows: tiles of 2048 terms summarised in parallel (strict_sum.h) ------------------------------------
+// One wave a sum is 5 ns a term: 85 us of a 140 us iteration at 16384 targets.  Beyond a row's first tile the tiles are
+// summarised by waves of their own, all at once -- strict_sum.h: inside a binade a run of float32 additions moves the
+// state's mantissa by an amount that depends only on its parity class, as long as no step leaves the binade; a wave
+// finds that translation and the interval of states it holds for by running the hardware's adds from a GUESS of the
+// tile's first state (the float64 sum of everything in front of it) -- and the row's wave walks through the records:
+// a record that covers the exact state is applied (proven equal to the additions one by one), one that does not is
+// replaced by the additions one by one.  ss_host_model restated for a wave a tile, the general path's kernels
+// (strict.hip) without their batching: here a row has eight tiles at most.
+namespace mini {
+using namespace ss;
+static_assert(sizeof(TileRec) == 64, "sixteen words a record");
+
+template <class T, class F>
+__device__ __forceinline__ T ordered_total(T v, int lane, F compose) {  // compose(lane 0's, lane 1's, ... lane 63's), in every lane
+  constexpr int kInts = (int)(sizeof(T) / 4);
+  static_assert(sizeof(T) % 4 == 0, "a record of 32-bit words");
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    T o;
+    int *po = reinterpret_cast<int *>(&o);
+    const int *pv = reinterpret_cast<const int *>(&v);
+#pragma unroll
+    for (int k = 0; k < kInts; k++) po[k] = __shfl_up(pv[k], off);
+    if (lane >= off) v = compose(o, v);
+  }
+  T out;
+  int *pout = reinterpret_cast<int *>(&out);
+  const int *pv = reinterpret_cast<const int *>(&v);
+#pragma unroll
+  for (int k = 0; k < kInts; k++) pout[k] = __shfl(pv[k], 63);
+  return out;
+}
+__device__ __forceinline__ double wave_excl_scan(double v, int lane, double &total) {
+  double x = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double o = __shfl_up(x, off);
+    if (lane >= off) x += o;
+  }
+  total = __shfl(x, 63);
+  const double before = __shfl_up(x, 1);
+  return lane == 0 ? 0.0 : before;
+}
+__device__ __forceinline__ uint32_t wave_umin(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = umin(v, (uint32_t)__shfl_xor((int)v, o));
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = umax(v, (uint32_t)__shfl_xor((int)v, o));
+  return v;
+}
+
+// A tile in a wave's registers: t[kLeaf] the lane's leaf (terms 32 * lane ... of the tile), and what the lane's guess chain
+// gave.  base: the guess of the state in front of the tile (ss_host_model, tile_guesses: the float64 prefix of the leaves'
+// sums, refined once by the prefix of the rounding errors the chains make when started from those first guesses).
+struct Leaf {
+  uint32_t guess;
+  ChainRange cr;
+};
+__device__ __forceinline__ Leaf tile_guesses(const float (&t)[kLeaf], double base, double lsum, int lane) {
+  Leaf L;
+  double tot;
+  const double pre = wave_excl_scan(lsum, lane, tot);
+  L.guess = f2u((float)(base + pre));
+  L.cr = guess_chain(t, L.guess);
+  const double err = ((double)u2f(L.cr.end) - (double)u2f(L.guess)) - lsum;
+  double etot;
+  const double e = wave_excl_scan(err, lane, etot);
+  const uint32_t g2 = f2u((float)(base + pre + e));
+  if (__ballot(g2 != L.guess) != 0ull) {
+    L.guess = g2;
+    L.cr = guess_chain(t, L.guess);
+  }
+  return L;
+}
+// the tile's window (-1: none: its states change sign or run through three binades) and whether it stays in ONE binade (E)
+__device__ __forceinline__ int32_t tile_window(const Leaf &L, int lane, bool &one_binade, uint32_t &E, uint32_t &sign) {
+  const uint32_t mn = wave_umin(L.cr.mn), mx = wave_umax(L.cr.mx);
+  const uint32_t sg_or = __ballot(L.cr.sg_or != 0u) != 0ull ? 1u : 0u, sg_and = __ballot(L.cr.sg_and == 0u) != 0ull ? 0u : 1u;
+  const uint32_t guess0 = (uint32_t)__shfl((int)L.guess, 0);
+  const int32_t key = sg_or == sg_and ? choose_window(mn, mx, sg_or, guess0 & 0x7fffffffu) : -1;
+  one_binade = key >= 0 && (mn >> 23) == (mx >> 23);
+  E = mn >> 23;
+  sign = sg_or;
+  return key;
+}
+// the record of one tile (ss_host_model: "strict_sum_kernel: one record per tile", a leaf a lane)
+__device__ __forceinline__ TileRec tile_record(const float (&t)[kLeaf], const Leaf &L, int lane) {
+  bool one_binade;
+  uint32_t E, sign;
+  TileRec T;
+  T.key = tile_window(L, lane, one_binade, E, sign);
+  T.in = (uint32_t)__shfl((int)L.guess, 0);
+  T.out = (uint32_t)__shfl((int)L.cr.end, 63);
+  const uint32_t next_guess = (uint32_t)__shfl_down((int)L.guess, 1);
+  T.cons = __ballot(lane < 63 && next_guess != L.cr.end) == 0ull ? 1 : 0;
+  T.s = summary_identity();
+  if (one_binade) {  // parity summaries
+    const Par mine = leaf_parity_summary(t, L.guess, L.cr, E, sign);
+    const Par acc = ordered_total(mine, lane, [](const Par &X, const Par &Y) { return par_compose(X, Y); });
+    T.s = par_expand(acc, E, T.key);
+  } else if (T.key >= 0) {
+    const bool leaf_one = (L.cr.mn >> 23) == (L.cr.mx >> 23);
+    const Summary mine = leaf_one ? leaf_summary_binade(t, L.guess, T.key) : leaf_summary_general(t, L.guess, T.key);
+    T.s = ordered_total(mine, lane, [](const Summary &X, const Summary &Y) { return compose(X, Y); });
+  }
+  return T;
+}
+}  // namespace mini
 
 // 64 terms added to s one after the other (term k in lane k of `term`; evaluator.go:122-145): v_readlane + v_add_f32 with
 // the term in a scalar register, 12 cycles = 5 ns a term whatever the order of the two (tools/micro/dpp_chain.cpp: the
@@ -957,20 +1080,25 @@ __global__ __launch_bounds__(kSmallBlock) void icp_small_fit_kernel(TreeView tv,
     }
     PCGX_STAMP_IF(it == PCGX_STAMP_ITER, small_fit, 8, blockIdx.x, 3);
     if (!alive) break;
-    // ---- the sums (evaluator.go:122-145): row r's chain by worker r, out of the terms' words as they come
+    // ---- the sums (evaluator.go:122-145), out of the terms' words as they come.  Row r's first tile (2048 terms) is its
+    // wave's chain; every further tile is summarised by a wave of its own meanwhile (mini::tile_record) and the row's
+    // wave walks through the records.  Roles in an order in which nobody waits for a later one (a launch of few
+    // workgroups gives a wave several): the tiles' waves tile by tile, then the rows'.
     if (worker >= 0) {
-      for (int row = worker; row < nrows && alive; row += nworkers) {  // uniform per wave
-        const unsigned long long *T = terms + (int64_t)row * ntp + lane;
-        PCGX_STAMP_WAVE_IF(it == PCGX_STAMP_ITER && row == 0, small_fit, 8, 1, 6);  // (workgroup 1's spare slots: row 0's chain)
-        float s = 0.0f;  // evaluator.go:122
-        // eight blocks of 64 terms asked for together, the next eight under these blocks' adds
+      const int nT = (int)((ntp + ss::kTile - 1) / ss::kTile);  // (<= kSmallMaxTiles)
+      const int n_tilers = nrows * (nT - 1), n_roles = n_tilers + nrows;
+      unsigned long long *tsum_w = reinterpret_cast<unsigned long long *>(scratch + kSmallTileSumsAt);
+      unsigned long long *recs_w = reinterpret_cast<unsigned long long *>(scratch + kSmallTileRecsAt);
+      // terms [begin, end) of row T added to s one after the other (eight blocks of 64 asked for together, the next eight
+      // under these blocks' adds)
+      auto chain_over = [&](const unsigned long long *T, float s, int64_t begin, int64_t end) -> float {
         constexpr int kB = 8;
         unsigned long long v[kB], vn[kB];
 #pragma unroll
-        for (int j = 0; j < kB; j++) v[j] = (int64_t)j * 64 < ntp ? word_in(T + j * 64) : tagged(0x80000000u, tag);
-        for (int64_t base = 0; base < ntp && alive; base += kB * 64) {
+        for (int j = 0; j < kB; j++) v[j] = begin + j * 64 < end ? word_in(T + begin + j * 64) : tagged(0x80000000u, tag);
+        for (int64_t base = begin; base < end && alive; base += kB * 64) {
 #pragma unroll
-          for (int j = 0; j < kB; j++) vn[j] = base + (kB + j) * 64 < ntp ? word_in(T + base + (kB + j) * 64) : tagged(0x80000000u, tag);
+          for (int j = 0; j < kB; j++) vn[j] = base + (kB + j) * 64 < end ? word_in(T + base + (kB + j) * 64) : tagged(0x80000000u, tag);
           for (;;) {  // this batch: every word this iteration's?
             bool ok = true;
 #pragma unroll
@@ -982,19 +1110,145 @@ __global__ __launch_bounds__(kSmallBlock) void icp_small_fit_kernel(TreeView tv,
             }
 #pragma unroll
             for (int j = 0; j < kB; j++)
-              if (base + j * 64 < ntp && (uint32_t)(v[j] >> 32) != tag) v[j] = word_in(T + base + j * 64);
+              if (base + j * 64 < end && (uint32_t)(v[j] >> 32) != tag) v[j] = word_in(T + base + j * 64);
           }
           if (!alive) break;
-          PCGX_STAMP_WAVE_IF(it == PCGX_STAMP_ITER && row == 0 && base == 0, small_fit, 8, 1, 7);
 #pragma unroll
           for (int j = 0; j < kB; j++) {
-            if (base + j * 64 >= ntp) break;  // uniform
+            if (base + j * 64 >= end) break;  // uniform
             s = chain64(s, __uint_as_float((uint32_t)v[j]));
           }
 #pragma unroll
           for (int j = 0; j < kB; j++) v[j] = vn[j];
         }
+        return s;
+      };
+      // the lane's leaf of tile k of row T (terms 32 * lane ... of the tile; behind the row's end: -0.0f, which changes no sum)
+      auto load_leaf = [&](const unsigned long long *T, int k, float (&t)[ss::kLeaf]) {
+        const int64_t i0 = (int64_t)k * ss::kTile + (int64_t)lane * ss::kLeaf;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {  // (sixteen words at a time: registers)
+          unsigned long long w[16];
+          for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 16; j++) w[j] = i0 + h * 16 + j < ntp ? word_in(T + i0 + h * 16 + j) : tagged(0x80000000u, tag);
+#pragma unroll
+            for (int j = 0; j < 16; j++) ok = ok && (uint32_t)(w[j] >> 32) == tag;
+            if (__ballot(ok) == ~0ull) break;
+            if (small_give_up(sy, wait)) {
+              alive = false;
+              break;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 16; j++) t[h * 16 + j] = __uint_as_float((uint32_t)w[j]);
+        }
+      };
+      auto leaf_sum = [&](const float (&t)[ss::kLeaf]) -> double {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < ss::kLeaf; j++) v += (double)t[j];
+        return v;
+      };
+      auto wave_sum = [&](double v) -> double {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+      };
+      auto put_tile_sum = [&](int row, int k, double v) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+        if (lane == 0) {
+          word_out(&tsum_w[((size_t)row * kSmallMaxTiles + k) * 2], tagged((uint32_t)bits, tag));
+          word_out(&tsum_w[((size_t)row * kSmallMaxTiles + k) * 2 + 1], tagged((uint32_t)(bits >> 32), tag));
+        }
+      };
+      for (int role = worker; role < n_roles && alive; role += nworkers) {  // uniform per wave
+        if (role < n_tilers) {
+          // ---- tile k >= 1 of a row: its record
+          const int k = 1 + role / nrows, row = role % nrows;
+          const unsigned long long *T = terms + (int64_t)row * ntp;
+          float t[ss::kLeaf];
+          double base = 0.0;
+          if (k == 1) {  // (the first tile's float64 sum: by the second tile's wave, for everybody behind it too)
+            load_leaf(T, 0, t);
+            if (!alive) break;
+            base = wave_sum(leaf_sum(t));
+            put_tile_sum(row, 0, base);
+          }
+          load_leaf(T, k, t);
+          if (!alive) break;
+          const double lsum = leaf_sum(t);
+          put_tile_sum(row, k, wave_sum(lsum));
+          if (k > 1) {  // the float64 sum of everything in front of the tile: the tiles' sums, by their waves
+            unsigned long long lo = 0ull, hi = 0ull;
+            for (;;) {
+              lo = lane < k ? word_in(&tsum_w[((size_t)row * kSmallMaxTiles + lane) * 2]) : tagged(0u, tag);
+              hi = lane < k ? word_in(&tsum_w[((size_t)row * kSmallMaxTiles + lane) * 2 + 1]) : tagged(0u, tag);
+              if (__ballot((uint32_t)(lo >> 32) == tag && (uint32_t)(hi >> 32) == tag) == ~0ull) break;
+              if (small_give_up(sy, wait)) {
+                alive = false;
+                break;
+              }
+            }
+            if (!alive) break;
+            const double mine = lane < k ? __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo)) : 0.0;
+            base = wave_sum(mine);
+          }
+          const mini::Leaf L = mini::tile_guesses(t, base, lsum, lane);
+          const ss::TileRec R = mini::tile_record(t, L, lane);
+          const uint32_t *rw = reinterpret_cast<const uint32_t *>(&R);
+          uint32_t mine = 0u;
+#pragma unroll
+          for (int j = 0; j < 16; j++) mine = lane == j ? rw[j] : mine;
+          if (lane < 16) word_out(&recs_w[((size_t)row * kSmallMaxTiles + k) * 16 + lane], tagged(mine, tag));
+          continue;
+        }
+        // ---- a row: its first tile term by term from 0.0f (evaluator.go:122: the state runs through a binade every few terms
+        // there, nothing to summarise), the others by their records
+        const int row = role - n_tilers;
+        const unsigned long long *T = terms + (int64_t)row * ntp;
+        PCGX_STAMP_WAVE_IF(it == PCGX_STAMP_ITER && row == 0, small_fit, 8, 1, 6);  // (workgroup 1's spare slots: row 0's sums)
+        uint32_t s_bits = __float_as_uint(chain_over(T + lane, 0.0f, 0, ntp < ss::kTile ? ntp : (int64_t)ss::kTile));
         if (!alive) break;
+        PCGX_STAMP_WAVE_IF(it == PCGX_STAMP_ITER && row == 0, small_fit, 8, 1, 7);
+#if defined(PCGX_STAMPS)
+        unsigned long long n_fail = 0ull;
+#endif
+        for (int k = 1; k < nT && alive; k++) {
+          unsigned long long w = 0ull;
+          for (;;) {
+            w = lane < 16 ? word_in(&recs_w[((size_t)row * kSmallMaxTiles + k) * 16 + lane]) : tagged(0u, tag);
+            if (__ballot((uint32_t)(w >> 32) == tag) == ~0ull) break;
+            if (small_give_up(sy, wait)) {
+              alive = false;
+              break;
+            }
+          }
+          if (!alive) break;
+          ss::TileRec R;
+          uint32_t *rw = reinterpret_cast<uint32_t *>(&R);
+#pragma unroll
+          for (int j = 0; j < 16; j++) rw[j] = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, j);
+          if (R.key >= 0 && ss::apply(s_bits, R.key, R.s)) continue;  // the record covers the state: proven the additions' result
+          if (R.cons && R.in == s_bits) {                             // ... or its guesses were the states themselves
+            s_bits = R.out;
+            continue;
+          }
+#if defined(PCGX_STAMPS)
+          n_fail += 256ull + (R.key < 0 ? 1ull : 0ull);
+#endif
+          // else the additions one by one: 11 us a tile.  (The tile leaf by leaf under windows of the leaves' own, runs of
+          // equal windows composed -- ss_host_model's resolve_tile, a leaf a lane -- was built and was SLOWER, 22 us: the tiles
+          // that get here are the ones whose sums hover around zero, where most leaves have no window either.)
+          const int64_t b0 = (int64_t)k * ss::kTile, b1 = b0 + ss::kTile < ntp ? b0 + ss::kTile : ntp;
+          s_bits = __float_as_uint(chain_over(T + lane, __uint_as_float(s_bits), b0, b1));
+        }
+        if (!alive) break;
+        const float s = __uint_as_float(s_bits);
+#if defined(PCGX_STAMPS)
+        if (it == PCGX_STAMP_ITER && lane == 0) g_small_fail[row] = n_fail;
+#endif
         PCGX_STAMP_WAVE_IF(it == PCGX_STAMP_ITER && row == 0, small_fit, 8, 2, 6);
         const int slot = row == 0 ? S_VALUE : (row <= 6 ? S_G0 + row - 1 : (row == 7 ? S_DIST_RMS : S_WEIGHT));
         if (row == 0) {  // the pair count rides with the first sum
@@ -1232,7 +1486,7 @@ bool small_fit_eligible(const TreeView &tv, int64_t nt, bool many_ties) {
   const SmallShape S = small_shape(tv, nt);
   return 12.0 + 0.0049 * (double)nt + 0.7 * (double)S.per_wave <= 36.0;
 }
-size_t small_fit_sync_bytes() { return kSmallPartnersAt + (size_t)16384 * sizeof(uint32_t); }
+size_t small_fit_sync_bytes() { return (kSmallScratchBytes + 15) & ~(size_t)15; }
 size_t small_fit_terms_bytes(int64_t nt) { return (size_t)kStrictRows * (size_t)((nt + 63) & ~(int64_t)63) * sizeof(unsigned long long); }
 int small_fit_max_iters() { return (1 << kSmallTagIterBits) - 2; }
 // a target large enough for the grouping to matter (and for a 20 us launch in front of the Fit not to)

@@ -42,6 +42,10 @@ def run_small():
         reg.Fit(t, target)
         raw.pcgx_debug_small_counts(cnt, 0)
         print("  one Fit (10 iterations, %d groups of 64 targets): %d chunks looked at, %d ruled out whole, %d gone through" % ((n_pts + 63) // 64, cnt[0], cnt[1], cnt[2]))
+        fl = (ctypes.c_ulonglong * 16)()
+        if getattr(raw, "pcgx_debug_small_fails", None) is not None and raw.pcgx_debug_small_fails(fl) == 0:
+            print("  the stamped iteration, tiles added term by term because their record did not cover the state, row by row (of them without a window): "
+                  + " ".join("%d(%d)" % (fl[r] >> 8, fl[r] & 255) for r in range(9)))
         it = (ctypes.c_ulonglong * 64)()
         if getattr(raw, "pcgx_debug_small_iter_times", None) is not None and raw.pcgx_debug_small_iter_times(it) == 0:
             tt = [x / 100.0 for x in it]
