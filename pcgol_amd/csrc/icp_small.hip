@@ -1529,15 +1529,16 @@ pcgx_status small_fit_enqueue(const TreeView &tv, const float *tx, const float *
   const int P = S.P;
   const int64_t nchunks = S.nchunks;
   if (Q > 256 || Q * P > 256) return fail(PCGX_E_INVALID, "icp (one launch): %d groups of targets", Q);
-  // Band by band (below what could not be ruled out) where a wave would otherwise look at 64 chunks or more.  Measured on
-  // the reference's benchmark shapes (10-iteration Fits, ms): 4096 points (17 chunks a wave) 0.72 flat / 0.91 band by
-  // band -- every one of the group's P workgroups keeps a list of its own and looks at all of a band's chunks on it;
-  // 16384 points (273 a wave) 5.9 / 1.75.  The bound from last time's partner costs a dependent fetch in front of the
-  // first chunk: where a wave has eight chunks or more to rule out with it.
+  // Band by band (below what could not be ruled out) where a wave would otherwise look at two dozen chunks or more.
+  // Measured (10- / 20-iteration host-pointer Fits, ms, chunk after chunk / band by band): the benchmark's plane at 4096
+  // points (17 chunks a wave) 0.65 / 0.76 -- every one of the group's P workgroups keeps a list of its own and looks at
+  // all of a band's chunks on it; a random surface at 8000 x 8000 (35 a wave) 1.77 / 1.06; the plane at 16384 (273 a
+  // wave) 5.9 / 1.23.  The bound from last time's partner costs a dependent fetch in front of the first chunk: where a
+  // wave has eight chunks or more to rule out with it.
   const int hier_forced = (int)small_knob("PCGX_ICP_SMALL_HIER", -1);  // (tests, measurements: read at every launch)
   const int64_t per_wave = S.per_wave;
   (void)nchunks;
-  const int hier = hier_forced >= 0 ? (hier_forced != 0) : (per_wave >= 64);
+  const int hier = hier_forced >= 0 ? (hier_forced != 0) : (per_wave >= 24);
   const int seeded = hier || per_wave >= 8;
   g_small_launches[0]++;
   if (hier) g_small_launches[1]++;

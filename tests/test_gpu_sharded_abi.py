@@ -180,9 +180,9 @@ def _session_worker(rank, world, port, q, n, mode):
                 return r, (time.perf_counter() - t0) * 1e3
             fit(False)
             (_, _, _), t_plain = fit(False)
-            # (the best of three: three processes share the box's one GPU with the test runner, and a round in which
+            # (the best of five: three processes share the box's one GPU with the test runner, and a round in which
             # the scheduler held one of them back for tens of milliseconds was seen once in ten)
-            (trans, st, _), t_skew = min((fit(True) for _ in range(3)), key=lambda r: r[1])
+            (trans, st, _), t_skew = min((fit(True) for _ in range(5)), key=lambda r: r[1])
             out["trans"], out["iters"], out["value"] = np.asarray(trans, np.float32), int(st.NumIteration), float(st.Evaluated.Value)
             out["t_plain"], out["t_skew"], out["delay"] = t_plain, t_skew, delay_ms
             dbg = s.sess.strict_stats()
