@@ -105,8 +105,9 @@ PCGX_API pcgx_status pcgx_debug_call_stats(int64_t out[2], int32_t reset);
  * winners and MinDistSq > 0 answers are those of the device path (csrc/knn_explicit.hip). */
 PCGX_API pcgx_status pcgx_debug_host_walks(int64_t *queries, int32_t reset);
 /* Measurement / test aid: launches of the ONE-LAUNCH Fit since the last reset (csrc/icp_small.hip: PointToPointICPGradient.Fit,
- * icp.go:23-67, for small clouds -- every iteration of the loop inside one launch).  out = {launches, of them band by band
- * (the tree's chunks looked at only below chunks that could not be ruled out), of them with the targets grouped by place}. */
+ * icp.go:23-67, for small clouds -- every iteration of the loop inside one launch).  out = {launches, of them with
+ * the tree's chunks looked at only below chunks that could not be ruled out (a queue, or band by band), of them with the
+ * targets grouped by place}. */
 PCGX_API pcgx_status pcgx_debug_icp_one_launch(int64_t out[3], int32_t reset);
 /* Measurement / test aid: which path the VoxelGrid filter calls took since the last reset.  The filter
  * (voxelgrid.go:136-187) has two device paths with identical output: the bucket path (the coordinates travel

@@ -722,7 +722,8 @@ __global__ __launch_bounds__(kSmallBlock) void icp_small_fit_kernel(TreeView tv,
                                                                     uint32_t launch_no, int P, int mode, int iters, const int32_t *__restrict__ perm,
                                                                     volatile uint32_t *__restrict__ mailbox,
                                                                     uint32_t mailbox_seq) {
-  const bool hier = (mode & 1) != 0, seeded = (mode & 2) != 0;
+  const bool hier = (mode & 1) != 0, seeded = (mode & 2) != 0, queued = (mode & 4) != 0, queued_flat = (mode & 8) != 0;
+  const int seeds_per_wg = mode >> 8;  // (the queue: the first band with this many chunks a workgroup is on it from the start)
   __shared__ uint32_t s_part[kPartWords][kSmallWaves][64];
   __shared__ int s_exited;         // the workgroup's waves that have left the loop
   __shared__ uint32_t s_best[64];  // the group's targets' best DistSq bits so far, over all waves of the workgroup (0: under the cut)
@@ -758,18 +759,41 @@ __global__ __launch_bounds__(kSmallBlock) void icp_small_fit_kernel(TreeView tv,
   // the sums' workers: every wave but a workgroup's first (which decides and, in workgroup 0, updates), workgroup by
   // workgroup first -- nine workgroups or more: a row a workgroup
   const int worker = wave == 0 ? -1 : (wave - 1) * (int)G + (int)blockIdx.x, nworkers = (kSmallWaves - 1) * (int)G;
+  // (the queue of chunks, below: what is on it from the start)
+  int seed_lr = 0, seed_total = 0;  // the deepest band on the queue from the start: its roots' level; the chunks down to it
+  {
+    int lr = 0, cnt = 1;
+    for (;;) {
+      seed_total += cnt;
+      seed_lr = lr;
+      const int kb = lr == 0 ? top_levels : kSmallBand;
+      if (cnt >= seeds_per_wg * P || lr + kb >= D || queued_flat) break;
+      lr += kb;
+      cnt = 1 << lr;
+    }
+    if (queued_flat) {  // (every chunk from the start: nothing is put on)
+      seed_total = nchunks;
+      seed_lr = D;
+    }
+  }
+  const int n_seeds = seed_total > p ? (seed_total - p + P - 1) / P : 0;
+  auto reset_queue = [&]() {  // (by the workgroup's first wave)
+    uint4 *q = reinterpret_cast<uint4 *>(&s_list[0][0]);
+    if (queued) {
+      for (int k = lane; k < 8192 * 2 / 16; k += 64) q[k] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
+    if (lane < 8) {
+      s_next[lane] = 0;
+      s_cnt[lane] = queued ? (lane == 0 ? n_seeds : 0) : (lane == 0 ? 1 : 0);
+    }
+    if (lane == 0 && !queued) s_list[0][0] = 0;
+  };
   bool alive = true;
   SmallWait wait;
   if (wave == 0) {
     s_best[lane] = 0xFFFFFFFFu;
-    if (lane < 8) {
-      s_next[lane] = 0;
-      s_cnt[lane] = lane == 0 ? 1 : 0;
-    }
-    if (lane == 0) {
-      s_list[0][0] = 0;
-      s_exited = 0;
-    }
+    reset_queue();
+    if (lane == 0) s_exited = 0;
   }
   __syncthreads();
 #if defined(PCGX_STAMPS)
@@ -873,7 +897,88 @@ __global__ __launch_bounds__(kSmallBlock) void icp_small_fit_kernel(TreeView tv,
       CA.rec = CB.rec = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       CA.r = CB.r = 1u;
       CA.lr = CB.lr = 0;
-      if (!hier) {
+      if (queued) {
+        // A QUEUE (LDS) of the workgroup's chunks: the chunks of the tree's upper bands are on it from the start (this
+        // workgroup's: every P-th), a chunk that could not be ruled out puts the chunks below it behind them (the bits of
+        // small_chunk_go), whoever is free takes the next.  No list a band and no barrier between bands, nothing looked at
+        // by two workgroups, nothing looked at below what was ruled out.  An entry is a claim first (a place in the
+        // queue) and a chunk once its producer has written it; the queue is done with when every entry taken has been
+        // gone through (whoever goes through a chunk counts it AFTER putting its children on) and none is left.
+        volatile uint16_t *queue = &s_list[0][0];
+        volatile int *q_head = &s_next[0], *q_tail = &s_cnt[0], *q_done = &s_cnt[1];
+        auto claim = [&]() -> int {
+          int h = 0;
+          if (lane == 0) h = atomicAdd(const_cast<int *>(q_head), 1);
+          return __builtin_amdgcn_readfirstlane(h);
+        };
+        // the chunk of claim h: -2 not there yet, -1 there will be none
+        auto look = [&](int h) -> int {
+          if (h < n_seeds) return p + h * P;
+          const int at = h - n_seeds;
+          if (at < 8192) {
+            const uint16_t v = queue[at];
+            if (v != 0xFFFFu) return (int)v;
+          }
+          const int d = *q_done, t = *q_tail;  // (done first: it only grows, and never past the tail)
+          if ((d == t && t <= h) || at >= 8192) return -1;
+          return -2;
+        };
+        auto wait_for = [&](int h) -> int {
+          for (;;) {
+            const int c = look(h);
+            if (c != -2) return c;
+            if (small_give_up(sy, wait)) {  // (bounded like every wait of the launch)
+              alive = false;
+              return -1;
+            }
+          }
+        };
+        auto through = [&](const SmallChunk &C, int c) {
+          const int kb = C.lr == 0 ? top_levels : kSmallBand;
+          const bool below = C.lr >= seed_lr && C.lr + kb < D;  // (the bands above: their children are on the queue from the start)
+          uint32_t live = 0u;
+          if (below) live = go_bands(C, c, true);
+          else go_flat(C, c);
+          if (live != 0u) {
+            int start = 0;  // the chunks in front of c's band
+            for (int lr = 0; lr < C.lr; lr += (lr == 0 ? top_levels : kSmallBand)) start += 1 << lr;
+            const int fan = __popc(live), first_below = start + (1 << C.lr) + ((c - start) << kb);
+            int at = 0;
+            if (lane == 0) at = atomicAdd(const_cast<int *>(q_tail), fan);
+            at = __builtin_amdgcn_readfirstlane(at) - n_seeds;
+            if (lane < 16 && ((live >> lane) & 1u) != 0u) {
+              const int slot = at + __popc(live & ((1u << lane) - 1u));
+              if (slot < 8192) queue[slot] = (uint16_t)(first_below + lane);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          }
+          if (lane == 0) atomicAdd(const_cast<int *>(q_done), 1);
+        };
+        int ha = claim();
+        int ca = wait_for(ha);
+        if (ca >= 0) small_chunk_fetch(tv.nodes, ca, top_levels, lane, CA);
+        while (ca >= 0) {
+          const int hb = claim();
+          int cb = look(hb);
+          if (cb >= 0) small_chunk_fetch(tv.nodes, cb, top_levels, lane, CB);
+          asm volatile("" : "+v"(CA.rec.x), "+v"(CA.rec.y), "+v"(CA.rec.z), "+v"(CA.rec.w));
+          through(CA, ca);
+          if (cb == -2) {  // (not there when asked for: perhaps one of the chunk's own children)
+            cb = wait_for(hb);
+            if (cb >= 0) small_chunk_fetch(tv.nodes, cb, top_levels, lane, CB);
+          }
+          if (cb < 0) break;
+          const int ha2 = claim();
+          ca = look(ha2);
+          if (ca >= 0) small_chunk_fetch(tv.nodes, ca, top_levels, lane, CA);
+          asm volatile("" : "+v"(CB.rec.x), "+v"(CB.rec.y), "+v"(CB.rec.z), "+v"(CB.rec.w));
+          through(CB, cb);
+          if (ca == -2) {
+            ca = wait_for(ha2);
+            if (ca >= 0) small_chunk_fetch(tv.nodes, ca, top_levels, lane, CA);
+          }
+        }
+      } else if (!hier) {
         // FLAT: the workgroup's chunks p, p + P, p + 2 P, ... taken by its waves as they come free
         auto take = [&]() -> int {
           int n = 0;
@@ -1008,11 +1113,7 @@ __global__ __launch_bounds__(kSmallBlock) void icp_small_fit_kernel(TreeView tv,
                ((unsigned long long)s_part[4][w][lane] << 32) | s_part[3][w][lane], s_part[5][w][lane]);
       // (for the next iteration -- which begins behind a pose that needs this workgroup's minima or terms, below)
       s_best[lane] = 0xFFFFFFFFu;
-      if (lane < 8) {
-        s_next[lane] = 0;
-        s_cnt[lane] = lane == 0 ? 1 : 0;
-      }
-      if (lane == 0) s_list[0][0] = 0;
+      reset_queue();
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // (in LDS before anything of this wave's leaves the workgroup)
       if (p != 0) {
         unsigned long long *mine = part_w + ((size_t)blockIdx.x * kPartWords) * 64 + lane;
@@ -1529,27 +1630,34 @@ pcgx_status small_fit_enqueue(const TreeView &tv, const float *tx, const float *
   const int P = S.P;
   const int64_t nchunks = S.nchunks;
   if (Q > 256 || Q * P > 256) return fail(PCGX_E_INVALID, "icp (one launch): %d groups of targets", Q);
-  // Band by band (below what could not be ruled out) where a wave would otherwise look at two dozen chunks or more.
-  // Measured (10- / 20-iteration host-pointer Fits, ms, chunk after chunk / band by band): the benchmark's plane at 4096
-  // points (17 chunks a wave) 0.65 / 0.76 -- every one of the group's P workgroups keeps a list of its own and looks at
-  // all of a band's chunks on it; a random surface at 8000 x 8000 (35 a wave) 1.77 / 1.06; the plane at 16384 (273 a
-  // wave) 5.9 / 1.23.  The bound from last time's partner costs a dependent fetch in front of the first chunk: where a
-  // wave has eight chunks or more to rule out with it.
-  const int hier_forced = (int)small_knob("PCGX_ICP_SMALL_HIER", -1);  // (tests, measurements: read at every launch)
+  // How a group's waves go through the tree's chunks (PCGX_ICP_SMALL_HIER: 0 / 2 / 1 force one; tests, measurements):
+  //   chunk after chunk   every chunk of the workgroup's share is looked at (most are ruled out by the plane test's bound):
+  //                       where a wave has fewer than eight to look at;
+  //   a queue             the upper bands' chunks from the start, below them only what hangs under a chunk that could not
+  //                       be ruled out, whoever is free takes the next: from eight chunks a wave on;
+  //   band by band        the same with a list a band and a barrier between bands (every one of the group's P workgroups
+  //                       keeps a list of its own): trees a workgroup has to itself, from 128 chunks a wave on.
+  // Measured (10- / 20-iteration host-pointer Fits, ms; chunk after chunk / queue / band by band): the benchmark's plane
+  // at 1024 points (1 chunk a wave) 0.22 / 0.25 / 0.36, at 4096 (17) 0.65 / 0.57 / 0.76, at 16384 (273) 5.9 / 1.27 / 1.23; a
+  // random surface 8000 x 8000 (35) 1.77 / 1.09 / 1.06.  The bound from last time's partner costs a dependent fetch in
+  // front of the first chunk: where a wave has eight chunks or more to rule out with it.
+  const int hier_forced = (int)small_knob("PCGX_ICP_SMALL_HIER", -1);  // (read at every launch)
   const int64_t per_wave = S.per_wave;
   (void)nchunks;
-  const int hier = hier_forced >= 0 ? (hier_forced != 0) : (per_wave >= 24);
-  const int seeded = hier || per_wave >= 8;
+  const int hier = hier_forced >= 0 ? (hier_forced == 1) : (per_wave >= 128);
+  const int queued = hier_forced >= 0 ? (hier_forced == 2 || hier_forced == 3) : (per_wave >= 8 && per_wave < 128);
+  const int queued_flat = hier_forced == 3;  // (every chunk on the queue from the start)
+  const int seeded = hier || queued || per_wave >= 8;
   g_small_launches[0]++;
-  if (hier) g_small_launches[1]++;
+  if (hier || queued) g_small_launches[1]++;
   if (perm) g_small_launches[2]++;
   launch_no &= (1u << (32 - kSmallTagIterBits)) - 1u;
   if (kp.min_dist_sq > 0.0f)
     hipLaunchKernelGGL(icp_small_fit_kernel<true>, dim3((unsigned)(Q * P)), dim3(kSmallBlock), 0, st, tv, tx, ty, tz, nt, ntp, state, kp,
-                       (unsigned long long *)terms, valid, sums10, (char *)sync, launch_no, P, hier | (seeded << 1), iters, perm, mailbox, mailbox_seq);
+                       (unsigned long long *)terms, valid, sums10, (char *)sync, launch_no, P, hier | (seeded << 1) | (queued << 2) | (queued_flat << 3) | ((int)small_knob("PCGX_ICP_SMALL_SEEDS", 4) << 8), iters, perm, mailbox, mailbox_seq);
   else
     hipLaunchKernelGGL(icp_small_fit_kernel<false>, dim3((unsigned)(Q * P)), dim3(kSmallBlock), 0, st, tv, tx, ty, tz, nt, ntp, state, kp,
-                       (unsigned long long *)terms, valid, sums10, (char *)sync, launch_no, P, hier | (seeded << 1), iters, perm, mailbox, mailbox_seq);
+                       (unsigned long long *)terms, valid, sums10, (char *)sync, launch_no, P, hier | (seeded << 1) | (queued << 2) | (queued_flat << 3) | ((int)small_knob("PCGX_ICP_SMALL_SEEDS", 4) << 8), iters, perm, mailbox, mailbox_seq);
   PCGX_HIP_TRY(hipGetLastError());
   return PCGX_OK;
 }

@@ -176,10 +176,12 @@ def test_small_fit_with_targets_that_find_nothing_and_non_finite_ones():
 
 
 
-@pytest.mark.parametrize("hier,p,order_from", [(0, 0, 100000), (1, 0, 100000), (1, 1, 0), (0, 3, 0), (1, 2, 0), (0, 1, 100000)],
-                         ids=["flat", "bands", "bands-P1-grouped", "flat-P3-grouped", "bands-P2-grouped", "flat-P1"])
+@pytest.mark.parametrize("hier,p,order_from", [(0, 0, 100000), (1, 0, 100000), (1, 1, 0), (0, 3, 0), (1, 2, 0), (0, 1, 100000), (2, 0, 0), (2, 1, 100000),
+                                               (2, 3, 0), (3, 2, 0)],
+                         ids=["flat", "bands", "bands-P1-grouped", "flat-P3-grouped", "bands-P2-grouped", "flat-P1", "queue-grouped", "queue-P1",
+                              "queue-P3-grouped", "queue-of-all-P2-grouped"])
 def test_every_way_through_the_tree_gives_the_same_fit(hier, p, order_from):
-    """The tree's chunks one after the other or band by band below what could not be ruled out; one workgroup a group of
+    """The tree's chunks one after the other, band by band or through a queue below what could not be ruled out; one workgroup a group of
     64 targets or several; the targets in the caller's order or grouped by place: how much work a Fit is, never what comes
     out.  The benchmark's ground plane (the approximate search: MinDistSq = res^2) and a random surface (exact)."""
     import os
@@ -202,7 +204,7 @@ def test_every_way_through_the_tree_gives_the_same_fit(hier, p, order_from):
         trans, st = reg.Fit(kdtree.New(base), target)
         _same(trans, st, O.icp_fit(O.KDTree(base), target, 0.5, 6, w, th, 12, sums_mode=0))
         n, bands, grouped = _one_launches()
-        assert n == 2 and bands == (2 if hier else 0) and grouped == (2 if order_from == 0 else 0)
+        assert n == 2 and bands == (2 if hier else 0) and grouped == (2 if order_from == 0 else 0)  # (bands: band by band, or the queue)
     finally:
         for k in ("PCGX_ICP_SMALL_HIER", "PCGX_ICP_SMALL_P", "PCGX_ICP_SMALL_ORDER_FROM"):
             os.environ.pop(k, None)
@@ -269,7 +271,7 @@ def test_which_clouds_get_the_one_launch_by_default():
             _same(trans, st, O.icp_fit(O.KDTree(base, mds), target, max_dist, 3, None, thr, 4, sums_mode=0))
             return _one_launches()
         base, target, mds = _ground_box(16384)
-        assert fits(base, target, mds, 2.0) == (1, 1, 1)  # band by band, grouped
+        assert fits(base, target, mds, 2.0) == (1, 1, 1)  # below what could not be ruled out only, grouped
         base, target, mds = _ground_box(1024)
         assert fits(base, target, mds, 2.0) == (1, 0, 0)
         c = synth.c4_icp(n=16000, width=4.0)
