@@ -311,3 +311,15 @@ def test_one_launch_fits_from_several_threads_at_once():
         t.join()
     assert not errors, errors[:2]
     assert _one_launches()[0] == 48
+
+
+def test_a_soak_of_random_shapes_and_ways_through_the_tree():
+    """tools/small_fuzz.py: random sizes (1 ... 20000 base points, 1 ... 16384 targets, the powers of two and their
+    neighbours among them), a surface / a lattice / a plane / twins, MaxDist, MinDistSq, weights, iterations, and for
+    every case a way through the tree at random (chunk after chunk, band by band, the queue; workgroups a group; grouped
+    targets or the caller's order): every Fit the oracle's."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "small_fuzz.py"), "150", "20261005"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert "150 cases, 0 mismatches; 150 one-launch Fits" in r.stdout, r.stdout[-500:]
