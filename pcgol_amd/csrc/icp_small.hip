@@ -8,7 +8,7 @@
 // for a million queries: 96 us per iteration at 1024 targets, 388 at 16384 (profiles/r05e_rows.json).
 //
 // Here a Fit is one persistent launch of G = Q * P workgroups (Q = ceil(nt / 64) groups of 64 targets, P workgroups
-// a group; G <= 256: resident together on the chip's 256 CUs) that loops over the iterations, two grid barriers in each:
+// a group; G <= 256: resident together on the chip's 256 CUs) that loops over the iterations:
 //   search  NOT a walk.  A lane walking its query alone is a chain of dependent fetches -- 140 ... 700 visits of ~200
 //          cycles on the benchmark's ground plane, where every third level of the tree ties and nothing is pruned:
 //          58 us an iteration at 1024 points (this file's first form) -- while all 1024 x 1024 distances are a million
@@ -25,32 +25,35 @@
 //          A point's place in the query's visit order is a number: two bits per level from the root down -- 0: in the
 //          near child's sub-tree, 2: in the far child's, 1: this node -- "near" by the reference's own comparison at
 //          every ancestor (:216; a node of two points has child0 only).  LANE = QUERY, and a wave goes through a
-//          sub-tree of four levels (a "chunk") node by node: the node is the same for all lanes, so its record is a
-//          scalar load, existence / leaf-or-pivot are scalar branches, and a lane's work per node is eight float
-//          operations for the distance (mat/vec3.go:18-20,38-40, unfused), the key's digit for the children and
-//          three running minima -- (key) under the cut, (DistSq, key) over all, (DistSq, ~key) over leaves.  The chunks
-//          of a group are dealt to the 8 P waves of its workgroups; minima meet in LDS, then in device memory, and the
-//          group's LAST workgroup (a ticket) decides, fetches the partner's record and writes the pair's nine float32
-//          terms (evaluator.go:130-144; strict_terms.h, pair_terms) into rows of the caller's target order -- small
-//          sessions keep that order, there is no Morton pass.  A query that is not finite (an overflowing pose) is
-//          walked the reference's way by its lane (small_walk): NaN compares false everywhere and the rule above is
-//          about numbers.  (A tree with a NaN point, or maxRange^2 < MinDistSq, is not a small session.)
-//   sums   evaluator.go:122-145 adds the terms up in float32, one after the other from 0.0f: row r's chain is ONE wave's
-//          (a wave of a workgroup of its own, hence of a SIMD of its own, wherever there are nine workgroups), the terms
-//          asked for eight blocks of 64 ahead, the adds by v_readlane + v_add_f32: a dependent add every 8 cycles, 3.3 ns
-//          -- 3.4 us at 1024 targets, 55 us at 16384.  (The summaries of strict_sum.h pay from ~10^5 terms on; below
-//          that their launches cost more than the chain itself.)
+//          sub-tree of four levels (a "chunk", 15 nodes) node by node: the node is the same for all lanes -- the
+//          chunk's records arrive by one load and are read lane by lane into scalar registers, the code is straight-
+//          line (SmallChunkInfo) -- and a lane's work per node is eight float operations for the distance
+//          (mat/vec3.go:18-20,38-40, unfused), the key's digit for the children and two running minima (SmallAcc).
+//          What a group's waves can rule out with the reference's own plane test -- every point below a chunk lies
+//          beyond the planes of the ancestors on whose far side the chunk hangs -- is not gone through, and where the
+//          tree is large not looked at either (small_chunk_go; the queue and the lists in the kernel); the targets are
+//          grouped by place for that, whatever order the caller has them in (small_order_kernel).  The minima of a
+//          group's waves meet in LDS, those of its P workgroups in its first one's hands, which decides, fetches the
+//          partner's record and writes the pair's nine float32 terms (evaluator.go:130-144; strict_terms.h, pair_terms)
+//          into rows of the CALLER's target order.  A query that is not finite (an overflowing pose) is walked the
+//          reference's way by its lane (small_walk): NaN compares false everywhere and the rule above is about
+//          numbers.  (A tree with a NaN point, or maxRange^2 < MinDistSq, is not a small session.)
+//   sums   evaluator.go:122-145 adds the terms up in float32, one after the other from 0.0f: a row's first 2048 terms
+//          are ONE wave's chain (v_readlane + v_add_f32, 5 ns a term), the tiles of 2048 behind them are summarised by
+//          waves of their own meanwhile (namespace mini: strict_sum.h's arithmetic, a wave a tile) and the row's wave
+//          walks through their records.
 //   update workgroup 0's first wave takes the nine sums, runs the evaluate tail and the pose update (evaluator.go:156-186,
 //          updater.go:44-71: icp_update_step, the code the other paths run) and hands the new pose to everybody.
-// NO BARRIERS.  Everything that passes between workgroups inside the launch -- the workgroups' minima, the terms, the
-// sums, the pose -- is a 64-bit word {payload, tag}, tag = {launch number, iteration + 1}, stored and polled with
-// agent-scope atomics: a word says by itself whether it is this iteration's, so nobody waits for anything but the
-// words they need, and a hand-over is one store and one load's flight (0.5 us one way between any two workgroups of
-// the chip, tools/micro/xcd_pingpong.cpp) -- where a grid barrier is a write-back of the L2, a returning atomic, a poll
-// and an invalidate: 8 us a barrier by this kernel's own stamps, two an iteration, and 4 us more to read the pose past
-// the caches (this file's second form: 55 us an iteration at 1024 points, 6 of them arithmetic).
+// NO BARRIERS between workgroups.  Everything that passes between them inside the launch -- the workgroups' minima, the
+// terms, the tiles' records, the sums, the pose -- is a 64-bit word {payload, tag}, tag = {launch number, iteration + 1},
+// stored and polled with agent-scope atomics: a word says by itself whether it is this iteration's, so nobody waits for
+// anything but the words they need, and a hand-over is one store and one load's flight (0.5 us one way between any two
+// workgroups of the chip, tools/micro/xcd_pingpong.cpp) -- where a grid barrier is a write-back of the L2, a returning
+// atomic, a poll and an invalidate: 8 us a barrier by this kernel's own stamps, two an iteration, and 4 us more to read
+// the pose past the caches (this file's second form: 55 us an iteration at 1024 points, 6 of them arithmetic).
 // Every wait is bounded by wall-clock time and looks at an abort word: a wave that gives up raises it, everybody leaves
-// the kernel and the Fit ends with PCGX_E_HIP -- the grid drains whatever happens.
+// the kernel and the Fit ends with PCGX_E_HIP -- the grid drains whatever happens.  DESIGN.md section 3.1 has the
+// measurements (0.22 / 0.58 / 1.24 ms per 10-iteration Fit at 1024 / 4096 / 16384 points; the general path: 0.96 / 1.84 / 3.9).
 #include "knn_walk.h"
 #include "strict_terms.h"
 #include "strict_sum.h"
@@ -63,9 +66,9 @@ namespace pcgx {
 #endif
 PCGX_STAMPS_DECLARE(small_fit, 256, 8)
 #if defined(PCGX_STAMPS)
-__device__ unsigned long long g_small_dbg[8];
+__device__ unsigned long long g_small_dbg[8];  // chunks looked at / ruled out whole / gone through (PCGX_SMALL_COUNTS); [6], [7]: free
 __device__ unsigned long long g_small_fail[16];  // the stamped iteration: row r's tiles whose record did not cover the state (low byte: key < 0)
-__device__ unsigned long long g_small_iter_t[64];  // workgroup 0's first wave: wall clock at the kernel's start, every iteration's top, the end  // chunks looked at / ruled out whole / gone through, of the stamped iteration
+__device__ unsigned long long g_small_iter_t[64];  // workgroup 0's first wave: wall clock at the kernel's start, every iteration's top, the end
 #if defined(PCGX_SMALL_COUNTS)  // (an atomic per chunk and wave: not beside time measurements)
 #define PCGX_SMALL_COUNT(K) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_small_dbg[K], 1ull); } while (0)
 #else
@@ -96,7 +99,7 @@ extern "C" __attribute__((visibility("default"))) int pcgx_debug_small_counts(un
 #define PCGX_SMALL_BLOCK 512
 #endif
 constexpr int kSmallBlock = PCGX_SMALL_BLOCK;
-constexpr long long kSmallBarrierTicks = 200000000;  // 2 s (s_memrealtime: 100 MHz)
+constexpr long long kSmallWaitTicks = 200000000;  // 2 s (s_memrealtime: 100 MHz)
 constexpr int kPartWords = 6;  // a lane's running minima, as words
 constexpr int kSmallTagIterBits = 12;  // a tag: {launch number (20 bits), iteration + 1}
 
@@ -124,7 +127,7 @@ __device__ __forceinline__ bool small_give_up(SmallSync *sy, SmallWait &w) {
   if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
   const long long now = (long long)wall_clock64();
   if (w.t_first == 0) w.t_first = now;
-  if (now - w.t_first > kSmallBarrierTicks) {
+  if (now - w.t_first > kSmallWaitTicks) {
     __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
   }
@@ -1573,9 +1576,9 @@ static SmallShape small_shape(const TreeView &tv, int64_t nt) {
 // the faster way.  An iteration here is ~12 us of hand-overs, deciding and the pose update, 4.9 ns a target for the sums'
 // chains and ~0.7 us for every chunk a wave has to look at; the general path's is ~42 us whatever the sizes ON CLOUDS
 // ITS WALK LIKES (tools/small_vs_general.py, random surfaces, 20-iteration host-pointer Fits, ms, here / there: 1000 x
-// 1000 0.39 / 0.77, 2000 x 2000 0.57 / 0.80, 4000 x 4000 0.92 / 0.85, 8000 x 8000 2.0 / 0.89) and several times that
+// 1000 0.39 / 0.77, 2000 x 2000 0.56 / 0.80, 4000 x 4000 0.89 / 0.86, 8000 x 8000 1.09 / 0.89) and several times that
 // on clouds whose coordinates repeat (pcgx_kdtree::many_ties -- the reference's own benchmark's ground plane,
-// icp_test.go:100-142, 10 iterations: 4096 points 0.66 / 1.84, 16384 points 1.5 / 3.9).  PCGX_ICP_SMALL_TARGET / _BASE /
+// icp_test.go:100-142, 10 iterations: 4096 points 0.58 / 1.84, 16384 points 1.24 / 3.9).  PCGX_ICP_SMALL_TARGET / _BASE /
 // _PAIRS set limits of their own (all three: the one launch wherever it can run -- the tests).
 bool small_fit_eligible(const TreeView &tv, int64_t nt, bool many_ties) {
   if (!(tv.n >= 1 && tv.n <= 65535 && tv.depth <= 16 && nt >= 1 && nt <= 16384)) return false;

@@ -6,7 +6,7 @@
 # (the reference's benchmark shapes, where the launch's iteration goes, the default's choice against the general path,
 # the two microbenchmarks its design rests on).  Summaries are copied under gpurun_out/
 # for the way back (gpurun merges gpurun_out/ only); the raw CSVs are dropped (tens of MB).
-TAG=${1:-r06f}
+TAG=${1:-r06g}
 mkdir -p gpurun_out
 bash profiles/collect.sh $TAG > gpurun_out/${TAG}_collect.log 2>&1
 echo collect rc=$?
