@@ -34,6 +34,17 @@ echo conc4 rc=$?
   timeout -k 5 120 tools/micro/dpp_chain.bin
 } > gpurun_out/${TAG}_small_fit.txt 2>&1
 echo small rc=$?
+# rocprofv3's own durations of the one-launch Fit's kernels at the three benchmark sizes (host-pointer Fits only)
+export TMPDIR=/tmp
+: > gpurun_out/${TAG}_small_kernel_stats.csv
+for n in 1024 4096 16384; do
+  rm -rf gpurun_out/prof_small_$n
+  PCGX_PROBE_HOST_ONLY=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_small_$n -- python3 tools/small_fit_probe.py $n 10 > /dev/null 2>&1
+  f=$(find gpurun_out/prof_small_$n -name '*kernel_stats.csv' | head -1)
+  [ -n "$f" ] && { echo "# $n points, ten host-pointer Fits of 10 iterations"; head -1 "$f"; grep -E 'icp_small_fit|small_prepare|small_order' "$f"; } >> gpurun_out/${TAG}_small_kernel_stats.csv
+  rm -rf gpurun_out/prof_small_$n
+done
+echo small_stats rc=$?
 for mem in dev host; do
   for n in 2 4 5; do
     [ $mem = host ] && [ $n = 5 ] && continue
